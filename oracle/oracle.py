@@ -1,0 +1,256 @@
+"""ctypes wrapper around oracle/liborc.so -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The class mirrors the faiss.Index surface the reference reaches from
+src/faiss_extension.cpp (:154 index_factory, :396/:583 train, :510/:607 add_with_ids,
+:512/:609 add, :631 search) so parity tests read like the reference's own tests.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liborc.so")
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+SEL_NONE, SEL_BITMAP, SEL_BATCH = 0, 1, 2
+PATH_AUTO, PATH_PAIR, PATH_BLAS = 0, 1, 2
+
+
+class OracleError(RuntimeError):
+    """Carries FAISS's exception text (the reference greps substrings of it)."""
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("nprobe", C.c_int64),
+        ("efSearch", C.c_int64),
+        ("sel_kind", C.c_int),
+        ("sel_data", C.c_void_p),
+        ("sel_n", C.c_int64),
+        ("force_path", C.c_int),
+    ]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("orc_core.c", "orc_hnsw.c", "orc.h", "Makefile")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liborc.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        p, i64, f32p, i64p = C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_int64)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_index_factory.restype = p
+        L.orc_index_factory.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        L.orc_index_free.argtypes = [p]
+        L.orc_d.argtypes = [p]
+        L.orc_ntotal.argtypes = [p]
+        L.orc_ntotal.restype = i64
+        L.orc_is_trained.argtypes = [p]
+        L.orc_metric.argtypes = [p]
+        L.orc_train.argtypes = [p, i64, p]
+        L.orc_add.argtypes = [p, i64, p]
+        L.orc_add_with_ids.argtypes = [p, i64, p, p]
+        L.orc_search.argtypes = [p, i64, p, i64, p, p, C.POINTER(_Params)]
+        L.orc_ivf_nlist.argtypes = [p]
+        L.orc_ivf_nlist.restype = i64
+        L.orc_ivf_get_centroids.argtypes = [p, p]
+        L.orc_ivf_set_centroids.argtypes = [p, p]
+        L.orc_ivf_list_size.argtypes = [p, i64]
+        L.orc_ivf_list_size.restype = i64
+        L.orc_ivf_get_list.argtypes = [p, i64, p, p]
+        L.orc_norms.argtypes = [p, i64, C.c_int, p]
+        L.orc_flat_search.argtypes = [C.c_int, C.c_int, i64, p, i64, p, i64, p, p, C.POINTER(_Params), p]
+        L.orc_flat_search_naive.argtypes = [C.c_int, C.c_int, i64, p, i64, p, i64, p, p, C.c_int]
+        L.orc_merge_shards.argtypes = [C.c_int, i64, i64, C.c_int, p, p, p, p]
+        L.orc_synth_uniform.argtypes = [p, i64, C.c_int, C.c_uint64, i64]
+        L.orc_synth_clustered.argtypes = [p, i64, C.c_int, C.c_uint64, i64, C.c_int, C.c_float]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc):
+    if rc:
+        raise OracleError(lib().orc_last_error().decode())
+
+
+def _mk_params(nprobe=0, efSearch=0, sel=None, force_path=PATH_AUTO):
+    """sel: None | ("bitmap", uint8 array) | ("batch", int64 array)"""
+    p = _Params()
+    p.nprobe, p.efSearch, p.force_path = nprobe, efSearch, force_path
+    keep = None
+    if sel is not None:
+        kind, data = sel
+        if kind == "bitmap":
+            keep = np.ascontiguousarray(data, dtype=np.uint8)
+            p.sel_kind, p.sel_n = SEL_BITMAP, keep.size
+        elif kind == "batch":
+            keep = _i64(data)
+            p.sel_kind, p.sel_n = SEL_BATCH, keep.size
+        else:
+            raise ValueError(kind)
+        p.sel_data = keep.ctypes.data
+    return p, keep
+
+
+class Index:
+    """CPU oracle index; same method names as faiss.Index."""
+
+    def __init__(self, d, description, metric=METRIC_INNER_PRODUCT):
+        # default metric INNER_PRODUCT: src/faiss_extension.cpp:105
+        self._h = lib().orc_index_factory(int(d), description.encode(), int(metric))
+        if not self._h:
+            raise OracleError(lib().orc_last_error().decode())
+        self.d = int(d)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_index_free(self._h)
+            self._h = None
+
+    @property
+    def ntotal(self):
+        return lib().orc_ntotal(self._h)
+
+    @property
+    def is_trained(self):
+        return bool(lib().orc_is_trained(self._h))
+
+    @property
+    def metric_type(self):
+        return lib().orc_metric(self._h)
+
+    def train(self, x):
+        x = _f32(x).reshape(-1, self.d)
+        _check(lib().orc_train(self._h, x.shape[0], _ptr(x)))
+
+    def add(self, x):
+        x = _f32(x).reshape(-1, self.d)
+        _check(lib().orc_add(self._h, x.shape[0], _ptr(x)))
+
+    def add_with_ids(self, x, ids):
+        x = _f32(x).reshape(-1, self.d)
+        ids = _i64(ids)
+        assert ids.size == x.shape[0]
+        _check(lib().orc_add_with_ids(self._h, x.shape[0], _ptr(x), _ptr(ids)))
+
+    def search(self, x, k, nprobe=0, efSearch=0, sel=None, force_path=PATH_AUTO):
+        x = _f32(x).reshape(-1, self.d)
+        nq = x.shape[0]
+        D = np.empty((nq, max(k, 0)), dtype=np.float32)
+        I = np.empty((nq, max(k, 0)), dtype=np.int64)
+        p, keep = _mk_params(nprobe, efSearch, sel, force_path)
+        _check(lib().orc_search(self._h, nq, _ptr(x), k, _ptr(D), _ptr(I), C.byref(p)))
+        del keep
+        return D, I
+
+    # IVF introspection (parity tests share centroids with the device index)
+    @property
+    def nlist(self):
+        return lib().orc_ivf_nlist(self._h)
+
+    def ivf_centroids(self):
+        out = np.empty((self.nlist, self.d), dtype=np.float32)
+        _check(lib().orc_ivf_get_centroids(self._h, _ptr(out)))
+        return out
+
+    def ivf_set_centroids(self, c):
+        c = _f32(c).reshape(self.nlist, self.d)
+        _check(lib().orc_ivf_set_centroids(self._h, _ptr(c)))
+
+    def ivf_list(self, list_no):
+        n = lib().orc_ivf_list_size(self._h, list_no)
+        ids = np.empty(n, dtype=np.int64)
+        codes = np.empty((n, self.d), dtype=np.float32)
+        _check(lib().orc_ivf_get_list(self._h, list_no, _ptr(ids), _ptr(codes)))
+        return ids, codes
+
+
+def norms(x):
+    x = _f32(x)
+    out = np.empty(x.shape[0], dtype=np.float32)
+    lib().orc_norms(_ptr(x), x.shape[0], x.shape[1], _ptr(out))
+    return out
+
+
+def flat_search(metric, xb, xq, k, force_path=PATH_AUTO, sel=None, id_map=None):
+    xb, xq = _f32(xb), _f32(xq)
+    d = xb.shape[1]
+    nq = xq.shape[0]
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    p, keep = _mk_params(sel=sel, force_path=force_path)
+    idm = _i64(id_map) if id_map is not None else None
+    _check(
+        lib().orc_flat_search(
+            metric, d, xb.shape[0], _ptr(xb), nq, _ptr(xq), k, _ptr(D), _ptr(I), C.byref(p), _ptr(idm) if idm is not None else None
+        )
+    )
+    del keep
+    return D, I
+
+
+def flat_search_naive(metric, xb, xq, k, path):
+    xb, xq = _f32(xb), _f32(xq)
+    nq = xq.shape[0]
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    _check(lib().orc_flat_search_naive(metric, xb.shape[1], xb.shape[0], _ptr(xb), nq, _ptr(xq), k, _ptr(D), _ptr(I), path))
+    return D, I
+
+
+def merge_shards(metric, D, I):
+    """D, I: [nshard, nq, k] with global labels -> merged [nq, k]"""
+    D, I = _f32(D), _i64(I)
+    ns, nq, k = D.shape
+    Do = np.empty((nq, k), dtype=np.float32)
+    Io = np.empty((nq, k), dtype=np.int64)
+    lib().orc_merge_shards(metric, nq, k, ns, _ptr(D), _ptr(I), _ptr(Do), _ptr(Io))
+    return Do, Io
+
+
+def synth_uniform(n, d, seed, row0=0):
+    out = np.empty((n, d), dtype=np.float32)
+    lib().orc_synth_uniform(_ptr(out), n, d, seed, row0)
+    return out
+
+
+def synth_clustered(n, d, seed, row0=0, n_centers=1024, sigma=0.1):
+    out = np.empty((n, d), dtype=np.float32)
+    lib().orc_synth_clustered(_ptr(out), n, d, seed, row0, n_centers, sigma)
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(n)

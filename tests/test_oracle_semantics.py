@@ -1,0 +1,168 @@
+"""Self-consistency of the CPU oracle: the packed AVX2 'BLAS path' equals the naive k-ordered
+fma triple loop bit for bit; FAISS dispatch thresholds; tie rules;
+IVF restatement sanity.  These paths have no golden values in the reference (parity unpinned)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def _data(nb, nq, d, seed=0, dup=0):
+    rng = np.random.default_rng(seed)
+    xb = rng.random((nb, d), dtype=np.float32)
+    xq = rng.random((nq, d), dtype=np.float32)
+    if dup:
+        # duplicated rows pin tie-breaking
+        src = rng.integers(0, nb, dup)
+        dst = rng.integers(0, nb, dup)
+        xb[dst] = xb[src]
+    return xb, xq
+
+
+@pytest.mark.parametrize("metric", [orc.METRIC_L2, orc.METRIC_INNER_PRODUCT])
+@pytest.mark.parametrize("d", [8, 33, 128])
+def test_packed_blas_path_equals_naive_chain(metric, d):
+    xb, xq = _data(3000, 37, d, seed=d, dup=200)
+    D, I = orc.flat_search(metric, xb, xq, 10, force_path=orc.PATH_BLAS)
+    Dn, In = orc.flat_search_naive(metric, xb, xq, 10, orc.PATH_BLAS)
+    assert np.array_equal(I, In)
+    assert np.array_equal(D.view(np.uint32), Dn.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [orc.METRIC_L2, orc.METRIC_INNER_PRODUCT])
+def test_pair_path_equals_naive_chain(metric):
+    xb, xq = _data(2000, 7, 24, seed=3, dup=100)
+    D, I = orc.flat_search(metric, xb, xq, 5, force_path=orc.PATH_PAIR)
+    Dn, In = orc.flat_search_naive(metric, xb, xq, 5, orc.PATH_PAIR)
+    assert np.array_equal(I, In) and np.array_equal(D.view(np.uint32), Dn.view(np.uint32))
+
+
+def test_dispatch_threshold_20():
+    """nq < 20 -> per-pair sum((x-y)^2); nq >= 20 -> xn + yn - 2 ip (distance_compute_blas_threshold)"""
+    xb, xq = _data(1500, 20, 16, seed=5)
+    Dp, _ = orc.flat_search(orc.METRIC_L2, xb, xq[:19], 4)
+    Dp_ref, _ = orc.flat_search_naive(orc.METRIC_L2, xb, xq[:19], 4, orc.PATH_PAIR)
+    assert np.array_equal(Dp, Dp_ref)
+    Db, _ = orc.flat_search(orc.METRIC_L2, xb, xq, 4)
+    Db_ref, _ = orc.flat_search_naive(orc.METRIC_L2, xb, xq, 4, orc.PATH_BLAS)
+    assert np.array_equal(Db, Db_ref)
+    # float64 ground truth: both within 1e-4 relative (north_star tolerance)
+    S = ((xq[:, None, :].astype(np.float64) - xb[None].astype(np.float64)) ** 2).sum(-1)
+    ref = np.sort(S, axis=1)[:, :4]
+    np.testing.assert_allclose(Db, ref, rtol=1e-4)
+
+
+def test_l2_ties_are_lexicographic_and_ascending():
+    """L2 (CMax heap): retained set = k smallest (dist, id); output ascending (dist, id)."""
+    xb = np.zeros((12, 4), np.float32)
+    xb[:, 0] = [5, 1, 1, 1, 3, 1, 0, 0, 9, 1, 2, 1]
+    xq = np.zeros((1, 4), np.float32)
+    D, I = orc.flat_search(orc.METRIC_L2, xb, xq, 5, force_path=orc.PATH_PAIR)
+    assert I.tolist() == [[6, 7, 1, 2, 3]]
+    assert D.tolist() == [[0, 0, 1, 1, 1]]
+    Db, Ib = orc.flat_search(orc.METRIC_L2, xb, xq, 5, force_path=orc.PATH_BLAS)
+    assert Ib.tolist() == I.tolist()
+
+
+def test_ip_tie_rule_is_arrival_order_dependent():
+    """IP (CMin heap): equal scores print in DESCENDING id order; a later strictly better element
+    evicts the SMALLEST-id tie (root among equal values) -- SURVEY.md Appendix A.1."""
+    xq = np.array([[1.0, 0.0]], np.float32)
+    xb = np.array([[5, 0], [5, 0], [5, 0], [7, 0]], np.float32)
+    D, I = orc.flat_search(orc.METRIC_INNER_PRODUCT, xb, xq, 2)
+    assert D.tolist() == [[7, 5]] and I.tolist() == [[3, 1]]
+    xb2 = np.array([[5, 0], [5, 0], [5, 0]], np.float32)
+    D, I = orc.flat_search(orc.METRIC_INNER_PRODUCT, xb2, xq, 2)
+    assert I.tolist() == [[1, 0]]
+
+
+def test_k_larger_than_ntotal_and_empty_index():
+    xb, xq = _data(3, 2, 4)
+    D, I = orc.flat_search(orc.METRIC_L2, xb, xq, 5)
+    assert (I[:, 3:] == -1).all() and (D[:, 3:] == np.finfo(np.float32).max).all()
+    ix = orc.Index(4, "Flat", orc.METRIC_L2)
+    D, I = ix.search(xq, 3)
+    assert (I == -1).all()
+    with pytest.raises(orc.OracleError, match="k > 0"):
+        ix.search(xq, 0)
+
+
+def test_factory_strings():
+    assert orc.Index(8, "Flat").is_trained
+    assert orc.Index(8, "IDMap,Flat").is_trained
+    assert not orc.Index(8, "IVF16,Flat").is_trained
+    assert not orc.Index(8, "IDMap,IVF16,Flat").is_trained
+    with pytest.raises(orc.OracleError, match="could not parse index string"):
+        orc.Index(8, "Bogus")
+    with pytest.raises(orc.OracleError, match="add does not make sense"):
+        orc.Index(8, "IDMap,Flat").add(np.zeros((1, 8), np.float32))
+
+
+def test_ivf_full_probe_equals_pairwise_flat():
+    """nprobe = nlist scans every vector with the per-pair arithmetic -> same set as Flat pair path"""
+    rng = np.random.default_rng(11)
+    centers = rng.normal(size=(8, 16)).astype(np.float32)
+    xb = (centers[rng.integers(0, 8, 4000)] + 0.1 * rng.normal(size=(4000, 16))).astype(np.float32)
+    xq = (centers[rng.integers(0, 8, 30)] + 0.1 * rng.normal(size=(30, 16))).astype(np.float32)
+    ix = orc.Index(16, "IVF8,Flat", orc.METRIC_L2)
+    ix.train(xb)
+    assert ix.is_trained
+    ix.add(xb)
+    assert ix.ntotal == 4000
+    assert sum(len(ix.ivf_list(l)[0]) for l in range(8)) == 4000
+    D, I = ix.search(xq, 10, nprobe=8)
+    Df, If = orc.flat_search(orc.METRIC_L2, xb, xq, 10, force_path=orc.PATH_PAIR)
+    assert np.array_equal(np.sort(I, 1), np.sort(If, 1))
+    assert np.array_equal(D, Df)
+    # nprobe=1 recall on clustered data is high but not necessarily 1
+    D1, I1 = ix.search(xq, 10, nprobe=1)
+    rec = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I1, If)])
+    assert rec > 0.8
+    # within a list entries keep input order (Appendix A.6)
+    ids0, _ = ix.ivf_list(0)
+    assert np.all(np.diff(ids0) > 0)
+
+
+def test_ivf_with_ids_and_selector():
+    rng = np.random.default_rng(2)
+    xb = rng.random((600, 8), dtype=np.float32)
+    ids = np.arange(600, dtype=np.int64) * 3 + 7
+    ix = orc.Index(8, "IDMap,IVF4,Flat", orc.METRIC_L2)
+    ix.train(xb)
+    ix.add_with_ids(xb, ids)
+    D, I = ix.search(xb[:5], 1, nprobe=4)
+    assert I.reshape(-1).tolist() == ids[:5].tolist()
+    keep = ids[ids % 2 == 0]
+    D, I = ix.search(xb[:25], 3, nprobe=4, sel=("batch", keep))
+    assert np.isin(I[I >= 0], keep).all()
+
+
+def test_merge_shards_equals_unsharded():
+    xb, xq = _data(5000, 40, 32, seed=9, dup=300)
+    for metric in (orc.METRIC_L2, orc.METRIC_INNER_PRODUCT):
+        Dref, Iref = orc.flat_search(metric, xb, xq, 10)
+        parts = np.array_split(np.arange(5000), 4)
+        Ds, Is = [], []
+        for p in parts:
+            D, I = orc.flat_search(metric, xb[p], xq, 10, force_path=orc.PATH_BLAS)
+            Ds.append(D)
+            Is.append(np.where(I >= 0, I + p[0], -1))
+        Dm, Im = orc.merge_shards(metric, np.stack(Ds), np.stack(Is))
+        assert np.array_equal(Dm, Dref)
+        if metric == orc.METRIC_L2:
+            assert np.array_equal(Im, Iref)
+        else:  # IP boundary ties are arrival-order dependent in FAISS; compare away from ties
+            D11, _ = orc.flat_search(metric, xb, xq, 11)
+            ok = np.array([len(np.unique(D11[q])) == 11 for q in range(40)])
+            assert ok.sum() > 20
+            assert np.array_equal(Im[ok], Iref[ok])
+
+
+def test_synth_generators_are_deterministic_and_windowed():
+    a = orc.synth_uniform(100, 16, 1234)
+    b = orc.synth_uniform(40, 16, 1234, row0=60)
+    assert np.array_equal(a[60:], b)
+    assert 0 <= a.min() and a.max() < 1 and abs(a.mean() - 0.5) < 0.02
+    c = orc.synth_clustered(200, 8, 7, n_centers=4, sigma=0.05)
+    c2 = orc.synth_clustered(50, 8, 7, row0=150, n_centers=4, sigma=0.05)
+    assert np.array_equal(c[150:], c2)
