@@ -1,0 +1,111 @@
+// csrc/common.h -- shared declarations of the MI355X (gfx950) vector-search library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace mvs {
+
+// Error carrying FAISS's message text (the reference greps substrings of it; include/mi355_faiss.h)
+struct Error : std::runtime_error {
+	explicit Error(const std::string &m) : std::runtime_error(m) {
+	}
+};
+
+[[noreturn]] void throw_faiss(const char *func, const char *file, const char *fmt, ...);
+
+#define MVS_HIP(expr)                                                                                                  \
+	do {                                                                                                               \
+		hipError_t e_ = (expr);                                                                                        \
+		if (e_ != hipSuccess)                                                                                          \
+			::mvs::throw_faiss(__func__, __FILE__, "HIP error %d (%s) in %s", (int)e_, hipGetErrorString(e_), #expr);  \
+	} while (0)
+
+constexpr int METRIC_IP = 0;
+constexpr int METRIC_L2 = 1;
+
+// ---------------------------------------------------------------------------------------------
+// Flat brute-force search geometry (DESIGN.md "K2/K3")
+//   workgroup = 256 threads = 4 waves; wave w owns queries [32w, 32w+32) of a 128-query block and
+//   keeps them as the B operand of v_mfma_f32_32x32x2_f32 (query on the lane => top-k is lane local)
+// ---------------------------------------------------------------------------------------------
+constexpr int QBLOCK = 128; // queries per workgroup
+constexpr int WAVE_Q = 32;  // queries per wave (= MFMA N)
+
+// Database storage: row-major, rows padded to dp floats; dp = kc * nch
+struct FlatGeom {
+	int d;      // logical dimension
+	int dp;     // padded row length (floats)
+	int kc;     // k extent of one LDS staging unit
+	int nch;    // staging units per row (1 => queries stay resident in registers)
+	int ntile;  // 32-row MFMA tiles per wave per row tile (2 resident, 8 streaming)
+	int bn() const {
+		return ntile * 32;
+	}
+};
+FlatGeom flat_geom_for(int d);
+
+struct FlatSearchPlan {
+	int nqb;             // query blocks of 128
+	int nsplit;          // database splits (partial top-k lists per query)
+	int64_t split_rows;  // rows per split (multiple of bn)
+	int grid;
+	size_t lds_bytes;
+	bool xcd_map;
+};
+
+// device views -------------------------------------------------------------------------------
+struct FlatDB {
+	const float *vecs;  // [n][dp]
+	const float *norms; // [n]   (sum of squares, k-ordered fma chain)
+	int64_t n;
+};
+
+struct SelectorDev {
+	int kind;              // MVS_SEL_*
+	const uint8_t *bitmap; // device
+	int64_t nbytes;
+	const int64_t *sorted_ids; // device, ascending
+	int64_t nids;
+};
+
+// kernels / launchers (flat_mfma.hip, flat_direct.hip, merge.hip, util_kernels.hip) ------------
+size_t qfrag_floats(const FlatGeom &g, int64_t nq);
+void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float *d_qf, float *d_qnorm,
+                         hipStream_t st);
+void launch_row_norms(const float *d_vecs, int64_t n, int dp, float *d_norms, hipStream_t st);
+void launch_pad_rows(const float *d_src, int64_t n, int d, float *d_dst, int dp, hipStream_t st);
+
+FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
+// partial lists: pd [nsplit][nq][k] f32, pi [nsplit][nq][k] i32
+void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
+                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, hipStream_t st);
+int64_t flat_mfma_max_k(const FlatGeom &g);
+
+// direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic
+struct DirectPlan {
+	int nsplit;
+	int64_t split_rows;
+	int grid;
+	size_t lds_bytes;
+	int qgroup;
+};
+DirectPlan plan_flat_direct(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
+void launch_flat_direct(const FlatGeom &g, const DirectPlan &p, int metric, const float *d_xq /*[nq][dp]*/, int64_t nq,
+                        FlatDB db, int64_t k, SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi,
+                        hipStream_t st);
+int64_t flat_direct_max_k();
+
+// merge partial lists -> final (FAISS order), translate labels
+void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, int nsplit, int64_t nq, int64_t k,
+                           const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
+
+void launch_synth_uniform(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, hipStream_t st);
+void launch_synth_clustered(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers,
+                            float sigma, hipStream_t st);
+
+} // namespace mvs

@@ -1,0 +1,383 @@
+// csrc/flat_direct.hip -- per-pair brute-force search (HBM-bound streaming kernel).
+//
+// Replaces what the reference reaches through entry.index->search(...)
+// (/root/reference/src/faiss_extension.cpp:631) when FAISS takes its NON-BLAS branch
+// [UPSTREAM faiss/utils/distances.cpp exhaustive_L2sqr_seq / exhaustive_inner_product_seq]:
+//   * nq < 20 (distance_compute_blas_threshold), e.g. the 1-query batches of the reference's Go harness
+//     (go/benches_c.go:143-161), and
+//   * any search with an IDSelector (faiss_search_filter / faiss_search_filter_set,
+//     src/faiss_extension.cpp:959,1008): `if (!sel->is_member(j)) continue;`
+// Arithmetic (bit-exact with oracle search_pair): L2 = k-ordered chain of fmaf(t,t,acc), t = x[k]-y[k];
+// IP = k-ordered chain of fmaf(x[k],y[k],acc).  MODE_L2_FORMULA reproduces the BLAS-branch value
+// (xn + yn) - 2 ip, used when k exceeds what the fused MFMA kernel's LDS lists can hold.
+//
+// Mapping: thread <-> database row (256-row tiles), queries are wave-uniform (scalar loads), the tile is
+// staged through LDS only to turn coalesced HBM reads into per-row register vectors.  Each wave keeps a
+// k-entry list per query in LDS, distributed over its lanes; insertion is wave-cooperative.
+#include "common.h"
+
+#include "../../include/mi355_faiss.h"
+
+namespace mvs {
+
+constexpr int MODE_IP = 0, MODE_L2_PAIR = 1, MODE_L2_FORMULA = 2;
+constexpr int DTILE = 256;
+
+struct DirectArgs {
+	const float *xq; // [nq_pad][dp], rows >= nq are zero
+	const float *xn; // query norms (formula mode)
+	const float *yb;
+	const float *yn;
+	float *pd;
+	int32_t *pi;
+	long long n, split_rows;
+	int nq, k, dp, nsplit, ngroups;
+	SelectorDev sel;
+	const long long *idmap;
+};
+
+__device__ __forceinline__ bool sel_member(const SelectorDev &s, long long id) {
+	if (s.kind == MVS_SEL_BITMAP) {
+		unsigned long long u = (unsigned long long)id;
+		if ((u >> 3) >= (unsigned long long)s.nbytes)
+			return false;
+		return (s.bitmap[u >> 3] >> (u & 7)) & 1;
+	}
+	if (s.kind == MVS_SEL_BATCH) {
+		long long lo = 0, hi = s.nids;
+		while (lo < hi) {
+			long long mid = (lo + hi) >> 1;
+			if (s.sorted_ids[mid] < id)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo < s.nids && s.sorted_ids[lo] == id;
+	}
+	return true;
+}
+
+template <bool IS_L2>
+__device__ __forceinline__ bool lex_better(float v, int id, float tv, int tid) {
+	if (IS_L2)
+		return v < tv || (v == tv && id < tid);
+	return v > tv || (v == tv && id < tid);
+}
+template <bool IS_L2>
+__device__ __forceinline__ bool lex_worse(float v, int id, float tv, int tid) {
+	if (IS_L2)
+		return v > tv || (v == tv && id > tid);
+	return v < tv || (v == tv && id > tid);
+}
+
+template <int KC, int QG, int MODE>
+__global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
+	constexpr bool IS_L2 = MODE != MODE_IP;
+	constexpr int LDA = KC + 1;
+	constexpr int F4_PER_ROW = KC / 4, F4 = DTILE * F4_PER_ROW, NLD = F4 / 256;
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	float *tbuf = smem; // [2][256][LDA]
+	const int k = a.k;
+	// per wave, per query: list [k] values + [k] ids, then worst (v,id,pos)
+	float *lv = smem + 2 * DTILE * LDA;
+	int *lid = (int *)(lv + 4 * QG * k);
+	float *wv = (float *)(lid + 4 * QG * k);
+	int *wid = (int *)(wv + 4 * QG);
+	int *wpos = wid + 4 * QG;
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int split = blockIdx.x / a.ngroups, grp = blockIdx.x % a.ngroups;
+	const int q0 = grp * QG;
+	const long long r_begin = (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + DTILE - 1) / DTILE) : 0;
+	const int nch = a.dp / KC;
+	const int total_units = ntiles * nch;
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+
+	for (int i = lane; i < QG * k; i += 64) {
+		lv[wave * QG * k + i] = neutral;
+		lid[wave * QG * k + i] = -1;
+	}
+	if (lane < QG) {
+		wv[wave * QG + lane] = neutral;
+		wid[wave * QG + lane] = -1;
+		wpos[wave * QG + lane] = 0;
+	}
+
+	float4 stg[NLD];
+	auto stage_load = [&](int u) {
+		const int tile = u / nch, ch = u - tile * nch;
+		const long long row0 = r_begin + (long long)tile * DTILE;
+#pragma unroll
+		for (int i = 0; i < NLD; ++i) {
+			const int f = i * 256 + tid;
+			const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+			long long gr = row0 + row;
+			if (gr >= a.n)
+				gr = a.n - 1;
+			stg[i] = *(const float4 *)(a.yb + (size_t)gr * a.dp + ch * KC + c4 * 4);
+		}
+	};
+	auto stage_store = [&](int u) {
+		float *dst = tbuf + (u & 1) * DTILE * LDA;
+#pragma unroll
+		for (int i = 0; i < NLD; ++i) {
+			const int f = i * 256 + tid;
+			const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+			float *p = dst + row * LDA + c4 * 4;
+			p[0] = stg[i].x;
+			p[1] = stg[i].y;
+			p[2] = stg[i].z;
+			p[3] = stg[i].w;
+		}
+	};
+
+	float acc[QG];
+	if (total_units > 0) {
+		stage_load(0);
+		stage_store(0);
+	}
+	__syncthreads();
+
+	for (int u = 0; u < total_units; ++u) {
+		const int tile = u / nch, ch = u - tile * nch;
+		if (u + 1 < total_units)
+			stage_load(u + 1);
+		if (ch == 0) {
+#pragma unroll
+			for (int qq = 0; qq < QG; ++qq)
+				acc[qq] = 0.f;
+		}
+		float y[KC];
+		const float *src = tbuf + (u & 1) * DTILE * LDA + tid * LDA;
+#pragma unroll
+		for (int kk = 0; kk < KC; ++kk)
+			y[kk] = src[kk];
+#pragma unroll
+		for (int qq = 0; qq < QG; ++qq) {
+			const float *xs = a.xq + (size_t)(q0 + qq) * a.dp + ch * KC; // wave-uniform: scalar loads
+			float s = acc[qq];
+#pragma unroll
+			for (int kk = 0; kk < KC; ++kk) {
+				if (MODE == MODE_L2_PAIR) {
+					const float t = xs[kk] - y[kk];
+					s = fmaf(t, t, s);
+				} else {
+					s = fmaf(xs[kk], y[kk], s);
+				}
+			}
+			acc[qq] = s;
+		}
+
+		if (ch == nch - 1) {
+			const long long row0 = r_begin + (long long)tile * DTILE;
+			const long long row = row0 + tid;
+			bool valid = row < r_end;
+			if (valid && a.sel.kind != MVS_SEL_NONE)
+				valid = sel_member(a.sel, a.idmap ? a.idmap[row] : row);
+			float ynr = 0.f;
+			if (MODE == MODE_L2_FORMULA)
+				ynr = a.yn[row < a.n ? row : a.n - 1];
+#pragma unroll
+			for (int qq = 0; qq < QG; ++qq) {
+				float v = acc[qq];
+				if (MODE == MODE_L2_FORMULA) {
+					v = fmaf(-2.0f, v, a.xn[q0 + qq < a.nq ? q0 + qq : 0] + ynr);
+					v = v < 0.f ? 0.f : v;
+				}
+				const int slot = wave * QG + qq;
+				float tv = wv[slot];
+				// rows arrive in ascending id order, so an equal value never beats the stored worst
+				const bool pass = valid && (q0 + qq < a.nq) && (IS_L2 ? v < tv : v > tv);
+				unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+				if (mask != 0ull) {
+					int tpos = wpos[slot];
+					float *mv = lv + slot * k;
+					int *mi = lid + slot * k;
+					while (mask) {
+						const int l = __builtin_ctzll(mask);
+						mask &= mask - 1;
+						const float cv = __shfl(v, l);
+						const int id = (int)(row0 + (tid - lane) + l);
+						if (IS_L2 ? cv < tv : cv > tv) {
+							// replace the worst entry, then wave-wide search for the new worst
+							if (lane == 0) {
+								mv[tpos] = cv;
+								mi[tpos] = id;
+							}
+							__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+							__builtin_amdgcn_wave_barrier();
+							float bv = 0.f;
+							int bi = 0, bp = -1;
+							for (int j = lane; j < k; j += 64) {
+								const float x = mv[j];
+								const int xi = mi[j];
+								if (bp < 0 || lex_worse<IS_L2>(x, xi, bv, bi)) {
+									bv = x;
+									bi = xi;
+									bp = j;
+								}
+							}
+#pragma unroll
+							for (int off = 32; off >= 1; off >>= 1) {
+								const float ov = __shfl_xor(bv, off);
+								const int oi = __shfl_xor(bi, off);
+								const int op = __shfl_xor(bp, off);
+								const bool take = op >= 0 && (bp < 0 || lex_worse<IS_L2>(ov, oi, bv, bi));
+								if (take) {
+									bv = ov;
+									bi = oi;
+									bp = op;
+								}
+							}
+							tv = bv;
+							tpos = bp;
+							if (lane == 0) {
+								wv[slot] = bv;
+								wid[slot] = bi;
+								wpos[slot] = bp;
+							}
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
+		}
+		if (u + 1 < total_units)
+			stage_store(u + 1);
+		__syncthreads();
+	}
+
+	// partial lists: [nsplit*4][nq][k] -- one partial per (split, wave)
+	for (int qq = 0; qq < QG; ++qq) {
+		const int q = q0 + qq;
+		if (q >= a.nq)
+			break;
+		float *od = a.pd + ((size_t)(split * 4 + wave) * a.nq + q) * k;
+		int32_t *oi = a.pi + ((size_t)(split * 4 + wave) * a.nq + q) * k;
+		for (int j = lane; j < k; j += 64) {
+			od[j] = lv[(wave * QG + qq) * k + j];
+			oi[j] = lid[(wave * QG + qq) * k + j];
+		}
+	}
+}
+
+// -------------------------------------------------------------------------------------------------------
+
+static int direct_kc(const FlatGeom &g) {
+	return g.dp == 8 ? 8 : (g.dp == 16 ? 16 : 32);
+}
+static size_t direct_lds(int kc, int qg, int64_t k) {
+	return (size_t)2 * DTILE * (kc + 1) * 4 + (size_t)4 * qg * k * 8 + 4 * qg * 12;
+}
+int64_t flat_direct_max_k() {
+	return (int64_t)((160 * 1024 - direct_lds(32, 1, 0)) / 32);
+}
+static int pick_qgroup(int64_t nq, int64_t k, int kc) {
+	const int cands[] = {20, 4, 1};
+	for (int qg : cands) {
+		if (qg > 1 && nq <= (qg == 20 ? 4 : 1))
+			continue; // small batches: do not pad to a wide group
+		if (direct_lds(kc, qg, k) <= 150 * 1024)
+			return qg;
+	}
+	return 1;
+}
+
+DirectPlan plan_flat_direct(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
+	DirectPlan p;
+	const int kc = direct_kc(g);
+	p.qgroup = pick_qgroup(nq, k, kc);
+	const int ngroups = (int)((nq + p.qgroup - 1) / p.qgroup);
+	const int64_t ntiles = (n + DTILE - 1) / DTILE;
+	int64_t nsplit = 2048 / (ngroups > 0 ? ngroups : 1);
+	if (nsplit > ntiles / 4)
+		nsplit = ntiles / 4;
+	if (nsplit < 1)
+		nsplit = 1;
+	// the merge kernel holds 4*nsplit*k candidates in LDS
+	while (nsplit > 1 && (size_t)(4 * nsplit + 1) * k * 8 > 150 * 1024)
+		nsplit /= 2;
+	const int64_t tiles_per_split = ntiles > 0 ? (ntiles + nsplit - 1) / nsplit : 1;
+	p.split_rows = tiles_per_split * DTILE;
+	p.nsplit = (int)nsplit;
+	p.grid = p.nsplit * ngroups;
+	p.lds_bytes = direct_lds(kc, p.qgroup, k);
+	return p;
+}
+
+template <int KC, int QG>
+static void launch_direct_inst(int mode, const DirectArgs &a, const DirectPlan &p, hipStream_t st) {
+#define MVS_LAUNCH_DIRECT(M)                                                                                           \
+	{                                                                                                                  \
+		auto kern = flat_direct_kernel<KC, QG, M>;                                                                     \
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes)); \
+		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);                                          \
+	}
+	if (mode == MODE_IP)
+		MVS_LAUNCH_DIRECT(MODE_IP)
+	else if (mode == MODE_L2_PAIR)
+		MVS_LAUNCH_DIRECT(MODE_L2_PAIR)
+	else
+		MVS_LAUNCH_DIRECT(MODE_L2_FORMULA)
+#undef MVS_LAUNCH_DIRECT
+	MVS_HIP(hipGetLastError());
+}
+
+template <int KC>
+static void launch_direct_kc(int mode, int qg, const DirectArgs &a, const DirectPlan &p, hipStream_t st) {
+	if (qg == 20)
+		launch_direct_inst<KC, 20>(mode, a, p, st);
+	else if (qg == 4)
+		launch_direct_inst<KC, 4>(mode, a, p, st);
+	else
+		launch_direct_inst<KC, 1>(mode, a, p, st);
+}
+
+// mode_formula: use the BLAS-branch L2 value (xn + yn - 2ip); d_xn must then be valid
+void launch_flat_direct(const FlatGeom &g, const DirectPlan &p, int metric, const float *d_xq, int64_t nq, FlatDB db,
+                        int64_t k, SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi,
+                        hipStream_t st);
+
+void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, bool formula, const float *d_xq,
+                           const float *d_xn, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,
+                           const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	DirectArgs a;
+	a.xq = d_xq;
+	a.xn = d_xn;
+	a.yb = db.vecs;
+	a.yn = db.norms;
+	a.pd = d_pd;
+	a.pi = d_pi;
+	a.n = db.n;
+	a.split_rows = p.split_rows;
+	a.nq = (int)nq;
+	a.k = (int)k;
+	a.dp = g.dp;
+	a.nsplit = p.nsplit;
+	a.ngroups = (int)((nq + p.qgroup - 1) / p.qgroup);
+	a.sel = sel;
+	a.idmap = (const long long *)d_idmap;
+	const int mode = metric == METRIC_IP ? MODE_IP : (formula ? MODE_L2_FORMULA : MODE_L2_PAIR);
+	const int kc = direct_kc(g);
+	if (kc == 8)
+		launch_direct_kc<8>(mode, p.qgroup, a, p, st);
+	else if (kc == 16)
+		launch_direct_kc<16>(mode, p.qgroup, a, p, st);
+	else
+		launch_direct_kc<32>(mode, p.qgroup, a, p, st);
+}
+
+void launch_flat_direct(const FlatGeom &g, const DirectPlan &p, int metric, const float *d_xq, int64_t nq, FlatDB db,
+                        int64_t k, SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi,
+                        hipStream_t st) {
+	launch_flat_direct_ex(g, p, metric, false, d_xq, nullptr, nq, db, k, sel, d_idmap, d_pd, d_pi, st);
+}
+
+} // namespace mvs

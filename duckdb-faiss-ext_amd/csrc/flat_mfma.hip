@@ -1,0 +1,439 @@
+// csrc/flat_mfma.hip -- K2/K3: brute-force L2 / inner-product search as an f32 MFMA contraction with the
+// top-k select fused into the accumulator epilogue (the nq x N distance matrix never reaches HBM).
+//
+// Replaces, for nq >= 20 and no selector, what the reference reaches through
+//   entry.index->search(...)            /root/reference/src/faiss_extension.cpp:631
+//     -> faiss::IndexFlat::search -> knn_L2sqr / knn_inner_product -> exhaustive_*_blas   [UPSTREAM FAISS]
+// i.e. ip = sgemm(Y, X); dis = |x|^2 + |y|^2 - 2 ip (clamped at 0); per-query k-best heap.
+//
+// Arithmetic contract (bit-exact with oracle/orc_core.c search_blas):
+//   v_mfma_f32_32x32x2_f32 is a k-ordered f32 fma chain (one rounding per product), so the accumulator
+//   equals fmaf(x[d-1],y[d-1], ... fmaf(x[0],y[0],0)); the epilogue computes (xn + yn) - 2*ip with the
+//   same two roundings as the oracle.  Zero padding of d up to dp adds fma(0,0,acc) = acc.
+//
+// Mapping (CDNA4, wave64):
+//   A operand = 32 database rows (M), B operand = 32 queries (N): D[i][j] lands with the QUERY on the
+//   lane (col = lane&31) and 16 database rows in the lane's 16 accumulator registers
+//   (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  So a lane tests its 16 distances against its own
+//   query's current k-th best with no cross-lane traffic; insertions (rare: ~k ln(N/k) per query) go to a
+//   per-query list in LDS owned by that wave.
+//   Workgroup = 4 waves x 32 queries; the database tile is staged once in LDS (padded rows => conflict
+//   free ds_read_b32 in natural k order) and shared by the 4 waves.
+//   d <= 128: the wave's 32 queries stay resident in registers as B fragments for the whole kernel.
+//   d  > 128: 256-row tiles (8 accumulator tiles per wave), k streamed in units of 32.
+#include "common.h"
+
+namespace mvs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MfmaArgs {
+	const float *qf; // query fragments, layout [qblk32][ch][s4][lane][4]
+	const float *qn; // query norms
+	const float *yb; // database [n][dp]
+	const float *yn; // database norms
+	float *pd;       // partial distances [nsplit][nq][k]
+	int32_t *pi;     // partial row ids
+	long long n;
+	long long split_rows;
+	int nq, k, nqb, nsplit, dp, nch, xcd_map;
+};
+
+struct Thr {
+	float v;
+	int id;
+	int pos;
+};
+
+// membership order (DESIGN.md "ties"): L2 keeps the k smallest (dist, id); IP keeps the k largest score,
+// equal scores prefer the smaller id.
+template <bool IS_L2>
+__device__ __forceinline__ bool cand_better(float v, int id, float tv, int tid) {
+	if (IS_L2)
+		return v < tv || (v == tv && id < tid);
+	return v > tv || (v == tv && id < tid);
+}
+
+// replace the current worst entry of one query's list and find the new worst (rare path)
+template <bool IS_L2>
+__device__ __noinline__ Thr list_insert(float *ld, int *li, int k, int pos, float v, int id) {
+	ld[pos] = v;
+	li[pos] = id;
+	float wv = ld[0];
+	int wi = li[0], wp = 0;
+	for (int j = 1; j < k; ++j) {
+		float x = ld[j];
+		int xi = li[j];
+		bool w = IS_L2 ? (x > wv || (x == wv && xi > wi)) : (x < wv || (x == wv && xi > wi));
+		if (w) {
+			wv = x;
+			wi = xi;
+			wp = j;
+		}
+	}
+	Thr t;
+	t.v = wv;
+	t.id = wi;
+	t.pos = wp;
+	return t;
+}
+
+template <int KSTEPS, int NT, bool RESIDENT, bool IS_L2>
+__global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const MfmaArgs a) {
+	constexpr int KC = 2 * KSTEPS, LDA = KC + 1, BN = 32 * NT;
+	constexpr int F4_PER_ROW = KC / 4, F4 = BN * F4_PER_ROW, NLD = (F4 + 255) / 256;
+	static_assert(KSTEPS % 4 == 0, "fragment layout packs 4 k-steps per float4");
+
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	float *tbuf = smem;                 // [2][BN][LDA]
+	float *nbuf = smem + 2 * BN * LDA;  // [2][BN]
+	float *ld = nbuf + 2 * BN;          // [128][k]
+	int *li = (int *)(ld + QBLOCK * a.k);
+	float *lthr = (float *)(li + QBLOCK * a.k);
+	int *lthrid = (int *)(lthr + QBLOCK);
+	int *lpos = lthrid + QBLOCK;
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int h = lane >> 5, c = lane & 31;
+	const int k = a.k;
+
+	int split, qb;
+	if (a.xcd_map) { // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD its own splits
+		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+		split = (idx / a.nqb) * 8 + xcd;
+		qb = idx % a.nqb;
+	} else {
+		split = blockIdx.x / a.nqb;
+		qb = blockIdx.x % a.nqb;
+	}
+	const int ql = wave * WAVE_Q + c; // query slot inside the block
+	const int q = qb * QBLOCK + ql;
+	const bool qvalid = q < a.nq;
+	const int qblk32 = qb * 4 + wave;
+
+	const long long r_begin = (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + BN - 1) / BN) : 0;
+	const int nch = RESIDENT ? 1 : a.nch;
+	const int total_units = ntiles * nch;
+
+	// ---- per-query list init (one lane per query) --------------------------------------------------
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+	// out-of-range query slots never accept anything
+	float thr = qvalid ? neutral : (IS_L2 ? -INFINITY : INFINITY);
+	if (h == 0) {
+		for (int j = 0; j < k; ++j) {
+			ld[ql * k + j] = neutral;
+			li[ql * k + j] = -1;
+		}
+		lthr[ql] = thr;
+		lthrid[ql] = -1;
+		lpos[ql] = 0;
+	}
+	const float xnq = (IS_L2 && qvalid) ? a.qn[q] : 0.f;
+
+	// ---- B fragments (queries) ---------------------------------------------------------------------
+	float qf[KSTEPS];
+	const float4 *qsrc = (const float4 *)a.qf + (size_t)qblk32 * nch * (KSTEPS / 4) * 64 + lane;
+#pragma unroll
+	for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
+		float4 v = qsrc[s4 * 64];
+		qf[4 * s4 + 0] = v.x;
+		qf[4 * s4 + 1] = v.y;
+		qf[4 * s4 + 2] = v.z;
+		qf[4 * s4 + 3] = v.w;
+	}
+
+	// ---- staging helpers ---------------------------------------------------------------------------
+	float4 stg[NLD];
+	float nstg = 0.f;
+	auto stage_load = [&](int u) {
+		const int tile = u / nch, ch = u - tile * nch;
+		const long long row0 = r_begin + (long long)tile * BN;
+#pragma unroll
+		for (int i = 0; i < NLD; ++i) {
+			const int f = i * 256 + tid;
+			if (F4 % 256 == 0 || f < F4) {
+				const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+				long long gr = row0 + row;
+				if (gr >= a.n)
+					gr = a.n - 1; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
+				stg[i] = *(const float4 *)(a.yb + (size_t)gr * a.dp + ch * KC + c4 * 4);
+			}
+		}
+		if (IS_L2 && ch == 0 && tid < BN) {
+			long long gr = row0 + tid;
+			if (gr >= a.n)
+				gr = a.n - 1;
+			nstg = a.yn[gr];
+		}
+	};
+	auto stage_store = [&](int u) {
+		const int tile = u / nch, ch = u - tile * nch;
+		float *dst = tbuf + (u & 1) * BN * LDA;
+#pragma unroll
+		for (int i = 0; i < NLD; ++i) {
+			const int f = i * 256 + tid;
+			if (F4 % 256 == 0 || f < F4) {
+				const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+				float *p = dst + row * LDA + c4 * 4;
+				p[0] = stg[i].x;
+				p[1] = stg[i].y;
+				p[2] = stg[i].z;
+				p[3] = stg[i].w;
+			}
+		}
+		if (IS_L2 && ch == 0 && tid < BN)
+			nbuf[(tile & 1) * BN + tid] = nstg;
+	};
+
+	f32x16 acc[NT];
+
+	if (total_units > 0) {
+		stage_load(0);
+		stage_store(0);
+	}
+	__syncthreads();
+
+	for (int u = 0; u < total_units; ++u) {
+		const int tile = u / nch, ch = u - tile * nch;
+		if (u + 1 < total_units)
+			stage_load(u + 1);
+		float qfn[RESIDENT ? 1 : KSTEPS];
+		if (!RESIDENT) {
+			// B fragments of the NEXT unit (L2/MALL resident), consumed after this unit's MFMAs
+			const int un = u + 1 < total_units ? u + 1 : u;
+			const int chn = un % nch;
+#pragma unroll
+			for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
+				float4 v = qsrc[(chn * (KSTEPS / 4) + s4) * 64];
+				qfn[4 * s4 + 0] = v.x;
+				qfn[4 * s4 + 1] = v.y;
+				qfn[4 * s4 + 2] = v.z;
+				qfn[4 * s4 + 3] = v.w;
+			}
+		}
+		if (ch == 0) {
+#pragma unroll
+			for (int t = 0; t < NT; ++t)
+#pragma unroll
+				for (int r = 0; r < 16; ++r)
+					acc[t][r] = 0.f;
+		}
+		const float *A = tbuf + (u & 1) * BN * LDA + c * LDA + h;
+#pragma unroll
+		for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+			for (int t = 0; t < NT; ++t) {
+				const float av = A[t * 32 * LDA + 2 * s];
+				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qf[s], acc[t], 0, 0, 0);
+			}
+		}
+		if (!RESIDENT) {
+#pragma unroll
+			for (int s = 0; s < KSTEPS; ++s)
+				qf[s] = qfn[s];
+		}
+
+		if (ch == nch - 1) {
+			// ---- fused epilogue: distances + threshold test, lane-local per query ---------------------
+			const long long row0 = r_begin + (long long)tile * BN;
+			const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
+			const float *nb = nbuf + (tile & 1) * BN;
+			bool any = false;
+#pragma unroll
+			for (int t = 0; t < NT; ++t) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+					if (IS_L2)
+						y4 = *(const float4 *)(nb + t * 32 + 8 * g + 4 * h);
+					const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						float v = acc[t][4 * g + e];
+						if (IS_L2) {
+							v = fmaf(-2.0f, v, xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
+							acc[t][4 * g + e] = v;
+							any |= v < thr;
+						} else {
+							any |= v > thr;
+						}
+					}
+				}
+			}
+			if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+				// ---- rare path: exact (value, id) insertion into this wave's per-query lists ----------
+				for (int hh = 0; hh < 2; ++hh) { // lanes l and l+32 share a query: take turns
+					if (h == hh) {
+						Thr cur;
+						cur.v = lthr[ql];
+						cur.id = lthrid[ql];
+						cur.pos = lpos[ql];
+#pragma unroll
+						for (int t = 0; t < NT; ++t) {
+#pragma unroll
+							for (int r = 0; r < 16; ++r) {
+								float v = acc[t][r];
+								if (IS_L2)
+									v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
+								const int rl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+								const int id = (int)(row0 + rl);
+								if (rl < nvalid && cand_better<IS_L2>(v, id, cur.v, cur.id))
+									cur = list_insert<IS_L2>(ld + ql * k, li + ql * k, k, cur.pos, v, id);
+							}
+						}
+						lthr[ql] = cur.v;
+						lthrid[ql] = cur.id;
+						lpos[ql] = cur.pos;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+				}
+				thr = lthr[ql];
+			}
+		}
+
+		if (u + 1 < total_units)
+			stage_store(u + 1);
+		__syncthreads();
+	}
+
+	// ---- partial result lists (unsorted; merged by K4) ----------------------------------------------
+	if (h == 0 && qvalid) {
+		float *od = a.pd + ((size_t)split * a.nq + q) * k;
+		int32_t *oi = a.pi + ((size_t)split * a.nq + q) * k;
+		for (int j = 0; j < k; ++j) {
+			od[j] = ld[ql * k + j];
+			oi[j] = li[ql * k + j];
+		}
+	}
+}
+
+// -------------------------------------------------------------------------------------------------
+
+FlatGeom flat_geom_for(int d) {
+	FlatGeom g;
+	g.d = d;
+	if (d <= 128) {
+		static const int kcs[] = {8, 16, 32, 64, 96, 128};
+		g.kc = 128;
+		for (int v : kcs)
+			if (v >= d) {
+				g.kc = v;
+				break;
+			}
+		g.dp = g.kc;
+		g.nch = 1;
+		g.ntile = 2;
+	} else {
+		g.kc = 32;
+		g.dp = (d + 31) / 32 * 32;
+		g.nch = g.dp / 32;
+		g.ntile = 8;
+	}
+	return g;
+}
+
+size_t qfrag_floats(const FlatGeom &g, int64_t nq) {
+	const int64_t nblk32 = (nq + QBLOCK - 1) / QBLOCK * 4;
+	return (size_t)nblk32 * 32 * g.dp;
+}
+
+static size_t mfma_lds_bytes(const FlatGeom &g, int64_t k) {
+	const size_t bn = g.bn();
+	return (2 * bn * (g.kc + 1) + 2 * bn) * sizeof(float) + (size_t)QBLOCK * k * 8 + QBLOCK * 12;
+}
+
+int64_t flat_mfma_max_k(const FlatGeom &g) {
+	const size_t fixed = mfma_lds_bytes(g, 0);
+	return (int64_t)((160 * 1024 - fixed) / (QBLOCK * 8));
+}
+
+FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
+	FlatSearchPlan p;
+	p.nqb = (int)((nq + QBLOCK - 1) / QBLOCK);
+	const int bn = g.bn();
+	const int64_t ntiles = (n + bn - 1) / bn;
+	int64_t nsplit = 2048 / (p.nqb > 0 ? p.nqb : 1); // ~4 rounds of 512 resident workgroups
+	const int64_t min_tiles = 16;                     // amortise list warm-up per split
+	if (nsplit > ntiles / min_tiles)
+		nsplit = ntiles / min_tiles;
+	if (nsplit < 1)
+		nsplit = 1;
+	p.xcd_map = false;
+	if (nsplit >= 8) {
+		nsplit = nsplit / 8 * 8;
+		p.xcd_map = true;
+	}
+	int64_t tiles_per_split = ntiles > 0 ? (ntiles + nsplit - 1) / nsplit : 1;
+	p.split_rows = tiles_per_split * bn;
+	p.nsplit = (int)nsplit;
+	p.grid = p.nqb * p.nsplit;
+	p.lds_bytes = mfma_lds_bytes(g, k);
+	return p;
+}
+
+template <int KSTEPS, int NT, bool RESIDENT>
+static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
+	if (metric == METRIC_L2) {
+		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, true>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+	} else {
+		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, false>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
+void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
+                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	MfmaArgs a;
+	a.qf = d_qf;
+	a.qn = d_qnorm;
+	a.yb = db.vecs;
+	a.yn = db.norms;
+	a.pd = d_pd;
+	a.pi = d_pi;
+	a.n = db.n;
+	a.split_rows = p.split_rows;
+	a.nq = (int)nq;
+	a.k = (int)k;
+	a.nqb = p.nqb;
+	a.nsplit = p.nsplit;
+	a.dp = g.dp;
+	a.nch = g.nch;
+	a.xcd_map = p.xcd_map ? 1 : 0;
+	if (g.nch == 1) {
+		switch (g.kc) {
+		case 8:
+			launch_inst<4, 2, true>(metric, a, p, st);
+			break;
+		case 16:
+			launch_inst<8, 2, true>(metric, a, p, st);
+			break;
+		case 32:
+			launch_inst<16, 2, true>(metric, a, p, st);
+			break;
+		case 64:
+			launch_inst<32, 2, true>(metric, a, p, st);
+			break;
+		case 96:
+			launch_inst<48, 2, true>(metric, a, p, st);
+			break;
+		default:
+			launch_inst<64, 2, true>(metric, a, p, st);
+			break;
+		}
+	} else {
+		launch_inst<16, 8, false>(metric, a, p, st);
+	}
+}
+
+} // namespace mvs

@@ -1,0 +1,184 @@
+// csrc/index.h -- device-native index classes behind the C ABI (include/mi355_faiss.h).
+#pragma once
+#include "common.h"
+
+#include "../../include/mi355_faiss.h"
+
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace mvs {
+
+struct DevBuf { // grow-only device scratch (contents NOT preserved on growth)
+	void *p = nullptr;
+	size_t cap = 0;
+	void reserve(size_t bytes);
+	void release();
+	~DevBuf() {
+		release();
+	}
+};
+
+// ring of pinned host buffers: the caller's rows are copied here so add()/search() can return /
+// overlap while hipMemcpyAsync drains the slot (SURVEY.md 8f-1 ingest staging)
+struct PinnedRing {
+	static constexpr int NB = 4;
+	static constexpr size_t SLOT_BYTES = 8u << 20;
+	void *buf[NB] = {nullptr, nullptr, nullptr, nullptr};
+	size_t cap[NB] = {0, 0, 0, 0};
+	hipEvent_t ev[NB] = {nullptr, nullptr, nullptr, nullptr};
+	int next = 0;
+	int acquire(size_t bytes);
+	void release(int slot, hipStream_t st);
+	~PinnedRing();
+};
+
+struct SelectorHolder {
+	DevBuf buf;
+	std::vector<int64_t> sorted;
+	SelectorDev upload(const mvs_search_params *p, hipStream_t st);
+};
+
+class IndexBase {
+public:
+	int kind, d, metric;
+	int64_t ntotal = 0;
+	bool is_trained = true;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int64_t label_offset = 0;
+	mvs_kernel_info kinfo {};
+
+	IndexBase(int kind, int d, int metric);
+	virtual ~IndexBase();
+	void use_device() const;
+
+	// faiss::Index virtuals the glue calls (src/faiss_extension.cpp:396,510,512,583,607,609,631)
+	virtual void train(int64_t n, const float *x);
+	virtual void add(int64_t n, const float *x) = 0;
+	virtual void add_with_ids(int64_t n, const float *x, const int64_t *ids);
+	virtual void search(int64_t nq, const float *x, int64_t k, float *D, int64_t *I, const mvs_search_params *params);
+	// device-resident variants
+	virtual void add_device(int64_t n, const float *d_x, hipStream_t st) = 0;
+	virtual void add_with_ids_device(int64_t n, const float *d_x, const int64_t *d_ids, hipStream_t st);
+	virtual void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                           const mvs_search_params *params, hipStream_t st) = 0;
+	// search on behalf of an IndexIDMap wrapper: selector tests d_idmap[internal], labels = d_idmap[internal]
+	virtual void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) = 0;
+	virtual void to_device(int new_device) = 0;
+	virtual void set_label_offset(int64_t off) {
+		label_offset = off;
+	}
+	virtual bool set_option(const char *, int64_t) {
+		return false;
+	}
+
+	// HIP-event timing of the dominant kernel (bench.py roofline)
+	virtual void set_timing(bool on) {
+		timing_enabled = on;
+	}
+	virtual void resolve_timing(int *count, double *total_ms) {
+		resolve_kernel_timing(count, total_ms);
+	}
+
+protected:
+	PinnedRing pinned;
+	DevBuf ws_hx, ws_hD, ws_hI;
+	bool timing_enabled = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
+	int timing_count = 0;
+	double timing_total_ms = 0;
+	void begin_kernel_timing(hipStream_t st);
+	void end_kernel_timing(hipStream_t st);
+	void resolve_kernel_timing(int *count, double *total_ms);
+};
+
+class FlatIndex : public IndexBase {
+public:
+	FlatGeom geom;
+	float *vecs = nullptr;  // [cap][dp]
+	float *norms = nullptr; // [cap]
+	int64_t cap = 0;
+	bool force_direct = false; // test hook: per-pair kernel for any nq
+
+	FlatIndex(int d, int metric);
+	~FlatIndex() override;
+	void reset();
+	void add(int64_t n, const float *x) override;
+	void add_device(int64_t n, const float *d_x, hipStream_t st) override;
+	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                   const mvs_search_params *params, hipStream_t st) override;
+	void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                   const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) override;
+	void to_device(int new_device) override;
+	bool set_option(const char *key, int64_t v) override;
+	void search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                 const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
+
+private:
+	DevBuf ws_q, ws_qn, ws_pd, ws_pi;
+	SelectorHolder selector;
+	void grow(int64_t need, hipStream_t st);
+};
+
+class IDMapIndex : public IndexBase {
+public:
+	IndexBase *sub; // owned
+	int64_t *ids = nullptr;
+	int64_t idcap = 0;
+
+	explicit IDMapIndex(IndexBase *sub);
+	~IDMapIndex() override;
+	void train(int64_t n, const float *x) override;
+	void add(int64_t n, const float *x) override;
+	void add_with_ids(int64_t n, const float *x, const int64_t *ids) override;
+	void add_device(int64_t n, const float *d_x, hipStream_t st) override;
+	void add_with_ids_device(int64_t n, const float *d_x, const int64_t *d_ids, hipStream_t st) override;
+	void search(int64_t nq, const float *x, int64_t k, float *D, int64_t *I, const mvs_search_params *params) override;
+	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                   const mvs_search_params *params, hipStream_t st) override;
+	void search_mapped(int64_t, const float *, int64_t, float *, int64_t *, const mvs_search_params *, const int64_t *,
+	                   hipStream_t) override {
+		throw_faiss("mvs::IDMapIndex::search_mapped", __FILE__, "nested IDMap is not supported");
+	}
+	void to_device(int new_device) override;
+	void set_label_offset(int64_t) override {
+	}
+	bool set_option(const char *key, int64_t v) override {
+		return sub->set_option(key, v);
+	}
+	void set_timing(bool on) override {
+		sub->set_timing(on);
+	}
+	void resolve_timing(int *count, double *total_ms) override {
+		sub->resolve_timing(count, total_ms);
+		kinfo = sub->kinfo;
+	}
+
+private:
+	void grow_ids(int64_t need, hipStream_t st);
+};
+
+IndexBase *index_factory(int d, const char *description, int metric);
+
+// csrc/ivf.hip
+IndexBase *make_ivf_index(int d, const std::string &desc, int metric); // nullptr if desc is not an IVF string
+IndexBase *ivf_quantizer_of(IndexBase *ix);
+// csrc/hnsw.hip
+IndexBase *make_hnsw_index(int d, const std::string &desc, int metric);
+bool hnsw_set_ef_construction(IndexBase *ix, int v);
+// csrc/io.cpp-ish (index_io.hip)
+void write_index_file(const IndexBase *ix, const char *filename);
+IndexBase *read_index_file(const char *filename);
+// csrc/merge_host.hip
+void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
+                       int64_t *I_out);
+
+void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, bool formula, const float *d_xq,
+                           const float *d_xn, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,
+                           const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st);
+
+} // namespace mvs

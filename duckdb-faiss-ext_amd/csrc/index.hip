@@ -1,0 +1,834 @@
+// csrc/index.hip -- device-native index objects + the C ABI of include/mi355_faiss.h.
+//
+// Host side of the hot path.  Mirrors the FAISS object graph the reference's glue walks
+// (/root/reference/src/faiss_extension.cpp:123-144 setIndexParameters, :668-721 innerCreateSearchParameters):
+//   FlatIndex     <- faiss::IndexFlat{L2,IP}      rows in HBM, padded row-major + per-row squared norms
+//   IDMapIndex    <- faiss::IndexIDMap            int64 id_map in HBM, translated in the merge kernel
+//   IVFFlatIndex  <- faiss::IndexIVFFlat          (csrc/ivf.hip)
+// Every index owns a HIP stream and a ring of pinned staging buffers: add() copies the caller's rows into
+// pinned memory (the caller's DataChunk buffer is only valid during the call, :493-512) and returns while
+// hipMemcpyAsync + the norm kernel run on the stream.
+#include "index.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+namespace mvs {
+
+static thread_local std::string g_last_error;
+
+void throw_faiss(const char *func, const char *file, const char *fmt, ...) {
+	char msg[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(msg, sizeof msg, fmt, ap);
+	va_end(ap);
+	// FAISS: "Error in <func> at <file>:<line>: <msg>" (impl/FaissException.cpp)
+	const char *base = strrchr(file, '/');
+	throw Error(std::string("Error in ") + func + " at " + (base ? base + 1 : file) + ": " + msg);
+}
+
+// ------------------------------------------------------------------------------------------ buffers
+
+void DevBuf::reserve(size_t bytes) {
+	if (bytes <= cap)
+		return;
+	if (p)
+		MVS_HIP(hipFree(p));
+	p = nullptr;
+	cap = 0;
+	size_t want = bytes + bytes / 4 + 256;
+	MVS_HIP(hipMalloc(&p, want));
+	cap = want;
+}
+void DevBuf::release() {
+	if (p)
+		(void)hipFree(p);
+	p = nullptr;
+	cap = 0;
+}
+
+PinnedRing::~PinnedRing() {
+	for (int i = 0; i < NB; ++i) {
+		if (buf[i])
+			(void)hipHostFree(buf[i]);
+		if (ev[i])
+			(void)hipEventDestroy(ev[i]);
+	}
+}
+int PinnedRing::acquire(size_t bytes) {
+	const int i = next;
+	next = (next + 1) % NB;
+	if (!ev[i])
+		MVS_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+	else
+		MVS_HIP(hipEventSynchronize(ev[i])); // previous copy out of this slot has finished
+	if (bytes > cap[i]) {
+		if (buf[i])
+			MVS_HIP(hipHostFree(buf[i]));
+		buf[i] = nullptr;
+		size_t want = std::max(bytes, (size_t)SLOT_BYTES);
+		MVS_HIP(hipHostMalloc(&buf[i], want, hipHostMallocDefault));
+		cap[i] = want;
+	}
+	return i;
+}
+void PinnedRing::release(int i, hipStream_t st) {
+	MVS_HIP(hipEventRecord(ev[i], st));
+}
+
+// ------------------------------------------------------------------------------------------ base
+
+static int env_device() {
+	const char *e = getenv("MVS_DEVICE");
+	return e ? atoi(e) : 0;
+}
+
+IndexBase::IndexBase(int kind_, int d_, int metric_) : kind(kind_), d(d_), metric(metric_) {
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		throw_faiss("mvs::IndexBase::IndexBase", __FILE__,
+		            "no MI355X (gfx950) device is usable (%s): the MI355X vector-search path has no CPU fallback",
+		            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+	device = env_device();
+	if (device < 0 || device >= ndev)
+		throw_faiss("mvs::IndexBase::IndexBase", __FILE__, "Invalid GPU device %d", device);
+	MVS_HIP(hipSetDevice(device));
+	MVS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+IndexBase::~IndexBase() {
+	if (stream) {
+		(void)hipSetDevice(device);
+		(void)hipStreamSynchronize(stream);
+		(void)hipStreamDestroy(stream);
+	}
+	for (auto &p : timing_events) {
+		(void)hipEventDestroy(p.first);
+		(void)hipEventDestroy(p.second);
+	}
+}
+void IndexBase::use_device() const {
+	MVS_HIP(hipSetDevice(device)); // DuckDB calls from arbitrary worker threads
+}
+void IndexBase::train(int64_t, const float *) {
+	// faiss::Index::train: "does nothing by default"
+}
+void IndexBase::add_with_ids(int64_t, const float *, const int64_t *) {
+	// faiss/Index.cpp -- substring matched at src/faiss_extension.cpp:523; user text pinned by faiss4.test:22
+	throw_faiss("virtual void faiss::Index::add_with_ids(faiss::idx_t, const float*, const faiss::idx_t*)",
+	            "faiss/Index.cpp", "add_with_ids not implemented for this type of index");
+}
+void IndexBase::add_with_ids_device(int64_t, const float *, const int64_t *, hipStream_t) {
+	throw_faiss("virtual void faiss::Index::add_with_ids(faiss::idx_t, const float*, const faiss::idx_t*)",
+	            "faiss/Index.cpp", "add_with_ids not implemented for this type of index");
+}
+
+// host-pointer search = stage queries, device search, copy back (src/faiss_extension.cpp:623-638)
+void IndexBase::search(int64_t nq, const float *x, int64_t k, float *D, int64_t *I, const mvs_search_params *params) {
+	use_device();
+	if (k <= 0)
+		throw_faiss("virtual void faiss::Index::search(...) const", "faiss/Index.cpp", "Error: 'k > 0' failed");
+	if (nq <= 0)
+		return;
+	ws_hx.reserve((size_t)nq * d * sizeof(float));
+	ws_hD.reserve((size_t)nq * k * sizeof(float));
+	ws_hI.reserve((size_t)nq * k * sizeof(int64_t));
+	const size_t xbytes = (size_t)nq * d * sizeof(float);
+	int slot = pinned.acquire(xbytes);
+	memcpy(pinned.buf[slot], x, xbytes);
+	MVS_HIP(hipMemcpyAsync(ws_hx.p, pinned.buf[slot], xbytes, hipMemcpyHostToDevice, stream));
+	pinned.release(slot, stream);
+	search_device(nq, (const float *)ws_hx.p, k, (float *)ws_hD.p, (int64_t *)ws_hI.p, params, stream);
+	const size_t dbytes = (size_t)nq * k * sizeof(float), ibytes = (size_t)nq * k * sizeof(int64_t);
+	slot = pinned.acquire(dbytes + ibytes);
+	char *hb = (char *)pinned.buf[slot];
+	MVS_HIP(hipMemcpyAsync(hb, ws_hD.p, dbytes, hipMemcpyDeviceToHost, stream));
+	MVS_HIP(hipMemcpyAsync(hb + dbytes, ws_hI.p, ibytes, hipMemcpyDeviceToHost, stream));
+	MVS_HIP(hipStreamSynchronize(stream));
+	memcpy(D, hb, dbytes);
+	memcpy(I, hb + dbytes, ibytes);
+	pinned.release(slot, stream);
+}
+
+void IndexBase::begin_kernel_timing(hipStream_t st) {
+	if (!timing_enabled)
+		return;
+	hipEvent_t a, b;
+	MVS_HIP(hipEventCreate(&a));
+	MVS_HIP(hipEventCreate(&b));
+	timing_events.emplace_back(a, b);
+	MVS_HIP(hipEventRecord(a, st));
+}
+void IndexBase::end_kernel_timing(hipStream_t st) {
+	if (!timing_enabled)
+		return;
+	MVS_HIP(hipEventRecord(timing_events.back().second, st));
+}
+void IndexBase::resolve_kernel_timing(int *count, double *total_ms) {
+	for (auto &p : timing_events) {
+		MVS_HIP(hipEventSynchronize(p.second));
+		float ms = 0.f;
+		MVS_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+		timing_total_ms += ms;
+		timing_count++;
+		kinfo.last_ms = ms;
+		(void)hipEventDestroy(p.first);
+		(void)hipEventDestroy(p.second);
+	}
+	timing_events.clear();
+	*count = timing_count;
+	*total_ms = timing_total_ms;
+}
+
+// ------------------------------------------------------------------------------------------ selector
+
+SelectorDev SelectorHolder::upload(const mvs_search_params *p, hipStream_t st) {
+	SelectorDev s;
+	memset(&s, 0, sizeof s);
+	if (!p || p->sel_kind == MVS_SEL_NONE)
+		return s;
+	s.kind = p->sel_kind;
+	if (p->sel_kind == MVS_SEL_BITMAP) {
+		// faiss::IDSelectorBitmap(n_bytes, bitmap): src/faiss_extension.cpp:959
+		buf.reserve((size_t)std::max<int64_t>(p->sel_n, 1));
+		if (p->sel_n > 0)
+			MVS_HIP(hipMemcpyAsync(buf.p, p->sel_data, (size_t)p->sel_n, hipMemcpyHostToDevice, st));
+		s.bitmap = (const uint8_t *)buf.p;
+		s.nbytes = p->sel_n;
+	} else if (p->sel_kind == MVS_SEL_BATCH) {
+		// faiss::IDSelectorBatch(n, ids): bloom filter + hash set == set membership; sorted array + bisect here
+		sorted.assign((const int64_t *)p->sel_data, (const int64_t *)p->sel_data + p->sel_n);
+		std::sort(sorted.begin(), sorted.end());
+		buf.reserve(std::max<size_t>(sorted.size() * sizeof(int64_t), 8));
+		if (!sorted.empty())
+			MVS_HIP(hipMemcpyAsync(buf.p, sorted.data(), sorted.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+		s.sorted_ids = (const int64_t *)buf.p;
+		s.nids = (int64_t)sorted.size();
+	} else {
+		throw_faiss("mvs::SelectorHolder::upload", __FILE__, "unknown selector kind %d", p->sel_kind);
+	}
+	return s;
+}
+
+// ------------------------------------------------------------------------------------------ Flat
+
+FlatIndex::FlatIndex(int d_, int metric_) : IndexBase(MVS_KIND_FLAT, d_, metric_) {
+	if (metric != METRIC_L2 && metric != METRIC_IP)
+		throw_faiss("mvs::FlatIndex::FlatIndex", __FILE__,
+		            "metric type %d is not implemented on the MI355X path (INNER_PRODUCT and L2 are)", metric);
+	geom = flat_geom_for(d);
+	is_trained = true;
+}
+FlatIndex::~FlatIndex() {
+	(void)hipSetDevice(device);
+	if (stream)
+		(void)hipStreamSynchronize(stream);
+	if (vecs)
+		(void)hipFree(vecs);
+	if (norms)
+		(void)hipFree(norms);
+}
+
+void FlatIndex::reset() {
+	ntotal = 0;
+}
+
+void FlatIndex::grow(int64_t need, hipStream_t st) {
+	if (need <= cap)
+		return;
+	int64_t nc = cap ? cap : 4096;
+	while (nc < need)
+		nc = nc + nc / 2 + 4096;
+	float *nv = nullptr, *nn = nullptr;
+	MVS_HIP(hipMalloc((void **)&nv, (size_t)nc * geom.dp * sizeof(float)));
+	MVS_HIP(hipMalloc((void **)&nn, (size_t)nc * sizeof(float)));
+	if (geom.dp != d) // padding columns must read as zero
+		MVS_HIP(hipMemsetAsync(nv + (size_t)ntotal * geom.dp, 0, (size_t)(nc - ntotal) * geom.dp * sizeof(float), st));
+	if (ntotal > 0) {
+		MVS_HIP(hipMemcpyAsync(nv, vecs, (size_t)ntotal * geom.dp * sizeof(float), hipMemcpyDeviceToDevice, st));
+		MVS_HIP(hipMemcpyAsync(nn, norms, (size_t)ntotal * sizeof(float), hipMemcpyDeviceToDevice, st));
+	}
+	MVS_HIP(hipStreamSynchronize(st));
+	if (vecs)
+		MVS_HIP(hipFree(vecs));
+	if (norms)
+		MVS_HIP(hipFree(norms));
+	vecs = nv;
+	norms = nn;
+	cap = nc;
+}
+
+// faiss::IndexFlatCodes::add: append n*d floats  (src/faiss_extension.cpp:512,609)
+void FlatIndex::add(int64_t n, const float *x) {
+	use_device();
+	if (n <= 0)
+		return;
+	if (ntotal + n > (int64_t)0x7fffffff - 1024)
+		throw_faiss("mvs::FlatIndex::add", __FILE__, "a single-device shard holds at most 2^31 rows");
+	grow(ntotal + n, stream);
+	// pinned staging in slots of <= SLOT_BYTES; the caller's buffer is free again when we return
+	const int64_t rows_per_slot = std::max<int64_t>(1, (int64_t)PinnedRing::SLOT_BYTES / ((int64_t)d * 4));
+	for (int64_t r0 = 0; r0 < n; r0 += rows_per_slot) {
+		const int64_t nr = std::min(rows_per_slot, n - r0);
+		const size_t bytes = (size_t)nr * d * sizeof(float);
+		const int slot = pinned.acquire(bytes);
+		memcpy(pinned.buf[slot], x + r0 * d, bytes);
+		float *dst = vecs + (size_t)(ntotal + r0) * geom.dp;
+		if (geom.dp == d)
+			MVS_HIP(hipMemcpyAsync(dst, pinned.buf[slot], bytes, hipMemcpyHostToDevice, stream));
+		else
+			MVS_HIP(hipMemcpy2DAsync(dst, (size_t)geom.dp * 4, pinned.buf[slot], (size_t)d * 4, (size_t)d * 4,
+			                         (size_t)nr, hipMemcpyHostToDevice, stream));
+		pinned.release(slot, stream);
+	}
+	launch_row_norms(vecs + (size_t)ntotal * geom.dp, n, geom.dp, norms + ntotal, stream);
+	ntotal += n;
+}
+
+void FlatIndex::add_device(int64_t n, const float *d_x, hipStream_t st) {
+	use_device();
+	if (n <= 0)
+		return;
+	if (!st)
+		st = stream;
+	grow(ntotal + n, st);
+	float *dst = vecs + (size_t)ntotal * geom.dp;
+	if (geom.dp == d)
+		MVS_HIP(hipMemcpyAsync(dst, d_x, (size_t)n * d * sizeof(float), hipMemcpyDeviceToDevice, st));
+	else
+		launch_pad_rows(d_x, n, d, dst, geom.dp, st);
+	launch_row_norms(dst, n, geom.dp, norms + ntotal, st);
+	ntotal += n;
+}
+
+__global__ void fill_results_kernel(float *D, long long *I, long long total, float v) {
+	long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < total) {
+		D[i] = v;
+		I[i] = -1;
+	}
+}
+
+// IndexFlat::search dispatch (faiss/IndexFlat.cpp, utils/distances.cpp):
+//   sel || nq < 20 -> per-pair arithmetic (flat_direct.hip); else BLAS-branch arithmetic (flat_mfma.hip)
+void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+                            const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
+	use_device();
+	if (k <= 0)
+		throw_faiss("virtual void faiss::IndexFlat::search(...) const", "faiss/IndexFlat.cpp", "Error: 'k > 0' failed");
+	if (nq <= 0)
+		return;
+	if (!st)
+		st = stream;
+	if (ntotal == 0) {
+		const long long total = (long long)nq * k;
+		hipLaunchKernelGGL(fill_results_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_D,
+		                   (long long *)d_I, total, metric == METRIC_L2 ? FLT_MAX : -FLT_MAX);
+		return;
+	}
+	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
+	const int64_t mfma_kmax = flat_mfma_max_k(geom);
+	const bool direct = has_sel || nq < 20 || k > mfma_kmax || force_direct;
+	FlatDB db {vecs, norms, ntotal};
+	memset(&kinfo, 0, sizeof kinfo);
+	if (direct) {
+		if (k > flat_direct_max_k())
+			throw_faiss("mvs::FlatIndex::search", __FILE__, "k = %lld exceeds the supported maximum %lld",
+			            (long long)k, (long long)flat_direct_max_k());
+		// BLAS-branch value when FAISS would have used sgemm (nq >= 20, no selector) but k is too large for
+		// the fused kernel's LDS lists
+		const bool formula = metric == METRIC_L2 && !has_sel && nq >= 20;
+		DirectPlan p = plan_flat_direct(geom, nq, ntotal, k);
+		const int64_t nq_pad = (nq + p.qgroup - 1) / p.qgroup * p.qgroup;
+		ws_q.reserve((size_t)nq_pad * geom.dp * sizeof(float));
+		MVS_HIP(hipMemsetAsync(ws_q.p, 0, (size_t)nq_pad * geom.dp * sizeof(float), st));
+		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, geom.dp, st);
+		float *qn = nullptr;
+		if (formula) {
+			ws_qn.reserve((size_t)nq * sizeof(float));
+			qn = (float *)ws_qn.p;
+			launch_row_norms((const float *)ws_q.p, nq, geom.dp, qn, st);
+		}
+		const int nparts = p.nsplit * 4;
+		ws_pd.reserve((size_t)nparts * nq * k * sizeof(float));
+		ws_pi.reserve((size_t)nparts * nq * k * sizeof(int32_t));
+		SelectorDev sel = selector.upload(params, st);
+		begin_kernel_timing(st);
+		launch_flat_direct_ex(geom, p, metric, formula, (const float *)ws_q.p, qn, nq, db, k, sel, d_idmap,
+		                      (float *)ws_pd.p, (int32_t *)ws_pi.p, st);
+		end_kernel_timing(st);
+		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, nparts, nq, k, d_idmap,
+		                      label_offset, d_D, d_I, st);
+		snprintf(kinfo.name, sizeof kinfo.name, "flat_direct_kernel");
+		const int64_t ngroups = (nq + p.qgroup - 1) / p.qgroup;
+		kinfo.flops = 2.0 * (double)nq * (double)ntotal * d * (metric == METRIC_L2 && !formula ? 1.5 : 1.0);
+		kinfo.bytes = (double)ngroups * (double)ntotal * geom.dp * 4.0;
+		kinfo.grid = p.grid;
+		kinfo.block = 256;
+		kinfo.lds_bytes = (int)p.lds_bytes;
+		kinfo.nsplit = p.nsplit;
+	} else {
+		FlatSearchPlan p = plan_flat_mfma(geom, nq, ntotal, k);
+		ws_q.reserve(qfrag_floats(geom, nq) * sizeof(float));
+		ws_qn.reserve((size_t)nq * sizeof(float));
+		launch_pack_queries(geom, d_x, nq, (float *)ws_q.p, (float *)ws_qn.p, st);
+		ws_pd.reserve((size_t)p.nsplit * nq * k * sizeof(float));
+		ws_pi.reserve((size_t)p.nsplit * nq * k * sizeof(int32_t));
+		begin_kernel_timing(st);
+		launch_flat_mfma(geom, p, metric, (const float *)ws_q.p, (const float *)ws_qn.p, nq, db, k, (float *)ws_pd.p,
+		                 (int32_t *)ws_pi.p, st);
+		end_kernel_timing(st);
+		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, k, d_idmap,
+		                      label_offset, d_D, d_I, st);
+		snprintf(kinfo.name, sizeof kinfo.name, "flat_mfma_kernel");
+		kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
+		kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * k * 12.0;
+		kinfo.grid = p.grid;
+		kinfo.block = 256;
+		kinfo.lds_bytes = (int)p.lds_bytes;
+		kinfo.nsplit = p.nsplit;
+	}
+}
+
+void FlatIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+                              const mvs_search_params *params, hipStream_t st) {
+	search_flat(nq, d_x, k, d_D, d_I, params, nullptr, st);
+}
+
+void FlatIndex::to_device(int new_device) {
+	if (new_device == device)
+		return;
+	int ndev = 0;
+	MVS_HIP(hipGetDeviceCount(&ndev));
+	if (new_device < 0 || new_device >= ndev)
+		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "Invalid GPU device %d", new_device);
+	use_device();
+	MVS_HIP(hipStreamSynchronize(stream));
+	float *nv = nullptr, *nn = nullptr;
+	MVS_HIP(hipSetDevice(new_device));
+	if (cap > 0) {
+		MVS_HIP(hipMalloc((void **)&nv, (size_t)cap * geom.dp * sizeof(float)));
+		MVS_HIP(hipMalloc((void **)&nn, (size_t)cap * sizeof(float)));
+		MVS_HIP(hipMemset(nv, 0, (size_t)cap * geom.dp * sizeof(float)));
+		if (ntotal > 0) {
+			MVS_HIP(hipMemcpyPeer(nv, new_device, vecs, device, (size_t)ntotal * geom.dp * sizeof(float)));
+			MVS_HIP(hipMemcpyPeer(nn, new_device, norms, device, (size_t)ntotal * sizeof(float)));
+		}
+	}
+	hipStream_t ns;
+	MVS_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+	MVS_HIP(hipSetDevice(device));
+	if (vecs)
+		MVS_HIP(hipFree(vecs));
+	if (norms)
+		MVS_HIP(hipFree(norms));
+	ws_q.release();
+	ws_qn.release();
+	ws_pd.release();
+	ws_pi.release();
+	ws_hx.release();
+	ws_hD.release();
+	ws_hI.release();
+	selector.buf.release();
+	MVS_HIP(hipStreamDestroy(stream));
+	vecs = nv;
+	norms = nn;
+	stream = ns;
+	device = new_device;
+	MVS_HIP(hipSetDevice(device));
+}
+
+// ------------------------------------------------------------------------------------------ IDMap
+
+IDMapIndex::IDMapIndex(IndexBase *sub_) : IndexBase(MVS_KIND_IDMAP, sub_->d, sub_->metric), sub(sub_) {
+	is_trained = sub->is_trained;
+}
+IDMapIndex::~IDMapIndex() {
+	(void)hipSetDevice(device);
+	if (ids)
+		(void)hipFree(ids);
+}
+void IDMapIndex::train(int64_t n, const float *x) {
+	sub->train(n, x);
+	is_trained = sub->is_trained;
+}
+void IDMapIndex::add(int64_t, const float *) {
+	throw_faiss("virtual void faiss::IndexIDMapTemplate<IndexT>::add(faiss::idx_t, const float*)",
+	            "faiss/IndexIDMap.cpp", "add does not make sense with IndexIDMap, use add_with_ids");
+}
+void IDMapIndex::add_device(int64_t, const float *, hipStream_t) {
+	throw_faiss("virtual void faiss::IndexIDMapTemplate<IndexT>::add(faiss::idx_t, const float*)",
+	            "faiss/IndexIDMap.cpp", "add does not make sense with IndexIDMap, use add_with_ids");
+}
+void IDMapIndex::grow_ids(int64_t need, hipStream_t st) {
+	if (need <= idcap)
+		return;
+	int64_t nc = idcap ? idcap : 4096;
+	while (nc < need)
+		nc = nc + nc / 2 + 4096;
+	int64_t *ni = nullptr;
+	MVS_HIP(hipMalloc((void **)&ni, (size_t)nc * sizeof(int64_t)));
+	if (ntotal > 0)
+		MVS_HIP(hipMemcpyAsync(ni, ids, (size_t)ntotal * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+	MVS_HIP(hipStreamSynchronize(st));
+	if (ids)
+		MVS_HIP(hipFree(ids));
+	ids = ni;
+	idcap = nc;
+}
+// IndexIDMap::add_with_ids: index->add(n, x); id_map.push_back(ids...)  (src/faiss_extension.cpp:510,607)
+void IDMapIndex::add_with_ids(int64_t n, const float *x, const int64_t *xids) {
+	use_device();
+	if (n <= 0)
+		return;
+	sub->add(n, x);
+	grow_ids(ntotal + n, stream);
+	const size_t bytes = (size_t)n * sizeof(int64_t);
+	const int slot = pinned.acquire(bytes);
+	memcpy(pinned.buf[slot], xids, bytes);
+	MVS_HIP(hipMemcpyAsync(ids + ntotal, pinned.buf[slot], bytes, hipMemcpyHostToDevice, stream));
+	pinned.release(slot, stream);
+	ntotal = sub->ntotal;
+}
+void IDMapIndex::add_with_ids_device(int64_t n, const float *d_x, const int64_t *d_ids, hipStream_t st) {
+	use_device();
+	if (n <= 0)
+		return;
+	if (!st)
+		st = stream;
+	sub->add_device(n, d_x, st);
+	grow_ids(ntotal + n, st);
+	MVS_HIP(hipMemcpyAsync(ids + ntotal, d_ids, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+	ntotal = sub->ntotal;
+}
+// IndexIDMap::search: selector tests EXTERNAL ids (IDSelectorTranslated), labels = id_map[internal]
+void IDMapIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+                               const mvs_search_params *params, hipStream_t st) {
+	use_device();
+	if (!st)
+		st = stream;
+	// writes of ids happened on our own stream; the sub-index searches on `st`
+	if (st != stream) {
+		hipEvent_t e;
+		MVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		MVS_HIP(hipEventRecord(e, stream));
+		MVS_HIP(hipStreamWaitEvent(st, e, 0));
+		MVS_HIP(hipEventDestroy(e));
+	}
+	sub->search_mapped(nq, d_x, k, d_D, d_I, params, ids, st);
+	kinfo = sub->kinfo;
+}
+void IDMapIndex::search(int64_t nq, const float *x, int64_t k, float *D, int64_t *I, const mvs_search_params *params) {
+	// the sub-index's stream carries its adds: search there
+	use_device();
+	MVS_HIP(hipStreamSynchronize(stream));
+	IndexBase::search(nq, x, k, D, I, params);
+}
+void IDMapIndex::to_device(int new_device) {
+	if (new_device == device)
+		return;
+	sub->to_device(new_device);
+	use_device();
+	MVS_HIP(hipStreamSynchronize(stream));
+	int64_t *ni = nullptr;
+	if (idcap > 0) {
+		MVS_HIP(hipSetDevice(new_device));
+		MVS_HIP(hipMalloc((void **)&ni, (size_t)idcap * sizeof(int64_t)));
+		if (ntotal > 0)
+			MVS_HIP(hipMemcpyPeer(ni, new_device, ids, device, (size_t)ntotal * sizeof(int64_t)));
+		MVS_HIP(hipSetDevice(device));
+		MVS_HIP(hipFree(ids));
+	}
+	ws_hx.release();
+	ws_hD.release();
+	ws_hI.release();
+	MVS_HIP(hipStreamDestroy(stream));
+	MVS_HIP(hipSetDevice(new_device));
+	MVS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	ids = ni;
+	device = new_device;
+}
+
+void FlatIndex::search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+                              const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
+	// adds were enqueued on our own stream
+	if (st && st != stream) {
+		hipEvent_t e;
+		MVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		MVS_HIP(hipEventRecord(e, stream));
+		MVS_HIP(hipStreamWaitEvent(st, e, 0));
+		MVS_HIP(hipEventDestroy(e));
+	}
+	search_flat(nq, d_x, k, d_D, d_I, params, d_idmap, st);
+}
+
+// ------------------------------------------------------------------------------------------ factory
+
+// faiss::index_factory subset (faiss/index_factory.cpp) -- the strings the reference and its tests use:
+// "Flat" (faiss.test:8), "IDMap,Flat" (faiss2.test:8), "IDMap,IVF1,Flat", "IVF<n>,Flat", "HNSW<M>"
+static IndexBase *factory_rec(int d, const std::string &desc, int metric, const std::string &full) {
+	if (desc.rfind("IDMap2,", 0) == 0 || desc.rfind("IDMap,", 0) == 0) {
+		IndexBase *sub = factory_rec(d, desc.substr(desc.find(',') + 1), metric, full);
+		try {
+			return new IDMapIndex(sub);
+		} catch (...) {
+			delete sub;
+			throw;
+		}
+	}
+	if (desc == "Flat")
+		return new FlatIndex(d, metric);
+	if (IndexBase *ix = make_ivf_index(d, desc, metric))
+		return ix;
+	if (IndexBase *ix = make_hnsw_index(d, desc, metric))
+		return ix;
+	throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
+	            "could not parse index string %s", full.c_str());
+}
+
+IndexBase *index_factory(int d, const char *description, int metric) {
+	if (d <= 0)
+		throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)",
+		            "faiss/index_factory.cpp", "invalid dimension %d", d);
+	return factory_rec(d, description, metric, description);
+}
+
+} // namespace mvs
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace mvs;
+
+struct mvs_index {
+	IndexBase *impl;
+	bool owned;
+	mvs_index *sub_handle = nullptr;
+	mvs_index *quantizer_handle = nullptr;
+	std::mutex mu; // the reference's faiss_lock serialises calls per index; be safe for other hosts
+};
+
+#define MVS_API_BEGIN                                                                                                  \
+	try {
+#define MVS_API_END                                                                                                    \
+	}                                                                                                                  \
+	catch (const std::exception &e) {                                                                                  \
+		g_last_error = e.what();                                                                                       \
+		return 1;                                                                                                      \
+	}                                                                                                                  \
+	catch (...) {                                                                                                      \
+		g_last_error = "unknown error";                                                                                \
+		return 1;                                                                                                      \
+	}                                                                                                                  \
+	return 0;
+
+extern "C" {
+
+const char *mvs_last_error(void) {
+	return g_last_error.c_str();
+}
+const char *mvs_version(void) {
+	return "mi355-faiss 0.1 (drop-in for duckdb-faiss-ext 0.12.1 hot path)";
+}
+int mvs_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int mvs_index_factory(mvs_index **out, int d, const char *description, int metric) {
+	MVS_API_BEGIN
+	*out = nullptr;
+	IndexBase *impl = index_factory(d, description, metric);
+	auto *h = new mvs_index;
+	h->impl = impl;
+	h->owned = true;
+	*out = h;
+	MVS_API_END
+}
+void mvs_index_free(mvs_index *ix) {
+	if (!ix)
+		return;
+	delete ix->sub_handle;
+	delete ix->quantizer_handle;
+	if (ix->owned) {
+		try {
+			delete ix->impl;
+		} catch (...) {
+		}
+	}
+	delete ix;
+}
+int mvs_index_d(const mvs_index *ix) {
+	return ix->impl->d;
+}
+int64_t mvs_index_ntotal(const mvs_index *ix) {
+	return ix->impl->ntotal;
+}
+int mvs_index_is_trained(const mvs_index *ix) {
+	return ix->impl->is_trained ? 1 : 0;
+}
+int mvs_index_metric_type(const mvs_index *ix) {
+	return ix->impl->metric;
+}
+int mvs_index_kind(const mvs_index *ix) {
+	return ix->impl->kind;
+}
+int mvs_index_device(const mvs_index *ix) {
+	return ix->impl->device;
+}
+mvs_index *mvs_index_idmap_sub(mvs_index *ix) {
+	if (ix->impl->kind != MVS_KIND_IDMAP)
+		return nullptr;
+	if (!ix->sub_handle) {
+		ix->sub_handle = new mvs_index;
+		ix->sub_handle->impl = static_cast<IDMapIndex *>(ix->impl)->sub;
+		ix->sub_handle->owned = false;
+	}
+	return ix->sub_handle;
+}
+mvs_index *mvs_index_ivf_quantizer(mvs_index *ix) {
+	IndexBase *q = ivf_quantizer_of(ix->impl);
+	if (!q)
+		return nullptr;
+	if (!ix->quantizer_handle) {
+		ix->quantizer_handle = new mvs_index;
+		ix->quantizer_handle->impl = q;
+		ix->quantizer_handle->owned = false;
+	}
+	return ix->quantizer_handle;
+}
+int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v) {
+	MVS_API_BEGIN
+	if (!hnsw_set_ef_construction(ix->impl, v))
+		throw_faiss("mvs_index_hnsw_set_ef_construction", __FILE__, "not an HNSW index");
+	MVS_API_END
+}
+
+int mvs_index_train(mvs_index *ix, int64_t n, const float *x) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	ix->impl->train(n, x);
+	MVS_API_END
+}
+int mvs_index_add(mvs_index *ix, int64_t n, const float *x) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	ix->impl->add(n, x);
+	MVS_API_END
+}
+int mvs_index_add_with_ids(mvs_index *ix, int64_t n, const float *x, const int64_t *ids) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	ix->impl->add_with_ids(n, x, ids);
+	MVS_API_END
+}
+int mvs_index_search(mvs_index *ix, int64_t n, const float *x, int64_t k, float *distances, int64_t *labels,
+                     const mvs_search_params *params) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	ix->impl->search(n, x, k, distances, labels, params);
+	MVS_API_END
+}
+int mvs_index_to_gpu(mvs_index *ix, int device) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	ix->impl->to_device(device);
+	MVS_API_END
+}
+int mvs_index_add_device(mvs_index *ix, int64_t n, const float *d_x, const int64_t *d_ids, void *stream) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	if (d_ids)
+		ix->impl->add_with_ids_device(n, d_x, d_ids, (hipStream_t)stream);
+	else
+		ix->impl->add_device(n, d_x, (hipStream_t)stream);
+	MVS_API_END
+}
+int mvs_index_search_device(mvs_index *ix, int64_t n, const float *d_x, int64_t k, float *d_distances,
+                            int64_t *d_labels, const mvs_search_params *params, void *stream) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	if (k <= 0)
+		throw_faiss("virtual void faiss::Index::search(...) const", "faiss/Index.cpp", "Error: 'k > 0' failed");
+	ix->impl->search_device(n, d_x, k, d_distances, d_labels, params, (hipStream_t)stream);
+	MVS_API_END
+}
+int mvs_index_set_label_offset(mvs_index *ix, int64_t offset) {
+	MVS_API_BEGIN
+	ix->impl->set_label_offset(offset);
+	MVS_API_END
+}
+
+int mvs_write_index(const mvs_index *ix, const char *filename) {
+	MVS_API_BEGIN
+	write_index_file(ix->impl, filename);
+	MVS_API_END
+}
+int mvs_read_index(mvs_index **out, const char *filename) {
+	MVS_API_BEGIN
+	*out = nullptr;
+	IndexBase *impl = read_index_file(filename);
+	auto *h = new mvs_index;
+	h->impl = impl;
+	h->owned = true;
+	*out = h;
+	MVS_API_END
+}
+
+int mvs_merge_shards(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
+                     int64_t *I_out) {
+	MVS_API_BEGIN
+	merge_shards_host(metric, n, k, nshard, D, I, D_out, I_out);
+	MVS_API_END
+}
+
+int mvs_synth_uniform_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, void *stream) {
+	MVS_API_BEGIN
+	launch_synth_uniform(d_out, n_rows, d, seed, row0, (hipStream_t)stream);
+	MVS_API_END
+}
+int mvs_synth_clustered_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers,
+                               float sigma, void *stream) {
+	MVS_API_BEGIN
+	launch_synth_clustered(d_out, n_rows, d, seed, row0, n_centers, sigma, (hipStream_t)stream);
+	MVS_API_END
+}
+
+int mvs_index_last_kernel_info(const mvs_index *ix, mvs_kernel_info *out) {
+	MVS_API_BEGIN
+	*out = ix->impl->kinfo;
+	MVS_API_END
+}
+int mvs_index_set_kernel_timing(mvs_index *ix, int enabled) {
+	MVS_API_BEGIN
+	ix->impl->set_timing(enabled != 0);
+	MVS_API_END
+}
+int mvs_index_kernel_time_stats(mvs_index *ix, int *count, double *total_ms) {
+	MVS_API_BEGIN
+	ix->impl->resolve_timing(count, total_ms);
+	MVS_API_END
+}
+int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value) {
+	MVS_API_BEGIN
+	if (!ix->impl->set_option(key, value))
+		throw_faiss("mvs_index_set_option", __FILE__, "unknown option %s", key);
+	MVS_API_END
+}
+
+} // extern "C"
+
+namespace mvs {
+bool FlatIndex::set_option(const char *key, int64_t v) {
+	if (!strcmp(key, "force_direct")) {
+		force_direct = v != 0;
+		return true;
+	}
+	return false;
+}
+} // namespace mvs

@@ -1,0 +1,268 @@
+// csrc/util_kernels.hip -- K1 (row norms), query fragment packing, K4 (partial-list merge), synthetic data.
+#include "common.h"
+
+namespace mvs {
+
+// ---- K1: squared norms, k-ordered fma chain (bit-exact with oracle orc_norms) ------------------------
+// One thread per row.  Used at add time (database) -- FAISS recomputes y norms per search
+// (utils/distances.cpp exhaustive_L2sqr_blas); storing them next to the shard is the MI355X design.
+__global__ void row_norms_kernel(const float *__restrict__ v, long long n, int dp, float *__restrict__ out) {
+	long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n)
+		return;
+	const float4 *p = (const float4 *)(v + (size_t)r * dp);
+	float acc = 0.f;
+	for (int i = 0; i < dp / 4; ++i) {
+		float4 x = p[i];
+		acc = fmaf(x.x, x.x, acc);
+		acc = fmaf(x.y, x.y, acc);
+		acc = fmaf(x.z, x.z, acc);
+		acc = fmaf(x.w, x.w, acc);
+	}
+	out[r] = acc;
+}
+void launch_row_norms(const float *d_vecs, int64_t n, int dp, float *d_norms, hipStream_t st) {
+	if (n <= 0)
+		return;
+	hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_vecs, (long long)n, dp,
+	                   d_norms);
+	MVS_HIP(hipGetLastError());
+}
+
+// row-major [n][d] -> row-major [n][dp] with zero padding
+__global__ void pad_rows_kernel(const float *__restrict__ src, long long n, int d, float *__restrict__ dst, int dp) {
+	long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	long long total = n * dp;
+	if (i >= total)
+		return;
+	long long r = i / dp;
+	int c = (int)(i - r * dp);
+	dst[i] = c < d ? src[r * d + c] : 0.f;
+}
+void launch_pad_rows(const float *d_src, int64_t n, int d, float *d_dst, int dp, hipStream_t st) {
+	if (n <= 0)
+		return;
+	long long total = (long long)n * dp;
+	hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_src, (long long)n, d,
+	                   d_dst, dp);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- query packing: [nq][d] -> MFMA B-fragment order + norms -----------------------------------------
+// qf[(((qblk32*nch + ch)*(KSTEPS/4) + s4)*64 + lane)*4 + e] = x[qblk32*32 + (lane&31)][ch*kc + 2*(4*s4+e) + (lane>>5)]
+__global__ void pack_queries_kernel(const float *__restrict__ x, long long nq, int d, int kc, int nch,
+                                    float *__restrict__ qf, long long total4) {
+	long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one float4 each
+	if (i >= total4)
+		return;
+	const int ks4 = kc / 8; // KSTEPS/4
+	int lane = (int)(i & 63);
+	long long t = i >> 6;
+	int s4 = (int)(t % ks4);
+	t /= ks4;
+	int ch = (int)(t % nch);
+	long long qblk32 = t / nch;
+	long long q = qblk32 * 32 + (lane & 31);
+	float o[4];
+#pragma unroll
+	for (int e = 0; e < 4; ++e) {
+		int kk = ch * kc + 2 * (4 * s4 + e) + (lane >> 5);
+		o[e] = (q < nq && kk < d) ? x[q * d + kk] : 0.f;
+	}
+	((float4 *)qf)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+__global__ void query_norms_kernel(const float *__restrict__ x, long long nq, int d, float *__restrict__ out) {
+	long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nq)
+		return;
+	const float *p = x + q * d;
+	float acc = 0.f;
+	for (int i = 0; i < d; ++i)
+		acc = fmaf(p[i], p[i], acc);
+	out[q] = acc;
+}
+void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float *d_qf, float *d_qnorm,
+                         hipStream_t st) {
+	if (nq <= 0)
+		return;
+	long long total4 = (long long)(qfrag_floats(g, nq) / 4);
+	hipLaunchKernelGGL(pack_queries_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, d_x,
+	                   (long long)nq, g.d, g.kc, g.nch, d_qf, total4);
+	if (d_qnorm)
+		hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_x,
+		                   (long long)nq, g.d, d_qnorm);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- K4: merge nsplit partial lists per query into the final k, FAISS order -------------------------
+// One wave per query.  Candidates (value, row id) sit in LDS; k rounds of "wave-wide lexicographic best".
+//   L2: ascending (dist, id)            [Heap.h heap_reorder over a CMax heap]
+//   IP: descending score; membership prefers the smaller id, equal scores are PRINTED in descending id
+//       order (heap_reorder over a CMin heap pops the smallest id of equal values to the back)
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void merge_partials_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi,
+                                                           int nsplit, long long nq, int k,
+                                                           const long long *__restrict__ idmap, long long label_offset,
+                                                           float *__restrict__ D, long long *__restrict__ I) {
+	extern __shared__ __attribute__((aligned(16))) float sm[];
+	const long long q = blockIdx.x;
+	const int lane = threadIdx.x;
+	const int C = nsplit * k;
+	float *cv = sm;
+	int *ci = (int *)(sm + C);
+	float *ov = (float *)(ci + C);
+	int *oi = (int *)(ov + k);
+	for (int i = lane; i < C; i += 64) {
+		int s = i / k, j = i - s * k;
+		cv[i] = pd[((size_t)s * nq + q) * k + j];
+		ci[i] = pi[((size_t)s * nq + q) * k + j];
+	}
+	__syncthreads();
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+	for (int r = 0; r < k; ++r) {
+		// lane-local best over its strided subset
+		float bv = neutral;
+		int bi = 0x7fffffff, bp = -1;
+		for (int i = lane; i < C; i += 64) {
+			float v = cv[i];
+			int id = ci[i];
+			if (id < 0)
+				continue;
+			bool better = IS_L2 ? (v < bv || (v == bv && id < bi)) : (v > bv || (v == bv && id < bi));
+			if (bp < 0 || better) {
+				bv = v;
+				bi = id;
+				bp = i;
+			}
+		}
+		// wave reduction
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			float ov_ = __shfl_xor(bv, off);
+			int oi_ = __shfl_xor(bi, off);
+			int op_ = __shfl_xor(bp, off);
+			bool take;
+			if (op_ < 0)
+				take = false;
+			else if (bp < 0)
+				take = true;
+			else
+				take = IS_L2 ? (ov_ < bv || (ov_ == bv && oi_ < bi)) : (ov_ > bv || (ov_ == bv && oi_ < bi));
+			if (take) {
+				bv = ov_;
+				bi = oi_;
+				bp = op_;
+			}
+		}
+		if (lane == 0) {
+			if (bp >= 0) {
+				ov[r] = bv;
+				oi[r] = bi;
+				ci[bp] = -1; // consumed
+			} else {
+				ov[r] = neutral;
+				oi[r] = -1;
+			}
+		}
+		__syncthreads();
+	}
+	for (int j = lane; j < k; j += 64) {
+		int src = j;
+		if (!IS_L2 && oi[j] >= 0) {
+			// reverse each run of equal scores (print order: larger id first)
+			int a = j, b = j;
+			while (a > 0 && oi[a - 1] >= 0 && ov[a - 1] == ov[j])
+				--a;
+			while (b + 1 < k && oi[b + 1] >= 0 && ov[b + 1] == ov[j])
+				++b;
+			src = a + (b - j);
+		}
+		int id = oi[src];
+		long long label = id < 0 ? -1ll : (idmap ? idmap[id] : (long long)id + label_offset);
+		D[q * k + j] = ov[src];
+		I[q * k + j] = label;
+	}
+}
+
+void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, int nsplit, int64_t nq, int64_t k,
+                           const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	size_t lds = ((size_t)nsplit * k + k) * 8;
+	if (lds > 160 * 1024)
+		throw_faiss(__func__, __FILE__, "merge: nsplit*k = %lld too large", (long long)nsplit * k);
+	if (metric == METRIC_L2) {
+		auto kern = merge_partials_kernel<true>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, nsplit, (long long)nq, (int)k,
+		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I);
+	} else {
+		auto kern = merge_partials_kernel<false>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, nsplit, (long long)nq, (int)k,
+		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- synthetic data: same integer arithmetic as oracle/orc_core.c orc_synth_* -------------------------
+__device__ __forceinline__ unsigned long long splitmix(unsigned long long z) {
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long ctr) {
+	unsigned long long z = splitmix(seed + (ctr + 1) * 0x9E3779B97F4A7C15ull);
+	return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ void synth_uniform_kernel(float *out, long long total, unsigned long long seed, long long ctr0) {
+	long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	long long stride = (long long)gridDim.x * blockDim.x;
+	for (; i < total; i += stride)
+		out[i] = u01(seed, (unsigned long long)(ctr0 + i));
+}
+void launch_synth_uniform(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, hipStream_t st) {
+	long long total = (long long)n_rows * d;
+	if (total <= 0)
+		return;
+	long long blocks = (total + 255) / 256;
+	if (blocks > 256 * 32)
+		blocks = 256 * 32;
+	hipLaunchKernelGGL(synth_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_out, total,
+	                   (unsigned long long)seed, (long long)row0 * d);
+	MVS_HIP(hipGetLastError());
+}
+__device__ __forceinline__ float ih4(unsigned long long seed, unsigned long long ctr) {
+	float a = u01(seed, 4 * ctr), b = u01(seed, 4 * ctr + 1), c = u01(seed, 4 * ctr + 2), e = u01(seed, 4 * ctr + 3);
+	return __fmul_rn(__fsub_rn(__fadd_rn(__fadd_rn(a, b), __fadd_rn(c, e)), 2.0f), 1.7320508f);
+}
+__global__ void synth_clustered_kernel(float *out, long long n_rows, int d, unsigned long long seed, long long row0,
+                                       int n_centers, float sigma) {
+	long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	long long stride = (long long)gridDim.x * blockDim.x;
+	long long total = n_rows * d;
+	for (; i < total; i += stride) {
+		long long r = i / d;
+		int col = (int)(i - r * d);
+		unsigned long long row = (unsigned long long)(row0 + r);
+		unsigned long long c =
+		    splitmix(seed ^ (row * 0xD1B54A32D192ED03ull + 0x5851F42D4C957F2Dull)) % (unsigned long long)n_centers;
+		float centre = ih4(0xC0FFEEull, c * (unsigned long long)d + (unsigned long long)col);
+		float g = ih4(seed, row * (unsigned long long)d + (unsigned long long)col);
+		out[i] = fmaf(sigma, g, centre);
+	}
+}
+void launch_synth_clustered(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers,
+                            float sigma, hipStream_t st) {
+	long long total = (long long)n_rows * d;
+	if (total <= 0)
+		return;
+	long long blocks = (total + 255) / 256;
+	if (blocks > 256 * 32)
+		blocks = 256 * 32;
+	hipLaunchKernelGGL(synth_clustered_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_out, (long long)n_rows, d,
+	                   (unsigned long long)seed, (long long)row0, n_centers, sigma);
+	MVS_HIP(hipGetLastError());
+}
+
+} // namespace mvs

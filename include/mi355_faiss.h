@@ -1,0 +1,149 @@
+/*
+ * include/mi355_faiss.h -- C ABI of libmi355faiss.so, the MI355X-native replacement for the FAISS
+ * calls the reference DuckDB extension makes on its vector-search hot path.
+ *
+ * Every entry point replaces ONE FAISS C++ symbol that /root/reference/src/faiss_extension.cpp (or
+ * src/gpu/gpu.cpp) reaches; the citation after each declaration is that call site.  Plain pointers
+ * and sizes only: the faiss::-namespaced C++ adaptor (duckdb-faiss-ext_amd/compat/faiss/...) and the
+ * Python ctypes host (duckdb-faiss-ext_amd/pyhost/mi355_faiss.py) are both thin layers over this file,
+ * and INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - return 0 on success; nonzero = failure, text in mvs_last_error() (thread-local).  The text
+ *     carries FAISS's exception message because the reference pattern-matches substrings of it:
+ *       "should be at least as large as number of clusters"      src/faiss_extension.cpp:400,592
+ *       "add_with_ids not implemented for this type of index"    src/faiss_extension.cpp:523
+ *       "This index type is not implemented"                     src/gpu/gpu.cpp:52
+ *       "Invalid GPU device"                                     src/gpu/gpu.cpp:56
+ *   - x / ids / D / I are HOST pointers owned by the caller and valid only for the duration of the
+ *     call (DuckDB vector buffers, new[] arrays: src/faiss_extension.cpp:626-627); the library
+ *     copies through pinned staging.  The *_device variants take device pointers instead.
+ *   - an index may be called from a different OS thread each time (DuckDB workers); calls on one
+ *     index are serialised internally as the reference's faiss_lock does (:394,:506,:581,:629).
+ *   - the product path has NO CPU fallback: every call fails loudly if no gfx950 device is usable.
+ */
+#ifndef MI355_FAISS_H
+#define MI355_FAISS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* faiss::MetricType enumerators the glue exposes (src/faiss_extension.cpp:58-68) */
+#define MVS_METRIC_INNER_PRODUCT 0
+#define MVS_METRIC_L2 1
+#define MVS_METRIC_L1 2
+#define MVS_METRIC_Linf 3
+#define MVS_METRIC_Lp 4
+#define MVS_METRIC_Canberra 20
+#define MVS_METRIC_BrayCurtis 21
+#define MVS_METRIC_JensenShannon 22
+#define MVS_METRIC_Jaccard 23
+
+/* dynamic_cast targets of the glue (src/faiss_extension.cpp:127,133,671,675,691,704; gpu.cpp:69) */
+#define MVS_KIND_FLAT 1    /* faiss::IndexFlat / IndexFlatL2 / IndexFlatIP */
+#define MVS_KIND_IDMAP 2   /* faiss::IndexIDMap                            */
+#define MVS_KIND_IVFFLAT 3 /* faiss::IndexIVFFlat (an IndexIVF)            */
+#define MVS_KIND_HNSW 4    /* faiss::IndexHNSWFlat (an IndexHNSW)          */
+
+#define MVS_SEL_NONE 0
+#define MVS_SEL_BITMAP 1 /* faiss::IDSelectorBitmap(n_bytes, bitmap)  src/faiss_extension.cpp:959  */
+#define MVS_SEL_BATCH 2  /* faiss::IDSelectorBatch(n, ids)            src/faiss_extension.cpp:1008 */
+
+typedef struct mvs_index mvs_index;
+
+/* faiss::SearchParameters / SearchParametersIVF / SearchParametersHNSW as built by
+ * innerCreateSearchParameters (src/faiss_extension.cpp:668-721).  Zero = FAISS default. */
+typedef struct mvs_search_params {
+	int64_t nprobe;       /* SearchParametersIVF::nprobe   (:683-686), default 1  */
+	int64_t efSearch;     /* SearchParametersHNSW::efSearch (:696-699), default 16 */
+	int32_t sel_kind;     /* MVS_SEL_*; SearchParameters::sel (:678,:694,:719)     */
+	int32_t reserved;
+	const void *sel_data; /* bitmap bytes | int64 ids; HOST memory owned by the caller */
+	int64_t sel_n;        /* bitmap: bytes; batch: number of ids */
+} mvs_search_params;
+
+/* faiss::FaissException::msg / what()  -- src/faiss_extension.cpp:397,514,584,632 */
+const char *mvs_last_error(void);
+
+/* faiss::index_factory(d, description, metric)  -- src/faiss_extension.cpp:154-155.
+ * The index is created device-native on the device named by env MVS_DEVICE (default 0). */
+int mvs_index_factory(mvs_index **out, int d, const char *description, int metric);
+/* ~Index (unique_ptr<faiss::Index> dropped by ObjectCache)  -- src/faiss_extension.cpp:264 */
+void mvs_index_free(mvs_index *ix);
+
+/* Index::d / ntotal / is_trained / metric_type  -- src/faiss_extension.cpp:159,355,490,518 */
+int mvs_index_d(const mvs_index *ix);
+int64_t mvs_index_ntotal(const mvs_index *ix);
+int mvs_index_is_trained(const mvs_index *ix);
+int mvs_index_metric_type(const mvs_index *ix);
+/* the glue's dynamic_cast to IndexIDMap / IndexIVF / IndexHNSW -- returns MVS_KIND_* */
+int mvs_index_kind(const mvs_index *ix);
+/* IndexIDMap::index (:129,:673) ; IndexIVF::quantizer (:680).  Borrowed pointers, NULL if n/a. */
+mvs_index *mvs_index_idmap_sub(mvs_index *ix);
+mvs_index *mvs_index_ivf_quantizer(mvs_index *ix);
+/* IndexHNSW::hnsw.efConstruction = v  -- src/faiss_extension.cpp:136-139 */
+int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v);
+
+/* Index::train(n, x)  -- src/faiss_extension.cpp:396,583 */
+int mvs_index_train(mvs_index *ix, int64_t n, const float *x);
+/* Index::add(n, x)  -- src/faiss_extension.cpp:512,609 */
+int mvs_index_add(mvs_index *ix, int64_t n, const float *x);
+/* Index::add_with_ids(n, x, ids)  -- src/faiss_extension.cpp:510,607 */
+int mvs_index_add_with_ids(mvs_index *ix, int64_t n, const float *x, const int64_t *ids);
+/* Index::search(n, x, k, distances, labels, params)  -- src/faiss_extension.cpp:631 */
+int mvs_index_search(mvs_index *ix, int64_t n, const float *x, int64_t k, float *distances, int64_t *labels,
+                     const mvs_search_params *params);
+
+/* faiss::gpu::index_cpu_to_gpu(resources, device, index)  -- src/gpu/gpu.cpp:48.
+ * Indexes are already device-native; this migrates the index to `device` (no-op if it is there). */
+int mvs_index_to_gpu(mvs_index *ix, int device);
+int mvs_index_device(const mvs_index *ix);
+
+/* faiss::write_index / read_index  -- src/faiss_extension.cpp:199,234 */
+int mvs_write_index(const mvs_index *ix, const char *filename);
+int mvs_read_index(mvs_index **out, const char *filename);
+
+/* ---- device-resident variants (same semantics, inputs/outputs already in HBM) --------------------
+ * Used by bench.py (the metric is quoted with inputs resident in HBM) and by the multi-GPU host,
+ * which hands the per-shard (distance,label) blocks to RCCL without a host round trip.
+ * `stream` is a hipStream_t (NULL = the index's own stream); the call only enqueues work. */
+int mvs_index_add_device(mvs_index *ix, int64_t n, const float *d_x, const int64_t *d_ids, void *stream);
+int mvs_index_search_device(mvs_index *ix, int64_t n, const float *d_x, int64_t k, float *d_distances,
+                            int64_t *d_labels, const mvs_search_params *params, void *stream);
+/* label offset added to implicit (non-IDMap) labels: row-sharded multi-GPU search returns GLOBAL ids */
+int mvs_index_set_label_offset(mvs_index *ix, int64_t offset);
+
+/* k-way merge of per-shard results [nshard][n][k] (global labels) with the FAISS ordering rule.
+ * Host arrays.  This is the "host k-way merge" that follows the RCCL all-gather. */
+int mvs_merge_shards(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
+                     int64_t *I_out);
+
+/* ---- synthetic data (counter-based, identical on host oracle and device) and diagnostics -------- */
+int mvs_synth_uniform_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, void *stream);
+int mvs_synth_clustered_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers,
+                               float sigma, void *stream);
+/* name + launch geometry + algorithmic flops/bytes of the dominant kernel of the last search on this
+ * index (bench.py's roofline object); returns 0 and fills the fields */
+typedef struct mvs_kernel_info {
+	char name[64];
+	double flops;       /* algorithmic flops of the launch            */
+	double bytes;       /* algorithmic HBM bytes of the launch        */
+	double last_ms;     /* HIP-event duration of that launch, if timed */
+	int32_t grid, block, lds_bytes, nsplit;
+} mvs_kernel_info;
+int mvs_index_last_kernel_info(const mvs_index *ix, mvs_kernel_info *out);
+/* when enabled, the dominant kernel of every search is bracketed by HIP events on its stream */
+int mvs_index_set_kernel_timing(mvs_index *ix, int enabled);
+/* number of timed launches so far and the sum of their HIP-event durations */
+int mvs_index_kernel_time_stats(mvs_index *ix, int *count, double *total_ms);
+/* implementation knobs (never needed by the reference glue): "force_direct" = 0/1 */
+int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value);
+int mvs_device_count(void);
+const char *mvs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
