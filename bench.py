@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X vector-search hot path.
+
+Metric (BASELINE.json): queries/sec (+ recall@10), FlatL2 d=128 N=10M nq=10k k=10, at 1/2/4/8 MI355X.
+
+One "step" = one pass of the hot path over one batch: all nq queries searched against the whole database
+(Index::search, /root/reference/src/faiss_extension.cpp:631), inputs already resident in HBM.
+With --gpus N the database is ROW-SHARDED over the N ranks (fixed total N => strong scaling); each step is
+local search -> RCCL all-gather of the per-shard (distance,label) blocks -> host k-way merge on rank 0
+(SURVEY.md 8e).  Rank 0 prints ONE JSON line.
+
+    python bench.py                      # N=1, defaults finish in a few minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", default="L2", choices=["L2", "IP"])
+    ap.add_argument("--index", default="Flat", help="factory string (Flat | IDMap,Flat | IVF4096,Flat ...)")
+    ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--chunk", type=int, default=0, help="queries per search call (2048 = DuckDB DataChunk); 0 = one batch")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "clustered"])
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(
+                "bench.py --gpus N>1 must be launched with one process per GPU: python -m torch.distributed.run "
+                "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ..."
+            )
+        args.gpus = world
+    os.environ["MVS_DEVICE"] = str(local_rank)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import mi355_faiss as mf
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    metric = mf.METRIC_L2 if args.metric == "L2" else mf.METRIC_INNER_PRODUCT
+    n, d, nq, k = args.n, args.d, args.nq, args.k
+    # row shard of this rank: [r0, r1)
+    r0 = n * rank // world
+    r1 = n * (rank + 1) // world
+    DB_SEED, Q_SEED = 1234, 4321
+
+    gen = mf.synth_uniform_torch if args.data == "uniform" else mf.synth_clustered_torch
+    ix = mf.index_factory(d, args.index, metric)
+    is_ivf = "IVF" in args.index
+    # build: device-side generation in slabs (keeps peak memory = index + one slab)
+    slab = 1 << 20
+    t_build0 = time.time()
+    if is_ivf:
+        xb_all = gen(r1 - r0, d, DB_SEED, row0=r0, device=dev)
+        ix.train_torch(xb_all) if hasattr(ix, "train_torch") else ix.train(xb_all.cpu().numpy())
+        ix.add_torch(xb_all)
+        del xb_all
+    else:
+        for s0 in range(r0, r1, slab):
+            m = min(slab, r1 - s0)
+            xb = gen(m, d, DB_SEED, row0=s0, device=dev)
+            ix.add_torch(xb)
+            torch.cuda.synchronize()
+            del xb
+    ix.set_label_offset(r0)
+    xq = gen(nq, d, Q_SEED, row0=0, device=dev)
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build0
+
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if world > 1:
+        gD = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+        gI = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
+        hD = torch.empty((world, nq, k), dtype=torch.float32, pin_memory=True)
+        hI = torch.empty((world, nq, k), dtype=torch.int64, pin_memory=True)
+    chunk = args.chunk if args.chunk > 0 else nq
+    search_kw = {"nprobe": args.nprobe} if is_ivf else {}
+    final = {}
+
+    def step():
+        for q0 in range(0, nq, chunk):
+            q1 = min(nq, q0 + chunk)
+            ix.search_torch(xq[q0:q1], k, D=D[q0:q1], I=I[q0:q1], **search_kw)
+        if world > 1:
+            # exchange step: per-shard (distance,label) blocks over xGMI, then host k-way merge (rank 0)
+            dist.all_gather_into_tensor(gD, D)
+            dist.all_gather_into_tensor(gI, I)
+            if rank == 0:
+                hD.copy_(gD, non_blocking=True)
+                hI.copy_(gI, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                final["D"], final["I"] = mf.merge_shards(metric, hD.numpy(), hI.numpy())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ix.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ix.set_kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_launch, kern_ms = ix.kernel_time_stats()
+    kinfo = ix.last_kernel_info()
+
+    if rank == 0:
+        if world == 1:
+            final["D"], final["I"] = D.cpu().numpy(), I.cpu().numpy()
+        ms_per_step = dt / args.steps * 1e3
+        qps = nq * args.steps / dt
+        out = {
+            "metric": "queries/sec, Flat%s d=%d N=%d nq=%d k=%d" % (args.metric, d, n, nq, k)
+            if not is_ivf
+            else "queries/sec, %s d=%d N=%d nprobe=%d nq=%d k=%d" % (args.index, d, n, args.nprobe, nq, k),
+            "value": round(qps, 1),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (counter-based %s, db seed %d, query seed %d)" % (args.data, DB_SEED, Q_SEED),
+            "config": {
+                "workload": "%s %s d=%d N=%d nq=%d k=%d" % (args.index, args.metric, d, n, nq, k),
+                "queries_per_call": chunk,
+                "row_shards": world,
+                "exchange": "rccl all_gather + host k-way merge" if world > 1 else "none",
+                "build_seconds": round(t_build, 2),
+            },
+        }
+        # ---- roofline of the dominant kernel (per launch, HIP events on the launch stream) ----------
+        if n_launch > 0 and kern_ms > 0:
+            avg_ms = kern_ms / n_launch
+            if kinfo["name"].startswith("flat_mfma"):
+                achieved = kinfo["flops"] / (avg_ms * 1e-3) / 1e12
+                out["roofline"] = {
+                    "kernel": kinfo["name"],
+                    "bound": "mfma",
+                    "achieved": round(achieved, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4),
+                    "launches": n_launch,
+                    "algorithmic_flops_per_launch": kinfo["flops"],
+                    "algorithmic_bytes_per_launch": kinfo["bytes"],
+                    "hbm_frac_of_8TBps": round(kinfo["bytes"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
+                    "grid": kinfo["grid"],
+                    "lds_bytes": kinfo["lds_bytes"],
+                }
+            else:
+                achieved = kinfo["bytes"] / (avg_ms * 1e-3) / 1e9
+                out["roofline"] = {
+                    "kernel": kinfo["name"],
+                    "bound": "hbm",
+                    "achieved": round(achieved, 1),
+                    "peak": PEAK_HBM_GBPS,
+                    "unit": "GB/s",
+                    "frac": round(achieved / PEAK_HBM_GBPS, 4),
+                    "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4),
+                    "launches": n_launch,
+                    "algorithmic_bytes_per_launch": kinfo["bytes"],
+                }
+        # ---- CPU baseline (oracle, BLAS-path arithmetic, all host cores) + recall, N=1 only ----------
+        if world == 1 and not args.no_cpu_baseline and not is_ivf:
+            from oracle import oracle as orc
+
+            gen_h = orc.synth_uniform if args.data == "uniform" else orc.synth_clustered
+            xb_h = gen_h(n, d, DB_SEED)
+            xq_h = gen_h(nq, d, Q_SEED)
+            cores = orc.num_threads()
+            nq_cpu, t_cpu, done = 24, 0.0, 0
+            hits = total = 0
+            labels_equal = True
+            while t_cpu < args.cpu_seconds and done < nq:
+                m = min(nq_cpu, nq - done)
+                t1 = time.perf_counter()
+                Do, Io = orc.flat_search(metric, xb_h, xq_h[done : done + m], k, force_path=orc.PATH_BLAS)
+                step_t = time.perf_counter() - t1
+                t_cpu += step_t
+                g = final["I"][done : done + m]
+                labels_equal &= bool(np.array_equal(g, Io))
+                for a, b in zip(g, Io):
+                    hits += len(set(a.tolist()) & set(b.tolist()))
+                    total += k
+                done += m
+                per_q = t_cpu / done
+                nq_cpu = int(max(24, min(2048, (args.cpu_seconds - t_cpu) / max(per_q, 1e-9))))
+                if args.cpu_seconds - t_cpu < per_q * 24:
+                    break
+            out["cpu_baseline"] = {
+                "value": round(done / t_cpu, 2),
+                "unit": "queries/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "%d of %d queries vs the full N=%d database in %.1f s (oracle/orc_core.c search_blas: "
+                "packed AVX2 k-ordered-fma GEMM + heaps, OpenMP)" % (done, nq, n, t_cpu),
+            }
+            out["recall_at_10"] = round(hits / max(total, 1), 6)
+            out["labels_bit_exact_vs_oracle"] = labels_equal
+            out["recall_sample_queries"] = done
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,31 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(hipcc --offload-arch=gfx950); the MI355X vector-search path has no CPU fallback"
     )
+
+
+def _preload_hip_runtime():
+    """libmi355faiss.so is linked without a NEEDED entry for libamdhip64 (csrc/Makefile): the host picks the
+    HIP runtime.  PyTorch wheels bundle their own libamdhip64 + libhsa-runtime64, and two HSA runtimes cannot
+    coexist in one process, so when torch is installed its copy is the one to share."""
+    import importlib.util
+
+    cands = []
+    spec = importlib.util.find_spec("torch")
+    if spec and spec.submodule_search_locations:
+        cands.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"))
+    cands += ["/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so"]
+    errs = []
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # pragma: no cover
+            errs.append(f"{c}: {e}")
+    raise ImportError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errs))
+
+
+_HIP = _preload_hip_runtime()
 _L = C.CDLL(LIB_PATH)
 _p, _i64 = C.c_void_p, C.c_int64
 _L.mvs_last_error.restype = C.c_char_p
