@@ -219,7 +219,7 @@ def main():
             xb_h = gen_h(n, d, DB_SEED)
             xq_h = gen_h(nq, d, Q_SEED)
             cores = orc.num_threads()
-            nq_cpu, t_cpu, done = 24, 0.0, 0
+            nq_cpu, t_cpu, done = 1536, 0.0, 0
             hits = total = 0
             labels_equal = True
             while t_cpu < args.cpu_seconds and done < nq:
@@ -235,7 +235,7 @@ def main():
                     total += k
                 done += m
                 per_q = t_cpu / done
-                nq_cpu = int(max(24, min(2048, (args.cpu_seconds - t_cpu) / max(per_q, 1e-9))))
+                nq_cpu = int(max(24, min(4096, (args.cpu_seconds - t_cpu) / max(per_q, 1e-9))))
                 if args.cpu_seconds - t_cpu < per_q * 24:
                     break
             out["cpu_baseline"] = {

@@ -121,6 +121,7 @@ public:
 private:
 	DevBuf ws_q, ws_qn, ws_pd, ws_pi;
 	SelectorHolder selector;
+	hipStream_t last_search_stream = nullptr;
 	void grow(int64_t need, hipStream_t st);
 };
 
@@ -163,6 +164,7 @@ private:
 };
 
 IndexBase *index_factory(int d, const char *description, int metric);
+void stream_wait(hipStream_t waiter, hipStream_t signal);
 
 // csrc/ivf.hip
 IndexBase *make_ivf_index(int d, const std::string &desc, int metric); // nullptr if desc is not an IVF string

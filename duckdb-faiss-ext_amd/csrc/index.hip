@@ -110,6 +110,17 @@ IndexBase::~IndexBase() {
 		(void)hipEventDestroy(p.second);
 	}
 }
+// make stream `waiter` wait for everything enqueued so far on `signal`
+void stream_wait(hipStream_t waiter, hipStream_t signal) {
+	if (waiter == signal)
+		return;
+	hipEvent_t e;
+	MVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	MVS_HIP(hipEventRecord(e, signal));
+	MVS_HIP(hipStreamWaitEvent(waiter, e, 0));
+	MVS_HIP(hipEventDestroy(e));
+}
+
 void IndexBase::use_device() const {
 	MVS_HIP(hipSetDevice(device)); // DuckDB calls from arbitrary worker threads
 }
@@ -292,8 +303,7 @@ void FlatIndex::add_device(int64_t n, const float *d_x, hipStream_t st) {
 	use_device();
 	if (n <= 0)
 		return;
-	if (!st)
-		st = stream;
+	stream_wait(st, stream); // earlier host-API adds live on our own stream
 	grow(ntotal + n, st);
 	float *dst = vecs + (size_t)ntotal * geom.dp;
 	if (geom.dp == d)
@@ -301,6 +311,7 @@ void FlatIndex::add_device(int64_t n, const float *d_x, hipStream_t st) {
 	else
 		launch_pad_rows(d_x, n, d, dst, geom.dp, st);
 	launch_row_norms(dst, n, geom.dp, norms + ntotal, st);
+	stream_wait(stream, st); // later host-API calls see these rows
 	ntotal += n;
 }
 
@@ -321,14 +332,15 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		throw_faiss("virtual void faiss::IndexFlat::search(...) const", "faiss/IndexFlat.cpp", "Error: 'k > 0' failed");
 	if (nq <= 0)
 		return;
-	if (!st)
-		st = stream;
 	if (ntotal == 0) {
 		const long long total = (long long)nq * k;
 		hipLaunchKernelGGL(fill_results_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_D,
 		                   (long long *)d_I, total, metric == METRIC_L2 ? FLT_MAX : -FLT_MAX);
 		return;
 	}
+	// the scratch buffers below are shared by all searches of this index: order this call after the last one
+	stream_wait(st, last_search_stream);
+	last_search_stream = st;
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
 	const int64_t mfma_kmax = flat_mfma_max_k(geom);
 	const bool direct = has_sel || nq < 20 || k > mfma_kmax || force_direct;
@@ -395,6 +407,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 
 void FlatIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                               const mvs_search_params *params, hipStream_t st) {
+	use_device();
+	stream_wait(st, stream); // adds were enqueued on our own stream
 	search_flat(nq, d_x, k, d_D, d_I, params, nullptr, st);
 }
 
@@ -497,34 +511,22 @@ void IDMapIndex::add_with_ids_device(int64_t n, const float *d_x, const int64_t 
 	use_device();
 	if (n <= 0)
 		return;
-	if (!st)
-		st = stream;
+	stream_wait(st, stream);
 	sub->add_device(n, d_x, st);
 	grow_ids(ntotal + n, st);
 	MVS_HIP(hipMemcpyAsync(ids + ntotal, d_ids, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+	stream_wait(stream, st);
 	ntotal = sub->ntotal;
 }
 // IndexIDMap::search: selector tests EXTERNAL ids (IDSelectorTranslated), labels = id_map[internal]
 void IDMapIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                                const mvs_search_params *params, hipStream_t st) {
 	use_device();
-	if (!st)
-		st = stream;
-	// writes of ids happened on our own stream; the sub-index searches on `st`
-	if (st != stream) {
-		hipEvent_t e;
-		MVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-		MVS_HIP(hipEventRecord(e, stream));
-		MVS_HIP(hipStreamWaitEvent(st, e, 0));
-		MVS_HIP(hipEventDestroy(e));
-	}
+	stream_wait(st, stream); // id_map writes happened on our own stream; the sub-index searches on `st`
 	sub->search_mapped(nq, d_x, k, d_D, d_I, params, ids, st);
 	kinfo = sub->kinfo;
 }
 void IDMapIndex::search(int64_t nq, const float *x, int64_t k, float *D, int64_t *I, const mvs_search_params *params) {
-	// the sub-index's stream carries its adds: search there
-	use_device();
-	MVS_HIP(hipStreamSynchronize(stream));
 	IndexBase::search(nq, x, k, D, I, params);
 }
 void IDMapIndex::to_device(int new_device) {
@@ -554,14 +556,8 @@ void IDMapIndex::to_device(int new_device) {
 
 void FlatIndex::search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                               const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
-	// adds were enqueued on our own stream
-	if (st && st != stream) {
-		hipEvent_t e;
-		MVS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-		MVS_HIP(hipEventRecord(e, stream));
-		MVS_HIP(hipStreamWaitEvent(st, e, 0));
-		MVS_HIP(hipEventDestroy(e));
-	}
+	use_device();
+	stream_wait(st, stream); // adds were enqueued on our own stream
 	search_flat(nq, d_x, k, d_D, d_I, params, d_idmap, st);
 }
 

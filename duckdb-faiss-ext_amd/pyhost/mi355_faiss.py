@@ -243,7 +243,11 @@ class Index:
 
     # ---- device-resident variants (torch tensors on the index's device) ----
     def add_torch(self, x, ids=None, stream=None):
-        assert x.is_cuda and x.dtype.is_floating_point and x.is_contiguous()
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
         _check(
             _L.mvs_index_add_device(
                 self._h, x.shape[0], x.data_ptr(), ids.data_ptr() if ids is not None else None, stream

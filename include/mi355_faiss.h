@@ -108,7 +108,9 @@ int mvs_read_index(mvs_index **out, const char *filename);
 /* ---- device-resident variants (same semantics, inputs/outputs already in HBM) --------------------
  * Used by bench.py (the metric is quoted with inputs resident in HBM) and by the multi-GPU host,
  * which hands the per-shard (distance,label) blocks to RCCL without a host round trip.
- * `stream` is a hipStream_t (NULL = the index's own stream); the call only enqueues work. */
+ * `stream` is a hipStream_t used exactly as given (NULL = HIP's null stream, which is PyTorch's default
+ * stream); the call only enqueues work and is ordered after/before the index's own host-API stream with
+ * events, so host-API and device-API calls may be mixed freely. */
 int mvs_index_add_device(mvs_index *ix, int64_t n, const float *d_x, const int64_t *d_ids, void *stream);
 int mvs_index_search_device(mvs_index *ix, int64_t n, const float *d_x, int64_t k, float *d_distances,
                             int64_t *d_labels, const mvs_search_params *params, void *stream);

@@ -349,11 +349,13 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 		heap_init(k, D + i * k, I + i * k, is_max);
 	const int npanel_max = BLAS_DBS / PANEL;
 	float *yt = (float *)aligned_alloc(64, (size_t)npanel_max * (size_t)d * PANEL * sizeof(float));
-	const int nt = omp_get_max_threads();
-	float *ipbuf_all = (float *)aligned_alloc(64, (size_t)nt * MR * BLAS_DBS * sizeof(float));
+	/* ip block of one (query block x database block) pair, as FAISS's ip_block (4096 x 1024 floats) */
+	const int64_t qbs = nq < BLAS_QBS ? (nq + MR - 1) / MR * MR : BLAS_QBS;
+	float *ipbuf_all = (float *)aligned_alloc(64, (size_t)(qbs + MR) * BLAS_DBS * sizeof(float));
 
 	for (int64_t i0 = 0; i0 < nq; i0 += BLAS_QBS) {
 		int64_t i1 = i0 + BLAS_QBS < nq ? i0 + BLAS_QBS : nq;
+		const int64_t ngroups = (i1 - i0 + MR - 1) / MR;
 		for (int64_t j0 = 0; j0 < nb; j0 += BLAS_DBS) {
 			int64_t j1 = j0 + BLAS_DBS < nb ? j0 + BLAS_DBS : nb;
 			int64_t jb = j1 - j0;
@@ -376,46 +378,45 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 						}
 					}
 				}
-				float *ipbuf = ipbuf_all + (size_t)omp_get_thread_num() * MR * BLAS_DBS;
-				int64_t ngroups = (i1 - i0 + MR - 1) / MR;
-#pragma omp for schedule(dynamic, 4)
+				/* "sgemm": every (query group, panel) pair is an independent task */
+#pragma omp for schedule(static) collapse(2)
 				for (int64_t g = 0; g < ngroups; g++) {
-					int64_t ia = i0 + g * MR;
-					int nrow = (int)((i1 - ia) < MR ? (i1 - ia) : MR);
-					if (nrow == MR) {
-						for (int p = 0; p < np; p++)
-							mk_6x16(d, xq + ia * d, d, yt + (size_t)p * d * PANEL, ipbuf + p * PANEL, BLAS_DBS);
-					} else {
-						for (int r = 0; r < nrow; r++)
-							for (int p = 0; p < np; p++)
-								mk_1x16(d, xq + (ia + r) * d, yt + (size_t)p * d * PANEL,
-								        ipbuf + (size_t)r * BLAS_DBS + p * PANEL);
-					}
-					/* HeapBlockResultHandler::add_results: j ascending, strict compare */
-					for (int r = 0; r < nrow; r++) {
-						int64_t i = ia + r;
-						float *hv = D + i * k;
-						int64_t *hi = I + i * k;
-						const float *ipl = ipbuf + (size_t)r * BLAS_DBS;
-						float thr = hv[0];
-						if (is_max) {
-							const float xni = xn[i];
-							for (int64_t j = 0; j < jb; j++) {
-								float dis = (xni + yn[j0 + j]) - 2.0f * ipl[j];
-								if (dis < 0)
-									dis = 0;
-								if (thr > dis) {
-									heap_replace_top(k, hv, hi, 1, dis, j0 + j);
-									thr = hv[0];
-								}
-							}
+					for (int p = 0; p < np; p++) {
+						int64_t ia = i0 + g * MR;
+						int nrow = (int)((i1 - ia) < MR ? (i1 - ia) : MR);
+						float *out = ipbuf_all + (size_t)(g * MR) * BLAS_DBS + p * PANEL;
+						if (nrow == MR) {
+							mk_6x16(d, xq + ia * d, d, yt + (size_t)p * d * PANEL, out, BLAS_DBS);
 						} else {
-							for (int64_t j = 0; j < jb; j++) {
-								float dis = ipl[j];
-								if (thr < dis) {
-									heap_replace_top(k, hv, hi, 0, dis, j0 + j);
-									thr = hv[0];
-								}
+							for (int r = 0; r < nrow; r++)
+								mk_1x16(d, xq + (ia + r) * d, yt + (size_t)p * d * PANEL, out + (size_t)r * BLAS_DBS);
+						}
+					}
+				}
+				/* HeapBlockResultHandler::add_results: per query, j ascending, strict compare */
+#pragma omp for schedule(static)
+				for (int64_t i = i0; i < i1; i++) {
+					float *hv = D + i * k;
+					int64_t *hi = I + i * k;
+					const float *ipl = ipbuf_all + (size_t)(i - i0) * BLAS_DBS;
+					float thr = hv[0];
+					if (is_max) {
+						const float xni = xn[i];
+						for (int64_t j = 0; j < jb; j++) {
+							float dis = (xni + yn[j0 + j]) - 2.0f * ipl[j];
+							if (dis < 0)
+								dis = 0;
+							if (thr > dis) {
+								heap_replace_top(k, hv, hi, 1, dis, j0 + j);
+								thr = hv[0];
+							}
+						}
+					} else {
+						for (int64_t j = 0; j < jb; j++) {
+							float dis = ipl[j];
+							if (thr < dis) {
+								heap_replace_top(k, hv, hi, 0, dis, j0 + j);
+								thr = hv[0];
 							}
 						}
 					}

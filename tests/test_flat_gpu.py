@@ -251,6 +251,6 @@ def test_medium_size_properties(mf):
     Dm, Im = mf.merge_shards(L2, np.stack(Ds), np.stack(Is))
     assert np.array_equal(Im, In) and np.array_equal(Dm, Dn)
     # oracle on a subsample of queries against the full database
-    sub = np.arange(0, nq, 64)
+    sub = np.arange(0, nq, 8)
     Do, Io = orc.flat_search(L2, xb.cpu().numpy(), xq[sub].cpu().numpy(), k, force_path=orc.PATH_BLAS)
     assert_same_results(Dn[sub], In[sub], Do, Io, True, what="1M subsample")

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: times the dominant flat-search kernel (HIP events on its stream) on synthetic data.
+    python tools/kbench.py --n 2000000 --nq 10000 --d 128 --k 10 --metric L2 --reps 5 [--opt key=value ...]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=2_000_000)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", default="L2")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--check", action="store_true", help="compare a query subsample with the oracle")
+    args = ap.parse_args()
+    import torch
+
+    import mi355_faiss as mf
+
+    metric = mf.METRIC_L2 if args.metric == "L2" else mf.METRIC_INNER_PRODUCT
+    ix = mf.index_factory(args.d, "Flat", metric)
+    for o in args.opt:
+        key, v = o.split("=")
+        ix.set_option(key, int(v))
+    slab = 1 << 20
+    for s0 in range(0, args.n, slab):
+        xb = mf.synth_uniform_torch(min(slab, args.n - s0), args.d, 1234, row0=s0)
+        ix.add_torch(xb)
+        torch.cuda.synchronize()
+    xq = mf.synth_uniform_torch(args.nq, args.d, 4321)
+    D, I = ix.search_torch(xq, args.k)
+    torch.cuda.synchronize()
+    ix.set_kernel_timing(True)
+    for _ in range(args.reps):
+        ix.search_torch(xq, args.k, D=D, I=I)
+    torch.cuda.synchronize()
+    n, ms = ix.kernel_time_stats()
+    ki = ix.last_kernel_info()
+    avg = ms / n
+    tf = ki["flops"] / (avg * 1e-3) / 1e12
+    gbs = ki["bytes"] / (avg * 1e-3) / 1e9
+    print(
+        f"{ki['name']} opts={args.opt} n={args.n} nq={args.nq} d={args.d} k={args.k} {args.metric}: "
+        f"{avg:.3f} ms/launch  {tf:.2f} TFLOP/s ({tf/157.3*100:.1f}% f32-MFMA peak)  {gbs:.1f} GB/s algorithmic  "
+        f"grid={ki['grid']} lds={ki['lds_bytes']} nsplit={ki['nsplit']}  qps={args.nq/(avg*1e-3):.0f}"
+    )
+    if args.check:
+        import numpy as np
+
+        from oracle import oracle as orc
+
+        xb_h = orc.synth_uniform(args.n, args.d, 1234)
+        sub = np.arange(0, args.nq, max(1, args.nq // 256))[:256]
+        Do, Io = orc.flat_search(metric, xb_h, xq[sub].cpu().numpy(), args.k, force_path=orc.PATH_BLAS if len(sub) >= 20 else orc.PATH_AUTO)
+        ok = np.array_equal(I.cpu().numpy()[sub], Io) and np.array_equal(D.cpu().numpy()[sub], Do)
+        print("check vs oracle (", len(sub), "queries ):", "BIT-EXACT" if ok else "MISMATCH")
+
+
+if __name__ == "__main__":
+    main()
