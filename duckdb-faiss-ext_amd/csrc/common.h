@@ -83,7 +83,7 @@ void launch_pad_rows(const float *d_src, int64_t n, int d, float *d_dst, int dp,
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 // partial lists: pd [nsplit][nq][k] f32, pi [nsplit][nq][k] i32
 void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
-                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, hipStream_t st);
+                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st);
 int64_t flat_mfma_max_k(const FlatGeom &g);
 
 // direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic

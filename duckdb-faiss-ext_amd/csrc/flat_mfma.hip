@@ -23,6 +23,8 @@
 //   d  > 128: 256-row tiles (8 accumulator tiles per wave), k streamed in units of 32.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace mvs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,10 +36,30 @@ struct MfmaArgs {
 	const float *yn; // database norms
 	float *pd;       // partial distances [nsplit][nq][k]
 	int32_t *pi;     // partial row ids
+	unsigned *gthr;  // [nq] order-preserving keys of the best k-th value any workgroup has published
 	long long n;
 	long long split_rows;
 	int nq, k, nqb, nsplit, dp, nch, xcd_map;
 };
+
+// order-preserving float <-> uint key (atomicMin/Max on floats of either sign)
+__device__ __forceinline__ unsigned f2key(float f) {
+	const unsigned b = __float_as_uint(f);
+	return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+	return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+// smallest float strictly greater than g >= 0 / largest float strictly smaller than g
+__device__ __forceinline__ float next_up_nonneg(float g) {
+	return __uint_as_float(__float_as_uint(g) + 1u);
+}
+__device__ __forceinline__ float next_down(float g) {
+	if (g == 0.f)
+		return __uint_as_float(0x80000001u);
+	const unsigned b = __float_as_uint(g);
+	return __uint_as_float(g > 0.f ? b - 1u : b + 1u);
+}
 
 struct Thr {
 	float v;
@@ -242,6 +264,14 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 			const long long row0 = r_begin + (long long)tile * BN;
 			const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
 			const float *nb = nbuf + (tile & 1) * BN;
+			// threshold broadcast: the best k-th value ANY workgroup has seen for this query bounds the final
+			// k-th value, so a row beyond it can never be in the result (ties with it are kept: <= / >=)
+			float gval = IS_L2 ? FLT_MAX : -FLT_MAX;
+			float teff = thr;
+			if (qvalid) {
+				gval = key2f(__hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+				teff = IS_L2 ? fminf(thr, next_up_nonneg(gval)) : fmaxf(thr, next_down(gval));
+			}
 			bool any = false;
 #pragma unroll
 			for (int t = 0; t < NT; ++t) {
@@ -257,9 +287,9 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 						if (IS_L2) {
 							v = fmaf(-2.0f, v, xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
 							acc[t][4 * g + e] = v;
-							any |= v < thr;
+							any |= v < teff;
 						} else {
-							any |= v > thr;
+							any |= v > teff;
 						}
 					}
 				}
@@ -281,9 +311,16 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 									v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
 								const int rl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 								const int id = (int)(row0 + rl);
-								if (rl < nvalid && cand_better<IS_L2>(v, id, cur.v, cur.id))
+								if (rl < nvalid && (IS_L2 ? v <= gval : v >= gval) && cand_better<IS_L2>(v, id, cur.v, cur.id))
 									cur = list_insert<IS_L2>(ld + ql * k, li + ql * k, k, cur.pos, v, id);
 							}
+						}
+						if (cur.v != lthr[ql] && qvalid) {
+							// publish this workgroup's k-th value (neutral while the list is not full: a no-op)
+							if (IS_L2)
+								__hip_atomic_fetch_min(a.gthr + q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							else
+								__hip_atomic_fetch_max(a.gthr + q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						}
 						lthr[ql] = cur.v;
 						lthrid[ql] = cur.id;
@@ -376,11 +413,23 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	return p;
 }
 
+__global__ void init_gthr_kernel(unsigned *g, int nq, int is_l2) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nq)
+		g[i] = f2key(is_l2 ? FLT_MAX : -FLT_MAX);
+}
+
 template <int KSTEPS, int NT, bool RESIDENT>
 static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
 	if (metric == METRIC_L2) {
 		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, true>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		if (getenv("MVS_DEBUG")) {
+			int nb = 0;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, p.lds_bytes);
+			fprintf(stderr, "[mvs] flat_mfma_kernel<%d,%d,%d,L2> grid=%d lds=%zu nsplit=%d split_rows=%lld blocks/CU=%d\n",
+			        KSTEPS, NT, (int)RESIDENT, p.grid, p.lds_bytes, p.nsplit, (long long)p.split_rows, nb);
+		}
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 	} else {
 		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, false>;
@@ -391,10 +440,13 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 }
 
 void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
-                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, hipStream_t st) {
+                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st) {
 	if (nq <= 0)
 		return;
+	hipLaunchKernelGGL(init_gthr_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_gthr, (int)nq,
+	                   metric == METRIC_L2 ? 1 : 0);
 	MfmaArgs a;
+	a.gthr = d_gthr;
 	a.qf = d_qf;
 	a.qn = d_qnorm;
 	a.yb = db.vecs;

@@ -389,9 +389,10 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		launch_pack_queries(geom, d_x, nq, (float *)ws_q.p, (float *)ws_qn.p, st);
 		ws_pd.reserve((size_t)p.nsplit * nq * k * sizeof(float));
 		ws_pi.reserve((size_t)p.nsplit * nq * k * sizeof(int32_t));
+		ws_gthr.reserve((size_t)nq * sizeof(unsigned));
 		begin_kernel_timing(st);
 		launch_flat_mfma(geom, p, metric, (const float *)ws_q.p, (const float *)ws_qn.p, nq, db, k, (float *)ws_pd.p,
-		                 (int32_t *)ws_pi.p, st);
+		                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
 		end_kernel_timing(st);
 		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, k, d_idmap,
 		                      label_offset, d_D, d_I, st);
