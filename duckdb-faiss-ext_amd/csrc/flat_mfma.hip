@@ -100,6 +100,244 @@ __device__ __noinline__ Thr list_insert(float *ld, int *li, int k, int pos, floa
 	return t;
 }
 
+
+// ---- fused epilogue of one row tile: distances + threshold test (lane-local per query) + rare insertion ----
+// acc[t][r] holds ip(query = lane&31, row = t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)).
+template <int NT, bool IS_L2>
+__device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb, long long row0, int nvalid, float xnq,
+                                              float &thr, bool qvalid, unsigned *gthr_q, float *ldq, int *liq, int k,
+                                              float *lthr_q, int *lthrid_q, int *lpos_q, int h) {
+	// threshold broadcast: the best k-th value ANY workgroup has seen for this query bounds the final k-th
+	// value, so a row beyond it can never be in the result (ties with it are kept: <= / >=)
+	float gval = IS_L2 ? FLT_MAX : -FLT_MAX;
+	float teff = thr;
+	if (qvalid) {
+		gval = key2f(__hip_atomic_load(gthr_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		teff = IS_L2 ? fminf(thr, next_up_nonneg(gval)) : fmaxf(thr, next_down(gval));
+	}
+	bool any = false;
+#pragma unroll
+	for (int t = 0; t < NT; ++t) {
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (IS_L2)
+				y4 = *(const float4 *)(nb + t * 32 + 8 * g + 4 * h);
+			const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				float v = acc[t][4 * g + e];
+				if (IS_L2) {
+					v = fmaf(-2.0f, v, xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
+					acc[t][4 * g + e] = v;
+					any |= v < teff;
+				} else {
+					any |= v > teff;
+				}
+			}
+		}
+	}
+	if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+		// ---- rare path: exact (value, id) insertion into this wave's per-query lists ----------
+		for (int hh = 0; hh < 2; ++hh) { // lanes l and l+32 share a query: take turns
+			if (h == hh) {
+				Thr cur;
+				cur.v = *lthr_q;
+				cur.id = *lthrid_q;
+				cur.pos = *lpos_q;
+#pragma unroll
+				for (int t = 0; t < NT; ++t) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						float v = acc[t][r];
+						if (IS_L2)
+							v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
+						const int rl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+						const int id = (int)(row0 + rl);
+						if (rl < nvalid && (IS_L2 ? v <= gval : v >= gval) && cand_better<IS_L2>(v, id, cur.v, cur.id))
+							cur = list_insert<IS_L2>(ldq, liq, k, cur.pos, v, id);
+					}
+				}
+				if (cur.v != *lthr_q && qvalid) {
+					// publish this workgroup's k-th value (neutral while the list is not full: a no-op)
+					if (IS_L2)
+						__hip_atomic_fetch_min(gthr_q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					else
+						__hip_atomic_fetch_max(gthr_q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				*lthr_q = cur.v;
+				*lthrid_q = cur.id;
+				*lpos_q = cur.pos;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+		thr = *lthr_q;
+	}
+}
+
+// =====================================================================================================
+// v2 resident kernel (d <= 128): database tile staged with LDS-DMA (global_load_lds, no staging VGPRs, no
+// ds_write pass) and A fragments software-pipelined through a two-group register ring so that an MFMA never
+// waits on the ds_read issued just before it.
+// =====================================================================================================
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(1))) const float glb_f32;
+
+template <int KSTEPS, bool IS_L2>
+__global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
+	constexpr int NT = 2, KC = 2 * KSTEPS, LDA = KC + 1, BN = 64;
+	constexpr int SEGS = (KC + 63) / 64; // 64-float LDS-DMA pieces per row
+	constexpr int G = KSTEPS >= 8 ? 4 : KSTEPS; // k-steps per A-fragment group
+	constexpr int NG = KSTEPS / G;
+	static_assert(KSTEPS % 4 == 0 && KSTEPS % G == 0, "");
+
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	float *tbuf = smem;                // [2][BN][LDA]
+	float *nbuf = smem + 2 * BN * LDA; // [2][BN]
+	float *ld = nbuf + 2 * BN;         // [128][k]
+	int *li = (int *)(ld + QBLOCK * a.k);
+	float *lthr = (float *)(li + QBLOCK * a.k);
+	int *lthrid = (int *)(lthr + QBLOCK);
+	int *lpos = lthrid + QBLOCK;
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int h = lane >> 5, c = lane & 31;
+	const int k = a.k;
+	int split, qb;
+	if (a.xcd_map) {
+		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+		split = (idx / a.nqb) * 8 + xcd;
+		qb = idx % a.nqb;
+	} else {
+		split = blockIdx.x / a.nqb;
+		qb = blockIdx.x % a.nqb;
+	}
+	const int ql = wave * WAVE_Q + c;
+	const int q = qb * QBLOCK + ql;
+	const bool qvalid = q < a.nq;
+	const int qblk32 = qb * 4 + wave;
+	const long long r_begin = (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + BN - 1) / BN) : 0;
+
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+	float thr = qvalid ? neutral : (IS_L2 ? -INFINITY : INFINITY);
+	if (h == 0) {
+		for (int j = 0; j < k; ++j) {
+			ld[ql * k + j] = neutral;
+			li[ql * k + j] = -1;
+		}
+		lthr[ql] = thr;
+		lthrid[ql] = -1;
+		lpos[ql] = 0;
+	}
+	const float xnq = (IS_L2 && qvalid) ? a.qn[q] : 0.f;
+
+	float qf[KSTEPS];
+	const float4 *qsrc = (const float4 *)a.qf + (size_t)qblk32 * (KSTEPS / 4) * 64 + lane;
+#pragma unroll
+	for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
+		float4 v = qsrc[s4 * 64];
+		qf[4 * s4 + 0] = v.x;
+		qf[4 * s4 + 1] = v.y;
+		qf[4 * s4 + 2] = v.z;
+		qf[4 * s4 + 3] = v.w;
+	}
+
+	// LDS-DMA staging: wave w moves rows [16w, 16w+16) of the tile; one instruction = 64 consecutive floats of
+	// one row (the padded row stride keeps every piece inside its row)
+	auto stage = [&](int tile) {
+		const long long row0 = r_begin + (long long)tile * BN;
+		lds_f32 *dst = (lds_f32 *)smem + (tile & 1) * BN * LDA;
+#pragma unroll
+		for (int rr = 0; rr < 16; ++rr) {
+			const int row = wave * 16 + rr;
+			long long gr = row0 + row;
+			if (gr >= a.n)
+				gr = a.n - 1; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
+			const float *src = a.yb + (size_t)gr * a.dp;
+#pragma unroll
+			for (int sg = 0; sg < SEGS; ++sg) {
+				if (KC - sg * 64 >= 64 || lane < KC - sg * 64)
+					__builtin_amdgcn_global_load_lds((glb_f32 *)(src + sg * 64 + lane), dst + row * LDA + sg * 64, 4, 0,
+					                                 0);
+			}
+		}
+		if (IS_L2 && wave == 0) {
+			long long gr = row0 + lane;
+			if (gr >= a.n)
+				gr = a.n - 1;
+			__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yn + gr), (lds_f32 *)smem + 2 * BN * LDA + (tile & 1) * BN,
+			                                 4, 0, 0);
+		}
+	};
+
+	f32x16 acc[NT];
+	if (ntiles > 0)
+		stage(0);
+	__syncthreads();
+
+	for (int tile = 0; tile < ntiles; ++tile) {
+		if (tile + 1 < ntiles)
+			stage(tile + 1);
+#pragma unroll
+		for (int t = 0; t < NT; ++t)
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+				acc[t][r] = 0.f;
+		const float *A = tbuf + (tile & 1) * BN * LDA + c * LDA + h;
+		float af[2][NT][G];
+#pragma unroll
+		for (int t = 0; t < NT; ++t)
+#pragma unroll
+			for (int s = 0; s < G; ++s)
+				af[0][t][s] = A[t * 32 * LDA + 2 * s];
+#pragma unroll
+		for (int g = 0; g < NG; ++g) {
+			// Order pinned with sched_barrier: [first k-step of group g] [ds_reads of group g+1] [rest of group g].
+			// hipcc otherwise sinks each ds_read to just before its MFMA (every MFMA then waits out the LDS
+			// latency), and its s_waitcnt at the head of a group is lgkmcnt(0): issuing the next group's reads one
+			// k-step INTO the group puts >= 6 MFMAs (384 cycles) between those reads and that wait.
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int t = 0; t < NT; ++t)
+				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][0], qf[g * G], acc[t], 0, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			if (g + 1 < NG) {
+#pragma unroll
+				for (int t = 0; t < NT; ++t)
+#pragma unroll
+					for (int s = 0; s < G; ++s)
+						af[(g + 1) & 1][t][s] = A[t * 32 * LDA + 2 * ((g + 1) * G + s)];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int s = 1; s < G; ++s)
+#pragma unroll
+				for (int t = 0; t < NT; ++t)
+					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][s], qf[g * G + s], acc[t], 0, 0, 0);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		const long long row0 = r_begin + (long long)tile * BN;
+		const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
+		tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, a.gthr + q, ld + ql * k,
+		                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
+	}
+
+	if (h == 0 && qvalid) {
+		float *od = a.pd + ((size_t)split * a.nq + q) * k;
+		int32_t *oi = a.pi + ((size_t)split * a.nq + q) * k;
+		for (int j = 0; j < k; ++j) {
+			od[j] = ld[ql * k + j];
+			oi[j] = li[ql * k + j];
+		}
+	}
+}
+
 template <int KSTEPS, int NT, bool RESIDENT, bool IS_L2>
 __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const MfmaArgs a) {
 	constexpr int KC = 2 * KSTEPS, LDA = KC + 1, BN = 32 * NT;
@@ -260,77 +498,10 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 		}
 
 		if (ch == nch - 1) {
-			// ---- fused epilogue: distances + threshold test, lane-local per query ---------------------
 			const long long row0 = r_begin + (long long)tile * BN;
 			const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
-			const float *nb = nbuf + (tile & 1) * BN;
-			// threshold broadcast: the best k-th value ANY workgroup has seen for this query bounds the final
-			// k-th value, so a row beyond it can never be in the result (ties with it are kept: <= / >=)
-			float gval = IS_L2 ? FLT_MAX : -FLT_MAX;
-			float teff = thr;
-			if (qvalid) {
-				gval = key2f(__hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-				teff = IS_L2 ? fminf(thr, next_up_nonneg(gval)) : fmaxf(thr, next_down(gval));
-			}
-			bool any = false;
-#pragma unroll
-			for (int t = 0; t < NT; ++t) {
-#pragma unroll
-				for (int g = 0; g < 4; ++g) {
-					float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
-					if (IS_L2)
-						y4 = *(const float4 *)(nb + t * 32 + 8 * g + 4 * h);
-					const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
-#pragma unroll
-					for (int e = 0; e < 4; ++e) {
-						float v = acc[t][4 * g + e];
-						if (IS_L2) {
-							v = fmaf(-2.0f, v, xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
-							acc[t][4 * g + e] = v;
-							any |= v < teff;
-						} else {
-							any |= v > teff;
-						}
-					}
-				}
-			}
-			if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-				// ---- rare path: exact (value, id) insertion into this wave's per-query lists ----------
-				for (int hh = 0; hh < 2; ++hh) { // lanes l and l+32 share a query: take turns
-					if (h == hh) {
-						Thr cur;
-						cur.v = lthr[ql];
-						cur.id = lthrid[ql];
-						cur.pos = lpos[ql];
-#pragma unroll
-						for (int t = 0; t < NT; ++t) {
-#pragma unroll
-							for (int r = 0; r < 16; ++r) {
-								float v = acc[t][r];
-								if (IS_L2)
-									v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
-								const int rl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-								const int id = (int)(row0 + rl);
-								if (rl < nvalid && (IS_L2 ? v <= gval : v >= gval) && cand_better<IS_L2>(v, id, cur.v, cur.id))
-									cur = list_insert<IS_L2>(ld + ql * k, li + ql * k, k, cur.pos, v, id);
-							}
-						}
-						if (cur.v != lthr[ql] && qvalid) {
-							// publish this workgroup's k-th value (neutral while the list is not full: a no-op)
-							if (IS_L2)
-								__hip_atomic_fetch_min(a.gthr + q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							else
-								__hip_atomic_fetch_max(a.gthr + q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						}
-						lthr[ql] = cur.v;
-						lthrid[ql] = cur.id;
-						lpos[ql] = cur.pos;
-					}
-					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-					__builtin_amdgcn_wave_barrier();
-				}
-				thr = lthr[ql];
-			}
+			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, a.gthr + q, ld + ql * k,
+			                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
 		}
 
 		if (u + 1 < total_units)
@@ -419,8 +590,36 @@ __global__ void init_gthr_kernel(unsigned *g, int nq, int is_l2) {
 		g[i] = f2key(is_l2 ? FLT_MAX : -FLT_MAX);
 }
 
+int g_mfma_variant = 2; // 1 = register-staged generic kernel, 2 = LDS-DMA + A-ring resident kernel
+
+template <int KSTEPS>
+static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
+	if (metric == METRIC_L2) {
+		auto kern = flat_mfma_resident_kernel<KSTEPS, true>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		if (getenv("MVS_DEBUG")) {
+			int nb = 0;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, p.lds_bytes);
+			fprintf(stderr, "[mvs] flat_mfma_resident_kernel<%d,L2> grid=%d lds=%zu nsplit=%d split_rows=%lld blocks/CU=%d\n",
+			        KSTEPS, p.grid, p.lds_bytes, p.nsplit, (long long)p.split_rows, nb);
+		}
+		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+	} else {
+		auto kern = flat_mfma_resident_kernel<KSTEPS, false>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
 template <int KSTEPS, int NT, bool RESIDENT>
 static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
+	if constexpr (RESIDENT) {
+		if (g_mfma_variant == 2) {
+			launch_resident_v2<KSTEPS>(metric, a, p, st);
+			return;
+		}
+	}
 	if (metric == METRIC_L2) {
 		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, true>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));

@@ -826,6 +826,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		force_direct = v != 0;
 		return true;
 	}
+	if (!strcmp(key, "mfma_variant")) { // A/B switch between kernel generations (process-wide)
+		g_mfma_variant = (int)v;
+		return true;
+	}
 	return false;
 }
 } // namespace mvs
