@@ -186,8 +186,9 @@ typedef __attribute__((address_space(1))) const float glb_f32;
 
 template <int KSTEPS, bool IS_L2>
 __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
-	constexpr int NT = 2, KC = 2 * KSTEPS, LDA = KC + 1, BN = 64;
-	constexpr int SEGS = (KC + 63) / 64; // 64-float LDS-DMA pieces per row
+	constexpr int NT = 2, KC = 2 * KSTEPS, BN = 64;
+	constexpr int SEGS = (KC + 63) / 64; // 64-float LDS-DMA pieces per row (always whole: EXEC stays full)
+	constexpr int LDA = SEGS * 64 + 1;   // a piece may run past the row's KC floats into columns nobody reads
 	constexpr int G = KSTEPS >= 8 ? 4 : KSTEPS; // k-steps per A-fragment group
 	constexpr int NG = KSTEPS / G;
 	static_assert(KSTEPS % 4 == 0 && KSTEPS % G == 0, "");
@@ -260,11 +261,8 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 				gr = a.n - 1; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
 			const float *src = a.yb + (size_t)gr * a.dp;
 #pragma unroll
-			for (int sg = 0; sg < SEGS; ++sg) {
-				if (KC - sg * 64 >= 64 || lane < KC - sg * 64)
-					__builtin_amdgcn_global_load_lds((glb_f32 *)(src + sg * 64 + lane), dst + row * LDA + sg * 64, 4, 0,
-					                                 0);
-			}
+			for (int sg = 0; sg < SEGS; ++sg)
+				__builtin_amdgcn_global_load_lds((glb_f32 *)(src + sg * 64 + lane), dst + row * LDA + sg * 64, 4, 0, 0);
 		}
 		if (IS_L2 && wave == 0) {
 			long long gr = row0 + lane;
@@ -552,7 +550,9 @@ size_t qfrag_floats(const FlatGeom &g, int64_t nq) {
 
 static size_t mfma_lds_bytes(const FlatGeom &g, int64_t k) {
 	const size_t bn = g.bn();
-	return (2 * bn * (g.kc + 1) + 2 * bn) * sizeof(float) + (size_t)QBLOCK * k * 8 + QBLOCK * 12;
+	// resident v2 kernel: rows padded to whole 64-float LDS-DMA pieces (+1)
+	const size_t lda = g.nch == 1 ? (size_t)((g.kc + 63) / 64 * 64 + 1) : (size_t)(g.kc + 1);
+	return (2 * bn * lda + 2 * bn) * sizeof(float) + (size_t)QBLOCK * k * 8 + QBLOCK * 12;
 }
 
 int64_t flat_mfma_max_k(const FlatGeom &g) {

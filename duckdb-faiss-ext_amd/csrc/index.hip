@@ -254,7 +254,8 @@ void FlatIndex::grow(int64_t need, hipStream_t st) {
 	while (nc < need)
 		nc = nc + nc / 2 + 4096;
 	float *nv = nullptr, *nn = nullptr;
-	MVS_HIP(hipMalloc((void **)&nv, (size_t)nc * geom.dp * sizeof(float)));
+	// +64 floats: the LDS-DMA staging reads whole 64-float pieces and may run past the last row
+	MVS_HIP(hipMalloc((void **)&nv, ((size_t)nc * geom.dp + 64) * sizeof(float)));
 	MVS_HIP(hipMalloc((void **)&nn, (size_t)nc * sizeof(float)));
 	if (geom.dp != d) // padding columns must read as zero
 		MVS_HIP(hipMemsetAsync(nv + (size_t)ntotal * geom.dp, 0, (size_t)(nc - ntotal) * geom.dp * sizeof(float), st));
@@ -425,9 +426,9 @@ void FlatIndex::to_device(int new_device) {
 	float *nv = nullptr, *nn = nullptr;
 	MVS_HIP(hipSetDevice(new_device));
 	if (cap > 0) {
-		MVS_HIP(hipMalloc((void **)&nv, (size_t)cap * geom.dp * sizeof(float)));
+		MVS_HIP(hipMalloc((void **)&nv, ((size_t)cap * geom.dp + 64) * sizeof(float)));
 		MVS_HIP(hipMalloc((void **)&nn, (size_t)cap * sizeof(float)));
-		MVS_HIP(hipMemset(nv, 0, (size_t)cap * geom.dp * sizeof(float)));
+		MVS_HIP(hipMemset(nv, 0, ((size_t)cap * geom.dp + 64) * sizeof(float)));
 		if (ntotal > 0) {
 			MVS_HIP(hipMemcpyPeer(nv, new_device, vecs, device, (size_t)ntotal * geom.dp * sizeof(float)));
 			MVS_HIP(hipMemcpyPeer(nn, new_device, norms, device, (size_t)ntotal * sizeof(float)));
