@@ -43,6 +43,11 @@ struct FlatGeom {
 	int kc;     // k extent of one LDS staging unit
 	int nch;    // staging units per row (1 => queries stay resident in registers)
 	int ntile;  // 32-row MFMA tiles per wave per row tile (2 resident, 8 streaming)
+	// HBM row format.  false: plain row-major.  true ("pair-interleaved", d <= 128): inside every group of four
+	// consecutive k the floats are stored as [k0,k2,k1,k3] for rows whose index has bit 4 clear and [k1,k3,k0,k2]
+	// for rows with bit 4 set -- the two k-steps one MFMA lane half needs are then ONE aligned 8-byte word, and
+	// the 32 lanes of a ds_read_b64 hit 32 distinct bank pairs (DESIGN.md "HBM layout").
+	bool pair_interleaved;
 	int bn() const {
 		return ntile * 32;
 	}
@@ -79,6 +84,9 @@ void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float 
                          hipStream_t st);
 void launch_row_norms(const float *d_vecs, int64_t n, int dp, float *d_norms, hipStream_t st);
 void launch_pad_rows(const float *d_src, int64_t n, int d, float *d_dst, int dp, hipStream_t st);
+// [n][d] row-major -> storage rows [n][dp] (zero padded; pair-interleaved if g says so); row0 = index of the first row
+void launch_pack_rows(const FlatGeom &g, const float *d_src, int64_t n, float *d_dst, int64_t row0, hipStream_t st);
+void launch_query_norms(const float *d_x, int64_t n, int d, float *d_out, hipStream_t st);
 
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 // partial lists: pd [nsplit][nq][k] f32, pi [nsplit][nq][k] i32

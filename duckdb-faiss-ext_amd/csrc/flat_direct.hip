@@ -31,7 +31,7 @@ struct DirectArgs {
 	float *pd;
 	int32_t *pi;
 	long long n, split_rows;
-	int nq, k, dp, nsplit, ngroups;
+	int nq, k, dp, nsplit, ngroups, interleaved;
 	SelectorDev sel;
 	const long long *idmap;
 };
@@ -128,10 +128,24 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 			const int f = i * 256 + tid;
 			const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
 			float *p = dst + row * LDA + c4 * 4;
-			p[0] = stg[i].x;
-			p[1] = stg[i].y;
-			p[2] = stg[i].z;
-			p[3] = stg[i].w;
+			// back to natural k order (FlatGeom::pair_interleaved; tiles start at multiples of 256 rows, so bit 4
+			// of the global row index is bit 4 of the tile row)
+			if (!a.interleaved) {
+				p[0] = stg[i].x;
+				p[1] = stg[i].y;
+				p[2] = stg[i].z;
+				p[3] = stg[i].w;
+			} else if (row & 16) { // stored [k1,k3,k0,k2]
+				p[0] = stg[i].z;
+				p[1] = stg[i].x;
+				p[2] = stg[i].w;
+				p[3] = stg[i].y;
+			} else { // stored [k0,k2,k1,k3]
+				p[0] = stg[i].x;
+				p[1] = stg[i].z;
+				p[2] = stg[i].y;
+				p[3] = stg[i].w;
+			}
 		}
 	};
 
@@ -360,6 +374,7 @@ void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, b
 	a.nq = (int)nq;
 	a.k = (int)k;
 	a.dp = g.dp;
+	a.interleaved = g.pair_interleaved ? 1 : 0;
 	a.nsplit = p.nsplit;
 	a.ngroups = (int)((nq + p.qgroup - 1) / p.qgroup);
 	a.sel = sel;

@@ -184,19 +184,28 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(1))) const float glb_f32;
 
-template <int KSTEPS, bool IS_L2>
+// ABL (ablation builds for profiling only; results are WRONG when != 0): bit0 = skip the epilogue,
+// bit1 = stage only the first tile, bit2 = reuse the first A-fragment group for every MFMA (no ds_reads)
+template <int KSTEPS, bool IS_L2, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
 	constexpr int NT = 2, KC = 2 * KSTEPS, BN = 64;
-	constexpr int SEGS = (KC + 63) / 64; // 64-float LDS-DMA pieces per row (always whole: EXEC stays full)
-	constexpr int LDA = SEGS * 64 + 1;   // a piece may run past the row's KC floats into columns nobody reads
-	constexpr int G = KSTEPS >= 8 ? 4 : KSTEPS; // k-steps per A-fragment group
-	constexpr int NG = KSTEPS / G;
-	static_assert(KSTEPS % 4 == 0 && KSTEPS % G == 0, "");
+	// LDS image of a tile: [64 rows][C 16-byte chunks], UNPADDED so that one LDS-DMA dwordx4 instruction (1 KiB per
+	// wave) lands whole; bank conflicts are removed by an XOR swizzle of the chunk position, applied on the SOURCE
+	// address of the DMA and again on the ds_read_b128 address (cdna_hip_programming.md rule 21):
+	//   chunk cg of row r lives at position cg ^ f(r),  f(r) = (r / R) & (min(C,16)-1),  R = max(1, 16/C)
+	// => the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank row.
+	constexpr int C = KC / 4;                    // chunks per row
+	constexpr int R = C >= 16 ? 1 : 16 / C;      // rows per 256-byte bank row
+	constexpr int FM = (C >= 16 ? 16 : C) - 1;   // swizzle mask
+	constexpr int NDMA = (BN * KC * 4) / 1024;   // LDS-DMA instructions per tile (whole workgroup)
+	constexpr int CG = C >= 2 ? 2 : 1;           // chunks per A-fragment group (= 4 k-steps)
+	constexpr int NG = C / CG;
+	static_assert(KSTEPS % 4 == 0 && (BN * KC * 4) % 1024 == 0, "");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
-	float *tbuf = smem;                // [2][BN][LDA]
-	float *nbuf = smem + 2 * BN * LDA; // [2][BN]
-	float *ld = nbuf + 2 * BN;         // [128][k]
+	float *tbuf = smem;               // [2][BN][KC]  (swizzled, see above)
+	float *nbuf = smem + 2 * BN * KC; // [2][BN]
+	float *ld = nbuf + 2 * BN;        // [128][k]
 	int *li = (int *)(ld + QBLOCK * a.k);
 	float *lthr = (float *)(li + QBLOCK * a.k);
 	int *lthrid = (int *)(lthr + QBLOCK);
@@ -248,28 +257,30 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 		qf[4 * s4 + 3] = v.w;
 	}
 
-	// LDS-DMA staging: wave w moves rows [16w, 16w+16) of the tile; one instruction = 64 consecutive floats of
-	// one row (the padded row stride keeps every piece inside its row)
+	// LDS-DMA staging: instruction i of the tile fills LDS bytes [1024 i, 1024 i + 1024); lane l owns chunk 64 i + l
 	auto stage = [&](int tile) {
 		const long long row0 = r_begin + (long long)tile * BN;
-		lds_f32 *dst = (lds_f32 *)smem + (tile & 1) * BN * LDA;
+		lds_f32 *dst = (lds_f32 *)smem + (tile & 1) * BN * KC;
 #pragma unroll
-		for (int rr = 0; rr < 16; ++rr) {
-			const int row = wave * 16 + rr;
-			long long gr = row0 + row;
-			if (gr >= a.n)
-				gr = a.n - 1; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
-			const float *src = a.yb + (size_t)gr * a.dp;
-#pragma unroll
-			for (int sg = 0; sg < SEGS; ++sg)
-				__builtin_amdgcn_global_load_lds((glb_f32 *)(src + sg * 64 + lane), dst + row * LDA + sg * 64, 4, 0, 0);
+		for (int i = 0; i < (NDMA + 3) / 4; ++i) {
+			const int inst = i * 4 + wave;
+			if (NDMA % 4 == 0 || inst < NDMA) {
+				const int L = inst * 64 + lane; // chunk slot in the LDS image
+				const int r = L / C, p = L % C;
+				const int cg = p ^ ((r / R) & FM);
+				long long gr = row0 + r;
+				if (gr >= a.n)
+					gr = a.n - 1; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
+				__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yb + (size_t)gr * a.dp + cg * 4), dst + inst * 256, 16, 0,
+				                                 0);
+			}
 		}
 		if (IS_L2 && wave == 0) {
 			long long gr = row0 + lane;
 			if (gr >= a.n)
 				gr = a.n - 1;
-			__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yn + gr), (lds_f32 *)smem + 2 * BN * LDA + (tile & 1) * BN,
-			                                 4, 0, 0);
+			__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yn + gr), (lds_f32 *)smem + 2 * BN * KC + (tile & 1) * BN, 4,
+			                                 0, 0);
 		}
 	};
 
@@ -279,50 +290,70 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	__syncthreads();
 
 	for (int tile = 0; tile < ntiles; ++tile) {
-		if (tile + 1 < ntiles)
+		if (tile + 1 < ntiles && !(ABL & 2))
 			stage(tile + 1);
 #pragma unroll
 		for (int t = 0; t < NT; ++t)
 #pragma unroll
 			for (int r = 0; r < 16; ++r)
 				acc[t][r] = 0.f;
-		const float *A = tbuf + (tile & 1) * BN * LDA + c * LDA + h;
-		float af[2][NT][G];
+		// A fragments: the database rows are PAIR-INTERLEAVED in HBM (FlatGeom::pair_interleaved), so the two k-steps
+		// a lane half needs from chunk cg -- k = 4cg + h and k = 4cg + 2 + h -- are one aligned 8-byte word at byte
+		// 8 * (h ^ bit4(row)) of the chunk: ds_read_b64, no selects, 32 distinct bank pairs per lane group.
+		const float *Abase = tbuf + ((ABL & 2) ? 0 : (tile & 1)) * BN * KC;
+		const int fsw = (c / R) & FM;
+		static_assert((32 / R) % (FM + 1) == 0, "row t*32 + c must have the same swizzle as row c");
+		const int hoff = 2 * (h ^ ((c >> 4) & 1));
+		float2 af[2][NT][CG];
 #pragma unroll
 		for (int t = 0; t < NT; ++t)
 #pragma unroll
-			for (int s = 0; s < G; ++s)
-				af[0][t][s] = A[t * 32 * LDA + 2 * s];
+			for (int j = 0; j < CG; ++j)
+				af[0][t][j] = *(const float2 *)(Abase + (t * 32 + c) * KC + ((j ^ fsw) * 4) + hoff);
 #pragma unroll
 		for (int g = 0; g < NG; ++g) {
 			// Order pinned with sched_barrier: [first k-step of group g] [ds_reads of group g+1] [rest of group g].
 			// hipcc otherwise sinks each ds_read to just before its MFMA (every MFMA then waits out the LDS
-			// latency), and its s_waitcnt at the head of a group is lgkmcnt(0): issuing the next group's reads one
-			// k-step INTO the group puts >= 6 MFMAs (384 cycles) between those reads and that wait.
+			// latency); issuing the next group's reads one k-step INTO the group puts >= 6 MFMAs (384 cycles)
+			// between those reads and the wait at the head of the next group.
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int t = 0; t < NT; ++t)
-				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][0], qf[g * G], acc[t], 0, 0, 0);
+				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][0].x, qf[g * 2 * CG], acc[t], 0, 0, 0);
 			__builtin_amdgcn_sched_barrier(0);
 			if (g + 1 < NG) {
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
 #pragma unroll
-					for (int s = 0; s < G; ++s)
-						af[(g + 1) & 1][t][s] = A[t * 32 * LDA + 2 * ((g + 1) * G + s)];
+					for (int j = 0; j < CG; ++j)
+						af[(g + 1) & 1][t][j] =
+						    (ABL & 4) ? af[g & 1][t][j]
+						              : *(const float2 *)(Abase + (t * 32 + c) * KC + ((((g + 1) * CG + j) ^ fsw) * 4) + hoff);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int s = 1; s < G; ++s)
+			for (int t = 0; t < NT; ++t)
+				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][0].y, qf[g * 2 * CG + 1], acc[t], 0, 0, 0);
+			if (CG == 2) {
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
-					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][s], qf[g * G + s], acc[t], 0, 0, 0);
+					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][CG - 1].x, qf[g * 2 * CG + 2], acc[t], 0, 0, 0);
+#pragma unroll
+				for (int t = 0; t < NT; ++t)
+					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][CG - 1].y, qf[g * 2 * CG + 3], acc[t], 0, 0, 0);
+			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		const long long row0 = r_begin + (long long)tile * BN;
 		const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
-		tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, a.gthr + q, ld + ql * k,
-		                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+		if (ABL & 1) {
+#pragma unroll
+			for (int t = 0; t < NT; ++t)
+				asm volatile("" ::"v"(acc[t])); // keep the MFMA chain alive
+		} else {
+			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, a.gthr + q,
+			                         ld + ql * k, li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+		}
 		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
 	}
 
@@ -524,7 +555,7 @@ FlatGeom flat_geom_for(int d) {
 	FlatGeom g;
 	g.d = d;
 	if (d <= 128) {
-		static const int kcs[] = {8, 16, 32, 64, 96, 128};
+		static const int kcs[] = {8, 16, 32, 64, 128};
 		g.kc = 128;
 		for (int v : kcs)
 			if (v >= d) {
@@ -534,11 +565,13 @@ FlatGeom flat_geom_for(int d) {
 		g.dp = g.kc;
 		g.nch = 1;
 		g.ntile = 2;
+		g.pair_interleaved = true;
 	} else {
 		g.kc = 32;
 		g.dp = (d + 31) / 32 * 32;
 		g.nch = g.dp / 32;
 		g.ntile = 8;
+		g.pair_interleaved = false;
 	}
 	return g;
 }
@@ -550,8 +583,8 @@ size_t qfrag_floats(const FlatGeom &g, int64_t nq) {
 
 static size_t mfma_lds_bytes(const FlatGeom &g, int64_t k) {
 	const size_t bn = g.bn();
-	// resident v2 kernel: rows padded to whole 64-float LDS-DMA pieces (+1)
-	const size_t lda = g.nch == 1 ? (size_t)((g.kc + 63) / 64 * 64 + 1) : (size_t)(g.kc + 1);
+	// resident kernel: unpadded swizzled rows; streaming kernel: rows padded by one float
+	const size_t lda = g.nch == 1 ? (size_t)g.kc : (size_t)(g.kc + 1);
 	return (2 * bn * lda + 2 * bn) * sizeof(float) + (size_t)QBLOCK * k * 8 + QBLOCK * 12;
 }
 
@@ -594,6 +627,19 @@ int g_mfma_variant = 2; // 1 = register-staged generic kernel, 2 = LDS-DMA + A-r
 
 template <int KSTEPS>
 static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
+	if (KSTEPS == 64 && metric == METRIC_L2 && g_mfma_variant >= 100) { // profiling ablations
+		const int abl = g_mfma_variant - 100;
+#define MVS_ABL(N)                                                                                                     \
+	if (abl == N) {                                                                                                    \
+		auto kern = flat_mfma_resident_kernel<64, true, N>;                                                            \
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes)); \
+		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);                                          \
+	}
+		MVS_ABL(1) MVS_ABL(2) MVS_ABL(3) MVS_ABL(7)
+#undef MVS_ABL
+		MVS_HIP(hipGetLastError());
+		return;
+	}
 	if (metric == METRIC_L2) {
 		auto kern = flat_mfma_resident_kernel<KSTEPS, true>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
@@ -615,11 +661,9 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 template <int KSTEPS, int NT, bool RESIDENT>
 static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
 	if constexpr (RESIDENT) {
-		if (g_mfma_variant == 2) {
-			launch_resident_v2<KSTEPS>(metric, a, p, st);
-			return;
-		}
-	}
+		launch_resident_v2<KSTEPS>(metric, a, p, st);
+		return;
+	} else {
 	if (metric == METRIC_L2) {
 		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, true>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
@@ -636,6 +680,7 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 	}
 	MVS_HIP(hipGetLastError());
+	}
 }
 
 void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
@@ -674,9 +719,6 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 			break;
 		case 64:
 			launch_inst<32, 2, true>(metric, a, p, st);
-			break;
-		case 96:
-			launch_inst<48, 2, true>(metric, a, p, st);
 			break;
 		default:
 			launch_inst<64, 2, true>(metric, a, p, st);

@@ -119,7 +119,7 @@ public:
 	                 const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
 
 private:
-	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr;
+	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add;
 	SelectorHolder selector;
 	hipStream_t last_search_stream = nullptr;
 	void grow(int64_t need, hipStream_t st);

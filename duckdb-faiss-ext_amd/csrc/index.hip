@@ -257,8 +257,6 @@ void FlatIndex::grow(int64_t need, hipStream_t st) {
 	// +64 floats: the LDS-DMA staging reads whole 64-float pieces and may run past the last row
 	MVS_HIP(hipMalloc((void **)&nv, ((size_t)nc * geom.dp + 64) * sizeof(float)));
 	MVS_HIP(hipMalloc((void **)&nn, (size_t)nc * sizeof(float)));
-	if (geom.dp != d) // padding columns must read as zero
-		MVS_HIP(hipMemsetAsync(nv + (size_t)ntotal * geom.dp, 0, (size_t)(nc - ntotal) * geom.dp * sizeof(float), st));
 	if (ntotal > 0) {
 		MVS_HIP(hipMemcpyAsync(nv, vecs, (size_t)ntotal * geom.dp * sizeof(float), hipMemcpyDeviceToDevice, st));
 		MVS_HIP(hipMemcpyAsync(nn, norms, (size_t)ntotal * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -281,22 +279,22 @@ void FlatIndex::add(int64_t n, const float *x) {
 	if (ntotal + n > (int64_t)0x7fffffff - 1024)
 		throw_faiss("mvs::FlatIndex::add", __FILE__, "a single-device shard holds at most 2^31 rows");
 	grow(ntotal + n, stream);
-	// pinned staging in slots of <= SLOT_BYTES; the caller's buffer is free again when we return
+	// pinned staging in slots of <= SLOT_BYTES (the caller's buffer is free again when we return); each slot is
+	// copied H2D into a raw device buffer and re-laid out into the storage format by pack_rows
 	const int64_t rows_per_slot = std::max<int64_t>(1, (int64_t)PinnedRing::SLOT_BYTES / ((int64_t)d * 4));
-	for (int64_t r0 = 0; r0 < n; r0 += rows_per_slot) {
+	ws_add.reserve((size_t)std::min(rows_per_slot, n) * d * sizeof(float) * 2);
+	int flip = 0;
+	for (int64_t r0 = 0; r0 < n; r0 += rows_per_slot, flip ^= 1) {
 		const int64_t nr = std::min(rows_per_slot, n - r0);
 		const size_t bytes = (size_t)nr * d * sizeof(float);
 		const int slot = pinned.acquire(bytes);
 		memcpy(pinned.buf[slot], x + r0 * d, bytes);
-		float *dst = vecs + (size_t)(ntotal + r0) * geom.dp;
-		if (geom.dp == d)
-			MVS_HIP(hipMemcpyAsync(dst, pinned.buf[slot], bytes, hipMemcpyHostToDevice, stream));
-		else
-			MVS_HIP(hipMemcpy2DAsync(dst, (size_t)geom.dp * 4, pinned.buf[slot], (size_t)d * 4, (size_t)d * 4,
-			                         (size_t)nr, hipMemcpyHostToDevice, stream));
+		float *raw = (float *)ws_add.p + (size_t)flip * std::min(rows_per_slot, n) * d;
+		MVS_HIP(hipMemcpyAsync(raw, pinned.buf[slot], bytes, hipMemcpyHostToDevice, stream));
 		pinned.release(slot, stream);
+		launch_pack_rows(geom, raw, nr, vecs + (size_t)(ntotal + r0) * geom.dp, ntotal + r0, stream);
+		launch_query_norms(raw, nr, d, norms + ntotal + r0, stream);
 	}
-	launch_row_norms(vecs + (size_t)ntotal * geom.dp, n, geom.dp, norms + ntotal, stream);
 	ntotal += n;
 }
 
@@ -306,12 +304,8 @@ void FlatIndex::add_device(int64_t n, const float *d_x, hipStream_t st) {
 		return;
 	stream_wait(st, stream); // earlier host-API adds live on our own stream
 	grow(ntotal + n, st);
-	float *dst = vecs + (size_t)ntotal * geom.dp;
-	if (geom.dp == d)
-		MVS_HIP(hipMemcpyAsync(dst, d_x, (size_t)n * d * sizeof(float), hipMemcpyDeviceToDevice, st));
-	else
-		launch_pad_rows(d_x, n, d, dst, geom.dp, st);
-	launch_row_norms(dst, n, geom.dp, norms + ntotal, st);
+	launch_pack_rows(geom, d_x, n, vecs + (size_t)ntotal * geom.dp, ntotal, st);
+	launch_query_norms(d_x, n, d, norms + ntotal, st);
 	stream_wait(stream, st); // later host-API calls see these rows
 	ntotal += n;
 }

@@ -48,6 +48,38 @@ void launch_pad_rows(const float *d_src, int64_t n, int d, float *d_dst, int dp,
 	MVS_HIP(hipGetLastError());
 }
 
+// [n][d] row-major -> storage rows (FlatGeom::pair_interleaved), one thread per 16-byte chunk
+__global__ void pack_rows_kernel(const float *__restrict__ src, long long n, int d, float *__restrict__ dst, int dp,
+                                 long long row0, int interleave) {
+	long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int cpr = dp / 4;
+	if (i >= n * cpr)
+		return;
+	const long long r = i / cpr;
+	const int cg = (int)(i - r * cpr);
+	const float *s = src + r * d + cg * 4;
+	float v[4];
+#pragma unroll
+	for (int e = 0; e < 4; ++e)
+		v[e] = (cg * 4 + e < d) ? s[e] : 0.f;
+	float4 o;
+	if (!interleave)
+		o = make_float4(v[0], v[1], v[2], v[3]);
+	else if (((row0 + r) >> 4) & 1)
+		o = make_float4(v[1], v[3], v[0], v[2]);
+	else
+		o = make_float4(v[0], v[2], v[1], v[3]);
+	((float4 *)dst)[i] = o;
+}
+void launch_pack_rows(const FlatGeom &g, const float *d_src, int64_t n, float *d_dst, int64_t row0, hipStream_t st) {
+	if (n <= 0)
+		return;
+	const long long total = (long long)n * (g.dp / 4);
+	hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_src, (long long)n,
+	                   g.d, d_dst, g.dp, (long long)row0, g.pair_interleaved ? 1 : 0);
+	MVS_HIP(hipGetLastError());
+}
+
 // ---- query packing: [nq][d] -> MFMA B-fragment order + norms -----------------------------------------
 // qf[(((qblk32*nch + ch)*(KSTEPS/4) + s4)*64 + lane)*4 + e] = x[qblk32*32 + (lane&31)][ch*kc + 2*(4*s4+e) + (lane>>5)]
 __global__ void pack_queries_kernel(const float *__restrict__ x, long long nq, int d, int kc, int nch,
@@ -80,6 +112,13 @@ __global__ void query_norms_kernel(const float *__restrict__ x, long long nq, in
 	for (int i = 0; i < d; ++i)
 		acc = fmaf(p[i], p[i], acc);
 	out[q] = acc;
+}
+void launch_query_norms(const float *d_x, int64_t n, int d, float *d_out, hipStream_t st) {
+	if (n <= 0)
+		return;
+	hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, (long long)n, d,
+	                   d_out);
+	MVS_HIP(hipGetLastError());
 }
 void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float *d_qf, float *d_qnorm,
                          hipStream_t st) {
