@@ -103,19 +103,22 @@ __device__ __noinline__ Thr list_insert(float *ld, int *li, int k, int pos, floa
 
 // ---- fused epilogue of one row tile: distances + threshold test (lane-local per query) + rare insertion ----
 // acc[t][r] holds ip(query = lane&31, row = t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)).
-template <int NT, bool IS_L2>
+// gkey = this query's published k-th value (order-preserving key), loaded by the caller at the START of the tile
+// so that the L2/MALL round trip of that load hides under the tile's MFMAs.
+template <int NT, bool IS_L2, bool SKIP_SLOW = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb, long long row0, int nvalid, float xnq,
-                                              float &thr, bool qvalid, unsigned *gthr_q, float *ldq, int *liq, int k,
-                                              float *lthr_q, int *lthrid_q, int *lpos_q, int h) {
+                                              float &thr, bool qvalid, unsigned gkey, unsigned *gthr_q, float *ldq,
+                                              int *liq, int k, float *lthr_q, int *lthrid_q, int *lpos_q, int h) {
 	// threshold broadcast: the best k-th value ANY workgroup has seen for this query bounds the final k-th
 	// value, so a row beyond it can never be in the result (ties with it are kept: <= / >=)
 	float gval = IS_L2 ? FLT_MAX : -FLT_MAX;
 	float teff = thr;
 	if (qvalid) {
-		gval = key2f(__hip_atomic_load(gthr_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		gval = key2f(gkey);
 		teff = IS_L2 ? fminf(thr, next_up_nonneg(gval)) : fmaxf(thr, next_down(gval));
 	}
-	bool any = false;
+	// best value of this lane's NT*16 rows (v_min3 / v_max3: one VALU op per two rows; NaN never wins)
+	float best = IS_L2 ? INFINITY : -INFINITY;
 #pragma unroll
 	for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -125,17 +128,24 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 				y4 = *(const float4 *)(nb + t * 32 + 8 * g + 4 * h);
 			const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				float v = acc[t][4 * g + e];
+			for (int e = 0; e < 4; e += 2) {
+				float v0 = acc[t][4 * g + e], v1 = acc[t][4 * g + e + 1];
 				if (IS_L2) {
-					v = fmaf(-2.0f, v, xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
-					acc[t][4 * g + e] = v;
-					any |= v < teff;
+					v0 = fmaf(-2.0f, v0, xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
+					v1 = fmaf(-2.0f, v1, xnq + yv[e + 1]);
+					acc[t][4 * g + e] = v0;
+					acc[t][4 * g + e + 1] = v1;
+					best = __builtin_fminf(best, __builtin_fminf(v0, v1));
 				} else {
-					any |= v > teff;
+					best = __builtin_fmaxf(best, __builtin_fmaxf(v0, v1));
 				}
 			}
 		}
+	}
+	const bool any = IS_L2 ? best < teff : best > teff;
+	if (SKIP_SLOW) {
+		asm volatile("" ::"v"(any));
+		return;
 	}
 	if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
 		// ---- rare path: exact (value, id) insertion into this wave's per-query lists ----------
@@ -292,6 +302,8 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	for (int tile = 0; tile < ntiles; ++tile) {
 		if (tile + 1 < ntiles && !(ABL & 2))
 			stage(tile + 1);
+		// published k-th value of this lane's query: issued now, consumed in the epilogue
+		const unsigned gkey = qvalid ? __hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
 		for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -351,8 +363,9 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 			for (int t = 0; t < NT; ++t)
 				asm volatile("" ::"v"(acc[t])); // keep the MFMA chain alive
 		} else {
-			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, a.gthr + q,
-			                         ld + ql * k, li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+			tile_epilogue<NT, IS_L2, (ABL & 8) != 0>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
+			                                         a.gthr + q, ld + ql * k, li + ql * k, k, lthr + ql, lthrid + ql,
+			                                         lpos + ql, h);
 		}
 		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
 	}
@@ -529,8 +542,10 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 		if (ch == nch - 1) {
 			const long long row0 = r_begin + (long long)tile * BN;
 			const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
-			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, a.gthr + q, ld + ql * k,
-			                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+			const unsigned gkey =
+			    qvalid ? __hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey, a.gthr + q,
+			                         ld + ql * k, li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
 		}
 
 		if (u + 1 < total_units)
@@ -635,7 +650,7 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes)); \
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);                                          \
 	}
-		MVS_ABL(1) MVS_ABL(2) MVS_ABL(3) MVS_ABL(7)
+		MVS_ABL(1) MVS_ABL(2) MVS_ABL(3) MVS_ABL(8) MVS_ABL(10)
 #undef MVS_ABL
 		MVS_HIP(hipGetLastError());
 		return;
