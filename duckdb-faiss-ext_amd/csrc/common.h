@@ -94,6 +94,7 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
                       int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st);
 int64_t flat_mfma_max_k(const FlatGeom &g);
 extern int g_mfma_variant;
+extern int g_mfma_nsplit;
 
 // direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic
 struct DirectPlan {

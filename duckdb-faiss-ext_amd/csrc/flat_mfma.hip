@@ -36,7 +36,8 @@ struct MfmaArgs {
 	const float *yn; // database norms
 	float *pd;       // partial distances [nsplit][nq][k]
 	int32_t *pi;     // partial row ids
-	unsigned *gthr;  // [nq] order-preserving keys of the best k-th value any workgroup has published
+	unsigned *gslot; // [nq][slot_stride] shared threshold slots (keys); see "threshold sharing" below
+	int slot_stride; // slots per query = k rounded up to a multiple of 16
 	long long n;
 	long long split_rows;
 	int nq, k, nqb, nsplit, dp, nch, xcd_map;
@@ -77,8 +78,10 @@ __device__ __forceinline__ bool cand_better(float v, int id, float tv, int tid) 
 }
 
 // replace the current worst entry of one query's list and find the new worst (rare path)
+// (always inlined: a real call would force every value that lives across it -- query fragments, accumulators --
+// into the callee-saved half of the VGPR file, i.e. spills)
 template <bool IS_L2>
-__device__ __noinline__ Thr list_insert(float *ld, int *li, int k, int pos, float v, int id) {
+__device__ __forceinline__ Thr list_insert(float *ld, int *li, int k, int pos, float v, int id) {
 	ld[pos] = v;
 	li[pos] = id;
 	float wv = ld[0];
@@ -101,23 +104,81 @@ __device__ __noinline__ Thr list_insert(float *ld, int *li, int k, int pos, floa
 }
 
 
+// "smaller is better" order-preserving key of a distance (L2) / score (IP)
+template <bool IS_L2>
+__device__ __forceinline__ unsigned bkey(float v) {
+	return IS_L2 ? f2key(v) : ~f2key(v);
+}
+template <bool IS_L2>
+__device__ __forceinline__ float bkey2f(unsigned k) {
+	return key2f(IS_L2 ? k : ~k);
+}
+
+// Cross-workgroup threshold sharing.  Rows are split into k classes (row id mod k); slot j of a query holds the
+// best value (as a "smaller is better" key) any workgroup has found among rows of class j.  If every slot is set
+// there are k DISTINCT rows with value <= max_j slot_j, so the final k-th best value is <= that maximum: rows
+// beyond it can never be in the result (ties are kept).  Updates are ONE fire-and-forget atomicMin -- no round trip
+// on the inserting wave; readers fetch the slots of their query at the start of a tile (two lanes share a query and
+// each loads half of a 16-slot WINDOW as 8-byte words) and reduce them in the epilogue.  For k > 16 the window
+// rotates: the maximum over all ceil(k/16) windows, read over that many consecutive tiles, becomes the bound for the
+// following tiles (slots only ever decrease, so a maximum assembled from older reads is still conservative).
+// Relaxed agent-scope atomics only: a stale (looser) bound is always safe.  Slots [k, stride) are padding and hold
+// key 0 (never the maximum).
+constexpr int SLOT_WORDS = 4; // 8-byte words per lane: a lane pair covers one 16-slot window per tile
+
+struct SlotRegs {
+	unsigned long long w[SLOT_WORDS];
+};
+__device__ __forceinline__ void slots_prefetch(SlotRegs &sr, const unsigned *gslot_q, int window, int h) {
+	const unsigned long long *src = (const unsigned long long *)(gslot_q + window * 16) + h * SLOT_WORDS;
+#pragma unroll
+	for (int j = 0; j < SLOT_WORDS; ++j)
+		sr.w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// rotating-window state: `run` accumulates the current sweep, `bound` is the last completed sweep's maximum
+struct SlotBound {
+	unsigned run = 0u, bound = 0xFFFFFFFFu;
+};
+__device__ __forceinline__ unsigned slots_update(SlotBound &sb, unsigned part, int window, int nwin) {
+	sb.run = sb.run > part ? sb.run : part;
+	if (window == nwin - 1) { // wave-uniform
+		sb.bound = sb.run;
+		sb.run = 0u;
+	}
+	return sb.bound;
+}
+// max over this lane's words, then with the partner lane (l ^ 32) that holds the other half of the query's slots
+__device__ __forceinline__ unsigned slots_reduce(const SlotRegs &sr) {
+	unsigned m = 0u;
+#pragma unroll
+	for (int j = 0; j < SLOT_WORDS; ++j) {
+		const unsigned lo = (unsigned)sr.w[j], hi = (unsigned)(sr.w[j] >> 32);
+		m = m > lo ? m : lo;
+		m = m > hi ? m : hi;
+	}
+	const unsigned o = (unsigned)__shfl_xor((int)m, 32);
+	return m > o ? m : o;
+}
+
 // ---- fused epilogue of one row tile: distances + threshold test (lane-local per query) + rare insertion ----
 // acc[t][r] holds ip(query = lane&31, row = t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)).
-// gkey = this query's published k-th value (order-preserving key), loaded by the caller at the START of the tile
-// so that the L2/MALL round trip of that load hides under the tile's MFMAs.
+// gkey = this query's shared bound (from the slot words the caller prefetched at the START of the tile, so that the
+// L2/MALL round trip hides under the tile's MFMAs); all-ones until the first sweep over the slots is complete.
 template <int NT, bool IS_L2, bool SKIP_SLOW = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb, long long row0, int nvalid, float xnq,
-                                              float &thr, bool qvalid, unsigned gkey, unsigned *gthr_q, float *ldq,
-                                              int *liq, int k, float *lthr_q, int *lthrid_q, int *lpos_q, int h) {
-	// threshold broadcast: the best k-th value ANY workgroup has seen for this query bounds the final k-th
-	// value, so a row beyond it can never be in the result (ties with it are kept: <= / >=)
+                                              float &thr, bool qvalid, unsigned gkey, unsigned *gslot_q,
+                                              float *ldq, int *liq, int k, float *lthr_q, int *lthrid_q, int *lpos_q,
+                                              int h) {
 	float gval = IS_L2 ? FLT_MAX : -FLT_MAX;
 	float teff = thr;
 	if (qvalid) {
-		gval = key2f(gkey);
+		const unsigned neutral_key = bkey<IS_L2>(IS_L2 ? FLT_MAX : -FLT_MAX);
+		gval = bkey2f<IS_L2>(gkey < neutral_key ? gkey : neutral_key);
+		// ties with the shared threshold are kept (<= / >=): one strict compare against its float neighbour
 		teff = IS_L2 ? fminf(thr, next_up_nonneg(gval)) : fmaxf(thr, next_down(gval));
 	}
-	// best value of this lane's NT*16 rows (v_min3 / v_max3: one VALU op per two rows; NaN never wins)
+	// best value of each group of 4 rows (kept for the rare path), then of all NT*16 rows.  NaN never wins.
+	float gm[NT][4];
 	float best = IS_L2 ? INFINITY : -INFINITY;
 #pragma unroll
 	for (int t = 0; t < NT; ++t) {
@@ -127,20 +188,26 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 			if (IS_L2)
 				y4 = *(const float4 *)(nb + t * 32 + 8 * g + 4 * h);
 			const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+			float v[4];
 #pragma unroll
-			for (int e = 0; e < 4; e += 2) {
-				float v0 = acc[t][4 * g + e], v1 = acc[t][4 * g + e + 1];
+			for (int e = 0; e < 4; ++e) {
+				v[e] = acc[t][4 * g + e];
 				if (IS_L2) {
-					v0 = fmaf(-2.0f, v0, xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
-					v1 = fmaf(-2.0f, v1, xnq + yv[e + 1]);
-					acc[t][4 * g + e] = v0;
-					acc[t][4 * g + e + 1] = v1;
-					best = __builtin_fminf(best, __builtin_fminf(v0, v1));
-				} else {
-					best = __builtin_fmaxf(best, __builtin_fmaxf(v0, v1));
+					v[e] = fmaf(-2.0f, v[e], xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
+					acc[t][4 * g + e] = v[e];
 				}
 			}
+			if (IS_L2)
+				gm[t][g] = __builtin_fminf(__builtin_fminf(v[0], v[1]), __builtin_fminf(v[2], v[3]));
+			else
+				gm[t][g] = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3]));
 		}
+		if (IS_L2)
+			best = __builtin_fminf(
+			    best, __builtin_fminf(__builtin_fminf(gm[t][0], gm[t][1]), __builtin_fminf(gm[t][2], gm[t][3])));
+		else
+			best = __builtin_fmaxf(
+			    best, __builtin_fmaxf(__builtin_fmaxf(gm[t][0], gm[t][1]), __builtin_fmaxf(gm[t][2], gm[t][3])));
 	}
 	const bool any = IS_L2 ? best < teff : best > teff;
 	if (SKIP_SLOW) {
@@ -149,32 +216,65 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 	}
 	if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
 		// ---- rare path: exact (value, id) insertion into this wave's per-query lists ----------
+		// The lane's passing rows (against the thresholds at entry, T0) are numbered in scan order; each pass of the
+		// loop below compacts the next two of them into registers (all indices static: no scratch, no calls inside
+		// the unrolled scan) and inserts them.  Usually one lane has one candidate and one pass suffices.
+		const float T0 = gval;
 		for (int hh = 0; hh < 2; ++hh) { // lanes l and l+32 share a query: take turns
-			if (h == hh) {
+			const bool mine = any && h == hh;
+			if (__builtin_amdgcn_ballot_w64(mine) == 0ull)
+				continue;
+			if (mine) {
 				Thr cur;
 				cur.v = *lthr_q;
 				cur.id = *lthrid_q;
 				cur.pos = *lpos_q;
+				float T = T0;
+				int done = 0, npass;
+				do {
+					float cv0 = 0.f, cv1 = 0.f;
+					int cid0 = 0, cid1 = 0;
+					npass = 0;
 #pragma unroll
-				for (int t = 0; t < NT; ++t) {
+					for (int t = 0; t < NT; ++t) {
 #pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						float v = acc[t][r];
-						if (IS_L2)
-							v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
-						const int rl = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-						const int id = (int)(row0 + rl);
-						if (rl < nvalid && (IS_L2 ? v <= gval : v >= gval) && cand_better<IS_L2>(v, id, cur.v, cur.id))
-							cur = list_insert<IS_L2>(ldq, liq, k, cur.pos, v, id);
+						for (int g = 0; g < 4; ++g) {
+							if (IS_L2 ? gm[t][g] <= T0 : gm[t][g] >= T0) {
+#pragma unroll
+								for (int e = 0; e < 4; ++e) {
+									float v = acc[t][4 * g + e];
+									if (IS_L2)
+										v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
+									const int rl = t * 32 + e + 8 * g + 4 * h;
+									if (rl < nvalid && (IS_L2 ? v <= T0 : v >= T0)) {
+										if (npass == done) {
+											cv0 = v;
+											cid0 = (int)(row0 + rl);
+										} else if (npass == done + 1) {
+											cv1 = v;
+											cid1 = (int)(row0 + rl);
+										}
+										++npass;
+									}
+								}
+							}
+						}
 					}
-				}
-				if (cur.v != *lthr_q && qvalid) {
-					// publish this workgroup's k-th value (neutral while the list is not full: a no-op)
-					if (IS_L2)
-						__hip_atomic_fetch_min(gthr_q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					else
-						__hip_atomic_fetch_max(gthr_q, f2key(cur.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
+#pragma unroll 1
+					for (int i = 0; i < 2; ++i) { // a real loop: ONE inlined copy of the insertion code
+						if (done + i < npass) {
+							const float v = i ? cv1 : cv0;
+							const int id = i ? cid1 : cid0;
+							if ((IS_L2 ? v <= T : v >= T) && cand_better<IS_L2>(v, id, cur.v, cur.id)) {
+								cur = list_insert<IS_L2>(ldq, liq, k, cur.pos, v, id);
+								// publish: best value of this row's class (fire and forget)
+								__hip_atomic_fetch_min(gslot_q + (unsigned)id % (unsigned)k, bkey<IS_L2>(v), __ATOMIC_RELAXED,
+									                       __HIP_MEMORY_SCOPE_AGENT);
+							}
+						}
+					}
+					done += 2;
+				} while (done < npass);
 				*lthr_q = cur.v;
 				*lthrid_q = cur.id;
 				*lpos_q = cur.pos;
@@ -221,7 +321,8 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	int *lthrid = (int *)(lthr + QBLOCK);
 	int *lpos = lthrid + QBLOCK;
 
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: stays in SGPRs
 	const int h = lane >> 5, c = lane & 31;
 	const int k = a.k;
 	int split, qb;
@@ -236,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	const int ql = wave * WAVE_Q + c;
 	const int q = qb * QBLOCK + ql;
 	const bool qvalid = q < a.nq;
+	const int nwin = a.slot_stride >> 4; // 16-slot windows of the shared threshold slots
 	const int qblk32 = qb * 4 + wave;
 	const long long r_begin = (long long)split * a.split_rows;
 	long long r_end = r_begin + a.split_rows;
@@ -267,26 +369,35 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 		qf[4 * s4 + 3] = v.w;
 	}
 
-	// LDS-DMA staging: instruction i of the tile fills LDS bytes [1024 i, 1024 i + 1024); lane l owns chunk 64 i + l
-	auto stage = [&](int tile) {
-		const long long row0 = r_begin + (long long)tile * BN;
-		lds_f32 *dst = (lds_f32 *)smem + (tile & 1) * BN * KC;
-#pragma unroll
-		for (int i = 0; i < (NDMA + 3) / 4; ++i) {
-			const int inst = i * 4 + wave;
-			if (NDMA % 4 == 0 || inst < NDMA) {
-				const int L = inst * 64 + lane; // chunk slot in the LDS image
-				const int r = L / C, p = L % C;
-				const int cg = p ^ ((r / R) & FM);
-				long long gr = row0 + r;
-				if (gr >= a.n)
-					gr = a.n - 1; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
-				__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yb + (size_t)gr * a.dp + cg * 4), dst + inst * 256, 16, 0,
-				                                 0);
-			}
+	// LDS-DMA staging: instruction `inst` of a tile fills LDS bytes [1024 inst, 1024 inst + 1024); lane l owns
+	// chunk slot 64 inst + l.  Wave w issues instructions w, w+4, ... -- ONE per A-fragment group of the MFMA loop,
+	// so that the ~100-cycle issue cost of an LDS-DMA instruction hides under the MFMA issued just before it.
+	constexpr int DMA_PER_WAVE = (NDMA + 3) / 4;
+	static_assert(DMA_PER_WAVE <= NG, "one LDS-DMA instruction per MFMA group");
+	auto dma_issue = [&](int tile, int i) {
+		const int inst = i * 4 + wave;
+		if (NDMA % 4 == 0 || inst < NDMA) {
+			const long long row0 = r_begin + (long long)tile * BN;
+			// per-lane part recomputed at every issue from an opaque copy of the lane id: hipcc would otherwise hoist
+			// the DMA_PER_WAVE loop-invariant offsets out of the tile loop and spill them (and reload them with a
+			// vmcnt(0) in the MFMA loop)
+			int lane_o = lane;
+			asm volatile("" : "+v"(lane_o));
+			const int L = inst * 64 + lane_o; // chunk slot in the LDS image
+			int r = L / C;
+			const int p = L % C;
+			const int cg = p ^ ((r / R) & FM);
+			const long long lim = a.n - 1 - row0; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
+			r = r < lim ? r : (int)lim;
+			const char *base = (const char *)(a.yb + (size_t)row0 * a.dp); // wave-uniform
+			const unsigned boff = (unsigned)(r * a.dp + cg * 4) * 4u;
+			__builtin_amdgcn_global_load_lds((glb_f32 *)(base + boff),
+			                                 (lds_f32 *)smem + (tile & 1) * BN * KC + inst * 256, 16, 0, 0);
 		}
+	};
+	auto dma_norms = [&](int tile) {
 		if (IS_L2 && wave == 0) {
-			long long gr = row0 + lane;
+			long long gr = r_begin + (long long)tile * BN + lane;
 			if (gr >= a.n)
 				gr = a.n - 1;
 			__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yn + gr), (lds_f32 *)smem + 2 * BN * KC + (tile & 1) * BN, 4,
@@ -295,15 +406,19 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	};
 
 	f32x16 acc[NT];
-	if (ntiles > 0)
-		stage(0);
+	SlotBound sbound;
+	if (ntiles > 0) {
+#pragma unroll
+		for (int i = 0; i < DMA_PER_WAVE; ++i)
+			dma_issue(0, i);
+		dma_norms(0);
+	}
 	__syncthreads();
 
 	for (int tile = 0; tile < ntiles; ++tile) {
-		if (tile + 1 < ntiles && !(ABL & 2))
-			stage(tile + 1);
-		// published k-th value of this lane's query: issued now, consumed in the epilogue
-		const unsigned gkey = qvalid ? __hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		const bool stage_next = tile + 1 < ntiles && !(ABL & 2);
+		SlotRegs sr;
+		const int window = tile % nwin;
 #pragma unroll
 		for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -324,23 +439,35 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 				af[0][t][j] = *(const float2 *)(Abase + (t * 32 + c) * KC + ((j ^ fsw) * 4) + hoff);
 #pragma unroll
 		for (int g = 0; g < NG; ++g) {
-			// Order pinned with sched_barrier: [first k-step of group g] [ds_reads of group g+1] [rest of group g].
-			// hipcc otherwise sinks each ds_read to just before its MFMA (every MFMA then waits out the LDS
-			// latency); issuing the next group's reads one k-step INTO the group puts >= 6 MFMAs (384 cycles)
-			// between those reads and the wait at the head of the next group.
+			// Order pinned with sched_barrier: [first k-step of group g] [ds_reads of group g+1, one LDS-DMA piece of
+			// the next tile] [rest of group g].  hipcc otherwise sinks each ds_read to just before its MFMA (every
+			// MFMA then waits out the LDS latency); issuing the next group's reads one k-step INTO the group puts
+			// >= 6 MFMAs (384 cycles) between those reads and the wait at the head of the next group.
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int t = 0; t < NT; ++t)
 				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][0].x, qf[g * 2 * CG], acc[t], 0, 0, 0);
 			__builtin_amdgcn_sched_barrier(0);
 			if (g + 1 < NG) {
+				// the swizzled chunk offsets are recomputed per group from an opaque copy of the swizzle (2 VALU per
+				// read pair): hipcc would otherwise hoist all C of them out of the tile loop and spill
+				int fo = fsw;
+				asm volatile("" : "+v"(fo));
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
 #pragma unroll
 					for (int j = 0; j < CG; ++j)
 						af[(g + 1) & 1][t][j] =
 						    (ABL & 4) ? af[g & 1][t][j]
-						              : *(const float2 *)(Abase + (t * 32 + c) * KC + ((((g + 1) * CG + j) ^ fsw) * 4) + hoff);
+						              : *(const float2 *)(Abase + (t * 32 + c) * KC + ((((g + 1) * CG + j) ^ fo) * 4) + hoff);
+			}
+			if (g < DMA_PER_WAVE && stage_next)
+				dma_issue(tile + 1, g);
+			if (g == 0) {
+				if (stage_next)
+					dma_norms(tile + 1);
+				// shared threshold slots of this lane's query: issued now, reduced in the epilogue
+				slots_prefetch(sr, a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, window, h);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -349,10 +476,12 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 			if (CG == 2) {
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
-					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][CG - 1].x, qf[g * 2 * CG + 2], acc[t], 0, 0, 0);
+					acc[t] =
+					    __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][CG - 1].x, qf[g * 2 * CG + 2], acc[t], 0, 0, 0);
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
-					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][CG - 1].y, qf[g * 2 * CG + 3], acc[t], 0, 0, 0);
+					acc[t] =
+					    __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][CG - 1].y, qf[g * 2 * CG + 3], acc[t], 0, 0, 0);
 			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
@@ -363,9 +492,10 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 			for (int t = 0; t < NT; ++t)
 				asm volatile("" ::"v"(acc[t])); // keep the MFMA chain alive
 		} else {
+			const unsigned gkey = slots_update(sbound, slots_reduce(sr), window, nwin);
 			tile_epilogue<NT, IS_L2, (ABL & 8) != 0>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
-			                                         a.gthr + q, ld + ql * k, li + ql * k, k, lthr + ql, lthrid + ql,
-			                                         lpos + ql, h);
+			                                         a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k,
+			                                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
 		}
 		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
 	}
@@ -395,7 +525,8 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 	int *lthrid = (int *)(lthr + QBLOCK);
 	int *lpos = lthrid + QBLOCK;
 
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: stays in SGPRs
 	const int h = lane >> 5, c = lane & 31;
 	const int k = a.k;
 
@@ -411,6 +542,7 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 	const int ql = wave * WAVE_Q + c; // query slot inside the block
 	const int q = qb * QBLOCK + ql;
 	const bool qvalid = q < a.nq;
+	const int nwin = a.slot_stride >> 4; // 16-slot windows of the shared threshold slots
 	const int qblk32 = qb * 4 + wave;
 
 	const long long r_begin = (long long)split * a.split_rows;
@@ -492,6 +624,7 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 	};
 
 	f32x16 acc[NT];
+	SlotBound sbound;
 
 	if (total_units > 0) {
 		stage_load(0);
@@ -542,10 +675,13 @@ __global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const 
 		if (ch == nch - 1) {
 			const long long row0 = r_begin + (long long)tile * BN;
 			const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
-			const unsigned gkey =
-			    qvalid ? __hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey, a.gthr + q,
-			                         ld + ql * k, li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+			SlotRegs sr;
+			const int window = tile % nwin;
+			slots_prefetch(sr, a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, window, h);
+			const unsigned gkey = slots_update(sbound, slots_reduce(sr), window, nwin);
+			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
+			                         a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k, li + ql * k, k,
+			                         lthr + ql, lthrid + ql, lpos + ql, h);
 		}
 
 		if (u + 1 < total_units)
@@ -608,22 +744,47 @@ int64_t flat_mfma_max_k(const FlatGeom &g) {
 	return (int64_t)((160 * 1024 - fixed) / (QBLOCK * 8));
 }
 
+int g_mfma_nsplit = 0; // 0 = heuristic; >0 forces the split count (tuning / tests)
+
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
 	FlatSearchPlan p;
 	p.nqb = (int)((nq + QBLOCK - 1) / QBLOCK);
 	const int bn = g.bn();
 	const int64_t ntiles = (n + bn - 1) / bn;
-	int64_t nsplit = 2048 / (p.nqb > 0 ? p.nqb : 1); // ~4 rounds of 512 resident workgroups
-	const int64_t min_tiles = 16;                     // amortise list warm-up per split
-	if (nsplit > ntiles / min_tiles)
-		nsplit = ntiles / min_tiles;
-	if (nsplit < 1)
-		nsplit = 1;
+	// The grid is nqb x nsplit workgroups over 512 resident slots (2 per CU).  Thresholds are shared across
+	// workgroups, so extra splits cost little; what matters is that the LAST round of workgroups is nearly full:
+	// pick the split count (a multiple of 8: one XCD per split residue, see xcd_map) whose grid wastes the least.
+	const int64_t slots = (g.nch == 1 ? 2 : 1) * 256;
+	const int64_t min_tiles = 16; // amortise the per-workgroup prologue
+	int64_t max_split = ntiles / min_tiles;
+	if (max_split > 128)
+		max_split = 128;
+	int64_t nsplit = 1;
 	p.xcd_map = false;
-	if (nsplit >= 8) {
-		nsplit = nsplit / 8 * 8;
-		p.xcd_map = true;
+	if (g_mfma_nsplit > 0) {
+		nsplit = g_mfma_nsplit;
+	} else if (max_split >= 8) {
+		double best_eff = -1;
+		for (int64_t s = 8; s <= max_split; s += 8) {
+			const int64_t w = s * p.nqb;
+			if (w < slots && s + 8 <= max_split)
+				continue; // fill the chip first
+			const int64_t rounds = (w + slots - 1) / slots;
+			double eff = (double)w / (double)(rounds * slots);
+			// mild preference for >= 3 rounds (tail of the last round averages out) and fewer splits
+			if (rounds < 3)
+				eff -= 0.03 * (3 - rounds);
+			eff -= 1e-4 * s;
+			if (eff > best_eff) {
+				best_eff = eff;
+				nsplit = s;
+			}
+		}
+	} else if (max_split >= 1) {
+		nsplit = max_split;
 	}
+	if (nsplit >= 8 && nsplit % 8 == 0)
+		p.xcd_map = true;
 	int64_t tiles_per_split = ntiles > 0 ? (ntiles + nsplit - 1) / nsplit : 1;
 	p.split_rows = tiles_per_split * bn;
 	p.nsplit = (int)nsplit;
@@ -632,10 +793,14 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	return p;
 }
 
-__global__ void init_gthr_kernel(unsigned *g, int nq, int is_l2) {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < nq)
-		g[i] = f2key(is_l2 ? FLT_MAX : -FLT_MAX);
+// slots [0,k) of every query = key of the neutral value (nothing found yet); padding slots = 0
+__global__ void init_gslot_kernel(unsigned *g, long long total, int stride, int k, int is_l2) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < total)
+		g[i] = (int)(i % stride) < k ? (is_l2 ? f2key(FLT_MAX) : ~f2key(-FLT_MAX)) : 0u;
+}
+int flat_mfma_slot_stride(int64_t k) {
+	return (int)((k + 15) / 16 * 16);
 }
 
 int g_mfma_variant = 2; // 1 = register-staged generic kernel, 2 = LDS-DMA + A-ring resident kernel
@@ -702,10 +867,14 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
                       int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st) {
 	if (nq <= 0)
 		return;
-	hipLaunchKernelGGL(init_gthr_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_gthr, (int)nq,
-	                   metric == METRIC_L2 ? 1 : 0);
+	const int stride = flat_mfma_slot_stride(k);
+	const long long gtotal = (long long)nq * stride;
+	if (gtotal > 0)
+		hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal,
+		                   stride, (int)k, metric == METRIC_L2 ? 1 : 0);
 	MfmaArgs a;
-	a.gthr = d_gthr;
+	a.gslot = d_gthr;
+	a.slot_stride = stride;
 	a.qf = d_qf;
 	a.qn = d_qnorm;
 	a.yb = db.vecs;

@@ -384,7 +384,7 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		launch_pack_queries(geom, d_x, nq, (float *)ws_q.p, (float *)ws_qn.p, st);
 		ws_pd.reserve((size_t)p.nsplit * nq * k * sizeof(float));
 		ws_pi.reserve((size_t)p.nsplit * nq * k * sizeof(int32_t));
-		ws_gthr.reserve((size_t)nq * sizeof(unsigned));
+		ws_gthr.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64); // shared threshold slots
 		begin_kernel_timing(st);
 		launch_flat_mfma(geom, p, metric, (const float *)ws_q.p, (const float *)ws_qn.p, nq, db, k, (float *)ws_pd.p,
 		                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
@@ -819,6 +819,10 @@ namespace mvs {
 bool FlatIndex::set_option(const char *key, int64_t v) {
 	if (!strcmp(key, "force_direct")) {
 		force_direct = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "mfma_nsplit")) {
+		g_mfma_nsplit = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "mfma_variant")) { // A/B switch between kernel generations (process-wide)
