@@ -179,6 +179,14 @@ def main():
         # ---- roofline of the dominant kernel (per launch, HIP events on the launch stream) ----------
         if n_launch > 0 and kern_ms > 0:
             avg_ms = kern_ms / n_launch
+            # HBM bytes per launch come from the committed PMC passes of this same workload (PMC counters cannot be
+            # collected from inside the process); null for any other workload
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            if os.path.exists(tpath) and world == 1 and chunk == nq:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == "%s %s d=%d N=%d nq=%d k=%d" % (args.index, args.metric, d, n, nq, k):
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r1_traffic.json (" + tj["source"] + ")"
             if kinfo["name"].startswith("flat_mfma"):
                 achieved = kinfo["flops"] / (avg_ms * 1e-3) / 1e12
                 out["roofline"] = {
@@ -188,7 +196,8 @@ def main():
                     "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": None,
+                    "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 4),
                     "launches": n_launch,
                     "algorithmic_flops_per_launch": kinfo["flops"],
@@ -219,7 +228,7 @@ def main():
             xb_h = gen_h(n, d, DB_SEED)
             xq_h = gen_h(nq, d, Q_SEED)
             cores = orc.num_threads()
-            nq_cpu, t_cpu, done = 1536, 0.0, 0
+            nq_cpu, t_cpu, done = 4096, 0.0, 0
             hits = total = 0
             labels_equal = True
             while t_cpu < args.cpu_seconds and done < nq:

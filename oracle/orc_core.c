@@ -276,60 +276,61 @@ static void search_pair(int metric, int d, int64_t nb, const float *xb, int64_t 
 }
 
 /* BLAS path: utils/distances.cpp exhaustive_{L2sqr,inner_product}_blas.
- * FAISS: query blocks of 4096 (distance_compute_blas_query_bs) x database blocks of
- * 1024 (distance_compute_blas_database_bs); ip = sgemm; dis = xn + yn - 2 ip, clamp at 0.
- * Here sgemm is a packed AVX2 micro-kernel whose per-element arithmetic is the
- * k-ordered fma chain (bitwise equal to ip_chain). */
-#define BLAS_QBS 4096
-#define BLAS_DBS 1024
-#define PANEL 16
-#define MR 6
+ * FAISS: ip = sgemm over (4096-query x 1024-row) blocks; dis = xn + yn - 2 ip, clamped at 0; every query's
+ * heap sees the rows in ascending order (HeapBlockResultHandler::add_results).
+ * Here "sgemm" is an AVX2 micro-kernel whose per-element arithmetic is the k-ordered fma chain (bitwise equal
+ * to ip_chain): the vector lanes run across QUERIES (queries packed k-major once), database rows are streamed
+ * row-major and broadcast, so no per-block packing or barrier is needed; one thread owns a group of queries
+ * and walks the database front to back, which keeps FAISS's arrival order per query exactly. */
+#define BLAS_DBS 1024 /* rows per ip buffer refill (distance_compute_blas_database_bs) */
+#define MRW 6         /* database rows per micro-kernel call */
 
-static inline void mk_6x16(int d, const float *x0, int64_t ldx, const float *yt, float *out, int64_t ldo) {
+/* ip[r][q] for 16 queries (xt: [d][16], k-major) x MRW rows (row-major, stride ldy) */
+static inline void mk_q16(int d, const float *xt, const float *y0, int64_t ldy, float *out /* [MRW][16] */) {
 	__m256 a00 = _mm256_setzero_ps(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00;
 	__m256 a30 = a00, a31 = a00, a40 = a00, a41 = a00, a50 = a00, a51 = a00;
-	const float *x1 = x0 + ldx, *x2 = x1 + ldx, *x3 = x2 + ldx, *x4 = x3 + ldx, *x5 = x4 + ldx;
+	const float *y1 = y0 + ldy, *y2 = y1 + ldy, *y3 = y2 + ldy, *y4 = y3 + ldy, *y5 = y4 + ldy;
 	for (int k = 0; k < d; k++) {
-		__m256 y0 = _mm256_loadu_ps(yt + (size_t)k * PANEL), y1 = _mm256_loadu_ps(yt + (size_t)k * PANEL + 8);
+		const __m256 x0 = _mm256_loadu_ps(xt + (size_t)k * 16), x1 = _mm256_loadu_ps(xt + (size_t)k * 16 + 8);
 		__m256 b;
-		b = _mm256_broadcast_ss(x0 + k);
-		a00 = _mm256_fmadd_ps(b, y0, a00);
-		a01 = _mm256_fmadd_ps(b, y1, a01);
-		b = _mm256_broadcast_ss(x1 + k);
-		a10 = _mm256_fmadd_ps(b, y0, a10);
-		a11 = _mm256_fmadd_ps(b, y1, a11);
-		b = _mm256_broadcast_ss(x2 + k);
-		a20 = _mm256_fmadd_ps(b, y0, a20);
-		a21 = _mm256_fmadd_ps(b, y1, a21);
-		b = _mm256_broadcast_ss(x3 + k);
-		a30 = _mm256_fmadd_ps(b, y0, a30);
-		a31 = _mm256_fmadd_ps(b, y1, a31);
-		b = _mm256_broadcast_ss(x4 + k);
-		a40 = _mm256_fmadd_ps(b, y0, a40);
-		a41 = _mm256_fmadd_ps(b, y1, a41);
-		b = _mm256_broadcast_ss(x5 + k);
-		a50 = _mm256_fmadd_ps(b, y0, a50);
-		a51 = _mm256_fmadd_ps(b, y1, a51);
+		b = _mm256_broadcast_ss(y0 + k);
+		a00 = _mm256_fmadd_ps(x0, b, a00);
+		a01 = _mm256_fmadd_ps(x1, b, a01);
+		b = _mm256_broadcast_ss(y1 + k);
+		a10 = _mm256_fmadd_ps(x0, b, a10);
+		a11 = _mm256_fmadd_ps(x1, b, a11);
+		b = _mm256_broadcast_ss(y2 + k);
+		a20 = _mm256_fmadd_ps(x0, b, a20);
+		a21 = _mm256_fmadd_ps(x1, b, a21);
+		b = _mm256_broadcast_ss(y3 + k);
+		a30 = _mm256_fmadd_ps(x0, b, a30);
+		a31 = _mm256_fmadd_ps(x1, b, a31);
+		b = _mm256_broadcast_ss(y4 + k);
+		a40 = _mm256_fmadd_ps(x0, b, a40);
+		a41 = _mm256_fmadd_ps(x1, b, a41);
+		b = _mm256_broadcast_ss(y5 + k);
+		a50 = _mm256_fmadd_ps(x0, b, a50);
+		a51 = _mm256_fmadd_ps(x1, b, a51);
 	}
 	_mm256_storeu_ps(out, a00);
 	_mm256_storeu_ps(out + 8, a01);
-	_mm256_storeu_ps(out + ldo, a10);
-	_mm256_storeu_ps(out + ldo + 8, a11);
-	_mm256_storeu_ps(out + 2 * ldo, a20);
-	_mm256_storeu_ps(out + 2 * ldo + 8, a21);
-	_mm256_storeu_ps(out + 3 * ldo, a30);
-	_mm256_storeu_ps(out + 3 * ldo + 8, a31);
-	_mm256_storeu_ps(out + 4 * ldo, a40);
-	_mm256_storeu_ps(out + 4 * ldo + 8, a41);
-	_mm256_storeu_ps(out + 5 * ldo, a50);
-	_mm256_storeu_ps(out + 5 * ldo + 8, a51);
+	_mm256_storeu_ps(out + 16, a10);
+	_mm256_storeu_ps(out + 24, a11);
+	_mm256_storeu_ps(out + 32, a20);
+	_mm256_storeu_ps(out + 40, a21);
+	_mm256_storeu_ps(out + 48, a30);
+	_mm256_storeu_ps(out + 56, a31);
+	_mm256_storeu_ps(out + 64, a40);
+	_mm256_storeu_ps(out + 72, a41);
+	_mm256_storeu_ps(out + 80, a50);
+	_mm256_storeu_ps(out + 88, a51);
 }
-static inline void mk_1x16(int d, const float *x0, const float *yt, float *out) {
+static inline void mk_q16_1(int d, const float *xt, const float *y0, float *out /* [16] */) {
 	__m256 a0 = _mm256_setzero_ps(), a1 = a0;
 	for (int k = 0; k < d; k++) {
-		__m256 b = _mm256_broadcast_ss(x0 + k);
-		a0 = _mm256_fmadd_ps(b, _mm256_loadu_ps(yt + (size_t)k * PANEL), a0);
-		a1 = _mm256_fmadd_ps(b, _mm256_loadu_ps(yt + (size_t)k * PANEL + 8), a1);
+		const __m256 b = _mm256_broadcast_ss(y0 + k);
+		a0 = _mm256_fmadd_ps(_mm256_loadu_ps(xt + (size_t)k * 16), b, a0);
+		a1 = _mm256_fmadd_ps(_mm256_loadu_ps(xt + (size_t)k * 16 + 8), b, a1);
 	}
 	_mm256_storeu_ps(out, a0);
 	_mm256_storeu_ps(out + 8, a1);
@@ -345,90 +346,60 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 		orc_norms(xq, nq, d, xn);
 		orc_norms(xb, nb, d, yn);
 	}
-	for (int64_t i = 0; i < nq; i++)
-		heap_init(k, D + i * k, I + i * k, is_max);
-	const int npanel_max = BLAS_DBS / PANEL;
-	float *yt = (float *)aligned_alloc(64, (size_t)npanel_max * (size_t)d * PANEL * sizeof(float));
-	/* ip block of one (query block x database block) pair, as FAISS's ip_block (4096 x 1024 floats) */
-	const int64_t qbs = nq < BLAS_QBS ? (nq + MR - 1) / MR * MR : BLAS_QBS;
-	float *ipbuf_all = (float *)aligned_alloc(64, (size_t)(qbs + MR) * BLAS_DBS * sizeof(float));
-
-	for (int64_t i0 = 0; i0 < nq; i0 += BLAS_QBS) {
-		int64_t i1 = i0 + BLAS_QBS < nq ? i0 + BLAS_QBS : nq;
-		const int64_t ngroups = (i1 - i0 + MR - 1) / MR;
-		for (int64_t j0 = 0; j0 < nb; j0 += BLAS_DBS) {
-			int64_t j1 = j0 + BLAS_DBS < nb ? j0 + BLAS_DBS : nb;
-			int64_t jb = j1 - j0;
-			int np = (int)((jb + PANEL - 1) / PANEL);
+	const int64_t ngroups = (nq + 15) / 16;
 #pragma omp parallel
-			{
-				/* pack database block as [panel][k][16] (zero padded) */
-#pragma omp for schedule(static)
-				for (int p = 0; p < np; p++) {
-					float *dst = yt + (size_t)p * d * PANEL;
-					for (int r = 0; r < PANEL; r++) {
-						int64_t j = j0 + (int64_t)p * PANEL + r;
-						if (j < j1) {
-							const float *src = xb + j * d;
-							for (int kk = 0; kk < d; kk++)
-								dst[(size_t)kk * PANEL + r] = src[kk];
-						} else {
-							for (int kk = 0; kk < d; kk++)
-								dst[(size_t)kk * PANEL + r] = 0.f;
-						}
-					}
-				}
-				/* "sgemm": every (query group, panel) pair is an independent task */
-#pragma omp for schedule(static) collapse(2)
-				for (int64_t g = 0; g < ngroups; g++) {
-					for (int p = 0; p < np; p++) {
-						int64_t ia = i0 + g * MR;
-						int nrow = (int)((i1 - ia) < MR ? (i1 - ia) : MR);
-						float *out = ipbuf_all + (size_t)(g * MR) * BLAS_DBS + p * PANEL;
-						if (nrow == MR) {
-							mk_6x16(d, xq + ia * d, d, yt + (size_t)p * d * PANEL, out, BLAS_DBS);
-						} else {
-							for (int r = 0; r < nrow; r++)
-								mk_1x16(d, xq + (ia + r) * d, yt + (size_t)p * d * PANEL, out + (size_t)r * BLAS_DBS);
-						}
-					}
-				}
-				/* HeapBlockResultHandler::add_results: per query, j ascending, strict compare */
-#pragma omp for schedule(static)
-				for (int64_t i = i0; i < i1; i++) {
-					float *hv = D + i * k;
-					int64_t *hi = I + i * k;
-					const float *ipl = ipbuf_all + (size_t)(i - i0) * BLAS_DBS;
+	{
+		float *xt = (float *)aligned_alloc(64, (size_t)d * 16 * sizeof(float));
+		float *ipbuf = (float *)aligned_alloc(64, (size_t)BLAS_DBS * 16 * sizeof(float));
+#pragma omp for schedule(dynamic, 1)
+		for (int64_t g = 0; g < ngroups; g++) {
+			const int64_t q0 = g * 16;
+			const int nqg = (int)(nq - q0 < 16 ? nq - q0 : 16);
+			for (int kk = 0; kk < d; kk++)
+				for (int q = 0; q < 16; q++)
+					xt[(size_t)kk * 16 + q] = q < nqg ? xq[(q0 + q) * d + kk] : 0.f;
+			for (int q = 0; q < nqg; q++)
+				heap_init(k, D + (q0 + q) * k, I + (q0 + q) * k, is_max);
+			for (int64_t j0 = 0; j0 < nb; j0 += BLAS_DBS) {
+				const int64_t jb = nb - j0 < BLAS_DBS ? nb - j0 : BLAS_DBS;
+				int64_t j = 0;
+				for (; j + MRW <= jb; j += MRW)
+					mk_q16(d, xt, xb + (j0 + j) * d, d, ipbuf + j * 16);
+				for (; j < jb; j++)
+					mk_q16_1(d, xt, xb + (j0 + j) * d, ipbuf + j * 16);
+				/* HeapBlockResultHandler::add_results: per query, rows ascending, strict compare */
+				for (int q = 0; q < nqg; q++) {
+					float *hv = D + (q0 + q) * k;
+					int64_t *hi = I + (q0 + q) * k;
 					float thr = hv[0];
 					if (is_max) {
-						const float xni = xn[i];
-						for (int64_t j = 0; j < jb; j++) {
-							float dis = (xni + yn[j0 + j]) - 2.0f * ipl[j];
+						const float xni = xn[q0 + q];
+						for (int64_t jj = 0; jj < jb; jj++) {
+							float dis = (xni + yn[j0 + jj]) - 2.0f * ipbuf[jj * 16 + q];
 							if (dis < 0)
 								dis = 0;
 							if (thr > dis) {
-								heap_replace_top(k, hv, hi, 1, dis, j0 + j);
+								heap_replace_top(k, hv, hi, 1, dis, j0 + jj);
 								thr = hv[0];
 							}
 						}
 					} else {
-						for (int64_t j = 0; j < jb; j++) {
-							float dis = ipl[j];
+						for (int64_t jj = 0; jj < jb; jj++) {
+							const float dis = ipbuf[jj * 16 + q];
 							if (thr < dis) {
-								heap_replace_top(k, hv, hi, 0, dis, j0 + j);
+								heap_replace_top(k, hv, hi, 0, dis, j0 + jj);
 								thr = hv[0];
 							}
 						}
 					}
 				}
 			}
+			for (int q = 0; q < nqg; q++)
+				heap_reorder(k, D + (q0 + q) * k, I + (q0 + q) * k, is_max);
 		}
+		free(xt);
+		free(ipbuf);
 	}
-#pragma omp parallel for schedule(static)
-	for (int64_t i = 0; i < nq; i++)
-		heap_reorder(k, D + i * k, I + i * k, is_max);
-	free(yt);
-	free(ipbuf_all);
 	free(xn);
 	free(yn);
 }
