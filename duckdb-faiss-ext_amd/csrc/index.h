@@ -69,6 +69,7 @@ public:
 	virtual void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) = 0;
 	virtual void to_device(int new_device) = 0;
+	virtual IndexBase *clone(int on_device) = 0; // deep copy living on `on_device`
 	virtual void set_label_offset(int64_t off) {
 		label_offset = off;
 	}
@@ -114,6 +115,7 @@ public:
 	void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                   const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) override;
 	void to_device(int new_device) override;
+	IndexBase *clone(int on_device) override;
 	bool set_option(const char *key, int64_t v) override;
 	void search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                 const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
@@ -146,6 +148,7 @@ public:
 		throw_faiss("mvs::IDMapIndex::search_mapped", __FILE__, "nested IDMap is not supported");
 	}
 	void to_device(int new_device) override;
+	IndexBase *clone(int on_device) override;
 	void set_label_offset(int64_t) override {
 	}
 	bool set_option(const char *key, int64_t v) override {

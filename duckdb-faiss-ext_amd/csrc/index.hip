@@ -451,6 +451,35 @@ void FlatIndex::to_device(int new_device) {
 	MVS_HIP(hipSetDevice(device));
 }
 
+static void check_device(int dev) {
+	int ndev = 0;
+	MVS_HIP(hipGetDeviceCount(&ndev));
+	if (dev < 0 || dev >= ndev)
+		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "Invalid GPU device %d", dev);
+}
+
+IndexBase *FlatIndex::clone(int on_device) {
+	check_device(on_device);
+	use_device();
+	MVS_HIP(hipStreamSynchronize(stream));
+	auto *c = new FlatIndex(d, metric);
+	try {
+		c->to_device(on_device);
+		c->use_device();
+		c->grow(ntotal, c->stream);
+		if (ntotal > 0) {
+			MVS_HIP(hipMemcpyPeer(c->vecs, on_device, vecs, device, (size_t)ntotal * geom.dp * sizeof(float)));
+			MVS_HIP(hipMemcpyPeer(c->norms, on_device, norms, device, (size_t)ntotal * sizeof(float)));
+		}
+		c->ntotal = ntotal;
+		c->label_offset = label_offset;
+	} catch (...) {
+		delete c;
+		throw;
+	}
+	return c;
+}
+
 // ------------------------------------------------------------------------------------------ IDMap
 
 IDMapIndex::IDMapIndex(IndexBase *sub_) : IndexBase(MVS_KIND_IDMAP, sub_->d, sub_->metric), sub(sub_) {
@@ -460,6 +489,7 @@ IDMapIndex::~IDMapIndex() {
 	(void)hipSetDevice(device);
 	if (ids)
 		(void)hipFree(ids);
+	delete sub;
 }
 void IDMapIndex::train(int64_t n, const float *x) {
 	sub->train(n, x);
@@ -548,6 +578,32 @@ void IDMapIndex::to_device(int new_device) {
 	MVS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 	ids = ni;
 	device = new_device;
+}
+
+IndexBase *IDMapIndex::clone(int on_device) {
+	check_device(on_device);
+	use_device();
+	MVS_HIP(hipStreamSynchronize(stream));
+	IndexBase *subc = sub->clone(on_device);
+	IDMapIndex *c = nullptr;
+	try {
+		c = new IDMapIndex(subc);
+	} catch (...) {
+		delete subc;
+		throw;
+	}
+	try {
+		c->to_device(on_device); // sub is already there: only moves this wrapper's stream / ids
+		c->use_device();
+		c->grow_ids(ntotal, c->stream);
+		if (ntotal > 0)
+			MVS_HIP(hipMemcpyPeer(c->ids, on_device, ids, device, (size_t)ntotal * sizeof(int64_t)));
+		c->ntotal = ntotal;
+	} catch (...) {
+		delete c;
+		throw;
+	}
+	return c;
 }
 
 void FlatIndex::search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
@@ -730,6 +786,17 @@ int mvs_index_to_gpu(mvs_index *ix, int device) {
 	MVS_API_BEGIN
 	std::lock_guard<std::mutex> g(ix->mu);
 	ix->impl->to_device(device);
+	MVS_API_END
+}
+int mvs_index_clone_to_gpu(mvs_index **out, const mvs_index *src, int device) {
+	MVS_API_BEGIN
+	*out = nullptr;
+	std::lock_guard<std::mutex> g(const_cast<mvs_index *>(src)->mu);
+	IndexBase *impl = src->impl->clone(device);
+	auto *h = new mvs_index;
+	h->impl = impl;
+	h->owned = true;
+	*out = h;
 	MVS_API_END
 }
 int mvs_index_add_device(mvs_index *ix, int64_t n, const float *d_x, const int64_t *d_ids, void *stream) {

@@ -107,6 +107,7 @@ _L.mvs_index_add.argtypes = [_p, _i64, _p]
 _L.mvs_index_add_with_ids.argtypes = [_p, _i64, _p, _p]
 _L.mvs_index_search.argtypes = [_p, _i64, _p, _i64, _p, _p, C.POINTER(SearchParams)]
 _L.mvs_index_to_gpu.argtypes = [_p, C.c_int]
+_L.mvs_index_clone_to_gpu.argtypes = [C.POINTER(_p), _p, C.c_int]
 _L.mvs_write_index.argtypes = [_p, C.c_char_p]
 _L.mvs_read_index.argtypes = [C.POINTER(_p), C.c_char_p]
 _L.mvs_index_add_device.argtypes = [_p, _i64, _p, _p, _p]
@@ -125,7 +126,8 @@ DECLARED_SYMBOLS = [
     "mvs_last_error", "mvs_index_factory", "mvs_index_free", "mvs_index_d", "mvs_index_ntotal",
     "mvs_index_is_trained", "mvs_index_metric_type", "mvs_index_kind", "mvs_index_idmap_sub",
     "mvs_index_ivf_quantizer", "mvs_index_hnsw_set_ef_construction", "mvs_index_train", "mvs_index_add",
-    "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_write_index",
+    "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
+    "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
     "mvs_merge_shards", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
@@ -238,8 +240,14 @@ class Index:
         return D, I
 
     def to_gpu(self, device):
-        """faiss_to_gpu(name, device): src/gpu/gpu.cpp:48"""
+        """faiss_to_gpu(name, device): src/gpu/gpu.cpp:48 (in place)"""
         _check(_L.mvs_index_to_gpu(self._h, int(device)))
+
+    def clone_to_gpu(self, device):
+        """faiss.index_cpu_to_gpu(res, device, index): returns a new index on `device`"""
+        h = _p()
+        _check(_L.mvs_index_clone_to_gpu(C.byref(h), self._h, int(device)))
+        return Index(h)
 
     # ---- device-resident variants (torch tensors on the index's device) ----
     def add_torch(self, x, ids=None, stream=None):

@@ -100,6 +100,9 @@ int mvs_index_search(mvs_index *ix, int64_t n, const float *x, int64_t k, float 
  * Indexes are already device-native; this migrates the index to `device` (no-op if it is there). */
 int mvs_index_to_gpu(mvs_index *ix, int device);
 int mvs_index_device(const mvs_index *ix);
+/* the same call with FAISS's ownership: returns a NEW index on `device` holding a copy of `src` (the glue replaces
+ * entry.index with the result and drops the old object, src/gpu/gpu.cpp:48) */
+int mvs_index_clone_to_gpu(mvs_index **out, const mvs_index *src, int device);
 
 /* faiss::write_index / read_index  -- src/faiss_extension.cpp:199,234 */
 int mvs_write_index(const mvs_index *ix, const char *filename);

@@ -1,0 +1,55 @@
+"""The C++ host path: boundary_driver reproduces the reference glue's call patterns (CreateFunction, AddFunction
+in <= 2048-row DataChunks from several threads, AddFinaliseFunction, searchIntoVector, MoveToGPUFunction) through
+the faiss:: adaptor classes and the C ABI; its printed rows are compared with the reference's golden vectors."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, goldens
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "duckdb-faiss-ext_amd", "host", "boundary_driver")
+
+
+def _rows(out, tag):
+    return [l.split("\t")[1:] for l in out.splitlines() if l.split("\t")[0] == tag]
+
+
+def test_driver_and_adaptor_are_built():
+    assert os.path.exists(DRIVER), "run __graft_entry__.build()"
+    assert os.path.exists(os.path.join(ROOT, "duckdb-faiss-ext_amd", "libfaiss_mi355.so"))
+
+
+@pytest.mark.gpu
+def test_glue_call_patterns_reproduce_reference_goldens():
+    out = subprocess.run(
+        [DRIVER, "golden", os.path.join(GOLDEN, "training.csv"), os.path.join(GOLDEN, "queries.csv")],
+        capture_output=True, text=True, timeout=300,
+    )  # fmt: skip
+    assert out.returncode == 0, out.stderr
+    g = goldens()
+    flat = _rows(out.stdout, "flat")
+    np.testing.assert_allclose([float(r[2]) for r in flat], g["flat_ip_k2_distances"], rtol=1e-6)  # faiss.test:19-38
+    idmap = _rows(out.stdout, "idmap")
+    assert [(int(r[0]), int(r[1])) for r in idmap] == [(r[0], r[1]) for r in g["idmap_flat_ip_k2"]]  # faiss3.test:25-44
+    np.testing.assert_allclose([float(r[2]) for r in idmap], [r[2] for r in g["idmap_flat_ip_k2"]], rtol=1e-6)
+    for tag in ("filter", "filterset"):  # faiss3.test:49-68
+        rows = _rows(out.stdout, tag)
+        assert [int(r[1]) for r in rows] == [r[1] for r in g["idmap_flat_ip_k2_filter_id_gt_100"]]
+        np.testing.assert_allclose([float(r[2]) for r in rows], [r[2] for r in g["idmap_flat_ip_k2_filter_id_gt_100"]], atol=1e-5)
+    # faiss4.test:22 -- the glue's translated message, byte for byte after DuckDB's "Invalid Input Error: " prefix
+    assert _rows(out.stdout, "error")[0][0] == g["error_add_ids_on_flat"].replace("Invalid Input Error: ", "")
+    assert _rows(out.stdout, "ntotal")[0][0] == "1000"
+    assert [int(r[1]) for r in _rows(out.stdout, "small")] == [231, -1]  # faiss7.test
+    assert [int(r[1]) for r in _rows(out.stdout, "smallfilter")] == [-1, -1]
+    assert _rows(out.stdout, "togpu") == idmap  # faiss_to_gpu keeps results
+    assert _rows(out.stdout, "gpuerror")[0][0] == "Invalid GPU index"  # gpu.cpp:56-57
+
+
+@pytest.mark.gpu
+def test_concurrent_datachunk_ingest():
+    out = subprocess.run([DRIVER, "ingest", "300000", "128", "6"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ingest\tOK" in out.stdout
