@@ -74,8 +74,7 @@ def main():
     metric = mf.METRIC_L2 if args.metric == "L2" else mf.METRIC_INNER_PRODUCT
     n, d, nq, k = args.n, args.d, args.nq, args.k
     # row shard of this rank: [r0, r1)
-    r0 = n * rank // world
-    r1 = n * (rank + 1) // world
+    r0, r1 = n * rank // world, n * (rank + 1) // world
     DB_SEED, Q_SEED = 1234, 4321
 
     gen = mf.synth_uniform_torch if args.data == "uniform" else mf.synth_clustered_torch
@@ -101,13 +100,11 @@ def main():
     torch.cuda.synchronize()
     t_build = time.time() - t_build0
 
+    from sharded import ShardExchange
+
     D = torch.empty((nq, k), dtype=torch.float32, device=dev)
     I = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    if world > 1:
-        gD = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-        gI = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
-        hD = torch.empty((world, nq, k), dtype=torch.float32, pin_memory=True)
-        hI = torch.empty((world, nq, k), dtype=torch.int64, pin_memory=True)
+    xch = ShardExchange(nq, k, dev)
     chunk = args.chunk if args.chunk > 0 else nq
     search_kw = {"nprobe": args.nprobe} if is_ivf else {}
     final = {}
@@ -118,13 +115,9 @@ def main():
             ix.search_torch(xq[q0:q1], k, D=D[q0:q1], I=I[q0:q1], **search_kw)
         if world > 1:
             # exchange step: per-shard (distance,label) blocks over xGMI, then host k-way merge (rank 0)
-            dist.all_gather_into_tensor(gD, D)
-            dist.all_gather_into_tensor(gI, I)
+            fD, fI = xch.merge(metric, D, I)
             if rank == 0:
-                hD.copy_(gD, non_blocking=True)
-                hI.copy_(gI, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                final["D"], final["I"] = mf.merge_shards(metric, hD.numpy(), hI.numpy())
+                final["D"], final["I"] = fD, fI
 
     def fence():
         if world > 1:
