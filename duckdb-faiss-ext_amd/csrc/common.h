@@ -114,6 +114,16 @@ int64_t flat_direct_max_k();
 void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, int nsplit, int64_t nq, int64_t k,
                            const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
 
+// IVF (csrc/ivf.hip)
+size_t direct_items_lds_bytes(int dp, int64_t k);
+void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, const float *d_rows, int64_t nrows,
+                         const int64_t *d_rowids, int64_t k, const void *d_items, int nitems, const int *d_qidx,
+                         SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st);
+void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
+                        int64_t k, const int64_t *d_rowids, const int64_t *d_idmap, float *d_D, int64_t *d_I,
+                        hipStream_t st);
+void launch_gather_rows(const float *d_src, const int *d_perm, int64_t n, int dp, float *d_dst, hipStream_t st);
+
 void launch_synth_uniform(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, hipStream_t st);
 void launch_synth_clustered(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers,
                             float sigma, hipStream_t st);

@@ -18,6 +18,8 @@
 
 #include "../../include/mi355_faiss.h"
 
+#include <cstring>
+
 namespace mvs {
 
 constexpr int MODE_IP = 0, MODE_L2_PAIR = 1, MODE_L2_FORMULA = 2;
@@ -34,6 +36,10 @@ struct DirectArgs {
 	int nq, k, dp, nsplit, ngroups, interleaved;
 	SelectorDev sel;
 	const long long *idmap;
+	// item mode (IVF list scan, csrc/ivf.hip): one workgroup per (row segment, <= QG queries) work item
+	const int4 *items;        // {row_begin, row_end, qoff, nq_item}; null = regular (split x query-group) grid
+	const int *qidx;          // query numbers of the items, indexed by qoff + slot
+	const long long *rowids;  // stored id of every row (selector tests it); null = the row index
 };
 
 __device__ __forceinline__ bool sel_member(const SelectorDev &s, long long id) {
@@ -86,12 +92,25 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 	int *wpos = wid + 4 * QG;
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int split = blockIdx.x / a.ngroups, grp = blockIdx.x % a.ngroups;
-	const int q0 = grp * QG;
-	const long long r_begin = (long long)split * a.split_rows;
-	long long r_end = r_begin + a.split_rows;
+	int split = 0, q0 = 0, qbase = 0, nq_item = 0;
+	long long r_begin, r_end;
+	if (a.items) {
+		const int4 it = a.items[blockIdx.x];
+		r_begin = it.x;
+		r_end = it.y;
+		qbase = it.z;
+		nq_item = it.w;
+	} else {
+		split = blockIdx.x / a.ngroups;
+		q0 = (blockIdx.x % a.ngroups) * QG;
+		r_begin = (long long)split * a.split_rows;
+		r_end = r_begin + a.split_rows;
+		nq_item = a.nq - q0 < QG ? a.nq - q0 : QG;
+	}
 	if (r_end > a.n)
 		r_end = a.n;
+	// query number of slot qq (wave-uniform); slots >= nq_item read query 0 and are never recorded
+	auto qnum = [&](int qq) -> int { return qq < nq_item ? (a.items ? a.qidx[qbase + qq] : q0 + qq) : 0; };
 	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + DTILE - 1) / DTILE) : 0;
 	const int nch = a.dp / KC;
 	const int total_units = ntiles * nch;
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 			y[kk] = src[kk];
 #pragma unroll
 		for (int qq = 0; qq < QG; ++qq) {
-			const float *xs = a.xq + (size_t)(q0 + qq) * a.dp + ch * KC; // wave-uniform: scalar loads
+			const float *xs = a.xq + (size_t)qnum(qq) * a.dp + ch * KC; // wave-uniform: scalar loads
 			float s = acc[qq];
 #pragma unroll
 			for (int kk = 0; kk < KC; ++kk) {
@@ -190,8 +209,10 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 			const long long row0 = r_begin + (long long)tile * DTILE;
 			const long long row = row0 + tid;
 			bool valid = row < r_end;
-			if (valid && a.sel.kind != MVS_SEL_NONE)
-				valid = sel_member(a.sel, a.idmap ? a.idmap[row] : row);
+			if (valid && a.sel.kind != MVS_SEL_NONE) {
+				long long lab = a.rowids ? a.rowids[row] : row;
+				valid = sel_member(a.sel, a.idmap ? a.idmap[lab] : lab);
+			}
 			float ynr = 0.f;
 			if (MODE == MODE_L2_FORMULA)
 				ynr = a.yn[row < a.n ? row : a.n - 1];
@@ -199,13 +220,13 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 			for (int qq = 0; qq < QG; ++qq) {
 				float v = acc[qq];
 				if (MODE == MODE_L2_FORMULA) {
-					v = fmaf(-2.0f, v, a.xn[q0 + qq < a.nq ? q0 + qq : 0] + ynr);
+					v = fmaf(-2.0f, v, a.xn[qnum(qq)] + ynr);
 					v = v < 0.f ? 0.f : v;
 				}
 				const int slot = wave * QG + qq;
 				float tv = wv[slot];
 				// rows arrive in ascending id order, so an equal value never beats the stored worst
-				const bool pass = valid && (q0 + qq < a.nq) && (IS_L2 ? v < tv : v > tv);
+				const bool pass = valid && (qq < nq_item) && (IS_L2 ? v < tv : v > tv);
 				unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
 				if (mask != 0ull) {
 					int tpos = wpos[slot];
@@ -266,16 +287,18 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 		__syncthreads();
 	}
 
-	// partial lists: [nsplit*4][nq][k] -- one partial per (split, wave)
+	// partial lists -- regular grid: [nsplit*4][nq][k], one per (split, wave); item mode: [item][wave][QG][k]
 	for (int qq = 0; qq < QG; ++qq) {
-		const int q = q0 + qq;
-		if (q >= a.nq)
+		if (qq >= nq_item)
 			break;
-		float *od = a.pd + ((size_t)(split * 4 + wave) * a.nq + q) * k;
-		int32_t *oi = a.pi + ((size_t)(split * 4 + wave) * a.nq + q) * k;
+		size_t base;
+		if (a.items)
+			base = (((size_t)blockIdx.x * 4 + wave) * QG + qq) * k;
+		else
+			base = ((size_t)(split * 4 + wave) * a.nq + (q0 + qq)) * k;
 		for (int j = lane; j < k; j += 64) {
-			od[j] = lv[(wave * QG + qq) * k + j];
-			oi[j] = lid[(wave * QG + qq) * k + j];
+			a.pd[base + j] = lv[(wave * QG + qq) * k + j];
+			a.pi[base + j] = lid[(wave * QG + qq) * k + j];
 		}
 	}
 }
@@ -379,6 +402,9 @@ void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, b
 	a.ngroups = (int)((nq + p.qgroup - 1) / p.qgroup);
 	a.sel = sel;
 	a.idmap = (const long long *)d_idmap;
+	a.items = nullptr;
+	a.qidx = nullptr;
+	a.rowids = nullptr;
 	const int mode = metric == METRIC_IP ? MODE_IP : (formula ? MODE_L2_FORMULA : MODE_L2_PAIR);
 	const int kc = direct_kc(g);
 	if (kc == 8)
@@ -387,6 +413,44 @@ void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, b
 		launch_direct_kc<16>(mode, p.qgroup, a, p, st);
 	else
 		launch_direct_kc<32>(mode, p.qgroup, a, p, st);
+}
+
+// IVF list scan: nitems work items over a plain-layout row store (csrc/ivf.hip); QG fixed at 20 slots per item
+size_t direct_items_lds_bytes(int dp, int64_t k) {
+	return direct_lds(dp == 8 ? 8 : (dp == 16 ? 16 : 32), 20, k);
+}
+void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, const float *d_rows, int64_t nrows,
+                         const int64_t *d_rowids, int64_t k, const void *d_items, int nitems, const int *d_qidx,
+                         SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st) {
+	if (nitems <= 0)
+		return;
+	DirectArgs a;
+	memset(&a, 0, sizeof a);
+	a.xq = d_xq;
+	a.yb = d_rows;
+	a.pd = d_pd;
+	a.pi = d_pi;
+	a.n = nrows;
+	a.nq = (int)nq;
+	a.k = (int)k;
+	a.dp = dp;
+	a.sel = sel;
+	a.idmap = (const long long *)d_idmap;
+	a.items = (const int4 *)d_items;
+	a.qidx = d_qidx;
+	a.rowids = (const long long *)d_rowids;
+	DirectPlan p;
+	p.grid = nitems;
+	p.qgroup = 20;
+	p.lds_bytes = direct_items_lds_bytes(dp, k);
+	const int mode = metric == METRIC_IP ? MODE_IP : MODE_L2_PAIR; // IVFFlatScanner: per-pair arithmetic
+	const int kc = dp == 8 ? 8 : (dp == 16 ? 16 : 32);
+	if (kc == 8)
+		launch_direct_kc<8>(mode, 20, a, p, st);
+	else if (kc == 16)
+		launch_direct_kc<16>(mode, 20, a, p, st);
+	else
+		launch_direct_kc<32>(mode, 20, a, p, st);
 }
 
 void launch_flat_direct(const FlatGeom &g, const DirectPlan &p, int metric, const float *d_xq, int64_t nq, FlatDB db,

@@ -108,6 +108,7 @@ public:
 	FlatIndex(int d, int metric);
 	~FlatIndex() override;
 	void reset();
+	void copy_rows_to_host(float *out); // logical [ntotal][d] rows (storage format undone)
 	void add(int64_t n, const float *x) override;
 	void add_device(int64_t n, const float *d_x, hipStream_t st) override;
 	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
@@ -172,6 +173,9 @@ void stream_wait(hipStream_t waiter, hipStream_t signal);
 // csrc/ivf.hip
 IndexBase *make_ivf_index(int d, const std::string &desc, int metric); // nullptr if desc is not an IVF string
 IndexBase *ivf_quantizer_of(IndexBase *ix);
+int64_t ivf_nlist_of(IndexBase *ix);
+bool ivf_get_centroids(IndexBase *ix, float *out);
+bool ivf_set_centroids(IndexBase *ix, const float *c);
 // csrc/hnsw.hip
 IndexBase *make_hnsw_index(int d, const std::string &desc, int metric);
 bool hnsw_set_ef_construction(IndexBase *ix, int v);

@@ -247,6 +247,26 @@ void FlatIndex::reset() {
 	ntotal = 0;
 }
 
+void FlatIndex::copy_rows_to_host(float *out) {
+	use_device();
+	MVS_HIP(hipStreamSynchronize(stream));
+	if (ntotal <= 0)
+		return;
+	std::vector<float> tmp((size_t)ntotal * geom.dp);
+	MVS_HIP(hipMemcpy(tmp.data(), vecs, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+	for (int64_t r = 0; r < ntotal; ++r) {
+		const float *s = &tmp[(size_t)r * geom.dp];
+		for (int kk = 0; kk < d; ++kk) {
+			int src = kk;
+			if (geom.pair_interleaved) { // stored [k0,k2,k1,k3] (bit 4 of r clear) or [k1,k3,k0,k2]
+				static const int pos0[4] = {0, 2, 1, 3}, pos1[4] = {2, 0, 3, 1};
+				src = (kk & ~3) + (((r >> 4) & 1) ? pos1[kk & 3] : pos0[kk & 3]);
+			}
+			out[(size_t)r * d + kk] = s[src];
+		}
+	}
+}
+
 void FlatIndex::grow(int64_t need, hipStream_t st) {
 	if (need <= cap)
 		return;
@@ -749,6 +769,32 @@ mvs_index *mvs_index_ivf_quantizer(mvs_index *ix) {
 		ix->quantizer_handle->owned = false;
 	}
 	return ix->quantizer_handle;
+}
+int64_t mvs_index_ivf_nlist(const mvs_index *ix) {
+	IndexBase *p = ix->impl;
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	return ivf_nlist_of(p);
+}
+int mvs_index_ivf_get_centroids(mvs_index *ix, float *out) {
+	MVS_API_BEGIN
+	IndexBase *p = ix->impl;
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	if (!ivf_get_centroids(p, out))
+		throw_faiss("mvs_index_ivf_get_centroids", __FILE__, "not an IVF index");
+	MVS_API_END
+}
+int mvs_index_ivf_set_centroids(mvs_index *ix, const float *centroids) {
+	MVS_API_BEGIN
+	IndexBase *p = ix->impl, *top = ix->impl;
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	if (!ivf_set_centroids(p, centroids))
+		throw_faiss("mvs_index_ivf_set_centroids", __FILE__, "not an IVF index");
+	for (IndexBase *w = top; w->kind == MVS_KIND_IDMAP; w = static_cast<IDMapIndex *>(w)->sub)
+		w->is_trained = true;
+	MVS_API_END
 }
 int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v) {
 	MVS_API_BEGIN

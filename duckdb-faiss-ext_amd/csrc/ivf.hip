@@ -1,13 +1,515 @@
-// csrc/ivf.hip -- IndexIVFFlat on device (placeholder until the segmented list-scan kernel lands).
+// csrc/ivf.hip -- faiss::IndexIVFFlat on device ("IVF<nlist>,Flat").
+//
+// Replaces what the reference reaches through index_factory (:154), Index::train (:396,:583), add/add_with_ids
+// (:607,:609 -- one call with all rows after training) and search with SearchParametersIVF{nprobe,sel} (:631,
+// :675-689) of /root/reference/src/faiss_extension.cpp.  Restated FAISS behaviour [UPSTREAM: faiss/IndexIVF.cpp,
+// IndexIVFFlat.cpp, Clustering.cpp, utils/random.cpp; see oracle/orc_core.c for the line-by-line restatement]:
+//   train  : k-means (niter 25, seed 1234, <= 256 points per centroid subsample via rand_perm, centroids initialised
+//            from rand_perm(seed+1), empty-cluster splitting, spherical for inner product).  The ASSIGNMENT step --
+//            27.5 TFLOP at IVF4096 -- runs on the fused MFMA Flat kernel (k = 1); the centroid update keeps FAISS's
+//            sequential summation order and runs on the host (cheap: ns*d adds per iteration).
+//   add    : assign = quantizer search k=1 in blocks of 65536 rows; (id, raw vector) appended to list assign[i] in
+//            input order.  Device store: append-only rows + a CSR view (rows grouped by list, input order inside a
+//            list) rebuilt lazily before the first search after an add.
+//   search : coarse = quantizer search k=nprobe; list scan in per-pair arithmetic (IVFFlatScanner::scan_codes):
+//            LIST-MAJOR -- queries are grouped per probed list so every list is streamed from HBM once per <= 20
+//            queries (flat_direct.hip item mode, HBM-bound), then one merge per query over its nprobe partial lists.
 #include "index.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <thread>
+
 namespace mvs {
-IndexBase *make_ivf_index(int, const std::string &desc, int) {
-	if (desc.rfind("IVF", 0) == 0)
-		throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
-		            "This index type is not implemented on the MI355X path yet: %s", desc.c_str());
-	return nullptr;
+
+namespace {
+
+// faiss::rand_perm (utils/random.cpp): Fisher-Yates with mt19937, i2 = i + rng() % (n - i)
+std::vector<int> rand_perm(size_t n, int64_t seed) {
+	std::vector<int> perm(n);
+	for (size_t i = 0; i < n; i++)
+		perm[i] = (int)i;
+	std::mt19937 mt((unsigned)seed);
+	for (size_t i = 0; i + 1 < n; i++) {
+		int i2 = (int)i + (int)(mt() % (uint32_t)(n - i));
+		std::swap(perm[i], perm[i2]);
+	}
+	return perm;
 }
-IndexBase *ivf_quantizer_of(IndexBase *) {
-	return nullptr;
+
+float chain_norm(const float *x, int d) {
+	float acc = 0.f;
+	for (int k = 0; k < d; k++)
+		acc = fmaf(x[k], x[k], acc);
+	return acc;
 }
+void renorm_l2(int d, int64_t n, float *x) {
+	for (int64_t i = 0; i < n; i++) {
+		float *xi = x + i * d;
+		float nr = chain_norm(xi, d);
+		if (nr > 0) {
+			const float inv = 1.0f / sqrtf(nr);
+			for (int j = 0; j < d; j++)
+				xi[j] *= inv;
+		}
+	}
+}
+
+} // namespace
+
+class IVFFlatIndex : public IndexBase {
+public:
+	FlatIndex *quantizer; // owned; nlist centroids, same metric (IndexFlat(d, metric))
+	int64_t nlist;
+	int64_t nprobe = 1;
+	bool spherical;
+	int dp; // padded row length of the list store (plain row-major)
+
+	IVFFlatIndex(int d_, int64_t nlist_, int metric_) : IndexBase(MVS_KIND_IVFFLAT, d_, metric_), nlist(nlist_) {
+		if (metric != METRIC_L2 && metric != METRIC_IP)
+			throw_faiss("mvs::IVFFlatIndex", __FILE__, "metric type %d is not implemented on the MI355X path", metric);
+		quantizer = new FlatIndex(d, metric);
+		is_trained = false;
+		spherical = metric == METRIC_IP; // IndexIVF ctor: "Spherical by default if the metric is inner_product"
+		dp = d <= 8 ? 8 : (d <= 16 ? 16 : (d + 31) / 32 * 32);
+	}
+	~IVFFlatIndex() override {
+		(void)hipSetDevice(device);
+		if (stream)
+			(void)hipStreamSynchronize(stream);
+		if (raw)
+			(void)hipFree(raw);
+		delete quantizer;
+	}
+
+	// ---------------------------------------------------------------------------------------------- train
+	void train(int64_t n, const float *x) override {
+		use_device();
+		if (quantizer->ntotal == nlist) { // "IVF quantizer does not need training."
+			is_trained = true;
+			return;
+		}
+		kmeans(n, x);
+		is_trained = true;
+	}
+
+	void kmeans(int64_t nx, const float *x_in) {
+		const int niter = 25, max_pts = 256, min_pts = 39;
+		const int64_t seed = 1234, k = nlist;
+		if (nx < k)
+			throw_faiss("virtual void faiss::Clustering::train_encoded(...)", "faiss/Clustering.cpp",
+			            "Error: 'nx >= k' failed: Number of training points (%ld) should be at least as large as number "
+			            "of clusters (%ld)",
+			            (long)nx, (long)k);
+		for (int64_t i = 0; i < nx * d; i++)
+			if (!std::isfinite(x_in[i]))
+				throw_faiss("virtual void faiss::Clustering::train_encoded(...)", "faiss/Clustering.cpp",
+				            "input contains NaN's or Inf's");
+		std::vector<float> sub;
+		const float *x = x_in;
+		if (nx > k * max_pts) { // subsample_training_set
+			std::vector<int> perm = rand_perm((size_t)nx, seed);
+			const int64_t n2 = k * max_pts;
+			sub.resize((size_t)n2 * d);
+			for (int64_t i = 0; i < n2; i++)
+				memcpy(&sub[(size_t)i * d], x_in + (int64_t)perm[i] * d, (size_t)d * sizeof(float));
+			x = sub.data();
+			nx = n2;
+		} else if (nx < k * min_pts) {
+			fprintf(stderr, "WARNING clustering %ld points to %ld centroids: please provide at least %ld training points\n",
+			        (long)nx, (long)k, (long)(k * min_pts));
+		}
+		std::vector<float> cent((size_t)k * d);
+		if (nx == k) {
+			memcpy(cent.data(), x, cent.size() * sizeof(float));
+			quantizer->reset();
+			quantizer->add(k, cent.data());
+			return;
+		}
+		{
+			std::vector<int> perm = rand_perm((size_t)nx, seed + 1);
+			for (int64_t i = 0; i < k; i++)
+				memcpy(&cent[(size_t)i * d], x + (int64_t)perm[i] * d, (size_t)d * sizeof(float));
+		}
+		if (spherical)
+			renorm_l2(d, k, cent.data());
+		quantizer->reset();
+		quantizer->add(k, cent.data());
+
+		// the training sample lives on device for the 25 assignment passes
+		DevBuf dx, dD, dI;
+		dx.reserve((size_t)nx * d * sizeof(float));
+		dD.reserve((size_t)nx * sizeof(float));
+		dI.reserve((size_t)nx * sizeof(int64_t));
+		MVS_HIP(hipMemcpyAsync(dx.p, x, (size_t)nx * d * sizeof(float), hipMemcpyHostToDevice, stream));
+		std::vector<int64_t> assign((size_t)nx);
+		std::vector<float> hassign((size_t)k);
+		const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+		for (int it = 0; it < niter; it++) {
+			quantizer->search_device(nx, (const float *)dx.p, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
+			MVS_HIP(hipMemcpyAsync(assign.data(), dI.p, (size_t)nx * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+			MVS_HIP(hipStreamSynchronize(stream));
+			// compute_centroids: each thread owns a range of centroids and walks ALL points in input order
+			std::fill(cent.begin(), cent.end(), 0.f);
+			std::fill(hassign.begin(), hassign.end(), 0.f);
+			std::vector<std::thread> th;
+			for (int r = 0; r < nt; r++)
+				th.emplace_back([&, r] {
+					const int64_t c0 = k * r / nt, c1 = k * (r + 1) / nt;
+					for (int64_t i = 0; i < nx; i++) {
+						const int64_t ci = assign[(size_t)i];
+						if (ci >= c0 && ci < c1) {
+							float *c = &cent[(size_t)ci * d];
+							const float *xi = x + i * d;
+							hassign[(size_t)ci] += 1.0f;
+							for (int j = 0; j < d; j++)
+								c[j] += xi[j];
+						}
+					}
+					for (int64_t ci = c0; ci < c1; ci++) {
+						if (hassign[(size_t)ci] == 0)
+							continue;
+						const float norm = 1 / hassign[(size_t)ci];
+						float *c = &cent[(size_t)ci * d];
+						for (int j = 0; j < d; j++)
+							c[j] *= norm;
+					}
+				});
+			for (auto &t : th)
+				t.join();
+			// split_clusters
+			{
+				const float EPS = (float)(1 / 1024.);
+				std::mt19937 mt(1234);
+				for (int64_t ci = 0; ci < k; ci++) {
+					if (hassign[(size_t)ci] != 0)
+						continue;
+					int64_t cj;
+					for (cj = 0;; cj = (cj + 1) % k) {
+						const float p = (hassign[(size_t)cj] - 1.0f) / (float)(nx - k);
+						const float r = (float)mt() / (float)mt.max();
+						if (r < p)
+							break;
+					}
+					memcpy(&cent[(size_t)ci * d], &cent[(size_t)cj * d], (size_t)d * sizeof(float));
+					for (int j = 0; j < d; j++) {
+						if (j % 2 == 0) {
+							cent[(size_t)ci * d + j] *= 1 + EPS;
+							cent[(size_t)cj * d + j] *= 1 - EPS;
+						} else {
+							cent[(size_t)ci * d + j] *= 1 - EPS;
+							cent[(size_t)cj * d + j] *= 1 + EPS;
+						}
+					}
+					hassign[(size_t)ci] = hassign[(size_t)cj] / 2;
+					hassign[(size_t)cj] -= hassign[(size_t)ci];
+				}
+			}
+			if (spherical)
+				renorm_l2(d, k, cent.data());
+			quantizer->reset();
+			quantizer->add(k, cent.data());
+		}
+	}
+
+	// ---------------------------------------------------------------------------------------------- add
+	void grow(int64_t need) {
+		if (need <= cap)
+			return;
+		int64_t nc = cap ? cap : 4096;
+		while (nc < need)
+			nc = nc + nc / 2 + 4096;
+		float *nr = nullptr;
+		MVS_HIP(hipMalloc((void **)&nr, (size_t)nc * dp * sizeof(float)));
+		if (ntotal > 0)
+			MVS_HIP(hipMemcpyAsync(nr, raw, (size_t)ntotal * dp * sizeof(float), hipMemcpyDeviceToDevice, stream));
+		MVS_HIP(hipStreamSynchronize(stream));
+		if (raw)
+			MVS_HIP(hipFree(raw));
+		raw = nr;
+		cap = nc;
+	}
+
+	// d_x: [n][d] rows already on device (on `stream` order); ids (host) may be null
+	void add_core_device(int64_t n, const float *d_x, const int64_t *ids_host) {
+		if (!is_trained)
+			throw_faiss("virtual void faiss::IndexIVFFlat::add_core(...)", "faiss/IndexIVFFlat.cpp",
+			            "Error: 'is_trained' failed");
+		if (ntotal + n > (int64_t)0x7fffffff - 1024)
+			throw_faiss("mvs::IVFFlatIndex::add", __FILE__, "a single-device shard holds at most 2^31 rows");
+		grow(ntotal + n);
+		const int64_t bs = 65536; // IndexIVF::add_with_ids block size
+		DevBuf dD, dI;
+		dD.reserve((size_t)std::min(bs, n) * sizeof(float));
+		dI.reserve((size_t)std::min(bs, n) * sizeof(int64_t));
+		std::vector<int64_t> lab((size_t)std::min(bs, n));
+		assign_h.reserve((size_t)(ntotal + n));
+		ids_h.reserve((size_t)(ntotal + n));
+		for (int64_t i0 = 0; i0 < n; i0 += bs) {
+			const int64_t nb = std::min(bs, n - i0);
+			quantizer->search_device(nb, d_x + i0 * d, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
+			MVS_HIP(hipMemcpyAsync(lab.data(), dI.p, (size_t)nb * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+			launch_pad_rows(d_x + i0 * d, nb, d, raw + (size_t)(ntotal + i0) * dp, dp, stream);
+			MVS_HIP(hipStreamSynchronize(stream));
+			for (int64_t i = 0; i < nb; i++) {
+				assign_h.push_back((int32_t)lab[(size_t)i]);
+				ids_h.push_back(ids_host ? ids_host[i0 + i] : ntotal + i0 + i);
+			}
+		}
+		ntotal += n;
+		dirty = true;
+	}
+	void add_host(int64_t n, const float *x, const int64_t *ids) {
+		use_device();
+		if (n <= 0)
+			return;
+		DevBuf dx;
+		dx.reserve((size_t)n * d * sizeof(float));
+		MVS_HIP(hipMemcpyAsync(dx.p, x, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice, stream));
+		add_core_device(n, (const float *)dx.p, ids);
+	}
+	void add(int64_t n, const float *x) override {
+		add_host(n, x, nullptr);
+	}
+	void add_with_ids(int64_t n, const float *x, const int64_t *ids) override {
+		add_host(n, x, ids);
+	}
+	void add_device(int64_t n, const float *d_x, hipStream_t st) override {
+		use_device();
+		if (n <= 0)
+			return;
+		stream_wait(stream, st);
+		add_core_device(n, d_x, nullptr);
+	}
+	void add_with_ids_device(int64_t n, const float *d_x, const int64_t *d_ids, hipStream_t st) override {
+		use_device();
+		if (n <= 0)
+			return;
+		stream_wait(stream, st);
+		std::vector<int64_t> ids((size_t)n);
+		MVS_HIP(hipMemcpy(ids.data(), d_ids, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+		add_core_device(n, d_x, ids.data());
+	}
+
+	// CSR view: rows grouped by list, input order inside a list (ArrayInvertedLists semantics)
+	void build_lists() {
+		if (!dirty)
+			return;
+		list_off.assign((size_t)nlist + 1, 0);
+		for (int64_t i = 0; i < ntotal; i++) {
+			const int32_t l = assign_h[(size_t)i];
+			if (l >= 0)
+				list_off[(size_t)l + 1]++;
+		}
+		for (int64_t l = 0; l < nlist; l++)
+			list_off[(size_t)l + 1] += list_off[(size_t)l];
+		nsorted = list_off[(size_t)nlist];
+		std::vector<int64_t> cursor(list_off.begin(), list_off.end() - 1);
+		std::vector<int32_t> perm((size_t)nsorted);
+		std::vector<int64_t> sid((size_t)nsorted);
+		for (int64_t i = 0; i < ntotal; i++) {
+			const int32_t l = assign_h[(size_t)i];
+			if (l < 0)
+				continue;
+			const int64_t p = cursor[(size_t)l]++;
+			perm[(size_t)p] = (int32_t)i;
+			sid[(size_t)p] = ids_h[(size_t)i];
+		}
+		codes.reserve(((size_t)nsorted * dp + 64) * sizeof(float));
+		rowids.reserve((size_t)std::max<int64_t>(nsorted, 1) * sizeof(int64_t));
+		DevBuf dperm;
+		dperm.reserve((size_t)std::max<int64_t>(nsorted, 1) * sizeof(int32_t));
+		if (nsorted > 0) {
+			MVS_HIP(hipMemcpyAsync(dperm.p, perm.data(), (size_t)nsorted * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+			MVS_HIP(hipMemcpyAsync(rowids.p, sid.data(), (size_t)nsorted * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+			launch_gather_rows(raw, (const int *)dperm.p, nsorted, dp, (float *)codes.p, stream);
+		}
+		MVS_HIP(hipStreamSynchronize(stream));
+		dirty = false;
+	}
+
+	// ---------------------------------------------------------------------------------------------- search
+	void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                   const int64_t *d_idmap, hipStream_t st) override {
+		use_device();
+		if (k <= 0)
+			throw_faiss("virtual void faiss::IndexIVF::search(...) const", "faiss/IndexIVF.cpp", "Error: 'k > 0' failed");
+		if (nq <= 0)
+			return;
+		if (k > 256)
+			throw_faiss("mvs::IVFFlatIndex::search", __FILE__, "k = %lld exceeds the supported maximum 256", (long long)k);
+		int64_t np = params && params->nprobe > 0 ? params->nprobe : nprobe;
+		np = std::min(np, nlist); // IndexIVF::search: nprobe = min(nlist, params->nprobe)
+		if (np <= 0)
+			throw_faiss("virtual void faiss::IndexIVF::search(...) const", "faiss/IndexIVF.cpp",
+			            "Error: 'nprobe > 0' failed");
+		// our stream carries the adds / list build; the caller's stream carries the queries
+		stream_wait(stream, st);
+		build_lists();
+		// 1. coarse quantisation on the whole batch (FAISS slices the batch by OpenMP thread; see oracle ivf_search)
+		ws_cD.reserve((size_t)nq * np * sizeof(float));
+		ws_cI.reserve((size_t)nq * np * sizeof(int64_t));
+		quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, nullptr, stream);
+		std::vector<int64_t> keys((size_t)nq * np);
+		MVS_HIP(hipMemcpyAsync(keys.data(), ws_cI.p, keys.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+		MVS_HIP(hipStreamSynchronize(stream));
+		// 2. list-major work items: every probed list x groups of <= 20 of the queries that probe it
+		std::vector<int32_t> cnt((size_t)nlist + 1, 0);
+		for (int64_t key : keys)
+			if (key >= 0)
+				cnt[(size_t)key + 1]++;
+		for (int64_t l = 0; l < nlist; l++)
+			cnt[(size_t)l + 1] += cnt[(size_t)l];
+		const int32_t npairs = cnt[(size_t)nlist];
+		std::vector<int32_t> qidx((size_t)std::max(npairs, 1)), cur(cnt.begin(), cnt.end() - 1);
+		std::vector<int32_t> pair_slot((size_t)nq * np, -1); // (q, probe) -> position in qidx
+		for (int64_t q = 0; q < nq; q++)
+			for (int64_t p = 0; p < np; p++) {
+				const int64_t key = keys[(size_t)(q * np + p)];
+				if (key < 0)
+					continue; // fewer than nprobe centroids
+				const int32_t pos = cur[(size_t)key]++;
+				qidx[(size_t)pos] = (int32_t)q;
+				pair_slot[(size_t)(q * np + p)] = pos;
+			}
+		struct Item {
+			int32_t row_begin, row_end, qoff, nq;
+		};
+		std::vector<Item> items;
+		std::vector<int32_t> item_of_pos((size_t)std::max(npairs, 1));
+		for (int64_t l = 0; l < nlist; l++) {
+			const int32_t a = cnt[(size_t)l], b = cnt[(size_t)l + 1];
+			for (int32_t g = a; g < b; g += 20) {
+				const int32_t ng = std::min(20, b - g);
+				for (int32_t t = 0; t < ng; t++)
+					item_of_pos[(size_t)(g + t)] = (int32_t)items.size();
+				items.push_back({(int32_t)list_off[(size_t)l], (int32_t)list_off[(size_t)l + 1], g, ng});
+			}
+		}
+		std::vector<int32_t> slots((size_t)nq * np, -1);
+		for (size_t i = 0; i < slots.size(); i++) {
+			const int32_t pos = pair_slot[i];
+			if (pos >= 0) {
+				const int32_t it = item_of_pos[(size_t)pos];
+				slots[i] = (it << 5) | (pos - items[(size_t)it].qoff);
+			}
+		}
+		const int nitems = (int)items.size();
+		// 3. upload, scan, merge
+		ws_items.reserve(std::max<size_t>(items.size() * sizeof(Item), 16));
+		ws_qidx.reserve(qidx.size() * sizeof(int32_t));
+		ws_slots.reserve(slots.size() * sizeof(int32_t));
+		ws_q.reserve((size_t)nq * dp * sizeof(float));
+		ws_pd.reserve(std::max<size_t>((size_t)nitems * 4 * 20 * k * sizeof(float), 16));
+		ws_pi.reserve(std::max<size_t>((size_t)nitems * 4 * 20 * k * sizeof(int32_t), 16));
+		if (nitems > 0) {
+			MVS_HIP(hipMemcpyAsync(ws_items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, stream));
+			MVS_HIP(hipMemcpyAsync(ws_qidx.p, qidx.data(), qidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		}
+		MVS_HIP(hipMemcpyAsync(ws_slots.p, slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
+		SelectorDev sel = selector.upload(params, stream);
+		memset(&kinfo, 0, sizeof kinfo);
+		begin_kernel_timing(stream);
+		launch_direct_items(dp, metric, (const float *)ws_q.p, nq, (const float *)codes.p, nsorted,
+		                    (const int64_t *)rowids.p, k, ws_items.p, nitems, (const int *)ws_qidx.p, sel, d_idmap,
+		                    (float *)ws_pd.p, (int32_t *)ws_pi.p, stream);
+		end_kernel_timing(stream);
+		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
+		                   k, (const int64_t *)rowids.p, d_idmap, d_D, d_I, stream);
+		// the caller's stream continues after ours; pageable staging vectors die with this frame
+		MVS_HIP(hipStreamSynchronize(stream));
+		stream_wait(st, stream);
+		snprintf(kinfo.name, sizeof kinfo.name, "ivf_list_scan (flat_direct_kernel items)");
+		double bytes = 0, pairs = 0;
+		for (const Item &it : items) {
+			bytes += (double)(it.row_end - it.row_begin) * dp * 4.0;
+			pairs += (double)(it.row_end - it.row_begin) * it.nq;
+		}
+		kinfo.bytes = bytes;                 // list-major algorithmic bytes: every item streams its list once
+		kinfo.flops = pairs * d * (metric == METRIC_L2 ? 3.0 : 2.0);
+		kinfo.grid = nitems;
+		kinfo.block = 256;
+		kinfo.lds_bytes = (int)direct_items_lds_bytes(dp, k);
+		kinfo.nsplit = (int)np;
+	}
+	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                   hipStream_t st) override {
+		search_mapped(nq, d_x, k, d_D, d_I, params, nullptr, st);
+	}
+
+	void to_device(int new_device) override {
+		if (new_device == device)
+			return;
+		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
+		            "moving an IVF index between devices is not implemented on the MI355X path yet");
+	}
+	IndexBase *clone(int on_device) override {
+		if (on_device == device)
+			throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
+			            "This index type is not implemented for cloning on the MI355X path yet (IVF)");
+		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "This index type is not implemented");
+	}
+	void set_timing(bool on) override {
+		timing_enabled = on;
+	}
+
+	// introspection for parity tests
+	void get_centroids(float *out) {
+		use_device();
+		quantizer->copy_rows_to_host(out);
+	}
+
+private:
+	float *raw = nullptr; // append-only [cap][dp]
+	int64_t cap = 0;
+	std::vector<int32_t> assign_h;
+	std::vector<int64_t> ids_h;
+	bool dirty = false;
+	std::vector<int64_t> list_off;
+	int64_t nsorted = 0;
+	DevBuf codes, rowids;
+	DevBuf ws_cD, ws_cI, ws_items, ws_qidx, ws_slots, ws_q, ws_pd, ws_pi;
+	SelectorHolder selector;
+};
+
+IndexBase *make_ivf_index(int d, const std::string &desc, int metric) {
+	if (desc.rfind("IVF", 0) != 0)
+		return nullptr;
+	char *end = nullptr;
+	const long nlist = strtol(desc.c_str() + 3, &end, 10);
+	if (end == desc.c_str() + 3 || nlist <= 0)
+		return nullptr;
+	if (!strcmp(end, ",Flat"))
+		return new IVFFlatIndex(d, nlist, metric);
+	// "IVF<n>_HNSW<m>,Flat" (reference Makefile:93) needs the HNSW coarse quantiser
+	throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
+	            "This index type is not implemented on the MI355X path yet: %s", desc.c_str());
+}
+IndexBase *ivf_quantizer_of(IndexBase *ix) {
+	if (ix->kind != MVS_KIND_IVFFLAT)
+		return nullptr;
+	return static_cast<IVFFlatIndex *>(ix)->quantizer;
+}
+int64_t ivf_nlist_of(IndexBase *ix) {
+	return ix->kind == MVS_KIND_IVFFLAT ? static_cast<IVFFlatIndex *>(ix)->nlist : 0;
+}
+bool ivf_get_centroids(IndexBase *ix, float *out) {
+	if (ix->kind != MVS_KIND_IVFFLAT)
+		return false;
+	static_cast<IVFFlatIndex *>(ix)->get_centroids(out);
+	return true;
+}
+bool ivf_set_centroids(IndexBase *ix, const float *c) {
+	if (ix->kind != MVS_KIND_IVFFLAT)
+		return false;
+	auto *v = static_cast<IVFFlatIndex *>(ix);
+	v->quantizer->reset();
+	v->quantizer->add(v->nlist, c);
+	v->is_trained = true;
+	return true;
+}
+
 } // namespace mvs

@@ -244,6 +244,125 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 	MVS_HIP(hipGetLastError());
 }
 
+// ---- IVF: merge the per-(probe item, wave) partial lists of one query ---------------------------------
+// slots[q*nprobe + p] = (item << 5 | slot) of probe p, or -1; partial lists live at [item][wave 0..3][20][k].
+// Order: L2 (dist asc, row position asc); IP (score desc, row position asc), equal scores printed in descending
+// label order is NOT attempted here: FAISS's own IVF tie order depends on probe order (DESIGN.md "ties").
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void merge_items_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi,
+                                                        const int *__restrict__ slots, int nprobe, int k,
+                                                        const long long *__restrict__ rowids,
+                                                        const long long *__restrict__ idmap, float *__restrict__ D,
+                                                        long long *__restrict__ I) {
+	extern __shared__ __attribute__((aligned(16))) float sm[];
+	const long long q = blockIdx.x;
+	const int lane = threadIdx.x;
+	const int C = nprobe * 4 * k;
+	float *cv = sm;
+	int *ci = (int *)(sm + C);
+	for (int i = lane; i < C; i += 64) {
+		const int p = i / (4 * k), rem = i - p * 4 * k, w = rem / k, j = rem - w * k;
+		const int s = slots[q * nprobe + p];
+		if (s < 0) {
+			cv[i] = 0.f;
+			ci[i] = -1;
+		} else {
+			const size_t base = (((size_t)(s >> 5) * 4 + w) * 20 + (s & 31)) * k + j;
+			cv[i] = pd[base];
+			ci[i] = pi[base];
+		}
+	}
+	__syncthreads();
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+	for (int r = 0; r < k; ++r) {
+		float bv = neutral;
+		int bi = 0x7fffffff, bp = -1;
+		for (int i = lane; i < C; i += 64) {
+			const float v = cv[i];
+			const int id = ci[i];
+			if (id < 0)
+				continue;
+			const bool better = IS_L2 ? (v < bv || (v == bv && id < bi)) : (v > bv || (v == bv && id < bi));
+			if (bp < 0 || better) {
+				bv = v;
+				bi = id;
+				bp = i;
+			}
+		}
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			const float ov_ = __shfl_xor(bv, off);
+			const int oi_ = __shfl_xor(bi, off);
+			const int op_ = __shfl_xor(bp, off);
+			bool take;
+			if (op_ < 0)
+				take = false;
+			else if (bp < 0)
+				take = true;
+			else
+				take = IS_L2 ? (ov_ < bv || (ov_ == bv && oi_ < bi)) : (ov_ > bv || (ov_ == bv && oi_ < bi));
+			if (take) {
+				bv = ov_;
+				bi = oi_;
+				bp = op_;
+			}
+		}
+		if (lane == 0) {
+			long long label = -1;
+			if (bp >= 0) {
+				ci[bp] = -1;
+				label = rowids[bi];
+				if (idmap)
+					label = idmap[label];
+			}
+			D[q * k + r] = bp >= 0 ? bv : neutral;
+			I[q * k + r] = label;
+		}
+		__syncthreads();
+	}
+}
+void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
+                        int64_t k, const int64_t *d_rowids, const int64_t *d_idmap, float *d_D, int64_t *d_I,
+                        hipStream_t st) {
+	if (nq <= 0)
+		return;
+	const size_t lds = (size_t)nprobe * 4 * k * 8;
+	if (lds > 160 * 1024)
+		throw_faiss(__func__, __FILE__, "IVF merge: nprobe*k = %lld too large", (long long)nprobe * k);
+	if (metric == METRIC_L2) {
+		auto kern = merge_items_kernel<true>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k,
+		                   (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
+	} else {
+		auto kern = merge_items_kernel<false>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k,
+		                   (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
+// rows gathered by a permutation: dst[i] = src[perm[i]] (16-byte chunks; dp % 4 == 0)
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int *__restrict__ perm, long long n, int dp,
+                                   float *__restrict__ dst) {
+	long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int cpr = dp / 4;
+	if (i >= n * cpr)
+		return;
+	const long long r = i / cpr;
+	const int c = (int)(i - r * cpr);
+	((float4 *)dst)[i] = ((const float4 *)src)[(long long)perm[r] * cpr + c];
+}
+void launch_gather_rows(const float *d_src, const int *d_perm, int64_t n, int dp, float *d_dst, hipStream_t st) {
+	if (n <= 0)
+		return;
+	const long long total = (long long)n * (dp / 4);
+	hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_src, d_perm,
+	                   (long long)n, dp, d_dst);
+	MVS_HIP(hipGetLastError());
+}
+
 // ---- synthetic data: same integer arithmetic as oracle/orc_core.c orc_synth_* -------------------------
 __device__ __forceinline__ unsigned long long splitmix(unsigned long long z) {
 	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

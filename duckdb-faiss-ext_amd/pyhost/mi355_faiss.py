@@ -102,6 +102,10 @@ _L.mvs_index_idmap_sub.restype = _p
 _L.mvs_index_ivf_quantizer.argtypes = [_p]
 _L.mvs_index_ivf_quantizer.restype = _p
 _L.mvs_index_hnsw_set_ef_construction.argtypes = [_p, C.c_int]
+_L.mvs_index_ivf_nlist.argtypes = [_p]
+_L.mvs_index_ivf_nlist.restype = _i64
+_L.mvs_index_ivf_get_centroids.argtypes = [_p, _p]
+_L.mvs_index_ivf_set_centroids.argtypes = [_p, _p]
 _L.mvs_index_train.argtypes = [_p, _i64, _p]
 _L.mvs_index_add.argtypes = [_p, _i64, _p]
 _L.mvs_index_add_with_ids.argtypes = [_p, _i64, _p, _p]
@@ -125,7 +129,8 @@ _L.mvs_index_set_option.argtypes = [_p, C.c_char_p, _i64]
 DECLARED_SYMBOLS = [
     "mvs_last_error", "mvs_index_factory", "mvs_index_free", "mvs_index_d", "mvs_index_ntotal",
     "mvs_index_is_trained", "mvs_index_metric_type", "mvs_index_kind", "mvs_index_idmap_sub",
-    "mvs_index_ivf_quantizer", "mvs_index_hnsw_set_ef_construction", "mvs_index_train", "mvs_index_add",
+    "mvs_index_ivf_quantizer", "mvs_index_ivf_nlist", "mvs_index_ivf_get_centroids", "mvs_index_ivf_set_centroids",
+    "mvs_index_hnsw_set_ef_construction", "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
@@ -211,6 +216,19 @@ class Index:
         """IndexIVF::quantizer (src/faiss_extension.cpp:680)"""
         h = _L.mvs_index_ivf_quantizer(self._h)
         return Index(h, owned=False, parent=self) if h else None
+
+    @property
+    def nlist(self):
+        return _L.mvs_index_ivf_nlist(self._h)
+
+    def ivf_centroids(self):
+        out = np.empty((self.nlist, self.d), dtype=np.float32)
+        _check(_L.mvs_index_ivf_get_centroids(self._h, _ptr(out)))
+        return out
+
+    def ivf_set_centroids(self, c):
+        c = _f32(c).reshape(self.nlist, self.d)
+        _check(_L.mvs_index_ivf_set_centroids(self._h, _ptr(c)))
 
     def set_ef_construction(self, v):
         _check(_L.mvs_index_hnsw_set_ef_construction(self._h, int(v)))

@@ -83,6 +83,10 @@ int mvs_index_kind(const mvs_index *ix);
 /* IndexIDMap::index (:129,:673) ; IndexIVF::quantizer (:680).  Borrowed pointers, NULL if n/a. */
 mvs_index *mvs_index_idmap_sub(mvs_index *ix);
 mvs_index *mvs_index_ivf_quantizer(mvs_index *ix);
+/* IVF introspection (IndexIVF::nlist, quantizer centroids): lets parity tests share centroids with the oracle */
+int64_t mvs_index_ivf_nlist(const mvs_index *ix);
+int mvs_index_ivf_get_centroids(mvs_index *ix, float *out /* nlist*d */);
+int mvs_index_ivf_set_centroids(mvs_index *ix, const float *centroids /* nlist*d; marks trained */);
 /* IndexHNSW::hnsw.efConstruction = v  -- src/faiss_extension.cpp:136-139 */
 int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v);
 

@@ -1,0 +1,125 @@
+"""IVFFlat on device vs the CPU oracle's restatement of IndexIVFFlat (no golden values exist in the reference for IVF
+results: parity unpinned by the reference).  Training assigns on the fused MFMA kernel and updates centroids in
+FAISS's summation order, so centroids are expected to be bit-identical to the oracle's; list scans use the per-pair
+arithmetic (IVFFlatScanner) and must match bit for bit away from exact distance ties."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+L2, IP = orc.METRIC_L2, orc.METRIC_INNER_PRODUCT
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import mi355_faiss
+
+    return mi355_faiss
+
+
+def _clustered(n, d, seed, ncent=64, sigma=0.15):
+    return orc.synth_clustered(n, d, seed, n_centers=ncent, sigma=sigma)
+
+
+def _no_tie_rows(D):
+    """queries whose k results have pairwise distinct distances (tie order is probe-order dependent in FAISS)"""
+    return np.array([len(np.unique(r)) == len(r) for r in D])
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_kmeans_centroids_bit_identical_to_oracle(mf, metric):
+    xb = _clustered(6000, 32, 7)
+    o = orc.Index(32, "IVF16,Flat", metric)
+    o.train(xb)
+    g = mf.index_factory(32, "IVF16,Flat", metric)
+    assert not g.is_trained and g.kind == mf.KIND_IVFFLAT and g.nlist == 16
+    g.train(xb)
+    assert g.is_trained
+    assert g.quantizer.ntotal == 16
+    assert np.array_equal(g.ivf_centroids().view(np.uint32), o.ivf_centroids().view(np.uint32))
+
+
+def test_subsampled_training_matches_oracle(mf):
+    """nx > 256*nlist: rand_perm(mt19937) subsample (Clustering.cpp subsample_training_set)"""
+    xb = _clustered(3000, 16, 3, ncent=8)
+    o = orc.Index(16, "IVF8,Flat", L2)
+    o.train(xb)  # 3000 > 8*256 = 2048
+    g = mf.index_factory(16, "IVF8,Flat", L2)
+    g.train(xb)
+    assert np.array_equal(g.ivf_centroids(), o.ivf_centroids())
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("nprobe", [1, 4, 16])
+def test_ivf_search_matches_oracle(mf, metric, nprobe):
+    d, nlist = 64, 16
+    xb = _clustered(20000, d, 11)
+    xq = _clustered(300, d, 12)
+    o = orc.Index(d, f"IVF{nlist},Flat", metric)
+    o.train(xb)
+    o.add(xb)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    g.ivf_set_centroids(o.ivf_centroids())  # share the centroids: this test is about add + search
+    for i0 in range(0, 20000, 7000):
+        g.add(xb[i0 : i0 + 7000])
+    assert g.ntotal == 20000
+    Do, Io = o.search(xq, 10, nprobe=nprobe)
+    D, I = g.search(xq, 10, nprobe=nprobe)
+    ok = _no_tie_rows(Do)
+    assert ok.sum() > 250
+    assert np.array_equal(I[ok], Io[ok])
+    assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
+    assert g.last_kernel_info()["name"].startswith("ivf_list_scan")
+
+
+def test_ivf_train_add_search_end_to_end_and_recall(mf):
+    """BASELINE config C3's shape in miniature: IVF64,Flat on a Gaussian mixture, recall@10 vs exact Flat"""
+    d, n, nq = 128, 60000, 500
+    xb = _clustered(n, d, 21, ncent=256, sigma=0.1)
+    xq = _clustered(nq, d, 22, ncent=256, sigma=0.1)
+    g = mf.index_factory(d, "IVF64,Flat", L2)
+    g.train(xb)
+    g.add(xb)
+    _, Igt = orc.flat_search(L2, xb, xq, 10)
+    recalls = {}
+    for nprobe in (1, 8, 64):
+        _, I = g.search(xq, 10, nprobe=nprobe)
+        recalls[nprobe] = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I, Igt)])
+    assert recalls[64] == 1.0  # probing every list is exhaustive
+    assert recalls[8] > 0.9 and recalls[1] > 0.4 and recalls[1] <= recalls[8] <= recalls[64]
+
+
+def test_idmap_ivf_with_ids_selector_and_small_cases(mf):
+    rng = np.random.default_rng(5)
+    xb = rng.random((3000, 8), dtype=np.float32)
+    ids = np.arange(3000, dtype=np.int64) * 3 + 7
+    o = orc.Index(8, "IDMap,IVF4,Flat", L2)
+    o.train(xb)
+    o.add_with_ids(xb, ids)
+    g = mf.index_factory(8, "IDMap,IVF4,Flat", L2)
+    assert not g.is_trained
+    g.train(xb)
+    assert g.is_trained
+    g.add_with_ids(xb, ids)
+    D, I = g.search(xb[:40], 3, nprobe=4)
+    Do, Io = o.search(xb[:40], 3, nprobe=4)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+    assert I[:, 0].tolist() == ids[:40].tolist()
+    keep = ids[ids % 2 == 0]
+    D, I = g.search(xb[:40], 3, nprobe=4, sel=("batch", keep))
+    Do, Io = o.search(xb[:40], 3, nprobe=4, sel=("batch", keep))
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+    # 'faiss_add_ids_with_train copy.test': IDMap,IVF1,Flat with a single vector (train(1) -> centroids = points)
+    s = mf.index_factory(2, "IDMap,IVF1,Flat")
+    x = np.array([[0.0040321066, 0.023423655]], np.float32)
+    s.train(x)
+    s.add_with_ids(x, np.array([231]))
+    D, I = s.search(x, 2)
+    assert I.tolist() == [[231, -1]]
+    # too few training points: substring the glue matches (src/faiss_extension.cpp:400,592)
+    t = mf.index_factory(4, "IVF8,Flat")
+    with pytest.raises(mf.FaissException, match="should be at least as large as number of clusters"):
+        t.train(np.zeros((3, 4), np.float32))
+    with pytest.raises(mf.FaissException, match="is_trained"):
+        t.add(np.zeros((3, 4), np.float32))
