@@ -118,7 +118,9 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 size_t direct_items_lds_bytes(int dp, int64_t k);
 void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, const float *d_rows, int64_t nrows,
                          const int64_t *d_rowids, int64_t k, const void *d_items, int nitems, const int *d_qidx,
-                         SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st);
+                         SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot,
+                         hipStream_t st);
+void launch_init_slots(unsigned *d_gslot, int64_t nq, int64_t k, int metric, hipStream_t st);
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
                         int64_t k, const int64_t *d_rowids, const int64_t *d_idmap, float *d_D, int64_t *d_I,
                         hipStream_t st);

@@ -40,6 +40,9 @@ struct DirectArgs {
 	const int4 *items;        // {row_begin, row_end, qoff, nq_item}; null = regular (split x query-group) grid
 	const int *qidx;          // query numbers of the items, indexed by qoff + slot
 	const long long *rowids;  // stored id of every row (selector tests it); null = the row index
+	// cross-workgroup threshold sharing (same scheme as flat_mfma.hip): [nq][slot_stride] keys, class = row mod k
+	unsigned *gslot;
+	int slot_stride;
 };
 
 __device__ __forceinline__ bool sel_member(const SelectorDev &s, long long id) {
@@ -61,6 +64,18 @@ __device__ __forceinline__ bool sel_member(const SelectorDev &s, long long id) {
 		return lo < s.nids && s.sorted_ids[lo] == id;
 	}
 	return true;
+}
+
+__device__ __forceinline__ unsigned d_f2key(float f) {
+	const unsigned b = __float_as_uint(f);
+	return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float d_key2f(unsigned k) {
+	return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+template <bool IS_L2>
+__device__ __forceinline__ unsigned d_bkey(float v) { // "smaller is better" key
+	return IS_L2 ? d_f2key(v) : ~d_f2key(v);
 }
 
 template <bool IS_L2>
@@ -110,7 +125,37 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 	if (r_end > a.n)
 		r_end = a.n;
 	// query number of slot qq (wave-uniform); slots >= nq_item read query 0 and are never recorded
-	auto qnum = [&](int qq) -> int { return qq < nq_item ? (a.items ? a.qidx[qbase + qq] : q0 + qq) : 0; };
+	auto qnum = [&](int qq) -> int {
+		return qq < nq_item ? (a.items ? __builtin_amdgcn_readfirstlane(a.qidx[qbase + qq]) : q0 + qq) : 0;
+	};
+	// shared bound of every query slot of this workgroup: gb[qq] = max over the k class slots of the query (a valid
+	// bound on its final k-th value; see flat_mfma.hip "threshold sharing"), refreshed once per row tile
+	float *gb = (float *)(wpos + 4 * QG); // [QG] (written redundantly by all waves with the same values... per wave copy)
+	gb += wave * QG;
+	auto refresh_bounds = [&]() {
+		for (int qq = 0; qq < QG; ++qq) {
+			unsigned m = 0u;
+			if (qq < nq_item && a.gslot) {
+				const unsigned *sl = a.gslot + (size_t)qnum(qq) * a.slot_stride;
+				for (int j = lane; j < a.slot_stride; j += 64) {
+					const unsigned x = __hip_atomic_load(sl + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					m = x > m ? x : m;
+				}
+#pragma unroll
+				for (int off = 32; off >= 1; off >>= 1) {
+					const unsigned o = (unsigned)__shfl_xor((int)m, off);
+					m = o > m ? o : m;
+				}
+			} else {
+				m = 0xFFFFFFFFu;
+			}
+			const unsigned nk = d_bkey<IS_L2>(IS_L2 ? FLT_MAX : -FLT_MAX);
+			if (lane == 0)
+				gb[qq] = IS_L2 ? d_key2f(m < nk ? m : nk) : d_key2f(~(m < nk ? m : nk));
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	};
 	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + DTILE - 1) / DTILE) : 0;
 	const int nch = a.dp / KC;
 	const int total_units = ntiles * nch;
@@ -183,6 +228,7 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 #pragma unroll
 			for (int qq = 0; qq < QG; ++qq)
 				acc[qq] = 0.f;
+			refresh_bounds();
 		}
 		float y[KC];
 		const float *src = tbuf + (u & 1) * DTILE * LDA + tid * LDA;
@@ -191,7 +237,9 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 			y[kk] = src[kk];
 #pragma unroll
 		for (int qq = 0; qq < QG; ++qq) {
-			const float *xs = a.xq + (size_t)qnum(qq) * a.dp + ch * KC; // wave-uniform: scalar loads
+			// wave-uniform address in the constant address space => s_load (SGPR operands of the VALU ops)
+			typedef __attribute__((address_space(4))) const float cfloat;
+			cfloat *xs = (cfloat *)(a.xq + (size_t)qnum(qq) * a.dp + ch * KC);
 			float s = acc[qq];
 #pragma unroll
 			for (int kk = 0; kk < KC; ++kk) {
@@ -225,8 +273,9 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 				}
 				const int slot = wave * QG + qq;
 				float tv = wv[slot];
+				const float gbv = gb[qq];
 				// rows arrive in ascending id order, so an equal value never beats the stored worst
-				const bool pass = valid && (qq < nq_item) && (IS_L2 ? v < tv : v > tv);
+				const bool pass = valid && (qq < nq_item) && (IS_L2 ? (v < tv && v <= gbv) : (v > tv && v >= gbv));
 				unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
 				if (mask != 0ull) {
 					int tpos = wpos[slot];
@@ -242,6 +291,9 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 							if (lane == 0) {
 								mv[tpos] = cv;
 								mi[tpos] = id;
+								if (a.gslot) // publish the best value of this row's class (fire and forget)
+									__hip_atomic_fetch_min(a.gslot + (size_t)qnum(qq) * a.slot_stride + (unsigned)id % (unsigned)k,
+									                       d_bkey<IS_L2>(cv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							}
 							__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 							__builtin_amdgcn_wave_barrier();
@@ -309,7 +361,7 @@ static int direct_kc(const FlatGeom &g) {
 	return g.dp == 8 ? 8 : (g.dp == 16 ? 16 : 32);
 }
 static size_t direct_lds(int kc, int qg, int64_t k) {
-	return (size_t)2 * DTILE * (kc + 1) * 4 + (size_t)4 * qg * k * 8 + 4 * qg * 12;
+	return (size_t)2 * DTILE * (kc + 1) * 4 + (size_t)4 * qg * k * 8 + 4 * qg * 16;
 }
 int64_t flat_direct_max_k() {
 	return (int64_t)((160 * 1024 - direct_lds(32, 1, 0)) / 32);
@@ -382,7 +434,7 @@ void launch_flat_direct(const FlatGeom &g, const DirectPlan &p, int metric, cons
 
 void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, bool formula, const float *d_xq,
                            const float *d_xn, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,
-                           const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st) {
+                           const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st) {
 	if (nq <= 0)
 		return;
 	DirectArgs a;
@@ -405,6 +457,8 @@ void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, b
 	a.items = nullptr;
 	a.qidx = nullptr;
 	a.rowids = nullptr;
+	a.gslot = d_gslot;
+	a.slot_stride = d_gslot ? (int)((k + 15) / 16 * 16) : 0;
 	const int mode = metric == METRIC_IP ? MODE_IP : (formula ? MODE_L2_FORMULA : MODE_L2_PAIR);
 	const int kc = direct_kc(g);
 	if (kc == 8)
@@ -415,13 +469,30 @@ void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, b
 		launch_direct_kc<32>(mode, p.qgroup, a, p, st);
 }
 
+__global__ void init_direct_slots_kernel(unsigned *g, long long total, int stride, int k, int is_l2) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < total)
+		g[i] = (int)(i % stride) < k ? (is_l2 ? d_f2key(FLT_MAX) : ~d_f2key(-FLT_MAX)) : 0u;
+}
+// slots [0,k) = neutral key, padding = 0 (never the maximum); stride = k rounded up to 16
+void launch_init_slots(unsigned *d_gslot, int64_t nq, int64_t k, int metric, hipStream_t st) {
+	const int stride = (int)((k + 15) / 16 * 16);
+	const long long total = (long long)nq * stride;
+	if (total <= 0)
+		return;
+	hipLaunchKernelGGL(init_direct_slots_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_gslot, total,
+	                   stride, (int)k, metric == METRIC_L2 ? 1 : 0);
+	MVS_HIP(hipGetLastError());
+}
+
 // IVF list scan: nitems work items over a plain-layout row store (csrc/ivf.hip); QG fixed at 20 slots per item
 size_t direct_items_lds_bytes(int dp, int64_t k) {
 	return direct_lds(dp == 8 ? 8 : (dp == 16 ? 16 : 32), 20, k);
 }
 void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, const float *d_rows, int64_t nrows,
                          const int64_t *d_rowids, int64_t k, const void *d_items, int nitems, const int *d_qidx,
-                         SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st) {
+                         SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot,
+                         hipStream_t st) {
 	if (nitems <= 0)
 		return;
 	DirectArgs a;
@@ -439,6 +510,8 @@ void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, cons
 	a.items = (const int4 *)d_items;
 	a.qidx = d_qidx;
 	a.rowids = (const long long *)d_rowids;
+	a.gslot = d_gslot;
+	a.slot_stride = d_gslot ? (int)((k + 15) / 16 * 16) : 0;
 	DirectPlan p;
 	p.grid = nitems;
 	p.qgroup = 20;
@@ -456,7 +529,7 @@ void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, cons
 void launch_flat_direct(const FlatGeom &g, const DirectPlan &p, int metric, const float *d_xq, int64_t nq, FlatDB db,
                         int64_t k, SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi,
                         hipStream_t st) {
-	launch_flat_direct_ex(g, p, metric, false, d_xq, nullptr, nq, db, k, sel, d_idmap, d_pd, d_pi, st);
+	launch_flat_direct_ex(g, p, metric, false, d_xq, nullptr, nq, db, k, sel, d_idmap, d_pd, d_pi, nullptr, st);
 }
 
 } // namespace mvs

@@ -188,6 +188,6 @@ void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float
 
 void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, bool formula, const float *d_xq,
                            const float *d_xn, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,
-                           const int64_t *d_idmap, float *d_pd, int32_t *d_pi, hipStream_t st);
+                           const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st);
 
 } // namespace mvs

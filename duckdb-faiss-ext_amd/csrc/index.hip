@@ -384,8 +384,10 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		ws_pi.reserve((size_t)nparts * nq * k * sizeof(int32_t));
 		SelectorDev sel = selector.upload(params, st);
 		begin_kernel_timing(st);
+		ws_gthr.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+		launch_init_slots((unsigned *)ws_gthr.p, nq, k, metric, st);
 		launch_flat_direct_ex(geom, p, metric, formula, (const float *)ws_q.p, qn, nq, db, k, sel, d_idmap,
-		                      (float *)ws_pd.p, (int32_t *)ws_pi.p, st);
+		                      (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
 		end_kernel_timing(st);
 		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, nparts, nq, k, d_idmap,
 		                      label_offset, d_D, d_I, st);

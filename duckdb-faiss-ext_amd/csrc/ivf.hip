@@ -412,10 +412,12 @@ public:
 		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
 		SelectorDev sel = selector.upload(params, stream);
 		memset(&kinfo, 0, sizeof kinfo);
+		ws_gslot.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+		launch_init_slots((unsigned *)ws_gslot.p, nq, k, metric, stream);
 		begin_kernel_timing(stream);
 		launch_direct_items(dp, metric, (const float *)ws_q.p, nq, (const float *)codes.p, nsorted,
 		                    (const int64_t *)rowids.p, k, ws_items.p, nitems, (const int *)ws_qidx.p, sel, d_idmap,
-		                    (float *)ws_pd.p, (int32_t *)ws_pi.p, stream);
+		                    (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
 		                   k, (const int64_t *)rowids.p, d_idmap, d_D, d_I, stream);
@@ -471,7 +473,7 @@ private:
 	std::vector<int64_t> list_off;
 	int64_t nsorted = 0;
 	DevBuf codes, rowids;
-	DevBuf ws_cD, ws_cI, ws_items, ws_qidx, ws_slots, ws_q, ws_pd, ws_pi;
+	DevBuf ws_cD, ws_cI, ws_items, ws_qidx, ws_slots, ws_q, ws_pd, ws_pi, ws_gslot;
 	SelectorHolder selector;
 };
 
