@@ -339,18 +339,51 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 		__syncthreads();
 	}
 
-	// partial lists -- regular grid: [nsplit*4][nq][k], one per (split, wave); item mode: [item][wave][QG][k]
-	for (int qq = 0; qq < QG; ++qq) {
+	// ---- workgroup-level merge of the 4 per-wave lists, then ONE partial list per (workgroup, query) -----------
+	// regular grid: [nsplit][nq][k]; item mode: [item][QG][k].  Wave w merges the query slots qq = w, w+4, ...
+	__syncthreads();
+	for (int qq = wave; qq < QG; qq += 4) {
 		if (qq >= nq_item)
 			break;
 		size_t base;
 		if (a.items)
-			base = (((size_t)blockIdx.x * 4 + wave) * QG + qq) * k;
+			base = ((size_t)blockIdx.x * QG + qq) * k;
 		else
-			base = ((size_t)(split * 4 + wave) * a.nq + (q0 + qq)) * k;
-		for (int j = lane; j < k; j += 64) {
-			a.pd[base + j] = lv[(wave * QG + qq) * k + j];
-			a.pi[base + j] = lid[(wave * QG + qq) * k + j];
+			base = ((size_t)split * a.nq + (q0 + qq)) * k;
+		for (int r = 0; r < k; ++r) { // k rounds of wave-wide lexicographic best over the 4k candidates
+			float bv = 0.f;
+			int bi = 0x7fffffff, bp = -1;
+			for (int c = lane; c < 4 * k; c += 64) {
+				const int w2 = c / k, j = c - w2 * k, p2 = (w2 * QG + qq) * k + j;
+				const float v = lv[p2];
+				const int id = lid[p2];
+				if (id < 0)
+					continue;
+				if (bp < 0 || lex_better<IS_L2>(v, id, bv, bi)) {
+					bv = v;
+					bi = id;
+					bp = p2;
+				}
+			}
+#pragma unroll
+			for (int off = 32; off >= 1; off >>= 1) {
+				const float ov = __shfl_xor(bv, off);
+				const int oi = __shfl_xor(bi, off);
+				const int op = __shfl_xor(bp, off);
+				if (op >= 0 && (bp < 0 || lex_better<IS_L2>(ov, oi, bv, bi))) {
+					bv = ov;
+					bi = oi;
+					bp = op;
+				}
+			}
+			if (lane == 0) {
+				a.pd[base + r] = bp >= 0 ? bv : neutral;
+				a.pi[base + r] = bp >= 0 ? bi : -1;
+				if (bp >= 0)
+					lid[bp] = -1; // consumed
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 		}
 	}
 }
@@ -389,7 +422,7 @@ DirectPlan plan_flat_direct(const FlatGeom &g, int64_t nq, int64_t n, int64_t k)
 	if (nsplit < 1)
 		nsplit = 1;
 	// the merge kernel holds 4*nsplit*k candidates in LDS
-	while (nsplit > 1 && (size_t)(4 * nsplit + 1) * k * 8 > 150 * 1024)
+	while (nsplit > 1 && (size_t)(nsplit + 1) * k * 8 > 150 * 1024)
 		nsplit /= 2;
 	const int64_t tiles_per_split = ntiles > 0 ? (ntiles + nsplit - 1) / nsplit : 1;
 	p.split_rows = tiles_per_split * DTILE;

@@ -296,9 +296,13 @@ typedef __attribute__((address_space(1))) const float glb_f32;
 
 // ABL (ablation builds for profiling only; results are WRONG when != 0): bit0 = skip the epilogue,
 // bit1 = stage only the first tile, bit2 = reuse the first A-fragment group for every MFMA (no ds_reads)
-template <int KSTEPS, bool IS_L2, int ABL = 0>
+// STREAM = false (d <= 128): NT = 2 (64-row tiles), one unit per tile, the wave's query fragments stay in registers.
+// STREAM = true  (d  > 128): NT = 4 (128-row tiles), k streamed in units of KC = 64; the accumulators persist over the
+//   units of a tile and the B fragments of the NEXT unit are refilled group by group behind the MFMAs that just
+//   consumed the current ones (one 64-byte-per-lane register set, no double buffer).
+template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false>
 __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
-	constexpr int NT = 2, KC = 2 * KSTEPS, BN = 64;
+	constexpr int KC = 2 * KSTEPS, BN = 32 * NT;
 	// LDS image of a tile: [64 rows][C 16-byte chunks], UNPADDED so that one LDS-DMA dwordx4 instruction (1 KiB per
 	// wave) lands whole; bank conflicts are removed by an XOR swizzle of the chunk position, applied on the SOURCE
 	// address of the DMA and again on the ds_read_b128 address (cdna_hip_programming.md rule 21):
@@ -344,6 +348,8 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	if (r_end > a.n)
 		r_end = a.n;
 	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + BN - 1) / BN) : 0;
+	const int nch = STREAM ? a.nch : 1;
+	const int nunits = ntiles * nch;
 
 	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
 	float thr = qvalid ? neutral : (IS_L2 ? -INFINITY : INFINITY);
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	const float xnq = (IS_L2 && qvalid) ? a.qn[q] : 0.f;
 
 	float qf[KSTEPS];
-	const float4 *qsrc = (const float4 *)a.qf + (size_t)qblk32 * (KSTEPS / 4) * 64 + lane;
+	const float4 *qsrc = (const float4 *)a.qf + (size_t)qblk32 * nch * (KSTEPS / 4) * 64 + lane;
 #pragma unroll
 	for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
 		float4 v = qsrc[s4 * 64];
@@ -374,9 +380,10 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	// so that the ~100-cycle issue cost of an LDS-DMA instruction hides under the MFMA issued just before it.
 	constexpr int DMA_PER_WAVE = (NDMA + 3) / 4;
 	static_assert(DMA_PER_WAVE <= NG, "one LDS-DMA instruction per MFMA group");
-	auto dma_issue = [&](int tile, int i) {
+	auto dma_issue = [&](int u, int i) {
 		const int inst = i * 4 + wave;
 		if (NDMA % 4 == 0 || inst < NDMA) {
+			const int tile = STREAM ? u / nch : u, ch = STREAM ? u - tile * nch : 0;
 			const long long row0 = r_begin + (long long)tile * BN;
 			// per-lane part recomputed at every issue from an opaque copy of the lane id: hipcc would otherwise hoist
 			// the DMA_PER_WAVE loop-invariant offsets out of the tile loop and spill them (and reload them with a
@@ -389,25 +396,26 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 			const int cg = p ^ ((r / R) & FM);
 			const long long lim = a.n - 1 - row0; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
 			r = r < lim ? r : (int)lim;
-			const char *base = (const char *)(a.yb + (size_t)row0 * a.dp); // wave-uniform
+			const char *base = (const char *)(a.yb + (size_t)row0 * a.dp + ch * KC); // wave-uniform
 			const unsigned boff = (unsigned)(r * a.dp + cg * 4) * 4u;
-			__builtin_amdgcn_global_load_lds((glb_f32 *)(base + boff),
-			                                 (lds_f32 *)smem + (tile & 1) * BN * KC + inst * 256, 16, 0, 0);
+			__builtin_amdgcn_global_load_lds((glb_f32 *)(base + boff), (lds_f32 *)smem + (u & 1) * BN * KC + inst * 256,
+			                                 16, 0, 0);
 		}
 	};
 	auto dma_norms = [&](int tile) {
-		if (IS_L2 && wave == 0) {
-			long long gr = r_begin + (long long)tile * BN + lane;
+		if (IS_L2 && wave < BN / 64) {
+			long long gr = r_begin + (long long)tile * BN + wave * 64 + lane;
 			if (gr >= a.n)
 				gr = a.n - 1;
-			__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yn + gr), (lds_f32 *)smem + 2 * BN * KC + (tile & 1) * BN, 4,
-			                                 0, 0);
+			__builtin_amdgcn_global_load_lds((glb_f32 *)(a.yn + gr),
+			                                 (lds_f32 *)smem + 2 * BN * KC + (tile & 1) * BN + wave * 64, 4, 0, 0);
 		}
 	};
 
 	f32x16 acc[NT];
 	SlotBound sbound;
-	if (ntiles > 0) {
+	SlotRegs sr;
+	if (nunits > 0) {
 #pragma unroll
 		for (int i = 0; i < DMA_PER_WAVE; ++i)
 			dma_issue(0, i);
@@ -415,19 +423,21 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	}
 	__syncthreads();
 
-	for (int tile = 0; tile < ntiles; ++tile) {
-		const bool stage_next = tile + 1 < ntiles && !(ABL & 2);
-		SlotRegs sr;
+	for (int u = 0; u < nunits; ++u) {
+		const int tile = STREAM ? u / nch : u, ch = STREAM ? u - tile * nch : 0;
+		const bool stage_next = u + 1 < nunits && !(ABL & 2);
 		const int window = tile % nwin;
+		if (ch == 0) {
 #pragma unroll
-		for (int t = 0; t < NT; ++t)
+			for (int t = 0; t < NT; ++t)
 #pragma unroll
-			for (int r = 0; r < 16; ++r)
-				acc[t][r] = 0.f;
+				for (int r = 0; r < 16; ++r)
+					acc[t][r] = 0.f;
+		}
 		// A fragments: the database rows are PAIR-INTERLEAVED in HBM (FlatGeom::pair_interleaved), so the two k-steps
 		// a lane half needs from chunk cg -- k = 4cg + h and k = 4cg + 2 + h -- are one aligned 8-byte word at byte
 		// 8 * (h ^ bit4(row)) of the chunk: ds_read_b64, no selects, 32 distinct bank pairs per lane group.
-		const float *Abase = tbuf + ((ABL & 2) ? 0 : (tile & 1)) * BN * KC;
+		const float *Abase = tbuf + ((ABL & 2) ? 0 : (u & 1)) * BN * KC;
 		const int fsw = (c / R) & FM;
 		static_assert((32 / R) % (FM + 1) == 0, "row t*32 + c must have the same swizzle as row c");
 		const int hoff = 2 * (h ^ ((c >> 4) & 1));
@@ -437,10 +447,13 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 #pragma unroll
 			for (int j = 0; j < CG; ++j)
 				af[0][t][j] = *(const float2 *)(Abase + (t * 32 + c) * KC + ((j ^ fsw) * 4) + hoff);
+		// B fragments of the next unit (STREAM): same query block, next k range
+		const int un = u + 1 < nunits ? u + 1 : u;
+		const float4 *qnext = qsrc + (size_t)((STREAM ? un % nch : 0) * (KSTEPS / 4)) * 64;
 #pragma unroll
 		for (int g = 0; g < NG; ++g) {
 			// Order pinned with sched_barrier: [first k-step of group g] [ds_reads of group g+1, one LDS-DMA piece of
-			// the next tile] [rest of group g].  hipcc otherwise sinks each ds_read to just before its MFMA (every
+			// the next unit] [rest of group g].  hipcc otherwise sinks each ds_read to just before its MFMA (every
 			// MFMA then waits out the LDS latency); issuing the next group's reads one k-step INTO the group puts
 			// >= 6 MFMAs (384 cycles) between those reads and the wait at the head of the next group.
 			__builtin_amdgcn_sched_barrier(0);
@@ -462,9 +475,9 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 						              : *(const float2 *)(Abase + (t * 32 + c) * KC + ((((g + 1) * CG + j) ^ fo) * 4) + hoff);
 			}
 			if (g < DMA_PER_WAVE && stage_next)
-				dma_issue(tile + 1, g);
-			if (g == 0) {
-				if (stage_next)
+				dma_issue(u + 1, g);
+			if (g == 0 && ch == 0) {
+				if (tile + 1 < ntiles && !(ABL & 2))
 					dma_norms(tile + 1);
 				// shared threshold slots of this lane's query: issued now, reduced in the epilogue
 				slots_prefetch(sr, a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, window, h);
@@ -483,213 +496,34 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 					acc[t] =
 					    __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][t][CG - 1].y, qf[g * 2 * CG + 3], acc[t], 0, 0, 0);
 			}
+			if (STREAM) {
+				// rolling refill: the MFMAs above were the last readers of this group's B registers in this unit
+				static_assert(!STREAM || CG == 2, "one float4 of query fragments per group");
+				const float4 v = qnext[g * 64];
+				qf[4 * g + 0] = v.x;
+				qf[4 * g + 1] = v.y;
+				qf[4 * g + 2] = v.z;
+				qf[4 * g + 3] = v.w;
+			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
-		const long long row0 = r_begin + (long long)tile * BN;
-		const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
-		if (ABL & 1) {
-#pragma unroll
-			for (int t = 0; t < NT; ++t)
-				asm volatile("" ::"v"(acc[t])); // keep the MFMA chain alive
-		} else {
-			const unsigned gkey = slots_update(sbound, slots_reduce(sr), window, nwin);
-			tile_epilogue<NT, IS_L2, (ABL & 8) != 0>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
-			                                         a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k,
-			                                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
-		}
-		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
-	}
-
-	if (h == 0 && qvalid) {
-		float *od = a.pd + ((size_t)split * a.nq + q) * k;
-		int32_t *oi = a.pi + ((size_t)split * a.nq + q) * k;
-		for (int j = 0; j < k; ++j) {
-			od[j] = ld[ql * k + j];
-			oi[j] = li[ql * k + j];
-		}
-	}
-}
-
-template <int KSTEPS, int NT, bool RESIDENT, bool IS_L2>
-__global__ __launch_bounds__(256, RESIDENT ? 2 : 1) void flat_mfma_kernel(const MfmaArgs a) {
-	constexpr int KC = 2 * KSTEPS, LDA = KC + 1, BN = 32 * NT;
-	constexpr int F4_PER_ROW = KC / 4, F4 = BN * F4_PER_ROW, NLD = (F4 + 255) / 256;
-	static_assert(KSTEPS % 4 == 0, "fragment layout packs 4 k-steps per float4");
-
-	extern __shared__ __attribute__((aligned(16))) float smem[];
-	float *tbuf = smem;                 // [2][BN][LDA]
-	float *nbuf = smem + 2 * BN * LDA;  // [2][BN]
-	float *ld = nbuf + 2 * BN;          // [128][k]
-	int *li = (int *)(ld + QBLOCK * a.k);
-	float *lthr = (float *)(li + QBLOCK * a.k);
-	int *lthrid = (int *)(lthr + QBLOCK);
-	int *lpos = lthrid + QBLOCK;
-
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: stays in SGPRs
-	const int h = lane >> 5, c = lane & 31;
-	const int k = a.k;
-
-	int split, qb;
-	if (a.xcd_map) { // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD its own splits
-		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-		split = (idx / a.nqb) * 8 + xcd;
-		qb = idx % a.nqb;
-	} else {
-		split = blockIdx.x / a.nqb;
-		qb = blockIdx.x % a.nqb;
-	}
-	const int ql = wave * WAVE_Q + c; // query slot inside the block
-	const int q = qb * QBLOCK + ql;
-	const bool qvalid = q < a.nq;
-	const int nwin = a.slot_stride >> 4; // 16-slot windows of the shared threshold slots
-	const int qblk32 = qb * 4 + wave;
-
-	const long long r_begin = (long long)split * a.split_rows;
-	long long r_end = r_begin + a.split_rows;
-	if (r_end > a.n)
-		r_end = a.n;
-	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + BN - 1) / BN) : 0;
-	const int nch = RESIDENT ? 1 : a.nch;
-	const int total_units = ntiles * nch;
-
-	// ---- per-query list init (one lane per query) --------------------------------------------------
-	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
-	// out-of-range query slots never accept anything
-	float thr = qvalid ? neutral : (IS_L2 ? -INFINITY : INFINITY);
-	if (h == 0) {
-		for (int j = 0; j < k; ++j) {
-			ld[ql * k + j] = neutral;
-			li[ql * k + j] = -1;
-		}
-		lthr[ql] = thr;
-		lthrid[ql] = -1;
-		lpos[ql] = 0;
-	}
-	const float xnq = (IS_L2 && qvalid) ? a.qn[q] : 0.f;
-
-	// ---- B fragments (queries) ---------------------------------------------------------------------
-	float qf[KSTEPS];
-	const float4 *qsrc = (const float4 *)a.qf + (size_t)qblk32 * nch * (KSTEPS / 4) * 64 + lane;
-#pragma unroll
-	for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
-		float4 v = qsrc[s4 * 64];
-		qf[4 * s4 + 0] = v.x;
-		qf[4 * s4 + 1] = v.y;
-		qf[4 * s4 + 2] = v.z;
-		qf[4 * s4 + 3] = v.w;
-	}
-
-	// ---- staging helpers ---------------------------------------------------------------------------
-	float4 stg[NLD];
-	float nstg = 0.f;
-	auto stage_load = [&](int u) {
-		const int tile = u / nch, ch = u - tile * nch;
-		const long long row0 = r_begin + (long long)tile * BN;
-#pragma unroll
-		for (int i = 0; i < NLD; ++i) {
-			const int f = i * 256 + tid;
-			if (F4 % 256 == 0 || f < F4) {
-				const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
-				long long gr = row0 + row;
-				if (gr >= a.n)
-					gr = a.n - 1; // tail tile: clamp (rows >= nvalid are masked in the epilogue)
-				stg[i] = *(const float4 *)(a.yb + (size_t)gr * a.dp + ch * KC + c4 * 4);
-			}
-		}
-		if (IS_L2 && ch == 0 && tid < BN) {
-			long long gr = row0 + tid;
-			if (gr >= a.n)
-				gr = a.n - 1;
-			nstg = a.yn[gr];
-		}
-	};
-	auto stage_store = [&](int u) {
-		const int tile = u / nch, ch = u - tile * nch;
-		float *dst = tbuf + (u & 1) * BN * LDA;
-#pragma unroll
-		for (int i = 0; i < NLD; ++i) {
-			const int f = i * 256 + tid;
-			if (F4 % 256 == 0 || f < F4) {
-				const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
-				float *p = dst + row * LDA + c4 * 4;
-				p[0] = stg[i].x;
-				p[1] = stg[i].y;
-				p[2] = stg[i].z;
-				p[3] = stg[i].w;
-			}
-		}
-		if (IS_L2 && ch == 0 && tid < BN)
-			nbuf[(tile & 1) * BN + tid] = nstg;
-	};
-
-	f32x16 acc[NT];
-	SlotBound sbound;
-
-	if (total_units > 0) {
-		stage_load(0);
-		stage_store(0);
-	}
-	__syncthreads();
-
-	for (int u = 0; u < total_units; ++u) {
-		const int tile = u / nch, ch = u - tile * nch;
-		if (u + 1 < total_units)
-			stage_load(u + 1);
-		float qfn[RESIDENT ? 1 : KSTEPS];
-		if (!RESIDENT) {
-			// B fragments of the NEXT unit (L2/MALL resident), consumed after this unit's MFMAs
-			const int un = u + 1 < total_units ? u + 1 : u;
-			const int chn = un % nch;
-#pragma unroll
-			for (int s4 = 0; s4 < KSTEPS / 4; ++s4) {
-				float4 v = qsrc[(chn * (KSTEPS / 4) + s4) * 64];
-				qfn[4 * s4 + 0] = v.x;
-				qfn[4 * s4 + 1] = v.y;
-				qfn[4 * s4 + 2] = v.z;
-				qfn[4 * s4 + 3] = v.w;
-			}
-		}
-		if (ch == 0) {
-#pragma unroll
-			for (int t = 0; t < NT; ++t)
-#pragma unroll
-				for (int r = 0; r < 16; ++r)
-					acc[t][r] = 0.f;
-		}
-		const float *A = tbuf + (u & 1) * BN * LDA + c * LDA + h;
-#pragma unroll
-		for (int s = 0; s < KSTEPS; ++s) {
-#pragma unroll
-			for (int t = 0; t < NT; ++t) {
-				const float av = A[t * 32 * LDA + 2 * s];
-				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qf[s], acc[t], 0, 0, 0);
-			}
-		}
-		if (!RESIDENT) {
-#pragma unroll
-			for (int s = 0; s < KSTEPS; ++s)
-				qf[s] = qfn[s];
-		}
-
 		if (ch == nch - 1) {
 			const long long row0 = r_begin + (long long)tile * BN;
 			const int nvalid = (int)((r_end - row0) < BN ? (r_end - row0) : BN);
-			SlotRegs sr;
-			const int window = tile % nwin;
-			slots_prefetch(sr, a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, window, h);
-			const unsigned gkey = slots_update(sbound, slots_reduce(sr), window, nwin);
-			tile_epilogue<NT, IS_L2>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
-			                         a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k, li + ql * k, k,
-			                         lthr + ql, lthrid + ql, lpos + ql, h);
+			if (ABL & 1) {
+#pragma unroll
+				for (int t = 0; t < NT; ++t)
+					asm volatile("" ::"v"(acc[t])); // keep the MFMA chain alive
+			} else {
+				const unsigned gkey = slots_update(sbound, slots_reduce(sr), window, nwin);
+				tile_epilogue<NT, IS_L2, (ABL & 8) != 0>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
+				                                         a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k,
+				                                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+			}
 		}
-
-		if (u + 1 < total_units)
-			stage_store(u + 1);
-		__syncthreads();
+		__syncthreads(); // also drains this unit's LDS-DMA (vmcnt(0)) before the next unit reads it
 	}
 
-	// ---- partial result lists (unsorted; merged by K4) ----------------------------------------------
 	if (h == 0 && qvalid) {
 		float *od = a.pd + ((size_t)split * a.nq + q) * k;
 		int32_t *oi = a.pi + ((size_t)split * a.nq + q) * k;
@@ -718,11 +552,11 @@ FlatGeom flat_geom_for(int d) {
 		g.ntile = 2;
 		g.pair_interleaved = true;
 	} else {
-		g.kc = 32;
-		g.dp = (d + 31) / 32 * 32;
-		g.nch = g.dp / 32;
-		g.ntile = 8;
-		g.pair_interleaved = false;
+		g.kc = 64;
+		g.dp = (d + 63) / 64 * 64;
+		g.nch = g.dp / 64;
+		g.ntile = 4;
+		g.pair_interleaved = true;
 	}
 	return g;
 }
@@ -734,8 +568,7 @@ size_t qfrag_floats(const FlatGeom &g, int64_t nq) {
 
 static size_t mfma_lds_bytes(const FlatGeom &g, int64_t k) {
 	const size_t bn = g.bn();
-	// resident kernel: unpadded swizzled rows; streaming kernel: rows padded by one float
-	const size_t lda = g.nch == 1 ? (size_t)g.kc : (size_t)(g.kc + 1);
+	const size_t lda = (size_t)g.kc; // unpadded, swizzled rows
 	return (2 * bn * lda + 2 * bn) * sizeof(float) + (size_t)QBLOCK * k * 8 + QBLOCK * 12;
 }
 
@@ -754,7 +587,7 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	// The grid is nqb x nsplit workgroups over 512 resident slots (2 per CU).  Thresholds are shared across
 	// workgroups, so extra splits cost little; what matters is that the LAST round of workgroups is nearly full:
 	// pick the split count (a multiple of 8: one XCD per split residue, see xcd_map) whose grid wastes the least.
-	const int64_t slots = (g.nch == 1 ? 2 : 1) * 256;
+	const int64_t slots = 2 * 256;
 	const int64_t min_tiles = 16; // amortise the per-workgroup prologue
 	int64_t max_split = ntiles / min_tiles;
 	if (max_split > 128)
@@ -842,24 +675,17 @@ template <int KSTEPS, int NT, bool RESIDENT>
 static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
 	if constexpr (RESIDENT) {
 		launch_resident_v2<KSTEPS>(metric, a, p, st);
-		return;
 	} else {
-	if (metric == METRIC_L2) {
-		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, true>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-		if (getenv("MVS_DEBUG")) {
-			int nb = 0;
-			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, p.lds_bytes);
-			fprintf(stderr, "[mvs] flat_mfma_kernel<%d,%d,%d,L2> grid=%d lds=%zu nsplit=%d split_rows=%lld blocks/CU=%d\n",
-			        KSTEPS, NT, (int)RESIDENT, p.grid, p.lds_bytes, p.nsplit, (long long)p.split_rows, nb);
+		if (metric == METRIC_L2) {
+			auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, NT, true>;
+			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+		} else {
+			auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, NT, true>;
+			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 		}
-		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
-	} else {
-		auto kern = flat_mfma_kernel<KSTEPS, NT, RESIDENT, false>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
-	}
-	MVS_HIP(hipGetLastError());
+		MVS_HIP(hipGetLastError());
 	}
 }
 
@@ -909,7 +735,7 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 			break;
 		}
 	} else {
-		launch_inst<16, 8, false>(metric, a, p, st);
+		launch_inst<32, 4, false>(metric, a, p, st); // d > 128: 128-row tiles, k streamed in units of 64
 	}
 }
 

@@ -379,7 +379,7 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 			qn = (float *)ws_qn.p;
 			launch_row_norms((const float *)ws_q.p, nq, geom.dp, qn, st);
 		}
-		const int nparts = p.nsplit * 4;
+		const int nparts = p.nsplit; // the 4 per-wave lists are merged inside the workgroup
 		ws_pd.reserve((size_t)nparts * nq * k * sizeof(float));
 		ws_pi.reserve((size_t)nparts * nq * k * sizeof(int32_t));
 		SelectorDev sel = selector.upload(params, st);

@@ -402,8 +402,8 @@ public:
 		ws_qidx.reserve(qidx.size() * sizeof(int32_t));
 		ws_slots.reserve(slots.size() * sizeof(int32_t));
 		ws_q.reserve((size_t)nq * dp * sizeof(float));
-		ws_pd.reserve(std::max<size_t>((size_t)nitems * 4 * 20 * k * sizeof(float), 16));
-		ws_pi.reserve(std::max<size_t>((size_t)nitems * 4 * 20 * k * sizeof(int32_t), 16));
+		ws_pd.reserve(std::max<size_t>((size_t)nitems * 20 * k * sizeof(float), 16));
+		ws_pi.reserve(std::max<size_t>((size_t)nitems * 20 * k * sizeof(int32_t), 16));
 		if (nitems > 0) {
 			MVS_HIP(hipMemcpyAsync(ws_items.p, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice, stream));
 			MVS_HIP(hipMemcpyAsync(ws_qidx.p, qidx.data(), qidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));

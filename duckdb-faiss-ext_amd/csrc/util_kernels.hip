@@ -245,7 +245,7 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 }
 
 // ---- IVF: merge the per-(probe item, wave) partial lists of one query ---------------------------------
-// slots[q*nprobe + p] = (item << 5 | slot) of probe p, or -1; partial lists live at [item][wave 0..3][20][k].
+// slots[q*nprobe + p] = (item << 5 | slot) of probe p, or -1; partial lists live at [item][20][k].
 // Order: L2 (dist asc, row position asc); IP (score desc, row position asc), equal scores printed in descending
 // label order is NOT attempted here: FAISS's own IVF tie order depends on probe order (DESIGN.md "ties").
 template <bool IS_L2>
@@ -257,17 +257,17 @@ __global__ __launch_bounds__(64) void merge_items_kernel(const float *__restrict
 	extern __shared__ __attribute__((aligned(16))) float sm[];
 	const long long q = blockIdx.x;
 	const int lane = threadIdx.x;
-	const int C = nprobe * 4 * k;
+	const int C = nprobe * k;
 	float *cv = sm;
 	int *ci = (int *)(sm + C);
 	for (int i = lane; i < C; i += 64) {
-		const int p = i / (4 * k), rem = i - p * 4 * k, w = rem / k, j = rem - w * k;
+		const int p = i / k, j = i - p * k;
 		const int s = slots[q * nprobe + p];
 		if (s < 0) {
 			cv[i] = 0.f;
 			ci[i] = -1;
 		} else {
-			const size_t base = (((size_t)(s >> 5) * 4 + w) * 20 + (s & 31)) * k + j;
+			const size_t base = ((size_t)(s >> 5) * 20 + (s & 31)) * k + j;
 			cv[i] = pd[base];
 			ci[i] = pi[base];
 		}
@@ -326,7 +326,7 @@ void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, cons
                         hipStream_t st) {
 	if (nq <= 0)
 		return;
-	const size_t lds = (size_t)nprobe * 4 * k * 8;
+	const size_t lds = (size_t)nprobe * k * 8;
 	if (lds > 160 * 1024)
 		throw_faiss(__func__, __FILE__, "IVF merge: nprobe*k = %lld too large", (long long)nprobe * k);
 	if (metric == METRIC_L2) {
