@@ -29,6 +29,17 @@ namespace mvs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Register-opacity / keep-alive helpers.  The "v" (VGPR) constraint only exists on the device pass; on the HOST pass
+// of a kernel TEMPLATE an invalid constraint on a dependent type silently invalidates the instantiation and hipcc
+// (ROCm 7.2) then emits no host stub for the kernel (undefined symbol at load time, no diagnostic).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MVS_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#define MVS_KEEP_VGPR(x) asm volatile("" ::"v"(x))
+#else
+#define MVS_OPAQUE_VGPR(x) ((void)(x))
+#define MVS_KEEP_VGPR(x) ((void)(x))
+#endif
+
 struct MfmaArgs {
 	const float *qf; // query fragments, layout [qblk32][ch][s4][lane][4]
 	const float *qn; // query norms
@@ -211,7 +222,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 	}
 	const bool any = IS_L2 ? best < teff : best > teff;
 	if (SKIP_SLOW) {
-		asm volatile("" ::"v"(any));
+		MVS_KEEP_VGPR(any);
 		return;
 	}
 	if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 			// the DMA_PER_WAVE loop-invariant offsets out of the tile loop and spill them (and reload them with a
 			// vmcnt(0) in the MFMA loop)
 			int lane_o = lane;
-			asm volatile("" : "+v"(lane_o));
+			MVS_OPAQUE_VGPR(lane_o);
 			const int L = inst * 64 + lane_o; // chunk slot in the LDS image
 			int r = L / C;
 			const int p = L % C;
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 				// the swizzled chunk offsets are recomputed per group from an opaque copy of the swizzle (2 VALU per
 				// read pair): hipcc would otherwise hoist all C of them out of the tile loop and spill
 				int fo = fsw;
-				asm volatile("" : "+v"(fo));
+				MVS_OPAQUE_VGPR(fo);
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 			if (ABL & 1) {
 #pragma unroll
 				for (int t = 0; t < NT; ++t)
-					asm volatile("" ::"v"(acc[t])); // keep the MFMA chain alive
+					MVS_KEEP_VGPR(acc[t]); // keep the MFMA chain alive
 			} else {
 				const unsigned gkey = slots_update(sbound, slots_reduce(sr), window, nwin);
 				tile_epilogue<NT, IS_L2, (ABL & 8) != 0>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
