@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--metric", default="L2", choices=["L2", "IP"])
     ap.add_argument("--index", default="Flat", help="factory string (Flat | IDMap,Flat | IVF4096,Flat ...)")
     ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--efsearch", type=int, default=128, help="SearchParametersHNSW::efSearch (HNSW indexes)")
+    ap.add_argument("--normalize", action="store_true", help="L2-normalise rows and queries (embedding-like, C4/C5)")
     ap.add_argument("--chunk", type=int, default=0, help="queries per search call (2048 = DuckDB DataChunk); 0 = one batch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +82,18 @@ def main():
     gen = mf.synth_uniform_torch if args.data == "uniform" else mf.synth_clustered_torch
     ix = mf.index_factory(d, args.index, metric)
     is_ivf = "IVF" in args.index
+    is_hnsw = "HNSW" in args.index
+    with_ids = args.index.startswith("IDMap")
+    if is_hnsw:
+        # the graph walk does not shard -> replicas only: every rank holds the whole graph + vectors and
+        # answers its slice of the queries; no data-path collective (rank 0 gathers the disjoint result rows)
+        r0, r1 = 0, n
+
+    def prep(x):
+        if args.normalize:
+            x /= x.norm(dim=1, keepdim=True)
+        return x
+
     # build: device-side generation in slabs (keeps peak memory = index + one slab)
     slab = 1 << 20
     t_build0 = time.time()
@@ -91,14 +105,18 @@ def main():
             ix.add_torch(xb_all[s0 : s0 + slab])
         torch.cuda.synchronize()
     else:
+        if is_hnsw:
+            slab = 1 << 16
         for s0 in range(r0, r1, slab):
             m = min(slab, r1 - s0)
-            xb = gen(m, d, DB_SEED, row0=s0, device=dev)
-            ix.add_torch(xb)
+            xb = prep(gen(m, d, DB_SEED, row0=s0, device=dev))
+            ids = torch.arange(s0, s0 + m, dtype=torch.int64, device=dev) if with_ids else None
+            ix.add_torch(xb, ids=ids)
             torch.cuda.synchronize()
             del xb
-    ix.set_label_offset(r0)
-    xq = gen(nq, d, Q_SEED, row0=0, device=dev)
+    if not with_ids:
+        ix.set_label_offset(r0)
+    xq = prep(gen(nq, d, Q_SEED, row0=0, device=dev))
     torch.cuda.synchronize()
     t_build = time.time() - t_build0
 
@@ -108,10 +126,29 @@ def main():
     I = torch.empty((nq, k), dtype=torch.int64, device=dev)
     xch = ShardExchange(nq, k, dev)
     chunk = args.chunk if args.chunk > 0 else nq
-    search_kw = {"nprobe": args.nprobe} if is_ivf else {}
+    search_kw = {"nprobe": args.nprobe} if is_ivf else ({"efSearch": args.efsearch} if is_hnsw else {})
     final = {}
+    # replicas: rank r answers queries [qa, qb)
+    per = (nq + world - 1) // world
+    qa, qb = min(nq, rank * per), min(nq, (rank + 1) * per)
+
+    def step_replicas():
+        if qb > qa:
+            ix.search_torch(xq[qa:qb], k, D=D[qa:qb], I=I[qa:qb], **search_kw)
+        if world > 1:
+            Dl = torch.zeros((per, k), dtype=torch.float32, device=dev)
+            Il = torch.full((per, k), -1, dtype=torch.int64, device=dev)
+            Dl[: qb - qa], Il[: qb - qa] = D[qa:qb], I[qa:qb]
+            Dg = torch.empty((world * per, k), dtype=torch.float32, device=dev)
+            Ig = torch.empty((world * per, k), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(Dg, Dl)
+            dist.all_gather_into_tensor(Ig, Il)
+            if rank == 0:
+                final["D"], final["I"] = Dg[:nq].cpu().numpy(), Ig[:nq].cpu().numpy()
 
     def step():
+        if is_hnsw:
+            return step_replicas()
         for q0 in range(0, nq, chunk):
             q1 = min(nq, q0 + chunk)
             ix.search_torch(xq[q0:q1], k, D=D[q0:q1], I=I[q0:q1], **search_kw)
@@ -149,7 +186,9 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         qps = nq * args.steps / dt
         out = {
-            "metric": "queries/sec, Flat%s d=%d N=%d nq=%d k=%d" % (args.metric, d, n, nq, k)
+            "metric": "queries/sec, %s %s d=%d N=%d efSearch=%d nq=%d k=%d" % (args.index, args.metric, d, n, args.efsearch, nq, k)
+            if is_hnsw
+            else "queries/sec, Flat%s d=%d N=%d nq=%d k=%d" % (args.metric, d, n, nq, k)
             if not is_ivf
             else "queries/sec, %s d=%d N=%d nprobe=%d nq=%d k=%d" % (args.index, d, n, args.nprobe, nq, k),
             "value": round(qps, 1),
@@ -159,15 +198,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if is_hnsw else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (counter-based %s, db seed %d, query seed %d)" % (args.data, DB_SEED, Q_SEED),
             "config": {
                 "workload": "%s %s d=%d N=%d nq=%d k=%d" % (args.index, args.metric, d, n, nq, k),
                 "queries_per_call": chunk,
-                "row_shards": world,
-                "exchange": "rccl all_gather + host k-way merge" if world > 1 else "none",
+                "row_shards": 1 if is_hnsw else world,
+                "replicas": world if is_hnsw else 1,
+                "exchange": ("gather of disjoint result rows" if is_hnsw else "rccl all_gather + host k-way merge")
+                if world > 1
+                else "none",
                 "build_seconds": round(t_build, 2),
             },
         }
@@ -203,7 +245,11 @@ def main():
                 }
             else:
                 achieved = kinfo["bytes"] / (avg_ms * 1e-3) / 1e9
-                out["roofline_note"] = "achieved = list-major algorithmic bytes (every work item streams its list once) / launch time"
+                out["roofline_note"] = (
+                    "achieved = distance evaluations counted by the kernel x (4d + 4) bytes / launch time (SURVEY 8d C5)"
+                    if is_hnsw
+                    else "achieved = list-major algorithmic bytes (every work item streams its list once) / launch time"
+                )
                 out["roofline"] = {
                     "kernel": kinfo["name"],
                     "bound": "hbm",
@@ -217,6 +263,54 @@ def main():
                     "algorithmic_bytes_per_launch": kinfo["bytes"],
                 }
         # ---- CPU baseline (oracle, BLAS-path arithmetic, all host cores) + recall, N=1 only ----------
+        if world == 1 and is_hnsw:
+            out["distance_evals_per_query"] = round(kinfo["bytes"] / (4.0 * d + 4.0) / nq, 1)
+            out["expanded_vertices_per_query"] = kinfo["nsplit"]
+            ns = min(nq, 1000)
+            flat = mf.index_factory(d, "Flat", metric)
+            for s0 in range(0, n, 1 << 20):
+                m = min(1 << 20, n - s0)
+                flat.add_torch(prep(gen(m, d, DB_SEED, row0=s0, device=dev)))
+            _, Igt = flat.search_torch(xq[:ns].contiguous(), k)
+            torch.cuda.synchronize()
+            Igt = Igt.cpu().numpy()
+            out["recall_at_10"] = round(
+                float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(final["I"][:ns], Igt)])), 5
+            )
+            out["recall_sample_queries"] = ns
+            if not args.no_cpu_baseline:
+                from oracle import oracle as orc
+
+                # the oracle walks the SAME graph (a single-thread oracle build of N rows would take hours):
+                # rows come back from the device generator, the graph from the device index
+                xb_h = np.empty((n, d), dtype=np.float32)
+                for s0 in range(0, n, 1 << 20):
+                    m = min(1 << 20, n - s0)
+                    xb_h[s0 : s0 + m] = prep(gen(m, d, DB_SEED, row0=s0, device=dev)).cpu().numpy()
+                del flat
+                o = orc.Index(d, args.index.replace("IDMap,", ""), metric)
+                o.hnsw_set_graph(xb_h, ix.hnsw_graph())
+                xq_h = xq.cpu().numpy()
+                nq_cpu, done, t_cpu = 256, 0, 0.0
+                same = True
+                while t_cpu < args.cpu_seconds and done < nq:
+                    m = min(nq_cpu, nq - done)
+                    t1 = time.perf_counter()
+                    Do, Io = o.search(xq_h[done : done + m], k, efSearch=args.efsearch)
+                    t_cpu += time.perf_counter() - t1
+                    same &= bool(np.array_equal(final["I"][done : done + m], Io))
+                    same &= bool(np.array_equal(final["D"][done : done + m].view(np.uint32), Do.view(np.uint32)))
+                    done += m
+                    nq_cpu = min(4096, nq_cpu * 2)
+                out["cpu_baseline"] = {
+                    "value": round(done / t_cpu, 2),
+                    "unit": "queries/s",
+                    "cores": orc.num_threads(),
+                    "kind": "port",
+                    "sample": "%d of %d queries, efSearch=%d, on the device-built graph (oracle/orc_hnsw.c "
+                    "orc_hnsw_search_one, OpenMP over queries) in %.1f s" % (done, nq, args.efsearch, t_cpu),
+                }
+                out["labels_and_distances_bit_exact_vs_oracle"] = same
         if world == 1 and is_ivf:
             # recall@10 against exact Flat ground truth (the Flat path is bit-exact vs the oracle) on a query sample
             ns = min(nq, 1000)
@@ -255,7 +349,7 @@ def main():
                     "took %.1f s (oracle/orc_core.c ivf_search, OpenMP over queries)" % (nq_cpu, nq, args.nprobe, n, t_add),
                 }
                 out["labels_bit_exact_vs_oracle"] = bool(np.array_equal(final["I"][:nq_cpu][same], Io[same]))
-        if world == 1 and not args.no_cpu_baseline and not is_ivf:
+        if world == 1 and not args.no_cpu_baseline and not is_ivf and not is_hnsw:
             from oracle import oracle as orc
 
             gen_h = orc.synth_uniform if args.data == "uniform" else orc.synth_clustered

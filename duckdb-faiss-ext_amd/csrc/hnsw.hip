@@ -1,13 +1,1226 @@
-// csrc/hnsw.hip -- IndexHNSWFlat on device (placeholder until the graph-walk kernel lands).
+// csrc/hnsw.hip -- faiss::IndexHNSWFlat on device ("HNSW<M>", "HNSW<M>,Flat").
+//
+// Replaces what the reference reaches through index_factory (:154), hnsw.efConstruction (:136-139), Index::add
+// (:510/:512 -- <= 2048 rows per call, so the graph grows incrementally) and Index::search with
+// SearchParametersHNSW{efSearch, sel} (:631, :691-702) of /root/reference/src/faiss_extension.cpp.  FAISS behaviour
+// restated [UPSTREAM: faiss/impl/HNSW.cpp, faiss/IndexHNSW.cpp; line-by-line restatement in oracle/orc_hnsw.c]:
+//   add    : levels from RandomGenerator(12345) with assign_probas (mult = 1/ln M), FAISS's flat offsets/neighbors
+//            layout (2M slots at level 0, M above, -1 = empty); points inserted bucket by bucket from the highest
+//            level down, each bucket shuffled with RandomGenerator(789); per point: greedy descent, then per level
+//            search_neighbors_to_add (efConstruction) -> shrink_neighbor_list -> links both ways (add_link).
+//   search : greedy descent on levels >= 1, level-0 best-first with the bounded candidate set (ef = max(efSearch,k)),
+//            stop when efSearch stored distances are below the popped one; selector filters RESULTS only; inner
+//            product is walked as the negated value and restored on output.
+//
+// MI355X design: ONE 64-lane wavefront owns one query (search) / one inserted point (build).
+//   * a distance = the whole wave reads one 4*dp-byte row as coalesced float4 (dwordx4) loads, G rows in flight,
+//     4 fma chains per lane, then a fixed DPP reduction tree -- the canonical HNSW arithmetic of oracle/orc_hnsw.c,
+//     so distances, graphs and results are bit-identical to the oracle;
+//   * the bounded sets (MinimaxHeap / result heap / construction result set) are SORTED 64-bit key arrays
+//     ((ordered distance bits << 32) | id) in LDS: insert = ballot-popcount for the position + one lane-parallel
+//     shift; pop-min, count_below and "current worst" are O(1) reads.  Heap shape is not part of FAISS's observable
+//     behaviour, the (distance, id) order is;
+//   * visited table = one byte per vertex per wave in HBM with a rolling stamp (VisitedTable);
+//   * build concurrency mirrors FAISS's OpenMP loop: many waves insert points of one level bucket at the same time
+//     under per-vertex spin locks (at most one lock held, exactly like add_with_locks); neighbour lists are read and
+//     written with agent-scope relaxed atomics so the eight XCD L2s cannot serve stale lists.  One wave
+//     (option hnsw_build_waves = 1) is the deterministic order and reproduces the oracle's graph bit for bit.
+// The graph walk is HBM-latency/bandwidth work: ~ n_visited * (4d + 4) bytes per query; no MFMA.
 #include "index.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+
 namespace mvs {
-IndexBase *make_hnsw_index(int, const std::string &desc, int) {
-	if (desc.rfind("HNSW", 0) == 0)
-		throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
-		            "This index type is not implemented on the MI355X path yet: %s", desc.c_str());
-	return nullptr;
+
+namespace {
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------------ device helpers
+
+__device__ __forceinline__ unsigned h_f2key(float f) {
+	const unsigned b = __float_as_uint(f);
+	return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-bool hnsw_set_ef_construction(IndexBase *, int) {
-	return false;
+__device__ __forceinline__ float h_key2f(unsigned k) {
+	const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+	return __uint_as_float(b);
 }
+// low word: ((id + 1) << 1) | flag ; 0 = tombstone (MinimaxHeap's id = -1 keeps its distance)
+__device__ __forceinline__ u64 mk_key(float dis, int id, unsigned flag = 0) {
+	return ((u64)h_f2key(dis) << 32) | (u64)((((unsigned)(id + 1)) << 1) | flag);
+}
+__device__ __forceinline__ float key_dis(u64 k) {
+	return h_key2f((unsigned)(k >> 32));
+}
+__device__ __forceinline__ int key_id(u64 k) {
+	return (int)(((unsigned)k) >> 1) - 1;
+}
+__device__ __forceinline__ int rfl(int v) {
+	return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ float rflf(float v) {
+	return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ u64 rfl64(u64 v) {
+	const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+	return ((u64)hi << 32) | lo;
+}
+// LDS traffic of one wave is in order in hardware; this only stops the compiler from reordering it
+__device__ __forceinline__ void wave_fence() {
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// adjacent-pair binary tree over the 64 lanes (oracle/orc_hnsw.c dc_q); every lane ends with the total
+__device__ __forceinline__ float wave_sum(float v) {
+	v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+	v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+	v += dpp_mov<0x141>(v); // row_half_mirror: quad 0 <-> quad 1
+	v += dpp_mov<0x140>(v); // row_mirror: lanes 0-7 <-> 8-15
+	v += __shfl_xor(v, 16);
+	v += __shfl_xor(v, 32);
+	return v;
+}
+
+template <int NI>
+struct QV {
+	float4 v[NI];
+};
+
+template <int NI>
+__device__ __forceinline__ void load_row(QV<NI> &q, const float *row, int dp4, int lane) {
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		const int idx = lane + 64 * i;
+		q.v[i] = idx < dp4 ? reinterpret_cast<const float4 *>(row)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+}
+
+template <int NI, bool IS_L2>
+__device__ __forceinline__ float lane_partial(const QV<NI> &q, const QV<NI> &y) {
+	float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		if (IS_L2) {
+			const float t0 = q.v[i].x - y.v[i].x, t1 = q.v[i].y - y.v[i].y;
+			const float t2 = q.v[i].z - y.v[i].z, t3 = q.v[i].w - y.v[i].w;
+			a0 = fmaf(t0, t0, a0);
+			a1 = fmaf(t1, t1, a1);
+			a2 = fmaf(t2, t2, a2);
+			a3 = fmaf(t3, t3, a3);
+		} else {
+			a0 = fmaf(q.v[i].x, y.v[i].x, a0);
+			a1 = fmaf(q.v[i].y, y.v[i].y, a1);
+			a2 = fmaf(q.v[i].z, y.v[i].z, a2);
+			a3 = fmaf(q.v[i].w, y.v[i].w, a3);
+		}
+	}
+	return (a0 + a1) + (a2 + a3);
+}
+
+template <int NI, bool IS_L2>
+__device__ __forceinline__ float wave_dist1(const QV<NI> &q, const float *vecs, int dp4, int id, int lane) {
+	QV<NI> y;
+	load_row(y, vecs + (size_t)id * dp4 * 4, dp4, lane);
+	const float t = wave_sum(lane_partial<NI, IS_L2>(q, y));
+	return rflf(IS_L2 ? t : -t);
+}
+
+// distances from q to the rows nid[l] of the lanes l in `mask`; lane l receives its own distance
+template <int NI, bool IS_L2, int G>
+__device__ __forceinline__ float eval_lanes(const QV<NI> &q, const float *vecs, int dp4, int nid, u64 mask, int lane) {
+	float mydd = 0.f;
+	while (mask) {
+		int ls[G], ids[G];
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			ls[g] = -1;
+			ids[g] = 0;
+			if (mask) {
+				ls[g] = (int)__builtin_ctzll(mask);
+				mask &= mask - 1;
+				ids[g] = __builtin_amdgcn_readlane(nid, ls[g]);
+			}
+		}
+		QV<NI> y[G];
+#pragma unroll
+		for (int g = 0; g < G; g++)
+			if (ls[g] >= 0)
+				load_row(y[g], vecs + (size_t)ids[g] * dp4 * 4, dp4, lane);
+#pragma unroll
+		for (int g = 0; g < G; g++)
+			if (ls[g] >= 0) {
+				const float t = wave_sum(lane_partial<NI, IS_L2>(q, y[g]));
+				if (lane == ls[g])
+					mydd = IS_L2 ? t : -t;
+			}
+	}
+	return mydd;
+}
+
+// keys[0..n) ascending; inserts nk, keeps at most cap entries (the largest falls off).  Returns the new count.
+__device__ __forceinline__ int sorted_insert(u64 *keys, int n, int cap, u64 nk, int lane) {
+	int pos = 0;
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + lane;
+		const bool lt = i < n && keys[i] < nk;
+		pos += (int)__popcll(__builtin_amdgcn_ballot_w64(lt));
+	}
+	if (pos >= cap)
+		return n;
+	const int n2 = n < cap ? n + 1 : cap;
+	for (int base = (n2 - 1) & ~63; base + 63 > pos; base -= 64) { // highest block first
+		const int i = base + lane;
+		const bool mv = i > pos && i < n2;
+		u64 t = 0;
+		if (mv)
+			t = keys[i - 1];
+		wave_fence();
+		if (mv)
+			keys[i] = t;
+		wave_fence();
+	}
+	if (lane == 0)
+		keys[pos] = nk;
+	wave_fence();
+	return n2;
+}
+
+struct GraphDev {
+	const float *vecs; // [n][4*dp4]
+	int dp4;
+	const long long *offsets; // [n+1]
+	int32_t *neighbors;
+	int M;
+};
+__device__ __forceinline__ int nb_at(const GraphDev &g, int level) {
+	return level == 0 ? 2 * g.M : g.M;
+}
+__device__ __forceinline__ int cum_at(const GraphDev &g, int level) {
+	return level == 0 ? 0 : (level + 1) * g.M;
+}
+template <bool ATOMIC>
+__device__ __forceinline__ int ld_nb(const int32_t *p) {
+	if (ATOMIC)
+		return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return *p;
+}
+__device__ __forceinline__ void st_nb(int32_t *p, int v) {
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lanes before the first empty slot (FAISS: "if (v < 0) break")
+__device__ __forceinline__ u64 valid_prefix(u64 vmask) {
+	const u64 inv = ~vmask;
+	return inv ? (vmask & ((1ull << __builtin_ctzll(inv)) - 1ull)) : vmask;
+}
+
+// HNSW.cpp greedy_update_nearest
+template <int NI, bool IS_L2, int G, bool ATOMIC>
+__device__ __forceinline__ void greedy_update_nearest(const GraphDev &g, const QV<NI> &q, int level, int &nearest,
+                                                      float &d_nearest, int lane, unsigned &ndis) {
+	const int L = nb_at(g, level);
+	for (;;) {
+		const int prev = nearest;
+		const long long base = g.offsets[nearest] + cum_at(g, level);
+		for (int c0 = 0; c0 < L; c0 += 64) {
+			const int j = c0 + lane;
+			const int nid = j < L ? ld_nb<ATOMIC>(g.neighbors + base + j) : -1;
+			const u64 vmask = __builtin_amdgcn_ballot_w64(nid >= 0);
+			u64 m = valid_prefix(vmask);
+			ndis += (unsigned)__popcll(m);
+			const float mydd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, m, lane);
+			while (m) {
+				const int l = (int)__builtin_ctzll(m);
+				m &= m - 1;
+				const float dd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydd), l));
+				if (dd < d_nearest) {
+					d_nearest = dd;
+					nearest = __builtin_amdgcn_readlane(nid, l);
+				}
+			}
+			if (~vmask)
+				break;
+		}
+		if (nearest == prev)
+			return;
+	}
+}
+
+__device__ __forceinline__ bool sel_member_dev(const SelectorDev &s, long long id) {
+	if (s.kind == MVS_SEL_BITMAP) {
+		const unsigned long long u = (unsigned long long)id;
+		if ((u >> 3) >= (unsigned long long)s.nbytes)
+			return false;
+		return (s.bitmap[u >> 3] >> (u & 7)) & 1;
+	}
+	if (s.kind == MVS_SEL_BATCH) {
+		long long lo = 0, hi = s.nids;
+		while (lo < hi) {
+			const long long mid = (lo + hi) >> 1;
+			if (s.sorted_ids[mid] < id)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo < s.nids && s.sorted_ids[lo] == id;
+	}
+	return true;
+}
+
+__device__ __forceinline__ void clear_table(uint8_t *vis, long long nbytes16, int lane) {
+	uint4 z = make_uint4(0, 0, 0, 0);
+	for (long long i = lane; i < nbytes16; i += 64)
+		reinterpret_cast<uint4 *>(vis)[i] = z;
+}
+
+// ------------------------------------------------------------------------------------------------ search kernel
+
+struct SearchArgs {
+	GraphDev g;
+	int entry_point, max_level;
+	const float *xq; // [nq][4*dp4]
+	long long nq;
+	int k, ef, efSearch;
+	SelectorDev sel;
+	const long long *idmap;
+	long long label_offset;
+	uint8_t *visited; // [grid][vstride]
+	long long vstride;
+	unsigned *vstamp; // [grid] rolling stamp, persists across searches
+	float *D;
+	long long *I;
+	unsigned long long *stats; // [0] distance evaluations, [1] expanded vertices
+};
+
+template <int NI, bool IS_L2, int G>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
+	extern __shared__ u64 smem[];
+	u64 *ckeys = smem;        // MinimaxHeap candidates(ef)
+	u64 *rkeys = smem + a.ef; // result heap (k)
+	const int lane = threadIdx.x;
+	const GraphDev &g = a.g;
+	uint8_t *vis = a.visited + (size_t)blockIdx.x * a.vstride;
+	unsigned stamp = a.vstamp[blockIdx.x], ndis = 0, nexp = 0;
+	const int ef = a.ef, k = a.k;
+	for (long long qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+		if (++stamp == 256) {
+			clear_table(vis, a.vstride / 16, lane);
+			stamp = 1;
+		}
+		QV<NI> q;
+		load_row(q, a.xq + (size_t)qi * g.dp4 * 4, g.dp4, lane);
+		int nearest = a.entry_point;
+		float d_nearest = wave_dist1<NI, IS_L2>(q, g.vecs, g.dp4, nearest, lane);
+		ndis++;
+		for (int level = a.max_level; level >= 1; level--)
+			greedy_update_nearest<NI, IS_L2, G, false>(g, q, level, nearest, d_nearest, lane, ndis);
+		// ---- search_from_candidates, level 0
+		int nc = 0, nr = 0, nvalid = 0;
+		nc = sorted_insert(ckeys, nc, ef, mk_key(d_nearest, nearest), lane);
+		nvalid = 1;
+		float rthr = FLT_MAX; // heap threshold: the k-heap starts full of (FLT_MAX, -1)
+		{
+			const bool pass = a.sel.kind == MVS_SEL_NONE || sel_member_dev(a.sel, a.idmap ? a.idmap[nearest] : nearest);
+			if (pass && d_nearest < rthr) {
+				nr = sorted_insert(rkeys, nr, k, mk_key(d_nearest, nearest), lane);
+				rthr = nr < k ? FLT_MAX : key_dis(rfl64(rkeys[k - 1]));
+			}
+		}
+		if (lane == 0)
+			vis[nearest] = (uint8_t)stamp;
+		while (nvalid > 0) {
+			// pop_min: first live entry of the sorted array
+			int pos = -1;
+			for (int base = 0; base < nc && pos < 0; base += 64) {
+				const int i = base + lane;
+				const bool live = i < nc && (unsigned)ckeys[i] != 0u;
+				const u64 m = __builtin_amdgcn_ballot_w64(live);
+				if (m)
+					pos = base + (int)__builtin_ctzll(m);
+			}
+			const u64 ck = rfl64(ckeys[pos]);
+			const int v0 = key_id(ck);
+			if (lane == 0)
+				ckeys[pos] = ck & 0xffffffff00000000ull; // tombstone keeps its distance
+			wave_fence();
+			nvalid--;
+			// count_below(d0) >= efSearch -> stop (check_relative_distance)
+			int nbelow = 0;
+			for (int base = 0; base < nc; base += 64) {
+				const int i = base + lane;
+				const bool lt = i < nc && (unsigned)(ckeys[i] >> 32) < (unsigned)(ck >> 32);
+				nbelow += (int)__popcll(__builtin_amdgcn_ballot_w64(lt));
+			}
+			if (nbelow >= a.efSearch)
+				break;
+			nexp++;
+			const long long base0 = g.offsets[v0];
+			const int L = 2 * g.M;
+			for (int c0 = 0; c0 < L; c0 += 64) {
+				const int j = c0 + lane;
+				const int nid = j < L ? g.neighbors[base0 + j] : -1;
+				const u64 vmask = __builtin_amdgcn_ballot_w64(nid >= 0);
+				const u64 pm = valid_prefix(vmask);
+				const bool valid = (pm >> lane) & 1ull;
+				bool fresh = false;
+				if (valid) {
+					fresh = vis[nid] != (uint8_t)stamp;
+					if (fresh)
+						vis[nid] = (uint8_t)stamp;
+				}
+				const u64 fmask = __builtin_amdgcn_ballot_w64(fresh);
+				ndis += (unsigned)__popcll(fmask);
+				const float mydd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, fmask, lane);
+				bool pass = fresh;
+				if (fresh && a.sel.kind != MVS_SEL_NONE)
+					pass = sel_member_dev(a.sel, a.idmap ? a.idmap[nid] : nid);
+				const float cmax = nc < ef ? FLT_MAX : key_dis(rfl64(ckeys[ef - 1]));
+				// thresholds only ever tighten, so lanes rejected now stay rejected during the sequential pass
+				const bool maybe = fresh && (nc < ef || mydd < cmax || (pass && mydd < rthr));
+				u64 mm = __builtin_amdgcn_ballot_w64(maybe);
+				const u64 passmask = __builtin_amdgcn_ballot_w64(pass);
+				while (mm) {
+					const int l = (int)__builtin_ctzll(mm);
+					mm &= mm - 1;
+					const float dd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydd), l));
+					const int id = __builtin_amdgcn_readlane(nid, l);
+					const u64 key = mk_key(dd, id);
+					if (((passmask >> l) & 1ull) && dd < rthr) { // res.add_result
+						nr = sorted_insert(rkeys, nr, k, key, lane);
+						rthr = nr < k ? FLT_MAX : key_dis(rfl64(rkeys[k - 1]));
+					}
+					// candidates.push(v1, d)
+					if (nc == ef) {
+						const u64 last = rfl64(ckeys[ef - 1]);
+						if (dd >= key_dis(last))
+							continue;
+						if ((unsigned)last != 0u)
+							nvalid--;
+					}
+					nc = sorted_insert(ckeys, nc, ef, key, lane);
+					nvalid++;
+				}
+				if (~vmask)
+					break;
+			}
+		}
+		// ---- heap_reorder + (IP) sign restore + label translation
+		for (int j = lane; j < k; j += 64) {
+			float dv = IS_L2 ? FLT_MAX : -FLT_MAX;
+			long long lab = -1;
+			if (j < nr) {
+				const u64 rk = rkeys[j];
+				const float dd = key_dis(rk);
+				dv = IS_L2 ? dd : -dd;
+				const int id = key_id(rk);
+				lab = a.idmap ? a.idmap[id] : (long long)id + a.label_offset;
+			}
+			a.D[qi * k + j] = dv;
+			a.I[qi * k + j] = lab;
+		}
+		wave_fence();
+	}
+	if (lane == 0) {
+		a.vstamp[blockIdx.x] = stamp;
+		if (a.stats) {
+			atomicAdd(&a.stats[0], (unsigned long long)ndis);
+			atomicAdd(&a.stats[1], (unsigned long long)nexp);
+		}
+	}
+}
+
+__global__ void hnsw_fill_empty_kernel(float *D, long long *I, long long n, float neutral) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		D[i] = neutral;
+		I[i] = -1;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ build kernel
+
+struct BuildArgs {
+	GraphDev g;
+	int entry_point, max_level;
+	int efC;
+	const int32_t *order; // insertion order of this add() call
+	int i0, i1;           // slice of `order` handled by this launch (all of level pt_level)
+	int pt_level;
+	int *counter;
+	int *locks;
+	int use_locks;
+	uint8_t *visited; // [grid][vstride]
+	long long vstride;
+	unsigned *vstamp; // [grid] rolling stamp, persists across launches
+	unsigned long long *stats;
+};
+
+__device__ __forceinline__ void wave_lock(const BuildArgs &a, int v, int lane) {
+	if (!a.use_locks)
+		return;
+	for (;;) {
+		int got = 0;
+		if (lane == 0) {
+			int expected = 0;
+			got = __hip_atomic_compare_exchange_strong(&a.locks[v], &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+			                                           __HIP_MEMORY_SCOPE_AGENT)
+			          ? 1
+			          : 0;
+		}
+		if (rfl(got))
+			break;
+		__builtin_amdgcn_s_sleep(8);
+	}
+	__atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ void wave_unlock(const BuildArgs &a, int v, int lane) {
+	if (!a.use_locks)
+		return;
+	__atomic_signal_fence(__ATOMIC_SEQ_CST);
+	__builtin_amdgcn_s_waitcnt(0); // every list store of this wave has been acknowledged
+	if (lane == 0)
+		__hip_atomic_store(&a.locks[v], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
+// HNSW.cpp shrink_neighbor_list on candidates sorted closest-first; result closest-first in out_id/out_d
+template <int NI, bool IS_L2, int G>
+__device__ __forceinline__ int shrink_select(const GraphDev &g, const u64 *keys, int n, int max_size, int *out_id,
+                                             float *out_d, int lane, unsigned &ndis) {
+	if (n < max_size) { // "if (input.size() < max_size) return;"
+		for (int j = lane; j < n; j += 64) {
+			const u64 kk = keys[j];
+			out_id[j] = key_id(kk);
+			out_d[j] = key_dis(kk);
+		}
+		wave_fence();
+		return n;
+	}
+	int nout = 0;
+	for (int c = 0; c < n; c++) {
+		const u64 ck = rfl64(keys[c]);
+		const int v1 = key_id(ck);
+		const float d1 = key_dis(ck);
+		bool good = true;
+		if (nout > 0) {
+			QV<NI> qc;
+			load_row(qc, g.vecs + (size_t)v1 * g.dp4 * 4, g.dp4, lane);
+			for (int j0 = 0; j0 < nout && good; j0 += 64) {
+				const int j = j0 + lane;
+				const int kid = j < nout ? out_id[j] : -1;
+				u64 m = __builtin_amdgcn_ballot_w64(j < nout);
+				// groups of G kept rows, stop at the first group holding a closer kept neighbour
+				while (m && good) {
+					u64 sub = 0;
+#pragma unroll
+					for (int t = 0; t < G; t++)
+						if (m) {
+							sub |= m & (~m + 1);
+							m &= m - 1;
+						}
+					ndis += (unsigned)__popcll(sub);
+					const float dd = eval_lanes<NI, IS_L2, G>(qc, g.vecs, g.dp4, kid, sub, lane);
+					const bool closer = ((sub >> lane) & 1ull) && dd < d1;
+					if (__builtin_amdgcn_ballot_w64(closer))
+						good = false;
+				}
+			}
+		}
+		if (good) {
+			if (lane == 0) {
+				out_id[nout] = v1;
+				out_d[nout] = d1;
+			}
+			wave_fence();
+			nout++;
+			if (nout >= max_size)
+				break;
+		}
+	}
+	return nout;
+}
+
+// HNSW.cpp add_link(src -> dest); srcq = row of src
+template <int NI, bool IS_L2, int G>
+__device__ __forceinline__ void add_link(const GraphDev &g, const QV<NI> &srcq, int src, int dest, int level, u64 *tkeys,
+                                         int *out_id, float *out_d, int lane, unsigned &ndis) {
+	const int L = nb_at(g, level);
+	int32_t *list = g.neighbors + g.offsets[src] + cum_at(g, level);
+	if (rfl(ld_nb<true>(list + L - 1)) == -1) { // room left: first free slot
+		int cnt = 0;
+		for (int c0 = 0; c0 < L; c0 += 64) {
+			const int j = c0 + lane;
+			const int nid = j < L ? ld_nb<true>(list + j) : -1;
+			const u64 vmask = __builtin_amdgcn_ballot_w64(nid >= 0);
+			// FAISS scans from the end for the last used slot; lists are packed, so that is the valid prefix
+			const u64 inv = ~vmask;
+			if (inv) {
+				cnt = c0 + (int)__builtin_ctzll(inv);
+				break;
+			}
+			cnt = c0 + 64;
+		}
+		if (lane == 0)
+			st_nb(list + cnt, dest);
+		return;
+	}
+	// full: shrink (current neighbours + dest) back to L
+	int nt = 0;
+	for (int c0 = 0; c0 < L; c0 += 64) {
+		const int j = c0 + lane;
+		const int nid = j < L ? ld_nb<true>(list + j) : -1;
+		u64 m = __builtin_amdgcn_ballot_w64(j < L && nid >= 0);
+		ndis += (unsigned)__popcll(m);
+		const float mydd = eval_lanes<NI, IS_L2, G>(srcq, g.vecs, g.dp4, nid, m, lane);
+		while (m) {
+			const int l = (int)__builtin_ctzll(m);
+			m &= m - 1;
+			const float dd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydd), l));
+			nt = sorted_insert(tkeys, nt, L + 1, mk_key(dd, __builtin_amdgcn_readlane(nid, l)), lane);
+		}
+	}
+	{
+		const float dd = wave_dist1<NI, IS_L2>(srcq, g.vecs, g.dp4, dest, lane);
+		ndis++;
+		nt = sorted_insert(tkeys, nt, L + 1, mk_key(dd, dest), lane);
+	}
+	const int nout = shrink_select<NI, IS_L2, G>(g, tkeys, nt, L, out_id, out_d, lane, ndis);
+	// "while (resultSet.size()) neighbors[i++] = resultSet.top().id" : farthest first, then -1
+	for (int c0 = 0; c0 < L; c0 += 64) {
+		const int j = c0 + lane;
+		if (j < L)
+			st_nb(list + j, j < nout ? out_id[nout - 1 - j] : -1);
+	}
+}
+
+template <int NI, bool IS_L2, int G>
+__global__ __launch_bounds__(64) void hnsw_build_kernel(const BuildArgs a) {
+	extern __shared__ u64 smem[];
+	const GraphDev &g = a.g;
+	const int L0 = 2 * g.M;
+	u64 *rkeys = smem;                      // [efC] construction result set, bit 0 = already expanded
+	u64 *tkeys = rkeys + a.efC;             // [2M+1] add_link scratch
+	int *out_id = (int *)(tkeys + L0 + 1);  // [2M+1]
+	float *out_d = (float *)(out_id + L0 + 1);
+	int *sel_id = (int *)(out_d + L0 + 1);  // [2M] link targets of the current level
+	const int lane = threadIdx.x;
+	uint8_t *vis = a.visited + (size_t)blockIdx.x * a.vstride;
+	unsigned stamp = a.vstamp[blockIdx.x];
+	unsigned ndis = 0;
+	const int efC = a.efC;
+	for (;;) {
+		int i = 0;
+		if (lane == 0)
+			i = atomicAdd(a.counter, 1);
+		i = rfl(i) + a.i0;
+		if (i >= a.i1)
+			break;
+		const int pt = a.order[i];
+		QV<NI> q;
+		load_row(q, g.vecs + (size_t)pt * g.dp4 * 4, g.dp4, lane);
+		wave_lock(a, pt, lane);
+		int nearest = a.entry_point;
+		float d_nearest = wave_dist1<NI, IS_L2>(q, g.vecs, g.dp4, nearest, lane);
+		ndis++;
+		int level = a.max_level;
+		for (; level > a.pt_level; level--)
+			greedy_update_nearest<NI, IS_L2, G, true>(g, q, level, nearest, d_nearest, lane, ndis);
+		for (; level >= 0; level--) {
+			// ---- search_neighbors_to_add: candidates = the not yet expanded entries of the result set
+			if (++stamp == 256) {
+				clear_table(vis, a.vstride / 16, lane);
+				stamp = 1;
+			}
+			int nr = sorted_insert(rkeys, 0, efC, mk_key(d_nearest, nearest), lane);
+			if (lane == 0)
+				vis[nearest] = (uint8_t)stamp;
+			const int L = nb_at(g, level);
+			for (;;) {
+				int pos = -1;
+				for (int base = 0; base < nr && pos < 0; base += 64) {
+					const int i2 = base + lane;
+					const bool open = i2 < nr && ((unsigned)rkeys[i2] & 1u) == 0u;
+					const u64 m = __builtin_amdgcn_ballot_w64(open);
+					if (m)
+						pos = base + (int)__builtin_ctzll(m);
+				}
+				if (pos < 0)
+					break;
+				const u64 ck = rfl64(rkeys[pos]);
+				if (lane == 0)
+					rkeys[pos] = ck | 1ull;
+				wave_fence();
+				const int cur = key_id(ck);
+				const long long base0 = g.offsets[cur] + cum_at(g, level);
+				for (int c0 = 0; c0 < L; c0 += 64) {
+					const int j = c0 + lane;
+					const int nid = j < L ? ld_nb<true>(g.neighbors + base0 + j) : -1;
+					const u64 vmask = __builtin_amdgcn_ballot_w64(nid >= 0);
+					const u64 pm = valid_prefix(vmask);
+					bool fresh = false;
+					if ((pm >> lane) & 1ull) {
+						fresh = vis[nid] != (uint8_t)stamp;
+						if (fresh)
+							vis[nid] = (uint8_t)stamp;
+					}
+					const u64 fmask = __builtin_amdgcn_ballot_w64(fresh);
+					ndis += (unsigned)__popcll(fmask);
+					const float mydd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, fmask, lane);
+					const float wmax = nr < efC ? FLT_MAX : key_dis(rfl64(rkeys[efC - 1]));
+					u64 mm = __builtin_amdgcn_ballot_w64(fresh && (nr < efC || mydd < wmax));
+					while (mm) {
+						const int l = (int)__builtin_ctzll(mm);
+						mm &= mm - 1;
+						const float dd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydd), l));
+						// "if (results.size() < efConstruction || results.top().d > dis)"
+						if (nr < efC || key_dis(rfl64(rkeys[nr - 1])) > dd)
+							nr = sorted_insert(rkeys, nr, efC, mk_key(dd, __builtin_amdgcn_readlane(nid, l)), lane);
+					}
+					if (~vmask)
+						break;
+				}
+			}
+			// ---- shrink to the level's capacity, then link both ways (add_links_starting_from)
+			const int nsel = shrink_select<NI, IS_L2, G>(g, rkeys, nr, L, out_id, out_d, lane, ndis);
+			for (int j = lane; j < nsel; j += 64)
+				sel_id[j] = out_id[nsel - 1 - j]; // priority_queue pops the farthest first
+			wave_fence();
+			for (int t = 0; t < nsel; t++)
+				add_link<NI, IS_L2, G>(g, q, pt, rfl(sel_id[t]), level, tkeys, out_id, out_d, lane, ndis);
+			wave_unlock(a, pt, lane);
+			for (int t = 0; t < nsel; t++) {
+				const int other = rfl(sel_id[t]);
+				wave_lock(a, other, lane);
+				QV<NI> qo;
+				load_row(qo, g.vecs + (size_t)other * g.dp4 * 4, g.dp4, lane);
+				add_link<NI, IS_L2, G>(g, qo, other, pt, level, tkeys, out_id, out_d, lane, ndis);
+				wave_unlock(a, other, lane);
+			}
+			wave_lock(a, pt, lane);
+		}
+		wave_unlock(a, pt, lane);
+	}
+	if (lane == 0) {
+		a.vstamp[blockIdx.x] = stamp;
+		if (a.stats)
+			atomicAdd(&a.stats[0], (unsigned long long)ndis);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch on d
+
+template <template <int, bool, int> class F, typename... A>
+void dispatch_ni(int dp4, bool is_l2, A &&...args) {
+	const int ni = (dp4 + 63) / 64;
+#define MVS_NI_CASE(NI, G)                                                                                             \
+	if (ni <= NI) {                                                                                                    \
+		if (is_l2)                                                                                                     \
+			F<NI, true, G>::run(std::forward<A>(args)...);                                                             \
+		else                                                                                                           \
+			F<NI, false, G>::run(std::forward<A>(args)...);                                                            \
+		return;                                                                                                        \
+	}
+	MVS_NI_CASE(1, 4)
+	MVS_NI_CASE(2, 4)
+	MVS_NI_CASE(3, 4)
+	MVS_NI_CASE(4, 2)
+	MVS_NI_CASE(6, 2)
+	MVS_NI_CASE(8, 1)
+	MVS_NI_CASE(16, 1)
+#undef MVS_NI_CASE
+	throw_faiss("mvs::HNSWIndex", __FILE__, "dimension %d exceeds the supported maximum 4096", dp4 * 4);
+}
+
+template <int NI, bool IS_L2, int G>
+struct SearchLaunch {
+	static void run(const SearchArgs &a, int grid, size_t lds, hipStream_t st) {
+		MVS_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<NI, IS_L2, G>,
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL((hnsw_search_kernel<NI, IS_L2, G>), dim3(grid), dim3(64), lds, st, a);
+		MVS_HIP(hipGetLastError());
+	}
+};
+template <int NI, bool IS_L2, int G>
+struct BuildLaunch {
+	static void run(const BuildArgs &a, int grid, size_t lds, hipStream_t st) {
+		MVS_HIP(hipFuncSetAttribute((const void *)hnsw_build_kernel<NI, IS_L2, G>,
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL((hnsw_build_kernel<NI, IS_L2, G>), dim3(grid), dim3(64), lds, st, a);
+		MVS_HIP(hipGetLastError());
+	}
+};
+
+// device buffer that keeps its contents when it grows
+struct KeepBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	void ensure(size_t need, size_t used, hipStream_t st, int fill = -2) {
+		if (need <= cap)
+			return;
+		size_t nc = cap ? cap : 4096;
+		while (nc < need)
+			nc = nc + nc / 2 + 4096;
+		void *np = nullptr;
+		MVS_HIP(hipMalloc(&np, nc));
+		if (fill != -2)
+			MVS_HIP(hipMemsetAsync(np, fill, nc, st));
+		if (used > 0 && p)
+			MVS_HIP(hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		if (p)
+			MVS_HIP(hipFree(p));
+		p = np;
+		cap = nc;
+	}
+	void release() {
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+} // namespace
+
+// =================================================================================================== HNSWIndex
+
+class HNSWIndex : public IndexBase {
+public:
+	int M;
+	int efConstruction = 40; // HNSW::efConstruction default
+	int efSearch = 16;       // HNSW::efSearch default (the glue always passes SearchParametersHNSW, :693)
+	int dp, dp4;
+	int64_t build_waves = 0; // 0 = auto (concurrent, FAISS OpenMP semantics); 1 = deterministic order
+	int entry_point = -1, max_level = -1;
+
+	HNSWIndex(int d_, int M_, int metric_) : IndexBase(MVS_KIND_HNSW, d_, metric_), M(M_), rng(12345) {
+		if (metric != METRIC_L2 && metric != METRIC_IP)
+			throw_faiss("mvs::HNSWIndex", __FILE__, "metric type %d is not implemented on the MI355X path", metric);
+		if (M < 2 || M > 512)
+			throw_faiss("mvs::HNSWIndex", __FILE__, "HNSW M = %d outside the supported range [2, 512]", M);
+		dp = (d + 3) / 4 * 4;
+		dp4 = dp / 4;
+		if (dp4 > 64 * 16)
+			throw_faiss("mvs::HNSWIndex", __FILE__, "dimension %d exceeds the supported maximum 4096", d);
+		// HNSW::set_default_probas(M, 1 / log(M))
+		const double mult = 1.0 / std::log((double)M);
+		int nn = 0;
+		cum_nn.push_back(0);
+		for (int level = 0;; level++) {
+			const double proba = std::exp(-level / mult) * (1 - std::exp(-1 / mult));
+			if (proba < 1e-9)
+				break;
+			assign_probas.push_back(proba);
+			nn += level == 0 ? M * 2 : M;
+			cum_nn.push_back(nn);
+		}
+		offsets_h.push_back(0);
+	}
+	~HNSWIndex() override {
+		(void)hipSetDevice(device);
+		if (stream)
+			(void)hipStreamSynchronize(stream);
+		vecs.release();
+		offsets.release();
+		neighbors.release();
+		locks.release();
+	}
+
+	// ---------------------------------------------------------------------------------------------- add
+	int random_level() {
+		double f = (double)((float)rng() / (float)rng.max()); // RandomGenerator::rand_float
+		for (size_t level = 0; level < assign_probas.size(); level++) {
+			if (f < assign_probas[level])
+				return (int)level;
+			f -= assign_probas[level];
+		}
+		return (int)assign_probas.size() - 1;
+	}
+
+	GraphDev graph_dev() const {
+		GraphDev g;
+		g.vecs = (const float *)vecs.p;
+		g.dp4 = dp4;
+		g.offsets = (const long long *)offsets.p;
+		g.neighbors = (int32_t *)neighbors.p;
+		g.M = M;
+		return g;
+	}
+
+	void launch_build(const int32_t *d_order, int i0, int i1, int pt_level, int waves) {
+		if (i1 <= i0)
+			return;
+		BuildArgs a;
+		a.g = graph_dev();
+		a.entry_point = entry_point;
+		a.max_level = max_level;
+		a.efC = efConstruction;
+		a.order = d_order;
+		a.i0 = i0;
+		a.i1 = i1;
+		a.pt_level = pt_level;
+		a.counter = (int *)ws_counter.p;
+		a.locks = (int *)locks.p;
+		a.use_locks = waves > 1;
+		a.visited = (uint8_t *)bvis.p;
+		a.vstride = bvis_stride;
+		a.vstamp = (unsigned *)bstamp.p;
+		a.stats = (unsigned long long *)ws_stats.p;
+		MVS_HIP(hipMemsetAsync(ws_counter.p, 0, sizeof(int), stream));
+		const int L0 = 2 * M;
+		const size_t lds = (size_t)(efConstruction + L0 + 1) * 8 + (size_t)(L0 + 1) * 8 + (size_t)L0 * 4 + 64;
+		dispatch_ni<BuildLaunch>(dp4, metric == METRIC_L2, a, waves, lds, stream);
+	}
+
+	// d_x: [n][d] rows on device, ordered after everything enqueued on `stream`
+	void add_core_device(int64_t n, const float *d_x) {
+		if (n <= 0)
+			return;
+		if (ntotal + n > (int64_t)0x3fffffff)
+			throw_faiss("mvs::HNSWIndex::add", __FILE__, "a single-device HNSW index holds at most 2^30 rows");
+		if (efConstruction < 1 || efConstruction > 4096)
+			throw_faiss("mvs::HNSWIndex::add", __FILE__, "efConstruction = %d outside the supported range [1, 4096]",
+			            efConstruction);
+		const int64_t n0 = ntotal, nt = ntotal + n;
+		// storage->add(n, x)
+		vecs.ensure((size_t)nt * dp * sizeof(float), (size_t)n0 * dp * sizeof(float), stream);
+		launch_pad_rows(d_x, n, d, (float *)vecs.p + (size_t)n0 * dp, dp, stream);
+		// prepare_level_tab
+		levels_h.resize((size_t)nt);
+		offsets_h.resize((size_t)nt + 1);
+		int bucket_max = 0;
+		for (int64_t i = 0; i < n; i++) {
+			const int pt_level = random_level();
+			levels_h[(size_t)(n0 + i)] = pt_level + 1;
+			bucket_max = std::max(bucket_max, pt_level);
+			offsets_h[(size_t)(n0 + i + 1)] = offsets_h[(size_t)(n0 + i)] + cum_nn[(size_t)pt_level + 1];
+		}
+		offsets.ensure((size_t)(nt + 1) * sizeof(int64_t), (size_t)(n0 + 1) * sizeof(int64_t), stream);
+		MVS_HIP(hipMemcpyAsync((int64_t *)offsets.p + n0, &offsets_h[(size_t)n0], (size_t)(n + 1) * sizeof(int64_t),
+		                       hipMemcpyHostToDevice, stream));
+		const size_t nb_old = (size_t)offsets_h[(size_t)n0] * 4, nb_new = (size_t)offsets_h[(size_t)nt] * 4;
+		neighbors.ensure(nb_new, nb_old, stream);
+		MVS_HIP(hipMemsetAsync((char *)neighbors.p + nb_old, 0xFF, nb_new - nb_old, stream)); // -1 = empty slot
+		locks.ensure((size_t)nt * sizeof(int), (size_t)n0 * sizeof(int), stream, 0);
+		// hnsw_add_vertices: bucket sort by level, per bucket (highest level first) shuffle with rng2(789)
+		std::vector<int> hist((size_t)bucket_max + 1, 0);
+		for (int64_t i = 0; i < n; i++)
+			hist[(size_t)levels_h[(size_t)(n0 + i)] - 1]++;
+		std::vector<int> off((size_t)bucket_max + 2, 0);
+		for (int l = 0; l <= bucket_max; l++)
+			off[(size_t)l + 1] = off[(size_t)l] + hist[(size_t)l];
+		std::vector<int32_t> order((size_t)n);
+		{
+			std::vector<int> cur(off.begin(), off.end() - 1);
+			for (int64_t i = 0; i < n; i++)
+				order[(size_t)cur[(size_t)levels_h[(size_t)(n0 + i)] - 1]++] = (int32_t)(n0 + i);
+		}
+		std::mt19937 rng2(789);
+		{
+			int i1 = (int)n;
+			for (int pt_level = bucket_max; pt_level >= 0; pt_level--) {
+				const int i0 = i1 - hist[(size_t)pt_level];
+				for (int j = i0; j < i1; j++)
+					std::swap(order[(size_t)j], order[(size_t)(j + (int)(rng2() % (uint32_t)(i1 - j)))]);
+				i1 = i0;
+			}
+		}
+		ws_order.reserve((size_t)n * sizeof(int32_t));
+		MVS_HIP(hipMemcpyAsync(ws_order.p, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		ws_counter.reserve(64);
+		ws_stats.reserve(64);
+		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 16, stream));
+		// visited tables of the build waves
+		int max_waves = build_waves > 0 ? (int)std::min<int64_t>(build_waves, 4096) : 1024;
+		const size_t vcap = vecs.cap / ((size_t)dp * sizeof(float)); // rows the vector store can hold
+		const size_t stride = (vcap + 15) / 16 * 16;
+		max_waves = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_waves, ((size_t)8 << 30) / stride));
+		if (stride != (size_t)bvis_stride || (size_t)max_waves > (size_t)bvis_waves) {
+			bvis.reserve(stride * (size_t)max_waves);
+			bstamp.reserve((size_t)max_waves * sizeof(unsigned));
+			MVS_HIP(hipMemsetAsync(bvis.p, 0, stride * (size_t)max_waves, stream));
+			MVS_HIP(hipMemsetAsync(bstamp.p, 0, (size_t)max_waves * sizeof(unsigned), stream));
+			bvis_stride = (int64_t)stride;
+			bvis_waves = max_waves;
+		}
+		// insert, bucket by bucket
+		ntotal = nt; // the kernels address rows up to nt
+		int64_t inserted = n0;
+		int i1 = (int)n;
+		for (int pt_level = bucket_max; pt_level >= 0; pt_level--) {
+			const int i0 = i1 - hist[(size_t)pt_level];
+			int pos = i0;
+			if (pos < i1 && entry_point < 0) { // very first vertex: becomes the entry point, no links
+				entry_point = order[(size_t)pos];
+				max_level = pt_level;
+				pos++;
+				inserted++;
+			} else if (pos < i1 && pt_level > max_level) {
+				// the first point above the current top level is linked alone, then becomes the entry point
+				launch_build((const int32_t *)ws_order.p, pos, pos + 1, pt_level, 1);
+				entry_point = order[(size_t)pos];
+				max_level = pt_level;
+				pos++;
+				inserted++;
+			}
+			while (pos < i1) {
+				int waves, seg;
+				if (build_waves == 1) {
+					waves = 1;
+					seg = i1 - pos;
+				} else {
+					// concurrency grows with the graph so that concurrent inserts stay a small fraction of it
+					waves = (int)std::max<int64_t>(1, std::min<int64_t>(max_waves, inserted / 32));
+					seg = std::min(i1 - pos, waves * 8);
+				}
+				launch_build((const int32_t *)ws_order.p, pos, pos + seg, pt_level, std::min(waves, seg));
+				pos += seg;
+				inserted += seg;
+			}
+			i1 = i0;
+		}
+		MVS_HIP(hipStreamSynchronize(stream)); // `order` (pageable) and the caller's rows are done
+		unsigned long long st[2] = {0, 0};
+		MVS_HIP(hipMemcpy(st, ws_stats.p, sizeof st, hipMemcpyDeviceToHost));
+		build_distances += st[0];
+	}
+	void add(int64_t n, const float *x) override {
+		use_device();
+		if (n <= 0)
+			return;
+		DevBuf dx;
+		dx.reserve((size_t)n * d * sizeof(float));
+		MVS_HIP(hipMemcpyAsync(dx.p, x, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice, stream));
+		add_core_device(n, (const float *)dx.p);
+	}
+	void add_device(int64_t n, const float *d_x, hipStream_t st) override {
+		use_device();
+		if (n <= 0)
+			return;
+		stream_wait(stream, st);
+		add_core_device(n, d_x);
+		stream_wait(st, stream);
+	}
+
+	// ---------------------------------------------------------------------------------------------- search
+	void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                   const int64_t *d_idmap, hipStream_t st) override {
+		use_device();
+		if (k <= 0)
+			throw_faiss("virtual void faiss::IndexHNSW::search(...) const", "faiss/IndexHNSW.cpp",
+			            "Error: 'k > 0' failed");
+		if (nq <= 0)
+			return;
+		const int64_t efs = params && params->efSearch > 0 ? params->efSearch : efSearch;
+		const int64_t ef = std::max(efs, k);
+		if (ef > 4096)
+			throw_faiss("mvs::HNSWIndex::search", __FILE__, "max(efSearch, k) = %lld exceeds the supported maximum 4096",
+			            (long long)ef);
+		stream_wait(stream, st);
+		memset(&kinfo, 0, sizeof kinfo);
+		if (ntotal == 0 || entry_point < 0) {
+			const long long tot = nq * k;
+			hipLaunchKernelGGL(hnsw_fill_empty_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, d_D,
+			                   (long long *)d_I, tot, metric == METRIC_L2 ? FLT_MAX : -FLT_MAX);
+			MVS_HIP(hipGetLastError());
+			stream_wait(st, stream);
+			return;
+		}
+		ws_q.reserve((size_t)nq * dp * sizeof(float));
+		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
+		const size_t lds = (size_t)(ef + k) * 8 + 64;
+		// resident waves: 16 per CU unless LDS says otherwise
+		int cus = 256;
+		{
+			hipDeviceProp_t prop;
+			if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+				cus = prop.multiProcessorCount;
+		}
+		const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(150 * 1024) / lds));
+		// visited tables (one byte per vertex per wave) persist across searches; the rolling stamp makes a fresh
+		// table unnecessary, they are zeroed only when (re)allocated
+		const size_t vcap = vecs.cap / ((size_t)dp * sizeof(float));
+		const size_t stride = (vcap + 15) / 16 * 16;
+		int grid = (int)std::min<int64_t>(nq, (int64_t)cus * per_cu);
+		grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)grid, ((size_t)16 << 30) / stride));
+		if ((int64_t)stride != svis_stride || grid > svis_waves) {
+			const int nw = std::max(grid, svis_waves);
+			ws_vis.reserve(stride * (size_t)nw);
+			sstamp.reserve((size_t)nw * sizeof(unsigned));
+			MVS_HIP(hipMemsetAsync(ws_vis.p, 0, stride * (size_t)nw, stream));
+			MVS_HIP(hipMemsetAsync(sstamp.p, 0, (size_t)nw * sizeof(unsigned), stream));
+			svis_stride = (int64_t)stride;
+			svis_waves = nw;
+		}
+		ws_stats.reserve(64);
+		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 16, stream));
+		SearchArgs a;
+		a.g = graph_dev();
+		a.entry_point = entry_point;
+		a.max_level = max_level;
+		a.xq = (const float *)ws_q.p;
+		a.nq = nq;
+		a.k = (int)k;
+		a.ef = (int)ef;
+		a.efSearch = (int)efs;
+		a.sel = selector.upload(params, stream);
+		a.idmap = (const long long *)d_idmap;
+		a.label_offset = label_offset;
+		a.visited = (uint8_t *)ws_vis.p;
+		a.vstride = (long long)stride;
+		a.vstamp = (unsigned *)sstamp.p;
+		a.D = d_D;
+		a.I = (long long *)d_I;
+		a.stats = (unsigned long long *)ws_stats.p;
+		begin_kernel_timing(stream);
+		dispatch_ni<SearchLaunch>(dp4, metric == METRIC_L2, a, grid, lds, stream);
+		end_kernel_timing(stream);
+		unsigned long long stt[2] = {0, 0};
+		MVS_HIP(hipMemcpyAsync(stt, ws_stats.p, sizeof stt, hipMemcpyDeviceToHost, stream));
+		MVS_HIP(hipStreamSynchronize(stream));
+		stream_wait(st, stream);
+		snprintf(kinfo.name, sizeof kinfo.name, "hnsw_search_kernel");
+		kinfo.bytes = (double)stt[0] * ((double)d * 4.0 + 4.0); // n_visited * (4d + 4), counted by the kernel
+		kinfo.flops = (double)stt[0] * d * (metric == METRIC_L2 ? 3.0 : 2.0);
+		kinfo.grid = grid;
+		kinfo.block = 64;
+		kinfo.lds_bytes = (int)lds;
+		kinfo.nsplit = (int)(stt[1] / (unsigned long long)std::max<int64_t>(nq, 1)); // mean expanded vertices per query
+	}
+	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                   hipStream_t st) override {
+		search_mapped(nq, d_x, k, d_D, d_I, params, nullptr, st);
+	}
+
+	// ---------------------------------------------------------------------------------------------- placement
+	void to_device(int new_device) override {
+		if (new_device == device)
+			return;
+		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
+		            "moving an HNSW index between devices is not implemented on the MI355X path yet");
+	}
+	IndexBase *clone(int on_device) override {
+		int ndev = 0;
+		MVS_HIP(hipGetDeviceCount(&ndev));
+		if (on_device < 0 || on_device >= ndev)
+			throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "Invalid GPU device %d", on_device);
+		if (on_device != device)
+			throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
+			            "This index type is not implemented for cloning across devices on the MI355X path yet (HNSW)");
+		use_device();
+		MVS_HIP(hipStreamSynchronize(stream));
+		auto *c = new HNSWIndex(d, M, metric);
+		try {
+			c->efConstruction = efConstruction;
+			c->efSearch = efSearch;
+			c->build_waves = build_waves;
+			c->rng = rng;
+			c->levels_h = levels_h;
+			c->offsets_h = offsets_h;
+			c->entry_point = entry_point;
+			c->max_level = max_level;
+			c->ntotal = ntotal;
+			c->label_offset = label_offset;
+			const size_t vb = (size_t)ntotal * dp * sizeof(float), ob = (size_t)(ntotal + 1) * sizeof(int64_t);
+			const size_t nb = (size_t)offsets_h[(size_t)ntotal] * 4;
+			c->vecs.ensure(std::max<size_t>(vb, 16), 0, c->stream);
+			c->offsets.ensure(ob, 0, c->stream);
+			c->neighbors.ensure(std::max<size_t>(nb, 16), 0, c->stream);
+			c->locks.ensure(std::max<size_t>((size_t)ntotal * 4, 16), 0, c->stream, 0);
+			if (vb)
+				MVS_HIP(hipMemcpyAsync(c->vecs.p, vecs.p, vb, hipMemcpyDeviceToDevice, c->stream));
+			MVS_HIP(hipMemcpyAsync(c->offsets.p, offsets.p, ob, hipMemcpyDeviceToDevice, c->stream));
+			if (nb)
+				MVS_HIP(hipMemcpyAsync(c->neighbors.p, neighbors.p, nb, hipMemcpyDeviceToDevice, c->stream));
+			MVS_HIP(hipStreamSynchronize(c->stream));
+		} catch (...) {
+			delete c;
+			throw;
+		}
+		return c;
+	}
+	bool set_option(const char *key, int64_t v) override {
+		if (!strcmp(key, "hnsw_build_waves")) {
+			build_waves = v;
+			return true;
+		}
+		if (!strcmp(key, "hnsw_ef_search")) {
+			efSearch = (int)v;
+			return true;
+		}
+		return false;
+	}
+
+	// introspection for parity tests (graph equality against the oracle)
+	int64_t graph_slots() const {
+		return offsets_h[(size_t)ntotal];
+	}
+	void get_graph(int32_t *levels_out, int64_t *offsets_out, int32_t *neighbors_out) {
+		use_device();
+		MVS_HIP(hipStreamSynchronize(stream));
+		memcpy(levels_out, levels_h.data(), (size_t)ntotal * sizeof(int32_t));
+		memcpy(offsets_out, offsets_h.data(), (size_t)(ntotal + 1) * sizeof(int64_t));
+		if (graph_slots() > 0)
+			MVS_HIP(hipMemcpy(neighbors_out, neighbors.p, (size_t)graph_slots() * 4, hipMemcpyDeviceToHost));
+	}
+	unsigned long long build_distances = 0;
+
+private:
+	std::mt19937 rng; // RandomGenerator(12345)
+	std::vector<double> assign_probas;
+	std::vector<int> cum_nn;
+	std::vector<int32_t> levels_h;
+	std::vector<int64_t> offsets_h;
+	KeepBuf vecs, offsets, neighbors, locks;
+	DevBuf ws_order, ws_counter, ws_stats, ws_q, ws_vis, sstamp, bvis, bstamp;
+	int64_t bvis_stride = 0, svis_stride = 0;
+	int bvis_waves = 0, svis_waves = 0;
+	SelectorHolder selector;
+};
+
+IndexBase *make_hnsw_index(int d, const std::string &desc, int metric) {
+	if (desc.rfind("HNSW", 0) != 0)
+		return nullptr;
+	// index_factory.cpp: "HNSW<M>" and "HNSW<M>,Flat" -> IndexHNSWFlat(d, M, metric); bare "HNSW" -> M = 32
+	char *end = nullptr;
+	long M = strtol(desc.c_str() + 4, &end, 10);
+	if (end == desc.c_str() + 4)
+		M = 32;
+	if (*end == 0 || !strcmp(end, ",Flat"))
+		return new HNSWIndex(d, (int)M, metric);
+	throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
+	            "This index type is not implemented on the MI355X path yet: %s", desc.c_str());
+}
+bool hnsw_set_ef_construction(IndexBase *ix, int v) {
+	if (ix->kind != MVS_KIND_HNSW)
+		return false;
+	static_cast<HNSWIndex *>(ix)->efConstruction = v;
+	return true;
+}
+int64_t hnsw_graph_info(IndexBase *ix, int *max_level, int *entry_point) {
+	if (ix->kind != MVS_KIND_HNSW)
+		return -1;
+	auto *h = static_cast<HNSWIndex *>(ix);
+	if (max_level)
+		*max_level = h->max_level;
+	if (entry_point)
+		*entry_point = h->entry_point;
+	return h->graph_slots();
+}
+bool hnsw_get_graph(IndexBase *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors) {
+	if (ix->kind != MVS_KIND_HNSW)
+		return false;
+	static_cast<HNSWIndex *>(ix)->get_graph(levels, offsets, neighbors);
+	return true;
+}
+
 } // namespace mvs

@@ -179,6 +179,8 @@ bool ivf_set_centroids(IndexBase *ix, const float *c);
 // csrc/hnsw.hip
 IndexBase *make_hnsw_index(int d, const std::string &desc, int metric);
 bool hnsw_set_ef_construction(IndexBase *ix, int v);
+int64_t hnsw_graph_info(IndexBase *ix, int *max_level, int *entry_point); // neighbour slots, -1 if not HNSW
+bool hnsw_get_graph(IndexBase *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors);
 // csrc/io.cpp-ish (index_io.hip)
 void write_index_file(const IndexBase *ix, const char *filename);
 IndexBase *read_index_file(const char *filename);

@@ -798,10 +798,28 @@ int mvs_index_ivf_set_centroids(mvs_index *ix, const float *centroids) {
 		w->is_trained = true;
 	MVS_API_END
 }
+static IndexBase *unwrap_idmap(IndexBase *p) {
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	return p;
+}
 int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v) {
 	MVS_API_BEGIN
-	if (!hnsw_set_ef_construction(ix->impl, v))
+	if (!hnsw_set_ef_construction(unwrap_idmap(ix->impl), v))
 		throw_faiss("mvs_index_hnsw_set_ef_construction", __FILE__, "not an HNSW index");
+	MVS_API_END
+}
+int64_t mvs_index_hnsw_graph_info(mvs_index *ix, int *max_level, int *entry_point) {
+	try {
+		return hnsw_graph_info(unwrap_idmap(ix->impl), max_level, entry_point);
+	} catch (...) {
+		return -1;
+	}
+}
+int mvs_index_hnsw_get_graph(mvs_index *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors) {
+	MVS_API_BEGIN
+	if (!hnsw_get_graph(unwrap_idmap(ix->impl), levels, offsets, neighbors))
+		throw_faiss("mvs_index_hnsw_get_graph", __FILE__, "not an HNSW index");
 	MVS_API_END
 }
 

@@ -102,6 +102,9 @@ _L.mvs_index_idmap_sub.restype = _p
 _L.mvs_index_ivf_quantizer.argtypes = [_p]
 _L.mvs_index_ivf_quantizer.restype = _p
 _L.mvs_index_hnsw_set_ef_construction.argtypes = [_p, C.c_int]
+_L.mvs_index_hnsw_graph_info.argtypes = [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+_L.mvs_index_hnsw_graph_info.restype = _i64
+_L.mvs_index_hnsw_get_graph.argtypes = [_p, _p, _p, _p]
 _L.mvs_index_ivf_nlist.argtypes = [_p]
 _L.mvs_index_ivf_nlist.restype = _i64
 _L.mvs_index_ivf_get_centroids.argtypes = [_p, _p]
@@ -130,7 +133,8 @@ DECLARED_SYMBOLS = [
     "mvs_last_error", "mvs_index_factory", "mvs_index_free", "mvs_index_d", "mvs_index_ntotal",
     "mvs_index_is_trained", "mvs_index_metric_type", "mvs_index_kind", "mvs_index_idmap_sub",
     "mvs_index_ivf_quantizer", "mvs_index_ivf_nlist", "mvs_index_ivf_get_centroids", "mvs_index_ivf_set_centroids",
-    "mvs_index_hnsw_set_ef_construction", "mvs_index_train", "mvs_index_add",
+    "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_get_graph",
+    "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
@@ -232,6 +236,19 @@ class Index:
 
     def set_ef_construction(self, v):
         _check(_L.mvs_index_hnsw_set_ef_construction(self._h, int(v)))
+
+    def hnsw_graph(self):
+        """-> dict(levels[n], offsets[n+1], neighbors[...], max_level, entry_point) (FAISS's HNSW arrays)"""
+        ml, ep = C.c_int(0), C.c_int(0)
+        nb = _L.mvs_index_hnsw_graph_info(self._h, C.byref(ml), C.byref(ep))
+        if nb < 0:
+            raise FaissException("not an HNSW index")
+        n = self.ntotal
+        levels = np.empty(n, dtype=np.int32)
+        offsets = np.empty(n + 1, dtype=np.int64)
+        neighbors = np.empty(max(nb, 1), dtype=np.int32)
+        _check(_L.mvs_index_hnsw_get_graph(self._h, _ptr(levels), _ptr(offsets), _ptr(neighbors)))
+        return dict(levels=levels, offsets=offsets, neighbors=neighbors[:nb], max_level=ml.value, entry_point=ep.value)
 
     def train(self, x):
         x = _f32(x).reshape(-1, self.d)

@@ -89,6 +89,12 @@ int mvs_index_ivf_get_centroids(mvs_index *ix, float *out /* nlist*d */);
 int mvs_index_ivf_set_centroids(mvs_index *ix, const float *centroids /* nlist*d; marks trained */);
 /* IndexHNSW::hnsw.efConstruction = v  -- src/faiss_extension.cpp:136-139 */
 int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v);
+/* HNSW introspection (HNSW::levels / offsets / neighbors, FAISS's flat layout: 2M slots at level 0, M above, -1 =
+ * empty): lets parity tests compare the device-built graph with the oracle's.  graph_info returns the number of
+ * neighbour slots (offsets[ntotal]) or -1 if the index is not an HNSW index. */
+int64_t mvs_index_hnsw_graph_info(mvs_index *ix, int *max_level, int *entry_point);
+int mvs_index_hnsw_get_graph(mvs_index *ix, int32_t *levels /* ntotal */, int64_t *offsets /* ntotal+1 */,
+                             int32_t *neighbors /* offsets[ntotal] */);
 
 /* Index::train(n, x)  -- src/faiss_extension.cpp:396,583 */
 int mvs_index_train(mvs_index *ix, int64_t n, const float *x);

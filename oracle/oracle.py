@@ -36,7 +36,7 @@ class _Params(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orc_core.c", "orc_hnsw.c", "orc.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_core.c", "orc_hnsw.c", "orc.h", "orc_internal.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liborc.so"], stdout=subprocess.DEVNULL)
     return _LIB
@@ -72,6 +72,11 @@ def lib():
         L.orc_ivf_list_size.argtypes = [p, i64]
         L.orc_ivf_list_size.restype = i64
         L.orc_ivf_get_list.argtypes = [p, i64, p, p]
+        L.orc_hnsw_set_ef_construction_ix.argtypes = [p, C.c_int]
+        L.orc_hnsw_graph_size.argtypes = [p, C.POINTER(C.c_int), C.POINTER(C.c_int32)]
+        L.orc_hnsw_graph_size.restype = i64
+        L.orc_hnsw_get_graph.argtypes = [p, p, p, p]
+        L.orc_hnsw_set_graph.argtypes = [p, i64, p, p, p, p, C.c_int32, C.c_int]
         L.orc_norms.argtypes = [p, i64, C.c_int, p]
         L.orc_flat_search.argtypes = [C.c_int, C.c_int, i64, p, i64, p, i64, p, p, C.POINTER(_Params), p]
         L.orc_flat_search_naive.argtypes = [C.c_int, C.c_int, i64, p, i64, p, i64, p, p, C.c_int]
@@ -191,6 +196,35 @@ class Index:
         codes = np.empty((n, self.d), dtype=np.float32)
         _check(lib().orc_ivf_get_list(self._h, list_no, _ptr(ids), _ptr(codes)))
         return ids, codes
+
+
+    # HNSW (src/faiss_extension.cpp:133-139 sets hnsw.efConstruction through the IDMap wrapper)
+    def hnsw_set_ef_construction(self, v):
+        _check(lib().orc_hnsw_set_ef_construction_ix(self._h, int(v)))
+
+    def hnsw_graph(self):
+        """-> dict(levels[n], offsets[n+1], neighbors[...], max_level, entry_point)"""
+        ml, ep = C.c_int(0), C.c_int32(0)
+        nb = lib().orc_hnsw_graph_size(self._h, C.byref(ml), C.byref(ep))
+        if nb < 0:
+            raise OracleError("not an HNSW index")
+        n = self.ntotal
+        levels = np.empty(n, dtype=np.int32)
+        offsets = np.empty(n + 1, dtype=np.int64)
+        neighbors = np.empty(nb, dtype=np.int32)
+        _check(lib().orc_hnsw_get_graph(self._h, _ptr(levels), _ptr(offsets), _ptr(neighbors)))
+        return dict(levels=levels, offsets=offsets, neighbors=neighbors, max_level=ml.value, entry_point=ep.value)
+
+
+    def hnsw_set_graph(self, x, graph):
+        """adopt rows + a graph dict as returned by hnsw_graph() (e.g. the device index's); search-only afterwards"""
+        x = _f32(x).reshape(-1, self.d)
+        lv = np.ascontiguousarray(graph["levels"], dtype=np.int32)
+        of = _i64(graph["offsets"])
+        nb = np.ascontiguousarray(graph["neighbors"], dtype=np.int32)
+        assert lv.size == x.shape[0] and of.size == x.shape[0] + 1 and nb.size == of[-1]
+        _check(lib().orc_hnsw_set_graph(self._h, x.shape[0], _ptr(x), _ptr(lv), _ptr(of), _ptr(nb),
+                                        int(graph["entry_point"]), int(graph["max_level"])))
 
 
 def norms(x):

@@ -87,6 +87,13 @@ int orc_ivf_set_centroids(orc_index *ix, const float *c);   /* marks trained */
 int64_t orc_ivf_list_size(const orc_index *ix, int64_t list_no);
 int orc_ivf_get_list(const orc_index *ix, int64_t list_no, int64_t *ids, float *codes);
 
+/* HNSW (orc_hnsw.c): efConstruction setter (src/faiss_extension.cpp:136-139) and graph export for parity tests */
+int orc_hnsw_set_ef_construction_ix(orc_index *ix, int v);
+int64_t orc_hnsw_graph_size(orc_index *ix, int *max_level, int32_t *entry_point); /* total neighbor slots, -1 if not HNSW */
+int orc_hnsw_get_graph(orc_index *ix, int *levels, int64_t *offsets, int32_t *neighbors);
+int orc_hnsw_set_graph(orc_index *ix, int64_t n, const float *x, const int *levels, const int64_t *offsets,
+                       const int32_t *neighbors, int32_t entry_point, int max_level); /* search-only afterwards */
+
 /* stand-alone kernels (used by tests and the cpu_baseline leg) */
 void orc_norms(const float *x, int64_t n, int d, float *out);
 int orc_flat_search(int metric, int d, int64_t nb, const float *xb, int64_t nq, const float *xq, int64_t k,

@@ -18,6 +18,7 @@
  */
 #define _GNU_SOURCE
 #include "orc.h"
+#include "orc_internal.h"
 
 #include <float.h>
 #include <immintrin.h>
@@ -58,10 +59,7 @@ void orc_set_num_threads(int n) {
 
 /* --------------------------------------------------- mt19937 (std::mt19937) */
 
-typedef struct {
-	uint32_t mt[624];
-	int idx;
-} mt19937_t;
+typedef orc_mt19937 mt19937_t;
 
 static void mt_seed(mt19937_t *r, uint32_t s) {
 	r->mt[0] = s;
@@ -199,12 +197,7 @@ void orc_norms(const float *x, int64_t n, int d, float *out) {
 
 /* ---------------------------------------------------------------- selectors */
 
-typedef struct {
-	int kind;
-	const uint8_t *bitmap;
-	int64_t n; /* bytes (bitmap) or ids (batch) */
-	int64_t *sorted; /* batch: sorted copy */
-} sel_t;
+typedef orc_sel sel_t;
 
 static int cmp_i64(const void *a, const void *b) {
 	int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
@@ -251,6 +244,29 @@ static inline int sel_member(const sel_t *s, int64_t id) {
 		return lo < s->n && s->sorted[lo] == id;
 	}
 	return 1;
+}
+
+/* exported to orc_hnsw.c */
+void orc_mt_seed(orc_mt19937 *r, uint32_t s) {
+	mt_seed(r, s);
+}
+int orc_mt_rand_int(orc_mt19937 *r, int max) {
+	return mt_rand_int(r, max);
+}
+float orc_mt_rand_float(orc_mt19937 *r) {
+	return mt_rand_float(r);
+}
+void orc_heap_init(int64_t k, float *hv, int64_t *hi, int is_max) {
+	heap_init(k, hv, hi, is_max);
+}
+void orc_heap_replace_top(int64_t k, float *hv, int64_t *hi, int is_max, float v, int64_t id) {
+	heap_replace_top(k, hv, hi, is_max, v, id);
+}
+void orc_heap_reorder(int64_t k, float *hv, int64_t *hi, int is_max) {
+	heap_reorder(k, hv, hi, is_max);
+}
+int orc_sel_member(const orc_sel *s, int64_t id) {
+	return sel_member(s, id);
 }
 
 /* ------------------------------------------------------------- flat search */
@@ -478,7 +494,7 @@ int orc_flat_search_naive(int metric, int d, int64_t nb, const float *xb, int64_
 
 /* --------------------------------------------------------------- index types */
 
-enum { IX_FLAT = 1, IX_IDMAP = 2, IX_IVFFLAT = 3 };
+enum { IX_FLAT = 1, IX_IDMAP = 2, IX_IVFFLAT = 3, IX_HNSW = 4 };
 
 typedef struct {
 	int64_t n, cap;
@@ -502,6 +518,8 @@ struct orc_index {
 	int64_t nlist, nprobe;
 	invlist_t *lists;
 	int spherical;
+	/* hnsw (IndexHNSWFlat: storage = IndexFlat in ->sub is NOT used; rows live in xb like a flat index) */
+	orc_hnsw *hnsw;
 };
 
 int orc_d(const orc_index *ix) {
@@ -555,6 +573,7 @@ void orc_index_free(orc_index *ix) {
 		}
 		free(ix->lists);
 	}
+	orc_hnsw_free(ix->hnsw);
 	free(ix);
 }
 
@@ -591,6 +610,19 @@ static orc_index *factory_rec(int d, const char *desc, int metric, const char *f
 			ix->is_trained = 0;
 			/* IndexIVF ctor: "Spherical by default if the metric is inner_product" */
 			ix->spherical = metric == ORC_METRIC_INNER_PRODUCT;
+			return ix;
+		}
+	}
+	if (!strncmp(desc, "HNSW", 4)) {
+		/* "HNSW<M>" and "HNSW<M>,Flat" -> IndexHNSWFlat(d, M, metric); bare "HNSW" means M = 32 */
+		char *end;
+		long M = strtol(desc + 4, &end, 10);
+		if (end == desc + 4)
+			M = 32;
+		if (M > 1 && (!*end || !strcmp(end, ",Flat"))) {
+			orc_index *ix = new_flat(d, metric);
+			ix->type = IX_HNSW;
+			ix->hnsw = orc_hnsw_new((int)M);
 			return ix;
 		}
 	}
@@ -900,6 +932,7 @@ int orc_ivf_get_list(const orc_index *ix, int64_t list_no, int64_t *ids, float *
 int orc_train(orc_index *ix, int64_t n, const float *x) {
 	switch (ix->type) {
 	case IX_FLAT:
+	case IX_HNSW: /* IndexHNSW::train trains the storage; flat storage: nothing to do */
 		return 0; /* Index::train: does nothing by default */
 	case IX_IDMAP: {
 		int rc = orc_train(ix->sub, n, x);
@@ -921,6 +954,13 @@ int orc_add(orc_index *ix, int64_t n, const float *x) {
 		            "add does not make sense with IndexIDMap, use add_with_ids");
 	case IX_IVFFLAT:
 		return ivf_add(ix, n, x, NULL);
+	case IX_HNSW: {
+		/* IndexHNSW::add: storage->add(n, x) then hnsw_add_vertices(*this, n0, n, x, ...) */
+		int64_t n0 = ix->ntotal;
+		flat_add(ix, n, x);
+		orc_hnsw_add(ix->hnsw, n0, n, ix->xb, ix->d, ix->metric == ORC_METRIC_L2);
+		return 0;
+	}
 	}
 	return fail("orc_add", "oracle", "bad index");
 }
@@ -928,6 +968,7 @@ int orc_add(orc_index *ix, int64_t n, const float *x) {
 int orc_add_with_ids(orc_index *ix, int64_t n, const float *x, const int64_t *ids) {
 	switch (ix->type) {
 	case IX_FLAT:
+	case IX_HNSW:
 		/* Index::add_with_ids default (faiss/Index.cpp) -- substring matched at src/faiss_extension.cpp:523,
 		 * user-visible text pinned by test/sql/faiss4.test:19-22 */
 		return fail("virtual void faiss::Index::add_with_ids(faiss::idx_t, const float*, const faiss::idx_t*)",
@@ -953,6 +994,27 @@ int orc_add_with_ids(orc_index *ix, int64_t n, const float *x, const int64_t *id
 	return fail("orc_add_with_ids", "oracle", "bad index");
 }
 
+/* IndexHNSW::search (IndexHNSW.cpp hnsw_search): per query HNSW::search, efSearch from SearchParametersHNSW */
+static int hnsw_search(const orc_index *ix, int64_t nq, const float *xq, int64_t k, float *D, int64_t *I,
+                       const orc_params *params, const int64_t *id_map) {
+	sel_t sel;
+	if (sel_build(&sel, params))
+		return 1;
+	const int ef = params && params->efSearch > 0 ? (int)params->efSearch : 16;
+	const int is_l2 = ix->metric == ORC_METRIC_L2;
+#pragma omp parallel
+	{
+		uint8_t *visited = (uint8_t *)calloc((size_t)(ix->ntotal > 0 ? ix->ntotal : 1), 1);
+#pragma omp for schedule(dynamic, 4)
+		for (int64_t q = 0; q < nq; q++)
+			orc_hnsw_search_one(ix->hnsw, ix->xb, ix->d, is_l2, xq + q * ix->d, k, ef, D + q * k, I + q * k, visited,
+			                    sel.kind ? &sel : NULL, id_map);
+		free(visited);
+	}
+	sel_free(&sel);
+	return 0;
+}
+
 static int search_rec(const orc_index *ix, int64_t nq, const float *x, int64_t k, float *D, int64_t *I,
                       const orc_params *params, const int64_t *id_map) {
 	switch (ix->type) {
@@ -960,6 +1022,8 @@ static int search_rec(const orc_index *ix, int64_t nq, const float *x, int64_t k
 		return flat_search_impl(ix->metric, ix->d, ix->ntotal, ix->xb, nq, x, k, D, I, params, id_map);
 	case IX_IVFFLAT:
 		return ivf_search(ix, nq, x, k, D, I, params, id_map);
+	case IX_HNSW:
+		return hnsw_search(ix, nq, x, k, D, I, params, id_map);
 	case IX_IDMAP: {
 		/* IndexIDMap::search: a user selector is wrapped in IDSelectorTranslated(id_map, sel);
 		 * inner search; labels[i] = labels[i] < 0 ? labels[i] : id_map[labels[i]] */
@@ -1081,4 +1145,47 @@ void orc_synth_clustered(float *out, int64_t n_rows, int d, uint64_t seed, int64
 			out[r * d + col] = fmaf(sigma, g, centre);
 		}
 	}
+}
+
+/* ------------------------------------------------------------------ HNSW API */
+static orc_index *hnsw_of(orc_index *ix) {
+	if (ix && ix->type == IX_IDMAP)
+		ix = ix->sub;
+	return ix && ix->type == IX_HNSW ? ix : NULL;
+}
+int orc_hnsw_set_ef_construction_ix(orc_index *ix, int v) {
+	orc_index *h = hnsw_of(ix);
+	if (!h)
+		return fail("orc_hnsw_set_ef_construction", "oracle", "not an HNSW index");
+	orc_hnsw_set_ef_construction(h->hnsw, v);
+	return 0;
+}
+int64_t orc_hnsw_graph_size(orc_index *ix, int *max_level, int32_t *entry_point) {
+	orc_index *h = hnsw_of(ix);
+	if (!h)
+		return -1;
+	if (max_level)
+		*max_level = orc_hnsw_max_level(h->hnsw);
+	if (entry_point)
+		*entry_point = orc_hnsw_entry_point(h->hnsw);
+	return orc_hnsw_nb_total(h->hnsw);
+}
+int orc_hnsw_get_graph(orc_index *ix, int *levels, int64_t *offsets, int32_t *neighbors) {
+	orc_index *h = hnsw_of(ix);
+	if (!h)
+		return fail("orc_hnsw_get_graph", "oracle", "not an HNSW index");
+	orc_hnsw_export(h->hnsw, levels, offsets, neighbors);
+	return 0;
+}
+/* replace rows + graph of an (empty or not) HNSW index by externally built ones; the level RNG is NOT advanced, so
+ * the index is meant for search only afterwards */
+int orc_hnsw_set_graph(orc_index *ix, int64_t n, const float *x, const int *levels, const int64_t *offsets,
+                       const int32_t *neighbors, int32_t entry_point, int max_level) {
+	orc_index *h = hnsw_of(ix);
+	if (!h || ix != h)
+		return fail("orc_hnsw_set_graph", "oracle", "not a plain HNSW index");
+	h->ntotal = 0;
+	flat_add(h, n, x);
+	orc_hnsw_import(h->hnsw, n, levels, offsets, neighbors, entry_point, max_level);
+	return 0;
 }
