@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--data", default="uniform", choices=["uniform", "clustered"])
+    ap.add_argument("--centers", type=int, default=1024, help="clustered data: number of mixture centres")
+    ap.add_argument("--sigma", type=float, default=0.1, help="clustered data: per-coordinate spread around a centre")
     return ap.parse_args()
 
 
@@ -79,7 +81,13 @@ def main():
     r0, r1 = n * rank // world, n * (rank + 1) // world
     DB_SEED, Q_SEED = 1234, 4321
 
-    gen = mf.synth_uniform_torch if args.data == "uniform" else mf.synth_clustered_torch
+    if args.data == "uniform":
+        gen = mf.synth_uniform_torch
+    else:
+
+        def gen(m, dd, seed, row0=0, device=None):
+            return mf.synth_clustered_torch(m, dd, seed, row0=row0, n_centers=args.centers, sigma=args.sigma, device=device)
+
     ix = mf.index_factory(d, args.index, metric)
     is_ivf = "IVF" in args.index
     is_hnsw = "HNSW" in args.index
@@ -201,7 +209,14 @@ def main():
             "scaling": "weak" if is_hnsw else "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (counter-based %s, db seed %d, query seed %d)" % (args.data, DB_SEED, Q_SEED),
+            "data": "synthetic (counter-based %s%s%s, db seed %d, query seed %d)"
+            % (
+                args.data,
+                " centres=%d sigma=%g" % (args.centers, args.sigma) if args.data == "clustered" else "",
+                ", rows L2-normalised" if args.normalize else "",
+                DB_SEED,
+                Q_SEED,
+            ),
             "config": {
                 "workload": "%s %s d=%d N=%d nq=%d k=%d" % (args.index, args.metric, d, n, nq, k),
                 "queries_per_call": chunk,
@@ -352,7 +367,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not is_ivf and not is_hnsw:
             from oracle import oracle as orc
 
-            gen_h = orc.synth_uniform if args.data == "uniform" else orc.synth_clustered
+            if args.data == "uniform":
+                gen_h = orc.synth_uniform
+            else:
+
+                def gen_h(m, dd, seed):
+                    return orc.synth_clustered(m, dd, seed, n_centers=args.centers, sigma=args.sigma)
+
             xb_h = gen_h(n, d, DB_SEED)
             xq_h = gen_h(nq, d, Q_SEED)
             cores = orc.num_threads()

@@ -296,6 +296,7 @@ struct SearchArgs {
 	uint8_t *visited; // [grid][vstride]
 	long long vstride;
 	unsigned *vstamp; // [grid] rolling stamp, persists across searches
+	int *counter;     // dynamic query queue (walk lengths vary a lot between queries)
 	float *D;
 	long long *I;
 	unsigned long long *stats; // [0] distance evaluations, [1] expanded vertices
@@ -311,7 +312,13 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 	uint8_t *vis = a.visited + (size_t)blockIdx.x * a.vstride;
 	unsigned stamp = a.vstamp[blockIdx.x], ndis = 0, nexp = 0;
 	const int ef = a.ef, k = a.k;
-	for (long long qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+	for (;;) {
+		int qn = 0;
+		if (lane == 0)
+			qn = atomicAdd(a.counter, 1);
+		const long long qi = rfl(qn);
+		if (qi >= a.nq)
+			break;
 		if (++stamp == 256) {
 			clear_table(vis, a.vstride / 16, lane);
 			stamp = 1;
@@ -833,6 +840,8 @@ public:
 		offsets.release();
 		neighbors.release();
 		locks.release();
+		if (h_stats)
+			(void)hipHostFree(h_stats);
 	}
 
 	// ---------------------------------------------------------------------------------------------- add
@@ -1039,11 +1048,9 @@ public:
 		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
 		const size_t lds = (size_t)(ef + k) * 8 + 64;
 		// resident waves: 16 per CU unless LDS says otherwise
-		int cus = 256;
-		{
-			hipDeviceProp_t prop;
-			if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-				cus = prop.multiProcessorCount;
+		if (cus <= 0) {
+			int v = 0;
+			cus = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0 ? v : 256;
 		}
 		const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(150 * 1024) / lds));
 		// visited tables (one byte per vertex per wave) persist across searches; the rolling stamp makes a fresh
@@ -1063,6 +1070,8 @@ public:
 		}
 		ws_stats.reserve(64);
 		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 16, stream));
+		ws_counter.reserve(64);
+		MVS_HIP(hipMemsetAsync(ws_counter.p, 0, sizeof(int), stream));
 		SearchArgs a;
 		a.g = graph_dev();
 		a.entry_point = entry_point;
@@ -1078,23 +1087,30 @@ public:
 		a.visited = (uint8_t *)ws_vis.p;
 		a.vstride = (long long)stride;
 		a.vstamp = (unsigned *)sstamp.p;
+		a.counter = (int *)ws_counter.p;
 		a.D = d_D;
 		a.I = (long long *)d_I;
 		a.stats = (unsigned long long *)ws_stats.p;
 		begin_kernel_timing(stream);
 		dispatch_ni<SearchLaunch>(dp4, metric == METRIC_L2, a, grid, lds, stream);
 		end_kernel_timing(stream);
-		unsigned long long stt[2] = {0, 0};
-		MVS_HIP(hipMemcpyAsync(stt, ws_stats.p, sizeof stt, hipMemcpyDeviceToHost, stream));
-		MVS_HIP(hipStreamSynchronize(stream));
-		stream_wait(st, stream);
 		snprintf(kinfo.name, sizeof kinfo.name, "hnsw_search_kernel");
-		kinfo.bytes = (double)stt[0] * ((double)d * 4.0 + 4.0); // n_visited * (4d + 4), counted by the kernel
-		kinfo.flops = (double)stt[0] * d * (metric == METRIC_L2 ? 3.0 : 2.0);
 		kinfo.grid = grid;
 		kinfo.block = 64;
 		kinfo.lds_bytes = (int)lds;
-		kinfo.nsplit = (int)(stt[1] / (unsigned long long)std::max<int64_t>(nq, 1)); // mean expanded vertices per query
+		if (timing_enabled) {
+			// the walk-length counters are only fetched when a bench asked for kernel timing: the plain search path
+			// stays asynchronous on the caller's stream
+			if (!h_stats)
+				MVS_HIP(hipHostMalloc((void **)&h_stats, 64, hipHostMallocDefault));
+			MVS_HIP(hipMemcpyAsync(h_stats, ws_stats.p, 16, hipMemcpyDeviceToHost, stream));
+			MVS_HIP(hipStreamSynchronize(stream));
+			const unsigned long long nd = h_stats[0], ne = h_stats[1];
+			kinfo.bytes = (double)nd * ((double)d * 4.0 + 4.0); // n_visited * (4d + 4), counted by the kernel
+			kinfo.flops = (double)nd * d * (metric == METRIC_L2 ? 3.0 : 2.0);
+			kinfo.nsplit = (int)(ne / (unsigned long long)std::max<int64_t>(nq, 1)); // mean expanded vertices per query
+		}
+		stream_wait(st, stream);
 	}
 	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                   hipStream_t st) override {
@@ -1108,45 +1124,84 @@ public:
 		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
 		            "moving an HNSW index between devices is not implemented on the MI355X path yet");
 	}
+	// deep copy through the host image (faiss::gpu::index_cpu_to_gpu also starts from host memory)
 	IndexBase *clone(int on_device) override {
 		int ndev = 0;
 		MVS_HIP(hipGetDeviceCount(&ndev));
 		if (on_device < 0 || on_device >= ndev)
 			throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "Invalid GPU device %d", on_device);
-		if (on_device != device)
-			throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
-			            "This index type is not implemented for cloning across devices on the MI355X path yet (HNSW)");
+		HostIndex h;
+		to_host(h);
+		HNSWIndex *c = static_cast<HNSWIndex *>(index_from_host(h, on_device));
+		c->rng = rng; // a clone continues the level stream where the source stands (read_index restarts it, like FAISS)
+		c->build_waves = build_waves;
+		c->label_offset = label_offset;
+		return c;
+	}
+	// IndexHNSWFlat image: struct HNSW + flat storage
+	void to_host(HostIndex &out) override {
 		use_device();
 		MVS_HIP(hipStreamSynchronize(stream));
-		auto *c = new HNSWIndex(d, M, metric);
-		try {
-			c->efConstruction = efConstruction;
-			c->efSearch = efSearch;
-			c->build_waves = build_waves;
-			c->rng = rng;
-			c->levels_h = levels_h;
-			c->offsets_h = offsets_h;
-			c->entry_point = entry_point;
-			c->max_level = max_level;
-			c->ntotal = ntotal;
-			c->label_offset = label_offset;
-			const size_t vb = (size_t)ntotal * dp * sizeof(float), ob = (size_t)(ntotal + 1) * sizeof(int64_t);
-			const size_t nb = (size_t)offsets_h[(size_t)ntotal] * 4;
-			c->vecs.ensure(std::max<size_t>(vb, 16), 0, c->stream);
-			c->offsets.ensure(ob, 0, c->stream);
-			c->neighbors.ensure(std::max<size_t>(nb, 16), 0, c->stream);
-			c->locks.ensure(std::max<size_t>((size_t)ntotal * 4, 16), 0, c->stream, 0);
-			if (vb)
-				MVS_HIP(hipMemcpyAsync(c->vecs.p, vecs.p, vb, hipMemcpyDeviceToDevice, c->stream));
-			MVS_HIP(hipMemcpyAsync(c->offsets.p, offsets.p, ob, hipMemcpyDeviceToDevice, c->stream));
-			if (nb)
-				MVS_HIP(hipMemcpyAsync(c->neighbors.p, neighbors.p, nb, hipMemcpyDeviceToDevice, c->stream));
-			MVS_HIP(hipStreamSynchronize(c->stream));
-		} catch (...) {
-			delete c;
-			throw;
+		out.kind = MVS_KIND_HNSW;
+		out.d = d;
+		out.metric = metric;
+		out.ntotal = ntotal;
+		out.is_trained = true;
+		out.assign_probas = assign_probas;
+		out.cum_nneighbor_per_level.assign(cum_nn.begin(), cum_nn.end());
+		out.levels = levels_h;
+		out.offsets.assign(offsets_h.begin(), offsets_h.end());
+		out.neighbors.resize((size_t)graph_slots());
+		if (graph_slots() > 0)
+			MVS_HIP(hipMemcpy(out.neighbors.data(), neighbors.p, (size_t)graph_slots() * 4, hipMemcpyDeviceToHost));
+		out.entry_point = entry_point;
+		out.max_level = max_level;
+		out.efConstruction = efConstruction;
+		out.efSearch = efSearch;
+		out.sub.reset(new HostIndex);
+		HostIndex &st = *out.sub;
+		st.kind = MVS_KIND_FLAT;
+		st.d = d;
+		st.metric = metric;
+		st.ntotal = ntotal;
+		st.rows.resize((size_t)ntotal * d);
+		if (ntotal > 0) {
+			std::vector<float> tmp((size_t)ntotal * dp);
+			MVS_HIP(hipMemcpy(tmp.data(), vecs.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+			for (int64_t i = 0; i < ntotal; i++)
+				memcpy(&st.rows[(size_t)i * d], &tmp[(size_t)i * dp], (size_t)d * sizeof(float));
 		}
-		return c;
+	}
+	void adopt(const HostIndex &h) {
+		use_device();
+		const int64_t n = h.ntotal;
+		if (!h.sub || h.sub->kind != MVS_KIND_FLAT || h.sub->ntotal != n || (int64_t)h.levels.size() != n ||
+		    (int64_t)h.offsets.size() != n + 1 || h.neighbors.size() != (size_t)h.offsets[(size_t)n])
+			throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+			            "inconsistent IndexHNSWFlat image (storage must be a Flat index of ntotal rows)");
+		for (int64_t i = 0; i < n; i++) // the kernels derive the per-level ranges from M
+			if (h.offsets[(size_t)i + 1] - h.offsets[(size_t)i] != (uint64_t)(h.levels[(size_t)i] + 1) * (uint64_t)M)
+				throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+				            "HNSW image with a non-default neighbour layout is not supported on the MI355X path");
+		efConstruction = h.efConstruction;
+		efSearch = h.efSearch;
+		entry_point = h.entry_point;
+		max_level = h.max_level;
+		levels_h = h.levels;
+		offsets_h.assign(h.offsets.begin(), h.offsets.end());
+		vecs.ensure(std::max<size_t>((size_t)n * dp * sizeof(float), 16), 0, stream);
+		offsets.ensure((size_t)(n + 1) * sizeof(int64_t), 0, stream);
+		neighbors.ensure(std::max<size_t>(h.neighbors.size() * 4, 16), 0, stream);
+		locks.ensure(std::max<size_t>((size_t)n * 4, 16), 0, stream, 0);
+		if (n > 0) {
+			std::vector<float> tmp((size_t)n * dp, 0.f);
+			for (int64_t i = 0; i < n; i++)
+				memcpy(&tmp[(size_t)i * dp], &h.sub->rows[(size_t)i * d], (size_t)d * sizeof(float));
+			MVS_HIP(hipMemcpy(vecs.p, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+			MVS_HIP(hipMemcpy(neighbors.p, h.neighbors.data(), h.neighbors.size() * 4, hipMemcpyHostToDevice));
+		}
+		MVS_HIP(hipMemcpy(offsets.p, offsets_h.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+		ntotal = n;
 	}
 	bool set_option(const char *key, int64_t v) override {
 		if (!strcmp(key, "hnsw_build_waves")) {
@@ -1182,6 +1237,8 @@ private:
 	std::vector<int64_t> offsets_h;
 	KeepBuf vecs, offsets, neighbors, locks;
 	DevBuf ws_order, ws_counter, ws_stats, ws_q, ws_vis, sstamp, bvis, bstamp;
+	int cus = 0;
+	unsigned long long *h_stats = nullptr; // pinned
 	int64_t bvis_stride = 0, svis_stride = 0;
 	int bvis_waves = 0, svis_waves = 0;
 	SelectorHolder selector;
@@ -1199,6 +1256,19 @@ IndexBase *make_hnsw_index(int d, const std::string &desc, int metric) {
 		return new HNSWIndex(d, (int)M, metric);
 	throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
 	            "This index type is not implemented on the MI355X path yet: %s", desc.c_str());
+}
+IndexBase *hnsw_from_host(const HostIndex &h, int device) {
+	CtorDevice scope(device);
+	if (h.cum_nneighbor_per_level.size() < 2 || h.cum_nneighbor_per_level[1] % 2 != 0)
+		throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp", "bad HNSW level table");
+	auto *x = new HNSWIndex(h.d, h.cum_nneighbor_per_level[1] / 2, h.metric);
+	try {
+		x->adopt(h);
+	} catch (...) {
+		delete x;
+		throw;
+	}
+	return x;
 }
 bool hnsw_set_ef_construction(IndexBase *ix, int v) {
 	if (ix->kind != MVS_KIND_HNSW)

@@ -4,6 +4,7 @@
 
 #include "../../include/mi355_faiss.h"
 
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -41,6 +42,34 @@ struct SelectorHolder {
 	SelectorDev upload(const mvs_search_params *p, hipStream_t st);
 };
 
+// Host-side image of an index: what faiss::write_index stores (impl/index_write.cpp).  Used by index_io.hip and by
+// cross-device clones (faiss::gpu::index_cpu_to_gpu), both of which go through host memory.
+struct HostIndex {
+	int kind = 0, d = 0, metric = 0;
+	int64_t ntotal = 0;
+	bool is_trained = true;
+	std::vector<float> rows;       // Flat: [ntotal][d]
+	std::unique_ptr<HostIndex> sub; // IDMap: wrapped index; IVF: quantizer; HNSW: storage (a Flat image)
+	std::vector<int64_t> ids;      // IDMap: id_map
+	bool idmap2 = false;
+	int64_t nlist = 0, nprobe = 1; // IVF
+	std::vector<std::vector<int64_t>> list_ids;
+	std::vector<std::vector<float>> list_codes; // per list [n][d]
+	// HNSW (struct HNSW fields in FAISS's order)
+	std::vector<double> assign_probas;
+	std::vector<int32_t> cum_nneighbor_per_level, levels, neighbors;
+	std::vector<uint64_t> offsets;
+	int32_t entry_point = -1;
+	int max_level = -1, efConstruction = 40, efSearch = 16;
+};
+
+// indexes constructed while one of these is alive (same thread) live on `dev` instead of MVS_DEVICE
+struct CtorDevice {
+	int prev;
+	explicit CtorDevice(int dev);
+	~CtorDevice();
+};
+
 class IndexBase {
 public:
 	int kind, d, metric;
@@ -70,6 +99,7 @@ public:
 	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) = 0;
 	virtual void to_device(int new_device) = 0;
 	virtual IndexBase *clone(int on_device) = 0; // deep copy living on `on_device`
+	virtual void to_host(HostIndex &out) = 0;    // host image (write_index, cross-device clone)
 	virtual void set_label_offset(int64_t off) {
 		label_offset = off;
 	}
@@ -117,6 +147,7 @@ public:
 	                   const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) override;
 	void to_device(int new_device) override;
 	IndexBase *clone(int on_device) override;
+	void to_host(HostIndex &out) override;
 	bool set_option(const char *key, int64_t v) override;
 	void search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                 const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
@@ -150,6 +181,7 @@ public:
 	}
 	void to_device(int new_device) override;
 	IndexBase *clone(int on_device) override;
+	void to_host(HostIndex &out) override;
 	void set_label_offset(int64_t) override {
 	}
 	bool set_option(const char *key, int64_t v) override {
@@ -163,11 +195,15 @@ public:
 		kinfo = sub->kinfo;
 	}
 
+	void adopt_ids(const int64_t *xids, int64_t n); // image load: rows are already in `sub`
+
 private:
 	void grow_ids(int64_t need, hipStream_t st);
 };
 
 IndexBase *index_factory(int d, const char *description, int metric);
+// rebuild a device index from its host image on the CURRENT default device (MVS_DEVICE / 0), or on `device` if >= 0
+IndexBase *index_from_host(const HostIndex &h, int device = -1);
 void stream_wait(hipStream_t waiter, hipStream_t signal);
 
 // csrc/ivf.hip
@@ -176,13 +212,15 @@ IndexBase *ivf_quantizer_of(IndexBase *ix);
 int64_t ivf_nlist_of(IndexBase *ix);
 bool ivf_get_centroids(IndexBase *ix, float *out);
 bool ivf_set_centroids(IndexBase *ix, const float *c);
+IndexBase *ivf_from_host(const HostIndex &h, int device);
 // csrc/hnsw.hip
 IndexBase *make_hnsw_index(int d, const std::string &desc, int metric);
 bool hnsw_set_ef_construction(IndexBase *ix, int v);
 int64_t hnsw_graph_info(IndexBase *ix, int *max_level, int *entry_point); // neighbour slots, -1 if not HNSW
 bool hnsw_get_graph(IndexBase *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors);
+IndexBase *hnsw_from_host(const HostIndex &h, int device);
 // csrc/io.cpp-ish (index_io.hip)
-void write_index_file(const IndexBase *ix, const char *filename);
+void write_index_file(IndexBase *ix, const char *filename);
 IndexBase *read_index_file(const char *filename);
 // csrc/merge_host.hip
 void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,

@@ -81,7 +81,17 @@ void PinnedRing::release(int i, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------ base
 
+static thread_local int tl_ctor_device = -1;
+CtorDevice::CtorDevice(int dev) : prev(tl_ctor_device) {
+	if (dev >= 0)
+		tl_ctor_device = dev;
+}
+CtorDevice::~CtorDevice() {
+	tl_ctor_device = prev;
+}
 static int env_device() {
+	if (tl_ctor_device >= 0)
+		return tl_ctor_device;
 	const char *e = getenv("MVS_DEVICE");
 	return e ? atoi(e) : 0;
 }
@@ -633,6 +643,88 @@ void FlatIndex::search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_
 	use_device();
 	stream_wait(st, stream); // adds were enqueued on our own stream
 	search_flat(nq, d_x, k, d_D, d_I, params, d_idmap, st);
+}
+
+// ------------------------------------------------------------------------------------------ host images
+
+void FlatIndex::to_host(HostIndex &out) {
+	out.kind = MVS_KIND_FLAT;
+	out.d = d;
+	out.metric = metric;
+	out.ntotal = ntotal;
+	out.is_trained = true;
+	out.rows.resize((size_t)ntotal * d);
+	copy_rows_to_host(out.rows.data());
+}
+void IDMapIndex::to_host(HostIndex &out) {
+	use_device();
+	MVS_HIP(hipStreamSynchronize(stream));
+	out.kind = MVS_KIND_IDMAP;
+	out.d = d;
+	out.metric = metric;
+	out.ntotal = ntotal;
+	out.is_trained = is_trained;
+	out.sub.reset(new HostIndex);
+	sub->to_host(*out.sub);
+	out.ids.resize((size_t)ntotal);
+	if (ntotal > 0)
+		MVS_HIP(hipMemcpy(out.ids.data(), ids, (size_t)ntotal * sizeof(int64_t), hipMemcpyDeviceToHost));
+}
+
+IndexBase *index_from_host(const HostIndex &h, int device) {
+	CtorDevice scope(device);
+	switch (h.kind) {
+	case MVS_KIND_FLAT: {
+		auto *f = new FlatIndex(h.d, h.metric);
+		try {
+			if (h.ntotal > 0)
+				f->add(h.ntotal, h.rows.data());
+		} catch (...) {
+			delete f;
+			throw;
+		}
+		return f;
+	}
+	case MVS_KIND_IDMAP: {
+		if (!h.sub)
+			throw_faiss("mvs::index_from_host", __FILE__, "IDMap image without a sub-index");
+		if (h.sub->ntotal != (int64_t)h.ids.size())
+			throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+			            "IDMap id_map size %zu does not match the sub-index ntotal %lld", h.ids.size(),
+			            (long long)h.sub->ntotal);
+		IndexBase *subi = index_from_host(*h.sub, device);
+		IDMapIndex *m = nullptr;
+		try {
+			m = new IDMapIndex(subi);
+		} catch (...) {
+			delete subi;
+			throw;
+		}
+		try {
+			m->adopt_ids(h.ids.data(), (int64_t)h.ids.size());
+		} catch (...) {
+			delete m;
+			throw;
+		}
+		return m;
+	}
+	case MVS_KIND_IVFFLAT:
+		return ivf_from_host(h, device);
+	case MVS_KIND_HNSW:
+		return hnsw_from_host(h, device);
+	}
+	throw_faiss("mvs::index_from_host", __FILE__, "unknown index kind %d", h.kind);
+}
+
+// IndexIDMap image load: the sub-index already holds the rows, only the id_map is missing
+void IDMapIndex::adopt_ids(const int64_t *xids, int64_t n) {
+	use_device();
+	grow_ids(n, stream);
+	if (n > 0)
+		MVS_HIP(hipMemcpyAsync(ids, xids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+	MVS_HIP(hipStreamSynchronize(stream));
+	ntotal = sub->ntotal;
+	is_trained = sub->is_trained;
 }
 
 // ------------------------------------------------------------------------------------------ factory

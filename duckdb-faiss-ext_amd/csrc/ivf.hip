@@ -446,13 +446,69 @@ public:
 		if (new_device == device)
 			return;
 		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
-		            "moving an IVF index between devices is not implemented on the MI355X path yet");
+		            "moving an IVF index between devices in place is not implemented on the MI355X path; clone it");
 	}
+	// deep copy through the host image (faiss::gpu::index_cpu_to_gpu also starts from host memory)
 	IndexBase *clone(int on_device) override {
-		if (on_device == device)
-			throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp",
-			            "This index type is not implemented for cloning on the MI355X path yet (IVF)");
-		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "This index type is not implemented");
+		int ndev = 0;
+		MVS_HIP(hipGetDeviceCount(&ndev));
+		if (on_device < 0 || on_device >= ndev)
+			throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "Invalid GPU device %d", on_device);
+		HostIndex h;
+		to_host(h);
+		return index_from_host(h, on_device);
+	}
+	// ArrayInvertedLists image: per list, rows and ids in insertion order
+	void to_host(HostIndex &out) override {
+		use_device();
+		MVS_HIP(hipStreamSynchronize(stream));
+		out.kind = MVS_KIND_IVFFLAT;
+		out.d = d;
+		out.metric = metric;
+		out.ntotal = ntotal;
+		out.is_trained = is_trained;
+		out.nlist = nlist;
+		out.nprobe = nprobe;
+		out.sub.reset(new HostIndex);
+		quantizer->to_host(*out.sub);
+		out.list_ids.assign((size_t)nlist, {});
+		out.list_codes.assign((size_t)nlist, {});
+		std::vector<float> rows((size_t)ntotal * dp);
+		if (ntotal > 0)
+			MVS_HIP(hipMemcpy(rows.data(), raw, rows.size() * sizeof(float), hipMemcpyDeviceToHost));
+		for (int64_t i = 0; i < ntotal; i++) {
+			const int32_t l = assign_h[(size_t)i];
+			if (l < 0)
+				continue;
+			out.list_ids[(size_t)l].push_back(ids_h[(size_t)i]);
+			auto &c = out.list_codes[(size_t)l];
+			c.insert(c.end(), &rows[(size_t)i * dp], &rows[(size_t)i * dp] + d);
+		}
+	}
+	// image load: rows enter in list order, which keeps the insertion order inside every list
+	void adopt_lists(const HostIndex &h) {
+		use_device();
+		int64_t n = 0;
+		for (const auto &l : h.list_ids)
+			n += (int64_t)l.size();
+		grow(n);
+		std::vector<float> rows((size_t)n * dp, 0.f);
+		assign_h.clear();
+		ids_h.clear();
+		int64_t r = 0;
+		for (int64_t l = 0; l < nlist; l++) {
+			const auto &li = h.list_ids[(size_t)l];
+			const auto &lc = h.list_codes[(size_t)l];
+			for (size_t j = 0; j < li.size(); j++, r++) {
+				memcpy(&rows[(size_t)r * dp], &lc[j * (size_t)d], (size_t)d * sizeof(float));
+				assign_h.push_back((int32_t)l);
+				ids_h.push_back(li[j]);
+			}
+		}
+		if (n > 0)
+			MVS_HIP(hipMemcpy(raw, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+		ntotal = n;
+		dirty = true;
 	}
 	void set_timing(bool on) override {
 		timing_enabled = on;
@@ -489,6 +545,26 @@ IndexBase *make_ivf_index(int d, const std::string &desc, int metric) {
 	// "IVF<n>_HNSW<m>,Flat" (reference Makefile:93) needs the HNSW coarse quantiser
 	throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
 	            "This index type is not implemented on the MI355X path yet: %s", desc.c_str());
+}
+IndexBase *ivf_from_host(const HostIndex &h, int device) {
+	CtorDevice scope(device);
+	if (!h.sub || h.sub->kind != MVS_KIND_FLAT)
+		throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+		            "only a Flat coarse quantizer is implemented on the MI355X path");
+	if ((int64_t)h.list_ids.size() != h.nlist || (int64_t)h.list_codes.size() != h.nlist)
+		throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp", "inverted lists do not match nlist");
+	auto *v = new IVFFlatIndex(h.d, h.nlist, h.metric);
+	try {
+		v->nprobe = h.nprobe;
+		if (h.sub->ntotal > 0)
+			v->quantizer->add(h.sub->ntotal, h.sub->rows.data());
+		v->is_trained = h.is_trained;
+		v->adopt_lists(h);
+	} catch (...) {
+		delete v;
+		throw;
+	}
+	return v;
 }
 IndexBase *ivf_quantizer_of(IndexBase *ix) {
 	if (ix->kind != MVS_KIND_IVFFLAT)
