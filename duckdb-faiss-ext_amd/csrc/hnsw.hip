@@ -135,34 +135,36 @@ __device__ __forceinline__ float wave_dist1(const QV<NI> &q, const float *vecs, 
 	return rflf(IS_L2 ? t : -t);
 }
 
-// distances from q to the rows nid[l] of the lanes l in `mask`; lane l receives its own distance
+// distances from q to the rows nid[l] of the lanes l in `mask`; lane l receives its own distance.
+// The G row loads of a group are issued back to back with NO control flow between them (a short last group re-reads
+// its first row instead of branching): with "if (slot used) load" the compiler fuses load and reduction per slot and
+// the rows arrive one HBM latency after the other.
 template <int NI, bool IS_L2, int G>
 __device__ __forceinline__ float eval_lanes(const QV<NI> &q, const float *vecs, int dp4, int nid, u64 mask, int lane) {
 	float mydd = 0.f;
 	while (mask) {
 		int ls[G], ids[G];
+		ls[0] = (int)__builtin_ctzll(mask);
+		mask &= mask - 1;
 #pragma unroll
-		for (int g = 0; g < G; g++) {
-			ls[g] = -1;
-			ids[g] = 0;
-			if (mask) {
-				ls[g] = (int)__builtin_ctzll(mask);
-				mask &= mask - 1;
-				ids[g] = __builtin_amdgcn_readlane(nid, ls[g]);
-			}
+		for (int g = 1; g < G; g++) {
+			const bool more = mask != 0;
+			const int l = more ? (int)__builtin_ctzll(mask) : ls[0];
+			ls[g] = more ? l : -1;
+			mask = more ? (mask & (mask - 1)) : mask;
+			ids[g] = __builtin_amdgcn_readlane(nid, l);
 		}
+		ids[0] = __builtin_amdgcn_readlane(nid, ls[0]);
 		QV<NI> y[G];
 #pragma unroll
 		for (int g = 0; g < G; g++)
-			if (ls[g] >= 0)
-				load_row(y[g], vecs + (size_t)ids[g] * dp4 * 4, dp4, lane);
+			load_row(y[g], vecs + (size_t)ids[g] * dp4 * 4, dp4, lane);
 #pragma unroll
-		for (int g = 0; g < G; g++)
-			if (ls[g] >= 0) {
-				const float t = wave_sum(lane_partial<NI, IS_L2>(q, y[g]));
-				if (lane == ls[g])
-					mydd = IS_L2 ? t : -t;
-			}
+		for (int g = 0; g < G; g++) {
+			const float t = wave_sum(lane_partial<NI, IS_L2>(q, y[g]));
+			if (lane == ls[g])
+				mydd = IS_L2 ? t : -t;
+		}
 	}
 	return mydd;
 }
@@ -282,7 +284,90 @@ __device__ __forceinline__ void clear_table(uint8_t *vis, long long nbytes16, in
 		reinterpret_cast<uint4 *>(vis)[i] = z;
 }
 
+// Visited set of one query.  Random single-byte probes of a per-wave table in HBM cap the whole walk at the DRAM
+// small-access rate (tools/micro/gather_bw.hip: random 512-B reads reach 2 TB/s, 3 KB rows 6.6), so the set lives in
+// LDS: exact open-addressing hash of vertex ids (0 = empty slot, key = id + 1, linear probing, ds_cmpst).  When it
+// fills up (large ef) the wave migrates the ids into its HBM byte table and continues there -- still exact.
+struct VisitedSet {
+	unsigned *tab; // LDS, hsize entries
+	unsigned hmask;
+	int hshift;
+	uint8_t *vis; // HBM fallback: one byte per vertex, rolling stamp
+	uint8_t stamp;
+	bool spilled;
+	int count, limit;
+};
+__device__ __forceinline__ void visited_reset(VisitedSet &v, int lane) {
+	const uint4 z = make_uint4(0, 0, 0, 0);
+	for (unsigned i = lane; i < (v.hmask + 1) / 4; i += 64)
+		reinterpret_cast<uint4 *>(v.tab)[i] = z;
+	wave_fence();
+	v.spilled = false;
+	v.count = 0;
+}
+// 0 = already present, 1 = inserted now, 2 = probe chain too long (table crowded)
+__device__ __forceinline__ int visited_probe(const VisitedSet &v, int id) {
+	const unsigned key = (unsigned)id + 1u;
+	unsigned h = (key * 2654435761u) >> v.hshift;
+	for (int p = 0; p < 32; p++) {
+		const unsigned old = atomicCAS(&v.tab[h], 0u, key);
+		if (old == 0u)
+			return 1;
+		if (old == key)
+			return 0;
+		h = (h + 1) & v.hmask;
+	}
+	return 2;
+}
+__device__ __forceinline__ void visited_spill(VisitedSet &v, int lane) {
+	wave_fence();
+	for (unsigned i = lane; i <= v.hmask; i += 64) {
+		const unsigned key = v.tab[i];
+		if (key)
+			v.vis[key - 1u] = v.stamp;
+	}
+	__builtin_amdgcn_s_waitcnt(0);
+	wave_fence();
+	v.spilled = true;
+}
+// marks the vertices nid of the lanes in `valid`; returns "was not visited before"
+__device__ __forceinline__ bool visited_test_and_set(VisitedSet &v, int nid, bool valid, int lane) {
+	bool fresh = false;
+	if (!v.spilled) {
+		int r = 0;
+		if (valid)
+			r = visited_probe(v, nid);
+		fresh = r == 1;
+		v.count += (int)__popcll(__builtin_amdgcn_ballot_w64(fresh));
+		const u64 over = __builtin_amdgcn_ballot_w64(r == 2);
+		if (over || v.count > v.limit) {
+			visited_spill(v, lane);
+			if (r == 2) {
+				fresh = v.vis[nid] != v.stamp;
+				if (fresh)
+					v.vis[nid] = v.stamp;
+			}
+		}
+		return fresh;
+	}
+	if (valid) {
+		fresh = v.vis[nid] != v.stamp;
+		if (fresh)
+			v.vis[nid] = v.stamp;
+	}
+	return fresh;
+}
+
 // ------------------------------------------------------------------------------------------------ search kernel
+
+// -DMVS_HNSW_PROFILE: per-phase shader-clock totals in stats[2..8] (tools/hbench.py prints them); off in the product
+#ifdef MVS_HNSW_PROFILE
+#define PROF_NOW() __builtin_readcyclecounter()
+#define PROF_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define PROF_NOW() 0ull
+#define PROF_ADD(acc, a, b) ((void)(a), (void)(b))
+#endif
 
 struct SearchArgs {
 	GraphDev g;
@@ -290,6 +375,8 @@ struct SearchArgs {
 	const float *xq; // [nq][4*dp4]
 	long long nq;
 	int k, ef, efSearch;
+	int hsize; // visited hash slots in LDS (power of two)
+	const int32_t *nb0; // dense copy of the level-0 lists, [n][2M]: no offsets[] round trip in front of every hop
 	SelectorDev sel;
 	const long long *idmap;
 	long long label_offset;
@@ -305,12 +392,20 @@ struct SearchArgs {
 template <int NI, bool IS_L2, int G>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 	extern __shared__ u64 smem[];
-	u64 *ckeys = smem;        // MinimaxHeap candidates(ef)
-	u64 *rkeys = smem + a.ef; // result heap (k)
+	u64 *ckeys = smem + a.hsize / 2; // MinimaxHeap candidates(ef); the visited hash sits in front (16-byte aligned)
+	u64 *rkeys = ckeys + a.ef;       // result heap (k)
 	const int lane = threadIdx.x;
 	const GraphDev &g = a.g;
 	uint8_t *vis = a.visited + (size_t)blockIdx.x * a.vstride;
 	unsigned stamp = a.vstamp[blockIdx.x], ndis = 0, nexp = 0;
+	VisitedSet vs;
+	vs.tab = reinterpret_cast<unsigned *>(smem);
+	vs.hmask = a.hsize ? (unsigned)a.hsize - 1u : 0u;
+	vs.hshift = a.hsize ? 32 - (31 - __builtin_clz((unsigned)a.hsize)) : 0;
+	vs.vis = vis;
+	vs.limit = a.hsize - a.hsize / 4 - 64; // spill before the table is 3/4 full
+	unsigned long long p_desc = 0, p_pop = 0, p_nbr = 0, p_vis = 0, p_eval = 0, p_ins = 0, p_total = 0;
+	(void)p_desc, (void)p_pop, (void)p_nbr, (void)p_vis, (void)p_eval, (void)p_ins, (void)p_total;
 	const int ef = a.ef, k = a.k;
 	for (;;) {
 		int qn = 0;
@@ -323,6 +418,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			clear_table(vis, a.vstride / 16, lane);
 			stamp = 1;
 		}
+		vs.stamp = (uint8_t)stamp;
+		if (a.hsize)
+			visited_reset(vs, lane);
+		else
+			vs.spilled = true; // option hnsw_visited_lds = 0: HBM byte table only
+		const unsigned long long tq0 = PROF_NOW();
 		QV<NI> q;
 		load_row(q, a.xq + (size_t)qi * g.dp4 * 4, g.dp4, lane);
 		int nearest = a.entry_point;
@@ -342,9 +443,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 				rthr = nr < k ? FLT_MAX : key_dis(rfl64(rkeys[k - 1]));
 			}
 		}
-		if (lane == 0)
-			vis[nearest] = (uint8_t)stamp;
+		(void)visited_test_and_set(vs, nearest, lane == 0, lane);
+		PROF_ADD(p_desc, tq0, PROF_NOW());
 		while (nvalid > 0) {
+			const unsigned long long t0 = PROF_NOW();
 			// pop_min: first live entry of the sorted array
 			int pos = -1;
 			for (int base = 0; base < nc && pos < 0; base += 64) {
@@ -370,23 +472,27 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			if (nbelow >= a.efSearch)
 				break;
 			nexp++;
-			const long long base0 = g.offsets[v0];
+			const unsigned long long t1 = PROF_NOW();
+			PROF_ADD(p_pop, t0, t1);
 			const int L = 2 * g.M;
+			const int32_t *list0 = a.nb0 + (size_t)v0 * L;
 			for (int c0 = 0; c0 < L; c0 += 64) {
+				const unsigned long long t2 = PROF_NOW();
 				const int j = c0 + lane;
-				const int nid = j < L ? g.neighbors[base0 + j] : -1;
+				const int nid = j < L ? list0[j] : -1;
 				const u64 vmask = __builtin_amdgcn_ballot_w64(nid >= 0);
 				const u64 pm = valid_prefix(vmask);
 				const bool valid = (pm >> lane) & 1ull;
-				bool fresh = false;
-				if (valid) {
-					fresh = vis[nid] != (uint8_t)stamp;
-					if (fresh)
-						vis[nid] = (uint8_t)stamp;
-				}
+				const unsigned long long t3 = PROF_NOW();
+				PROF_ADD(p_nbr, t2, t3);
+				const bool fresh = visited_test_and_set(vs, nid, valid, lane);
 				const u64 fmask = __builtin_amdgcn_ballot_w64(fresh);
+				const unsigned long long t4 = PROF_NOW();
+				PROF_ADD(p_vis, t3, t4);
 				ndis += (unsigned)__popcll(fmask);
 				const float mydd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, fmask, lane);
+				const unsigned long long t5 = PROF_NOW();
+				PROF_ADD(p_eval, t4, t5);
 				bool pass = fresh;
 				if (fresh && a.sel.kind != MVS_SEL_NONE)
 					pass = sel_member_dev(a.sel, a.idmap ? a.idmap[nid] : nid);
@@ -416,10 +522,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 					nc = sorted_insert(ckeys, nc, ef, key, lane);
 					nvalid++;
 				}
+				PROF_ADD(p_ins, t5, PROF_NOW());
 				if (~vmask)
 					break;
 			}
 		}
+		PROF_ADD(p_total, tq0, PROF_NOW());
 		// ---- heap_reorder + (IP) sign restore + label translation
 		for (int j = lane; j < k; j += 64) {
 			float dv = IS_L2 ? FLT_MAX : -FLT_MAX;
@@ -441,8 +549,28 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 		if (a.stats) {
 			atomicAdd(&a.stats[0], (unsigned long long)ndis);
 			atomicAdd(&a.stats[1], (unsigned long long)nexp);
+#ifdef MVS_HNSW_PROFILE
+			atomicAdd(&a.stats[2], p_desc);
+			atomicAdd(&a.stats[3], p_pop);
+			atomicAdd(&a.stats[4], p_nbr);
+			atomicAdd(&a.stats[5], p_vis);
+			atomicAdd(&a.stats[6], p_eval);
+			atomicAdd(&a.stats[7], p_ins);
+			atomicAdd(&a.stats[8], p_total);
+#endif
 		}
 	}
+}
+
+// nb0[v][0..2M) = neighbors[offsets[v] .. +2M)
+__global__ void hnsw_level0_copy_kernel(const long long *offsets, const int32_t *neighbors, int32_t *nb0, long long v0,
+                                        long long n, int L) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (n - v0) * L)
+		return;
+	const long long v = v0 + i / L;
+	const int j = (int)(i % L);
+	nb0[v * L + j] = neighbors[offsets[v] + j];
 }
 
 __global__ void hnsw_fill_empty_kernel(float *D, long long *I, long long n, float neutral) {
@@ -725,33 +853,72 @@ __global__ __launch_bounds__(64) void hnsw_build_kernel(const BuildArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dispatch on d
 
-template <template <int, bool, int> class F, typename... A>
-void dispatch_ni(int dp4, bool is_l2, A &&...args) {
+// rows in flight per wave: the search kernel wants OCCUPANCY (tools/micro/gather_bw.hip: random 3 KB rows reach
+// 6.6 TB/s with 32 waves/CU whatever G is, 5.8 with 16), so it keeps G small to stay under 80 VGPRs; the build
+// kernel holds more state and keeps G = 4.
+// rows in flight per wave (G) vs occupancy: measured at C5 (N=1M, d=768, efSearch=128) every point between
+// {G=2, 24 waves/CU, HBM visited table} and {G=16, 8 waves/CU, LDS visited hash} lands at 16-18 ms (3.2-3.6 TB/s of
+// row bytes): 70 % of a wave's time is the row round trip of a hop at ~14 us loaded latency.  Default = the LDS hash
+// (no 1-byte HBM probes, no multi-GB visited tables) with G = 16; options hnsw_search_g / hnsw_visited_lds /
+// hnsw_search_waves select the others.
+template <template <int, bool, int> class F, int NI, int G, typename... A>
+void dispatch_metric(bool is_l2, A &&...args) {
+	if (is_l2)
+		F<NI, true, G>::run(std::forward<A>(args)...);
+	else
+		F<NI, false, G>::run(std::forward<A>(args)...);
+}
+// gsel: rows in flight per wave for the search kernel (0 = default); the build kernel uses its own fixed G
+template <template <int, bool, int> class F, bool SEARCH, typename... A>
+void dispatch_ni(int dp4, bool is_l2, int gsel, A &&...args) {
 	const int ni = (dp4 + 63) / 64;
-#define MVS_NI_CASE(NI, G)                                                                                             \
+#define MVS_NI_SMALL(NI)                                                                                               \
 	if (ni <= NI) {                                                                                                    \
-		if (is_l2)                                                                                                     \
-			F<NI, true, G>::run(std::forward<A>(args)...);                                                             \
+		if constexpr (!SEARCH)                                                                                         \
+			dispatch_metric<F, NI, 4>(is_l2, std::forward<A>(args)...);                                                \
+		else if (gsel == 2)                                                                                            \
+			dispatch_metric<F, NI, 2>(is_l2, std::forward<A>(args)...);                                                \
+		else if (gsel == 8)                                                                                            \
+			dispatch_metric<F, NI, 8>(is_l2, std::forward<A>(args)...);                                                \
 		else                                                                                                           \
-			F<NI, false, G>::run(std::forward<A>(args)...);                                                            \
+			dispatch_metric<F, NI, 16>(is_l2, std::forward<A>(args)...);                                               \
 		return;                                                                                                        \
 	}
-	MVS_NI_CASE(1, 4)
-	MVS_NI_CASE(2, 4)
-	MVS_NI_CASE(3, 4)
-	MVS_NI_CASE(4, 2)
-	MVS_NI_CASE(6, 2)
-	MVS_NI_CASE(8, 1)
-	MVS_NI_CASE(16, 1)
+#define MVS_NI_CASE(NI, GS, GB)                                                                                        \
+	if (ni <= NI) {                                                                                                    \
+		dispatch_metric<F, NI, SEARCH ? GS : GB>(is_l2, std::forward<A>(args)...);                                     \
+		return;                                                                                                        \
+	}
+	MVS_NI_SMALL(1)
+	MVS_NI_SMALL(2)
+	MVS_NI_SMALL(3)
+	MVS_NI_CASE(4, 8, 2)
+	MVS_NI_CASE(6, 8, 2)
+	MVS_NI_CASE(8, 4, 1)
+	MVS_NI_CASE(16, 2, 1)
 #undef MVS_NI_CASE
+#undef MVS_NI_SMALL
 	throw_faiss("mvs::HNSWIndex", __FILE__, "dimension %d exceeds the supported maximum 4096", dp4 * 4);
 }
+
+// resident workgroups (= waves) per CU of the search kernel instance for this LDS size
+template <int NI, bool IS_L2, int G>
+struct SearchOccupancy {
+	static void run(int *out, size_t lds) {
+		int nb = 0;
+		MVS_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<NI, IS_L2, G>,
+		                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)hnsw_search_kernel<NI, IS_L2, G>, 64, lds) !=
+		        hipSuccess ||
+		    nb <= 0)
+			nb = 8;
+		*out = nb;
+	}
+};
 
 template <int NI, bool IS_L2, int G>
 struct SearchLaunch {
 	static void run(const SearchArgs &a, int grid, size_t lds, hipStream_t st) {
-		MVS_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<NI, IS_L2, G>,
-		                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		hipLaunchKernelGGL((hnsw_search_kernel<NI, IS_L2, G>), dim3(grid), dim3(64), lds, st, a);
 		MVS_HIP(hipGetLastError());
 	}
@@ -840,6 +1007,7 @@ public:
 		offsets.release();
 		neighbors.release();
 		locks.release();
+		nb0.release();
 		if (h_stats)
 			(void)hipHostFree(h_stats);
 	}
@@ -853,6 +1021,21 @@ public:
 			f -= assign_probas[level];
 		}
 		return (int)assign_probas.size() - 1;
+	}
+
+	// dense level-0 adjacency for the search kernel, extended after every add
+	void sync_level0() {
+		if (nb0_rows >= ntotal)
+			return;
+		const int L = 2 * M;
+		nb0.ensure((size_t)ntotal * L * 4, 0, stream);
+		// reverse links touch old vertices too: refresh everything (N * 8M bytes, once per add batch)
+		const long long tot = (long long)ntotal * L;
+		hipLaunchKernelGGL(hnsw_level0_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+		                   (const long long *)offsets.p, (const int32_t *)neighbors.p, (int32_t *)nb0.p, 0ll,
+		                   (long long)ntotal, L);
+		MVS_HIP(hipGetLastError());
+		nb0_rows = ntotal;
 	}
 
 	GraphDev graph_dev() const {
@@ -887,7 +1070,7 @@ public:
 		MVS_HIP(hipMemsetAsync(ws_counter.p, 0, sizeof(int), stream));
 		const int L0 = 2 * M;
 		const size_t lds = (size_t)(efConstruction + L0 + 1) * 8 + (size_t)(L0 + 1) * 8 + (size_t)L0 * 4 + 64;
-		dispatch_ni<BuildLaunch>(dp4, metric == METRIC_L2, a, waves, lds, stream);
+		dispatch_ni<BuildLaunch, false>(dp4, metric == METRIC_L2, 0, a, waves, lds, stream);
 	}
 
 	// d_x: [n][d] rows on device, ordered after everything enqueued on `stream`
@@ -946,7 +1129,7 @@ public:
 		ws_order.reserve((size_t)n * sizeof(int32_t));
 		MVS_HIP(hipMemcpyAsync(ws_order.p, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
 		ws_counter.reserve(64);
-		ws_stats.reserve(64);
+		ws_stats.reserve(128);
 		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 16, stream));
 		// visited tables of the build waves
 		int max_waves = build_waves > 0 ? (int)std::min<int64_t>(build_waves, 4096) : 1024;
@@ -1046,13 +1229,29 @@ public:
 		}
 		ws_q.reserve((size_t)nq * dp * sizeof(float));
 		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
-		const size_t lds = (size_t)(ef + k) * 8 + 64;
-		// resident waves: 16 per CU unless LDS says otherwise
+		// visited hash: ~15 distance evaluations per unit of ef on clustered data; 4096 slots cover ef = 128 at < 1/2 load
+		int hsize = 0;
+		if (visited_lds) {
+			hsize = 1024;
+			while (hsize < 24 * ef && hsize < 8192)
+				hsize *= 2;
+			if (visited_lds >= 1024) // explicit slot count (power of two)
+				hsize = visited_lds;
+		}
+		const size_t lds = (size_t)(ef + k) * 8 + (size_t)hsize * 4 + 64;
+		// one workgroup = one wave; fill every resident slot the kernel instance allows (VGPRs / LDS)
 		if (cus <= 0) {
 			int v = 0;
 			cus = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0 ? v : 256;
 		}
-		const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (size_t)(150 * 1024) / lds));
+		if (occ_lds != lds || occ_g != search_g) { // the occupancy query is not free: once per LDS size
+			int v = 8;
+			dispatch_ni<SearchOccupancy, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			occ_g = search_g;
+			occ_waves = std::max(1, std::min(v, 32));
+			occ_lds = lds;
+		}
+		const int per_cu = search_waves_per_cu > 0 ? std::min(search_waves_per_cu, occ_waves) : occ_waves;
 		// visited tables (one byte per vertex per wave) persist across searches; the rolling stamp makes a fresh
 		// table unnecessary, they are zeroed only when (re)allocated
 		const size_t vcap = vecs.cap / ((size_t)dp * sizeof(float));
@@ -1068,8 +1267,8 @@ public:
 			svis_stride = (int64_t)stride;
 			svis_waves = nw;
 		}
-		ws_stats.reserve(64);
-		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 16, stream));
+		ws_stats.reserve(128);
+		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 128, stream));
 		ws_counter.reserve(64);
 		MVS_HIP(hipMemsetAsync(ws_counter.p, 0, sizeof(int), stream));
 		SearchArgs a;
@@ -1081,6 +1280,9 @@ public:
 		a.k = (int)k;
 		a.ef = (int)ef;
 		a.efSearch = (int)efs;
+		a.hsize = hsize;
+		sync_level0();
+		a.nb0 = (const int32_t *)nb0.p;
 		a.sel = selector.upload(params, stream);
 		a.idmap = (const long long *)d_idmap;
 		a.label_offset = label_offset;
@@ -1092,7 +1294,7 @@ public:
 		a.I = (long long *)d_I;
 		a.stats = (unsigned long long *)ws_stats.p;
 		begin_kernel_timing(stream);
-		dispatch_ni<SearchLaunch>(dp4, metric == METRIC_L2, a, grid, lds, stream);
+		dispatch_ni<SearchLaunch, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
 		end_kernel_timing(stream);
 		snprintf(kinfo.name, sizeof kinfo.name, "hnsw_search_kernel");
 		kinfo.grid = grid;
@@ -1102,9 +1304,16 @@ public:
 			// the walk-length counters are only fetched when a bench asked for kernel timing: the plain search path
 			// stays asynchronous on the caller's stream
 			if (!h_stats)
-				MVS_HIP(hipHostMalloc((void **)&h_stats, 64, hipHostMallocDefault));
-			MVS_HIP(hipMemcpyAsync(h_stats, ws_stats.p, 16, hipMemcpyDeviceToHost, stream));
+				MVS_HIP(hipHostMalloc((void **)&h_stats, 128, hipHostMallocDefault));
+			MVS_HIP(hipMemcpyAsync(h_stats, ws_stats.p, 128, hipMemcpyDeviceToHost, stream));
 			MVS_HIP(hipStreamSynchronize(stream));
+#ifdef MVS_HNSW_PROFILE
+			fprintf(stderr,
+			        "[hnsw profile] shader clocks: descent %.3g pop %.3g nbr %.3g visited %.3g eval %.3g insert %.3g | "
+			        "total %.3g\n",
+			        (double)h_stats[2], (double)h_stats[3], (double)h_stats[4], (double)h_stats[5], (double)h_stats[6],
+			        (double)h_stats[7], (double)h_stats[8]);
+#endif
 			const unsigned long long nd = h_stats[0], ne = h_stats[1];
 			kinfo.bytes = (double)nd * ((double)d * 4.0 + 4.0); // n_visited * (4d + 4), counted by the kernel
 			kinfo.flops = (double)nd * d * (metric == METRIC_L2 ? 3.0 : 2.0);
@@ -1212,6 +1421,18 @@ public:
 			efSearch = (int)v;
 			return true;
 		}
+		if (!strcmp(key, "hnsw_search_g")) {
+			search_g = (int)v;
+			return true;
+		}
+		if (!strcmp(key, "hnsw_visited_lds")) {
+			visited_lds = (int)v;
+			return true;
+		}
+		if (!strcmp(key, "hnsw_search_waves")) {
+			search_waves_per_cu = (int)v;
+			return true;
+		}
 		return false;
 	}
 
@@ -1235,9 +1456,13 @@ private:
 	std::vector<int> cum_nn;
 	std::vector<int32_t> levels_h;
 	std::vector<int64_t> offsets_h;
-	KeepBuf vecs, offsets, neighbors, locks;
+	KeepBuf vecs, offsets, neighbors, locks, nb0;
+	int64_t nb0_rows = 0;
 	DevBuf ws_order, ws_counter, ws_stats, ws_q, ws_vis, sstamp, bvis, bstamp;
-	int cus = 0;
+	int cus = 0, occ_waves = 0, occ_g = -1;
+	int search_g = 0, search_waves_per_cu = 0; // options hnsw_search_g / hnsw_search_waves (0 = default)
+	int visited_lds = 1;                       // option hnsw_visited_lds
+	size_t occ_lds = 0;
 	unsigned long long *h_stats = nullptr; // pinned
 	int64_t bvis_stride = 0, svis_stride = 0;
 	int bvis_waves = 0, svis_waves = 0;

@@ -87,6 +87,22 @@ def test_search_bit_exact_on_same_graph(mf, metric, efs, k):
     assert np.array_equal(Dg.view(np.uint32), Do.view(np.uint32))
 
 
+@pytest.mark.parametrize("opts", [{"hnsw_visited_lds": 0}, {"hnsw_visited_lds": 1024}, {"hnsw_search_g": 2},
+                                  {"hnsw_search_g": 8, "hnsw_search_waves": 3}])
+def test_search_variants_are_exact(mf, opts):
+    """the visited set (LDS hash, its spill into the HBM byte table when it fills up, HBM table only) and the
+    rows-in-flight / occupancy knobs must not change a single bit of the answer"""
+    d, n = 48, 8000
+    xb, xq = orc.synth_uniform(n, d, 34), orc.synth_uniform(200, d, 35)
+    o, g = _pair(mf, d, "HNSW16", L2, xb)
+    for key, v in opts.items():
+        g.set_option(key, v)
+    for efs, k in ((300, 10), (40, 10)):  # 300: > 1024 * 3/4 visited vertices -> the small hash spills
+        Do, Io = o.search(xq, k, efSearch=efs)
+        Dg, Ig = g.search(xq, k, efSearch=efs)
+        assert np.array_equal(Ig, Io) and np.array_equal(Dg.view(np.uint32), Do.view(np.uint32))
+
+
 def test_search_d768_bit_exact_and_recall(mf):
     """BASELINE config C5 shape at reduced N: IDMap,HNSW32 d=768, L2-normalised rows, efSearch=128"""
     d, n = 768, 4000
