@@ -121,6 +121,12 @@ void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, cons
                          SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot,
                          hipStream_t st);
 void launch_init_slots(unsigned *d_gslot, int64_t nq, int64_t k, int metric, hipStream_t st);
+// csrc/ivf_scan.hip: list-major scan without LDS staging (dp multiple of 16); same item / partial-list formats
+bool ivf_scan_supported(int dp, int64_t k);
+size_t ivf_scan_lds_bytes(int64_t k);
+void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows, int64_t nrows, const int64_t *d_rowids,
+                     int64_t k, const void *d_items, int nitems, const int *d_qidx, SelectorDev sel,
+                     const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st);
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
                         int64_t k, const int64_t *d_rowids, const int64_t *d_idmap, float *d_D, int64_t *d_I,
                         hipStream_t st);

@@ -415,16 +415,22 @@ public:
 		ws_gslot.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
 		launch_init_slots((unsigned *)ws_gslot.p, nq, k, metric, stream);
 		begin_kernel_timing(stream);
-		launch_direct_items(dp, metric, (const float *)ws_q.p, nq, (const float *)codes.p, nsorted,
-		                    (const int64_t *)rowids.p, k, ws_items.p, nitems, (const int *)ws_qidx.p, sel, d_idmap,
-		                    (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
+		const bool fast_scan = use_fast_scan && ivf_scan_supported(dp, k);
+		if (fast_scan)
+			launch_ivf_scan(dp, metric, (const float *)ws_q.p, (const float *)codes.p, nsorted, (const int64_t *)rowids.p, k,
+			                ws_items.p, nitems, (const int *)ws_qidx.p, sel, d_idmap, (float *)ws_pd.p, (int32_t *)ws_pi.p,
+			                (unsigned *)ws_gslot.p, stream);
+		else
+			launch_direct_items(dp, metric, (const float *)ws_q.p, nq, (const float *)codes.p, nsorted,
+			                    (const int64_t *)rowids.p, k, ws_items.p, nitems, (const int *)ws_qidx.p, sel, d_idmap,
+			                    (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
 		                   k, (const int64_t *)rowids.p, d_idmap, d_D, d_I, stream);
 		// the caller's stream continues after ours; pageable staging vectors die with this frame
 		MVS_HIP(hipStreamSynchronize(stream));
 		stream_wait(st, stream);
-		snprintf(kinfo.name, sizeof kinfo.name, "ivf_list_scan (flat_direct_kernel items)");
+		snprintf(kinfo.name, sizeof kinfo.name, fast_scan ? "ivf_scan_kernel" : "ivf_list_scan (flat_direct_kernel items)");
 		double bytes = 0, pairs = 0;
 		for (const Item &it : items) {
 			bytes += (double)(it.row_end - it.row_begin) * dp * 4.0;
@@ -434,7 +440,7 @@ public:
 		kinfo.flops = pairs * d * (metric == METRIC_L2 ? 3.0 : 2.0);
 		kinfo.grid = nitems;
 		kinfo.block = 256;
-		kinfo.lds_bytes = (int)direct_items_lds_bytes(dp, k);
+		kinfo.lds_bytes = (int)(fast_scan ? ivf_scan_lds_bytes(k) : direct_items_lds_bytes(dp, k));
 		kinfo.nsplit = (int)np;
 	}
 	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
@@ -513,6 +519,14 @@ public:
 	void set_timing(bool on) override {
 		timing_enabled = on;
 	}
+	bool set_option(const char *key, int64_t v) override {
+		if (!strcmp(key, "ivf_fast_scan")) { // 0 = the LDS-staged flat_direct item kernel
+			use_fast_scan = v != 0;
+			return true;
+		}
+		return quantizer->set_option(key, v);
+	}
+	bool use_fast_scan = true;
 
 	// introspection for parity tests
 	void get_centroids(float *out) {

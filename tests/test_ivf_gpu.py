@@ -50,9 +50,10 @@ def test_subsampled_training_matches_oracle(mf):
     assert np.array_equal(g.ivf_centroids(), o.ivf_centroids())
 
 
+@pytest.mark.parametrize("fast_scan", [1, 0])
 @pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("nprobe", [1, 4, 16])
-def test_ivf_search_matches_oracle(mf, metric, nprobe):
+def test_ivf_search_matches_oracle(mf, metric, nprobe, fast_scan):
     d, nlist = 64, 16
     xb = _clustered(20000, d, 11)
     xq = _clustered(300, d, 12)
@@ -61,16 +62,18 @@ def test_ivf_search_matches_oracle(mf, metric, nprobe):
     o.add(xb)
     g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
     g.ivf_set_centroids(o.ivf_centroids())  # share the centroids: this test is about add + search
+    g.set_option("ivf_fast_scan", fast_scan)  # 1: csrc/ivf_scan.hip, 0: the LDS-staged flat_direct item kernel
     for i0 in range(0, 20000, 7000):
         g.add(xb[i0 : i0 + 7000])
     assert g.ntotal == 20000
-    Do, Io = o.search(xq, 10, nprobe=nprobe)
-    D, I = g.search(xq, 10, nprobe=nprobe)
-    ok = _no_tie_rows(Do)
-    assert ok.sum() > 250
-    assert np.array_equal(I[ok], Io[ok])
-    assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
-    assert g.last_kernel_info()["name"].startswith("ivf_list_scan")
+    for k in (10, 40):  # 40: threshold classes wider than one 16-slot row
+        Do, Io = o.search(xq, k, nprobe=nprobe)
+        D, I = g.search(xq, k, nprobe=nprobe)
+        ok = _no_tie_rows(Do)
+        assert ok.sum() > 250
+        assert np.array_equal(I[ok], Io[ok])
+        assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
+    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel" if fast_scan else "ivf_list_scan")
 
 
 def test_ivf_train_add_search_end_to_end_and_recall(mf):
