@@ -124,9 +124,16 @@ void launch_init_slots(unsigned *d_gslot, int64_t nq, int64_t k, int metric, hip
 // csrc/ivf_scan.hip: list-major scan without LDS staging (dp multiple of 16); same item / partial-list formats
 bool ivf_scan_supported(int dp, int64_t k);
 size_t ivf_scan_lds_bytes(int64_t k);
+size_t ivf_scan_query_pack_bytes(int dp, int nitems); // workspace d_xi: the items' queries, slot pairs interleaved
 void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows, int64_t nrows, const int64_t *d_rowids,
                      int64_t k, const void *d_items, int nitems, const int *d_qidx, SelectorDev sel,
-                     const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st);
+                     const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, float *d_xi,
+                     const int *d_nitems /* device item count, grid = upper bound; may be null */, hipStream_t st);
+// device-side construction of the work items from the coarse-search labels (no host round trip)
+int ivf_group_max_items(int64_t npairs, int64_t nlist);
+size_t ivf_group_ws_ints(int64_t nlist);
+void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, const int64_t *d_list_off, int *ws_int,
+                      void *d_items, int *d_qidx, int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st);
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
                         int64_t k, const int64_t *d_rowids, const int64_t *d_idmap, float *d_D, int64_t *d_I,
                         hipStream_t st);

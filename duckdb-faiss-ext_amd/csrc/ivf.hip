@@ -326,6 +326,9 @@ public:
 			MVS_HIP(hipMemcpyAsync(rowids.p, sid.data(), (size_t)nsorted * sizeof(int64_t), hipMemcpyHostToDevice, stream));
 			launch_gather_rows(raw, (const int *)dperm.p, nsorted, dp, (float *)codes.p, stream);
 		}
+		list_off_dev.reserve(list_off.size() * sizeof(int64_t));
+		MVS_HIP(hipMemcpyAsync(list_off_dev.p, list_off.data(), list_off.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+		                       stream));
 		MVS_HIP(hipStreamSynchronize(stream));
 		dirty = false;
 	}
@@ -352,6 +355,64 @@ public:
 		ws_cD.reserve((size_t)nq * np * sizeof(float));
 		ws_cI.reserve((size_t)nq * np * sizeof(int64_t));
 		quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, nullptr, stream);
+		const bool fast_scan = use_fast_scan && ivf_scan_supported(dp, k) && nq * np < (int64_t)1 << 26;
+		if (fast_scan)
+			device_grouped_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
+		else
+			host_grouped_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
+	}
+
+	// list scan with the work items built ON DEVICE from the coarse labels: no host round trip inside a search
+	void device_grouped_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, int64_t np) {
+		const int64_t npairs = nq * np;
+		const int max_items = ivf_group_max_items(npairs, nlist);
+		ws_items.reserve((size_t)max_items * 16);
+		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
+		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
+		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		int *d_nitems = nullptr, *d_cnt = nullptr;
+		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, (const int64_t *)list_off_dev.p, (int *)ws_group.p,
+		                 ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
+		ws_q.reserve((size_t)nq * dp * sizeof(float));
+		ws_pd.reserve((size_t)max_items * 20 * k * sizeof(float));
+		ws_pi.reserve((size_t)max_items * 20 * k * sizeof(int32_t));
+		ws_xi.reserve(ivf_scan_query_pack_bytes(dp, max_items));
+		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
+		SelectorDev sel = selector.upload(params, stream);
+		memset(&kinfo, 0, sizeof kinfo);
+		ws_gslot.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+		launch_init_slots((unsigned *)ws_gslot.p, nq, k, metric, stream);
+		begin_kernel_timing(stream);
+		launch_ivf_scan(dp, metric, (const float *)ws_q.p, (const float *)codes.p, nsorted, (const int64_t *)rowids.p, k,
+		                ws_items.p, max_items, (const int *)ws_qidx.p, sel, d_idmap, (float *)ws_pd.p, (int32_t *)ws_pi.p,
+		                (unsigned *)ws_gslot.p, (float *)ws_xi.p, d_nitems, stream);
+		end_kernel_timing(stream);
+		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
+		                   k, (const int64_t *)rowids.p, d_idmap, d_D, d_I, stream);
+		snprintf(kinfo.name, sizeof kinfo.name, "ivf_scan_kernel");
+		kinfo.grid = max_items;
+		kinfo.block = 256;
+		kinfo.lds_bytes = (int)ivf_scan_lds_bytes(k);
+		kinfo.nsplit = (int)np;
+		if (timing_enabled) { // algorithmic bytes need the per-list pair counts: fetched only for a bench
+			std::vector<int> cnt((size_t)nlist);
+			MVS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nlist * sizeof(int), hipMemcpyDeviceToHost, stream));
+			MVS_HIP(hipStreamSynchronize(stream));
+			double bytes = 0, pairs = 0;
+			for (int64_t l = 0; l < nlist; l++) {
+				const double len = (double)(list_off[(size_t)l + 1] - list_off[(size_t)l]);
+				bytes += (double)((cnt[(size_t)l] + 19) / 20) * len * dp * 4.0;
+				pairs += (double)cnt[(size_t)l] * len;
+			}
+			kinfo.bytes = bytes; // list-major algorithmic bytes: every item streams its list once
+			kinfo.flops = pairs * d * (metric == METRIC_L2 ? 3.0 : 2.0);
+		}
+		stream_wait(st, stream);
+	}
+
+	void host_grouped_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                         const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, int64_t np) {
 		std::vector<int64_t> keys((size_t)nq * np);
 		MVS_HIP(hipMemcpyAsync(keys.data(), ws_cI.p, keys.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 		MVS_HIP(hipStreamSynchronize(stream));
@@ -415,12 +476,7 @@ public:
 		ws_gslot.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
 		launch_init_slots((unsigned *)ws_gslot.p, nq, k, metric, stream);
 		begin_kernel_timing(stream);
-		const bool fast_scan = use_fast_scan && ivf_scan_supported(dp, k);
-		if (fast_scan)
-			launch_ivf_scan(dp, metric, (const float *)ws_q.p, (const float *)codes.p, nsorted, (const int64_t *)rowids.p, k,
-			                ws_items.p, nitems, (const int *)ws_qidx.p, sel, d_idmap, (float *)ws_pd.p, (int32_t *)ws_pi.p,
-			                (unsigned *)ws_gslot.p, stream);
-		else
+		const bool fast_scan = false;
 			launch_direct_items(dp, metric, (const float *)ws_q.p, nq, (const float *)codes.p, nsorted,
 			                    (const int64_t *)rowids.p, k, ws_items.p, nitems, (const int *)ws_qidx.p, sel, d_idmap,
 			                    (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
@@ -543,7 +599,7 @@ private:
 	std::vector<int64_t> list_off;
 	int64_t nsorted = 0;
 	DevBuf codes, rowids;
-	DevBuf ws_cD, ws_cI, ws_items, ws_qidx, ws_slots, ws_q, ws_pd, ws_pi, ws_gslot;
+	DevBuf ws_cD, ws_cI, ws_items, ws_qidx, ws_slots, ws_q, ws_pd, ws_pi, ws_gslot, ws_xi, ws_group, list_off_dev;
 	SelectorHolder selector;
 };
 

@@ -6,7 +6,10 @@
 //     the next chunk in flight -- no LDS staging, no workgroup barrier in the scan loop; the 64 rows of a wave span
 //     64 cache lines per load instruction and the following instructions hit the same lines in L1;
 //   * the query values are wave-uniform: they arrive through the scalar cache as s_load_dwordx16 and feed the VALU
-//     as SGPR operands, so a distance costs exactly v_sub + v_fmac per dimension (L2) / v_fmac (IP);
+//     as SGPR operands.  The item's queries are first re-packed (ivf_pack_item_queries_kernel) so that the values
+//     of TWO query slots for one dimension are adjacent: one v_pk_add_f32 (SGPR pair - row value broadcast by
+//     op_sel) + one v_pk_fma_f32 advance two distance chains by one dimension -- packed fp32 doubles the VALU rate
+//     (157 vs 79 TFLOP/s), and each component is the same IEEE fma as the scalar instruction;
 //   * per-pair arithmetic in k order (fvec_L2sqr / fvec_inner_product restated as one fma chain per pair), so list
 //     scans are bit-identical to oracle/orc_core.c ivf_search;
 //   * 20 independent chains per thread give the ILP; ~80 VGPRs => 6 waves per SIMD hide the scalar-load latency;
@@ -25,11 +28,13 @@ namespace {
 constexpr int SQG = 20;    // query slots per work item
 constexpr int STILE = 256; // rows per tile = threads per workgroup
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(4))) const f32x16 cf32x16;
 
 struct ScanArgs {
 	const float *xq; // [nq][dp]
+	const float *xi; // [item][SQG/2][dp/16][2][8][2]: per item, slot pairs interleaved per dimension
 	const float *rows; // [n][dp], lists are contiguous row segments
 	float *pd;
 	int32_t *pi;
@@ -37,6 +42,7 @@ struct ScanArgs {
 	int k, dp;
 	SelectorDev sel;
 	const long long *idmap;
+	const int *nitems_dev;   // device-side item count (grid is an upper bound); null = every block is an item
 	const int4 *items;       // {row_begin, row_end, qoff, nq_item}
 	const int *qidx;         // query number of slot qoff + s
 	const long long *rowids; // stored id of every row
@@ -95,6 +101,8 @@ __device__ __forceinline__ void wave_sync() {
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
+	if (a.nitems_dev && (int)blockIdx.x >= *a.nitems_dev)
+		return;
 	const int k = a.k;
 	float *lv = smem;                       // [4][SQG][k] per-wave list values
 	int *lid = (int *)(lv + 4 * SQG * k);   // [4][SQG][k] row positions
@@ -195,10 +203,11 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 		for (int i = 0; i < 4; ++i)
 			yc[i] = yp[i];
 		refresh_bounds();
-		float acc[SQG];
+		f32x2 acc2[SQG / 2];
 #pragma unroll
-		for (int qq = 0; qq < SQG; ++qq)
-			acc[qq] = 0.f;
+		for (int p = 0; p < SQG / 2; ++p)
+			acc2[p] = (f32x2) {0.f, 0.f};
+		const float *xitem = a.xi + (size_t)blockIdx.x * (SQG / 2) * nchunk * 32;
 		for (int c = 0; c < nchunk; ++c) {
 			float4 yn[4];
 			const int cn = c + 1 < nchunk ? c + 1 : c;
@@ -207,30 +216,39 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 				yn[i] = yp[cn * 4 + i];
 			const float y[16] = {yc[0].x, yc[0].y, yc[0].z, yc[0].w, yc[1].x, yc[1].y, yc[1].z, yc[1].w,
 			                     yc[2].x, yc[2].y, yc[2].z, yc[2].w, yc[3].x, yc[3].y, yc[3].z, yc[3].w};
-			// one basic block per slot: s_load_dwordx16 of the slot's 16 query values, then 16 x (v_sub, v_fmac).  The
-			// scalar-load latency is covered by the other waves of the SIMD (a hand-pipelined variant that issued
-			// the next slot's load early made the compiler roll the loop with indexed VGPRs and ran 17 % slower).
+			// one basic block per slot pair: 2 x s_load_dwordx16 (16 dimensions x 2 slots), then per dimension one
+			// v_pk_add_f32 + one v_pk_fma_f32 (L2) / one v_pk_fma_f32 (IP).  The scalar-load latency is covered by
+			// the other waves of the SIMD.
 #pragma unroll
-			for (int qq = 0; qq < SQG; ++qq) {
-				if (qq < nq_item) { // wave-uniform
-					const f32x16 x = *(cf32x16 *)(a.xq + (size_t)qn[qq] * a.dp + c * 16);
-					float s = acc[qq];
+			for (int p = 0; p < SQG / 2; ++p) {
+				if (2 * p < nq_item) { // wave-uniform
+					const float *xb = xitem + ((size_t)p * nchunk + c) * 32;
+					const f32x16 x0 = *(cf32x16 *)xb;
+					const f32x16 x1 = *(cf32x16 *)(xb + 16);
+					f32x2 s2 = acc2[p];
 #pragma unroll
 					for (int kk = 0; kk < 16; ++kk) {
+						const f32x2 xx = kk < 8 ? (f32x2) {x0[2 * kk], x0[2 * kk + 1]}
+						                        : (f32x2) {x1[2 * (kk - 8)], x1[2 * (kk - 8) + 1]};
+						const f32x2 yy = {y[kk], y[kk]};
 						if (IS_L2) {
-							const float t = x[kk] - y[kk];
-							s = fmaf(t, t, s);
+							const f32x2 t = xx - yy;
+							s2 = __builtin_elementwise_fma(t, t, s2);
 						} else {
-							s = fmaf(x[kk], y[kk], s);
+							s2 = __builtin_elementwise_fma(xx, yy, s2);
 						}
 					}
-					acc[qq] = s;
+					acc2[p] = s2;
 				}
 			}
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
 				yc[i] = yn[i];
 		}
+		float acc[SQG];
+#pragma unroll
+		for (int qq = 0; qq < SQG; ++qq)
+			acc[qq] = (qq & 1) ? acc2[qq / 2].y : acc2[qq / 2].x;
 
 		// ---- k-best update of the tile
 		bool valid = row < r_end;
@@ -344,6 +362,95 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 	}
 }
 
+// xi[item][p][c][h][kk][j] = xq[qidx[qoff + 2p + j]][16c + 8h + kk]   (0 for unused slots)
+__global__ void ivf_pack_item_queries_kernel(const float *xq, const int *qidx, const int4 *items, const int *nitems_dev,
+                                             int dp, float *xi) {
+	if (nitems_dev && (int)blockIdx.x >= *nitems_dev)
+		return;
+	const int4 it = items[blockIdx.x];
+	const int nchunk = dp / 16;
+	const int total = (SQG / 2) * nchunk * 32;
+	float *dst = xi + (size_t)blockIdx.x * total;
+	for (int e = threadIdx.x; e < total; e += blockDim.x) {
+		const int j = e & 1, kk = (e >> 1) & 7, h = (e >> 4) & 1, pc = e >> 5;
+		const int c = pc % nchunk, p = pc / nchunk;
+		const int slot = 2 * p + j;
+		float v = 0.f;
+		if (slot < it.w)
+			v = xq[(size_t)qidx[it.z + slot] * dp + c * 16 + h * 8 + kk];
+		dst[e] = v;
+	}
+}
+
+// ---- device-side grouping of the (query, probed list) pairs into work items (no host round trip) ---------------
+// keys[q][p] = list probed by query q at rank p (-1: fewer than nprobe lists).  Any order of the pairs inside a list
+// gives the same results (the per-query merge is order independent), so positions come from atomics.
+__global__ void ivf_group_count_kernel(const long long *keys, int npairs, int *cnt) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < npairs && keys[i] >= 0)
+		atomicAdd(&cnt[keys[i]], 1);
+}
+// single workgroup: pair offsets and item offsets per list (exclusive scans), total item count
+__global__ __launch_bounds__(1024) void ivf_group_scan_kernel(const int *cnt, int nlist, int *pair_off, int *item_off,
+                                                             int *cursor, int *nitems_out) {
+	__shared__ int part_p[1024], part_i[1024];
+	const int t = threadIdx.x;
+	const int per = (nlist + 1023) / 1024;
+	const int l0 = t * per, l1 = min(nlist, l0 + per);
+	int sp = 0, si = 0;
+	for (int l = l0; l < l1; ++l) {
+		sp += cnt[l];
+		si += (cnt[l] + SQG - 1) / SQG;
+	}
+	part_p[t] = sp;
+	part_i[t] = si;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+		const int vp = t >= off ? part_p[t - off] : 0, vi = t >= off ? part_i[t - off] : 0;
+		__syncthreads();
+		part_p[t] += vp;
+		part_i[t] += vi;
+		__syncthreads();
+	}
+	int bp = part_p[t] - sp, bi = part_i[t] - si;
+	for (int l = l0; l < l1; ++l) {
+		pair_off[l] = bp;
+		cursor[l] = bp;
+		item_off[l] = bi;
+		bp += cnt[l];
+		bi += (cnt[l] + SQG - 1) / SQG;
+	}
+	if (t == 1023) {
+		pair_off[nlist] = part_p[1023];
+		item_off[nlist] = part_i[1023];
+		*nitems_out = part_i[1023];
+	}
+}
+__global__ void ivf_group_scatter_kernel(const long long *keys, int npairs, int nprobe, const int *pair_off,
+                                         const int *item_off, int *cursor, int *qidx, int *slots) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= npairs)
+		return;
+	const long long l = keys[i];
+	if (l < 0) {
+		slots[i] = -1;
+		return;
+	}
+	const int pos = atomicAdd(&cursor[l], 1);
+	qidx[pos] = i / nprobe;
+	const int rel = pos - pair_off[l];
+	slots[i] = ((item_off[l] + rel / SQG) << 5) | (rel % SQG);
+}
+__global__ void ivf_group_items_kernel(const int *cnt, const int *pair_off, const int *item_off, const long long *list_off,
+                                       int nlist, int4 *items) {
+	const int l = blockIdx.x * blockDim.x + threadIdx.x;
+	if (l >= nlist)
+		return;
+	const int n = cnt[l];
+	for (int g = 0; g * SQG < n; ++g)
+		items[item_off[l] + g] = make_int4((int)list_off[l], (int)list_off[l + 1], pair_off[l] + g * SQG, min(SQG, n - g * SQG));
+}
+
 size_t scan_lds_bytes(int64_t k) {
 	return (size_t)4 * SQG * k * 8 + (size_t)4 * SQG * 16 + SQG * 4 + 64;
 }
@@ -356,14 +463,48 @@ bool ivf_scan_supported(int dp, int64_t k) {
 size_t ivf_scan_lds_bytes(int64_t k) {
 	return scan_lds_bytes(k);
 }
+size_t ivf_scan_query_pack_bytes(int dp, int nitems) {
+	return (size_t)nitems * SQG * dp * sizeof(float);
+}
+
+// ws_int: [4*(nlist+1) + 4] ints.  Outputs: d_items (<= max_items), d_qidx [npairs], d_slots [npairs], *d_nitems.
+int ivf_group_max_items(int64_t npairs, int64_t nlist) {
+	return (int)(npairs / SQG + nlist + 1);
+}
+size_t ivf_group_ws_ints(int64_t nlist) {
+	return (size_t)4 * (nlist + 1) + 4;
+}
+void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, const int64_t *d_list_off, int *ws_int,
+                      void *d_items, int *d_qidx, int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st) {
+	const int npairs = (int)(nq * nprobe);
+	int *cnt = ws_int, *pair_off = cnt + (nlist + 1), *item_off = pair_off + (nlist + 1), *cursor = item_off + (nlist + 1);
+	int *nitems = cursor + (nlist + 1);
+	MVS_HIP(hipMemsetAsync(cnt, 0, (size_t)(nlist + 1) * sizeof(int), st));
+	hipLaunchKernelGGL(ivf_group_count_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, (const long long *)d_keys,
+	                   npairs, cnt);
+	hipLaunchKernelGGL(ivf_group_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int)nlist, pair_off, item_off, cursor,
+	                   nitems);
+	hipLaunchKernelGGL(ivf_group_scatter_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, (const long long *)d_keys,
+	                   npairs, nprobe, pair_off, item_off, cursor, d_qidx, d_slots);
+	hipLaunchKernelGGL(ivf_group_items_kernel, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, st, cnt, pair_off,
+	                   item_off, (const long long *)d_list_off, (int)nlist, (int4 *)d_items);
+	MVS_HIP(hipGetLastError());
+	*d_nitems_out = nitems;
+	*d_cnt_out = cnt;
+}
 
 void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows, int64_t nrows, const int64_t *d_rowids,
                      int64_t k, const void *d_items, int nitems, const int *d_qidx, SelectorDev sel,
-                     const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st) {
+                     const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, float *d_xi,
+                     const int *d_nitems, hipStream_t st) {
 	if (nitems <= 0)
 		return;
+	hipLaunchKernelGGL(ivf_pack_item_queries_kernel, dim3(nitems), dim3(256), 0, st, d_xq, d_qidx, (const int4 *)d_items,
+	                   d_nitems, dp, d_xi);
+	MVS_HIP(hipGetLastError());
 	ScanArgs a;
 	a.xq = d_xq;
+	a.xi = d_xi;
 	a.rows = d_rows;
 	a.pd = d_pd;
 	a.pi = d_pi;
@@ -373,6 +514,7 @@ void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows,
 	a.sel = sel;
 	a.idmap = (const long long *)d_idmap;
 	a.items = (const int4 *)d_items;
+	a.nitems_dev = d_nitems;
 	a.qidx = d_qidx;
 	a.rowids = (const long long *)d_rowids;
 	a.gslot = d_gslot;
