@@ -129,6 +129,10 @@ void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows,
                      int64_t k, const void *d_items, int nitems, const int *d_qidx, SelectorDev sel,
                      const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, float *d_xi,
                      const int *d_nitems /* device item count, grid = upper bound; may be null */, hipStream_t st);
+// Flat per-pair path on the same kernel (regular grid over row splits x groups of 20 queries); partials [nsplit][nq][k]
+void launch_pair_scan(int dp, bool interleaved, int metric, const float *d_xq, int64_t nq, const float *d_rows,
+                      int64_t nrows, int64_t k, int nsplit, int64_t split_rows, SelectorDev sel, const int64_t *d_idmap,
+                      float *d_pd, int32_t *d_pi, unsigned *d_gslot, float *d_xi, hipStream_t st);
 // device-side construction of the work items from the coarse-search labels (no host round trip)
 int ivf_group_max_items(int64_t npairs, int64_t nlist);
 size_t ivf_group_ws_ints(int64_t nlist);

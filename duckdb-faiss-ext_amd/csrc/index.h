@@ -134,6 +134,7 @@ public:
 	float *norms = nullptr; // [cap]
 	int64_t cap = 0;
 	bool force_direct = false; // test hook: per-pair kernel for any nq
+	bool force_staged = false; // test hook: LDS-staged flat_direct kernel instead of the packed scan kernel
 
 	FlatIndex(int d, int metric);
 	~FlatIndex() override;
@@ -153,7 +154,7 @@ public:
 	                 const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
 
 private:
-	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add;
+	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi;
 	SelectorHolder selector;
 	hipStream_t last_search_stream = nullptr;
 	void grow(int64_t need, hipStream_t st);

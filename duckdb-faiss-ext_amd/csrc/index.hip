@@ -378,6 +378,40 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		// BLAS-branch value when FAISS would have used sgemm (nq >= 20, no selector) but k is too large for
 		// the fused kernel's LDS lists
 		const bool formula = metric == METRIC_L2 && !has_sel && nq >= 20;
+		if (!formula && !force_staged && ivf_scan_supported(geom.dp, k)) {
+			// per-pair arithmetic (exhaustive_L2sqr_seq / exhaustive_inner_product_seq): packed-fp32 scan kernel of
+			// csrc/ivf_scan.hip in grid mode
+			const int ngroups = (int)((nq + 19) / 20);
+			const int64_t ntiles = (ntotal + 255) / 256;
+			int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(4096 / ngroups, ntiles / 4));
+			while (nsplit > 1 && (size_t)(nsplit + 1) * k * 8 > 150 * 1024) // the merge kernel keeps nsplit*k candidates in LDS
+				nsplit /= 2;
+			const int64_t split_rows = (ntiles + nsplit - 1) / nsplit * 256;
+			nsplit = (ntotal + split_rows - 1) / split_rows;
+			ws_q.reserve((size_t)nq * geom.dp * sizeof(float));
+			launch_pad_rows(d_x, nq, d, (float *)ws_q.p, geom.dp, st);
+			ws_pd.reserve((size_t)nsplit * nq * k * sizeof(float));
+			ws_pi.reserve((size_t)nsplit * nq * k * sizeof(int32_t));
+			ws_xi.reserve(ivf_scan_query_pack_bytes(geom.dp, ngroups));
+			SelectorDev sel = selector.upload(params, st);
+			begin_kernel_timing(st);
+			ws_gthr.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+			launch_init_slots((unsigned *)ws_gthr.p, nq, k, metric, st);
+			launch_pair_scan(geom.dp, geom.pair_interleaved, metric, (const float *)ws_q.p, nq, vecs, ntotal, k, (int)nsplit,
+			                 split_rows, sel, d_idmap, (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p,
+			                 (float *)ws_xi.p, st);
+			end_kernel_timing(st);
+			launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (int)nsplit, nq, k, d_idmap,
+			                      label_offset, d_D, d_I, st);
+			snprintf(kinfo.name, sizeof kinfo.name, "flat_pair_scan (ivf_scan_kernel)");
+			kinfo.flops = 2.0 * (double)nq * (double)ntotal * d * (metric == METRIC_L2 ? 1.5 : 1.0);
+			kinfo.bytes = (double)ngroups * (double)ntotal * geom.dp * 4.0;
+			kinfo.grid = (int)(nsplit * ngroups);
+			kinfo.block = 256;
+			kinfo.lds_bytes = (int)ivf_scan_lds_bytes(k);
+			kinfo.nsplit = (int)nsplit;
+			return;
+		}
 		DirectPlan p = plan_flat_direct(geom, nq, ntotal, k);
 		const int64_t nq_pad = (nq + p.qgroup - 1) / p.qgroup * p.qgroup;
 		ws_q.reserve((size_t)nq_pad * geom.dp * sizeof(float));
@@ -1042,6 +1076,10 @@ int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value) {
 
 namespace mvs {
 bool FlatIndex::set_option(const char *key, int64_t v) {
+	if (!strcmp(key, "force_staged")) { // per-pair path on the LDS-staged flat_direct kernel instead of the scan kernel
+		force_staged = v != 0;
+		return true;
+	}
 	if (!strcmp(key, "force_direct")) {
 		force_direct = v != 0;
 		return true;

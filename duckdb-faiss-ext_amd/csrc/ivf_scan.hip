@@ -48,6 +48,10 @@ struct ScanArgs {
 	const long long *rowids; // stored id of every row
 	unsigned *gslot;         // [nq][slot_stride] shared threshold classes
 	int slot_stride;
+	// grid mode (items == null): the Flat per-pair path.  Block b = (row split b / ngroups, query group b % ngroups);
+	// partial lists [nsplit][nq][k]; rows may be pair-interleaved (FlatGeom::pair_interleaved)
+	int ngroups, nq;
+	long long split_rows;
 };
 
 __device__ __forceinline__ bool sel_member_scan(const SelectorDev &s, long long id) {
@@ -98,7 +102,7 @@ __device__ __forceinline__ void wave_sync() {
 	__builtin_amdgcn_wave_barrier();
 }
 
-template <bool IS_L2>
+template <bool IS_L2, bool INTERLEAVED>
 __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	if (a.nitems_dev && (int)blockIdx.x >= *a.nitems_dev)
@@ -113,10 +117,23 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 	int *qn_s = (int *)(gb + 4 * SQG);      // [SQG] query numbers (for lane-indexed access)
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int4 it = a.items[blockIdx.x];
-	const long long r_begin = it.x;
-	long long r_end = it.y;
-	const int qbase = it.z, nq_item = it.w;
+	long long r_begin, r_end;
+	int qbase, nq_item, split = 0, xblock;
+	if (a.items) {
+		const int4 it = a.items[blockIdx.x];
+		r_begin = it.x;
+		r_end = it.y;
+		qbase = it.z;
+		nq_item = it.w;
+		xblock = blockIdx.x;
+	} else {
+		split = blockIdx.x / a.ngroups;
+		xblock = blockIdx.x - split * a.ngroups;
+		r_begin = (long long)split * a.split_rows;
+		r_end = r_begin + a.split_rows;
+		qbase = xblock * SQG;
+		nq_item = a.nq - qbase < SQG ? a.nq - qbase : SQG;
+	}
 	if (r_end > a.n)
 		r_end = a.n;
 	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
@@ -125,9 +142,10 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 	int qn[SQG];
 #pragma unroll
 	for (int qq = 0; qq < SQG; ++qq)
-		qn[qq] = __builtin_amdgcn_readfirstlane(a.qidx[qbase + (qq < nq_item ? qq : 0)]);
+		qn[qq] = a.qidx ? __builtin_amdgcn_readfirstlane(a.qidx[qbase + (qq < nq_item ? qq : 0)])
+		                : qbase + (qq < nq_item ? qq : 0);
 	if (tid < SQG)
-		qn_s[tid] = a.qidx[qbase + (tid < nq_item ? tid : 0)];
+		qn_s[tid] = a.qidx ? a.qidx[qbase + (tid < nq_item ? tid : 0)] : qbase + (tid < nq_item ? tid : 0);
 	for (int i = lane; i < SQG * k; i += 64) {
 		lv[wave * SQG * k + i] = neutral;
 		lid[wave * SQG * k + i] = -1;
@@ -207,15 +225,29 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 #pragma unroll
 		for (int p = 0; p < SQG / 2; ++p)
 			acc2[p] = (f32x2) {0.f, 0.f};
-		const float *xitem = a.xi + (size_t)blockIdx.x * (SQG / 2) * nchunk * 32;
+		const float *xitem = a.xi + (size_t)xblock * (SQG / 2) * nchunk * 32;
+		const bool hi16 = (row >> 4) & 1; // pair-interleaved storage: [k0,k2,k1,k3] / [k1,k3,k0,k2] by bit 4 of the row
 		for (int c = 0; c < nchunk; ++c) {
 			float4 yn[4];
 			const int cn = c + 1 < nchunk ? c + 1 : c;
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
 				yn[i] = yp[cn * 4 + i];
-			const float y[16] = {yc[0].x, yc[0].y, yc[0].z, yc[0].w, yc[1].x, yc[1].y, yc[1].z, yc[1].w,
-			                     yc[2].x, yc[2].y, yc[2].z, yc[2].w, yc[3].x, yc[3].y, yc[3].z, yc[3].w};
+			float y[16];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				if (INTERLEAVED) { // back to natural k order, once per 16 values (amortised over the 20 chains)
+					y[4 * i + 0] = hi16 ? yc[i].z : yc[i].x;
+					y[4 * i + 1] = hi16 ? yc[i].x : yc[i].z;
+					y[4 * i + 2] = hi16 ? yc[i].w : yc[i].y;
+					y[4 * i + 3] = hi16 ? yc[i].y : yc[i].w;
+				} else {
+					y[4 * i + 0] = yc[i].x;
+					y[4 * i + 1] = yc[i].y;
+					y[4 * i + 2] = yc[i].z;
+					y[4 * i + 3] = yc[i].w;
+				}
+			}
 			// one basic block per slot pair: 2 x s_load_dwordx16 (16 dimensions x 2 slots), then per dimension one
 			// v_pk_add_f32 + one v_pk_fma_f32 (L2) / one v_pk_fma_f32 (IP).  The scalar-load latency is covered by
 			// the other waves of the SIMD.
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 	// ---- merge the 4 per-wave lists: ONE partial list per (item, query slot), [item][SQG][k]
 	__syncthreads();
 	for (int qq = wave; qq < nq_item; qq += 4) {
-		const size_t base = ((size_t)blockIdx.x * SQG + qq) * k;
+		const size_t base = a.items ? ((size_t)blockIdx.x * SQG + qq) * k : ((size_t)split * a.nq + (qbase + qq)) * k;
 		for (int r = 0; r < k; ++r) {
 			float bv = 0.f;
 			int bi = 0x7fffffff, bp = -1;
@@ -364,10 +396,16 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 
 // xi[item][p][c][h][kk][j] = xq[qidx[qoff + 2p + j]][16c + 8h + kk]   (0 for unused slots)
 __global__ void ivf_pack_item_queries_kernel(const float *xq, const int *qidx, const int4 *items, const int *nitems_dev,
-                                             int dp, float *xi) {
+                                             int dp, int nq, float *xi) {
 	if (nitems_dev && (int)blockIdx.x >= *nitems_dev)
 		return;
-	const int4 it = items[blockIdx.x];
+	int4 it;
+	if (items) {
+		it = items[blockIdx.x];
+	} else { // grid mode: block = query group, slots = consecutive queries; nitems_dev is unused, it.w from nq
+		it.z = blockIdx.x * SQG;
+		it.w = nq - it.z < SQG ? nq - it.z : SQG;
+	}
 	const int nchunk = dp / 16;
 	const int total = (SQG / 2) * nchunk * 32;
 	float *dst = xi + (size_t)blockIdx.x * total;
@@ -377,7 +415,7 @@ __global__ void ivf_pack_item_queries_kernel(const float *xq, const int *qidx, c
 		const int slot = 2 * p + j;
 		float v = 0.f;
 		if (slot < it.w)
-			v = xq[(size_t)qidx[it.z + slot] * dp + c * 16 + h * 8 + kk];
+			v = xq[(size_t)(qidx ? qidx[it.z + slot] : it.z + slot) * dp + c * 16 + h * 8 + kk];
 		dst[e] = v;
 	}
 }
@@ -463,6 +501,29 @@ bool ivf_scan_supported(int dp, int64_t k) {
 size_t ivf_scan_lds_bytes(int64_t k) {
 	return scan_lds_bytes(k);
 }
+static void launch_scan_kernel(int metric, bool interleaved, const ScanArgs &a, int grid, int64_t k, hipStream_t st) {
+	const size_t lds = scan_lds_bytes(k);
+#define MVS_SCAN(L2, IL)                                                                                               \
+	{                                                                                                                  \
+		auto kern = ivf_scan_kernel<L2, IL>;                                                                           \
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
+	}
+	if (metric == METRIC_IP) {
+		if (interleaved)
+			MVS_SCAN(false, true)
+		else
+			MVS_SCAN(false, false)
+	} else {
+		if (interleaved)
+			MVS_SCAN(true, true)
+		else
+			MVS_SCAN(true, false)
+	}
+#undef MVS_SCAN
+	MVS_HIP(hipGetLastError());
+}
+
 size_t ivf_scan_query_pack_bytes(int dp, int nitems) {
 	return (size_t)nitems * SQG * dp * sizeof(float);
 }
@@ -500,7 +561,7 @@ void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows,
 	if (nitems <= 0)
 		return;
 	hipLaunchKernelGGL(ivf_pack_item_queries_kernel, dim3(nitems), dim3(256), 0, st, d_xq, d_qidx, (const int4 *)d_items,
-	                   d_nitems, dp, d_xi);
+	                   d_nitems, dp, 0, d_xi);
 	MVS_HIP(hipGetLastError());
 	ScanArgs a;
 	a.xq = d_xq;
@@ -519,17 +580,44 @@ void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows,
 	a.rowids = (const long long *)d_rowids;
 	a.gslot = d_gslot;
 	a.slot_stride = d_gslot ? (int)((k + 15) / 16 * 16) : 0;
-	const size_t lds = scan_lds_bytes(k);
-	if (metric == METRIC_IP) {
-		MVS_HIP(hipFuncSetAttribute((const void *)ivf_scan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-		                            (int)lds));
-		hipLaunchKernelGGL(ivf_scan_kernel<false>, dim3(nitems), dim3(256), lds, st, a);
-	} else {
-		MVS_HIP(hipFuncSetAttribute((const void *)ivf_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-		                            (int)lds));
-		hipLaunchKernelGGL(ivf_scan_kernel<true>, dim3(nitems), dim3(256), lds, st, a);
-	}
+	a.ngroups = 0;
+	a.nq = 0;
+	a.split_rows = 0;
+	launch_scan_kernel(metric, false, a, nitems, k, st);
+}
+
+// Flat per-pair path (nq < 20 or a selector; IndexFlat::search -> exhaustive_*_seq): regular grid over
+// (row split, group of 20 queries).  d_xi: ceil(nq/20) packed query groups.
+void launch_pair_scan(int dp, bool interleaved, int metric, const float *d_xq, int64_t nq, const float *d_rows,
+                      int64_t nrows, int64_t k, int nsplit, int64_t split_rows, SelectorDev sel, const int64_t *d_idmap,
+                      float *d_pd, int32_t *d_pi, unsigned *d_gslot, float *d_xi, hipStream_t st) {
+	if (nq <= 0 || nrows <= 0)
+		return;
+	const int ngroups = (int)((nq + SQG - 1) / SQG);
+	hipLaunchKernelGGL(ivf_pack_item_queries_kernel, dim3(ngroups), dim3(256), 0, st, d_xq, (const int *)nullptr,
+	                   (const int4 *)nullptr, (const int *)nullptr, dp, (int)nq, d_xi);
 	MVS_HIP(hipGetLastError());
+	ScanArgs a;
+	a.xq = d_xq;
+	a.xi = d_xi;
+	a.rows = d_rows;
+	a.pd = d_pd;
+	a.pi = d_pi;
+	a.n = nrows;
+	a.k = (int)k;
+	a.dp = dp;
+	a.sel = sel;
+	a.idmap = (const long long *)d_idmap;
+	a.items = nullptr;
+	a.nitems_dev = nullptr;
+	a.qidx = nullptr;
+	a.rowids = nullptr;
+	a.gslot = d_gslot;
+	a.slot_stride = d_gslot ? (int)((k + 15) / 16 * 16) : 0;
+	a.ngroups = ngroups;
+	a.nq = (int)nq;
+	a.split_rows = split_rows;
+	launch_scan_kernel(metric, interleaved, a, nsplit * ngroups, k, st);
 }
 
 } // namespace mvs

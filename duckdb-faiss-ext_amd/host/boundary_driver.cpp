@@ -19,6 +19,7 @@
 #include "faiss/gpu/GpuCloner.h"
 #include "faiss/gpu/StandardGpuResources.h"
 #include "faiss/index_factory.h"
+#include "faiss/index_io.h"
 
 #include <atomic>
 #include <cstdio>
@@ -360,6 +361,63 @@ int run_ingest(size_t n, int d, int threads) {
 	return ok == nq ? 0 : 1;
 }
 
+// README.md:61 index "IDMap,HNSW32": CreateFunction with the efConstruction parameter (:127-139), chunked faiss_add with
+// ids, faiss_search with SearchParametersHNSW (:691-702), then faiss_save / faiss_load (:188-240) and the same search
+int run_hnsw(size_t n, int d, int threads, const char *path) {
+	std::vector<float> xb(n * (size_t)d), xq(256 * (size_t)d);
+	uint64_t s = 0x2545F4914F6CDD1Dull;
+	auto next = [&]() {
+		s ^= s << 13;
+		s ^= s >> 7;
+		s ^= s << 17;
+		return (float)(s >> 40) * (1.0f / 16777216.0f);
+	};
+	for (auto &v : xb)
+		v = next();
+	for (auto &v : xq)
+		v = next();
+	std::vector<faiss::idx_t> ids(n);
+	for (size_t i = 0; i < n; ++i)
+		ids[i] = (faiss::idx_t)(500 + 3 * i);
+	auto e = create(d, "IDMap,HNSW32", faiss::METRIC_L2);
+	{ // the glue's parameter application: unwrap IDMap, dynamic_cast to IndexHNSW, set hnsw.efConstruction
+		faiss::Index *ix = e->index.get();
+		if (auto idmap = dynamic_cast<faiss::IndexIDMap *>(ix))
+			ix = idmap->index;
+		auto hnsw = dynamic_cast<faiss::IndexHNSW *>(ix);
+		if (!hnsw) {
+			printf("hnsw\tFAIL dynamic_cast<IndexHNSW*>\n");
+			return 1;
+		}
+		hnsw->hnsw.efConstruction = 64;
+	}
+	faiss_add(*e, n, xb.data(), ids.data(), threads);
+	auto exact = create(d, "IDMap,Flat", faiss::METRIC_L2);
+	faiss_add(*exact, n, xb.data(), ids.data(), 1);
+	const size_t nq = 256, k = 10;
+	auto got = faiss_search(*e, nq, xq.data(), k, nullptr, 0, 128);
+	auto want = faiss_search(*exact, nq, xq.data(), k);
+	size_t hits = 0;
+	for (size_t q = 0; q < nq; ++q)
+		for (size_t a = 0; a < k; ++a)
+			for (size_t b = 0; b < k; ++b)
+				hits += got[q * k + a].label == want[q * k + b].label;
+	const double recall = (double)hits / (double)(nq * k);
+	printf("hnsw\t%s recall@10 %.4f ntotal=%lld\n", recall >= 0.9 ? "OK" : "FAIL", recall, (long long)e->index->ntotal);
+	// SaveFunction :199 / LoadFunction :234
+	faiss::write_index(e->index.get(), path);
+	IndexEntry loaded;
+	loaded.index.reset(faiss::read_index(path));
+	auto again = faiss_search(loaded, nq, xq.data(), k, nullptr, 0, 128);
+	size_t same = 0;
+	for (size_t i = 0; i < got.size(); ++i)
+		same += got[i].label == again[i].label && got[i].distance == again[i].distance;
+	printf("hnswio\t%s %zu/%zu identical rows after write_index/read_index, d=%d ntotal=%lld trained=%d\n",
+	       same == got.size() ? "OK" : "FAIL", same, got.size(), loaded.index->d, (long long)loaded.index->ntotal,
+	       (int)loaded.index->is_trained);
+	return recall >= 0.9 && same == got.size() ? 0 : 1;
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
@@ -368,10 +426,13 @@ int main(int argc, char **argv) {
 			return run_golden(argv[2], argv[3]);
 		if (argc >= 5 && !strcmp(argv[1], "ingest"))
 			return run_ingest((size_t)atoll(argv[2]), atoi(argv[3]), atoi(argv[4]));
+		if (argc >= 6 && !strcmp(argv[1], "hnsw"))
+			return run_hnsw((size_t)atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), argv[5]);
 	} catch (const std::exception &e) {
 		fprintf(stderr, "fatal: %s\n", e.what());
 		return 3;
 	}
-	fprintf(stderr, "usage: boundary_driver golden <training.csv> <queries.csv> | ingest <n> <d> <threads>\n");
+	fprintf(stderr, "usage: boundary_driver golden <training.csv> <queries.csv> | ingest <n> <d> <threads> | "
+	                "hnsw <n> <d> <threads> <index file>\n");
 	return 2;
 }

@@ -53,3 +53,14 @@ def test_concurrent_datachunk_ingest():
     out = subprocess.run([DRIVER, "ingest", "300000", "128", "6"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ingest\tOK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_hnsw_through_the_cpp_glue_path_with_save_and_load(tmp_path):
+    """IDMap,HNSW32 driven the way the glue drives it: efConstruction through dynamic_cast<IndexHNSW*>, chunked
+    multi-threaded faiss_add with ids, SearchParametersHNSW, then write_index / read_index"""
+    out = subprocess.run([DRIVER, "hnsw", "20000", "64", "4", str(tmp_path / "h.index")], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert _rows(out.stdout, "hnsw")[0][0].startswith("OK")
+    assert _rows(out.stdout, "hnswio")[0][0].startswith("OK")

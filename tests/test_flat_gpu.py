@@ -132,17 +132,43 @@ def test_flat_matches_oracle_bit_exact(mf, metric, nb, nq, d, k):
     assert_same_results(D, I, Do, Io, metric == L2, what=f"flat m={metric} nb={nb} nq={nq} d={d} k={k}")
 
 
+@pytest.mark.parametrize("staged", [0, 1])
 @pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("nq", [1, 5, 19])
-def test_small_batches_take_the_per_pair_path(mf, metric, nq):
-    """nq < 20: FAISS computes sum((x-y)^2) directly (distance_compute_blas_threshold)"""
+def test_small_batches_take_the_per_pair_path(mf, metric, nq, staged):
+    """nq < 20: FAISS computes sum((x-y)^2) directly (distance_compute_blas_threshold).  Two kernels implement the
+    per-pair arithmetic: the packed-fp32 scan kernel (default) and the LDS-staged flat_direct kernel"""
     xb, xq = _data(7000, nq, 128, seed=nq, center=True)
     ix = mf.index_factory(128, "Flat", metric)
+    ix.set_option("force_staged", staged)
     ix.add(xb)
     D, I = ix.search(xq, 10)
     Do, Io = orc.flat_search(metric, xb, xq, 10)
     assert_same_results(D, I, Do, Io, metric == L2, what=f"pair path nq={nq}")
-    assert ix.last_kernel_info()["name"] == "flat_direct_kernel"
+    assert ix.last_kernel_info()["name"] == ("flat_direct_kernel" if staged else "flat_pair_scan (ivf_scan_kernel)")
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d", [16, 40, 100, 200])
+def test_pair_scan_dims_and_selector(mf, metric, d):
+    """per-pair scan kernel across row formats (dp = 16 / 64 / 128 pair-interleaved, 256 streaming format), ragged N,
+    with and without a selector, nq on both sides of one 20-query group"""
+    nb = 5003
+    xb, xq = _data(nb, 45, d, seed=d, center=True)
+    ix = mf.index_factory(d, "Flat", metric)
+    ix.add(xb)
+    keep = np.arange(nb)[np.arange(nb) % 3 != 1]
+    Dg, Ig = ix.search(xq, 7, sel=("batch", keep))
+    Do, Io = orc.flat_search(metric, xb, xq, 7, sel=("batch", keep))
+    assert ix.last_kernel_info()["name"].startswith("flat_pair_scan")
+    if metric == IP:
+        Dk1, _ = orc.flat_search(metric, xb, xq, 8, sel=("batch", keep))
+        ok = Dk1[:, 6] != Dk1[:, 7]
+        Dg, Ig, Do, Io = Dg[ok], Ig[ok], Do[ok], Io[ok]
+    assert_same_results(Dg, Ig, Do, Io, metric == L2, what=f"pair scan + selector d={d}")
+    D1, I1 = ix.search(xq[:3], 7)
+    Do1, Io1 = orc.flat_search(metric, xb, xq[:3], 7)
+    assert_same_results(D1, I1, Do1, Io1, metric == L2, what=f"pair scan nq=3 d={d}")
 
 
 def test_l2_blas_vs_pair_arithmetic_differ_but_both_match(mf):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--check", action="store_true", help="compare a query subsample with the oracle")
+    ap.add_argument("--sel-frac", type=float, default=0.0, help="> 0: IDSelectorBitmap keeping about this fraction of the rows")
     args = ap.parse_args()
     import torch
 
@@ -37,11 +38,17 @@ def main():
         ix.add_torch(xb)
         torch.cuda.synchronize()
     xq = mf.synth_uniform_torch(args.nq, args.d, 4321)
-    D, I = ix.search_torch(xq, args.k)
+    sel = None
+    if args.sel_frac > 0:
+        import numpy as np
+
+        rs = np.random.RandomState(7)
+        sel = ("bitmap", np.packbits(rs.rand((args.n + 7) // 8 * 8) < args.sel_frac, bitorder="little"))
+    D, I = ix.search_torch(xq, args.k, sel=sel)
     torch.cuda.synchronize()
     ix.set_kernel_timing(True)
     for _ in range(args.reps):
-        ix.search_torch(xq, args.k, D=D, I=I)
+        ix.search_torch(xq, args.k, D=D, I=I, sel=sel)
     torch.cuda.synchronize()
     n, ms = ix.kernel_time_stats()
     ki = ix.last_kernel_info()
@@ -60,7 +67,8 @@ def main():
 
         xb_h = orc.synth_uniform(args.n, args.d, 1234)
         sub = np.arange(0, args.nq, max(1, args.nq // 256))[:256]
-        Do, Io = orc.flat_search(metric, xb_h, xq[sub].cpu().numpy(), args.k, force_path=orc.PATH_BLAS if len(sub) >= 20 else orc.PATH_AUTO)
+        Do, Io = orc.flat_search(metric, xb_h, xq[sub].cpu().numpy(), args.k, sel=sel,
+                                 force_path=orc.PATH_AUTO if (sel is not None or args.nq < 20) else orc.PATH_BLAS)
         ok = np.array_equal(I.cpu().numpy()[sub], Io) and np.array_equal(D.cpu().numpy()[sub], Do)
         print("check vs oracle (", len(sub), "queries ):", "BIT-EXACT" if ok else "MISMATCH")
 
