@@ -378,7 +378,9 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		// BLAS-branch value when FAISS would have used sgemm (nq >= 20, no selector) but k is too large for
 		// the fused kernel's LDS lists
 		const bool formula = metric == METRIC_L2 && !has_sel && nq >= 20;
-		if (!formula && !force_staged && ivf_scan_supported(geom.dp, k)) {
+		// 1-4 queries are pure streaming: the LDS-staged kernel (coalesced tiles, 1 or 4 chains per thread) reaches
+		// 3.2 TB/s there, the thread-per-row scan 1.6; from ~8 queries on the packed scan wins (3x at nq = 2000)
+		if (!formula && !force_staged && nq > 4 && ivf_scan_supported(geom.dp, k)) {
 			// per-pair arithmetic (exhaustive_L2sqr_seq / exhaustive_inner_product_seq): packed-fp32 scan kernel of
 			// csrc/ivf_scan.hip in grid mode
 			const int ngroups = (int)((nq + 19) / 20);

@@ -52,6 +52,10 @@ struct ScanArgs {
 	// partial lists [nsplit][nq][k]; rows may be pair-interleaved (FlatGeom::pair_interleaved)
 	int ngroups, nq;
 	long long split_rows;
+	// tiles between two refreshes of the shared bounds: every workgroup that scans for the same queries reads (and
+	// publishes to) the same few cache lines, and with ~1000 row splits of ONE query group those agent-scope
+	// accesses serialise in L2 (nq = 16, N = 10M: 6.6 ms with a refresh per tile)
+	int refresh_every;
 };
 
 __device__ __forceinline__ bool sel_member_scan(const SelectorDev &s, long long id) {
@@ -160,13 +164,12 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 
 	// gb[qq] = max over the k class slots of the query: a valid bound on its final k-th value (flat_mfma.hip
 	// "threshold sharing").  All loads of a pass are issued before any is consumed.
-	auto refresh_bounds = [&]() {
-		const unsigned nk = s_bkey<IS_L2>(neutral);
-		if (!a.gslot) {
-			if (lane < SQG)
-				gb[lane] = neutral;
-		} else if (a.slot_stride == 16) {
-			unsigned m[SQG / 4];
+	// The loads are issued at the top of a tile and consumed right before its k-best update, so their (agent-scope,
+	// L2-miss) latency hides behind the tile's distance chains.  Slot rows wider than 16 classes take the slow loop.
+	const bool fast_slots = a.gslot && a.slot_stride == 16;
+	unsigned m[SQG / 4];
+	auto refresh_issue = [&]() {
+		if (fast_slots) {
 #pragma unroll
 			for (int p = 0; p < SQG / 4; ++p) { // 4 queries x 16 classes per pass
 				const int qq = p * 4 + (lane >> 4);
@@ -174,6 +177,14 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 				                                        __HIP_MEMORY_SCOPE_AGENT)
 				                    : 0u;
 			}
+		}
+	};
+	auto refresh_finish = [&]() {
+		const unsigned nk = s_bkey<IS_L2>(neutral);
+		if (!a.gslot) {
+			if (lane < SQG)
+				gb[lane] = neutral;
+		} else if (fast_slots) {
 #pragma unroll
 			for (int p = 0; p < SQG / 4; ++p) {
 				unsigned x = m[p];
@@ -220,7 +231,9 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
 			yc[i] = yp[i];
-		refresh_bounds();
+		const bool refresh = tile % a.refresh_every == 0;
+		if (refresh)
+			refresh_issue();
 		f32x2 acc2[SQG / 2];
 #pragma unroll
 		for (int p = 0; p < SQG / 2; ++p)
@@ -283,6 +296,8 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const ScanArgs a) {
 			acc[qq] = (qq & 1) ? acc2[qq / 2].y : acc2[qq / 2].x;
 
 		// ---- k-best update of the tile
+		if (refresh)
+			refresh_finish();
 		bool valid = row < r_end;
 		if (valid && a.sel.kind != MVS_SEL_NONE) {
 			const long long lab = a.rowids ? a.rowids[row] : row;
@@ -583,6 +598,7 @@ void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows,
 	a.ngroups = 0;
 	a.nq = 0;
 	a.split_rows = 0;
+	a.refresh_every = 1;
 	launch_scan_kernel(metric, false, a, nitems, k, st);
 }
 
@@ -617,6 +633,7 @@ void launch_pair_scan(int dp, bool interleaved, int metric, const float *d_xq, i
 	a.ngroups = ngroups;
 	a.nq = (int)nq;
 	a.split_rows = split_rows;
+	a.refresh_every = nsplit >= 64 ? nsplit / 32 : 1;
 	launch_scan_kernel(metric, interleaved, a, nsplit * ngroups, k, st);
 }
 
