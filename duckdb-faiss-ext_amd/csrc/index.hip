@@ -507,6 +507,9 @@ void FlatIndex::to_device(int new_device) {
 	ws_qn.release();
 	ws_pd.release();
 	ws_pi.release();
+	ws_xi.release();
+	ws_gthr.release();
+	ws_add.release();
 	ws_hx.release();
 	ws_hD.release();
 	ws_hI.release();

@@ -58,6 +58,25 @@ def test_deterministic_build_reproduces_oracle_graph(mf, metric, d, M, n):
     _assert_same_graph(o, g)
 
 
+def test_harness_shape_hnsw128_d1536(mf):
+    """the Go harness index (go/benches_c.go:59): IDMap,HNSW128,Flat, d=1536, default metric inner product -- level-0
+    lists of 256 slots (4 lane chunks), 6 float4 per lane per row"""
+    d, n = 1536, 700
+    xb = orc.synth_clustered(n, d, 40, n_centers=16, sigma=0.5)
+    xq = orc.synth_clustered(20, d, 41, n_centers=16, sigma=0.5)
+    ids = np.arange(n, dtype=np.int64) + 10**6
+    o = orc.Index(d, "IDMap,HNSW128,Flat", IP)
+    g = mf.index_factory(d, "IDMap,HNSW128,Flat", IP)
+    g.set_option("hnsw_build_waves", 1)
+    o.add_with_ids(xb, ids)
+    g.add_with_ids(xb, ids)
+    _assert_same_graph(o, g)
+    for k, efs in ((11, 16), (200, 64)):  # the harness sweeps k far beyond efSearch
+        Do, Io = o.search(xq, k, efSearch=efs)
+        Dg, Ig = g.search(xq, k, efSearch=efs)
+        assert np.array_equal(Ig, Io) and np.array_equal(Dg.view(np.uint32), Do.view(np.uint32))
+
+
 def test_incremental_adds_like_duckdb_chunks(mf):
     """the glue adds <= 2048 rows per call (src/faiss_extension.cpp:510-512): levels and graph continue across calls"""
     xb = orc.synth_clustered(5000, 48, 22, n_centers=32, sigma=0.2)
