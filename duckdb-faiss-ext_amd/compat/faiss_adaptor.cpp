@@ -57,8 +57,12 @@ void fill_params(const Index *, const SearchParameters *params, mvs_search_param
 	memset(out, 0, sizeof *out);
 	if (!params)
 		return;
-	if (auto ivf = dynamic_cast<const SearchParametersIVF *>(params))
+	if (auto ivf = dynamic_cast<const SearchParametersIVF *>(params)) {
 		out->nprobe = (int64_t)ivf->nprobe;
+		// IVF<n>_HNSW<m>: the glue hangs the coarse quantizer's SearchParametersHNSW here (:679-681)
+		if (auto qh = dynamic_cast<const SearchParametersHNSW *>(ivf->quantizer_params))
+			out->efSearch = qh->efSearch;
+	}
 	if (auto hnsw = dynamic_cast<const SearchParametersHNSW *>(params))
 		out->efSearch = hnsw->efSearch;
 	if (params->sel) {

@@ -61,16 +61,24 @@ void renorm_l2(int d, int64_t n, float *x) {
 
 class IVFFlatIndex : public IndexBase {
 public:
-	FlatIndex *quantizer; // owned; nlist centroids, same metric (IndexFlat(d, metric))
+	// owned; nlist centroids.  IndexFlat(d, metric) for "IVF<n>,Flat"; IndexHNSWFlat(d, M, metric) for
+	// "IVF<n>_HNSW<M>,Flat" (reference Makefile:93), in which case k-means assigns with a temporary IndexFlatL2 and
+	// the final centroids are inserted into the graph (index_factory: quantizer_trains_alone = 2)
+	IndexBase *quantizer;
 	int64_t nlist;
+	int hnsw_M; // 0 = flat quantizer
 	int64_t nprobe = 1;
 	bool spherical;
 	int dp; // padded row length of the list store (plain row-major)
 
-	IVFFlatIndex(int d_, int64_t nlist_, int metric_) : IndexBase(MVS_KIND_IVFFLAT, d_, metric_), nlist(nlist_) {
+	IVFFlatIndex(int d_, int64_t nlist_, int metric_, int hnsw_M_ = 0)
+	    : IndexBase(MVS_KIND_IVFFLAT, d_, metric_), nlist(nlist_), hnsw_M(hnsw_M_) {
 		if (metric != METRIC_L2 && metric != METRIC_IP)
 			throw_faiss("mvs::IVFFlatIndex", __FILE__, "metric type %d is not implemented on the MI355X path", metric);
-		quantizer = new FlatIndex(d, metric);
+		if (hnsw_M > 0)
+			quantizer = make_hnsw_index(d, "HNSW" + std::to_string(hnsw_M), metric);
+		else
+			quantizer = new FlatIndex(d, metric);
 		is_trained = false;
 		spherical = metric == METRIC_IP; // IndexIVF ctor: "Spherical by default if the metric is inner_product"
 		dp = d <= 8 ? 8 : (d <= 16 ? 16 : (d + 31) / 32 * 32);
@@ -91,11 +99,20 @@ public:
 			is_trained = true;
 			return;
 		}
-		kmeans(n, x);
+		if (hnsw_M > 0) {
+			// Level1Quantizer::train_q1, quantizer_trains_alone == 2: k-means on an IndexFlatL2, centroids -> quantizer
+			FlatIndex assigner(d, METRIC_L2);
+			kmeans(n, x, &assigner);
+			std::vector<float> cent((size_t)nlist * d);
+			assigner.copy_rows_to_host(cent.data());
+			quantizer->add(nlist, cent.data());
+		} else {
+			kmeans(n, x, static_cast<FlatIndex *>(quantizer));
+		}
 		is_trained = true;
 	}
 
-	void kmeans(int64_t nx, const float *x_in) {
+	void kmeans(int64_t nx, const float *x_in, FlatIndex *qz) {
 		const int niter = 25, max_pts = 256, min_pts = 39;
 		const int64_t seed = 1234, k = nlist;
 		if (nx < k)
@@ -124,8 +141,8 @@ public:
 		std::vector<float> cent((size_t)k * d);
 		if (nx == k) {
 			memcpy(cent.data(), x, cent.size() * sizeof(float));
-			quantizer->reset();
-			quantizer->add(k, cent.data());
+			qz->reset();
+			qz->add(k, cent.data());
 			return;
 		}
 		{
@@ -135,8 +152,8 @@ public:
 		}
 		if (spherical)
 			renorm_l2(d, k, cent.data());
-		quantizer->reset();
-		quantizer->add(k, cent.data());
+		qz->reset();
+		qz->add(k, cent.data());
 
 		// the training sample lives on device for the 25 assignment passes
 		DevBuf dx, dD, dI;
@@ -148,7 +165,7 @@ public:
 		std::vector<float> hassign((size_t)k);
 		const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 		for (int it = 0; it < niter; it++) {
-			quantizer->search_device(nx, (const float *)dx.p, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
+			qz->search_device(nx, (const float *)dx.p, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
 			MVS_HIP(hipMemcpyAsync(assign.data(), dI.p, (size_t)nx * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 			MVS_HIP(hipStreamSynchronize(stream));
 			// compute_centroids: each thread owns a range of centroids and walks ALL points in input order
@@ -209,8 +226,8 @@ public:
 			}
 			if (spherical)
 				renorm_l2(d, k, cent.data());
-			quantizer->reset();
-			quantizer->add(k, cent.data());
+			qz->reset();
+			qz->add(k, cent.data());
 		}
 	}
 
@@ -354,7 +371,10 @@ public:
 		// 1. coarse quantisation on the whole batch (FAISS slices the batch by OpenMP thread; see oracle ivf_search)
 		ws_cD.reserve((size_t)nq * np * sizeof(float));
 		ws_cI.reserve((size_t)nq * np * sizeof(int64_t));
-		quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, nullptr, stream);
+		mvs_search_params qp;
+		memset(&qp, 0, sizeof qp);
+		qp.efSearch = params ? params->efSearch : 0; // quantizer_params of an HNSW coarse quantizer (:679-681)
+		quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, hnsw_M > 0 ? &qp : nullptr, stream);
 		const bool fast_scan = use_fast_scan && ivf_scan_supported(dp, k) && nq * np < (int64_t)1 << 26;
 		if (fast_scan)
 			device_grouped_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
@@ -587,7 +607,10 @@ public:
 	// introspection for parity tests
 	void get_centroids(float *out) {
 		use_device();
-		quantizer->copy_rows_to_host(out);
+		HostIndex h;
+		quantizer->to_host(h);
+		const std::vector<float> &rows = h.kind == MVS_KIND_FLAT ? h.rows : h.sub->rows;
+		memcpy(out, rows.data(), rows.size() * sizeof(float));
 	}
 
 private:
@@ -612,21 +635,35 @@ IndexBase *make_ivf_index(int d, const std::string &desc, int metric) {
 		return nullptr;
 	if (!strcmp(end, ",Flat"))
 		return new IVFFlatIndex(d, nlist, metric);
-	// "IVF<n>_HNSW<m>,Flat" (reference Makefile:93) needs the HNSW coarse quantiser
+	if (!strncmp(end, "_HNSW", 5)) { // "IVF<n>_HNSW<m>,Flat" (reference Makefile:93): HNSW coarse quantizer, M default 32
+		char *end2 = nullptr;
+		long M = strtol(end + 5, &end2, 10);
+		if (end2 == end + 5)
+			M = 32;
+		if (!strcmp(end2, ",Flat") && M > 1)
+			return new IVFFlatIndex(d, nlist, metric, (int)M);
+	}
 	throw_faiss("faiss::Index* faiss::index_factory(int, const char*, faiss::MetricType)", "faiss/index_factory.cpp",
 	            "This index type is not implemented on the MI355X path yet: %s", desc.c_str());
 }
 IndexBase *ivf_from_host(const HostIndex &h, int device) {
 	CtorDevice scope(device);
-	if (!h.sub || h.sub->kind != MVS_KIND_FLAT)
+	if (!h.sub || (h.sub->kind != MVS_KIND_FLAT && h.sub->kind != MVS_KIND_HNSW))
 		throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
-		            "only a Flat coarse quantizer is implemented on the MI355X path");
+		            "only Flat and HNSWFlat coarse quantizers are implemented on the MI355X path");
+	const bool hq = h.sub->kind == MVS_KIND_HNSW;
+	if (hq && (h.sub->cum_nneighbor_per_level.size() < 2))
+		throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp", "bad HNSW level table");
 	if ((int64_t)h.list_ids.size() != h.nlist || (int64_t)h.list_codes.size() != h.nlist)
 		throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp", "inverted lists do not match nlist");
-	auto *v = new IVFFlatIndex(h.d, h.nlist, h.metric);
+	auto *v = new IVFFlatIndex(h.d, h.nlist, h.metric, hq ? h.sub->cum_nneighbor_per_level[1] / 2 : 0);
 	try {
 		v->nprobe = h.nprobe;
-		if (h.sub->ntotal > 0)
+		if (hq) { // adopt the stored graph instead of rebuilding it
+			IndexBase *q = hnsw_from_host(*h.sub, device);
+			delete v->quantizer;
+			v->quantizer = q;
+		} else if (h.sub->ntotal > 0)
 			v->quantizer->add(h.sub->ntotal, h.sub->rows.data());
 		v->is_trained = h.is_trained;
 		v->adopt_lists(h);
@@ -654,7 +691,12 @@ bool ivf_set_centroids(IndexBase *ix, const float *c) {
 	if (ix->kind != MVS_KIND_IVFFLAT)
 		return false;
 	auto *v = static_cast<IVFFlatIndex *>(ix);
-	v->quantizer->reset();
+	if (v->hnsw_M > 0) {
+		if (v->quantizer->ntotal != 0)
+			throw_faiss("mvs_index_ivf_set_centroids", __FILE__, "the HNSW coarse quantizer already holds centroids");
+	} else {
+		static_cast<FlatIndex *>(v->quantizer)->reset();
+	}
 	v->quantizer->add(v->nlist, c);
 	v->is_trained = true;
 	return true;

@@ -57,7 +57,8 @@ typedef struct mvs_index mvs_index;
  * innerCreateSearchParameters (src/faiss_extension.cpp:668-721).  Zero = FAISS default. */
 typedef struct mvs_search_params {
 	int64_t nprobe;       /* SearchParametersIVF::nprobe   (:683-686), default 1  */
-	int64_t efSearch;     /* SearchParametersHNSW::efSearch (:696-699), default 16 */
+	int64_t efSearch;     /* SearchParametersHNSW::efSearch (:696-699), default 16; for IVF<n>_HNSW<m> the efSearch of
+	                         the coarse quantizer's SearchParametersHNSW (quantizer_params, :679-681) */
 	int32_t sel_kind;     /* MVS_SEL_*; SearchParameters::sel (:678,:694,:719)     */
 	int32_t reserved;
 	const void *sel_data; /* bitmap bytes | int64 ids; HOST memory owned by the caller */

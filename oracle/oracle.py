@@ -202,13 +202,17 @@ class Index:
     def hnsw_set_ef_construction(self, v):
         _check(lib().orc_hnsw_set_ef_construction_ix(self._h, int(v)))
 
-    def hnsw_graph(self):
+    def quantizer_hnsw_graph(self):
+        """graph of the HNSW coarse quantizer of an "IVF<n>_HNSW<m>,Flat" index"""
+        return self.hnsw_graph(n=self.nlist)
+
+    def hnsw_graph(self, n=None):
         """-> dict(levels[n], offsets[n+1], neighbors[...], max_level, entry_point)"""
         ml, ep = C.c_int(0), C.c_int32(0)
         nb = lib().orc_hnsw_graph_size(self._h, C.byref(ml), C.byref(ep))
         if nb < 0:
             raise OracleError("not an HNSW index")
-        n = self.ntotal
+        n = self.ntotal if n is None else n
         levels = np.empty(n, dtype=np.int32)
         offsets = np.empty(n + 1, dtype=np.int64)
         neighbors = np.empty(nb, dtype=np.int32)

@@ -598,6 +598,13 @@ static orc_index *factory_rec(int d, const char *desc, int metric, const char *f
 	if (!strncmp(desc, "IVF", 3)) {
 		char *end;
 		long nlist = strtol(desc + 3, &end, 10);
+		int hnsw_M = 0;
+		if (end != desc + 3 && !strncmp(end, "_HNSW", 5)) { /* "IVF<n>_HNSW<m>,Flat": HNSW coarse quantizer, M default 32 */
+			char *end2;
+			long m = strtol(end + 5, &end2, 10);
+			hnsw_M = end2 == end + 5 ? 32 : (int)m;
+			end = end2;
+		}
 		if (end != desc + 3 && nlist > 0 && !strcmp(end, ",Flat")) {
 			orc_index *ix = (orc_index *)calloc(1, sizeof *ix);
 			ix->type = IX_IVFFLAT;
@@ -606,6 +613,10 @@ static orc_index *factory_rec(int d, const char *desc, int metric, const char *f
 			ix->nlist = nlist;
 			ix->nprobe = 1;
 			ix->quantizer = new_flat(d, metric); /* IndexFlat(d, metric) coarse quantizer */
+			if (hnsw_M > 1) {                    /* IndexHNSWFlat(d, M, metric) */
+				ix->quantizer->type = IX_HNSW;
+				ix->quantizer->hnsw = orc_hnsw_new(hnsw_M);
+			}
 			ix->lists = (invlist_t *)calloc((size_t)nlist, sizeof(invlist_t));
 			ix->is_trained = 0;
 			/* IndexIVF ctor: "Spherical by default if the metric is inner_product" */
@@ -781,15 +792,43 @@ static void invlist_append(invlist_t *l, int d, int64_t id, const float *x) {
 	l->n++;
 }
 
-/* IndexIVF::train -> Level1Quantizer::train_q1 (quantizer_trains_alone == 0) */
+static int hnsw_search(const orc_index *ix, int64_t nq, const float *xq, int64_t k, float *D, int64_t *I,
+                       const orc_params *params, const int64_t *id_map);
+/* coarse quantizer search: IndexFlat, or IndexHNSWFlat for "IVF<n>_HNSW<m>,Flat" (efSearch = the quantizer_params the
+ * glue builds at src/faiss_extension.cpp:679-681, default 16) */
+static int quantizer_search(const orc_index *qz, int64_t nq, const float *xq, int64_t k, float *D, int64_t *I,
+                            int64_t efSearch) {
+	if (qz->type == IX_HNSW) {
+		orc_params p;
+		memset(&p, 0, sizeof p);
+		p.efSearch = efSearch;
+		return hnsw_search(qz, nq, xq, k, D, I, &p, NULL);
+	}
+	return flat_search_impl(qz->metric, qz->d, qz->ntotal, qz->xb, nq, xq, k, D, I, NULL, NULL);
+}
+
+/* IndexIVF::train -> Level1Quantizer::train_q1.  Flat quantizer: quantizer_trains_alone == 0, k-means assigns with
+ * the quantizer itself.  HNSW quantizer (index_factory sets quantizer_trains_alone = 2): "kmeans training on a flat
+ * index + add the centroids to the quantizer" -- the assigner is an IndexFlatL2 whatever the metric. */
 static int ivf_train(orc_index *ix, int64_t n, const float *x) {
 	if (ix->quantizer->is_trained && ix->quantizer->ntotal == ix->nlist) {
 		ix->is_trained = 1; /* "IVF quantizer does not need training." */
 		return 0;
 	}
 	float *cent = (float *)malloc((size_t)ix->nlist * ix->d * sizeof(float));
-	flat_reset(ix->quantizer);
-	int rc = kmeans_train(ix->d, ix->nlist, n, x, ix->quantizer, ix->spherical, cent);
+	int rc;
+	if (ix->quantizer->type == IX_HNSW) {
+		orc_index *assigner = new_flat(ix->d, ORC_METRIC_L2);
+		rc = kmeans_train(ix->d, ix->nlist, n, x, assigner, ix->spherical, cent);
+		if (!rc) {
+			memcpy(cent, assigner->xb, (size_t)ix->nlist * ix->d * sizeof(float)); /* final centroids */
+			rc = orc_add(ix->quantizer, ix->nlist, cent);
+		}
+		orc_index_free(assigner);
+	} else {
+		flat_reset(ix->quantizer);
+		rc = kmeans_train(ix->d, ix->nlist, n, x, ix->quantizer, ix->spherical, cent);
+	}
 	free(cent);
 	if (rc)
 		return rc;
@@ -808,8 +847,7 @@ static int ivf_add(orc_index *ix, int64_t n, const float *x, const int64_t *xids
 		int64_t nb = n - i0 < bs ? n - i0 : bs;
 		int64_t *assign = (int64_t *)malloc((size_t)nb * sizeof(int64_t));
 		float *dis = (float *)malloc((size_t)nb * sizeof(float));
-		int rc = flat_search_impl(ix->quantizer->metric, ix->d, ix->quantizer->ntotal, ix->quantizer->xb, nb,
-		                          x + i0 * ix->d, 1, dis, assign, NULL, NULL);
+		int rc = quantizer_search(ix->quantizer, nb, x + i0 * ix->d, 1, dis, assign, 16);
 		if (rc) {
 			free(assign);
 			free(dis);
@@ -849,8 +887,8 @@ static int ivf_search(const orc_index *ix, int64_t nq, const float *xq, int64_t 
 	float *cdis = (float *)malloc((size_t)nq * nprobe * sizeof(float));
 	/* coarse quantisation: quantizer->search(n, x, nprobe) on the whole batch (FAISS slices the
 	 * batch by OpenMP thread count, which makes its pair/BLAS choice machine dependent) */
-	int rc = flat_search_impl(ix->quantizer->metric, d, ix->quantizer->ntotal, ix->quantizer->xb, nq, xq, nprobe, cdis,
-	                          keys, NULL, NULL);
+	int rc = quantizer_search(ix->quantizer, nq, xq, nprobe, cdis, keys,
+	                          params && params->efSearch > 0 ? params->efSearch : 16);
 	if (!rc) {
 #pragma omp parallel for schedule(dynamic, 1)
 		for (int64_t i = 0; i < nq; i++) {
@@ -900,8 +938,16 @@ int orc_ivf_set_centroids(orc_index *ix, const float *c) {
 		ix = ix->sub;
 	if (ix->type != IX_IVFFLAT)
 		return fail("orc_ivf_set_centroids", "oracle", "not an IVF index");
-	flat_reset(ix->quantizer);
-	flat_add(ix->quantizer, ix->nlist, c);
+	if (ix->quantizer->type == IX_HNSW) { /* centroids are inserted into the (still empty) graph */
+		if (ix->quantizer->ntotal != 0)
+			return fail("orc_ivf_set_centroids", "oracle", "the HNSW coarse quantizer already holds centroids");
+		int rc = orc_add(ix->quantizer, ix->nlist, c);
+		if (rc)
+			return rc;
+	} else {
+		flat_reset(ix->quantizer);
+		flat_add(ix->quantizer, ix->nlist, c);
+	}
 	ix->is_trained = 1;
 	for (orc_index *p = top; p->type == IX_IDMAP; p = p->sub)
 		p->is_trained = 1;
@@ -1151,6 +1197,8 @@ void orc_synth_clustered(float *out, int64_t n_rows, int d, uint64_t seed, int64
 static orc_index *hnsw_of(orc_index *ix) {
 	if (ix && ix->type == IX_IDMAP)
 		ix = ix->sub;
+	if (ix && ix->type == IX_IVFFLAT) /* "IVF<n>_HNSW<m>,Flat": the coarse quantizer */
+		ix = ix->quantizer;
 	return ix && ix->type == IX_HNSW ? ix : NULL;
 }
 int orc_hnsw_set_ef_construction_ix(orc_index *ix, int v) {
@@ -1181,8 +1229,8 @@ int orc_hnsw_get_graph(orc_index *ix, int *levels, int64_t *offsets, int32_t *ne
  * the index is meant for search only afterwards */
 int orc_hnsw_set_graph(orc_index *ix, int64_t n, const float *x, const int *levels, const int64_t *offsets,
                        const int32_t *neighbors, int32_t entry_point, int max_level) {
-	orc_index *h = hnsw_of(ix);
-	if (!h || ix != h)
+	orc_index *h = ix && ix->type == IX_HNSW ? ix : NULL;
+	if (!h)
 		return fail("orc_hnsw_set_graph", "oracle", "not a plain HNSW index");
 	h->ntotal = 0;
 	flat_add(h, n, x);

@@ -127,3 +127,44 @@ def test_idmap_ivf_with_ids_selector_and_small_cases(mf):
         t.train(np.zeros((3, 4), np.float32))
     with pytest.raises(mf.FaissException, match="is_trained"):
         t.add(np.zeros((3, 4), np.float32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_ivf_with_hnsw_coarse_quantizer(mf, tmp_path, metric):
+    """"IVF<n>_HNSW<m>,Flat" (reference Makefile:93): index_factory sets quantizer_trains_alone = 2 -- k-means on an
+    IndexFlatL2, centroids inserted into an IndexHNSWFlat that then serves assign (k=1) and the coarse search"""
+    d, nlist = 32, 32
+    xb = _clustered(20000, d, 41, ncent=64, sigma=0.2)
+    xq = _clustered(200, d, 42, ncent=64, sigma=0.2)
+    desc = f"IVF{nlist}_HNSW8,Flat"
+    o = orc.Index(d, desc, metric)
+    g = mf.index_factory(d, desc, metric)
+    assert g.kind == mf.KIND_IVFFLAT and not g.is_trained and g.quantizer.kind == mf.KIND_HNSW
+    g.set_option("hnsw_build_waves", 1)  # reaches the quantizer: FAISS's single-thread graph = the oracle's
+    o.train(xb)
+    g.train(xb)
+    assert g.is_trained and g.quantizer.ntotal == nlist
+    assert np.array_equal(g.ivf_centroids().view(np.uint32), o.ivf_centroids().view(np.uint32))
+    go, gg = o_graph(o), g.quantizer.hnsw_graph()
+    assert np.array_equal(go["neighbors"], gg["neighbors"]) and go["entry_point"] == gg["entry_point"]
+    o.add(xb)
+    g.add(xb)
+    for nprobe, efs in ((1, 0), (4, 16), (8, 64)):
+        Do, Io = o.search(xq, 10, nprobe=nprobe, efSearch=efs)
+        D, I = g.search(xq, 10, nprobe=nprobe, efSearch=efs)
+        ok = _no_tie_rows(Do)
+        assert ok.sum() > 150
+        assert np.array_equal(I[ok], Io[ok]) and np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
+    # write_index / read_index keep the graph of the quantizer
+    p = str(tmp_path / "ivf_hnsw.index")
+    mf.write_index(g, p)
+    ld = mf.read_index(p)
+    assert ld.quantizer.kind == mf.KIND_HNSW and ld.ntotal == g.ntotal
+    D0, I0 = g.search(xq, 10, nprobe=4, efSearch=32)
+    D1, I1 = ld.search(xq, 10, nprobe=4, efSearch=32)
+    assert np.array_equal(I0, I1) and np.array_equal(D0, D1)
+
+
+def o_graph(o):
+    """HNSW graph of the oracle's coarse quantizer"""
+    return o.quantizer_hnsw_graph()

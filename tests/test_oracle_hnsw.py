@@ -150,3 +150,26 @@ def test_idmap_and_selector_filter_results_only():
         bm[i >> 3] |= 1 << (i & 7)
     Db, Ib = ix.search(xq, 10, efSearch=64, sel=("bitmap", bm))
     assert np.array_equal(Ib, Is) and np.array_equal(Db, Ds)
+
+
+def test_ivf_with_hnsw_coarse_quantizer():
+    """"IVF<n>_HNSW<m>,Flat" (reference Makefile:93): k-means on an IndexFlatL2 (quantizer_trains_alone = 2), so the
+    centroids equal those of "IVF<n>,Flat" for L2; assign and coarse search walk the HNSW graph"""
+    d, n = 16, 12000
+    xb = orc.synth_clustered(n, d, 50, n_centers=32, sigma=0.2)
+    xq = orc.synth_clustered(100, d, 51, n_centers=32, sigma=0.2)
+    a = orc.Index(d, "IVF32,Flat", L2)
+    b = orc.Index(d, "IVF32_HNSW8,Flat", L2)
+    assert not b.is_trained
+    a.train(xb)
+    b.train(xb)
+    assert np.array_equal(a.ivf_centroids(), b.ivf_centroids())
+    g = b.quantizer_hnsw_graph()
+    assert len(g["levels"]) == 32 and g["entry_point"] >= 0
+    a.add(xb)
+    b.add(xb)
+    Da, Ia = a.search(xq, 10, nprobe=32)
+    Db, Ib = b.search(xq, 10, nprobe=32, efSearch=64)  # every list probed: both exhaustive
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+    with pytest.raises(orc.OracleError, match="could not parse"):
+        orc.Index(d, "IVF32_HNSW8,PQ4", L2)
