@@ -377,7 +377,11 @@ def main():
             xb_h = gen_h(n, d, DB_SEED)
             xq_h = gen_h(nq, d, Q_SEED)
             cores = orc.num_threads()
-            nq_cpu, t_cpu, done = 4096, 0.0, 0
+            # first slice: 4096 queries keep every host thread busy (16 queries per thread group); shrink it when even
+            # that would blow the budget (the oracle sustains roughly 0.5 TFLOP/s on this class of host)
+            est = 2.0 * 4096 * n * d / 0.5e12
+            nq_cpu = 4096 if est <= 2 * args.cpu_seconds else max(256, int(4096 * 2 * args.cpu_seconds / est) // 256 * 256)
+            t_cpu, done = 0.0, 0
             hits = total = 0
             labels_equal = True
             while t_cpu < args.cpu_seconds and done < nq:
