@@ -95,6 +95,7 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 int64_t flat_mfma_max_k(const FlatGeom &g);
 extern int g_mfma_variant;
 extern int g_mfma_nsplit;
+extern int g_mfma_warm;
 
 // direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic
 struct DirectPlan {
@@ -129,6 +130,10 @@ void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows,
                      int64_t k, const void *d_items, int nitems, const int *d_qidx, SelectorDev sel,
                      const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, float *d_xi,
                      const int *d_nitems /* device item count, grid = upper bound; may be null */, hipStream_t st);
+// csrc/kmeans_update.hip: compute_centroids of Clustering::train on device, FAISS's summation order
+size_t kmeans_update_ws_bytes(int64_t nx, int64_t k);
+void launch_kmeans_update(const float *d_x, int64_t nx, int d, const int64_t *d_assign, int64_t k, float *d_cent,
+                          float *d_hassign, void *ws, size_t ws_bytes, hipStream_t st);
 // Flat per-pair path on the same kernel (regular grid over row splits x groups of 20 queries); partials [nsplit][nq][k]
 void launch_pair_scan(int dp, bool interleaved, int metric, const float *d_xq, int64_t nq, const float *d_rows,
                       int64_t nrows, int64_t k, int nsplit, int64_t split_rows, SelectorDev sel, const int64_t *d_idmap,

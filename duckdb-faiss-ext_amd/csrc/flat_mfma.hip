@@ -589,6 +589,7 @@ int64_t flat_mfma_max_k(const FlatGeom &g) {
 }
 
 int g_mfma_nsplit = 0; // 0 = heuristic; >0 forces the split count (tuning / tests)
+int g_mfma_warm = 0;   // > 1: warm-up pre-pass over n / g_mfma_warm rows (experiment)
 
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
 	FlatSearchPlan p;
@@ -750,8 +751,21 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 			launch_inst<32, 4, false>(metric, aa, pp, st); // d > 128: 128-row tiles, k streamed in units of 64
 		}
 	};
-	// (A threshold warm-up pre-pass over the first 1/64 of the rows was measured: it costs its 1.8 % and buys nothing --
-	// the shared class slots already tighten within the first tiles.)
+	// Optional threshold warm-up (option mfma_warm = divisor): a pre-pass of the same kernel over the first
+	// n/divisor rows leaves the shared class slots holding valid bounds before all workgroups start cold.
+	if (g_mfma_warm > 1 && db.n / g_mfma_warm >= 4096) {
+		const int64_t n_pre = db.n / g_mfma_warm;
+		FlatSearchPlan pp = plan_flat_mfma(g, nq, n_pre, k);
+		if (pp.nsplit <= p.nsplit) {
+			MfmaArgs ap = a;
+			ap.n = n_pre;
+			ap.split_rows = pp.split_rows;
+			ap.nqb = pp.nqb;
+			ap.nsplit = pp.nsplit;
+			ap.xcd_map = pp.xcd_map ? 1 : 0;
+			launch_one(ap, pp);
+		}
+	}
 	launch_one(a, p);
 }
 

@@ -1089,6 +1089,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		force_direct = v != 0;
 		return true;
 	}
+	if (!strcmp(key, "mfma_warm")) {
+		g_mfma_warm = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "mfma_nsplit")) {
 		g_mfma_nsplit = (int)v;
 		return true;

@@ -7,7 +7,8 @@
 //   train  : k-means (niter 25, seed 1234, <= 256 points per centroid subsample via rand_perm, centroids initialised
 //            from rand_perm(seed+1), empty-cluster splitting, spherical for inner product).  The ASSIGNMENT step --
 //            27.5 TFLOP at IVF4096 -- runs on the fused MFMA Flat kernel (k = 1); the centroid update keeps FAISS's
-//            sequential summation order and runs on the host (cheap: ns*d adds per iteration).
+//            sequential summation order on device too (stable sort by assignment + one thread per (centroid, dim),
+//            csrc/kmeans_update.hip); the host only replays the RNG-driven empty-cluster splits on k x d values.
 //   add    : assign = quantizer search k=1 in blocks of 65536 rows; (id, raw vector) appended to list assign[i] in
 //            input order.  Device store: append-only rows + a CSR view (rows grouped by list, input order inside a
 //            list) rebuilt lazily before the first search after an add.
@@ -161,41 +162,21 @@ public:
 		dD.reserve((size_t)nx * sizeof(float));
 		dI.reserve((size_t)nx * sizeof(int64_t));
 		MVS_HIP(hipMemcpyAsync(dx.p, x, (size_t)nx * d * sizeof(float), hipMemcpyHostToDevice, stream));
-		std::vector<int64_t> assign((size_t)nx);
 		std::vector<float> hassign((size_t)k);
-		const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+		DevBuf dcent, dhass, dws;
+		dcent.reserve((size_t)k * d * sizeof(float));
+		dhass.reserve((size_t)k * sizeof(float));
+		const size_t wsb = kmeans_update_ws_bytes(nx, k);
+		dws.reserve(wsb);
 		for (int it = 0; it < niter; it++) {
 			qz->search_device(nx, (const float *)dx.p, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
-			MVS_HIP(hipMemcpyAsync(assign.data(), dI.p, (size_t)nx * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+			// compute_centroids on device in FAISS's summation order (csrc/kmeans_update.hip); only the k x d
+			// centroids and the k counts come back for the (rare, RNG-driven) empty-cluster splits
+			launch_kmeans_update((const float *)dx.p, nx, d, (const int64_t *)dI.p, k, (float *)dcent.p, (float *)dhass.p,
+			                     dws.p, wsb, stream);
+			MVS_HIP(hipMemcpyAsync(cent.data(), dcent.p, cent.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+			MVS_HIP(hipMemcpyAsync(hassign.data(), dhass.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, stream));
 			MVS_HIP(hipStreamSynchronize(stream));
-			// compute_centroids: each thread owns a range of centroids and walks ALL points in input order
-			std::fill(cent.begin(), cent.end(), 0.f);
-			std::fill(hassign.begin(), hassign.end(), 0.f);
-			std::vector<std::thread> th;
-			for (int r = 0; r < nt; r++)
-				th.emplace_back([&, r] {
-					const int64_t c0 = k * r / nt, c1 = k * (r + 1) / nt;
-					for (int64_t i = 0; i < nx; i++) {
-						const int64_t ci = assign[(size_t)i];
-						if (ci >= c0 && ci < c1) {
-							float *c = &cent[(size_t)ci * d];
-							const float *xi = x + i * d;
-							hassign[(size_t)ci] += 1.0f;
-							for (int j = 0; j < d; j++)
-								c[j] += xi[j];
-						}
-					}
-					for (int64_t ci = c0; ci < c1; ci++) {
-						if (hassign[(size_t)ci] == 0)
-							continue;
-						const float norm = 1 / hassign[(size_t)ci];
-						float *c = &cent[(size_t)ci * d];
-						for (int j = 0; j < d; j++)
-							c[j] *= norm;
-					}
-				});
-			for (auto &t : th)
-				t.join();
 			// split_clusters
 			{
 				const float EPS = (float)(1 / 1024.);
