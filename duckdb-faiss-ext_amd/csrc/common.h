@@ -91,7 +91,8 @@ void launch_query_norms(const float *d_x, int64_t n, int d, float *d_out, hipStr
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 // partial lists: pd [nsplit][nq][k] f32, pi [nsplit][nq][k] i32
 void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
-                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st);
+                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
+                      const SelectorDev *sel = nullptr, const int64_t *d_idmap = nullptr); // sel: inner product only
 int64_t flat_mfma_max_k(const FlatGeom &g);
 extern int g_mfma_variant;
 extern int g_mfma_nsplit;

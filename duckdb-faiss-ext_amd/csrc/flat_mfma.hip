@@ -23,6 +23,10 @@
 //   d  > 128: 256-row tiles (8 accumulator tiles per wave), k streamed in units of 32.
 #include "common.h"
 
+#include "../../include/mi355_faiss.h"
+
+#include <cstring>
+
 #include <cstdlib>
 
 namespace mvs {
@@ -52,6 +56,10 @@ struct MfmaArgs {
 	long long n;
 	long long split_rows;
 	int nq, k, nqb, nsplit, dp, nch, xcd_map;
+	// SEL instances only (inner product + IDSelector): FAISS's per-pair fvec_inner_product IS the k-ordered chain the
+	// MFMA computes, so filtered IP search stays on the fused kernel and masks the rejected rows in the epilogue
+	SelectorDev sel;
+	const long long *idmap;
 };
 
 // order-preserving float <-> uint key (atomicMin/Max on floats of either sign)
@@ -71,6 +79,27 @@ __device__ __forceinline__ float next_down(float g) {
 		return __uint_as_float(0x80000001u);
 	const unsigned b = __float_as_uint(g);
 	return __uint_as_float(g > 0.f ? b - 1u : b + 1u);
+}
+
+__device__ __forceinline__ bool mfma_sel_member(const SelectorDev &s, long long id) {
+	if (s.kind == MVS_SEL_BITMAP) {
+		const unsigned long long u = (unsigned long long)id;
+		if ((u >> 3) >= (unsigned long long)s.nbytes)
+			return false;
+		return (s.bitmap[u >> 3] >> (u & 7)) & 1;
+	}
+	if (s.kind == MVS_SEL_BATCH) {
+		long long lo = 0, hi = s.nids;
+		while (lo < hi) {
+			const long long mid = (lo + hi) >> 1;
+			if (s.sorted_ids[mid] < id)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo < s.nids && s.sorted_ids[lo] == id;
+	}
+	return true;
 }
 
 struct Thr {
@@ -175,11 +204,11 @@ __device__ __forceinline__ unsigned slots_reduce(const SlotRegs &sr) {
 // acc[t][r] holds ip(query = lane&31, row = t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)).
 // gkey = this query's shared bound (from the slot words the caller prefetched at the START of the tile, so that the
 // L2/MALL round trip hides under the tile's MFMAs); all-ones until the first sweep over the slots is complete.
-template <int NT, bool IS_L2, bool SKIP_SLOW = false>
+template <int NT, bool IS_L2, bool SKIP_SLOW = false, bool SEL = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb, long long row0, int nvalid, float xnq,
                                               float &thr, bool qvalid, unsigned gkey, unsigned *gslot_q,
                                               float *ldq, int *liq, int k, float *lthr_q, int *lthrid_q, int *lpos_q,
-                                              int h) {
+                                              int h, const unsigned long long *rowmask = nullptr) {
 	float gval = IS_L2 ? FLT_MAX : -FLT_MAX;
 	float teff = thr;
 	if (qvalid) {
@@ -206,6 +235,13 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 				if (IS_L2) {
 					v[e] = fmaf(-2.0f, v[e], xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
 					acc[t][4 * g + e] = v[e];
+				}
+				if (SEL) { // rows the IDSelector rejects can never be a result
+					const int rl = t * 32 + e + 8 * g + 4 * h;
+					if (!((rowmask[rl >> 6] >> (rl & 63)) & 1ull)) {
+						v[e] = IS_L2 ? INFINITY : -INFINITY;
+						acc[t][4 * g + e] = v[e];
+					}
 				}
 			}
 			if (IS_L2)
@@ -311,7 +347,7 @@ typedef __attribute__((address_space(1))) const float glb_f32;
 // STREAM = true  (d  > 128): NT = 4 (128-row tiles), k streamed in units of KC = 64; the accumulators persist over the
 //   units of a tile and the B fragments of the NEXT unit are refilled group by group behind the MFMAs that just
 //   consumed the current ones (one 64-byte-per-lane register set, no double buffer).
-template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false>
+template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false, bool SEL = false>
 __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
 	constexpr int KC = 2 * KSTEPS, BN = 32 * NT;
 	// LDS image of a tile: [64 rows][C 16-byte chunks], UNPADDED so that one LDS-DMA dwordx4 instruction (1 KiB per
@@ -527,9 +563,20 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 					MVS_KEEP_VGPR(acc[t]); // keep the MFMA chain alive
 			} else {
 				const unsigned gkey = slots_update(sbound, slots_reduce(sr), window, nwin);
-				tile_epilogue<NT, IS_L2, (ABL & 8) != 0>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
-				                                         a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k,
-				                                         li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h);
+				unsigned long long rowmask[(NT + 1) / 2];
+				if (SEL) { // lane l tests rows l, l + 64, ... of the tile once; every lane then reads the ballots
+#pragma unroll
+					for (int m = 0; m < (NT + 1) / 2; ++m) {
+						const long long row = row0 + m * 64 + lane;
+						bool ok = m * 64 + lane < nvalid;
+						if (ok)
+							ok = mfma_sel_member(a.sel, a.idmap ? a.idmap[row] : row);
+						rowmask[m] = __builtin_amdgcn_ballot_w64(ok);
+					}
+				}
+				tile_epilogue<NT, IS_L2, (ABL & 8) != 0, SEL>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
+				                                              a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k,
+				                                              li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h, rowmask);
 			}
 		}
 		__syncthreads(); // also drains this unit's LDS-DMA (vmcnt(0)) before the next unit reads it
@@ -675,6 +722,10 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 			        KSTEPS, p.grid, p.lds_bytes, p.nsplit, (long long)p.split_rows, nb);
 		}
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+	} else if (a.sel.kind != MVS_SEL_NONE) {
+		auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, 2, false, true>;
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 	} else {
 		auto kern = flat_mfma_resident_kernel<KSTEPS, false>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
@@ -692,6 +743,10 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 			auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, NT, true>;
 			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
 			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+		} else if (a.sel.kind != MVS_SEL_NONE) {
+			auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, NT, true, true>;
+			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 		} else {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, NT, true>;
 			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
@@ -702,7 +757,8 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 }
 
 void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
-                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st) {
+                      int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
+                      const SelectorDev *sel, const int64_t *d_idmap) {
 	if (nq <= 0)
 		return;
 	const int stride = flat_mfma_slot_stride(k);
@@ -711,6 +767,14 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 		hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal,
 		                   stride, (int)k, metric == METRIC_L2 ? 1 : 0);
 	MfmaArgs a;
+	memset(&a.sel, 0, sizeof a.sel);
+	a.idmap = nullptr;
+	if (sel && sel->kind != MVS_SEL_NONE) {
+		if (metric != METRIC_IP)
+			throw_faiss("mvs::launch_flat_mfma", __FILE__, "the fused kernel takes a selector for inner product only");
+		a.sel = *sel;
+		a.idmap = (const long long *)d_idmap;
+	}
 	a.gslot = d_gthr;
 	a.slot_stride = stride;
 	a.qf = d_qf;

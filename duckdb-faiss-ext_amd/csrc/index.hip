@@ -368,7 +368,11 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	last_search_stream = st;
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
 	const int64_t mfma_kmax = flat_mfma_max_k(geom);
-	const bool direct = has_sel || nq < 20 || k > mfma_kmax || force_direct;
+	// Inner product + selector: FAISS's per-pair fvec_inner_product is the k-ordered chain the MFMA computes, so the
+	// filtered search -- the reference's signature feature, on its default metric -- stays on the fused kernel, which
+	// masks the rejected rows in its epilogue.  (L2 + selector is Sum (x-y)^2 per pair: packed scan kernel.)
+	const bool sel_on_mfma = has_sel && metric == METRIC_IP && nq >= 8 && k <= mfma_kmax && !force_direct && !force_staged;
+	const bool direct = (has_sel && !sel_on_mfma) || (nq < 20 && !sel_on_mfma) || k > mfma_kmax || force_direct;
 	FlatDB db {vecs, norms, ntotal};
 	memset(&kinfo, 0, sizeof kinfo);
 	if (direct) {
@@ -454,8 +458,9 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		ws_pi.reserve((size_t)p.nsplit * nq * k * sizeof(int32_t));
 		ws_gthr.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64); // shared threshold slots
 		begin_kernel_timing(st);
+		SelectorDev sel = selector.upload(params, st);
 		launch_flat_mfma(geom, p, metric, (const float *)ws_q.p, (const float *)ws_qn.p, nq, db, k, (float *)ws_pd.p,
-		                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
+		                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st, &sel, d_idmap);
 		end_kernel_timing(st);
 		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, k, d_idmap,
 		                      label_offset, d_D, d_I, st);

@@ -161,7 +161,8 @@ def test_pair_scan_dims_and_selector(mf, metric, d):
     keep = np.arange(nb)[np.arange(nb) % 3 != 1]
     Dg, Ig = ix.search(xq, 7, sel=("batch", keep))
     Do, Io = orc.flat_search(metric, xb, xq, 7, sel=("batch", keep))
-    assert ix.last_kernel_info()["name"].startswith("flat_pair_scan")
+    # L2 + selector = per-pair arithmetic (scan kernel); inner product + selector rides the fused MFMA kernel
+    assert ix.last_kernel_info()["name"].startswith("flat_pair_scan" if metric == L2 else "flat_mfma_kernel")
     if metric == IP:
         Dk1, _ = orc.flat_search(metric, xb, xq, 8, sel=("batch", keep))
         ok = Dk1[:, 6] != Dk1[:, 7]
@@ -282,3 +283,28 @@ def test_medium_size_properties(mf):
     sub = np.arange(0, nq, 8)
     Do, Io = orc.flat_search(L2, xb.cpu().numpy(), xq[sub].cpu().numpy(), k, force_path=orc.PATH_BLAS)
     assert_same_results(Dn[sub], In[sub], Do, Io, True, what="1M subsample")
+
+
+@pytest.mark.parametrize("idmap", [False, True])
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 20000, 64, 10), (24, 5003, 8, 3), (200, 9001, 33, 40), (768, 3000, 20, 10)])
+def test_filtered_inner_product_runs_on_the_fused_kernel(mf, d, nb, nq, k, idmap):
+    """inner product + IDSelector: FAISS's per-pair fvec_inner_product is the same k-ordered chain as the MFMA, so the
+    filtered search (faiss_search_filter on the default metric) stays on the fused kernel and must still match the
+    oracle's per-pair path bit for bit -- bitmap and batch selectors, through IDMap (external ids) or not"""
+    xb, xq = _data(nb, nq, d, seed=nb + d, center=True)
+    ids = (np.random.RandomState(d).permutation(3 * nb)[:nb] + 17).astype(np.int64) if idmap else np.arange(nb, dtype=np.int64)
+    desc = "IDMap,Flat" if idmap else "Flat"
+    ix, o = mf.index_factory(d, desc, IP), orc.Index(d, desc, IP)
+    for a in (ix, o):
+        a.add_with_ids(xb, ids) if idmap else a.add(xb)
+    keep = ids[np.random.RandomState(nb).rand(nb) < 0.3]
+    bm = bitmap_from_ids(ids, np.isin(ids, keep))
+    for sel in (("batch", keep), ("bitmap", bm)):
+        D, I = ix.search(xq, k, sel=sel)
+        assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+        Do, Io = o.search(xq, k, sel=sel)
+        Dk1, _ = o.search(xq, k + 1, sel=sel)
+        ok = Dk1[:, k - 1] != Dk1[:, k]
+        assert ok.sum() >= nq // 2
+        assert np.all(np.isin(I[I >= 0], keep))
+        assert_same_results(D[ok], I[ok], Do[ok], Io[ok], False, what=f"filtered IP on MFMA d={d} {sel[0]} idmap={idmap}")
