@@ -25,6 +25,7 @@
 
 #include "../../include/mi355_faiss.h"
 
+#include <algorithm>
 #include <cstring>
 
 #include <cstdlib>
@@ -649,8 +650,10 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	const int64_t slots = 2 * 256;
 	const int64_t min_tiles = 16; // amortise the per-workgroup prologue
 	int64_t max_split = ntiles / min_tiles;
-	if (max_split > 128)
-		max_split = 128;
+	// few query blocks (small batches routed here for inner product): allow enough splits to fill the 512 slots
+	const int64_t split_cap = std::max<int64_t>(128, std::min<int64_t>(512, slots / p.nqb));
+	if (max_split > split_cap)
+		max_split = split_cap;
 	int64_t nsplit = 1;
 	p.xcd_map = false;
 	if (g_mfma_nsplit > 0) {

@@ -371,8 +371,11 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	// Inner product + selector: FAISS's per-pair fvec_inner_product is the k-ordered chain the MFMA computes, so the
 	// filtered search -- the reference's signature feature, on its default metric -- stays on the fused kernel, which
 	// masks the rejected rows in its epilogue.  (L2 + selector is Sum (x-y)^2 per pair: packed scan kernel.)
-	const bool sel_on_mfma = has_sel && metric == METRIC_IP && nq >= 8 && k <= mfma_kmax && !force_direct && !force_staged;
-	const bool direct = (has_sel && !sel_on_mfma) || (nq < 20 && !sel_on_mfma) || k > mfma_kmax || force_direct;
+	// The same identity covers small inner-product batches (nq < 20, FAISS's per-pair branch): from 8 queries on the
+	// MFMA kernel beats the per-pair kernels even with a mostly empty 128-query block.
+	const bool ip_on_mfma = metric == METRIC_IP && (has_sel || nq < 20) && nq >= 8 && k <= mfma_kmax && !force_direct &&
+	                        !force_staged;
+	const bool direct = ((has_sel || nq < 20) && !ip_on_mfma) || k > mfma_kmax || force_direct;
 	FlatDB db {vecs, norms, ntotal};
 	memset(&kinfo, 0, sizeof kinfo);
 	if (direct) {

@@ -145,8 +145,12 @@ def test_small_batches_take_the_per_pair_path(mf, metric, nq, staged):
     D, I = ix.search(xq, 10)
     Do, Io = orc.flat_search(metric, xb, xq, 10)
     assert_same_results(D, I, Do, Io, metric == L2, what=f"pair path nq={nq}")
-    # 1-4 queries always stream through the LDS-staged kernel
-    assert ix.last_kernel_info()["name"] == ("flat_direct_kernel" if staged or nq <= 4 else "flat_pair_scan (ivf_scan_kernel)")
+    # 1-4 queries always stream through the LDS-staged kernel; inner-product batches of >= 8 ride the MFMA kernel
+    # (fvec_inner_product is the same k-ordered chain)
+    want = "flat_direct_kernel" if staged or nq <= 4 else "flat_pair_scan (ivf_scan_kernel)"
+    if metric == IP and nq >= 8 and not staged:
+        want = "flat_mfma_kernel"
+    assert ix.last_kernel_info()["name"] == want
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
@@ -170,7 +174,7 @@ def test_pair_scan_dims_and_selector(mf, metric, d):
     assert_same_results(Dg, Ig, Do, Io, metric == L2, what=f"pair scan + selector d={d}")
     D1, I1 = ix.search(xq[:7], 7)
     Do1, Io1 = orc.flat_search(metric, xb, xq[:7], 7)
-    assert ix.last_kernel_info()["name"].startswith("flat_pair_scan")
+    assert ix.last_kernel_info()["name"].startswith("flat_pair_scan")  # 5-7 queries: scan kernel for both metrics
     assert_same_results(D1, I1, Do1, Io1, metric == L2, what=f"pair scan nq=7 d={d}")
 
 
