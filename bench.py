@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="queries per search call (2048 = DuckDB DataChunk); 0 = one batch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="index option key=value (e.g. ivf_mfma=1)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "clustered"])
     ap.add_argument("--centers", type=int, default=1024, help="clustered data: number of mixture centres")
     ap.add_argument("--sigma", type=float, default=0.1, help="clustered data: per-coordinate spread around a centre")
@@ -89,6 +90,9 @@ def main():
             return mf.synth_clustered_torch(m, dd, seed, row0=row0, n_centers=args.centers, sigma=args.sigma, device=device)
 
     ix = mf.index_factory(d, args.index, metric)
+    for o in args.opt:
+        key, v = o.split("=")
+        ix.set_option(key, int(v))
     is_ivf = "IVF" in args.index
     is_hnsw = "HNSW" in args.index
     with_ids = args.index.startswith("IDMap")
@@ -226,6 +230,7 @@ def main():
                 if world > 1
                 else "none",
                 "build_seconds": round(t_build, 2),
+                "options": args.opt,
             },
         }
         # ---- roofline of the dominant kernel (per launch, HIP events on the launch stream) ----------

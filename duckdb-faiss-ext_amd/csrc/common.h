@@ -94,6 +94,15 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
                       int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
                       const SelectorDev *sel = nullptr, const int64_t *d_idmap = nullptr); // sel: inner product only
 int64_t flat_mfma_max_k(const FlatGeom &g);
+// IVF list scan as a segmented variant of the fused kernel (csrc/flat_mfma.hip, ITEMS instances)
+bool flat_mfma_items_supported(const FlatGeom &g, int64_t k);
+size_t flat_mfma_item_query_floats(const FlatGeom &g, int max_items);
+int flat_mfma_item_slots(); // query slots per work item (128)
+void launch_flat_mfma_items(const FlatGeom &g, int metric, const float *d_qf, const float *d_qnorm, int64_t nq,
+                            const float *d_rows, const float *d_norms, int64_t nrows, int64_t k, const void *d_items,
+                            const int *d_nitems, int max_items, const int *d_qidx, const int64_t *d_rowids,
+                            const SelectorDev *sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gthr,
+                            hipStream_t st);
 extern int g_mfma_variant;
 extern int g_mfma_nsplit;
 extern int g_mfma_warm;
@@ -140,13 +149,16 @@ void launch_pair_scan(int dp, bool interleaved, int metric, const float *d_xq, i
                       int64_t nrows, int64_t k, int nsplit, int64_t split_rows, SelectorDev sel, const int64_t *d_idmap,
                       float *d_pd, int32_t *d_pi, unsigned *d_gslot, float *d_xi, hipStream_t st);
 // device-side construction of the work items from the coarse-search labels (no host round trip)
-int ivf_group_max_items(int64_t npairs, int64_t nlist);
+int ivf_group_max_items(int64_t npairs, int64_t nlist, int group);
 size_t ivf_group_ws_ints(int64_t nlist);
-void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, const int64_t *d_list_off, int *ws_int,
-                      void *d_items, int *d_qidx, int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st);
+void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, int group, int shift,
+                      const int64_t *d_list_begin, const int64_t *d_list_end, int *ws_int, void *d_items, int *d_qidx,
+                      int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st);
+void launch_ivf_pack_item_fragments(const float *d_x, int d, int kc, int nch, const void *d_items, const int *d_nitems,
+                                    int max_items, const int *d_qidx, float *d_qf, hipStream_t st);
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
                         int64_t k, const int64_t *d_rowids, const int64_t *d_idmap, float *d_D, int64_t *d_I,
-                        hipStream_t st);
+                        hipStream_t st, int group = 20, int shift = 5);
 void launch_gather_rows(const float *d_src, const int *d_perm, int64_t n, int dp, float *d_dst, hipStream_t st);
 
 void launch_synth_uniform(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, hipStream_t st);

@@ -61,6 +61,12 @@ struct MfmaArgs {
 	// MFMA computes, so filtered IP search stays on the fused kernel and masks the rejected rows in the epilogue
 	SelectorDev sel;
 	const long long *idmap;
+	// ITEMS instances (IVF list scan as a segmented variant of this kernel): one workgroup per work item =
+	// (row segment of one inverted list, <= 128 of the queries that probe it)
+	const int4 *items;       // {row_begin (multiple of 64), row_end, qoff, nq_item}
+	const int *nitems_dev;   // device-side item count; the grid is an upper bound
+	const int *qidx;         // query number of slot qoff + s
+	const long long *rowids; // stored id of every row (selector); row position is what the partial lists carry
 };
 
 // order-preserving float <-> uint key (atomicMin/Max on floats of either sign)
@@ -348,7 +354,7 @@ typedef __attribute__((address_space(1))) const float glb_f32;
 // STREAM = true  (d  > 128): NT = 4 (128-row tiles), k streamed in units of KC = 64; the accumulators persist over the
 //   units of a tile and the B fragments of the NEXT unit are refilled group by group behind the MFMAs that just
 //   consumed the current ones (one 64-byte-per-lane register set, no double buffer).
-template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false, bool SEL = false>
+template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false, bool SEL = false, bool ITEMS = false>
 __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
 	constexpr int KC = 2 * KSTEPS, BN = 32 * NT;
 	// LDS image of a tile: [64 rows][C 16-byte chunks], UNPADDED so that one LDS-DMA dwordx4 instruction (1 KiB per
@@ -377,22 +383,36 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: stays in SGPRs
 	const int h = lane >> 5, c = lane & 31;
 	const int k = a.k;
-	int split, qb;
-	if (a.xcd_map) {
-		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-		split = (idx / a.nqb) * 8 + xcd;
-		qb = idx % a.nqb;
-	} else {
-		split = blockIdx.x / a.nqb;
-		qb = blockIdx.x % a.nqb;
-	}
+	int split = 0, qb = 0, q;
+	bool qvalid;
+	long long r_begin, r_end;
 	const int ql = wave * WAVE_Q + c;
-	const int q = qb * QBLOCK + ql;
-	const bool qvalid = q < a.nq;
+	int qblk32;
+	if (ITEMS) {
+		if (a.nitems_dev && (int)blockIdx.x >= *a.nitems_dev)
+			return; // whole workgroup, before any barrier
+		const int4 it = a.items[blockIdx.x];
+		r_begin = it.x;
+		r_end = it.y;
+		qvalid = ql < it.w;
+		q = qvalid ? a.qidx[it.z + ql] : 0;
+		qblk32 = blockIdx.x * 4 + wave; // the item's queries were packed for it (pack_item_queries_kernel)
+	} else {
+		if (a.xcd_map) {
+			const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+			split = (idx / a.nqb) * 8 + xcd;
+			qb = idx % a.nqb;
+		} else {
+			split = blockIdx.x / a.nqb;
+			qb = blockIdx.x % a.nqb;
+		}
+		q = qb * QBLOCK + ql;
+		qvalid = q < a.nq;
+		qblk32 = qb * 4 + wave;
+		r_begin = (long long)split * a.split_rows;
+		r_end = r_begin + a.split_rows;
+	}
 	const int nwin = a.slot_stride >> 4; // 16-slot windows of the shared threshold slots
-	const int qblk32 = qb * 4 + wave;
-	const long long r_begin = (long long)split * a.split_rows;
-	long long r_end = r_begin + a.split_rows;
 	if (r_end > a.n)
 		r_end = a.n;
 	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + BN - 1) / BN) : 0;
@@ -471,10 +491,26 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	}
 	__syncthreads();
 
+	// ITEMS: a wave whose 32 query slots are all empty (item with <= 96 queries) only helps with the staging and keeps
+	// in step at the barriers; its SIMD is left to the other workgroup of the CU
+	bool wave_idle = false;
+	if (ITEMS)
+		wave_idle = wave * WAVE_Q >= a.items[blockIdx.x].w;
 	for (int u = 0; u < nunits; ++u) {
 		const int tile = STREAM ? u / nch : u, ch = STREAM ? u - tile * nch : 0;
 		const bool stage_next = u + 1 < nunits && !(ABL & 2);
 		const int window = tile % nwin;
+		if (ITEMS && wave_idle) {
+			if (stage_next) {
+#pragma unroll
+				for (int g = 0; g < DMA_PER_WAVE; ++g)
+					dma_issue(u + 1, g);
+			}
+			if (ch == 0 && tile + 1 < ntiles)
+				dma_norms(tile + 1);
+			__syncthreads();
+			continue;
+		}
 		if (ch == 0) {
 #pragma unroll
 			for (int t = 0; t < NT; ++t)
@@ -570,8 +606,10 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 					for (int m = 0; m < (NT + 1) / 2; ++m) {
 						const long long row = row0 + m * 64 + lane;
 						bool ok = m * 64 + lane < nvalid;
-						if (ok)
-							ok = mfma_sel_member(a.sel, a.idmap ? a.idmap[row] : row);
+						if (ok) {
+							const long long lab = a.rowids ? a.rowids[row] : row;
+							ok = mfma_sel_member(a.sel, a.idmap ? a.idmap[lab] : lab);
+						}
 						rowmask[m] = __builtin_amdgcn_ballot_w64(ok);
 					}
 				}
@@ -584,8 +622,9 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	}
 
 	if (h == 0 && qvalid) {
-		float *od = a.pd + ((size_t)split * a.nq + q) * k;
-		int32_t *oi = a.pi + ((size_t)split * a.nq + q) * k;
+		const size_t ob = ITEMS ? ((size_t)blockIdx.x * QBLOCK + ql) * k : ((size_t)split * a.nq + q) * k;
+		float *od = a.pd + ob;
+		int32_t *oi = a.pi + ob;
 		for (int j = 0; j < k; ++j) {
 			od[j] = ld[ql * k + j];
 			oi[j] = li[ql * k + j];
@@ -770,8 +809,7 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 		hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal,
 		                   stride, (int)k, metric == METRIC_L2 ? 1 : 0);
 	MfmaArgs a;
-	memset(&a.sel, 0, sizeof a.sel);
-	a.idmap = nullptr;
+	memset(&a, 0, sizeof a);
 	if (sel && sel->kind != MVS_SEL_NONE) {
 		if (metric != METRIC_IP)
 			throw_faiss("mvs::launch_flat_mfma", __FILE__, "the fused kernel takes a selector for inner product only");
@@ -834,6 +872,85 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 		}
 	}
 	launch_one(a, p);
+}
+
+// ---- IVF list scan as a segmented variant of the fused kernel ---------------------------------------------------
+// Work item = (row segment of one inverted list, <= 128 of the queries probing it); rows in the Flat storage format
+// (pair-interleaved, lists padded to 64 rows), the items' queries packed into B-fragment order per item.  Distances
+// follow the Flat BLAS-branch arithmetic (inner product: the exact k-ordered chain; L2: ||x||^2 + ||y||^2 - 2<x,y>).
+bool flat_mfma_items_supported(const FlatGeom &g, int64_t k) {
+	return (g.nch > 1 || g.kc >= 64) && k <= flat_mfma_max_k(g);
+}
+size_t flat_mfma_item_query_floats(const FlatGeom &g, int max_items) {
+	return (size_t)max_items * QBLOCK * g.dp;
+}
+int flat_mfma_item_slots() {
+	return QBLOCK;
+}
+template <int KSTEPS, int NT, bool STREAM>
+static void launch_items_inst(int metric, bool has_sel, const MfmaArgs &a, int grid, size_t lds, hipStream_t st) {
+#define MVS_ITEMS(L2, SEL)                                                                                             \
+	{                                                                                                                  \
+		auto kern = flat_mfma_resident_kernel<KSTEPS, L2, 0, NT, STREAM, SEL, true>;                                   \
+		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
+	}
+	if (metric == METRIC_L2) {
+		if (has_sel)
+			MVS_ITEMS(true, true)
+		else
+			MVS_ITEMS(true, false)
+	} else {
+		if (has_sel)
+			MVS_ITEMS(false, true)
+		else
+			MVS_ITEMS(false, false)
+	}
+#undef MVS_ITEMS
+	MVS_HIP(hipGetLastError());
+}
+void launch_flat_mfma_items(const FlatGeom &g, int metric, const float *d_qf, const float *d_qnorm, int64_t nq,
+                            const float *d_rows, const float *d_norms, int64_t nrows, int64_t k, const void *d_items,
+                            const int *d_nitems, int max_items, const int *d_qidx, const int64_t *d_rowids,
+                            const SelectorDev *sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gthr,
+                            hipStream_t st) {
+	if (max_items <= 0)
+		return;
+	const int stride = flat_mfma_slot_stride(k);
+	const long long gtotal = (long long)nq * stride;
+	if (gtotal > 0)
+		hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal,
+		                   stride, (int)k, metric == METRIC_L2 ? 1 : 0);
+	MfmaArgs a;
+	memset(&a, 0, sizeof a);
+	const bool has_sel = sel && sel->kind != MVS_SEL_NONE;
+	if (has_sel)
+		a.sel = *sel;
+	a.idmap = (const long long *)d_idmap;
+	a.gslot = d_gthr;
+	a.slot_stride = stride;
+	a.qf = d_qf;
+	a.qn = d_qnorm;
+	a.yb = d_rows;
+	a.yn = d_norms;
+	a.pd = d_pd;
+	a.pi = d_pi;
+	a.n = nrows;
+	a.nq = (int)nq;
+	a.k = (int)k;
+	a.dp = g.dp;
+	a.nch = g.nch;
+	a.items = (const int4 *)d_items;
+	a.nitems_dev = d_nitems;
+	a.qidx = d_qidx;
+	a.rowids = (const long long *)d_rowids;
+	const size_t lds = mfma_lds_bytes(g, k);
+	if (g.nch > 1)
+		launch_items_inst<32, 4, true>(metric, has_sel, a, max_items, lds, st);
+	else if (g.kc == 64)
+		launch_items_inst<32, 2, false>(metric, has_sel, a, max_items, lds, st);
+	else
+		launch_items_inst<64, 2, false>(metric, has_sel, a, max_items, lds, st);
 }
 
 } // namespace mvs

@@ -60,6 +60,22 @@ void renorm_l2(int d, int64_t n, float *x) {
 
 } // namespace
 
+// rows of the padded MFMA store: dst[r][0..d) = src[perm[r]][0..d) (src rows have stride sdp), zeros where perm < 0
+__global__ void ivf_gather_plain_kernel(const float *src, int sdp, const int *perm, long long n, int d, float *dst) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * d)
+		return;
+	const long long r = i / d;
+	const int j = (int)(i - r * d);
+	const int p = perm[r];
+	dst[i] = p >= 0 ? src[(size_t)p * sdp + j] : 0.f;
+}
+__global__ void ivf_gather_ids_kernel(const long long *src, const int *perm, long long n, long long *dst) {
+	const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < n)
+		dst[r] = perm[r] >= 0 ? src[perm[r]] : -1;
+}
+
 class IVFFlatIndex : public IndexBase {
 public:
 	// owned; nlist centroids.  IndexFlat(d, metric) for "IVF<n>,Flat"; IndexHNSWFlat(d, M, metric) for
@@ -329,6 +345,54 @@ public:
 		                       stream));
 		MVS_HIP(hipStreamSynchronize(stream));
 		dirty = false;
+		mf_dirty = true;
+	}
+
+	// Second view of the lists for the MFMA variant of the scan (csrc/flat_mfma.hip ITEMS): the Flat storage format
+	// (pair-interleaved rows of geom.dp floats) with every list padded to a multiple of 64 rows, plus row norms.
+	// Built lazily the first time that variant runs.
+	void build_lists_mf() {
+		build_lists();
+		if (!mf_dirty)
+			return;
+		geom = flat_geom_for(d);
+		std::vector<int64_t> pb((size_t)nlist), pe((size_t)nlist);
+		int64_t pos = 0;
+		for (int64_t l = 0; l < nlist; l++) {
+			const int64_t len = list_off[(size_t)l + 1] - list_off[(size_t)l];
+			pb[(size_t)l] = pos;
+			pe[(size_t)l] = pos + len;
+			pos += (len + 63) / 64 * 64;
+		}
+		nrows_mf = pos;
+		std::vector<int32_t> perm((size_t)std::max<int64_t>(nrows_mf, 1), -1);
+		for (int64_t l = 0; l < nlist; l++)
+			for (int64_t j = 0; j < pe[(size_t)l] - pb[(size_t)l]; j++)
+				perm[(size_t)(pb[(size_t)l] + j)] = (int32_t)(list_off[(size_t)l] + j);
+		DevBuf dperm, tmp;
+		dperm.reserve(perm.size() * sizeof(int32_t));
+		tmp.reserve(std::max<size_t>((size_t)nrows_mf * d * sizeof(float), 16));
+		codes_mf.reserve(((size_t)nrows_mf * geom.dp + 64) * sizeof(float));
+		norms_mf.reserve(std::max<size_t>((size_t)nrows_mf * sizeof(float), 16));
+		rowids_mf.reserve(std::max<size_t>((size_t)nrows_mf * sizeof(int64_t), 16));
+		lb_dev.reserve((size_t)nlist * sizeof(int64_t));
+		le_dev.reserve((size_t)nlist * sizeof(int64_t));
+		MVS_HIP(hipMemcpyAsync(dperm.p, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		MVS_HIP(hipMemcpyAsync(lb_dev.p, pb.data(), (size_t)nlist * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+		MVS_HIP(hipMemcpyAsync(le_dev.p, pe.data(), (size_t)nlist * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+		if (nrows_mf > 0) {
+			const long long tot = (long long)nrows_mf * d;
+			hipLaunchKernelGGL(ivf_gather_plain_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+			                   (const float *)codes.p, dp, (const int *)dperm.p, (long long)nrows_mf, d, (float *)tmp.p);
+			hipLaunchKernelGGL(ivf_gather_ids_kernel, dim3((unsigned)((nrows_mf + 255) / 256)), dim3(256), 0, stream,
+			                   (const long long *)rowids.p, (const int *)dperm.p, (long long)nrows_mf,
+			                   (long long *)rowids_mf.p);
+			MVS_HIP(hipGetLastError());
+			launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
+			launch_query_norms((const float *)tmp.p, nrows_mf, d, (float *)norms_mf.p, stream);
+		}
+		MVS_HIP(hipStreamSynchronize(stream));
+		mf_dirty = false;
 	}
 
 	// ---------------------------------------------------------------------------------------------- search
@@ -356,7 +420,17 @@ public:
 		memset(&qp, 0, sizeof qp);
 		qp.efSearch = params ? params->efSearch : 0; // quantizer_params of an HNSW coarse quantizer (:679-681)
 		quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, hnsw_M > 0 ? &qp : nullptr, stream);
-		const bool fast_scan = use_fast_scan && ivf_scan_supported(dp, k) && nq * np < (int64_t)1 << 26;
+		// Inner product: the MFMA variant is the same k-ordered chain as IVFFlatScanner's fvec_inner_product -> default.
+		// L2: it evaluates ||x||^2 + ||y||^2 - 2<x,y> (the Flat BLAS-branch arithmetic) instead of the scanner's
+		// sum (x-y)^2, i.e. the same neighbours up to rounding-level near-ties -> opt-in (option ivf_mfma = 1); the
+		// default keeps the scanner's arithmetic bit for bit.
+		const bool want_mfma = mfma_mode == 1 || (mfma_mode < 0 && metric == METRIC_IP);
+		const bool small = nq * np < (int64_t)1 << 26;
+		if (want_mfma && small && flat_mfma_items_supported(flat_geom_for(d), k)) {
+			mfma_grouped_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
+			return;
+		}
+		const bool fast_scan = use_fast_scan && ivf_scan_supported(dp, k) && small;
 		if (fast_scan)
 			device_grouped_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
 		else
@@ -367,14 +441,15 @@ public:
 	void device_grouped_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, int64_t np) {
 		const int64_t npairs = nq * np;
-		const int max_items = ivf_group_max_items(npairs, nlist);
+		const int max_items = ivf_group_max_items(npairs, nlist, 20);
 		ws_items.reserve((size_t)max_items * 16);
 		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
 		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
 		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
 		int *d_nitems = nullptr, *d_cnt = nullptr;
-		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, (const int64_t *)list_off_dev.p, (int *)ws_group.p,
-		                 ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
+		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, 20, 5, (const int64_t *)list_off_dev.p,
+		                 (const int64_t *)list_off_dev.p + 1, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p,
+		                 (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
 		ws_q.reserve((size_t)nq * dp * sizeof(float));
 		ws_pd.reserve((size_t)max_items * 20 * k * sizeof(float));
 		ws_pi.reserve((size_t)max_items * 20 * k * sizeof(int32_t));
@@ -408,6 +483,59 @@ public:
 			}
 			kinfo.bytes = bytes; // list-major algorithmic bytes: every item streams its list once
 			kinfo.flops = pairs * d * (metric == METRIC_L2 ? 3.0 : 2.0);
+		}
+		stream_wait(st, stream);
+	}
+
+	// IVF list scan as a segmented variant of the fused Flat kernel: items of <= 128 queries per list
+	void mfma_grouped_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                         const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, int64_t np) {
+		build_lists_mf();
+		const int G = flat_mfma_item_slots(), shift = 7;
+		const int64_t npairs = nq * np;
+		const int max_items = ivf_group_max_items(npairs, nlist, G);
+		ws_items.reserve((size_t)max_items * 16);
+		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
+		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
+		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		int *d_nitems = nullptr, *d_cnt = nullptr;
+		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
+		                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
+		                 &d_nitems, &d_cnt, stream);
+		ws_xi.reserve(flat_mfma_item_query_floats(geom, max_items) * sizeof(float));
+		launch_ivf_pack_item_fragments(d_x, d, geom.kc, geom.nch, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p,
+		                               (float *)ws_xi.p, stream);
+		ws_q.reserve((size_t)nq * sizeof(float)); // query norms (L2)
+		launch_query_norms(d_x, nq, d, (float *)ws_q.p, stream);
+		ws_pd.reserve((size_t)max_items * G * k * sizeof(float));
+		ws_pi.reserve((size_t)max_items * G * k * sizeof(int32_t));
+		SelectorDev sel = selector.upload(params, stream);
+		memset(&kinfo, 0, sizeof kinfo);
+		ws_gslot.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+		begin_kernel_timing(stream);
+		launch_flat_mfma_items(geom, metric, (const float *)ws_xi.p, (const float *)ws_q.p, nq, (const float *)codes_mf.p,
+		                       (const float *)norms_mf.p, nrows_mf, k, ws_items.p, d_nitems, max_items,
+		                       (const int *)ws_qidx.p, (const int64_t *)rowids_mf.p, &sel, d_idmap, (float *)ws_pd.p,
+		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
+		end_kernel_timing(stream);
+		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
+		                   k, (const int64_t *)rowids_mf.p, d_idmap, d_D, d_I, stream, G, shift);
+		snprintf(kinfo.name, sizeof kinfo.name, "ivf_mfma_scan (flat_mfma_resident_kernel items)");
+		kinfo.grid = max_items;
+		kinfo.block = 256;
+		kinfo.nsplit = (int)np;
+		if (timing_enabled) {
+			std::vector<int> cnt((size_t)nlist);
+			MVS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nlist * sizeof(int), hipMemcpyDeviceToHost, stream));
+			MVS_HIP(hipStreamSynchronize(stream));
+			double bytes = 0, pairs = 0;
+			for (int64_t l = 0; l < nlist; l++) {
+				const double len = (double)(list_off[(size_t)l + 1] - list_off[(size_t)l]);
+				bytes += (double)((cnt[(size_t)l] + G - 1) / G) * len * geom.dp * 4.0;
+				pairs += (double)cnt[(size_t)l] * len;
+			}
+			kinfo.bytes = bytes; // list-major algorithmic bytes: every item streams its list once
+			kinfo.flops = pairs * d * 2.0;
 		}
 		stream_wait(st, stream);
 	}
@@ -577,6 +705,10 @@ public:
 		timing_enabled = on;
 	}
 	bool set_option(const char *key, int64_t v) override {
+		if (!strcmp(key, "ivf_mfma")) {
+			mfma_mode = (int)v;
+			return true;
+		}
 		if (!strcmp(key, "ivf_fast_scan")) { // 0 = the LDS-staged flat_direct item kernel
 			use_fast_scan = v != 0;
 			return true;
@@ -584,6 +716,7 @@ public:
 		return quantizer->set_option(key, v);
 	}
 	bool use_fast_scan = true;
+	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always
 
 	// introspection for parity tests
 	void get_centroids(float *out) {
@@ -604,6 +737,11 @@ private:
 	int64_t nsorted = 0;
 	DevBuf codes, rowids;
 	DevBuf ws_cD, ws_cI, ws_items, ws_qidx, ws_slots, ws_q, ws_pd, ws_pi, ws_gslot, ws_xi, ws_group, list_off_dev;
+	// MFMA view of the lists (build_lists_mf)
+	FlatGeom geom {};
+	bool mf_dirty = true;
+	int64_t nrows_mf = 0;
+	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev;
 	SelectorHolder selector;
 };
 

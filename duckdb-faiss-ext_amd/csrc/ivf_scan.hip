@@ -445,8 +445,8 @@ __global__ void ivf_group_count_kernel(const long long *keys, int npairs, int *c
 		atomicAdd(&cnt[keys[i]], 1);
 }
 // single workgroup: pair offsets and item offsets per list (exclusive scans), total item count
-__global__ __launch_bounds__(1024) void ivf_group_scan_kernel(const int *cnt, int nlist, int *pair_off, int *item_off,
-                                                             int *cursor, int *nitems_out) {
+__global__ __launch_bounds__(1024) void ivf_group_scan_kernel(const int *cnt, int nlist, int G, int *pair_off,
+                                                             int *item_off, int *cursor, int *nitems_out) {
 	__shared__ int part_p[1024], part_i[1024];
 	const int t = threadIdx.x;
 	const int per = (nlist + 1023) / 1024;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(1024) void ivf_group_scan_kernel(const int *cnt, in
 	int sp = 0, si = 0;
 	for (int l = l0; l < l1; ++l) {
 		sp += cnt[l];
-		si += (cnt[l] + SQG - 1) / SQG;
+		si += (cnt[l] + G - 1) / G;
 	}
 	part_p[t] = sp;
 	part_i[t] = si;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(1024) void ivf_group_scan_kernel(const int *cnt, in
 		cursor[l] = bp;
 		item_off[l] = bi;
 		bp += cnt[l];
-		bi += (cnt[l] + SQG - 1) / SQG;
+		bi += (cnt[l] + G - 1) / G;
 	}
 	if (t == 1023) {
 		pair_off[nlist] = part_p[1023];
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(1024) void ivf_group_scan_kernel(const int *cnt, in
 		*nitems_out = part_i[1023];
 	}
 }
-__global__ void ivf_group_scatter_kernel(const long long *keys, int npairs, int nprobe, const int *pair_off,
-                                         const int *item_off, int *cursor, int *qidx, int *slots) {
+__global__ void ivf_group_scatter_kernel(const long long *keys, int npairs, int nprobe, int G, int shift,
+                                         const int *pair_off, const int *item_off, int *cursor, int *qidx, int *slots) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= npairs)
 		return;
@@ -493,16 +493,17 @@ __global__ void ivf_group_scatter_kernel(const long long *keys, int npairs, int 
 	const int pos = atomicAdd(&cursor[l], 1);
 	qidx[pos] = i / nprobe;
 	const int rel = pos - pair_off[l];
-	slots[i] = ((item_off[l] + rel / SQG) << 5) | (rel % SQG);
+	slots[i] = ((item_off[l] + rel / G) << shift) | (rel % G);
 }
-__global__ void ivf_group_items_kernel(const int *cnt, const int *pair_off, const int *item_off, const long long *list_off,
-                                       int nlist, int4 *items) {
+__global__ void ivf_group_items_kernel(const int *cnt, const int *pair_off, const int *item_off,
+                                       const long long *list_begin, const long long *list_end, int nlist, int G,
+                                       int4 *items) {
 	const int l = blockIdx.x * blockDim.x + threadIdx.x;
 	if (l >= nlist)
 		return;
 	const int n = cnt[l];
-	for (int g = 0; g * SQG < n; ++g)
-		items[item_off[l] + g] = make_int4((int)list_off[l], (int)list_off[l + 1], pair_off[l] + g * SQG, min(SQG, n - g * SQG));
+	for (int g = 0; g * G < n; ++g)
+		items[item_off[l] + g] = make_int4((int)list_begin[l], (int)list_end[l], pair_off[l] + g * G, min(G, n - g * G));
 }
 
 size_t scan_lds_bytes(int64_t k) {
@@ -545,29 +546,70 @@ size_t ivf_scan_query_pack_bytes(int dp, int nitems) {
 }
 
 // ws_int: [4*(nlist+1) + 4] ints.  Outputs: d_items (<= max_items), d_qidx [npairs], d_slots [npairs], *d_nitems.
-int ivf_group_max_items(int64_t npairs, int64_t nlist) {
-	return (int)(npairs / SQG + nlist + 1);
+// group = query slots per item (20 for the per-pair scan, 128 for the MFMA variant); slot code = item << shift | slot.
+int ivf_group_max_items(int64_t npairs, int64_t nlist, int group) {
+	return (int)(npairs / group + nlist + 1);
 }
 size_t ivf_group_ws_ints(int64_t nlist) {
 	return (size_t)4 * (nlist + 1) + 4;
 }
-void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, const int64_t *d_list_off, int *ws_int,
-                      void *d_items, int *d_qidx, int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st) {
+void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, int group, int shift,
+                      const int64_t *d_list_begin, const int64_t *d_list_end, int *ws_int, void *d_items, int *d_qidx,
+                      int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st) {
 	const int npairs = (int)(nq * nprobe);
 	int *cnt = ws_int, *pair_off = cnt + (nlist + 1), *item_off = pair_off + (nlist + 1), *cursor = item_off + (nlist + 1);
 	int *nitems = cursor + (nlist + 1);
 	MVS_HIP(hipMemsetAsync(cnt, 0, (size_t)(nlist + 1) * sizeof(int), st));
 	hipLaunchKernelGGL(ivf_group_count_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, (const long long *)d_keys,
 	                   npairs, cnt);
-	hipLaunchKernelGGL(ivf_group_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int)nlist, pair_off, item_off, cursor,
-	                   nitems);
+	hipLaunchKernelGGL(ivf_group_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int)nlist, group, pair_off, item_off,
+	                   cursor, nitems);
 	hipLaunchKernelGGL(ivf_group_scatter_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st, (const long long *)d_keys,
-	                   npairs, nprobe, pair_off, item_off, cursor, d_qidx, d_slots);
+	                   npairs, nprobe, group, shift, pair_off, item_off, cursor, d_qidx, d_slots);
 	hipLaunchKernelGGL(ivf_group_items_kernel, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, st, cnt, pair_off,
-	                   item_off, (const long long *)d_list_off, (int)nlist, (int4 *)d_items);
+	                   item_off, (const long long *)d_list_begin, (const long long *)d_list_end, (int)nlist, group,
+	                   (int4 *)d_items);
 	MVS_HIP(hipGetLastError());
 	*d_nitems_out = nitems;
 	*d_cnt_out = cnt;
+}
+
+// the items' queries in MFMA B-fragment order (util_kernels.hip pack_queries_kernel), gathered through qidx:
+// qf[((((item*4 + w)*nch + ch)*(kc/8) + s4)*64 + lane)*4 + e] = x[qidx[qoff + 32w + (lane&31)]][ch*kc + 2*(4*s4+e) + (lane>>5)]
+__global__ void ivf_pack_item_fragments_kernel(const float *x, int d, int kc, int nch, const int4 *items,
+                                               const int *nitems_dev, const int *qidx, float *qf) {
+	if ((int)blockIdx.x >= *nitems_dev)
+		return;
+	const int4 it = items[blockIdx.x];
+	const int ks4 = kc / 8;
+	const int per_item4 = 4 * nch * ks4 * 64;
+	float4 *dst = reinterpret_cast<float4 *>(qf) + (size_t)blockIdx.x * per_item4;
+	for (int i = threadIdx.x; i < per_item4; i += blockDim.x) {
+		const int lane = i & 63;
+		int t = i >> 6;
+		const int s4 = t % ks4;
+		t /= ks4;
+		const int ch = t % nch, w = t / nch;
+		const int slot = w * 32 + (lane & 31);
+		float o[4] = {0.f, 0.f, 0.f, 0.f};
+		if (slot < it.w) {
+			const float *xr = x + (size_t)qidx[it.z + slot] * d;
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int kk = ch * kc + 2 * (4 * s4 + e) + (lane >> 5);
+				o[e] = kk < d ? xr[kk] : 0.f;
+			}
+		}
+		dst[i] = make_float4(o[0], o[1], o[2], o[3]);
+	}
+}
+void launch_ivf_pack_item_fragments(const float *d_x, int d, int kc, int nch, const void *d_items, const int *d_nitems,
+                                    int max_items, const int *d_qidx, float *d_qf, hipStream_t st) {
+	if (max_items <= 0)
+		return;
+	hipLaunchKernelGGL(ivf_pack_item_fragments_kernel, dim3(max_items), dim3(256), 0, st, d_x, d, kc, nch,
+	                   (const int4 *)d_items, d_nitems, d_qidx, d_qf);
+	MVS_HIP(hipGetLastError());
 }
 
 void launch_ivf_scan(int dp, int metric, const float *d_xq, const float *d_rows, int64_t nrows, const int64_t *d_rowids,

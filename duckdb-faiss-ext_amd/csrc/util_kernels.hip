@@ -250,7 +250,8 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 // label order is NOT attempted here: FAISS's own IVF tie order depends on probe order (DESIGN.md "ties").
 template <bool IS_L2>
 __global__ __launch_bounds__(64) void merge_items_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi,
-                                                        const int *__restrict__ slots, int nprobe, int k,
+                                                        const int *__restrict__ slots, int nprobe, int k, int group,
+                                                        int shift,
                                                         const long long *__restrict__ rowids,
                                                         const long long *__restrict__ idmap, float *__restrict__ D,
                                                         long long *__restrict__ I) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64) void merge_items_kernel(const float *__restrict
 			cv[i] = 0.f;
 			ci[i] = -1;
 		} else {
-			const size_t base = ((size_t)(s >> 5) * 20 + (s & 31)) * k + j;
+			const size_t base = ((size_t)(s >> shift) * group + (s & ((1 << shift) - 1))) * k + j;
 			cv[i] = pd[base];
 			ci[i] = pi[base];
 		}
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64) void merge_items_kernel(const float *__restrict
 }
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
                         int64_t k, const int64_t *d_rowids, const int64_t *d_idmap, float *d_D, int64_t *d_I,
-                        hipStream_t st) {
+                        hipStream_t st, int group, int shift) {
 	if (nq <= 0)
 		return;
 	const size_t lds = (size_t)nprobe * k * 8;
@@ -332,12 +333,12 @@ void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, cons
 	if (metric == METRIC_L2) {
 		auto kern = merge_items_kernel<true>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k,
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k, group, shift,
 		                   (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
 	} else {
 		auto kern = merge_items_kernel<false>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k,
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k, group, shift,
 		                   (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
 	}
 	MVS_HIP(hipGetLastError());

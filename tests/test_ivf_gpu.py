@@ -63,6 +63,7 @@ def test_ivf_search_matches_oracle(mf, metric, nprobe, fast_scan):
     g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
     g.ivf_set_centroids(o.ivf_centroids())  # share the centroids: this test is about add + search
     g.set_option("ivf_fast_scan", fast_scan)  # 1: csrc/ivf_scan.hip, 0: the LDS-staged flat_direct item kernel
+    g.set_option("ivf_mfma", 0)  # inner product would default to the MFMA variant (tested separately below)
     for i0 in range(0, 20000, 7000):
         g.add(xb[i0 : i0 + 7000])
     assert g.ntotal == 20000
@@ -168,3 +169,57 @@ def test_ivf_with_hnsw_coarse_quantizer(mf, tmp_path, metric):
 def o_graph(o):
     """HNSW graph of the oracle's coarse quantizer"""
     return o.quantizer_hnsw_graph()
+
+
+@pytest.mark.parametrize("d,nlist", [(64, 16), (128, 8), (200, 16)])
+def test_ivf_inner_product_scans_on_the_mfma_kernel_bit_exact(mf, d, nlist):
+    """inner product: IVFFlatScanner's fvec_inner_product is the k-ordered chain the MFMA computes, so the list scan
+    runs as a segmented variant of the fused Flat kernel (items of <= 128 queries per list, lists padded to 64 rows
+    in the pair-interleaved format) and still matches the oracle bit for bit; selectors through IDMap included"""
+    n = 20000
+    xb = _clustered(n, d, 61, ncent=64, sigma=0.2)
+    xq = _clustered(300, d, 62, ncent=64, sigma=0.2)
+    ids = np.arange(n, dtype=np.int64) * 2 + 9
+    o = orc.Index(d, f"IDMap,IVF{nlist},Flat", IP)
+    g = mf.index_factory(d, f"IDMap,IVF{nlist},Flat", IP)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    for i0 in range(0, n, 6000):
+        o.add_with_ids(xb[i0 : i0 + 6000], ids[i0 : i0 + 6000])
+        g.add_with_ids(xb[i0 : i0 + 6000], ids[i0 : i0 + 6000])
+    keep = ids[np.arange(n) % 3 == 0]
+    for nprobe, k, sel in ((1, 10, None), (4, 10, None), (nlist, 40, None), (4, 10, ("batch", keep))):
+        Do, Io = o.search(xq, k, nprobe=nprobe, sel=sel)
+        D, I = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"].startswith("ivf_mfma_scan")
+        ok = _no_tie_rows(Do)
+        assert ok.sum() > 250
+        assert np.array_equal(I[ok], Io[ok]), (nprobe, k, sel and sel[0])
+        assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
+    g.set_option("ivf_mfma", 0)  # the per-pair scan kernel gives the same answers
+    D2, I2 = g.search(xq, 10, nprobe=4)
+    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+    D1, I1 = o.search(xq, 10, nprobe=4)
+    ok = _no_tie_rows(D1)
+    assert np.array_equal(I2[ok], I1[ok])
+
+
+def test_ivf_l2_mfma_mode_is_recall_equivalent(mf):
+    """L2 on the MFMA variant (option ivf_mfma = 1) evaluates ||x||^2 + ||y||^2 - 2<x,y> instead of the scanner's
+    sum (x-y)^2: the same neighbours up to rounding-level near-ties, distances within 1e-4 relative"""
+    d, nlist, n = 128, 32, 40000
+    xb = _clustered(n, d, 71, ncent=128, sigma=0.15)
+    xq = _clustered(500, d, 72, ncent=128, sigma=0.15)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+    g.train(xb)
+    g.add(xb)
+    De, Ie = g.search(xq, 10, nprobe=8)
+    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")  # default for L2: the scanner's arithmetic
+    g.set_option("ivf_mfma", 1)
+    Dm, Im = g.search(xq, 10, nprobe=8)
+    assert g.last_kernel_info()["name"].startswith("ivf_mfma_scan")
+    overlap = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(Im, Ie)])
+    assert overlap >= 0.999, overlap
+    same = Im == Ie
+    np.testing.assert_allclose(Dm[same], De[same], rtol=1e-4, atol=1e-6)
+    assert np.all(np.diff(Dm, axis=1) >= 0)
