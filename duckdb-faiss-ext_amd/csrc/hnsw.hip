@@ -171,6 +171,36 @@ __device__ __forceinline__ float eval_lanes(const QV<NI> &q, const float *vecs, 
 
 // keys[0..n) ascending; inserts nk, keeps at most cap entries (the largest falls off).  Returns the new count.
 __device__ __forceinline__ int sorted_insert(u64 *keys, int n, int cap, u64 nk, int lane) {
+	if (cap <= 256) {
+		// every lane reads its (<= 4) elements once, the position is the popcount of "smaller than nk", and the
+		// elements that are not smaller move one slot to the right -- all reads before all writes, one fence
+		u64 v[4];
+		int pos = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			v[b] = ~0ull;
+			if (b * 64 < n) { // wave-uniform
+				const int i = b * 64 + lane;
+				if (i < n)
+					v[b] = keys[i];
+				pos += (int)__popcll(__builtin_amdgcn_ballot_w64(i < n && v[b] < nk));
+			}
+		}
+		if (pos >= cap)
+			return n;
+		wave_fence();
+#pragma unroll
+		for (int b = 0; b < 4; ++b)
+			if (b * 64 < n) {
+				const int i = b * 64 + lane;
+				if (i < n && !(v[b] < nk) && i + 1 < cap)
+					keys[i + 1] = v[b];
+			}
+		if (lane == 0)
+			keys[pos] = nk;
+		wave_fence();
+		return n < cap ? n + 1 : cap;
+	}
 	int pos = 0;
 	for (int base = 0; base < n; base += 64) {
 		const int i = base + lane;
