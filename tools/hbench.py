@@ -73,6 +73,7 @@ def main():
     _, Igt = fl.search_torch(xq[:ns].contiguous(), args.k)
     torch.cuda.synchronize()
     Igt = Igt.cpu().numpy()
+    nl0, ms0 = 0, 0.0  # kernel_time_stats() is cumulative over the life of the index
     for ef in [int(e) for e in args.efs.split(",")]:
         D, I = ix.search_torch(xq, args.k, efSearch=ef)
         torch.cuda.synchronize()
@@ -83,7 +84,9 @@ def main():
         torch.cuda.synchronize()
         wall = (time.time() - t1) / args.reps
         ix.set_kernel_timing(False)
-        nl, ms = ix.kernel_time_stats()
+        nl1, ms1 = ix.kernel_time_stats()
+        nl, ms = nl1 - nl0, ms1 - ms0
+        nl0, ms0 = nl1, ms1
         ki = ix.last_kernel_info()
         Ih = I[:ns].cpu().numpy()
         rec = np.mean([len(set(a.tolist()) & set(b.tolist())) / args.k for a, b in zip(Ih, Igt)])
