@@ -312,3 +312,20 @@ def test_filtered_inner_product_runs_on_the_fused_kernel(mf, d, nb, nq, k, idmap
         assert ok.sum() >= nq // 2
         assert np.all(np.isin(I[I >= 0], keep))
         assert_same_results(D[ok], I[ok], Do[ok], Io[ok], False, what=f"filtered IP on MFMA d={d} {sel[0]} idmap={idmap}")
+
+
+def test_small_batch_large_k_on_the_fused_kernel(mf):
+    """few query blocks make the planner split the rows many ways; the split count must still respect the merge
+    kernel's LDS budget when k is large"""
+    xb, xq = _data(300000, 24, 64, seed=5, center=True)
+    for metric, k in ((L2, 80), (IP, 64)):
+        ix = mf.index_factory(64, "Flat", metric)
+        ix.add(xb)
+        D, I = ix.search(xq, k)
+        assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+        Do, Io = orc.flat_search(metric, xb, xq, k)
+        ok = np.ones(len(xq), dtype=bool)
+        if metric == IP:
+            Dk1, _ = orc.flat_search(metric, xb, xq, k + 1)
+            ok = Dk1[:, k - 1] != Dk1[:, k]
+        assert_same_results(D[ok], I[ok], Do[ok], Io[ok], metric == L2, what=f"small batch large k m={metric}")
