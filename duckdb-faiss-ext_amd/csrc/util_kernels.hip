@@ -1,6 +1,8 @@
 // csrc/util_kernels.hip -- K1 (row norms), query fragment packing, K4 (partial-list merge), synthetic data.
 #include "common.h"
 
+#include <algorithm>
+
 namespace mvs {
 
 // ---- K1: squared norms, k-ordered fma chain (bit-exact with oracle orc_norms) ------------------------
@@ -248,78 +250,100 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 // slots[q*nprobe + p] = (item << 5 | slot) of probe p, or -1; partial lists live at [item][20][k].
 // Order: L2 (dist asc, row position asc); IP (score desc, row position asc), equal scores printed in descending
 // label order is NOT attempted here: FAISS's own IVF tie order depends on probe order (DESIGN.md "ties").
+// Probes are merged in chunks of `pchunk` lists: LDS holds the running best k (front) plus one chunk of candidates, so
+// any nprobe (up to nlist) fits.
 template <bool IS_L2>
 __global__ __launch_bounds__(64) void merge_items_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi,
-                                                        const int *__restrict__ slots, int nprobe, int k, int group,
-                                                        int shift,
-                                                        const long long *__restrict__ rowids,
+                                                        const int *__restrict__ slots, int nprobe, int pchunk, int k,
+                                                        int group, int shift, const long long *__restrict__ rowids,
                                                         const long long *__restrict__ idmap, float *__restrict__ D,
                                                         long long *__restrict__ I) {
 	extern __shared__ __attribute__((aligned(16))) float sm[];
 	const long long q = blockIdx.x;
 	const int lane = threadIdx.x;
-	const int C = nprobe * k;
+	const int CAP = (pchunk + 1) * k; // [0,k): running best, [k, k + chunk*k): candidates of the current chunk
 	float *cv = sm;
-	int *ci = (int *)(sm + C);
-	for (int i = lane; i < C; i += 64) {
-		const int p = i / k, j = i - p * k;
-		const int s = slots[q * nprobe + p];
-		if (s < 0) {
-			cv[i] = 0.f;
-			ci[i] = -1;
-		} else {
-			const size_t base = ((size_t)(s >> shift) * group + (s & ((1 << shift) - 1))) * k + j;
-			cv[i] = pd[base];
-			ci[i] = pi[base];
-		}
-	}
-	__syncthreads();
+	int *ci = (int *)(sm + CAP);
+	float *ov = (float *)(ci + CAP); // selection output of a pass
+	int *oi = (int *)(ov + k);
 	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
-	for (int r = 0; r < k; ++r) {
-		float bv = neutral;
-		int bi = 0x7fffffff, bp = -1;
-		for (int i = lane; i < C; i += 64) {
-			const float v = cv[i];
-			const int id = ci[i];
-			if (id < 0)
-				continue;
-			const bool better = IS_L2 ? (v < bv || (v == bv && id < bi)) : (v > bv || (v == bv && id < bi));
-			if (bp < 0 || better) {
-				bv = v;
-				bi = id;
-				bp = i;
+	for (int i = lane; i < k; i += 64) {
+		cv[i] = neutral;
+		ci[i] = -1;
+	}
+	for (int p0 = 0; p0 < nprobe; p0 += pchunk) {
+		const int np = nprobe - p0 < pchunk ? nprobe - p0 : pchunk;
+		const int C = (np + 1) * k;
+		for (int i = k + lane; i < C; i += 64) {
+			const int p = p0 + (i - k) / k, j = (i - k) % k;
+			const int s = slots[q * nprobe + p];
+			if (s < 0) {
+				cv[i] = 0.f;
+				ci[i] = -1;
+			} else {
+				const size_t base = ((size_t)(s >> shift) * group + (s & ((1 << shift) - 1))) * k + j;
+				cv[i] = pd[base];
+				ci[i] = pi[base];
 			}
-		}
-#pragma unroll
-		for (int off = 32; off >= 1; off >>= 1) {
-			const float ov_ = __shfl_xor(bv, off);
-			const int oi_ = __shfl_xor(bi, off);
-			const int op_ = __shfl_xor(bp, off);
-			bool take;
-			if (op_ < 0)
-				take = false;
-			else if (bp < 0)
-				take = true;
-			else
-				take = IS_L2 ? (ov_ < bv || (ov_ == bv && oi_ < bi)) : (ov_ > bv || (ov_ == bv && oi_ < bi));
-			if (take) {
-				bv = ov_;
-				bi = oi_;
-				bp = op_;
-			}
-		}
-		if (lane == 0) {
-			long long label = -1;
-			if (bp >= 0) {
-				ci[bp] = -1;
-				label = rowids[bi];
-				if (idmap)
-					label = idmap[label];
-			}
-			D[q * k + r] = bp >= 0 ? bv : neutral;
-			I[q * k + r] = label;
 		}
 		__syncthreads();
+		for (int r = 0; r < k; ++r) {
+			float bv = neutral;
+			int bi = 0x7fffffff, bp = -1;
+			for (int i = lane; i < C; i += 64) {
+				const float v = cv[i];
+				const int id = ci[i];
+				if (id < 0)
+					continue;
+				const bool better = IS_L2 ? (v < bv || (v == bv && id < bi)) : (v > bv || (v == bv && id < bi));
+				if (bp < 0 || better) {
+					bv = v;
+					bi = id;
+					bp = i;
+				}
+			}
+#pragma unroll
+			for (int off = 32; off >= 1; off >>= 1) {
+				const float ov_ = __shfl_xor(bv, off);
+				const int oi_ = __shfl_xor(bi, off);
+				const int op_ = __shfl_xor(bp, off);
+				bool take;
+				if (op_ < 0)
+					take = false;
+				else if (bp < 0)
+					take = true;
+				else
+					take = IS_L2 ? (ov_ < bv || (ov_ == bv && oi_ < bi)) : (ov_ > bv || (ov_ == bv && oi_ < bi));
+				if (take) {
+					bv = ov_;
+					bi = oi_;
+					bp = op_;
+				}
+			}
+			if (lane == 0) {
+				if (bp >= 0)
+					ci[bp] = -1;
+				ov[r] = bp >= 0 ? bv : neutral;
+				oi[r] = bp >= 0 ? bi : -1;
+			}
+			__syncthreads();
+		}
+		for (int i = lane; i < k; i += 64) { // the pass result becomes the running best
+			cv[i] = ov[i];
+			ci[i] = oi[i];
+		}
+		__syncthreads();
+	}
+	for (int r = lane; r < k; r += 64) {
+		const int bi = ci[r];
+		long long label = -1;
+		if (bi >= 0) {
+			label = rowids[bi];
+			if (idmap)
+				label = idmap[label];
+		}
+		D[q * k + r] = bi >= 0 ? cv[r] : neutral;
+		I[q * k + r] = label;
 	}
 }
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,
@@ -327,19 +351,21 @@ void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, cons
                         hipStream_t st, int group, int shift) {
 	if (nq <= 0)
 		return;
-	const size_t lds = (size_t)nprobe * k * 8;
-	if (lds > 160 * 1024)
-		throw_faiss(__func__, __FILE__, "IVF merge: nprobe*k = %lld too large", (long long)nprobe * k);
+	// candidates of one pass: at most ~8k entries (64 KB of LDS)
+	int pchunk = (int)std::max<int64_t>(1, std::min<int64_t>(nprobe, 8192 / k));
+	const size_t lds = ((size_t)(pchunk + 1) * k + k) * 8;
+	if (lds > 150 * 1024)
+		throw_faiss(__func__, __FILE__, "IVF merge: k = %lld too large", (long long)k);
 	if (metric == METRIC_L2) {
 		auto kern = merge_items_kernel<true>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k, group, shift,
-		                   (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, pchunk, (int)k, group,
+		                   shift, (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
 	} else {
 		auto kern = merge_items_kernel<false>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, (int)k, group, shift,
-		                   (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, pchunk, (int)k, group,
+		                   shift, (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
 	}
 	MVS_HIP(hipGetLastError());
 }

@@ -223,3 +223,25 @@ def test_ivf_l2_mfma_mode_is_recall_equivalent(mf):
     same = Im == Ie
     np.testing.assert_allclose(Dm[same], De[same], rtol=1e-4, atol=1e-6)
     assert np.all(np.diff(Dm, axis=1) >= 0)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_every_list_probed_large_nprobe_times_k(mf, metric):
+    """nprobe = nlist (FAISS clamps larger values): nprobe*k candidates per query exceed one LDS pass of the merge,
+    which then runs in chunks; probing every list is exhaustive, so the result also equals the Flat per-pair search"""
+    d, nlist, n, k = 16, 256, 30000, 40
+    xb = _clustered(n, d, 81, ncent=300, sigma=0.3)
+    xq = _clustered(60, d, 82, ncent=300, sigma=0.3)
+    o = orc.Index(d, f"IVF{nlist},Flat", metric)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    o.add(xb)
+    g.add(xb)
+    D, I = g.search(xq, k, nprobe=nlist + 7)
+    Do, Io = o.search(xq, k, nprobe=nlist + 7)
+    ok = _no_tie_rows(Do)
+    assert ok.sum() > 40
+    assert np.array_equal(I[ok], Io[ok]) and np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
+    Df, If = orc.flat_search(metric, xb, xq, k, force_path=orc.PATH_PAIR)
+    assert np.array_equal(I[ok], If[ok])
