@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--index", default="Flat", help="factory string (Flat | IDMap,Flat | IVF4096,Flat ...)")
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--efsearch", type=int, default=128, help="SearchParametersHNSW::efSearch (HNSW indexes)")
+    ap.add_argument("--efconstruction", type=int, default=0, help="hnsw.efConstruction (0 = FAISS default 40)")
     ap.add_argument("--normalize", action="store_true", help="L2-normalise rows and queries (embedding-like, C4/C5)")
     ap.add_argument("--chunk", type=int, default=0, help="queries per search call (2048 = DuckDB DataChunk); 0 = one batch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (rank 0, N=1 only)")
@@ -95,6 +96,8 @@ def main():
         ix.set_option(key, int(v))
     is_ivf = "IVF" in args.index
     is_hnsw = "HNSW" in args.index
+    if is_hnsw and not is_ivf and args.efconstruction > 0:
+        ix.set_ef_construction(args.efconstruction)
     with_ids = args.index.startswith("IDMap")
     if is_hnsw:
         # the graph walk does not shard -> replicas only: every rank holds the whole graph + vectors and
@@ -231,6 +234,7 @@ def main():
                 else "none",
                 "build_seconds": round(t_build, 2),
                 "options": args.opt,
+                "efConstruction": (args.efconstruction or 40) if is_hnsw else None,
             },
         }
         # ---- roofline of the dominant kernel (per launch, HIP events on the launch stream) ----------
