@@ -61,6 +61,7 @@ struct FlatSearchPlan {
 	int grid;
 	size_t lds_bytes;
 	bool xcd_map;
+	bool global_lists; // k-lists in the partial-result buffers (global memory) instead of LDS
 };
 
 // device views -------------------------------------------------------------------------------
@@ -90,10 +91,11 @@ void launch_query_norms(const float *d_x, int64_t n, int d, float *d_out, hipStr
 
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 // partial lists: pd [nsplit][nq][k] f32, pi [nsplit][nq][k] i32
-void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
+void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p_in, int metric, const float *d_qf, const float *d_qnorm,
                       int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
                       const SelectorDev *sel = nullptr, const int64_t *d_idmap = nullptr); // sel: inner product only
 int64_t flat_mfma_max_k(const FlatGeom &g);
+int64_t flat_mfma_max_k_lds(const FlatGeom &g); // selector / IVF-item instances keep their k-lists in LDS
 // IVF list scan as a segmented variant of the fused kernel (csrc/flat_mfma.hip, ITEMS instances)
 bool flat_mfma_items_supported(const FlatGeom &g, int64_t k);
 size_t flat_mfma_item_query_floats(const FlatGeom &g, int max_items);
@@ -106,6 +108,7 @@ void launch_flat_mfma_items(const FlatGeom &g, int metric, const float *d_qf, co
 extern int g_mfma_variant;
 extern int g_mfma_nsplit;
 extern int g_mfma_warm;
+extern int g_mfma_global_lists;
 
 // direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic
 struct DirectPlan {

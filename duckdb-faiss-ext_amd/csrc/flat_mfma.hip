@@ -354,7 +354,10 @@ typedef __attribute__((address_space(1))) const float glb_f32;
 // STREAM = true  (d  > 128): NT = 4 (128-row tiles), k streamed in units of KC = 64; the accumulators persist over the
 //   units of a tile and the B fragments of the NEXT unit are refilled group by group behind the MFMAs that just
 //   consumed the current ones (one 64-byte-per-lane register set, no double buffer).
-template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false, bool SEL = false, bool ITEMS = false>
+// GL: the per-query k-lists live directly in the partial-result buffers in global memory (L2-resident; touched only by
+// the rare insertion path) instead of LDS, so that k > 12 does not push the workgroup over half a CU's LDS.
+template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false, bool SEL = false, bool ITEMS = false,
+          bool GL = false>
 __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
 	constexpr int KC = 2 * KSTEPS, BN = 32 * NT;
 	// LDS image of a tile: [64 rows][C 16-byte chunks], UNPADDED so that one LDS-DMA dwordx4 instruction (1 KiB per
@@ -373,9 +376,9 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	float *tbuf = smem;               // [2][BN][KC]  (swizzled, see above)
 	float *nbuf = smem + 2 * BN * KC; // [2][BN]
-	float *ld = nbuf + 2 * BN;        // [128][k]
-	int *li = (int *)(ld + QBLOCK * a.k);
-	float *lthr = (float *)(li + QBLOCK * a.k);
+	float *ld = nbuf + 2 * BN;        // [128][k]  (absent with GL)
+	int *li = (int *)(ld + (GL ? 0 : QBLOCK * a.k));
+	float *lthr = (float *)(li + (GL ? 0 : QBLOCK * a.k));
 	int *lthrid = (int *)(lthr + QBLOCK);
 	int *lpos = lthrid + QBLOCK;
 
@@ -421,11 +424,15 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 
 	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
 	float thr = qvalid ? neutral : (IS_L2 ? -INFINITY : INFINITY);
+	const size_t ob = ITEMS ? ((size_t)blockIdx.x * QBLOCK + ql) * k : ((size_t)split * a.nq + (qvalid ? q : 0)) * k;
+	float *ldq = GL ? a.pd + ob : ld + ql * k;
+	int *liq = GL ? (int *)(a.pi + ob) : li + ql * k;
 	if (h == 0) {
-		for (int j = 0; j < k; ++j) {
-			ld[ql * k + j] = neutral;
-			li[ql * k + j] = -1;
-		}
+		if (!GL || qvalid)
+			for (int j = 0; j < k; ++j) {
+				ldq[j] = neutral;
+				liq[j] = -1;
+			}
 		lthr[ql] = thr;
 		lthrid[ql] = -1;
 		lpos[ql] = 0;
@@ -614,20 +621,19 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 					}
 				}
 				tile_epilogue<NT, IS_L2, (ABL & 8) != 0, SEL>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
-				                                              a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ld + ql * k,
-				                                              li + ql * k, k, lthr + ql, lthrid + ql, lpos + ql, h, rowmask);
+				                                              a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ldq, liq, k,
+				                                              lthr + ql, lthrid + ql, lpos + ql, h, rowmask);
 			}
 		}
 		__syncthreads(); // also drains this unit's LDS-DMA (vmcnt(0)) before the next unit reads it
 	}
 
-	if (h == 0 && qvalid) {
-		const size_t ob = ITEMS ? ((size_t)blockIdx.x * QBLOCK + ql) * k : ((size_t)split * a.nq + q) * k;
+	if (!GL && h == 0 && qvalid) {
 		float *od = a.pd + ob;
 		int32_t *oi = a.pi + ob;
 		for (int j = 0; j < k; ++j) {
-			od[j] = ld[ql * k + j];
-			oi[j] = li[ql * k + j];
+			od[j] = ldq[j];
+			oi[j] = liq[j];
 		}
 	}
 }
@@ -664,19 +670,25 @@ size_t qfrag_floats(const FlatGeom &g, int64_t nq) {
 	return (size_t)nblk32 * 32 * g.dp;
 }
 
-static size_t mfma_lds_bytes(const FlatGeom &g, int64_t k) {
+static size_t mfma_lds_bytes(const FlatGeom &g, int64_t k, bool global_lists = false) {
 	const size_t bn = g.bn();
 	const size_t lda = (size_t)g.kc; // unpadded, swizzled rows
-	return (2 * bn * lda + 2 * bn) * sizeof(float) + (size_t)QBLOCK * k * 8 + QBLOCK * 12;
+	return (2 * bn * lda + 2 * bn) * sizeof(float) + (global_lists ? 0 : (size_t)QBLOCK * k * 8) + QBLOCK * 12;
 }
 
-int64_t flat_mfma_max_k(const FlatGeom &g) {
+// largest k with the k-lists in LDS (selector and IVF item instances) / at all (lists in global memory beyond 12)
+int64_t flat_mfma_max_k_lds(const FlatGeom &g) {
 	const size_t fixed = mfma_lds_bytes(g, 0);
 	return (int64_t)((160 * 1024 - fixed) / (QBLOCK * 8));
+}
+int64_t flat_mfma_max_k(const FlatGeom &) {
+	return 256;
 }
 
 int g_mfma_nsplit = 0; // 0 = heuristic; >0 forces the split count (tuning / tests)
 int g_mfma_warm = 0;   // > 1: warm-up pre-pass over n / g_mfma_warm rows (experiment)
+int g_mfma_global_lists = 1; // 1: k-lists in global memory for every k > 12 (10-16 % faster than one workgroup per CU
+                             // with LDS lists, measured k = 16...80); 0 / -1: only when the LDS cannot hold them (k > 88)
 
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
 	FlatSearchPlan p;
@@ -725,7 +737,11 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	p.split_rows = tiles_per_split * bn;
 	p.nsplit = (int)nsplit;
 	p.grid = p.nqb * p.nsplit;
-	p.lds_bytes = mfma_lds_bytes(g, k);
+	// two workgroups per CU need <= ~80 KB each: with the 64 KB of tile buffers that is k <= 12 for LDS-resident lists
+	p.global_lists = g_mfma_global_lists < 0 ? k > flat_mfma_max_k_lds(g) : (g_mfma_global_lists > 0 && k > 12);
+	if (k > flat_mfma_max_k_lds(g))
+		p.global_lists = true;
+	p.lds_bytes = mfma_lds_bytes(g, k, p.global_lists);
 	return p;
 }
 
@@ -756,6 +772,19 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 		MVS_HIP(hipGetLastError());
 		return;
 	}
+	if (p.global_lists && a.sel.kind == MVS_SEL_NONE) {
+		if (metric == METRIC_L2) {
+			auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, 2, false, false, false, true>;
+			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+		} else {
+			auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, 2, false, false, false, true>;
+			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+		}
+		MVS_HIP(hipGetLastError());
+		return;
+	}
 	if (metric == METRIC_L2) {
 		auto kern = flat_mfma_resident_kernel<KSTEPS, true>;
 		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
@@ -783,6 +812,19 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 	if constexpr (RESIDENT) {
 		launch_resident_v2<KSTEPS>(metric, a, p, st);
 	} else {
+		if (p.global_lists && a.sel.kind == MVS_SEL_NONE) {
+			if (metric == METRIC_L2) {
+				auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, NT, true, false, false, true>;
+				MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+				hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+			} else {
+				auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, NT, true, false, false, true>;
+				MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+				hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+			}
+			MVS_HIP(hipGetLastError());
+			return;
+		}
 		if (metric == METRIC_L2) {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, NT, true>;
 			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
@@ -800,7 +842,7 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 	}
 }
 
-void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, const float *d_qf, const float *d_qnorm,
+void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p_in, int metric, const float *d_qf, const float *d_qnorm,
                       int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
                       const SelectorDev *sel, const int64_t *d_idmap) {
 	if (nq <= 0)
@@ -810,9 +852,14 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 	if (gtotal > 0)
 		hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal,
 		                   stride, (int)k, metric == METRIC_L2 ? 1 : 0);
+	FlatSearchPlan p = p_in;
 	MfmaArgs a;
 	memset(&a, 0, sizeof a);
 	if (sel && sel->kind != MVS_SEL_NONE) {
+		if (k > flat_mfma_max_k_lds(g))
+			throw_faiss("mvs::launch_flat_mfma", __FILE__, "k = %lld too large for the selector instances", (long long)k);
+		p.global_lists = false; // the SEL instances keep their k-lists in LDS
+		p.lds_bytes = mfma_lds_bytes(g, k, false);
 		if (metric != METRIC_IP)
 			throw_faiss("mvs::launch_flat_mfma", __FILE__, "the fused kernel takes a selector for inner product only");
 		a.sel = *sel;
@@ -881,7 +928,7 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 // (pair-interleaved, lists padded to 64 rows), the items' queries packed into B-fragment order per item.  Distances
 // follow the Flat BLAS-branch arithmetic (inner product: the exact k-ordered chain; L2: ||x||^2 + ||y||^2 - 2<x,y>).
 bool flat_mfma_items_supported(const FlatGeom &g, int64_t k) {
-	return (g.nch > 1 || g.kc >= 64) && k <= flat_mfma_max_k(g);
+	return (g.nch > 1 || g.kc >= 64) && k <= flat_mfma_max_k_lds(g);
 }
 size_t flat_mfma_item_query_floats(const FlatGeom &g, int max_items) {
 	return (size_t)max_items * QBLOCK * g.dp;

@@ -373,8 +373,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	// masks the rejected rows in its epilogue.  (L2 + selector is Sum (x-y)^2 per pair: packed scan kernel.)
 	// The same identity covers small inner-product batches (nq < 20, FAISS's per-pair branch): from 8 queries on the
 	// MFMA kernel beats the per-pair kernels even with a mostly empty 128-query block.
-	const bool ip_on_mfma = metric == METRIC_IP && (has_sel || nq < 20) && nq >= 8 && k <= mfma_kmax && !force_direct &&
-	                        !force_staged;
+	const bool ip_on_mfma = metric == METRIC_IP && (has_sel || nq < 20) && nq >= 8 &&
+	                        k <= (has_sel ? flat_mfma_max_k_lds(geom) : mfma_kmax) && !force_direct && !force_staged;
 	const bool direct = ((has_sel || nq < 20) && !ip_on_mfma) || k > mfma_kmax || force_direct;
 	FlatDB db {vecs, norms, ntotal};
 	memset(&kinfo, 0, sizeof kinfo);
@@ -1095,6 +1095,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "force_direct")) {
 		force_direct = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "mfma_global_lists")) {
+		g_mfma_global_lists = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "mfma_warm")) {

@@ -329,3 +329,21 @@ def test_small_batch_large_k_on_the_fused_kernel(mf):
             Dk1, _ = orc.flat_search(metric, xb, xq, k + 1)
             ok = Dk1[:, k - 1] != Dk1[:, k]
         assert_same_results(D[ok], I[ok], Do[ok], Io[ok], metric == L2, what=f"small batch large k m={metric}")
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,k", [(128, 13), (128, 100), (64, 200), (200, 150)])
+def test_k_beyond_12_keeps_lists_in_global_memory(mf, metric, d, k):
+    """k > 12: the per-query k-lists of the fused kernel live in the partial-result buffers (global memory) so that two
+    workgroups still fit a CU; the answers must not change"""
+    xb, xq = _data(40000, 150, d, seed=k, center=True)
+    ix = mf.index_factory(d, "Flat", metric)
+    ix.add(xb)
+    D, I = ix.search(xq, k)
+    assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+    Do, Io = orc.flat_search(metric, xb, xq, k)
+    ok = np.ones(len(xq), dtype=bool)
+    if metric == IP:
+        Dk1, _ = orc.flat_search(metric, xb, xq, k + 1)
+        ok = Dk1[:, k - 1] != Dk1[:, k]
+    assert_same_results(D[ok], I[ok], Do[ok], Io[ok], metric == L2, what=f"global k-lists d={d} k={k} m={metric}")
