@@ -7,15 +7,16 @@
 #include "index.h"
 
 #include <algorithm>
+#include <thread>
 
 namespace mvs {
 
-void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
-                       int64_t *I_out) {
+static void merge_range(int metric, int64_t q0, int64_t q1, int64_t n, int64_t k, int nshard, const float *D,
+                        const int64_t *I, float *D_out, int64_t *I_out) {
 	const bool is_l2 = metric == METRIC_L2;
 	const float neutral = is_l2 ? FLT_MAX : -FLT_MAX;
 	std::vector<int> pos((size_t)nshard);
-	for (int64_t q = 0; q < n; ++q) {
+	for (int64_t q = q0; q < q1; ++q) {
 		// shard lists are sorted: classic k-way merge by repeatedly taking the best head
 		std::fill(pos.begin(), pos.end(), 0);
 		int64_t m = 0;
@@ -84,6 +85,22 @@ void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float
 			I_out[q * k + m] = -1;
 		}
 	}
+}
+
+// queries are independent: the merge runs on up to 16 host threads (it sits on the critical path of every multi-GPU
+// search step, after the all-gather)
+void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
+                       int64_t *I_out) {
+	int nt = (int)std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / 512 + 1);
+	if (nt <= 1) {
+		merge_range(metric, 0, n, n, k, nshard, D, I, D_out, I_out);
+		return;
+	}
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; ++t)
+		th.emplace_back(merge_range, metric, n * t / nt, n * (t + 1) / nt, n, k, nshard, D, I, D_out, I_out);
+	for (auto &x : th)
+		x.join();
 }
 
 } // namespace mvs
