@@ -7,7 +7,11 @@ import pytest
 
 from oracle import oracle as orc
 
+import os
+
 pytestmark = pytest.mark.gpu
+# MVS_FUZZ_SCALE=4 runs four times as many seeds (one-off soak runs)
+_SCALE = int(os.environ.get("MVS_FUZZ_SCALE", "1"))
 L2, IP = orc.METRIC_L2, orc.METRIC_INNER_PRODUCT
 
 
@@ -37,7 +41,7 @@ def _rows_without_boundary_ties(D, Dk1, k):
     return Dk1[:, k - 1] != Dk1[:, k]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_flat_fuzz(mf, seed):
     rs = np.random.RandomState(1000 + seed)
     d = int(rs.choice([1, 3, 8, 17, 32, 64, 100, 128, 130, 200, 300]))
@@ -66,7 +70,7 @@ def test_flat_fuzz(mf, seed):
     assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32)), what
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * _SCALE))
 def test_ivf_fuzz(mf, seed):
     rs = np.random.RandomState(2000 + seed)
     d = int(rs.choice([4, 8, 16, 20, 33, 64, 96, 128, 200]))
@@ -96,7 +100,7 @@ def test_ivf_fuzz(mf, seed):
     assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32)), what
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * _SCALE))
 def test_hnsw_fuzz(mf, seed):
     rs = np.random.RandomState(3000 + seed)
     d = int(rs.choice([2, 5, 16, 31, 64, 100, 260, 520]))
