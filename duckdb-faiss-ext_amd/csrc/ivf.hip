@@ -70,6 +70,13 @@ __global__ void ivf_gather_plain_kernel(const float *src, int sdp, const int *pe
 	const int p = perm[r];
 	dst[i] = p >= 0 ? src[(size_t)p * sdp + j] : 0.f;
 }
+__global__ void ivf_fill_empty_kernel(float *D, long long *I, long long n, float neutral) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		D[i] = neutral;
+		I[i] = -1;
+	}
+}
 __global__ void ivf_gather_ids_kernel(const long long *src, const int *perm, long long n, long long *dst) {
 	const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r < n)
@@ -412,6 +419,15 @@ public:
 			            "Error: 'nprobe > 0' failed");
 		// our stream carries the adds / list build; the caller's stream carries the queries
 		stream_wait(stream, st);
+		if (ntotal == 0) { // trained but empty: every heap stays at its neutral value
+			const long long tot = nq * k;
+			hipLaunchKernelGGL(ivf_fill_empty_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, d_D,
+			                   (long long *)d_I, tot, metric == METRIC_L2 ? FLT_MAX : -FLT_MAX);
+			MVS_HIP(hipGetLastError());
+			memset(&kinfo, 0, sizeof kinfo);
+			stream_wait(st, stream);
+			return;
+		}
 		build_lists();
 		// 1. coarse quantisation on the whole batch (FAISS slices the batch by OpenMP thread; see oracle ivf_search)
 		ws_cD.reserve((size_t)nq * np * sizeof(float));

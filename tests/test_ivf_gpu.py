@@ -245,3 +245,27 @@ def test_every_list_probed_large_nprobe_times_k(mf, metric):
     assert np.array_equal(I[ok], Io[ok]) and np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
     Df, If = orc.flat_search(metric, xb, xq, k, force_path=orc.PATH_PAIR)
     assert np.array_equal(I[ok], If[ok])
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_ivf_edge_cases_empty_and_tiny(mf, metric):
+    """trained but empty index, a single stored row, k larger than what the probed lists hold, one query"""
+    d, nlist = 64, 8
+    xb = _clustered(2000, d, 91, ncent=8, sigma=0.2)
+    o = orc.Index(d, f"IVF{nlist},Flat", metric)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    neutral = np.finfo(np.float32).max * (1 if metric == L2 else -1)
+    D, I = g.search(xb[:3], 5, nprobe=4)
+    assert np.all(I == -1) and np.all(D == neutral)
+    o.add(xb[:1])
+    g.add(xb[:1])
+    for a in (o, g):
+        D, I = a.search(xb[:2], 5, nprobe=nlist)
+        assert np.all(I[:, 0] == 0) and np.all(I[:, 1:] == -1) and np.all(D[:, 1:] == neutral)
+    o.add(xb[1:40])
+    g.add(xb[1:40])
+    Do, Io = o.search(xb[5:6], 30, nprobe=2)  # one query, k beyond the rows of the two probed lists
+    D, I = g.search(xb[5:6], 30, nprobe=2)
+    assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
