@@ -347,3 +347,22 @@ def test_k_beyond_12_keeps_lists_in_global_memory(mf, metric, d, k):
         Dk1, _ = orc.flat_search(metric, xb, xq, k + 1)
         ok = Dk1[:, k - 1] != Dk1[:, k]
     assert_same_results(D[ok], I[ok], Do[ok], Io[ok], metric == L2, what=f"global k-lists d={d} k={k} m={metric}")
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("desc", ["Flat", "IDMap,Flat", "IDMap,IVF4,Flat", "IDMap,HNSW8"])
+def test_selectors_that_reject_everything(mf, metric, desc):
+    """an empty id batch / an all-zero or zero-length bitmap: every slot comes back (-1, neutral) on every path"""
+    d, n = 32, 3000
+    xb, xq = _data(n, 30, d, seed=3, center=True)
+    ids = np.arange(n, dtype=np.int64) + 1000
+    ix = mf.index_factory(d, desc, metric)
+    ix.train(xb)
+    ix.add_with_ids(xb, ids) if desc.startswith("IDMap") else ix.add(xb)
+    neutral = np.finfo(np.float32).max * (1 if metric == L2 else -1)
+    for sel in (("batch", np.zeros(0, dtype=np.int64)), ("bitmap", np.zeros(1, dtype=np.uint8)), ("bitmap", np.zeros(0, dtype=np.uint8)),
+                ("batch", np.array([10**9], dtype=np.int64))):  # nobody has this id
+        for q in (xq, xq[:3]):
+            D, I = ix.search(q, 4, sel=sel, nprobe=4, efSearch=32)
+            assert np.all(I == -1), (desc, sel[0], len(q))
+            assert np.all(D == neutral)
