@@ -64,3 +64,46 @@ def test_hnsw_through_the_cpp_glue_path_with_save_and_load(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert _rows(out.stdout, "hnsw")[0][0].startswith("OK")
     assert _rows(out.stdout, "hnswio")[0][0].startswith("OK")
+
+
+@pytest.mark.gpu
+def test_different_indexes_searched_from_concurrent_host_threads():
+    """the glue serialises calls per index (faiss_lock) but DuckDB runs different indexes from different worker
+    threads at the same time: every index owns its stream and scratch buffers, results must equal the serial ones"""
+    import threading
+
+    import mi355_faiss as mf
+    from oracle import oracle as orc
+
+    xb = orc.synth_clustered(20000, 64, 5, n_centers=32, sigma=0.2)
+    xq = orc.synth_clustered(256, 64, 6, n_centers=32, sigma=0.2)
+    specs = [("Flat", mf.METRIC_L2, {}), ("Flat", mf.METRIC_INNER_PRODUCT, {}), ("IVF16,Flat", mf.METRIC_L2, {"nprobe": 4}),
+             ("IVF16,Flat", mf.METRIC_INNER_PRODUCT, {"nprobe": 4}), ("HNSW16", mf.METRIC_L2, {"efSearch": 64}),
+             ("IDMap,Flat", mf.METRIC_L2, {})]
+    idx, serial = [], []
+    for desc, metric, kw in specs:
+        ix = mf.index_factory(64, desc, metric)
+        ix.train(xb)
+        if desc.startswith("IDMap"):
+            ix.add_with_ids(xb, np.arange(len(xb), dtype=np.int64) + 7)
+        else:
+            ix.add(xb)
+        idx.append(ix)
+        serial.append(ix.search(xq, 10, **kw))
+    errors, out = [], [None] * len(specs)
+
+    def worker(i):
+        try:
+            for _ in range(20):
+                out[i] = idx[i].search(xq, 10, **specs[i][2])
+        except Exception as e:  # noqa: BLE001
+            errors.append((specs[i][0], repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(specs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for (D, I), (Ds, Is), spec in zip(out, serial, specs):
+        assert np.array_equal(I, Is) and np.array_equal(D, Ds), spec[0]
