@@ -18,6 +18,11 @@ struct Error : std::runtime_error {
 
 [[noreturn]] void throw_faiss(const char *func, const char *file, const char *fmt, ...);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-kernel, process-wide setting: different indexes (different k / ef)
+// launch the same kernel instance from different host threads, so the limit is only ever RAISED (a thread that lowered
+// it between another thread's "set" and "launch" would make that launch fail).  Per device.
+void ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 #define MVS_HIP(expr)                                                                                                  \
 	do {                                                                                                               \
 		hipError_t e_ = (expr);                                                                                        \

@@ -437,7 +437,7 @@ static void launch_direct_inst(int mode, const DirectArgs &a, const DirectPlan &
 #define MVS_LAUNCH_DIRECT(M)                                                                                           \
 	{                                                                                                                  \
 		auto kern = flat_direct_kernel<KC, QG, M>;                                                                     \
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes)); \
+		ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes)); \
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);                                          \
 	}
 	if (mode == MODE_IP)

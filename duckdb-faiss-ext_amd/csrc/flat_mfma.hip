@@ -764,7 +764,7 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 #define MVS_ABL(N)                                                                                                     \
 	if (abl == N) {                                                                                                    \
 		auto kern = flat_mfma_resident_kernel<64, true, N>;                                                            \
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes)); \
+		ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes)); \
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);                                          \
 	}
 		MVS_ABL(1) MVS_ABL(2) MVS_ABL(3) MVS_ABL(8) MVS_ABL(10)
@@ -775,11 +775,11 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 	if (p.global_lists && a.sel.kind == MVS_SEL_NONE) {
 		if (metric == METRIC_L2) {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, 2, false, false, false, true>;
-			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 		} else {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, 2, false, false, false, true>;
-			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 		}
 		MVS_HIP(hipGetLastError());
@@ -787,7 +787,7 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 	}
 	if (metric == METRIC_L2) {
 		auto kern = flat_mfma_resident_kernel<KSTEPS, true>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 		if (getenv("MVS_DEBUG")) {
 			int nb = 0;
 			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, p.lds_bytes);
@@ -797,11 +797,11 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 	} else if (a.sel.kind != MVS_SEL_NONE) {
 		auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, 2, false, true>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 	} else {
 		auto kern = flat_mfma_resident_kernel<KSTEPS, false>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+		ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 	}
 	MVS_HIP(hipGetLastError());
@@ -815,11 +815,11 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 		if (p.global_lists && a.sel.kind == MVS_SEL_NONE) {
 			if (metric == METRIC_L2) {
 				auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, NT, true, false, false, true>;
-				MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+				ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 				hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 			} else {
 				auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, NT, true, false, false, true>;
-				MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+				ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 				hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 			}
 			MVS_HIP(hipGetLastError());
@@ -827,15 +827,15 @@ static void launch_inst(int metric, const MfmaArgs &a, const FlatSearchPlan &p, 
 		}
 		if (metric == METRIC_L2) {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, NT, true>;
-			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 		} else if (a.sel.kind != MVS_SEL_NONE) {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, NT, true, true>;
-			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 		} else {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, false, 0, NT, true>;
-			MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+			ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
 			hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
 		}
 		MVS_HIP(hipGetLastError());
@@ -941,7 +941,7 @@ static void launch_items_inst(int metric, bool has_sel, const MfmaArgs &a, int g
 #define MVS_ITEMS(L2, SEL)                                                                                             \
 	{                                                                                                                  \
 		auto kern = flat_mfma_resident_kernel<KSTEPS, L2, 0, NT, STREAM, SEL, true>;                                   \
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+		ensure_dynamic_lds((const void *)kern, (size_t)(lds));        \
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
 	}
 	if (metric == METRIC_L2) {

@@ -936,8 +936,7 @@ template <int NI, bool IS_L2, int G>
 struct SearchOccupancy {
 	static void run(int *out, size_t lds) {
 		int nb = 0;
-		MVS_HIP(hipFuncSetAttribute((const void *)hnsw_search_kernel<NI, IS_L2, G>,
-		                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G>, lds);
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)hnsw_search_kernel<NI, IS_L2, G>, 64, lds) !=
 		        hipSuccess ||
 		    nb <= 0)
@@ -949,6 +948,7 @@ struct SearchOccupancy {
 template <int NI, bool IS_L2, int G>
 struct SearchLaunch {
 	static void run(const SearchArgs &a, int grid, size_t lds, hipStream_t st) {
+		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G>, lds); // map lookup; raises the limit if needed
 		hipLaunchKernelGGL((hnsw_search_kernel<NI, IS_L2, G>), dim3(grid), dim3(64), lds, st, a);
 		MVS_HIP(hipGetLastError());
 	}
@@ -956,8 +956,7 @@ struct SearchLaunch {
 template <int NI, bool IS_L2, int G>
 struct BuildLaunch {
 	static void run(const BuildArgs &a, int grid, size_t lds, hipStream_t st) {
-		MVS_HIP(hipFuncSetAttribute((const void *)hnsw_build_kernel<NI, IS_L2, G>,
-		                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		ensure_dynamic_lds((const void *)hnsw_build_kernel<NI, IS_L2, G>, lds);
 		hipLaunchKernelGGL((hnsw_build_kernel<NI, IS_L2, G>), dim3(grid), dim3(64), lds, st, a);
 		MVS_HIP(hipGetLastError());
 	}

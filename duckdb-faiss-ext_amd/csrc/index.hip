@@ -10,6 +10,9 @@
 // hipMemcpyAsync + the norm kernel run on the stream.
 #include "index.h"
 
+#include <map>
+#include <mutex>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
@@ -77,6 +80,19 @@ int PinnedRing::acquire(size_t bytes) {
 }
 void PinnedRing::release(int i, hipStream_t st) {
 	MVS_HIP(hipEventRecord(ev[i], st));
+}
+
+void ensure_dynamic_lds(const void *kernel, size_t bytes) {
+	static std::mutex mu;
+	static std::map<std::pair<int, const void *>, size_t> raised;
+	int dev = 0;
+	MVS_HIP(hipGetDevice(&dev));
+	std::lock_guard<std::mutex> g(mu);
+	size_t &cur = raised[{dev, kernel}];
+	if (bytes > cur) {
+		MVS_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+		cur = bytes;
+	}
 }
 
 // ------------------------------------------------------------------------------------------ base

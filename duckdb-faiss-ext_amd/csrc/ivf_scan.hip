@@ -523,7 +523,7 @@ static void launch_scan_kernel(int metric, bool interleaved, const ScanArgs &a, 
 #define MVS_SCAN(L2, IL)                                                                                               \
 	{                                                                                                                  \
 		auto kern = ivf_scan_kernel<L2, IL>;                                                                           \
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+		ensure_dynamic_lds((const void *)kern, (size_t)(lds));        \
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
 	}
 	if (metric == METRIC_IP) {

@@ -234,12 +234,12 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 		throw_faiss(__func__, __FILE__, "merge: nsplit*k = %lld too large", (long long)nsplit * k);
 	if (metric == METRIC_L2) {
 		auto kern = merge_partials_kernel<true>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, nsplit, (long long)nq, (int)k,
 		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I);
 	} else {
 		auto kern = merge_partials_kernel<false>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, nsplit, (long long)nq, (int)k,
 		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I);
 	}
@@ -358,12 +358,12 @@ void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, cons
 		throw_faiss(__func__, __FILE__, "IVF merge: k = %lld too large", (long long)k);
 	if (metric == METRIC_L2) {
 		auto kern = merge_items_kernel<true>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, pchunk, (int)k, group,
 		                   shift, (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
 	} else {
 		auto kern = merge_items_kernel<false>;
-		MVS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, pchunk, (int)k, group,
 		                   shift, (const long long *)d_rowids, (const long long *)d_idmap, d_D, (long long *)d_I);
 	}
