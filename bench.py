@@ -420,6 +420,32 @@ def main():
             out["recall_at_10"] = round(hits / max(total, 1), 6)
             out["labels_bit_exact_vs_oracle"] = labels_equal
             out["recall_sample_queries"] = done
+            # second CPU number: the sgemm that dominates CPU FAISS's BLAS branch, alone, on OpenBLAS (numpy, all host
+            # threads) -- an UPPER bound for a CPU FAISS+OpenBLAS search (norms, formula and heap updates excluded).
+            # Not a parity reference (sgemm's summation order is its own); bounded to a few seconds.
+            try:
+                qb = np.ascontiguousarray(xq_h[: min(nq, 2048)])
+                _ = qb @ xb_h[: 1 << 16].T  # warm the thread pool
+                t_gemm, rows_done = 0.0, 0
+                for r0 in range(0, n, 1 << 18):
+                    blk = xb_h[r0 : r0 + (1 << 18)]
+                    t1 = time.perf_counter()
+                    ip = qb @ blk.T
+                    t_gemm += time.perf_counter() - t1
+                    rows_done += len(blk)
+                    del ip
+                    if t_gemm > max(3.0, args.cpu_seconds / 3):
+                        break
+                tf = 2.0 * len(qb) * rows_done * d / t_gemm / 1e12
+                out["cpu_sgemm_upper_bound"] = {
+                    "value": round(len(qb) / (t_gemm * n / rows_done), 2),
+                    "unit": "queries/s",
+                    "tflops": round(tf, 3),
+                    "kind": "numpy/OpenBLAS sgemm only (%d queries x %d of %d rows timed, scaled to N); norms, distance "
+                    "formula and top-k excluded" % (len(qb), rows_done, n),
+                }
+            except Exception as e:  # noqa: BLE001  (never let the extra number break the bench line)
+                out["cpu_sgemm_upper_bound"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
