@@ -109,13 +109,18 @@ def main():
             x /= x.norm(dim=1, keepdim=True)
         return x
 
+    if not with_ids:
+        ix.set_label_offset(r0)  # global labels of this row shard (IVF stores them at add time)
     # build: device-side generation in slabs (keeps peak memory = index + one slab)
     slab = 1 << 20
     t_build0 = time.time()
     if is_ivf:
         # the reference trains on ALL rows it was given (src/faiss_extension.cpp:583) and then adds them (:609)
+        # N > 1: rank 0 trains on its rows, the centroids are replicated, every list is row-sharded
+        from sharded import replicate_ivf_centroids
+
         xb_all = gen(r1 - r0, d, DB_SEED, row0=r0, device=dev)
-        ix.train(xb_all.cpu().numpy())
+        replicate_ivf_centroids(ix, xb_all.cpu().numpy() if rank == 0 else None, src=0, device=dev)
         for s0 in range(0, r1 - r0, slab):
             ix.add_torch(xb_all[s0 : s0 + slab])
         torch.cuda.synchronize()
@@ -129,8 +134,6 @@ def main():
             ix.add_torch(xb, ids=ids)
             torch.cuda.synchronize()
             del xb
-    if not with_ids:
-        ix.set_label_offset(r0)
     xq = prep(gen(nq, d, Q_SEED, row0=0, device=dev))
     torch.cuda.synchronize()
     t_build = time.time() - t_build0

@@ -276,11 +276,19 @@ public:
 			MVS_HIP(hipStreamSynchronize(stream));
 			for (int64_t i = 0; i < nb; i++) {
 				assign_h.push_back((int32_t)lab[(size_t)i]);
-				ids_h.push_back(ids_host ? ids_host[i0 + i] : ntotal + i0 + i);
+				ids_h.push_back(ids_host ? ids_host[i0 + i] : label_offset + ntotal + i0 + i);
 			}
 		}
 		ntotal += n;
 		dirty = true;
+	}
+	// row shards: the implicit ids of a shard start at its first global row; they are stored in the lists,
+	// so the offset has to be known before the first add
+	void set_label_offset(int64_t off) override {
+		if (ntotal > 0 && off != label_offset)
+			throw_faiss("mvs::IVFFlatIndex::set_label_offset", __FILE__,
+			            "the label offset of an IVF index must be set before rows are added");
+		label_offset = off;
 	}
 	void add_host(int64_t n, const float *x, const int64_t *ids) {
 		use_device();

@@ -18,6 +18,25 @@ def shard_bounds(n, rank, world):
     return n * rank // world, n * (rank + 1) // world
 
 
+def replicate_ivf_centroids(ix, x_train=None, src=0, device=None, group=None):
+    """IVF over row shards: ONE set of centroids on every GPU, every inverted list row-sharded, so that
+    the union of the ranks' list scans is exactly the single-index scan and the merged top-k equals the unsharded result.
+    Rank `src` trains on `x_train` (the reference trains once, src/faiss_extension.cpp:583), the nlist x d centroids
+    (2 MB at IVF4096, d=128) are broadcast, and the other ranks install them instead of training."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if rank == src:
+        ix.train(x_train)
+    if world == 1:
+        return
+    c = torch.empty((ix.nlist, ix.d), dtype=torch.float32, device=device if device is not None else "cpu")
+    if rank == src:
+        c.copy_(torch.from_numpy(ix.ivf_centroids()))
+    dist.broadcast(c, src=src, group=group)
+    if rank != src:
+        ix.ivf_set_centroids(c.cpu().numpy())
+
+
 class ShardExchange:
     """Pre-allocated buffers for the exchange step of one (nq, k) search shape."""
 

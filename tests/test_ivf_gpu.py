@@ -269,3 +269,34 @@ def test_ivf_edge_cases_empty_and_tiny(mf, metric):
     Do, Io = o.search(xb[5:6], 30, nprobe=2)  # one query, k beyond the rows of the two probed lists
     D, I = g.search(xb[5:6], 30, nprobe=2)
     assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_row_sharded_lists_with_replicated_centroids_equal_one_index(mf, metric):
+    """one set of centroids on every GPU, each inverted list row-sharded; the host merge of the shards'
+    results must be the single-index result bit for bit (here: three shard indexes on one device)."""
+    n, d, nq, k, nprobe = 60000, 64, 300, 10, 6
+    xb = orc.synth_clustered(n, d, 1234, n_centers=64, sigma=0.2)
+    xq = orc.synth_clustered(nq, d, 4321, n_centers=64, sigma=0.2)
+    one = mf.index_factory(d, "IVF64,Flat", metric)
+    one.train(xb)
+    one.add(xb)
+    Dr, Ir = one.search(xq, k, nprobe=nprobe)
+    cent = one.ivf_centroids()
+    bounds = [0, 17000, 17001, 41000, n]  # ragged shards, one of a single row
+    Ds, Is = [], []
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        sh = mf.index_factory(d, "IVF64,Flat", metric)
+        sh.ivf_set_centroids(cent)
+        assert sh.is_trained
+        sh.set_label_offset(r0)  # implicit ids of the shard = global row numbers (stored in the lists at add time)
+        sh.add(xb[r0:r1])
+        with pytest.raises(mf.FaissException, match="before rows are added"):
+            sh.set_label_offset(r0 + 1)
+        D, I = sh.search(xq, k, nprobe=nprobe)
+        Ds.append(D)
+        Is.append(I)
+    Dm, Im = mf.merge_shards(metric, np.stack(Ds), np.stack(Is))
+    assert np.array_equal(Dm, Dr)
+    assert np.array_equal(Im, Ir)

@@ -51,3 +51,46 @@ def test_two_rank_exchange_and_merge_equals_unsharded(metric):
     port = 29500 + (os.getpid() % 2000) + metric
     mp.spawn(_worker, args=(2, port, metric, ret), nprocs=2, join=True)
     assert ret["same_D"] and ret["same_I"] and ret["n_ok"] > 32
+
+
+def _ivf_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from sharded import ShardExchange, replicate_ivf_centroids, shard_bounds
+
+    orc.set_num_threads(2)
+    n, d, nq, k, nprobe = 12000, 16, 48, 10, 5
+    xb = orc.synth_uniform(n, d, 1234)
+    xq = orc.synth_uniform(nq, d, 4321)
+    r0, r1 = shard_bounds(n, rank, world)
+    # the oracle index stands in for the per-GPU shard index (same method names as mi355_faiss.Index)
+    ix = orc.Index(d, "IDMap,IVF32,Flat", orc.METRIC_L2)
+    replicate_ivf_centroids(ix, xb if rank == 0 else None, src=0)
+    assert ix.is_trained
+    ix.add_with_ids(xb[r0:r1], np.arange(r0, r1, dtype=np.int64))
+    D, I = ix.search(xq, k, nprobe=nprobe)
+    xch = ShardExchange(nq, k, "cpu")
+    Dm, Im = xch.merge(orc.METRIC_L2, torch.from_numpy(D), torch.from_numpy(I))
+    if rank == 0:
+        one = orc.Index(d, "IDMap,IVF32,Flat", orc.METRIC_L2)
+        one.train(xb)
+        one.add_with_ids(xb, np.arange(n, dtype=np.int64))
+        Dr, Ir = one.search(xq, k, nprobe=nprobe)
+        ret["same_D"] = bool(np.array_equal(Dm, Dr))
+        ret["same_I"] = bool(np.array_equal(Im, Ir))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ivf_replicated_centroids_equals_unsharded():
+    """centroids replicated (rank 0 trains, broadcast), every inverted list row-sharded -> the merged
+    result is the single-index result, bit for bit"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31700 + (os.getpid() % 2000)
+    mp.spawn(_ivf_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["same_D"] and ret["same_I"]
