@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=10_000_000)  # --rows: torchrun's parser trips over "--n"
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
@@ -64,6 +64,11 @@ def main():
                 "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ..."
             )
         args.gpus = world
+    # debugging aid for the N > 1 flow on a 1-GPU box: MVS_BENCH_SHARED_GPU=1 MVS_BENCH_BACKEND=gloo puts every rank
+    # on device 0 (RCCL refuses two ranks on one GPU); never set by the driver, numbers from it mean nothing
+    if os.environ.get("MVS_BENCH_SHARED_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("MVS_BENCH_BACKEND", "nccl")
     os.environ["MVS_DEVICE"] = str(local_rank)
 
     import numpy as np
@@ -75,7 +80,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     metric = mf.METRIC_L2 if args.metric == "L2" else mf.METRIC_INNER_PRODUCT
     n, d, nq, k = args.n, args.d, args.nq, args.k
@@ -111,6 +119,21 @@ def main():
 
     if not with_ids:
         ix.set_label_offset(r0)  # global labels of this row shard (IVF stores them at add time)
+    def host_rows(count, seed):
+        """the same rows on the host for the oracle: the host generator (bit-identical to the device one) or, when the
+        rows are normalised on the device, a copy of exactly those"""
+        from oracle import oracle as orc
+
+        if not args.normalize:
+            if args.data == "uniform":
+                return orc.synth_uniform(count, d, seed)
+            return orc.synth_clustered(count, d, seed, n_centers=args.centers, sigma=args.sigma)
+        out_h = np.empty((count, d), dtype=np.float32)
+        for s0 in range(0, count, 1 << 20):
+            m = min(1 << 20, count - s0)
+            out_h[s0 : s0 + m] = prep(gen(m, d, seed, row0=s0, device=dev)).cpu().numpy()
+        return out_h
+
     # build: device-side generation in slabs (keeps peak memory = index + one slab)
     slab = 1 << 20
     t_build0 = time.time()
@@ -379,15 +402,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not is_ivf and not is_hnsw:
             from oracle import oracle as orc
 
-            if args.data == "uniform":
-                gen_h = orc.synth_uniform
-            else:
-
-                def gen_h(m, dd, seed):
-                    return orc.synth_clustered(m, dd, seed, n_centers=args.centers, sigma=args.sigma)
-
-            xb_h = gen_h(n, d, DB_SEED)
-            xq_h = gen_h(nq, d, Q_SEED)
+            xb_h = host_rows(n, DB_SEED)
+            xq_h = xq.cpu().numpy()
             cores = orc.num_threads()
             # first slice: 4096 queries keep every host thread busy (16 queries per thread group); shrink it when even
             # that would blow the budget (the oracle sustains roughly 0.5 TFLOP/s on this class of host)
@@ -449,6 +465,22 @@ def main():
                 }
             except Exception as e:  # noqa: BLE001  (never let the extra number break the bench line)
                 out["cpu_sgemm_upper_bound"] = {"error": repr(e)[:200]}
+        if world > 1 and not args.no_cpu_baseline and not is_ivf and not is_hnsw:
+            # N > 1: no CPU timing, but the MERGED result of the row shards is checked against the oracle's search of
+            # the whole database on a query sample (outside the timed region)
+            from oracle import oracle as orc
+
+            ns = min(nq, 256)
+            xb_h, xq_h = host_rows(n, DB_SEED), xq[:ns].cpu().numpy()
+            Do, Io = orc.flat_search(metric, xb_h, xq_h, k, force_path=orc.PATH_BLAS)
+            out["merged_labels_bit_exact_vs_oracle"] = bool(np.array_equal(final["I"][:ns], Io))
+            out["merged_distances_bit_exact_vs_oracle"] = bool(
+                np.array_equal(final["D"][:ns].view(np.uint32), Do.view(np.uint32))
+            )
+            out["recall_at_10"] = round(
+                float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(final["I"][:ns], Io)])), 6
+            )
+            out["recall_sample_queries"] = ns
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
