@@ -270,10 +270,10 @@ def main():
             # collected from inside the process); null for any other workload
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-            if os.path.exists(tpath) and world == 1 and chunk == nq:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == "%s %s d=%d N=%d nq=%d k=%d" % (args.index, args.metric, d, n, nq, k):
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r1_traffic.json (" + tj["source"] + ")"
+            if os.path.exists(tpath) and world == 1 and chunk == nq and not args.opt and args.efconstruction == 0:
+                for w in json.load(open(tpath)).get("workloads", []):
+                    if w["metric"] == out["metric"] and w["data"] == out["data"]:
+                        traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r1_traffic.json (" + w["source"] + ")"
             if kinfo["name"].startswith("flat_mfma"):
                 achieved = kinfo["flops"] / (avg_ms * 1e-3) / 1e12
                 out["roofline"] = {
@@ -307,7 +307,8 @@ def main():
                     "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBPS, 4),
-                    "traffic": None,
+                    "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 4),
                     "launches": n_launch,
                     "algorithmic_bytes_per_launch": kinfo["bytes"],
