@@ -469,19 +469,22 @@ def main():
         if world > 1 and not args.no_cpu_baseline and not is_ivf and not is_hnsw:
             # N > 1: no CPU timing, but the MERGED result of the row shards is checked against the oracle's search of
             # the whole database on a query sample (outside the timed region)
-            from oracle import oracle as orc
+            try:
+                from oracle import oracle as orc
 
-            ns = min(nq, 256)
-            xb_h, xq_h = host_rows(n, DB_SEED), xq[:ns].cpu().numpy()
-            Do, Io = orc.flat_search(metric, xb_h, xq_h, k, force_path=orc.PATH_BLAS)
-            out["merged_labels_bit_exact_vs_oracle"] = bool(np.array_equal(final["I"][:ns], Io))
-            out["merged_distances_bit_exact_vs_oracle"] = bool(
-                np.array_equal(final["D"][:ns].view(np.uint32), Do.view(np.uint32))
-            )
-            out["recall_at_10"] = round(
-                float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(final["I"][:ns], Io)])), 6
-            )
-            out["recall_sample_queries"] = ns
+                ns = min(nq, 256)
+                xb_h, xq_h = host_rows(n, DB_SEED), xq[:ns].cpu().numpy()
+                Do, Io = orc.flat_search(metric, xb_h, xq_h, k, force_path=orc.PATH_BLAS)
+                out["merged_labels_bit_exact_vs_oracle"] = bool(np.array_equal(final["I"][:ns], Io))
+                out["merged_distances_bit_exact_vs_oracle"] = bool(
+                    np.array_equal(final["D"][:ns].view(np.uint32), Do.view(np.uint32))
+                )
+                out["recall_at_10"] = round(
+                    float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(final["I"][:ns], Io)])), 6
+                )
+                out["recall_sample_queries"] = ns
+            except Exception as e:  # noqa: BLE001  (the check must never cost the scaling run its bench line)
+                out["merged_check_error"] = repr(e)[:200]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
