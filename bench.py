@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--index", default="Flat", help="factory string (Flat | IDMap,Flat | IVF4096,Flat ...)")
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--efsearch", type=int, default=128, help="SearchParametersHNSW::efSearch (HNSW indexes)")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: merge every batch before searching the next")
     ap.add_argument("--efconstruction", type=int, default=0, help="hnsw.efConstruction (0 = FAISS default 40)")
     ap.add_argument("--normalize", action="store_true", help="L2-normalise rows and queries (embedding-like, C4/C5)")
     ap.add_argument("--chunk", type=int, default=0, help="queries per search call (2048 = DuckDB DataChunk); 0 = one batch")
@@ -165,7 +166,15 @@ def main():
 
     D = torch.empty((nq, k), dtype=torch.float32, device=dev)
     I = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    xch = ShardExchange(nq, k, dev)
+    # N > 1: two result / exchange buffer sets, so that the host merge of batch i runs while the GPUs search batch i+1
+    pipelined = world > 1 and not is_hnsw and not args.no_pipeline
+    Dbuf, Ibuf = [D], [I]
+    xchs = [ShardExchange(nq, k, dev)]
+    if pipelined:
+        Dbuf.append(torch.empty_like(D))
+        Ibuf.append(torch.empty_like(I))
+        xchs.append(ShardExchange(nq, k, dev))
+    state = {"it": 0, "pending": None}
     chunk = args.chunk if args.chunk > 0 else nq
     search_kw = {"nprobe": args.nprobe} if is_ivf else ({"efSearch": args.efsearch} if is_hnsw else {})
     final = {}
@@ -190,16 +199,35 @@ def main():
     def step():
         if is_hnsw:
             return step_replicas()
+        slot = state["it"] % len(xchs)
+        state["it"] += 1
+        Ds, Is = Dbuf[slot], Ibuf[slot]
         for q0 in range(0, nq, chunk):
             q1 = min(nq, q0 + chunk)
-            ix.search_torch(xq[q0:q1], k, D=D[q0:q1], I=I[q0:q1], **search_kw)
+            ix.search_torch(xq[q0:q1], k, D=Ds[q0:q1], I=Is[q0:q1], **search_kw)
         if world > 1:
-            # exchange step: per-shard (distance,label) blocks over xGMI, then host k-way merge (rank 0)
-            fD, fI = xch.merge(metric, D, I)
-            if rank == 0:
-                final["D"], final["I"] = fD, fI
+            # exchange step: per-shard (distance,label) blocks over xGMI + copy to pinned host memory, enqueued behind
+            # the search; then the host k-way merge (rank 0) -- of the PREVIOUS batch when pipelined, so that it
+            # overlaps this batch's search (every merge still happens inside the timed region: fence() drains)
+            xchs[slot].gather_async(Ds, Is)
+            if pipelined:
+                drain()
+                state["pending"] = slot
+            else:
+                finish(slot)
+
+    def finish(slot):
+        fD, fI = xchs[slot].merge_host(metric)
+        if rank == 0:
+            final["D"], final["I"] = fD, fI
+
+    def drain():
+        if state["pending"] is not None:
+            finish(state["pending"])
+            state["pending"] = None
 
     def fence():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -255,7 +283,12 @@ def main():
                 "queries_per_call": chunk,
                 "row_shards": 1 if is_hnsw else world,
                 "replicas": world if is_hnsw else 1,
-                "exchange": ("gather of disjoint result rows" if is_hnsw else "rccl all_gather + host k-way merge")
+                "exchange": (
+                    "gather of disjoint result rows"
+                    if is_hnsw
+                    else "rccl all_gather + host k-way merge"
+                    + (" (merge of batch i overlaps the search of batch i+1)" if pipelined else "")
+                )
                 if world > 1
                 else "none",
                 "build_seconds": round(t_build, 2),

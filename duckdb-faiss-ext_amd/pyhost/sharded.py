@@ -61,15 +61,38 @@ class ShardExchange:
         dist.all_gather_into_tensor(self.gI.view(self.world * self.nq, self.k), I.contiguous(), group=self.group)
         return self.gD, self.gI
 
-    def merge(self, metric, D, I, merge_rank=0):
-        """exchange + host merge; returns (D, I) numpy [nq, k] on merge_rank, (None, None) elsewhere"""
+    def gather_async(self, D, I, merge_rank=0):
+        """first half of merge(): all-gather + (on merge_rank) the device-to-pinned-host copy, all enqueued on the
+        current stream; nothing here waits for the GPU, so the caller can go on enqueuing the next batch"""
         gD, gI = self.all_gather(D, I)
+        self._pending = None
         if self.rank != merge_rank:
-            return None, None
+            return
         if self.world == 1:
-            return D.cpu().numpy(), I.cpu().numpy()
+            self._pending = (D, I, None)
+            return
         self.hD.copy_(gD, non_blocking=True)
         self.hI.copy_(gI, non_blocking=True)
+        ev = None
         if gD.is_cuda:
-            torch.cuda.current_stream(gD.device).synchronize()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(gD.device))
+        self._pending = (None, None, ev)
+
+    def merge_host(self, metric):
+        """second half: wait for the copy enqueued by gather_async, then the host k-way merge; (None, None) on the
+        ranks that do not merge"""
+        pend, self._pending = getattr(self, "_pending", None), None
+        if pend is None:
+            return None, None
+        D, I, ev = pend
+        if self.world == 1:
+            return D.cpu().numpy(), I.cpu().numpy()
+        if ev is not None:
+            ev.synchronize()
         return mf.merge_shards(metric, self.hD.numpy(), self.hI.numpy())
+
+    def merge(self, metric, D, I, merge_rank=0):
+        """exchange + host merge; returns (D, I) numpy [nq, k] on merge_rank, (None, None) elsewhere"""
+        self.gather_async(D, I, merge_rank)
+        return self.merge_host(metric)
