@@ -702,7 +702,7 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	const int64_t min_tiles = 16; // amortise the per-workgroup prologue
 	int64_t max_split = ntiles / min_tiles;
 	// few query blocks (small batches routed here for inner product): allow enough splits to fill the 512 slots
-	int64_t split_cap = std::max<int64_t>(128, std::min<int64_t>(512, slots / p.nqb));
+	int64_t split_cap = std::max<int64_t>(k <= 12 ? 256 : 128, std::min<int64_t>(512, slots / p.nqb));
 	// K4 (merge_partials_kernel) holds nsplit*k candidates of one query in LDS
 	split_cap = std::max<int64_t>(8, std::min<int64_t>(split_cap, (int64_t)(150 * 1024 / 8) / std::max<int64_t>(k, 1) - 1));
 	if (max_split > split_cap)
