@@ -366,3 +366,29 @@ def test_selectors_that_reject_everything(mf, metric, desc):
             D, I = ix.search(q, 4, sel=sel, nprobe=4, efSearch=32)
             assert np.all(I == -1), (desc, sel[0], len(q))
             assert np.all(D == neutral)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_result_does_not_depend_on_the_row_split_count(mf, metric):
+    """The planner's split count (8...256, chosen for grid efficiency) is a pure performance knob: partial lists are
+    merged with the exact (value, id) rule, so any forced count gives the default's result and the oracle's."""
+    xb, xq = _data(300_000, 200, 128, seed=21, dup=500)
+    ix = mf.index_factory(128, "Flat", metric)
+    ix.add(xb)
+    try:
+        D0, I0 = ix.search(xq, 10)
+        assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+        Do, Io = orc.flat_search(metric, xb, xq, 10)
+        assert np.array_equal(D0, Do)
+        ok = np.ones(len(xq), bool)
+        if metric == IP:  # boundary ties at rank k (DESIGN: exact tie replay is future work)
+            D11, _ = orc.flat_search(metric, xb, xq, 11)
+            ok = D11[:, 9] != D11[:, 10]
+        assert np.array_equal(I0[ok], Io[ok])
+        for ns in (1, 8, 40, 136, 256):
+            ix.set_option("mfma_nsplit", ns)
+            D, I = ix.search(xq, 10)
+            assert ix.last_kernel_info()["nsplit"] == ns
+            assert np.array_equal(D, D0) and np.array_equal(I, I0), ns
+    finally:
+        ix.set_option("mfma_nsplit", 0)
