@@ -720,7 +720,7 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	const int64_t min_tiles = 16; // amortise the per-workgroup prologue
 	int64_t max_split = ntiles / min_tiles;
 	// few query blocks (small batches routed here for inner product): allow enough splits to fill the 512 slots
-	int64_t split_cap = std::max<int64_t>(k <= 12 ? 256 : 128, std::min<int64_t>(512, slots / p.nqb));
+	int64_t split_cap = std::max<int64_t>(k <= 16 ? 256 : 128, std::min<int64_t>(512, slots / p.nqb));
 	// K4 (merge_partials_kernel) holds nsplit*k candidates of one query in LDS
 	split_cap = std::max<int64_t>(8, std::min<int64_t>(split_cap, (int64_t)(150 * 1024 / 8) / std::max<int64_t>(k, 1) - 1));
 	if (max_split > split_cap)
@@ -740,10 +740,10 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 			// mild preference for >= 3 rounds (tail of the last round averages out)
 			if (rounds < 3)
 				eff -= 0.03 * (3 - rounds);
-			// ... and, at equal efficiency, for MORE splits while k is small and a split keeps >= 128 tiles (more rounds
+			// ... and, at equal efficiency, for MORE splits while k <= 16 and a split keeps >= 128 tiles (more rounds
 			// average the tail better: +1.9 % at the headline, 32 -> 128 splits), for FEWER otherwise (every
 			// (query, split) pair pays its own cold-start insertions: k = 100 is 50 % slower at 128 splits than at 32)
-			eff += (k <= 12 && s * 128 <= ntiles ? 1e-4 : -1e-4) * s;
+			eff += (k <= 16 && s * 128 <= ntiles ? 1e-4 : -1e-4) * s;
 			if (eff > best_eff) {
 				best_eff = eff;
 				nsplit = s;
