@@ -305,7 +305,11 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
             if os.path.exists(tpath) and world == 1 and chunk == nq and not args.opt and args.efconstruction == 0:
                 for w in json.load(open(tpath)).get("workloads", []):
-                    if w["metric"] == out["metric"] and w["data"] == out["data"]:
+                    if (
+                        w["metric"] == out["metric"]
+                        and w.get("workload") == out["config"]["workload"]
+                        and w["data"] == out["data"]
+                    ):
                         traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r1_traffic.json (" + w["source"] + ")"
             if kinfo["name"].startswith("flat_mfma"):
                 achieved = kinfo["flops"] / (avg_ms * 1e-3) / 1e12
