@@ -392,3 +392,27 @@ def test_result_does_not_depend_on_the_row_split_count(mf, metric):
             assert np.array_equal(D, D0) and np.array_equal(I, I0), ns
     finally:
         ix.set_option("mfma_nsplit", 0)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("k", [10, 33, 100])
+def test_heavy_ties_large_k_heap_lists(mf, metric, k):
+    """The fused kernel's k-lists are heaps on (value, id): a database made of 40 distinct vectors repeated over and
+    over (almost every comparison is an exact value tie decided by the id) must still give the oracle's result."""
+    rng = np.random.default_rng(33)
+    base = rng.random((40, 96), dtype=np.float32)
+    xb = base[rng.integers(0, 40, 30_000)]
+    xq = rng.random((64, 96), dtype=np.float32)
+    ix = mf.index_factory(96, "Flat", metric)
+    ix.add(xb)
+    D, I = ix.search(xq, k)
+    assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+    Do, Io = orc.flat_search(metric, xb, xq, k)
+    assert np.array_equal(D, Do)
+    if metric == L2:
+        assert np.array_equal(I, Io)
+    else:  # inner product keeps the FIRST of a boundary tie in FAISS's heap: compare away from the rank-k boundary
+        Dn, _ = orc.flat_search(metric, xb, xq, k + 1)
+        for q in range(len(xq)):
+            inner = D[q] != Dn[q, k]  # rows strictly better than the (k+1)-th value
+            assert np.array_equal(I[q][inner], Io[q][inner])
