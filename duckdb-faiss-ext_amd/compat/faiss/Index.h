@@ -37,7 +37,8 @@ struct Index {
 	bool owns_handle = true;
 	void refresh();
 	static Index *wrap(mvs_index *h, bool owned); // builds the IndexIDMap / IndexIVF / IndexHNSW / IndexFlat graph
-protected:
+	// pushes members the glue assigns directly on the wrapper (IndexHNSW::hnsw.efConstruction, :136-139) to the
+	// device index before rows arrive; wrappers forward it down the chain
 	virtual void before_add() {
 	}
 };

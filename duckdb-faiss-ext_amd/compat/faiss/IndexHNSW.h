@@ -12,8 +12,6 @@ struct SearchParametersHNSW : SearchParameters {
 struct IndexHNSW : Index {
 	HNSW hnsw;
 	Index *storage = nullptr;
-
-protected:
 	void before_add() override; // pushes hnsw.efConstruction to the device index
 };
 struct IndexHNSWFlat : IndexHNSW {};

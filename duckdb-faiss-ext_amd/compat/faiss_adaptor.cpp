@@ -90,6 +90,10 @@ void Index::search(idx_t n, const float *x, idx_t k, float *distances, idx_t *la
 IndexIDMap::~IndexIDMap() {
 	delete index;
 }
+void IndexIDMap::before_add() {
+	if (index)
+		index->before_add();
+}
 IndexIVF::~IndexIVF() {
 	delete quantizer;
 }

@@ -1421,6 +1421,25 @@ public:
 			if (h.offsets[(size_t)i + 1] - h.offsets[(size_t)i] != (uint64_t)(h.levels[(size_t)i] + 1) * (uint64_t)M)
 				throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
 				            "HNSW image with a non-default neighbour layout is not supported on the MI355X path");
+		// a truncated or crafted file must not make the walk kernels read out of bounds: every link is -1 or a vertex,
+		// the entry point is a vertex that exists on the top level, no vertex is taller than max_level
+		if (n == 0 ? (h.entry_point != -1) : (h.entry_point < 0 || h.entry_point >= n))
+			throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+			            "HNSW image: entry point %d outside [0, %lld)", h.entry_point, (long long)n);
+		int top = -1;
+		for (int64_t i = 0; i < n; i++) {
+			if (h.levels[(size_t)i] < 1 || h.levels[(size_t)i] > 64)
+				throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+				            "HNSW image: vertex %lld has level count %d", (long long)i, h.levels[(size_t)i]);
+			top = std::max(top, h.levels[(size_t)i] - 1);
+		}
+		if (h.max_level != top || (n > 0 && h.levels[(size_t)h.entry_point] - 1 != h.max_level))
+			throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+			            "HNSW image: max_level %d does not match the level table (top %d)", h.max_level, top);
+		for (size_t s = 0; s < h.neighbors.size(); s++)
+			if (h.neighbors[s] < -1 || h.neighbors[s] >= n)
+				throw_faiss("faiss::Index* faiss::read_index(...)", "faiss/impl/index_read.cpp",
+				            "HNSW image: neighbour slot %zu holds %d, outside [-1, %lld)", s, h.neighbors[s], (long long)n);
 		efConstruction = h.efConstruction;
 		efSearch = h.efSearch;
 		entry_point = h.entry_point;
@@ -1529,6 +1548,9 @@ bool hnsw_set_ef_construction(IndexBase *ix, int v) {
 		return false;
 	static_cast<HNSWIndex *>(ix)->efConstruction = v;
 	return true;
+}
+int hnsw_get_ef_construction(IndexBase *ix) {
+	return ix->kind == MVS_KIND_HNSW ? static_cast<HNSWIndex *>(ix)->efConstruction : -1;
 }
 int64_t hnsw_graph_info(IndexBase *ix, int *max_level, int *entry_point) {
 	if (ix->kind != MVS_KIND_HNSW)

@@ -157,6 +157,7 @@ private:
 	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi;
 	SelectorHolder selector;
 	hipStream_t last_search_stream = nullptr;
+	bool have_last_search = false;
 	void grow(int64_t need, hipStream_t st);
 };
 
@@ -217,6 +218,7 @@ IndexBase *ivf_from_host(const HostIndex &h, int device);
 // csrc/hnsw.hip
 IndexBase *make_hnsw_index(int d, const std::string &desc, int metric);
 bool hnsw_set_ef_construction(IndexBase *ix, int v);
+int hnsw_get_ef_construction(IndexBase *ix); // -1 if not HNSW
 int64_t hnsw_graph_info(IndexBase *ix, int *max_level, int *entry_point); // neighbour slots, -1 if not HNSW
 bool hnsw_get_graph(IndexBase *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors);
 IndexBase *hnsw_from_host(const HostIndex &h, int device);

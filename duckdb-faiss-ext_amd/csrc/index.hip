@@ -380,8 +380,10 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		return;
 	}
 	// the scratch buffers below are shared by all searches of this index: order this call after the last one
-	stream_wait(st, last_search_stream);
+	if (have_last_search) // (a null last_search_stream is HIP's NULL stream, a legitimate caller stream)
+		stream_wait(st, last_search_stream);
 	last_search_stream = st;
+	have_last_search = true;
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
 	const int64_t mfma_kmax = flat_mfma_max_k(geom);
 	// Inner product + selector: FAISS's per-pair fvec_inner_product is the k-ordered chain the MFMA computes, so the
@@ -963,6 +965,9 @@ int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v) {
 	if (!hnsw_set_ef_construction(unwrap_idmap(ix->impl), v))
 		throw_faiss("mvs_index_hnsw_set_ef_construction", __FILE__, "not an HNSW index");
 	MVS_API_END
+}
+int mvs_index_hnsw_get_ef_construction(mvs_index *ix) {
+	return hnsw_get_ef_construction(unwrap_idmap(ix->impl));
 }
 int64_t mvs_index_hnsw_graph_info(mvs_index *ix, int *max_level, int *entry_point) {
 	try {

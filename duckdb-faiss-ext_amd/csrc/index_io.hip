@@ -226,6 +226,9 @@ void read_image(Reader &r, HostIndex &h) {
 			std::vector<int64_t> pairs;
 			uint64_t n = 0;
 			r.one(n);
+			if (n > ((uint64_t)1 << 40) / (2 * sizeof(int64_t))) // same bound READVECTOR applies
+				throw_faiss("faiss::Index* faiss::read_index(const char*, int)", "faiss/impl/index_read.cpp",
+				            "Error: 'size >= 0 && size < (uint64_t{1} << 40)' failed in %s", r.name);
 			pairs.resize((size_t)n * 2);
 			r.raw(pairs.data(), pairs.size() * sizeof(int64_t));
 		}
@@ -267,6 +270,9 @@ void read_image(Reader &r, HostIndex &h) {
 		for (size_t i = 0; i < (size_t)nlist; i++) {
 			if (!sizes[i])
 				continue;
+			if (sizes[i] > ((uint64_t)1 << 40) / ((uint64_t)h.d * sizeof(float)))
+				throw_faiss("faiss::Index* faiss::read_index(const char*, int)", "faiss/impl/index_read.cpp",
+				            "inverted list %zu: size %llu out of range in %s", i, (unsigned long long)sizes[i], r.name);
 			h.list_codes[i].resize((size_t)sizes[i] * h.d);
 			h.list_ids[i].resize((size_t)sizes[i]);
 			r.raw(h.list_codes[i].data(), h.list_codes[i].size() * sizeof(float));

@@ -137,7 +137,9 @@ public:
 	}
 
 	void kmeans(int64_t nx, const float *x_in, FlatIndex *qz) {
-		const int niter = 25, max_pts = 256, min_pts = 39;
+		// Clustering defaults (faiss/Clustering.h) except niter: Level1Quantizer's constructor sets cp.niter = 10 for
+		// every IndexIVF ("typically used for large clusterings", faiss/IndexIVF.cpp)
+		const int niter = 10, max_pts = 256, min_pts = 39;
 		const int64_t seed = 1234, k = nlist;
 		if (nx < k)
 			throw_faiss("virtual void faiss::Clustering::train_encoded(...)", "faiss/Clustering.cpp",
@@ -200,6 +202,16 @@ public:
 			MVS_HIP(hipMemcpyAsync(cent.data(), dcent.p, cent.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
 			MVS_HIP(hipMemcpyAsync(hassign.data(), dhass.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, stream));
 			MVS_HIP(hipStreamSynchronize(stream));
+			{
+				double counted = 0;
+				for (float h : hassign)
+					counted += h;
+				if ((int64_t)counted != nx) // compute_centroids: FAISS_ASSERT(ci >= 0 && ci < k)
+					throw_faiss("void faiss::compute_centroids(...)", "faiss/Clustering.cpp",
+					            "Error: 'ci >= 0 && ci < k' failed: %lld of %lld training points have no finite nearest "
+					            "centroid (distance overflow)",
+					            (long long)(nx - (int64_t)counted), (long long)nx);
+			}
 			// split_clusters
 			{
 				const float EPS = (float)(1 / 1024.);

@@ -16,13 +16,20 @@ namespace mvs {
 
 namespace {
 
-__global__ void km_keys_kernel(const long long *lab, int n, int *keys, int *vals, int *cnt) {
+// A label outside [0,k) (the k = 1 assignment search returns -1 when no finite distance exists, e.g. an overflow to
+// inf) is filed under the extra key k: it sorts behind every real cluster and is not counted, so the caller sees
+// sum(hassign) < nx and raises FAISS's "ci >= 0 && ci < k" assertion instead of writing out of bounds.
+__global__ void km_keys_kernel(const long long *lab, int n, int k, int *keys, int *vals, int *cnt) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
-	const int c = (int)lab[i];
-	keys[i] = c;
+	const long long c = lab[i];
 	vals[i] = i;
+	if (c < 0 || c >= k) {
+		keys[i] = k;
+		return;
+	}
+	keys[i] = (int)c;
 	atomicAdd(&cnt[c], 1);
 }
 // exclusive scan of cnt[0..k) into off[0..k] (single workgroup; k is the number of centroids)
@@ -86,9 +93,9 @@ void launch_kmeans_update(const float *d_x, int64_t nx, int d, const int64_t *d_
 	size_t temp_bytes = ws_bytes - (size_t)(temp - (char *)ws);
 	MVS_HIP(hipMemsetAsync(cnt, 0, (size_t)k * sizeof(int), st));
 	hipLaunchKernelGGL(km_keys_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, (const long long *)d_assign,
-	                   (int)nx, keys, vals, cnt);
+	                   (int)nx, (int)k, keys, vals, cnt);
 	int bits = 1;
-	while (((int64_t)1 << bits) < k)
+	while (((int64_t)1 << bits) <= k) // keys run over [0, k]: k = "label out of range"
 		bits++;
 	MVS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_s, vals, vals_s, (size_t)nx, 0, bits, st));
 	hipLaunchKernelGGL(km_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int)k, off);

@@ -392,6 +392,11 @@ int run_hnsw(size_t n, int d, int threads, const char *path) {
 		hnsw->hnsw.efConstruction = 64;
 	}
 	faiss_add(*e, n, xb.data(), ids.data(), threads);
+	// the graph must have been built with the value the glue assigned on the IDMap's sub-index wrapper
+	const int efc = mvs_index_hnsw_get_ef_construction(e->index->handle);
+	printf("hnswefc\t%s device efConstruction=%d (set 64 through IndexIDMap::index)\n", efc == 64 ? "OK" : "FAIL", efc);
+	if (efc != 64)
+		return 1;
 	auto exact = create(d, "IDMap,Flat", faiss::METRIC_L2);
 	faiss_add(*exact, n, xb.data(), ids.data(), 1);
 	const size_t nq = 256, k = 10;

@@ -102,6 +102,7 @@ _L.mvs_index_idmap_sub.restype = _p
 _L.mvs_index_ivf_quantizer.argtypes = [_p]
 _L.mvs_index_ivf_quantizer.restype = _p
 _L.mvs_index_hnsw_set_ef_construction.argtypes = [_p, C.c_int]
+_L.mvs_index_hnsw_get_ef_construction.argtypes = [_p]
 _L.mvs_index_hnsw_graph_info.argtypes = [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _L.mvs_index_hnsw_graph_info.restype = _i64
 _L.mvs_index_hnsw_get_graph.argtypes = [_p, _p, _p, _p]
@@ -133,7 +134,7 @@ DECLARED_SYMBOLS = [
     "mvs_last_error", "mvs_index_factory", "mvs_index_free", "mvs_index_d", "mvs_index_ntotal",
     "mvs_index_is_trained", "mvs_index_metric_type", "mvs_index_kind", "mvs_index_idmap_sub",
     "mvs_index_ivf_quantizer", "mvs_index_ivf_nlist", "mvs_index_ivf_get_centroids", "mvs_index_ivf_set_centroids",
-    "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_get_graph",
+    "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_get_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_get_graph",
     "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_write_index",

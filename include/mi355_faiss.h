@@ -90,6 +90,8 @@ int mvs_index_ivf_get_centroids(mvs_index *ix, float *out /* nlist*d */);
 int mvs_index_ivf_set_centroids(mvs_index *ix, const float *centroids /* nlist*d; marks trained */);
 /* IndexHNSW::hnsw.efConstruction = v  -- src/faiss_extension.cpp:136-139 */
 int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v);
+/* the value the next add will build with (IDMap wrappers are looked through); -1 if the index is not HNSW */
+int mvs_index_hnsw_get_ef_construction(mvs_index *ix);
 /* HNSW introspection (HNSW::levels / offsets / neighbors, FAISS's flat layout: 2M slots at level 0, M above, -1 =
  * empty): lets parity tests compare the device-built graph with the oracle's.  graph_info returns the number of
  * neighbour slots (offsets[ntotal]) or -1 if the index is not an HNSW index. */

@@ -665,7 +665,9 @@ static void renorm_l2(int d, int64_t n, float *x) {
 }
 
 static int kmeans_train(int d, int64_t k, int64_t nx, const float *x_in, orc_index *qz, int spherical, float *centroids) {
-	const int niter = 25, max_pts = 256, min_pts = 39;
+	/* ClusteringParameters defaults except niter: faiss/IndexIVF.cpp Level1Quantizer::Level1Quantizer sets
+	 * cp.niter = 10 and this k-means is only reached through IndexIVF::train (train_q1) */
+	const int niter = 10, max_pts = 256, min_pts = 39;
 	const int64_t seed = 1234;
 	if (nx < k)
 		return fail("virtual void faiss::Clustering::train_encoded(...)", "faiss/Clustering.cpp",

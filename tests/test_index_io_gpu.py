@@ -134,3 +134,34 @@ def test_errors(mf, tmp_path):
     p.write_bytes(b"IxF2" + b"\\0" * 10)
     with pytest.raises(mf.FaissException, match="read error"):
         mf.read_index(str(p))
+
+
+def test_crafted_hnsw_image_is_rejected(mf, tmp_path):
+    """A neighbour id / entry point outside [0, ntotal) would make the walk kernels read out of bounds: read_index must
+    refuse the file (FAISS-style read error) instead of building a device graph from it."""
+    xb = orc.synth_uniform(400, 12, 21)
+    ix = mf.index_factory(12, "HNSW8", L2)
+    ix.add(xb)
+    p = str(tmp_path / "h.index")
+    mf.write_index(ix, p)
+    raw = bytearray(open(p, "rb").read())
+    g = ix.hnsw_graph()
+    nb = g["neighbors"].astype(np.int32)
+    pos = raw.find(nb[:64].tobytes())  # the neighbour table inside the file
+    assert pos > 0
+    first = int(np.flatnonzero(nb >= 0)[0])
+    bad = bytearray(raw)
+    bad[pos + 4 * first : pos + 4 * first + 4] = struct.pack("<i", 400)  # one link past the last vertex
+    q = tmp_path / "bad_link.index"
+    q.write_bytes(bytes(bad))
+    with pytest.raises(mf.FaissException, match="neighbour slot"):
+        mf.read_index(str(q))
+    # entry point: stored right after the neighbour table (HNSW::entry_point, then max_level, ...)
+    ep_pos = pos + 4 * len(nb)
+    assert struct.unpack_from("<i", raw, ep_pos)[0] == g["entry_point"]
+    bad = bytearray(raw)
+    bad[ep_pos : ep_pos + 4] = struct.pack("<i", 100000)
+    q = tmp_path / "bad_entry.index"
+    q.write_bytes(bytes(bad))
+    with pytest.raises(mf.FaissException, match="entry point"):
+        mf.read_index(str(q))
