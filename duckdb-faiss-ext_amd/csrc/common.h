@@ -99,6 +99,10 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p_in, int metric, const float *d_qf, const float *d_qnorm,
                       int64_t nq, FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
                       const SelectorDev *sel = nullptr, const int64_t *d_idmap = nullptr); // sel: inner product only
+// tie pass of an inner-product search (FlatIndex::search_flat): per query the k smallest row ids with score >= d_T[q]
+void launch_flat_mfma_tie(const FlatGeom &g, const FlatSearchPlan &p_in, const float *d_qf, const float *d_T, int64_t nq,
+                          FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
+                          const SelectorDev *sel, const int64_t *d_idmap);
 int64_t flat_mfma_max_k(const FlatGeom &g);
 int64_t flat_mfma_max_k_lds(const FlatGeom &g); // selector / IVF-item instances keep their k-lists in LDS
 // IVF list scan as a segmented variant of the fused kernel (csrc/flat_mfma.hip, ITEMS instances)
@@ -130,8 +134,24 @@ void launch_flat_direct(const FlatGeom &g, const DirectPlan &p, int metric, cons
 int64_t flat_direct_max_k();
 
 // merge partial lists -> final (FAISS order), translate labels
+// The lists hold k entries and the first kout are written out.  Tie detection (inner product, kout = k - 1): a query
+// whose kout-th and (kout+1)-th scores are bit-equal is appended to the flag buffers {count, query, raw top-k values,
+// raw top-k row ids} for the tie pass.
+struct TieFlags {
+	int *count;  // [1]
+	int *query;  // [nq]
+	float *val;  // [nq][k]   merged candidates in the pure order (score desc, row id asc)
+	int *row;    // [nq][k]
+};
 void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, int nsplit, int64_t nq, int64_t k,
-                           const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
+                           const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st,
+                           int64_t kout = -1, const TieFlags *flags = nullptr);
+// flagged queries -> contiguous [nf][d] query rows and their boundary scores T
+void launch_gather_flagged(const float *d_x, int d, const TieFlags &f, int nf, int64_t k, int64_t kout, float *d_xf,
+                           float *d_T, hipStream_t st);
+// FAISS's CMin-heap outcome for the flagged queries from (raw top-k, the kout smallest row ids with score >= T)
+void launch_tie_resolve(const TieFlags &f, int nf, int64_t k, int64_t kout, const int64_t *d_first_ids /*[nf][kout]*/,
+                        const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
 
 // IVF (csrc/ivf.hip)
 size_t direct_items_lds_bytes(int dp, int64_t k);

@@ -229,7 +229,10 @@ __device__ __forceinline__ unsigned slots_reduce(const SlotRegs &sr) {
 // acc[t][r] holds ip(query = lane&31, row = t*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)).
 // gkey = this query's shared bound (from the slot words the caller prefetched at the START of the tile, so that the
 // L2/MALL round trip hides under the tile's MFMAs); all-ones until the first sweep over the slots is complete.
-template <int NT, bool IS_L2, bool SKIP_SLOW = false, bool SEL = false>
+// TIE (instances of the tie pass, IS_L2 = true): the accumulator holds an inner-product score and xnq the query's
+// boundary score T; a row counts as "distance 0" when score >= T and as +inf otherwise, so the smaller-is-better
+// (value, id) lists end up holding the k SMALLEST ROW IDS with score >= T (see FlatIndex::search_flat, "ties").
+template <int NT, bool IS_L2, bool SKIP_SLOW = false, bool SEL = false, bool TIE = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb, long long row0, int nvalid, float xnq,
                                               float &thr, bool qvalid, unsigned gkey, unsigned *gslot_q,
                                               float *ldq, int *liq, int k, float *lthr_q, int *lthrid_q, int *lpos_q,
@@ -250,7 +253,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
 			float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (IS_L2)
+			if (IS_L2 && !TIE)
 				y4 = *(const float4 *)(nb + t * 32 + 8 * g + 4 * h);
 			const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 			float v[4];
@@ -258,7 +261,10 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 			for (int e = 0; e < 4; ++e) {
 				v[e] = acc[t][4 * g + e];
 				if (IS_L2) {
-					v[e] = fmaf(-2.0f, v[e], xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
+					if (TIE)
+						v[e] = v[e] >= xnq ? 0.f : INFINITY; // NaN scores never count (FAISS: strict compares)
+					else
+						v[e] = fmaf(-2.0f, v[e], xnq + yv[e]); // (xn + yn) - 2 ip, two roundings as the oracle
 					acc[t][4 * g + e] = v[e];
 				}
 				if (SEL) { // rows the IDSelector rejects can never be a result
@@ -375,7 +381,7 @@ typedef __attribute__((address_space(1))) const float glb_f32;
 // GL: the per-query k-lists live directly in the partial-result buffers in global memory (L2-resident; touched only by
 // the rare insertion path) instead of LDS, so that k > 12 does not push the workgroup over half a CU's LDS.
 template <int KSTEPS, bool IS_L2, int ABL = 0, int NT = 2, bool STREAM = false, bool SEL = false, bool ITEMS = false,
-          bool GL = false>
+          bool GL = false, bool TIE = false>
 __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaArgs a) {
 	constexpr int KC = 2 * KSTEPS, BN = 32 * NT;
 	// LDS image of a tile: [64 rows][C 16-byte chunks], UNPADDED so that one LDS-DMA dwordx4 instruction (1 KiB per
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 		}
 	};
 	auto dma_norms = [&](int tile) {
-		if (IS_L2 && wave < BN / 64) {
+		if (IS_L2 && !TIE && wave < BN / 64) {
 			long long gr = r_begin + (long long)tile * BN + wave * 64 + lane;
 			if (gr >= a.n)
 				gr = a.n - 1;
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 						rowmask[m] = __builtin_amdgcn_ballot_w64(ok);
 					}
 				}
-				tile_epilogue<NT, IS_L2, (ABL & 8) != 0, SEL>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
+				tile_epilogue<NT, IS_L2, (ABL & 8) != 0, SEL, TIE>(acc, nbuf + (tile & 1) * BN, row0, nvalid, xnq, thr, qvalid, gkey,
 				                                              a.gslot + (size_t)(qvalid ? q : 0) * a.slot_stride, ldq, liq, k,
 				                                              lthr + ql, lthrid + ql, lpos + ql, h, rowmask);
 			}
@@ -942,6 +948,74 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p_in, int metric,
 		}
 	}
 	launch_one(a, p);
+}
+
+// ---- tie pass (inner product): the k smallest row ids with score >= T_q, per query -------------------------------
+// Same contraction as the search itself (so the scores are bit-identical to the ones the boundary value T came from),
+// TIE epilogue, lists in global memory.  d_T[q] travels in the query-norm slot.  Partial lists as in launch_flat_mfma:
+// pd holds 0 / FLT_MAX, pi the row ids.
+template <int KSTEPS, int NT, bool STREAM>
+static void launch_tie_inst(const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
+	auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, NT, STREAM, true, false, true, true>;
+	ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));
+	hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);
+	MVS_HIP(hipGetLastError());
+}
+void launch_flat_mfma_tie(const FlatGeom &g, const FlatSearchPlan &p_in, const float *d_qf, const float *d_T, int64_t nq,
+                          FlatDB db, int64_t k, float *d_pd, int32_t *d_pi, unsigned *d_gthr, hipStream_t st,
+                          const SelectorDev *sel, const int64_t *d_idmap) {
+	if (nq <= 0)
+		return;
+	const int stride = flat_mfma_slot_stride(k);
+	const long long gtotal = (long long)nq * stride;
+	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal, stride,
+	                   (int)k, 1);
+	FlatSearchPlan p = p_in;
+	p.global_lists = true;
+	p.lds_bytes = mfma_lds_bytes(g, k, true);
+	MfmaArgs a;
+	memset(&a, 0, sizeof a);
+	if (sel)
+		a.sel = *sel;
+	a.idmap = (const long long *)d_idmap;
+	a.gslot = d_gthr;
+	a.slot_stride = stride;
+	a.qf = d_qf;
+	a.qn = d_T;
+	a.yb = db.vecs;
+	a.yn = db.norms;
+	a.pd = d_pd;
+	a.pi = d_pi;
+	a.n = db.n;
+	a.split_rows = p.split_rows;
+	a.nq = (int)nq;
+	a.k = (int)k;
+	a.nqb = p.nqb;
+	a.nsplit = p.nsplit;
+	a.dp = g.dp;
+	a.nch = g.nch;
+	a.xcd_map = p.xcd_map ? 1 : 0;
+	if (g.nch == 1) {
+		switch (g.kc) {
+		case 8:
+			launch_tie_inst<4, 2, false>(a, p, st);
+			break;
+		case 16:
+			launch_tie_inst<8, 2, false>(a, p, st);
+			break;
+		case 32:
+			launch_tie_inst<16, 2, false>(a, p, st);
+			break;
+		case 64:
+			launch_tie_inst<32, 2, false>(a, p, st);
+			break;
+		default:
+			launch_tie_inst<64, 2, false>(a, p, st);
+			break;
+		}
+	} else {
+		launch_tie_inst<32, 4, true>(a, p, st);
+	}
 }
 
 // ---- IVF list scan as a segmented variant of the fused kernel ---------------------------------------------------

@@ -155,6 +155,11 @@ public:
 
 private:
 	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi;
+	DevBuf ws_flag, ws_tie; // inner-product boundary ties: flagged queries + tie-pass scratch
+	int *h_flag_count = nullptr; // pinned
+	bool ip_exact_ties = true;   // option "ip_exact_ties" = 0: keep the pure (score desc, id asc) order (raw shard lists)
+	void resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const TieFlags &fl, SelectorDev sel,
+	                     const int64_t *d_idmap, float *d_D, int64_t *d_I, hipStream_t st);
 	SelectorHolder selector;
 	hipStream_t last_search_stream = nullptr;
 	bool have_last_search = false;

@@ -267,6 +267,8 @@ FlatIndex::~FlatIndex() {
 		(void)hipFree(vecs);
 	if (norms)
 		(void)hipFree(norms);
+	if (h_flag_count)
+		(void)hipHostFree(h_flag_count);
 }
 
 void FlatIndex::reset() {
@@ -386,6 +388,24 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	have_last_search = true;
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
 	const int64_t mfma_kmax = flat_mfma_max_k(geom);
+	// Inner product, exact ties at the k-th score: FAISS's CMin heap keeps/evicts equal scores by
+	// arrival order.  The kernels keep the pure order (score desc, row id asc) -- a function of the data alone, so
+	// it merges across splits -- with ONE extra entry per list; the merge flags the queries whose k-th and (k+1)-th
+	// scores are bit-equal and resolve_ip_ties() replays the heap's outcome for those (usually none).
+	const int64_t k_user = k;
+	const bool tie_detect = metric == METRIC_IP && ip_exact_ties && ntotal > k && k + 1 <= mfma_kmax;
+	if (tie_detect)
+		k = k + 1;
+	TieFlags fl = {nullptr, nullptr, nullptr, nullptr};
+	if (tie_detect) {
+		ws_flag.reserve(16 + (size_t)nq * 4 + (size_t)nq * k * 8);
+		fl.count = (int *)ws_flag.p;
+		fl.query = fl.count + 4;
+		fl.val = (float *)(fl.query + nq);
+		fl.row = (int *)(fl.val + (size_t)nq * k);
+		MVS_HIP(hipMemsetAsync(fl.count, 0, sizeof(int), st));
+	}
+	const TieFlags *flp = tie_detect ? &fl : nullptr;
 	// Inner product + selector: FAISS's per-pair fvec_inner_product is the k-ordered chain the MFMA computes, so the
 	// filtered search -- the reference's signature feature, on its default metric -- stays on the fused kernel, which
 	// masks the rejected rows in its epilogue.  (L2 + selector is Sum (x-y)^2 per pair: packed scan kernel.)
@@ -429,7 +449,7 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 			                 (float *)ws_xi.p, st);
 			end_kernel_timing(st);
 			launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (int)nsplit, nq, k, d_idmap,
-			                      label_offset, d_D, d_I, st);
+			                      label_offset, d_D, d_I, st, k_user, flp);
 			snprintf(kinfo.name, sizeof kinfo.name, "flat_pair_scan (ivf_scan_kernel)");
 			kinfo.flops = 2.0 * (double)nq * (double)ntotal * d * (metric == METRIC_L2 ? 1.5 : 1.0);
 			kinfo.bytes = (double)ngroups * (double)ntotal * geom.dp * 4.0;
@@ -437,6 +457,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 			kinfo.block = 256;
 			kinfo.lds_bytes = (int)ivf_scan_lds_bytes(k);
 			kinfo.nsplit = (int)nsplit;
+			if (tie_detect)
+				resolve_ip_ties(nq, d_x, k_user, fl, sel, d_idmap, d_D, d_I, st);
 			return;
 		}
 		DirectPlan p = plan_flat_direct(geom, nq, ntotal, k);
@@ -461,7 +483,9 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		                      (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
 		end_kernel_timing(st);
 		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, nparts, nq, k, d_idmap,
-		                      label_offset, d_D, d_I, st);
+		                      label_offset, d_D, d_I, st, k_user, flp);
+		if (tie_detect)
+			resolve_ip_ties(nq, d_x, k_user, fl, sel, d_idmap, d_D, d_I, st);
 		snprintf(kinfo.name, sizeof kinfo.name, "flat_direct_kernel");
 		const int64_t ngroups = (nq + p.qgroup - 1) / p.qgroup;
 		kinfo.flops = 2.0 * (double)nq * (double)ntotal * d * (metric == METRIC_L2 && !formula ? 1.5 : 1.0);
@@ -484,15 +508,57 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st, &sel, d_idmap);
 		end_kernel_timing(st);
 		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, k, d_idmap,
-		                      label_offset, d_D, d_I, st);
+		                      label_offset, d_D, d_I, st, k_user, flp);
+		const int main_nsplit = p.nsplit, main_grid = p.grid;
+		const size_t main_lds = p.lds_bytes;
+		if (tie_detect)
+			resolve_ip_ties(nq, d_x, k_user, fl, sel, d_idmap, d_D, d_I, st);
 		snprintf(kinfo.name, sizeof kinfo.name, "flat_mfma_kernel");
 		kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
-		kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * k * 12.0;
-		kinfo.grid = p.grid;
+		kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * k_user * 12.0;
+		kinfo.grid = main_grid;
 		kinfo.block = 256;
-		kinfo.lds_bytes = (int)p.lds_bytes;
-		kinfo.nsplit = p.nsplit;
+		kinfo.lds_bytes = (int)main_lds;
+		kinfo.nsplit = main_nsplit;
 	}
+}
+
+// Tie pass of an inner-product search.  The flag count is the only host-visible decision of a search: one 4-byte
+// D2H + stream sync per IP search (the search is >= 100 us of kernels).  Flagged queries are re-run through the SAME
+// contraction (bit-identical scores) with the TIE epilogue, which collects per query the k smallest row ids whose
+// score is >= the boundary score T; tie_resolve_kernel then applies FAISS's heap outcome (csrc/util_kernels.hip).
+void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const TieFlags &fl, SelectorDev sel,
+                                const int64_t *d_idmap, float *d_D, int64_t *d_I, hipStream_t st) {
+	if (!h_flag_count)
+		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
+	MVS_HIP(hipMemcpyAsync(h_flag_count, fl.count, sizeof(int), hipMemcpyDeviceToHost, st));
+	MVS_HIP(hipStreamSynchronize(st));
+	const int nf = *h_flag_count;
+	if (nf <= 0)
+		return;
+	const int64_t kraw = k + 1;
+	const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
+	const size_t t_bytes = ((size_t)nf * sizeof(float) + 255) & ~(size_t)255;
+	const size_t td_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
+	ws_tie.reserve(xf_bytes + t_bytes + td_bytes + (size_t)nf * k * sizeof(int64_t));
+	float *xf = (float *)ws_tie.p;
+	float *T = (float *)((char *)ws_tie.p + xf_bytes);
+	float *tD = (float *)((char *)T + t_bytes);
+	int64_t *tI = (int64_t *)((char *)tD + td_bytes);
+	launch_gather_flagged(d_x, d, fl, nf, kraw, k, xf, T, st);
+	FlatSearchPlan p = plan_flat_mfma(geom, nf, ntotal, k);
+	ws_q.reserve(qfrag_floats(geom, nf) * sizeof(float));
+	launch_pack_queries(geom, xf, nf, (float *)ws_q.p, nullptr, st);
+	ws_pd.reserve((size_t)p.nsplit * nf * k * sizeof(float));
+	ws_pi.reserve((size_t)p.nsplit * nf * k * sizeof(int32_t));
+	ws_gthr.reserve((size_t)nf * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+	FlatDB db {vecs, norms, ntotal};
+	launch_flat_mfma_tie(geom, p, (const float *)ws_q.p, T, nf, db, k, (float *)ws_pd.p, (int32_t *)ws_pi.p,
+	                     (unsigned *)ws_gthr.p, st, &sel, d_idmap);
+	// k smallest (0, row id): the L2-ordered merge; ids come out as plain row numbers
+	launch_merge_partials(METRIC_L2, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nf, k, nullptr, 0, tD, tI,
+	                      st);
+	launch_tie_resolve(fl, nf, kraw, k, tI, d_idmap, label_offset, d_D, d_I, st);
 }
 
 void FlatIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
@@ -1112,6 +1178,10 @@ namespace mvs {
 bool FlatIndex::set_option(const char *key, int64_t v) {
 	if (!strcmp(key, "force_staged")) { // per-pair path on the LDS-staged flat_direct kernel instead of the scan kernel
 		force_staged = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "ip_exact_ties")) { // 0: pure (score desc, id asc) order, no tie pass (diagnostics)
+		ip_exact_ties = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "force_direct")) {

@@ -140,11 +140,13 @@ void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float 
 //   L2: ascending (dist, id)            [Heap.h heap_reorder over a CMax heap]
 //   IP: descending score; membership prefers the smaller id, equal scores are PRINTED in descending id
 //       order (heap_reorder over a CMin heap pops the smallest id of equal values to the back)
+// kout <= k entries are written (tie detection merges k = kout + 1 candidates); flag != nullptr: see TieFlags.
 template <bool IS_L2>
 __global__ __launch_bounds__(64) void merge_partials_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi,
                                                            int nsplit, long long nq, int k,
                                                            const long long *__restrict__ idmap, long long label_offset,
-                                                           float *__restrict__ D, long long *__restrict__ I) {
+                                                           float *__restrict__ D, long long *__restrict__ I, int kout,
+                                                           TieFlags flag) {
 	extern __shared__ __attribute__((aligned(16))) float sm[];
 	const long long q = blockIdx.x;
 	const int lane = threadIdx.x;
@@ -207,28 +209,154 @@ __global__ __launch_bounds__(64) void merge_partials_kernel(const float *__restr
 		}
 		__syncthreads();
 	}
-	for (int j = lane; j < k; j += 64) {
+	for (int j = lane; j < kout; j += 64) {
 		int src = j;
 		if (!IS_L2 && oi[j] >= 0) {
 			// reverse each run of equal scores (print order: larger id first)
 			int a = j, b = j;
 			while (a > 0 && oi[a - 1] >= 0 && ov[a - 1] == ov[j])
 				--a;
-			while (b + 1 < k && oi[b + 1] >= 0 && ov[b + 1] == ov[j])
+			while (b + 1 < kout && oi[b + 1] >= 0 && ov[b + 1] == ov[j])
 				++b;
 			src = a + (b - j);
 		}
 		int id = oi[src];
 		long long label = id < 0 ? -1ll : (idmap ? idmap[id] : (long long)id + label_offset);
-		D[q * k + j] = ov[src];
-		I[q * k + j] = label;
+		D[q * kout + j] = ov[src];
+		I[q * kout + j] = label;
+	}
+	// boundary tie: the kout-th and (kout+1)-th best scores are bit-equal -> which of the tied rows FAISS's heap keeps
+	// depends on arrival order; hand the query to the tie pass with its raw candidates
+	if (flag.count && kout < k && oi[kout] >= 0 && ov[kout] == ov[kout - 1]) {
+		int slot = 0;
+		if (lane == 0) {
+			slot = atomicAdd(flag.count, 1);
+			flag.query[slot] = (int)q;
+		}
+		slot = __shfl(slot, 0);
+		for (int j = lane; j < k; j += 64) {
+			flag.val[(size_t)slot * k + j] = ov[j];
+			flag.row[(size_t)slot * k + j] = oi[j];
+		}
 	}
 }
 
+__global__ void gather_flagged_kernel(const float *__restrict__ x, int d, const int *__restrict__ fq,
+                                      const float *__restrict__ fval, int nf, int k, int kout, float *__restrict__ xf,
+                                      float *__restrict__ T) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (long long)nf * d)
+		return;
+	const int f = (int)(i / d), c = (int)(i - (long long)f * d);
+	xf[i] = x[(long long)fq[f] * d + c];
+	if (c == 0)
+		T[f] = fval[(size_t)f * k + kout - 1];
+}
+void launch_gather_flagged(const float *d_x, int d, const TieFlags &f, int nf, int64_t k, int64_t kout, float *d_xf,
+                           float *d_T, hipStream_t st) {
+	if (nf <= 0)
+		return;
+	const long long total = (long long)nf * d;
+	hipLaunchKernelGGL(gather_flagged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_x, d, f.query,
+	                   f.val, nf, (int)k, (int)kout, d_xf, d_T);
+	MVS_HIP(hipGetLastError());
+}
+
+// FAISS's inner-product result under an exact tie at the k-th score (faiss/utils/Heap.h, CMin heap fed in ascending
+// row order with the strict insert rule).  Let T = k-th best score, A = rows with score >= T in
+// ascending row order, A_k = its first k entries.  Until A_k is complete the heap's root is below T, so every row of
+// A_k is inserted and none of them evicted; afterwards rows equal to T are rejected and every later row ABOVE T
+// evicts the root = the tied row with the smallest id.  Hence
+//     result = {rows above T}  +  {tied rows of A_k, minus the G with the smallest ids},  G = #(rows above T not in A_k)
+// printed by heap_reorder: score descending, equal scores in descending id order.
+// One thread per flagged query: raw = merged top-(k+1) in the pure order (score desc, id asc), which holds every row
+// above T; first = A_k from the tie pass (ascending ids).
+__global__ void tie_resolve_kernel(TieFlags f, int nf, int kraw, int k, const long long *__restrict__ first,
+                                   const long long *__restrict__ idmap, long long label_offset, float *__restrict__ D,
+                                   long long *__restrict__ I) {
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nf)
+		return;
+	const long long q = f.query[t];
+	const float *rv = f.val + (size_t)t * kraw;
+	const int *rr = f.row + (size_t)t * kraw;
+	const long long *ak = first + (size_t)t * k;
+	const float T = rv[k - 1];
+	int ngt = 0;
+	while (ngt < k && rv[ngt] > T)
+		++ngt;
+	auto above = [&](long long row) {
+		for (int j = 0; j < ngt; ++j)
+			if (rr[j] == row)
+				return true;
+		return false;
+	};
+	int in_a = 0;
+	for (int j = 0; j < k; ++j)
+		if (ak[j] >= 0 && above(ak[j]))
+			++in_a;
+	const int G = ngt - in_a;
+	float *Dq = D + q * k;
+	long long *Iq = I + q * k;
+	// rows above T: raw order is (score desc, id asc); print equal-score runs in descending id order
+	for (int j = 0; j < ngt;) {
+		int e = j;
+		while (e + 1 < ngt && rv[e + 1] == rv[j])
+			++e;
+		for (int m = j; m <= e; ++m) {
+			const int id = rr[j + (e - m)];
+			Dq[m] = rv[j];
+			Iq[m] = idmap ? idmap[id] : (long long)id + label_offset;
+		}
+		j = e + 1;
+	}
+	// tied rows of A_k in ascending id, the first G dropped; written back to front (descending id)
+	int seen = 0, pos = k - 1;
+	for (int j = 0; j < k; ++j) {
+		const long long row = ak[j];
+		if (row < 0 || above(row))
+			continue;
+		if (seen++ < G)
+			continue;
+		if (pos < ngt)
+			break; // cannot happen (p - G = k - ngt); guards the write
+		Dq[pos] = T;
+		Iq[pos] = idmap ? idmap[row] : row + label_offset;
+		--pos;
+	}
+	// the kept tied rows were written from the back in ASCENDING id, i.e. the slice reads descending from ngt on -- but
+	// only if it is full; compact if fewer than k - ngt were found (k >= number of rows >= T cannot occur when flagged)
+	if (pos >= ngt) {
+		const int missing = pos - ngt + 1;
+		for (int m = ngt; m + missing < k; ++m) {
+			Dq[m] = Dq[m + missing];
+			Iq[m] = Iq[m + missing];
+		}
+		for (int m = k - missing; m < k; ++m) {
+			Dq[m] = -FLT_MAX;
+			Iq[m] = -1;
+		}
+	}
+}
+void launch_tie_resolve(const TieFlags &f, int nf, int64_t k, int64_t kout, const int64_t *d_first_ids,
+                        const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st) {
+	if (nf <= 0)
+		return;
+	hipLaunchKernelGGL(tie_resolve_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f, nf, (int)k, (int)kout,
+	                   (const long long *)d_first_ids, (const long long *)d_idmap, (long long)label_offset, d_D,
+	                   (long long *)d_I);
+	MVS_HIP(hipGetLastError());
+}
+
 void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, int nsplit, int64_t nq, int64_t k,
-                           const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st) {
+                           const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st,
+                           int64_t kout_, const TieFlags *flags) {
 	if (nq <= 0)
 		return;
+	const int kout = (int)(kout_ < 0 ? k : kout_);
+	TieFlags fl = {nullptr, nullptr, nullptr, nullptr};
+	if (flags)
+		fl = *flags;
 	size_t lds = ((size_t)nsplit * k + k) * 8;
 	if (lds > 160 * 1024)
 		throw_faiss(__func__, __FILE__, "merge: nsplit*k = %lld too large", (long long)nsplit * k);
@@ -236,12 +364,12 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 		auto kern = merge_partials_kernel<true>;
 		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, nsplit, (long long)nq, (int)k,
-		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I);
+		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I, kout, fl);
 	} else {
 		auto kern = merge_partials_kernel<false>;
 		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, nsplit, (long long)nq, (int)k,
-		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I);
+		                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I, kout, fl);
 	}
 	MVS_HIP(hipGetLastError());
 }

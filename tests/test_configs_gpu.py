@@ -1,0 +1,229 @@
+"""Every BASELINE.json configuration at FULL size through the C ABI, checked against the oracle.
+
+  H   FlatL2 d=128 N=10M nq=10k k=10                      (headline; src/faiss_extension.cpp:631 -> IndexFlat::search)
+  C2  FlatL2 d=128 N=1M  nq=10k k=10
+  C3  IVF4096,Flat d=128 N=10M nprobe=32 nq=10k k=10      (train :583, add :609, search :631 with SearchParametersIVF)
+  C4  FlatIP d=768 N=100M row-sharded over 8 GPUs         -> the shard ONE GPU holds (N=12.5M, global labels), and the
+                                                             same rows as 8 virtual shards merged by mvs_merge_shards
+  C5  IDMap,HNSW32 d=768 N=1M efSearch=128 nq=10k k=10
+
+The oracle runs on a query sample where a full batch would take minutes on the host (sample sizes in the tests); on
+ALL queries the size-independent properties are checked (FAISS output order, labels in range and distinct, self
+queries, shard merge == unsharded).  Rows come from the counter-based generators, identical on host and device.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+L2, IP = orc.METRIC_L2, orc.METRIC_INNER_PRODUCT
+DB_SEED, Q_SEED = 1234, 4321
+SLAB = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import mi355_faiss
+
+    return mi355_faiss
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    return t
+
+
+def _check_order_and_range(D, I, lo, hi, is_l2):
+    """FAISS output contract on every query: heap_reorder order, labels inside the shard's id range, no repeats."""
+    assert I.min() >= lo and I.max() < hi
+    d = np.diff(D, axis=1)
+    assert (d >= 0).all() if is_l2 else (d <= 0).all()
+    s = np.sort(I, axis=1)
+    assert (np.diff(s, axis=1) != 0).all(), "a label repeats inside one result row"
+    assert np.isfinite(D).all()
+
+
+def _build_flat_uniform(mf, torch, n, d, metric, desc="Flat"):
+    ix = mf.index_factory(d, desc, metric)
+    for s0 in range(0, n, SLAB):
+        m = min(SLAB, n - s0)
+        ix.add_torch(mf.synth_uniform_torch(m, d, DB_SEED, row0=s0))
+        torch.cuda.synchronize()
+    return ix
+
+
+def test_headline_flat_l2_10m(mf, torch):
+    n, d, nq, k = 10_000_000, 128, 10_000, 10
+    ix = _build_flat_uniform(mf, torch, n, d, L2)
+    xq = mf.synth_uniform_torch(nq, d, Q_SEED)
+    D, I = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"].startswith("flat_mfma")
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    _check_order_and_range(D, I, 0, n, True)
+    ns = 256  # 0.65 TFLOP on the host
+    xb_h = orc.synth_uniform(n, d, DB_SEED)
+    Do, Io = orc.flat_search(L2, xb_h, xq[:ns].cpu().numpy(), k, force_path=orc.PATH_BLAS)
+    assert np.array_equal(I[:ns], Io), "labels differ from the oracle"
+    assert np.array_equal(D[:ns].view(np.uint32), Do.view(np.uint32)), "distances differ from the oracle"
+    # the DuckDB granularity (<= 2048 queries per call, :903-925) returns the same rows
+    D2, I2 = ix.search_torch(xq[2048:4096].contiguous(), k)
+    torch.cuda.synchronize()
+    assert np.array_equal(I2.cpu().numpy(), I[2048:4096]) and np.array_equal(D2.cpu().numpy(), D[2048:4096])
+    # distances within 1e-4 relative of float64 truth (north_star's tolerance) on the sampled queries
+    xq64 = xq[:32].cpu().numpy().astype(np.float64)
+    for q in range(32):
+        rows = xb_h[I[q]].astype(np.float64)
+        truth = ((rows - xq64[q]) ** 2).sum(axis=1)
+        np.testing.assert_allclose(D[q], truth, rtol=1e-4)
+
+
+def test_c2_flat_l2_1m_full_batch(mf, torch):
+    n, d, nq, k = 1_000_000, 128, 10_000, 10
+    ix = _build_flat_uniform(mf, torch, n, d, L2)
+    xq = mf.synth_uniform_torch(nq, d, Q_SEED)
+    D, I = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    _check_order_and_range(D, I, 0, n, True)
+    xb_h = orc.synth_uniform(n, d, DB_SEED)
+    ns = 2048
+    Do, Io = orc.flat_search(L2, xb_h, xq[:ns].cpu().numpy(), k, force_path=orc.PATH_BLAS)
+    assert np.array_equal(I[:ns], Io) and np.array_equal(D[:ns].view(np.uint32), Do.view(np.uint32))
+
+
+def test_c3_ivf4096_10m_nprobe32(mf, torch):
+    n, d, nq, k, nprobe = 10_000_000, 128, 10_000, 10, 32
+    gen = lambda m, seed, row0=0: mf.synth_clustered_torch(m, d, seed, row0=row0, n_centers=1024, sigma=0.1)
+    xb = gen(n, DB_SEED)
+    torch.cuda.synchronize()
+    xb_h = xb.cpu().numpy()
+    ix = mf.index_factory(d, "IVF4096,Flat", L2)
+    ix.train(xb_h)  # the reference trains on ALL rows it was given (:583)
+    for s0 in range(0, n, SLAB):
+        ix.add_torch(xb[s0 : s0 + SLAB])
+    torch.cuda.synchronize()
+    assert ix.is_trained and ix.ntotal == n
+    xq = gen(nq, Q_SEED)
+    D, I = ix.search_torch(xq, k, nprobe=nprobe)
+    torch.cuda.synchronize()
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    _check_order_and_range(D, I, 0, n, True)
+    # oracle IVF sharing the trained centroids, 512 queries, bit-exact
+    o = orc.Index(d, "IVF4096,Flat", L2)
+    o.ivf_set_centroids(ix.ivf_centroids())
+    o.add(xb_h)
+    ns = 512
+    Do, Io = o.search(xq[:ns].cpu().numpy(), k, nprobe=nprobe)
+    assert np.array_equal(I[:ns], Io), "IVF labels differ from the oracle"
+    assert np.array_equal(D[:ns].view(np.uint32), Do.view(np.uint32)), "IVF distances differ from the oracle"
+    # recall@10 against exact search on the same rows
+    flat = mf.index_factory(d, "Flat", L2)
+    for s0 in range(0, n, SLAB):
+        flat.add_torch(xb[s0 : s0 + SLAB])
+    nr = 1000
+    _, Igt = flat.search_torch(xq[:nr].contiguous(), k)
+    torch.cuda.synchronize()
+    Igt = Igt.cpu().numpy()
+    recall = np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(I[:nr], Igt)])
+    assert recall >= 0.99, recall
+
+
+def _normalised(mf, torch, m, d, seed, row0):
+    x = mf.synth_clustered_torch(m, d, seed, row0=row0, n_centers=1024, sigma=1.0)
+    x /= x.norm(dim=1, keepdim=True)
+    return x
+
+
+def test_c5_idmap_hnsw32_768_1m(mf, torch):
+    n, d, nq, k, ef = 1_000_000, 768, 10_000, 10, 128
+    ix = mf.index_factory(d, "IDMap,HNSW32", L2)
+    xb_h = np.empty((n, d), dtype=np.float32)
+    slab = 1 << 16
+    for s0 in range(0, n, slab):
+        m = min(slab, n - s0)
+        xb = _normalised(mf, torch, m, d, DB_SEED, s0)
+        ids = torch.arange(s0, s0 + m, dtype=torch.int64, device=xb.device) * 2 + 1  # external ids != row numbers
+        ix.add_torch(xb, ids=ids)
+        torch.cuda.synchronize()
+        xb_h[s0 : s0 + m] = xb.cpu().numpy()
+    assert ix.ntotal == n
+    xq = _normalised(mf, torch, nq, d, Q_SEED, 0)
+    D, I = ix.search_torch(xq, k, efSearch=ef)
+    torch.cuda.synchronize()
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    assert (I % 2 == 1).all() and I.min() >= 1 and I.max() < 2 * n
+    assert (np.diff(D, axis=1) >= 0).all()
+    # the oracle walks the graph the device built (FAISS's own multi-thread build is not reproducible either):
+    # labels AND distances bit-exact on the whole batch
+    o = orc.Index(d, "HNSW32", L2)
+    o.hnsw_set_graph(xb_h, ix.hnsw_graph())
+    Do, Io = o.search(xq.cpu().numpy(), k, efSearch=ef)
+    assert np.array_equal((I - 1) // 2, Io), "HNSW labels differ from the oracle walking the same graph"
+    assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # recall@10 vs exact search (FAISS's default efConstruction = 40 graph; DESIGN.md 5 explains the 0.8)
+    flat = mf.index_factory(d, "Flat", L2)
+    for s0 in range(0, n, slab * 4):
+        flat.add(xb_h[s0 : s0 + slab * 4])
+    nr = 1000
+    _, Igt = flat.search(xq[:nr].cpu().numpy(), k)
+    recall = np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip((I[:nr] - 1) // 2, Igt)])
+    assert recall >= 0.75, recall
+
+
+def test_c4_flat_ip_768_one_gpu_shard_of_100m(mf, torch):
+    """What ONE of the 8 GPUs holds at C4: rows [87.5M, 100M) of the 100M x 768 database (global labels through
+    label_offset), nq=10k.  Oracle: block-wise over the same rows (host memory stays at one block) + the host merge."""
+    N, G, d, nq, k = 100_000_000, 8, 768, 10_000, 10
+    r0, r1 = N * (G - 1) // G, N
+    n = r1 - r0
+    blk = n // 8
+    assert blk * 8 == n
+    ix = mf.index_factory(d, "Flat", IP)
+    ix.set_label_offset(r0)
+    shards = []
+    xq = _normalised(mf, torch, nq, d, Q_SEED, 0)
+    xq_h = xq.cpu().numpy()
+    ns = 64
+    Dblk, Iblk = [], []
+    for b in range(8):
+        s0 = r0 + b * blk
+        sh = mf.index_factory(d, "Flat", IP)
+        sh.set_label_offset(s0)
+        for t0 in range(s0, s0 + blk, 1 << 19):
+            m = min(1 << 19, s0 + blk - t0)
+            xb = _normalised(mf, torch, m, d, DB_SEED, t0)
+            ix.add_torch(xb)
+            sh.add_torch(xb)
+            torch.cuda.synchronize()
+        shards.append(sh)
+        # oracle on this block, 64 queries (the block is regenerated on the device and copied out: normalisation is
+        # a device op, so the host sees exactly the rows the index holds)
+        xb_h = np.empty((blk, d), dtype=np.float32)
+        for t0 in range(0, blk, 1 << 19):
+            m = min(1 << 19, blk - t0)
+            xb_h[t0 : t0 + m] = _normalised(mf, torch, m, d, DB_SEED, s0 + t0).cpu().numpy()
+        Do, Io = orc.flat_search(IP, xb_h, xq_h[:ns], k, force_path=orc.PATH_BLAS)
+        Dblk.append(Do)
+        Iblk.append(Io + s0)
+        del xb_h
+    assert ix.ntotal == n
+    D, I = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    _check_order_and_range(D, I, r0, r1, False)
+    Dor, Ior = orc.merge_shards(IP, np.stack(Dblk), np.stack(Iblk))
+    assert np.array_equal(I[:ns], Ior), "labels differ from the oracle"
+    assert np.array_equal(D[:ns].view(np.uint32), Dor.view(np.uint32))
+    # 8 virtual shards of N/8 rows, merged with the host k-way merge == the unsharded search, on all 10k queries
+    Ds, Is = [], []
+    for sh in shards:
+        Dj, Ij = sh.search_torch(xq, k)
+        torch.cuda.synchronize()
+        Ds.append(Dj.cpu().numpy())
+        Is.append(Ij.cpu().numpy())
+    Dm, Im = mf.merge_shards(IP, np.stack(Ds), np.stack(Is))
+    assert np.array_equal(Im, I) and np.array_equal(Dm.view(np.uint32), D.view(np.uint32))
