@@ -4,6 +4,7 @@
 
 #include "../../include/mi355_faiss.h"
 
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -153,10 +154,18 @@ public:
 	void search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                 const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
 
-private:
 	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi;
 	DevBuf ws_flag, ws_tie; // inner-product boundary ties: flagged queries + tie-pass scratch
 	int *h_flag_count = nullptr; // pinned
+	// row shard of a ShardedIndex (csrc/sharded.hip): results are the shard's ROW numbers in the pure order, no tie pass
+	// (the sharded index resolves ties across shards); an id map passed to search_flat then only feeds the selector
+	bool raw_rows = false;
+	// tie pass for `nf` flagged queries: out[f][0..k) = the k smallest row ids with score >= d_T[f] (ascending, -1 padded)
+	void tie_candidates(int64_t nf, const float *d_xf, const float *d_T, int64_t k, int64_t *d_rows_out, SelectorDev sel,
+	                    const int64_t *d_selmap, hipStream_t st);
+	SelectorDev upload_selector(const mvs_search_params *p, hipStream_t st) {
+		return selector.upload(p, st);
+	}
 	bool ip_exact_ties = true;   // option "ip_exact_ties" = 0: keep the pure (score desc, id asc) order (raw shard lists)
 	void resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const TieFlags &fl, SelectorDev sel,
 	                     const int64_t *d_idmap, float *d_D, int64_t *d_I, hipStream_t st);
@@ -230,6 +239,14 @@ IndexBase *hnsw_from_host(const HostIndex &h, int device);
 // csrc/io.cpp-ish (index_io.hip)
 void write_index_file(IndexBase *ix, const char *filename);
 IndexBase *read_index_file(const char *filename);
+// csrc/sharded.hip: one index over several devices behind the same surface
+std::vector<int> shard_devices_from_env(); // env MVS_DEVICES="0,1,...,7" (empty / unset: no sharding)
+IndexBase *make_sharded_index(int d, const char *desc, int metric, const std::vector<int> &devices);
+IndexBase *shard_from_host(const HostIndex &h, const std::vector<int> &devices);
+bool is_sharded(const IndexBase *ix);
+IndexBase *sharded_inner_view(IndexBase *ix); // the index the glue's dynamic_casts should see (ix itself if unsharded)
+void sharded_for_each(IndexBase *ix, const std::function<void(IndexBase *)> &f);
+int sharded_info(const IndexBase *ix, int *devices, int max_devices, int64_t *rows_per_shard, int64_t *last_flagged);
 // csrc/merge_host.hip
 void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
                        int64_t *I_out);

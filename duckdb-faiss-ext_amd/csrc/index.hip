@@ -393,7 +393,9 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	// it merges across splits -- with ONE extra entry per list; the merge flags the queries whose k-th and (k+1)-th
 	// scores are bit-equal and resolve_ip_ties() replays the heap's outcome for those (usually none).
 	const int64_t k_user = k;
-	const bool tie_detect = metric == METRIC_IP && ip_exact_ties && ntotal > k && k + 1 <= mfma_kmax;
+	const bool tie_detect = metric == METRIC_IP && ip_exact_ties && !raw_rows && ntotal > k && k + 1 <= mfma_kmax;
+	const int64_t *out_map = raw_rows ? nullptr : d_idmap; // label translation of the merge
+	const int64_t out_off = raw_rows ? 0 : label_offset;
 	if (tie_detect)
 		k = k + 1;
 	TieFlags fl = {nullptr, nullptr, nullptr, nullptr};
@@ -448,8 +450,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 			                 split_rows, sel, d_idmap, (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p,
 			                 (float *)ws_xi.p, st);
 			end_kernel_timing(st);
-			launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (int)nsplit, nq, k, d_idmap,
-			                      label_offset, d_D, d_I, st, k_user, flp);
+			launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (int)nsplit, nq, k, out_map,
+			                      out_off, d_D, d_I, st, k_user, flp);
 			snprintf(kinfo.name, sizeof kinfo.name, "flat_pair_scan (ivf_scan_kernel)");
 			kinfo.flops = 2.0 * (double)nq * (double)ntotal * d * (metric == METRIC_L2 ? 1.5 : 1.0);
 			kinfo.bytes = (double)ngroups * (double)ntotal * geom.dp * 4.0;
@@ -482,8 +484,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		launch_flat_direct_ex(geom, p, metric, formula, (const float *)ws_q.p, qn, nq, db, k, sel, d_idmap,
 		                      (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
 		end_kernel_timing(st);
-		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, nparts, nq, k, d_idmap,
-		                      label_offset, d_D, d_I, st, k_user, flp);
+		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, nparts, nq, k, out_map,
+		                      out_off, d_D, d_I, st, k_user, flp);
 		if (tie_detect)
 			resolve_ip_ties(nq, d_x, k_user, fl, sel, d_idmap, d_D, d_I, st);
 		snprintf(kinfo.name, sizeof kinfo.name, "flat_direct_kernel");
@@ -507,8 +509,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		launch_flat_mfma(geom, p, metric, (const float *)ws_q.p, (const float *)ws_qn.p, nq, db, k, (float *)ws_pd.p,
 		                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st, &sel, d_idmap);
 		end_kernel_timing(st);
-		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, k, d_idmap,
-		                      label_offset, d_D, d_I, st, k_user, flp);
+		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, k, out_map,
+		                      out_off, d_D, d_I, st, k_user, flp);
 		const int main_nsplit = p.nsplit, main_grid = p.grid;
 		const size_t main_lds = p.lds_bytes;
 		if (tie_detect)
@@ -546,19 +548,33 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 	float *tD = (float *)((char *)T + t_bytes);
 	int64_t *tI = (int64_t *)((char *)tD + td_bytes);
 	launch_gather_flagged(d_x, d, fl, nf, kraw, k, xf, T, st);
+	(void)tD;
+	tie_candidates(nf, xf, T, k, tI, sel, d_idmap, st);
+	launch_tie_resolve(fl, nf, kraw, k, tI, d_idmap, label_offset, d_D, d_I, st);
+}
+
+void FlatIndex::tie_candidates(int64_t nf, const float *d_xf, const float *d_T, int64_t k, int64_t *d_rows_out,
+                               SelectorDev sel, const int64_t *d_selmap, hipStream_t st) {
+	use_device();
+	if (nf <= 0)
+		return;
+	if (ntotal == 0) {
+		MVS_HIP(hipMemsetAsync(d_rows_out, 0xff, (size_t)nf * k * sizeof(int64_t), st));
+		return;
+	}
 	FlatSearchPlan p = plan_flat_mfma(geom, nf, ntotal, k);
 	ws_q.reserve(qfrag_floats(geom, nf) * sizeof(float));
-	launch_pack_queries(geom, xf, nf, (float *)ws_q.p, nullptr, st);
+	launch_pack_queries(geom, d_xf, nf, (float *)ws_q.p, nullptr, st);
 	ws_pd.reserve((size_t)p.nsplit * nf * k * sizeof(float));
 	ws_pi.reserve((size_t)p.nsplit * nf * k * sizeof(int32_t));
 	ws_gthr.reserve((size_t)nf * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+	ws_qn.reserve((size_t)nf * k * sizeof(float)); // the merge's distance output (all 0 / FLT_MAX), unused
 	FlatDB db {vecs, norms, ntotal};
-	launch_flat_mfma_tie(geom, p, (const float *)ws_q.p, T, nf, db, k, (float *)ws_pd.p, (int32_t *)ws_pi.p,
-	                     (unsigned *)ws_gthr.p, st, &sel, d_idmap);
+	launch_flat_mfma_tie(geom, p, (const float *)ws_q.p, d_T, nf, db, k, (float *)ws_pd.p, (int32_t *)ws_pi.p,
+	                     (unsigned *)ws_gthr.p, st, &sel, d_selmap);
 	// k smallest (0, row id): the L2-ordered merge; ids come out as plain row numbers
-	launch_merge_partials(METRIC_L2, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nf, k, nullptr, 0, tD, tI,
-	                      st);
-	launch_tie_resolve(fl, nf, kraw, k, tI, d_idmap, label_offset, d_D, d_I, st);
+	launch_merge_partials(METRIC_L2, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nf, k, nullptr, 0,
+	                      (float *)ws_qn.p, d_rows_out, st);
 }
 
 void FlatIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
@@ -936,7 +952,9 @@ int mvs_device_count(void) {
 int mvs_index_factory(mvs_index **out, int d, const char *description, int metric) {
 	MVS_API_BEGIN
 	*out = nullptr;
-	IndexBase *impl = index_factory(d, description, metric);
+	// env MVS_DEVICES=0,1,...,7: the index is created row-sharded / replicated over those devices (csrc/sharded.hip)
+	const std::vector<int> devs = shard_devices_from_env();
+	IndexBase *impl = devs.size() > 1 ? make_sharded_index(d, description, metric, devs) : index_factory(d, description, metric);
 	auto *h = new mvs_index;
 	h->impl = impl;
 	h->owned = true;
@@ -979,13 +997,14 @@ mvs_index *mvs_index_idmap_sub(mvs_index *ix) {
 		return nullptr;
 	if (!ix->sub_handle) {
 		ix->sub_handle = new mvs_index;
-		ix->sub_handle->impl = static_cast<IDMapIndex *>(ix->impl)->sub;
+		ix->sub_handle->impl =
+		    is_sharded(ix->impl) ? sharded_inner_view(ix->impl) : static_cast<IDMapIndex *>(ix->impl)->sub;
 		ix->sub_handle->owned = false;
 	}
 	return ix->sub_handle;
 }
 mvs_index *mvs_index_ivf_quantizer(mvs_index *ix) {
-	IndexBase *q = ivf_quantizer_of(ix->impl);
+	IndexBase *q = ivf_quantizer_of(sharded_inner_view(ix->impl));
 	if (!q)
 		return nullptr;
 	if (!ix->quantizer_handle) {
@@ -995,40 +1014,47 @@ mvs_index *mvs_index_ivf_quantizer(mvs_index *ix) {
 	}
 	return ix->quantizer_handle;
 }
-int64_t mvs_index_ivf_nlist(const mvs_index *ix) {
-	IndexBase *p = ix->impl;
+static IndexBase *unwrap_idmap(IndexBase *p) {
+	p = sharded_inner_view(p); // a sharded index answers for its first shard / replica
 	while (p->kind == MVS_KIND_IDMAP)
 		p = static_cast<IDMapIndex *>(p)->sub;
-	return ivf_nlist_of(p);
+	return p;
+}
+int64_t mvs_index_ivf_nlist(const mvs_index *ix) {
+	return ivf_nlist_of(unwrap_idmap(ix->impl));
 }
 int mvs_index_ivf_get_centroids(mvs_index *ix, float *out) {
 	MVS_API_BEGIN
-	IndexBase *p = ix->impl;
-	while (p->kind == MVS_KIND_IDMAP)
-		p = static_cast<IDMapIndex *>(p)->sub;
-	if (!ivf_get_centroids(p, out))
+	if (!ivf_get_centroids(unwrap_idmap(ix->impl), out))
 		throw_faiss("mvs_index_ivf_get_centroids", __FILE__, "not an IVF index");
 	MVS_API_END
 }
 int mvs_index_ivf_set_centroids(mvs_index *ix, const float *centroids) {
 	MVS_API_BEGIN
-	IndexBase *p = ix->impl, *top = ix->impl;
-	while (p->kind == MVS_KIND_IDMAP)
-		p = static_cast<IDMapIndex *>(p)->sub;
-	if (!ivf_set_centroids(p, centroids))
+	bool ok = true;
+	sharded_for_each(ix->impl, [&](IndexBase *top) { // every row shard probes the same lists
+		IndexBase *p = top;
+		while (p->kind == MVS_KIND_IDMAP)
+			p = static_cast<IDMapIndex *>(p)->sub;
+		ok = ok && ivf_set_centroids(p, centroids);
+		for (IndexBase *w = top; w->kind == MVS_KIND_IDMAP; w = static_cast<IDMapIndex *>(w)->sub)
+			w->is_trained = true;
+	});
+	if (!ok)
 		throw_faiss("mvs_index_ivf_set_centroids", __FILE__, "not an IVF index");
-	for (IndexBase *w = top; w->kind == MVS_KIND_IDMAP; w = static_cast<IDMapIndex *>(w)->sub)
-		w->is_trained = true;
+	ix->impl->is_trained = true;
 	MVS_API_END
-}
-static IndexBase *unwrap_idmap(IndexBase *p) {
-	while (p->kind == MVS_KIND_IDMAP)
-		p = static_cast<IDMapIndex *>(p)->sub;
-	return p;
 }
 int mvs_index_hnsw_set_ef_construction(mvs_index *ix, int v) {
 	MVS_API_BEGIN
-	if (!hnsw_set_ef_construction(unwrap_idmap(ix->impl), v))
+	bool ok = true;
+	sharded_for_each(ix->impl, [&](IndexBase *top) { // every replica builds with the same parameter
+		IndexBase *p = top;
+		while (p->kind == MVS_KIND_IDMAP)
+			p = static_cast<IDMapIndex *>(p)->sub;
+		ok = ok && hnsw_set_ef_construction(p, v);
+	});
+	if (!ok)
 		throw_faiss("mvs_index_hnsw_set_ef_construction", __FILE__, "not an HNSW index");
 	MVS_API_END
 }
@@ -1084,12 +1110,47 @@ int mvs_index_clone_to_gpu(mvs_index **out, const mvs_index *src, int device) {
 	MVS_API_BEGIN
 	*out = nullptr;
 	std::lock_guard<std::mutex> g(const_cast<mvs_index *>(src)->mu);
-	IndexBase *impl = src->impl->clone(device);
+	IndexBase *impl = nullptr;
+	if (device < 0) { // faiss_to_gpu(name, -1): every device of MVS_DEVICES, or all visible ones
+		std::vector<int> devs = shard_devices_from_env();
+		if (devs.empty())
+			for (int i = 0; i < mvs_device_count(); ++i)
+				devs.push_back(i);
+		HostIndex img;
+		src->impl->to_host(img);
+		impl = shard_from_host(img, devs);
+	} else {
+		impl = src->impl->clone(device);
+	}
 	auto *h = new mvs_index;
 	h->impl = impl;
 	h->owned = true;
 	*out = h;
 	MVS_API_END
+}
+int mvs_index_shard_to_gpus(mvs_index *ix, const int *devices, int ndev) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	if (ndev <= 0 || !devices)
+		throw_faiss("mvs_index_shard_to_gpus", __FILE__, "Invalid GPU device list");
+	if (ix->sub_handle || ix->quantizer_handle) {
+		// borrowed views of the old object graph (IndexIDMap::index, IndexIVF::quantizer) die with it
+		delete ix->sub_handle;
+		delete ix->quantizer_handle;
+		ix->sub_handle = ix->quantizer_handle = nullptr;
+	}
+	HostIndex img;
+	ix->impl->to_host(img);
+	IndexBase *sharded = shard_from_host(img, std::vector<int>(devices, devices + ndev));
+	if (ix->owned)
+		delete ix->impl;
+	ix->impl = sharded;
+	ix->owned = true;
+	MVS_API_END
+}
+int mvs_index_shard_info(const mvs_index *ix, int *devices, int max_devices, int64_t *rows_per_shard,
+                         int64_t *last_tie_queries) {
+	return sharded_info(ix->impl, devices, max_devices, rows_per_shard, last_tie_queries);
 }
 int mvs_index_add_device(mvs_index *ix, int64_t n, const float *d_x, const int64_t *d_ids, void *stream) {
 	MVS_API_BEGIN
@@ -1178,6 +1239,10 @@ namespace mvs {
 bool FlatIndex::set_option(const char *key, int64_t v) {
 	if (!strcmp(key, "force_staged")) { // per-pair path on the LDS-staged flat_direct kernel instead of the scan kernel
 		force_staged = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "raw_rows")) {
+		raw_rows = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "ip_exact_ties")) { // 0: pure (score desc, id asc) order, no tie pass (diagnostics)

@@ -344,6 +344,10 @@ IndexBase *read_index_file(const char *filename) {
 		throw;
 	}
 	fclose(f);
+	// env MVS_DEVICES=0,1,...: the loaded index is spread over those devices (csrc/sharded.hip)
+	const std::vector<int> devs = shard_devices_from_env();
+	if (devs.size() > 1)
+		return shard_from_host(h, devs);
 	return index_from_host(h, -1);
 }
 

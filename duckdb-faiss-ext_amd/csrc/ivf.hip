@@ -4,9 +4,9 @@
 // (:607,:609 -- one call with all rows after training) and search with SearchParametersIVF{nprobe,sel} (:631,
 // :675-689) of /root/reference/src/faiss_extension.cpp.  Restated FAISS behaviour [UPSTREAM: faiss/IndexIVF.cpp,
 // IndexIVFFlat.cpp, Clustering.cpp, utils/random.cpp; see oracle/orc_core.c for the line-by-line restatement]:
-//   train  : k-means (niter 25, seed 1234, <= 256 points per centroid subsample via rand_perm, centroids initialised
+//   train  : k-means (niter 10 = Level1Quantizer's cp.niter, seed 1234, <= 256 points per centroid subsample via rand_perm, centroids initialised
 //            from rand_perm(seed+1), empty-cluster splitting, spherical for inner product).  The ASSIGNMENT step --
-//            27.5 TFLOP at IVF4096 -- runs on the fused MFMA Flat kernel (k = 1); the centroid update keeps FAISS's
+//            11 TFLOP at IVF4096 -- runs on the fused MFMA Flat kernel (k = 1); the centroid update keeps FAISS's
 //            sequential summation order on device too (stable sort by assignment + one thread per (centroid, dim),
 //            csrc/kmeans_update.hip); the host only replays the RNG-driven empty-cluster splits on k x d values.
 //   add    : assign = quantizer search k=1 in blocks of 65536 rows; (id, raw vector) appended to list assign[i] in
@@ -501,7 +501,7 @@ public:
 		                (unsigned *)ws_gslot.p, (float *)ws_xi.p, d_nitems, stream);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
-		                   k, (const int64_t *)rowids.p, d_idmap, d_D, d_I, stream);
+		                   k, (const int64_t *)rowids.p, raw_ids ? nullptr : d_idmap, d_D, d_I, stream);
 		snprintf(kinfo.name, sizeof kinfo.name, "ivf_scan_kernel");
 		kinfo.grid = max_items;
 		kinfo.block = 256;
@@ -555,7 +555,7 @@ public:
 		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
-		                   k, (const int64_t *)rowids_mf.p, d_idmap, d_D, d_I, stream, G, shift);
+		                   k, (const int64_t *)rowids_mf.p, raw_ids ? nullptr : d_idmap, d_D, d_I, stream, G, shift);
 		snprintf(kinfo.name, sizeof kinfo.name, "ivf_mfma_scan (flat_mfma_resident_kernel items)");
 		kinfo.grid = max_items;
 		kinfo.block = 256;
@@ -647,7 +647,7 @@ public:
 			                    (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
-		                   k, (const int64_t *)rowids.p, d_idmap, d_D, d_I, stream);
+		                   k, (const int64_t *)rowids.p, raw_ids ? nullptr : d_idmap, d_D, d_I, stream);
 		// the caller's stream continues after ours; pageable staging vectors die with this frame
 		MVS_HIP(hipStreamSynchronize(stream));
 		stream_wait(st, stream);
@@ -745,6 +745,10 @@ public:
 			mfma_mode = (int)v;
 			return true;
 		}
+		if (!strcmp(key, "ivf_raw_ids")) { // row shards: labels = the stored ids even when an id map feeds the selector
+			raw_ids = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_fast_scan")) { // 0 = the LDS-staged flat_direct item kernel
 			use_fast_scan = v != 0;
 			return true;
@@ -752,6 +756,7 @@ public:
 		return quantizer->set_option(key, v);
 	}
 	bool use_fast_scan = true;
+	bool raw_ids = false;
 	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always
 
 	// introspection for parity tests

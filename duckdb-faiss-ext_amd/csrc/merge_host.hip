@@ -1,9 +1,10 @@
 // csrc/merge_host.hip -- host k-way merge of per-shard (distance,label) blocks.
-// Follows the RCCL all-gather in the row-sharded multi-GPU search: every shard returns its k best per query
-// in FAISS order with GLOBAL labels; the merged list is the k best of the union under
-//   L2: (distance asc, label asc)                    == what one CMax heap over all rows keeps
-//   IP: (score desc, label asc) membership, equal scores printed in descending label order
-// [faiss/utils/Heap.h heap_reorder; faiss::IndexShards merges with the same heap rule]
+// Follows the RCCL all-gather / per-device gather in the row-sharded multi-GPU search: every shard returns its best
+// candidates per query with GLOBAL ids; the merged list is the best of the union under the pure order
+//   L2: (distance asc, id asc)                    == what one CMax heap over all rows keeps
+//   IP: (score desc, id asc); equal scores are PRINTED in descending id order (heap_reorder over a CMin heap)
+// [faiss/utils/Heap.h heap_reorder; faiss::IndexShards merges with the same heap rule].
+// The inputs are never modified (they may be read-only / mmapped RCCL receive buffers).
 #include "index.h"
 
 #include <algorithm>
@@ -11,96 +12,140 @@
 
 namespace mvs {
 
-static void merge_range(int metric, int64_t q0, int64_t q1, int64_t n, int64_t k, int nshard, const float *D,
-                        const int64_t *I, float *D_out, int64_t *I_out) {
-	const bool is_l2 = metric == METRIC_L2;
-	const float neutral = is_l2 ? FLT_MAX : -FLT_MAX;
-	std::vector<int> pos((size_t)nshard);
-	for (int64_t q = q0; q < q1; ++q) {
-		// shard lists are sorted: classic k-way merge by repeatedly taking the best head
-		std::fill(pos.begin(), pos.end(), 0);
-		int64_t m = 0;
-		for (; m < k; ++m) {
-			int best = -1;
-			float bv = 0;
-			int64_t bi = 0;
-			for (int s = 0; s < nshard; ++s) {
-				// within a shard equal IP scores are printed in descending label order; membership prefers the
-				// smaller label, so scan the run of equal scores for its smallest unconsumed label
-				if (pos[s] >= k)
-					continue;
-				const float *ds = D + ((size_t)s * n + q) * k;
-				const int64_t *is = I + ((size_t)s * n + q) * k;
-				int p = pos[s];
-				if (is[p] < 0)
-					continue;
-				float v = ds[p];
-				int64_t id = is[p];
-				if (!is_l2) {
-					int e = p;
-					while (e + 1 < k && is[e + 1] >= 0 && ds[e + 1] == v)
-						++e;
-					id = is[e]; // smallest label of the run sits at its end
-				}
-				bool better = best < 0 || (is_l2 ? (v < bv || (v == bv && id < bi)) : (v > bv || (v == bv && id < bi)));
-				if (better) {
-					best = s;
-					bv = v;
-					bi = id;
-				}
-			}
-			if (best < 0)
-				break;
-			D_out[q * k + m] = bv;
-			I_out[q * k + m] = bi;
-			if (is_l2) {
-				pos[best]++;
-			} else {
-				// consume the run's last element: shrink the run from its end by marking it used
-				const float *ds = D + ((size_t)best * n + q) * k;
-				int64_t *is = const_cast<int64_t *>(I + ((size_t)best * n + q) * k);
-				int p = pos[best], e = p;
-				while (e + 1 < k && is[e + 1] >= 0 && ds[e + 1] == ds[p])
-					++e;
-				// rotate: move is[e] out by shifting [p, e) right by one; cheaper: swap with head and advance
-				std::swap(is[p], is[e]);
-				pos[best]++;
-				// restore descending order of the remaining run [p+1, e]
-				std::sort(is + p + 1, is + e + 1, [](int64_t a, int64_t b) { return a > b; });
-			}
-		}
-		if (!is_l2) {
-			// print equal scores in descending label order
-			int64_t a = 0;
-			while (a < m) {
-				int64_t b = a + 1;
-				while (b < m && D_out[q * k + b] == D_out[q * k + a])
-					++b;
-				std::reverse(I_out + q * k + a, I_out + q * k + b);
-				a = b;
-			}
-		}
-		for (; m < k; ++m) {
-			D_out[q * k + m] = neutral;
-			I_out[q * k + m] = -1;
-		}
+namespace {
+
+struct Cand {
+	float v;
+	int64_t id;    // ordering id (global row number)
+	int64_t label; // what the caller sees
+};
+
+inline bool cand_before(bool is_l2, const Cand &a, const Cand &b) {
+	if (a.v != b.v)
+		return is_l2 ? a.v < b.v : a.v > b.v;
+	return a.id < b.id;
+}
+
+// print order of an inner-product result: runs of equal scores in descending id
+inline void print_order_ip(Cand *c, int64_t m) {
+	int64_t a = 0;
+	while (a < m) {
+		int64_t b = a + 1;
+		while (b < m && c[b].v == c[a].v)
+			++b;
+		std::reverse(c + a, c + b);
+		a = b;
 	}
 }
 
-// queries are independent: the merge runs on up to 16 host threads (it sits on the critical path of every multi-GPU
-// search step, after the all-gather)
-void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
-                       int64_t *I_out) {
+template <typename F>
+void parallel_queries(int64_t n, F &&body) {
 	int nt = (int)std::min<int64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), n / 512 + 1);
 	if (nt <= 1) {
-		merge_range(metric, 0, n, n, k, nshard, D, I, D_out, I_out);
+		body((int64_t)0, n);
 		return;
 	}
 	std::vector<std::thread> th;
 	for (int t = 0; t < nt; ++t)
-		th.emplace_back(merge_range, metric, n * t / nt, n * (t + 1) / nt, n, k, nshard, D, I, D_out, I_out);
+		th.emplace_back([&, t] { body(n * t / nt, n * (t + 1) / nt); });
 	for (auto &x : th)
 		x.join();
+}
+
+} // namespace
+
+// queries are independent: the merge runs on up to 16 host threads (it sits on the critical path of every multi-GPU
+// search step, after the exchange).  Per query: collect the nshard*k candidates, order them, keep k.
+void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
+                       int64_t *I_out) {
+	const bool is_l2 = metric == METRIC_L2;
+	const float neutral = is_l2 ? FLT_MAX : -FLT_MAX;
+	parallel_queries(n, [&](int64_t q0, int64_t q1) {
+		std::vector<Cand> c((size_t)nshard * k);
+		for (int64_t q = q0; q < q1; ++q) {
+			int64_t m = 0;
+			for (int s = 0; s < nshard; ++s) {
+				const float *ds = D + ((size_t)s * n + q) * k;
+				const int64_t *is = I + ((size_t)s * n + q) * k;
+				for (int64_t j = 0; j < k; ++j)
+					if (is[j] >= 0)
+						c[(size_t)m++] = {ds[j], is[j], is[j]};
+			}
+			const int64_t keep = std::min(m, k);
+			std::partial_sort(c.begin(), c.begin() + keep, c.begin() + m,
+			                  [&](const Cand &a, const Cand &b) { return cand_before(is_l2, a, b); });
+			if (!is_l2)
+				print_order_ip(c.data(), keep);
+			for (int64_t j = 0; j < k; ++j) {
+				D_out[q * k + j] = j < keep ? c[(size_t)j].v : neutral;
+				I_out[q * k + j] = j < keep ? c[(size_t)j].label : -1;
+			}
+		}
+	});
+}
+
+// ---- ShardedIndex (csrc/sharded.hip): merge of RAW shard lists ---------------------------------------------------
+// Shard s hands over kk candidates per query: value, global row number (the ordering id; < 0 = empty slot).  Output: the
+// first kk of the union in the pure order (val[nq][kk], gnum[nq][kk]; unfilled slots gnum = -1).
+void merge_raw_lists_host(int metric, int64_t nq, int64_t kk, int nshard, const float *const *D, const int64_t *const *G,
+                          float *val, int64_t *gnum) {
+	const bool is_l2 = metric == METRIC_L2;
+	const float neutral = is_l2 ? FLT_MAX : -FLT_MAX;
+	parallel_queries(nq, [&](int64_t q0, int64_t q1) {
+		std::vector<Cand> c((size_t)nshard * kk);
+		for (int64_t q = q0; q < q1; ++q) {
+			int64_t m = 0;
+			for (int s = 0; s < nshard; ++s)
+				for (int64_t j = 0; j < kk; ++j)
+					if (G[s][q * kk + j] >= 0)
+						c[(size_t)m++] = {D[s][q * kk + j], G[s][q * kk + j], 0};
+			const int64_t keep = std::min(m, kk);
+			std::partial_sort(c.begin(), c.begin() + keep, c.begin() + m,
+			                  [&](const Cand &a, const Cand &b) { return cand_before(is_l2, a, b); });
+			for (int64_t j = 0; j < kk; ++j) {
+				val[q * kk + j] = j < keep ? c[(size_t)j].v : neutral;
+				gnum[q * kk + j] = j < keep ? c[(size_t)j].id : -1;
+			}
+		}
+	});
+}
+
+// FAISS's CMin-heap outcome for one query with an exact tie at its k-th score (same closed form as
+// tie_resolve_kernel, csrc/util_kernels.hip): raw = merged top-(k+1) in the pure order, first = the k smallest global
+// row numbers with score >= T (ascending, -1 padded).  Writes k (value, gnum) pairs in heap_reorder's print order.
+void resolve_ip_tie_host(int64_t k, const float *raw_v, const int64_t *raw_g, const int64_t *first, float *out_v,
+                         int64_t *out_g) {
+	const float T = raw_v[k - 1];
+	int64_t ngt = 0;
+	while (ngt < k && raw_v[ngt] > T)
+		++ngt;
+	auto above = [&](int64_t g) {
+		for (int64_t j = 0; j < ngt; ++j)
+			if (raw_g[j] == g)
+				return true;
+		return false;
+	};
+	int64_t in_a = 0;
+	for (int64_t j = 0; j < k; ++j)
+		if (first[j] >= 0 && above(first[j]))
+			++in_a;
+	const int64_t G = ngt - in_a;
+	std::vector<Cand> c;
+	for (int64_t j = 0; j < ngt; ++j)
+		c.push_back({raw_v[j], raw_g[j], 0});
+	int64_t seen = 0;
+	for (int64_t j = 0; j < k && (int64_t)c.size() < k; ++j) {
+		if (first[j] < 0 || above(first[j]))
+			continue;
+		if (seen++ < G)
+			continue;
+		c.push_back({T, first[j], 0});
+	}
+	print_order_ip(c.data(), (int64_t)c.size());
+	for (int64_t j = 0; j < k; ++j) {
+		out_v[j] = j < (int64_t)c.size() ? c[(size_t)j].v : -FLT_MAX;
+		out_g[j] = j < (int64_t)c.size() ? c[(size_t)j].id : -1;
+	}
 }
 
 } // namespace mvs

@@ -116,6 +116,8 @@ _L.mvs_index_add_with_ids.argtypes = [_p, _i64, _p, _p]
 _L.mvs_index_search.argtypes = [_p, _i64, _p, _i64, _p, _p, C.POINTER(SearchParams)]
 _L.mvs_index_to_gpu.argtypes = [_p, C.c_int]
 _L.mvs_index_clone_to_gpu.argtypes = [C.POINTER(_p), _p, C.c_int]
+_L.mvs_index_shard_to_gpus.argtypes = [_p, C.POINTER(C.c_int), C.c_int]
+_L.mvs_index_shard_info.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_write_index.argtypes = [_p, C.c_char_p]
 _L.mvs_read_index.argtypes = [C.POINTER(_p), C.c_char_p]
 _L.mvs_index_add_device.argtypes = [_p, _i64, _p, _p, _p]
@@ -137,7 +139,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_get_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_get_graph",
     "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
-    "mvs_write_index",
+    "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
     "mvs_merge_shards", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
@@ -284,6 +286,19 @@ class Index:
         h = _p()
         _check(_L.mvs_index_clone_to_gpu(C.byref(h), self._h, int(device)))
         return Index(h)
+
+    def shard_to_gpus(self, devices):
+        """spread this index over `devices` in place (row shards; HNSW: replicas) -- include/mi355_faiss.h"""
+        arr = (C.c_int * len(devices))(*[int(v) for v in devices])
+        _check(_L.mvs_index_shard_to_gpus(self._h, arr, len(devices)))
+
+    def shard_info(self):
+        """-> None (not sharded) | dict(devices, rows_per_shard, last_tie_queries)"""
+        devs, rows, ties = (C.c_int * 64)(), (_i64 * 64)(), _i64(0)
+        n = _L.mvs_index_shard_info(self._h, devs, 64, rows, C.byref(ties))
+        if n <= 0:
+            return None
+        return {"devices": list(devs[:n]), "rows_per_shard": list(rows[:n]), "last_tie_queries": ties.value}
 
     # ---- device-resident variants (torch tensors on the index's device) ----
     def add_torch(self, x, ids=None, stream=None):

@@ -117,6 +117,22 @@ int mvs_index_device(const mvs_index *ix);
  * entry.index with the result and drops the old object, src/gpu/gpu.cpp:48) */
 int mvs_index_clone_to_gpu(mvs_index **out, const mvs_index *src, int device);
 
+/* ---- several devices behind the same surface -------------------------------------------------
+ * The reference's hook names ONE device (MoveToGPUFunction, src/gpu/gpu.cpp:34-63 -> index_cpu_to_gpu(res, device,
+ * index) :48).  Three ways reach all GPUs of the node WITHOUT touching src/faiss_extension.cpp:
+ *   - faiss_to_gpu(name, -1): mvs_index_clone_to_gpu(out, src, -1) returns the index spread over every device of env
+ *     MVS_DEVICES ("0,1,...,7"; default: all visible devices);
+ *   - env MVS_DEVICES set when faiss_create / faiss_load run: mvs_index_factory / mvs_read_index build it sharded;
+ *   - mvs_index_shard_to_gpus: the same conversion in place, for hosts that hold the handle.
+ * Flat / IDMap,Flat / IVF<n>,Flat are ROW-SHARDED (IVF: one set of centroids, trained once, on every device; every
+ * inverted list split); HNSW is REPLICATED and the queries are split.  Results are identical to the single-device
+ * index bit for bit (labels and distances, including inner-product boundary ties): one exchange of the per-shard
+ * (value, global row) blocks -- option "shard_exchange" 0 = per-device D2H, 1 = one ncclAllGather over xGMI -- then the
+ * host k-way merge.  mvs_index_shard_info returns the shard count (0 = not sharded). */
+int mvs_index_shard_to_gpus(mvs_index *ix, const int *devices, int ndev);
+int mvs_index_shard_info(const mvs_index *ix, int *devices, int max_devices, int64_t *rows_per_shard,
+                         int64_t *last_tie_queries);
+
 /* faiss::write_index / read_index  -- src/faiss_extension.cpp:199,234 */
 int mvs_write_index(const mvs_index *ix, const char *filename);
 int mvs_read_index(mvs_index **out, const char *filename);

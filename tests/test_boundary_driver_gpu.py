@@ -23,10 +23,16 @@ def test_driver_and_adaptor_are_built():
 
 
 @pytest.mark.gpu
-def test_glue_call_patterns_reproduce_reference_goldens():
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_glue_call_patterns_reproduce_reference_goldens(devices):
+    """devices = "0,0,0": the same unmodified call sequence with env MVS_DEVICES set, i.e. every index the glue creates is
+    row-sharded (three virtual shards on the one device of this box) behind the faiss:: surface -- same goldens."""
+    env = dict(os.environ)
+    if devices:
+        env["MVS_DEVICES"] = devices
     out = subprocess.run(
         [DRIVER, "golden", os.path.join(GOLDEN, "training.csv"), os.path.join(GOLDEN, "queries.csv")],
-        capture_output=True, text=True, timeout=300,
+        capture_output=True, text=True, timeout=300, env=env,
     )  # fmt: skip
     assert out.returncode == 0, out.stderr
     g = goldens()
@@ -49,8 +55,12 @@ def test_glue_call_patterns_reproduce_reference_goldens():
 
 
 @pytest.mark.gpu
-def test_concurrent_datachunk_ingest():
-    out = subprocess.run([DRIVER, "ingest", "300000", "128", "6"], capture_output=True, text=True, timeout=600)
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_concurrent_datachunk_ingest(devices):
+    env = dict(os.environ)
+    if devices:
+        env["MVS_DEVICES"] = devices
+    out = subprocess.run([DRIVER, "ingest", "300000", "128", "6"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ingest\tOK" in out.stdout
 

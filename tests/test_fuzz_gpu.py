@@ -35,12 +35,6 @@ def _selector(rs, ids):
     return ("bitmap", bm)
 
 
-def _rows_without_boundary_ties(D, Dk1, k):
-    if Dk1.shape[1] <= k:
-        return np.ones(len(D), dtype=bool)
-    return Dk1[:, k - 1] != Dk1[:, k]
-
-
 @pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_flat_fuzz(mf, seed):
     rs = np.random.RandomState(1000 + seed)
@@ -62,12 +56,9 @@ def test_flat_fuzz(mf, seed):
     sel = _selector(rs, ids)
     D, I = g.search(xq, k, sel=sel)
     Do, Io = o.search(xq, k, sel=sel)
-    ok = np.ones(nq, dtype=bool)
-    if metric == IP:
-        ok = _rows_without_boundary_ties(Do, o.search(xq, k + 1, sel=sel)[0], k)
     what = f"flat seed={seed} d={d} n={n} nq={nq} k={k} metric={metric} idmap={idmap} sel={sel and sel[0]}"
-    assert np.array_equal(I[ok], Io[ok]), what
-    assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32)), what
+    assert np.array_equal(I, Io), what
+    assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), what
 
 
 @pytest.mark.parametrize("seed", range(10 * _SCALE))

@@ -1,0 +1,163 @@
+"""Sharding BEHIND the boundary (csrc/sharded.hip): one index handle spread over several devices inside
+libmi355faiss.so, reached through the unmodified surface -- faiss_to_gpu(name, -1) / env MVS_DEVICES /
+mvs_index_shard_to_gpus (reference hook: src/gpu/gpu.cpp:34-63).  This box has one GPU, so the shards are VIRTUAL
+(several shards on device 0, host exchange): the merged answer must equal the unsharded index bit for bit, labels and
+distances, including inner-product boundary ties across shards.  The RCCL exchange is exercised with one rank."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import bitmap_from_ids
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+L2, IP = orc.METRIC_L2, orc.METRIC_INNER_PRODUCT
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import mi355_faiss
+
+    return mi355_faiss
+
+
+def _same(a, b, what):
+    assert np.array_equal(a[1], b[1]), what + ": labels"
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), what + ": distances"
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("idmap", [False, True])
+@pytest.mark.parametrize("G", [2, 5])
+def test_flat_row_shards_equal_unsharded_and_oracle(mf, metric, idmap, G):
+    d, nb, k = 64, 40_000, 10
+    rs = np.random.RandomState(7 + G)
+    xb = rs.rand(nb, d).astype(np.float32)
+    xb[rs.randint(0, nb, 3000)] = xb[rs.randint(0, nb, 3000)]  # duplicate rows: exact ties across shards
+    xq = np.concatenate([rs.rand(90, d).astype(np.float32), xb[rs.randint(0, nb, 40)]])
+    ids = (rs.permutation(3 * nb)[:nb] + 9).astype(np.int64)
+    desc = "IDMap,Flat" if idmap else "Flat"
+    one, sh, o = mf.index_factory(d, desc, metric), mf.index_factory(d, desc, metric), orc.Index(d, desc, metric)
+    sh.shard_to_gpus([0] * G)  # an EMPTY index is sharded, then filled the way AddFunction does: <= 2048-row chunks
+    assert sh.shard_info()["devices"] == [0] * G
+    for a in (one, sh, o):
+        for i0 in range(0, nb, 2048):
+            a.add_with_ids(xb[i0 : i0 + 2048], ids[i0 : i0 + 2048]) if idmap else a.add(xb[i0 : i0 + 2048])
+    rows = sh.shard_info()["rows_per_shard"]
+    assert sum(rows) == nb and max(rows) - min(rows) <= 2048 and sh.ntotal == nb
+    keep = ids[rs.rand(nb) < 0.4] if idmap else np.arange(nb)[rs.rand(nb) < 0.4]
+    all_ids = ids if idmap else np.arange(nb)
+    for sel in (None, ("batch", keep), ("bitmap", bitmap_from_ids(all_ids, np.isin(all_ids, keep)))):
+        for q in (xq, xq[:7]):  # both FAISS dispatch branches
+            ref = one.search(q, k, sel=sel)
+            _same(sh.search(q, k, sel=sel), ref, f"sharded vs unsharded m={metric} idmap={idmap} sel={sel and sel[0]} nq={len(q)}")
+            _same(ref, o.search(q, k, sel=sel), "unsharded vs oracle")
+
+
+@pytest.mark.parametrize("G", [3])
+def test_inner_product_ties_across_shards(mf, G):
+    """integer coordinates -> most queries have many rows tied at the k-th score, spread over all shards, with better rows
+    arriving later in other shards: the cross-shard tie pass must reproduce the single CMin heap"""
+    d, nb, k = 12, 30_000, 10
+    rs = np.random.RandomState(3)
+    xb = rs.randint(-2, 3, size=(nb, d)).astype(np.float32)
+    xq = rs.randint(-2, 3, size=(64, d)).astype(np.float32)
+    sh, o = mf.index_factory(d, "Flat", IP), orc.Index(d, "Flat", IP)
+    for i0 in range(0, nb, 2048):
+        sh.add(xb[i0 : i0 + 2048])
+        o.add(xb[i0 : i0 + 2048])
+    sh.shard_to_gpus([0] * G)  # a FILLED index is redistributed
+    assert sum(sh.shard_info()["rows_per_shard"]) == nb
+    _same(sh.search(xq, k), o.search(xq, k), "IP ties across shards")
+    assert sh.shard_info()["last_tie_queries"] > 20
+
+
+def test_env_devices_shards_at_creation(mf, monkeypatch):
+    monkeypatch.setenv("MVS_DEVICES", "0,0,0,0")
+    ix = mf.index_factory(32, "IDMap,Flat", L2)
+    monkeypatch.delenv("MVS_DEVICES")
+    assert ix.shard_info()["devices"] == [0, 0, 0, 0] and ix.kind == mf.KIND_IDMAP and ix.index.kind == mf.KIND_FLAT
+    xb, xq = orc.synth_uniform(20000, 32, 1), orc.synth_uniform(30, 32, 2)
+    ids = np.arange(20000, dtype=np.int64) * 5 + 1
+    ix.add_with_ids(xb, ids)  # >= 4096 rows per device: one contiguous piece each
+    assert ix.shard_info()["rows_per_shard"] == [5000] * 4
+    ix.add_with_ids(xb[:100] * 0.5, ids[:100] + 1)  # a DataChunk-sized add goes whole to one device
+    assert sorted(ix.shard_info()["rows_per_shard"]) == [5000, 5000, 5000, 5100]
+    o = orc.Index(32, "IDMap,Flat", L2)
+    o.add_with_ids(xb, ids)
+    o.add_with_ids(xb[:100] * 0.5, ids[:100] + 1)
+    _same(ix.search(xq, 5), o.search(xq, 5), "env-sharded IDMap,Flat")
+    with pytest.raises(mf.FaissException, match="add does not make sense"):
+        ix.add(xb[:3])
+    plain = mf.index_factory(32, "Flat", L2)
+    with pytest.raises(mf.FaissException, match="add_with_ids not implemented"):
+        plain.shard_to_gpus([0, 0]) or plain.add_with_ids(xb[:3], ids[:3])
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("idmap", [False, True])
+def test_ivf_row_sharded_lists(mf, metric, idmap):
+    d, nb, k, G = 48, 30_000, 10, 3
+    xb = orc.synth_clustered(nb, d, 5, n_centers=64, sigma=0.15)
+    xq = orc.synth_clustered(200, d, 6, n_centers=64, sigma=0.15)
+    ids = np.arange(nb, dtype=np.int64) * 3 + 100
+    desc = ("IDMap," if idmap else "") + "IVF64,Flat"
+    one, sh = mf.index_factory(d, desc, metric), mf.index_factory(d, desc, metric)
+    sh.shard_to_gpus([0] * G)
+    for a in (one, sh):
+        a.train(xb)  # the sharded index trains ONCE on the global training set and replicates the centroids
+        assert a.is_trained
+        a.add_with_ids(xb, ids) if idmap else a.add(xb)
+    assert np.array_equal(one.ivf_centroids(), sh.ivf_centroids()) and sh.nlist == 64
+    keep = (ids if idmap else np.arange(nb))[::3]
+    for sel in (None, ("batch", keep)):
+        for nprobe in (1, 8):
+            D1, I1 = one.search(xq, k, nprobe=nprobe, sel=sel)
+            D2, I2 = sh.search(xq, k, nprobe=nprobe, sel=sel)
+            ok = np.array([len(np.unique(r)) == k for r in D1]) if metric == IP else np.ones(len(xq), bool)
+            assert np.array_equal(I1[ok], I2[ok]) and np.array_equal(D1[ok], D2[ok]), (metric, idmap, nprobe, sel and sel[0])
+
+
+def test_hnsw_replicas_split_the_queries(mf, tmp_path):
+    d, nb = 32, 6000
+    xb, xq = orc.synth_uniform(nb, d, 11), orc.synth_uniform(101, d, 12)
+    ids = np.arange(nb, dtype=np.int64) + 7
+    one = mf.index_factory(d, "IDMap,HNSW16", L2)
+    one.set_option("hnsw_build_waves", 1)
+    one.set_ef_construction(60)
+    one.add_with_ids(xb, ids)
+    ref = one.search(xq, 10, efSearch=64)
+    sh = one.clone_to_gpu(-1)  # faiss_to_gpu(name, -1): all visible devices (one here) ...
+    assert sh.shard_info()["devices"] == [0]
+    _same(sh.search(xq, 10, efSearch=64), ref, "one replica")
+    one.shard_to_gpus([0, 0, 0])  # ... and three replicas of the stored graph, queries split three ways
+    assert one.shard_info()["rows_per_shard"] == [nb] * 3 and one.kind == mf.KIND_IDMAP and one.index.kind == mf.KIND_HNSW
+    _same(one.search(xq, 10, efSearch=64), ref, "three replicas")
+    p = str(tmp_path / "r.index")
+    mf.write_index(one, p)  # SaveFunction on a sharded index writes the equivalent single index
+    _same(mf.read_index(p).search(xq, 10, efSearch=64), ref, "after write/read")
+
+
+@pytest.mark.parametrize("desc,metric", [("Flat", L2), ("IDMap,Flat", IP)])
+def test_rccl_exchange_single_rank_and_save(mf, tmp_path, desc, metric):
+    """shard_exchange = rccl: in-process communicator + ONE ncclAllGather of the packed records (a single rank on this
+    box; two virtual shards on one device are refused by RCCL and must fail loudly, not fall back silently)"""
+    d, nb = 40, 12_000
+    xb, xq = orc.synth_uniform(nb, d, 21), orc.synth_uniform(50, d, 22)
+    ids = np.arange(nb, dtype=np.int64) * 2 + 3
+    ix, o = mf.index_factory(d, desc, metric), orc.Index(d, desc, metric)
+    for a in (ix, o):
+        a.add_with_ids(xb, ids) if desc.startswith("IDMap") else a.add(xb)
+    ix.shard_to_gpus([0])
+    ix.set_option("shard_exchange", 1)
+    _same(ix.search(xq, 10), o.search(xq, 10), "rccl exchange, one rank")
+    p = str(tmp_path / "s.index")
+    mf.write_index(ix, p)
+    _same(mf.read_index(p).search(xq, 10), o.search(xq, 10), "sharded -> file -> single index")
+    two = mf.index_factory(d, "Flat", L2)
+    two.add(xb)
+    two.shard_to_gpus([0, 0])
+    two.set_option("shard_exchange", 1)
+    with pytest.raises(mf.FaissException, match="one device per shard"):
+        two.search(xq, 10)
