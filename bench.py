@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (spec; ~2.0 PF at the clock it holds)
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 
 
@@ -302,16 +303,50 @@ def main():
             # HBM bytes per launch come from the committed PMC passes of this same workload (PMC counters cannot be
             # collected from inside the process); null for any other workload
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
             if os.path.exists(tpath) and world == 1 and chunk == nq and not args.opt and args.efconstruction == 0:
                 for w in json.load(open(tpath)).get("workloads", []):
+                    # a PMC figure is only valid for the launch it was measured on: same workload, same dominant kernel,
+                    # same grid (the planner's split count) -- anything else reports null rather than a stale number
                     if (
                         w["metric"] == out["metric"]
                         and w.get("workload") == out["config"]["workload"]
                         and w["data"] == out["data"]
+                        and w.get("kernel") == kinfo["name"]
+                        and w.get("grid") == kinfo["grid"]
                     ):
-                        traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r1_traffic.json (" + w["source"] + ")"
-            if kinfo["name"].startswith("flat_mfma"):
+                        traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r2_traffic.json (" + w["source"] + ")"
+            if kinfo["name"].startswith("flat_bf16x3"):
+                # bf16x3 prefilter (csrc/flat_bf16.hip): three bf16 MFMA products per element pair are the algorithm
+                # (hi*hi + hi*lo + lo*hi), so its algorithmic flops are 3 x 2 nq N d, priced against the dense bf16 peak
+                st = ix.prefilter_stats()
+                exec_flops = 3.0 * kinfo["flops"]
+                achieved = exec_flops / (avg_ms * 1e-3) / 1e12
+                out["dtype"] = "f32 results (bf16x3 matrix-pipe prefilter + exact f32 re-scoring of the candidates)"
+                out["roofline"] = {
+                    "kernel": kinfo["name"],
+                    "bound": "mfma",
+                    "achieved": round(achieved, 1),
+                    "peak": PEAK_BF16_MFMA_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "avg_launch_ms": round(avg_ms, 4),
+                    "launches": n_launch,
+                    "algorithmic_flops_per_launch": exec_flops,
+                    "f32_equivalent_tflops": round(kinfo["flops"] / (avg_ms * 1e-3) / 1e12, 1),
+                    "f32_equivalent_vs_f32_mfma_peak": round(kinfo["flops"] / (avg_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                    "algorithmic_bytes_per_launch": kinfo["bytes"],
+                    "hbm_frac_of_8TBps": round(kinfo["bytes"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
+                    "grid": kinfo["grid"],
+                    "lds_bytes": kinfo["lds_bytes"],
+                    "queries_rerun_on_exact_kernel": st["fallback_queries"],
+                    "queries_served": st["queries"],
+                    "observed_max_rel_err": st["max_rel_err"],
+                    "proof_err_bound": st["err_bound"],
+                }
+            elif kinfo["name"].startswith("flat_mfma"):
                 achieved = kinfo["flops"] / (avg_ms * 1e-3) / 1e12
                 out["roofline"] = {
                     "kernel": kinfo["name"],

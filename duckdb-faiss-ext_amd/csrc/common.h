@@ -114,6 +114,27 @@ void launch_flat_mfma_items(const FlatGeom &g, int metric, const float *d_qf, co
                             const int *d_nitems, int max_items, const int *d_qidx, const int64_t *d_rowids,
                             const SelectorDev *sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gthr,
                             hipStream_t st);
+// bf16x3 prefilter + exact f32 re-scoring (csrc/flat_bf16.hip)
+bool prefilter_supported(const FlatGeom &g);
+float prefilter_cerr(int d);
+FlatSearchPlan plan_prefilter(const FlatGeom &g, int64_t nq, int64_t n, int64_t kp);
+size_t prefilter_qfrag_bytes(const FlatGeom &g, int64_t nq);
+void launch_rows_to_bf16(const FlatGeom &g, const float *d_vecs, int64_t row0, int64_t nrows, unsigned short *d_bf,
+                         const float *d_norms, unsigned *d_max_norm_bits, hipStream_t st);
+void launch_pack_queries_bf16(const FlatGeom &g, const float *d_x, int64_t nq, void *d_qf, hipStream_t st);
+void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, const void *d_qf, const float *d_qnorm,
+                      int64_t nq, const unsigned short *d_rows_bf, const float *d_norms, int64_t n, int64_t kp, float *d_pd,
+                      int32_t *d_pi, unsigned *d_gthr, hipStream_t st);
+void launch_rescore_verify(int metric, const float *d_ca, const int64_t *d_ci, int64_t nq, int kp, int kk, const float *d_x,
+                           const FlatGeom &g, const float *d_vecs, const float *d_norms, const float *d_qn,
+                           const unsigned *d_max_norm_bits, float *d_pd1, int32_t *d_pi1, int *d_fail_cnt, int *d_fail_q,
+                           unsigned *d_max_rel_err_bits, hipStream_t st);
+void launch_gather_query_rows(const float *d_x, int d, const int *d_fq, int nf, float *d_xf, hipStream_t st);
+void launch_scatter_rows(const int *d_fq, int nf, int64_t k, const float *d_Df, const int64_t *d_If, float *d_D,
+                         int64_t *d_I, hipStream_t st);
+extern int g_pf_nsplit;
+extern int g_pf_abl;
+extern int g_pf_seed;
 extern int g_mfma_variant;
 extern int g_mfma_nsplit;
 extern int g_mfma_warm;

@@ -156,6 +156,22 @@ public:
 
 	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi;
 	DevBuf ws_flag, ws_tie; // inner-product boundary ties: flagged queries + tie-pass scratch
+	// bf16x3 prefilter (csrc/flat_bf16.hip): rows as bf16 hi/lo, derived lazily from `vecs` before a search
+	unsigned short *vecs_bf = nullptr; // [bf_cap][2 dp]
+	int64_t bf_cap = 0, bf_rows = 0;
+	unsigned *d_max_norm_bits = nullptr; // largest squared row norm among the first bf_rows rows (float bits)
+	int prefilter_mode = -1;             // option "prefilter": -1 auto, 0 off, 1 whenever the kernel supports the shape
+	int pf_margin = 5;                   // spare candidate ranks beyond k (option "pf_margin")
+	bool pf_suppressed = false;          // set while the queries the proof rejected are re-run on the exact kernel
+	int64_t pf_last_fallback = 0;        // diagnostics: queries of the last search that were re-run
+	int64_t pf_queries_total = 0, pf_fallback_total = 0;
+	float pf_max_rel_err = 0.f; // largest observed |approx - exact| / (||x|| ||y||) among re-scored candidates
+	DevBuf ws_pfq, ws_cand, ws_ex, ws_fail, ws_fb;
+	void ensure_bf16_rows(hipStream_t st);
+	void drop_bf16_rows();
+	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
+	                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
+	                      const TieFlags *flp, hipStream_t st);
 	int *h_flag_count = nullptr; // pinned
 	// row shard of a ShardedIndex (csrc/sharded.hip): results are the shard's ROW numbers in the pure order, no tie pass
 	// (the sharded index resolves ties across shards); an id map passed to search_flat then only feeds the selector
@@ -168,7 +184,7 @@ public:
 	}
 	bool ip_exact_ties = true;   // option "ip_exact_ties" = 0: keep the pure (score desc, id asc) order (raw shard lists)
 	void resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const TieFlags &fl, SelectorDev sel,
-	                     const int64_t *d_idmap, float *d_D, int64_t *d_I, hipStream_t st);
+	                     const int64_t *d_idmap, float *d_D, int64_t *d_I, hipStream_t st, int64_t kraw = 0);
 	SelectorHolder selector;
 	hipStream_t last_search_stream = nullptr;
 	bool have_last_search = false;

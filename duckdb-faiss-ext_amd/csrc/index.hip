@@ -269,10 +269,55 @@ FlatIndex::~FlatIndex() {
 		(void)hipFree(norms);
 	if (h_flag_count)
 		(void)hipHostFree(h_flag_count);
+	if (vecs_bf)
+		(void)hipFree(vecs_bf);
+	if (d_max_norm_bits)
+		(void)hipFree(d_max_norm_bits);
 }
+
+void FlatIndex::drop_bf16_rows() {
+	if (vecs_bf)
+		(void)hipFree(vecs_bf);
+	vecs_bf = nullptr;
+	bf_cap = bf_rows = 0;
+	if (d_max_norm_bits)
+		(void)hipFree(d_max_norm_bits);
+	d_max_norm_bits = nullptr;
+}
+
+// rows [bf_rows, ntotal) of the f32 store -> bf16 hi/lo (+ running maximum of the squared norms); derived data, so add(),
+// clone() and to_device() never have to know about it
+void FlatIndex::ensure_bf16_rows(hipStream_t st) {
+	if (bf_rows == ntotal && vecs_bf)
+		return;
+	if (ntotal > bf_cap || !vecs_bf) {
+		unsigned short *nb = nullptr;
+		const int64_t nc = std::max<int64_t>(cap, ntotal);
+		// + 64 rows: the kernel prefetches up to two tiles past the last row without clamping
+		const size_t nbytes = ((size_t)nc + 64) * 2 * geom.dp * sizeof(unsigned short);
+		MVS_HIP(hipMalloc((void **)&nb, nbytes));
+		MVS_HIP(hipMemsetAsync(nb, 0, nbytes, st));
+		if (bf_rows > 0)
+			MVS_HIP(hipMemcpyAsync(nb, vecs_bf, (size_t)bf_rows * 2 * geom.dp * sizeof(unsigned short),
+			                       hipMemcpyDeviceToDevice, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		if (vecs_bf)
+			MVS_HIP(hipFree(vecs_bf));
+		vecs_bf = nb;
+		bf_cap = nc;
+	}
+	if (!d_max_norm_bits) {
+		MVS_HIP(hipMalloc((void **)&d_max_norm_bits, 64));
+		MVS_HIP(hipMemsetAsync(d_max_norm_bits, 0, 64, st));
+	}
+	launch_rows_to_bf16(geom, vecs, bf_rows, ntotal - bf_rows, vecs_bf, norms, d_max_norm_bits, st);
+	bf_rows = ntotal;
+}
+
 
 void FlatIndex::reset() {
 	ntotal = 0;
+	drop_bf16_rows();
 }
 
 void FlatIndex::copy_rows_to_host(float *out) {
@@ -304,7 +349,7 @@ void FlatIndex::grow(int64_t need, hipStream_t st) {
 	float *nv = nullptr, *nn = nullptr;
 	// +64 floats: the LDS-DMA staging reads whole 64-float pieces and may run past the last row
 	MVS_HIP(hipMalloc((void **)&nv, ((size_t)nc * geom.dp + 64) * sizeof(float)));
-	MVS_HIP(hipMalloc((void **)&nn, (size_t)nc * sizeof(float)));
+	MVS_HIP(hipMalloc((void **)&nn, ((size_t)nc + 64) * sizeof(float))); // + 64: the prefilter stages norms past the end
 	if (ntotal > 0) {
 		MVS_HIP(hipMemcpyAsync(nv, vecs, (size_t)ntotal * geom.dp * sizeof(float), hipMemcpyDeviceToDevice, st));
 		MVS_HIP(hipMemcpyAsync(nn, norms, (size_t)ntotal * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -400,11 +445,13 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		k = k + 1;
 	TieFlags fl = {nullptr, nullptr, nullptr, nullptr};
 	if (tie_detect) {
-		ws_flag.reserve(16 + (size_t)nq * 4 + (size_t)nq * k * 8);
+		// raw candidate lists of the flagged queries: k entries each, or the prefilter's k + margin (search_prefilter)
+		const size_t kflag = (size_t)(k + std::max<int64_t>(16, k / 2));
+		ws_flag.reserve(16 + (size_t)nq * 4 + (size_t)nq * kflag * 8);
 		fl.count = (int *)ws_flag.p;
 		fl.query = fl.count + 4;
 		fl.val = (float *)(fl.query + nq);
-		fl.row = (int *)(fl.val + (size_t)nq * k);
+		fl.row = (int *)(fl.val + (size_t)nq * kflag);
 		MVS_HIP(hipMemsetAsync(fl.count, 0, sizeof(int), st));
 	}
 	const TieFlags *flp = tie_detect ? &fl : nullptr;
@@ -413,9 +460,11 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	// masks the rejected rows in its epilogue.  (L2 + selector is Sum (x-y)^2 per pair: packed scan kernel.)
 	// The same identity covers small inner-product batches (nq < 20, FAISS's per-pair branch): from 8 queries on the
 	// MFMA kernel beats the per-pair kernels even with a mostly empty 128-query block.
-	const bool ip_on_mfma = metric == METRIC_IP && (has_sel || nq < 20) && nq >= 8 &&
+	// (queries re-run for the prefilter belong to a batch FAISS sends down its BLAS branch, however few they are)
+	const bool small_batch = nq < 20 && !pf_suppressed;
+	const bool ip_on_mfma = metric == METRIC_IP && (has_sel || small_batch) && nq >= 8 &&
 	                        k <= (has_sel ? flat_mfma_max_k_lds(geom) : mfma_kmax) && !force_direct && !force_staged;
-	const bool direct = ((has_sel || nq < 20) && !ip_on_mfma) || k > mfma_kmax || force_direct;
+	const bool direct = ((has_sel || small_batch) && !ip_on_mfma) || k > mfma_kmax || force_direct;
 	FlatDB db {vecs, norms, ntotal};
 	memset(&kinfo, 0, sizeof kinfo);
 	if (direct) {
@@ -424,7 +473,7 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 			            (long long)k, (long long)flat_direct_max_k());
 		// BLAS-branch value when FAISS would have used sgemm (nq >= 20, no selector) but k is too large for
 		// the fused kernel's LDS lists
-		const bool formula = metric == METRIC_L2 && !has_sel && nq >= 20;
+		const bool formula = metric == METRIC_L2 && !has_sel && !small_batch;
 		// 1-4 queries are pure streaming: the LDS-staged kernel (coalesced tiles, 1 or 4 chains per thread) reaches
 		// 3.2 TB/s there, the thread-per-row scan 1.6; from ~8 queries on the packed scan wins (3x at nq = 2000)
 		if (!formula && !force_staged && nq > 4 && ivf_scan_supported(geom.dp, k)) {
@@ -496,6 +545,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		kinfo.block = 256;
 		kinfo.lds_bytes = (int)p.lds_bytes;
 		kinfo.nsplit = p.nsplit;
+	} else if (search_prefilter(nq, d_x, k_user, k, d_D, d_I, params, d_idmap, out_map, out_off, flp, st)) {
+		// bf16x3 prefilter + exact re-scoring took the batch (csrc/flat_bf16.hip); same results
 	} else {
 		FlatSearchPlan p = plan_flat_mfma(geom, nq, ntotal, k);
 		ws_q.reserve(qfrag_floats(geom, nq) * sizeof(float));
@@ -525,12 +576,109 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	}
 }
 
+// BLAS-branch search through the bf16x3 prefilter (csrc/flat_bf16.hip).  Returns false when the shape is not served
+// (the caller then runs the exact f32 kernel).  kk = k_user (+1 with inner-product tie detection).
+bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
+                                 const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map,
+                                 int64_t out_off, const TieFlags *flp, hipStream_t st) {
+	if (prefilter_mode == 0 || pf_suppressed || !prefilter_supported(geom) || kk > 40)
+		return false;
+	// auto: the contraction must dominate (one 256-query block per workgroup, >= 8192 rows per split)
+	if (prefilter_mode < 0 && (nq < 512 || ntotal < 262144))
+		return false;
+	if (ntotal < 4096 || ntotal <= kk)
+		return false;
+	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the
+	// headline (N = 10M, d = 128) 5 spare ranks leave ~3 of 10 000 queries to the exact kernel, 8 spare ranks ~none
+	const int kp = (int)(kk + std::max<int64_t>(pf_margin, kk / 2));
+	ensure_bf16_rows(st);
+	FlatSearchPlan p = plan_prefilter(geom, nq, ntotal, kp);
+	ws_pfq.reserve(prefilter_qfrag_bytes(geom, nq));
+	ws_qn.reserve((size_t)nq * sizeof(float));
+	launch_pack_queries_bf16(geom, d_x, nq, ws_pfq.p, st);
+	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
+	ws_pd.reserve((size_t)p.nsplit * nq * kp * sizeof(float));
+	ws_pi.reserve((size_t)p.nsplit * nq * kp * sizeof(int32_t));
+	ws_gthr.reserve((size_t)nq * ((kp + 15) / 16 * 16) * sizeof(unsigned) + 64);
+	begin_kernel_timing(st);
+	launch_prefilter(geom, p, metric, ws_pfq.p, (const float *)ws_qn.p, nq, vecs_bf, norms, ntotal, kp, (float *)ws_pd.p,
+	                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
+	end_kernel_timing(st);
+	// approximate top-kp per query (plain row numbers)
+	const size_t ca_bytes = ((size_t)nq * kp * sizeof(float) + 255) & ~(size_t)255;
+	ws_cand.reserve(ca_bytes + (size_t)nq * kp * sizeof(int64_t));
+	float *ca = (float *)ws_cand.p;
+	int64_t *ci = (int64_t *)((char *)ws_cand.p + ca_bytes);
+	launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, kp, nullptr, 0, ca, ci, st);
+	// exact values of the candidates + the per-query proof
+	const size_t ex_bytes = ((size_t)nq * kp * sizeof(float) + 255) & ~(size_t)255;
+	ws_ex.reserve(ex_bytes + (size_t)nq * kp * sizeof(int32_t));
+	float *pd1 = (float *)ws_ex.p;
+	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
+	ws_fail.reserve(64 + (size_t)nq * sizeof(int));
+	int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
+	MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+	launch_rescore_verify(metric, ca, ci, nq, kp, (int)kk, d_x, geom, vecs, norms, (const float *)ws_qn.p, d_max_norm_bits,
+	                      pd1, pi1, fail_cnt, fail_q, d_max_norm_bits + 4, st);
+	// the exact candidates through the normal merge: FAISS order, labels, inner-product tie flags
+	launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp);
+	if (!h_flag_count)
+		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
+	MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+	MVS_HIP(hipMemcpyAsync(h_flag_count + 9, d_max_norm_bits + 4, sizeof(int), hipMemcpyDeviceToHost, st));
+	if (flp) {
+		SelectorDev nosel;
+		memset(&nosel, 0, sizeof nosel);
+		resolve_ip_ties(nq, d_x, k_user, *flp, nosel, d_idmap, d_D, d_I, st, kp); // (syncs the stream)
+	} else {
+		MVS_HIP(hipStreamSynchronize(st));
+	}
+	const int nf = h_flag_count[8];
+	pf_last_fallback = nf;
+	pf_queries_total += nq;
+	pf_fallback_total += nf;
+	memcpy(&pf_max_rel_err, h_flag_count + 9, sizeof(float));
+	snprintf(kinfo.name, sizeof kinfo.name, "flat_bf16x3_kernel");
+	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
+	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * k_user * 12.0;
+	kinfo.grid = p.grid;
+	kinfo.block = 256;
+	kinfo.lds_bytes = (int)p.lds_bytes;
+	kinfo.nsplit = p.nsplit;
+	if (nf > 0) {
+		// queries whose candidate set could not be proven complete: the exact kernel decides (results overwrite theirs)
+		const mvs_kernel_info keep = kinfo;
+		const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
+		const size_t df_bytes = ((size_t)nf * k_user * sizeof(float) + 255) & ~(size_t)255;
+		ws_fb.reserve(xf_bytes + df_bytes + (size_t)nf * k_user * sizeof(int64_t));
+		float *xf = (float *)ws_fb.p;
+		float *Df = (float *)((char *)ws_fb.p + xf_bytes);
+		int64_t *If = (int64_t *)((char *)Df + df_bytes);
+		launch_gather_query_rows(d_x, d, fail_q, nf, xf, st);
+		pf_suppressed = true;
+		const bool timing = timing_enabled;
+		timing_enabled = false; // the bench's dominant kernel stays the prefilter launch
+		try {
+			search_flat(nf, xf, k_user, Df, If, params, d_idmap, st);
+		} catch (...) {
+			pf_suppressed = false;
+			timing_enabled = timing;
+			throw;
+		}
+		pf_suppressed = false;
+		timing_enabled = timing;
+		launch_scatter_rows(fail_q, nf, k_user, Df, If, d_D, d_I, st);
+		kinfo = keep;
+	}
+	return true;
+}
+
 // Tie pass of an inner-product search.  The flag count is the only host-visible decision of a search: one 4-byte
 // D2H + stream sync per IP search (the search is >= 100 us of kernels).  Flagged queries are re-run through the SAME
 // contraction (bit-identical scores) with the TIE epilogue, which collects per query the k smallest row ids whose
 // score is >= the boundary score T; tie_resolve_kernel then applies FAISS's heap outcome (csrc/util_kernels.hip).
 void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const TieFlags &fl, SelectorDev sel,
-                                const int64_t *d_idmap, float *d_D, int64_t *d_I, hipStream_t st) {
+                                const int64_t *d_idmap, float *d_D, int64_t *d_I, hipStream_t st, int64_t kraw_in) {
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	MVS_HIP(hipMemcpyAsync(h_flag_count, fl.count, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -538,7 +686,7 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 	const int nf = *h_flag_count;
 	if (nf <= 0)
 		return;
-	const int64_t kraw = k + 1;
+	const int64_t kraw = kraw_in > 0 ? kraw_in : k + 1; // length of the raw candidate lists the merge recorded
 	const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
 	const size_t t_bytes = ((size_t)nf * sizeof(float) + 255) & ~(size_t)255;
 	const size_t td_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
@@ -597,7 +745,7 @@ void FlatIndex::to_device(int new_device) {
 	MVS_HIP(hipSetDevice(new_device));
 	if (cap > 0) {
 		MVS_HIP(hipMalloc((void **)&nv, ((size_t)cap * geom.dp + 64) * sizeof(float)));
-		MVS_HIP(hipMalloc((void **)&nn, (size_t)cap * sizeof(float)));
+		MVS_HIP(hipMalloc((void **)&nn, ((size_t)cap + 64) * sizeof(float)));
 		MVS_HIP(hipMemset(nv, 0, ((size_t)cap * geom.dp + 64) * sizeof(float)));
 		if (ntotal > 0) {
 			MVS_HIP(hipMemcpyPeer(nv, new_device, vecs, device, (size_t)ntotal * geom.dp * sizeof(float)));
@@ -611,6 +759,9 @@ void FlatIndex::to_device(int new_device) {
 		MVS_HIP(hipFree(vecs));
 	if (norms)
 		MVS_HIP(hipFree(norms));
+	drop_bf16_rows();
+	for (DevBuf *b : {&ws_flag, &ws_tie, &ws_pfq, &ws_cand, &ws_ex, &ws_fail, &ws_fb})
+		b->release();
 	ws_q.release();
 	ws_qn.release();
 	ws_pd.release();
@@ -1148,6 +1299,25 @@ int mvs_index_shard_to_gpus(mvs_index *ix, const int *devices, int ndev) {
 	ix->owned = true;
 	MVS_API_END
 }
+int mvs_index_prefilter_stats(mvs_index *ix, int64_t *queries, int64_t *fallback_queries, float *max_rel_err,
+                              float *err_bound) {
+	MVS_API_BEGIN
+	IndexBase *p = sharded_inner_view(ix->impl);
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	if (p->kind != MVS_KIND_FLAT)
+		throw_faiss("mvs_index_prefilter_stats", __FILE__, "not a Flat index");
+	auto *f = static_cast<FlatIndex *>(p);
+	if (queries)
+		*queries = f->pf_queries_total;
+	if (fallback_queries)
+		*fallback_queries = f->pf_fallback_total;
+	if (max_rel_err)
+		*max_rel_err = f->pf_max_rel_err;
+	if (err_bound)
+		*err_bound = prefilter_cerr(f->d);
+	MVS_API_END
+}
 int mvs_index_shard_info(const mvs_index *ix, int *devices, int max_devices, int64_t *rows_per_shard,
                          int64_t *last_tie_queries) {
 	return sharded_info(ix->impl, devices, max_devices, rows_per_shard, last_tie_queries);
@@ -1239,6 +1409,26 @@ namespace mvs {
 bool FlatIndex::set_option(const char *key, int64_t v) {
 	if (!strcmp(key, "force_staged")) { // per-pair path on the LDS-staged flat_direct kernel instead of the scan kernel
 		force_staged = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "prefilter")) { // -1 auto, 0 off (exact f32 kernel only), 1 wherever the bf16x3 kernel supports the shape
+		prefilter_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "pf_seed")) { // rows of the prefilter's seeding pre-pass (0 = off)
+		g_pf_seed = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "pf_abl")) { // profiling only: results are wrong
+		g_pf_abl = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "pf_margin")) {
+		pf_margin = (int)std::min<int64_t>(16, std::max<int64_t>(1, v));
+		return true;
+	}
+	if (!strcmp(key, "pf_nsplit")) {
+		g_pf_nsplit = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "raw_rows")) {

@@ -174,6 +174,11 @@ int mvs_index_set_kernel_timing(mvs_index *ix, int enabled);
 int mvs_index_kernel_time_stats(mvs_index *ix, int *count, double *total_ms);
 /* implementation knobs (never needed by the reference glue): "force_direct" = 0/1 */
 int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value);
+/* bf16x3 prefilter of the Flat BLAS-branch search (csrc/flat_bf16.hip; results are those of the exact f32 kernel): queries
+ * it served so far, how many of them could not be proven and were re-run on the exact kernel, the largest observed
+ * |approx - exact| / (||x|| ||y||) among re-scored candidates and the bound c(d) the proof uses */
+int mvs_index_prefilter_stats(mvs_index *ix, int64_t *queries, int64_t *fallback_queries, float *max_rel_err,
+                              float *err_bound);
 int mvs_device_count(void);
 const char *mvs_version(void);
 

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--check", action="store_true", help="compare a query subsample with the oracle")
+    ap.add_argument("--sweep", default="", help="key=v1,v2,...: repeat the timing for each value of one option (same index)")
     ap.add_argument("--sel-frac", type=float, default=0.0, help="> 0: IDSelectorBitmap keeping about this fraction of the rows")
     args = ap.parse_args()
     import torch
@@ -44,22 +45,40 @@ def main():
 
         rs = np.random.RandomState(7)
         sel = ("bitmap", np.packbits(rs.rand((args.n + 7) // 8 * 8) < args.sel_frac, bitorder="little"))
-    D, I = ix.search_torch(xq, args.k, sel=sel)
-    torch.cuda.synchronize()
-    ix.set_kernel_timing(True)
-    for _ in range(args.reps):
-        ix.search_torch(xq, args.k, D=D, I=I, sel=sel)
-    torch.cuda.synchronize()
-    n, ms = ix.kernel_time_stats()
-    ki = ix.last_kernel_info()
-    avg = ms / n
-    tf = ki["flops"] / (avg * 1e-3) / 1e12
-    gbs = ki["bytes"] / (avg * 1e-3) / 1e9
-    print(
-        f"{ki['name']} opts={args.opt} n={args.n} nq={args.nq} d={args.d} k={args.k} {args.metric}: "
-        f"{avg:.3f} ms/launch  {tf:.2f} TFLOP/s ({tf/157.3*100:.1f}% f32-MFMA peak)  {gbs:.1f} GB/s algorithmic  "
-        f"grid={ki['grid']} lds={ki['lds_bytes']} nsplit={ki['nsplit']}  qps={args.nq/(avg*1e-3):.0f}"
-    )
+    import time
+
+    sweep = [None]
+    if args.sweep:
+        skey, svals = args.sweep.split("=")
+        sweep = [int(v) for v in svals.split(",")]
+    for sv in sweep:
+        if sv is not None:
+            ix.set_option(skey, sv)
+        D, I = ix.search_torch(xq, args.k, sel=sel)
+        torch.cuda.synchronize()
+        n0, ms0 = ix.kernel_time_stats()
+        ix.set_kernel_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            ix.search_torch(xq, args.k, D=D, I=I, sel=sel)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / args.reps * 1e3
+        ix.set_kernel_timing(False)
+        n, ms = ix.kernel_time_stats()
+        n, ms = n - n0, ms - ms0
+        ki = ix.last_kernel_info()
+        avg = ms / n
+        tf = ki["flops"] / (avg * 1e-3) / 1e12
+        gbs = ki["bytes"] / (avg * 1e-3) / 1e9
+        extra = ""
+        if ki["name"].startswith("flat_bf16"):
+            extra = f"  prefilter={ix.prefilter_stats()}"
+        print(
+            f"{ki['name']} opts={args.opt} {args.sweep.split('=')[0]}={sv} n={args.n} nq={args.nq} d={args.d} k={args.k} {args.metric}: "
+            f"{avg:.3f} ms/launch  wall {wall:.3f} ms/search  {tf:.2f} TFLOP/s algorithmic  {gbs:.1f} GB/s algorithmic  "
+            f"grid={ki['grid']} lds={ki['lds_bytes']} nsplit={ki['nsplit']}  qps={args.nq/(wall*1e-3):.0f}{extra}",
+            flush=True,
+        )
     if args.check:
         import numpy as np
 
