@@ -145,7 +145,17 @@ def main():
         from sharded import replicate_ivf_centroids
 
         xb_all = gen(r1 - r0, d, DB_SEED, row0=r0, device=dev)
-        replicate_ivf_centroids(ix, xb_all.cpu().numpy() if rank == 0 else None, src=0, device=dev)
+        if world > 1 and rank == 0:
+            # the centroids must be those of the 1-GPU run: rank 0 trains on ALL N rows (FAISS subsamples 256 per
+            # centroid out of them with its own RNG), not on its shard
+            x_train = np.empty((n, d), dtype=np.float32)
+            for s0 in range(0, n, slab):
+                m = min(slab, n - s0)
+                x_train[s0 : s0 + m] = gen(m, d, DB_SEED, row0=s0, device=dev).cpu().numpy()
+        else:
+            x_train = xb_all.cpu().numpy() if rank == 0 else None
+        replicate_ivf_centroids(ix, x_train, src=0, device=dev)
+        del x_train
         for s0 in range(0, r1 - r0, slab):
             ix.add_torch(xb_all[s0 : s0 + slab])
         torch.cuda.synchronize()
@@ -165,12 +175,19 @@ def main():
 
     from sharded import ShardExchange
 
-    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    # Row shards + inner product: FAISS's CMin heap resolves exact ties at the k-th score by arrival order, so the shards
+    # hand over k + 1 candidates in the pure order and rank 0 runs the tie protocol (pyhost/sharded.py); L2 is a pure
+    # function of the data and needs neither.
+    ip_ties = world > 1 and metric == mf.METRIC_INNER_PRODUCT and not is_ivf and not is_hnsw and not with_ids
+    ks = k + 1 if ip_ties else k
+    if ip_ties:
+        ix.set_option("ip_exact_ties", 0)
+    D = torch.empty((nq, ks), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, ks), dtype=torch.int64, device=dev)
     # N > 1: two result / exchange buffer sets, so that the host merge of batch i runs while the GPUs search batch i+1
-    pipelined = world > 1 and not is_hnsw and not args.no_pipeline
+    pipelined = world > 1 and not is_hnsw and not args.no_pipeline and not ip_ties
     Dbuf, Ibuf = [D], [I]
-    xchs = [ShardExchange(nq, k, dev)]
+    xchs = [ShardExchange(nq, k, dev, ip_ties=ip_ties)]
     if pipelined:
         Dbuf.append(torch.empty_like(D))
         Ibuf.append(torch.empty_like(I))
@@ -205,7 +222,12 @@ def main():
         Ds, Is = Dbuf[slot], Ibuf[slot]
         for q0 in range(0, nq, chunk):
             q1 = min(nq, q0 + chunk)
-            ix.search_torch(xq[q0:q1], k, D=Ds[q0:q1], I=Is[q0:q1], **search_kw)
+            ix.search_torch(xq[q0:q1], ks, D=Ds[q0:q1], I=Is[q0:q1], **search_kw)
+        if ip_ties:
+            fD, fI = xchs[slot].merge_ip_exact(Ds, Is, xq, lambda xf, T: ix.tie_candidates_torch(xf, T, k))
+            if rank == 0:
+                final["D"], final["I"] = fD, fI
+            return
         if world > 1:
             # exchange step: per-shard (distance,label) blocks over xGMI + copy to pinned host memory, enqueued behind
             # the search; then the host k-way merge (rank 0) -- of the PREVIOUS batch when pipelined, so that it
@@ -287,7 +309,7 @@ def main():
                 "exchange": (
                     "gather of disjoint result rows"
                     if is_hnsw
-                    else "rccl all_gather + host k-way merge"
+                    else "one rccl all_gather of packed {value,label} records + host k-way merge"
                     + (" (merge of batch i overlaps the search of batch i+1)" if pipelined else "")
                 )
                 if world > 1
@@ -297,6 +319,22 @@ def main():
                 "efConstruction": (args.efconstruction or 40) if is_hnsw else None,
             },
         }
+        # achievable HBM bandwidth on THIS box: device-to-device copy of 2 GiB (read + write counted), best of 5
+        try:
+            src_t = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+            dst_t = torch.empty_like(src_t)
+            best = 0.0
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dst_t.copy_(src_t)
+                e1.record()
+                torch.cuda.synchronize()
+                best = max(best, 2.0 * src_t.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            out["hbm_copy_gbps_measured"] = round(best, 1)
+            del src_t, dst_t
+        except Exception as e:  # noqa: BLE001
+            out["hbm_copy_gbps_measured"] = None
         # ---- roofline of the dominant kernel (per launch, HIP events on the launch stream) ----------
         if n_launch > 0 and kern_ms > 0:
             avg_ms = kern_ms / n_launch

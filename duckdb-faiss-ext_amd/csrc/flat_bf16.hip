@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16x3_kernel(const MfmaArgs a) {
 				MVS_KEEP_VGPR(acc[t][0]);
 				continue;
 			}
-			tile_epilogue<1, IS_L2, (ABL & 16) != 0, false, false, true, GL ? 2 : 1, true>(acc[t], nullptr, row0, nvalid, xnq[t], thr[t], qvalid[t], gkey[t],
+			tile_epilogue<1, IS_L2, (ABL & 16) != 0, false, false, true, GL ? 2 : 1, false>(acc[t], nullptr, row0, nvalid, xnq[t], thr[t], qvalid[t], gkey[t],
 			                                                   a.gslot + (size_t)(qvalid[t] ? q[t] : 0) * a.slot_stride, ldq[t],
 			                                                   liq[t], k, lthr + ql[t], lthrid + ql[t], lpos + ql[t], h, nullptr,
 			                                                   yn4);

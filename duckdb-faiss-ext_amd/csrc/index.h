@@ -161,7 +161,7 @@ public:
 	int64_t bf_cap = 0, bf_rows = 0;
 	unsigned *d_max_norm_bits = nullptr; // largest squared row norm among the first bf_rows rows (float bits)
 	int prefilter_mode = -1;             // option "prefilter": -1 auto, 0 off, 1 whenever the kernel supports the shape
-	int pf_margin = 5;                   // spare candidate ranks beyond k (option "pf_margin")
+	int pf_margin = 6;                   // spare candidate ranks beyond k (option "pf_margin")
 	bool pf_suppressed = false;          // set while the queries the proof rejected are re-run on the exact kernel
 	int64_t pf_last_fallback = 0;        // diagnostics: queries of the last search that were re-run
 	int64_t pf_queries_total = 0, pf_fallback_total = 0;
@@ -179,6 +179,7 @@ public:
 	// tie pass for `nf` flagged queries: out[f][0..k) = the k smallest row ids with score >= d_T[f] (ascending, -1 padded)
 	void tie_candidates(int64_t nf, const float *d_xf, const float *d_T, int64_t k, int64_t *d_rows_out, SelectorDev sel,
 	                    const int64_t *d_selmap, hipStream_t st);
+	void offset_rows(int64_t *d_rows, int64_t total, hipStream_t st); // += label_offset on valid entries
 	SelectorDev upload_selector(const mvs_search_params *p, hipStream_t st) {
 		return selector.upload(p, st);
 	}
@@ -264,6 +265,10 @@ IndexBase *sharded_inner_view(IndexBase *ix); // the index the glue's dynamic_ca
 void sharded_for_each(IndexBase *ix, const std::function<void(IndexBase *)> &f);
 int sharded_info(const IndexBase *ix, int *devices, int max_devices, int64_t *rows_per_shard, int64_t *last_flagged);
 // csrc/merge_host.hip
+void merge_shards_raw_host(int metric, int64_t n, int64_t kk, int nshard, const float *D, const int64_t *I, float *D_out,
+                           int64_t *I_out);
+void finish_ip_ties_host(int64_t n, int64_t k, int64_t kk, const float *raw_v, const int64_t *raw_g, int64_t nf,
+                         const int64_t *fq, const int64_t *first, float *D_out, int64_t *I_out);
 void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
                        int64_t *I_out);
 

@@ -590,7 +590,9 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		return false;
 	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the
 	// headline (N = 10M, d = 128) 5 spare ranks leave ~3 of 10 000 queries to the exact kernel, 8 spare ranks ~none
-	const int kp = (int)(kk + std::max<int64_t>(pf_margin, kk / 2));
+	int kp = (int)(kk + std::max<int64_t>(pf_margin, kk / 2));
+	if (kp > 16 && kk + 5 <= 16)
+		kp = 16; // one 16-slot window of shared thresholds: a second window costs more than the lost margin (measured: 61 vs 70 ms)
 	ensure_bf16_rows(st);
 	FlatSearchPlan p = plan_prefilter(geom, nq, ntotal, kp);
 	ws_pfq.reserve(prefilter_qfrag_bytes(geom, nq));
@@ -699,6 +701,18 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 	(void)tD;
 	tie_candidates(nf, xf, T, k, tI, sel, d_idmap, st);
 	launch_tie_resolve(fl, nf, kraw, k, tI, d_idmap, label_offset, d_D, d_I, st);
+}
+
+__global__ void offset_rows_kernel(long long *I, long long total, long long off) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < total && I[i] >= 0)
+		I[i] += off;
+}
+void FlatIndex::offset_rows(int64_t *d_rows, int64_t total, hipStream_t st) {
+	if (total <= 0 || label_offset == 0)
+		return;
+	hipLaunchKernelGGL(offset_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long *)d_rows,
+	                   (long long)total, (long long)label_offset);
 }
 
 void FlatIndex::tie_candidates(int64_t nf, const float *d_xf, const float *d_T, int64_t k, int64_t *d_rows_out,
@@ -1369,6 +1383,33 @@ int mvs_merge_shards(int metric, int64_t n, int64_t k, int nshard, const float *
 	MVS_API_END
 }
 
+int mvs_merge_shards_raw(int metric, int64_t n, int64_t kk, int nshard, const float *D, const int64_t *I, float *D_out,
+                         int64_t *I_out) {
+	MVS_API_BEGIN
+	merge_shards_raw_host(metric, n, kk, nshard, D, I, D_out, I_out);
+	MVS_API_END
+}
+int mvs_finish_ip_ties(int64_t n, int64_t k, int64_t kk, const float *raw_D, const int64_t *raw_I, int64_t nf,
+                       const int64_t *flagged, const int64_t *first_rows, float *D_out, int64_t *I_out) {
+	MVS_API_BEGIN
+	finish_ip_ties_host(n, k, kk, raw_D, raw_I, nf, flagged, first_rows, D_out, I_out);
+	MVS_API_END
+}
+int mvs_index_tie_candidates_device(mvs_index *ix, int64_t nf, const float *d_xf, const float *d_T, int64_t k,
+                                    int64_t *d_rows_out, const mvs_search_params *params, void *stream) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	if (ix->impl->kind != MVS_KIND_FLAT || is_sharded(ix->impl))
+		throw_faiss("mvs_index_tie_candidates_device", __FILE__, "a plain single-device Flat index is required");
+	auto *f = static_cast<FlatIndex *>(ix->impl);
+	hipStream_t st = (hipStream_t)stream;
+	f->use_device();
+	stream_wait(st, f->stream);
+	SelectorDev sel = f->upload_selector(params, st);
+	f->tie_candidates(nf, d_xf, d_T, k, d_rows_out, sel, nullptr, st);
+	f->offset_rows(d_rows_out, nf * k, st); // shard rows -> global rows (label offset)
+	MVS_API_END
+}
 int mvs_synth_uniform_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, void *stream) {
 	MVS_API_BEGIN
 	launch_synth_uniform(d_out, n_rows, d, seed, row0, (hipStream_t)stream);

@@ -54,6 +54,11 @@ void parallel_queries(int64_t n, F &&body) {
 
 } // namespace
 
+void merge_raw_lists_host(int metric, int64_t nq, int64_t kk, int nshard, const float *const *D, const int64_t *const *G,
+                          float *val, int64_t *gnum);
+void resolve_ip_tie_host(int64_t k, const float *raw_v, const int64_t *raw_g, const int64_t *first, float *out_v,
+                         int64_t *out_g);
+
 // queries are independent: the merge runs on up to 16 host threads (it sits on the critical path of every multi-GPU
 // search step, after the exchange).  Per query: collect the nshard*k candidates, order them, keep k.
 void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
@@ -82,6 +87,40 @@ void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float
 			}
 		}
 	});
+}
+
+// The same merge for a multi-PROCESS host (pyhost/sharded.py under torchrun): shard blocks [nshard][n][kk] as gathered,
+// output the first kk of the union in the PURE order (no print reversal), -1 / neutral padded.
+void merge_shards_raw_host(int metric, int64_t n, int64_t kk, int nshard, const float *D, const int64_t *I, float *D_out,
+                           int64_t *I_out) {
+	std::vector<const float *> dp((size_t)nshard);
+	std::vector<const int64_t *> ip((size_t)nshard);
+	for (int s = 0; s < nshard; ++s) {
+		dp[(size_t)s] = D + (size_t)s * n * kk;
+		ip[(size_t)s] = I + (size_t)s * n * kk;
+	}
+	merge_raw_lists_host(metric, n, kk, nshard, dp.data(), ip.data(), D_out, I_out);
+}
+
+// FAISS print order of the first k of every raw list + the closed-form outcome for the flagged queries.
+// first: [nf][k] the k smallest global rows with score >= T of flagged query f (ascending, -1 padded).
+void finish_ip_ties_host(int64_t n, int64_t k, int64_t kk, const float *raw_v, const int64_t *raw_g, int64_t nf,
+                         const int64_t *fq, const int64_t *first, float *D_out, int64_t *I_out) {
+	for (int64_t q = 0; q < n; ++q) {
+		std::vector<Cand> c;
+		for (int64_t j = 0; j < k; ++j)
+			if (raw_g[q * kk + j] >= 0)
+				c.push_back({raw_v[q * kk + j], raw_g[q * kk + j], 0});
+		print_order_ip(c.data(), (int64_t)c.size());
+		for (int64_t j = 0; j < k; ++j) {
+			D_out[q * k + j] = j < (int64_t)c.size() ? c[(size_t)j].v : -FLT_MAX;
+			I_out[q * k + j] = j < (int64_t)c.size() ? c[(size_t)j].id : -1;
+		}
+	}
+	for (int64_t f = 0; f < nf; ++f) {
+		const int64_t q = fq[f];
+		resolve_ip_tie_host(k, raw_v + q * kk, raw_g + q * kk, first + f * k, D_out + q * k, I_out + q * k);
+	}
 }
 
 // ---- ShardedIndex (csrc/sharded.hip): merge of RAW shard lists ---------------------------------------------------

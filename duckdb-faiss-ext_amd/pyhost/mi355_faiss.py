@@ -125,6 +125,9 @@ _L.mvs_index_add_device.argtypes = [_p, _i64, _p, _p, _p]
 _L.mvs_index_search_device.argtypes = [_p, _i64, _p, _i64, _p, _p, C.POINTER(SearchParams), _p]
 _L.mvs_index_set_label_offset.argtypes = [_p, _i64]
 _L.mvs_merge_shards.argtypes = [C.c_int, _i64, _i64, C.c_int, _p, _p, _p, _p]
+_L.mvs_merge_shards_raw.argtypes = [C.c_int, _i64, _i64, C.c_int, _p, _p, _p, _p]
+_L.mvs_finish_ip_ties.argtypes = [_i64, _i64, _i64, _p, _p, _i64, _p, _p, _p, _p]
+_L.mvs_index_tie_candidates_device.argtypes = [_p, _i64, _p, _p, _i64, _p, C.POINTER(SearchParams), _p]
 _L.mvs_synth_uniform_device.argtypes = [_p, _i64, C.c_int, C.c_uint64, _i64, _p]
 _L.mvs_synth_clustered_device.argtypes = [_p, _i64, C.c_int, C.c_uint64, _i64, C.c_int, C.c_float, _p]
 _L.mvs_index_last_kernel_info.argtypes = [_p, C.POINTER(KernelInfo)]
@@ -142,7 +145,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_index_prefilter_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
-    "mvs_merge_shards", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
+    "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
     "mvs_version",
 ]  # fmt: skip
@@ -335,6 +338,19 @@ class Index:
         del keep
         return D, I
 
+    def tie_candidates_torch(self, xf, T, k, sel=None, stream=None):
+        """per flagged query the k smallest GLOBAL rows with score >= T (ascending, -1 padded) -- include/mi355_faiss.h"""
+        import torch
+
+        nf = xf.shape[0]
+        out = torch.empty((nf, k), dtype=torch.int64, device=xf.device)
+        p, keep = make_params(0, 0, sel)
+        if stream is None:
+            stream = torch.cuda.current_stream(xf.device).cuda_stream
+        _check(_L.mvs_index_tie_candidates_device(self._h, nf, xf.data_ptr(), T.data_ptr(), k, out.data_ptr(), C.byref(p), stream))
+        del keep
+        return out
+
     def set_label_offset(self, off):
         _check(_L.mvs_index_set_label_offset(self._h, int(off)))
 
@@ -382,6 +398,27 @@ def merge_shards(metric, D, I):
     Do = np.empty((nq, k), dtype=np.float32)
     Io = np.empty((nq, k), dtype=np.int64)
     _check(_L.mvs_merge_shards(metric, nq, k, ns, _ptr(D), _ptr(I), _ptr(Do), _ptr(Io)))
+    return Do, Io
+
+
+def merge_shards_raw(metric, D, I):
+    """[nshard, nq, kk] blocks -> merged top-kk per query in the PURE order (score desc / dist asc, id asc)"""
+    D, I = _f32(D), _i64a(I)
+    ns, nq, kk = D.shape
+    Do = np.empty((nq, kk), dtype=np.float32)
+    Io = np.empty((nq, kk), dtype=np.int64)
+    _check(_L.mvs_merge_shards_raw(metric, nq, kk, ns, _ptr(D), _ptr(I), _ptr(Do), _ptr(Io)))
+    return Do, Io
+
+
+def finish_ip_ties(k, rawD, rawI, flagged, first_rows):
+    """FAISS print order of the first k of every raw list + the CMin-heap outcome for the flagged queries"""
+    rawD, rawI = _f32(rawD), _i64a(rawI)
+    nq, kk = rawD.shape
+    flagged, first_rows = _i64a(flagged), _i64a(first_rows)
+    Do = np.empty((nq, k), dtype=np.float32)
+    Io = np.empty((nq, k), dtype=np.int64)
+    _check(_L.mvs_finish_ip_ties(nq, k, kk, _ptr(rawD), _ptr(rawI), flagged.size, _ptr(flagged), _ptr(first_rows), _ptr(Do), _ptr(Io)))
     return Do, Io
 
 

@@ -154,6 +154,21 @@ int mvs_index_set_label_offset(mvs_index *ix, int64_t offset);
 int mvs_merge_shards(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
                      int64_t *I_out);
 
+/* ---- inner-product boundary ties across PROCESSES (one rank per GPU, pyhost/sharded.py under torchrun) ----------
+ * FAISS's CMin heap keeps an arrival-order dependent subset of the rows tied at the k-th score.  A row
+ * shard therefore hands over its k+1 best in the PURE order (option "ip_exact_ties" = 0, search with k+1):
+ *   1. gather, mvs_merge_shards_raw -> merged top-(k+1), pure order;
+ *   2. queries whose k-th and (k+1)-th scores are bit-equal: every rank reports, per such query, its k smallest GLOBAL
+ *      rows with score >= T (mvs_index_tie_candidates_device; T = the k-th score), gather, keep the k smallest;
+ *   3. mvs_finish_ip_ties writes FAISS's print order for all queries and the heap's outcome for the flagged ones.
+ * (A ShardedIndex does the same inside the library.) */
+int mvs_merge_shards_raw(int metric, int64_t n, int64_t kk, int nshard, const float *D, const int64_t *I, float *D_out,
+                         int64_t *I_out);
+int mvs_index_tie_candidates_device(mvs_index *ix, int64_t nf, const float *d_xf, const float *d_T, int64_t k,
+                                    int64_t *d_rows_out, const mvs_search_params *params, void *stream);
+int mvs_finish_ip_ties(int64_t n, int64_t k, int64_t kk, const float *raw_D, const int64_t *raw_I, int64_t nf,
+                       const int64_t *flagged, const int64_t *first_rows, float *D_out, int64_t *I_out);
+
 /* ---- synthetic data (counter-based, identical on host oracle and device) and diagnostics -------- */
 int mvs_synth_uniform_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, void *stream);
 int mvs_synth_clustered_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers,

@@ -28,18 +28,39 @@ def _worker(rank, world, port, metric, ret):
     xb = orc.synth_uniform(n, d, 1234)
     xb[::97] = xb[5]  # duplicates -> ties across shards
     xq = orc.synth_uniform(nq, d, 4321)
+    if metric == orc.METRIC_INNER_PRODUCT:  # small integers: nearly every query has rows tied at its k-th score
+        xb = np.floor(xb * 5 - 2).astype(np.float32)
+        xq = np.floor(xq * 5 - 2).astype(np.float32)
     r0, r1 = shard_bounds(n, rank, world)
     D, I = orc.flat_search(metric, xb[r0:r1], xq, k, force_path=orc.PATH_BLAS)
     I = np.where(I >= 0, I + r0, -1)  # global labels (mvs_index_set_label_offset on the device path)
-    xch = ShardExchange(nq, k, "cpu")
-    Dm, Im = xch.merge(metric, torch.from_numpy(D), torch.from_numpy(I))
+    if metric == orc.METRIC_L2:
+        xch = ShardExchange(nq, k, "cpu")
+        Dm, Im = xch.merge(metric, torch.from_numpy(D), torch.from_numpy(I))
+    else:
+        # inner product: pure-order k+1 lists per shard + the tie protocol.  The device calls are stood in for by numpy:
+        # pure order = (score desc, row asc); tie candidates = the k smallest rows of the shard with score >= T.
+        sc = xq @ xb[r0:r1].T  # integer-valued data below: exact in f32, so ties are real ties
+        order = np.lexsort((np.broadcast_to(np.arange(r1 - r0), sc.shape), -sc), axis=1)[:, : k + 1]
+        Dp = np.take_along_axis(sc, order, axis=1).astype(np.float32)
+        Ip = (order + r0).astype(np.int64)
+
+        def tie_candidates(xf, T):
+            s2 = xf.numpy() @ xb[r0:r1].T
+            out = np.full((len(T), k), -1, dtype=np.int64)
+            for f in range(len(T)):
+                rows = np.nonzero(s2[f] >= T[f].item())[0][:k] + r0
+                out[f, : len(rows)] = rows
+            return torch.from_numpy(out)
+
+        xch = ShardExchange(nq, k, "cpu", ip_ties=True)
+        Dm, Im = xch.merge_ip_exact(torch.from_numpy(Dp), torch.from_numpy(Ip), torch.from_numpy(xq), tie_candidates)
     if rank == 0:
         Dr, Ir = orc.flat_search(metric, xb, xq, k, force_path=orc.PATH_BLAS)
         D11, _ = orc.flat_search(metric, xb, xq, k + 1, force_path=orc.PATH_BLAS)
-        ok = D11[:, k - 1] != D11[:, k] if metric == orc.METRIC_INNER_PRODUCT else np.ones(nq, bool)
         ret["same_D"] = bool(np.array_equal(Dm, Dr))
-        ret["same_I"] = bool(np.array_equal(Im[ok], Ir[ok]))
-        ret["n_ok"] = int(ok.sum())
+        ret["same_I"] = bool(np.array_equal(Im, Ir))  # every query, boundary ties included
+        ret["n_ok"] = int((D11[:, k - 1] == D11[:, k]).sum()) if metric == orc.METRIC_INNER_PRODUCT else nq
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,7 +71,7 @@ def test_two_rank_exchange_and_merge_equals_unsharded(metric):
     ret = mgr.dict()
     port = 29500 + (os.getpid() % 2000) + metric
     mp.spawn(_worker, args=(2, port, metric, ret), nprocs=2, join=True)
-    assert ret["same_D"] and ret["same_I"] and ret["n_ok"] > 32
+    assert ret["same_D"] and ret["same_I"] and ret["n_ok"] > 16, dict(ret)
 
 
 def _ivf_worker(rank, world, port, ret):
