@@ -101,6 +101,51 @@ template <bool IS_L2>
 __device__ __forceinline__ bool entry_worse(float x, int xi, float y, int yi) {
 	return IS_L2 ? (x > y || (x == y && xi > yi)) : (x < y || (x == y && xi > yi));
 }
+struct Thr {
+	float v;
+	int id;
+	int pos;
+};
+
+// GLOBAL-memory k-lists (LSPACE != 1: k > 12 in the f32 kernel, e.g. the IVF coarse search with k = nprobe) stay heaps.
+// The k-list of a query is a binary heap on (value, id) with the WORST entry at the root (slot 0 = the threshold):
+// an insertion replaces the root and sifts down, <= log2(k) levels of two child reads, instead of rescanning all k
+// slots for the new worst (k = 32: ~4x fewer dependent LDS / L2 round trips per insertion).  The all-neutral initial
+// list is a valid heap; the merge kernels sort the partial lists, so the slot order never reaches the caller.
+template <bool IS_L2>
+__device__ __forceinline__ Thr list_insert(float *ld, int *li, int k, int /*pos*/, float v, int id) {
+	int i = 0;
+	for (;;) {
+		const int l = 2 * i + 1, r = l + 1;
+		if (l >= k)
+			break;
+		float cv = ld[l];
+		int cid = li[l], c = l;
+		if (r < k) {
+			const float rv = ld[r];
+			const int rid = li[r];
+			if (entry_worse<IS_L2>(rv, rid, cv, cid)) {
+				cv = rv;
+				cid = rid;
+				c = r;
+			}
+		}
+		if (!entry_worse<IS_L2>(cv, cid, v, id))
+			break; // the new entry is at least as bad as both children: it stays here
+		ld[i] = cv;
+		li[i] = cid;
+		i = c;
+	}
+	ld[i] = v;
+	li[i] = id;
+	Thr t;
+	t.v = ld[0];
+	t.id = li[0];
+	t.pos = 0;
+	return t;
+}
+
+
 // "smaller is better" order-preserving key of a distance (L2) / score (IP)
 template <bool IS_L2>
 __device__ __forceinline__ unsigned bkey(float v) {
@@ -269,6 +314,68 @@ __device__ __forceinline__ float rare_insert_body(const f32x16 (&acc)[NT], long 
 			if (IS_L2)
 				v = v < 0.f ? 0.f : v;
 			const int id = (int)(row0 + (j >> 4) * 32 + (j & 3) + 8 * ((j >> 2) & 3) + 4 * h);
+			if (__popcll(bal) >= 6) {
+				// MANY lanes hold a candidate (cold start of a workgroup, small databases, large k): serialising them through
+				// the cooperative insert would cost one LDS round trip per candidate.  Every lane inserts into its own
+				// query's list instead -- an insertion sort from the back, lanes in parallel; the two lanes that share a
+				// query (l, l + 32) take turns.
+				for (int hh = 0; hh < 2; ++hh) {
+					const bool mine = has && h == hh;
+					if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
+						if (mine) {
+							typedef typename ListPtr<LSPACE>::F FP;
+							typedef typename ListPtr<LSPACE>::I IP_;
+							FP ld_ = ListPtr<LSPACE>::f((int)ldq_u, (int)(ldq_u >> 32));
+							IP_ li_ = ListPtr<LSPACE>::i((int)liq_u, (int)(liq_u >> 32));
+							const unsigned ad0 = (unsigned)ldq_u, ai0 = (unsigned)liq_u; // LDS byte offsets (LSPACE == 1)
+							auto rd = [&](int i, float &ev, int &ei) {
+								if (LSPACE == 1) // by hand: see the cooperative insert below
+									asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+									             : "=&v"(ev), "=&v"(ei)
+									             : "v"(ad0 + 4u * (unsigned)i), "v"(ai0 + 4u * (unsigned)i)
+									             : "memory");
+								else {
+									ev = ld_[i];
+									ei = li_[i];
+								}
+							};
+							auto wr = [&](int i, float ev, int ei) {
+								if (LSPACE == 1)
+									asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3" ::"v"(ad0 + 4u * (unsigned)i),
+									             "v"(ai0 + 4u * (unsigned)i), "v"(ev), "v"(ei)
+									             : "memory");
+								else {
+									ld_[i] = ev;
+									li_[i] = ei;
+								}
+							};
+							int i = k - 1;
+							float ev;
+							int ei;
+							rd(i, ev, ei);
+							if (entry_worse<IS_L2>(ev, ei, v, id)) {
+								while (i > 0) {
+									rd(i - 1, ev, ei);
+									if (!entry_worse<IS_L2>(ev, ei, v, id))
+										break;
+									wr(i, ev, ei);
+									--i;
+								}
+								wr(i, v, id);
+								typedef __attribute__((address_space(1))) unsigned *GU;
+								__hip_atomic_fetch_min((GU)gsl_u + (unsigned)id % (unsigned)k, bkey<IS_L2>(v), __ATOMIC_RELAXED,
+								                       __HIP_MEMORY_SCOPE_AGENT);
+							}
+						}
+						if (LSPACE == 1)
+							asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						else
+							__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+						__builtin_amdgcn_wave_barrier();
+					}
+				}
+				bal = 0ull;
+			}
 			while (bal != 0ull) {
 				const int L = __builtin_ctzll(bal); // wave-uniform
 				bal &= bal - 1ull;
@@ -466,10 +573,84 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 		return;
 	}
 	if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-		if constexpr (OUTLINE && NT == 1)
-			thr = rare_insert_outlined<IS_L2, LSPACE>(acc[0], row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h);
-		else
-			thr = rare_insert_body<NT, IS_L2, LSPACE>(acc, row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h);
+		if constexpr (LSPACE == 1) {
+			if constexpr (OUTLINE && NT == 1)
+				thr = rare_insert_outlined<IS_L2, LSPACE>(acc[0], row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h);
+			else
+				thr = rare_insert_body<NT, IS_L2, LSPACE>(acc, row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h);
+		} else {
+			// Lists in GLOBAL memory (or of unknown placement): every list access is an L2 round trip, so an insertion must
+			// be O(log k) accesses and the lanes must work in parallel -- binary heaps, one lane per query, the two lanes
+			// that share a query taking turns.  (LDS lists, above, are sorted arrays filled cooperatively.)
+			// ---- rare path: exact (value, id) insertion into this wave's per-query lists ----------
+			// The lane's passing rows (against the thresholds at entry, T0) are numbered in scan order; each pass of the
+			// loop below compacts the next two of them into registers (all indices static: no scratch, no calls inside
+			// the unrolled scan) and inserts them.  Usually one lane has one candidate and one pass suffices.
+			const float T0 = gval;
+			for (int hh = 0; hh < 2; ++hh) { // lanes l and l+32 share a query: take turns
+				const bool mine = any && h == hh;
+				if (__builtin_amdgcn_ballot_w64(mine) == 0ull)
+					continue;
+				if (mine) {
+					Thr cur;
+					cur.v = *lthr_q;
+					cur.id = *lthrid_q;
+					cur.pos = *lpos_q;
+					float T = T0;
+					int done = 0, npass;
+					do {
+						float cv0 = 0.f, cv1 = 0.f;
+						int cid0 = 0, cid1 = 0;
+						npass = 0;
+	#pragma unroll
+						for (int t = 0; t < NT; ++t) {
+	#pragma unroll
+							for (int g = 0; g < 4; ++g) {
+								if (IS_L2 ? gm[t][g] <= T0 : gm[t][g] >= T0) {
+	#pragma unroll
+									for (int e = 0; e < 4; ++e) {
+										float v = acc[t][4 * g + e];
+										if (IS_L2)
+											v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
+										const int rl = t * 32 + e + 8 * g + 4 * h;
+										if (rl < nvalid && (IS_L2 ? v <= T0 : v >= T0)) {
+											if (npass == done) {
+												cv0 = v;
+												cid0 = (int)(row0 + rl);
+											} else if (npass == done + 1) {
+												cv1 = v;
+												cid1 = (int)(row0 + rl);
+											}
+											++npass;
+										}
+									}
+								}
+							}
+						}
+	#pragma unroll 1
+						for (int i = 0; i < 2; ++i) { // a real loop: ONE inlined copy of the insertion code
+							if (done + i < npass) {
+								const float v = i ? cv1 : cv0;
+								const int id = i ? cid1 : cid0;
+								if ((IS_L2 ? v <= T : v >= T) && cand_better<IS_L2>(v, id, cur.v, cur.id)) {
+									cur = list_insert<IS_L2>(ldq, liq, k, cur.pos, v, id);
+									// publish: best value of this row's class (fire and forget)
+									__hip_atomic_fetch_min((__attribute__((address_space(1))) unsigned *)(uintptr_t)gslot_q + (unsigned)id % (unsigned)k,
+									                       bkey<IS_L2>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								}
+							}
+						}
+						done += 2;
+					} while (done < npass);
+					*lthr_q = cur.v;
+					*lthrid_q = cur.id;
+					*lpos_q = cur.pos;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+			thr = *lthr_q;
+		}
 	}
 }
 
