@@ -423,6 +423,12 @@ def main():
                     "launches": n_launch,
                     "algorithmic_bytes_per_launch": kinfo["bytes"],
                 }
+                if is_ivf:
+                    # SURVEY 8d's own figure: every stored vector and id read ONCE per batch (list-major lower bound),
+                    # whatever the number of <= 20-query work items that actually stream a list
+                    lm = float(n) * d * 4 + float(n) * 8
+                    out["roofline"]["list_major_bytes_8d"] = lm
+                    out["roofline"]["frac_list_major_8d"] = round(lm / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
         # ---- CPU baseline (oracle, BLAS-path arithmetic, all host cores) + recall, N=1 only ----------
         if world == 1 and is_hnsw:
             out["distance_evals_per_query"] = round(kinfo["bytes"] / (4.0 * d + 4.0) / nq, 1)

@@ -411,7 +411,7 @@ extern "C" void mvs_debug_counters(unsigned long long *out, int reset) {
 }
 #endif
 int g_pf_nsplit = 0;
-int g_pf_seed = 16384; // rows of the seeding pre-pass (0 = off)
+int g_pf_seed = 0; // rows of the seeding pre-pass (0 = off: measured no gain, the insertions are not what the first round waits for)
 int g_pf_abl = 0; // profiling: ablation instance of the d = 128 L2 kernel (results wrong)
 
 FlatSearchPlan plan_prefilter(const FlatGeom &g, int64_t nq, int64_t n, int64_t kp) {
