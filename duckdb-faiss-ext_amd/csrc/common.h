@@ -135,6 +135,7 @@ void launch_scatter_rows(const int *d_fq, int nf, int64_t k, const float *d_Df, 
 extern int g_pf_nsplit;
 extern int g_pf_abl;
 extern int g_pf_seed;
+extern int g_pf_classes32;
 extern int g_mfma_variant;
 extern int g_mfma_nsplit;
 extern int g_mfma_warm;

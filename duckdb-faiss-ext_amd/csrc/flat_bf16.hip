@@ -307,7 +307,54 @@ __global__ __launch_bounds__(256, 2) void flat_bf16x3_kernel(const MfmaArgs a) {
 		// a vmcnt(0) that also covers the next tile's LDS-DMA.
 		// (most insertions of a (query, split) pair happen in its first few hundred rows: refresh every other tile there)
 		const int period = u < a.k ? 2 : (u < 256 ? 8 : PF_SLOT_PERIOD);
-		if ((ABL & 4) ? u == 0 : (u % period) == 0) {
+		if (a.nclass == 32 && ((ABL & 4) ? u == 0 : (u % period) == 0)) {
+			// 32 row classes for k' <= 16 lists: the bound is the k'-th SMALLEST of the 32 per-class minima (k' distinct rows
+			// at least that good exist), ~the 1.4 k'-th best row seen so far by anyone; the maximum over k' classes that the
+			// generic scheme uses is ~the 3 k'-th best (coupon collecting), i.e. ~2.4x more rows pass the filter and each of
+			// them stalls the workgroup's other waves at the tile barrier.  Lanes l and l + 32 hold 16 keys each; ten
+			// bisection steps on the order-preserving keys find the k'-th smallest to 1/1024 of the key range (the upper end
+			// of the final interval is returned: still a valid bound).
+#pragma unroll 1
+			for (int t = 0; t < 2; ++t) {
+				const unsigned long long *src =
+				    (const unsigned long long *)(a.gslot + (size_t)(qvalid[t] ? q[t] : 0) * a.slot_stride + 16 * h);
+				unsigned long long w[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				unsigned key[16];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					key[2 * j] = (unsigned)w[j];
+					key[2 * j + 1] = (unsigned)(w[j] >> 32);
+				}
+				unsigned lo = key[0], hi = key[0];
+#pragma unroll
+				for (int j = 1; j < 16; ++j) {
+					lo = lo < key[j] ? lo : key[j];
+					hi = hi > key[j] ? hi : key[j];
+				}
+				{
+					const unsigned olo = (unsigned)__shfl_xor((int)lo, 32), ohi = (unsigned)__shfl_xor((int)hi, 32);
+					lo = lo < olo ? lo : olo;
+					hi = hi > ohi ? hi : ohi;
+				}
+#pragma unroll 1
+				for (int it = 0; it < 10 && lo < hi; ++it) {
+					const unsigned mid = lo + ((hi - lo) >> 1);
+					int cnt = 0;
+#pragma unroll
+					for (int j = 0; j < 16; ++j)
+						cnt += key[j] <= mid ? 1 : 0;
+					cnt += __shfl_xor(cnt, 32);
+					if (cnt >= k)
+						hi = mid;
+					else
+						lo = mid + 1;
+				}
+				gkey[t] = hi;
+			}
+		} else if ((ABL & 4) ? u == 0 : (u % period) == 0) {
 			const int window = (u / period) % nwin;
 			SlotRegs sr[2];
 #pragma unroll
@@ -371,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16x3_kernel(const MfmaArgs a) {
 			tile_epilogue<1, IS_L2, (ABL & 16) != 0, false, false, true, GL ? 2 : 1, false>(acc[t], nullptr, row0, nvalid, xnq[t], thr[t], qvalid[t], gkey[t],
 			                                                   a.gslot + (size_t)(qvalid[t] ? q[t] : 0) * a.slot_stride, ldq[t],
 			                                                   liq[t], k, lthr + ql[t], lthrid + ql[t], lpos + ql[t], h, nullptr,
-			                                                   yn4);
+			                                                   yn4, a.nclass);
 		}
 		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
 	}
@@ -411,6 +458,7 @@ extern "C" void mvs_debug_counters(unsigned long long *out, int reset) {
 }
 #endif
 int g_pf_nsplit = 0;
+int g_pf_classes32 = 0; // option pf_classes32 = 1: 32 classes + k-th smallest (2.2x fewer insertions, but its blocking read + bisection cost more than they save: 67.4 vs 65.5 ms, same box)
 int g_pf_seed = 0; // rows of the seeding pre-pass (0 = off: measured no gain, the insertions are not what the first round waits for)
 int g_pf_abl = 0; // profiling: ablation instance of the d = 128 L2 kernel (results wrong)
 
@@ -488,14 +536,16 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
                       int32_t *d_pi, unsigned *d_gthr, hipStream_t st) {
 	if (nq <= 0)
 		return;
-	const int stride = flat_mfma_slot_stride(kp);
+	const int nclass = (kp <= 16 && g_pf_classes32) ? 32 : (int)kp; // 32 classes + k'-th smallest for the common small-k case
+	const int stride = flat_mfma_slot_stride(nclass);
 	const long long gtotal = (long long)nq * stride;
 	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal, stride,
-	                   (int)kp, metric == METRIC_L2 ? 1 : 0);
+	                   nclass, metric == METRIC_L2 ? 1 : 0);
 	MfmaArgs a;
 	memset(&a, 0, sizeof a);
 	a.gslot = d_gthr;
 	a.slot_stride = stride;
+	a.nclass = nclass;
 	a.qf = (const float *)d_qf;
 	a.qn = d_qnorm;
 	a.yb = (const float *)d_rows_bf;

@@ -30,6 +30,7 @@ struct MfmaArgs {
 	int32_t *pi;     // partial row ids
 	unsigned *gslot; // [nq][slot_stride] shared threshold slots (keys); see "threshold sharing" below
 	int slot_stride; // slots per query = k rounded up to a multiple of 16
+	int nclass;      // row classes (row id mod nclass) the slots stand for; 0 = k
 	long long n;
 	long long split_rows;
 	int nq, k, nqb, nsplit, dp, nch, xcd_map;
@@ -260,7 +261,8 @@ struct ListPtr<2> { // global memory
 // cost scratch traffic only when it runs, instead of SGPR / VGPR spills inside the tile loop.
 template <int NT, bool IS_L2, int LSPACE>
 __device__ __forceinline__ float rare_insert_body(const f32x16 (&acc)[NT], long long row0, int nvalid, float thr, bool qvalid,
-                                                 float gval, bool any, unsigned *gslot_q, float *ldq, int *liq, int k, int h) {
+                                                 float gval, bool any, unsigned *gslot_q, float *ldq, int *liq, int k, int h,
+                                                 int nclass) {
 		// ---- rare path: exact (value, id) insertion, WAVE-COOPERATIVE -------------------------------------------
 		// Every lane marks its passing rows in a bit mask (against the shared bound at entry, T0; ties kept).  Then, round by
 		// round, every lane pulls its next marked value out of the accumulators (a select tree: no dynamic register
@@ -363,7 +365,7 @@ __device__ __forceinline__ float rare_insert_body(const f32x16 (&acc)[NT], long 
 								}
 								wr(i, v, id);
 								typedef __attribute__((address_space(1))) unsigned *GU;
-								__hip_atomic_fetch_min((GU)gsl_u + (unsigned)id % (unsigned)k, bkey<IS_L2>(v), __ATOMIC_RELAXED,
+								__hip_atomic_fetch_min((GU)gsl_u + (unsigned)id % (unsigned)nclass, bkey<IS_L2>(v), __ATOMIC_RELAXED,
 								                       __HIP_MEMORY_SCOPE_AGENT);
 							}
 						}
@@ -474,7 +476,7 @@ __device__ __forceinline__ float rare_insert_body(const f32x16 (&acc)[NT], long 
 					typedef __attribute__((address_space(1))) unsigned *GU;
 					GU gsL = (GU)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(gsl_u >> 32), L) << 32) |
 					              (unsigned)__builtin_amdgcn_readlane((int)gsl_u, L));
-					__hip_atomic_fetch_min(gsL + (unsigned)cid % (unsigned)k, bkey<IS_L2>(cv), __ATOMIC_RELAXED,
+					__hip_atomic_fetch_min(gsL + (unsigned)cid % (unsigned)nclass, bkey<IS_L2>(cv), __ATOMIC_RELAXED,
 					                       __HIP_MEMORY_SCOPE_AGENT);
 				}
 				if (!(LSPACE == 1 && k <= 64))
@@ -501,9 +503,9 @@ __device__ __forceinline__ float rare_insert_body(const f32x16 (&acc)[NT], long 
 template <bool IS_L2, int LSPACE>
 __device__ __attribute__((noinline)) float rare_insert_outlined(f32x16 acc0, long long row0, int nvalid, float thr, bool qvalid,
                                                                 float gval, bool any, unsigned *gslot_q, float *ldq, int *liq,
-                                                                int k, int h) {
+                                                                int k, int h, int nclass) {
 	f32x16 acc[1] = {acc0};
-	return rare_insert_body<1, IS_L2, LSPACE>(acc, row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h);
+	return rare_insert_body<1, IS_L2, LSPACE>(acc, row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h, nclass);
 }
 
 // YPRE: the row norms were already fetched into registers by the caller (ypre[t * 4 + g] = norms of rows
@@ -516,7 +518,8 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
                                               float &thr, bool qvalid, unsigned gkey, unsigned *gslot_q,
                                               float *ldq, int *liq, int k, float *lthr_q, int *lthrid_q, int *lpos_q,
                                               int h, const unsigned long long *rowmask = nullptr,
-                                              const float4 *ypre = nullptr) {
+                                              const float4 *ypre = nullptr, int nclass_in = 0) {
+	const int nclass = nclass_in > 0 ? nclass_in : k;
 	float gval = IS_L2 ? FLT_MAX : -FLT_MAX;
 	float teff = thr;
 	if (qvalid) {
@@ -575,9 +578,9 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 	if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
 		if constexpr (LSPACE == 1) {
 			if constexpr (OUTLINE && NT == 1)
-				thr = rare_insert_outlined<IS_L2, LSPACE>(acc[0], row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h);
+				thr = rare_insert_outlined<IS_L2, LSPACE>(acc[0], row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h, nclass);
 			else
-				thr = rare_insert_body<NT, IS_L2, LSPACE>(acc, row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h);
+				thr = rare_insert_body<NT, IS_L2, LSPACE>(acc, row0, nvalid, thr, qvalid, gval, any, gslot_q, ldq, liq, k, h, nclass);
 		} else {
 			// Lists in GLOBAL memory (or of unknown placement): every list access is an L2 round trip, so an insertion must
 			// be O(log k) accesses and the lanes must work in parallel -- binary heaps, one lane per query, the two lanes
@@ -635,7 +638,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[NT], const float *nb
 								if ((IS_L2 ? v <= T : v >= T) && cand_better<IS_L2>(v, id, cur.v, cur.id)) {
 									cur = list_insert<IS_L2>(ldq, liq, k, cur.pos, v, id);
 									// publish: best value of this row's class (fire and forget)
-									__hip_atomic_fetch_min((__attribute__((address_space(1))) unsigned *)(uintptr_t)gslot_q + (unsigned)id % (unsigned)k,
+									__hip_atomic_fetch_min((__attribute__((address_space(1))) unsigned *)(uintptr_t)gslot_q + (unsigned)id % (unsigned)nclass,
 									                       bkey<IS_L2>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 								}
 							}

@@ -601,7 +601,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
 	ws_pd.reserve((size_t)p.nsplit * nq * kp * sizeof(float));
 	ws_pi.reserve((size_t)p.nsplit * nq * kp * sizeof(int32_t));
-	ws_gthr.reserve((size_t)nq * ((kp + 15) / 16 * 16) * sizeof(unsigned) + 64);
+	ws_gthr.reserve((size_t)nq * std::max(32, (kp + 15) / 16 * 16) * sizeof(unsigned) + 64);
 	begin_kernel_timing(st);
 	launch_prefilter(geom, p, metric, ws_pfq.p, (const float *)ws_qn.p, nq, vecs_bf, norms, ntotal, kp, (float *)ws_pd.p,
 	                 (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
@@ -1454,6 +1454,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "prefilter")) { // -1 auto, 0 off (exact f32 kernel only), 1 wherever the bf16x3 kernel supports the shape
 		prefilter_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "pf_classes32")) {
+		g_pf_classes32 = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "pf_seed")) { // rows of the prefilter's seeding pre-pass (0 = off)

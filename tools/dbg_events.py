@@ -7,8 +7,8 @@ for s0 in range(0, n, 1 << 20):
     ix.add_torch(mf.synth_uniform_torch(min(1 << 20, n - s0), 128, 1234, row0=s0)); torch.cuda.synchronize()
 xq = mf.synth_uniform_torch(10000, 128, 4321)
 L = mf.lib(); out = (C.c_ulonglong * 4)()
-for seed in (0, 16384, 131072):
-  ix.set_option("pf_seed", seed)
+for seed in (0, 1):
+  ix.set_option("pf_classes32", seed)
   ix.search_torch(xq, 10); torch.cuda.synchronize()
   L.mvs_debug_counters(out, 1)
   ix.search_torch(xq, 10); torch.cuda.synchronize()
