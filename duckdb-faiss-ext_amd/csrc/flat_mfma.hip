@@ -38,6 +38,10 @@ namespace mvs {
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(1))) const float glb_f32;
 
+// Measured dead end (round 2): issuing the A-fragment reads by hand (inline ds_read_b64 + s_waitcnt lgkmcnt(0)) removes the
+// eight s_waitcnt vmcnt(0) per tile that hipcc puts in front of LDS reads while an LDS-DMA is in flight, but loses the
+// ds_read2st64_b64 pairing: 212.9 vs 207.9 ms at the headline, 262 vs 260 ms at d = 768 (same box).  The other workgroup
+// of the CU covers those waits here (a tile is 8192 MFMA cycles); in the 5x shorter tiles of flat_bf16.hip it does not.
 // ABL (ablation builds for profiling only; results are WRONG when != 0): bit0 = skip the epilogue,
 // bit1 = stage only the first tile, bit2 = reuse the first A-fragment group for every MFMA (no ds_reads)
 // STREAM = false (d <= 128): NT = 2 (64-row tiles), one unit per tile, the wave's query fragments stay in registers.

@@ -583,6 +583,8 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
                                  int64_t out_off, const TieFlags *flp, hipStream_t st) {
 	if (prefilter_mode == 0 || pf_suppressed || !prefilter_supported(geom) || kk > 40)
 		return false;
+	if (params && params->sel_kind != MVS_SEL_NONE) // filtered inner product stays on the exact fused kernel (SEL instances)
+		return false;
 	// auto: the contraction must dominate (one 256-query block per workgroup, >= 8192 rows per split)
 	if (prefilter_mode < 0 && (nq < 512 || ntotal < 262144))
 		return false;

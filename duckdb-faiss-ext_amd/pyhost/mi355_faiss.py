@@ -19,7 +19,7 @@ KIND_FLAT, KIND_IDMAP, KIND_IVFFLAT, KIND_HNSW = 1, 2, 3, 4
 SEL_NONE, SEL_BITMAP, SEL_BATCH = 0, 1, 2
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libmi355faiss.so")
+LIB_PATH = os.environ.get("MVS_LIB_PATH") or os.path.join(_PKG, "libmi355faiss.so")  # (override: A/B of two builds)
 
 
 class FaissException(RuntimeError):

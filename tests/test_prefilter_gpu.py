@@ -118,3 +118,21 @@ def test_error_model_is_an_upper_bound_with_room(mf):
     D, I = pf.search(xq[:64], 10)
     truth = ((xb[I].astype(np.float64) - xq[:64, None, :].astype(np.float64)) ** 2).sum(-1)
     np.testing.assert_allclose(D, truth, rtol=1e-4)
+
+
+def test_selector_searches_never_take_the_prefilter(mf):
+    """inner product + IDSelector rides the fused f32 kernel's SEL instances (FAISS's per-pair branch); at sizes where
+    the auto mode would pick the prefilter the selector must still be honoured"""
+    rs = np.random.RandomState(4)
+    xb = rs.rand(300_000, 64).astype(np.float32) - 0.5
+    xq = rs.rand(600, 64).astype(np.float32) - 0.5
+    ix = mf.index_factory(64, "Flat", IP)
+    ix.add(xb)
+    keep = np.arange(300_000)[rs.rand(300_000) < 0.3]
+    D, I = ix.search(xq, 10, sel=("batch", keep))
+    assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+    assert np.isin(I, keep).all()
+    Do, Io = orc.flat_search(IP, xb, xq[:64], 10, sel=("batch", keep))
+    assert np.array_equal(I[:64], Io) and np.array_equal(D[:64], Do)
+    D2, I2 = ix.search(xq, 10)  # and without the selector the same index does take it
+    assert ix.last_kernel_info()["name"] == "flat_bf16x3_kernel"
