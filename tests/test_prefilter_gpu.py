@@ -136,3 +136,35 @@ def test_selector_searches_never_take_the_prefilter(mf):
     assert np.array_equal(I[:64], Io) and np.array_equal(D[:64], Do)
     D2, I2 = ix.search(xq, 10)  # and without the selector the same index does take it
     assert ix.last_kernel_info()["name"] == "flat_bf16x3_kernel"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_prefilter_fuzz(mf, seed):
+    """seeded differential fuzz with the prefilter FORCED at small, ragged shapes: random d in (32, 128], N, nq, k, metric,
+    IDMap, duplicates, scaled / shifted data -- always the exact kernel's answer, bit for bit, and the oracle's"""
+    rs = np.random.RandomState(7000 + seed)
+    d = int(rs.choice([33, 40, 64, 65, 96, 100, 127, 128]))
+    n = int(rs.choice([4096, 5000, 8191, 20000, 33333]))
+    nq = int(rs.choice([20, 21, 64, 255, 257, 300]))
+    k = int(rs.choice([1, 2, 7, 10, 11, 16, 27, 39]))
+    metric = [L2, IP][rs.randint(2)]
+    idmap = bool(rs.randint(2))
+    scale = float(rs.choice([1.0, 1e-3, 300.0]))
+    xb = ((rs.rand(n, d).astype(np.float32) - (0.5 if rs.randint(2) else 0.0)) * scale).astype(np.float32)
+    xq = ((rs.rand(nq, d).astype(np.float32) - 0.5) * scale).astype(np.float32)
+    if rs.randint(2):
+        xb[rs.randint(0, n, n // 10)] = xb[rs.randint(0, n, n // 10)]  # duplicates: ties, proof failures
+        xq[: nq // 4] = xb[rs.randint(0, n, nq // 4)]
+    ids = (rs.permutation(3 * n)[:n] + 5).astype(np.int64) if idmap else None
+    desc = "IDMap,Flat" if idmap else "Flat"
+    pf, ex = _pair(mf, d, metric, xb, desc=desc, ids=ids)
+    D1, I1 = pf.search(xq, k)
+    assert pf.last_kernel_info()["name"] == "flat_bf16x3_kernel"
+    D0, I0 = ex.search(xq, k)
+    what = f"seed={seed} d={d} n={n} nq={nq} k={k} metric={metric} idmap={idmap} scale={scale}"
+    assert np.array_equal(I1, I0), what
+    assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), what
+    o = orc.Index(d, desc, metric)
+    o.add_with_ids(xb, ids) if idmap else o.add(xb)
+    Do, Io = o.search(xq, k)
+    assert np.array_equal(I1, Io) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32)), what
