@@ -205,7 +205,7 @@ class Index:
         self._parent = parent  # keeps the owning index alive for borrowed handles
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._owned:
+        if getattr(self, "_h", None) and self._owned and _L is not None:  # (_L is None during interpreter shutdown)
             _L.mvs_index_free(self._h)
         self._h = None
 
