@@ -83,6 +83,90 @@ __global__ void ivf_gather_ids_kernel(const long long *src, const int *perm, lon
 		dst[r] = perm[r] >= 0 ? src[perm[r]] : -1;
 }
 
+__global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *out_bits) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	float v = i < n ? norms[i] : 0.f;
+	for (int o = 32; o >= 1; o >>= 1)
+		v = fmaxf(v, __shfl_xor(v, o));
+	if ((threadIdx.x & 63) == 0 && __float_as_uint(v) > *out_bits)
+		atomicMax(out_bits, __float_as_uint(v)); // squared norms are >= 0: the bit pattern orders like the value
+}
+
+// L2 list scan through the MFMA ITEMS kernel as a PREFILTER (same scheme as csrc/flat_bf16.hip): the kernel's values follow
+// the BLAS-branch formula (xn + yn) - 2<x,y>, IVFFlatScanner computes sum (x - y)^2.  Both sit within
+//   E = 4 (d + 2) 2^-24 (xn + yn_max)
+// of the real distance ((2d+2) u (xn+yn) for the three chains and the two roundings of the formula, (d+3) u D <= 2(d+3) u
+// (xn+yn) for the scanner's chain; u = 2^-24), so |formula - scanner| <= 2E... the proof below uses 2 x that again.
+// One wave per query, lane j <-> candidate j of the merged top-kp (formula values, best first, row POSITIONS in the
+// MFMA list store): exact_j = the scanner's value of that row (t = x_k - y_k, acc = fmaf(t, t, acc), k ascending).
+// If a_(kp) > a_(k) + 2 * (2E), every row whose scanner value can reach the exact k-th is among the kp candidates (proof:
+// rescore_verify_kernel in flat_bf16.hip); otherwise the query is appended to fail_q and re-run on the scanner kernel.
+__global__ __launch_bounds__(64) void ivf_rescore_verify_kernel(const float *__restrict__ ca, const long long *__restrict__ ci,
+                                                               int kp, int k, const float *__restrict__ x, int d,
+                                                               const float *__restrict__ rows, int dp, int interleaved,
+                                                               const float *__restrict__ qn,
+                                                               const unsigned *__restrict__ max_norm_bits,
+                                                               float *__restrict__ pd1, int *__restrict__ pi1,
+                                                               int *__restrict__ fail_cnt, int *__restrict__ fail_q) {
+	const long long q = blockIdx.x;
+	const int j = threadIdx.x;
+	long long pos = -1;
+	float av = FLT_MAX;
+	if (j < kp) {
+		pos = ci[q * kp + j];
+		av = ca[q * kp + j];
+	}
+	float ex = FLT_MAX;
+	if (pos >= 0) {
+		const float *y = rows + (size_t)pos * dp;
+		const float *xq = x + q * d;
+		const bool odd = interleaved && ((pos >> 4) & 1);
+		float acc = 0.f;
+		for (int g4 = 0; g4 < d; g4 += 4) {
+			const float4 s = *(const float4 *)(y + g4);
+			float v0, v1, v2, v3;
+			if (!interleaved)
+				v0 = s.x, v1 = s.y, v2 = s.z, v3 = s.w;
+			else if (odd)
+				v0 = s.z, v1 = s.x, v2 = s.w, v3 = s.y;
+			else
+				v0 = s.x, v1 = s.z, v2 = s.y, v3 = s.w;
+			float t = xq[g4] - v0;
+			acc = fmaf(t, t, acc);
+			if (g4 + 1 < d) {
+				t = xq[g4 + 1] - v1;
+				acc = fmaf(t, t, acc);
+			}
+			if (g4 + 2 < d) {
+				t = xq[g4 + 2] - v2;
+				acc = fmaf(t, t, acc);
+			}
+			if (g4 + 3 < d) {
+				t = xq[g4 + 3] - v3;
+				acc = fmaf(t, t, acc);
+			}
+		}
+		ex = acc;
+	}
+	if (j < kp) {
+		pd1[q * kp + j] = ex;
+		pi1[q * kp + j] = (int)pos;
+	}
+	const int navail = __popcll(__builtin_amdgcn_ballot_w64(pos >= 0));
+	if (navail >= kp) { // a full list: candidates may be missing unless the margin proves otherwise
+		const float a_k = __shfl(av, k - 1), a_kp = __shfl(av, kp - 1);
+		const float e = 4.f * (float)(d + 2) * 5.9604645e-8f * (qn[q] + __uint_as_float(*max_norm_bits));
+		const bool ok = kp > k && a_kp > a_k + 4.f * e;
+		if (!ok && j == 0)
+			fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
+	}
+}
+__global__ void ivf_map_labels_kernel(long long *I, long long total, const long long *idmap) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < total && I[i] >= 0)
+		I[i] = idmap[I[i]];
+}
+
 class IVFFlatIndex : public IndexBase {
 public:
 	// owned; nlist centroids.  IndexFlat(d, metric) for "IVF<n>,Flat"; IndexHNSWFlat(d, M, metric) for
@@ -113,6 +197,8 @@ public:
 			(void)hipStreamSynchronize(stream);
 		if (raw)
 			(void)hipFree(raw);
+		if (h_fail)
+			(void)hipHostFree(h_fail);
 		delete quantizer;
 	}
 
@@ -418,6 +504,11 @@ public:
 			launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
 			launch_query_norms((const float *)tmp.p, nrows_mf, d, (float *)norms_mf.p, stream);
 		}
+		max_norm_mf.reserve(64);
+		MVS_HIP(hipMemsetAsync(max_norm_mf.p, 0, 64, stream));
+		if (nrows_mf > 0)
+			hipLaunchKernelGGL(ivf_max_norm_kernel, dim3((unsigned)((nrows_mf + 255) / 256)), dim3(256), 0, stream,
+			                   (const float *)norms_mf.p, (long long)nrows_mf, (unsigned *)max_norm_mf.p);
 		MVS_HIP(hipStreamSynchronize(stream));
 		mf_dirty = false;
 	}
@@ -455,13 +546,25 @@ public:
 		mvs_search_params qp;
 		memset(&qp, 0, sizeof qp);
 		qp.efSearch = params ? params->efSearch : 0; // quantizer_params of an HNSW coarse quantizer (:679-681)
-		quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, hnsw_M > 0 ? &qp : nullptr, stream);
+		if (!reuse_coarse) // (a prefilter re-run keeps the coarse assignment of the batch its queries came from)
+			quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, hnsw_M > 0 ? &qp : nullptr, stream);
 		// Inner product: the MFMA variant is the same k-ordered chain as IVFFlatScanner's fvec_inner_product -> default.
 		// L2: it evaluates ||x||^2 + ||y||^2 - 2<x,y> (the Flat BLAS-branch arithmetic) instead of the scanner's
 		// sum (x-y)^2, i.e. the same neighbours up to rounding-level near-ties -> opt-in (option ivf_mfma = 1); the
 		// default keeps the scanner's arithmetic bit for bit.
 		const bool want_mfma = mfma_mode == 1 || (mfma_mode < 0 && metric == METRIC_IP);
 		const bool small = nq * np < (int64_t)1 << 26;
+		// L2, default: the MFMA scan as a prefilter + exact scanner-arithmetic re-scoring with a per-query proof
+		// (option ivf_mfma = 2.  Not the default: the formula's error scales with ||x||^2 + ||y||^2, the distance does not --
+		// on data far from the origin (the C3 mixture: norms ~130, distances ~2.5) the proof fails for most queries and the
+		// re-runs cost more than the prefilter saves: 390 k vs 805 k QPS.  Residuals against the list centroid would fix
+		// that, DESIGN.md 7.  k + 4 candidates: with more the k-lists push the workgroup past half a CU's LDS.)
+		const int64_t kp = k + 4;
+		if (metric == METRIC_L2 && mfma_mode == 2 && !pf_suppressed && small && kp <= 64 && nq >= 64 &&
+		    flat_mfma_items_supported(flat_geom_for(d), kp)) {
+			mfma_prefilter_search(nq, d_x, k, (int)kp, d_D, d_I, params, d_idmap, st, np);
+			return;
+		}
 		if (want_mfma && small && flat_mfma_items_supported(flat_geom_for(d), k)) {
 			mfma_grouped_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
 			return;
@@ -572,6 +675,123 @@ public:
 			}
 			kinfo.bytes = bytes; // list-major algorithmic bytes: every item streams its list once
 			kinfo.flops = pairs * d * 2.0;
+		}
+		stream_wait(st, stream);
+	}
+
+	// L2: ITEMS scan with kp = k + 6 candidates per query (every list streamed ONCE for <= 128 of its queries), exact
+	// re-scoring in IVFFlatScanner's arithmetic, proof, re-run of the unproven queries on the scanner kernel
+	void mfma_prefilter_search(int64_t nq, const float *d_x, int64_t k, int kp, float *d_D, int64_t *d_I,
+	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, int64_t np) {
+		build_lists_mf();
+		const int G = flat_mfma_item_slots(), shift = 7;
+		const int64_t npairs = nq * np;
+		const int max_items = ivf_group_max_items(npairs, nlist, G);
+		ws_items.reserve((size_t)max_items * 16);
+		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
+		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
+		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		int *d_nitems = nullptr, *d_cnt = nullptr;
+		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
+		                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
+		                 &d_nitems, &d_cnt, stream);
+		ws_xi.reserve(flat_mfma_item_query_floats(geom, max_items) * sizeof(float));
+		launch_ivf_pack_item_fragments(d_x, d, geom.kc, geom.nch, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p,
+		                               (float *)ws_xi.p, stream);
+		ws_q.reserve((size_t)nq * sizeof(float));
+		launch_query_norms(d_x, nq, d, (float *)ws_q.p, stream);
+		ws_pd.reserve((size_t)max_items * G * kp * sizeof(float));
+		ws_pi.reserve((size_t)max_items * G * kp * sizeof(int32_t));
+		SelectorDev sel = selector.upload(params, stream);
+		memset(&kinfo, 0, sizeof kinfo);
+		ws_gslot.reserve((size_t)nq * ((kp + 15) / 16 * 16) * sizeof(unsigned) + 64);
+		begin_kernel_timing(stream);
+		launch_flat_mfma_items(geom, metric, (const float *)ws_xi.p, (const float *)ws_q.p, nq, (const float *)codes_mf.p,
+		                       (const float *)norms_mf.p, nrows_mf, kp, ws_items.p, d_nitems, max_items,
+		                       (const int *)ws_qidx.p, (const int64_t *)rowids_mf.p, &sel, d_idmap, (float *)ws_pd.p,
+		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
+		end_kernel_timing(stream);
+		// merged top-kp per query: formula values + row POSITIONS in the MFMA list store
+		const size_t ca_bytes = ((size_t)nq * kp * sizeof(float) + 255) & ~(size_t)255;
+		ws_cand.reserve(ca_bytes + (size_t)nq * kp * sizeof(int64_t));
+		float *ca = (float *)ws_cand.p;
+		int64_t *ci = (int64_t *)((char *)ws_cand.p + ca_bytes);
+		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq, kp,
+		                   nullptr, nullptr, ca, ci, stream, G, shift);
+		const size_t ex_bytes = ((size_t)nq * kp * sizeof(float) + 255) & ~(size_t)255;
+		ws_ex.reserve(ex_bytes + (size_t)nq * kp * sizeof(int32_t));
+		float *pd1 = (float *)ws_ex.p;
+		int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
+		ws_fail.reserve(64 + (size_t)nq * sizeof(int));
+		int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
+		MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), stream));
+		hipLaunchKernelGGL(ivf_rescore_verify_kernel, dim3((unsigned)nq), dim3(64), 0, stream, ca, (const long long *)ci, kp,
+		                   (int)k, d_x, d, (const float *)codes_mf.p, geom.dp, geom.pair_interleaved ? 1 : 0,
+		                   (const float *)ws_q.p, (const unsigned *)max_norm_mf.p, pd1, pi1, fail_cnt, fail_q);
+		MVS_HIP(hipGetLastError());
+		// exact values -> the k best by (value, position), labels = stored ids (then the id map of an IDMap wrapper)
+		launch_merge_partials(metric, pd1, pi1, 1, nq, kp, (const int64_t *)rowids_mf.p, 0, d_D, d_I, stream, k, nullptr);
+		if (d_idmap && !raw_ids) {
+			const long long tot = (long long)nq * k;
+			hipLaunchKernelGGL(ivf_map_labels_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+			                   (long long *)d_I, tot, (const long long *)d_idmap);
+		}
+		if (!h_fail)
+			MVS_HIP(hipHostMalloc((void **)&h_fail, 64, hipHostMallocDefault));
+		MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+		snprintf(kinfo.name, sizeof kinfo.name, "ivf_mfma_prefilter (flat_mfma_resident_kernel items)");
+		kinfo.grid = max_items;
+		kinfo.block = 256;
+		kinfo.nsplit = (int)np;
+		std::vector<int> cnt;
+		if (timing_enabled) {
+			cnt.resize((size_t)nlist);
+			MVS_HIP(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nlist * sizeof(int), hipMemcpyDeviceToHost, stream));
+		}
+		MVS_HIP(hipStreamSynchronize(stream));
+		if (timing_enabled) {
+			double bytes = 0, pairs = 0;
+			for (int64_t l = 0; l < nlist; l++) {
+				const double len = (double)(list_off[(size_t)l + 1] - list_off[(size_t)l]);
+				bytes += (double)((cnt[(size_t)l] + G - 1) / G) * len * geom.dp * 4.0;
+				pairs += (double)cnt[(size_t)l] * len;
+			}
+			kinfo.bytes = bytes;
+			kinfo.flops = pairs * d * 2.0;
+		}
+		const int nf = *h_fail;
+		pf_queries_total += nq;
+		pf_fallback_total += nf;
+		if (nf > 0) {
+			const mvs_kernel_info keep = kinfo;
+			const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
+			const size_t df_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
+			ws_fb.reserve(xf_bytes + df_bytes + (size_t)nf * k * sizeof(int64_t));
+			float *xf = (float *)ws_fb.p;
+			float *Df = (float *)((char *)ws_fb.p + xf_bytes);
+			int64_t *If = (int64_t *)((char *)Df + df_bytes);
+			launch_gather_query_rows(d_x, d, fail_q, nf, xf, stream);
+			// their probe lists, compacted to the front of the coarse-label buffer (np int64 = 2 np floats per query)
+			DevBuf csub;
+			csub.reserve((size_t)nf * np * sizeof(int64_t));
+			launch_gather_query_rows((const float *)ws_cI.p, (int)(2 * np), fail_q, nf, (float *)csub.p, stream);
+			MVS_HIP(hipMemcpyAsync(ws_cI.p, csub.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+			pf_suppressed = true;
+			reuse_coarse = true;
+			const bool timing = timing_enabled;
+			timing_enabled = false;
+			try {
+				search_mapped(nf, xf, k, Df, If, params, d_idmap, stream);
+			} catch (...) {
+				pf_suppressed = reuse_coarse = false;
+				timing_enabled = timing;
+				throw;
+			}
+			pf_suppressed = reuse_coarse = false;
+			timing_enabled = timing;
+			MVS_HIP(hipStreamSynchronize(stream)); // csub is freed at scope exit
+			launch_scatter_rows(fail_q, nf, k, Df, If, d_D, d_I, stream);
+			kinfo = keep;
 		}
 		stream_wait(st, stream);
 	}
@@ -757,7 +977,7 @@ public:
 	}
 	bool use_fast_scan = true;
 	bool raw_ids = false;
-	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always
+	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always, 2 = L2 prefilter + exact re-scoring
 
 	// introspection for parity tests
 	void get_centroids(float *out) {
@@ -782,7 +1002,12 @@ private:
 	FlatGeom geom {};
 	bool mf_dirty = true;
 	int64_t nrows_mf = 0;
-	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev;
+	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf;
+	DevBuf ws_cand, ws_ex, ws_fail, ws_fb;
+	int *h_fail = nullptr; // pinned
+	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel
+	bool reuse_coarse = false;
+	int64_t pf_fallback_total = 0, pf_queries_total = 0;
 	SelectorHolder selector;
 };
 

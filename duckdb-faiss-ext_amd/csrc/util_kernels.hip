@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) void merge_items_kernel(const float *__restrict
 		const int bi = ci[r];
 		long long label = -1;
 		if (bi >= 0) {
-			label = rowids[bi];
+			label = rowids ? rowids[bi] : (long long)bi; // rowids == nullptr: the caller wants row positions
 			if (idmap)
 				label = idmap[label];
 		}

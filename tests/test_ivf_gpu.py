@@ -300,3 +300,36 @@ def test_row_sharded_lists_with_replicated_centroids_equal_one_index(mf, metric)
     Dm, Im = mf.merge_shards(metric, np.stack(Ds), np.stack(Is))
     assert np.array_equal(Dm, Dr)
     assert np.array_equal(Im, Ir)
+
+
+@pytest.mark.parametrize("idmap", [False, True])
+@pytest.mark.parametrize("d,nlist,n,nq,k,nprobe", [(128, 64, 60000, 500, 10, 8), (64, 16, 20000, 200, 5, 16), (96, 32, 30000, 64, 20, 4)])
+def test_l2_prefilter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, nprobe, idmap):
+    """option ivf_mfma = 2, L2 batches of >= 64 queries: MFMA list scan as a prefilter (BLAS-branch formula, k + 4 candidates) + exact re-scoring
+    in IVFFlatScanner's arithmetic + per-query proof; must equal the plain scanner kernel and the oracle bit for bit, also
+    on duplicate-heavy data where queries are re-run (same coarse assignment) and with a selector"""
+    xb = orc.synth_clustered(n, d, 31, n_centers=nlist, sigma=0.2)
+    xq = orc.synth_clustered(nq, d, 32, n_centers=nlist, sigma=0.2)
+    xb[n // 2 :: 7] = xb[: len(xb[n // 2 :: 7])]  # duplicates: exact distance ties near the top
+    xq[: nq // 4] = xb[5 : 5 + nq // 4]
+    ids = (np.arange(n, dtype=np.int64) * 3 + 11)
+    desc = ("IDMap," if idmap else "") + f"IVF{nlist},Flat"
+    g, o = mf.index_factory(d, desc, L2), orc.Index(d, desc, L2)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    for a in (g, o):
+        a.add_with_ids(xb, ids)
+    keep = ids[::2]
+    for sel in (None, ("batch", keep)):
+        g.set_option("ivf_mfma", 2)
+        D1, I1 = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"].startswith("ivf_mfma_prefilter")
+        g.set_option("ivf_mfma", 0)
+        D0, I0 = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+        g.set_option("ivf_mfma", -1)
+        Do, Io = o.search(xq, k, nprobe=nprobe, sel=sel)
+        ok = _no_tie_rows(Do)
+        assert ok.sum() >= 1
+        assert np.array_equal(D1, D0) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32)), (sel and sel[0])
+        assert np.array_equal(I1[ok], I0[ok]) and np.array_equal(I1[ok], Io[ok]), (sel and sel[0])
