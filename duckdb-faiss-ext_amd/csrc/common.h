@@ -136,6 +136,7 @@ extern int g_pf_nsplit;
 extern int g_pf_abl;
 extern int g_pf_seed;
 extern int g_pf_classes32;
+extern int g_pf_sched;
 extern int g_mfma_variant;
 extern int g_mfma_nsplit;
 extern int g_mfma_warm;

@@ -224,6 +224,22 @@ __global__ __launch_bounds__(256, 2) void flat_bf16x3_kernel(const MfmaArgs a) {
 		xnq[t] = (IS_L2 && qvalid[t]) ? a.qn[q[t]] : 0.f;
 	}
 
+	// Two workgroups share a CU (two waves per SIMD).  Left alone they phase-lock: both in their MFMA phase (alternating
+	// issue, each at half speed), then both in their epilogue + barrier with the matrix pipe idle.  The wave slot this wave
+	// occupies on its SIMD (HW_ID.WAVE_ID) tells the two apart: the odd slot gets the lower issue priority (it then fills
+	// the gaps the even slot's epilogues leave) and / or starts half a tile late.
+	if (a.sched) {
+		const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u; // HW_REG_HW_ID, WAVE_ID[3:0]
+		if (a.sched & 1) {
+			if (slot)
+				__builtin_amdgcn_s_setprio(0);
+			else
+				__builtin_amdgcn_s_setprio(2);
+		}
+		if ((a.sched & 2) && slot)
+			__builtin_amdgcn_s_sleep(24); // 24 x 64 clocks ~ one tile's MFMA phase
+	}
+
 	// B fragments, resident: [query tile][k-chunk][hi | lo]
 	bf16x8 bq[2][KCH][2];
 	{
@@ -458,6 +474,7 @@ extern "C" void mvs_debug_counters(unsigned long long *out, int reset) {
 }
 #endif
 int g_pf_nsplit = 0;
+int g_pf_sched = 0; // option pf_sched (see the kernel)
 int g_pf_classes32 = 0; // option pf_classes32 = 1: 32 classes + k-th smallest (2.2x fewer insertions, but its blocking read + bisection cost more than they save: 67.4 vs 65.5 ms, same box)
 int g_pf_seed = 0; // rows of the seeding pre-pass (0 = off: measured no gain, the insertions are not what the first round waits for)
 int g_pf_abl = 0; // profiling: ablation instance of the d = 128 L2 kernel (results wrong)
@@ -546,6 +563,7 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 	a.gslot = d_gthr;
 	a.slot_stride = stride;
 	a.nclass = nclass;
+	a.sched = g_pf_sched;
 	a.qf = (const float *)d_qf;
 	a.qn = d_qnorm;
 	a.yb = (const float *)d_rows_bf;

@@ -31,6 +31,7 @@ struct MfmaArgs {
 	unsigned *gslot; // [nq][slot_stride] shared threshold slots (keys); see "threshold sharing" below
 	int slot_stride; // slots per query = k rounded up to a multiple of 16
 	int nclass;      // row classes (row id mod nclass) the slots stand for; 0 = k
+	int sched;       // prefilter kernel: 0 = none, 1 = s_setprio by wave slot parity, 2 = half-tile start stagger by slot parity, 3 = both
 	long long n;
 	long long split_rows;
 	int nq, k, nqb, nsplit, dp, nch, xcd_map;

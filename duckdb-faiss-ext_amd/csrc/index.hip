@@ -1458,6 +1458,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		prefilter_mode = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "pf_sched")) {
+		g_pf_sched = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "pf_classes32")) {
 		g_pf_classes32 = (int)v;
 		return true;
