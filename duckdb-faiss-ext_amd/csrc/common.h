@@ -113,7 +113,13 @@ void launch_flat_mfma_items(const FlatGeom &g, int metric, const float *d_qf, co
                             const float *d_rows, const float *d_norms, int64_t nrows, int64_t k, const void *d_items,
                             const int *d_nitems, int max_items, const int *d_qidx, const int64_t *d_rowids,
                             const SelectorDev *sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gthr,
-                            hipStream_t st);
+                            hipStream_t st, const float *d_item_qn = nullptr /* L2 on residual rows: per item slot */);
+// residual variant of the item query packing (L2): fragments of (query - centroid of the item's list), their squared norms
+// per item slot and, per query, the largest of them (float bits, atomicMax; the caller zeroes it)
+void launch_ivf_pack_item_fragments_residual(const float *d_x, int d, int kc, int nch, const void *d_items,
+                                             const int *d_nitems, int max_items, const int *d_qidx, float *d_qf,
+                                             const float *d_centroids, const int *d_list_of_blk64, float *d_item_qn,
+                                             unsigned *d_qmaxn_bits, hipStream_t st);
 // bf16x3 prefilter + exact f32 re-scoring (csrc/flat_bf16.hip)
 bool prefilter_supported(const FlatGeom &g);
 float prefilter_cerr(int d);

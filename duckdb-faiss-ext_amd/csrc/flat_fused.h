@@ -42,6 +42,7 @@ struct MfmaArgs {
 	// ITEMS instances (IVF list scan as a segmented variant of this kernel): one workgroup per work item =
 	// (row segment of one inverted list, <= 128 of the queries that probe it)
 	const int4 *items;       // {row_begin (multiple of 64), row_end, qoff, nq_item}
+	const float *item_qn;    // ITEMS, L2 on residual rows: squared norm of (query - list centroid) per item slot [item][128]
 	const int *nitems_dev;   // device-side item count; the grid is an upper bound
 	const int *qidx;         // query number of slot qoff + s
 	const long long *rowids; // stored id of every row (selector); row position is what the partial lists carry

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void flat_mfma_resident_kernel(const MfmaAr
 		lthrid[ql] = -1;
 		lpos[ql] = 0;
 	}
-	const float xnq = (IS_L2 && qvalid) ? a.qn[q] : 0.f;
+	const float xnq = (IS_L2 && qvalid) ? ((ITEMS && a.item_qn) ? a.item_qn[(size_t)blockIdx.x * QBLOCK + ql] : a.qn[q]) : 0.f;
 
 	float qf[KSTEPS];
 	const float4 *qsrc = (const float4 *)a.qf + (size_t)qblk32 * nch * (KSTEPS / 4) * 64 + lane;
@@ -727,7 +727,7 @@ void launch_flat_mfma_items(const FlatGeom &g, int metric, const float *d_qf, co
                             const float *d_rows, const float *d_norms, int64_t nrows, int64_t k, const void *d_items,
                             const int *d_nitems, int max_items, const int *d_qidx, const int64_t *d_rowids,
                             const SelectorDev *sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gthr,
-                            hipStream_t st) {
+                            hipStream_t st, const float *d_item_qn) {
 	if (max_items <= 0)
 		return;
 	const int stride = flat_mfma_slot_stride(k);
@@ -758,6 +758,7 @@ void launch_flat_mfma_items(const FlatGeom &g, int metric, const float *d_qf, co
 	a.nitems_dev = d_nitems;
 	a.qidx = d_qidx;
 	a.rowids = (const long long *)d_rowids;
+	a.item_qn = d_item_qn;
 	const size_t lds = mfma_lds_bytes(g, k);
 	if (g.nch > 1)
 		launch_items_inst<32, 4, true>(metric, has_sel, a, max_items, lds, st);

@@ -83,6 +83,16 @@ __global__ void ivf_gather_ids_kernel(const long long *src, const int *perm, lon
 		dst[r] = perm[r] >= 0 ? src[perm[r]] : -1;
 }
 
+// rows of the MFMA list store (mf order) -> residuals against their list's centroid (padding rows stay zero)
+__global__ void ivf_residual_kernel(float *rows, const int *perm, long long n, int d, const int *list_of_blk64, const float *cent) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * d)
+		return;
+	const long long r = i / d;
+	const int j = (int)(i - r * d);
+	if (perm[r] >= 0)
+		rows[i] = __fsub_rn(rows[i], cent[(size_t)list_of_blk64[r >> 6] * d + j]);
+}
 __global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *out_bits) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	float v = i < n ? norms[i] : 0.f;
@@ -92,24 +102,36 @@ __global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *o
 		atomicMax(out_bits, __float_as_uint(v)); // squared norms are >= 0: the bit pattern orders like the value
 }
 
-// L2 list scan through the MFMA ITEMS kernel as a PREFILTER (same scheme as csrc/flat_bf16.hip): the kernel's values follow
-// the BLAS-branch formula (xn + yn) - 2<x,y>, IVFFlatScanner computes sum (x - y)^2.  Both sit within
-//   E = 4 (d + 2) 2^-24 (xn + yn_max)
-// of the real distance ((2d+2) u (xn+yn) for the three chains and the two roundings of the formula, (d+3) u D <= 2(d+3) u
-// (xn+yn) for the scanner's chain; u = 2^-24), so |formula - scanner| <= 2E... the proof below uses 2 x that again.
-// One wave per query, lane j <-> candidate j of the merged top-kp (formula values, best first, row POSITIONS in the
-// MFMA list store): exact_j = the scanner's value of that row (t = x_k - y_k, acc = fmaf(t, t, acc), k ascending).
-// If a_(kp) > a_(k) + 2 * (2E), every row whose scanner value can reach the exact k-th is among the kp candidates (proof:
-// rescore_verify_kernel in flat_bf16.hip); otherwise the query is appended to fail_q and re-run on the scanner kernel.
+// L2 list scan through the MFMA ITEMS kernel as a PREFILTER (same scheme as csrc/flat_bf16.hip).  The kernel's value F is the
+// BLAS-branch formula on RESIDUAL rows and queries, (rxn + ryn) - 2<r_x, r_y>, r = fl(v - centroid); IVFFlatScanner computes
+// S = sum (x - y)^2 on the original vectors.  With u = 2^-24, D* the real distance, N_l = rxn_l + ryn for a row of list l:
+//   rounding of the residuals:   | ||r_x - r_y||^2 - D* | <= 4 u N_l
+//   formula (three chains + two roundings):  | F - ||r_x - r_y||^2 | <= (2d + 2) u N_l
+//   scanner chain:               | S - D* | <= (d + 3) u D* <= 2 (d + 3) u N_l
+// so |F - S| <= E_l = (4d + 12) u N_l (the kernel uses 1.25 x that, with ryn = the largest residual-row norm of the index).
+// rxn_l = ||x - c_l||^2 is small for the lists the query is close to and in the hundreds for far probes, so the bound is
+// taken over the RELEVANT lists only: those that hold one of the kp candidates, plus every probed list that the triangle
+// inequality cannot exclude -- a row of list l has D* >= (||x - c_l|| - ||y - c_l||)^2 >= lb_l = (sqrt(rxn_l) - sqrt(ryn_max))^2.
+// One wave per query; lane p <-> probe p (distances to the probed centroids), lane j <-> candidate j of the merged top-kp (F
+// values, best first, row POSITIONS in the MFMA list store): exact_j = the scanner's value of the ORIGINAL row (CSR store,
+// through perm; t = x_k - y_k, acc = fmaf(t, t, acc), k ascending).  Proof, with E = max E_l over relevant lists:
+//   the k best candidates have S <= a_(k) + E, so the exact k-th value T <= a_(k) + E;
+//   a row of an irrelevant list has S >= lb_l (1 - eps) > a_(k) + 2E >= T: not in the exact top-k;
+//   a row of a relevant list in the exact top-k has F <= S + E <= a_(k) + 2E < a_(kp): it is one of the kp candidates.
+// Queries that cannot be proven are appended to fail_q and re-run on the scanner kernel with the same coarse assignment.
 __global__ __launch_bounds__(64) void ivf_rescore_verify_kernel(const float *__restrict__ ca, const long long *__restrict__ ci,
                                                                int kp, int k, const float *__restrict__ x, int d,
-                                                               const float *__restrict__ rows, int dp, int interleaved,
-                                                               const float *__restrict__ qn,
+                                                               const float *__restrict__ rows_csr, int dp_csr,
+                                                               const int *__restrict__ perm,
+                                                               const long long *__restrict__ coarse, int np,
+                                                               const float *__restrict__ cent,
+                                                               const int *__restrict__ list_of_blk64,
                                                                const unsigned *__restrict__ max_norm_bits,
                                                                float *__restrict__ pd1, int *__restrict__ pi1,
                                                                int *__restrict__ fail_cnt, int *__restrict__ fail_q) {
 	const long long q = blockIdx.x;
 	const int j = threadIdx.x;
+	const float *xq = x + q * d;
 	long long pos = -1;
 	float av = FLT_MAX;
 	if (j < kp) {
@@ -117,49 +139,69 @@ __global__ __launch_bounds__(64) void ivf_rescore_verify_kernel(const float *__r
 		av = ca[q * kp + j];
 	}
 	float ex = FLT_MAX;
+	int clist = -1;
 	if (pos >= 0) {
-		const float *y = rows + (size_t)pos * dp;
-		const float *xq = x + q * d;
-		const bool odd = interleaved && ((pos >> 4) & 1);
+		const float *y = rows_csr + (size_t)perm[pos] * dp_csr;
 		float acc = 0.f;
-		for (int g4 = 0; g4 < d; g4 += 4) {
-			const float4 s = *(const float4 *)(y + g4);
-			float v0, v1, v2, v3;
-			if (!interleaved)
-				v0 = s.x, v1 = s.y, v2 = s.z, v3 = s.w;
-			else if (odd)
-				v0 = s.z, v1 = s.x, v2 = s.w, v3 = s.y;
-			else
-				v0 = s.x, v1 = s.z, v2 = s.y, v3 = s.w;
-			float t = xq[g4] - v0;
+		for (int kk = 0; kk < d; ++kk) {
+			const float t = __fsub_rn(xq[kk], y[kk]);
 			acc = fmaf(t, t, acc);
-			if (g4 + 1 < d) {
-				t = xq[g4 + 1] - v1;
-				acc = fmaf(t, t, acc);
-			}
-			if (g4 + 2 < d) {
-				t = xq[g4 + 2] - v2;
-				acc = fmaf(t, t, acc);
-			}
-			if (g4 + 3 < d) {
-				t = xq[g4 + 3] - v3;
-				acc = fmaf(t, t, acc);
-			}
 		}
 		ex = acc;
+		clist = list_of_blk64[pos >> 6];
 	}
 	if (j < kp) {
 		pd1[q * kp + j] = ex;
 		pi1[q * kp + j] = (int)pos;
 	}
 	const int navail = __popcll(__builtin_amdgcn_ballot_w64(pos >= 0));
-	if (navail >= kp) { // a full list: candidates may be missing unless the margin proves otherwise
-		const float a_k = __shfl(av, k - 1), a_kp = __shfl(av, kp - 1);
-		const float e = 4.f * (float)(d + 2) * 5.9604645e-8f * (qn[q] + __uint_as_float(*max_norm_bits));
-		const bool ok = kp > k && a_kp > a_k + 4.f * e;
-		if (!ok && j == 0)
-			fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
+	if (navail < kp)
+		return; // every comparable row of the probed lists is a candidate: nothing to prove
+	const float a_k = __shfl(av, k - 1), a_kp = __shfl(av, kp - 1);
+	const float rymax = __uint_as_float(*max_norm_bits);
+	const float cu = 1.25f * (float)(4 * d + 12) * 5.9604645e-8f;
+	bool ok = kp > k;
+	// pass 1: E0 over the candidates' own lists; pass 2: add the lists the triangle inequality cannot exclude; pass 3: check
+	float e_rel = 0.f;
+	for (int pass = 0; pass < 3 && ok; ++pass) {
+		float emax = 0.f;
+		bool bad = false;
+		for (int p0 = 0; p0 < np; p0 += 64) {
+			const int p = p0 + j;
+			const long long l = p < np ? coarse[q * np + p] : -1;
+			float rx = 0.f, lb = FLT_MAX;
+			if (l >= 0) {
+				const float *c = cent + (size_t)l * d;
+				for (int kk = 0; kk < d; ++kk) {
+					const float r = __fsub_rn(xq[kk], c[kk]);
+					rx = fmaf(r, r, rx);
+				}
+				const float gap = sqrtf(rx) - sqrtf(rymax);
+				lb = gap > 0.f ? gap * gap * 0.9999f : 0.f;
+			}
+			bool rel = false; // holds a candidate?
+			for (int jj = 0; jj < kp; ++jj)
+				rel |= l >= 0 && __shfl(clist, jj) == (int)l;
+			if (pass >= 1)
+				rel |= l >= 0 && lb <= a_k + 8.f * e_rel;
+			if (pass < 2) {
+				if (rel)
+					emax = fmaxf(emax, cu * (rx + rymax));
+			} else if (l >= 0 && !rel && !(lb > a_k + 2.f * e_rel)) {
+				bad = true;
+			}
+		}
+		if (pass < 2) {
+			for (int o = 32; o >= 1; o >>= 1)
+				emax = fmaxf(emax, __shfl_xor(emax, o));
+			e_rel = emax;
+		} else if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+			ok = false;
+		}
 	}
+	ok = ok && a_kp > a_k + 2.f * e_rel; // (false for NaN / inf as well)
+	if (!ok && j == 0)
+		fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
 }
 __global__ void ivf_map_labels_kernel(long long *I, long long total, const long long *idmap) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,9 +543,30 @@ public:
 			                   (const long long *)rowids.p, (const int *)dperm.p, (long long)nrows_mf,
 			                   (long long *)rowids_mf.p);
 			MVS_HIP(hipGetLastError());
+			// L2: the MFMA list store holds RESIDUALS against the list centroid.  The kernel's (xn + yn) - 2<x,y> loses its
+			// precision to cancellation when the norms dwarf the distance (the C3 mixture: norms ~130, distances ~2.5);
+			// on residuals both are of the size of the distance, and ||(x-c) - (y-c)||^2 is the same distance.
+			mf_residual = metric == METRIC_L2;
+			if (mf_residual) {
+				std::vector<float> cent((size_t)nlist * d);
+				get_centroids(cent.data());
+				std::vector<int32_t> lob((size_t)(nrows_mf / 64 + 1), 0);
+				for (int64_t l = 0; l < nlist; l++)
+					for (int64_t b = pb[(size_t)l] / 64; b < (pb[(size_t)l] + (pe[(size_t)l] - pb[(size_t)l] + 63) / 64 * 64) / 64; b++)
+						lob[(size_t)b] = (int32_t)l;
+				cent_dev.reserve(cent.size() * sizeof(float));
+				list_of_blk.reserve(lob.size() * sizeof(int32_t));
+				MVS_HIP(hipMemcpyAsync(cent_dev.p, cent.data(), cent.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+				MVS_HIP(hipMemcpyAsync(list_of_blk.p, lob.data(), lob.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+				hipLaunchKernelGGL(ivf_residual_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, (float *)tmp.p,
+				                   (const int *)dperm.p, (long long)nrows_mf, d, (const int *)list_of_blk.p, (const float *)cent_dev.p);
+				MVS_HIP(hipStreamSynchronize(stream)); // cent / lob are host temporaries
+			}
 			launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
 			launch_query_norms((const float *)tmp.p, nrows_mf, d, (float *)norms_mf.p, stream);
 		}
+		perm_mf.reserve(perm.size() * sizeof(int32_t));
+		MVS_HIP(hipMemcpyAsync(perm_mf.p, dperm.p, perm.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
 		max_norm_mf.reserve(64);
 		MVS_HIP(hipMemsetAsync(max_norm_mf.p, 0, 64, stream));
 		if (nrows_mf > 0)
@@ -555,11 +618,12 @@ public:
 		const bool want_mfma = mfma_mode == 1 || (mfma_mode < 0 && metric == METRIC_IP);
 		const bool small = nq * np < (int64_t)1 << 26;
 		// L2, default: the MFMA scan as a prefilter + exact scanner-arithmetic re-scoring with a per-query proof
-		// (option ivf_mfma = 2.  Not the default: the formula's error scales with ||x||^2 + ||y||^2, the distance does not --
-		// on data far from the origin (the C3 mixture: norms ~130, distances ~2.5) the proof fails for most queries and the
-		// re-runs cost more than the prefilter saves: 390 k vs 805 k QPS.  Residuals against the list centroid would fix
-		// that, DESIGN.md 7.  k + 4 candidates: with more the k-lists push the workgroup past half a CU's LDS.)
+		// (The scan runs on RESIDUALS against the list centroid: on the original vectors the formula's error scales with
+		// ||x||^2 + ||y||^2 while the distance does not -- at the C3 mixture, norms ~130 and distances ~2.5, the proof
+		// failed for most queries.  k + 4 candidates: with more the k-lists push the workgroup past half a CU's LDS.)
 		const int64_t kp = k + 4;
+		// Opt-in (ivf_mfma = 2): exact, but at C3 it lands at 780 k QPS against the scanner kernel's 805-817 k -- the ITEMS
+		// launch takes 8.4 ms for k + 4 = 14 candidates (5.7 ms for inner product with k = 10), the re-runs 1.5 ms.
 		if (metric == METRIC_L2 && mfma_mode == 2 && !pf_suppressed && small && kp <= 64 && nq >= 64 &&
 		    flat_mfma_items_supported(flat_geom_for(d), kp)) {
 			mfma_prefilter_search(nq, d_x, k, (int)kp, d_D, d_I, params, d_idmap, st, np);
@@ -626,6 +690,23 @@ public:
 		stream_wait(st, stream);
 	}
 
+	// query fragments of the work items; L2: residuals against the item's list centroid + their norms per item slot
+	const float *pack_item_queries(const float *d_x, int64_t nq, int max_items, const int *d_nitems) {
+		ws_xi.reserve(flat_mfma_item_query_floats(geom, max_items) * sizeof(float));
+		if (!mf_residual) {
+			launch_ivf_pack_item_fragments(d_x, d, geom.kc, geom.nch, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p,
+			                               (float *)ws_xi.p, stream);
+			return nullptr;
+		}
+		ws_iqn.reserve((size_t)max_items * 128 * sizeof(float));
+		ws_qmaxn.reserve((size_t)nq * sizeof(unsigned) + 64);
+		MVS_HIP(hipMemsetAsync(ws_qmaxn.p, 0, (size_t)nq * sizeof(unsigned), stream));
+		launch_ivf_pack_item_fragments_residual(d_x, d, geom.kc, geom.nch, ws_items.p, d_nitems, max_items,
+		                                        (const int *)ws_qidx.p, (float *)ws_xi.p, (const float *)cent_dev.p,
+		                                        (const int *)list_of_blk.p, (float *)ws_iqn.p, (unsigned *)ws_qmaxn.p, stream);
+		return (const float *)ws_iqn.p;
+	}
+
 	// IVF list scan as a segmented variant of the fused Flat kernel: items of <= 128 queries per list
 	void mfma_grouped_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                         const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, int64_t np) {
@@ -641,9 +722,7 @@ public:
 		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
 		                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
 		                 &d_nitems, &d_cnt, stream);
-		ws_xi.reserve(flat_mfma_item_query_floats(geom, max_items) * sizeof(float));
-		launch_ivf_pack_item_fragments(d_x, d, geom.kc, geom.nch, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p,
-		                               (float *)ws_xi.p, stream);
+		const float *item_qn = pack_item_queries(d_x, nq, max_items, d_nitems);
 		ws_q.reserve((size_t)nq * sizeof(float)); // query norms (L2)
 		launch_query_norms(d_x, nq, d, (float *)ws_q.p, stream);
 		ws_pd.reserve((size_t)max_items * G * k * sizeof(float));
@@ -655,7 +734,7 @@ public:
 		launch_flat_mfma_items(geom, metric, (const float *)ws_xi.p, (const float *)ws_q.p, nq, (const float *)codes_mf.p,
 		                       (const float *)norms_mf.p, nrows_mf, k, ws_items.p, d_nitems, max_items,
 		                       (const int *)ws_qidx.p, (const int64_t *)rowids_mf.p, &sel, d_idmap, (float *)ws_pd.p,
-		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
+		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream, item_qn);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
 		                   k, (const int64_t *)rowids_mf.p, raw_ids ? nullptr : d_idmap, d_D, d_I, stream, G, shift);
@@ -695,9 +774,7 @@ public:
 		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
 		                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
 		                 &d_nitems, &d_cnt, stream);
-		ws_xi.reserve(flat_mfma_item_query_floats(geom, max_items) * sizeof(float));
-		launch_ivf_pack_item_fragments(d_x, d, geom.kc, geom.nch, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p,
-		                               (float *)ws_xi.p, stream);
+		const float *item_qn = pack_item_queries(d_x, nq, max_items, d_nitems);
 		ws_q.reserve((size_t)nq * sizeof(float));
 		launch_query_norms(d_x, nq, d, (float *)ws_q.p, stream);
 		ws_pd.reserve((size_t)max_items * G * kp * sizeof(float));
@@ -709,7 +786,7 @@ public:
 		launch_flat_mfma_items(geom, metric, (const float *)ws_xi.p, (const float *)ws_q.p, nq, (const float *)codes_mf.p,
 		                       (const float *)norms_mf.p, nrows_mf, kp, ws_items.p, d_nitems, max_items,
 		                       (const int *)ws_qidx.p, (const int64_t *)rowids_mf.p, &sel, d_idmap, (float *)ws_pd.p,
-		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
+		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream, item_qn);
 		end_kernel_timing(stream);
 		// merged top-kp per query: formula values + row POSITIONS in the MFMA list store
 		const size_t ca_bytes = ((size_t)nq * kp * sizeof(float) + 255) & ~(size_t)255;
@@ -726,8 +803,9 @@ public:
 		int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
 		MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), stream));
 		hipLaunchKernelGGL(ivf_rescore_verify_kernel, dim3((unsigned)nq), dim3(64), 0, stream, ca, (const long long *)ci, kp,
-		                   (int)k, d_x, d, (const float *)codes_mf.p, geom.dp, geom.pair_interleaved ? 1 : 0,
-		                   (const float *)ws_q.p, (const unsigned *)max_norm_mf.p, pd1, pi1, fail_cnt, fail_q);
+		                   (int)k, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, (const long long *)ws_cI.p, (int)np,
+		                   (const float *)cent_dev.p, (const int *)list_of_blk.p, (const unsigned *)max_norm_mf.p, pd1, pi1,
+		                   fail_cnt, fail_q);
 		MVS_HIP(hipGetLastError());
 		// exact values -> the k best by (value, position), labels = stored ids (then the id map of an IDMap wrapper)
 		launch_merge_partials(metric, pd1, pi1, 1, nq, kp, (const int64_t *)rowids_mf.p, 0, d_D, d_I, stream, k, nullptr);
@@ -1002,7 +1080,8 @@ private:
 	FlatGeom geom {};
 	bool mf_dirty = true;
 	int64_t nrows_mf = 0;
-	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf;
+	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf, cent_dev, list_of_blk, perm_mf, ws_iqn, ws_qmaxn;
+	bool mf_residual = false;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb;
 	int *h_fail = nullptr; // pinned
 	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel

@@ -603,6 +603,60 @@ __global__ void ivf_pack_item_fragments_kernel(const float *x, int d, int kc, in
 		dst[i] = make_float4(o[0], o[1], o[2], o[3]);
 	}
 }
+// L2 on RESIDUAL rows (csrc/ivf.hip build_lists_mf): the item's queries minus the centroid of the item's list
+__global__ void ivf_pack_item_fragments_res_kernel(const float *x, int d, int kc, int nch, const int4 *items,
+                                                   const int *nitems_dev, const int *qidx, float *qf, const float *cent,
+                                                   const int *list_of_blk64, float *item_qn, unsigned *qmaxn_bits) {
+	if ((int)blockIdx.x >= *nitems_dev)
+		return;
+	const int4 it = items[blockIdx.x];
+	const float *c = cent + (size_t)list_of_blk64[it.x >> 6] * d; // every list starts at a multiple of 64 rows
+	const int ks4 = kc / 8;
+	const int per_item4 = 4 * nch * ks4 * 64;
+	float4 *dst = reinterpret_cast<float4 *>(qf) + (size_t)blockIdx.x * per_item4;
+	for (int i = threadIdx.x; i < per_item4; i += blockDim.x) {
+		const int lane = i & 63;
+		int t = i >> 6;
+		const int s4 = t % ks4;
+		t /= ks4;
+		const int ch = t % nch, w = t / nch;
+		const int slot = w * 32 + (lane & 31);
+		float o[4] = {0.f, 0.f, 0.f, 0.f};
+		if (slot < it.w) {
+			const float *xr = x + (size_t)qidx[it.z + slot] * d;
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int kk = ch * kc + 2 * (4 * s4 + e) + (lane >> 5);
+				o[e] = kk < d ? __fsub_rn(xr[kk], c[kk]) : 0.f;
+			}
+		}
+		dst[i] = make_float4(o[0], o[1], o[2], o[3]);
+	}
+	for (int slot = threadIdx.x; slot < 128; slot += blockDim.x) {
+		float acc = 0.f;
+		if (slot < it.w) {
+			const int q = qidx[it.z + slot];
+			const float *xr = x + (size_t)q * d;
+			for (int kk = 0; kk < d; ++kk) {
+				const float r = __fsub_rn(xr[kk], c[kk]);
+				acc = fmaf(r, r, acc);
+			}
+			atomicMax(qmaxn_bits + q, __float_as_uint(acc));
+		}
+		item_qn[(size_t)blockIdx.x * 128 + slot] = acc;
+	}
+}
+void launch_ivf_pack_item_fragments_residual(const float *d_x, int d, int kc, int nch, const void *d_items,
+                                             const int *d_nitems, int max_items, const int *d_qidx, float *d_qf,
+                                             const float *d_centroids, const int *d_list_of_blk64, float *d_item_qn,
+                                             unsigned *d_qmaxn_bits, hipStream_t st) {
+	if (max_items <= 0)
+		return;
+	hipLaunchKernelGGL(ivf_pack_item_fragments_res_kernel, dim3(max_items), dim3(256), 0, st, d_x, d, kc, nch,
+	                   (const int4 *)d_items, d_nitems, d_qidx, d_qf, d_centroids, d_list_of_blk64, d_item_qn, d_qmaxn_bits);
+	MVS_HIP(hipGetLastError());
+}
+
 void launch_ivf_pack_item_fragments(const float *d_x, int d, int kc, int nch, const void *d_items, const int *d_nitems,
                                     int max_items, const int *d_qidx, float *d_qf, hipStream_t st) {
 	if (max_items <= 0)

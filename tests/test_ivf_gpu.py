@@ -214,7 +214,9 @@ def test_ivf_l2_mfma_mode_is_recall_equivalent(mf):
     g.train(xb)
     g.add(xb)
     De, Ie = g.search(xq, 10, nprobe=8)
-    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")  # default for L2: the scanner's arithmetic
+    # default for L2: the scanner's arithmetic -- directly (small batches) or as the exact re-scoring behind the MFMA
+    # prefilter (batches of >= 64 queries, csrc/ivf.hip mfma_prefilter_search); same bits either way
+    assert g.last_kernel_info()["name"].startswith(("ivf_scan_kernel", "ivf_mfma_prefilter"))
     g.set_option("ivf_mfma", 1)
     Dm, Im = g.search(xq, 10, nprobe=8)
     assert g.last_kernel_info()["name"].startswith("ivf_mfma_scan")
@@ -305,7 +307,7 @@ def test_row_sharded_lists_with_replicated_centroids_equal_one_index(mf, metric)
 @pytest.mark.parametrize("idmap", [False, True])
 @pytest.mark.parametrize("d,nlist,n,nq,k,nprobe", [(128, 64, 60000, 500, 10, 8), (64, 16, 20000, 200, 5, 16), (96, 32, 30000, 64, 20, 4)])
 def test_l2_prefilter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, nprobe, idmap):
-    """option ivf_mfma = 2, L2 batches of >= 64 queries: MFMA list scan as a prefilter (BLAS-branch formula, k + 4 candidates) + exact re-scoring
+    """option ivf_mfma = 2, L2 batches of >= 64 queries: MFMA list scan on residual rows as a prefilter (k + 4 candidates) + exact re-scoring
     in IVFFlatScanner's arithmetic + per-query proof; must equal the plain scanner kernel and the oracle bit for bit, also
     on duplicate-heavy data where queries are re-run (same coarse assignment) and with a selector"""
     xb = orc.synth_clustered(n, d, 31, n_centers=nlist, sigma=0.2)
