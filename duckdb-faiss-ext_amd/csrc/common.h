@@ -32,6 +32,17 @@ void ensure_dynamic_lds(const void *kernel, size_t bytes);
 
 constexpr int METRIC_IP = 0;
 constexpr int METRIC_L2 = 1;
+// the other MetricType values the glue registers (src/faiss_extension.cpp:58-68; faiss/MetricType.h)
+constexpr int METRIC_L1 = 2, METRIC_LINF = 3, METRIC_LP = 4, METRIC_CANBERRA = 20, METRIC_BRAYCURTIS = 21,
+              METRIC_JENSENSHANNON = 22, METRIC_JACCARD = 23;
+inline bool metric_is_extra(int m) {
+	return (m >= METRIC_L1 && m <= METRIC_LP) || (m >= METRIC_CANBERRA && m <= METRIC_JACCARD);
+}
+// list order of a metric's results: similarity metrics (is_similarity_metric) keep the largest values, like inner
+// product; every other one the smallest, like L2 -- merges, neutral values and threshold keys only need this
+inline int metric_order(int m) {
+	return (m == METRIC_IP || m == METRIC_JACCARD) ? METRIC_IP : METRIC_L2;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Flat brute-force search geometry (DESIGN.md "K2/K3")

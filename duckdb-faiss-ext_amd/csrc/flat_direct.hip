@@ -23,6 +23,16 @@
 namespace mvs {
 
 constexpr int MODE_IP = 0, MODE_L2_PAIR = 1, MODE_L2_FORMULA = 2;
+// The other metrics the glue registers (src/faiss_extension.cpp:58-68) -> faiss::knn_extra_metrics: always per pair,
+// VectorDistance<mt> of faiss/utils/extra_distances-inl.h as plain sequential float loops (oracle/orc_core.c
+// extra_distance), one strict-insert heap per query; Jaccard is a similarity (kept: the largest), the others distances.
+constexpr int MODE_L1 = 3, MODE_LINF = 4, MODE_LP = 5, MODE_CANBERRA = 6, MODE_BRAYCURTIS = 7, MODE_JS = 8, MODE_JACCARD = 9;
+__host__ __device__ constexpr bool mode_two_sums(int m) {
+	return m == MODE_BRAYCURTIS || m == MODE_JACCARD;
+}
+__host__ __device__ constexpr bool mode_needs_dim_guard(int m) { // zero padding is not neutral: 0^0, 0/0, 0 log(0/0)
+	return m == MODE_LP || m == MODE_CANBERRA || m == MODE_JS;
+}
 constexpr int DTILE = 256;
 
 struct DirectArgs {
@@ -34,6 +44,8 @@ struct DirectArgs {
 	int32_t *pi;
 	long long n, split_rows;
 	int nq, k, dp, nsplit, ngroups, interleaved;
+	int d;            // logical dimension (extra metrics: padded dimensions are skipped)
+	float metric_arg; // Lp exponent
 	SelectorDev sel;
 	const long long *idmap;
 	// item mode (IVF list scan, csrc/ivf.hip): one workgroup per (row segment, <= QG queries) work item
@@ -93,7 +105,7 @@ __device__ __forceinline__ bool lex_worse(float v, int id, float tv, int tid) {
 
 template <int KC, int QG, int MODE>
 __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
-	constexpr bool IS_L2 = MODE != MODE_IP;
+	constexpr bool IS_L2 = MODE != MODE_IP && MODE != MODE_JACCARD; // "smaller is better"
 	constexpr int LDA = KC + 1;
 	constexpr int F4_PER_ROW = KC / 4, F4 = DTILE * F4_PER_ROW, NLD = F4 / 256;
 	extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -214,6 +226,7 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 	};
 
 	float acc[QG];
+	float acc2[mode_two_sums(MODE) ? QG : 1]; // BrayCurtis / Jaccard: the denominator
 	if (total_units > 0) {
 		stage_load(0);
 		stage_store(0);
@@ -226,8 +239,11 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 			stage_load(u + 1);
 		if (ch == 0) {
 #pragma unroll
-			for (int qq = 0; qq < QG; ++qq)
+			for (int qq = 0; qq < QG; ++qq) {
 				acc[qq] = 0.f;
+				if (mode_two_sums(MODE))
+					acc2[qq] = 0.f;
+			}
 			refresh_bounds();
 		}
 		float y[KC];
@@ -241,16 +257,43 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 			typedef __attribute__((address_space(4))) const float cfloat;
 			cfloat *xs = (cfloat *)(a.xq + (size_t)qnum(qq) * a.dp + ch * KC);
 			float s = acc[qq];
+			float s2 = mode_two_sums(MODE) ? acc2[qq] : 0.f;
 #pragma unroll
 			for (int kk = 0; kk < KC; ++kk) {
 				if (MODE == MODE_L2_PAIR) {
 					const float t = xs[kk] - y[kk];
 					s = fmaf(t, t, s);
-				} else {
+				} else if (MODE <= MODE_L2_FORMULA) {
 					s = fmaf(xs[kk], y[kk], s);
+				} else {
+					if (mode_needs_dim_guard(MODE) && ch * KC + kk >= a.d)
+						continue;
+					const float xi = xs[kk], yi = y[kk];
+					if (MODE == MODE_L1) {
+						s = __fadd_rn(s, fabsf(__fsub_rn(xi, yi)));
+					} else if (MODE == MODE_LINF) {
+						s = fmaxf(s, fabsf(__fsub_rn(xi, yi)));
+					} else if (MODE == MODE_LP) {
+						s = __fadd_rn(s, powf(fabsf(__fsub_rn(xi, yi)), a.metric_arg));
+					} else if (MODE == MODE_CANBERRA) {
+						s = __fadd_rn(s, __fdiv_rn(fabsf(__fsub_rn(xi, yi)), __fadd_rn(fabsf(xi), fabsf(yi))));
+					} else if (MODE == MODE_BRAYCURTIS) {
+						s = __fadd_rn(s, fabsf(__fsub_rn(xi, yi)));
+						s2 = __fadd_rn(s2, fabsf(__fadd_rn(xi, yi)));
+					} else if (MODE == MODE_JS) {
+						const float mi = __fmul_rn(0.5f, __fadd_rn(xi, yi));
+						const float kl1 = __fmul_rn(-xi, logf(__fdiv_rn(mi, xi)));
+						const float kl2 = __fmul_rn(-yi, logf(__fdiv_rn(mi, yi)));
+						s = __fadd_rn(s, __fadd_rn(kl1, kl2));
+					} else { // MODE_JACCARD
+						s = __fadd_rn(s, fminf(xi, yi));
+						s2 = __fadd_rn(s2, fmaxf(xi, yi));
+					}
 				}
 			}
 			acc[qq] = s;
+			if (mode_two_sums(MODE))
+				acc2[qq] = s2;
 		}
 
 		if (ch == nch - 1) {
@@ -271,6 +314,10 @@ __global__ __launch_bounds__(256) void flat_direct_kernel(const DirectArgs a) {
 					v = fmaf(-2.0f, v, a.xn[qnum(qq)] + ynr);
 					v = v < 0.f ? 0.f : v;
 				}
+				if (mode_two_sums(MODE))
+					v = __fdiv_rn(v, acc2[qq]);
+				if (MODE == MODE_JS)
+					v = __fmul_rn(0.5f, v);
 				const int slot = wave * QG + qq;
 				float tv = wv[slot];
 				const float gbv = gb[qq];
@@ -410,10 +457,19 @@ static int pick_qgroup(int64_t nq, int64_t k, int kc) {
 	return 1;
 }
 
+static DirectPlan plan_direct_with_group(const FlatGeom &g, int64_t nq, int64_t n, int64_t k, int qgroup);
 DirectPlan plan_flat_direct(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
+	return plan_direct_with_group(g, nq, n, k, pick_qgroup(nq, k, direct_kc(g)));
+}
+// the extra-metric instances exist for 20 and 1 queries per workgroup only
+DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
+	const int qg = nq > 1 && direct_lds(direct_kc(g), 20, k) <= 150 * 1024 ? 20 : 1;
+	return plan_direct_with_group(g, nq, n, k, qg);
+}
+static DirectPlan plan_direct_with_group(const FlatGeom &g, int64_t nq, int64_t n, int64_t k, int qgroup) {
 	DirectPlan p;
 	const int kc = direct_kc(g);
-	p.qgroup = pick_qgroup(nq, k, kc);
+	p.qgroup = qgroup;
 	const int ngroups = (int)((nq + p.qgroup - 1) / p.qgroup);
 	const int64_t ntiles = (n + DTILE - 1) / DTILE;
 	int64_t nsplit = 2048 / (ngroups > 0 ? ngroups : 1);
@@ -444,8 +500,25 @@ static void launch_direct_inst(int mode, const DirectArgs &a, const DirectPlan &
 		MVS_LAUNCH_DIRECT(MODE_IP)
 	else if (mode == MODE_L2_PAIR)
 		MVS_LAUNCH_DIRECT(MODE_L2_PAIR)
-	else
+	else if (mode == MODE_L2_FORMULA)
 		MVS_LAUNCH_DIRECT(MODE_L2_FORMULA)
+	else if constexpr (QG != 4) { // the extra-metric instances: 20 or 1 queries per workgroup (plan_flat_direct_extra)
+		if (mode == MODE_L1)
+			MVS_LAUNCH_DIRECT(MODE_L1)
+		else if (mode == MODE_LINF)
+			MVS_LAUNCH_DIRECT(MODE_LINF)
+		else if (mode == MODE_LP)
+			MVS_LAUNCH_DIRECT(MODE_LP)
+		else if (mode == MODE_CANBERRA)
+			MVS_LAUNCH_DIRECT(MODE_CANBERRA)
+		else if (mode == MODE_BRAYCURTIS)
+			MVS_LAUNCH_DIRECT(MODE_BRAYCURTIS)
+		else if (mode == MODE_JS)
+			MVS_LAUNCH_DIRECT(MODE_JS)
+		else
+			MVS_LAUNCH_DIRECT(MODE_JACCARD)
+	} else
+		throw_faiss("mvs::launch_direct_inst", __FILE__, "no 4-query instance for metric mode %d", mode);
 #undef MVS_LAUNCH_DIRECT
 	MVS_HIP(hipGetLastError());
 }
@@ -493,6 +566,61 @@ void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, b
 	a.gslot = d_gslot;
 	a.slot_stride = d_gslot ? (int)((k + 15) / 16 * 16) : 0;
 	const int mode = metric == METRIC_IP ? MODE_IP : (formula ? MODE_L2_FORMULA : MODE_L2_PAIR);
+	const int kc = direct_kc(g);
+	if (kc == 8)
+		launch_direct_kc<8>(mode, p.qgroup, a, p, st);
+	else if (kc == 16)
+		launch_direct_kc<16>(mode, p.qgroup, a, p, st);
+	else
+		launch_direct_kc<32>(mode, p.qgroup, a, p, st);
+}
+
+static int extra_mode(int metric) {
+	switch (metric) {
+	case METRIC_L1:
+		return MODE_L1;
+	case METRIC_LINF:
+		return MODE_LINF;
+	case METRIC_LP:
+		return MODE_LP;
+	case METRIC_CANBERRA:
+		return MODE_CANBERRA;
+	case METRIC_BRAYCURTIS:
+		return MODE_BRAYCURTIS;
+	case METRIC_JENSENSHANNON:
+		return MODE_JS;
+	case METRIC_JACCARD:
+		return MODE_JACCARD;
+	}
+	throw_faiss("mvs::extra_mode", __FILE__, "metric %d has no kernel instance", metric);
+}
+void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,
+                              const float *d_xq, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,
+                              const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	DirectArgs a;
+	memset(&a, 0, sizeof a);
+	a.xq = d_xq;
+	a.yb = db.vecs;
+	a.yn = db.norms;
+	a.pd = d_pd;
+	a.pi = d_pi;
+	a.n = db.n;
+	a.split_rows = p.split_rows;
+	a.nq = (int)nq;
+	a.k = (int)k;
+	a.dp = g.dp;
+	a.d = d;
+	a.metric_arg = metric_arg;
+	a.interleaved = g.pair_interleaved ? 1 : 0;
+	a.nsplit = p.nsplit;
+	a.ngroups = (int)((nq + p.qgroup - 1) / p.qgroup);
+	a.sel = sel;
+	a.idmap = (const long long *)d_idmap;
+	a.gslot = d_gslot;
+	a.slot_stride = d_gslot ? (int)((k + 15) / 16 * 16) : 0;
+	const int mode = extra_mode(metric);
 	const int kc = direct_kc(g);
 	if (kc == 8)
 		launch_direct_kc<8>(mode, p.qgroup, a, p, st);

@@ -47,6 +47,7 @@ struct SelectorHolder {
 // cross-device clones (faiss::gpu::index_cpu_to_gpu), both of which go through host memory.
 struct HostIndex {
 	int kind = 0, d = 0, metric = 0;
+	float metric_arg = 0.f;
 	int64_t ntotal = 0;
 	bool is_trained = true;
 	std::vector<float> rows;       // Flat: [ntotal][d]
@@ -79,6 +80,7 @@ public:
 	int device = 0;
 	hipStream_t stream = nullptr;
 	int64_t label_offset = 0;
+	float metric_arg = 0.f; // faiss::Index::metric_arg (Lp exponent); the glue leaves it at 0
 	mvs_kernel_info kinfo {};
 
 	IndexBase(int kind, int d, int metric);
@@ -153,6 +155,8 @@ public:
 	bool set_option(const char *key, int64_t v) override;
 	void search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                 const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
+	void search_extra_metric(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+	                         const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
 
 	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi;
 	DevBuf ws_flag, ws_tie; // inner-product boundary ties: flagged queries + tie-pass scratch
@@ -272,6 +276,10 @@ void finish_ip_ties_host(int64_t n, int64_t k, int64_t kk, const float *raw_v, c
 void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
                        int64_t *I_out);
 
+DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
+void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,
+                              const float *d_xq, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,
+                              const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st);
 void launch_flat_direct_ex(const FlatGeom &g, const DirectPlan &p, int metric, bool formula, const float *d_xq,
                            const float *d_xn, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,
                            const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot, hipStream_t st);

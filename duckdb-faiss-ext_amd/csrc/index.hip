@@ -253,9 +253,9 @@ SelectorDev SelectorHolder::upload(const mvs_search_params *p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------ Flat
 
 FlatIndex::FlatIndex(int d_, int metric_) : IndexBase(MVS_KIND_FLAT, d_, metric_) {
-	if (metric != METRIC_L2 && metric != METRIC_IP)
-		throw_faiss("mvs::FlatIndex::FlatIndex", __FILE__,
-		            "metric type %d is not implemented on the MI355X path (INNER_PRODUCT and L2 are)", metric);
+	if (metric != METRIC_L2 && metric != METRIC_IP && !metric_is_extra(metric))
+		throw_faiss("mvs::FlatIndex::FlatIndex", __FILE__, "metric type %d is not a faiss::MetricType the glue registers",
+		            metric);
 	geom = flat_geom_for(d);
 	is_trained = true;
 }
@@ -411,6 +411,47 @@ __global__ void fill_results_kernel(float *D, long long *I, long long total, flo
 	}
 }
 
+// L1, Linf, Lp, Canberra, BrayCurtis, JensenShannon, Jaccard [IndexFlat::search -> knn_extra_metrics,
+// faiss/utils/extra_distances.cpp]: per-pair value on the LDS-staged flat_direct kernel (one instance per metric), the
+// partial lists merged under the metric's order.  A cold path of the reference (the glue only forwards the metric
+// name); no MFMA shape exists for these, the kernel is VALU-bound (|x-y| chains) or transcendental-bound (Lp, JS).
+// Jaccard is a similarity: CMin lists like inner product, exact ties at the k-th score resolved in the pure order.
+void FlatIndex::search_extra_metric(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
+                                    const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
+	if (k > flat_direct_max_k())
+		throw_faiss("mvs::FlatIndex::search", __FILE__, "k = %lld exceeds the supported maximum %lld", (long long)k,
+		            (long long)flat_direct_max_k());
+	const int om = metric_order(metric);
+	const int64_t *out_map = raw_rows ? nullptr : d_idmap;
+	const int64_t out_off = raw_rows ? 0 : label_offset;
+	FlatDB db {vecs, norms, ntotal};
+	memset(&kinfo, 0, sizeof kinfo);
+	DirectPlan p = plan_flat_direct_extra(geom, nq, ntotal, k);
+	const int64_t nq_pad = (nq + p.qgroup - 1) / p.qgroup * p.qgroup;
+	ws_q.reserve((size_t)nq_pad * geom.dp * sizeof(float));
+	MVS_HIP(hipMemsetAsync(ws_q.p, 0, (size_t)nq_pad * geom.dp * sizeof(float), st));
+	launch_pad_rows(d_x, nq, d, (float *)ws_q.p, geom.dp, st);
+	ws_pd.reserve((size_t)p.nsplit * nq * k * sizeof(float));
+	ws_pi.reserve((size_t)p.nsplit * nq * k * sizeof(int32_t));
+	SelectorDev sel = selector.upload(params, st);
+	begin_kernel_timing(st);
+	ws_gthr.reserve((size_t)nq * ((k + 15) / 16 * 16) * sizeof(unsigned) + 64);
+	launch_init_slots((unsigned *)ws_gthr.p, nq, k, om, st);
+	launch_flat_direct_extra(geom, p, metric, metric_arg, d, (const float *)ws_q.p, nq, db, k, sel, d_idmap,
+	                         (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gthr.p, st);
+	end_kernel_timing(st);
+	launch_merge_partials(om, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, p.nsplit, nq, k, out_map, out_off, d_D,
+	                      d_I, st, k, nullptr);
+	snprintf(kinfo.name, sizeof kinfo.name, "flat_direct_kernel (metric %d)", metric);
+	const int64_t ngroups = (nq + p.qgroup - 1) / p.qgroup;
+	kinfo.flops = 3.0 * (double)nq * (double)ntotal * d;
+	kinfo.bytes = (double)ngroups * (double)ntotal * geom.dp * 4.0;
+	kinfo.grid = p.grid;
+	kinfo.block = 256;
+	kinfo.lds_bytes = (int)p.lds_bytes;
+	kinfo.nsplit = p.nsplit;
+}
+
 // IndexFlat::search dispatch (faiss/IndexFlat.cpp, utils/distances.cpp):
 //   sel || nq < 20 -> per-pair arithmetic (flat_direct.hip); else BLAS-branch arithmetic (flat_mfma.hip)
 void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
@@ -423,7 +464,7 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	if (ntotal == 0) {
 		const long long total = (long long)nq * k;
 		hipLaunchKernelGGL(fill_results_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_D,
-		                   (long long *)d_I, total, metric == METRIC_L2 ? FLT_MAX : -FLT_MAX);
+		                   (long long *)d_I, total, metric_order(metric) == METRIC_L2 ? FLT_MAX : -FLT_MAX);
 		return;
 	}
 	// the scratch buffers below are shared by all searches of this index: order this call after the last one
@@ -431,6 +472,10 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 		stream_wait(st, last_search_stream);
 	last_search_stream = st;
 	have_last_search = true;
+	if (metric_is_extra(metric)) {
+		search_extra_metric(nq, d_x, k, d_D, d_I, params, d_idmap, st);
+		return;
+	}
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
 	const int64_t mfma_kmax = flat_mfma_max_k(geom);
 	// Inner product, exact ties at the k-th score: FAISS's CMin heap keeps/evicts equal scores by
@@ -965,6 +1010,7 @@ void FlatIndex::to_host(HostIndex &out) {
 	out.kind = MVS_KIND_FLAT;
 	out.d = d;
 	out.metric = metric;
+	out.metric_arg = metric_arg;
 	out.ntotal = ntotal;
 	out.is_trained = true;
 	out.rows.resize((size_t)ntotal * d);
@@ -990,6 +1036,7 @@ IndexBase *index_from_host(const HostIndex &h, int device) {
 	switch (h.kind) {
 	case MVS_KIND_FLAT: {
 		auto *f = new FlatIndex(h.d, h.metric);
+		f->metric_arg = h.metric_arg;
 		try {
 			if (h.ntotal > 0)
 				f->add(h.ntotal, h.rows.data());
@@ -1450,6 +1497,11 @@ int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value) {
 
 namespace mvs {
 bool FlatIndex::set_option(const char *key, int64_t v) {
+	if (!strcmp(key, "metric_arg_bits")) { // faiss::Index::metric_arg as IEEE-754 bits (the option channel carries integers)
+		const uint32_t b = (uint32_t)v;
+		memcpy(&metric_arg, &b, 4);
+		return true;
+	}
 	if (!strcmp(key, "force_staged")) { // per-pair path on the LDS-staged flat_direct kernel instead of the scan kernel
 		force_staged = v != 0;
 		return true;

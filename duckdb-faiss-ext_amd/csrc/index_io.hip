@@ -87,7 +87,7 @@ void write_header(Writer &w, const HostIndex &h) {
 	w.one(trained);
 	w.one(metric);
 	if (metric > 1) {
-		const float metric_arg = 0.f;
+		const float metric_arg = h.metric_arg;
 		w.one(metric_arg);
 	}
 }
@@ -104,6 +104,7 @@ void read_header(Reader &r, HostIndex &h) {
 	if (metric > 1) {
 		float metric_arg;
 		r.one(metric_arg);
+		h.metric_arg = metric_arg;
 	}
 	h.d = d;
 	h.ntotal = ntotal;

@@ -63,7 +63,7 @@ void resolve_ip_tie_host(int64_t k, const float *raw_v, const int64_t *raw_g, co
 // search step, after the exchange).  Per query: collect the nshard*k candidates, order them, keep k.
 void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
                        int64_t *I_out) {
-	const bool is_l2 = metric == METRIC_L2;
+	const bool is_l2 = metric_order(metric) == METRIC_L2;
 	const float neutral = is_l2 ? FLT_MAX : -FLT_MAX;
 	parallel_queries(n, [&](int64_t q0, int64_t q1) {
 		std::vector<Cand> c((size_t)nshard * k);
@@ -128,7 +128,7 @@ void finish_ip_ties_host(int64_t n, int64_t k, int64_t kk, const float *raw_v, c
 // first kk of the union in the pure order (val[nq][kk], gnum[nq][kk]; unfilled slots gnum = -1).
 void merge_raw_lists_host(int metric, int64_t nq, int64_t kk, int nshard, const float *const *D, const int64_t *const *G,
                           float *val, int64_t *gnum) {
-	const bool is_l2 = metric == METRIC_L2;
+	const bool is_l2 = metric_order(metric) == METRIC_L2;
 	const float neutral = is_l2 ? FLT_MAX : -FLT_MAX;
 	parallel_queries(nq, [&](int64_t q0, int64_t q1) {
 		std::vector<Cand> c((size_t)nshard * kk);

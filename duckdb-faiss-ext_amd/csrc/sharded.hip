@@ -537,9 +537,9 @@ public:
 			kinfo = shards[0]->kinfo;
 			return;
 		}
-		const bool is_l2 = metric == METRIC_L2;
+		const bool is_l2 = metric_order(metric) == METRIC_L2;
 		// inner product: one extra candidate per list detects an exact tie at the k-th score (FlatIndex::search_flat)
-		const bool tie_detect = !is_l2 && mode == ROWS_FLAT && ntotal > k && k + 1 <= 256;
+		const bool tie_detect = metric == METRIC_IP && mode == ROWS_FLAT && ntotal > k && k + 1 <= 256;
 		const int64_t kk = tie_detect ? k + 1 : k;
 		const size_t cells = (size_t)nq * kk;
 		std::vector<const float *> hD(G);

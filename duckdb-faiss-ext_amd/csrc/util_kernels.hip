@@ -360,7 +360,7 @@ void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, i
 	size_t lds = ((size_t)nsplit * k + k) * 8;
 	if (lds > 160 * 1024)
 		throw_faiss(__func__, __FILE__, "merge: nsplit*k = %lld too large", (long long)nsplit * k);
-	if (metric == METRIC_L2) {
+	if (metric_order(metric) == METRIC_L2) {
 		auto kern = merge_partials_kernel<true>;
 		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, nsplit, (long long)nq, (int)k,
@@ -484,7 +484,7 @@ void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, cons
 	const size_t lds = ((size_t)(pchunk + 1) * k + k) * 8;
 	if (lds > 150 * 1024)
 		throw_faiss(__func__, __FILE__, "IVF merge: k = %lld too large", (long long)k);
-	if (metric == METRIC_L2) {
+	if (metric_order(metric) == METRIC_L2) {
 		auto kern = merge_items_kernel<true>;
 		ensure_dynamic_lds((const void *)kern, (size_t)(lds));
 		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, d_pd, d_pi, d_slots, nprobe, pchunk, (int)k, group,

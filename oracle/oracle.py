@@ -290,5 +290,10 @@ def num_threads():
     return lib().orc_num_threads()
 
 
+def set_metric_arg(v):
+    """Index::metric_arg (Lp exponent) for the metrics beyond L2 / inner product"""
+    lib().orc_set_metric_arg(C.c_float(v))
+
+
 def set_num_threads(n):
     lib().orc_set_num_threads(n)

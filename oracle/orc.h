@@ -95,6 +95,8 @@ int orc_hnsw_set_graph(orc_index *ix, int64_t n, const float *x, const int *leve
                        const int32_t *neighbors, int32_t entry_point, int max_level); /* search-only afterwards */
 
 /* stand-alone kernels (used by tests and the cpu_baseline leg) */
+/* Index::metric_arg of the Lp metric (FAISS default 0; the glue never sets it) -- process-wide in the oracle */
+void orc_set_metric_arg(float v);
 void orc_norms(const float *x, int64_t n, int d, float *out);
 int orc_flat_search(int metric, int d, int64_t nb, const float *xb, int64_t nq, const float *xq, int64_t k,
                     float *D, int64_t *I, const orc_params *params, const int64_t *id_map);

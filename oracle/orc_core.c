@@ -269,11 +269,87 @@ int orc_sel_member(const orc_sel *s, int64_t id) {
 	return sel_member(s, id);
 }
 
+/* ---- the other metrics the glue registers (src/faiss_extension.cpp:58-68): faiss/utils/extra_distances-inl.h
+ * VectorDistance<mt>::operator() -- plain sequential float loops (reference implementations of fvec_L1 / fvec_Linf;
+ * FAISS's SIMD builds may reassociate L1) -- and knn_extra_metrics: one heap per query, strict insert, rows ascending;
+ * CMax (smallest kept) except for the similarity metric Jaccard (is_similarity_metric: CMin, like inner product). */
+static inline int metric_is_similarity(int metric) {
+	return metric == ORC_METRIC_INNER_PRODUCT || metric == 23 /* Jaccard */;
+}
+static float extra_distance(int metric, float metric_arg, const float *x, const float *y, int d) {
+	switch (metric) {
+	case 2: { /* L1 */
+		float res = 0;
+		for (int i = 0; i < d; i++) {
+			const float tmp = x[i] - y[i];
+			res += fabsf(tmp);
+		}
+		return res;
+	}
+	case 3: { /* Linf */
+		float res = 0;
+		for (int i = 0; i < d; i++)
+			res = fmaxf(res, fabsf(x[i] - y[i]));
+		return res;
+	}
+	case 4: { /* Lp */
+		float accu = 0;
+		for (int i = 0; i < d; i++) {
+			const float diff = fabsf(x[i] - y[i]);
+			accu += powf(diff, metric_arg);
+		}
+		return accu;
+	}
+	case 20: { /* Canberra */
+		float accu = 0;
+		for (int i = 0; i < d; i++) {
+			const float xi = x[i], yi = y[i];
+			accu += fabsf(xi - yi) / (fabsf(xi) + fabsf(yi));
+		}
+		return accu;
+	}
+	case 21: { /* BrayCurtis */
+		float num = 0, den = 0;
+		for (int i = 0; i < d; i++) {
+			const float xi = x[i], yi = y[i];
+			num += fabsf(xi - yi);
+			den += fabsf(xi + yi);
+		}
+		return num / den;
+	}
+	case 22: { /* JensenShannon */
+		float accu = 0;
+		for (int i = 0; i < d; i++) {
+			const float xi = x[i], yi = y[i];
+			const float mi = 0.5f * (xi + yi);
+			const float kl1 = -xi * logf(mi / xi);
+			const float kl2 = -yi * logf(mi / yi);
+			accu += kl1 + kl2;
+		}
+		return 0.5f * accu;
+	}
+	case 23: { /* Jaccard (defined for non-negative vectors) */
+		float num = 0, den = 0;
+		for (int i = 0; i < d; i++) {
+			num += fminf(x[i], y[i]);
+			den += fmaxf(x[i], y[i]);
+		}
+		return num / den;
+	}
+	}
+	return NAN;
+}
+static float g_metric_arg = 0.f; /* Index::metric_arg: the glue never sets it (FAISS default 0) */
+void orc_set_metric_arg(float v) {
+	g_metric_arg = v;
+}
+
 /* ------------------------------------------------------------- flat search */
 /* per-pair path: utils/distances.cpp exhaustive_{L2sqr,inner_product}_seq */
 static void search_pair(int metric, int d, int64_t nb, const float *xb, int64_t nq, const float *xq, int64_t k, float *D,
                         int64_t *I, const sel_t *sel, const int64_t *id_map) {
-	const int is_max = metric == ORC_METRIC_L2;
+	const int is_max = !metric_is_similarity(metric);
+	const float marg = g_metric_arg;
 #pragma omp parallel for schedule(dynamic, 1)
 	for (int64_t i = 0; i < nq; i++) {
 		const float *x = xq + i * d;
@@ -283,7 +359,9 @@ static void search_pair(int metric, int d, int64_t nb, const float *xb, int64_t 
 		for (int64_t j = 0; j < nb; j++) {
 			if (sel && sel->kind && !sel_member(sel, id_map ? id_map[j] : j))
 				continue;
-			float dis = is_max ? l2_chain(x, xb + j * d, d) : ip_chain(x, xb + j * d, d);
+			float dis = metric == ORC_METRIC_L2              ? l2_chain(x, xb + j * d, d)
+			            : metric == ORC_METRIC_INNER_PRODUCT ? ip_chain(x, xb + j * d, d)
+			                                                 : extra_distance(metric, marg, x, xb + j * d, d);
 			if (accepts(is_max, hv[0], dis))
 				heap_replace_top(k, hv, hi, is_max, dis, j);
 		}
@@ -432,12 +510,15 @@ static int flat_search_impl(int metric, int d, int64_t nb, const float *xb, int6
                             float *D, int64_t *I, const orc_params *params, const int64_t *id_map) {
 	if (k <= 0)
 		return fail("virtual void faiss::IndexFlat::search(...) const", "faiss/IndexFlat.cpp", "Error: 'k > 0' failed");
-	if (metric != ORC_METRIC_L2 && metric != ORC_METRIC_INNER_PRODUCT)
+	const int extra = metric != ORC_METRIC_L2 && metric != ORC_METRIC_INNER_PRODUCT;
+	if (extra && !(metric == 2 || metric == 3 || metric == 4 || (metric >= 20 && metric <= 23)))
 		return fail("orc_flat_search", "faiss/IndexFlat.cpp", "metric type %d not supported by the oracle", metric);
 	sel_t sel;
 	if (sel_build(&sel, params))
 		return 1;
 	int path = params ? params->force_path : ORC_PATH_AUTO;
+	if (extra) /* IndexFlat::search -> knn_extra_metrics: always per pair */
+		path = ORC_PATH_PAIR;
 	if (path == ORC_PATH_AUTO)
 		path = (sel.kind || nq < 20) ? ORC_PATH_PAIR : ORC_PATH_BLAS;
 	if (path == ORC_PATH_BLAS && sel.kind) {
