@@ -200,6 +200,17 @@ void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, cons
                          SelectorDev sel, const int64_t *d_idmap, float *d_pd, int32_t *d_pi, unsigned *d_gslot,
                          hipStream_t st);
 void launch_init_slots(unsigned *d_gslot, int64_t nq, int64_t k, int metric, hipStream_t st);
+// IVF with k beyond the k-list kernels (csrc/ivf_select.hip): all distances of the probed lists + segmented sort
+struct IvfSelectPair {
+	long long out; // first key slot of this (query, list) pair
+	int row_begin, len, q, pad;
+};
+size_t ivf_select_temp_bytes(int64_t total, int64_t nseg);
+void launch_ivf_select(int metric, const float *d_xq, int dp, const float *d_rows, const int64_t *d_rowids,
+                       const IvfSelectPair *d_pairs, int npairs, const int *d_seg, int64_t nseg, int64_t total, int64_t k,
+                       SelectorDev sel, const int64_t *d_idmap_sel, const int64_t *d_idmap_out, unsigned long long *keys_a,
+                       unsigned long long *keys_b, void *d_temp, size_t temp_bytes, float *d_D, int64_t *d_I,
+                       hipStream_t st);
 // csrc/ivf_scan.hip: list-major scan without LDS staging (dp multiple of 16); same item / partial-list formats
 bool ivf_scan_supported(int dp, int64_t k);
 size_t ivf_scan_lds_bytes(int64_t k);

@@ -584,8 +584,6 @@ public:
 			throw_faiss("virtual void faiss::IndexIVF::search(...) const", "faiss/IndexIVF.cpp", "Error: 'k > 0' failed");
 		if (nq <= 0)
 			return;
-		if (k > 256)
-			throw_faiss("mvs::IVFFlatIndex::search", __FILE__, "k = %lld exceeds the supported maximum 256", (long long)k);
 		int64_t np = params && params->nprobe > 0 ? params->nprobe : nprobe;
 		np = std::min(np, nlist); // IndexIVF::search: nprobe = min(nlist, params->nprobe)
 		if (np <= 0)
@@ -615,6 +613,10 @@ public:
 		// L2: it evaluates ||x||^2 + ||y||^2 - 2<x,y> (the Flat BLAS-branch arithmetic) instead of the scanner's
 		// sum (x-y)^2, i.e. the same neighbours up to rounding-level near-ties -> opt-in (option ivf_mfma = 1); the
 		// default keeps the scanner's arithmetic bit for bit.
+		if (k > 256 || force_select) { // beyond the k-list kernels: all distances + segmented sort (csrc/ivf_select.hip)
+			select_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
+			return;
+		}
 		const bool want_mfma = mfma_mode == 1 || (mfma_mode < 0 && metric == METRIC_IP);
 		const bool small = nq * np < (int64_t)1 << 26;
 		// L2, default: the MFMA scan as a prefilter + exact scanner-arithmetic re-scoring with a per-query proof
@@ -962,6 +964,79 @@ public:
 		kinfo.lds_bytes = (int)(fast_scan ? ivf_scan_lds_bytes(k) : direct_items_lds_bytes(dp, k));
 		kinfo.nsplit = (int)np;
 	}
+	// k > 256 (the harness's post-filter runs ask for ~2 000 rows, go/main_test.go:17-45): every probed list's distances as
+	// sortable keys, one segmented sort per chunk of queries, first k decoded.  The batch is cut so that one chunk holds at
+	// most 2^26 candidates (1 GiB of keys, double-buffered).
+	void select_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                   const int64_t *d_idmap, hipStream_t st, int64_t np) {
+		std::vector<int64_t> cl((size_t)nq * np);
+		MVS_HIP(hipMemcpyAsync(cl.data(), ws_cI.p, cl.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+		MVS_HIP(hipStreamSynchronize(stream));
+		ws_q.reserve((size_t)nq * dp * sizeof(float));
+		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
+		SelectorDev sel = selector.upload(params, stream);
+		memset(&kinfo, 0, sizeof kinfo);
+		const int64_t budget = (int64_t)1 << 26;
+		std::vector<IvfSelectPair> pairs;
+		std::vector<int> seg;
+		double bytes = 0, cands = 0;
+		int64_t q0 = 0;
+		while (q0 < nq) {
+			pairs.clear();
+			seg.assign(1, 0);
+			int64_t total = 0, q1 = q0;
+			for (; q1 < nq; ++q1) {
+				int64_t tq = 0;
+				for (int64_t p = 0; p < np; ++p) {
+					const int64_t l = cl[(size_t)(q1 * np + p)];
+					if (l >= 0)
+						tq += list_off[(size_t)l + 1] - list_off[(size_t)l];
+				}
+				if (q1 > q0 && total + tq > budget)
+					break;
+				if (tq >= ((int64_t)1 << 31) - total)
+					throw_faiss("mvs::IVFFlatIndex::search", __FILE__, "one query probes %lld rows: too many for k = %lld",
+					            (long long)tq, (long long)k);
+				for (int64_t p = 0; p < np; ++p) {
+					const int64_t l = cl[(size_t)(q1 * np + p)];
+					if (l < 0)
+						continue; // fewer than nprobe centroids
+					const int64_t len = list_off[(size_t)l + 1] - list_off[(size_t)l];
+					if (len > 0)
+						pairs.push_back({total, (int)list_off[(size_t)l], (int)len, (int)q1, 0});
+					total += len;
+				}
+				seg.push_back((int)total);
+			}
+			const int64_t nseg = q1 - q0;
+			ws_items.reserve(std::max<size_t>(pairs.size() * sizeof(IvfSelectPair), 16));
+			ws_slots.reserve(seg.size() * sizeof(int));
+			ws_pd.reserve(std::max<size_t>((size_t)total * 8, 16));
+			ws_pi.reserve(std::max<size_t>((size_t)total * 8, 16));
+			const size_t temp = total > 0 ? ivf_select_temp_bytes(total, nseg) : 0;
+			ws_xi.reserve(std::max<size_t>(temp, 16));
+			if (!pairs.empty())
+				MVS_HIP(hipMemcpyAsync(ws_items.p, pairs.data(), pairs.size() * sizeof(IvfSelectPair), hipMemcpyHostToDevice,
+				                       stream));
+			MVS_HIP(hipMemcpyAsync(ws_slots.p, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+			begin_kernel_timing(stream);
+			launch_ivf_select(metric, (const float *)ws_q.p, dp, (const float *)codes.p, (const int64_t *)rowids.p,
+			                  (const IvfSelectPair *)ws_items.p, (int)pairs.size(), (const int *)ws_slots.p, nseg, total, k, sel,
+			                  d_idmap, raw_ids ? nullptr : d_idmap, (unsigned long long *)ws_pd.p,
+			                  (unsigned long long *)ws_pi.p, ws_xi.p, temp, d_D + q0 * k, d_I + q0 * k, stream);
+			end_kernel_timing(stream);
+			MVS_HIP(hipStreamSynchronize(stream)); // the pageable staging vectors are reused by the next chunk
+			bytes += (double)total * dp * 4.0;
+			cands += (double)total;
+			q0 = q1;
+		}
+		stream_wait(st, stream);
+		snprintf(kinfo.name, sizeof kinfo.name, "ivf_select (all distances + segmented sort)");
+		kinfo.bytes = bytes + cands * 8.0 * 2.0 * 9.0; // list rows once per probing query + 8 radix passes + the key write
+		kinfo.flops = cands * d * (metric == METRIC_L2 ? 3.0 : 2.0);
+		kinfo.block = 256;
+		kinfo.nsplit = (int)np;
+	}
 	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                   hipStream_t st) override {
 		search_mapped(nq, d_x, k, d_D, d_I, params, nullptr, st);
@@ -1047,6 +1122,10 @@ public:
 			raw_ids = v != 0;
 			return true;
 		}
+		if (!strcmp(key, "ivf_select")) { // 1 = the all-distances + segmented-sort path for any k (default: k > 256 only)
+			force_select = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_fast_scan")) { // 0 = the LDS-staged flat_direct item kernel
 			use_fast_scan = v != 0;
 			return true;
@@ -1054,6 +1133,7 @@ public:
 		return quantizer->set_option(key, v);
 	}
 	bool use_fast_scan = true;
+	bool force_select = false;
 	bool raw_ids = false;
 	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always, 2 = L2 prefilter + exact re-scoring
 

@@ -335,3 +335,51 @@ def test_l2_prefilter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, nprobe, 
         assert ok.sum() >= 1
         assert np.array_equal(D1, D0) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32)), (sel and sel[0])
         assert np.array_equal(I1[ok], I0[ok]) and np.array_equal(I1[ok], Io[ok]), (sel and sel[0])
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("idmap", [False, True])
+def test_ivf_large_k_select_path(mf, metric, idmap):
+    """k beyond the k-list kernels (> 256) -- the harness's post-filter runs ask an IVF index for ~2 000 rows
+    (go/main_test.go:17-45): all distances of the probed lists + one segmented sort (csrc/ivf_select.hip)"""
+    d, nlist, n = 48, 32, 40000
+    xb = _clustered(n, d, 31)
+    xq = _clustered(70, d, 32)
+    desc = f"IDMap,IVF{nlist},Flat" if idmap else f"IVF{nlist},Flat"
+    o = orc.Index(d, desc, metric)
+    o.train(xb)
+    g = mf.index_factory(d, desc, metric)
+    g.ivf_set_centroids(o.ivf_centroids())
+    ids = (np.random.RandomState(1).permutation(3 * n)[:n] + 11).astype(np.int64)
+    for a in (o, g):
+        a.add_with_ids(xb, ids) if idmap else a.add(xb)
+    all_ids = ids if idmap else np.arange(n)
+    keep = all_ids[np.random.RandomState(2).rand(n) < 0.3].astype(np.int64)
+    for k, nprobe, q, sel in [(300, 4, xq, None), (1000, 8, xq[:1], None), (2048, 8, xq, None), (2048, 1, xq[:5], None),
+                              (1500, 8, xq[:20], ("batch", keep)), (3000, 32, xq[:3], None)]:
+        Do, Io = o.search(q, k, nprobe=nprobe, sel=sel)
+        D, I = g.search(q, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"].startswith("ivf_select")
+        # same candidates, same per-pair arithmetic: the sorted distance lists agree bit for bit (incl. the -1 / neutral
+        # padding when fewer than k rows were probed); labels wherever a distance is unique within its list
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), (k, nprobe)
+        assert np.array_equal(I == -1, Io == -1)
+        uniq = np.ones_like(I, dtype=bool)
+        uniq[:, 1:] &= Do[:, 1:] != Do[:, :-1]
+        uniq[:, :-1] &= Do[:, 1:] != Do[:, :-1]
+        assert uniq[Io >= 0].mean() > 0.9
+        assert np.array_equal(I[uniq], Io[uniq]), (k, nprobe)
+
+
+def test_ivf_select_path_equals_k_list_path_at_small_k(mf):
+    d, nlist, n = 64, 16, 20000
+    xb = _clustered(n, d, 41)
+    xq = _clustered(100, d, 42)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+    g.train(xb)
+    g.add(xb)
+    D0, I0 = g.search(xq, 50, nprobe=4)
+    g.set_option("ivf_select", 1)
+    D1, I1 = g.search(xq, 50, nprobe=4)
+    assert g.last_kernel_info()["name"].startswith("ivf_select")
+    assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
