@@ -1,0 +1,724 @@
+// csrc/flat_collect.hip -- bf16 COARSE FILTER for the brute-force search: one bf16 MFMA per 16 dimensions, candidates by a
+// proven bound, exact f32 re-scoring.
+//
+// Same place in the path as flat_mfma.hip / flat_bf16.hip (IndexFlat::search, /root/reference/src/faiss_extension.cpp:631,
+// BLAS branch of knn_L2sqr / knn_inner_product) and the same results bit for bit.  flat_bf16.hip keeps the k' best
+// APPROXIMATE values (three bf16 products per element pair, error ~2^-18) and proves afterwards that they contain the
+// exact top-k.  This file turns the argument round so that ONE product per pair (error ~2^-8) is enough:
+//
+//   coarse value      s(q, row) = 2 <qh, yh> - ||y||^2   (L2; the larger the nearer)      or  <qh, yh>   (inner product)
+//                     qh, yh = bf16(q), bf16(y); f32 accumulation on the matrix pipe
+//   error bound       |s - s_exact| <= E(q) for every row, E from ||q||, max ||y|| and d (collect_bounds_kernel)
+//   running bound     B(q) = min over kk row classes (row id mod kk) of the best s seen in the class, shared by all
+//                     workgroups through the threshold slots of DESIGN.md 3.3: kk DISTINCT rows have s >= B, so the exact
+//                     kk-th best value is no worse than B - E
+//   candidates        every row with s >= B - 2E at the time it is scanned (B only rises) -- a row of the exact top-kk has
+//                     s >= (its exact value) - E >= (B - E) - E.  No row of the result can be missed; ties at the k-th value
+//                     are ALL candidates, so FAISS's (value, id) order is applied to exact values only.
+//   re-scoring        the candidates (a few hundred per query out of 10^7 rows) are grouped by query (one radix sort),
+//                     re-computed with the oracle's arithmetic (k-ordered fmaf chain over the f32 row, (xn + yn) - 2 ip,
+//                     clamp) and the kk best per query go through the normal merge: labels AND distances are those of
+//                     flat_mfma.hip / oracle/orc_core.c search_blas.
+//
+// No k-lists in the scan kernel at all: the epilogue is one fma + half a max3 per value and a compare per 16 values; the
+// rare path appends (query, row) to a workgroup queue in LDS that is flushed to a global stream with one atomic per
+// ~1000 candidates.  Queries whose bound is not finite (NaN / Inf / overflowing norms) are re-run on the exact kernel.
+//
+// Geometry (CDNA4): workgroup = 4 waves x 128 queries (four 32-query B tiles resident as bf16: 128 VGPRs), database tiles
+// of 32 rows x 256 B (bf16, 16-byte chunks XOR-swizzled by row) double-buffered by LDS-DMA, one ds_read_b128 per 4 MFMAs;
+// two workgroups per CU, i.e. 1024 queries share every byte a CU pulls out of L2.
+#include "flat_fused.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace mvs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) float lds_f32c;
+typedef __attribute__((address_space(1))) const float glb_f32c;
+
+constexpr int CL_QBLOCK = 512;  // queries per workgroup
+constexpr int CL_BN = 32;       // rows per staged tile
+constexpr int CL_QCAP = 2048;   // candidate queue of a workgroup (entries of 8 bytes)
+constexpr int CL_FLUSH_EVERY = 4; // tiles between two looks at the queue
+
+struct CollectArgs {
+	const void *qf;            // query fragments (bf16), [qblk32][ch][lane] x 16 bytes
+	const unsigned short *yb;  // bf16 rows [n + 64][dp]
+	const float *yn;           // squared row norms (f32, padded by 64)
+	const float *e2;           // [nq] 2E(q) (NaN: the query is not served here)
+	unsigned *gslot;           // [nq][slot_stride] class slots: keys of the best s per row class (smaller key = better)
+	unsigned long long *stream; // candidates (q << 32 | row)
+	unsigned long long *stream_cnt; // [0] entries appended
+	long long stream_cap;
+	int slot_stride, nclass;
+	long long n, row_first, split_rows;
+	int nq, nqb, nsplit, xcd_map;
+};
+
+__device__ __forceinline__ unsigned skey(float s) { // "larger s is better" as a smaller-is-better key
+	return ~f2key(s);
+}
+__device__ __forceinline__ float skey2f(unsigned k) {
+	return key2f(~k);
+}
+
+// ---- storage: rows as bf16 (round to nearest even) -------------------------------------------------------------------
+__global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp,
+                                       int interleaved, unsigned short *__restrict__ dst, const float *__restrict__ norms,
+                                       unsigned *__restrict__ max_norm_bits) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int g8 = dp / 8;
+	if (i >= nrows * g8)
+		return;
+	const long long r = row0 + i / g8;
+	const int c8 = (int)(i % g8);
+	const float4 s0 = *(const float4 *)(src + (size_t)r * dp + c8 * 8);
+	const float4 s1 = *(const float4 *)(src + (size_t)r * dp + c8 * 8 + 4);
+	float v[8];
+	if (!interleaved) {
+		v[0] = s0.x, v[1] = s0.y, v[2] = s0.z, v[3] = s0.w, v[4] = s1.x, v[5] = s1.y, v[6] = s1.z, v[7] = s1.w;
+	} else if ((r >> 4) & 1) { // stored [k1,k3,k0,k2] (FlatGeom::pair_interleaved)
+		v[0] = s0.z, v[1] = s0.x, v[2] = s0.w, v[3] = s0.y, v[4] = s1.z, v[5] = s1.x, v[6] = s1.w, v[7] = s1.y;
+	} else { // stored [k0,k2,k1,k3]
+		v[0] = s0.x, v[1] = s0.z, v[2] = s0.y, v[3] = s0.w, v[4] = s1.x, v[5] = s1.z, v[6] = s1.y, v[7] = s1.w;
+	}
+	bf16x8 hi;
+#pragma unroll
+	for (int e = 0; e < 8; ++e)
+		hi[e] = (__bf16)v[e];
+	*(bf16x8 *)(dst + (size_t)r * dp + c8 * 8) = hi;
+	if (c8 == 0) {
+		const unsigned b = __float_as_uint(norms[r]);
+		if (b > *max_norm_bits)
+			atomicMax(max_norm_bits, b);
+	}
+}
+void launch_rows_to_bf16_hi(const FlatGeom &g, const float *d_vecs, int64_t row0, int64_t nrows, unsigned short *d_bf,
+                            const float *d_norms, unsigned *d_max_norm_bits, hipStream_t st) {
+	if (nrows <= 0)
+		return;
+	const long long total = (long long)nrows * (g.dp / 8);
+	hipLaunchKernelGGL(rows_to_bf16_hi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_vecs,
+	                   (long long)row0, (long long)nrows, g.dp, g.pair_interleaved ? 1 : 0, d_bf, d_norms, d_max_norm_bits);
+	MVS_HIP(hipGetLastError());
+}
+
+// queries -> B fragments: qf[(qblk32 * KCH + ch) * 64 + lane] = 8 bf16 of query qblk32*32 + (lane & 31), dims ch*16 +
+// 8*(lane >> 5) + 0..7 (v_mfma_f32_32x32x16_bf16 B operand: lane l holds B[k = 8(l>>5) + j][col l & 31])
+__global__ void collect_pack_queries_kernel(const float *__restrict__ x, long long nq, int d, int kch,
+                                            bf16x8 *__restrict__ qf, long long total) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one (qblk32, ch, lane)
+	if (i >= total)
+		return;
+	const int lane = (int)(i & 63);
+	const long long t = i >> 6;
+	const int ch = (int)(t % kch);
+	const long long qblk32 = t / kch;
+	const long long q = qblk32 * 32 + (lane & 31);
+	bf16x8 hi;
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		const int kk = ch * 16 + 8 * (lane >> 5) + e;
+		hi[e] = (__bf16)((q < nq && kk < d) ? x[q * d + kk] : 0.f);
+	}
+	qf[i] = hi;
+}
+size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq) {
+	const int64_t nblk32 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 32);
+	return (size_t)nblk32 * (g.dp / 16) * 64 * 16;
+}
+void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, void *d_qf, hipStream_t st) {
+	const int64_t nblk32 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 32);
+	const long long total = (long long)nblk32 * (g.dp / 16) * 64;
+	hipLaunchKernelGGL(collect_pack_queries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_x,
+	                   (long long)nq, g.d, g.dp / 16, (bf16x8 *)d_qf, total);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- error bound ---------------------------------------------------------------------------------------------------
+// u = 2^-24, S = ||q|| ||y||_max >= sum |q_i y_i| (Cauchy-Schwarz; both norms inflated by 1e-4 for their own rounding).
+//   bf16 rounding of both operands: |q_i y_i - qh_i yh_i| <= (2 * 2^-9 + 2^-18) |q_i y_i|            -> (2^-8 + 2^-18) S
+//   bf16 MFMA accumulation (d / 16 instructions, undocumented internal rounding modelled as 4 ulp-units of the magnitudes,
+//   with a 1.25 safety factor as in flat_bf16.hip prefilter_cerr):                                      -> 1.25 (d/16) 4u (1 + 2^-7) S
+//   => |a - <q,y>| <= ea
+//   L2:  s = fl(2a - yn): one rounding, |.| <= u (2 (S + ea) + yn_max);  the exact value the oracle reports is
+//        D = max(0, fl(fl(xn + yn) - 2 chain)), chain = d sequential fmas: |D - (xn + yn - 2<q,y>)| <= 2 d u S + 4u (xn + yn_max)
+//        in "s" units (s_exact = xn - D): E = 2 ea + u (2 (S + ea) + yn_max) + 2 d u S + 4u (xn + yn_max)
+//   IP:  s = a, the oracle reports the chain: E = ea + d u S
+//   e2 = 2 E (1 + 2^-10) + the rounding of (B - e2) itself.  Anything non-finite -> NaN (the query goes to the exact kernel).
+template <bool IS_L2>
+__global__ void collect_bounds_kernel(const float *__restrict__ x, const float *__restrict__ qn, long long nq, int d,
+                                      const unsigned *__restrict__ max_norm_bits, float *__restrict__ e2,
+                                      int *__restrict__ fail_cnt, int *__restrict__ fail_q) {
+	const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nq)
+		return;
+	float xn;
+	if (IS_L2) {
+		xn = qn[q];
+	} else {
+		xn = 0.f;
+		for (int t = 0; t < d; ++t)
+			xn = fmaf(x[q * d + t], x[q * d + t], xn);
+	}
+	const float yn = __uint_as_float(*max_norm_bits);
+	const double u = 5.9604644775390625e-08;
+	const double S = sqrt((double)xn * 1.0001) * sqrt((double)yn * 1.0001);
+	const double ea = (0.00390625 + 3.814697265625e-06) * S + 1.25 * ((double)d / 16.0) * 4.0 * u * (1.0 + 0.0078125) * S;
+	double E;
+	if (IS_L2)
+		E = 2.0 * ea + u * (2.0 * (S + ea) + yn) + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn);
+	else
+		E = ea + (double)d * u * S;
+	float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn) + 1e-30);
+	const bool ok = isfinite(xn) && isfinite(yn) && isfinite(r) && r < 1e30f;
+	if (!ok) {
+		r = __uint_as_float(0x7fc00000u);
+		fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
+	}
+	e2[q] = r;
+}
+void launch_collect_bounds(int metric, const float *d_x, const float *d_qn, int64_t nq, int d,
+                           const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	const dim3 grid((unsigned)((nq + 255) / 256));
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(collect_bounds_kernel<true>, grid, dim3(256), 0, st, d_x, d_qn, (long long)nq, d, d_max_norm_bits,
+		                   d_e2, d_fail_cnt, d_fail_q);
+	else
+		hipLaunchKernelGGL(collect_bounds_kernel<false>, grid, dim3(256), 0, st, d_x, d_qn, (long long)nq, d, d_max_norm_bits,
+		                   d_e2, d_fail_cnt, d_fail_q);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- the scan kernel ---------------------------------------------------------------------------------------------------
+// COLLECT = false: bound estimation only (publish to the slots, append nothing) -- the pre-pass over the first rows
+template <int KCH, bool IS_L2, bool COLLECT>
+__global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const CollectArgs a) {
+	constexpr int DP = KCH * 16;
+	constexpr int PITCH = DP * 2;             // bytes per row (256 at d = 128)
+	constexpr int C = PITCH / 16;             // 16-byte chunks per row
+	constexpr int TILE_BYTES = CL_BN * PITCH; // 8 KB at d = 128
+	constexpr int NDMA = TILE_BYTES / 1024;   // LDS-DMA instructions per tile (1 KB per wave-instruction)
+	constexpr int DMA_PER_WAVE = NDMA / 4;
+	static_assert(C == 16 && NDMA % 4 == 0 && DMA_PER_WAVE <= KCH, "d = 128 geometry");
+
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	char *tbuf = (char *)smem;                                  // [2][TILE_BYTES]
+	float *nbuf = (float *)(tbuf + 2 * TILE_BYTES);             // [2][64] squared row norms
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
+	unsigned *qctl = (unsigned *)(qbuf + CL_QCAP);              // [0] queue fill, [2..3] flush base
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int h = lane >> 5, c = lane & 31;
+	int split, qb;
+	if (a.xcd_map) {
+		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+		split = (idx / a.nqb) * 8 + xcd;
+		qb = idx % a.nqb;
+	} else {
+		split = blockIdx.x / a.nqb;
+		qb = blockIdx.x % a.nqb;
+	}
+	const long long r_begin = a.row_first + (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + CL_BN - 1) / CL_BN) : 0;
+	if (tid == 0)
+		qctl[0] = 0u;
+
+	// the lane's four queries (one per 32-query B tile of the wave)
+	const int q0 = qb * CL_QBLOCK + wave * 128 + c;
+	float e2q[4], cq[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		const int q = q0 + 32 * t;
+		e2q[t] = q < a.nq ? a.e2[q] : __uint_as_float(0x7fc00000u);
+		cq[t] = e2q[t] != e2q[t] ? e2q[t] : -INFINITY; // NaN: nothing ever passes; else no bound yet: everything does
+	}
+
+	// B fragments, resident: [query tile][k-chunk]
+	bf16x8 bq[4][KCH];
+	{
+		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			const size_t qblk32 = (size_t)qb * (CL_QBLOCK / 32) + wave * 4 + t;
+#pragma unroll
+			for (int ch = 0; ch < KCH; ++ch)
+				bq[t][ch] = qsrc[(qblk32 * KCH + ch) * 64 + lane];
+		}
+	}
+
+	// LDS-DMA staging.  Instruction `inst` of a tile fills LDS bytes [1024 inst, +1024); lane l owns 16-byte slot S = 64 inst
+	// + l = (row r = S / 16, position p = S % 16) and fetches the row's chunk p ^ (r & 15).  Wave w issues inst = 4 i + w:
+	// r = 16 i + 4 w + l / 16, so r & 15 does not depend on i and the per-lane byte offset is loop invariant; every issue is
+	// ONE instruction with a uniform base.  Tiles past the end are fetched as well (64 rows of zero padding): no clamp, no
+	// branch around a vector-memory instruction ("what round 2 learnt").
+	unsigned dma_off;
+	{
+		const int rr = 4 * wave + (lane >> 4);
+		dma_off = (unsigned)(rr * PITCH + (((lane & 15) ^ rr) * 16));
+	}
+	auto dma_issue = [&](int u, int i) {
+		const char *base = (const char *)a.yb + ((size_t)(r_begin + (long long)u * CL_BN) + (size_t)i * 16) * PITCH; // uniform
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + dma_off),
+		                                 (lds_f32c *)(smem + ((u & 1) * TILE_BYTES + (i * 4 + wave) * 1024) / 4), 16, 0, 0);
+	};
+	auto dma_norms = [&](int u) {
+		if (IS_L2) {
+			const float *base = a.yn + (r_begin + (long long)u * CL_BN); // uniform
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + lane),
+			                                 (lds_f32c *)(smem + (2 * TILE_BYTES) / 4 + (u & 1) * 64), 4, 0, 0);
+		}
+	};
+	if (ntiles > 0) {
+#pragma unroll
+		for (int i = 0; i < DMA_PER_WAVE; ++i)
+			dma_issue(0, i);
+		dma_norms(0);
+	}
+	__syncthreads();
+
+	// read address of (row c, chunk 2 ch + h): c * PITCH + (((2 ch + h) ^ (c & 15)) * 16) = rbase ^ (ch * 32)
+	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)((((c & 15) ^ h) & 15) * 16);
+	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
+	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+
+	for (int u = 0; u < ntiles; ++u) {
+		// Shared bound: every `period` tiles the wave fetches the class slots of its 4 x 32 queries and WAITS for them (one L2
+		// round trip; the accumulators are dead here, so the 32 transient registers are free).
+		const int period = u < 16 ? 2 : (u < 256 ? 8 : 32);
+		if ((u % period) == 0) {
+			SlotRegs sr[4];
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const int q = q0 + 32 * t;
+				slots_prefetch(sr[t], a.gslot + (size_t)(q < a.nq ? q : 0) * a.slot_stride, 0, h);
+			}
+#pragma unroll
+			for (int t = 0; t < 4; ++t)
+				asm volatile("" : "+v"(sr[t].w[0]), "+v"(sr[t].w[1]), "+v"(sr[t].w[2]), "+v"(sr[t].w[3]));
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const float B = skey2f(slots_reduce(sr[t])); // -FLT_MAX while a class is still empty
+				const float v = B - e2q[t];                   // NaN stays NaN
+				cq[t] = v;
+			}
+		}
+		f32x16 acc[4];
+#pragma unroll
+		for (int t = 0; t < 4; ++t)
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+				acc[t][r] = 0.f;
+		const char *Abase = tbuf + (u & 1) * TILE_BYTES;
+		bf16x8 af[2];
+		auto read_a = [&](int ch, int slot) {
+			unsigned rb = rbase;
+			MVS_OPAQUE_VGPR(rb);
+			af[slot] = *(const bf16x8 *)(Abase + (rb ^ (unsigned)(ch * 32)));
+		};
+		read_a(0, 0);
+#pragma unroll
+		for (int ch = 0; ch < KCH; ++ch) {
+			__builtin_amdgcn_sched_barrier(0);
+			if (ch + 1 < KCH)
+				read_a(ch + 1, (ch + 1) & 1);
+			if (ch < DMA_PER_WAVE)
+				dma_issue(u + 1, ch);
+			if (ch == 0)
+				dma_norms(u + 1);
+			__builtin_amdgcn_sched_barrier(0);
+			const bf16x8 ah = af[ch & 1];
+#pragma unroll
+			for (int t = 0; t < 4; ++t)
+				acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[t][ch], acc[t], 0, 0, 0);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		const long long row0 = r_begin + (long long)u * CL_BN;
+		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN);
+		// Row norms of this tile, LDS -> registers by hand (hipcc would put s_waitcnt vmcnt(0) in front of a compiled LDS read
+		// while the next tile's LDS-DMA is in flight)
+		float4 yn4[4];
+		if (IS_L2) {
+			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * h));
+			asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+			             "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(yn4[0]), "=&v"(yn4[1]), "=&v"(yn4[2]), "=&v"(yn4[3])
+			             : "v"(nb_lds)
+			             : "memory");
+		}
+		// fast path: s = 2a - yn (one fma), best of the 16 rows against the query's bound
+		bool any[4];
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			float m = -INFINITY;
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const float yv[4] = {yn4[g].x, yn4[g].y, yn4[g].z, yn4[g].w};
+				float s[4];
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					s[e] = IS_L2 ? fmaf(2.0f, acc[t][4 * g + e], -yv[e]) : acc[t][4 * g + e];
+					acc[t][4 * g + e] = s[e];
+				}
+				m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(s[0], s[1]), __builtin_fmaxf(s[2], s[3])));
+			}
+			any[t] = m >= cq[t]; // NaN on either side: false
+		}
+		if (__builtin_amdgcn_ballot_w64(any[0] || any[1] || any[2] || any[3]) != 0ull) {
+			// rare path: every lane walks its own passing rows
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				if (__builtin_amdgcn_ballot_w64(any[t]) == 0ull)
+					continue;
+				unsigned m = 0u;
+				if (any[t]) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+						if (rl < nvalid && acc[t][r] >= cq[t])
+							m |= 1u << r;
+					}
+				}
+				const int q = q0 + 32 * t;
+				while (m != 0u) {
+					const int j = __builtin_ctz(m);
+					m &= m - 1u;
+					float sel[16];
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						sel[i] = acc[t][i];
+#pragma unroll
+					for (int w = 16, bit = 0; w > 1; w >>= 1, ++bit)
+#pragma unroll
+						for (int i = 0; i < w / 2; ++i)
+							sel[i] = ((j >> bit) & 1) ? sel[2 * i + 1] : sel[2 * i];
+					const float sv = sel[0];
+					const unsigned row = (unsigned)(row0 + (j & 3) + 8 * (j >> 2) + 4 * h);
+					typedef __attribute__((address_space(1))) unsigned *GU;
+					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * a.slot_stride) + row % (unsigned)a.nclass, skey(sv),
+					                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (COLLECT) {
+						unsigned pos;
+						const unsigned one = 1u;
+						asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+						const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+						if (pos < (unsigned)CL_QCAP) {
+							asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+						} else { // a burst beyond the queue (cold start): straight to the stream
+							const unsigned long long gp = atomicAdd(a.stream_cnt, 1ull);
+							if ((long long)gp < a.stream_cap)
+								a.stream[gp] = ent;
+						}
+					}
+				}
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
+		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
+			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue)
+			const unsigned fill = qctl[0];
+			__syncthreads(); // everybody has read the same fill before anyone appends again
+			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
+			if (n >= (unsigned)CL_QCAP / 2 || (u == ntiles - 1 && n > 0)) {
+				if (tid == 0) {
+					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+					qctl[0] = 0u;
+				}
+				__syncthreads();
+				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
+				for (unsigned i = tid; i < n; i += 256)
+					if ((long long)(base + i) < a.stream_cap)
+						a.stream[base + i] = qbuf[i];
+				__syncthreads();
+			}
+		}
+	}
+}
+
+static size_t collect_lds_bytes(const FlatGeom &g) {
+	return (size_t)2 * CL_BN * g.dp * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + 64;
+}
+
+bool collect_supported(const FlatGeom &g) {
+	return g.nch == 1 && g.dp == 128;
+}
+
+int g_cl_nsplit = 0;      // option cl_nsplit: row splits of the main scan (0 = planned)
+int g_cl_seed_rows = 32768; // option cl_seed_rows: rows of the bound-estimation pre-pass
+
+int flat_mfma_slot_stride(int64_t k);
+__global__ void init_gslot_kernel(unsigned *g, long long total, int stride, int k, int is_l2);
+
+template <bool COLLECT>
+static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, int64_t row_first, int64_t row_end,
+                                 int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out) {
+	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
+	const int64_t ntiles = (row_end - row_first + CL_BN - 1) / CL_BN;
+	const int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(nsplit_want, ntiles));
+	a.xcd_map = (nsplit >= 8 && nsplit % 8 == 0) ? 1 : 0;
+	a.row_first = row_first;
+	a.n = row_end;
+	a.split_rows = (ntiles + nsplit - 1) / nsplit * CL_BN;
+	a.nqb = nqb;
+	a.nsplit = (int)nsplit;
+	const int grid = nqb * (int)nsplit;
+	const size_t lds = collect_lds_bytes(g);
+	if (metric == METRIC_L2) {
+		auto kern = flat_bf16_collect_kernel<8, true, COLLECT>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+	} else {
+		auto kern = flat_bf16_collect_kernel<8, false, COLLECT>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+	}
+	MVS_HIP(hipGetLastError());
+	if (grid_out)
+		*grid_out = grid;
+	if (nsplit_out)
+		*nsplit_out = (int)nsplit;
+}
+
+int collect_slot_stride(int kk) {
+	return flat_mfma_slot_stride(kk);
+}
+
+// slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
+void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
+                            int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
+                            unsigned long long *d_stream_cnt, hipStream_t st) {
+	const int stride = flat_mfma_slot_stride(kk);
+	const long long gtotal = (long long)nq * stride;
+	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, kk,
+	                   0 /* larger s is better */);
+	MVS_HIP(hipMemsetAsync(d_stream_cnt, 0, 16, st));
+	CollectArgs a;
+	memset(&a, 0, sizeof a);
+	a.qf = d_qf;
+	a.yb = d_rows;
+	a.yn = d_norms;
+	a.e2 = d_e2;
+	a.gslot = d_gslot;
+	a.slot_stride = stride;
+	a.nclass = kk;
+	a.nq = (int)nq;
+	const int64_t seed = std::min<int64_t>(n, g_cl_seed_rows);
+	if (seed > 0 && seed < n)
+		launch_collect_range<false>(g, metric, a, 0, seed, 8, nq, st, nullptr, nullptr);
+}
+
+// the main scan: every row, candidates into the stream
+void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
+                         int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
+                         unsigned long long *d_stream_cnt, int64_t stream_cap, hipStream_t st, int *grid_out, int *nsplit_out,
+                         int *lds_out) {
+	CollectArgs a;
+	memset(&a, 0, sizeof a);
+	a.qf = d_qf;
+	a.yb = d_rows;
+	a.yn = d_norms;
+	a.e2 = d_e2;
+	a.gslot = d_gslot;
+	a.slot_stride = flat_mfma_slot_stride(kk);
+	a.nclass = kk;
+	a.nq = (int)nq;
+	a.stream = d_stream;
+	a.stream_cnt = d_stream_cnt;
+	a.stream_cap = stream_cap;
+	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
+	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 8192 rows per split
+	int64_t nsplit = g_cl_nsplit;
+	if (nsplit <= 0) {
+		const int64_t max_split = std::max<int64_t>(1, n / 8192);
+		nsplit = 1;
+		double best = -1;
+		for (int64_t s = 8; s <= std::min<int64_t>(max_split, 512); s += 8) {
+			const int64_t w = s * nqb, rounds = (w + 511) / 512;
+			double eff = (double)w / (double)(rounds * 512);
+			if (rounds < 2)
+				eff -= 0.05;
+			eff -= 1e-4 * s;
+			if (eff > best) {
+				best = eff;
+				nsplit = s;
+			}
+		}
+		if (max_split < 8)
+			nsplit = max_split;
+	}
+	launch_collect_range<true>(g, metric, a, 0, n, nsplit, nq, st, grid_out, nsplit_out);
+	if (lds_out)
+		*lds_out = (int)collect_lds_bytes(g);
+}
+
+// ---- candidates -> exact values ----------------------------------------------------------------------------------------
+// segment of every query in the stream sorted by query
+__global__ void collect_segments_kernel(const unsigned long long *__restrict__ sorted, long long n, int *__restrict__ seg_b,
+                                        int *__restrict__ seg_e) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const unsigned q = (unsigned)(sorted[i] >> 32);
+	if (i == 0 || (unsigned)(sorted[i - 1] >> 32) != q)
+		seg_b[q] = (int)i;
+	if (i == n - 1 || (unsigned)(sorted[i + 1] >> 32) != q)
+		seg_e[q] = (int)(i + 1);
+}
+
+// Thread <-> candidate: the oracle's value of the row (ip = fmaf chain in k order over the ORIGINAL f32 row; L2:
+// max(0, (xn + yn) - 2 ip)) replaces the query number in the entry: (order-preserving value key << 32) | row.  FAISS
+// inserts a value only if it beats the neutral element (strict compare; NaN never): such entries become EMPTY.
+// One wave per 64 candidates.  The rows are staged through LDS with coalesced loads (half a wave per 512-byte row; a
+// thread streaming its own row thrashes the 32 KB L1: 6.2 ms for 10^7 candidates), row pitch DP + 4 floats so that the 16
+// lanes of a ds_read_b128 phase hit distinct banks; then lane <-> candidate runs the k-ordered chain.
+template <bool IS_L2, int DP>
+__global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *__restrict__ sorted, long long ncand,
+                                                          const float *__restrict__ x, int d,
+                                                          const float *__restrict__ vecs, int interleaved,
+                                                          const float *__restrict__ norms, const float *__restrict__ qn) {
+	constexpr int PITCH = DP + 4, CPR = DP / 4; // floats per LDS row, float4 chunks per row
+	constexpr int RPI = 64 / CPR;               // rows per load instruction (2 at DP = 128)
+	__shared__ __attribute__((aligned(16))) float rows[64 * PITCH];
+	const int lane = threadIdx.x;
+	const long long i0 = (long long)blockIdx.x * 64;
+	const long long i = i0 + lane;
+	const unsigned long long ent = i < ncand ? sorted[i] : 0ull;
+	const unsigned row = (unsigned)ent;
+	const long long q = (long long)(ent >> 32);
+	const int sub = lane / CPR, ch = lane % CPR;
+#pragma unroll 8
+	for (int r = 0; r < 64; r += RPI) {
+		const unsigned rr = (unsigned)__shfl((int)row, r + sub);
+		const float4 v = *(const float4 *)(vecs + (size_t)rr * DP + ch * 4);
+		*(float4 *)(rows + (r + sub) * PITCH + ch * 4) = v;
+	}
+	__syncthreads();
+	if (i >= ncand)
+		return;
+	const float *y = rows + lane * PITCH;
+	const float *xq = x + q * d;
+	const bool odd = interleaved && ((row >> 4) & 1);
+	float ip = 0.f;
+	for (int g4 = 0; g4 < d; g4 += 4) {
+		const float4 s = *(const float4 *)(y + g4);
+		float v0, v1, v2, v3;
+		if (!interleaved)
+			v0 = s.x, v1 = s.y, v2 = s.z, v3 = s.w;
+		else if (odd)
+			v0 = s.z, v1 = s.x, v2 = s.w, v3 = s.y;
+		else
+			v0 = s.x, v1 = s.z, v2 = s.y, v3 = s.w;
+		ip = fmaf(xq[g4], v0, ip);
+		if (g4 + 1 < d)
+			ip = fmaf(xq[g4 + 1], v1, ip);
+		if (g4 + 2 < d)
+			ip = fmaf(xq[g4 + 2], v2, ip);
+		if (g4 + 3 < d)
+			ip = fmaf(xq[g4 + 3], v3, ip);
+	}
+	float ex;
+	bool ok;
+	if (IS_L2) {
+		ex = fmaf(-2.0f, ip, qn[q] + norms[row]);
+		ex = ex < 0.f ? 0.f : ex; // FAISS: if (dis < 0) dis = 0
+		ok = ex < FLT_MAX;
+	} else {
+		ex = ip;
+		ok = ex > -FLT_MAX;
+	}
+	sorted[i] = ok ? (((unsigned long long)bkey<IS_L2>(ex) << 32) | row) : ~0ull;
+}
+
+// One wave per query: the kk best keys (value, row) of its segment, kept as a sorted list spread over the lanes (lane i =
+// entry i): insert position by ballot, shift by one lane.
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long long *__restrict__ keys,
+                                                           const int *__restrict__ seg_b, const int *__restrict__ seg_e,
+                                                           int kk, float *__restrict__ pd1, int *__restrict__ pi1) {
+	const long long q = blockIdx.x;
+	const int lane = threadIdx.x;
+	const int b = seg_b[q], e = seg_e[q];
+	const unsigned long long EMPTY = ~0ull;
+	unsigned long long mine = EMPTY; // entry `lane` of the sorted list
+	unsigned long long worst = EMPTY;
+	for (int base = b; base < e; base += 64) {
+		const int i = base + lane;
+		const unsigned long long key = i < e ? keys[i] : EMPTY;
+		unsigned long long pend = __builtin_amdgcn_ballot_w64(key < worst);
+		while (pend != 0ull) {
+			const int L = __builtin_ctzll(pend);
+			pend &= pend - 1ull;
+			const unsigned long long ck = __shfl(key, L);
+			if (ck >= worst)
+				continue;
+			const int pos = __popcll(__builtin_amdgcn_ballot_w64(lane < kk && mine <= ck));
+			const unsigned long long up = __shfl_up(mine, 1);
+			if (lane == pos)
+				mine = ck;
+			else if (lane > pos && lane < kk)
+				mine = up;
+			worst = __shfl(mine, kk - 1);
+		}
+	}
+	if (lane < kk) {
+		const bool have = mine != EMPTY;
+		pd1[q * kk + lane] = have ? bkey2f<IS_L2>((unsigned)(mine >> 32)) : (IS_L2 ? FLT_MAX : -FLT_MAX);
+		pi1[q * kk + lane] = have ? (int)(unsigned)mine : -1;
+	}
+}
+
+size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq) {
+	size_t bytes = 0;
+	int qbits = 1;
+	while (((int64_t)1 << qbits) < nq)
+		++qbits;
+	MVS_HIP(rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+	                                 (size_t)ncand, 32, 32 + qbits, (hipStream_t) nullptr));
+	return bytes;
+}
+
+// stream (ncand entries) -> per query the kk best exact candidates: pd1 / pi1 [nq][kk] (value, row), best first
+void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
+                            size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
+                            const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
+                            hipStream_t st) {
+	if (nq <= 0)
+		return;
+	int qbits = 1;
+	while (((int64_t)1 << qbits) < nq)
+		++qbits;
+	MVS_HIP(hipMemsetAsync(d_seg, 0, (size_t)2 * nq * sizeof(int), st));
+	if (ncand > 0) {
+		MVS_HIP(rocprim::radix_sort_keys(d_temp, temp_bytes, d_stream, d_sorted, (size_t)ncand, 32, 32 + qbits, st));
+		hipLaunchKernelGGL(collect_segments_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, d_sorted,
+		                   (long long)ncand, d_seg, d_seg + nq);
+	}
+	if (metric == METRIC_L2) {
+		if (ncand > 0)
+			hipLaunchKernelGGL((collect_exact_kernel<true, 128>), dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
+			                   (long long)ncand, d_x, g.d, d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
+		hipLaunchKernelGGL(collect_select_kernel<true>, dim3((unsigned)nq), dim3(64), 0, st, d_sorted, d_seg, d_seg + nq, kk,
+		                   d_pd1, d_pi1);
+	} else {
+		if (ncand > 0)
+			hipLaunchKernelGGL((collect_exact_kernel<false, 128>), dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
+			                   (long long)ncand, d_x, g.d, d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
+		hipLaunchKernelGGL(collect_select_kernel<false>, dim3((unsigned)nq), dim3(64), 0, st, d_sorted, d_seg, d_seg + nq, kk,
+		                   d_pd1, d_pi1);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
+} // namespace mvs

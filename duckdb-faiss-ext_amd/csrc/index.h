@@ -171,7 +171,15 @@ public:
 	int64_t pf_queries_total = 0, pf_fallback_total = 0;
 	float pf_max_rel_err = 0.f; // largest observed |approx - exact| / (||x|| ||y||) among re-scored candidates
 	DevBuf ws_pfq, ws_cand, ws_ex, ws_fail, ws_fb;
+	// bf16 coarse filter (csrc/flat_collect.hip): rows as bf16 only, candidate stream, per-query bounds
+	unsigned short *vecs_h1 = nullptr; // [h1_cap + 64][dp]
+	int64_t h1_cap = 0, h1_rows = 0;
+	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0;
+	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg;
 	void ensure_bf16_rows(hipStream_t st);
+	void ensure_h1_rows(hipStream_t st);
+	bool collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1, int32_t **pi1, int *fail_cnt, int *fail_q,
+	                        hipStream_t st);
 	void drop_bf16_rows();
 	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
 	                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
@@ -276,6 +284,28 @@ void finish_ip_ties_host(int64_t n, int64_t k, int64_t kk, const float *raw_v, c
 void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
                        int64_t *I_out);
 
+// csrc/flat_collect.hip
+bool collect_supported(const FlatGeom &g);
+void launch_rows_to_bf16_hi(const FlatGeom &g, const float *d_vecs, int64_t row0, int64_t nrows, unsigned short *d_bf,
+                            const float *d_norms, unsigned *d_max_norm_bits, hipStream_t st);
+size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
+void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, void *d_qf, hipStream_t st);
+void launch_collect_bounds(int metric, const float *d_x, const float *d_qn, int64_t nq, int d,
+                           const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st);
+int collect_slot_stride(int kk);
+void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
+                            int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
+                            unsigned long long *d_stream_cnt, hipStream_t st);
+void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
+                         int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
+                         unsigned long long *d_stream_cnt, int64_t stream_cap, hipStream_t st, int *grid_out, int *nsplit_out,
+                         int *lds_out);
+size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq);
+void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
+                            size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
+                            const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
+                            hipStream_t st);
+extern int g_cl_nsplit, g_cl_seed_rows;
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,
                               const float *d_xq, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,

@@ -280,6 +280,10 @@ void FlatIndex::drop_bf16_rows() {
 		(void)hipFree(vecs_bf);
 	vecs_bf = nullptr;
 	bf_cap = bf_rows = 0;
+	if (vecs_h1)
+		(void)hipFree(vecs_h1);
+	vecs_h1 = nullptr;
+	h1_cap = h1_rows = 0;
 	if (d_max_norm_bits)
 		(void)hipFree(d_max_norm_bits);
 	d_max_norm_bits = nullptr;
@@ -314,6 +318,92 @@ void FlatIndex::ensure_bf16_rows(hipStream_t st) {
 	bf_rows = ntotal;
 }
 
+// the same for the coarse filter's store: rows as bf16 only (csrc/flat_collect.hip)
+void FlatIndex::ensure_h1_rows(hipStream_t st) {
+	if (h1_rows == ntotal && vecs_h1)
+		return;
+	if (ntotal > h1_cap || !vecs_h1) {
+		unsigned short *nb = nullptr;
+		const int64_t nc = std::max<int64_t>(cap, ntotal);
+		const size_t nbytes = ((size_t)nc + 64) * geom.dp * sizeof(unsigned short); // + 64 rows: unclamped prefetch
+		MVS_HIP(hipMalloc((void **)&nb, nbytes));
+		MVS_HIP(hipMemsetAsync(nb, 0, nbytes, st));
+		if (h1_rows > 0)
+			MVS_HIP(hipMemcpyAsync(nb, vecs_h1, (size_t)h1_rows * geom.dp * sizeof(unsigned short), hipMemcpyDeviceToDevice, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		if (vecs_h1)
+			MVS_HIP(hipFree(vecs_h1));
+		vecs_h1 = nb;
+		h1_cap = nc;
+	}
+	if (!d_max_norm_bits) {
+		MVS_HIP(hipMalloc((void **)&d_max_norm_bits, 64));
+		MVS_HIP(hipMemsetAsync(d_max_norm_bits, 0, 64, st));
+	}
+	launch_rows_to_bf16_hi(geom, vecs, h1_rows, ntotal - h1_rows, vecs_h1, norms, d_max_norm_bits, st);
+	h1_rows = ntotal;
+}
+
+// Coarse filter front half (csrc/flat_collect.hip): bound estimation pre-pass, the scan, candidates grouped by query and
+// re-scored exactly.  Leaves the kk best exact candidates per query in *pd1 / *pi1 ([nq][kk]) and the queries whose bound
+// is not finite in fail_q.  false: the candidate stream overflowed (the caller uses the bf16x3 path instead).
+bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1_out, int32_t **pi1_out, int *fail_cnt,
+                                   int *fail_q, hipStream_t st) {
+	ensure_h1_rows(st);
+	ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
+	ws_qn.reserve((size_t)nq * sizeof(float));
+	launch_collect_pack_queries(geom, d_x, nq, ws_pfq.p, st);
+	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
+	ws_e2.reserve((size_t)nq * sizeof(float));
+	launch_collect_bounds(metric, d_x, (const float *)ws_qn.p, nq, d, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
+	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk) * sizeof(unsigned) + 64);
+	const int64_t cap_entries = std::max<int64_t>(nq * 4096, (int64_t)1 << 20);
+	const size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+	ws_stream.reserve(256 + 2 * half);
+	unsigned long long *cnt = (unsigned long long *)ws_stream.p;
+	unsigned long long *stream = (unsigned long long *)((char *)ws_stream.p + 256);
+	unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, norms, ntotal, nq, kk, (const float *)ws_e2.p,
+	                       (unsigned *)ws_gthr.p, cnt, st);
+	int grid = 0, nsplit = 0, lds = 0;
+	begin_kernel_timing(st);
+	launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, norms, ntotal, nq, kk, (const float *)ws_e2.p,
+	                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, st, &grid, &nsplit, &lds);
+	end_kernel_timing(st);
+	if (!h_flag_count)
+		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
+	MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	MVS_HIP(hipStreamSynchronize(st));
+	unsigned long long ncand_u;
+	memcpy(&ncand_u, h_flag_count + 10, sizeof ncand_u);
+	const int64_t ncand = (int64_t)ncand_u;
+	cl_last_candidates = ncand;
+	if (ncand > cap_entries) {
+		++cl_overflows;
+		return false;
+	}
+	cl_queries_total += nq;
+	cl_candidates_total += ncand;
+	const size_t temp = ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0;
+	ws_sorttmp.reserve(std::max<size_t>(temp, 16));
+	ws_seg.reserve((size_t)2 * nq * sizeof(int));
+	const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
+	ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
+	float *pd1 = (float *)ws_ex.p;
+	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
+	launch_collect_rescore(metric, stream, sorted, ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
+	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, st);
+	*pd1_out = pd1;
+	*pi1_out = pi1;
+	snprintf(kinfo.name, sizeof kinfo.name, "flat_bf16_collect_kernel");
+	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
+	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * kk * 12.0;
+	kinfo.grid = grid;
+	kinfo.block = 256;
+	kinfo.lds_bytes = lds;
+	kinfo.nsplit = nsplit;
+	return true;
+}
 
 void FlatIndex::reset() {
 	ntotal = 0;
@@ -635,9 +725,25 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		return false;
 	if (ntotal < 4096 || ntotal <= kk)
 		return false;
+	ws_fail.reserve(64 + (size_t)nq * sizeof(int));
+	int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
+	MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+	float *pd1 = nullptr;
+	int32_t *pi1 = nullptr;
+	int kp = 0;
+	bool collected = false;
+	// Coarse filter (one bf16 product per pair, candidates by a proven bound): mode 2 forces it, auto prefers it where
+	// its kernel exists (d = 128 geometry, lists of <= 16); on a stream overflow the bf16x3 path below takes the batch
+	if (prefilter_mode == 2 && collect_supported(geom) && kk <= 16) {
+		kp = (int)kk;
+		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, st);
+		if (!collected)
+			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+	}
+	if (!collected) {
 	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the
 	// headline (N = 10M, d = 128) 5 spare ranks leave ~3 of 10 000 queries to the exact kernel, 8 spare ranks ~none
-	int kp = (int)(kk + std::max<int64_t>(pf_margin, kk / 2));
+	kp = (int)(kk + std::max<int64_t>(pf_margin, kk / 2));
 	if (kp > 16 && kk + 5 <= 16)
 		kp = 16; // one 16-slot window of shared thresholds: a second window costs more than the lost margin (measured: 61 vs 70 ms)
 	ensure_bf16_rows(st);
@@ -662,13 +768,18 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	// exact values of the candidates + the per-query proof
 	const size_t ex_bytes = ((size_t)nq * kp * sizeof(float) + 255) & ~(size_t)255;
 	ws_ex.reserve(ex_bytes + (size_t)nq * kp * sizeof(int32_t));
-	float *pd1 = (float *)ws_ex.p;
-	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
-	ws_fail.reserve(64 + (size_t)nq * sizeof(int));
-	int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
-	MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+	pd1 = (float *)ws_ex.p;
+	pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
 	launch_rescore_verify(metric, ca, ci, nq, kp, (int)kk, d_x, geom, vecs, norms, (const float *)ws_qn.p, d_max_norm_bits,
 	                      pd1, pi1, fail_cnt, fail_q, d_max_norm_bits + 4, st);
+	snprintf(kinfo.name, sizeof kinfo.name, "flat_bf16x3_kernel");
+	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
+	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * k_user * 12.0;
+	kinfo.grid = p.grid;
+	kinfo.block = 256;
+	kinfo.lds_bytes = (int)p.lds_bytes;
+	kinfo.nsplit = p.nsplit;
+	}
 	// the exact candidates through the normal merge: FAISS order, labels, inner-product tie flags
 	launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp);
 	if (!h_flag_count)
@@ -687,13 +798,6 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	pf_queries_total += nq;
 	pf_fallback_total += nf;
 	memcpy(&pf_max_rel_err, h_flag_count + 9, sizeof(float));
-	snprintf(kinfo.name, sizeof kinfo.name, "flat_bf16x3_kernel");
-	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
-	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * k_user * 12.0;
-	kinfo.grid = p.grid;
-	kinfo.block = 256;
-	kinfo.lds_bytes = (int)p.lds_bytes;
-	kinfo.nsplit = p.nsplit;
 	if (nf > 0) {
 		// queries whose candidate set could not be proven complete: the exact kernel decides (results overwrite theirs)
 		const mvs_kernel_info keep = kinfo;
@@ -821,7 +925,7 @@ void FlatIndex::to_device(int new_device) {
 	if (norms)
 		MVS_HIP(hipFree(norms));
 	drop_bf16_rows();
-	for (DevBuf *b : {&ws_flag, &ws_tie, &ws_pfq, &ws_cand, &ws_ex, &ws_fail, &ws_fb})
+	for (DevBuf *b : {&ws_flag, &ws_tie, &ws_pfq, &ws_cand, &ws_ex, &ws_fail, &ws_fb, &ws_e2, &ws_stream, &ws_sorttmp, &ws_seg})
 		b->release();
 	ws_q.release();
 	ws_qn.release();
@@ -1381,6 +1485,22 @@ int mvs_index_prefilter_stats(mvs_index *ix, int64_t *queries, int64_t *fallback
 		*err_bound = prefilter_cerr(f->d);
 	MVS_API_END
 }
+int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates, int64_t *overflows) {
+	MVS_API_BEGIN
+	IndexBase *p = sharded_inner_view(ix->impl);
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	if (p->kind != MVS_KIND_FLAT)
+		throw_faiss("mvs_index_collect_stats", __FILE__, "not a Flat index");
+	auto *f = static_cast<FlatIndex *>(p);
+	if (queries)
+		*queries = f->cl_queries_total;
+	if (candidates)
+		*candidates = f->cl_candidates_total;
+	if (overflows)
+		*overflows = f->cl_overflows;
+	MVS_API_END
+}
 int mvs_index_shard_info(const mvs_index *ix, int *devices, int max_devices, int64_t *rows_per_shard,
                          int64_t *last_tie_queries) {
 	return sharded_info(ix->impl, devices, max_devices, rows_per_shard, last_tie_queries);
@@ -1508,6 +1628,14 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "prefilter")) { // -1 auto, 0 off (exact f32 kernel only), 1 wherever the bf16x3 kernel supports the shape
 		prefilter_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_nsplit")) { // coarse filter: row splits of the main scan (0 = planned)
+		g_cl_nsplit = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_seed_rows")) { // coarse filter: rows of the bound-estimation pre-pass
+		g_cl_seed_rows = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "pf_sched")) {

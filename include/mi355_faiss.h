@@ -194,6 +194,9 @@ int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value);
  * |approx - exact| / (||x|| ||y||) among re-scored candidates and the bound c(d) the proof uses */
 int mvs_index_prefilter_stats(mvs_index *ix, int64_t *queries, int64_t *fallback_queries, float *max_rel_err,
                               float *err_bound);
+/* bf16 coarse filter of the same search (csrc/flat_collect.hip; option prefilter = 2): queries it served, candidates it
+ * re-scored exactly for them, batches whose candidate stream overflowed (served by the bf16x3 path instead) */
+int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates, int64_t *overflows);
 int mvs_device_count(void);
 const char *mvs_version(void);
 

@@ -1,0 +1,155 @@
+"""bf16 coarse filter + exact f32 re-scoring (csrc/flat_collect.hip, option prefilter = 2) behind IndexFlat::search
+(src/faiss_extension.cpp:631): ONE bf16 product per element pair selects candidates by a proven bound; the answers must
+be those of the exact f32 kernel and of the oracle's BLAS branch BIT FOR BIT -- labels and distances -- on friendly data,
+on duplicate-heavy data (every tied row is a candidate: no fall back needed), on non-finite input (those queries are
+re-run on the exact kernel), for both metrics, with inner-product boundary ties, through IDMap."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+L2, IP = orc.METRIC_L2, orc.METRIC_INNER_PRODUCT
+KERNEL = "flat_bf16_collect_kernel"
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import mi355_faiss
+
+    return mi355_faiss
+
+
+def _pair(mf, d, metric, xb, desc="Flat", ids=None):
+    cl, ex = mf.index_factory(d, desc, metric), mf.index_factory(d, desc, metric)
+    cl.set_option("prefilter", 2)
+    ex.set_option("prefilter", 0)
+    for ix in (cl, ex):
+        for i0 in range(0, len(xb), 1 << 16):
+            if ids is None:
+                ix.add(xb[i0 : i0 + (1 << 16)])
+            else:
+                ix.add_with_ids(xb[i0 : i0 + (1 << 16)], ids[i0 : i0 + (1 << 16)])
+    return cl, ex
+
+
+def _check(cl, ex, xq, k, metric, xb=None, oracle_rows=0, overflow=False):
+    D1, I1 = cl.search(xq, k)
+    # (a batch whose candidate stream overflows is handed to the bf16x3 path)
+    assert cl.last_kernel_info()["name"] in (("flat_bf16x3_kernel", KERNEL) if overflow else (KERNEL,))
+    D0, I0 = ex.search(xq, k)
+    assert ex.last_kernel_info()["name"] == "flat_mfma_kernel"
+    assert np.array_equal(I1, I0), "labels differ from the exact f32 kernel"
+    assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), "distances differ from the exact f32 kernel"
+    if oracle_rows:
+        Do, Io = orc.flat_search(metric, xb, xq[:oracle_rows], k, force_path=orc.PATH_BLAS)
+        assert np.array_equal(I1[:oracle_rows], Io) and np.array_equal(D1[:oracle_rows].view(np.uint32), Do.view(np.uint32))
+    return D1, I1
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 200_000, 700, 10), (100, 99_991, 257, 1), (128, 70_000, 1100, 15), (65, 50_000, 64, 10),
+                                       (128, 33_000, 20, 4)])
+def test_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
+    rs = np.random.RandomState(d + nb)
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    cl, ex = _pair(mf, d, metric, xb)
+    _check(cl, ex, xq, k, metric, xb, oracle_rows=64)
+    st = cl.collect_stats()
+    assert st["queries"] == nq and st["overflows"] == 0 and st["candidates"] >= nq * min(k, nb), st
+    assert cl.prefilter_stats()["fallback_queries"] == 0
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_duplicates_and_ties_need_no_fall_back(mf, metric):
+    """40 distinct vectors repeated 100k times: every row tied at the k-th value is a candidate -- 2 500 copies of each of
+    the nearest vectors, more than the candidate stream holds: the batch overflows and the bf16x3 path (and behind it the
+    exact kernel) serves it.  Mixed data: the tied rows are all candidates and the exact (value, id) order decides."""
+    rs = np.random.RandomState(5)
+    base = rs.rand(40, 128).astype(np.float32)
+    xb = base[rs.randint(0, 40, 100_000)]
+    xq = rs.rand(300, 128).astype(np.float32)
+    cl, ex = _pair(mf, 128, metric, xb)
+    _check(cl, ex, xq, 10, metric, xb, oracle_rows=32, overflow=True)
+    xb2 = rs.rand(120_000, 128).astype(np.float32)
+    xb2[rs.randint(0, 120_000, 30_000)] = xb2[rs.randint(0, 120_000, 30_000)]
+    xq2 = np.concatenate([rs.rand(200, 128).astype(np.float32), xb2[rs.randint(0, 120_000, 200)]])
+    cl, ex = _pair(mf, 128, metric, xb2)
+    _check(cl, ex, xq2, 10, metric, xb2, oracle_rows=400)
+
+
+def test_idmap_and_integer_inner_product_ties(mf):
+    rs = np.random.RandomState(9)
+    xb = rs.randint(-3, 4, size=(80_000, 100)).astype(np.float32)
+    xq = rs.randint(-3, 4, size=(256, 100)).astype(np.float32)
+    ids = (rs.permutation(400_000)[:80_000] + 11).astype(np.int64)
+    cl, ex = _pair(mf, 100, IP, xb, desc="IDMap,Flat", ids=ids)
+    D, I = _check(cl, ex, xq, 10, IP)
+    o = orc.Index(100, "IDMap,Flat", IP)
+    o.add_with_ids(xb, ids)
+    Do, Io = o.search(xq, 10)
+    assert np.array_equal(I, Io) and np.array_equal(D, Do)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_non_finite_and_huge_values(mf, metric):
+    rs = np.random.RandomState(2)
+    xb = rs.rand(60_000, 128).astype(np.float32)
+    xq = rs.rand(128, 128).astype(np.float32)
+    xq[3, 1] = np.nan
+    xq[4] *= 1e19
+    xq[5, 0] = np.inf
+    cl, ex = _pair(mf, 128, metric, xb)
+    D1, I1 = cl.search(xq, 10)
+    assert cl.last_kernel_info()["name"] == KERNEL
+    D0, I0 = ex.search(xq, 10)
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
+    assert 2 <= cl.prefilter_stats()["fallback_queries"] <= 3  # only the queries without a finite bound are re-run
+    xb[100, 5] = np.nan
+    xb[200, 7] = np.inf
+    xb[300] *= 1e18
+    xb[400] *= 1e-20
+    cl, ex = _pair(mf, 128, metric, xb)  # a row norm overflows: no finite bound for anybody, everything is re-run
+    D1, I1 = cl.search(xq, 10)
+    D0, I0 = ex.search(xq, 10)
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
+
+
+def test_large_norm_offset_data(mf):
+    """rows far from the origin: the bound (which scales with the norms) admits many candidates, still exact"""
+    rs = np.random.RandomState(12)
+    xb = (rs.rand(80_000, 128).astype(np.float32) + 3.0)
+    xq = (rs.rand(100, 128).astype(np.float32) + 3.0)
+    cl, ex = _pair(mf, 128, L2, xb)
+    _check(cl, ex, xq, 10, L2, xb, oracle_rows=32, overflow=True)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_collect_fuzz(mf, seed):
+    rs = np.random.RandomState(9000 + seed)
+    d = int(rs.choice([65, 96, 100, 127, 128]))
+    n = int(rs.choice([4096, 5000, 8191, 20000, 33333, 70001]))
+    nq = int(rs.choice([20, 21, 64, 255, 513, 600]))
+    k = int(rs.choice([1, 2, 7, 10, 11, 15]))
+    metric = [L2, IP][rs.randint(2)]
+    idmap = bool(rs.randint(2))
+    scale = float(rs.choice([1.0, 1e-3, 300.0]))
+    xb = ((rs.rand(n, d).astype(np.float32) - (0.5 if rs.randint(2) else 0.0)) * scale).astype(np.float32)
+    xq = ((rs.rand(nq, d).astype(np.float32) - 0.5) * scale).astype(np.float32)
+    if rs.randint(2):
+        xb[rs.randint(0, n, n // 10)] = xb[rs.randint(0, n, n // 10)]
+        xq[: nq // 4] = xb[rs.randint(0, n, nq // 4)]
+    ids = (rs.permutation(3 * n)[:n] + 5).astype(np.int64) if idmap else None
+    desc = "IDMap,Flat" if idmap else "Flat"
+    cl, ex = _pair(mf, d, metric, xb, desc=desc, ids=ids)
+    D1, I1 = cl.search(xq, k)
+    assert cl.last_kernel_info()["name"] == KERNEL
+    D0, I0 = ex.search(xq, k)
+    what = f"seed={seed} d={d} n={n} nq={nq} k={k} metric={metric} idmap={idmap} scale={scale}"
+    assert np.array_equal(I1, I0), what
+    assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), what
+    o = orc.Index(d, desc, metric)
+    o.add_with_ids(xb, ids) if idmap else o.add(xb)
+    Do, Io = o.search(xq, k)
+    assert np.array_equal(I1, Io) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32)), what

@@ -72,7 +72,7 @@ def main():
         gbs = ki["bytes"] / (avg * 1e-3) / 1e9
         extra = ""
         if ki["name"].startswith("flat_bf16"):
-            extra = f"  prefilter={ix.prefilter_stats()}"
+            extra = f"  prefilter={ix.prefilter_stats()} collect={ix.collect_stats()}"
         print(
             f"{ki['name']} opts={args.opt} {args.sweep.split('=')[0]}={sv} n={args.n} nq={args.nq} d={args.d} k={args.k} {args.metric}: "
             f"{avg:.3f} ms/launch  wall {wall:.3f} ms/search  {tf:.2f} TFLOP/s algorithmic  {gbs:.1f} GB/s algorithmic  "
