@@ -6,10 +6,11 @@
 // APPROXIMATE values (three bf16 products per element pair, error ~2^-18) and proves afterwards that they contain the
 // exact top-k.  This file turns the argument round so that ONE product per pair (error ~2^-8) is enough:
 //
-//   coarse value      s(q, row) = 2 <qh, yh> - ||y||^2   (L2; the larger the nearer)      or  <qh, yh>   (inner product)
-//                     qh, yh = bf16(q), bf16(y); f32 accumulation on the matrix pipe
-//   error bound       |s - s_exact| <= E(q) for every row, E from ||q||, max ||y|| and d (collect_bounds_kernel)
-//   running bound     B(q) = min over kk row classes (row id mod kk) of the best s seen in the class, shared by all
+//   coarse value      s(q, row) = 2 <bf(x'), bf(y')> - ||y'||^2  (L2; the larger the nearer)  or  <bf(x'), bf(y')> + <mu, y>
+//                     (inner product); x' = x - mu, y' = y - mu (mu = mean row: the error scales with ||x'|| ||y'||, distances
+//                     do not), bf = bf16 rounding, f32 accumulation on the matrix pipe
+//   error bound       |s - s_exact| <= E(q) for every row, E from ||x'||, max ||y'||, ... and d (collect_bounds_kernel)
+//   running bound     B(q) = the kk-th best of the best s seen in each of 16 row classes (row id mod 16), shared by all
 //                     workgroups through the threshold slots of DESIGN.md 3.3: kk DISTINCT rows have s >= B, so the exact
 //                     kk-th best value is no worse than B - E
 //   candidates        every row with s >= B - 2E at the time it is scanned (B only rises) -- a row of the exact top-kk has
@@ -38,6 +39,8 @@
 namespace mvs {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float lds_f32c;
 typedef __attribute__((address_space(1))) const float glb_f32c;
 
@@ -49,13 +52,13 @@ constexpr int CL_FLUSH_EVERY = 4; // tiles between two looks at the queue
 struct CollectArgs {
 	const void *qf;            // query fragments (bf16), [qblk32][ch][lane] x 16 bytes
 	const unsigned short *yb;  // bf16 rows [n + 64][dp]
-	const float *yn;           // squared row norms (f32, padded by 64)
+	const float *yn;           // beta(row): -||y'||^2 (L2) or <mu, y> (inner product), f32, padded by 64
 	const float *e2;           // [nq] 2E(q) (NaN: the query is not served here)
 	unsigned *gslot;           // [nq][slot_stride] class slots: keys of the best s per row class (smaller key = better)
 	unsigned long long *stream; // candidates (q << 32 | row)
 	unsigned long long *stream_cnt; // [0] entries appended
 	long long stream_cap;
-	int slot_stride, nclass;
+	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
 	long long n, row_first, split_rows;
 	int nq, nqb, nsplit, xcd_map;
 };
@@ -67,51 +70,124 @@ __device__ __forceinline__ float skey2f(unsigned k) {
 	return key2f(~k);
 }
 
-// ---- storage: rows as bf16 (round to nearest even) -------------------------------------------------------------------
-__global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp,
-                                       int interleaved, unsigned short *__restrict__ dst, const float *__restrict__ norms,
-                                       unsigned *__restrict__ max_norm_bits) {
-	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-	const int g8 = dp / 8;
-	if (i >= nrows * g8)
-		return;
-	const long long r = row0 + i / g8;
-	const int c8 = (int)(i % g8);
-	const float4 s0 = *(const float4 *)(src + (size_t)r * dp + c8 * 8);
-	const float4 s1 = *(const float4 *)(src + (size_t)r * dp + c8 * 8 + 4);
-	float v[8];
-	if (!interleaved) {
-		v[0] = s0.x, v[1] = s0.y, v[2] = s0.z, v[3] = s0.w, v[4] = s1.x, v[5] = s1.y, v[6] = s1.z, v[7] = s1.w;
-	} else if ((r >> 4) & 1) { // stored [k1,k3,k0,k2] (FlatGeom::pair_interleaved)
-		v[0] = s0.z, v[1] = s0.x, v[2] = s0.w, v[3] = s0.y, v[4] = s1.z, v[5] = s1.x, v[6] = s1.w, v[7] = s1.y;
-	} else { // stored [k0,k2,k1,k3]
-		v[0] = s0.x, v[1] = s0.z, v[2] = s0.y, v[3] = s0.w, v[4] = s1.x, v[5] = s1.z, v[6] = s1.y, v[7] = s1.w;
+// ---- storage: CENTRED rows as bf16 (round to nearest even) + one f32 per row -----------------------------------------------
+// The error of a bf16 product scales with ||x|| ||y||, distances do not: rows and queries are shifted by mu (the mean of the
+// rows present when the store is first built; ANY vector is valid, it only has to be the same for rows and queries):
+//   L2:  ||x - y||^2 = ||x'||^2 + ||y'||^2 - 2 <x', y'>,          x' = x - mu, y' = y - mu     beta(row) = -||y'||^2, alpha = 2
+//   IP:  <x, y> = <x', y'> + <mu, y> + <x', mu>  (last term: per query)                        beta(row) = <mu, y>,  alpha = 1
+// coarse value s = alpha <bf16(x'), bf16(y')> + beta(row).
+__global__ __launch_bounds__(256) void collect_colsum_kernel(const float *__restrict__ src, long long nrows, int dp,
+                                                            int interleaved, float *__restrict__ sum) {
+	// block = (dp / 8 column groups) x (256 / (dp / 8) row lanes); 1024 rows per block
+	const int g8 = dp / 8, rl = threadIdx.x / g8, c8 = threadIdx.x % g8, nrl = 256 / g8;
+	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	const long long r0 = (long long)blockIdx.x * 1024;
+	for (long long r = r0 + rl; r < r0 + 1024 && r < nrows; r += nrl) {
+		const float4 s0 = *(const float4 *)(src + (size_t)r * dp + c8 * 8);
+		const float4 s1 = *(const float4 *)(src + (size_t)r * dp + c8 * 8 + 4);
+		float v[8];
+		if (!interleaved) {
+			v[0] = s0.x, v[1] = s0.y, v[2] = s0.z, v[3] = s0.w, v[4] = s1.x, v[5] = s1.y, v[6] = s1.z, v[7] = s1.w;
+		} else if ((r >> 4) & 1) {
+			v[0] = s0.z, v[1] = s0.x, v[2] = s0.w, v[3] = s0.y, v[4] = s1.z, v[5] = s1.x, v[6] = s1.w, v[7] = s1.y;
+		} else {
+			v[0] = s0.x, v[1] = s0.z, v[2] = s0.y, v[3] = s0.w, v[4] = s1.x, v[5] = s1.z, v[6] = s1.y, v[7] = s1.w;
+		}
+#pragma unroll
+		for (int e = 0; e < 8; ++e)
+			acc[e] += v[e];
 	}
-	bf16x8 hi;
 #pragma unroll
 	for (int e = 0; e < 8; ++e)
-		hi[e] = (__bf16)v[e];
+		atomicAdd(sum + c8 * 8 + e, acc[e]);
+}
+__global__ void collect_mean_kernel(float *sum, int dp, int d, float inv_n) {
+	const int i = threadIdx.x;
+	if (i < dp)
+		sum[i] = i < d ? sum[i] * inv_n : 0.f;
+}
+// mu[dp] <- column means of the first `nrows` rows (padded dimensions: 0)
+void launch_collect_mean(const FlatGeom &g, const float *d_vecs, int64_t nrows, float *d_mu, hipStream_t st) {
+	MVS_HIP(hipMemsetAsync(d_mu, 0, (size_t)g.dp * sizeof(float), st));
+	if (nrows <= 0)
+		return;
+	hipLaunchKernelGGL(collect_colsum_kernel, dim3((unsigned)((nrows + 1023) / 1024)), dim3(256), 0, st, d_vecs,
+	                   (long long)nrows, g.dp, g.pair_interleaved ? 1 : 0, d_mu);
+	hipLaunchKernelGGL(collect_mean_kernel, dim3(1), dim3(256), 0, st, d_mu, g.dp, g.d, 1.0f / (float)nrows);
+	MVS_HIP(hipGetLastError());
+}
+
+// one thread per (row, 8 dims); the dp / 8 threads of a row are neighbours in a wave
+// max_bits[0]: largest squared norm of the ORIGINAL rows (shared with flat_bf16.hip), max_bits[8]: of the centred rows
+template <bool IS_L2>
+__global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp,
+                                       int interleaved, const float *__restrict__ mu, unsigned short *__restrict__ dst,
+                                       float *__restrict__ beta, const float *__restrict__ norms,
+                                       unsigned *__restrict__ max_bits) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int g8 = dp / 8;
+	const bool live = i < nrows * g8;
+	const long long r = row0 + (live ? i / g8 : 0);
+	const int c8 = (int)(i % g8);
+	float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	if (live) {
+		const float4 s0 = *(const float4 *)(src + (size_t)r * dp + c8 * 8);
+		const float4 s1 = *(const float4 *)(src + (size_t)r * dp + c8 * 8 + 4);
+		if (!interleaved) {
+			v[0] = s0.x, v[1] = s0.y, v[2] = s0.z, v[3] = s0.w, v[4] = s1.x, v[5] = s1.y, v[6] = s1.z, v[7] = s1.w;
+		} else if ((r >> 4) & 1) { // stored [k1,k3,k0,k2] (FlatGeom::pair_interleaved)
+			v[0] = s0.z, v[1] = s0.x, v[2] = s0.w, v[3] = s0.y, v[4] = s1.z, v[5] = s1.x, v[6] = s1.w, v[7] = s1.y;
+		} else { // stored [k0,k2,k1,k3]
+			v[0] = s0.x, v[1] = s0.z, v[2] = s0.y, v[3] = s0.w, v[4] = s1.x, v[5] = s1.z, v[6] = s1.y, v[7] = s1.w;
+		}
+	}
+	bf16x8 hi;
+	float n2 = 0.f, my = 0.f; // partial ||y'||^2 and <mu, y>
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		const float m = mu[c8 * 8 + e];
+		const float c = v[e] - m;
+		hi[e] = (__bf16)c;
+		n2 = fmaf(c, c, n2);
+		my = fmaf(m, v[e], my);
+	}
+	for (int o = g8 >> 1; o >= 1; o >>= 1) { // the row's threads are an aligned group of g8 lanes
+		n2 += __shfl_xor(n2, o);
+		my += __shfl_xor(my, o);
+	}
+	if (!live)
+		return;
 	*(bf16x8 *)(dst + (size_t)r * dp + c8 * 8) = hi;
 	if (c8 == 0) {
+		beta[r] = IS_L2 ? -n2 : my;
 		const unsigned b = __float_as_uint(norms[r]);
-		if (b > *max_norm_bits)
-			atomicMax(max_norm_bits, b);
+		if (b > max_bits[0])
+			atomicMax(max_bits, b);
+		const unsigned bc = __float_as_uint(n2); // (>= 0 or NaN: the bit pattern orders like the value, NaN above everything)
+		if (bc > max_bits[8])
+			atomicMax(max_bits + 8, bc);
 	}
 }
-void launch_rows_to_bf16_hi(const FlatGeom &g, const float *d_vecs, int64_t row0, int64_t nrows, unsigned short *d_bf,
-                            const float *d_norms, unsigned *d_max_norm_bits, hipStream_t st) {
+void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, int64_t row0, int64_t nrows, const float *d_mu,
+                            unsigned short *d_bf, float *d_beta, const float *d_norms, unsigned *d_max_norm_bits,
+                            hipStream_t st) {
 	if (nrows <= 0)
 		return;
 	const long long total = (long long)nrows * (g.dp / 8);
-	hipLaunchKernelGGL(rows_to_bf16_hi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_vecs,
-	                   (long long)row0, (long long)nrows, g.dp, g.pair_interleaved ? 1 : 0, d_bf, d_norms, d_max_norm_bits);
+	const dim3 grid((unsigned)((total + 255) / 256));
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<true>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp,
+		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
+	else
+		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<false>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp,
+		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
 	MVS_HIP(hipGetLastError());
 }
 
 // queries -> B fragments: qf[(qblk32 * KCH + ch) * 64 + lane] = 8 bf16 of query qblk32*32 + (lane & 31), dims ch*16 +
 // 8*(lane >> 5) + 0..7 (v_mfma_f32_32x32x16_bf16 B operand: lane l holds B[k = 8(l>>5) + j][col l & 31])
 __global__ void collect_pack_queries_kernel(const float *__restrict__ x, long long nq, int d, int kch,
-                                            bf16x8 *__restrict__ qf, long long total) {
+                                            const float *__restrict__ mu, bf16x8 *__restrict__ qf, long long total) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one (qblk32, ch, lane)
 	if (i >= total)
 		return;
@@ -124,7 +200,7 @@ __global__ void collect_pack_queries_kernel(const float *__restrict__ x, long lo
 #pragma unroll
 	for (int e = 0; e < 8; ++e) {
 		const int kk = ch * 16 + 8 * (lane >> 5) + e;
-		hi[e] = (__bf16)((q < nq && kk < d) ? x[q * d + kk] : 0.f);
+		hi[e] = (__bf16)((q < nq && kk < d) ? x[q * d + kk] - mu[kk] : 0.f);
 	}
 	qf[i] = hi;
 }
@@ -132,74 +208,83 @@ size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq) {
 	const int64_t nblk32 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 32);
 	return (size_t)nblk32 * (g.dp / 16) * 64 * 16;
 }
-void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, void *d_qf, hipStream_t st) {
+void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
+                                 hipStream_t st) {
 	const int64_t nblk32 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 32);
 	const long long total = (long long)nblk32 * (g.dp / 16) * 64;
 	hipLaunchKernelGGL(collect_pack_queries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_x,
-	                   (long long)nq, g.d, g.dp / 16, (bf16x8 *)d_qf, total);
+	                   (long long)nq, g.d, g.dp / 16, d_mu, (bf16x8 *)d_qf, total);
 	MVS_HIP(hipGetLastError());
 }
 
 // ---- error bound ---------------------------------------------------------------------------------------------------
-// u = 2^-24, S = ||q|| ||y||_max >= sum |q_i y_i| (Cauchy-Schwarz; both norms inflated by 1e-4 for their own rounding).
-//   bf16 rounding of both operands: |q_i y_i - qh_i yh_i| <= (2 * 2^-9 + 2^-18) |q_i y_i|            -> (2^-8 + 2^-18) S
+// u = 2^-24.  Primed quantities are centred (x' = fl(x - mu), y' = fl(y - mu)); S' = ||x'|| ||y'||_max >= sum |x'_i y'_i|
+// (Cauchy-Schwarz), S = ||x|| ||y||_max; every norm is inflated by 1e-4 for its own rounding.
+//   bf16 rounding of both operands: |x'_i y'_i - bf(x'_i) bf(y'_i)| <= (2 * 2^-9 + 2^-18) |x'_i y'_i|  -> (2^-8 + 2^-18) S'
 //   bf16 MFMA accumulation (d / 16 instructions, undocumented internal rounding modelled as 4 ulp-units of the magnitudes,
-//   with a 1.25 safety factor as in flat_bf16.hip prefilter_cerr):                                      -> 1.25 (d/16) 4u (1 + 2^-7) S
-//   => |a - <q,y>| <= ea
-//   L2:  s = fl(2a - yn): one rounding, |.| <= u (2 (S + ea) + yn_max);  the exact value the oracle reports is
-//        D = max(0, fl(fl(xn + yn) - 2 chain)), chain = d sequential fmas: |D - (xn + yn - 2<q,y>)| <= 2 d u S + 4u (xn + yn_max)
-//        in "s" units (s_exact = xn - D): E = 2 ea + u (2 (S + ea) + yn_max) + 2 d u S + 4u (xn + yn_max)
-//   IP:  s = a, the oracle reports the chain: E = ea + d u S
-//   e2 = 2 E (1 + 2^-10) + the rounding of (B - e2) itself.  Anything non-finite -> NaN (the query goes to the exact kernel).
+//   with a 1.25 safety factor as in flat_bf16.hip prefilter_cerr):                                      -> 1.25 (d/16) 4u (1 + 2^-7) S'
+//   => |a - <x', y'>| <= ea
+//   centring: x', y' carry one rounding per component (<= u |.|), beta is a d-term f32 chain:
+//        L2: | ||x-y||^2 - (||x'||^2 + ||y'||^2 - 2<x',y'>) | <= 4u (xn' + yn'_max);  |beta + ||y'||^2| <= d u yn'_max
+//        IP: | <x,y> - (<x',y'> + <mu,y> + <x',mu>) | <= 4u S' + 2u ||mu|| ||y||_max;   |beta - <mu,y>| <= d u ||mu|| ||y||_max
+//   s = fl(alpha a + beta): one rounding, <= u (alpha (S' + ea) + |beta|_max)
+//   the exact value the oracle reports: L2 D = max(0, fl(fl(xn + yn) - 2 chain)), chain = d sequential fmas:
+//        |D - ||x-y||^2| <= 2 d u S + 4u (xn + yn_max);   IP: |chain - <x,y>| <= d u S
+//   E = the sum of the applicable lines (in "s" units: L2 counts ea twice); e2 = 2 E (1 + 2^-10) + the rounding of (B - e2)
+//   itself.  Anything non-finite -> NaN (the query goes to the exact kernel).
 template <bool IS_L2>
-__global__ void collect_bounds_kernel(const float *__restrict__ x, const float *__restrict__ qn, long long nq, int d,
+__global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq, int d, const float *__restrict__ mu,
                                       const unsigned *__restrict__ max_norm_bits, float *__restrict__ e2,
                                       int *__restrict__ fail_cnt, int *__restrict__ fail_q) {
 	const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= nq)
 		return;
-	float xn;
-	if (IS_L2) {
-		xn = qn[q];
-	} else {
-		xn = 0.f;
-		for (int t = 0; t < d; ++t)
-			xn = fmaf(x[q * d + t], x[q * d + t], xn);
+	float xn = 0.f, xnc = 0.f, mun = 0.f;
+	for (int t = 0; t < d; ++t) {
+		const float v = x[q * d + t], m = mu[t], c = v - m;
+		xn = fmaf(v, v, xn);
+		xnc = fmaf(c, c, xnc);
+		mun = fmaf(m, m, mun);
 	}
-	const float yn = __uint_as_float(*max_norm_bits);
-	const double u = 5.9604644775390625e-08;
-	const double S = sqrt((double)xn * 1.0001) * sqrt((double)yn * 1.0001);
-	const double ea = (0.00390625 + 3.814697265625e-06) * S + 1.25 * ((double)d / 16.0) * 4.0 * u * (1.0 + 0.0078125) * S;
+	const float yn = __uint_as_float(max_norm_bits[0]), ync = __uint_as_float(max_norm_bits[8]);
+	const double u = 5.9604644775390625e-08, infl = 1.0001;
+	const double S = sqrt((double)xn * infl) * sqrt((double)yn * infl);
+	const double Sc = sqrt((double)xnc * infl) * sqrt((double)ync * infl);
+	const double MY = sqrt((double)mun * infl) * sqrt((double)yn * infl); // >= |<mu, y>|
+	const double ea = (0.00390625 + 3.814697265625e-06) * Sc + 1.25 * ((double)d / 16.0) * 4.0 * u * (1.0 + 0.0078125) * Sc;
 	double E;
 	if (IS_L2)
-		E = 2.0 * ea + u * (2.0 * (S + ea) + yn) + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn);
+		E = 2.0 * ea + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + u * (2.0 * (Sc + ea) + ync) + 2.0 * d * u * S +
+		    4.0 * u * ((double)xn + yn);
 	else
-		E = ea + (double)d * u * S;
-	float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn) + 1e-30);
-	const bool ok = isfinite(xn) && isfinite(yn) && isfinite(r) && r < 1e30f;
+		E = ea + 4.0 * u * Sc + 2.0 * u * MY + (double)d * u * MY + u * (Sc + ea + MY) + (double)d * u * S;
+	float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (Sc + MY + (double)xnc + ync) + 1e-30);
+	const bool ok = isfinite(xn) && isfinite(yn) && isfinite(ync) && isfinite(mun) && isfinite(r) && r < 1e30f;
 	if (!ok) {
 		r = __uint_as_float(0x7fc00000u);
 		fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
 	}
 	e2[q] = r;
 }
-void launch_collect_bounds(int metric, const float *d_x, const float *d_qn, int64_t nq, int d,
+void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st) {
 	if (nq <= 0)
 		return;
 	const dim3 grid((unsigned)((nq + 255) / 256));
 	if (metric == METRIC_L2)
-		hipLaunchKernelGGL(collect_bounds_kernel<true>, grid, dim3(256), 0, st, d_x, d_qn, (long long)nq, d, d_max_norm_bits,
-		                   d_e2, d_fail_cnt, d_fail_q);
+		hipLaunchKernelGGL(collect_bounds_kernel<true>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, d_e2,
+		                   d_fail_cnt, d_fail_q);
 	else
-		hipLaunchKernelGGL(collect_bounds_kernel<false>, grid, dim3(256), 0, st, d_x, d_qn, (long long)nq, d, d_max_norm_bits,
-		                   d_e2, d_fail_cnt, d_fail_q);
+		hipLaunchKernelGGL(collect_bounds_kernel<false>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, d_e2,
+		                   d_fail_cnt, d_fail_q);
 	MVS_HIP(hipGetLastError());
 }
 
 // ---- the scan kernel ---------------------------------------------------------------------------------------------------
 // COLLECT = false: bound estimation only (publish to the slots, append nothing) -- the pre-pass over the first rows
-template <int KCH, bool IS_L2, bool COLLECT>
+// ABL (profiling builds of the L2 collect instance only; results are WRONG when != 0): bit 0 = no rare path, bit 1 = no
+// fold either (bare MFMA + staging), bit 2 = stage only the first tile
+template <int KCH, bool IS_L2, bool COLLECT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const CollectArgs a) {
 	constexpr int DP = KCH * 16;
 	constexpr int PITCH = DP * 2;             // bytes per row (256 at d = 128)
@@ -237,13 +322,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 
 	// the lane's four queries (one per 32-query B tile of the wave)
 	const int q0 = qb * CL_QBLOCK + wave * 128 + c;
-	float e2q[4], cq[4];
+	float cq[4]; // the query's pass bound: B - 2E (NaN: the query is not served, nothing ever passes)
 #pragma unroll
-	for (int t = 0; t < 4; ++t) {
-		const int q = q0 + 32 * t;
-		e2q[t] = q < a.nq ? a.e2[q] : __uint_as_float(0x7fc00000u);
-		cq[t] = e2q[t] != e2q[t] ? e2q[t] : -INFINITY; // NaN: nothing ever passes; else no bound yet: everything does
-	}
+	for (int t = 0; t < 4; ++t)
+		cq[t] = __uint_as_float(0x7fc00000u);
 
 	// B fragments, resident: [query tile][k-chunk]
 	bf16x8 bq[4][KCH];
@@ -274,11 +356,9 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		                                 (lds_f32c *)(smem + ((u & 1) * TILE_BYTES + (i * 4 + wave) * 1024) / 4), 16, 0, 0);
 	};
 	auto dma_norms = [&](int u) {
-		if (IS_L2) {
-			const float *base = a.yn + (r_begin + (long long)u * CL_BN); // uniform
-			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + lane),
-			                                 (lds_f32c *)(smem + (2 * TILE_BYTES) / 4 + (u & 1) * 64), 4, 0, 0);
-		}
+		const float *base = a.yn + (r_begin + (long long)u * CL_BN); // uniform
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + lane), (lds_f32c *)(smem + (2 * TILE_BYTES) / 4 + (u & 1) * 64),
+		                                 4, 0, 0);
 	};
 	if (ntiles > 0) {
 #pragma unroll
@@ -293,137 +373,252 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
 
-	for (int u = 0; u < ntiles; ++u) {
-		// Shared bound: every `period` tiles the wave fetches the class slots of its 4 x 32 queries and WAITS for them (one L2
-		// round trip; the accumulators are dead here, so the 32 transient registers are free).
-		const int period = u < 16 ? 2 : (u < 256 ? 8 : 32);
-		if ((u % period) == 0) {
-			SlotRegs sr[4];
+	// Rare path of one 32-query tile (acc holds s): group by group of four rows, every passing row is published to its class
+	// slot (16 classes: row & 15) and appended.
+	auto rare = [&](const f32x16 &sv16, int t, bool any_t, long long row0, int nvalid) {
+		if (ABL & 1) {
+			MVS_KEEP_VGPR(any_t);
+			return;
+		}
+		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+			return;
+		int qo = q0;
+		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)
+		const int q = qo + 32 * t;
+		const float c0 = cq[t];
 #pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				const int q = q0 + 32 * t;
-				slots_prefetch(sr[t], a.gslot + (size_t)(q < a.nq ? q : 0) * a.slot_stride, 0, h);
+		for (int g = 0; g < 4; ++g) {
+			unsigned m = 0u;
+			if (any_t) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e)
+					if (8 * g + 4 * h + e < nvalid && sv16[4 * g + e] >= c0)
+						m |= 1u << e;
 			}
-#pragma unroll
-			for (int t = 0; t < 4; ++t)
-				asm volatile("" : "+v"(sr[t].w[0]), "+v"(sr[t].w[1]), "+v"(sr[t].w[2]), "+v"(sr[t].w[3]));
-#pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				const float B = skey2f(slots_reduce(sr[t])); // -FLT_MAX while a class is still empty
-				const float v = B - e2q[t];                   // NaN stays NaN
-				cq[t] = v;
-			}
-		}
-		f32x16 acc[4];
-#pragma unroll
-		for (int t = 0; t < 4; ++t)
-#pragma unroll
-			for (int r = 0; r < 16; ++r)
-				acc[t][r] = 0.f;
-		const char *Abase = tbuf + (u & 1) * TILE_BYTES;
-		bf16x8 af[2];
-		auto read_a = [&](int ch, int slot) {
-			unsigned rb = rbase;
-			MVS_OPAQUE_VGPR(rb);
-			af[slot] = *(const bf16x8 *)(Abase + (rb ^ (unsigned)(ch * 32)));
-		};
-		read_a(0, 0);
-#pragma unroll
-		for (int ch = 0; ch < KCH; ++ch) {
-			__builtin_amdgcn_sched_barrier(0);
-			if (ch + 1 < KCH)
-				read_a(ch + 1, (ch + 1) & 1);
-			if (ch < DMA_PER_WAVE)
-				dma_issue(u + 1, ch);
-			if (ch == 0)
-				dma_norms(u + 1);
-			__builtin_amdgcn_sched_barrier(0);
-			const bf16x8 ah = af[ch & 1];
-#pragma unroll
-			for (int t = 0; t < 4; ++t)
-				acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[t][ch], acc[t], 0, 0, 0);
-		}
-		__builtin_amdgcn_sched_barrier(0);
-		const long long row0 = r_begin + (long long)u * CL_BN;
-		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN);
-		// Row norms of this tile, LDS -> registers by hand (hipcc would put s_waitcnt vmcnt(0) in front of a compiled LDS read
-		// while the next tile's LDS-DMA is in flight)
-		float4 yn4[4];
-		if (IS_L2) {
-			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * h));
-			asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
-			             "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
-			             : "=&v"(yn4[0]), "=&v"(yn4[1]), "=&v"(yn4[2]), "=&v"(yn4[3])
-			             : "v"(nb_lds)
-			             : "memory");
-		}
-		// fast path: s = 2a - yn (one fma), best of the 16 rows against the query's bound
-		bool any[4];
-#pragma unroll
-		for (int t = 0; t < 4; ++t) {
-			float m = -INFINITY;
-#pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				const float yv[4] = {yn4[g].x, yn4[g].y, yn4[g].z, yn4[g].w};
-				float s[4];
-#pragma unroll
-				for (int e = 0; e < 4; ++e) {
-					s[e] = IS_L2 ? fmaf(2.0f, acc[t][4 * g + e], -yv[e]) : acc[t][4 * g + e];
-					acc[t][4 * g + e] = s[e];
-				}
-				m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(s[0], s[1]), __builtin_fmaxf(s[2], s[3])));
-			}
-			any[t] = m >= cq[t]; // NaN on either side: false
-		}
-		if (__builtin_amdgcn_ballot_w64(any[0] || any[1] || any[2] || any[3]) != 0ull) {
-			// rare path: every lane walks its own passing rows
-#pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				if (__builtin_amdgcn_ballot_w64(any[t]) == 0ull)
-					continue;
-				unsigned m = 0u;
-				if (any[t]) {
-#pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-						if (rl < nvalid && acc[t][r] >= cq[t])
-							m |= 1u << r;
-					}
-				}
-				const int q = q0 + 32 * t;
-				while (m != 0u) {
-					const int j = __builtin_ctz(m);
-					m &= m - 1u;
-					float sel[16];
-#pragma unroll
-					for (int i = 0; i < 16; ++i)
-						sel[i] = acc[t][i];
-#pragma unroll
-					for (int w = 16, bit = 0; w > 1; w >>= 1, ++bit)
-#pragma unroll
-						for (int i = 0; i < w / 2; ++i)
-							sel[i] = ((j >> bit) & 1) ? sel[2 * i + 1] : sel[2 * i];
-					const float sv = sel[0];
-					const unsigned row = (unsigned)(row0 + (j & 3) + 8 * (j >> 2) + 4 * h);
-					typedef __attribute__((address_space(1))) unsigned *GU;
-					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * a.slot_stride) + row % (unsigned)a.nclass, skey(sv),
-					                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (COLLECT) {
-						unsigned pos;
-						const unsigned one = 1u;
-						asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
-						const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-						if (pos < (unsigned)CL_QCAP) {
-							asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
-						} else { // a burst beyond the queue (cold start): straight to the stream
-							const unsigned long long gp = atomicAdd(a.stream_cnt, 1ull);
-							if ((long long)gp < a.stream_cap)
-								a.stream[gp] = ent;
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const float lo = (j & 1) ? sv16[4 * g + 1] : sv16[4 * g + 0];
+				const float hi = (j & 1) ? sv16[4 * g + 3] : sv16[4 * g + 2];
+				const float sv = (j & 2) ? hi : lo;
+				const unsigned row = (unsigned)(row0 + 8 * g + 4 * h + j);
+				typedef __attribute__((address_space(1))) unsigned *GU;
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(sv), __ATOMIC_RELAXED,
+				                       __HIP_MEMORY_SCOPE_AGENT);
+				if (COLLECT) {
+					unsigned pos;
+					const unsigned one = 1u;
+					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+					if (pos < (unsigned)CL_QCAP) {
+						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+					} else { // a burst beyond the queue (cold start): straight to the stream.  By hand, wait included: a compiled
+						// atomic with a result makes hipcc wait for vmcnt(0) where the branches meet, i.e. EVERY candidate would sit
+						// out the class-slot atomic's L2 round trip and the next tile's LDS-DMA
+						unsigned long long gp;
+						const unsigned long long one64 = 1ull;
+						typedef __attribute__((address_space(1))) unsigned long long *GUL;
+						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+						             : "=&v"(gp)
+						             : "v"((GUL)a.stream_cnt), "v"(one64)
+						             : "memory");
+						if ((long long)gp < a.stream_cap) {
+							typedef __attribute__((address_space(1))) unsigned long long *GULs;
+							*((GULs)a.stream + gp) = ent;
 						}
 					}
 				}
 			}
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	};
+
+	for (int u = 0; u < ntiles; ++u) {
+		// Shared bound: every `period` tiles the wave fetches the class slots of its 4 x 32 queries and WAITS for them (one L2
+		// round trip; the accumulators are dead here, so the 32 transient registers are free).
+		const int period = u < 8 ? 2 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
+		if ((u % period) == 0) {
+			// B = the kk-th best of the 16 class bests (kk distinct rows are at least that good): as keys, the kk-th smallest.
+			// The lane pair (l, l + 32) shares its four queries: lane h takes queries 2h and 2h + 1, loads their 16 slots,
+			// sorts them (bitonic network in registers) and the two lanes exchange the results.
+			int qo = q0;
+			MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this block out of the hot loop's registers)
+			unsigned long long w[2][8];
+			float e2v[2];
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				const int q = qo + 32 * (2 * h + i);
+				const int qc = q < a.nq ? q : 0;
+				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					w[i][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				e2v[i] = __builtin_nontemporal_load(a.e2 + qc);
+			}
+#pragma unroll
+			for (int i = 0; i < 2; ++i) // every load is issued before the first is consumed: one round trip
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					asm volatile("" : "+v"(w[i][j]));
+			float v[2];
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				unsigned key[16];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					key[2 * j] = (unsigned)w[i][j];
+					key[2 * j + 1] = (unsigned)(w[i][j] >> 32);
+				}
+#pragma unroll
+				for (int kb = 2; kb <= 16; kb <<= 1)
+#pragma unroll
+					for (int jb = kb >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+						for (int x0 = 0; x0 < 16; ++x0) {
+							const int x1 = x0 ^ jb;
+							if (x1 > x0) {
+								const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
+								const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
+								const bool asc = (x0 & kb) == 0;
+								key[x0] = asc ? lo : hi;
+								key[x1] = asc ? hi : lo;
+							}
+						}
+				unsigned kth = key[0];
+#pragma unroll
+				for (int j = 1; j < 16; ++j)
+					kth = (a.nclass - 1 == j) ? key[j] : kth;
+				const unsigned neutral = skey(-FLT_MAX);
+				const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
+				const int q = qo + 32 * (2 * h + i);
+				v[i] = q < a.nq ? B - e2v[i] : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN)
+			}
+			const float o0 = __shfl_xor(v[0], 32), o1 = __shfl_xor(v[1], 32);
+			cq[0] = h ? o0 : v[0];
+			cq[1] = h ? o1 : v[1];
+			cq[2] = h ? v[0] : o0;
+			cq[3] = h ? v[1] : o1;
+		}
+		// The A fragments of the WHOLE tile (8 x ds_read_b128 = 32 VGPRs), by hand: the reads are issued before the next
+		// tile's LDS-DMA (hipcc would put s_waitcnt vmcnt(0) in front of a compiled LDS read issued after it) and each is
+		// waited for just before its first MFMA.
+		bf16x8 A[KCH];
+		{
+			const unsigned ab = (unsigned)(uintptr_t)((lds_f32c *)(smem + (((ABL & 4) ? 0 : (u & 1)) * TILE_BYTES) / 4)) + rbase;
+#pragma unroll
+			for (int ch = 0; ch < KCH; ++ch)
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[ch]) : "v"(ab ^ (unsigned)(ch * 32)) : "memory");
+		}
+		// beta of this tile's rows: fetched group by group (four rows of the lane) two folds ahead, by hand as well
+		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * h));
+		f32x4n Y[2];
+		auto yn_issue = [&](int g) {
+			{
+				if (g == 0)
+					asm volatile("ds_read_b128 %0, %1" : "=v"(Y[0]) : "v"(nb_lds) : "memory");
+				else if (g == 1)
+					asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(Y[1]) : "v"(nb_lds) : "memory");
+				else if (g == 2)
+					asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(Y[0]) : "v"(nb_lds) : "memory");
+				else
+					asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(Y[1]) : "v"(nb_lds) : "memory");
+			}
+		};
+		if (!(ABL & 4)) {
+#pragma unroll
+			for (int i = 0; i < DMA_PER_WAVE; ++i)
+				dma_issue(u + 1, i);
+			dma_norms(u + 1);
+		}
+		const long long row0 = r_begin + (long long)u * CL_BN;
+		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN);
+
+		// Four 32-query tiles in turn, two accumulators: while the matrix pipe works on tile t the vector ALU folds tile
+		// t - 1 (s = 2a - yn, running maximum: one group of four rows after each MFMA), so a wave overlaps its own epilogue
+		// and does not depend on the CU's other workgroup being in the opposite phase.
+		f32x16 acc[2];
+		float mx = -INFINITY; // best s of the tile being folded
+		auto fold = [&](f32x16 &p, int g) { // rows 8g + 4h + 0..3 of the previous tile
+			if (ABL & 2) {
+				if (g == 3)
+					MVS_KEEP_VGPR(p);
+				return;
+			}
+			{ // group g has arrived (LDS returns in order; at most the read of group g + 1 is still out)
+				if (g < 3)
+					asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(Y[g & 1]));
+				else
+					asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Y[g & 1]));
+			}
+			const f32x4n yv = Y[g & 1];
+			f32x2n s01 = {p[4 * g + 0], p[4 * g + 1]}, s23 = {p[4 * g + 2], p[4 * g + 3]};
+			{ // s = alpha a + beta: v_pk_fma_f32, two values per instruction
+				const f32x2n al = {IS_L2 ? 2.0f : 1.0f, IS_L2 ? 2.0f : 1.0f}, y01 = {yv[0], yv[1]}, y23 = {yv[2], yv[3]};
+				s01 = __builtin_elementwise_fma(s01, al, y01);
+				s23 = __builtin_elementwise_fma(s23, al, y23);
+				p[4 * g + 0] = s01[0];
+				p[4 * g + 1] = s01[1];
+				p[4 * g + 2] = s23[0];
+				p[4 * g + 3] = s23[1];
+			}
+			mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(s01[0], s01[1]), __builtin_fmaxf(s23[0], s23[1])));
+			if (g + 2 < 4)
+				yn_issue(g + 2);
+		};
+		auto any_of = [&](float c) { // NaN on either side: false
+			const bool r = mx >= c;
+			mx = -INFINITY;
+			return r;
+		};
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			f32x16 &cur = acc[t & 1];
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+				cur[r] = 0.f;
+			if (t > 0) {
+				yn_issue(0);
+				yn_issue(1);
+			}
+#pragma unroll
+			for (int ch = 0; ch < KCH; ++ch) {
+				if (t == 0) { // A[ch] (and, by the last one, the norms) have arrived
+					if (ch == 0)
+						asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(A[0]));
+					else if (ch == 1)
+						asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[1]));
+					else if (ch == 2)
+						asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(A[2]));
+					else if (ch == 3)
+						asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[3]));
+					else if (ch == 4)
+						asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[4]));
+					else if (ch == 5)
+						asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[5]));
+					else if (ch == 6)
+						asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(A[6]));
+					else
+						asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[7]));
+				}
+				if ((ABL & 8) && (ch & 1)) // profiling: two independent accumulation chains (results wrong)
+					acc[(t + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ch], bq[t][ch], acc[(t + 1) & 1], 0, 0, 0);
+				else
+					cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ch], bq[t][ch], cur, 0, 0, 0);
+				if (t > 0 && ch >= 1 && ch <= 4)
+					fold(acc[(t - 1) & 1], ch - 1);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			if (t > 0)
+				rare(acc[(t - 1) & 1], t - 1, any_of(cq[t - 1]), row0, nvalid);
+		}
+		{
+			f32x16 &last = acc[1];
+			yn_issue(0);
+			yn_issue(1);
+#pragma unroll
+			for (int g = 0; g < 4; ++g)
+				fold(last, g);
+			rare(last, 3, any_of(cq[3]), row0, nvalid);
 		}
 		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
 		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
@@ -455,6 +650,7 @@ bool collect_supported(const FlatGeom &g) {
 	return g.nch == 1 && g.dp == 128;
 }
 
+int g_cl_abl = 0;         // option cl_abl: profiling ablation of the L2 scan (results wrong)
 int g_cl_nsplit = 0;      // option cl_nsplit: row splits of the main scan (0 = planned)
 int g_cl_seed_rows = 32768; // option cl_seed_rows: rows of the bound-estimation pre-pass
 
@@ -475,7 +671,16 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 	a.nsplit = (int)nsplit;
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_lds_bytes(g);
-	if (metric == METRIC_L2) {
+	if (metric == METRIC_L2 && COLLECT && g_cl_abl) {
+#define MVS_CL_ABL(N)                                                                                                  \
+	if (g_cl_abl == N) {                                                                                               \
+		auto kern = flat_bf16_collect_kernel<8, true, true, N>;                                                        \
+		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
+	}
+		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7) MVS_CL_ABL(11)
+#undef MVS_CL_ABL
+	} else if (metric == METRIC_L2) {
 		auto kern = flat_bf16_collect_kernel<8, true, COLLECT>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
@@ -492,16 +697,17 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 }
 
 int collect_slot_stride(int kk) {
-	return flat_mfma_slot_stride(kk);
+	(void)kk;
+	return 16;
 }
 
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
                             unsigned long long *d_stream_cnt, hipStream_t st) {
-	const int stride = flat_mfma_slot_stride(kk);
+	const int stride = 16; // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
-	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, kk,
+	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, 16,
 	                   0 /* larger s is better */);
 	MVS_HIP(hipMemsetAsync(d_stream_cnt, 0, 16, st));
 	CollectArgs a;
@@ -531,7 +737,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.yn = d_norms;
 	a.e2 = d_e2;
 	a.gslot = d_gslot;
-	a.slot_stride = flat_mfma_slot_stride(kk);
+	a.slot_stride = 16;
 	a.nclass = kk;
 	a.nq = (int)nq;
 	a.stream = d_stream;

@@ -172,7 +172,9 @@ public:
 	float pf_max_rel_err = 0.f; // largest observed |approx - exact| / (||x|| ||y||) among re-scored candidates
 	DevBuf ws_pfq, ws_cand, ws_ex, ws_fail, ws_fb;
 	// bf16 coarse filter (csrc/flat_collect.hip): rows as bf16 only, candidate stream, per-query bounds
-	unsigned short *vecs_h1 = nullptr; // [h1_cap + 64][dp]
+	unsigned short *vecs_h1 = nullptr; // [h1_cap + 64][dp] centred rows as bf16
+	float *beta_h1 = nullptr;          // [h1_cap + 64] -||y - mu||^2 (L2) or <mu, y> (inner product)
+	float *mu_h1 = nullptr;            // [dp] the centre (mean of the rows present at the first build)
 	int64_t h1_cap = 0, h1_rows = 0;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0;
 	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg;
@@ -286,11 +288,14 @@ void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float
 
 // csrc/flat_collect.hip
 bool collect_supported(const FlatGeom &g);
-void launch_rows_to_bf16_hi(const FlatGeom &g, const float *d_vecs, int64_t row0, int64_t nrows, unsigned short *d_bf,
-                            const float *d_norms, unsigned *d_max_norm_bits, hipStream_t st);
+void launch_collect_mean(const FlatGeom &g, const float *d_vecs, int64_t nrows, float *d_mu, hipStream_t st);
+void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, int64_t row0, int64_t nrows, const float *d_mu,
+                            unsigned short *d_bf, float *d_beta, const float *d_norms, unsigned *d_max_norm_bits,
+                            hipStream_t st);
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
-void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, void *d_qf, hipStream_t st);
-void launch_collect_bounds(int metric, const float *d_x, const float *d_qn, int64_t nq, int d,
+void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
+                                 hipStream_t st);
+void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 int collect_slot_stride(int kk);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
@@ -305,7 +310,7 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
                             hipStream_t st);
-extern int g_cl_nsplit, g_cl_seed_rows;
+extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl;
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,
                               const float *d_xq, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,

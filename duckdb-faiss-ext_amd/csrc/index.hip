@@ -282,7 +282,12 @@ void FlatIndex::drop_bf16_rows() {
 	bf_cap = bf_rows = 0;
 	if (vecs_h1)
 		(void)hipFree(vecs_h1);
+	if (beta_h1)
+		(void)hipFree(beta_h1);
+	if (mu_h1)
+		(void)hipFree(mu_h1);
 	vecs_h1 = nullptr;
+	beta_h1 = mu_h1 = nullptr;
 	h1_cap = h1_rows = 0;
 	if (d_max_norm_bits)
 		(void)hipFree(d_max_norm_bits);
@@ -322,25 +327,37 @@ void FlatIndex::ensure_bf16_rows(hipStream_t st) {
 void FlatIndex::ensure_h1_rows(hipStream_t st) {
 	if (h1_rows == ntotal && vecs_h1)
 		return;
-	if (ntotal > h1_cap || !vecs_h1) {
-		unsigned short *nb = nullptr;
-		const int64_t nc = std::max<int64_t>(cap, ntotal);
-		const size_t nbytes = ((size_t)nc + 64) * geom.dp * sizeof(unsigned short); // + 64 rows: unclamped prefetch
-		MVS_HIP(hipMalloc((void **)&nb, nbytes));
-		MVS_HIP(hipMemsetAsync(nb, 0, nbytes, st));
-		if (h1_rows > 0)
-			MVS_HIP(hipMemcpyAsync(nb, vecs_h1, (size_t)h1_rows * geom.dp * sizeof(unsigned short), hipMemcpyDeviceToDevice, st));
-		MVS_HIP(hipStreamSynchronize(st));
-		if (vecs_h1)
-			MVS_HIP(hipFree(vecs_h1));
-		vecs_h1 = nb;
-		h1_cap = nc;
-	}
 	if (!d_max_norm_bits) {
 		MVS_HIP(hipMalloc((void **)&d_max_norm_bits, 64));
 		MVS_HIP(hipMemsetAsync(d_max_norm_bits, 0, 64, st));
 	}
-	launch_rows_to_bf16_hi(geom, vecs, h1_rows, ntotal - h1_rows, vecs_h1, norms, d_max_norm_bits, st);
+	if (!mu_h1) { // the centre is fixed at the first build (any vector is valid; rows added later only fit it less well)
+		MVS_HIP(hipMalloc((void **)&mu_h1, (size_t)geom.dp * sizeof(float)));
+		launch_collect_mean(geom, vecs, std::min<int64_t>(ntotal, (int64_t)1 << 20), mu_h1, st);
+	}
+	if (ntotal > h1_cap || !vecs_h1) {
+		unsigned short *nb = nullptr;
+		float *nbeta = nullptr;
+		const int64_t nc = std::max<int64_t>(cap, ntotal);
+		const size_t nbytes = ((size_t)nc + 64) * geom.dp * sizeof(unsigned short); // + 64 rows: unclamped prefetch
+		MVS_HIP(hipMalloc((void **)&nb, nbytes));
+		MVS_HIP(hipMalloc((void **)&nbeta, ((size_t)nc + 64) * sizeof(float)));
+		MVS_HIP(hipMemsetAsync(nb, 0, nbytes, st));
+		MVS_HIP(hipMemsetAsync(nbeta, 0, ((size_t)nc + 64) * sizeof(float), st));
+		if (h1_rows > 0) {
+			MVS_HIP(hipMemcpyAsync(nb, vecs_h1, (size_t)h1_rows * geom.dp * sizeof(unsigned short), hipMemcpyDeviceToDevice, st));
+			MVS_HIP(hipMemcpyAsync(nbeta, beta_h1, (size_t)h1_rows * sizeof(float), hipMemcpyDeviceToDevice, st));
+		}
+		MVS_HIP(hipStreamSynchronize(st));
+		if (vecs_h1)
+			MVS_HIP(hipFree(vecs_h1));
+		if (beta_h1)
+			MVS_HIP(hipFree(beta_h1));
+		vecs_h1 = nb;
+		beta_h1 = nbeta;
+		h1_cap = nc;
+	}
+	launch_rows_to_bf16_hi(geom, metric, vecs, h1_rows, ntotal - h1_rows, mu_h1, vecs_h1, beta_h1, norms, d_max_norm_bits, st);
 	h1_rows = ntotal;
 }
 
@@ -352,10 +369,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ensure_h1_rows(st);
 	ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
 	ws_qn.reserve((size_t)nq * sizeof(float));
-	launch_collect_pack_queries(geom, d_x, nq, ws_pfq.p, st);
+	launch_collect_pack_queries(geom, d_x, nq, mu_h1, ws_pfq.p, st);
 	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
 	ws_e2.reserve((size_t)nq * sizeof(float));
-	launch_collect_bounds(metric, d_x, (const float *)ws_qn.p, nq, d, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
+	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
 	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk) * sizeof(unsigned) + 64);
 	const int64_t cap_entries = std::max<int64_t>(nq * 4096, (int64_t)1 << 20);
 	const size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
@@ -363,11 +380,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	unsigned long long *cnt = (unsigned long long *)ws_stream.p;
 	unsigned long long *stream = (unsigned long long *)((char *)ws_stream.p + 256);
 	unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
-	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, norms, ntotal, nq, kk, (const float *)ws_e2.p,
+	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, st);
 	int grid = 0, nsplit = 0, lds = 0;
 	begin_kernel_timing(st);
-	launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, norms, ntotal, nq, kk, (const float *)ws_e2.p,
+	launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
 	                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, st, &grid, &nsplit, &lds);
 	end_kernel_timing(st);
 	if (!h_flag_count)
@@ -1628,6 +1645,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "prefilter")) { // -1 auto, 0 off (exact f32 kernel only), 1 wherever the bf16x3 kernel supports the shape
 		prefilter_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_abl")) {
+		g_cl_abl = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "cl_nsplit")) { // coarse filter: row splits of the main scan (0 = planned)

@@ -117,12 +117,21 @@ def test_non_finite_and_huge_values(mf, metric):
 
 
 def test_large_norm_offset_data(mf):
-    """rows far from the origin: the bound (which scales with the norms) admits many candidates, still exact"""
+    """rows far from the origin: the store is centred on the mean row, so the bound scales with the spread of the data and
+    not with its offset -- no flood of candidates"""
     rs = np.random.RandomState(12)
     xb = (rs.rand(80_000, 128).astype(np.float32) + 3.0)
     xq = (rs.rand(100, 128).astype(np.float32) + 3.0)
     cl, ex = _pair(mf, 128, L2, xb)
-    _check(cl, ex, xq, 10, L2, xb, oracle_rows=32, overflow=True)
+    _check(cl, ex, xq, 10, L2, xb, oracle_rows=32)
+    st = cl.collect_stats()
+    assert st["overflows"] == 0 and st["candidates"] < 100 * 4096, st
+    xb = rs.rand(80_000, 128).astype(np.float32) + np.linspace(-2, 5, 128, dtype=np.float32)  # per-dimension offsets
+    xq = rs.rand(100, 128).astype(np.float32) + np.linspace(-2, 5, 128, dtype=np.float32)
+    for metric in (L2, IP):
+        cl, ex = _pair(mf, 128, metric, xb)
+        _check(cl, ex, xq, 10, metric, xb, oracle_rows=32)
+        assert cl.collect_stats()["overflows"] == 0
 
 
 @pytest.mark.parametrize("seed", range(12))
