@@ -184,36 +184,38 @@ void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, 
 	MVS_HIP(hipGetLastError());
 }
 
-// queries -> B fragments: qf[(qblk32 * KCH + ch) * 64 + lane] = 8 bf16 of query qblk32*32 + (lane & 31), dims ch*16 +
-// 8*(lane >> 5) + 0..7 (v_mfma_f32_32x32x16_bf16 B operand: lane l holds B[k = 8(l>>5) + j][col l & 31])
-__global__ void collect_pack_queries_kernel(const float *__restrict__ x, long long nq, int d, int kch,
-                                            const float *__restrict__ mu, bf16x8 *__restrict__ qf, long long total) {
-	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one (qblk32, ch, lane)
+// queries -> B fragments of v_mfma_f32_16x16x32_bf16: qf[(qblk16 * KB + kb) * 64 + lane] = 8 bf16 of alpha x (the CENTRED query
+// qblk16*16 + (lane & 15)), dims kb*32 + 8*(lane >> 4) + 0..7; alpha = 2 (L2) or 1 goes into the operand so that the MFMA chain,
+// started from beta(row) instead of 0, delivers s = alpha <x', y'> + beta with no vector-ALU work at all
+__global__ void collect_pack_queries_kernel(const float *__restrict__ x, long long nq, int d, int nkb,
+                                            const float *__restrict__ mu, float alpha, bf16x8 *__restrict__ qf,
+                                            long long total) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one (qblk16, kb, lane)
 	if (i >= total)
 		return;
 	const int lane = (int)(i & 63);
 	const long long t = i >> 6;
-	const int ch = (int)(t % kch);
-	const long long qblk32 = t / kch;
-	const long long q = qblk32 * 32 + (lane & 31);
+	const int kb = (int)(t % nkb);
+	const long long qblk16 = t / nkb;
+	const long long q = qblk16 * 16 + (lane & 15);
 	bf16x8 hi;
 #pragma unroll
 	for (int e = 0; e < 8; ++e) {
-		const int kk = ch * 16 + 8 * (lane >> 5) + e;
-		hi[e] = (__bf16)((q < nq && kk < d) ? x[q * d + kk] - mu[kk] : 0.f);
+		const int kk = kb * 32 + 8 * (lane >> 4) + e;
+		hi[e] = (__bf16)((q < nq && kk < d) ? alpha * (x[q * d + kk] - mu[kk]) : 0.f); // (alpha = 1 or 2: exact)
 	}
 	qf[i] = hi;
 }
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq) {
-	const int64_t nblk32 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 32);
-	return (size_t)nblk32 * (g.dp / 16) * 64 * 16;
+	const int64_t nblk16 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 16);
+	return (size_t)nblk16 * (g.dp / 32) * 64 * 16;
 }
-void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
+void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
                                  hipStream_t st) {
-	const int64_t nblk32 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 32);
-	const long long total = (long long)nblk32 * (g.dp / 16) * 64;
+	const int64_t nblk16 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 16);
+	const long long total = (long long)nblk16 * (g.dp / 32) * 64;
 	hipLaunchKernelGGL(collect_pack_queries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_x,
-	                   (long long)nq, g.d, g.dp / 16, d_mu, (bf16x8 *)d_qf, total);
+	                   (long long)nq, g.d, g.dp / 32, d_mu, metric == METRIC_L2 ? 2.0f : 1.0f, (bf16x8 *)d_qf, total);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -221,16 +223,16 @@ void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq
 // u = 2^-24.  Primed quantities are centred (x' = fl(x - mu), y' = fl(y - mu)); S' = ||x'|| ||y'||_max >= sum |x'_i y'_i|
 // (Cauchy-Schwarz), S = ||x|| ||y||_max; every norm is inflated by 1e-4 for its own rounding.
 //   bf16 rounding of both operands: |x'_i y'_i - bf(x'_i) bf(y'_i)| <= (2 * 2^-9 + 2^-18) |x'_i y'_i|  -> (2^-8 + 2^-18) S'
-//   bf16 MFMA accumulation (d / 16 instructions, undocumented internal rounding modelled as 4 ulp-units of the magnitudes,
-//   with a 1.25 safety factor as in flat_bf16.hip prefilter_cerr):                                      -> 1.25 (d/16) 4u (1 + 2^-7) S'
-//   => |a - <x', y'>| <= ea
+//   bf16 MFMA accumulation, the chain starting at C = beta (undocumented internal rounding modelled as 4 ulp-units of the
+//   magnitudes per instruction, counted as d / 16 instructions, with a 1.25 safety factor as in flat_bf16.hip
+//   prefilter_cerr):                                                                      -> 1.25 (d/16) 4u ((1 + 2^-7) alpha S' + |beta|_max)
+//   => |s - (alpha <x', y'> + beta)| <= es = alpha (2^-8 + 2^-18) S' + that
 //   centring: x', y' carry one rounding per component (<= u |.|), beta is a d-term f32 chain:
 //        L2: | ||x-y||^2 - (||x'||^2 + ||y'||^2 - 2<x',y'>) | <= 4u (xn' + yn'_max);  |beta + ||y'||^2| <= d u yn'_max
 //        IP: | <x,y> - (<x',y'> + <mu,y> + <x',mu>) | <= 4u S' + 2u ||mu|| ||y||_max;   |beta - <mu,y>| <= d u ||mu|| ||y||_max
-//   s = fl(alpha a + beta): one rounding, <= u (alpha (S' + ea) + |beta|_max)
 //   the exact value the oracle reports: L2 D = max(0, fl(fl(xn + yn) - 2 chain)), chain = d sequential fmas:
 //        |D - ||x-y||^2| <= 2 d u S + 4u (xn + yn_max);   IP: |chain - <x,y>| <= d u S
-//   E = the sum of the applicable lines (in "s" units: L2 counts ea twice); e2 = 2 E (1 + 2^-10) + the rounding of (B - e2)
+//   E = the sum of the applicable lines; e2 = 2 E (1 + 2^-10) + the rounding of (B - e2)
 //   itself.  Anything non-finite -> NaN (the query goes to the exact kernel).
 template <bool IS_L2>
 __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq, int d, const float *__restrict__ mu,
@@ -251,13 +253,16 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
 	const double S = sqrt((double)xn * infl) * sqrt((double)yn * infl);
 	const double Sc = sqrt((double)xnc * infl) * sqrt((double)ync * infl);
 	const double MY = sqrt((double)mun * infl) * sqrt((double)yn * infl); // >= |<mu, y>|
-	const double ea = (0.00390625 + 3.814697265625e-06) * Sc + 1.25 * ((double)d / 16.0) * 4.0 * u * (1.0 + 0.0078125) * Sc;
+	// s comes straight out of the MFMA chain: C starts at beta, the B operand carries alpha
+	const double al = IS_L2 ? 2.0 : 1.0;
+	const double bmax = IS_L2 ? (double)ync : MY; // >= |beta|
+	const double es = al * (0.00390625 + 3.814697265625e-06) * Sc +
+	                  1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * al * Sc + bmax);
 	double E;
 	if (IS_L2)
-		E = 2.0 * ea + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + u * (2.0 * (Sc + ea) + ync) + 2.0 * d * u * S +
-		    4.0 * u * ((double)xn + yn);
+		E = es + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn);
 	else
-		E = ea + 4.0 * u * Sc + 2.0 * u * MY + (double)d * u * MY + u * (Sc + ea + MY) + (double)d * u * S;
+		E = es + 4.0 * u * Sc + 2.0 * u * MY + (double)d * u * MY + (double)d * u * S;
 	float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (Sc + MY + (double)xnc + ync) + 1e-30);
 	const bool ok = isfinite(xn) && isfinite(yn) && isfinite(ync) && isfinite(mun) && isfinite(r) && r < 1e30f;
 	if (!ok) {
@@ -281,28 +286,35 @@ void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, cons
 }
 
 // ---- the scan kernel ---------------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16: D[16 x 16] += A[16 x 32] B[32 x 16]; lane l holds A[row l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4)
+// + j][col l & 15] (8 bf16 each) and D[row 4 (l >> 4) + r][col l & 15] (4 f32).  A 32-row x 32-query block is four such tiles
+// with FOUR INDEPENDENT accumulators: back-to-back MFMAs never wait for each other's result (with the 32x32x16 shape the 8
+// MFMAs of a block form one dependent chain: 18.2 vs 14.4 ms for the bare loop).
 // COLLECT = false: bound estimation only (publish to the slots, append nothing) -- the pre-pass over the first rows
 // ABL (profiling builds of the L2 collect instance only; results are WRONG when != 0): bit 0 = no rare path, bit 1 = no
 // fold either (bare MFMA + staging), bit 2 = stage only the first tile
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
 template <int KCH, bool IS_L2, bool COLLECT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const CollectArgs a) {
 	constexpr int DP = KCH * 16;
+	constexpr int KB = DP / 32;               // k-blocks of 32 dimensions
 	constexpr int PITCH = DP * 2;             // bytes per row (256 at d = 128)
 	constexpr int C = PITCH / 16;             // 16-byte chunks per row
 	constexpr int TILE_BYTES = CL_BN * PITCH; // 8 KB at d = 128
 	constexpr int NDMA = TILE_BYTES / 1024;   // LDS-DMA instructions per tile (1 KB per wave-instruction)
 	constexpr int DMA_PER_WAVE = NDMA / 4;
-	static_assert(C == 16 && NDMA % 4 == 0 && DMA_PER_WAVE <= KCH, "d = 128 geometry");
+	static_assert(C == 16 && KB == 4 && NDMA % 4 == 0, "d = 128 geometry");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	char *tbuf = (char *)smem;                                  // [2][TILE_BYTES]
-	float *nbuf = (float *)(tbuf + 2 * TILE_BYTES);             // [2][64] squared row norms
+	float *nbuf = (float *)(tbuf + 2 * TILE_BYTES);             // [2][64] beta of the tile's rows
 	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
-	unsigned *qctl = (unsigned *)(qbuf + CL_QCAP);              // [0] queue fill, [2..3] flush base
+	float *cqtab = (float *)(qbuf + CL_QCAP);                   // [4 waves][4 t][16 c][2]: pass bound of every query
+	unsigned *qctl = (unsigned *)(cqtab + CL_QBLOCK);           // [0] queue fill, [2..3] flush base
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int h = lane >> 5, c = lane & 31;
+	const int hq = lane >> 4, c = lane & 15;
 	int split, qb;
 	if (a.xcd_map) {
 		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -320,23 +332,20 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	if (tid == 0)
 		qctl[0] = 0u;
 
-	// the lane's four queries (one per 32-query B tile of the wave)
-	const int q0 = qb * CL_QBLOCK + wave * 128 + c;
-	float cq[4]; // the query's pass bound: B - 2E (NaN: the query is not served, nothing ever passes)
-#pragma unroll
-	for (int t = 0; t < 4; ++t)
-		cq[t] = __uint_as_float(0x7fc00000u);
+	// the wave's 128 queries = 8 column blocks of 16; block cb = 2 t + i belongs to "tile" t; lane (hq, c) sees query
+	// qw + 16 cb + c in every block and OWNS (bound refresh) the two blocks of t = hq
+	const int qw = qb * CL_QBLOCK + wave * 128;
 
-	// B fragments, resident: [query tile][k-chunk]
-	bf16x8 bq[4][KCH];
+	// B fragments, resident: [column block][k-block]
+	bf16x8 bq[8][KB];
 	{
 		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
 #pragma unroll
-		for (int t = 0; t < 4; ++t) {
-			const size_t qblk32 = (size_t)qb * (CL_QBLOCK / 32) + wave * 4 + t;
+		for (int cb = 0; cb < 8; ++cb) {
+			const size_t qblk16 = (size_t)qb * (CL_QBLOCK / 16) + wave * 8 + cb;
 #pragma unroll
-			for (int ch = 0; ch < KCH; ++ch)
-				bq[t][ch] = qsrc[(qblk32 * KCH + ch) * 64 + lane];
+			for (int kb = 0; kb < KB; ++kb)
+				bq[cb][kb] = qsrc[(qblk16 * KB + kb) * 64 + lane];
 		}
 	}
 
@@ -368,42 +377,46 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	}
 	__syncthreads();
 
-	// read address of (row c, chunk 2 ch + h): c * PITCH + (((2 ch + h) ^ (c & 15)) * 16) = rbase ^ (ch * 32)
-	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)((((c & 15) ^ h) & 15) * 16);
+	// A fragment (row block rb, k-block kb): row 16 rb + c, chunk 4 kb + hq -> byte 4096 rb + 256 c + (((4 kb + hq) ^ c) * 16)
+	// = 4096 rb + (rbase ^ (64 kb)) with rbase = 256 c | ((hq ^ c) * 16)  (4 kb and hq occupy disjoint bits of the chunk number)
+	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)(((hq ^ c) & 15) * 16);
 	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+	// the lane's two bounds of tile t: cqtab[wave][t][c][0..1]
+	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 64 + c) * 8);
 
-	// Rare path of one 32-query tile (acc holds s): group by group of four rows, every passing row is published to its class
-	// slot (16 classes: row & 15) and appended.
-	auto rare = [&](const f32x16 &sv16, int t, bool any_t, long long row0, int nvalid) {
+	// Rare path of half a 32-query tile (row block rb; sv holds s of its 4 rows x 2 queries per lane): every passing row is
+	// published to its class slot (16 classes: row & 15) and appended.  Lane (hq, c): rows 16 rb + 4 hq + r, queries of column
+	// blocks 2 t + i.
+	auto rare = [&](const f32x4acc (&sv)[2], int rb, int t, bool any_t, f32x2n cqv, long long row0, int nvalid) {
 		if (ABL & 1) {
 			MVS_KEEP_VGPR(any_t);
 			return;
 		}
 		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
 			return;
-		int qo = q0;
+		int qo = qw;
 		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)
-		const int q = qo + 32 * t;
-		const float c0 = cq[t];
 #pragma unroll
-		for (int g = 0; g < 4; ++g) {
+		for (int i = 0; i < 2; ++i) {
+			const int q = qo + 32 * t + 16 * i + c;
+			const float c0 = cqv[i];
 			unsigned m = 0u;
 			if (any_t) {
 #pragma unroll
-				for (int e = 0; e < 4; ++e)
-					if (8 * g + 4 * h + e < nvalid && sv16[4 * g + e] >= c0)
-						m |= 1u << e;
+				for (int r = 0; r < 4; ++r)
+					if (16 * rb + 4 * hq + r < nvalid && sv[i][r] >= c0)
+						m |= 1u << r;
 			}
 			while (m != 0u) {
 				const int j = __builtin_ctz(m);
 				m &= m - 1u;
-				const float lo = (j & 1) ? sv16[4 * g + 1] : sv16[4 * g + 0];
-				const float hi = (j & 1) ? sv16[4 * g + 3] : sv16[4 * g + 2];
-				const float sv = (j & 2) ? hi : lo;
-				const unsigned row = (unsigned)(row0 + 8 * g + 4 * h + j);
+				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
+				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
+				const float v = (j & 2) ? hi : lo;
+				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
 				typedef __attribute__((address_space(1))) unsigned *GU;
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(sv), __ATOMIC_RELAXED,
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
 				if (COLLECT) {
 					unsigned pos;
@@ -412,9 +425,9 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
 					if (pos < (unsigned)CL_QCAP) {
 						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
-					} else { // a burst beyond the queue (cold start): straight to the stream.  By hand, wait included: a compiled
-						// atomic with a result makes hipcc wait for vmcnt(0) where the branches meet, i.e. EVERY candidate would sit
-						// out the class-slot atomic's L2 round trip and the next tile's LDS-DMA
+					} else { // a burst beyond the queue (cold start): straight to the stream.  By hand, wait included: a
+						// compiled atomic with a result makes hipcc wait for vmcnt(0) where the branches meet, i.e. EVERY
+						// candidate would sit out the class-slot atomic's L2 round trip and the next tile's LDS-DMA
 						unsigned long long gp;
 						const unsigned long long one64 = 1ull;
 						typedef __attribute__((address_space(1))) unsigned long long *GUL;
@@ -422,10 +435,8 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 						             : "=&v"(gp)
 						             : "v"((GUL)a.stream_cnt), "v"(one64)
 						             : "memory");
-						if ((long long)gp < a.stream_cap) {
-							typedef __attribute__((address_space(1))) unsigned long long *GULs;
-							*((GULs)a.stream + gp) = ent;
-						}
+						if ((long long)gp < a.stream_cap)
+							*((GUL)a.stream + gp) = ent;
 					}
 				}
 			}
@@ -434,20 +445,19 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	};
 
 	for (int u = 0; u < ntiles; ++u) {
-		// Shared bound: every `period` tiles the wave fetches the class slots of its 4 x 32 queries and WAITS for them (one L2
-		// round trip; the accumulators are dead here, so the 32 transient registers are free).
+		// Shared bound: every `period` tiles the lane fetches the 16 class slots of the two column blocks it owns and WAITS for
+		// them (one L2 round trip; the accumulators are dead here, so the transient registers are free).
 		const int period = u < 8 ? 2 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
 		if ((u % period) == 0) {
-			// B = the kk-th best of the 16 class bests (kk distinct rows are at least that good): as keys, the kk-th smallest.
-			// The lane pair (l, l + 32) shares its four queries: lane h takes queries 2h and 2h + 1, loads their 16 slots,
-			// sorts them (bitonic network in registers) and the two lanes exchange the results.
-			int qo = q0;
+			// B = the kk-th best of the 16 class bests (kk distinct rows are at least that good): as keys, the kk-th smallest
+			// (bitonic network in registers).  The pass bound B - 2E goes to the wave's table in LDS.
+			int qo = qw;
 			MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this block out of the hot loop's registers)
 			unsigned long long w[2][8];
 			float e2v[2];
 #pragma unroll
 			for (int i = 0; i < 2; ++i) {
-				const int q = qo + 32 * (2 * h + i);
+				const int q = qo + 32 * hq + 16 * i + c;
 				const int qc = q < a.nq ? q : 0;
 				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
 #pragma unroll
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 #pragma unroll
 				for (int j = 0; j < 8; ++j)
 					asm volatile("" : "+v"(w[i][j]));
-			float v[2];
+			f32x2n v;
 #pragma unroll
 			for (int i = 0; i < 2; ++i) {
 				unsigned key[16];
@@ -470,16 +480,16 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 					key[2 * j + 1] = (unsigned)(w[i][j] >> 32);
 				}
 #pragma unroll
-				for (int kb = 2; kb <= 16; kb <<= 1)
+				for (int kbit = 2; kbit <= 16; kbit <<= 1)
 #pragma unroll
-					for (int jb = kb >> 1; jb > 0; jb >>= 1)
+					for (int jb = kbit >> 1; jb > 0; jb >>= 1)
 #pragma unroll
 						for (int x0 = 0; x0 < 16; ++x0) {
 							const int x1 = x0 ^ jb;
 							if (x1 > x0) {
 								const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
 								const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
-								const bool asc = (x0 & kb) == 0;
+								const bool asc = (x0 & kbit) == 0;
 								key[x0] = asc ? lo : hi;
 								key[x1] = asc ? hi : lo;
 							}
@@ -490,40 +500,26 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 					kth = (a.nclass - 1 == j) ? key[j] : kth;
 				const unsigned neutral = skey(-FLT_MAX);
 				const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
-				const int q = qo + 32 * (2 * h + i);
-				v[i] = q < a.nq ? B - e2v[i] : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN)
+				const int q = qo + 32 * hq + 16 * i + c;
+				v[i] = q < a.nq ? B - e2v[i] : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
 			}
-			const float o0 = __shfl_xor(v[0], 32), o1 = __shfl_xor(v[1], 32);
-			cq[0] = h ? o0 : v[0];
-			cq[1] = h ? o1 : v[1];
-			cq[2] = h ? v[0] : o0;
-			cq[3] = h ? v[1] : o1;
+			*(f32x2n *)(cqtab + (wave * 64 + hq * 16 + c) * 2) = v;
 		}
-		// The A fragments of the WHOLE tile (8 x ds_read_b128 = 32 VGPRs), by hand: the reads are issued before the next
-		// tile's LDS-DMA (hipcc would put s_waitcnt vmcnt(0) in front of a compiled LDS read issued after it) and each is
-		// waited for just before its first MFMA.
-		bf16x8 A[KCH];
+		// The A fragments of the WHOLE tile (8 x ds_read_b128 = 32 VGPRs) and the rows' beta (2 x ds_read_b128), by hand: the
+		// reads are issued before the next tile's LDS-DMA (hipcc would put s_waitcnt vmcnt(0) in front of a compiled LDS read
+		// issued after it) and each is waited for just before its first use.
+		bf16x8 A[KB][2];
+		f32x4n Y[2];
 		{
+			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * hq));
+			asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(Y[0]), "=&v"(Y[1]) : "v"(nb_lds) : "memory");
 			const unsigned ab = (unsigned)(uintptr_t)((lds_f32c *)(smem + (((ABL & 4) ? 0 : (u & 1)) * TILE_BYTES) / 4)) + rbase;
 #pragma unroll
-			for (int ch = 0; ch < KCH; ++ch)
-				asm volatile("ds_read_b128 %0, %1" : "=v"(A[ch]) : "v"(ab ^ (unsigned)(ch * 32)) : "memory");
-		}
-		// beta of this tile's rows: fetched group by group (four rows of the lane) two folds ahead, by hand as well
-		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * h));
-		f32x4n Y[2];
-		auto yn_issue = [&](int g) {
-			{
-				if (g == 0)
-					asm volatile("ds_read_b128 %0, %1" : "=v"(Y[0]) : "v"(nb_lds) : "memory");
-				else if (g == 1)
-					asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(Y[1]) : "v"(nb_lds) : "memory");
-				else if (g == 2)
-					asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(Y[0]) : "v"(nb_lds) : "memory");
-				else
-					asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(Y[1]) : "v"(nb_lds) : "memory");
+			for (int kb = 0; kb < KB; ++kb) {
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[kb][0]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
+				asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A[kb][1]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
 			}
-		};
+		}
 		if (!(ABL & 4)) {
 #pragma unroll
 			for (int i = 0; i < DMA_PER_WAVE; ++i)
@@ -533,92 +529,74 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		const long long row0 = r_begin + (long long)u * CL_BN;
 		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN);
 
-		// Four 32-query tiles in turn, two accumulators: while the matrix pipe works on tile t the vector ALU folds tile
-		// t - 1 (s = 2a - yn, running maximum: one group of four rows after each MFMA), so a wave overlaps its own epilogue
-		// and does not depend on the CU's other workgroup being in the opposite phase.
-		f32x16 acc[2];
-		float mx = -INFINITY; // best s of the tile being folded
-		auto fold = [&](f32x16 &p, int g) { // rows 8g + 4h + 0..3 of the previous tile
+		// Eight half tiles (32 queries x 16 rows: 8 MFMAs into two interleaved accumulators) in turn: while the matrix pipe
+		// works on one half the vector ALU folds the PREVIOUS half (running maximum of s per query) and runs its
+		// rare path, so a wave overlaps its own epilogue and does not depend on the CU's other workgroup being in the opposite
+		// phase; only the last half's fold is exposed.  One accumulator set: half (t, rb) lives in acc[rb][*] until the same row
+		// block of tile t + 1 starts, a full phase after its fold.
+		f32x4acc acc[2][2]; // [row block][column block of the tile]
+		f32x2n cqv[2];      // pass bounds of tile t in cqv[t & 1]
+		float mx0 = -INFINITY, mx1 = -INFINITY;
+		auto fold = [&](f32x4acc &p, int rb, int i) { // four rows of one query: the accumulator already holds s
 			if (ABL & 2) {
-				if (g == 3)
-					MVS_KEEP_VGPR(p);
+				MVS_KEEP_VGPR(p);
 				return;
 			}
-			{ // group g has arrived (LDS returns in order; at most the read of group g + 1 is still out)
-				if (g < 3)
-					asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(Y[g & 1]));
-				else
-					asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Y[g & 1]));
-			}
-			const f32x4n yv = Y[g & 1];
-			f32x2n s01 = {p[4 * g + 0], p[4 * g + 1]}, s23 = {p[4 * g + 2], p[4 * g + 3]};
-			{ // s = alpha a + beta: v_pk_fma_f32, two values per instruction
-				const f32x2n al = {IS_L2 ? 2.0f : 1.0f, IS_L2 ? 2.0f : 1.0f}, y01 = {yv[0], yv[1]}, y23 = {yv[2], yv[3]};
-				s01 = __builtin_elementwise_fma(s01, al, y01);
-				s23 = __builtin_elementwise_fma(s23, al, y23);
-				p[4 * g + 0] = s01[0];
-				p[4 * g + 1] = s01[1];
-				p[4 * g + 2] = s23[0];
-				p[4 * g + 3] = s23[1];
-			}
-			mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(s01[0], s01[1]), __builtin_fmaxf(s23[0], s23[1])));
-			if (g + 2 < 4)
-				yn_issue(g + 2);
+			(void)rb;
+			if (i == 0) // two v_max3_f32
+				mx0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx0, p[0]), p[1]), p[2]), p[3]);
+			else
+				mx1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx1, p[0]), p[1]), p[2]), p[3]);
 		};
-		auto any_of = [&](float c) { // NaN on either side: false
-			const bool r = mx >= c;
-			mx = -INFINITY;
+		auto any_of = [&](f32x2n cqp) { // NaN on either side: false
+			const bool r = (mx0 >= cqp[0]) || (mx1 >= cqp[1]);
+			mx0 = -INFINITY;
+			mx1 = -INFINITY;
 			return r;
 		};
 #pragma unroll
 		for (int t = 0; t < 4; ++t) {
-			f32x16 &cur = acc[t & 1];
+			// this tile's bounds (written at a refresh by the owning lane; LDS keeps a wave's accesses in order)
+			asm volatile("ds_read_b64 %0, %1" : "=v"(cqv[t & 1]) : "v"(cq_lds + (unsigned)(t * 128)) : "memory");
 #pragma unroll
-			for (int r = 0; r < 16; ++r)
-				cur[r] = 0.f;
-			if (t > 0) {
-				yn_issue(0);
-				yn_issue(1);
-			}
+			for (int rb = 0; rb < 2; ++rb) {
+				const int prb = rb ^ 1, pt = rb == 0 ? t - 1 : t; // the half folded under this one
 #pragma unroll
-			for (int ch = 0; ch < KCH; ++ch) {
-				if (t == 0) { // A[ch] (and, by the last one, the norms) have arrived
-					if (ch == 0)
-						asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(A[0]));
-					else if (ch == 1)
-						asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[1]));
-					else if (ch == 2)
-						asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(A[2]));
-					else if (ch == 3)
-						asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[3]));
-					else if (ch == 4)
-						asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[4]));
-					else if (ch == 5)
-						asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[5]));
-					else if (ch == 6)
-						asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(A[6]));
-					else
-						asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[7]));
+				for (int kb = 0; kb < KB; ++kb) {
+					if (t == 0) { // beta and A[kb][rb] have arrived (LDS returns in order: the reads behind them are counted)
+						if (rb == 0 && kb == 0)
+							asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(A[0][0]), "+v"(Y[0]), "+v"(Y[1]));
+						else if (rb == 0 && kb == 1)
+							asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[1][0]));
+						else if (rb == 0 && kb == 2)
+							asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[2][0]));
+						else if (rb == 0 && kb == 3)
+							asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[3][0]));
+						else if (rb == 1 && kb == 0) // everything: the other row block's fragments, the bounds
+							asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0][1]), "+v"(A[1][1]), "+v"(A[2][1]), "+v"(A[3][1]), "+v"(cqv[0]));
+					}
+#pragma unroll
+					for (int i = 0; i < 2; ++i) {
+						if (kb == 0) // the chain starts at beta(row): s = alpha <x', y'> + beta comes out of the matrix pipe
+							acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb][rb], bq[2 * t + i][kb], Y[rb], 0, 0, 0);
+						else
+							acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb][rb], bq[2 * t + i][kb], acc[rb][i], 0, 0, 0);
+					}
+					if (pt >= 0 && kb < 2)
+						fold(acc[prb][kb], prb, kb);
+					__builtin_amdgcn_sched_barrier(0);
 				}
-				if ((ABL & 8) && (ch & 1)) // profiling: two independent accumulation chains (results wrong)
-					acc[(t + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ch], bq[t][ch], acc[(t + 1) & 1], 0, 0, 0);
-				else
-					cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ch], bq[t][ch], cur, 0, 0, 0);
-				if (t > 0 && ch >= 1 && ch <= 4)
-					fold(acc[(t - 1) & 1], ch - 1);
-				__builtin_amdgcn_sched_barrier(0);
+				if (pt >= 0) {
+					if (rb == 0) // (pt = t - 1: its bounds were read a tile ago; this tile's read is waited for as well)
+						asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cqv[0]), "+v"(cqv[1]));
+					rare(acc[prb], prb, pt, any_of(cqv[pt & 1]), cqv[pt & 1], row0, nvalid);
+				}
 			}
-			if (t > 0)
-				rare(acc[(t - 1) & 1], t - 1, any_of(cq[t - 1]), row0, nvalid);
 		}
 		{
-			f32x16 &last = acc[1];
-			yn_issue(0);
-			yn_issue(1);
-#pragma unroll
-			for (int g = 0; g < 4; ++g)
-				fold(last, g);
-			rare(last, 3, any_of(cq[3]), row0, nvalid);
+			fold(acc[1][0], 1, 0);
+			fold(acc[1][1], 1, 1);
+			rare(acc[1], 1, 3, any_of(cqv[1]), cqv[1], row0, nvalid);
 		}
 		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
 		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
@@ -643,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 }
 
 static size_t collect_lds_bytes(const FlatGeom &g) {
-	return (size_t)2 * CL_BN * g.dp * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + 64;
+	return (size_t)2 * CL_BN * g.dp * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)CL_QBLOCK * 4 + 64;
 }
 
 bool collect_supported(const FlatGeom &g) {
@@ -678,7 +656,7 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
 	}
-		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7) MVS_CL_ABL(11)
+		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7)
 #undef MVS_CL_ABL
 	} else if (metric == METRIC_L2) {
 		auto kern = flat_bf16_collect_kernel<8, true, COLLECT>;

@@ -293,7 +293,7 @@ void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, 
                             unsigned short *d_bf, float *d_beta, const float *d_norms, unsigned *d_max_norm_bits,
                             hipStream_t st);
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
-void launch_collect_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
+void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
                                  hipStream_t st);
 void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st);

@@ -369,7 +369,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ensure_h1_rows(st);
 	ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
 	ws_qn.reserve((size_t)nq * sizeof(float));
-	launch_collect_pack_queries(geom, d_x, nq, mu_h1, ws_pfq.p, st);
+	launch_collect_pack_queries(geom, metric, d_x, nq, mu_h1, ws_pfq.p, st);
 	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
 	ws_e2.reserve((size_t)nq * sizeof(float));
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
