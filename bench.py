@@ -354,7 +354,36 @@ def main():
                         and w.get("grid") == kinfo["grid"]
                     ):
                         traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r2_traffic.json (" + w["source"] + ")"
-            if kinfo["name"].startswith("flat_bf16x3"):
+            if kinfo["name"].startswith("flat_bf16_collect"):
+                # bf16 coarse filter (csrc/flat_collect.hip): ONE bf16 MFMA product per element pair is the algorithm, so its
+                # algorithmic flops are 2 nq N d, priced against the dense bf16 peak; the candidates it admits are re-scored
+                # exactly in f32 (their kernels are inside the timed step, not inside this launch)
+                st = ix.prefilter_stats()
+                cs = ix.collect_stats()
+                achieved = kinfo["flops"] / (avg_ms * 1e-3) / 1e12
+                out["dtype"] = "f32 results (bf16 matrix-pipe coarse filter with a proven bound + exact f32 re-scoring of the candidates)"
+                out["roofline"] = {
+                    "kernel": kinfo["name"],
+                    "bound": "mfma",
+                    "achieved": round(achieved, 1),
+                    "peak": PEAK_BF16_MFMA_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "avg_launch_ms": round(avg_ms, 4),
+                    "launches": n_launch,
+                    "algorithmic_flops_per_launch": kinfo["flops"],
+                    "f32_equivalent_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
+                    "algorithmic_bytes_per_launch": kinfo["bytes"],
+                    "hbm_frac_of_8TBps": round(kinfo["bytes"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
+                    "grid": kinfo["grid"],
+                    "lds_bytes": kinfo["lds_bytes"],
+                    "candidates_rescored_per_query": round(cs["candidates"] / max(cs["queries"], 1), 1),
+                    "candidate_stream_overflows": cs["overflows"],
+                    "queries_rerun_on_exact_kernel": st["fallback_queries"],
+                }
+            elif kinfo["name"].startswith("flat_bf16x3"):
                 # bf16x3 prefilter (csrc/flat_bf16.hip): three bf16 MFMA products per element pair are the algorithm
                 # (hi*hi + hi*lo + lo*hi), so its algorithmic flops are 3 x 2 nq N d, priced against the dense bf16 peak
                 st = ix.prefilter_stats()

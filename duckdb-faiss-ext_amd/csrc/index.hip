@@ -751,7 +751,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	bool collected = false;
 	// Coarse filter (one bf16 product per pair, candidates by a proven bound): mode 2 forces it, auto prefers it where
 	// its kernel exists (d = 128 geometry, lists of <= 16); on a stream overflow the bf16x3 path below takes the batch
-	if (prefilter_mode == 2 && collect_supported(geom) && kk <= 16) {
+	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16) {
 		kp = (int)kk;
 		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, st);
 		if (!collected)

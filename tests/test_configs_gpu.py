@@ -61,10 +61,11 @@ def test_headline_flat_l2_10m(mf, torch):
     xq = mf.synth_uniform_torch(nq, d, Q_SEED)
     D, I = ix.search_torch(xq, k)
     torch.cuda.synchronize()
-    # default path at this size: bf16x3 matrix-pipe prefilter + exact f32 re-scoring (csrc/flat_bf16.hip)
-    assert ix.last_kernel_info()["name"] == "flat_bf16x3_kernel"
-    st = ix.prefilter_stats()
-    assert st["queries"] == nq and st["fallback_queries"] <= 10 and st["max_rel_err"] < st["err_bound"] / 5, st
+    # default path at this size: bf16 coarse filter with a proven bound + exact f32 re-scoring (csrc/flat_collect.hip)
+    assert ix.last_kernel_info()["name"] == "flat_bf16_collect_kernel"
+    cs = ix.collect_stats()
+    assert cs["queries"] == nq and cs["overflows"] == 0 and k * nq <= cs["candidates"] <= 1000 * nq, cs
+    assert ix.prefilter_stats()["fallback_queries"] == 0
     D, I = D.cpu().numpy(), I.cpu().numpy()
     # ... and the exact f32 MFMA kernel on the same index gives the same answers, bit for bit, on all 10k queries
     ix.set_option("prefilter", 0)
@@ -72,6 +73,14 @@ def test_headline_flat_l2_10m(mf, torch):
     torch.cuda.synchronize()
     assert ix.last_kernel_info()["name"].startswith("flat_mfma")
     assert np.array_equal(Ix.cpu().numpy(), I) and np.array_equal(Dx.cpu().numpy().view(np.uint32), D.view(np.uint32))
+    # ... and so does the bf16x3 prefilter (three bf16 products per pair, top-k' lists + proof: csrc/flat_bf16.hip)
+    ix.set_option("prefilter", 1)
+    D3, I3 = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"] == "flat_bf16x3_kernel"
+    st = ix.prefilter_stats()
+    assert st["fallback_queries"] <= 10 and st["max_rel_err"] < st["err_bound"] / 5, st
+    assert np.array_equal(I3.cpu().numpy(), I) and np.array_equal(D3.cpu().numpy().view(np.uint32), D.view(np.uint32))
     ix.set_option("prefilter", -1)
     _check_order_and_range(D, I, 0, n, True)
     ns = 256  # 0.65 TFLOP on the host
