@@ -117,6 +117,10 @@ void launch_collect_mean(const FlatGeom &g, const float *d_vecs, int64_t nrows, 
 	MVS_HIP(hipGetLastError());
 }
 
+template <int CTRL>
+__device__ __forceinline__ float cl_dpp(float v) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 // one thread per (row, 8 dims); the dp / 8 threads of a row are neighbours in a wave
 // max_bits[0]: largest squared norm of the ORIGINAL rows (shared with flat_bf16.hip), max_bits[8]: of the centred rows
 template <bool IS_L2>
@@ -151,9 +155,16 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 		n2 = fmaf(c, c, n2);
 		my = fmaf(m, v[e], my);
 	}
-	for (int o = g8 >> 1; o >= 1; o >>= 1) { // the row's threads are an aligned group of g8 lanes
-		n2 += __shfl_xor(n2, o);
-		my += __shfl_xor(my, o);
+	if (g8 == 16) { // the row's threads are one DPP row of 16 lanes: sum by quad_perm x 2, row_half_mirror, row_mirror (no LDS)
+		n2 += cl_dpp<0xB1>(n2), my += cl_dpp<0xB1>(my);
+		n2 += cl_dpp<0x4E>(n2), my += cl_dpp<0x4E>(my);
+		n2 += cl_dpp<0x141>(n2), my += cl_dpp<0x141>(my);
+		n2 += cl_dpp<0x140>(n2), my += cl_dpp<0x140>(my);
+	} else {
+		for (int o = g8 >> 1; o >= 1; o >>= 1) { // an aligned group of g8 lanes
+			n2 += __shfl_xor(n2, o);
+			my += __shfl_xor(my, o);
+		}
 	}
 	if (!live)
 		return;

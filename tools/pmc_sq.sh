@@ -11,7 +11,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if "bf16x3" in k or "flat_mfma" in k:
+    if "bf16" in k or "flat_mfma" in k:
         print(k)
         for c, v in sorted(d.items()):
             print(f"   {c}: dispatches={len(v)} mean={sum(v)/len(v):.6g}")

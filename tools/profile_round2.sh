@@ -29,6 +29,7 @@ for p in $parts; do case $p in
 headline)
   python3 bench.py > $out/headline_bench.json 2> $out/headline_bench.err; cut -c1-300 $out/headline_bench.json
   python3 bench.py --opt prefilter=0 --no-cpu-baseline > $out/headline_f32kernel_bench.json 2>/dev/null
+  python3 bench.py --opt prefilter=1 --no-cpu-baseline > $out/headline_bf16x3_bench.json 2>/dev/null
   kstats headline ;;
 chunk)   # the DuckDB granularity: <= 2048 queries per search call (src/faiss_extension.cpp:903-925)
   python3 bench.py --chunk 2048 --no-cpu-baseline > $out/headline_chunk2048_bench.json 2>/dev/null; cut -c1-200 $out/headline_chunk2048_bench.json ;;
