@@ -45,9 +45,10 @@ typedef __attribute__((address_space(3))) float lds_f32c;
 typedef __attribute__((address_space(1))) const float glb_f32c;
 
 constexpr int CL_QBLOCK = 512;  // queries per workgroup
-constexpr int CL_BN = 32;       // rows per staged tile
+constexpr int CL_BN = 32;       // rows per tile (one pass of the MFMA loop)
+constexpr int CL_SUB = 2;       // tiles per staged block (one barrier per CL_SUB tiles)
 constexpr int CL_QCAP = 2048;   // candidate queue of a workgroup (entries of 8 bytes)
-constexpr int CL_FLUSH_EVERY = 4; // tiles between two looks at the queue
+constexpr int CL_FLUSH_EVERY = 2; // staged blocks between two looks at the queue
 
 struct CollectArgs {
 	const void *qf;            // query fragments (bf16), [qblk32][ch][lane] x 16 bytes
@@ -311,14 +312,15 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	constexpr int KB = DP / 32;               // k-blocks of 32 dimensions
 	constexpr int PITCH = DP * 2;             // bytes per row (256 at d = 128)
 	constexpr int C = PITCH / 16;             // 16-byte chunks per row
-	constexpr int TILE_BYTES = CL_BN * PITCH; // 8 KB at d = 128
-	constexpr int NDMA = TILE_BYTES / 1024;   // LDS-DMA instructions per tile (1 KB per wave-instruction)
+	constexpr int TILE_BYTES = CL_BN * PITCH; // 8 KB at d = 128: what one pass of the MFMA loop consumes
+	constexpr int STAGE_BYTES = CL_SUB * TILE_BYTES; // what is staged between two barriers (CL_SUB tiles)
+	constexpr int NDMA = STAGE_BYTES / 1024;  // LDS-DMA instructions per stage (1 KB per wave-instruction)
 	constexpr int DMA_PER_WAVE = NDMA / 4;
-	static_assert(C == 16 && KB == 4 && NDMA % 4 == 0, "d = 128 geometry");
+	static_assert(C == 16 && KB == 4 && NDMA % 4 == 0 && CL_SUB * CL_BN <= 64, "d = 128 geometry");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
-	char *tbuf = (char *)smem;                                  // [2][TILE_BYTES]
-	float *nbuf = (float *)(tbuf + 2 * TILE_BYTES);             // [2][64] beta of the tile's rows
+	char *tbuf = (char *)smem;                                  // [2][STAGE_BYTES]
+	float *nbuf = (float *)(tbuf + 2 * STAGE_BYTES);            // [2][64] beta of the staged rows
 	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
 	float *cqtab = (float *)(qbuf + CL_QCAP);                   // [4 waves][4 t][16 c][2]: pass bound of every query
 	unsigned *qctl = (unsigned *)(cqtab + CL_QBLOCK);           // [0] queue fill, [2..3] flush base
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	long long r_end = r_begin + a.split_rows;
 	if (r_end > a.n)
 		r_end = a.n;
-	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + CL_BN - 1) / CL_BN) : 0;
+	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + CL_SUB * CL_BN - 1) / (CL_SUB * CL_BN)) : 0; // staged blocks
 	if (tid == 0)
 		qctl[0] = 0u;
 
@@ -371,13 +373,13 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		dma_off = (unsigned)(rr * PITCH + (((lane & 15) ^ rr) * 16));
 	}
 	auto dma_issue = [&](int u, int i) {
-		const char *base = (const char *)a.yb + ((size_t)(r_begin + (long long)u * CL_BN) + (size_t)i * 16) * PITCH; // uniform
+		const char *base = (const char *)a.yb + ((size_t)(r_begin + (long long)u * (CL_SUB * CL_BN)) + (size_t)i * 16) * PITCH; // uniform
 		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + dma_off),
-		                                 (lds_f32c *)(smem + ((u & 1) * TILE_BYTES + (i * 4 + wave) * 1024) / 4), 16, 0, 0);
+		                                 (lds_f32c *)(smem + ((u & 1) * STAGE_BYTES + (i * 4 + wave) * 1024) / 4), 16, 0, 0);
 	};
 	auto dma_norms = [&](int u) {
-		const float *base = a.yn + (r_begin + (long long)u * CL_BN); // uniform
-		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + lane), (lds_f32c *)(smem + (2 * TILE_BYTES) / 4 + (u & 1) * 64),
+		const float *base = a.yn + (r_begin + (long long)u * (CL_SUB * CL_BN)); // uniform
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + lane), (lds_f32c *)(smem + (2 * STAGE_BYTES) / 4 + (u & 1) * 64),
 		                                 4, 0, 0);
 	};
 	if (ntiles > 0) {
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	for (int u = 0; u < ntiles; ++u) {
 		// Shared bound: every `period` tiles the lane fetches the 16 class slots of the two column blocks it owns and WAITS for
 		// them (one L2 round trip; the accumulators are dead here, so the transient registers are free).
-		const int period = u < 8 ? 2 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
+		const int period = u < 4 ? 1 : (u < 32 ? 4 : (u < 256 ? 16 : 64)); // (in staged blocks of CL_SUB tiles)
 		if ((u % period) == 0) {
 			// B = the kk-th best of the 16 class bests (kk distinct rows are at least that good): as keys, the kk-th smallest
 			// (bitonic network in registers).  The pass bound B - 2E goes to the wave's table in LDS.
@@ -516,29 +518,32 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			}
 			*(f32x2n *)(cqtab + (wave * 64 + hq * 16 + c) * 2) = v;
 		}
+#pragma unroll 1
+		for (int sub = 0; sub < CL_SUB; ++sub) {
 		// The A fragments of the WHOLE tile (8 x ds_read_b128 = 32 VGPRs) and the rows' beta (2 x ds_read_b128), by hand: the
 		// reads are issued before the next tile's LDS-DMA (hipcc would put s_waitcnt vmcnt(0) in front of a compiled LDS read
 		// issued after it) and each is waited for just before its first use.
 		bf16x8 A[KB][2];
 		f32x4n Y[2];
 		{
-			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * hq));
+			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + sub * CL_BN + 4 * hq));
 			asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(Y[0]), "=&v"(Y[1]) : "v"(nb_lds) : "memory");
-			const unsigned ab = (unsigned)(uintptr_t)((lds_f32c *)(smem + (((ABL & 4) ? 0 : (u & 1)) * TILE_BYTES) / 4)) + rbase;
+			const unsigned ab =
+			    (unsigned)(uintptr_t)((lds_f32c *)(smem + (((ABL & 4) ? 0 : (u & 1)) * STAGE_BYTES + sub * TILE_BYTES) / 4)) + rbase;
 #pragma unroll
 			for (int kb = 0; kb < KB; ++kb) {
 				asm volatile("ds_read_b128 %0, %1" : "=v"(A[kb][0]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
 				asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A[kb][1]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
 			}
 		}
-		if (!(ABL & 4)) {
+		if (!(ABL & 4) && sub == 0) { // the next staged block, behind this tile's fragment reads
 #pragma unroll
 			for (int i = 0; i < DMA_PER_WAVE; ++i)
 				dma_issue(u + 1, i);
 			dma_norms(u + 1);
 		}
-		const long long row0 = r_begin + (long long)u * CL_BN;
-		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN);
+		const long long row0 = r_begin + ((long long)u * CL_SUB + sub) * CL_BN;
+		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN); // (<= 0 behind the split's last row)
 
 		// Eight half tiles (32 queries x 16 rows: 8 MFMAs into two interleaved accumulators) in turn: while the matrix pipe
 		// works on one half the vector ALU folds the PREVIOUS half (running maximum of s per query) and runs its
@@ -609,7 +614,8 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			fold(acc[1][1], 1, 1);
 			rare(acc[1], 1, 3, any_of(cqv[1]), cqv[1], row0, nvalid);
 		}
-		__syncthreads(); // also drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
+		} // sub
+		__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
 		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
 			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue)
 			const unsigned fill = qctl[0];
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 }
 
 static size_t collect_lds_bytes(const FlatGeom &g) {
-	return (size_t)2 * CL_BN * g.dp * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)CL_QBLOCK * 4 + 64;
+	return (size_t)2 * CL_SUB * CL_BN * g.dp * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)CL_QBLOCK * 4 + 64;
 }
 
 bool collect_supported(const FlatGeom &g) {
@@ -641,7 +647,7 @@ bool collect_supported(const FlatGeom &g) {
 
 int g_cl_abl = 0;         // option cl_abl: profiling ablation of the L2 scan (results wrong)
 int g_cl_nsplit = 0;      // option cl_nsplit: row splits of the main scan (0 = planned)
-int g_cl_seed_rows = 32768; // option cl_seed_rows: rows of the bound-estimation pre-pass
+int g_cl_seed_rows = 16384; // option cl_seed_rows: rows of the bound-estimation pre-pass
 
 int flat_mfma_slot_stride(int64_t k);
 __global__ void init_gslot_kernel(unsigned *g, long long total, int stride, int k, int is_l2);
@@ -650,12 +656,12 @@ template <bool COLLECT>
 static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, int64_t row_first, int64_t row_end,
                                  int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out) {
 	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
-	const int64_t ntiles = (row_end - row_first + CL_BN - 1) / CL_BN;
+	const int64_t ntiles = (row_end - row_first + CL_SUB * CL_BN - 1) / (CL_SUB * CL_BN); // staged blocks
 	const int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(nsplit_want, ntiles));
 	a.xcd_map = (nsplit >= 8 && nsplit % 8 == 0) ? 1 : 0;
 	a.row_first = row_first;
 	a.n = row_end;
-	a.split_rows = (ntiles + nsplit - 1) / nsplit * CL_BN;
+	a.split_rows = (ntiles + nsplit - 1) / nsplit * (CL_SUB * CL_BN);
 	a.nqb = nqb;
 	a.nsplit = (int)nsplit;
 	const int grid = nqb * (int)nsplit;
@@ -744,7 +750,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 			double eff = (double)w / (double)(rounds * 512);
 			if (rounds < 2)
 				eff -= 0.05;
-			eff -= 1e-4 * s;
+			eff += 1e-5 * (double)std::min<int64_t>(rounds, 10); // at equal fill: more, shorter rounds balance better (17.6 vs 17.9 ms)
 			if (eff > best) {
 				best = eff;
 				nsplit = s;

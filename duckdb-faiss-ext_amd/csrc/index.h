@@ -172,8 +172,8 @@ public:
 	float pf_max_rel_err = 0.f; // largest observed |approx - exact| / (||x|| ||y||) among re-scored candidates
 	DevBuf ws_pfq, ws_cand, ws_ex, ws_fail, ws_fb;
 	// bf16 coarse filter (csrc/flat_collect.hip): rows as bf16 only, candidate stream, per-query bounds
-	unsigned short *vecs_h1 = nullptr; // [h1_cap + 64][dp] centred rows as bf16
-	float *beta_h1 = nullptr;          // [h1_cap + 64] -||y - mu||^2 (L2) or <mu, y> (inner product)
+	unsigned short *vecs_h1 = nullptr; // [h1_cap + 192][dp] centred rows as bf16
+	float *beta_h1 = nullptr;          // [h1_cap + 192] -||y - mu||^2 (L2) or <mu, y> (inner product)
 	float *mu_h1 = nullptr;            // [dp] the centre (mean of the rows present at the first build)
 	int64_t h1_cap = 0, h1_rows = 0;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0;

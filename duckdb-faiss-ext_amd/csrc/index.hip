@@ -339,11 +339,11 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 		unsigned short *nb = nullptr;
 		float *nbeta = nullptr;
 		const int64_t nc = std::max<int64_t>(cap, ntotal);
-		const size_t nbytes = ((size_t)nc + 64) * geom.dp * sizeof(unsigned short); // + 64 rows: unclamped prefetch
+		const size_t nbytes = ((size_t)nc + 192) * geom.dp * sizeof(unsigned short); // + 192 rows: unclamped prefetch of a 64-row block
 		MVS_HIP(hipMalloc((void **)&nb, nbytes));
-		MVS_HIP(hipMalloc((void **)&nbeta, ((size_t)nc + 64) * sizeof(float)));
+		MVS_HIP(hipMalloc((void **)&nbeta, ((size_t)nc + 192) * sizeof(float)));
 		MVS_HIP(hipMemsetAsync(nb, 0, nbytes, st));
-		MVS_HIP(hipMemsetAsync(nbeta, 0, ((size_t)nc + 64) * sizeof(float), st));
+		MVS_HIP(hipMemsetAsync(nbeta, 0, ((size_t)nc + 192) * sizeof(float), st));
 		if (h1_rows > 0) {
 			MVS_HIP(hipMemcpyAsync(nb, vecs_h1, (size_t)h1_rows * geom.dp * sizeof(unsigned short), hipMemcpyDeviceToDevice, st));
 			MVS_HIP(hipMemcpyAsync(nbeta, beta_h1, (size_t)h1_rows * sizeof(float), hipMemcpyDeviceToDevice, st));
