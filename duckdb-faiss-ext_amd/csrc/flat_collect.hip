@@ -890,11 +890,9 @@ size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq) {
 	return bytes;
 }
 
-// stream (ncand entries) -> per query the kk best exact candidates: pd1 / pi1 [nq][kk] (value, row), best first
-void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
-                            size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
-                            const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
-                            hipStream_t st) {
+// stream (ncand entries of q << 32 | row) -> sorted by query + the segment of every query (d_seg: [2 nq] begin | end)
+void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
+                          size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st) {
 	if (nq <= 0)
 		return;
 	int qbits = 1;
@@ -905,21 +903,42 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
 		MVS_HIP(rocprim::radix_sort_keys(d_temp, temp_bytes, d_stream, d_sorted, (size_t)ncand, 32, 32 + qbits, st));
 		hipLaunchKernelGGL(collect_segments_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, d_sorted,
 		                   (long long)ncand, d_seg, d_seg + nq);
+		MVS_HIP(hipGetLastError());
 	}
-	if (metric == METRIC_L2) {
-		if (ncand > 0)
-			hipLaunchKernelGGL((collect_exact_kernel<true, 128>), dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
-			                   (long long)ncand, d_x, g.d, d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
-		hipLaunchKernelGGL(collect_select_kernel<true>, dim3((unsigned)nq), dim3(64), 0, st, d_sorted, d_seg, d_seg + nq, kk,
-		                   d_pd1, d_pi1);
-	} else {
-		if (ncand > 0)
-			hipLaunchKernelGGL((collect_exact_kernel<false, 128>), dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
-			                   (long long)ncand, d_x, g.d, d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
-		hipLaunchKernelGGL(collect_select_kernel<false>, dim3((unsigned)nq), dim3(64), 0, st, d_sorted, d_seg, d_seg + nq, kk,
-		                   d_pd1, d_pi1);
-	}
+}
+// keys (order-preserving value key << 32 | id) of every query's segment -> the kk best: pd1 / pi1 [nq][kk], best first
+void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,
+                           int32_t *d_pi1, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(collect_select_kernel<true>, dim3((unsigned)nq), dim3(64), 0, st, d_keys, d_seg, d_seg + nq, kk, d_pd1,
+		                   d_pi1);
+	else
+		hipLaunchKernelGGL(collect_select_kernel<false>, dim3((unsigned)nq), dim3(64), 0, st, d_keys, d_seg, d_seg + nq, kk, d_pd1,
+		                   d_pi1);
 	MVS_HIP(hipGetLastError());
+}
+
+// stream (ncand entries) -> per query the kk best exact candidates: pd1 / pi1 [nq][kk] (value, row), best first
+void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
+                            size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
+                            const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
+                            hipStream_t st) {
+	if (nq <= 0)
+		return;
+	launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st);
+	if (ncand > 0) {
+		const dim3 grid((unsigned)((ncand + 63) / 64));
+		if (metric == METRIC_L2)
+			hipLaunchKernelGGL((collect_exact_kernel<true, 128>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
+		else
+			hipLaunchKernelGGL((collect_exact_kernel<false, 128>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
+		MVS_HIP(hipGetLastError());
+	}
+	launch_collect_select(metric, d_sorted, d_seg, nq, kk, d_pd1, d_pi1, st);
 }
 
 } // namespace mvs

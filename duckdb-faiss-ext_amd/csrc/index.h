@@ -310,7 +310,25 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
                             hipStream_t st);
+void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
+                          size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
+void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,
+                           int32_t *d_pi1, hipStream_t st);
 extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl;
+// csrc/ivf_collect.hip
+void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
+                             float *d_beta, unsigned *d_list_max_bits, hipStream_t st);
+size_t ivf_collect_xi_bytes(int max_items);
+void launch_ivf_collect_pack(const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
+                             const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
+                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st);
+void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
+                             const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
+                             unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
+                             int64_t stream_cap, int kk, hipStream_t st);
+void launch_ivf_collect_exact(unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
+                              int dp_csr, const int *d_perm, hipStream_t st);
+void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st);
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,
                               const float *d_xq, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,

@@ -93,6 +93,12 @@ __global__ void ivf_residual_kernel(float *rows, const int *perm, long long n, i
 	if (perm[r] >= 0)
 		rows[i] = __fsub_rn(rows[i], cent[(size_t)list_of_blk64[r >> 6] * d + j]);
 }
+// flagged queries -> list
+__global__ void ivf_compact_flags_kernel(const int *flags, int n, int *cnt, int *out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && flags[i])
+		out[atomicAdd(cnt, 1)] = i;
+}
 __global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *out_bits) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	float v = i < n ? norms[i] : 0.f;
@@ -560,6 +566,17 @@ public:
 				MVS_HIP(hipMemcpyAsync(list_of_blk.p, lob.data(), lob.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
 				hipLaunchKernelGGL(ivf_residual_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, (float *)tmp.p,
 				                   (const int *)dperm.p, (long long)nrows_mf, d, (const int *)list_of_blk.p, (const float *)cent_dev.p);
+				have_bfr = d <= 128;
+				if (have_bfr) { // the coarse filter's view of the same residuals: bf16 rows, -||y'||^2, per-list maximum
+					codes_bfr.reserve(((size_t)nrows_mf + 192) * 128 * sizeof(unsigned short));
+					beta_mf.reserve(((size_t)nrows_mf + 192) * sizeof(float));
+					list_max.reserve((size_t)nlist * sizeof(unsigned));
+					MVS_HIP(hipMemsetAsync(codes_bfr.p, 0, ((size_t)nrows_mf + 192) * 128 * sizeof(unsigned short), stream));
+					MVS_HIP(hipMemsetAsync(beta_mf.p, 0, ((size_t)nrows_mf + 192) * sizeof(float), stream));
+					MVS_HIP(hipMemsetAsync(list_max.p, 0, (size_t)nlist * sizeof(unsigned), stream));
+					launch_ivf_rows_to_bf16((const float *)tmp.p, nrows_mf, d, (const int *)list_of_blk.p,
+					                        (unsigned short *)codes_bfr.p, (float *)beta_mf.p, (unsigned *)list_max.p, stream);
+				}
 				MVS_HIP(hipStreamSynchronize(stream)); // cent / lob are host temporaries
 			}
 			launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
@@ -616,6 +633,13 @@ public:
 		if (k > 256 || force_select) { // beyond the k-list kernels: all distances + segmented sort (csrc/ivf_select.hip)
 			select_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
 			return;
+		}
+		// L2, default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
+		if (metric == METRIC_L2 && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= 16 && d <= 128 &&
+		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26) && (collect_mode > 0 || nq >= 64) &&
+		    !(params && params->sel_kind != MVS_SEL_NONE)) {
+			if (collect_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
+				return;
 		}
 		const bool want_mfma = mfma_mode == 1 || (mfma_mode < 0 && metric == METRIC_IP);
 		const bool small = nq * np < (int64_t)1 << 26;
@@ -762,6 +786,136 @@ public:
 
 	// L2: ITEMS scan with kp = k + 6 candidates per query (every list streamed ONCE for <= 128 of its queries), exact
 	// re-scoring in IVFFlatScanner's arithmetic, proof, re-run of the unproven queries on the scanner kernel
+	// bf16 coarse filter (csrc/ivf_collect.hip).  false: the candidate stream overflowed (the caller uses the scanner kernel).
+	bool collect_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                    const int64_t *d_idmap, hipStream_t st, int64_t np) {
+		build_lists_mf();
+		if (!have_bfr)
+			return false;
+		const int G = 128, shift = 7, kk = (int)k;
+		const int64_t npairs = nq * np;
+		const int max_items = ivf_group_max_items(npairs, nlist, G);
+		ws_items.reserve((size_t)max_items * 16);
+		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
+		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
+		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		ws_xi.reserve(ivf_collect_xi_bytes(max_items));
+		ws_ig.reserve((size_t)max_items * 128 * sizeof(float));
+		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
+		ws_qfail.reserve((size_t)nq * sizeof(int));
+		ws_cimask.reserve((size_t)npairs * sizeof(int64_t));
+		ws_gslot.reserve((size_t)nq * 16 * sizeof(unsigned) + 64);
+		launch_init_slots((unsigned *)ws_gslot.p, nq, 16, METRIC_IP, stream); // "larger s is better": all 16 classes neutral
+		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, (size_t)nq * sizeof(int), stream));
+		const int64_t cap_entries = std::max<int64_t>(nq * 4096, (int64_t)1 << 20);
+		const size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+		ws_stream.reserve(256 + 2 * half);
+		unsigned long long *cnt = (unsigned long long *)ws_stream.p;
+		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
+		unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+		MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
+		memset(&kinfo, 0, sizeof kinfo);
+		// probe rank 0 first (every query's nearest list: it warms the query's bound), then the other nprobe - 1 ranks
+		for (int phase = 0; phase < 2; ++phase) {
+			if (phase == 1 && np == 1)
+				break;
+			launch_ivf_mask_probes((const int64_t *)ws_cI.p, nq, (int)np, phase == 0 ? 0 : 1, phase == 0 ? 1 : (int)np,
+			                       (int64_t *)ws_cimask.p, stream);
+			int *d_nitems = nullptr, *d_cnt = nullptr;
+			launch_ivf_group((const int64_t *)ws_cimask.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
+			                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
+			                 &d_nitems, &d_cnt, stream);
+			launch_ivf_collect_pack(d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
+			                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
+			                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream);
+			if (phase == 1 || np == 1)
+				begin_kernel_timing(stream);
+			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
+			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, stream);
+			if (phase == 1 || np == 1)
+				end_kernel_timing(stream);
+		}
+		// queries without a finite bound -> fail list
+		ws_fail.reserve(64 + (size_t)nq * sizeof(int));
+		int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
+		MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), stream));
+		hipLaunchKernelGGL(ivf_compact_flags_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
+		                   (const int *)ws_qfail.p, (int)nq, fail_cnt, fail_q);
+		if (!h_fail)
+			MVS_HIP(hipHostMalloc((void **)&h_fail, 64, hipHostMallocDefault));
+		MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+		MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+		MVS_HIP(hipStreamSynchronize(stream));
+		unsigned long long ncand_u;
+		memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
+		const int64_t ncand = (int64_t)ncand_u;
+		if (ncand > cap_entries) {
+			++cl_overflows;
+			return false;
+		}
+		cl_queries_total += nq;
+		cl_candidates_total += ncand;
+		const size_t temp = ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0;
+		ws_sorttmp.reserve(std::max<size_t>(temp, 16));
+		ws_seg.reserve((size_t)2 * nq * sizeof(int));
+		const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
+		ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
+		float *pd1 = (float *)ws_ex.p;
+		int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
+		launch_collect_group(strm, sorted, ncand, ws_sorttmp.p, temp, nq, (int *)ws_seg.p, stream);
+		launch_ivf_collect_exact(sorted, ncand, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream);
+		launch_collect_select(METRIC_L2, sorted, (const int *)ws_seg.p, nq, kk, pd1, pi1, stream);
+		// the k best by (value, position in the list-sorted store), labels = stored ids (then the id map of an IDMap wrapper)
+		launch_merge_partials(metric, pd1, pi1, 1, nq, kk, (const int64_t *)rowids.p, 0, d_D, d_I, stream, k, nullptr);
+		if (d_idmap && !raw_ids) {
+			const long long tot = (long long)nq * k;
+			hipLaunchKernelGGL(ivf_map_labels_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+			                   (long long *)d_I, tot, (const long long *)d_idmap);
+		}
+		snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel");
+		kinfo.grid = max_items;
+		kinfo.block = 64;
+		kinfo.nsplit = (int)np;
+		kinfo.bytes = (double)nrows_mf * 256.0;               // every list's bf16 rows once (each list is probed by >= 1 item)
+		kinfo.flops = (double)nq * np * ((double)nsorted / nlist) * d * 2.0; // (average list length)
+		const int nf = *h_fail;
+		pf_queries_total += nq;
+		pf_fallback_total += nf;
+		if (nf > 0) { // re-run on the scanner kernel with the same coarse assignment
+			const mvs_kernel_info keep = kinfo;
+			const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
+			const size_t df_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
+			ws_fb.reserve(xf_bytes + df_bytes + (size_t)nf * k * sizeof(int64_t));
+			float *xf = (float *)ws_fb.p;
+			float *Df = (float *)((char *)ws_fb.p + xf_bytes);
+			int64_t *If = (int64_t *)((char *)Df + df_bytes);
+			launch_gather_query_rows(d_x, d, fail_q, nf, xf, stream);
+			DevBuf csub;
+			csub.reserve((size_t)nf * np * sizeof(int64_t));
+			launch_gather_query_rows((const float *)ws_cI.p, (int)(2 * np), fail_q, nf, (float *)csub.p, stream);
+			MVS_HIP(hipMemcpyAsync(ws_cI.p, csub.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+			pf_suppressed = true;
+			reuse_coarse = true;
+			const bool timing = timing_enabled;
+			timing_enabled = false;
+			try {
+				search_mapped(nf, xf, k, Df, If, params, d_idmap, stream);
+			} catch (...) {
+				pf_suppressed = reuse_coarse = false;
+				timing_enabled = timing;
+				throw;
+			}
+			pf_suppressed = reuse_coarse = false;
+			timing_enabled = timing;
+			MVS_HIP(hipStreamSynchronize(stream)); // csub is freed at scope exit
+			launch_scatter_rows(fail_q, nf, k, Df, If, d_D, d_I, stream);
+			kinfo = keep;
+		}
+		stream_wait(st, stream);
+		return true;
+	}
+
 	void mfma_prefilter_search(int64_t nq, const float *d_x, int64_t k, int kp, float *d_D, int64_t *d_I,
 	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, int64_t np) {
 		build_lists_mf();
@@ -1114,6 +1268,10 @@ public:
 		timing_enabled = on;
 	}
 	bool set_option(const char *key, int64_t v) override {
+		if (!strcmp(key, "ivf_collect")) {
+			collect_mode = (int)v;
+			return true;
+		}
 		if (!strcmp(key, "ivf_mfma")) {
 			mfma_mode = (int)v;
 			return true;
@@ -1135,6 +1293,7 @@ public:
 	bool use_fast_scan = true;
 	bool force_select = false;
 	bool raw_ids = false;
+	int collect_mode = -1; // option ivf_collect: -1 auto, 0 never, 1 wherever the kernel exists (L2, d <= 128, k <= 16)
 	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always, 2 = L2 prefilter + exact re-scoring
 
 	// introspection for parity tests
@@ -1162,6 +1321,10 @@ private:
 	int64_t nrows_mf = 0;
 	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf, cent_dev, list_of_blk, perm_mf, ws_iqn, ws_qmaxn;
 	bool mf_residual = false;
+	// bf16 coarse filter (csrc/ivf_collect.hip): residual rows as bf16, -||y'||^2, the largest ||y'||^2 of every list
+	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask;
+	bool have_bfr = false;
+	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb;
 	int *h_fail = nullptr; // pinned
 	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel

@@ -1,0 +1,543 @@
+// csrc/ivf_collect.hip -- bf16 COARSE FILTER for the IVFFlat list scan (L2): the flat_collect.hip argument on inverted lists.
+//
+// Same place in the path as ivf_scan.hip (IndexIVF::search_preassigned + IVFFlatScanner::scan_codes behind
+// /root/reference/src/faiss_extension.cpp:631) and the same results: labels and distances are those of the scanner kernel
+// and of oracle/orc_core.c's IVF restatement, bit for bit away from exact distance ties.
+//
+//   rows        list by list (every list padded to a multiple of 64 rows), as RESIDUALS y' = y - c_list in bf16, with
+//               beta(row) = -||y'||^2 in f32; the residual against the list's own centroid is the natural centring: the error
+//               of a bf16 product scales with ||x'|| ||y'|| = (distance to the centroid)^2-sized numbers, not with ||x|| ||y||
+//   work item   (list, <= 128 of the queries that probe it) = ONE wavefront; its queries enter as bf16(2 (x - c_list)) with
+//               gamma(slot) = -||x - c_list||^2, and the MFMA chain starts at C = beta(row) + gamma(slot):
+//               s = 2 <x', y'> - ||y'||^2 - ||x'||^2 = -||x - y||^2 (approximately), comparable across the lists of a query
+//   bound       |s - s_exact| <= E(slot) from ||x'||, the list's largest ||y'|| and d (ivf_collect_pack_kernel); the running
+//               bound B(q) = kk-th best of 16 row classes, shared by all items of the query through the class slots; every row
+//               with s >= B - 2E is a candidate (flat_collect.hip, "candidates")
+//   re-scoring  the candidates are grouped by query, recomputed with the scanner's arithmetic (t = x_k - y_k, acc = fmaf(t, t,
+//               acc), k ascending, on the ORIGINAL f32 rows) and the k best by (value, position in the list-sorted store)
+//               are kept -- the order of ivf_scan_kernel + merge_items_kernel.
+// The probe-0 list of every query is scanned first (one launch), which warms the bounds for the other nprobe - 1.
+#include "flat_fused.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace mvs {
+
+typedef __bf16 bf16x8i __attribute__((ext_vector_type(8)));
+typedef float f32x4i __attribute__((ext_vector_type(4)));
+typedef float f32x2i __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_f32i;
+typedef __attribute__((address_space(1))) const float glb_f32i;
+
+constexpr int IC_BN = 32;    // rows per tile
+constexpr int IC_QCAP = 256; // candidate queue of a work item (entries of 8 bytes)
+
+struct IvfCollectArgs {
+	const int4 *items;         // {row_begin (multiple of 64, padded row space), row_end, qoff, nq_item <= 128}
+	const int *nitems_dev;     // device-side item count; the grid is an upper bound
+	const int *qidx;           // query number of slot qoff + s
+	const void *xi;            // [item][8 column blocks][4 k-blocks][64 lanes] x 16 bytes: bf16(2 (x - c)) fragments
+	const float *igamma;       // [item][128] -||x - c||^2
+	const float *ie2;          // [item][128] 2E (NaN: the slot is empty / the query is not served here)
+	const unsigned short *yb;  // bf16 residual rows [nrows_mf + 192][128]
+	const float *beta;         // [nrows_mf + 192] -||y'||^2
+	unsigned *gslot;           // [nq][16] class slots
+	unsigned long long *stream; // candidates (q << 32 | padded row)
+	unsigned long long *stream_cnt;
+	long long stream_cap;
+	int kk;
+};
+
+__device__ __forceinline__ unsigned ic_skey(float s) { // "larger s is better" as a smaller-is-better key
+	return ~f2key(s);
+}
+__device__ __forceinline__ float ic_skey2f(unsigned k) {
+	return key2f(~k);
+}
+template <int CTRL>
+__device__ __forceinline__ float ic_dpp(float v) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// ---- storage: residual rows [n][d] f32 (padding rows are zero) -> bf16 [n][128] + beta + the largest ||y'||^2 of every list
+__global__ void ivf_rows_to_bf16_kernel(const float *__restrict__ src, long long nrows, int d,
+                                        const int *__restrict__ list_of_blk64, unsigned short *__restrict__ dst,
+                                        float *__restrict__ beta, unsigned *__restrict__ list_max_bits) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one (row, 8 dims); 16 neighbours share a row
+	const bool live = i < nrows * 16;
+	const long long r = live ? i >> 4 : 0;
+	const int c8 = (int)(i & 15);
+	bf16x8i hi;
+	float n2 = 0.f;
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		const int kk = c8 * 8 + e;
+		const float v = (live && kk < d) ? src[(size_t)r * d + kk] : 0.f;
+		hi[e] = (__bf16)v;
+		n2 = fmaf(v, v, n2);
+	}
+	n2 += ic_dpp<0xB1>(n2);
+	n2 += ic_dpp<0x4E>(n2);
+	n2 += ic_dpp<0x141>(n2);
+	n2 += ic_dpp<0x140>(n2);
+	if (!live)
+		return;
+	*(bf16x8i *)(dst + (size_t)r * 128 + c8 * 8) = hi;
+	if (c8 == 0) {
+		beta[r] = -n2;
+		unsigned *m = list_max_bits + list_of_blk64[r >> 6];
+		const unsigned b = __float_as_uint(n2); // (>= 0 or NaN: the bit pattern orders like the value)
+		if (b > *m)
+			atomicMax(m, b);
+	}
+}
+void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
+                             float *d_beta, unsigned *d_list_max_bits, hipStream_t st) {
+	if (nrows <= 0)
+		return;
+	const long long total = (long long)nrows * 16;
+	hipLaunchKernelGGL(ivf_rows_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_res,
+	                   (long long)nrows, d, d_list_of_blk64, d_bf, d_beta, d_list_max_bits);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- per item: query fragments, gamma, 2E ------------------------------------------------------------------------------
+// Error bound, in "s" units (s_exact = -D_oracle, the scanner's value), u = 2^-24, S' = ||x'|| ||y'||_max(list), norms inflated
+// by 1e-4 for their own rounding:
+//   bf16 rounding of both operands (the query operand carries the exact factor 2):        2 (2^-8 + 2^-18) S'
+//   MFMA accumulation from C = beta + gamma (4 ulp-units of the magnitudes per instruction, counted as d / 16 instructions,
+//   1.25 safety factor as in flat_collect.hip):                                            1.25 (d/16) 4u ((1 + 2^-7) 2 S' + xn' + yn'_max)
+//   C = fl(beta + gamma), beta and gamma d-term f32 chains:                               (d + 1) u (xn' + yn'_max)
+//   the scanner's value: D = sum fl((x_k - y_k)^2) accumulated in f32, on x' - y' = x - y up to one rounding per component of
+//   each residual:                                                                        (d + 8) u (||x'|| + ||y'||_max)^2
+//   E = the sum; e2 = 2 E (1 + 2^-10) + slack.  Non-finite -> NaN (the query is re-run on the scanner kernel).
+__global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__restrict__ x, int d, const int4 *__restrict__ items,
+                                                             const int *__restrict__ nitems_dev, const int *__restrict__ qidx,
+                                                             const float *__restrict__ cent,
+                                                             const int *__restrict__ list_of_blk64,
+                                                             const unsigned *__restrict__ list_max_bits,
+                                                             bf16x8i *__restrict__ xi, float *__restrict__ igamma,
+                                                             float *__restrict__ ie2, int *__restrict__ qfail) {
+	if ((int)blockIdx.x >= *nitems_dev)
+		return;
+	const int4 it = items[blockIdx.x];
+	const int l = list_of_blk64[it.x >> 6]; // every list starts at a multiple of 64 rows
+	const float *c = cent + (size_t)l * d;
+	bf16x8i *dst = xi + (size_t)blockIdx.x * (8 * 4 * 64);
+	for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) { // (column block, k-block, lane)
+		const int lane = i & 63, kb = (i >> 6) & 3, cb = i >> 8;
+		const int slot = cb * 16 + (lane & 15);
+		bf16x8i v;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			const int kk = kb * 32 + 8 * (lane >> 4) + e;
+			float o = 0.f;
+			if (slot < it.w && kk < d)
+				o = 2.0f * __fsub_rn(x[(size_t)qidx[it.z + slot] * d + kk], c[kk]);
+			v[e] = (__bf16)o;
+		}
+		dst[i] = v;
+	}
+	if (threadIdx.x < 128) {
+		const int slot = threadIdx.x;
+		float g = 0.f, e2 = __uint_as_float(0x7fc00000u);
+		if (slot < it.w) {
+			const int q = qidx[it.z + slot];
+			float xn = 0.f;
+			for (int kk = 0; kk < d; ++kk) {
+				const float r = __fsub_rn(x[(size_t)q * d + kk], c[kk]);
+				xn = fmaf(r, r, xn);
+			}
+			g = -xn;
+			const float yn = __uint_as_float(list_max_bits[l]);
+			const double u = 5.9604644775390625e-08, infl = 1.0001;
+			const double nx = sqrt((double)xn * infl), ny = sqrt((double)yn * infl), S = nx * ny;
+			const double E = 2.0 * (0.00390625 + 3.814697265625e-06) * S +
+			                 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * 2.0 * S + (double)xn + yn) +
+			                 ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
+			const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn) + 1e-30);
+			if (isfinite(xn) && isfinite(yn) && isfinite(r) && r < 1e30f)
+				e2 = r;
+			else
+				qfail[q] = 1;
+		}
+		igamma[(size_t)blockIdx.x * 128 + slot] = g;
+		ie2[(size_t)blockIdx.x * 128 + slot] = e2;
+	}
+}
+size_t ivf_collect_xi_bytes(int max_items) {
+	return (size_t)max_items * 8 * 4 * 64 * 16;
+}
+void launch_ivf_collect_pack(const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
+                             const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
+                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st) {
+	if (max_items <= 0)
+		return;
+	hipLaunchKernelGGL(ivf_collect_pack_kernel, dim3(max_items), dim3(256), 0, st, d_x, d, (const int4 *)d_items, d_nitems,
+	                   d_qidx, d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- the scan kernel: one wavefront per work item -----------------------------------------------------------------------
+// MFMA geometry, LDS layout of a tile, half-tile pipeline and rare path as flat_bf16_collect_kernel (csrc/flat_collect.hip);
+// what differs: the wave stages its own tiles (8 LDS-DMA instructions per 32-row tile), the chain starts at beta + gamma, the
+// bounds of the item's 128 slots live in an LDS table {B - 2E, gamma} that the wave refreshes itself.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollectArgs a) {
+	constexpr int KB = 4, PITCH = 256, TILE_BYTES = IC_BN * PITCH;
+	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 4 + 64) / 4];
+	char *tbuf = (char *)smem;                                        // [2][TILE_BYTES]
+	float *nbuf = (float *)(tbuf + 2 * TILE_BYTES);                   // [2][64] beta of the tile's rows
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [IC_QCAP] candidate queue
+	float *ctab = (float *)(qbuf + IC_QCAP);                          // [4 t][16 c][2 i]{B - 2E, gamma}
+	int *qtab = (int *)(ctab + 128 * 2);                              // [128] query number of every slot
+	unsigned *qctl = (unsigned *)(qtab + 128);                        // [0] queue fill
+
+	if ((int)blockIdx.x >= *a.nitems_dev)
+		return;
+	const int4 it = a.items[blockIdx.x];
+	const int lane = threadIdx.x;
+	const int hq = lane >> 4, c = lane & 15;
+	const long long r_begin = it.x, r_end = it.y;
+	const int ntiles = (int)((r_end - r_begin + IC_BN - 1) / IC_BN);
+	if (lane == 0)
+		qctl[0] = 0u;
+
+	// the lane OWNS (bound refresh) slots 32 hq + 16 i + c, i = 0, 1, i.e. column blocks 2 hq + i = the two blocks of tile t = hq
+	int own_q[2];
+	float own_e2[2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+		const int slot = 32 * hq + 16 * i + c;
+		own_q[i] = slot < it.w ? a.qidx[it.z + slot] : -1;
+		own_e2[i] = a.ie2[(size_t)blockIdx.x * 128 + slot];
+		qtab[slot] = own_q[i];
+		ctab[((hq * 16 + c) * 2 + i) * 2 + 1] = a.igamma[(size_t)blockIdx.x * 128 + slot];
+	}
+
+	// B fragments, resident: [column block][k-block]
+	bf16x8i bq[8][KB];
+	{
+		const bf16x8i *qsrc = (const bf16x8i *)a.xi + (size_t)blockIdx.x * (8 * 4 * 64);
+#pragma unroll
+		for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+			for (int kb = 0; kb < KB; ++kb)
+				bq[cb][kb] = qsrc[(cb * 4 + kb) * 64 + lane];
+	}
+
+	// LDS-DMA staging by this one wave: instruction i of a tile fills LDS bytes [1024 i, +1024) = rows 4 i + (l >> 4), position
+	// l & 15, and fetches the row's chunk (l & 15) ^ (row & 15): four loop-invariant lane offsets (i & 3), + 4096 for i >= 4
+	unsigned dma_off[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int rr = 4 * i + (lane >> 4);
+		dma_off[i] = (unsigned)(rr * PITCH + (((lane & 15) ^ rr) * 16));
+	}
+	auto dma_tile = [&](int u) {
+		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)u * IC_BN) * PITCH; // uniform
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			__builtin_amdgcn_global_load_lds((glb_f32i *)(base + (i >> 2) * 4096 + dma_off[i & 3]),
+			                                 (lds_f32i *)(smem + ((u & 1) * TILE_BYTES + i * 1024) / 4), 16, 0, 0);
+		const float *bb = a.beta + (r_begin + (long long)u * IC_BN); // uniform
+		__builtin_amdgcn_global_load_lds((glb_f32i *)(bb + lane), (lds_f32i *)(smem + (2 * TILE_BYTES) / 4 + (u & 1) * 64), 4, 0, 0);
+	};
+	if (ntiles > 0)
+		dma_tile(0);
+	__syncthreads();
+
+	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)(((hq ^ c) & 15) * 16);
+	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
+	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+	const unsigned qtab_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int *)qtab);
+	const unsigned ct_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)ctab) + (unsigned)(c * 16);
+
+	// flush the candidate queue to the global stream (the whole wave; by hand: no compiled atomic with a result in the loop)
+	auto flush = [&](unsigned n) {
+		unsigned long long base = 0ull;
+		if (lane == 0) {
+			const unsigned long long n64 = n;
+			typedef __attribute__((address_space(1))) unsigned long long *GUL;
+			asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+			             : "=&v"(base)
+			             : "v"((GUL)a.stream_cnt), "v"(n64)
+			             : "memory");
+		}
+		const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+		const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+		const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
+		for (unsigned i = lane; i < n; i += 64) {
+			unsigned long long ent;
+			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ent) : "v"(qbuf_lds + 8u * i) : "memory");
+			if ((long long)(b + i) < a.stream_cap) {
+				typedef __attribute__((address_space(1))) unsigned long long *GUL;
+				*((GUL)a.stream + (b + i)) = ent;
+			}
+		}
+		if (lane == 0) {
+			const unsigned zero = 0u;
+			asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(qcnt_lds), "v"(zero) : "memory");
+		}
+	};
+
+	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid) {
+		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+			return;
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const float c0 = cg[2 * i];
+			unsigned m = 0u;
+			if (any_t) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (16 * rb + 4 * hq + r < nvalid && sv[i][r] >= c0)
+						m |= 1u << r;
+			}
+			if (m == 0u)
+				continue;
+			int q;
+			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q) : "v"(qtab_lds + (unsigned)((32 * t + 16 * i + c) * 4)) : "memory");
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
+				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
+				const float v = (j & 2) ? hi : lo;
+				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
+				typedef __attribute__((address_space(1))) unsigned *GU;
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), ic_skey(v), __ATOMIC_RELAXED,
+				                       __HIP_MEMORY_SCOPE_AGENT);
+				unsigned pos;
+				const unsigned one = 1u;
+				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+				const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+				if (pos < (unsigned)IC_QCAP) {
+					asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+				} else { // a burst beyond the queue (cold start): straight to the stream
+					unsigned long long gp;
+					const unsigned long long one64 = 1ull;
+					typedef __attribute__((address_space(1))) unsigned long long *GUL;
+					asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+					             : "=&v"(gp)
+					             : "v"((GUL)a.stream_cnt), "v"(one64)
+					             : "memory");
+					if ((long long)gp < a.stream_cap)
+						*((GUL)a.stream + gp) = ent;
+				}
+			}
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	};
+
+	for (int u = 0; u < ntiles; ++u) {
+		// bounds of the 128 slots: B = the kk-th best of the query's 16 class bests (bitonic network), table entry = B - 2E
+		const int period = u < 4 ? 1 : (u < 32 ? 4 : 16);
+		if ((u % period) == 0) {
+			unsigned long long w[2][8];
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				const int qc = own_q[i] >= 0 ? own_q[i] : 0;
+				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					w[i][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					asm volatile("" : "+v"(w[i][j]));
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				unsigned key[16];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					key[2 * j] = (unsigned)w[i][j];
+					key[2 * j + 1] = (unsigned)(w[i][j] >> 32);
+				}
+#pragma unroll
+				for (int kbit = 2; kbit <= 16; kbit <<= 1)
+#pragma unroll
+					for (int jb = kbit >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+						for (int x0 = 0; x0 < 16; ++x0) {
+							const int x1 = x0 ^ jb;
+							if (x1 > x0) {
+								const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
+								const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
+								const bool asc = (x0 & kbit) == 0;
+								key[x0] = asc ? lo : hi;
+								key[x1] = asc ? hi : lo;
+							}
+						}
+				unsigned kth = key[0];
+#pragma unroll
+				for (int j = 1; j < 16; ++j)
+					kth = (a.kk - 1 == j) ? key[j] : kth;
+				const unsigned neutral = ic_skey(-FLT_MAX);
+				const float B = ic_skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
+				const float v = own_q[i] >= 0 ? B - own_e2[i] : __uint_as_float(0x7fc00000u); // NaN: nothing passes
+				ctab[((hq * 16 + c) * 2 + i) * 2 + 0] = v;
+			}
+		}
+		bf16x8i A[KB][2];
+		f32x4i Y[2];
+		{
+			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32i *)(nbuf + (u & 1) * 64 + 4 * hq));
+			asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(Y[0]), "=&v"(Y[1]) : "v"(nb_lds) : "memory");
+			const unsigned ab = (unsigned)(uintptr_t)((lds_f32i *)(smem + ((u & 1) * TILE_BYTES) / 4)) + rbase;
+#pragma unroll
+			for (int kb = 0; kb < KB; ++kb) {
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[kb][0]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
+				asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A[kb][1]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
+			}
+		}
+		dma_tile(u + 1);
+		const long long row0 = r_begin + (long long)u * IC_BN;
+		const int nvalid = (int)((r_end - row0) < IC_BN ? (r_end - row0) : IC_BN);
+
+		f32x4a acc[2][2]; // [row block][column block of the tile]
+		f32x4i cg[2];     // {B - 2E, gamma} x 2 column blocks of tile t in cg[t & 1]
+		float mx0 = -INFINITY, mx1 = -INFINITY;
+		auto fold = [&](const f32x4a &p, int i) {
+			if (i == 0)
+				mx0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx0, p[0]), p[1]), p[2]), p[3]);
+			else
+				mx1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mx1, p[0]), p[1]), p[2]), p[3]);
+		};
+		auto any_of = [&](f32x4i cgp) { // NaN on either side: false
+			const bool r = (mx0 >= cgp[0]) || (mx1 >= cgp[2]);
+			mx0 = -INFINITY;
+			mx1 = -INFINITY;
+			return r;
+		};
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			asm volatile("ds_read_b128 %0, %1" : "=v"(cg[t & 1]) : "v"(ct_lds + (unsigned)(t * 256)) : "memory");
+#pragma unroll
+			for (int rb = 0; rb < 2; ++rb) {
+				const int prb = rb ^ 1, pt = rb == 0 ? t - 1 : t; // the half folded under this one
+				if (rb == 0) // the tile's table entry (and at t = 0: beta, every fragment) has arrived
+					asm volatile("s_waitcnt lgkmcnt(0)"
+					             : "+v"(cg[0]), "+v"(cg[1]), "+v"(Y[0]), "+v"(Y[1]), "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]),
+					               "+v"(A[1][1]), "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[3][0]), "+v"(A[3][1]));
+				// the chain starts at beta(row) + gamma(slot): s = 2 <x', y'> - ||y'||^2 - ||x'||^2 comes out of the matrix pipe
+				f32x4a c0v = Y[rb] + cg[t & 1][1], c1v = Y[rb] + cg[t & 1][3];
+#pragma unroll
+				for (int kb = 0; kb < KB; ++kb) {
+					acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb][rb], bq[2 * t + 0][kb], kb == 0 ? c0v : acc[rb][0], 0, 0, 0);
+					acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb][rb], bq[2 * t + 1][kb], kb == 0 ? c1v : acc[rb][1], 0, 0, 0);
+					if (pt >= 0 && kb < 2)
+						fold(acc[prb][kb], kb);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				if (pt >= 0)
+					rare(acc[prb], prb, pt, any_of(cg[pt & 1]), cg[pt & 1], row0, nvalid);
+			}
+		}
+		fold(acc[1][0], 0);
+		fold(acc[1][1], 1);
+		rare(acc[1], 1, 3, any_of(cg[1]), cg[1], row0, nvalid);
+		__syncthreads(); // one wave: drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
+		unsigned fill;
+		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fill) : "v"(qcnt_lds) : "memory");
+		fill = (unsigned)__builtin_amdgcn_readfirstlane((int)fill);
+		if (fill >= (unsigned)IC_QCAP / 2 || (u == ntiles - 1 && fill > 0))
+			flush(fill < (unsigned)IC_QCAP ? fill : (unsigned)IC_QCAP);
+	}
+}
+
+void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
+                             const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
+                             unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
+                             int64_t stream_cap, int kk, hipStream_t st) {
+	if (max_items <= 0)
+		return;
+	IvfCollectArgs a;
+	memset(&a, 0, sizeof a);
+	a.items = (const int4 *)d_items;
+	a.nitems_dev = d_nitems;
+	a.qidx = d_qidx;
+	a.xi = d_xi;
+	a.igamma = d_igamma;
+	a.ie2 = d_ie2;
+	a.yb = d_rows_bf;
+	a.beta = d_beta;
+	a.gslot = d_gslot;
+	a.stream = d_stream;
+	a.stream_cnt = d_stream_cnt;
+	a.stream_cap = stream_cap;
+	a.kk = kk;
+	hipLaunchKernelGGL(ivf_bf16_collect_kernel, dim3(max_items), dim3(64), 0, st, a);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- candidates -> exact values (the scanner's arithmetic) ----------------------------------------------------------------
+// One wave per 64 candidates of the query-sorted stream; rows (ORIGINAL f32, list-sorted plain store, row = perm[padded row])
+// staged through LDS with coalesced loads (row pitch + 4 floats: conflict-free reads of one row per lane); lane <-> candidate: t = x_k - y_k, acc = fmaf(t, t, acc), k ascending.  The entry
+// becomes (order-preserving value key << 32) | position in the list-sorted store; values that cannot enter FAISS's heap (not
+// < FLT_MAX; NaN) become EMPTY.
+__global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long long *__restrict__ sorted, long long ncand,
+                                                              const float *__restrict__ x, int d,
+                                                              const float *__restrict__ rows_csr, int dp,
+                                                              const int *__restrict__ perm) {
+	__shared__ __attribute__((aligned(16))) float rows[64 * (128 + 4)];
+	const int pitch = dp + 4, cpr = dp / 4; // floats per LDS row (bank spread), float4 chunks per row
+	const int lane = threadIdx.x;
+	const long long i = (long long)blockIdx.x * 64 + lane;
+	const unsigned long long ent = i < ncand ? sorted[i] : 0ull;
+	const long long q = (long long)(ent >> 32);
+	const int pos = i < ncand ? perm[(unsigned)ent] : 0;
+	for (int it = 0; it < cpr; ++it) { // 64 consecutive float4 of the 64 x cpr block per step
+		const int idx = it * 64 + lane, r = idx / cpr, ch = idx - r * cpr;
+		const int pp = __shfl(pos, r);
+		const float4 v = *(const float4 *)(rows_csr + (size_t)(pp < 0 ? 0 : pp) * dp + ch * 4);
+		*(float4 *)(rows + r * pitch + ch * 4) = v;
+	}
+	__syncthreads();
+	if (i >= ncand)
+		return;
+	const float *y = rows + lane * pitch;
+	const float *xq = x + q * d;
+	float acc = 0.f;
+	for (int kk = 0; kk < d; ++kk) {
+		const float t = __fsub_rn(xq[kk], y[kk]);
+		acc = fmaf(t, t, acc);
+	}
+	const bool ok = pos >= 0 && acc < FLT_MAX;
+	sorted[i] = ok ? (((unsigned long long)f2key(acc) << 32) | (unsigned)pos) : ~0ull;
+}
+// dp_csr: row pitch of the list-sorted f32 store (floats; a multiple of 4, <= 128)
+void launch_ivf_collect_exact(unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
+                              int dp_csr, const int *d_perm, hipStream_t st) {
+	if (ncand <= 0)
+		return;
+	if (dp_csr % 4 != 0 || dp_csr > 128)
+		throw_faiss("mvs::launch_ivf_collect_exact", __FILE__, "row pitch %d is not served", dp_csr);
+	hipLaunchKernelGGL(ivf_collect_exact_kernel, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
+	                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm);
+	MVS_HIP(hipGetLastError());
+}
+
+// keep only one probe rank range of the coarse labels: out[q][p] = (lo <= p < hi) ? in[q][p] : -1
+__global__ void ivf_mask_probes_kernel(const long long *__restrict__ in, long long total, int np, int lo, int hi,
+                                       long long *__restrict__ out) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total)
+		return;
+	const int p = (int)(i % np);
+	out[i] = (p >= lo && p < hi) ? in[i] : -1;
+}
+void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st) {
+	const long long total = (long long)nq * np;
+	if (total <= 0)
+		return;
+	hipLaunchKernelGGL(ivf_mask_probes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const long long *)d_in,
+	                   total, np, lo, hi, (long long *)d_out);
+	MVS_HIP(hipGetLastError());
+}
+
+} // namespace mvs

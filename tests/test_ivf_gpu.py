@@ -216,7 +216,7 @@ def test_ivf_l2_mfma_mode_is_recall_equivalent(mf):
     De, Ie = g.search(xq, 10, nprobe=8)
     # default for L2: the scanner's arithmetic -- directly (small batches) or as the exact re-scoring behind the MFMA
     # prefilter (batches of >= 64 queries, csrc/ivf.hip mfma_prefilter_search); same bits either way
-    assert g.last_kernel_info()["name"].startswith(("ivf_scan_kernel", "ivf_mfma_prefilter"))
+    assert g.last_kernel_info()["name"].startswith(("ivf_scan_kernel", "ivf_mfma_prefilter", "ivf_bf16_collect"))
     g.set_option("ivf_mfma", 1)
     Dm, Im = g.search(xq, 10, nprobe=8)
     assert g.last_kernel_info()["name"].startswith("ivf_mfma_scan")
@@ -383,3 +383,55 @@ def test_ivf_select_path_equals_k_list_path_at_small_k(mf):
     D1, I1 = g.search(xq, 50, nprobe=4)
     assert g.last_kernel_info()["name"].startswith("ivf_select")
     assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
+
+
+@pytest.mark.parametrize("idmap", [False, True])
+@pytest.mark.parametrize("d,nlist,n,nq,k,nprobe", [(128, 64, 60000, 500, 10, 8), (64, 16, 20000, 200, 5, 16), (96, 32, 30000, 64, 16, 4),
+                                                   (128, 32, 50000, 300, 1, 1), (100, 48, 40000, 777, 10, 48)])
+def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, nprobe, idmap):
+    """default for L2 batches of >= 64 queries, k <= 16 (option ivf_collect): bf16 coarse filter on residual rows with a
+    proven bound + exact re-scoring in IVFFlatScanner's arithmetic (csrc/ivf_collect.hip); must equal the plain scanner
+    kernel and the oracle bit for bit, also on duplicate-heavy data (all tied rows are candidates) and with an id map"""
+    xb = orc.synth_clustered(n, d, 31, n_centers=nlist, sigma=0.2)
+    xq = orc.synth_clustered(nq, d, 32, n_centers=nlist, sigma=0.2)
+    xb[n // 2 :: 7] = xb[: len(xb[n // 2 :: 7])]  # duplicates: exact distance ties near the top
+    xq[: nq // 4] = xb[5 : 5 + nq // 4]
+    ids = (np.arange(n, dtype=np.int64) * 3 + 11)
+    desc = ("IDMap," if idmap else "") + f"IVF{nlist},Flat"
+    g, o = mf.index_factory(d, desc, L2), orc.Index(d, desc, L2)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    for a in (g, o):
+        a.add_with_ids(xb, ids)
+    D1, I1 = g.search(xq, k, nprobe=nprobe)
+    assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+    g.set_option("ivf_collect", 0)
+    D0, I0 = g.search(xq, k, nprobe=nprobe)
+    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+    Do, Io = o.search(xq, k, nprobe=nprobe)
+    ok = _no_tie_rows(Do)
+    assert ok.sum() >= 1
+    assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32))
+    assert np.array_equal(I1[ok], I0[ok]) and np.array_equal(I1[ok], Io[ok])
+    # a selector search stays on the scanner kernel
+    g.set_option("ivf_collect", -1)
+    D2, I2 = g.search(xq, k, nprobe=nprobe, sel=("batch", ids[::2]))
+    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+
+
+def test_l2_coarse_filter_non_finite_queries_fall_back(mf):
+    d, nlist, n = 128, 16, 20000
+    xb = orc.synth_clustered(n, d, 5, n_centers=nlist, sigma=0.2)
+    xq = orc.synth_clustered(100, d, 6, n_centers=nlist, sigma=0.2)
+    xq[3, 7] = np.nan
+    xq[9] *= 1e19
+    g, o = mf.index_factory(d, f"IVF{nlist},Flat", L2), orc.Index(d, f"IVF{nlist},Flat", L2)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    g.add(xb)
+    o.add(xb)
+    D1, I1 = g.search(xq, 10, nprobe=4)
+    assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+    g.set_option("ivf_collect", 0)
+    D0, I0 = g.search(xq, 10, nprobe=4)
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
