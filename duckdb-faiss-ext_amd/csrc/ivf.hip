@@ -815,25 +815,31 @@ public:
 		unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 		MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
 		memset(&kinfo, 0, sizeof kinfo);
-		// probe rank 0 first (every query's nearest list: it warms the query's bound), then the other nprobe - 1 ranks
+		// pre-pass: the first 256 rows of every query's nearest list, publish only (warms the query's bound); then every probed
+		// list in segments of 512 rows, one wavefront per (work item, segment)
+		int64_t max_list = 0;
+		for (int64_t l = 0; l < nlist; l++)
+			max_list = std::max(max_list, list_off[(size_t)l + 1] - list_off[(size_t)l]);
+		const int seg_rows = 512, nseg = (int)((max_list + seg_rows - 1) / seg_rows);
 		for (int phase = 0; phase < 2; ++phase) {
-			if (phase == 1 && np == 1)
-				break;
-			launch_ivf_mask_probes((const int64_t *)ws_cI.p, nq, (int)np, phase == 0 ? 0 : 1, phase == 0 ? 1 : (int)np,
-			                       (int64_t *)ws_cimask.p, stream);
+			const int64_t *keys = (const int64_t *)ws_cI.p;
+			if (phase == 0) {
+				launch_ivf_mask_probes((const int64_t *)ws_cI.p, nq, (int)np, 0, 1, (int64_t *)ws_cimask.p, stream);
+				keys = (const int64_t *)ws_cimask.p;
+			}
 			int *d_nitems = nullptr, *d_cnt = nullptr;
-			launch_ivf_group((const int64_t *)ws_cimask.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
-			                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
-			                 &d_nitems, &d_cnt, stream);
+			launch_ivf_group(keys, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
+			                 (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
 			launch_ivf_collect_pack(d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
 			                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
 			                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream);
-			if (phase == 1 || np == 1)
+			if (phase == 1)
 				begin_kernel_timing(stream);
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, stream);
-			if (phase == 1 || np == 1)
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, phase == 0 ? 256 : seg_rows,
+			                        phase == 0 ? 1 : nseg, phase, stream);
+			if (phase == 1)
 				end_kernel_timing(stream);
 		}
 		// queries without a finite bound -> fail list
@@ -874,7 +880,7 @@ public:
 			                   (long long *)d_I, tot, (const long long *)d_idmap);
 		}
 		snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel");
-		kinfo.grid = max_items;
+		kinfo.grid = max_items * nseg;
 		kinfo.block = 64;
 		kinfo.nsplit = (int)np;
 		kinfo.bytes = (double)nrows_mf * 256.0;               // every list's bf16 rows once (each list is probed by >= 1 item)

@@ -16,7 +16,8 @@
 //   re-scoring  the candidates are grouped by query, recomputed with the scanner's arithmetic (t = x_k - y_k, acc = fmaf(t, t,
 //               acc), k ascending, on the ORIGINAL f32 rows) and the k best by (value, position in the list-sorted store)
 //               are kept -- the order of ivf_scan_kernel + merge_items_kernel.
-// The probe-0 list of every query is scanned first (one launch), which warms the bounds for the other nprobe - 1.
+// A list is walked in segments of 512 rows, one wavefront each (long lists do not set the pace).  A pre-pass over the first 256
+// rows of every query's nearest list (publish only) warms the bounds.
 #include "flat_fused.h"
 
 #include <algorithm>
@@ -48,6 +49,8 @@ struct IvfCollectArgs {
 	unsigned long long *stream_cnt;
 	long long stream_cap;
 	int kk;
+	int seg_rows; // rows per block: grid.y walks a list in segments (one wavefront per segment: long lists do not set the pace)
+	int collect;  // 0: bound estimation only (publish to the slots, append nothing)
 };
 
 __device__ __forceinline__ unsigned ic_skey(float s) { // "larger s is better" as a smaller-is-better key
@@ -71,12 +74,23 @@ __global__ void ivf_rows_to_bf16_kernel(const float *__restrict__ src, long long
 	const int c8 = (int)(i & 15);
 	bf16x8i hi;
 	float n2 = 0.f;
+	float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	if (live && (d & 7) == 0) { // 16-byte aligned: two vector loads
+		if (c8 * 8 < d) {
+			const float4 s0 = *(const float4 *)(src + (size_t)r * d + c8 * 8);
+			const float4 s1 = *(const float4 *)(src + (size_t)r * d + c8 * 8 + 4);
+			v8[0] = s0.x, v8[1] = s0.y, v8[2] = s0.z, v8[3] = s0.w, v8[4] = s1.x, v8[5] = s1.y, v8[6] = s1.z, v8[7] = s1.w;
+		}
+	} else if (live) {
+#pragma unroll
+		for (int e = 0; e < 8; ++e)
+			if (c8 * 8 + e < d)
+				v8[e] = src[(size_t)r * d + c8 * 8 + e];
+	}
 #pragma unroll
 	for (int e = 0; e < 8; ++e) {
-		const int kk = c8 * 8 + e;
-		const float v = (live && kk < d) ? src[(size_t)r * d + kk] : 0.f;
-		hi[e] = (__bf16)v;
-		n2 = fmaf(v, v, n2);
+		hi[e] = (__bf16)v8[e];
+		n2 = fmaf(v8[e], v8[e], n2);
 	}
 	n2 += ic_dpp<0xB1>(n2);
 	n2 += ic_dpp<0x4E>(n2);
@@ -200,7 +214,10 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	const int4 it = a.items[blockIdx.x];
 	const int lane = threadIdx.x;
 	const int hq = lane >> 4, c = lane & 15;
-	const long long r_begin = it.x, r_end = it.y;
+	const long long r_begin = (long long)it.x + (long long)blockIdx.y * a.seg_rows;
+	if (r_begin >= it.y)
+		return;
+	const long long r_end = r_begin + a.seg_rows < it.y ? r_begin + a.seg_rows : it.y;
 	const int ntiles = (int)((r_end - r_begin + IC_BN - 1) / IC_BN);
 	if (lane == 0)
 		qctl[0] = 0u;
@@ -310,6 +327,8 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 				typedef __attribute__((address_space(1))) unsigned *GU;
 				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), ic_skey(v), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
+				if (!a.collect)
+					continue;
 				unsigned pos;
 				const unsigned one = 1u;
 				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
@@ -453,8 +472,8 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
-                             int64_t stream_cap, int kk, hipStream_t st) {
-	if (max_items <= 0)
+                             int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, hipStream_t st) {
+	if (max_items <= 0 || nseg <= 0)
 		return;
 	IvfCollectArgs a;
 	memset(&a, 0, sizeof a);
@@ -471,7 +490,9 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.stream_cnt = d_stream_cnt;
 	a.stream_cap = stream_cap;
 	a.kk = kk;
-	hipLaunchKernelGGL(ivf_bf16_collect_kernel, dim3(max_items), dim3(64), 0, st, a);
+	a.seg_rows = seg_rows;
+	a.collect = collect;
+	hipLaunchKernelGGL(ivf_bf16_collect_kernel, dim3(max_items, nseg), dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
 
