@@ -715,7 +715,8 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.slot_stride = stride;
 	a.nclass = kk;
 	a.nq = (int)nq;
-	const int64_t seed = std::min<int64_t>(n, g_cl_seed_rows);
+	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
+	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	if (seed > 0 && seed < n)
 		launch_collect_range<false>(g, metric, a, 0, seed, 8, nq, st, nullptr, nullptr);
 }
