@@ -187,11 +187,11 @@ def main():
     # N > 1: two result / exchange buffer sets, so that the host merge of batch i runs while the GPUs search batch i+1
     pipelined = world > 1 and not is_hnsw and not args.no_pipeline and not ip_ties
     Dbuf, Ibuf = [D], [I]
-    xchs = [ShardExchange(nq, k, dev, ip_ties=ip_ties)]
+    xchs = [ShardExchange(nq, k, dev, ip_ties=ip_ties, metric=metric)]
     if pipelined:
         Dbuf.append(torch.empty_like(D))
         Ibuf.append(torch.empty_like(I))
-        xchs.append(ShardExchange(nq, k, dev))
+        xchs.append(ShardExchange(nq, k, dev, metric=metric))
     state = {"it": 0, "pending": None}
     chunk = args.chunk if args.chunk > 0 else nq
     search_kw = {"nprobe": args.nprobe} if is_ivf else ({"efSearch": args.efsearch} if is_hnsw else {})
@@ -309,8 +309,8 @@ def main():
                 "exchange": (
                     "gather of disjoint result rows"
                     if is_hnsw
-                    else "one rccl all_gather of packed {value,label} records + host k-way merge"
-                    + (" (merge of batch i overlaps the search of batch i+1)" if pipelined else "")
+                    else "one rccl all_gather of packed {value,label} records + k-way merge on rank 0's device (mvs_merge_records_device)"
+                    + (" (the copy-out of batch i overlaps the search of batch i+1)" if pipelined else "")
                 )
                 if world > 1
                 else "none",

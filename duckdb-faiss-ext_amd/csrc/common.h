@@ -193,6 +193,8 @@ void launch_gather_flagged(const float *d_x, int d, const TieFlags &f, int nf, i
 void launch_tie_resolve(const TieFlags &f, int nf, int64_t k, int64_t kout, const int64_t *d_first_ids /*[nf][kout]*/,
                         const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
 
+void launch_merge_records(int metric, const int64_t *d_rec, int nshard, int64_t nq, int kk, int kout, bool raw, float *d_D,
+                          int64_t *d_I, hipStream_t st);
 // IVF (csrc/ivf.hip)
 size_t direct_items_lds_bytes(int dp, int64_t k);
 void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, const float *d_rows, int64_t nrows,

@@ -1569,6 +1569,13 @@ int mvs_merge_shards(int metric, int64_t n, int64_t k, int nshard, const float *
 	MVS_API_END
 }
 
+int mvs_merge_records_device(int metric, int64_t n, int kk, int kout, int nshard, const int64_t *d_records, int raw,
+                             float *d_D_out, int64_t *d_I_out, void *stream) {
+	MVS_API_BEGIN
+	launch_merge_records(metric, d_records, nshard, n, kk, kout, raw != 0, d_D_out, d_I_out, (hipStream_t)stream);
+	MVS_API_END
+}
+
 int mvs_merge_shards_raw(int metric, int64_t n, int64_t kk, int nshard, const float *D, const int64_t *I, float *D_out,
                          int64_t *I_out) {
 	MVS_API_BEGIN

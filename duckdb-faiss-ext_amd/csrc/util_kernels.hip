@@ -498,6 +498,101 @@ void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, cons
 	MVS_HIP(hipGetLastError());
 }
 
+// ---- cross-shard merge ON THE DEVICE (one process per GPU: pyhost/sharded.py after the RCCL all-gather) -------------------
+// rec: [nshard][nq][kk][2] int64 records {value bits (low 32), global label} exactly as gathered; one wave per query keeps
+// the kout best of the nshard * kk candidates under the pure order (L2: value asc, label asc; inner product: value desc,
+// label asc) and, unless `raw`, prints inner-product runs of equal scores in descending label order (heap_reorder over a
+// CMin heap; csrc/merge_host.hip merge_shards_host is the host twin).  Entries with label < 0 are empty.
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void merge_records_kernel(const long long *__restrict__ rec, int nshard, long long nq, int kk,
+                                                          int kout, int raw, float *__restrict__ D,
+                                                          long long *__restrict__ I) {
+	extern __shared__ __attribute__((aligned(16))) long long mr_sm[];
+	const long long q = blockIdx.x;
+	const int lane = threadIdx.x, c = nshard * kk;
+	long long *lab = mr_sm;              // [c]
+	float *val = (float *)(lab + c);     // [c]
+	float *ov = val + c;                 // [kout]
+	long long *oi = (long long *)(mr_sm + c + (c + kout + 1) / 2); // [kout] (8-byte aligned)
+	for (int i = lane; i < c; i += 64) {
+		const int s = i / kk, j = i - s * kk;
+		const long long *r = rec + (((size_t)s * nq + q) * kk + j) * 2;
+		val[i] = __int_as_float((int)r[0]);
+		lab[i] = r[1];
+	}
+	__syncthreads();
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+	for (int o = 0; o < kout; ++o) {
+		float bv = 0.f;
+		long long bl = -1;
+		int bi = -1;
+		for (int i = lane; i < c; i += 64) {
+			const long long l = lab[i];
+			if (l < 0)
+				continue;
+			const float v = val[i];
+			const bool better = bi < 0 || (IS_L2 ? (v < bv || (v == bv && l < bl)) : (v > bv || (v == bv && l < bl)));
+			if (better) {
+				bv = v;
+				bl = l;
+				bi = i;
+			}
+		}
+		for (int off = 32; off >= 1; off >>= 1) {
+			const float v2 = __shfl_xor(bv, off);
+			const long long l2 = __shfl_xor(bl, off);
+			const int i2 = __shfl_xor(bi, off);
+			const bool take = i2 >= 0 && (bi < 0 || (IS_L2 ? (v2 < bv || (v2 == bv && l2 < bl)) : (v2 > bv || (v2 == bv && l2 < bl))));
+			if (take) {
+				bv = v2;
+				bl = l2;
+				bi = i2;
+			}
+		}
+		if (lane == 0) {
+			ov[o] = bi >= 0 ? bv : neutral;
+			oi[o] = bi >= 0 ? bl : -1;
+			if (bi >= 0)
+				lab[bi] = -1; // consumed
+		}
+		__syncthreads();
+	}
+	for (int o = lane; o < kout; o += 64) {
+		int src = o;
+		if (!IS_L2 && !raw && oi[o] >= 0) { // the run of equal scores around o, printed back to front
+			int a = o, b = o + 1;
+			while (a > 0 && oi[a - 1] >= 0 && ov[a - 1] == ov[o])
+				--a;
+			while (b < kout && oi[b] >= 0 && ov[b] == ov[o])
+				++b;
+			src = a + b - 1 - o;
+		}
+		D[q * kout + o] = ov[src];
+		I[q * kout + o] = oi[src];
+	}
+}
+void launch_merge_records(int metric, const int64_t *d_rec, int nshard, int64_t nq, int kk, int kout, bool raw, float *d_D,
+                          int64_t *d_I, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	const int c = nshard * kk;
+	const size_t lds = (size_t)c * 8 + ((size_t)(c + kout + 1) / 2) * 8 + (size_t)kout * 8 + 16;
+	if (lds > 150 * 1024)
+		throw_faiss(__func__, __FILE__, "merge: nshard * k = %d too large", c);
+	if (metric_order(metric) == METRIC_L2) {
+		auto kern = merge_records_kernel<true>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, (const long long *)d_rec, nshard, (long long)nq, kk, kout,
+		                   raw ? 1 : 0, d_D, (long long *)d_I);
+	} else {
+		auto kern = merge_records_kernel<false>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), lds, st, (const long long *)d_rec, nshard, (long long)nq, kk, kout,
+		                   raw ? 1 : 0, d_D, (long long *)d_I);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
 // rows gathered by a permutation: dst[i] = src[perm[i]] (16-byte chunks; dp % 4 == 0)
 __global__ void gather_rows_kernel(const float *__restrict__ src, const int *__restrict__ perm, long long n, int dp,
                                    float *__restrict__ dst) {

@@ -127,6 +127,7 @@ _L.mvs_index_search_device.argtypes = [_p, _i64, _p, _i64, _p, _p, C.POINTER(Sea
 _L.mvs_index_set_label_offset.argtypes = [_p, _i64]
 _L.mvs_merge_shards.argtypes = [C.c_int, _i64, _i64, C.c_int, _p, _p, _p, _p]
 _L.mvs_merge_shards_raw.argtypes = [C.c_int, _i64, _i64, C.c_int, _p, _p, _p, _p]
+_L.mvs_merge_records_device.argtypes = [C.c_int, _i64, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p]
 _L.mvs_finish_ip_ties.argtypes = [_i64, _i64, _i64, _p, _p, _i64, _p, _p, _p, _p]
 _L.mvs_index_tie_candidates_device.argtypes = [_p, _i64, _p, _p, _i64, _p, C.POINTER(SearchParams), _p]
 _L.mvs_synth_uniform_device.argtypes = [_p, _i64, C.c_int, C.c_uint64, _i64, _p]
@@ -146,7 +147,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
-    "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
+    "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
     "mvs_version",
 ]  # fmt: skip
@@ -405,6 +406,20 @@ def merge_shards(metric, D, I):
     Io = np.empty((nq, k), dtype=np.int64)
     _check(_L.mvs_merge_shards(metric, nq, k, ns, _ptr(D), _ptr(I), _ptr(Do), _ptr(Io)))
     return Do, Io
+
+
+def merge_records_torch(metric, rec, kout, raw=False):
+    """device merge of gathered records: rec [nshard, nq, kk, 2] int64 (torch, on the GPU) -> (D [nq, kout] f32, I [nq, kout]
+    i64) torch tensors on the same device; raw: pure order instead of FAISS's print order"""
+    import torch
+
+    ns, nq, kk, _ = rec.shape
+    D = torch.empty((nq, kout), dtype=torch.float32, device=rec.device)
+    I = torch.empty((nq, kout), dtype=torch.int64, device=rec.device)
+    st = torch.cuda.current_stream(rec.device).cuda_stream
+    _check(_L.mvs_merge_records_device(int(metric), nq, kk, int(kout), ns, C.c_void_p(rec.data_ptr()), 1 if raw else 0,
+                                       C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()), C.c_void_p(st)))
+    return D, I
 
 
 def merge_shards_raw(metric, D, I):

@@ -62,7 +62,11 @@ class ShardExchange:
     """Pre-allocated buffers for the exchange step of one (nq, kk) search shape; kk = k, or k + 1 for inner product
     with exact boundary ties (`ip_ties=True`: shards must then search with k + 1 and option ip_exact_ties = 0)."""
 
-    def __init__(self, nq, k, device, group=None, ip_ties=False):
+    def __init__(self, nq, k, device, group=None, ip_ties=False, metric=None):
+        # metric given + GPU tensors: the merge runs ON THE DEVICE right behind the all-gather (mvs_merge_records_device) and
+        # only the merged [nq, k] block crosses PCIe; otherwise the gathered blocks go to pinned host memory and
+        # mvs_merge_shards merges them on the CPU (gloo tests, or when the caller does not say which order applies)
+        self.metric = metric
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -86,6 +90,17 @@ class ShardExchange:
         dist.all_gather_into_tensor(self.grec.view(self.world * self.nq, self.kk, 2), rec, group=self.group)
         if self.rank != merge_rank:
             return
+        if self.grec.is_cuda and self.metric is not None and not self.ip_ties:
+            Dm, Im = mf.merge_records_torch(self.metric, self.grec, self.k)
+            if not hasattr(self, "hD"):
+                self.hD = torch.empty((self.nq, self.k), dtype=torch.float32, pin_memory=True)
+                self.hI = torch.empty((self.nq, self.k), dtype=torch.int64, pin_memory=True)
+            self.hD.copy_(Dm, non_blocking=True)
+            self.hI.copy_(Im, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.grec.device))
+            self._pending = ("device", None, ev)
+            return
         self.hrec.copy_(self.grec, non_blocking=True)
         ev = None
         if self.grec.is_cuda:
@@ -104,6 +119,8 @@ class ShardExchange:
             return D.cpu().numpy(), I.cpu().numpy()
         if ev is not None:
             ev.synchronize()
+        if isinstance(D, str):  # merged on the device by gather_async
+            return self.hD.numpy().copy(), self.hI.numpy().copy()
         hD, hI = unpack_records(self.hrec.numpy())
         return mf.merge_shards(metric, hD, hI)
 
@@ -125,11 +142,15 @@ class ShardExchange:
             self.gather_async(D, I, merge_rank)
             rawD = rawI = None
             if self.rank == merge_rank:
-                _, _, ev = self._pending
-                if ev is not None:
-                    ev.synchronize()
-                hD, hI = unpack_records(self.hrec.numpy())
-                rawD, rawI = mf.merge_shards_raw(mf.METRIC_INNER_PRODUCT, hD, hI)
+                if self.grec.is_cuda:  # merged top-(k+1) in the pure order, on the device
+                    rD, rI = mf.merge_records_torch(mf.METRIC_INNER_PRODUCT, self.grec, kk, raw=True)
+                    rawD, rawI = rD.cpu().numpy(), rI.cpu().numpy()
+                else:
+                    _, _, ev = self._pending
+                    if ev is not None:
+                        ev.synchronize()
+                    hD, hI = unpack_records(self.hrec.numpy())
+                    rawD, rawI = mf.merge_shards_raw(mf.METRIC_INNER_PRODUCT, hD, hI)
             self._pending = None
         # which queries have a bit-equal k-th and (k+1)-th score?  (decided on merge_rank, announced to everyone)
         flagged = np.zeros(0, dtype=np.int64)

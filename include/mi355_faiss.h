@@ -154,6 +154,13 @@ int mvs_index_set_label_offset(mvs_index *ix, int64_t offset);
 int mvs_merge_shards(int metric, int64_t n, int64_t k, int nshard, const float *D, const int64_t *I, float *D_out,
                      int64_t *I_out);
 
+/* The same merge ON THE DEVICE, straight from the gathered records: d_records = [nshard][n][kk][2] int64 {value bits in the
+ * low word, global label} as the all-gather delivers them (pyhost/sharded.py pack_records); keeps the kout <= kk best per
+ * query.  raw = 1: the pure order (what step 1 of the tie protocol below needs); raw = 0: FAISS's print order.  With 8
+ * GPUs the per-rank search of the headline is ~3 ms and a host merge of 8 x 10k x 10 candidates costs more than that. */
+int mvs_merge_records_device(int metric, int64_t n, int kk, int kout, int nshard, const int64_t *d_records, int raw,
+                             float *d_D_out, int64_t *d_I_out, void *stream);
+
 /* ---- inner-product boundary ties across PROCESSES (one rank per GPU, pyhost/sharded.py under torchrun) ----------
  * FAISS's CMin heap keeps an arrival-order dependent subset of the rows tied at the k-th score.  A row
  * shard therefore hands over its k+1 best in the PURE order (option "ip_exact_ties" = 0, search with k+1):
