@@ -512,10 +512,13 @@ public:
 	// Second view of the lists for the MFMA variant of the scan (csrc/flat_mfma.hip ITEMS): the Flat storage format
 	// (pair-interleaved rows of geom.dp floats) with every list padded to a multiple of 64 rows, plus row norms.
 	// Built lazily the first time that variant runs.
-	void build_lists_mf() {
+	// need_f32: also the f32 (MFMA-packed) copy of the rows + their norms, which only the f32 ITEMS scans read (inner product,
+	// options ivf_mfma = 1 / 2); the L2 default (csrc/ivf_collect.hip) reads the bf16 residual copy and the list-sorted store
+	void build_lists_mf(bool need_f32 = true) {
 		build_lists();
-		if (!mf_dirty)
+		if (!mf_dirty && (!need_f32 || mf_have_f32))
 			return;
+		mf_have_f32 = need_f32;
 		geom = flat_geom_for(d);
 		std::vector<int64_t> pb((size_t)nlist), pe((size_t)nlist);
 		int64_t pos = 0;
@@ -533,8 +536,10 @@ public:
 		DevBuf dperm, tmp;
 		dperm.reserve(perm.size() * sizeof(int32_t));
 		tmp.reserve(std::max<size_t>((size_t)nrows_mf * d * sizeof(float), 16));
-		codes_mf.reserve(((size_t)nrows_mf * geom.dp + 64) * sizeof(float));
-		norms_mf.reserve(std::max<size_t>((size_t)nrows_mf * sizeof(float), 16));
+		if (need_f32) {
+			codes_mf.reserve(((size_t)nrows_mf * geom.dp + 64) * sizeof(float));
+			norms_mf.reserve(std::max<size_t>((size_t)nrows_mf * sizeof(float), 16));
+		}
 		rowids_mf.reserve(std::max<size_t>((size_t)nrows_mf * sizeof(int64_t), 16));
 		lb_dev.reserve((size_t)nlist * sizeof(int64_t));
 		le_dev.reserve((size_t)nlist * sizeof(int64_t));
@@ -579,14 +584,16 @@ public:
 				}
 				MVS_HIP(hipStreamSynchronize(stream)); // cent / lob are host temporaries
 			}
-			launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
-			launch_query_norms((const float *)tmp.p, nrows_mf, d, (float *)norms_mf.p, stream);
+			if (need_f32) {
+				launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
+				launch_query_norms((const float *)tmp.p, nrows_mf, d, (float *)norms_mf.p, stream);
+			}
 		}
 		perm_mf.reserve(perm.size() * sizeof(int32_t));
 		MVS_HIP(hipMemcpyAsync(perm_mf.p, dperm.p, perm.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
 		max_norm_mf.reserve(64);
 		MVS_HIP(hipMemsetAsync(max_norm_mf.p, 0, 64, stream));
-		if (nrows_mf > 0)
+		if (nrows_mf > 0 && need_f32)
 			hipLaunchKernelGGL(ivf_max_norm_kernel, dim3((unsigned)((nrows_mf + 255) / 256)), dim3(256), 0, stream,
 			                   (const float *)norms_mf.p, (long long)nrows_mf, (unsigned *)max_norm_mf.p);
 		MVS_HIP(hipStreamSynchronize(stream));
@@ -789,7 +796,7 @@ public:
 	// bf16 coarse filter (csrc/ivf_collect.hip).  false: the candidate stream overflowed (the caller uses the scanner kernel).
 	bool collect_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                    const int64_t *d_idmap, hipStream_t st, int64_t np) {
-		build_lists_mf();
+		build_lists_mf(false);
 		if (!have_bfr)
 			return false;
 		const int G = 128, shift = 7, kk = (int)k;
@@ -1329,7 +1336,7 @@ private:
 	bool mf_residual = false;
 	// bf16 coarse filter (csrc/ivf_collect.hip): residual rows as bf16, -||y'||^2, the largest ||y'||^2 of every list
 	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask;
-	bool have_bfr = false;
+	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb;
 	int *h_fail = nullptr; // pinned
