@@ -58,6 +58,7 @@ struct CollectArgs {
 	unsigned *gslot;           // [nq][slot_stride] class slots: keys of the best s per row class (smaller key = better)
 	unsigned long long *stream; // candidates (q << 32 | row)
 	unsigned long long *stream_cnt; // [0] entries appended
+	const unsigned long long *rowmask; // SEL instances: bit r of word b = row 64 b + r passes the IDSelector
 	long long stream_cap;
 	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
 	long long n, row_first, split_rows;
@@ -306,7 +307,9 @@ void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, cons
 // ABL (profiling builds of the L2 collect instance only; results are WRONG when != 0): bit 0 = no rare path, bit 1 = no
 // fold either (bare MFMA + staging), bit 2 = stage only the first tile
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
-template <int KCH, bool IS_L2, bool COLLECT, int ABL = 0>
+// SEL: an IDSelector is active -- only the rows whose bit is set in a.rowmask (one bit per row, built per search by
+// collect_rowmask_kernel) are published and appended; the bound then is the kk-th best SELECTED row's, as it must be
+template <int KCH, bool IS_L2, bool COLLECT, int ABL = 0, bool SEL = false>
 __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const CollectArgs a) {
 	constexpr int DP = KCH * 16;
 	constexpr int KB = DP / 32;               // k-blocks of 32 dimensions
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// Rare path of half a 32-query tile (row block rb; sv holds s of its 4 rows x 2 queries per lane): every passing row is
 	// published to its class slot (16 classes: row & 15) and appended.  Lane (hq, c): rows 16 rb + 4 hq + r, queries of column
 	// blocks 2 t + i.
-	auto rare = [&](const f32x4acc (&sv)[2], int rb, int t, bool any_t, f32x2n cqv, long long row0, int nvalid) {
+	auto rare = [&](const f32x4acc (&sv)[2], int rb, int t, bool any_t, f32x2n cqv, long long row0, int nvalid, unsigned rowbits) {
 		if (ABL & 1) {
 			MVS_KEEP_VGPR(any_t);
 			return;
@@ -420,6 +423,8 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				for (int r = 0; r < 4; ++r)
 					if (16 * rb + 4 * hq + r < nvalid && sv[i][r] >= c0)
 						m |= 1u << r;
+				if (SEL) // rows the IDSelector rejects: neither a candidate nor evidence for the bound
+					m &= (rowbits >> (16 * rb + 4 * hq)) & 15u;
 			}
 			while (m != 0u) {
 				const int j = __builtin_ctz(m);
@@ -544,6 +549,11 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		}
 		const long long row0 = r_begin + ((long long)u * CL_SUB + sub) * CL_BN;
 		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN); // (<= 0 behind the split's last row)
+		unsigned rowbits = 0xFFFFFFFFu;
+		if (SEL) { // this tile's 32 selector bits: a wave-uniform (scalar) load; blocks start at multiples of 64 rows
+			typedef __attribute__((address_space(4))) const unsigned cuint;
+			rowbits = *((cuint *)a.rowmask + (row0 >> 5));
+		}
 
 		// Eight half tiles (32 queries x 16 rows: 8 MFMAs into two interleaved accumulators) in turn: while the matrix pipe
 		// works on one half the vector ALU folds the PREVIOUS half (running maximum of s per query) and runs its
@@ -605,14 +615,14 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				if (pt >= 0) {
 					if (rb == 0) // (pt = t - 1: its bounds were read a tile ago; this tile's read is waited for as well)
 						asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cqv[0]), "+v"(cqv[1]));
-					rare(acc[prb], prb, pt, any_of(cqv[pt & 1]), cqv[pt & 1], row0, nvalid);
+					rare(acc[prb], prb, pt, any_of(cqv[pt & 1]), cqv[pt & 1], row0, nvalid, rowbits);
 				}
 			}
 		}
 		{
 			fold(acc[1][0], 1, 0);
 			fold(acc[1][1], 1, 1);
-			rare(acc[1], 1, 3, any_of(cqv[1]), cqv[1], row0, nvalid);
+			rare(acc[1], 1, 3, any_of(cqv[1]), cqv[1], row0, nvalid, rowbits);
 		}
 		} // sub
 		__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
@@ -645,6 +655,49 @@ bool collect_supported(const FlatGeom &g) {
 	return g.nch == 1 && g.dp == 128;
 }
 
+// one bit per row: does the IDSelector accept it?  (ids as the SEL instances of the f32 kernel see them: idmap[row] behind
+// an IndexIDMap, the row number otherwise.)  One wave writes one 64-bit word; rows >= n: 0.
+__device__ __forceinline__ bool cl_sel_member(const SelectorDev &s, long long id) {
+	if (s.kind == MVS_SEL_BITMAP) {
+		const unsigned long long u = (unsigned long long)id;
+		if ((u >> 3) >= (unsigned long long)s.nbytes)
+			return false;
+		return (s.bitmap[u >> 3] >> (u & 7)) & 1;
+	}
+	if (s.kind == MVS_SEL_BATCH) {
+		long long lo = 0, hi = s.nids;
+		while (lo < hi) {
+			const long long mid = (lo + hi) >> 1;
+			if (s.sorted_ids[mid] < id)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo < s.nids && s.sorted_ids[lo] == id;
+	}
+	return true;
+}
+__global__ __launch_bounds__(256) void collect_rowmask_kernel(SelectorDev sel, const long long *__restrict__ idmap, long long n,
+                                                             long long nwords, unsigned long long *__restrict__ mask) {
+	const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	bool ok = false;
+	if (row < n)
+		ok = cl_sel_member(sel, idmap ? idmap[row] : row);
+	const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
+	if ((threadIdx.x & 63) == 0 && (row >> 6) < nwords)
+		mask[row >> 6] = b;
+}
+size_t collect_rowmask_bytes(int64_t n) {
+	return (size_t)((n + 63) / 64 + 64) * 8; // + slack: tiles past the last row are looked up, never used
+}
+void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, unsigned long long *d_mask, hipStream_t st) {
+	const long long nwords = (long long)(collect_rowmask_bytes(n) / 8);
+	const long long rows = nwords * 64;
+	hipLaunchKernelGGL(collect_rowmask_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sel,
+	                   (const long long *)d_idmap, (long long)n, nwords, d_mask);
+	MVS_HIP(hipGetLastError());
+}
+
 int g_cl_abl = 0;         // option cl_abl: profiling ablation of the L2 scan (results wrong)
 int g_cl_nsplit = 0;      // option cl_nsplit: row splits of the main scan (0 = planned)
 int g_cl_seed_rows = 16384; // option cl_seed_rows: rows of the bound-estimation pre-pass
@@ -675,6 +728,16 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 	}
 		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7)
 #undef MVS_CL_ABL
+	} else if (a.rowmask) {
+		if (metric == METRIC_L2) {
+			auto kern = flat_bf16_collect_kernel<8, true, COLLECT, 0, true>;
+			ensure_dynamic_lds((const void *)kern, lds);
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+		} else {
+			auto kern = flat_bf16_collect_kernel<8, false, COLLECT, 0, true>;
+			ensure_dynamic_lds((const void *)kern, lds);
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+		}
 	} else if (metric == METRIC_L2) {
 		auto kern = flat_bf16_collect_kernel<8, true, COLLECT>;
 		ensure_dynamic_lds((const void *)kern, lds);
@@ -699,7 +762,7 @@ int collect_slot_stride(int kk) {
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, hipStream_t st) {
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, hipStream_t st) {
 	const int stride = 16; // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
 	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, 16,
@@ -715,6 +778,7 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.slot_stride = stride;
 	a.nclass = kk;
 	a.nq = (int)nq;
+	a.rowmask = d_rowmask;
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
 	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	if (seed > 0 && seed < n)
@@ -724,8 +788,8 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 // the main scan: every row, candidates into the stream
 void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
-                         unsigned long long *d_stream_cnt, int64_t stream_cap, hipStream_t st, int *grid_out, int *nsplit_out,
-                         int *lds_out) {
+                         unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, hipStream_t st,
+                         int *grid_out, int *nsplit_out, int *lds_out) {
 	CollectArgs a;
 	memset(&a, 0, sizeof a);
 	a.qf = d_qf;
@@ -739,6 +803,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.stream = d_stream;
 	a.stream_cnt = d_stream_cnt;
 	a.stream_cap = stream_cap;
+	a.rowmask = d_rowmask;
 	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
 	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 8192 rows per split
 	int64_t nsplit = g_cl_nsplit;
@@ -785,7 +850,8 @@ __global__ void collect_segments_kernel(const unsigned long long *__restrict__ s
 // One wave per 64 candidates.  The rows are staged through LDS with coalesced loads (half a wave per 512-byte row; a
 // thread streaming its own row thrashes the 32 KB L1: 6.2 ms for 10^7 candidates), row pitch DP + 4 floats so that the 16
 // lanes of a ds_read_b128 phase hit distinct banks; then lane <-> candidate runs the k-ordered chain.
-template <bool IS_L2, int DP>
+// PAIR (L2 with an IDSelector: FAISS's per-pair branch, exhaustive_L2sqr_seq): t = x_k - y_k, acc = fmaf(t, t, acc), k ascending
+template <bool IS_L2, int DP, bool PAIR = false>
 __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *__restrict__ sorted, long long ncand,
                                                           const float *__restrict__ x, int d,
                                                           const float *__restrict__ vecs, int interleaved,
@@ -822,6 +888,23 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 			v0 = s.z, v1 = s.x, v2 = s.w, v3 = s.y;
 		else
 			v0 = s.x, v1 = s.z, v2 = s.y, v3 = s.w;
+		if (PAIR) {
+			float t = __fsub_rn(xq[g4], v0);
+			ip = fmaf(t, t, ip);
+			if (g4 + 1 < d) {
+				t = __fsub_rn(xq[g4 + 1], v1);
+				ip = fmaf(t, t, ip);
+			}
+			if (g4 + 2 < d) {
+				t = __fsub_rn(xq[g4 + 2], v2);
+				ip = fmaf(t, t, ip);
+			}
+			if (g4 + 3 < d) {
+				t = __fsub_rn(xq[g4 + 3], v3);
+				ip = fmaf(t, t, ip);
+			}
+			continue;
+		}
 		ip = fmaf(xq[g4], v0, ip);
 		if (g4 + 1 < d)
 			ip = fmaf(xq[g4 + 1], v1, ip);
@@ -832,7 +915,10 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 	}
 	float ex;
 	bool ok;
-	if (IS_L2) {
+	if (PAIR) {
+		ex = ip;
+		ok = ex < FLT_MAX;
+	} else if (IS_L2) {
 		ex = fmaf(-2.0f, ip, qn[q] + norms[row]);
 		ex = ex < 0.f ? 0.f : ex; // FAISS: if (dis < 0) dis = 0
 		ok = ex < FLT_MAX;
@@ -925,13 +1011,16 @@ void launch_collect_select(int metric, const unsigned long long *d_keys, const i
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
-                            hipStream_t st) {
+                            bool per_pair, hipStream_t st) {
 	if (nq <= 0)
 		return;
 	launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st);
 	if (ncand > 0) {
 		const dim3 grid((unsigned)((ncand + 63) / 64));
-		if (metric == METRIC_L2)
+		if (metric == METRIC_L2 && per_pair)
+			hipLaunchKernelGGL((collect_exact_kernel<true, 128, true>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
+		else if (metric == METRIC_L2)
 			hipLaunchKernelGGL((collect_exact_kernel<true, 128>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,
 			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
 		else

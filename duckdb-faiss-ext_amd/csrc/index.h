@@ -177,11 +177,11 @@ public:
 	float *mu_h1 = nullptr;            // [dp] the centre (mean of the rows present at the first build)
 	int64_t h1_cap = 0, h1_rows = 0;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0;
-	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg;
+	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask;
 	void ensure_bf16_rows(hipStream_t st);
 	void ensure_h1_rows(hipStream_t st);
 	bool collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1, int32_t **pi1, int *fail_cnt, int *fail_q,
-	                        hipStream_t st);
+	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
 	void drop_bf16_rows();
 	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
 	                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
@@ -300,16 +300,18 @@ void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, cons
 int collect_slot_stride(int kk);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, hipStream_t st);
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, hipStream_t st);
+size_t collect_rowmask_bytes(int64_t n);
+void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, unsigned long long *d_mask, hipStream_t st);
 void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
-                         unsigned long long *d_stream_cnt, int64_t stream_cap, hipStream_t st, int *grid_out, int *nsplit_out,
-                         int *lds_out);
+                         unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, hipStream_t st,
+                         int *grid_out, int *nsplit_out, int *lds_out);
 size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq);
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
-                            hipStream_t st);
+                            bool per_pair, hipStream_t st);
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,

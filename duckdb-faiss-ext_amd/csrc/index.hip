@@ -365,8 +365,17 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 // re-scored exactly.  Leaves the kk best exact candidates per query in *pd1 / *pi1 ([nq][kk]) and the queries whose bound
 // is not finite in fail_q.  false: the candidate stream overflowed (the caller uses the bf16x3 path instead).
 bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1_out, int32_t **pi1_out, int *fail_cnt,
-                                   int *fail_q, hipStream_t st) {
+                                   int *fail_q, const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
 	ensure_h1_rows(st);
+	// IDSelector: one bit per row, built per search (the selector sees idmap[row] behind an IndexIDMap, the row number else)
+	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
+	const unsigned long long *rowmask = nullptr;
+	if (has_sel) {
+		SelectorDev sel = selector.upload(params, st);
+		ws_rowmask.reserve(collect_rowmask_bytes(ntotal));
+		launch_collect_rowmask(sel, d_idmap, ntotal, (unsigned long long *)ws_rowmask.p, st);
+		rowmask = (const unsigned long long *)ws_rowmask.p;
+	}
 	ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
 	ws_qn.reserve((size_t)nq * sizeof(float));
 	launch_collect_pack_queries(geom, metric, d_x, nq, mu_h1, ws_pfq.p, st);
@@ -381,11 +390,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	unsigned long long *stream = (unsigned long long *)((char *)ws_stream.p + 256);
 	unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
-	                       (unsigned *)ws_gthr.p, cnt, st);
+	                       (unsigned *)ws_gthr.p, cnt, rowmask, st);
 	int grid = 0, nsplit = 0, lds = 0;
 	begin_kernel_timing(st);
 	launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
-	                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, st, &grid, &nsplit, &lds);
+	                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, st, &grid, &nsplit, &lds);
 	end_kernel_timing(st);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
@@ -408,8 +417,9 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
 	float *pd1 = (float *)ws_ex.p;
 	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
+	// (with a selector FAISS takes its per-pair branch: L2 = sum (x_k - y_k)^2; inner product is the same chain either way)
 	launch_collect_rescore(metric, stream, sorted, ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
-	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, st);
+	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel, st);
 	*pd1_out = pd1;
 	*pi1_out = pi1;
 	snprintf(kinfo.name, sizeof kinfo.name, "flat_bf16_collect_kernel");
@@ -619,7 +629,12 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	const bool direct = ((has_sel || small_batch) && !ip_on_mfma) || k > mfma_kmax || force_direct;
 	FlatDB db {vecs, norms, ntotal};
 	memset(&kinfo, 0, sizeof kinfo);
-	if (direct) {
+	// L2 + selector on a large batch: the bf16 coarse filter masks by the selector and re-scores its candidates with the
+	// per-pair arithmetic FAISS uses there (csrc/flat_collect.hip, SEL instances); same results as the packed scan kernel
+	if (has_sel && metric == METRIC_L2 && !force_direct && !force_staged &&
+	    search_prefilter(nq, d_x, k_user, k, d_D, d_I, params, d_idmap, out_map, out_off, flp, st)) {
+		// handled
+	} else if (direct) {
 		if (k > flat_direct_max_k())
 			throw_faiss("mvs::FlatIndex::search", __FILE__, "k = %lld exceeds the supported maximum %lld",
 			            (long long)k, (long long)flat_direct_max_k());
@@ -735,7 +750,9 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
                                  int64_t out_off, const TieFlags *flp, hipStream_t st) {
 	if (prefilter_mode == 0 || pf_suppressed || !prefilter_supported(geom) || kk > 40)
 		return false;
-	if (params && params->sel_kind != MVS_SEL_NONE) // filtered inner product stays on the exact fused kernel (SEL instances)
+	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
+	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
+	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16))
 		return false;
 	// auto: the contraction must dominate (one 256-query block per workgroup, >= 8192 rows per split)
 	if (prefilter_mode < 0 && (nq < 512 || ntotal < 262144))
@@ -753,10 +770,12 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	// its kernel exists (d = 128 geometry, lists of <= 16); on a stream overflow the bf16x3 path below takes the batch
 	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16) {
 		kp = (int)kk;
-		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, st);
+		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st);
 		if (!collected)
 			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 	}
+	if (!collected && has_sel)
+		return false; // (stream overflow under a selector: the exact kernels take the batch)
 	if (!collected) {
 	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the
 	// headline (N = 10M, d = 128) 5 spare ranks leave ~3 of 10 000 queries to the exact kernel, 8 spare ranks ~none
@@ -804,9 +823,11 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 9, d_max_norm_bits + 4, sizeof(int), hipMemcpyDeviceToHost, st));
 	if (flp) {
-		SelectorDev nosel;
-		memset(&nosel, 0, sizeof nosel);
-		resolve_ip_ties(nq, d_x, k_user, *flp, nosel, d_idmap, d_D, d_I, st, kp); // (syncs the stream)
+		SelectorDev tsel;
+		memset(&tsel, 0, sizeof tsel);
+		if (has_sel)
+			tsel = selector.upload(params, st);
+		resolve_ip_ties(nq, d_x, k_user, *flp, tsel, d_idmap, d_D, d_I, st, kp); // (syncs the stream)
 	} else {
 		MVS_HIP(hipStreamSynchronize(st));
 	}

@@ -162,3 +162,34 @@ def test_collect_fuzz(mf, seed):
     o.add_with_ids(xb, ids) if idmap else o.add(xb)
     Do, Io = o.search(xq, k)
     assert np.array_equal(I1, Io) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32)), what
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("idmap", [False, True])
+@pytest.mark.parametrize("frac", [0.3, 0.02])
+def test_selector_searches_on_the_coarse_filter(mf, metric, idmap, frac):
+    """filtered search (IDSelectorBitmap / IDSelectorBatch, the reference's signature feature): the selector becomes one bit per
+    row, rejected rows are neither candidates nor evidence for the bound, candidates are re-scored with the per-pair
+    arithmetic FAISS uses under a selector; must equal the exact kernels' SEL instances and the oracle bit for bit"""
+    from helpers import bitmap_from_ids
+
+    rs = np.random.RandomState(17 + int(frac * 100))
+    d, n, nq, k = 128, 150_000, 300, 10
+    xb = rs.rand(n, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[rs.randint(0, n, 2000)] = xb[rs.randint(0, n, 2000)]
+    ids = (rs.permutation(4 * n)[:n] + 3).astype(np.int64) if idmap else np.arange(n, dtype=np.int64)
+    desc = "IDMap,Flat" if idmap else "Flat"
+    cl, ex = _pair(mf, d, metric, xb, desc=desc, ids=ids if idmap else None)
+    o = orc.Index(d, desc, metric)
+    o.add_with_ids(xb, ids) if idmap else o.add(xb)
+    keep = ids[rs.rand(n) < frac]
+    for sel in (("batch", keep), ("bitmap", bitmap_from_ids(ids, np.isin(ids, keep)))):
+        D1, I1 = cl.search(xq, k, sel=sel)
+        assert cl.last_kernel_info()["name"] == KERNEL
+        D0, I0 = ex.search(xq, k, sel=sel)
+        assert ex.last_kernel_info()["name"] != KERNEL
+        assert np.isin(I1[I1 >= 0], keep).all()
+        assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), (metric, idmap, sel[0])
+        Do, Io = o.search(xq[:64], k, sel=sel)
+        assert np.array_equal(I1[:64], Io) and np.array_equal(D1[:64].view(np.uint32), Do.view(np.uint32))
