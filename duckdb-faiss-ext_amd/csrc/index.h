@@ -327,7 +327,11 @@ void launch_ivf_collect_pack(const float *d_x, int d, const void *d_items, const
 void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
-                             int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, hipStream_t st);
+                             int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
+                             hipStream_t st);
+size_t ivf_rowmask_bytes(int64_t nrows_mf);
+void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
+                        void *d_mask, hipStream_t st);
 void launch_ivf_collect_exact(unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
                               int dp_csr, const int *d_perm, hipStream_t st);
 void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st);

@@ -643,8 +643,7 @@ public:
 		}
 		// L2, default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
 		if (metric == METRIC_L2 && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= 16 && d <= 128 &&
-		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26) && (collect_mode > 0 || nq >= 64) &&
-		    !(params && params->sel_kind != MVS_SEL_NONE)) {
+		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26) && (collect_mode > 0 || nq >= 64)) {
 			if (collect_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
 				return;
 		}
@@ -822,6 +821,14 @@ public:
 		unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 		MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
 		memset(&kinfo, 0, sizeof kinfo);
+		// IDSelector: one bit per padded row, built per search (the selector sees the stored id, through the id map if any)
+		const unsigned *rowmask = nullptr;
+		if (params && params->sel_kind != MVS_SEL_NONE) {
+			SelectorDev sel = selector.upload(params, stream);
+			ws_rowmask.reserve(ivf_rowmask_bytes(nrows_mf));
+			launch_ivf_rowmask(sel, (const int64_t *)rowids_mf.p, (const int *)perm_mf.p, d_idmap, nrows_mf, ws_rowmask.p, stream);
+			rowmask = (const unsigned *)ws_rowmask.p;
+		}
 		// pre-pass: the first 256 rows of every query's nearest list, publish only (warms the query's bound); then every probed
 		// list in segments of 512 rows, one wavefront per (work item, segment)
 		int64_t max_list = 0;
@@ -845,7 +852,7 @@ public:
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
 			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, phase == 0 ? 256 : seg_rows,
-			                        phase == 0 ? 1 : nseg, phase, stream);
+			                        phase == 0 ? 1 : nseg, phase, rowmask, stream);
 			if (phase == 1)
 				end_kernel_timing(stream);
 		}
@@ -1335,7 +1342,7 @@ private:
 	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf, cent_dev, list_of_blk, perm_mf, ws_iqn, ws_qmaxn;
 	bool mf_residual = false;
 	// bf16 coarse filter (csrc/ivf_collect.hip): residual rows as bf16, -||y'||^2, the largest ||y'||^2 of every list
-	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask;
+	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb;

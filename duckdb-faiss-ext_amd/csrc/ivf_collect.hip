@@ -51,6 +51,7 @@ struct IvfCollectArgs {
 	int kk;
 	int seg_rows; // rows per block: grid.y walks a list in segments (one wavefront per segment: long lists do not set the pace)
 	int collect;  // 0: bound estimation only (publish to the slots, append nothing)
+	const unsigned *rowmask; // IDSelector active: bit r of word w = padded row 32 w + r is accepted (nullptr: no selector)
 };
 
 __device__ __forceinline__ unsigned ic_skey(float s) { // "larger s is better" as a smaller-is-better key
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		}
 	};
 
-	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid) {
+	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid, unsigned rowbits) {
 		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
 			return;
 #pragma unroll
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 				for (int r = 0; r < 4; ++r)
 					if (16 * rb + 4 * hq + r < nvalid && sv[i][r] >= c0)
 						m |= 1u << r;
+				m &= (rowbits >> (16 * rb + 4 * hq)) & 15u; // rows the IDSelector rejects: no candidate, no evidence for the bound
 			}
 			if (m == 0u)
 				continue;
@@ -417,6 +419,11 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		dma_tile(u + 1);
 		const long long row0 = r_begin + (long long)u * IC_BN;
 		const int nvalid = (int)((r_end - row0) < IC_BN ? (r_end - row0) : IC_BN);
+		unsigned rowbits = 0xFFFFFFFFu;
+		if (a.rowmask) { // this tile's 32 selector bits: one wave-uniform (scalar) load (tiles start at multiples of 32 rows)
+			typedef __attribute__((address_space(4))) const unsigned cuint;
+			rowbits = *((cuint *)a.rowmask + (row0 >> 5));
+		}
 
 		f32x4a acc[2][2]; // [row block][column block of the tile]
 		f32x4i cg[2];     // {B - 2E, gamma} x 2 column blocks of tile t in cg[t & 1]
@@ -454,12 +461,12 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 					__builtin_amdgcn_sched_barrier(0);
 				}
 				if (pt >= 0)
-					rare(acc[prb], prb, pt, any_of(cg[pt & 1]), cg[pt & 1], row0, nvalid);
+					rare(acc[prb], prb, pt, any_of(cg[pt & 1]), cg[pt & 1], row0, nvalid, rowbits);
 			}
 		}
 		fold(acc[1][0], 0);
 		fold(acc[1][1], 1);
-		rare(acc[1], 1, 3, any_of(cg[1]), cg[1], row0, nvalid);
+		rare(acc[1], 1, 3, any_of(cg[1]), cg[1], row0, nvalid, rowbits);
 		__syncthreads(); // one wave: drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
 		unsigned fill;
 		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fill) : "v"(qcnt_lds) : "memory");
@@ -472,7 +479,8 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
-                             int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, hipStream_t st) {
+                             int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
+                             hipStream_t st) {
 	if (max_items <= 0 || nseg <= 0)
 		return;
 	IvfCollectArgs a;
@@ -492,6 +500,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.kk = kk;
 	a.seg_rows = seg_rows;
 	a.collect = collect;
+	a.rowmask = d_rowmask;
 	hipLaunchKernelGGL(ivf_bf16_collect_kernel, dim3(max_items, nseg), dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
@@ -540,6 +549,53 @@ void launch_ivf_collect_exact(unsigned long long *d_sorted, int64_t ncand, const
 		throw_faiss("mvs::launch_ivf_collect_exact", __FILE__, "row pitch %d is not served", dp_csr);
 	hipLaunchKernelGGL(ivf_collect_exact_kernel, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
 	                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm);
+	MVS_HIP(hipGetLastError());
+}
+
+// one bit per padded row: does the IDSelector accept the row's stored id (through the id map of an IndexIDMap wrapper)?
+__device__ __forceinline__ bool ic_sel_member(const SelectorDev &s, long long id) {
+	if (s.kind == MVS_SEL_BITMAP) {
+		const unsigned long long u = (unsigned long long)id;
+		if ((u >> 3) >= (unsigned long long)s.nbytes)
+			return false;
+		return (s.bitmap[u >> 3] >> (u & 7)) & 1;
+	}
+	if (s.kind == MVS_SEL_BATCH) {
+		long long lo = 0, hi = s.nids;
+		while (lo < hi) {
+			const long long mid = (lo + hi) >> 1;
+			if (s.sorted_ids[mid] < id)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo < s.nids && s.sorted_ids[lo] == id;
+	}
+	return true;
+}
+__global__ __launch_bounds__(256) void ivf_rowmask_kernel(SelectorDev sel, const long long *__restrict__ rowids_mf,
+                                                         const int *__restrict__ perm, const long long *__restrict__ idmap,
+                                                         long long nrows, long long nwords, unsigned long long *__restrict__ mask) {
+	const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	bool ok = false;
+	if (row < nrows && perm[row] >= 0) {
+		const long long lab = rowids_mf[row];
+		ok = ic_sel_member(sel, idmap ? idmap[lab] : lab);
+	}
+	const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
+	if ((threadIdx.x & 63) == 0 && (row >> 6) < nwords)
+		mask[row >> 6] = b;
+}
+size_t ivf_rowmask_bytes(int64_t nrows_mf) {
+	return (size_t)((nrows_mf + 63) / 64 + 64) * 8;
+}
+void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
+                        void *d_mask, hipStream_t st) {
+	const long long nwords = (long long)(ivf_rowmask_bytes(nrows_mf) / 8);
+	const long long rows = nwords * 64;
+	hipLaunchKernelGGL(ivf_rowmask_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, sel,
+	                   (const long long *)d_rowids_mf, d_perm, (const long long *)d_idmap, (long long)nrows_mf, nwords,
+	                   (unsigned long long *)d_mask);
 	MVS_HIP(hipGetLastError());
 }
 

@@ -413,10 +413,20 @@ def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, npro
     assert ok.sum() >= 1
     assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32))
     assert np.array_equal(I1[ok], I0[ok]) and np.array_equal(I1[ok], Io[ok])
-    # a selector search stays on the scanner kernel
-    g.set_option("ivf_collect", -1)
-    D2, I2 = g.search(xq, k, nprobe=nprobe, sel=("batch", ids[::2]))
-    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+    # IDSelector: one selector bit per row in front of the same kernel; the scanner kernel and the oracle agree
+    keep = ids[::2] if idmap else np.arange(n, dtype=np.int64)[::2]
+    for sel in (("batch", keep), ("bitmap", np.packbits(np.isin(np.arange(int(keep.max()) + 8), keep), bitorder="little"))):
+        g.set_option("ivf_collect", -1)
+        D2, I2 = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+        g.set_option("ivf_collect", 0)
+        D3, I3 = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+        Do2, Io2 = o.search(xq, k, nprobe=nprobe, sel=sel)
+        assert np.isin(I2[I2 >= 0], keep).all()
+        assert np.array_equal(D2.view(np.uint32), D3.view(np.uint32)) and np.array_equal(D2.view(np.uint32), Do2.view(np.uint32)), sel[0]
+        ok2 = _no_tie_rows(Do2)
+        assert np.array_equal(I2[ok2], I3[ok2]) and np.array_equal(I2[ok2], Io2[ok2]), sel[0]
 
 
 def test_l2_coarse_filter_non_finite_queries_fall_back(mf):
