@@ -321,7 +321,7 @@ extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl;
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
                              float *d_beta, unsigned *d_list_max_bits, hipStream_t st);
 size_t ivf_collect_xi_bytes(int max_items);
-void launch_ivf_collect_pack(const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
+void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
                              float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st);
 void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
@@ -332,7 +332,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 size_t ivf_rowmask_bytes(int64_t nrows_mf);
 void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
                         void *d_mask, hipStream_t st);
-void launch_ivf_collect_exact(unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
+void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
                               int dp_csr, const int *d_perm, hipStream_t st);
 void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st);
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);

@@ -93,6 +93,18 @@ __global__ void ivf_residual_kernel(float *rows, const int *perm, long long n, i
 	if (perm[r] >= 0)
 		rows[i] = __fsub_rn(rows[i], cent[(size_t)list_of_blk64[r >> 6] * d + j]);
 }
+// selected (value, position) lists [nq][kk], best first -> D / I [nq][k] with labels = stored ids
+__global__ void ivf_emit_sorted_kernel(const float *pd1, const int *pi1, int kk, int k, long long total, const long long *rowids,
+                                       float *D, long long *I) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total)
+		return;
+	const long long q = i / k;
+	const int j = (int)(i - q * k);
+	const int p = pi1[q * kk + j];
+	D[i] = pd1[q * kk + j];
+	I[i] = p >= 0 ? rowids[p] : -1;
+}
 // flagged queries -> list
 __global__ void ivf_compact_flags_kernel(const int *flags, int n, int *cnt, int *out) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,7 +570,12 @@ public:
 			// precision to cancellation when the norms dwarf the distance (the C3 mixture: norms ~130, distances ~2.5);
 			// on residuals both are of the size of the distance, and ||(x-c) - (y-c)||^2 is the same distance.
 			mf_residual = metric == METRIC_L2;
-			if (mf_residual) {
+			// inner product: the f32 ITEMS scan reads the rows themselves -- packed before the residuals overwrite `tmp`
+			if (need_f32 && !mf_residual) {
+				launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
+				launch_query_norms((const float *)tmp.p, nrows_mf, d, (float *)norms_mf.p, stream);
+			}
+			{
 				std::vector<float> cent((size_t)nlist * d);
 				get_centroids(cent.data());
 				std::vector<int32_t> lob((size_t)(nrows_mf / 64 + 1), 0);
@@ -572,7 +589,7 @@ public:
 				hipLaunchKernelGGL(ivf_residual_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, (float *)tmp.p,
 				                   (const int *)dperm.p, (long long)nrows_mf, d, (const int *)list_of_blk.p, (const float *)cent_dev.p);
 				have_bfr = d <= 128;
-				if (have_bfr) { // the coarse filter's view of the same residuals: bf16 rows, -||y'||^2, per-list maximum
+				if (have_bfr) { // the coarse filter's view of the residuals: bf16 rows, beta (L2: -||y'||^2, IP: 0), per-list max
 					codes_bfr.reserve(((size_t)nrows_mf + 192) * 128 * sizeof(unsigned short));
 					beta_mf.reserve(((size_t)nrows_mf + 192) * sizeof(float));
 					list_max.reserve((size_t)nlist * sizeof(unsigned));
@@ -581,10 +598,12 @@ public:
 					MVS_HIP(hipMemsetAsync(list_max.p, 0, (size_t)nlist * sizeof(unsigned), stream));
 					launch_ivf_rows_to_bf16((const float *)tmp.p, nrows_mf, d, (const int *)list_of_blk.p,
 					                        (unsigned short *)codes_bfr.p, (float *)beta_mf.p, (unsigned *)list_max.p, stream);
+					if (!mf_residual) // inner product: s = <x, y'> + <x, c>, no row term
+						MVS_HIP(hipMemsetAsync(beta_mf.p, 0, ((size_t)nrows_mf + 192) * sizeof(float), stream));
 				}
 				MVS_HIP(hipStreamSynchronize(stream)); // cent / lob are host temporaries
 			}
-			if (need_f32) {
+			if (need_f32 && mf_residual) {
 				launch_pack_rows(geom, (const float *)tmp.p, nrows_mf, (float *)codes_mf.p, 0, stream);
 				launch_query_norms((const float *)tmp.p, nrows_mf, d, (float *)norms_mf.p, stream);
 			}
@@ -641,8 +660,8 @@ public:
 			select_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
 			return;
 		}
-		// L2, default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
-		if (metric == METRIC_L2 && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= 16 && d <= 128 &&
+		// default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
+		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= 16 && d <= 128 &&
 		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26) && (collect_mode > 0 || nq >= 64)) {
 			if (collect_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
 				return;
@@ -844,7 +863,7 @@ public:
 			int *d_nitems = nullptr, *d_cnt = nullptr;
 			launch_ivf_group(keys, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
 			                 (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
-			launch_ivf_collect_pack(d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
+			launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
 			                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
 			                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream);
 			if (phase == 1)
@@ -884,10 +903,18 @@ public:
 		float *pd1 = (float *)ws_ex.p;
 		int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
 		launch_collect_group(strm, sorted, ncand, ws_sorttmp.p, temp, nq, (int *)ws_seg.p, stream);
-		launch_ivf_collect_exact(sorted, ncand, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream);
-		launch_collect_select(METRIC_L2, sorted, (const int *)ws_seg.p, nq, kk, pd1, pi1, stream);
+		launch_ivf_collect_exact(metric, sorted, ncand, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream);
+		launch_collect_select(metric, sorted, (const int *)ws_seg.p, nq, kk, pd1, pi1, stream);
 		// the k best by (value, position in the list-sorted store), labels = stored ids (then the id map of an IDMap wrapper)
-		launch_merge_partials(metric, pd1, pi1, 1, nq, kk, (const int64_t *)rowids.p, 0, d_D, d_I, stream, k, nullptr);
+		// (the selected lists are already in the scan kernels' order: value, then position -- inner product keeps it as
+		// merge_items_kernel does; the L2 merge of one split only translates the labels)
+		if (metric == METRIC_L2) {
+			launch_merge_partials(metric, pd1, pi1, 1, nq, kk, (const int64_t *)rowids.p, 0, d_D, d_I, stream, k, nullptr);
+		} else {
+			const long long tot = (long long)nq * k;
+			hipLaunchKernelGGL(ivf_emit_sorted_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, pd1, pi1, (int)kk,
+			                   (int)k, tot, (const long long *)rowids.p, d_D, (long long *)d_I);
+		}
 		if (d_idmap && !raw_ids) {
 			const long long tot = (long long)nq * k;
 			hipLaunchKernelGGL(ivf_map_labels_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,

@@ -128,6 +128,10 @@ void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int
 //   the scanner's value: D = sum fl((x_k - y_k)^2) accumulated in f32, on x' - y' = x - y up to one rounding per component of
 //   each residual:                                                                        (d + 8) u (||x'|| + ||y'||_max)^2
 //   E = the sum; e2 = 2 E (1 + 2^-10) + slack.  Non-finite -> NaN (the query is re-run on the scanner kernel).
+// Inner product (IS_L2 = false): the query enters as bf16(x) (not centred: <x, y> = <x, y'> + <x, c>), gamma = <x, c_list>, beta = 0;
+//   E = (2^-8 + 2^-18) S + 1.25 (d/16) 4u ((1 + 2^-7) S + |gamma|) + d u ||x|| ||c|| (gamma's chain) + u S (y' rounding)
+//       + d u ||x|| (||c|| + ||y'||_max) (the scanner's chain over the original row),   S = ||x|| ||y'||_max(list)
+template <bool IS_L2>
 __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__restrict__ x, int d, const int4 *__restrict__ items,
                                                              const int *__restrict__ nitems_dev, const int *__restrict__ qidx,
                                                              const float *__restrict__ cent,
@@ -149,8 +153,10 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		for (int e = 0; e < 8; ++e) {
 			const int kk = kb * 32 + 8 * (lane >> 4) + e;
 			float o = 0.f;
-			if (slot < it.w && kk < d)
-				o = 2.0f * __fsub_rn(x[(size_t)qidx[it.z + slot] * d + kk], c[kk]);
+			if (slot < it.w && kk < d) {
+				const float xv = x[(size_t)qidx[it.z + slot] * d + kk];
+				o = IS_L2 ? 2.0f * __fsub_rn(xv, c[kk]) : xv;
+			}
 			v[e] = (__bf16)o;
 		}
 		dst[i] = v;
@@ -160,19 +166,27 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		float g = 0.f, e2 = __uint_as_float(0x7fc00000u);
 		if (slot < it.w) {
 			const int q = qidx[it.z + slot];
-			float xn = 0.f;
+			float xn = 0.f, cn = 0.f, xc = 0.f; // ||x'||^2 (L2) or ||x||^2 (IP); ||c||^2; <x, c>
 			for (int kk = 0; kk < d; ++kk) {
-				const float r = __fsub_rn(x[(size_t)q * d + kk], c[kk]);
+				const float xv = x[(size_t)q * d + kk];
+				const float r = IS_L2 ? __fsub_rn(xv, c[kk]) : xv;
 				xn = fmaf(r, r, xn);
+				cn = fmaf(c[kk], c[kk], cn);
+				xc = fmaf(xv, c[kk], xc);
 			}
-			g = -xn;
+			g = IS_L2 ? -xn : xc;
 			const float yn = __uint_as_float(list_max_bits[l]);
 			const double u = 5.9604644775390625e-08, infl = 1.0001;
-			const double nx = sqrt((double)xn * infl), ny = sqrt((double)yn * infl), S = nx * ny;
-			const double E = 2.0 * (0.00390625 + 3.814697265625e-06) * S +
-			                 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * 2.0 * S + (double)xn + yn) +
-			                 ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
-			const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn) + 1e-30);
+			const double nx = sqrt((double)xn * infl), ny = sqrt((double)yn * infl), nc = sqrt((double)cn * infl), S = nx * ny;
+			double E;
+			if (IS_L2)
+				E = 2.0 * (0.00390625 + 3.814697265625e-06) * S +
+				    1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * 2.0 * S + (double)xn + yn) +
+				    ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
+			else
+				E = (0.00390625 + 3.814697265625e-06) * S + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * S + nx * nc) +
+				    (double)d * u * nx * nc + u * S + ((double)d + 2.0) * u * nx * (nc + ny);
+			const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn + nx * nc) + 1e-30);
 			if (isfinite(xn) && isfinite(yn) && isfinite(r) && r < 1e30f)
 				e2 = r;
 			else
@@ -185,13 +199,17 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 size_t ivf_collect_xi_bytes(int max_items) {
 	return (size_t)max_items * 8 * 4 * 64 * 16;
 }
-void launch_ivf_collect_pack(const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
+void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
                              float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st) {
 	if (max_items <= 0)
 		return;
-	hipLaunchKernelGGL(ivf_collect_pack_kernel, dim3(max_items), dim3(256), 0, st, d_x, d, (const int4 *)d_items, d_nitems,
-	                   d_qidx, d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(ivf_collect_pack_kernel<true>, dim3(max_items), dim3(256), 0, st, d_x, d, (const int4 *)d_items,
+		                   d_nitems, d_qidx, d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+	else
+		hipLaunchKernelGGL(ivf_collect_pack_kernel<false>, dim3(max_items), dim3(256), 0, st, d_x, d, (const int4 *)d_items,
+		                   d_nitems, d_qidx, d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -510,6 +528,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 // staged through LDS with coalesced loads (row pitch + 4 floats: conflict-free reads of one row per lane); lane <-> candidate: t = x_k - y_k, acc = fmaf(t, t, acc), k ascending.  The entry
 // becomes (order-preserving value key << 32) | position in the list-sorted store; values that cannot enter FAISS's heap (not
 // < FLT_MAX; NaN) become EMPTY.
+template <bool IS_L2>
 __global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long long *__restrict__ sorted, long long ncand,
                                                               const float *__restrict__ x, int d,
                                                               const float *__restrict__ rows_csr, int dp,
@@ -534,21 +553,29 @@ __global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long lon
 	const float *xq = x + q * d;
 	float acc = 0.f;
 	for (int kk = 0; kk < d; ++kk) {
-		const float t = __fsub_rn(xq[kk], y[kk]);
-		acc = fmaf(t, t, acc);
+		if (IS_L2) {
+			const float t = __fsub_rn(xq[kk], y[kk]);
+			acc = fmaf(t, t, acc);
+		} else {
+			acc = fmaf(xq[kk], y[kk], acc); // fvec_inner_product: the k-ordered chain
+		}
 	}
-	const bool ok = pos >= 0 && acc < FLT_MAX;
-	sorted[i] = ok ? (((unsigned long long)f2key(acc) << 32) | (unsigned)pos) : ~0ull;
+	const bool ok = pos >= 0 && (IS_L2 ? acc < FLT_MAX : acc > -FLT_MAX);
+	sorted[i] = ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)pos) : ~0ull;
 }
 // dp_csr: row pitch of the list-sorted f32 store (floats; a multiple of 4, <= 128)
-void launch_ivf_collect_exact(unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
+void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
                               int dp_csr, const int *d_perm, hipStream_t st) {
 	if (ncand <= 0)
 		return;
 	if (dp_csr % 4 != 0 || dp_csr > 128)
 		throw_faiss("mvs::launch_ivf_collect_exact", __FILE__, "row pitch %d is not served", dp_csr);
-	hipLaunchKernelGGL(ivf_collect_exact_kernel, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
-	                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm);
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(ivf_collect_exact_kernel<true>, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
+		                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm);
+	else
+		hipLaunchKernelGGL(ivf_collect_exact_kernel<false>, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
+		                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm);
 	MVS_HIP(hipGetLastError());
 }
 

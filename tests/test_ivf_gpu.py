@@ -187,6 +187,7 @@ def test_ivf_inner_product_scans_on_the_mfma_kernel_bit_exact(mf, d, nlist):
     for i0 in range(0, n, 6000):
         o.add_with_ids(xb[i0 : i0 + 6000], ids[i0 : i0 + 6000])
         g.add_with_ids(xb[i0 : i0 + 6000], ids[i0 : i0 + 6000])
+    g.set_option("ivf_collect", 0)  # (large batches default to the bf16 coarse filter: tested below)
     keep = ids[np.arange(n) % 3 == 0]
     for nprobe, k, sel in ((1, 10, None), (4, 10, None), (nlist, 40, None), (4, 10, ("batch", keep))):
         Do, Io = o.search(xq, k, nprobe=nprobe, sel=sel)
@@ -385,10 +386,11 @@ def test_ivf_select_path_equals_k_list_path_at_small_k(mf):
     assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
 
 
+@pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("idmap", [False, True])
 @pytest.mark.parametrize("d,nlist,n,nq,k,nprobe", [(128, 64, 60000, 500, 10, 8), (64, 16, 20000, 200, 5, 16), (96, 32, 30000, 64, 16, 4),
                                                    (128, 32, 50000, 300, 1, 1), (100, 48, 40000, 777, 10, 48)])
-def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, nprobe, idmap):
+def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, nprobe, idmap, metric):
     """default for L2 batches of >= 64 queries, k <= 16 (option ivf_collect): bf16 coarse filter on residual rows with a
     proven bound + exact re-scoring in IVFFlatScanner's arithmetic (csrc/ivf_collect.hip); must equal the plain scanner
     kernel and the oracle bit for bit, also on duplicate-heavy data (all tied rows are candidates) and with an id map"""
@@ -398,7 +400,7 @@ def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, npro
     xq[: nq // 4] = xb[5 : 5 + nq // 4]
     ids = (np.arange(n, dtype=np.int64) * 3 + 11)
     desc = ("IDMap," if idmap else "") + f"IVF{nlist},Flat"
-    g, o = mf.index_factory(d, desc, L2), orc.Index(d, desc, L2)
+    g, o = mf.index_factory(d, desc, metric), orc.Index(d, desc, metric)
     o.train(xb)
     g.ivf_set_centroids(o.ivf_centroids())
     for a in (g, o):
@@ -407,10 +409,14 @@ def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, npro
     assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
     g.set_option("ivf_collect", 0)
     D0, I0 = g.search(xq, k, nprobe=nprobe)
-    assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+    assert g.last_kernel_info()["name"].startswith(("ivf_scan_kernel", "ivf_mfma_scan"))
     Do, Io = o.search(xq, k, nprobe=nprobe)
     ok = _no_tie_rows(Do)
+    if metric == IP:  # ... and no tie ACROSS the k-th boundary either (FAISS keeps one of the two by probe order)
+        Dk1, _ = o.search(xq, k + 1, nprobe=nprobe)
+        ok &= Dk1[:, k - 1] != Dk1[:, k]
     assert ok.sum() >= 1
+    # (values of tied rows agree by definition, so whole distance rows agree; labels away from exact ties)
     assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32))
     assert np.array_equal(I1[ok], I0[ok]) and np.array_equal(I1[ok], Io[ok])
     # IDSelector: one selector bit per row in front of the same kernel; the scanner kernel and the oracle agree
@@ -421,11 +427,14 @@ def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, npro
         assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
         g.set_option("ivf_collect", 0)
         D3, I3 = g.search(xq, k, nprobe=nprobe, sel=sel)
-        assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+        assert g.last_kernel_info()["name"].startswith(("ivf_scan_kernel", "ivf_mfma_scan"))
         Do2, Io2 = o.search(xq, k, nprobe=nprobe, sel=sel)
         assert np.isin(I2[I2 >= 0], keep).all()
         assert np.array_equal(D2.view(np.uint32), D3.view(np.uint32)) and np.array_equal(D2.view(np.uint32), Do2.view(np.uint32)), sel[0]
         ok2 = _no_tie_rows(Do2)
+        if metric == IP:
+            Dk2, _ = o.search(xq, k + 1, nprobe=nprobe, sel=sel)
+            ok2 &= Dk2[:, k - 1] != Dk2[:, k]
         assert np.array_equal(I2[ok2], I3[ok2]) and np.array_equal(I2[ok2], Io2[ok2]), sel[0]
 
 
