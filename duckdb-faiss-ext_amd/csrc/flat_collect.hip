@@ -244,7 +244,8 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
 //        L2: | ||x-y||^2 - (||x'||^2 + ||y'||^2 - 2<x',y'>) | <= 4u (xn' + yn'_max);  |beta + ||y'||^2| <= d u yn'_max
 //        IP: | <x,y> - (<x',y'> + <mu,y> + <x',mu>) | <= 4u S' + 2u ||mu|| ||y||_max;   |beta - <mu,y>| <= d u ||mu|| ||y||_max
 //   the exact value the oracle reports: L2 D = max(0, fl(fl(xn + yn) - 2 chain)), chain = d sequential fmas:
-//        |D - ||x-y||^2| <= 2 d u S + 4u (xn + yn_max);   IP: |chain - <x,y>| <= d u S
+//        |D - ||x-y||^2| <= 2 d u S + 4u (xn + yn_max); per-pair branch (selector, nq < 20): D = sum fl((x_k - y_k)^2) accumulated
+//        in f32: <= (d + 4) u ||x-y||^2 <= 2 (d + 8) u (xn + yn_max);   IP: |chain - <x,y>| <= d u S
 //   E = the sum of the applicable lines; e2 = 2 E (1 + 2^-10) + the rounding of (B - e2)
 //   itself.  Anything non-finite -> NaN (the query goes to the exact kernel).
 template <bool IS_L2>
@@ -273,7 +274,8 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
 	                  1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * al * Sc + bmax);
 	double E;
 	if (IS_L2)
-		E = es + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn);
+		E = es + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn) +
+		    2.0 * ((double)d + 8.0) * u * ((double)xn + yn); // (+ the per-pair value FAISS reports under a selector / for < 20 queries)
 	else
 		E = es + 4.0 * u * Sc + 2.0 * u * MY + (double)d * u * MY + (double)d * u * S;
 	float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (Sc + MY + (double)xnc + ync) + 1e-30);

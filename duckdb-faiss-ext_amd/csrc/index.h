@@ -167,6 +167,7 @@ public:
 	int prefilter_mode = -1;             // option "prefilter": -1 auto, 0 off, 1 whenever the kernel supports the shape
 	int pf_margin = 6;                   // spare candidate ranks beyond k (option "pf_margin")
 	bool pf_suppressed = false;          // set while the queries the proof rejected are re-run on the exact kernel
+	bool pf_pair_branch = false;         // ... and whether their batch was one FAISS sends down its per-pair branch (nq < 20)
 	int64_t pf_last_fallback = 0;        // diagnostics: queries of the last search that were re-run
 	int64_t pf_queries_total = 0, pf_fallback_total = 0;
 	float pf_max_rel_err = 0.f; // largest observed |approx - exact| / (||x|| ||y||) among re-scored candidates

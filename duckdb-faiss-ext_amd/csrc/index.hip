@@ -417,9 +417,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
 	float *pd1 = (float *)ws_ex.p;
 	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
-	// (with a selector FAISS takes its per-pair branch: L2 = sum (x_k - y_k)^2; inner product is the same chain either way)
+	// (with a selector or fewer than 20 queries FAISS takes its per-pair branch: L2 = sum (x_k - y_k)^2; inner product is the
+	// same chain either way)
 	launch_collect_rescore(metric, stream, sorted, ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
-	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel, st);
+	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel || nq < 20, st);
 	*pd1_out = pd1;
 	*pi1_out = pi1;
 	snprintf(kinfo.name, sizeof kinfo.name, "flat_bf16_collect_kernel");
@@ -623,15 +624,16 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	// The same identity covers small inner-product batches (nq < 20, FAISS's per-pair branch): from 8 queries on the
 	// MFMA kernel beats the per-pair kernels even with a mostly empty 128-query block.
 	// (queries re-run for the prefilter belong to a batch FAISS sends down its BLAS branch, however few they are)
-	const bool small_batch = nq < 20 && !pf_suppressed;
+	const bool small_batch = pf_suppressed ? pf_pair_branch : nq < 20; // (a re-run inherits the branch of its batch)
 	const bool ip_on_mfma = metric == METRIC_IP && (has_sel || small_batch) && nq >= 8 &&
 	                        k <= (has_sel ? flat_mfma_max_k_lds(geom) : mfma_kmax) && !force_direct && !force_staged;
 	const bool direct = ((has_sel || small_batch) && !ip_on_mfma) || k > mfma_kmax || force_direct;
 	FlatDB db {vecs, norms, ntotal};
 	memset(&kinfo, 0, sizeof kinfo);
-	// L2 + selector on a large batch: the bf16 coarse filter masks by the selector and re-scores its candidates with the
-	// per-pair arithmetic FAISS uses there (csrc/flat_collect.hip, SEL instances); same results as the packed scan kernel
-	if (has_sel && metric == METRIC_L2 && !force_direct && !force_staged &&
+	// L2 + selector, or a small batch (FAISS's per-pair branch, nq < 20) on a large database: the bf16 coarse filter masks by
+	// the selector and re-scores its candidates with the per-pair arithmetic FAISS uses there (csrc/flat_collect.hip); same
+	// results as the packed scan / staged kernels
+	if (((has_sel && metric == METRIC_L2) || small_batch) && !force_direct && !force_staged &&
 	    search_prefilter(nq, d_x, k_user, k, d_D, d_I, params, d_idmap, out_map, out_off, flp, st)) {
 		// handled
 	} else if (direct) {
@@ -757,7 +759,9 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	// auto: the contraction must dominate.  The coarse filter wins from FAISS's first BLAS-branch batch on (N = 10M: 1.3 ms vs
 	// 3.5 ms at 64 queries, 1.7 vs 11.0 at 500); the bf16x3 kernel needs whole 256-query blocks to pay
 	const bool collect_ok = (prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16;
-	if (prefilter_mode < 0 && (ntotal < 262144 || (nq < 512 && !(collect_ok && nq >= 20))))
+	if (prefilter_mode < 0 && (ntotal < 262144 || (nq < 512 && !collect_ok)))
+		return false;
+	if (nq < 20 && !collect_ok) // (FAISS's per-pair branch: only the coarse filter re-scores in that arithmetic)
 		return false;
 	if (ntotal < 4096 || ntotal <= kk)
 		return false;
@@ -776,8 +780,8 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		if (!collected)
 			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 	}
-	if (!collected && has_sel)
-		return false; // (stream overflow under a selector: the exact kernels take the batch)
+	if (!collected && (has_sel || nq < 20))
+		return false; // (stream overflow under a selector / in the per-pair branch: the exact kernels take the batch)
 	if (!collected) {
 	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the
 	// headline (N = 10M, d = 128) 5 spare ranks leave ~3 of 10 000 queries to the exact kernel, 8 spare ranks ~none
@@ -849,6 +853,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		int64_t *If = (int64_t *)((char *)Df + df_bytes);
 		launch_gather_query_rows(d_x, d, fail_q, nf, xf, st);
 		pf_suppressed = true;
+		pf_pair_branch = nq < 20;
 		const bool timing = timing_enabled;
 		timing_enabled = false; // the bench's dominant kernel stays the prefilter launch
 		try {

@@ -193,3 +193,28 @@ def test_selector_searches_on_the_coarse_filter(mf, metric, idmap, frac):
         assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), (metric, idmap, sel[0])
         Do, Io = o.search(xq[:64], k, sel=sel)
         assert np.array_equal(I1[:64], Io) and np.array_equal(D1[:64].view(np.uint32), Do.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("nq", [1, 3, 8, 13, 19])
+def test_small_batches_take_faiss_per_pair_branch_on_the_coarse_filter(mf, metric, nq):
+    """fewer than 20 queries: FAISS computes sum (x_k - y_k)^2 per pair (not the norms formula); from 8 queries on a large
+    database the coarse filter serves these too (a single query included) and re-scores in that arithmetic, also for the queries it re-runs"""
+    rs = np.random.RandomState(100 + nq)
+    d, n, k = 128, 300_000, 10
+    xb = rs.rand(n, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[rs.randint(0, n, 3000)] = xb[rs.randint(0, n, 3000)]
+    xq[0] = xb[7]
+    if nq > 2:
+        xq[2, 5] = np.nan  # re-run on the exact kernels, in the same branch's arithmetic
+    ix = mf.index_factory(d, "Flat", metric)
+    ix.add(xb)
+    D, I = ix.search(xq, k)
+    assert ix.last_kernel_info()["name"] == KERNEL
+    Do, Io = orc.flat_search(metric, xb, xq, k)  # PATH_AUTO: the per-pair branch for nq < 20
+    assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    ix.set_option("prefilter", 0)
+    D0, I0 = ix.search(xq, k)
+    assert ix.last_kernel_info()["name"] != KERNEL
+    assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
