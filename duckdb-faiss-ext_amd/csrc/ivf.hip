@@ -662,7 +662,7 @@ public:
 		}
 		// default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
 		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= 16 && d <= 128 &&
-		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26) && (collect_mode > 0 || nq >= 64)) {
+		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26)) { // (faster than the scanner kernel from one query on)
 			if (collect_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
 				return;
 		}
