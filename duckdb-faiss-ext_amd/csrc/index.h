@@ -178,7 +178,8 @@ public:
 	float *mu_h1 = nullptr;            // [dp] the centre (mean of the rows present at the first build)
 	int64_t h1_cap = 0, h1_rows = 0;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0;
-	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask;
+	bool cl_small_path = true; // batches of <= 256 queries on the one-wavefront-per-segment kernel (option cl_small_path)
+	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask, ws_items1;
 	void ensure_bf16_rows(hipStream_t st);
 	void ensure_h1_rows(hipStream_t st);
 	bool collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1, int32_t **pi1, int *fail_cnt, int *fail_q,
@@ -335,6 +336,7 @@ void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *
                         void *d_mask, hipStream_t st);
 void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
                               int dp_csr, const int *d_perm, hipStream_t st);
+void launch_collect_flat_items(void *d_items, int *d_nitems, int *d_qidx, int64_t nq, int64_t n, hipStream_t st);
 void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st);
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,

@@ -380,7 +380,9 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_qn.reserve((size_t)nq * sizeof(float));
 	launch_collect_pack_queries(geom, metric, d_x, nq, mu_h1, ws_pfq.p, st);
 	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
-	ws_e2.reserve((size_t)nq * sizeof(float));
+	const int64_t nq128 = (nq + 127) / 128 * 128;
+	ws_e2.reserve((size_t)nq128 * sizeof(float));
+	MVS_HIP(hipMemsetAsync(ws_e2.p, 0xff, (size_t)nq128 * sizeof(float), st)); // NaN: the slots behind the last query
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
 	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk) * sizeof(unsigned) + 64);
 	const int64_t cap_entries = std::max<int64_t>(nq * 4096, (int64_t)1 << 20);
@@ -392,9 +394,31 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, rowmask, st);
 	int grid = 0, nsplit = 0, lds = 0;
+	const bool few = nq <= 128 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	begin_kernel_timing(st);
-	launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
-	                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, st, &grid, &nsplit, &lds);
+	if (few) {
+		// Small batches are bound by streaming the bf16 store, not by the matrix pipe: the one-wavefront-per-segment kernel of
+		// the IVF scan (csrc/ivf_collect.hip: the database as one list, identity query map, gamma = 0) keeps more bytes in
+		// flight per CU than two 256-thread workgroups do
+		const int nit = (int)((nq + 127) / 128), seg_rows = 2048;
+		const int nseg = (int)((ntotal + seg_rows - 1) / seg_rows);
+		const size_t it_bytes = 256, q_bytes = ((size_t)nq * 4 + 255) & ~(size_t)255, g_bytes = (size_t)nit * 128 * sizeof(float);
+		ws_items1.reserve(it_bytes + 256 + q_bytes + g_bytes);
+		char *b = (char *)ws_items1.p;
+		int *nitems_dev = (int *)(b + it_bytes);
+		int *qidx = (int *)(b + it_bytes + 256);
+		float *gam = (float *)(b + it_bytes + 256 + q_bytes);
+		MVS_HIP(hipMemsetAsync(gam, 0, g_bytes, st));
+		launch_collect_flat_items(b, nitems_dev, qidx, nq, ntotal, st);
+		launch_ivf_collect_scan(b, nitems_dev, nit, qidx, ws_pfq.p, gam, (const float *)ws_e2.p, vecs_h1, beta_h1,
+		                        (unsigned *)ws_gthr.p, stream, cnt, cap_entries, kk, seg_rows, nseg, 1, (const unsigned *)rowmask, st);
+		grid = nit * nseg;
+		nsplit = nseg;
+		lds = 20544;
+	} else {
+		launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
+		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, st, &grid, &nsplit, &lds);
+	}
 	end_kernel_timing(st);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
@@ -427,7 +451,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
 	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * kk * 12.0;
 	kinfo.grid = grid;
-	kinfo.block = 256;
+	kinfo.block = few ? 64 : 256;
 	kinfo.lds_bytes = lds;
 	kinfo.nsplit = nsplit;
 	return true;
@@ -759,7 +783,11 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	// auto: the contraction must dominate.  The coarse filter wins from FAISS's first BLAS-branch batch on (N = 10M: 1.3 ms vs
 	// 3.5 ms at 64 queries, 1.7 vs 11.0 at 500); the bf16x3 kernel needs whole 256-query blocks to pay
 	const bool collect_ok = (prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16;
-	if (prefilter_mode < 0 && (ntotal < 262144 || (nq < 512 && !collect_ok)))
+	// (N = 131 072: 0.35 vs 0.46 ms at 64 queries, 1.36 vs 3.88 at 10k; N = 65 536: 1.40 vs 2.25 at 10k but 1.07 vs 0.61 at 2048;
+	// below that the f32 kernel's ~0.3 ms wins everywhere)
+	const bool big_enough = ntotal >= 262144 || (collect_ok && ntotal >= 65536 && (double)nq * (double)ntotal >= 5e8) ||
+	                        (collect_ok && ntotal >= 131072 && nq <= 128);
+	if (prefilter_mode < 0 && (!big_enough || (nq < 512 && !collect_ok)))
 		return false;
 	if (nq < 20 && !collect_ok) // (FAISS's per-pair branch: only the coarse filter re-scores in that arithmetic)
 		return false;
@@ -1680,6 +1708,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "prefilter")) { // -1 auto, 0 off (exact f32 kernel only), 1 wherever the bf16x3 kernel supports the shape
 		prefilter_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_small_path")) { // 0: small batches on flat_bf16_collect_kernel as well (A/B)
+		cl_small_path = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "cl_abl")) {

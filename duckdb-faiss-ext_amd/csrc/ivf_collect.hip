@@ -626,6 +626,26 @@ void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *
 	MVS_HIP(hipGetLastError());
 }
 
+// Flat small batches ride this kernel too (csrc/index.hip collect_candidates): the whole database is ONE list, every group of
+// <= 128 queries one work item, identity query map.  With one wavefront per 2048-row segment, seven or eight of them per
+// CU keep 8 KB each in flight, against two 16 KB blocks per CU for flat_bf16_collect_kernel.
+__global__ void collect_flat_items_kernel(int4 *items, int *nitems, int *qidx, long long nq, long long n) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	const int ni = (int)((nq + 127) / 128);
+	if (i < ni)
+		items[i] = make_int4(0, (int)n, (int)(i * 128), (int)((nq - i * 128) < 128 ? (nq - i * 128) : 128));
+	if (i < nq)
+		qidx[i] = (int)i;
+	if (i == 0)
+		*nitems = ni;
+}
+void launch_collect_flat_items(void *d_items, int *d_nitems, int *d_qidx, int64_t nq, int64_t n, hipStream_t st) {
+	const long long t = std::max<long long>(nq, (nq + 127) / 128);
+	hipLaunchKernelGGL(collect_flat_items_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, (int4 *)d_items, d_nitems,
+	                   d_qidx, (long long)nq, (long long)n);
+	MVS_HIP(hipGetLastError());
+}
+
 // keep only one probe rank range of the coarse labels: out[q][p] = (lo <= p < hi) ? in[q][p] : -1
 __global__ void ivf_mask_probes_kernel(const long long *__restrict__ in, long long total, int np, int lo, int hi,
                                        long long *__restrict__ out) {
