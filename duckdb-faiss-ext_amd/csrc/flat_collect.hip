@@ -702,6 +702,7 @@ void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, 
 
 int g_cl_abl = 0;         // option cl_abl: profiling ablation of the L2 scan (results wrong)
 int g_cl_nsplit = 0;      // option cl_nsplit: row splits of the main scan (0 = planned)
+int g_cl_seed_split = 0;    // option cl_seed_split: row splits of the pre-pass (0 = 32: 4.70 vs 4.96 ms per 2048-query call)
 int g_cl_seed_rows = 16384; // option cl_seed_rows: rows of the bound-estimation pre-pass
 
 int flat_mfma_slot_stride(int64_t k);
@@ -784,7 +785,7 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
 	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	if (seed > 0 && seed < n)
-		launch_collect_range<false>(g, metric, a, 0, seed, 8, nq, st, nullptr, nullptr);
+		launch_collect_range<false>(g, metric, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
 }
 
 // the main scan: every row, candidates into the stream

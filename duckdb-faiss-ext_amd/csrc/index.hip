@@ -1722,6 +1722,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_cl_nsplit = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "cl_seed_split")) {
+		g_cl_seed_split = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "cl_seed_rows")) { // coarse filter: rows of the bound-estimation pre-pass
 		g_cl_seed_rows = (int)v;
 		return true;
