@@ -307,7 +307,7 @@ void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, cons
 // MFMAs of a block form one dependent chain: 18.2 vs 14.4 ms for the bare loop).
 // COLLECT = false: bound estimation only (publish to the slots, append nothing) -- the pre-pass over the first rows
 // ABL (profiling builds of the L2 collect instance only; results are WRONG when != 0): bit 0 = no rare path, bit 1 = no
-// fold either (bare MFMA + staging), bit 2 = stage only the first tile
+// fold either (bare MFMA + staging), bit 2 = stage only the first tile, bit 3 = no workgroup barrier
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 // SEL: an IDSelector is active -- only the rows whose bit is set in a.rowmask (one bit per row, built per search by
 // collect_rowmask_kernel) are published and appended; the bound then is the kk-th best SELECTED row's, as it must be
@@ -627,7 +627,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			rare(acc[1], 1, 3, any_of(cqv[1]), cqv[1], row0, nvalid, rowbits);
 		}
 		} // sub
-		__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
+		if (ABL & 8) // profiling: no workgroup barrier (the waves drift apart; results wrong)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		else
+			__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
 		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
 			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue)
 			const unsigned fill = qctl[0];
@@ -729,7 +732,7 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
 	}
-		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7)
+		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7) MVS_CL_ABL(11) MVS_CL_ABL(15)
 #undef MVS_CL_ABL
 	} else if (a.rowmask) {
 		if (metric == METRIC_L2) {
