@@ -1,0 +1,83 @@
+"""The coarse filter's error bound (csrc/flat_collect.hip collect_bounds_kernel), restated in numpy and confronted with an
+emulation of what the scan kernel computes: operands rounded to bf16 (round to nearest even), products exact, f32
+accumulation in MFMA-sized groups starting from C = beta.  The kernels' exactness only needs E to be an UPPER bound of
+|s - s_exact|; this checks the formula (not the device) on data with offsets, large norms and tiny values.  CPU only."""
+import numpy as np
+import pytest
+
+U = 2.0**-24
+
+
+def bf16(x):
+    """round-to-nearest-even to bfloat16, returned as float32"""
+    b = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def mfma_chain(a, b, c0, group=32):
+    """sum_k a_k b_k + c0 with exact products and an f32 running sum updated once per `group` terms (one MFMA each)"""
+    acc = np.float32(c0)
+    for g in range(0, len(a), group):
+        p = (a[g : g + group].astype(np.float64) * b[g : g + group].astype(np.float64)).sum()
+        acc = np.float32(np.float64(acc) + p)
+    return float(acc)
+
+
+def flat_bound(metric_l2, x, mu, yn_max, ync_max, d):
+    """2E of collect_bounds_kernel (same terms, same order)"""
+    xn = float((x.astype(np.float64) ** 2).sum())
+    xc = (x - mu).astype(np.float32)
+    xnc = float((xc.astype(np.float64) ** 2).sum())
+    mun = float((mu.astype(np.float64) ** 2).sum())
+    infl = 1.0001
+    S = np.sqrt(xn * infl) * np.sqrt(yn_max * infl)
+    Sc = np.sqrt(xnc * infl) * np.sqrt(ync_max * infl)
+    MY = np.sqrt(mun * infl) * np.sqrt(yn_max * infl)
+    al = 2.0 if metric_l2 else 1.0
+    bmax = ync_max if metric_l2 else MY
+    es = al * (2.0**-8 + 2.0**-18) * Sc + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 2.0**-7) * al * Sc + bmax)
+    if metric_l2:
+        E = es + 4 * U * (xnc + ync_max) + d * U * ync_max + 2 * d * U * S + 4 * U * (xn + yn_max) + 2 * (d + 8) * U * (xn + yn_max)
+    else:
+        E = es + 4 * U * Sc + 2 * U * MY + d * U * MY + d * U * S
+    return 2.0 * E * (1.0 + 2.0**-10) + 8.0 * U * (Sc + MY + xnc + ync_max) + 1e-30
+
+
+@pytest.mark.parametrize("metric_l2", [True, False])
+@pytest.mark.parametrize("kind", ["uniform", "offset", "scaled", "tiny", "signed"])
+def test_flat_bound_covers_the_emulated_coarse_value(metric_l2, kind):
+    seed = {"uniform": 1, "offset": 2, "scaled": 3, "tiny": 4, "signed": 5}[kind] * 2 + int(metric_l2)
+    rs = np.random.RandomState(seed)
+    d, n, nq = 128, 400, 10
+    scale, shift = {"uniform": (1.0, 0.0), "offset": (1.0, 3.0), "scaled": (300.0, 0.0), "tiny": (1e-3, 0.0), "signed": (2.0, -1.0)}[kind]
+    xb = (rs.rand(n, d) * scale + shift).astype(np.float32)
+    xq = (rs.rand(nq, d) * scale + shift).astype(np.float32)
+    mu = xb.mean(0).astype(np.float32)
+    yc = (xb - mu).astype(np.float32)  # what the store holds before the bf16 rounding
+    yn_max = float((xb.astype(np.float64) ** 2).sum(1).max())
+    ync = (yc.astype(np.float64) ** 2).sum(1)
+    worst = 0.0
+    for q in range(nq):
+        x = xq[q]
+        E = flat_bound(metric_l2, x, mu, yn_max, float(ync.max()), d) / 2.0
+        xc = (x - mu).astype(np.float32)
+        bx = bf16(np.float32(2.0 if metric_l2 else 1.0) * xc)  # alpha rides in the query operand (exact scaling)
+        for r in range(0, n, 5):
+            by = bf16(yc[r])
+            if metric_l2:
+                s = mfma_chain(bx, by, np.float32(-ync[r]))  # beta = -||y'||^2
+                s_exact = float((xc.astype(np.float64) ** 2).sum()) - float(((x.astype(np.float64) - xb[r]) ** 2).sum())
+            else:
+                s = mfma_chain(bx, by, np.float32((mu.astype(np.float64) * xb[r]).sum()))  # beta = <mu, y>
+                s_exact = float((x.astype(np.float64) * xb[r]).sum()) - float((xc.astype(np.float64) * mu).sum())
+            worst = max(worst, abs(s - s_exact) / E)
+    assert worst < 0.9, worst  # below E with room: the Cauchy-Schwarz bf16 term dominates and is rarely tight
+    assert worst > 1e-4  # ... and the rounding is exercised (not a vacuous check)
+
+
+def test_bf16_emulation_is_round_to_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.01171875, -3.0000001, 0.0], dtype=np.float32)
+    y = bf16(x)
+    assert y[0] == 1.0 and y[1] == 1.0 and y[2] == np.float32(1.015625)  # tie to even, tie to even (up)
+    assert np.all(np.abs(y - x) <= np.abs(x) * 2.0**-8)
