@@ -1,0 +1,54 @@
+// csrc/flat_collect.h -- shared by the coarse-filter scan kernels (flat_collect.hip: d <= 128; flat_collect_wide.hip: 128 < d <= 512)
+#pragma once
+#include "flat_fused.h"
+
+namespace mvs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_f32c;
+typedef __attribute__((address_space(1))) const float glb_f32c;
+
+constexpr int CL_QBLOCK = 512;  // queries per workgroup
+constexpr int CL_BN = 32;       // rows per tile (one pass of the MFMA loop)
+constexpr int CL_SUB = 2;       // tiles per staged block (one barrier per CL_SUB tiles)
+constexpr int CL_QCAP = 2048;   // candidate queue of a workgroup (entries of 8 bytes)
+constexpr int CL_FLUSH_EVERY = 2; // staged blocks between two looks at the queue
+
+struct CollectArgs {
+	const void *qf;            // query fragments (bf16), [qblk32][ch][lane] x 16 bytes
+	const unsigned short *yb;  // bf16 rows [n + 64][dp]
+	const float *yn;           // beta(row): -||y'||^2 (L2) or <mu, y> (inner product), f32, padded by 64
+	const float *e2;           // [nq] 2E(q) (NaN: the query is not served here)
+	unsigned *gslot;           // [nq][slot_stride] class slots: keys of the best s per row class (smaller key = better)
+	unsigned long long *stream; // candidates (q << 32 | row)
+	unsigned long long *stream_cnt; // [0] entries appended
+	const unsigned long long *rowmask; // SEL instances: bit r of word b = row 64 b + r passes the IDSelector
+	long long stream_cap;
+	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
+	long long n, row_first, split_rows;
+	int nq, nqb, nsplit, xcd_map;
+};
+
+// csrc/flat_collect_wide.hip
+int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512; 0 = the coarse filter does not serve d
+int collect_wide_qblock(int dp1);
+size_t collect_wide_lds_bytes(int dp1);
+int collect_wide_block_rows(int dp1);
+void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,
+                               int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out);
+void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
+                              const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
+                              unsigned *d_max_norm_bits, hipStream_t st);
+void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d,
+                               const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st);
+
+__device__ __forceinline__ unsigned skey(float s) { // "larger s is better" as a smaller-is-better key
+	return ~f2key(s);
+}
+__device__ __forceinline__ float skey2f(unsigned k) {
+	return key2f(~k);
+}
+
+} // namespace mvs

@@ -28,7 +28,7 @@
 // Geometry (CDNA4): workgroup = 4 waves x 128 queries (four 32-query B tiles resident as bf16: 128 VGPRs), database tiles
 // of 32 rows x 256 B (bf16, 16-byte chunks XOR-swizzled by row) double-buffered by LDS-DMA, one ds_read_b128 per 4 MFMAs;
 // two workgroups per CU, i.e. 1024 queries share every byte a CU pulls out of L2.
-#include "flat_fused.h"
+#include "flat_collect.h"
 
 #include <algorithm>
 #include <cmath>
@@ -37,40 +37,6 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace mvs {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4n __attribute__((ext_vector_type(4)));
-typedef float f32x2n __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) float lds_f32c;
-typedef __attribute__((address_space(1))) const float glb_f32c;
-
-constexpr int CL_QBLOCK = 512;  // queries per workgroup
-constexpr int CL_BN = 32;       // rows per tile (one pass of the MFMA loop)
-constexpr int CL_SUB = 2;       // tiles per staged block (one barrier per CL_SUB tiles)
-constexpr int CL_QCAP = 2048;   // candidate queue of a workgroup (entries of 8 bytes)
-constexpr int CL_FLUSH_EVERY = 2; // staged blocks between two looks at the queue
-
-struct CollectArgs {
-	const void *qf;            // query fragments (bf16), [qblk32][ch][lane] x 16 bytes
-	const unsigned short *yb;  // bf16 rows [n + 64][dp]
-	const float *yn;           // beta(row): -||y'||^2 (L2) or <mu, y> (inner product), f32, padded by 64
-	const float *e2;           // [nq] 2E(q) (NaN: the query is not served here)
-	unsigned *gslot;           // [nq][slot_stride] class slots: keys of the best s per row class (smaller key = better)
-	unsigned long long *stream; // candidates (q << 32 | row)
-	unsigned long long *stream_cnt; // [0] entries appended
-	const unsigned long long *rowmask; // SEL instances: bit r of word b = row 64 b + r passes the IDSelector
-	long long stream_cap;
-	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
-	long long n, row_first, split_rows;
-	int nq, nqb, nsplit, xcd_map;
-};
-
-__device__ __forceinline__ unsigned skey(float s) { // "larger s is better" as a smaller-is-better key
-	return ~f2key(s);
-}
-__device__ __forceinline__ float skey2f(unsigned k) {
-	return key2f(~k);
-}
 
 // ---- storage: CENTRED rows as bf16 (round to nearest even) + one f32 per row -----------------------------------------------
 // The error of a bf16 product scales with ||x|| ||y||, distances do not: rows and queries are shifted by mu (the mean of the
@@ -84,6 +50,8 @@ __global__ __launch_bounds__(256) void collect_colsum_kernel(const float *__rest
 	const int g8 = dp / 8, rl = threadIdx.x / g8, c8 = threadIdx.x % g8, nrl = 256 / g8;
 	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	const long long r0 = (long long)blockIdx.x * 1024;
+	if (rl >= nrl) // dp / 8 does not divide 256: the leftover threads would count rows twice
+		return;
 	for (long long r = r0 + rl; r < r0 + 1024 && r < nrows; r += nrl) {
 		const float4 s0 = *(const float4 *)(src + (size_t)r * dp + c8 * 8);
 		const float4 s1 = *(const float4 *)(src + (size_t)r * dp + c8 * 8 + 4);
@@ -104,13 +72,12 @@ __global__ __launch_bounds__(256) void collect_colsum_kernel(const float *__rest
 		atomicAdd(sum + c8 * 8 + e, acc[e]);
 }
 __global__ void collect_mean_kernel(float *sum, int dp, int d, float inv_n) {
-	const int i = threadIdx.x;
-	if (i < dp)
+	for (int i = threadIdx.x; i < dp; i += blockDim.x)
 		sum[i] = i < d ? sum[i] * inv_n : 0.f;
 }
 // mu[dp] <- column means of the first `nrows` rows (padded dimensions: 0)
 void launch_collect_mean(const FlatGeom &g, const float *d_vecs, int64_t nrows, float *d_mu, hipStream_t st) {
-	MVS_HIP(hipMemsetAsync(d_mu, 0, (size_t)g.dp * sizeof(float), st));
+	MVS_HIP(hipMemsetAsync(d_mu, 0, (size_t)std::max(g.dp, 768) * sizeof(float), st)); // (sized for the widest bf16 store)
 	if (nrows <= 0)
 		return;
 	hipLaunchKernelGGL(collect_colsum_kernel, dim3((unsigned)((nrows + 1023) / 1024)), dim3(256), 0, st, d_vecs,
@@ -222,6 +189,19 @@ __global__ void collect_pack_queries_kernel(const float *__restrict__ x, long lo
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq) {
 	const int64_t nblk16 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 16);
 	return (size_t)nblk16 * (g.dp / 32) * 64 * 16;
+}
+// the same for a store of dp1 dims and workgroups of `qblock` queries (csrc/flat_collect_wide.hip)
+size_t collect_qfrag_bytes_ex(int dp1, int qblock, int64_t nq) {
+	const int64_t nblk16 = (nq + qblock - 1) / qblock * (qblock / 16);
+	return (size_t)nblk16 * (dp1 / 32) * 64 * 16;
+}
+void launch_collect_pack_queries_ex(int d, int dp1, int qblock, int metric, const float *d_x, int64_t nq, const float *d_mu,
+                                    void *d_qf, hipStream_t st) {
+	const int64_t nblk16 = (nq + qblock - 1) / qblock * (qblock / 16);
+	const long long total = (long long)nblk16 * (dp1 / 32) * 64;
+	hipLaunchKernelGGL(collect_pack_queries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_x,
+	                   (long long)nq, d, dp1 / 32, d_mu, metric == METRIC_L2 ? 2.0f : 1.0f, (bf16x8 *)d_qf, total);
+	MVS_HIP(hipGetLastError());
 }
 void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
                                  hipStream_t st) {
@@ -657,7 +637,7 @@ static size_t collect_lds_bytes(const FlatGeom &g) {
 }
 
 bool collect_supported(const FlatGeom &g) {
-	return g.nch == 1 && g.dp == 128;
+	return collect_store_dims(g.d) > 0;
 }
 
 // one bit per row: does the IDSelector accept it?  (ids as the SEL instances of the f32 kernel see them: idmap[row] behind
@@ -787,8 +767,13 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.rowmask = d_rowmask;
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
 	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
-	if (seed > 0 && seed < n)
-		launch_collect_range<false>(g, metric, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
+	const int dp1 = collect_store_dims(g.d);
+	if (seed > 0 && seed < n) {
+		if (dp1 > 128)
+			launch_collect_wide_range(dp1, metric, false, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
+		else
+			launch_collect_range<false>(g, metric, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
+	}
 }
 
 // the main scan: every row, candidates into the stream
@@ -810,7 +795,9 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.stream_cnt = d_stream_cnt;
 	a.stream_cap = stream_cap;
 	a.rowmask = d_rowmask;
-	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
+	const int dp1 = collect_store_dims(g.d);
+	const int qblock = dp1 > 128 ? collect_wide_qblock(dp1) : CL_QBLOCK;
+	const int nqb = (int)((nq + qblock - 1) / qblock);
 	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 8192 rows per split
 	int64_t nsplit = g_cl_nsplit;
 	if (nsplit <= 0) {
@@ -831,9 +818,12 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 		if (max_split < 8)
 			nsplit = max_split;
 	}
-	launch_collect_range<true>(g, metric, a, 0, n, nsplit, nq, st, grid_out, nsplit_out);
+	if (dp1 > 128)
+		launch_collect_wide_range(dp1, metric, true, a, 0, n, nsplit, nq, st, grid_out, nsplit_out);
+	else
+		launch_collect_range<true>(g, metric, a, 0, n, nsplit, nq, st, grid_out, nsplit_out);
 	if (lds_out)
-		*lds_out = (int)collect_lds_bytes(g);
+		*lds_out = (int)(dp1 > 128 ? collect_wide_lds_bytes(dp1) : collect_lds_bytes(g));
 }
 
 // ---- candidates -> exact values ----------------------------------------------------------------------------------------
@@ -1021,7 +1011,9 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
 	if (nq <= 0)
 		return;
 	launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st);
-	if (ncand > 0) {
+	if (ncand > 0 && collect_store_dims(g.d) > 128) {
+		launch_collect_exact_wide(metric, per_pair, d_sorted, ncand, d_x, g.d, d_vecs, g.dp, g.pair_interleaved ? 1 : 0, d_norms, d_qn, st);
+	} else if (ncand > 0) {
 		const dim3 grid((unsigned)((ncand + 63) / 64));
 		if (metric == METRIC_L2 && per_pair)
 			hipLaunchKernelGGL((collect_exact_kernel<true, 128, true>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,

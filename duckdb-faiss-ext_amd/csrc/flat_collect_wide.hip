@@ -1,0 +1,493 @@
+// csrc/flat_collect_wide.hip -- the bf16 coarse filter of flat_collect.hip for 128 < d <= 512.
+//
+// Same argument, same bound, same candidate stream and re-scoring (see flat_collect.hip); what changes is the geometry.  The
+// query fragments of a wave must stay in registers for the whole scan (re-streaming them costs more L2 bandwidth than the
+// matrix pipe saves), and 128 queries x 512 dims do not fit: a wave keeps 32 * QT queries (QT = 2 up to d = 256, 1 beyond) x
+// all KB k-blocks = 8 * QT * KB VGPRs (128 at d = 256 and 512), a workgroup 128 * QT queries, so the database is re-read by
+// nq / (128 QT) query blocks instead of nq / 512 -- the scan becomes bound by L2 -> LDS traffic rather than by the matrix
+// pipe, and still several times faster than the f32 kernel (which serves d > 128 otherwise; and d > 512: 32 queries x
+// 768 dims = 192 VGPRs of fragments spill).
+//   rows      16 per tile (one MFMA row block), staged 1-3 tiles per barrier (<= 24 KB) by LDS-DMA, chunks XOR-swizzled by
+//             row within aligned groups of 16 chunks
+//   A         fragments read on demand, two k-blocks ahead (hand-written ds_read_b128, a ring of 4 VGPR quads)
+//   per tile  QT passes of 2 * KB MFMAs (two accumulators, the chain starting at C = beta(row)), then the running maxima and
+//             the rare path of that pass (not overlapped: 10 vector instructions per 2 * KB MFMAs)
+#include "flat_collect.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace mvs {
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+template <int KB, int QT, bool IS_L2, bool COLLECT>
+__global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArgs a) {
+	constexpr int PITCH = 64 * KB;            // bytes per row
+	constexpr int C = 4 * KB;                 // 16-byte chunks per row (a multiple of 16)
+	constexpr int RT = 16;                    // rows per tile
+	constexpr int TILE_BYTES = RT * PITCH;    // 1 KB * KB
+	constexpr int WSUB = KB >= 16 ? 1 : (KB >= 12 ? 2 : 3); // tiles per staged block (16 - 24 KB)
+	constexpr int STAGE_BYTES = WSUB * TILE_BYTES;
+	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096; // 1 KB per wave-instruction, four waves
+	constexpr int QW = 32 * QT, QB = 4 * QW;  // queries per wave / workgroup
+	static_assert(KB % 4 == 0 && STAGE_BYTES % 4096 == 0 && WSUB * RT <= 64, "geometry");
+
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	char *tbuf = (char *)smem;                                        // [2][STAGE_BYTES]
+	float *nbuf = (float *)(tbuf + 2 * STAGE_BYTES);                  // [2][64] beta of the staged rows
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
+	float *cqtab = (float *)(qbuf + CL_QCAP);                         // [4 waves][QT][16 c][2]: pass bound of every query
+	unsigned *qctl = (unsigned *)(cqtab + QB);                        // [0] queue fill, [2..3] flush base
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int hq = lane >> 4, c = lane & 15;
+	int split, qb;
+	if (a.xcd_map) {
+		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+		split = (idx / a.nqb) * 8 + xcd;
+		qb = idx % a.nqb;
+	} else {
+		split = blockIdx.x / a.nqb;
+		qb = blockIdx.x % a.nqb;
+	}
+	const long long r_begin = a.row_first + (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int nblocks = r_end > r_begin ? (int)((r_end - r_begin + WSUB * RT - 1) / (WSUB * RT)) : 0; // staged blocks
+	if (tid == 0)
+		qctl[0] = 0u;
+	const int qw = qb * QB + wave * QW;
+
+	// B fragments, resident: [column block][k-block]
+	bf16x8 bq[2 * QT][KB];
+	{
+		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
+#pragma unroll
+		for (int cb = 0; cb < 2 * QT; ++cb) {
+			const size_t qblk16 = (size_t)qb * (QB / 16) + wave * (2 * QT) + cb;
+#pragma unroll
+			for (int kb = 0; kb < KB; ++kb)
+				bq[cb][kb] = qsrc[(qblk16 * KB + kb) * 64 + lane];
+		}
+	}
+
+	// LDS-DMA: instruction inst = 4 i + wave of a staged block fills LDS bytes [1024 inst, +1024); lane l owns 16-byte slot
+	// S = 64 inst + l = (row r = S / C, position p = S % C) and fetches the row's chunk (p & ~15) | ((p & 15) ^ (r & 15))
+	auto dma_block = [&](int u) {
+		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)u * (WSUB * RT)) * PITCH; // uniform
+#pragma unroll
+		for (int i = 0; i < DMA_PER_WAVE; ++i) {
+			const int inst = 4 * i + wave;
+			const int S = 64 * inst + lane, r = S / C, p = S - r * C;
+			const unsigned off = (unsigned)(r * PITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + off),
+			                                 (lds_f32c *)(smem + ((u & 1) * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
+		}
+		const float *bb = a.yn + (r_begin + (long long)u * (WSUB * RT)); // uniform
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (2 * STAGE_BYTES) / 4 + (u & 1) * 64), 4, 0, 0);
+	};
+	if (nblocks > 0)
+		dma_block(0);
+	__syncthreads();
+
+	// A fragment (k-block kb) of the tile's 16 rows: row c, chunk 4 kb + hq -> byte c * PITCH + 256 (kb >> 2) + (rb16 ^ (64 (kb & 3)))
+	// with rb16 = ((hq ^ c) & 15) * 16  (4 (kb & 3) and hq occupy disjoint bits of the chunk number's low nibble)
+	const unsigned rbase = (unsigned)(c * PITCH) + (unsigned)(((hq ^ c) & 15) * 16);
+	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
+	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * QT * 16 + c) * 8);
+
+	auto rare = [&](const f32x4w (&sv)[2], int t, bool any_t, f32x2n cqv, long long row0, int nvalid) {
+		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+			return;
+		int qo = qw;
+		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const int q = qo + 32 * t + 16 * i + c;
+			const float c0 = cqv[i];
+			unsigned m = 0u;
+			if (any_t) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (4 * hq + r < nvalid && sv[i][r] >= c0)
+						m |= 1u << r;
+			}
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
+				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
+				const float v = (j & 2) ? hi : lo;
+				const unsigned row = (unsigned)(row0 + 4 * hq + j);
+				typedef __attribute__((address_space(1))) unsigned *GU;
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
+				                       __HIP_MEMORY_SCOPE_AGENT);
+				if (COLLECT) {
+					unsigned pos;
+					const unsigned one = 1u;
+					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+					if (pos < (unsigned)CL_QCAP) {
+						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+					} else { // a burst beyond the queue: straight to the stream (by hand, wait included: flat_collect.hip)
+						unsigned long long gp;
+						const unsigned long long one64 = 1ull;
+						typedef __attribute__((address_space(1))) unsigned long long *GUL;
+						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+						             : "=&v"(gp)
+						             : "v"((GUL)a.stream_cnt), "v"(one64)
+						             : "memory");
+						if ((long long)gp < a.stream_cap)
+							*((GUL)a.stream + gp) = ent;
+					}
+				}
+			}
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	};
+
+	for (int u = 0; u < nblocks; ++u) {
+		const int period = u < 4 ? 1 : (u < 32 ? 4 : (u < 256 ? 16 : 64));
+		if ((u % period) == 0) {
+			// B = the kk-th best of the 16 class bests (bitonic network in registers); lane (hq, c) owns the two column blocks of
+			// query tile t = hq (hq < QT); the pass bound B - 2E goes to the wave's table in LDS
+			if (hq < QT) {
+				int qo = qw;
+				MVS_OPAQUE_VGPR(qo);
+				unsigned long long w[2][8];
+				float e2v[2];
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+					const int q = qo + 32 * hq + 16 * i + c;
+					const int qc = q < a.nq ? q : 0;
+					const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						w[i][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					e2v[i] = __builtin_nontemporal_load(a.e2 + qc);
+				}
+#pragma unroll
+				for (int i = 0; i < 2; ++i)
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						asm volatile("" : "+v"(w[i][j]));
+				f32x2n v;
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+					unsigned key[16];
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						key[2 * j] = (unsigned)w[i][j];
+						key[2 * j + 1] = (unsigned)(w[i][j] >> 32);
+					}
+#pragma unroll
+					for (int kbit = 2; kbit <= 16; kbit <<= 1)
+#pragma unroll
+						for (int jb = kbit >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+							for (int x0 = 0; x0 < 16; ++x0) {
+								const int x1 = x0 ^ jb;
+								if (x1 > x0) {
+									const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
+									const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
+									const bool asc = (x0 & kbit) == 0;
+									key[x0] = asc ? lo : hi;
+									key[x1] = asc ? hi : lo;
+								}
+							}
+					unsigned kth = key[0];
+#pragma unroll
+					for (int j = 1; j < 16; ++j)
+						kth = (a.nclass - 1 == j) ? key[j] : kth;
+					const unsigned neutral = skey(-FLT_MAX);
+					const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
+					const int q = qo + 32 * hq + 16 * i + c;
+					v[i] = q < a.nq ? B - e2v[i] : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
+				}
+				*(f32x2n *)(cqtab + (wave * QT * 16 + hq * 16 + c) * 2) = v;
+			}
+		}
+		dma_block(u + 1); // the next staged block streams in under this one's MFMAs (every LDS read below is hand-written)
+#pragma unroll 1
+		for (int sub = 0; sub < WSUB; ++sub) {
+			const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + ((u & 1) * STAGE_BYTES + sub * TILE_BYTES) / 4)) + rbase;
+			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + sub * RT + 4 * hq));
+			const long long row0 = r_begin + ((long long)u * WSUB + sub) * RT;
+			const int nvalid = (int)((r_end - row0) < RT ? (r_end - row0) : RT); // (<= 0 behind the split's last row)
+			f32x4n Y;
+			asm volatile("ds_read_b128 %0, %1" : "=v"(Y) : "v"(nb_lds) : "memory");
+#pragma unroll
+			for (int t = 0; t < QT; ++t) {
+				f32x2n cqv;
+				asm volatile("ds_read_b64 %0, %1" : "=v"(cqv) : "v"(cq_lds + (unsigned)(t * 128)) : "memory");
+				bf16x8 A[4]; // ring: k-block kb lives in A[kb & 3]; two k-blocks are read ahead
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[0]) : "v"(tb) : "memory");
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[1]) : "v"(tb ^ 64u) : "memory");
+				f32x4w acc[2];
+#pragma unroll
+				for (int g = 0; g < KB / 2; ++g) { // groups of two k-blocks
+					if (g + 1 < KB / 2) {
+						const int k2 = 2 * g + 2, k3 = 2 * g + 3;
+						asm volatile("ds_read_b128 %0, %1" : "=v"(A[k2 & 3]) : "v"((tb ^ (unsigned)((k2 & 3) * 64)) + (unsigned)((k2 >> 2) * 256)) : "memory");
+						asm volatile("ds_read_b128 %0, %1" : "=v"(A[k3 & 3]) : "v"((tb ^ (unsigned)((k3 & 3) * 64)) + (unsigned)((k3 >> 2) * 256)) : "memory");
+						// this group's two fragments (and, the first time, beta and the bounds) have arrived: LDS returns in order
+						asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cqv));
+					} else {
+						asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cqv));
+					}
+#pragma unroll
+					for (int kk2 = 0; kk2 < 2; ++kk2) {
+						const int kb = 2 * g + kk2;
+#pragma unroll
+						for (int i = 0; i < 2; ++i) {
+							if (kb == 0) // the chain starts at beta(row): s comes out of the matrix pipe
+								acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[2 * t + i][kb], Y, 0, 0, 0);
+							else
+								acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[2 * t + i][kb], acc[i], 0, 0, 0);
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				const float mx0 = __builtin_fmaxf(__builtin_fmaxf(acc[0][0], acc[0][1]), __builtin_fmaxf(acc[0][2], acc[0][3]));
+				const float mx1 = __builtin_fmaxf(__builtin_fmaxf(acc[1][0], acc[1][1]), __builtin_fmaxf(acc[1][2], acc[1][3]));
+				const bool any_t = (mx0 >= cqv[0]) || (mx1 >= cqv[1]); // NaN on either side: false
+				rare(acc, t, any_t, cqv, row0, nvalid);
+			}
+		}
+		__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
+		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == nblocks - 1)) {
+			const unsigned fill = qctl[0];
+			__syncthreads(); // everybody has read the same fill before anyone appends again
+			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
+			if (n >= (unsigned)CL_QCAP / 2 || (u == nblocks - 1 && n > 0)) {
+				if (tid == 0) {
+					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+					qctl[0] = 0u;
+				}
+				__syncthreads();
+				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
+				for (unsigned i = tid; i < n; i += 256)
+					if ((long long)(base + i) < a.stream_cap)
+						a.stream[base + i] = qbuf[i];
+				__syncthreads();
+			}
+		}
+	}
+}
+
+// ---- storage: one wave per row (plain f32 rows of pitch sdp, d logical dims) -> centred bf16 [dp1] + beta ------------------------
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__restrict__ src, int sdp, int d, int dp1,
+                                                               int interleaved, long long row0, long long nrows, const float *__restrict__ mu,
+                                                               unsigned short *__restrict__ dst, float *__restrict__ beta,
+                                                               const float *__restrict__ norms, unsigned *__restrict__ max_bits) {
+	const long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (r >= row0 + nrows)
+		return;
+	// FlatGeom::pair_interleaved: every 4 floats stored [k0,k2,k1,k3] (bit 4 of the row clear) or [k1,k3,k0,k2]
+	const int flip = interleaved ? (((r >> 4) & 1) ? 2 : 0) : 0;
+	float n2 = 0.f, my = 0.f;
+	for (int c8 = lane; c8 < dp1 / 8; c8 += 64) {
+		bf16x8 hi;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			const int kk = c8 * 8 + e;
+			const int j = kk & 3, sk = interleaved ? ((kk & ~3) + ((((j & 1) << 1) | (j >> 1)) ^ flip)) : kk;
+			const float v = kk < d ? src[(size_t)r * sdp + sk] : 0.f;
+			const float m = kk < d ? mu[kk] : 0.f;
+			const float cv = v - m;
+			hi[e] = (__bf16)cv;
+			n2 = fmaf(cv, cv, n2);
+			my = fmaf(m, v, my);
+		}
+		*(bf16x8 *)(dst + (size_t)r * dp1 + c8 * 8) = hi;
+	}
+	for (int o = 32; o >= 1; o >>= 1) {
+		n2 += __shfl_xor(n2, o);
+		my += __shfl_xor(my, o);
+	}
+	if (lane == 0) {
+		beta[r] = IS_L2 ? -n2 : my;
+		const unsigned b = __float_as_uint(norms[r]);
+		if (b > max_bits[0])
+			atomicMax(max_bits, b);
+		const unsigned bc = __float_as_uint(n2);
+		if (bc > max_bits[8])
+			atomicMax(max_bits + 8, bc);
+	}
+}
+void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
+                              const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
+                              unsigned *d_max_norm_bits, hipStream_t st) {
+	if (nrows <= 0)
+		return;
+	const dim3 grid((unsigned)((nrows + 3) / 4));
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(rows_to_bf16_wide_kernel<true>, grid, dim3(256), 0, st, d_vecs, sdp, d, dp1, interleaved, (long long)row0,
+		                   (long long)nrows, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
+	else
+		hipLaunchKernelGGL(rows_to_bf16_wide_kernel<false>, grid, dim3(256), 0, st, d_vecs, sdp, d, dp1, interleaved, (long long)row0,
+		                   (long long)nrows, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- candidates -> exact values: one wave per 16 candidates, rows (plain f32, pitch sdp) staged through LDS with coalesced loads,
+// lanes 0..15 run the k-ordered chains (PAIR: FAISS's per-pair branch for L2, see flat_collect.hip)
+template <bool IS_L2, bool PAIR>
+__global__ __launch_bounds__(64) void collect_exact_wide_kernel(unsigned long long *__restrict__ sorted, long long ncand,
+                                                               const float *__restrict__ x, int d,
+                                                               const float *__restrict__ vecs, int sdp, int interleaved,
+                                                               const float *__restrict__ norms, const float *__restrict__ qn) {
+	extern __shared__ __attribute__((aligned(16))) float wrows[]; // [16][sdp + 4]
+	const int pitch = sdp + 4, cpr = sdp / 4;
+	const int lane = threadIdx.x;
+	const long long i0 = (long long)blockIdx.x * 16;
+	const long long i = i0 + (lane & 15);
+	const unsigned long long ent = i < ncand ? sorted[i] : 0ull;
+	const unsigned row = (unsigned)ent;
+	const long long q = (long long)(ent >> 32);
+	for (int it = 0; it < (16 * cpr + 63) / 64; ++it) { // 64 consecutive float4 of the 16 x cpr block per step
+		const int idx = it * 64 + lane;
+		if (idx < 16 * cpr) {
+			const int r = idx / cpr, ch = idx - r * cpr;
+			const unsigned rr = (unsigned)__shfl((int)row, r);
+			*(float4 *)(wrows + r * pitch + ch * 4) = *(const float4 *)(vecs + (size_t)rr * sdp + ch * 4);
+		} else {
+			(void)__shfl((int)row, 0);
+		}
+	}
+	__syncthreads();
+	if (lane >= 16 || i >= ncand)
+		return;
+	const float *y = wrows + lane * pitch;
+	const float *xq = x + q * d;
+	const int flip = interleaved ? (((row >> 4) & 1) ? 2 : 0) : 0; // FlatGeom::pair_interleaved
+	float acc = 0.f;
+	for (int kk = 0; kk < d; ++kk) {
+		const int j = kk & 3, sk = interleaved ? ((kk & ~3) + ((((j & 1) << 1) | (j >> 1)) ^ flip)) : kk;
+		if (PAIR) {
+			const float t = __fsub_rn(xq[kk], y[sk]);
+			acc = fmaf(t, t, acc);
+		} else {
+			acc = fmaf(xq[kk], y[sk], acc);
+		}
+	}
+	float ex;
+	bool ok;
+	if (PAIR) {
+		ex = acc;
+		ok = ex < FLT_MAX;
+	} else if (IS_L2) {
+		ex = fmaf(-2.0f, acc, qn[q] + norms[row]);
+		ex = ex < 0.f ? 0.f : ex; // FAISS: if (dis < 0) dis = 0
+		ok = ex < FLT_MAX;
+	} else {
+		ex = acc;
+		ok = ex > -FLT_MAX;
+	}
+	sorted[i] = ok ? (((unsigned long long)bkey<IS_L2>(ex) << 32) | row) : ~0ull;
+}
+void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d,
+                               const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st) {
+	if (ncand <= 0)
+		return;
+	const dim3 grid((unsigned)((ncand + 15) / 16));
+	const size_t lds = (size_t)16 * (sdp + 4) * sizeof(float);
+#define MVS_EXW(L2, PR)                                                                                                \
+	{                                                                                                                  \
+		auto kern = collect_exact_wide_kernel<L2, PR>;                                                                 \
+		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
+		hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, d_sorted, (long long)ncand, d_x, d, d_vecs, sdp, interleaved, d_norms, d_qn); \
+	}
+	if (metric == METRIC_L2 && per_pair)
+		MVS_EXW(true, true)
+	else if (metric == METRIC_L2)
+		MVS_EXW(true, false)
+	else
+		MVS_EXW(false, false)
+#undef MVS_EXW
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+// row pitch (dims) of the bf16 store for a logical dimension: 128 (flat_collect.hip), 256, 384 or 512; 0 = not served
+// (d = 768: 32 queries x 24 k-blocks = 192 VGPRs of fragments spill; 16 queries per wave would make LDS reads the bound)
+int collect_store_dims(int d) {
+	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : 0))));
+}
+static int wide_qt(int dp1) {
+	return dp1 <= 256 ? 2 : 1;
+}
+int collect_wide_qblock(int dp1) {
+	return 128 * wide_qt(dp1);
+}
+static int wide_wsub(int dp1) {
+	const int KB = dp1 / 32;
+	return KB >= 16 ? 1 : (KB >= 12 ? 2 : 3);
+}
+size_t collect_wide_lds_bytes(int dp1) {
+	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)collect_wide_qblock(dp1) * 4 + 64;
+}
+int collect_wide_block_rows(int dp1) {
+	return 16 * wide_wsub(dp1);
+}
+
+template <int KB, int QT, bool COLLECT>
+static void launch_wide_inst(int metric, const CollectArgs &a, int grid, size_t lds, hipStream_t st) {
+	if (metric == METRIC_L2) {
+		auto kern = flat_bf16_wide_kernel<KB, QT, true, COLLECT>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+	} else {
+		auto kern = flat_bf16_wide_kernel<KB, QT, false, COLLECT>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
+// one launch over rows [row_first, row_end): collect = false -> bound estimation only
+void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,
+                               int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out) {
+	const int QB = collect_wide_qblock(dp1), BR = collect_wide_block_rows(dp1);
+	const int nqb = (int)((nq + QB - 1) / QB);
+	const int64_t nblocks = (row_end - row_first + BR - 1) / BR;
+	const int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(nsplit_want, nblocks));
+	a.xcd_map = (nsplit >= 8 && nsplit % 8 == 0) ? 1 : 0;
+	a.row_first = row_first;
+	a.n = row_end;
+	a.split_rows = (nblocks + nsplit - 1) / nsplit * BR;
+	a.nqb = nqb;
+	a.nsplit = (int)nsplit;
+	const int grid = nqb * (int)nsplit;
+	const size_t lds = collect_wide_lds_bytes(dp1);
+	if (dp1 == 256) {
+		if (collect)
+			launch_wide_inst<8, 2, true>(metric, a, grid, lds, st);
+		else
+			launch_wide_inst<8, 2, false>(metric, a, grid, lds, st);
+	} else if (dp1 == 384) {
+		if (collect)
+			launch_wide_inst<12, 1, true>(metric, a, grid, lds, st);
+		else
+			launch_wide_inst<12, 1, false>(metric, a, grid, lds, st);
+	} else if (dp1 == 512) {
+		if (collect)
+			launch_wide_inst<16, 1, true>(metric, a, grid, lds, st);
+		else
+			launch_wide_inst<16, 1, false>(metric, a, grid, lds, st);
+	} else {
+		throw_faiss("mvs::launch_collect_wide_range", __FILE__, "no instance for a %d-dim store", dp1);
+	}
+	if (grid_out)
+		*grid_out = grid;
+	if (nsplit_out)
+		*nsplit_out = (int)nsplit;
+}
+
+} // namespace mvs

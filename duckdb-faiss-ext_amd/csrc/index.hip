@@ -327,25 +327,26 @@ void FlatIndex::ensure_bf16_rows(hipStream_t st) {
 void FlatIndex::ensure_h1_rows(hipStream_t st) {
 	if (h1_rows == ntotal && vecs_h1)
 		return;
+	const int dp1 = collect_store_dims(d); // row pitch of the bf16 store: 128 up to d = 128, else 256 / 384 / 512
 	if (!d_max_norm_bits) {
 		MVS_HIP(hipMalloc((void **)&d_max_norm_bits, 64));
 		MVS_HIP(hipMemsetAsync(d_max_norm_bits, 0, 64, st));
 	}
 	if (!mu_h1) { // the centre is fixed at the first build (any vector is valid; rows added later only fit it less well)
-		MVS_HIP(hipMalloc((void **)&mu_h1, (size_t)geom.dp * sizeof(float)));
+		MVS_HIP(hipMalloc((void **)&mu_h1, (size_t)std::max(geom.dp, 768) * sizeof(float)));
 		launch_collect_mean(geom, vecs, std::min<int64_t>(ntotal, (int64_t)1 << 20), mu_h1, st);
 	}
 	if (ntotal > h1_cap || !vecs_h1) {
 		unsigned short *nb = nullptr;
 		float *nbeta = nullptr;
 		const int64_t nc = std::max<int64_t>(cap, ntotal);
-		const size_t nbytes = ((size_t)nc + 192) * geom.dp * sizeof(unsigned short); // + 192 rows: unclamped prefetch of a 64-row block
+		const size_t nbytes = ((size_t)nc + 192) * dp1 * sizeof(unsigned short); // + 192 rows: unclamped prefetch of a 64-row block
 		MVS_HIP(hipMalloc((void **)&nb, nbytes));
 		MVS_HIP(hipMalloc((void **)&nbeta, ((size_t)nc + 192) * sizeof(float)));
 		MVS_HIP(hipMemsetAsync(nb, 0, nbytes, st));
 		MVS_HIP(hipMemsetAsync(nbeta, 0, ((size_t)nc + 192) * sizeof(float), st));
 		if (h1_rows > 0) {
-			MVS_HIP(hipMemcpyAsync(nb, vecs_h1, (size_t)h1_rows * geom.dp * sizeof(unsigned short), hipMemcpyDeviceToDevice, st));
+			MVS_HIP(hipMemcpyAsync(nb, vecs_h1, (size_t)h1_rows * dp1 * sizeof(unsigned short), hipMemcpyDeviceToDevice, st));
 			MVS_HIP(hipMemcpyAsync(nbeta, beta_h1, (size_t)h1_rows * sizeof(float), hipMemcpyDeviceToDevice, st));
 		}
 		MVS_HIP(hipStreamSynchronize(st));
@@ -357,7 +358,11 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 		beta_h1 = nbeta;
 		h1_cap = nc;
 	}
-	launch_rows_to_bf16_hi(geom, metric, vecs, h1_rows, ntotal - h1_rows, mu_h1, vecs_h1, beta_h1, norms, d_max_norm_bits, st);
+	if (dp1 > 128) // csrc/flat_collect_wide.hip
+		launch_rows_to_bf16_wide(metric, vecs, geom.dp, geom.pair_interleaved ? 1 : 0, d, dp1, h1_rows, ntotal - h1_rows, mu_h1, vecs_h1,
+		                         beta_h1, norms, d_max_norm_bits, st);
+	else
+		launch_rows_to_bf16_hi(geom, metric, vecs, h1_rows, ntotal - h1_rows, mu_h1, vecs_h1, beta_h1, norms, d_max_norm_bits, st);
 	h1_rows = ntotal;
 }
 
@@ -376,11 +381,20 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		launch_collect_rowmask(sel, d_idmap, ntotal, (unsigned long long *)ws_rowmask.p, st);
 		rowmask = (const unsigned long long *)ws_rowmask.p;
 	}
-	ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
+	const int dp1 = collect_store_dims(d);
+	const bool wide = dp1 > 128; // csrc/flat_collect_wide.hip: no selector instance, no one-wavefront-per-segment path
+	if (wide && has_sel)
+		throw_faiss("mvs::FlatIndex::collect_candidates", __FILE__, "the wide coarse filter has no selector instance (d = %d)", d);
 	ws_qn.reserve((size_t)nq * sizeof(float));
-	launch_collect_pack_queries(geom, metric, d_x, nq, mu_h1, ws_pfq.p, st);
+	if (wide) {
+		ws_pfq.reserve(collect_qfrag_bytes_ex(dp1, collect_wide_qblock(dp1), nq));
+		launch_collect_pack_queries_ex(d, dp1, collect_wide_qblock(dp1), metric, d_x, nq, mu_h1, ws_pfq.p, st);
+	} else {
+		ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
+		launch_collect_pack_queries(geom, metric, d_x, nq, mu_h1, ws_pfq.p, st);
+	}
 	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
-	const int64_t nq128 = (nq + 127) / 128 * 128;
+	const int64_t nq128 = (nq + 255) / 256 * 256;
 	ws_e2.reserve((size_t)nq128 * sizeof(float));
 	MVS_HIP(hipMemsetAsync(ws_e2.p, 0xff, (size_t)nq128 * sizeof(float), st)); // NaN: the slots behind the last query
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
@@ -394,7 +408,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, rowmask, st);
 	int grid = 0, nsplit = 0, lds = 0;
-	const bool few = nq <= 128 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
+	const bool few = !wide && nq <= 128 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	begin_kernel_timing(st);
 	if (few) {
 		// Small batches are bound by streaming the bf16 store, not by the matrix pipe: the one-wavefront-per-segment kernel of
@@ -447,7 +461,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel || nq < 20, st);
 	*pd1_out = pd1;
 	*pi1_out = pi1;
-	snprintf(kinfo.name, sizeof kinfo.name, "flat_bf16_collect_kernel");
+	snprintf(kinfo.name, sizeof kinfo.name, wide ? "flat_bf16_wide_kernel" : "flat_bf16_collect_kernel");
 	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
 	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * kk * 12.0;
 	kinfo.grid = grid;
@@ -774,10 +788,14 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
                                  const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map,
                                  int64_t out_off, const TieFlags *flp, hipStream_t st) {
-	if (prefilter_mode == 0 || pf_suppressed || !prefilter_supported(geom) || kk > 40)
+	// 128 < d <= 512: only the coarse filter exists (csrc/flat_collect_wide.hip; no selector instance, no bf16x3 behind it)
+	const bool wide = collect_store_dims(d) > 128;
+	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !wide) || kk > 40)
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
+	if (wide && (has_sel || kk > 16 || prefilter_mode == 1))
+		return false;
 	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16))
 		return false;
 	// auto: the contraction must dominate.  The coarse filter wins from FAISS's first BLAS-branch batch on (N = 10M: 1.3 ms vs
@@ -808,7 +826,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		if (!collected)
 			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 	}
-	if (!collected && (has_sel || nq < 20))
+	if (!collected && (has_sel || nq < 20 || wide))
 		return false; // (stream overflow under a selector / in the per-pair branch: the exact kernels take the batch)
 	if (!collected) {
 	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the

@@ -1,0 +1,143 @@
+"""bf16 coarse filter for 128 < d <= 512 (csrc/flat_collect_wide.hip, option prefilter = 2) behind IndexFlat::search
+(src/faiss_extension.cpp:631): same contract as tests/test_collect_gpu.py -- labels and distances BIT FOR BIT those of the
+exact f32 kernel and of the oracle's BLAS branch -- at the store widths 256 / 384 / 512, with ragged dimensions, both
+metrics, through IDMap, with duplicates, offset data, non-finite queries and small (per-pair branch) batches."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+L2, IP = orc.METRIC_L2, orc.METRIC_INNER_PRODUCT
+KERNEL = "flat_bf16_wide_kernel"
+
+
+@pytest.fixture(scope="module")
+def mf():
+    import mi355_faiss
+
+    return mi355_faiss
+
+
+def _pair(mf, d, metric, xb, desc="Flat", ids=None):
+    cl, ex = mf.index_factory(d, desc, metric), mf.index_factory(d, desc, metric)
+    cl.set_option("prefilter", 2)
+    ex.set_option("prefilter", 0)
+    for ix in (cl, ex):
+        for i0 in range(0, len(xb), 1 << 15):
+            if ids is None:
+                ix.add(xb[i0 : i0 + (1 << 15)])
+            else:
+                ix.add_with_ids(xb[i0 : i0 + (1 << 15)], ids[i0 : i0 + (1 << 15)])
+    return cl, ex
+
+
+def _check(cl, ex, xq, k, metric, xb=None, oracle_rows=0, path=orc.PATH_BLAS, kernel=KERNEL):
+    D1, I1 = cl.search(xq, k)
+    assert cl.last_kernel_info()["name"] == kernel, cl.last_kernel_info()
+    D0, I0 = ex.search(xq, k)
+    assert ex.last_kernel_info()["name"] != KERNEL
+    assert np.array_equal(I1, I0), "labels differ from the exact f32 kernel"
+    assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), "distances differ from the exact f32 kernel"
+    if oracle_rows:
+        Do, Io = orc.flat_search(metric, xb, xq[:oracle_rows], k, force_path=path)
+        assert np.array_equal(I1[:oracle_rows], Io) and np.array_equal(D1[:oracle_rows].view(np.uint32), Do.view(np.uint32))
+    return D1, I1
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,nb,nq,k", [(256, 60_000, 600, 10), (192, 40_001, 257, 1), (129, 30_000, 300, 5), (384, 50_000, 333, 10),
+                                       (300, 35_000, 130, 15), (512, 40_000, 260, 10), (400, 20_000, 64, 3)])
+def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
+    rs = np.random.RandomState(d + nb)
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    cl, ex = _pair(mf, d, metric, xb)
+    _check(cl, ex, xq, k, metric, xb, oracle_rows=48)
+    st = cl.collect_stats()
+    assert st["queries"] == nq and st["overflows"] == 0 and st["candidates"] >= nq * k, st
+    assert cl.prefilter_stats()["fallback_queries"] == 0
+    # the filter does filter: far fewer candidates than rows
+    assert st["candidates"] < nq * nb * 0.2, st
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_wide_normalised_embeddings_and_added_rows(mf, metric):
+    """unit vectors (the C4 shape at a width the kernel serves), rows added after the first search (the store grows, the
+    centre stays), lists up to the filter's 16"""
+    rs = np.random.RandomState(11)
+    d = 384
+    xb = rs.randn(45_000, d).astype(np.float32)
+    xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+    xq = rs.randn(400, d).astype(np.float32)
+    xq /= np.linalg.norm(xq, axis=1, keepdims=True)
+    cl, ex = _pair(mf, d, metric, xb[:30_000])
+    _check(cl, ex, xq, 10, metric, xb[:30_000], oracle_rows=32)
+    cl.add(xb[30_000:])
+    ex.add(xb[30_000:])
+    _check(cl, ex, xq, 16 if metric == L2 else 15, metric, xb, oracle_rows=32)  # (inner product keeps one rank for its tie detection)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_wide_duplicates_offsets_and_idmap(mf, metric):
+    rs = np.random.RandomState(3)
+    d = 256
+    xb = (rs.rand(50_000, d) * 2.0 + 3.0).astype(np.float32)  # far from the origin: the centring keeps the bound tight
+    xb[rs.randint(0, 50_000, 8_000)] = xb[rs.randint(0, 50_000, 8_000)]
+    xq = np.concatenate([(rs.rand(150, d) * 2.0 + 3.0).astype(np.float32), xb[rs.randint(0, 50_000, 150)]])
+    ids = rs.permutation(1 << 20)[:50_000].astype(np.int64)
+    cl, ex = _pair(mf, d, metric, xb, desc="IDMap,Flat", ids=ids)
+    D1, I1 = _check(cl, ex, xq, 10, metric)
+    Do, Io = orc.flat_search(metric, xb, xq[:64], 10, force_path=orc.PATH_BLAS)
+    assert np.array_equal(I1[:64], ids[Io]) and np.array_equal(D1[:64].view(np.uint32), Do.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_wide_non_finite_queries_go_to_the_exact_kernel(mf, metric):
+    rs = np.random.RandomState(8)
+    d = 320
+    xb = rs.rand(30_000, d).astype(np.float32)
+    xq = rs.rand(200, d).astype(np.float32)
+    xq[5, 7] = np.inf
+    xq[17, 300] = np.nan
+    xq[99] *= 1e30
+    cl, ex = _pair(mf, d, metric, xb)
+    D1, I1 = cl.search(xq, 5)
+    D0, I0 = ex.search(xq, 5)
+    assert cl.last_kernel_info()["name"] == KERNEL
+    assert cl.prefilter_stats()["fallback_queries"] >= 3
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_wide_small_batch_uses_the_per_pair_arithmetic(mf, metric):
+    """fewer than 20 queries: FAISS's per-pair branch (L2 = sum (x - y)^2); the candidates are re-scored in that arithmetic"""
+    rs = np.random.RandomState(21)
+    d = 256
+    xb = rs.rand(40_000, d).astype(np.float32)
+    xq = rs.rand(7, d).astype(np.float32)
+    cl, ex = _pair(mf, d, metric, xb)
+    D1, I1 = cl.search(xq, 10)
+    assert cl.last_kernel_info()["name"] == KERNEL
+    D0, I0 = ex.search(xq, 10)
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
+    Do, Io = orc.flat_search(metric, xb, xq, 10)  # the oracle picks the branch by the batch size, as FAISS does
+    assert np.array_equal(I1, Io) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32))
+
+
+def test_wide_is_not_used_where_it_has_no_instance(mf):
+    """d > 512 and selectors stay on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
+    rs = np.random.RandomState(2)
+    xb = rs.rand(20_000, 768).astype(np.float32)
+    ix = mf.index_factory(768, "Flat", L2)
+    ix.set_option("prefilter", 2)
+    ix.add(xb)
+    D, I = ix.search(xb[:40], 3)
+    assert ix.last_kernel_info()["name"] == "flat_mfma_kernel" and np.array_equal(I[:, 0], np.arange(40))
+    xb = rs.rand(30_000, 256).astype(np.float32)
+    cl, ex = _pair(mf, 256, L2, xb)
+    sel = ("batch", np.arange(0, 30_000, 3, dtype=np.int64))
+    D1, I1 = cl.search(xb[:50], 5, sel=sel)
+    assert cl.last_kernel_info()["name"] != KERNEL
+    D0, I0 = ex.search(xb[:50], 5, sel=sel)
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
