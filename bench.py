@@ -354,8 +354,8 @@ def main():
                         and w.get("grid") == kinfo["grid"]
                     ):
                         traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r2_traffic.json (" + w["source"] + ")"
-            if kinfo["name"].startswith("flat_bf16_collect"):
-                # bf16 coarse filter (csrc/flat_collect.hip): ONE bf16 MFMA product per element pair is the algorithm, so its
+            if kinfo["name"].startswith("flat_bf16_collect") or kinfo["name"].startswith("flat_bf16_wide"):
+                # bf16 coarse filter (csrc/flat_collect.hip; 128 < d <= 768: csrc/flat_collect_wide.hip): ONE bf16 MFMA product per element pair is the algorithm, so its
                 # algorithmic flops are 2 nq N d, priced against the dense bf16 peak; the candidates it admits are re-scored
                 # exactly in f32 (their kernels are inside the timed step, not inside this launch)
                 st = ix.prefilter_stats()

@@ -1,12 +1,12 @@
-// csrc/flat_collect_wide.hip -- the bf16 coarse filter of flat_collect.hip for 128 < d <= 512.
+// csrc/flat_collect_wide.hip -- the bf16 coarse filter of flat_collect.hip for 128 < d <= 768.
 //
 // Same argument, same bound, same candidate stream and re-scoring (see flat_collect.hip); what changes is the geometry.  The
 // query fragments of a wave must stay in registers for the whole scan (re-streaming them costs more L2 bandwidth than the
 // matrix pipe saves), and 128 queries x 512 dims do not fit: a wave keeps 32 * QT queries (QT = 2 up to d = 256, 1 beyond) x
 // all KB k-blocks = 8 * QT * KB VGPRs (128 at d = 256 and 512), a workgroup 128 * QT queries, so the database is re-read by
 // nq / (128 QT) query blocks instead of nq / 512 -- the scan becomes bound by L2 -> LDS traffic rather than by the matrix
-// pipe, and still several times faster than the f32 kernel (which serves d > 128 otherwise; and d > 512: 32 queries x
-// 768 dims = 192 VGPRs of fragments spill).
+// pipe, and still several times faster than the f32 kernel (which serves d > 128 otherwise).  512 < d <= 768: 32 queries x
+// 768 dims = 192 VGPRs of fragments spill -- flat_bf16_ksplit_kernel below splits the k dimension over a wave pair.
 //   rows      16 per tile (one MFMA row block), staged 1-3 tiles per barrier (<= 24 KB) by LDS-DMA, chunks XOR-swizzled by
 //             row within aligned groups of 16 chunks
 //   A         fragments read on demand, two k-blocks ahead (hand-written ds_read_b128, a ring of 4 VGPR quads)
@@ -279,6 +279,245 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 	}
 }
 
+// ---- 512 < d <= 768: the k dimension split over a wave pair ---------------------------------------------------------------------
+// 32 queries x 24 k-blocks are 192 VGPRs of query fragments -- too many for one wave.  Waves 2 g and 2 g + 1 share the 32 queries
+// of group g and hold 12 k-blocks each (96 VGPRs); both run their half of the chain over the same 16-row tile, hand the partial
+// sums of the OTHER wave's column block over through LDS (1 KB each way) and finish their own 16 queries: s = (beta + half) + half.
+// (One more f32 addition than the single chain; the bound counts d / 16 accumulation steps where d / 32 + 1 happen.)
+// A workgroup serves 64 queries, a staged block is one tile (24 KB), the workgroup barrier of the hand-over is the staging barrier.
+template <bool IS_L2, bool COLLECT>
+__global__ __launch_bounds__(256, 2) void flat_bf16_ksplit_kernel(const CollectArgs a) {
+	constexpr int KBT = 24, KH = 12;
+	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
+	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB
+	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096;
+	constexpr int QB = 64;
+	constexpr int FLUSH_EVERY = 8;
+
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	char *tbuf = (char *)smem;                                        // [2][STAGE_BYTES]
+	float *nbuf = (float *)(tbuf + 2 * STAGE_BYTES);                  // [2][64] beta of the staged rows (16 used)
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
+	f32x4w *xbuf = (f32x4w *)(qbuf + CL_QCAP);                        // [2][4 waves][64 lanes] partial sums for the partner wave
+	float *cqtab = (float *)(xbuf + 2 * 4 * 64);                      // [4 waves][16 c]: pass bound of every query
+	unsigned *qctl = (unsigned *)(cqtab + QB);                        // [0] queue fill, [2..3] flush base
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int kh = wave & 1, qg = wave >> 1;
+	const int hq = lane >> 4, c = lane & 15;
+	int split, qb;
+	if (a.xcd_map) {
+		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+		split = (idx / a.nqb) * 8 + xcd;
+		qb = idx % a.nqb;
+	} else {
+		split = blockIdx.x / a.nqb;
+		qb = blockIdx.x % a.nqb;
+	}
+	const long long r_begin = a.row_first + (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int nblocks = r_end > r_begin ? (int)((r_end - r_begin + RT - 1) / RT) : 0;
+	if (tid == 0)
+		qctl[0] = 0u;
+	const int qown = qb * QB + wave * 16; // the 16 queries this wave finishes: column block kh of group qg
+
+	bf16x8 bq[2][KH]; // [column block of the group][k-block of this wave's half]
+	{
+		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
+#pragma unroll
+		for (int cb = 0; cb < 2; ++cb) {
+			const size_t qblk16 = (size_t)qb * (QB / 16) + qg * 2 + cb;
+#pragma unroll
+			for (int kb = 0; kb < KH; ++kb)
+				bq[cb][kb] = qsrc[(qblk16 * KBT + kh * KH + kb) * 64 + lane];
+		}
+	}
+
+	auto dma_block = [&](int u) {
+		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)u * RT) * PITCH; // uniform
+#pragma unroll
+		for (int i = 0; i < DMA_PER_WAVE; ++i) {
+			const int inst = 4 * i + wave;
+			const int S = 64 * inst + lane, r = S / C, p = S - r * C;
+			const unsigned off = (unsigned)(r * PITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + off),
+			                                 (lds_f32c *)(smem + ((u & 1) * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
+		}
+		if (wave == 0) {
+			const float *bb = a.yn + (r_begin + (long long)u * RT); // uniform
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (2 * STAGE_BYTES) / 4 + (u & 1) * 64), 4, 0, 0);
+		}
+	};
+	if (nblocks > 0)
+		dma_block(0);
+	__syncthreads();
+
+	const unsigned rbase = (unsigned)(c * PITCH) + (unsigned)(((hq ^ c) & 15) * 16) + (unsigned)(kh * (KH / 4) * 256);
+	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
+	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 16 + c) * 4);
+
+	for (int u = 0; u < nblocks; ++u) {
+		const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
+		if ((u % period) == 0 && hq == 0) {
+			// B = the kk-th best of the 16 class bests of the lane's own query (bitonic network in registers)
+			int qo = qown;
+			MVS_OPAQUE_VGPR(qo);
+			const int q = qo + c;
+			const int qc = q < a.nq ? q : 0;
+			unsigned long long w[8];
+			const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const float e2v = __builtin_nontemporal_load(a.e2 + qc);
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				asm volatile("" : "+v"(w[j]));
+			unsigned key[16];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				key[2 * j] = (unsigned)w[j];
+				key[2 * j + 1] = (unsigned)(w[j] >> 32);
+			}
+#pragma unroll
+			for (int kbit = 2; kbit <= 16; kbit <<= 1)
+#pragma unroll
+				for (int jb = kbit >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+					for (int x0 = 0; x0 < 16; ++x0) {
+						const int x1 = x0 ^ jb;
+						if (x1 > x0) {
+							const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
+							const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
+							const bool asc = (x0 & kbit) == 0;
+							key[x0] = asc ? lo : hi;
+							key[x1] = asc ? hi : lo;
+						}
+					}
+			unsigned kth = key[0];
+#pragma unroll
+			for (int j = 1; j < 16; ++j)
+				kth = (a.nclass - 1 == j) ? key[j] : kth;
+			const unsigned neutral = skey(-FLT_MAX);
+			const float B = skey2f(kth < neutral ? kth : neutral);
+			cqtab[wave * 16 + c] = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u);
+		}
+		dma_block(u + 1);
+		const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + ((u & 1) * STAGE_BYTES) / 4)) + rbase;
+		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * hq));
+		const long long row0 = r_begin + (long long)u * RT;
+		const int nvalid = (int)((r_end - row0) < RT ? (r_end - row0) : RT);
+		f32x4n Y;
+		float cq;
+		asm volatile("ds_read_b128 %0, %1" : "=v"(Y) : "v"(nb_lds) : "memory");
+		asm volatile("ds_read_b32 %0, %1" : "=v"(cq) : "v"(cq_lds) : "memory");
+		bf16x8 A[4];
+		asm volatile("ds_read_b128 %0, %1" : "=v"(A[0]) : "v"(tb) : "memory");
+		asm volatile("ds_read_b128 %0, %1" : "=v"(A[1]) : "v"(tb ^ 64u) : "memory");
+		f32x4w acc[2];
+#pragma unroll
+		for (int g = 0; g < KH / 2; ++g) {
+			if (g + 1 < KH / 2) {
+				const int k2 = 2 * g + 2, k3 = 2 * g + 3;
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[k2 & 3]) : "v"((tb ^ (unsigned)((k2 & 3) * 64)) + (unsigned)((k2 >> 2) * 256)) : "memory");
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[k3 & 3]) : "v"((tb ^ (unsigned)((k3 & 3) * 64)) + (unsigned)((k3 >> 2) * 256)) : "memory");
+				asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cq));
+			} else {
+				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cq));
+			}
+#pragma unroll
+			for (int kk2 = 0; kk2 < 2; ++kk2) {
+				const int kb = 2 * g + kk2;
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+					if (kb == 0) { // beta(row) enters the chain of the column block this wave finishes, once
+						f32x4w y0;
+#pragma unroll
+						for (int r = 0; r < 4; ++r)
+							y0[r] = (i == kh) ? Y[r] : 0.f;
+						acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[i][kb], y0, 0, 0, 0);
+					} else {
+						acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[i][kb], acc[i], 0, 0, 0);
+					}
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		xbuf[((u & 1) * 4 + wave) * 64 + lane] = kh ? acc[0] : acc[1];
+		__syncthreads(); // the partner's half is there; the next block's LDS-DMA has landed (vmcnt(0)); this stage is free again
+		const f32x4w mine = kh ? acc[1] : acc[0];
+		const f32x4w other = xbuf[((u & 1) * 4 + (wave ^ 1)) * 64 + lane];
+		const f32x4w sv = mine + other;
+		const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
+		const bool any_t = mx >= cq; // NaN on either side: false
+		if (__builtin_amdgcn_ballot_w64(any_t) != 0ull) {
+			int qo = qown;
+			MVS_OPAQUE_VGPR(qo);
+			const int q = qo + c;
+			unsigned m = 0u;
+			if (any_t) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (4 * hq + r < nvalid && sv[r] >= cq)
+						m |= 1u << r;
+			}
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const float lo = (j & 1) ? sv[1] : sv[0];
+				const float hi = (j & 1) ? sv[3] : sv[2];
+				const float v = (j & 2) ? hi : lo;
+				const unsigned row = (unsigned)(row0 + 4 * hq + j);
+				typedef __attribute__((address_space(1))) unsigned *GU;
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
+				                       __HIP_MEMORY_SCOPE_AGENT);
+				if (COLLECT) {
+					unsigned pos;
+					const unsigned one = 1u;
+					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+					if (pos < (unsigned)CL_QCAP) {
+						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+					} else {
+						unsigned long long gp;
+						const unsigned long long one64 = 1ull;
+						typedef __attribute__((address_space(1))) unsigned long long *GUL;
+						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+						             : "=&v"(gp)
+						             : "v"((GUL)a.stream_cnt), "v"(one64)
+						             : "memory");
+						if ((long long)gp < a.stream_cap)
+							*((GUL)a.stream + gp) = ent;
+					}
+				}
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+		if (COLLECT && ((u % FLUSH_EVERY) == FLUSH_EVERY - 1 || u == nblocks - 1)) {
+			__syncthreads(); // every wave's appends of this block are in
+			const unsigned fill = qctl[0];
+			__syncthreads();
+			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
+			if (n >= (unsigned)CL_QCAP / 2 || (u == nblocks - 1 && n > 0)) {
+				if (tid == 0) {
+					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+					qctl[0] = 0u;
+				}
+				__syncthreads();
+				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
+				for (unsigned i = tid; i < n; i += 256)
+					if ((long long)(base + i) < a.stream_cap)
+						a.stream[base + i] = qbuf[i];
+				__syncthreads();
+			}
+		}
+	}
+}
+
 // ---- storage: one wave per row (plain f32 rows of pitch sdp, d logical dims) -> centred bf16 [dp1] + beta ------------------------
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__restrict__ src, int sdp, int d, int dp1,
@@ -415,22 +654,23 @@ void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
-// row pitch (dims) of the bf16 store for a logical dimension: 128 (flat_collect.hip), 256, 384 or 512; 0 = not served
-// (d = 768: 32 queries x 24 k-blocks = 192 VGPRs of fragments spill; 16 queries per wave would make LDS reads the bound)
+// row pitch (dims) of the bf16 store for a logical dimension: 128 (flat_collect.hip), 256, 384, 512 or 768 (k-split); 0 = not served
 int collect_store_dims(int d) {
-	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : 0))));
+	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : 0)))));
 }
 static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }
 int collect_wide_qblock(int dp1) {
-	return 128 * wide_qt(dp1);
+	return dp1 == 768 ? 64 : 128 * wide_qt(dp1);
 }
 static int wide_wsub(int dp1) {
 	const int KB = dp1 / 32;
 	return KB >= 16 ? 1 : (KB >= 12 ? 2 : 3);
 }
 size_t collect_wide_lds_bytes(int dp1) {
+	if (dp1 == 768) // flat_bf16_ksplit_kernel: two 24 KB stages, beta, queue, hand-over buffers, bounds, control
+		return (size_t)2 * 16 * 768 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + 2 * 4 * 64 * 16 + 64 * 4 + 64;
 	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)collect_wide_qblock(dp1) * 4 + 64;
 }
 int collect_wide_block_rows(int dp1) {
@@ -481,6 +721,23 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 			launch_wide_inst<16, 1, true>(metric, a, grid, lds, st);
 		else
 			launch_wide_inst<16, 1, false>(metric, a, grid, lds, st);
+	} else if (dp1 == 768) {
+#define MVS_KSP(L2, CO)                                                                                         \
+	{                                                                                                           \
+		auto kern = flat_bf16_ksplit_kernel<L2, CO>;                                                            \
+		ensure_dynamic_lds((const void *)kern, lds);                                                            \
+		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                                  \
+	}
+		if (metric == METRIC_L2 && collect)
+			MVS_KSP(true, true)
+		else if (metric == METRIC_L2)
+			MVS_KSP(true, false)
+		else if (collect)
+			MVS_KSP(false, true)
+		else
+			MVS_KSP(false, false)
+#undef MVS_KSP
+		MVS_HIP(hipGetLastError());
 	} else {
 		throw_faiss("mvs::launch_collect_wide_range", __FILE__, "no instance for a %d-dim store", dp1);
 	}

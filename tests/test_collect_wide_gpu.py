@@ -1,6 +1,6 @@
-"""bf16 coarse filter for 128 < d <= 512 (csrc/flat_collect_wide.hip, option prefilter = 2) behind IndexFlat::search
+"""bf16 coarse filter for 128 < d <= 768 (csrc/flat_collect_wide.hip, option prefilter = 2) behind IndexFlat::search
 (src/faiss_extension.cpp:631): same contract as tests/test_collect_gpu.py -- labels and distances BIT FOR BIT those of the
-exact f32 kernel and of the oracle's BLAS branch -- at the store widths 256 / 384 / 512, with ragged dimensions, both
+exact f32 kernel and of the oracle's BLAS branch -- at the store widths 256 / 384 / 512 / 768 (the last: k split over a wave pair), with ragged dimensions, both
 metrics, through IDMap, with duplicates, offset data, non-finite queries and small (per-pair branch) batches."""
 import numpy as np
 import pytest
@@ -47,7 +47,8 @@ def _check(cl, ex, xq, k, metric, xb=None, oracle_rows=0, path=orc.PATH_BLAS, ke
 
 @pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("d,nb,nq,k", [(256, 60_000, 600, 10), (192, 40_001, 257, 1), (129, 30_000, 300, 5), (384, 50_000, 333, 10),
-                                       (300, 35_000, 130, 15), (512, 40_000, 260, 10), (400, 20_000, 64, 3)])
+                                       (300, 35_000, 130, 15), (512, 40_000, 260, 10), (400, 20_000, 64, 3),
+                                       (768, 40_000, 300, 10), (600, 25_000, 65, 15), (513, 20_000, 200, 1), (700, 30_000, 1000, 4)])
 def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
     rs = np.random.RandomState(d + nb)
     xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
@@ -61,12 +62,12 @@ def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
     assert st["candidates"] < nq * nb * 0.2, st
 
 
+@pytest.mark.parametrize("d", [384, 768])
 @pytest.mark.parametrize("metric", [L2, IP])
-def test_wide_normalised_embeddings_and_added_rows(mf, metric):
+def test_wide_normalised_embeddings_and_added_rows(mf, metric, d):
     """unit vectors (the C4 shape at a width the kernel serves), rows added after the first search (the store grows, the
     centre stays), lists up to the filter's 16"""
     rs = np.random.RandomState(11)
-    d = 384
     xb = rs.randn(45_000, d).astype(np.float32)
     xb /= np.linalg.norm(xb, axis=1, keepdims=True)
     xq = rs.randn(400, d).astype(np.float32)
@@ -79,9 +80,9 @@ def test_wide_normalised_embeddings_and_added_rows(mf, metric):
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
-def test_wide_duplicates_offsets_and_idmap(mf, metric):
+@pytest.mark.parametrize("d", [256, 768])
+def test_wide_duplicates_offsets_and_idmap(mf, metric, d):
     rs = np.random.RandomState(3)
-    d = 256
     xb = (rs.rand(50_000, d) * 2.0 + 3.0).astype(np.float32)  # far from the origin: the centring keeps the bound tight
     xb[rs.randint(0, 50_000, 8_000)] = xb[rs.randint(0, 50_000, 8_000)]
     xq = np.concatenate([(rs.rand(150, d) * 2.0 + 3.0).astype(np.float32), xb[rs.randint(0, 50_000, 150)]])
@@ -93,9 +94,9 @@ def test_wide_duplicates_offsets_and_idmap(mf, metric):
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
-def test_wide_non_finite_queries_go_to_the_exact_kernel(mf, metric):
+@pytest.mark.parametrize("d", [320, 640])
+def test_wide_non_finite_queries_go_to_the_exact_kernel(mf, metric, d):
     rs = np.random.RandomState(8)
-    d = 320
     xb = rs.rand(30_000, d).astype(np.float32)
     xq = rs.rand(200, d).astype(np.float32)
     xq[5, 7] = np.inf
@@ -110,10 +111,10 @@ def test_wide_non_finite_queries_go_to_the_exact_kernel(mf, metric):
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
-def test_wide_small_batch_uses_the_per_pair_arithmetic(mf, metric):
+@pytest.mark.parametrize("d", [256, 768])
+def test_wide_small_batch_uses_the_per_pair_arithmetic(mf, metric, d):
     """fewer than 20 queries: FAISS's per-pair branch (L2 = sum (x - y)^2); the candidates are re-scored in that arithmetic"""
     rs = np.random.RandomState(21)
-    d = 256
     xb = rs.rand(40_000, d).astype(np.float32)
     xq = rs.rand(7, d).astype(np.float32)
     cl, ex = _pair(mf, d, metric, xb)
@@ -126,10 +127,10 @@ def test_wide_small_batch_uses_the_per_pair_arithmetic(mf, metric):
 
 
 def test_wide_is_not_used_where_it_has_no_instance(mf):
-    """d > 512 and selectors stay on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
+    """d > 768 and selectors stay on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
     rs = np.random.RandomState(2)
-    xb = rs.rand(20_000, 768).astype(np.float32)
-    ix = mf.index_factory(768, "Flat", L2)
+    xb = rs.rand(20_000, 1024).astype(np.float32)
+    ix = mf.index_factory(1024, "Flat", L2)
     ix.set_option("prefilter", 2)
     ix.add(xb)
     D, I = ix.search(xb[:40], 3)
