@@ -1003,6 +1003,46 @@ void launch_collect_select(int metric, const unsigned long long *d_keys, const i
 	MVS_HIP(hipGetLastError());
 }
 
+// Inner-product tie pass from the candidate list (instead of another pass over the database): for flagged query f with boundary
+// score T the rows with exact score >= T all are candidates (they are at least as good as the kk-th best), so A_k -- the k smallest
+// row ids among them, ascending; what FlatIndex::tie_candidates computes with the TIE epilogue -- is read off the query's
+// segment of the re-scored list.  One wave per flagged query, k rounds of "smallest row id above the previous one".
+__global__ __launch_bounds__(64) void collect_tie_rows_kernel(const unsigned long long *__restrict__ sorted, const int *__restrict__ seg_b,
+                                                             const int *__restrict__ seg_e, const int *__restrict__ fq,
+                                                             const float *__restrict__ T, int k, long long *__restrict__ first) {
+	const int f = blockIdx.x, lane = threadIdx.x;
+	const int q = fq[f];
+	const unsigned tk = bkey<false>(T[f]); // smaller key = larger score
+	const int b = seg_b[q], e = seg_e[q];
+	long long last = -1;
+	for (int j = 0; j < k; ++j) {
+		unsigned best = 0xffffffffu;
+		if (last != -2) {
+			for (int i = b + lane; i < e; i += 64) {
+				const unsigned long long ent = sorted[i];
+				const unsigned row = (unsigned)ent;
+				if (ent != ~0ull && (unsigned)(ent >> 32) <= tk && (long long)row > last && row < best)
+					best = row;
+			}
+			for (int o = 32; o >= 1; o >>= 1) {
+				const unsigned other = (unsigned)__shfl_xor((int)best, o);
+				best = other < best ? other : best;
+			}
+		}
+		if (lane == 0)
+			first[(size_t)f * k + j] = best == 0xffffffffu ? -1ll : (long long)best;
+		last = best == 0xffffffffu ? -2 : (long long)best; // exhausted: the remaining slots are -1
+	}
+}
+void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_seg, int64_t nq, const int *d_flag_query,
+                             const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st) {
+	if (nf <= 0)
+		return;
+	hipLaunchKernelGGL(collect_tie_rows_kernel, dim3((unsigned)nf), dim3(64), 0, st, d_sorted, d_seg, d_seg + nq, d_flag_query, d_T,
+	                   k, (long long *)d_first);
+	MVS_HIP(hipGetLastError());
+}
+
 // stream (ncand entries) -> per query the kk best exact candidates: pd1 / pi1 [nq][kk] (value, row), best first
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,

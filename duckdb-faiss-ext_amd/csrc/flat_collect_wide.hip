@@ -575,47 +575,71 @@ void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int inte
 	MVS_HIP(hipGetLastError());
 }
 
-// ---- candidates -> exact values: one wave per 16 candidates, rows (plain f32, pitch sdp) staged through LDS with coalesced loads,
-// lanes 0..15 run the k-ordered chains (PAIR: FAISS's per-pair branch for L2, see flat_collect.hip)
+// ---- candidates -> exact values: one wave per 64 candidates, one k-ordered chain per lane (PAIR: FAISS's per-pair branch for L2,
+// see flat_collect.hip).  The 64 rows (f32, pitch sdp, FlatGeom::pair_interleaved or plain) pass through LDS in slabs of 64
+// dimensions fetched with coalesced 16-byte loads; the candidates are sorted by query, so the query values are broadcast loads.
 template <bool IS_L2, bool PAIR>
 __global__ __launch_bounds__(64) void collect_exact_wide_kernel(unsigned long long *__restrict__ sorted, long long ncand,
                                                                const float *__restrict__ x, int d,
                                                                const float *__restrict__ vecs, int sdp, int interleaved,
                                                                const float *__restrict__ norms, const float *__restrict__ qn) {
-	extern __shared__ __attribute__((aligned(16))) float wrows[]; // [16][sdp + 4]
-	const int pitch = sdp + 4, cpr = sdp / 4;
+	__shared__ float tile[64][65];
 	const int lane = threadIdx.x;
-	const long long i0 = (long long)blockIdx.x * 16;
-	const long long i = i0 + (lane & 15);
-	const unsigned long long ent = i < ncand ? sorted[i] : 0ull;
+	const long long i = (long long)blockIdx.x * 64 + lane;
+	const unsigned long long ent = i < ncand ? sorted[i] : 0ull; // (idle lanes: row 0 of query 0, computed and dropped)
 	const unsigned row = (unsigned)ent;
 	const long long q = (long long)(ent >> 32);
-	for (int it = 0; it < (16 * cpr + 63) / 64; ++it) { // 64 consecutive float4 of the 16 x cpr block per step
-		const int idx = it * 64 + lane;
-		if (idx < 16 * cpr) {
-			const int r = idx / cpr, ch = idx - r * cpr;
-			const unsigned rr = (unsigned)__shfl((int)row, r);
-			*(float4 *)(wrows + r * pitch + ch * 4) = *(const float4 *)(vecs + (size_t)rr * sdp + ch * 4);
-		} else {
-			(void)__shfl((int)row, 0);
-		}
-	}
-	__syncthreads();
-	if (lane >= 16 || i >= ncand)
-		return;
-	const float *y = wrows + lane * pitch;
+	const bool flip = interleaved && ((row >> 4) & 1); // stored [k1,k3,k0,k2] instead of [k0,k2,k1,k3]
 	const float *xq = x + q * d;
-	const int flip = interleaved ? (((row >> 4) & 1) ? 2 : 0) : 0; // FlatGeom::pair_interleaved
+	const bool x16 = (d & 3) == 0;
 	float acc = 0.f;
-	for (int kk = 0; kk < d; ++kk) {
-		const int j = kk & 3, sk = interleaved ? ((kk & ~3) + ((((j & 1) << 1) | (j >> 1)) ^ flip)) : kk;
-		if (PAIR) {
-			const float t = __fsub_rn(xq[kk], y[sk]);
-			acc = fmaf(t, t, acc);
-		} else {
-			acc = fmaf(xq[kk], y[sk], acc);
+	for (int c0 = 0; c0 < sdp; c0 += 64) {
+#pragma unroll 4
+		for (int it = 0; it < 16; ++it) { // 4 rows x 16 float4 per step
+			const int r = it * 4 + (lane >> 4), ch = lane & 15;
+			const unsigned rr = (unsigned)__shfl((int)row, r);
+			const float4 v = *(const float4 *)(vecs + (size_t)rr * sdp + c0 + ch * 4);
+			tile[r][ch * 4 + 0] = v.x;
+			tile[r][ch * 4 + 1] = v.y;
+			tile[r][ch * 4 + 2] = v.z;
+			tile[r][ch * 4 + 3] = v.w;
 		}
+		__syncthreads();
+		const int w = d - c0 < 64 ? d - c0 : 64; // (<= 0 in the padding)
+		for (int g = 0; g * 4 < w; ++g) {
+			const float s0 = tile[lane][g * 4], s1 = tile[lane][g * 4 + 1], s2 = tile[lane][g * 4 + 2], s3 = tile[lane][g * 4 + 3];
+			float y[4];
+			if (interleaved) {
+				y[0] = flip ? s2 : s0, y[1] = flip ? s0 : s2, y[2] = flip ? s3 : s1, y[3] = flip ? s1 : s3;
+			} else {
+				y[0] = s0, y[1] = s1, y[2] = s2, y[3] = s3;
+			}
+			float xv[4] = {0.f, 0.f, 0.f, 0.f};
+			if (x16) {
+				const float4 t4 = *(const float4 *)(xq + c0 + g * 4);
+				xv[0] = t4.x, xv[1] = t4.y, xv[2] = t4.z, xv[3] = t4.w;
+			} else {
+#pragma unroll
+				for (int e = 0; e < 4; ++e)
+					if (g * 4 + e < w)
+						xv[e] = xq[c0 + g * 4 + e];
+			}
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				if (g * 4 + e < w) {
+					if (PAIR) {
+						const float t = __fsub_rn(xv[e], y[e]);
+						acc = fmaf(t, t, acc);
+					} else {
+						acc = fmaf(xv[e], y[e], acc);
+					}
+				}
+			}
+		}
+		__syncthreads();
 	}
+	if (i >= ncand)
+		return;
 	float ex;
 	bool ok;
 	if (PAIR) {
@@ -635,13 +659,11 @@ void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_
                                const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st) {
 	if (ncand <= 0)
 		return;
-	const dim3 grid((unsigned)((ncand + 15) / 16));
-	const size_t lds = (size_t)16 * (sdp + 4) * sizeof(float);
+	const dim3 grid((unsigned)((ncand + 63) / 64));
 #define MVS_EXW(L2, PR)                                                                                                \
 	{                                                                                                                  \
 		auto kern = collect_exact_wide_kernel<L2, PR>;                                                                 \
-		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
-		hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, d_sorted, (long long)ncand, d_x, d, d_vecs, sdp, interleaved, d_norms, d_qn); \
+		hipLaunchKernelGGL(kern, grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, d, d_vecs, sdp, interleaved, d_norms, d_qn); \
 	}
 	if (metric == METRIC_L2 && per_pair)
 		MVS_EXW(true, true)

@@ -178,6 +178,9 @@ public:
 	float *mu_h1 = nullptr;            // [dp] the centre (mean of the rows present at the first build)
 	int64_t h1_cap = 0, h1_rows = 0;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0;
+	const unsigned long long *cl_sorted = nullptr;  // the re-scored candidate list of the last coarse-filter batch (in ws_stream)
+	const unsigned long long *tie_sorted = nullptr; // != nullptr: resolve_ip_ties reads A_k off that list instead of scanning again
+	bool tie_from_candidates = true; // option tie_from_candidates = 0: inner-product ties re-scan the database (A/B, tests)
 	bool cl_small_path = true; // batches of <= 256 queries on the one-wavefront-per-segment kernel (option cl_small_path)
 	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask, ws_items1;
 	void ensure_bf16_rows(hipStream_t st);
@@ -322,6 +325,8 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
                             bool per_pair, hipStream_t st);
+void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_seg, int64_t nq, const int *d_flag_query,
+                             const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st);
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,

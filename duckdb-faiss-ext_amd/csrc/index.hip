@@ -393,7 +393,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
 		launch_collect_pack_queries(geom, metric, d_x, nq, mu_h1, ws_pfq.p, st);
 	}
-	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
+	if (metric == METRIC_L2) // (inner product re-scores without them)
+		launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
 	const int64_t nq128 = (nq + 255) / 256 * 256;
 	ws_e2.reserve((size_t)nq128 * sizeof(float));
 	MVS_HIP(hipMemsetAsync(ws_e2.p, 0xff, (size_t)nq128 * sizeof(float), st)); // NaN: the slots behind the last query
@@ -461,6 +462,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel || nq < 20, st);
 	*pd1_out = pd1;
 	*pi1_out = pi1;
+	cl_sorted = sorted;
 	snprintf(kinfo.name, sizeof kinfo.name, wide ? "flat_bf16_wide_kernel" : "flat_bf16_collect_kernel");
 	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
 	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * kk * 12.0;
@@ -879,7 +881,15 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		memset(&tsel, 0, sizeof tsel);
 		if (has_sel)
 			tsel = selector.upload(params, st);
-		resolve_ip_ties(nq, d_x, k_user, *flp, tsel, d_idmap, d_D, d_I, st, kp); // (syncs the stream)
+		// (after the coarse filter the rows at or above the boundary score all are candidates: no second pass over the database)
+		tie_sorted = collected && tie_from_candidates ? cl_sorted : nullptr;
+		try {
+			resolve_ip_ties(nq, d_x, k_user, *flp, tsel, d_idmap, d_D, d_I, st, kp); // (syncs the stream)
+		} catch (...) {
+			tie_sorted = nullptr;
+			throw;
+		}
+		tie_sorted = nullptr;
 	} else {
 		MVS_HIP(hipStreamSynchronize(st));
 	}
@@ -941,7 +951,10 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 	int64_t *tI = (int64_t *)((char *)tD + td_bytes);
 	launch_gather_flagged(d_x, d, fl, nf, kraw, k, xf, T, st);
 	(void)tD;
-	tie_candidates(nf, xf, T, k, tI, sel, d_idmap, st);
+	if (tie_sorted)
+		launch_collect_tie_rows(tie_sorted, (const int *)ws_seg.p, nq, fl.query, T, nf, (int)k, tI, st);
+	else
+		tie_candidates(nf, xf, T, k, tI, sel, d_idmap, st);
 	launch_tie_resolve(fl, nf, kraw, k, tI, d_idmap, label_offset, d_D, d_I, st);
 }
 
@@ -1726,6 +1739,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "prefilter")) { // -1 auto, 0 off (exact f32 kernel only), 1 wherever the bf16x3 kernel supports the shape
 		prefilter_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "tie_from_candidates")) {
+		tie_from_candidates = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "cl_small_path")) { // 0: small batches on flat_bf16_collect_kernel as well (A/B)

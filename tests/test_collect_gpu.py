@@ -218,3 +218,26 @@ def test_small_batches_take_faiss_per_pair_branch_on_the_coarse_filter(mf, metri
     D0, I0 = ix.search(xq, k)
     assert ix.last_kernel_info()["name"] != KERNEL
     assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
+
+
+@pytest.mark.parametrize("with_sel", [False, True])
+def test_inner_product_ties_are_resolved_from_the_candidate_list(mf, with_sel):
+    """A tie crossing rank k (integer data: dozens of rows share the k-th score) is FAISS's heap outcome.  The
+    rows at or above the boundary score all are candidates of the coarse filter, so the outcome is computed from that list --
+    no second pass over the database; it must equal the re-scan (option tie_from_candidates = 0) and the oracle."""
+    rs = np.random.RandomState(31)
+    xb = rs.randint(-2, 3, size=(90_000, 96)).astype(np.float32)
+    xq = rs.randint(-2, 3, size=(300, 96)).astype(np.float32)
+    sel = ("batch", np.sort(rs.permutation(90_000)[:60_000]).astype(np.int64)) if with_sel else None
+    cl, ex = _pair(mf, 96, IP, xb)
+    D1, I1 = cl.search(xq, 7, sel=sel)
+    assert cl.last_kernel_info()["name"] == KERNEL
+    cl.set_option("tie_from_candidates", 0)
+    D2, I2 = cl.search(xq, 7, sel=sel)
+    D0, I0 = ex.search(xq, 7, sel=sel)
+    o = orc.Index(96, "Flat", IP)
+    o.add(xb)
+    Do, Io = o.search(xq, 7, sel=sel)
+    assert (Do[:, 6] == Do[:, 5]).mean() > 0.25  # (the data does tie around rank k)
+    for D, I in ((D1, I1), (D2, I2), (D0, I0)):
+        assert np.array_equal(I, Io) and np.array_equal(D, Do)

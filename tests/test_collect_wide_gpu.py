@@ -142,3 +142,17 @@ def test_wide_is_not_used_where_it_has_no_instance(mf):
     assert cl.last_kernel_info()["name"] != KERNEL
     D0, I0 = ex.search(xb[:50], 5, sel=sel)
     assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
+
+
+@pytest.mark.parametrize("d", [256, 768])
+def test_wide_inner_product_boundary_ties(mf, d):
+    """integer data: many rows share the k-th score; FAISS's heap outcome from the candidate list (tests/test_collect_gpu.py)"""
+    rs = np.random.RandomState(d)
+    xb = rs.randint(-1, 2, size=(40_000, d)).astype(np.float32)
+    xq = rs.randint(-1, 2, size=(150, d)).astype(np.float32)
+    cl, ex = _pair(mf, d, IP, xb)
+    D1, I1 = _check(cl, ex, xq, 6, IP)
+    o = orc.Index(d, "Flat", IP)
+    o.add(xb)
+    Do, Io = o.search(xq, 6)
+    assert np.array_equal(I1, Io) and np.array_equal(D1, Do)
