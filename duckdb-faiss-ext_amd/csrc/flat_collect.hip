@@ -799,14 +799,15 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	const int qblock = dp1 > 128 ? collect_wide_qblock(dp1) : CL_QBLOCK;
 	const int nqb = (int)((nq + qblock - 1) / qblock);
 	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 8192 rows per split
+	const int64_t slots = (dp1 == 768 && g_ksplit_waves == 8) ? 256 : 512; // resident workgroups
 	int64_t nsplit = g_cl_nsplit;
 	if (nsplit <= 0) {
 		const int64_t max_split = std::max<int64_t>(1, n / 8192);
 		nsplit = 1;
 		double best = -1;
 		for (int64_t s = 8; s <= std::min<int64_t>(max_split, 512); s += 8) {
-			const int64_t w = s * nqb, rounds = (w + 511) / 512;
-			double eff = (double)w / (double)(rounds * 512);
+			const int64_t w = s * nqb, rounds = (w + slots - 1) / slots;
+			double eff = (double)w / (double)(rounds * slots);
 			if (rounds < 2)
 				eff -= 0.05;
 			eff += 1e-5 * (double)std::min<int64_t>(rounds, 10); // at equal fill: more, shorter rounds balance better (17.6 vs 17.9 ms)

@@ -285,21 +285,22 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 // sums of the OTHER wave's column block over through LDS (1 KB each way) and finish their own 16 queries: s = (beta + half) + half.
 // (One more f32 addition than the single chain; the bound counts d / 16 accumulation steps where d / 32 + 1 happen.)
 // A workgroup serves 64 queries, a staged block is one tile (24 KB), the workgroup barrier of the hand-over is the staging barrier.
-template <bool IS_L2, bool COLLECT>
-__global__ __launch_bounds__(256, 2) void flat_bf16_ksplit_kernel(const CollectArgs a) {
+template <bool IS_L2, bool COLLECT, int NW, int NST>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_kernel(const CollectArgs a) {
 	constexpr int KBT = 24, KH = 12;
 	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
 	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB
-	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096;
-	constexpr int QB = 64;
-	constexpr int FLUSH_EVERY = 8;
+	constexpr int DMA_PER_WAVE = STAGE_BYTES / (1024 * NW);
+	constexpr int QB = 16 * NW;
+	constexpr int FLUSH_EVERY = NST == 3 ? 16 : 8;
+	static_assert(NST == 2 || NST == 3, "two stages (one tile ahead, __syncthreads) or a ring of three (two tiles ahead)");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
-	char *tbuf = (char *)smem;                                        // [2][STAGE_BYTES]
-	float *nbuf = (float *)(tbuf + 2 * STAGE_BYTES);                  // [2][64] beta of the staged rows (16 used)
-	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
-	f32x4w *xbuf = (f32x4w *)(qbuf + CL_QCAP);                        // [2][4 waves][64 lanes] partial sums for the partner wave
-	float *cqtab = (float *)(xbuf + 2 * 4 * 64);                      // [4 waves][16 c]: pass bound of every query
+	char *tbuf = (char *)smem;                                        // [NST][STAGE_BYTES]
+	float *nbuf = (float *)(tbuf + NST * STAGE_BYTES);                // [NST][64] beta of the staged rows (16 used)
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + NST * 64); // [CL_QCAP] candidate queue
+	f32x4w *xbuf = (f32x4w *)(qbuf + CL_QCAP);                        // [2][NW waves][64 lanes] partial sums for the partner wave
+	float *cqtab = (float *)(xbuf + 2 * NW * 64);                     // [NW waves][16 c]: pass bound of every query
 	unsigned *qctl = (unsigned *)(cqtab + QB);                        // [0] queue fill, [2..3] flush base
 
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -336,29 +337,34 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_ksplit_kernel(const CollectA
 		}
 	}
 
-	auto dma_block = [&](int u) {
+	auto dma_block = [&](int u, int stg) {
 		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)u * RT) * PITCH; // uniform
 #pragma unroll
 		for (int i = 0; i < DMA_PER_WAVE; ++i) {
-			const int inst = 4 * i + wave;
+			const int inst = NW * i + wave;
 			const int S = 64 * inst + lane, r = S / C, p = S - r * C;
 			const unsigned off = (unsigned)(r * PITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
 			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + off),
-			                                 (lds_f32c *)(smem + ((u & 1) * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
+			                                 (lds_f32c *)(smem + (stg * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
 		}
 		if (wave == 0) {
 			const float *bb = a.yn + (r_begin + (long long)u * RT); // uniform
-			__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (2 * STAGE_BYTES) / 4 + (u & 1) * 64), 4, 0, 0);
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (NST * STAGE_BYTES) / 4 + stg * 64), 4, 0, 0);
 		}
 	};
-	if (nblocks > 0)
-		dma_block(0);
+	if (nblocks > 0) {
+		dma_block(0, 0);
+		if (NST == 3)
+			dma_block(1, 1);
+	}
 	__syncthreads();
 
 	const unsigned rbase = (unsigned)(c * PITCH) + (unsigned)(((hq ^ c) & 15) * 16) + (unsigned)(kh * (KH / 4) * 256);
 	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
 	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 16 + c) * 4);
+	const unsigned xb_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) f32x4w *)xbuf) + (unsigned)(lane * 16);
+	int stg = 0; // stage of block u
 
 	for (int u = 0; u < nblocks; ++u) {
 		const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
@@ -406,9 +412,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_ksplit_kernel(const CollectA
 			const float B = skey2f(kth < neutral ? kth : neutral);
 			cqtab[wave * 16 + c] = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u);
 		}
-		dma_block(u + 1);
-		const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + ((u & 1) * STAGE_BYTES) / 4)) + rbase;
-		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + 4 * hq));
+		// NST = 3: block u + 2 goes to the stage block u - 1 left at the last barrier; NST = 2: block u + 1
+		dma_block(u + NST - 1, stg == 0 ? NST - 1 : stg - 1);
+		const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + (stg * STAGE_BYTES) / 4)) + rbase;
+		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + stg * 64 + 4 * hq));
 		const long long row0 = r_begin + (long long)u * RT;
 		const int nvalid = (int)((r_end - row0) < RT ? (r_end - row0) : RT);
 		f32x4n Y;
@@ -447,10 +454,24 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_ksplit_kernel(const CollectA
 			}
 			__builtin_amdgcn_sched_barrier(0);
 		}
-		xbuf[((u & 1) * 4 + wave) * 64 + lane] = kh ? acc[0] : acc[1];
-		__syncthreads(); // the partner's half is there; the next block's LDS-DMA has landed (vmcnt(0)); this stage is free again
+		{
+			const f32x4w theirs = kh ? acc[0] : acc[1];
+			asm volatile("ds_write_b128 %0, %1" ::"v"(xb_lds + (unsigned)(((u & 1) * NW + wave) * 1024)), "v"(theirs) : "memory");
+		}
+		// the partner's half is there; block u + 1 has landed; this stage is free again.  NST = 3: the newest block (the last
+		// DMA_PER_WAVE (+ 1: beta) loads of this wave, nothing else is in flight: loads return in order) stays in flight
+		if (NST == 3) {
+			if (wave == 0)
+				asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 1) : "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
+		} else {
+			__syncthreads();
+		}
+		stg = stg + 1 == NST ? 0 : stg + 1;
 		const f32x4w mine = kh ? acc[1] : acc[0];
-		const f32x4w other = xbuf[((u & 1) * 4 + (wave ^ 1)) * 64 + lane];
+		f32x4w other;
+		asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(other) : "v"(xb_lds + (unsigned)(((u & 1) * NW + (wave ^ 1)) * 1024)) : "memory");
 		const f32x4w sv = mine + other;
 		const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
 		const bool any_t = mx >= cq; // NaN on either side: false
@@ -495,7 +516,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_ksplit_kernel(const CollectA
 					}
 				}
 			}
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			if (NST == 3) // (the slot and stream updates are done before the next LDS-DMA is issued: the barrier counts loads only)
+				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+			else
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		}
 		if (COLLECT && ((u % FLUSH_EVERY) == FLUSH_EVERY - 1 || u == nblocks - 1)) {
 			__syncthreads(); // every wave's appends of this block are in
@@ -509,13 +533,14 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_ksplit_kernel(const CollectA
 				}
 				__syncthreads();
 				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
-				for (unsigned i = tid; i < n; i += 256)
+				for (unsigned i = tid; i < n; i += 64 * NW)
 					if ((long long)(base + i) < a.stream_cap)
 						a.stream[base + i] = qbuf[i];
 				__syncthreads();
 			}
 		}
 	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the blocks fetched past the split's end)
 }
 
 // ---- storage: one wave per row (plain f32 rows of pitch sdp, d logical dims) -> centred bf16 [dp1] + beta ------------------------
@@ -680,11 +705,12 @@ void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_
 int collect_store_dims(int d) {
 	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : 0)))));
 }
+int g_ksplit_waves = 8; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
 static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }
 int collect_wide_qblock(int dp1) {
-	return dp1 == 768 ? 64 : 128 * wide_qt(dp1);
+	return dp1 == 768 ? 16 * g_ksplit_waves : 128 * wide_qt(dp1);
 }
 static int wide_wsub(int dp1) {
 	const int KB = dp1 / 32;
@@ -692,7 +718,8 @@ static int wide_wsub(int dp1) {
 }
 size_t collect_wide_lds_bytes(int dp1) {
 	if (dp1 == 768) // flat_bf16_ksplit_kernel: two 24 KB stages, beta, queue, hand-over buffers, bounds, control
-		return (size_t)2 * 16 * 768 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + 2 * 4 * 64 * 16 + 64 * 4 + 64;
+		return (size_t)(g_ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + (size_t)2 * g_ksplit_waves * 64 * 16 +
+		       g_ksplit_waves * 16 * 4 + 64;
 	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)collect_wide_qblock(dp1) * 4 + 64;
 }
 int collect_wide_block_rows(int dp1) {
@@ -746,9 +773,15 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	} else if (dp1 == 768) {
 #define MVS_KSP(L2, CO)                                                                                         \
 	{                                                                                                           \
-		auto kern = flat_bf16_ksplit_kernel<L2, CO>;                                                            \
-		ensure_dynamic_lds((const void *)kern, lds);                                                            \
-		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                                  \
+		if (g_ksplit_waves == 8) {                                                                              \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3>;                                                     \
+			ensure_dynamic_lds((const void *)kern, lds);                                                        \
+			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                              \
+		} else {                                                                                                \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2>;                                                     \
+			ensure_dynamic_lds((const void *)kern, lds);                                                        \
+			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                              \
+		}                                                                                                       \
 	}
 		if (metric == METRIC_L2 && collect)
 			MVS_KSP(true, true)

@@ -14,6 +14,6 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"][:60]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in agg.items():
-    if "mfma" in k or "direct" in k or "ivf" in k or "hnsw" in k:
+    if "mfma" in k or "direct" in k or "ivf" in k or "hnsw" in k or "bf16" in k:
         print(k, {c: f"{v:.4g}" for c, v in d.items()})
 PY
