@@ -34,7 +34,7 @@ struct CollectArgs {
 // csrc/flat_collect_wide.hip
 int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512; 0 = the coarse filter does not serve d
 int collect_wide_qblock(int dp1);
-extern int g_ksplit_waves; // 8: the k-split kernel runs one 512-thread workgroup per CU
+extern int g_ksplit_waves, g_ksplit_ncb; // 8: the k-split kernel runs one 512-thread workgroup per CU
 size_t collect_wide_lds_bytes(int dp1);
 int collect_wide_block_rows(int dp1);
 void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,

@@ -285,22 +285,25 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 // sums of the OTHER wave's column block over through LDS (1 KB each way) and finish their own 16 queries: s = (beta + half) + half.
 // (One more f32 addition than the single chain; the bound counts d / 16 accumulation steps where d / 32 + 1 happen.)
 // A workgroup serves 64 queries, a staged block is one tile (24 KB), the workgroup barrier of the hand-over is the staging barrier.
-template <bool IS_L2, bool COLLECT, int NW, int NST>
+template <bool IS_L2, bool COLLECT, int NW, int NST, int NCB>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_kernel(const CollectArgs a) {
 	constexpr int KBT = 24, KH = 12;
 	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
 	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB
 	constexpr int DMA_PER_WAVE = STAGE_BYTES / (1024 * NW);
-	constexpr int QB = 16 * NW;
+	constexpr int QP = 16 * NCB;        // queries of a wave pair: NCB column blocks (the third one finished by the two waves in turn)
+	constexpr int QB = (NW / 2) * QP;
 	constexpr int FLUSH_EVERY = NST == 3 ? 16 : 8;
+	constexpr int QCAP = (NW == 4 && NCB == 3) ? CL_QCAP / 2 : CL_QCAP; // (two workgroups per CU must fit 160 KB)
+	static_assert(NCB == 2 || NCB == 3, "column blocks per wave pair");
 	static_assert(NST == 2 || NST == 3, "two stages (one tile ahead, __syncthreads) or a ring of three (two tiles ahead)");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	char *tbuf = (char *)smem;                                        // [NST][STAGE_BYTES]
 	float *nbuf = (float *)(tbuf + NST * STAGE_BYTES);                // [NST][64] beta of the staged rows (16 used)
-	unsigned long long *qbuf = (unsigned long long *)(nbuf + NST * 64); // [CL_QCAP] candidate queue
-	f32x4w *xbuf = (f32x4w *)(qbuf + CL_QCAP);                        // [2][NW waves][64 lanes] partial sums for the partner wave
-	float *cqtab = (float *)(xbuf + 2 * NW * 64);                     // [NW waves][16 c]: pass bound of every query
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + NST * 64); // [QCAP] candidate queue
+	f32x4w *xbuf = (f32x4w *)(qbuf + QCAP);                        // [2][NW waves][NCB - 1][64 lanes] partial sums for the partner wave
+	float *cqtab = (float *)(xbuf + 2 * NW * (NCB - 1) * 64);         // [NW / 2 pairs][QP]: pass bound of every query
 	unsigned *qctl = (unsigned *)(cqtab + QB);                        // [0] queue fill, [2..3] flush base
 
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -323,14 +326,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 	const int nblocks = r_end > r_begin ? (int)((r_end - r_begin + RT - 1) / RT) : 0;
 	if (tid == 0)
 		qctl[0] = 0u;
-	const int qown = qb * QB + wave * 16; // the 16 queries this wave finishes: column block kh of group qg
+	const int qpair = qb * QB + qg * QP; // the pair's queries; this wave finishes column block kh (and block 2 on tiles u & 1 == kh)
 
-	bf16x8 bq[2][KH]; // [column block of the group][k-block of this wave's half]
+	bf16x8 bq[NCB][KH]; // [column block of the group][k-block of this wave's half]
 	{
 		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
 #pragma unroll
-		for (int cb = 0; cb < 2; ++cb) {
-			const size_t qblk16 = (size_t)qb * (QB / 16) + qg * 2 + cb;
+		for (int cb = 0; cb < NCB; ++cb) {
+			const size_t qblk16 = (size_t)qb * (QB / 16) + qg * NCB + cb;
 #pragma unroll
 			for (int kb = 0; kb < KH; ++kb)
 				bq[cb][kb] = qsrc[(qblk16 * KBT + kh * KH + kb) * 64 + lane];
@@ -362,17 +365,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 	const unsigned rbase = (unsigned)(c * PITCH) + (unsigned)(((hq ^ c) & 15) * 16) + (unsigned)(kh * (KH / 4) * 256);
 	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
-	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 16 + c) * 4);
+	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((qg * QP + kh * 16 + c) * 4);
+	const unsigned cq2_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((qg * QP + 32 + c) * 4);
 	const unsigned xb_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) f32x4w *)xbuf) + (unsigned)(lane * 16);
 	int stg = 0; // stage of block u
 
 	for (int u = 0; u < nblocks; ++u) {
 		const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
-		if ((u % period) == 0 && hq == 0) {
-			// B = the kk-th best of the 16 class bests of the lane's own query (bitonic network in registers)
-			int qo = qown;
+		if ((u % period) == 0 && hq < NCB - 1) {
+			// B = the kk-th best of the 16 class bests of the lane's query (bitonic network in registers): lanes hq = 0 own the wave's
+			// column block, lanes hq = 1 the pair's third one (both waves write it: either value is a valid bound)
+			const int qoff = hq == 0 ? kh * 16 : 32;
+			int qo = qpair;
 			MVS_OPAQUE_VGPR(qo);
-			const int q = qo + c;
+			const int q = qo + qoff + c;
 			const int qc = q < a.nq ? q : 0;
 			unsigned long long w[8];
 			const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 				kth = (a.nclass - 1 == j) ? key[j] : kth;
 			const unsigned neutral = skey(-FLT_MAX);
 			const float B = skey2f(kth < neutral ? kth : neutral);
-			cqtab[wave * 16 + c] = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u);
+			cqtab[qg * QP + qoff + c] = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u);
 		}
 		// NST = 3: block u + 2 goes to the stage block u - 1 left at the last barrier; NST = 2: block u + 1
 		dma_block(u + NST - 1, stg == 0 ? NST - 1 : stg - 1);
@@ -418,34 +424,38 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + stg * 64 + 4 * hq));
 		const long long row0 = r_begin + (long long)u * RT;
 		const int nvalid = (int)((r_end - row0) < RT ? (r_end - row0) : RT);
+		const bool mine2 = NCB == 3 && (u & 1) == kh; // this wave finishes the third column block of this tile
 		f32x4n Y;
-		float cq;
+		float cq, cq2 = 0.f;
 		asm volatile("ds_read_b128 %0, %1" : "=v"(Y) : "v"(nb_lds) : "memory");
 		asm volatile("ds_read_b32 %0, %1" : "=v"(cq) : "v"(cq_lds) : "memory");
+		if (NCB == 3)
+			asm volatile("ds_read_b32 %0, %1" : "=v"(cq2) : "v"(cq2_lds) : "memory");
 		bf16x8 A[4];
 		asm volatile("ds_read_b128 %0, %1" : "=v"(A[0]) : "v"(tb) : "memory");
 		asm volatile("ds_read_b128 %0, %1" : "=v"(A[1]) : "v"(tb ^ 64u) : "memory");
-		f32x4w acc[2];
+		f32x4w acc[NCB];
 #pragma unroll
 		for (int g = 0; g < KH / 2; ++g) {
 			if (g + 1 < KH / 2) {
 				const int k2 = 2 * g + 2, k3 = 2 * g + 3;
 				asm volatile("ds_read_b128 %0, %1" : "=v"(A[k2 & 3]) : "v"((tb ^ (unsigned)((k2 & 3) * 64)) + (unsigned)((k2 >> 2) * 256)) : "memory");
 				asm volatile("ds_read_b128 %0, %1" : "=v"(A[k3 & 3]) : "v"((tb ^ (unsigned)((k3 & 3) * 64)) + (unsigned)((k3 >> 2) * 256)) : "memory");
-				asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cq));
+				asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cq), "+v"(cq2));
 			} else {
-				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cq));
+				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[(2 * g) & 3]), "+v"(A[(2 * g + 1) & 3]), "+v"(Y), "+v"(cq), "+v"(cq2));
 			}
 #pragma unroll
 			for (int kk2 = 0; kk2 < 2; ++kk2) {
 				const int kb = 2 * g + kk2;
 #pragma unroll
-				for (int i = 0; i < 2; ++i) {
-					if (kb == 0) { // beta(row) enters the chain of the column block this wave finishes, once
+				for (int i = 0; i < NCB; ++i) {
+					if (kb == 0) { // beta(row) enters the chain of the column block(s) this wave finishes, once
+						const bool fin = i == 2 ? mine2 : i == kh;
 						f32x4w y0;
 #pragma unroll
 						for (int r = 0; r < 4; ++r)
-							y0[r] = (i == kh) ? Y[r] : 0.f;
+							y0[r] = fin ? Y[r] : 0.f;
 						acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[i][kb], y0, 0, 0, 0);
 					} else {
 						acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[i][kb], acc[i], 0, 0, 0);
@@ -456,7 +466,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 		}
 		{
 			const f32x4w theirs = kh ? acc[0] : acc[1];
-			asm volatile("ds_write_b128 %0, %1" ::"v"(xb_lds + (unsigned)(((u & 1) * NW + wave) * 1024)), "v"(theirs) : "memory");
+			asm volatile("ds_write_b128 %0, %1" ::"v"(xb_lds + (unsigned)((((u & 1) * NW + wave) * (NCB - 1)) * 1024)), "v"(theirs) : "memory");
+			if (NCB == 3 && !mine2)
+				asm volatile("ds_write_b128 %0, %1" ::"v"(xb_lds + (unsigned)((((u & 1) * NW + wave) * (NCB - 1) + 1) * 1024)), "v"(acc[NCB - 1]) : "memory");
 		}
 		// the partner's half is there; block u + 1 has landed; this stage is free again.  NST = 3: the newest block (the last
 		// DMA_PER_WAVE (+ 1: beta) loads of this wave, nothing else is in flight: loads return in order) stays in flight
@@ -469,21 +481,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 			__syncthreads();
 		}
 		stg = stg + 1 == NST ? 0 : stg + 1;
-		const f32x4w mine = kh ? acc[1] : acc[0];
-		f32x4w other;
-		asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(other) : "v"(xb_lds + (unsigned)(((u & 1) * NW + (wave ^ 1)) * 1024)) : "memory");
-		const f32x4w sv = mine + other;
-		const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
-		const bool any_t = mx >= cq; // NaN on either side: false
-		if (__builtin_amdgcn_ballot_w64(any_t) != 0ull) {
-			int qo = qown;
+		auto finish = [&](const f32x4w sv, const float cqv, const int qoff) {
+			const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
+			const bool any_t = mx >= cqv; // NaN on either side: false
+			if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+				return;
+			int qo = qpair;
 			MVS_OPAQUE_VGPR(qo);
-			const int q = qo + c;
+			const int q = qo + qoff + c;
 			unsigned m = 0u;
 			if (any_t) {
 #pragma unroll
 				for (int r = 0; r < 4; ++r)
-					if (4 * hq + r < nvalid && sv[r] >= cq)
+					if (4 * hq + r < nvalid && sv[r] >= cqv)
 						m |= 1u << r;
 			}
 			while (m != 0u) {
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 					const unsigned one = 1u;
 					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
 					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-					if (pos < (unsigned)CL_QCAP) {
+					if (pos < (unsigned)QCAP) {
 						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
 					} else {
 						unsigned long long gp;
@@ -520,13 +530,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 			else
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		};
+		{
+			const f32x4w mine = kh ? acc[1] : acc[0];
+			f32x4w other, other2;
+			asm volatile("ds_read_b128 %0, %1" : "=v"(other) : "v"(xb_lds + (unsigned)((((u & 1) * NW + (wave ^ 1)) * (NCB - 1)) * 1024)) : "memory");
+			if (NCB == 3 && mine2)
+				asm volatile("ds_read_b128 %0, %1" : "=v"(other2) : "v"(xb_lds + (unsigned)((((u & 1) * NW + (wave ^ 1)) * (NCB - 1) + 1) * 1024)) : "memory");
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(other), "+v"(other2));
+			finish(mine + other, cq, kh * 16);
+			if (NCB == 3 && mine2)
+				finish(acc[NCB - 1] + other2, cq2, 32);
 		}
 		if (COLLECT && ((u % FLUSH_EVERY) == FLUSH_EVERY - 1 || u == nblocks - 1)) {
 			__syncthreads(); // every wave's appends of this block are in
 			const unsigned fill = qctl[0];
 			__syncthreads();
-			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
-			if (n >= (unsigned)CL_QCAP / 2 || (u == nblocks - 1 && n > 0)) {
+			const unsigned n = fill < (unsigned)QCAP ? fill : (unsigned)QCAP;
+			if (n >= (unsigned)QCAP / 2 || (u == nblocks - 1 && n > 0)) {
 				if (tid == 0) {
 					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
 					qctl[0] = 0u;
@@ -706,11 +727,15 @@ int collect_store_dims(int d) {
 	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : 0)))));
 }
 int g_ksplit_waves = 8; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
+int g_ksplit_ncb = 3;   // column blocks per wave pair (option cl_ksplit_ncb: 2, or 3 with 8 waves)
+static int ksplit_ncb() {
+	return g_ksplit_ncb == 3 ? 3 : 2;
+}
 static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }
 int collect_wide_qblock(int dp1) {
-	return dp1 == 768 ? 16 * g_ksplit_waves : 128 * wide_qt(dp1);
+	return dp1 == 768 ? (g_ksplit_waves / 2) * 16 * ksplit_ncb() : 128 * wide_qt(dp1);
 }
 static int wide_wsub(int dp1) {
 	const int KB = dp1 / 32;
@@ -718,8 +743,9 @@ static int wide_wsub(int dp1) {
 }
 size_t collect_wide_lds_bytes(int dp1) {
 	if (dp1 == 768) // flat_bf16_ksplit_kernel: two 24 KB stages, beta, queue, hand-over buffers, bounds, control
-		return (size_t)(g_ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + (size_t)2 * g_ksplit_waves * 64 * 16 +
-		       g_ksplit_waves * 16 * 4 + 64;
+		return (size_t)(g_ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) +
+		       (size_t)(g_ksplit_waves == 4 && ksplit_ncb() == 3 ? CL_QCAP / 2 : CL_QCAP) * 8 +
+		       (size_t)2 * g_ksplit_waves * (ksplit_ncb() - 1) * 64 * 16 + (size_t)collect_wide_qblock(768) * 4 + 64;
 	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)collect_wide_qblock(dp1) * 4 + 64;
 }
 int collect_wide_block_rows(int dp1) {
@@ -773,12 +799,20 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	} else if (dp1 == 768) {
 #define MVS_KSP(L2, CO)                                                                                         \
 	{                                                                                                           \
-		if (g_ksplit_waves == 8) {                                                                              \
-			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3>;                                                     \
+		if (g_ksplit_waves == 8 && ksplit_ncb() == 3) {                                                         \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 3>;                                               \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                              \
+		} else if (g_ksplit_waves == 8) {                                                                       \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 2>;                                                     \
+			ensure_dynamic_lds((const void *)kern, lds);                                                        \
+			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                              \
+		} else if (ksplit_ncb() == 3) {                                                                         \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 3>;                                               \
+			ensure_dynamic_lds((const void *)kern, lds);                                                        \
+			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                              \
 		} else {                                                                                                \
-			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2>;                                                     \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 2>;                                                     \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                              \
 		}                                                                                                       \

@@ -1741,6 +1741,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		prefilter_mode = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "cl_ksplit_ncb")) { // column blocks per wave pair of the k-split coarse filter (2 | 3)
+		g_ksplit_ncb = v == 2 ? 2 : 3;
+		return true;
+	}
 	if (!strcmp(key, "cl_ksplit_waves")) { // 512 < d <= 768: waves per workgroup of the k-split coarse filter (4 or 8)
 		g_ksplit_waves = v == 4 ? 4 : 8;
 		return true;
