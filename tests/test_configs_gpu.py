@@ -244,8 +244,17 @@ def test_c4_flat_ip_768_one_gpu_shard_of_100m(mf, torch):
     assert ix.ntotal == n
     D, I = ix.search_torch(xq, k)
     torch.cuda.synchronize()
+    # the bf16 coarse filter with the k dimension split over wave pairs (csrc/flat_collect_wide.hip) serves this shape ...
+    assert ix.last_kernel_info()["name"] == "flat_bf16_wide_kernel", ix.last_kernel_info()
     D, I = D.cpu().numpy(), I.cpu().numpy()
     _check_order_and_range(D, I, r0, r1, False)
+    # ... with the answers of the exact f32 kernel on all 10k queries, bit for bit
+    ix.set_option("prefilter", 0)
+    D0, I0 = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+    assert np.array_equal(I0.cpu().numpy(), I) and np.array_equal(D0.cpu().numpy().view(np.uint32), D.view(np.uint32))
+    ix.set_option("prefilter", -1)
     Dor, Ior = orc.merge_shards(IP, np.stack(Dblk), np.stack(Iblk))
     assert np.array_equal(I[:ns], Ior), "labels differ from the oracle"
     assert np.array_equal(D[:ns].view(np.uint32), Dor.view(np.uint32))
