@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 					if (4 * hq + r < nvalid && sv[i][r] >= c0)
 						m |= 1u << r;
 			}
+			if (a.rowmask && m != 0u) { // IDSelector: rejected rows are neither candidates nor evidence for the bound
+				const unsigned long long rr = (unsigned long long)(row0 + 4 * hq);
+				m &= (unsigned)(((const unsigned *)a.rowmask)[rr >> 5] >> (rr & 31u));
+			}
 			while (m != 0u) {
 				const int j = __builtin_ctz(m);
 				m &= m - 1u;
@@ -495,6 +499,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 				for (int r = 0; r < 4; ++r)
 					if (4 * hq + r < nvalid && sv[r] >= cqv)
 						m |= 1u << r;
+			}
+			if (a.rowmask && m != 0u) { // IDSelector: rejected rows are neither candidates nor evidence for the bound
+				const unsigned long long rr = (unsigned long long)(row0 + 4 * hq);
+				m &= (unsigned)(((const unsigned *)a.rowmask)[rr >> 5] >> (rr & 31u));
 			}
 			while (m != 0u) {
 				const int j = __builtin_ctz(m);

@@ -382,9 +382,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		rowmask = (const unsigned long long *)ws_rowmask.p;
 	}
 	const int dp1 = collect_store_dims(d);
-	const bool wide = dp1 > 128; // csrc/flat_collect_wide.hip: no selector instance, no one-wavefront-per-segment path
-	if (wide && has_sel)
-		throw_faiss("mvs::FlatIndex::collect_candidates", __FILE__, "the wide coarse filter has no selector instance (d = %d)", d);
+	const bool wide = dp1 > 128; // csrc/flat_collect_wide.hip: no one-wavefront-per-segment path
 	ws_qn.reserve((size_t)nq * sizeof(float));
 	if (wide) {
 		ws_pfq.reserve(collect_qfrag_bytes_ex(dp1, collect_wide_qblock(dp1), nq));
@@ -790,13 +788,13 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
                                  const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map,
                                  int64_t out_off, const TieFlags *flp, hipStream_t st) {
-	// 128 < d <= 512: only the coarse filter exists (csrc/flat_collect_wide.hip; no selector instance, no bf16x3 behind it)
+	// 128 < d <= 768: only the coarse filter exists (csrc/flat_collect_wide.hip; no bf16x3 behind it)
 	const bool wide = collect_store_dims(d) > 128;
 	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !wide) || kk > 40)
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
-	if (wide && (has_sel || kk > 16 || prefilter_mode == 1))
+	if (wide && (kk > 16 || prefilter_mode == 1))
 		return false;
 	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16))
 		return false;

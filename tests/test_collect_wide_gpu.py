@@ -127,7 +127,7 @@ def test_wide_small_batch_uses_the_per_pair_arithmetic(mf, metric, d):
 
 
 def test_wide_is_not_used_where_it_has_no_instance(mf):
-    """d > 768 and selectors stay on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
+    """d > 768 stays on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
     rs = np.random.RandomState(2)
     xb = rs.rand(20_000, 1024).astype(np.float32)
     ix = mf.index_factory(1024, "Flat", L2)
@@ -135,13 +135,40 @@ def test_wide_is_not_used_where_it_has_no_instance(mf):
     ix.add(xb)
     D, I = ix.search(xb[:40], 3)
     assert ix.last_kernel_info()["name"] == "flat_mfma_kernel" and np.array_equal(I[:, 0], np.arange(40))
-    xb = rs.rand(30_000, 256).astype(np.float32)
-    cl, ex = _pair(mf, 256, L2, xb)
-    sel = ("batch", np.arange(0, 30_000, 3, dtype=np.int64))
-    D1, I1 = cl.search(xb[:50], 5, sel=sel)
-    assert cl.last_kernel_info()["name"] != KERNEL
-    D0, I0 = ex.search(xb[:50], 5, sel=sel)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,idmap,frac", [(256, False, 0.5), (384, True, 0.05), (768, False, 0.3), (640, True, 0.9), (512, False, 0.01)])
+def test_wide_selector_searches(mf, metric, d, idmap, frac):
+    """IDSelectorBitmap / IDSelectorBatch in front of the wide kernels: one selector bit per row, rejected rows are neither
+    candidates nor evidence for the bound; FAISS's per-pair arithmetic under a selector (tests/test_collect_gpu.py)"""
+    rs = np.random.RandomState(d + int(frac * 100))
+    nb, nq, k = 40_000, 150, 8
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    ids = (rs.permutation(1 << 18)[:nb] + 5).astype(np.int64) if idmap else None
+    universe = ids if idmap else np.arange(nb, dtype=np.int64)
+    keep = np.sort(universe[rs.rand(nb) < frac])
+    if d % 128 == 0:
+        bm = np.zeros((int(universe.max()) + 8) // 8, dtype=np.uint8)
+        np.bitwise_or.at(bm, keep >> 3, (1 << (keep & 7)).astype(np.uint8))
+        sel = ("bitmap", bm)
+    else:
+        sel = ("batch", keep)
+    cl, ex = _pair(mf, d, metric, xb, desc="IDMap,Flat" if idmap else "Flat", ids=ids)
+    D1, I1 = cl.search(xq, k, sel=sel)
+    assert cl.last_kernel_info()["name"] == KERNEL, cl.last_kernel_info()
+    D0, I0 = ex.search(xq, k, sel=sel)
+    assert ex.last_kernel_info()["name"] != KERNEL
     assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
+    o = orc.Index(d, "IDMap,Flat" if idmap else "Flat", metric)
+    if idmap:
+        o.add_with_ids(xb, ids)
+    else:
+        o.add(xb)
+    Do, Io = o.search(xq[:48], k, sel=sel)
+    assert np.array_equal(I1[:48], Io) and np.array_equal(D1[:48].view(np.uint32), Do.view(np.uint32))
+    assert np.isin(I1[I1 >= 0], keep).all()
 
 
 @pytest.mark.parametrize("d", [256, 768])
