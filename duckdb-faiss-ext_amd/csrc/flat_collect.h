@@ -29,12 +29,13 @@ struct CollectArgs {
 	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
 	long long n, row_first, split_rows;
 	int nq, nqb, nsplit, xcd_map;
+	int opt; // bit 0: k-split kernel, 8 waves: s_setprio skew between the two waves of a SIMD (A/B)
 };
 
 // csrc/flat_collect_wide.hip
 int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512; 0 = the coarse filter does not serve d
 int collect_wide_qblock(int dp1);
-extern int g_ksplit_waves, g_ksplit_ncb; // 8: the k-split kernel runs one 512-thread workgroup per CU
+extern int g_ksplit_waves, g_ksplit_ncb, g_ksplit_opt; // 8: the k-split kernel runs one 512-thread workgroup per CU
 size_t collect_wide_lds_bytes(int dp1);
 int collect_wide_block_rows(int dp1);
 void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,

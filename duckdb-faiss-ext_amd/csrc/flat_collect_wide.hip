@@ -373,6 +373,85 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 	const unsigned cq2_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((qg * QP + 32 + c) * 4);
 	const unsigned xb_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) f32x4w *)xbuf) + (unsigned)(lane * 16);
 	int stg = 0; // stage of block u
+	// the bound test of tile u - 1 runs behind the MFMAs of tile u (the partner's sums then are one barrier old): what it needs
+	f32x4w pmine = {0.f, 0.f, 0.f, 0.f}, pmine2 = {0.f, 0.f, 0.f, 0.f};
+	float pcq = 0.f, pcq2 = 0.f;
+	if (NW == 8 && (a.opt & 1)) // the two waves of a SIMD take the matrix pipe one after the other (measured: 30.4 vs 29.x ms without)
+	{
+		if (wave < 4)
+			__builtin_amdgcn_s_setprio(1);
+		else
+			__builtin_amdgcn_s_setprio(0);
+	}
+
+	auto finish = [&](const f32x4w sv, const float cqv, const int qoff, const long long row0, const int nvalid) {
+		const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
+		const bool any_t = mx >= cqv; // NaN on either side: false
+		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+			return;
+		int qo = qpair;
+		MVS_OPAQUE_VGPR(qo);
+		const int q = qo + qoff + c;
+		unsigned m = 0u;
+		if (any_t) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				if (4 * hq + r < nvalid && sv[r] >= cqv)
+					m |= 1u << r;
+		}
+		if (a.rowmask && m != 0u) { // IDSelector: rejected rows are neither candidates nor evidence for the bound
+			const unsigned long long rr = (unsigned long long)(row0 + 4 * hq);
+			m &= (unsigned)(((const unsigned *)a.rowmask)[rr >> 5] >> (rr & 31u));
+		}
+		while (m != 0u) {
+			const int j = __builtin_ctz(m);
+			m &= m - 1u;
+			const float lo = (j & 1) ? sv[1] : sv[0];
+			const float hi = (j & 1) ? sv[3] : sv[2];
+			const float v = (j & 2) ? hi : lo;
+			const unsigned row = (unsigned)(row0 + 4 * hq + j);
+			typedef __attribute__((address_space(1))) unsigned *GU;
+			__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
+			                       __HIP_MEMORY_SCOPE_AGENT);
+			if (COLLECT) {
+				unsigned pos;
+				const unsigned one = 1u;
+				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+				const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+				if (pos < (unsigned)QCAP) {
+					asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+				} else {
+					unsigned long long gp;
+					const unsigned long long one64 = 1ull;
+					typedef __attribute__((address_space(1))) unsigned long long *GUL;
+					asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+					             : "=&v"(gp)
+					             : "v"((GUL)a.stream_cnt), "v"(one64)
+					             : "memory");
+					if ((long long)gp < a.stream_cap)
+						*((GUL)a.stream + gp) = ent;
+				}
+			}
+		}
+		if (NST == 3) // (the slot and stream updates are done before the next LDS-DMA is issued: the barrier counts loads only)
+			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		else
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	};
+	// tile t (t = u - 1 inside the loop): the partner's sums from xbuf[t & 1] + this wave's, then the bound test
+	auto epilogue = [&](int t) {
+		const bool m2 = NCB == 3 && (t & 1) == kh;
+		f32x4w other, other2;
+		asm volatile("ds_read_b128 %0, %1" : "=v"(other) : "v"(xb_lds + (unsigned)((((t & 1) * NW + (wave ^ 1)) * (NCB - 1)) * 1024)) : "memory");
+		if (NCB == 3 && m2)
+			asm volatile("ds_read_b128 %0, %1" : "=v"(other2) : "v"(xb_lds + (unsigned)((((t & 1) * NW + (wave ^ 1)) * (NCB - 1) + 1) * 1024)) : "memory");
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(other), "+v"(other2));
+		const long long row0 = r_begin + (long long)t * RT;
+		const int nvalid = (int)((r_end - row0) < RT ? (r_end - row0) : RT);
+		finish(pmine + other, pcq, kh * 16, row0, nvalid);
+		if (NCB == 3 && m2)
+			finish(pmine2 + other2, pcq2, 32, row0, nvalid);
+	};
 
 	for (int u = 0; u < nblocks; ++u) {
 		const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
@@ -474,6 +553,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 			if (NCB == 3 && !mine2)
 				asm volatile("ds_write_b128 %0, %1" ::"v"(xb_lds + (unsigned)((((u & 1) * NW + wave) * (NCB - 1) + 1) * 1024)), "v"(acc[NCB - 1]) : "memory");
 		}
+		if (u > 0)
+			epilogue(u - 1);
+		pmine = kh ? acc[1] : acc[0];
+		if (NCB == 3)
+			pmine2 = acc[NCB - 1];
+		pcq = cq;
+		pcq2 = cq2;
 		// the partner's half is there; block u + 1 has landed; this stage is free again.  NST = 3: the newest block (the last
 		// DMA_PER_WAVE (+ 1: beta) loads of this wave, nothing else is in flight: loads return in order) stays in flight
 		if (NST == 3) {
@@ -485,77 +571,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 			__syncthreads();
 		}
 		stg = stg + 1 == NST ? 0 : stg + 1;
-		auto finish = [&](const f32x4w sv, const float cqv, const int qoff) {
-			const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
-			const bool any_t = mx >= cqv; // NaN on either side: false
-			if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
-				return;
-			int qo = qpair;
-			MVS_OPAQUE_VGPR(qo);
-			const int q = qo + qoff + c;
-			unsigned m = 0u;
-			if (any_t) {
-#pragma unroll
-				for (int r = 0; r < 4; ++r)
-					if (4 * hq + r < nvalid && sv[r] >= cqv)
-						m |= 1u << r;
-			}
-			if (a.rowmask && m != 0u) { // IDSelector: rejected rows are neither candidates nor evidence for the bound
-				const unsigned long long rr = (unsigned long long)(row0 + 4 * hq);
-				m &= (unsigned)(((const unsigned *)a.rowmask)[rr >> 5] >> (rr & 31u));
-			}
-			while (m != 0u) {
-				const int j = __builtin_ctz(m);
-				m &= m - 1u;
-				const float lo = (j & 1) ? sv[1] : sv[0];
-				const float hi = (j & 1) ? sv[3] : sv[2];
-				const float v = (j & 2) ? hi : lo;
-				const unsigned row = (unsigned)(row0 + 4 * hq + j);
-				typedef __attribute__((address_space(1))) unsigned *GU;
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
-				                       __HIP_MEMORY_SCOPE_AGENT);
-				if (COLLECT) {
-					unsigned pos;
-					const unsigned one = 1u;
-					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
-					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-					if (pos < (unsigned)QCAP) {
-						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
-					} else {
-						unsigned long long gp;
-						const unsigned long long one64 = 1ull;
-						typedef __attribute__((address_space(1))) unsigned long long *GUL;
-						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-						             : "=&v"(gp)
-						             : "v"((GUL)a.stream_cnt), "v"(one64)
-						             : "memory");
-						if ((long long)gp < a.stream_cap)
-							*((GUL)a.stream + gp) = ent;
-					}
-				}
-			}
-			if (NST == 3) // (the slot and stream updates are done before the next LDS-DMA is issued: the barrier counts loads only)
-				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-			else
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		};
-		{
-			const f32x4w mine = kh ? acc[1] : acc[0];
-			f32x4w other, other2;
-			asm volatile("ds_read_b128 %0, %1" : "=v"(other) : "v"(xb_lds + (unsigned)((((u & 1) * NW + (wave ^ 1)) * (NCB - 1)) * 1024)) : "memory");
-			if (NCB == 3 && mine2)
-				asm volatile("ds_read_b128 %0, %1" : "=v"(other2) : "v"(xb_lds + (unsigned)((((u & 1) * NW + (wave ^ 1)) * (NCB - 1) + 1) * 1024)) : "memory");
-			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(other), "+v"(other2));
-			finish(mine + other, cq, kh * 16);
-			if (NCB == 3 && mine2)
-				finish(acc[NCB - 1] + other2, cq2, 32);
-		}
-		if (COLLECT && ((u % FLUSH_EVERY) == FLUSH_EVERY - 1 || u == nblocks - 1)) {
-			__syncthreads(); // every wave's appends of this block are in
+		if (COLLECT && (u % FLUSH_EVERY) == FLUSH_EVERY - 1 && u != nblocks - 1) {
+			__syncthreads();
 			const unsigned fill = qctl[0];
 			__syncthreads();
 			const unsigned n = fill < (unsigned)QCAP ? fill : (unsigned)QCAP;
-			if (n >= (unsigned)QCAP / 2 || (u == nblocks - 1 && n > 0)) {
+			if (n >= (unsigned)QCAP / 2) {
 				if (tid == 0) {
 					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
 					qctl[0] = 0u;
@@ -570,6 +591,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the blocks fetched past the split's end)
+	if (nblocks > 0)
+		epilogue(nblocks - 1);
+	if (COLLECT) {
+		__syncthreads(); // every wave's appends are in
+		const unsigned fill = qctl[0];
+		const unsigned n = fill < (unsigned)QCAP ? fill : (unsigned)QCAP;
+		if (n > 0) {
+			if (tid == 0)
+				*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+			__syncthreads();
+			const unsigned long long base = *(const unsigned long long *)(qctl + 2);
+			for (unsigned i = tid; i < n; i += 64 * NW)
+				if ((long long)(base + i) < a.stream_cap)
+					a.stream[base + i] = qbuf[i];
+		}
+	}
 }
 
 // ---- storage: one wave per row (plain f32 rows of pitch sdp, d logical dims) -> centred bf16 [dp1] + beta ------------------------
@@ -734,7 +771,8 @@ void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_
 int collect_store_dims(int d) {
 	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : 0)))));
 }
-int g_ksplit_waves = 8; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
+int g_ksplit_waves = 4; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
+int g_ksplit_opt = 0;   // option cl_ksplit_opt: bit 0 = s_setprio skew
 int g_ksplit_ncb = 3;   // column blocks per wave pair (option cl_ksplit_ncb: 2, or 3 with 8 waves)
 static int ksplit_ncb() {
 	return g_ksplit_ncb == 3 ? 3 : 2;
@@ -787,6 +825,7 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	a.split_rows = (nblocks + nsplit - 1) / nsplit * BR;
 	a.nqb = nqb;
 	a.nsplit = (int)nsplit;
+	a.opt = g_ksplit_opt;
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_wide_lds_bytes(dp1);
 	if (dp1 == 256) {
