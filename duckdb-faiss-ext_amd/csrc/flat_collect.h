@@ -1,4 +1,4 @@
-// csrc/flat_collect.h -- shared by the coarse-filter scan kernels (flat_collect.hip: d <= 128; flat_collect_wide.hip: 128 < d <= 512)
+// csrc/flat_collect.h -- shared by the coarse-filter scan kernels (flat_collect.hip: d <= 128; flat_collect_wide.hip: 128 < d <= 1024)
 #pragma once
 #include "flat_fused.h"
 
@@ -33,8 +33,9 @@ struct CollectArgs {
 };
 
 // csrc/flat_collect_wide.hip
-int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512; 0 = the coarse filter does not serve d
+int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512, 768, 1024; 0 = the coarse filter does not serve d
 int collect_wide_qblock(int dp1);
+int collect_wide_slots(int dp1);
 extern int g_ksplit_waves, g_ksplit_ncb, g_ksplit_opt; // 8: the k-split kernel runs one 512-thread workgroup per CU
 size_t collect_wide_lds_bytes(int dp1);
 int collect_wide_block_rows(int dp1);

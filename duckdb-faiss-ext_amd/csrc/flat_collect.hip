@@ -77,7 +77,7 @@ __global__ void collect_mean_kernel(float *sum, int dp, int d, float inv_n) {
 }
 // mu[dp] <- column means of the first `nrows` rows (padded dimensions: 0)
 void launch_collect_mean(const FlatGeom &g, const float *d_vecs, int64_t nrows, float *d_mu, hipStream_t st) {
-	MVS_HIP(hipMemsetAsync(d_mu, 0, (size_t)std::max(g.dp, 768) * sizeof(float), st)); // (sized for the widest bf16 store)
+	MVS_HIP(hipMemsetAsync(d_mu, 0, (size_t)std::max(g.dp, 1024) * sizeof(float), st)); // (sized for the widest bf16 store)
 	if (nrows <= 0)
 		return;
 	hipLaunchKernelGGL(collect_colsum_kernel, dim3((unsigned)((nrows + 1023) / 1024)), dim3(256), 0, st, d_vecs,
@@ -799,7 +799,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	const int qblock = dp1 > 128 ? collect_wide_qblock(dp1) : CL_QBLOCK;
 	const int nqb = (int)((nq + qblock - 1) / qblock);
 	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 8192 rows per split
-	const int64_t slots = (dp1 == 768 && g_ksplit_waves == 8) ? 256 : 512; // resident workgroups
+	const int64_t slots = dp1 > 128 ? collect_wide_slots(dp1) : 512; // resident workgroups
 	int64_t nsplit = g_cl_nsplit;
 	if (nsplit <= 0) {
 		const int64_t max_split = std::max<int64_t>(1, n / 8192);

@@ -1,4 +1,4 @@
-// csrc/flat_collect_wide.hip -- the bf16 coarse filter of flat_collect.hip for 128 < d <= 768.
+// csrc/flat_collect_wide.hip -- the bf16 coarse filter of flat_collect.hip for 128 < d <= 1024.
 //
 // Same argument, same bound, same candidate stream and re-scoring (see flat_collect.hip); what changes is the geometry.  The
 // query fragments of a wave must stay in registers for the whole scan (re-streaming them costs more L2 bandwidth than the
@@ -283,18 +283,20 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 	}
 }
 
-// ---- 512 < d <= 768: the k dimension split over a wave pair ---------------------------------------------------------------------
+// ---- 512 < d <= 1024: the k dimension split over a wave pair ---------------------------------------------------------------------
 // 32 queries x 24 k-blocks are 192 VGPRs of query fragments -- too many for one wave.  Waves 2 g and 2 g + 1 share the 32 queries
 // of group g and hold 12 k-blocks each (96 VGPRs); both run their half of the chain over the same 16-row tile, hand the partial
 // sums of the OTHER wave's column block over through LDS (1 KB each way) and finish their own 16 queries: s = (beta + half) + half.
 // (One more f32 addition than the single chain; the bound counts d / 16 accumulation steps where d / 32 + 1 happen.)
 // A workgroup serves 64 queries, a staged block is one tile (24 KB), the workgroup barrier of the hand-over is the staging barrier.
-template <bool IS_L2, bool COLLECT, int NW, int NST, int NCB>
+template <bool IS_L2, bool COLLECT, int NW, int NST, int NCB, int KBT>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_kernel(const CollectArgs a) {
-	constexpr int KBT = 24, KH = 12;
+	constexpr int KH = KBT / 2; // k-blocks per wave: 12 (store of 768 dims) or 16 (1024)
+	static_assert(KH % 4 == 0 && 8 * NCB * KH <= 576, "k-blocks per wave");
 	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
-	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB
+	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB (32 KB)
 	constexpr int DMA_PER_WAVE = STAGE_BYTES / (1024 * NW);
+	static_assert(STAGE_BYTES % (1024 * NW) == 0, "staging");
 	constexpr int QP = 16 * NCB;        // queries of a wave pair: NCB column blocks (the third one finished by the two waves in turn)
 	constexpr int QB = (NW / 2) * QP;
 	constexpr int FLUSH_EVERY = NST == 3 ? 16 : 8;
@@ -769,7 +771,7 @@ void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // row pitch (dims) of the bf16 store for a logical dimension: 128 (flat_collect.hip), 256, 384, 512 or 768 (k-split); 0 = not served
 int collect_store_dims(int d) {
-	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : 0)))));
+	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : 0))))));
 }
 int g_ksplit_waves = 4; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
 int g_ksplit_opt = 0;   // option cl_ksplit_opt: bit 0 = s_setprio skew
@@ -781,13 +783,21 @@ static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }
 int collect_wide_qblock(int dp1) {
+	if (dp1 == 1024) // 8 waves, two column blocks per pair (2 x 16 k-blocks = 128 VGPRs of fragments)
+		return 128;
 	return dp1 == 768 ? (g_ksplit_waves / 2) * 16 * ksplit_ncb() : 128 * wide_qt(dp1);
 }
 static int wide_wsub(int dp1) {
 	const int KB = dp1 / 32;
 	return KB >= 16 ? 1 : (KB >= 12 ? 2 : 3);
 }
+// resident workgroups of the scan kernel on the device (256 CUs)
+int collect_wide_slots(int dp1) {
+	return (dp1 == 1024 || (dp1 == 768 && g_ksplit_waves == 8)) ? 256 : 512;
+}
 size_t collect_wide_lds_bytes(int dp1) {
+	if (dp1 == 1024) // flat_bf16_ksplit_kernel<8, 2, 2, 32>: two 32 KB stages, beta, queue, hand-over buffers, bounds, control
+		return (size_t)2 * (16 * 1024 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + (size_t)2 * 8 * 64 * 16 + 128 * 4 + 64;
 	if (dp1 == 768) // flat_bf16_ksplit_kernel: two 24 KB stages, beta, queue, hand-over buffers, bounds, control
 		return (size_t)(g_ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) +
 		       (size_t)(g_ksplit_waves == 4 && ksplit_ncb() == 3 ? CL_QCAP / 2 : CL_QCAP) * 8 +
@@ -847,19 +857,19 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 #define MVS_KSP(L2, CO)                                                                                         \
 	{                                                                                                           \
 		if (g_ksplit_waves == 8 && ksplit_ncb() == 3) {                                                         \
-			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 3>;                                               \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 3, 24>;                                               \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                              \
 		} else if (g_ksplit_waves == 8) {                                                                       \
-			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 2>;                                                     \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 2, 24>;                                               \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                              \
 		} else if (ksplit_ncb() == 3) {                                                                         \
-			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 3>;                                               \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 3, 24>;                                               \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                              \
 		} else {                                                                                                \
-			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 2>;                                                     \
+			auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 2, 24>;                                               \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                              \
 		}                                                                                                       \
@@ -873,6 +883,23 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 		else
 			MVS_KSP(false, false)
 #undef MVS_KSP
+		MVS_HIP(hipGetLastError());
+	} else if (dp1 == 1024) {
+#define MVS_KSP1(L2, CO)                                                                                        \
+	{                                                                                                           \
+		auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 2, 2, 32>;                                               \
+		ensure_dynamic_lds((const void *)kern, lds);                                                            \
+		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                                  \
+	}
+		if (metric == METRIC_L2 && collect)
+			MVS_KSP1(true, true)
+		else if (metric == METRIC_L2)
+			MVS_KSP1(true, false)
+		else if (collect)
+			MVS_KSP1(false, true)
+		else
+			MVS_KSP1(false, false)
+#undef MVS_KSP1
 		MVS_HIP(hipGetLastError());
 	} else {
 		throw_faiss("mvs::launch_collect_wide_range", __FILE__, "no instance for a %d-dim store", dp1);

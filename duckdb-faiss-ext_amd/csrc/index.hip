@@ -333,7 +333,7 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 		MVS_HIP(hipMemsetAsync(d_max_norm_bits, 0, 64, st));
 	}
 	if (!mu_h1) { // the centre is fixed at the first build (any vector is valid; rows added later only fit it less well)
-		MVS_HIP(hipMalloc((void **)&mu_h1, (size_t)std::max(geom.dp, 768) * sizeof(float)));
+		MVS_HIP(hipMalloc((void **)&mu_h1, (size_t)std::max(geom.dp, 1024) * sizeof(float)));
 		launch_collect_mean(geom, vecs, std::min<int64_t>(ntotal, (int64_t)1 << 20), mu_h1, st);
 	}
 	if (ntotal > h1_cap || !vecs_h1) {
@@ -788,7 +788,7 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
                                  const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map,
                                  int64_t out_off, const TieFlags *flp, hipStream_t st) {
-	// 128 < d <= 768: only the coarse filter exists (csrc/flat_collect_wide.hip; no bf16x3 behind it)
+	// 128 < d <= 1024: only the coarse filter exists (csrc/flat_collect_wide.hip; no bf16x3 behind it)
 	const bool wide = collect_store_dims(d) > 128;
 	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !wide) || kk > 40)
 		return false;

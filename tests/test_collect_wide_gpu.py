@@ -1,6 +1,6 @@
-"""bf16 coarse filter for 128 < d <= 768 (csrc/flat_collect_wide.hip, option prefilter = 2) behind IndexFlat::search
+"""bf16 coarse filter for 128 < d <= 1024 (csrc/flat_collect_wide.hip, option prefilter = 2) behind IndexFlat::search
 (src/faiss_extension.cpp:631): same contract as tests/test_collect_gpu.py -- labels and distances BIT FOR BIT those of the
-exact f32 kernel and of the oracle's BLAS branch -- at the store widths 256 / 384 / 512 / 768 (the last: k split over a wave pair), with ragged dimensions, both
+exact f32 kernel and of the oracle's BLAS branch -- at the store widths 256 / 384 / 512 / 768 / 1024 (the last two: k split over a wave pair), with ragged dimensions, both
 metrics, through IDMap, with duplicates, offset data, non-finite queries and small (per-pair branch) batches."""
 import numpy as np
 import pytest
@@ -48,12 +48,15 @@ def _check(cl, ex, xq, k, metric, xb=None, oracle_rows=0, path=orc.PATH_BLAS, ke
 @pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("d,nb,nq,k", [(256, 60_000, 600, 10), (192, 40_001, 257, 1), (129, 30_000, 300, 5), (384, 50_000, 333, 10),
                                        (300, 35_000, 130, 15), (512, 40_000, 260, 10), (400, 20_000, 64, 3),
-                                       (768, 40_000, 300, 10), (600, 25_000, 65, 15), (513, 20_000, 200, 1), (700, 30_000, 1000, 4)])
+                                       (768, 40_000, 300, 10), (600, 25_000, 65, 15), (513, 20_000, 200, 1), (700, 30_000, 1000, 4),
+                                       (1024, 30_000, 300, 10), (900, 20_000, 129, 16), (769, 20_000, 40, 2)])
 def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
     rs = np.random.RandomState(d + nb)
     xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
     xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
     cl, ex = _pair(mf, d, metric, xb)
+    if metric == IP and k == 16:
+        k = 15  # (inner product keeps one rank for its tie detection)
     _check(cl, ex, xq, k, metric, xb, oracle_rows=48)
     st = cl.collect_stats()
     assert st["queries"] == nq and st["overflows"] == 0 and st["candidates"] >= nq * k, st
@@ -62,7 +65,7 @@ def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
     assert st["candidates"] < nq * nb * 0.2, st
 
 
-@pytest.mark.parametrize("d", [384, 768])
+@pytest.mark.parametrize("d", [384, 768, 1024])
 @pytest.mark.parametrize("metric", [L2, IP])
 def test_wide_normalised_embeddings_and_added_rows(mf, metric, d):
     """unit vectors (the C4 shape at a width the kernel serves), rows added after the first search (the store grows, the
@@ -127,10 +130,10 @@ def test_wide_small_batch_uses_the_per_pair_arithmetic(mf, metric, d):
 
 
 def test_wide_is_not_used_where_it_has_no_instance(mf):
-    """d > 768 stays on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
+    """d > 1024 stays on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
     rs = np.random.RandomState(2)
-    xb = rs.rand(20_000, 1024).astype(np.float32)
-    ix = mf.index_factory(1024, "Flat", L2)
+    xb = rs.rand(20_000, 1536).astype(np.float32)
+    ix = mf.index_factory(1536, "Flat", L2)
     ix.set_option("prefilter", 2)
     ix.add(xb)
     D, I = ix.search(xb[:40], 3)
@@ -138,7 +141,7 @@ def test_wide_is_not_used_where_it_has_no_instance(mf):
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
-@pytest.mark.parametrize("d,idmap,frac", [(256, False, 0.5), (384, True, 0.05), (768, False, 0.3), (640, True, 0.9), (512, False, 0.01)])
+@pytest.mark.parametrize("d,idmap,frac", [(256, False, 0.5), (384, True, 0.05), (768, False, 0.3), (640, True, 0.9), (512, False, 0.01), (1024, True, 0.2)])
 def test_wide_selector_searches(mf, metric, d, idmap, frac):
     """IDSelectorBitmap / IDSelectorBatch in front of the wide kernels: one selector bit per row, rejected rows are neither
     candidates nor evidence for the bound; FAISS's per-pair arithmetic under a selector (tests/test_collect_gpu.py)"""
@@ -171,7 +174,7 @@ def test_wide_selector_searches(mf, metric, d, idmap, frac):
     assert np.isin(I1[I1 >= 0], keep).all()
 
 
-@pytest.mark.parametrize("d", [256, 768])
+@pytest.mark.parametrize("d", [256, 768, 1000])
 def test_wide_inner_product_boundary_ties(mf, d):
     """integer data: many rows share the k-th score; FAISS's heap outcome from the candidate list (tests/test_collect_gpu.py)"""
     rs = np.random.RandomState(d)
