@@ -21,7 +21,7 @@ namespace mvs {
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
-template <int KB, int QT, bool IS_L2, bool COLLECT>
+template <int KB, int QT, int NCBP, bool IS_L2, bool COLLECT>
 __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArgs a) {
 	constexpr int PITCH = 64 * KB;            // bytes per row
 	constexpr int C = 4 * KB;                 // 16-byte chunks per row (a multiple of 16)
@@ -30,15 +30,16 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 	constexpr int WSUB = KB >= 16 ? 1 : (KB >= 12 ? 2 : 3); // tiles per staged block (16 - 24 KB)
 	constexpr int STAGE_BYTES = WSUB * TILE_BYTES;
 	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096; // 1 KB per wave-instruction, four waves
-	constexpr int QW = 32 * QT, QB = 4 * QW;  // queries per wave / workgroup
+	constexpr int QW = 16 * NCBP * QT, QB = 4 * QW; // queries per wave (QT passes of NCBP column blocks) / workgroup
+	static_assert(NCBP == 2 || NCBP == 3, "column blocks per pass");
 	static_assert(KB % 4 == 0 && STAGE_BYTES % 4096 == 0 && WSUB * RT <= 64, "geometry");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	char *tbuf = (char *)smem;                                        // [2][STAGE_BYTES]
 	float *nbuf = (float *)(tbuf + 2 * STAGE_BYTES);                  // [2][64] beta of the staged rows
 	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
-	float *cqtab = (float *)(qbuf + CL_QCAP);                         // [4 waves][QT][16 c][2]: pass bound of every query
-	unsigned *qctl = (unsigned *)(cqtab + QB);                        // [0] queue fill, [2..3] flush base
+	float *cqtab = (float *)(qbuf + CL_QCAP);                         // [4 waves][QT][16 c][4]: pass bound of every query (NCBP used)
+	unsigned *qctl = (unsigned *)(cqtab + 4 * QT * 16 * 4);                        // [0] queue fill, [2..3] flush base
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,12 +63,12 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 	const int qw = qb * QB + wave * QW;
 
 	// B fragments, resident: [column block][k-block]
-	bf16x8 bq[2 * QT][KB];
+	bf16x8 bq[NCBP * QT][KB];
 	{
 		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
 #pragma unroll
-		for (int cb = 0; cb < 2 * QT; ++cb) {
-			const size_t qblk16 = (size_t)qb * (QB / 16) + wave * (2 * QT) + cb;
+		for (int cb = 0; cb < NCBP * QT; ++cb) {
+			const size_t qblk16 = (size_t)qb * (QB / 16) + wave * (NCBP * QT) + cb;
 #pragma unroll
 			for (int kb = 0; kb < KB; ++kb)
 				bq[cb][kb] = qsrc[(qblk16 * KB + kb) * 64 + lane];
@@ -98,16 +99,16 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 	const unsigned rbase = (unsigned)(c * PITCH) + (unsigned)(((hq ^ c) & 15) * 16);
 	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
-	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * QT * 16 + c) * 8);
+	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * QT * 16 + c) * 16);
 
-	auto rare = [&](const f32x4w (&sv)[2], int t, bool any_t, f32x2n cqv, long long row0, int nvalid) {
+	auto rare = [&](const f32x4w (&sv)[NCBP], int t, bool any_t, f32x4n cqv, long long row0, int nvalid) {
 		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
 			return;
 		int qo = qw;
 		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)
 #pragma unroll
-		for (int i = 0; i < 2; ++i) {
-			const int q = qo + 32 * t + 16 * i + c;
+		for (int i = 0; i < NCBP; ++i) {
+			const int q = qo + 16 * NCBP * t + 16 * i + c;
 			const float c0 = cqv[i];
 			unsigned m = 0u;
 			if (any_t) {
@@ -162,31 +163,25 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 			if (hq < QT) {
 				int qo = qw;
 				MVS_OPAQUE_VGPR(qo);
-				unsigned long long w[2][8];
-				float e2v[2];
-#pragma unroll
-				for (int i = 0; i < 2; ++i) {
-					const int q = qo + 32 * hq + 16 * i + c;
+				f32x4n v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+				for (int i = 0; i < NCBP; ++i) { // (one query at a time: the resident fragments leave few registers)
+					const int q = qo + 16 * NCBP * hq + 16 * i + c;
 					const int qc = q < a.nq ? q : 0;
 					const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+					unsigned long long w[8];
 #pragma unroll
 					for (int j = 0; j < 8; ++j)
-						w[i][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					e2v[i] = __builtin_nontemporal_load(a.e2 + qc);
-				}
-#pragma unroll
-				for (int i = 0; i < 2; ++i)
+						w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const float e2v = __builtin_nontemporal_load(a.e2 + qc);
 #pragma unroll
 					for (int j = 0; j < 8; ++j)
-						asm volatile("" : "+v"(w[i][j]));
-				f32x2n v;
-#pragma unroll
-				for (int i = 0; i < 2; ++i) {
+						asm volatile("" : "+v"(w[j]));
 					unsigned key[16];
 #pragma unroll
 					for (int j = 0; j < 8; ++j) {
-						key[2 * j] = (unsigned)w[i][j];
-						key[2 * j + 1] = (unsigned)(w[i][j] >> 32);
+						key[2 * j] = (unsigned)w[j];
+						key[2 * j + 1] = (unsigned)(w[j] >> 32);
 					}
 #pragma unroll
 					for (int kbit = 2; kbit <= 16; kbit <<= 1)
@@ -209,10 +204,12 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 						kth = (a.nclass - 1 == j) ? key[j] : kth;
 					const unsigned neutral = skey(-FLT_MAX);
 					const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
-					const int q = qo + 32 * hq + 16 * i + c;
-					v[i] = q < a.nq ? B - e2v[i] : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
+					const float bv = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
+					v[0] = i == 0 ? bv : v[0];
+					v[1] = i == 1 ? bv : v[1];
+					v[2] = i == 2 ? bv : v[2];
 				}
-				*(f32x2n *)(cqtab + (wave * QT * 16 + hq * 16 + c) * 2) = v;
+				*(f32x4n *)(cqtab + (wave * QT * 16 + hq * 16 + c) * 4) = v;
 			}
 		}
 		dma_block(u + 1); // the next staged block streams in under this one's MFMAs (every LDS read below is hand-written)
@@ -226,12 +223,12 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 			asm volatile("ds_read_b128 %0, %1" : "=v"(Y) : "v"(nb_lds) : "memory");
 #pragma unroll
 			for (int t = 0; t < QT; ++t) {
-				f32x2n cqv;
-				asm volatile("ds_read_b64 %0, %1" : "=v"(cqv) : "v"(cq_lds + (unsigned)(t * 128)) : "memory");
+				f32x4n cqv;
+				asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds + (unsigned)(t * 256)) : "memory");
 				bf16x8 A[4]; // ring: k-block kb lives in A[kb & 3]; two k-blocks are read ahead
 				asm volatile("ds_read_b128 %0, %1" : "=v"(A[0]) : "v"(tb) : "memory");
 				asm volatile("ds_read_b128 %0, %1" : "=v"(A[1]) : "v"(tb ^ 64u) : "memory");
-				f32x4w acc[2];
+				f32x4w acc[NCBP];
 #pragma unroll
 				for (int g = 0; g < KB / 2; ++g) { // groups of two k-blocks
 					if (g + 1 < KB / 2) {
@@ -247,18 +244,22 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 					for (int kk2 = 0; kk2 < 2; ++kk2) {
 						const int kb = 2 * g + kk2;
 #pragma unroll
-						for (int i = 0; i < 2; ++i) {
+						for (int i = 0; i < NCBP; ++i) {
 							if (kb == 0) // the chain starts at beta(row): s comes out of the matrix pipe
-								acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[2 * t + i][kb], Y, 0, 0, 0);
+								acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[NCBP * t + i][kb], Y, 0, 0, 0);
 							else
-								acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[2 * t + i][kb], acc[i], 0, 0, 0);
+								acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb & 3], bq[NCBP * t + i][kb], acc[i], 0, 0, 0);
 						}
 					}
 					__builtin_amdgcn_sched_barrier(0);
 				}
 				const float mx0 = __builtin_fmaxf(__builtin_fmaxf(acc[0][0], acc[0][1]), __builtin_fmaxf(acc[0][2], acc[0][3]));
 				const float mx1 = __builtin_fmaxf(__builtin_fmaxf(acc[1][0], acc[1][1]), __builtin_fmaxf(acc[1][2], acc[1][3]));
-				const bool any_t = (mx0 >= cqv[0]) || (mx1 >= cqv[1]); // NaN on either side: false
+				bool any_t = (mx0 >= cqv[0]) || (mx1 >= cqv[1]); // NaN on either side: false
+				if (NCBP == 3) {
+					const float mx2 = __builtin_fmaxf(__builtin_fmaxf(acc[2][0], acc[2][1]), __builtin_fmaxf(acc[2][2], acc[2][3]));
+					any_t = any_t || (mx2 >= cqv[2]);
+				}
 				rare(acc, t, any_t, cqv, row0, nvalid);
 			}
 		}
@@ -774,6 +775,7 @@ int collect_store_dims(int d) {
 	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : 0))))));
 }
 int g_ksplit_waves = 4; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
+int g_wide384_ncb = 3;  // option cl_wide384_ncb: column blocks per wave of the 384-dim instance (2 | 3)
 int g_ksplit_opt = 0;   // option cl_ksplit_opt: bit 0 = s_setprio skew
 int g_ksplit_ncb = 3;   // column blocks per wave pair (option cl_ksplit_ncb: 2, or 3 with 8 waves)
 static int ksplit_ncb() {
@@ -785,6 +787,8 @@ static int wide_qt(int dp1) {
 int collect_wide_qblock(int dp1) {
 	if (dp1 == 1024) // 8 waves, two column blocks per pair (2 x 16 k-blocks = 128 VGPRs of fragments)
 		return 128;
+	if (dp1 == 384)
+		return g_wide384_ncb == 3 ? 192 : 128;
 	return dp1 == 768 ? (g_ksplit_waves / 2) * 16 * ksplit_ncb() : 128 * wide_qt(dp1);
 }
 static int wide_wsub(int dp1) {
@@ -802,20 +806,20 @@ size_t collect_wide_lds_bytes(int dp1) {
 		return (size_t)(g_ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) +
 		       (size_t)(g_ksplit_waves == 4 && ksplit_ncb() == 3 ? CL_QCAP / 2 : CL_QCAP) * 8 +
 		       (size_t)2 * g_ksplit_waves * (ksplit_ncb() - 1) * 64 * 16 + (size_t)collect_wide_qblock(768) * 4 + 64;
-	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)collect_wide_qblock(dp1) * 4 + 64;
+	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)4 * wide_qt(dp1) * 16 * 4 * 4 + 64;
 }
 int collect_wide_block_rows(int dp1) {
 	return 16 * wide_wsub(dp1);
 }
 
-template <int KB, int QT, bool COLLECT>
+template <int KB, int QT, int NCBP, bool COLLECT>
 static void launch_wide_inst(int metric, const CollectArgs &a, int grid, size_t lds, hipStream_t st) {
 	if (metric == METRIC_L2) {
-		auto kern = flat_bf16_wide_kernel<KB, QT, true, COLLECT>;
+		auto kern = flat_bf16_wide_kernel<KB, QT, NCBP, true, COLLECT>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 	} else {
-		auto kern = flat_bf16_wide_kernel<KB, QT, false, COLLECT>;
+		auto kern = flat_bf16_wide_kernel<KB, QT, NCBP, false, COLLECT>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 	}
@@ -840,19 +844,26 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	const size_t lds = collect_wide_lds_bytes(dp1);
 	if (dp1 == 256) {
 		if (collect)
-			launch_wide_inst<8, 2, true>(metric, a, grid, lds, st);
+			launch_wide_inst<8, 2, 2, true>(metric, a, grid, lds, st);
 		else
-			launch_wide_inst<8, 2, false>(metric, a, grid, lds, st);
+			launch_wide_inst<8, 2, 2, false>(metric, a, grid, lds, st);
 	} else if (dp1 == 384) {
-		if (collect)
-			launch_wide_inst<12, 1, true>(metric, a, grid, lds, st);
-		else
-			launch_wide_inst<12, 1, false>(metric, a, grid, lds, st);
+		if (g_wide384_ncb == 3) {
+			if (collect)
+				launch_wide_inst<12, 1, 3, true>(metric, a, grid, lds, st);
+			else
+				launch_wide_inst<12, 1, 3, false>(metric, a, grid, lds, st);
+		} else {
+			if (collect)
+				launch_wide_inst<12, 1, 2, true>(metric, a, grid, lds, st);
+			else
+				launch_wide_inst<12, 1, 2, false>(metric, a, grid, lds, st);
+		}
 	} else if (dp1 == 512) {
 		if (collect)
-			launch_wide_inst<16, 1, true>(metric, a, grid, lds, st);
+			launch_wide_inst<16, 1, 2, true>(metric, a, grid, lds, st);
 		else
-			launch_wide_inst<16, 1, false>(metric, a, grid, lds, st);
+			launch_wide_inst<16, 1, 2, false>(metric, a, grid, lds, st);
 	} else if (dp1 == 768) {
 #define MVS_KSP(L2, CO)                                                                                         \
 	{                                                                                                           \
