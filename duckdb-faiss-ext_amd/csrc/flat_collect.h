@@ -36,7 +36,7 @@ struct CollectArgs {
 int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512, 768, 1024; 0 = the coarse filter does not serve d
 int collect_wide_qblock(int dp1);
 int collect_wide_slots(int dp1);
-extern int g_ksplit_waves, g_ksplit_ncb, g_ksplit_opt, g_wide384_ncb; // 8: the k-split kernel runs one 512-thread workgroup per CU
+extern int g_ksplit_waves, g_ksplit_ncb, g_ksplit_opt, g_wide384_ncb, g_wide512_ksplit; // 8: the k-split kernel runs one 512-thread workgroup per CU
 size_t collect_wide_lds_bytes(int dp1);
 int collect_wide_block_rows(int dp1);
 void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,

@@ -775,6 +775,7 @@ int collect_store_dims(int d) {
 	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : 0))))));
 }
 int g_ksplit_waves = 4; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
+int g_wide512_ksplit = 0; // option cl_wide512_ksplit: the 512-dim store on the k-split kernel (8 k-blocks per wave, 3 column blocks)
 int g_wide384_ncb = 3;  // option cl_wide384_ncb: column blocks per wave of the 384-dim instance (2 | 3)
 int g_ksplit_opt = 0;   // option cl_ksplit_opt: bit 0 = s_setprio skew
 int g_ksplit_ncb = 3;   // column blocks per wave pair (option cl_ksplit_ncb: 2, or 3 with 8 waves)
@@ -789,6 +790,8 @@ int collect_wide_qblock(int dp1) {
 		return 128;
 	if (dp1 == 384)
 		return g_wide384_ncb == 3 ? 192 : 128;
+	if (dp1 == 512 && g_wide512_ksplit)
+		return 96;
 	return dp1 == 768 ? (g_ksplit_waves / 2) * 16 * ksplit_ncb() : 128 * wide_qt(dp1);
 }
 static int wide_wsub(int dp1) {
@@ -802,6 +805,8 @@ int collect_wide_slots(int dp1) {
 size_t collect_wide_lds_bytes(int dp1) {
 	if (dp1 == 1024) // flat_bf16_ksplit_kernel<8, 2, 2, 32>: two 32 KB stages, beta, queue, hand-over buffers, bounds, control
 		return (size_t)2 * (16 * 1024 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + (size_t)2 * 8 * 64 * 16 + 128 * 4 + 64;
+	if (dp1 == 512 && g_wide512_ksplit) // flat_bf16_ksplit_kernel<4, 2, 3, 16>
+		return (size_t)2 * (16 * 512 * 2 + 64 * 4) + (size_t)(CL_QCAP / 2) * 8 + (size_t)2 * 4 * 2 * 64 * 16 + 96 * 4 + 64;
 	if (dp1 == 768) // flat_bf16_ksplit_kernel: two 24 KB stages, beta, queue, hand-over buffers, bounds, control
 		return (size_t)(g_ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) +
 		       (size_t)(g_ksplit_waves == 4 && ksplit_ncb() == 3 ? CL_QCAP / 2 : CL_QCAP) * 8 +
@@ -859,6 +864,23 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 			else
 				launch_wide_inst<12, 1, 2, false>(metric, a, grid, lds, st);
 		}
+	} else if (dp1 == 512 && g_wide512_ksplit) {
+#define MVS_KSP5(L2, CO)                                                                                        \
+	{                                                                                                           \
+		auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 3, 16>;                                               \
+		ensure_dynamic_lds((const void *)kern, lds);                                                            \
+		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                                  \
+	}
+		if (metric == METRIC_L2 && collect)
+			MVS_KSP5(true, true)
+		else if (metric == METRIC_L2)
+			MVS_KSP5(true, false)
+		else if (collect)
+			MVS_KSP5(false, true)
+		else
+			MVS_KSP5(false, false)
+#undef MVS_KSP5
+		MVS_HIP(hipGetLastError());
 	} else if (dp1 == 512) {
 		if (collect)
 			launch_wide_inst<16, 1, 2, true>(metric, a, grid, lds, st);

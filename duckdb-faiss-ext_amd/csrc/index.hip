@@ -1739,6 +1739,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		prefilter_mode = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "cl_wide512_ksplit")) { // 384 < d <= 512 coarse filter on the k-split kernel (1) or on wide<16,1,2> (0)
+		g_wide512_ksplit = v != 0;
+		return true;
+	}
 	if (!strcmp(key, "cl_wide384_ncb")) { // 256 < d <= 384 coarse filter: column blocks per wave (2 | 3)
 		g_wide384_ncb = v == 2 ? 2 : 3;
 		return true;

@@ -1,7 +1,11 @@
 #!/bin/bash
+# wide coarse filter (128 < d <= 1024): kernel timings against the f32 kernel, N = 2M, nq = 10k
 cd $GRAFT_REPO_ROOT
-timeout 1500 python3 -m pytest tests/test_collect_wide_gpu.py tests/test_collect_gpu.py -q -x 2>&1 | tail -4 | tee gpurun_out/wide_tests.txt
-bash tools/wide_prof.sh 768 IP 2000000
-rm -f gpurun_out/wide_bench6.txt
-echo "== C4 (12.5M x 768, IP, normalised)" | tee -a gpurun_out/wide_bench6.txt
-timeout 900 python3 bench.py --rows 12500000 --d 768 --metric IP --normalize --steps 5 --warmup 1 --cpu-seconds 10 2>&1 | tail -1 | tee -a gpurun_out/wide_bench6.txt
+rm -f gpurun_out/wide_table.txt
+for cfg in "256 L2" "256 IP" "384 L2" "384 IP" "512 L2" "512 IP" "768 L2" "768 IP" "1024 L2" "1024 IP"; do
+  set -- $cfg
+  echo "== d=$1 $2 n=2000000 nq=10000" | tee -a gpurun_out/wide_table.txt
+  timeout 300 python3 tools/kbench.py --n 2000000 --nq 10000 --d $1 --metric $2 --k 10 --reps 3 2>&1 | tail -1 | cut -c1-300 | tee -a gpurun_out/wide_table.txt
+done
+echo "== d=256 L2 n=10000000" | tee -a gpurun_out/wide_table.txt
+timeout 300 python3 tools/kbench.py --n 10000000 --nq 10000 --d 256 --metric L2 --k 10 --reps 3 2>&1 | tail -1 | cut -c1-300 | tee -a gpurun_out/wide_table.txt
