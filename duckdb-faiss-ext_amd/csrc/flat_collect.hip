@@ -453,31 +453,25 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			// (bitonic network in registers).  The pass bound B - 2E goes to the wave's table in LDS.
 			int qo = qw;
 			MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this block out of the hot loop's registers)
-			unsigned long long w[2][8];
-			float e2v[2];
-#pragma unroll
-			for (int i = 0; i < 2; ++i) {
+			f32x2n v = {0.f, 0.f};
+#pragma unroll 1
+			for (int i = 0; i < 2; ++i) { // one query at a time: 128 VGPRs of fragments are resident, the network needs ~40 more
 				const int q = qo + 32 * hq + 16 * i + c;
 				const int qc = q < a.nq ? q : 0;
 				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+				unsigned long long w[8];
 #pragma unroll
 				for (int j = 0; j < 8; ++j)
-					w[i][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				e2v[i] = __builtin_nontemporal_load(a.e2 + qc);
-			}
+					w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const float e2v = __builtin_nontemporal_load(a.e2 + qc);
 #pragma unroll
-			for (int i = 0; i < 2; ++i) // every load is issued before the first is consumed: one round trip
-#pragma unroll
-				for (int j = 0; j < 8; ++j)
-					asm volatile("" : "+v"(w[i][j]));
-			f32x2n v;
-#pragma unroll
-			for (int i = 0; i < 2; ++i) {
+				for (int j = 0; j < 8; ++j) // every load is issued before the first is consumed: one round trip
+					asm volatile("" : "+v"(w[j]));
 				unsigned key[16];
 #pragma unroll
 				for (int j = 0; j < 8; ++j) {
-					key[2 * j] = (unsigned)w[i][j];
-					key[2 * j + 1] = (unsigned)(w[i][j] >> 32);
+					key[2 * j] = (unsigned)w[j];
+					key[2 * j + 1] = (unsigned)(w[j] >> 32);
 				}
 #pragma unroll
 				for (int kbit = 2; kbit <= 16; kbit <<= 1)
@@ -500,8 +494,9 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 					kth = (a.nclass - 1 == j) ? key[j] : kth;
 				const unsigned neutral = skey(-FLT_MAX);
 				const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
-				const int q = qo + 32 * hq + 16 * i + c;
-				v[i] = q < a.nq ? B - e2v[i] : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
+				const float bv = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
+				v[0] = i == 0 ? bv : v[0];
+				v[1] = i == 1 ? bv : v[1];
 			}
 			*(f32x2n *)(cqtab + (wave * 64 + hq * 16 + c) * 2) = v;
 		}
