@@ -29,7 +29,8 @@ struct CollectArgs {
 	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
 	long long n, row_first, split_rows;
 	int nq, nqb, nsplit, xcd_map;
-	int opt; // bit 0: k-split kernel, 8 waves: s_setprio skew between the two waves of a SIMD (A/B)
+	int opt; // A/B bits (option cl_ksplit_opt): 0 = k-split kernel with 8 waves: s_setprio skew between the two waves of a SIMD;
+	         // 1 = wide kernels: bound refresh cadence counted in staged blocks instead of rows
 };
 
 // csrc/flat_collect_wide.hip
