@@ -1,0 +1,226 @@
+// csrc/coarse_select.hip -- IVF coarse quantisation (IndexIVF::search -> quantizer->search(n, x, nprobe), faiss/IndexIVF.cpp;
+// reference call site src/faiss_extension.cpp:631 through IndexIVFFlat) for a Flat L2 quantizer of a few thousand centroids.
+//
+// The k-list kernels are built for k << N: with k = nprobe = 32 lists over 4096 rows every (query, row split) pair starts cold
+// and a fifth of all rows is inserted somewhere (1.35 ms at C3, a third of the step).  Here the whole [nq][nlist] distance
+// matrix is written once -- the SAME arithmetic as the BLAS branch (exhaustive_L2sqr_blas): ip = one k-ordered fma chain,
+// dis = max(0, fmaf(-2, ip, ||x||^2 + ||y||^2)) -- and one wavefront per query selects the nprobe smallest (dis, id) pairs
+// with two bitwise binary searches (on the distance bits, then on the ids among the rows tied at the nprobe-th distance).
+// merge_partials_kernel then orders the list as always.  HBM-bound on the matrix: nq * nlist * 8 bytes.
+#include "common.h"
+#include "index.h"
+
+#include <cfloat>
+
+namespace mvs {
+
+// ---- D[q][c]: 64 queries x 128 centroids per workgroup, 4 x 8 chains per thread, operands through LDS in slabs of 16 dims ------
+// centroid rows: pitch sdp, FlatGeom::pair_interleaved (every 4 floats stored [k0,k2,k1,k3] or, bit 4 of the row set,
+// [k1,k3,k0,k2]); dimensions >= d are zero on both sides (fma(0, 0, acc) = acc)
+__global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ x, long long nq, int d,
+                                                         const float *__restrict__ cent, int sdp, int interleaved, int nlist,
+                                                         const float *__restrict__ qn, const float *__restrict__ cn,
+                                                         float *__restrict__ D) {
+	__shared__ float xs[16][64 + 4];
+	__shared__ float ys[16][128 + 4];
+	const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+	const long long q0 = (long long)blockIdx.y * 64;
+	const int c0 = blockIdx.x * 128;
+	float acc[4][8];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 8; ++j)
+			acc[i][j] = 0.f;
+	for (int k0 = 0; k0 < d; k0 += 16) {
+		{ // queries: thread -> (row tid >> 2, dims 4 (tid & 3) ..)
+			const long long q = q0 + (tid >> 2);
+			const int kk = k0 + 4 * (tid & 3);
+#pragma unroll
+			for (int e = 0; e < 4; ++e)
+				xs[4 * (tid & 3) + e][tid >> 2] = (q < nq && kk + e < d) ? x[q * d + kk + e] : 0.f;
+		}
+		{ // centroids: thread -> (row tid >> 1, dims 8 (tid & 1) ..)
+			const int c = c0 + (tid >> 1);
+			const int kk = k0 + 8 * (tid & 1);
+			const bool flip = interleaved && ((c >> 4) & 1);
+#pragma unroll
+			for (int g = 0; g < 2; ++g) {
+				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (c < nlist && kk + 4 * g < sdp)
+					v = *(const float4 *)(cent + (size_t)c * sdp + kk + 4 * g);
+				float y0 = v.x, y1 = v.y, y2 = v.z, y3 = v.w;
+				if (interleaved) {
+					y0 = flip ? v.z : v.x, y1 = flip ? v.x : v.z, y2 = flip ? v.w : v.y, y3 = flip ? v.y : v.w;
+				}
+				const int kb = 8 * (tid & 1) + 4 * g;
+				ys[kb + 0][tid >> 1] = y0;
+				ys[kb + 1][tid >> 1] = y1;
+				ys[kb + 2][tid >> 1] = y2;
+				ys[kb + 3][tid >> 1] = y3;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < 16; ++k) { // k ascending: every accumulator is ONE k-ordered chain
+			float xv[4], yv[8];
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				xv[i] = xs[k][4 * ty + i];
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				yv[j] = ys[k][8 * tx + j];
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					acc[i][j] = fmaf(xv[i], yv[j], acc[i][j]);
+		}
+		__syncthreads();
+	}
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const long long q = q0 + 4 * ty + i;
+		if (q >= nq)
+			continue;
+		const float xn = qn[q];
+		float out[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int c = c0 + 8 * tx + j;
+			float dis = fmaf(-2.0f, acc[i][j], xn + (c < nlist ? cn[c] : 0.f));
+			dis = dis < 0.f ? 0.f : dis; // FAISS: if (dis < 0) dis = 0  (NaN stays NaN)
+			out[j] = dis;
+		}
+		if (c0 + 8 * tx + 7 < nlist) {
+			*(float4 *)(D + q * nlist + c0 + 8 * tx) = make_float4(out[0], out[1], out[2], out[3]);
+			*(float4 *)(D + q * nlist + c0 + 8 * tx + 4) = make_float4(out[4], out[5], out[6], out[7]);
+		} else {
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				if (c0 + 8 * tx + j < nlist)
+					D[q * nlist + c0 + 8 * tx + j] = out[j];
+		}
+	}
+}
+
+// ---- one wavefront per query: the np smallest (dis, id) of its row of D -> pd / pi [nq][np] (any order; missing: FLT_MAX, -1) --
+// PL = values per lane (nlist <= 64 PL, a multiple of 4).  A row is a candidate iff dis < FLT_MAX (the heap's strict compare
+// against its neutral value; NaN never enters).
+template <int PL>
+__global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restrict__ D, int nlist, int np,
+                                                          float *__restrict__ pd, int *__restrict__ pi) {
+	const long long q = blockIdx.x;
+	const int lane = threadIdx.x;
+	const float *row = D + q * nlist;
+	unsigned key[PL]; // lane holds ids (4 (64 it + lane) + e), it < PL / 4
+#pragma unroll
+	for (int it = 0; it < PL / 4; ++it) {
+		const int c = 4 * (64 * it + lane);
+		float4 v = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+		if (c + 3 < nlist) {
+			v = *(const float4 *)(row + c);
+		} else {
+			if (c < nlist)
+				v.x = row[c];
+			if (c + 1 < nlist)
+				v.y = row[c + 1];
+			if (c + 2 < nlist)
+				v.z = row[c + 2];
+		}
+		const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int e = 0; e < 4; ++e) {
+			const unsigned b = __float_as_uint(f[e]); // dis >= 0 or NaN: the bit pattern orders the finite values
+			key[4 * it + e] = (f[e] < FLT_MAX) ? b : 0xffffffffu;
+		}
+	}
+	auto wave_sum = [&](int v) {
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1)
+			v += __shfl_xor(v, o);
+		return v;
+	};
+	// T = the np-th smallest key: the largest T with #(key < T) < np  (bit by bit)
+	unsigned T = 0u;
+#pragma unroll 1
+	for (int b = 31; b >= 0; --b) {
+		const unsigned t = T | (1u << b);
+		int cnt = 0;
+#pragma unroll
+		for (int j = 0; j < PL; ++j)
+			cnt += key[j] < t ? 1 : 0;
+		if (wave_sum(cnt) < np)
+			T = t;
+	}
+	int less = 0;
+#pragma unroll
+	for (int j = 0; j < PL; ++j)
+		less += key[j] < T ? 1 : 0;
+	less = wave_sum(less);
+	// rows tied at T: the np - less smallest ids (T = 0xffffffff: fewer than np candidates exist, nothing tied is taken)
+	const int need = T == 0xffffffffu ? 0 : np - less;
+	unsigned Tid = 0u; // ids < Tid among the tied rows are taken: the largest Tid with #(tied, id < Tid) <= need ... found bitwise
+#pragma unroll 1
+	for (int b = 16; b >= 0; --b) {
+		const unsigned t = Tid | (1u << b);
+		int cnt = 0;
+#pragma unroll
+		for (int j = 0; j < PL; ++j) {
+			const unsigned id = 4u * (64u * (unsigned)(j >> 2) + (unsigned)lane) + (unsigned)(j & 3);
+			cnt += (key[j] == T && id < t) ? 1 : 0;
+		}
+		if (wave_sum(cnt) <= need)
+			Tid = t;
+	}
+	// emit
+	int base = 0;
+#pragma unroll
+	for (int j = 0; j < PL; ++j) {
+		const unsigned id = 4u * (64u * (unsigned)(j >> 2) + (unsigned)lane) + (unsigned)(j & 3);
+		const bool take = key[j] < T || (need > 0 && key[j] == T && id < Tid);
+		const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+		if (take) {
+			const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+			if (pos < np) {
+				pd[q * np + pos] = __uint_as_float(key[j]);
+				pi[q * np + pos] = (int)id;
+			}
+		}
+		base += __builtin_popcountll(m);
+	}
+	for (int pos = base + lane; pos < np; pos += 64) {
+		pd[q * np + pos] = FLT_MAX;
+		pi[q * np + pos] = -1;
+	}
+}
+
+bool coarse_select_supported(int64_t nlist, int64_t np) {
+	return nlist >= 256 && nlist <= 8192 && nlist % 4 == 0 && np >= 1 && np <= 256 && np < nlist; // (16-byte rows of D)
+}
+size_t coarse_select_matrix_bytes(int64_t nq, int64_t nlist) {
+	return (size_t)nq * nlist * sizeof(float);
+}
+
+// D (scratch, [nq][nlist]) <- distances; pd / pi [nq][np] <- the np nearest centroids of every query, unordered
+void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
+                          const float *d_qn, const float *d_cn, int64_t np, float *d_D, float *d_pd, int32_t *d_pi,
+                          hipStream_t st) {
+	if (nq <= 0)
+		return;
+	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 63) / 64));
+	hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist, d_qn,
+	                   d_cn, d_D);
+	MVS_HIP(hipGetLastError());
+	if (nlist <= 1024)
+		hipLaunchKernelGGL(coarse_select_kernel<16>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+	else if (nlist <= 2048)
+		hipLaunchKernelGGL(coarse_select_kernel<32>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+	else if (nlist <= 4096)
+		hipLaunchKernelGGL(coarse_select_kernel<64>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+	else
+		hipLaunchKernelGGL(coarse_select_kernel<128>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+	MVS_HIP(hipGetLastError());
+}
+
+} // namespace mvs

@@ -185,6 +185,9 @@ public:
 	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask, ws_items1;
 	void ensure_bf16_rows(hipStream_t st);
 	void ensure_h1_rows(hipStream_t st);
+	// IVF coarse quantisation: the np nearest rows (L2, FAISS order) by distance matrix + selection (csrc/coarse_select.hip);
+	// false: shape not served, the caller uses search_device
+	bool coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st);
 	bool collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1, int32_t **pi1, int *fail_cnt, int *fail_q,
 	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
 	void drop_bf16_rows();
@@ -328,6 +331,11 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
                             bool per_pair, hipStream_t st);
 void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_seg, int64_t nq, const int *d_flag_query,
                              const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st);
+bool coarse_select_supported(int64_t nlist, int64_t np);
+void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
+                          const float *d_qn, const float *d_cn, int64_t np, float *d_D, float *d_pd, int32_t *d_pi,
+                          hipStream_t st);
+extern int g_coarse_select;
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,

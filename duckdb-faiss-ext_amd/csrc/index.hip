@@ -992,6 +992,29 @@ void FlatIndex::tie_candidates(int64_t nf, const float *d_xf, const float *d_T, 
 	                      (float *)ws_qn.p, d_rows_out, st);
 }
 
+int g_coarse_select = 1; // option ivf_coarse_select: 0 = the IVF coarse quantiser runs on the k-list kernels
+bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st) {
+	if (!g_coarse_select || metric != METRIC_L2 || nq < 20 || !coarse_select_supported(ntotal, np))
+		return false; // (fewer than 20 queries: FAISS's per-pair branch, other arithmetic)
+	use_device();
+	stream_wait(st, stream); // adds were enqueued on our own stream
+	const int64_t qchunk = std::max<int64_t>(64, std::min<int64_t>(nq, ((int64_t)512 << 20) / (ntotal * 4) / 64 * 64));
+	ws_q.reserve((size_t)qchunk * ntotal * sizeof(float));
+	ws_qn.reserve((size_t)nq * sizeof(float));
+	ws_pd.reserve((size_t)nq * np * sizeof(float));
+	ws_pi.reserve((size_t)nq * np * sizeof(int32_t));
+	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
+	begin_kernel_timing(st);
+	for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
+		const int64_t m = std::min(qchunk, nq - q0);
+		launch_coarse_select(d_x + q0 * d, m, d, vecs, geom.dp, geom.pair_interleaved ? 1 : 0, ntotal, (const float *)ws_qn.p + q0, norms,
+		                     np, (float *)ws_q.p, (float *)ws_pd.p + q0 * np, (int32_t *)ws_pi.p + q0 * np, st);
+	}
+	end_kernel_timing(st);
+	launch_merge_partials(METRIC_L2, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, 1, nq, np, nullptr, label_offset, d_D, d_I, st);
+	return true;
+}
+
 void FlatIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                               const mvs_search_params *params, hipStream_t st) {
 	use_device();
@@ -1757,6 +1780,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "cl_ksplit_waves")) { // 512 < d <= 768: waves per workgroup of the k-split coarse filter (4 or 8)
 		g_ksplit_waves = v == 4 ? 4 : 8;
+		return true;
+	}
+	if (!strcmp(key, "ivf_coarse_select")) { // IVF coarse quantiser: distance matrix + selection (1) or the k-list kernels (0)
+		g_coarse_select = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "tie_from_candidates")) {

@@ -650,8 +650,13 @@ public:
 		mvs_search_params qp;
 		memset(&qp, 0, sizeof qp);
 		qp.efSearch = params ? params->efSearch : 0; // quantizer_params of an HNSW coarse quantizer (:679-681)
-		if (!reuse_coarse) // (a prefilter re-run keeps the coarse assignment of the batch its queries came from)
-			quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, hnsw_M > 0 ? &qp : nullptr, stream);
+		if (!reuse_coarse) { // (a prefilter re-run keeps the coarse assignment of the batch its queries came from)
+			// a Flat L2 quantizer of a few thousand centroids: distance matrix + per-query selection (csrc/coarse_select.hip)
+			const bool done = hnsw_M == 0 && static_cast<FlatIndex *>(quantizer)->coarse_topk(nq, d_x, np, (float *)ws_cD.p,
+			                                                                                  (int64_t *)ws_cI.p, stream);
+			if (!done)
+				quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, hnsw_M > 0 ? &qp : nullptr, stream);
+		}
 		// Inner product: the MFMA variant is the same k-ordered chain as IVFFlatScanner's fvec_inner_product -> default.
 		// L2: it evaluates ||x||^2 + ||y||^2 - 2<x,y> (the Flat BLAS-branch arithmetic) instead of the scanner's
 		// sum (x-y)^2, i.e. the same neighbours up to rounding-level near-ties -> opt-in (option ivf_mfma = 1); the
