@@ -135,12 +135,7 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 			key[4 * it + e] = (f[e] < FLT_MAX) ? b : 0xffffffffu;
 		}
 	}
-	auto wave_sum = [&](int v) {
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1)
-			v += __shfl_xor(v, o);
-		return v;
-	};
+	// counts over the wave: one ballot + scalar population count per register slot (no cross-lane data movement)
 	// T = the np-th smallest key: the largest T with #(key < T) < np  (bit by bit)
 	unsigned T = 0u;
 #pragma unroll 1
@@ -149,18 +144,17 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 		int cnt = 0;
 #pragma unroll
 		for (int j = 0; j < PL; ++j)
-			cnt += key[j] < t ? 1 : 0;
-		if (wave_sum(cnt) < np)
+			cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] < t));
+		if (cnt < np)
 			T = t;
 	}
 	int less = 0;
 #pragma unroll
 	for (int j = 0; j < PL; ++j)
-		less += key[j] < T ? 1 : 0;
-	less = wave_sum(less);
+		less += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] < T));
 	// rows tied at T: the np - less smallest ids (T = 0xffffffff: fewer than np candidates exist, nothing tied is taken)
 	const int need = T == 0xffffffffu ? 0 : np - less;
-	unsigned Tid = 0u; // ids < Tid among the tied rows are taken: the largest Tid with #(tied, id < Tid) <= need ... found bitwise
+	unsigned Tid = 0u; // ids < Tid among the tied rows are taken: the largest Tid with #(tied, id < Tid) <= need, found bitwise
 #pragma unroll 1
 	for (int b = 16; b >= 0; --b) {
 		const unsigned t = Tid | (1u << b);
@@ -168,9 +162,9 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 #pragma unroll
 		for (int j = 0; j < PL; ++j) {
 			const unsigned id = 4u * (64u * (unsigned)(j >> 2) + (unsigned)lane) + (unsigned)(j & 3);
-			cnt += (key[j] == T && id < t) ? 1 : 0;
+			cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] == T && id < t));
 		}
-		if (wave_sum(cnt) <= need)
+		if (cnt <= need)
 			Tid = t;
 	}
 	// emit
