@@ -8,6 +8,7 @@
 // with two bitwise binary searches (on the distance bits, then on the ids among the rows tied at the nprobe-th distance).
 // merge_partials_kernel then orders the list as always.  HBM-bound on the matrix: nq * nlist * 8 bytes.
 #include "common.h"
+#include "flat_fused.h"
 #include "index.h"
 
 #include <cfloat>
@@ -20,7 +21,7 @@ namespace mvs {
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ x, long long nq, int d,
                                                          const float *__restrict__ cent, int sdp, int interleaved, int nlist,
                                                          const float *__restrict__ qn, const float *__restrict__ cn,
-                                                         float *__restrict__ D) {
+                                                         int is_l2, float *__restrict__ D) {
 	__shared__ float xs[16][64 + 4];
 	__shared__ float ys[16][128 + 4];
 	const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -83,14 +84,14 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 		const long long q = q0 + 4 * ty + i;
 		if (q >= nq)
 			continue;
-		const float xn = qn[q];
+		const float xn = is_l2 ? qn[q] : 0.f;
 		float out[8];
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			const int c = c0 + 8 * tx + j;
 			float dis = fmaf(-2.0f, acc[i][j], xn + (c < nlist ? cn[c] : 0.f));
 			dis = dis < 0.f ? 0.f : dis; // FAISS: if (dis < 0) dis = 0  (NaN stays NaN)
-			out[j] = dis;
+			out[j] = is_l2 ? dis : acc[i][j]; // inner product: the chain itself
 		}
 		if (c0 + 8 * tx + 7 < nlist) {
 			*(float4 *)(D + q * nlist + c0 + 8 * tx) = make_float4(out[0], out[1], out[2], out[3]);
@@ -105,9 +106,10 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 }
 
 // ---- one wavefront per query: the np smallest (dis, id) of its row of D -> pd / pi [nq][np] (any order; missing: FLT_MAX, -1) --
-// PL = values per lane (nlist <= 64 PL, a multiple of 4).  A row is a candidate iff dis < FLT_MAX (the heap's strict compare
-// against its neutral value; NaN never enters).
-template <int PL>
+// PL = values per lane (nlist <= 64 PL, a multiple of 4).  A row is a candidate iff dis < FLT_MAX / score > -FLT_MAX (the heap's
+// strict compare against its neutral value; NaN never enters).  Inner product: the pure order (score descending, id ascending);
+// the caller asks for one entry more than nprobe and lets the merge flag boundary ties (FlatIndex::resolve_ip_ties).
+template <int PL, bool IS_L2>
 __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restrict__ D, int nlist, int np,
                                                           float *__restrict__ pd, int *__restrict__ pi) {
 	const long long q = blockIdx.x;
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 #pragma unroll
 	for (int it = 0; it < PL / 4; ++it) {
 		const int c = 4 * (64 * it + lane);
-		float4 v = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+		const float pad = __uint_as_float(0x7fc00000u); // NaN: never a candidate, whatever the metric
+		float4 v = make_float4(pad, pad, pad, pad);
 		if (c + 3 < nlist) {
 			v = *(const float4 *)(row + c);
 		} else {
@@ -131,8 +134,9 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 		const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
 		for (int e = 0; e < 4; ++e) {
-			const unsigned b = __float_as_uint(f[e]); // dis >= 0 or NaN: the bit pattern orders the finite values
-			key[4 * it + e] = (f[e] < FLT_MAX) ? b : 0xffffffffu;
+			// L2: dis >= 0 or NaN, the bit pattern orders the finite values; inner product: larger score = smaller key
+			const unsigned b = IS_L2 ? __float_as_uint(f[e]) : ~f2key(f[e]);
+			key[4 * it + e] = (IS_L2 ? f[e] < FLT_MAX : f[e] > -FLT_MAX) ? b : 0xffffffffu;
 		}
 	}
 	// counts over the wave: one ballot + scalar population count per register slot (no cross-lane data movement)
@@ -177,14 +181,14 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 		if (take) {
 			const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
 			if (pos < np) {
-				pd[q * np + pos] = __uint_as_float(key[j]);
+				pd[q * np + pos] = IS_L2 ? __uint_as_float(key[j]) : key2f(~key[j]);
 				pi[q * np + pos] = (int)id;
 			}
 		}
 		base += __builtin_popcountll(m);
 	}
 	for (int pos = base + lane; pos < np; pos += 64) {
-		pd[q * np + pos] = FLT_MAX;
+		pd[q * np + pos] = IS_L2 ? FLT_MAX : -FLT_MAX;
 		pi[q * np + pos] = -1;
 	}
 }
@@ -198,22 +202,30 @@ size_t coarse_select_matrix_bytes(int64_t nq, int64_t nlist) {
 
 // D (scratch, [nq][nlist]) <- distances; pd / pi [nq][np] <- the np nearest centroids of every query, unordered
 void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
-                          const float *d_qn, const float *d_cn, int64_t np, float *d_D, float *d_pd, int32_t *d_pi,
+                          const float *d_qn, const float *d_cn, int64_t np, int is_l2, float *d_D, float *d_pd, int32_t *d_pi,
                           hipStream_t st) {
 	if (nq <= 0)
 		return;
 	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 63) / 64));
 	hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist, d_qn,
-	                   d_cn, d_D);
+	                   d_cn, is_l2, d_D);
 	MVS_HIP(hipGetLastError());
+#define MVS_CSEL(PL)                                                                                                               \
+	{                                                                                                                              \
+		if (is_l2)                                                                                                                 \
+			hipLaunchKernelGGL((coarse_select_kernel<PL, true>), dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi); \
+		else                                                                                                                       \
+			hipLaunchKernelGGL((coarse_select_kernel<PL, false>), dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi); \
+	}
 	if (nlist <= 1024)
-		hipLaunchKernelGGL(coarse_select_kernel<16>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+		MVS_CSEL(16)
 	else if (nlist <= 2048)
-		hipLaunchKernelGGL(coarse_select_kernel<32>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+		MVS_CSEL(32)
 	else if (nlist <= 4096)
-		hipLaunchKernelGGL(coarse_select_kernel<64>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+		MVS_CSEL(64)
 	else
-		hipLaunchKernelGGL(coarse_select_kernel<128>, dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi);
+		MVS_CSEL(128)
+#undef MVS_CSEL
 	MVS_HIP(hipGetLastError());
 }
 

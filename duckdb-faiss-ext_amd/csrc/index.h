@@ -333,7 +333,7 @@ void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_se
                              const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st);
 bool coarse_select_supported(int64_t nlist, int64_t np);
 void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
-                          const float *d_qn, const float *d_cn, int64_t np, float *d_D, float *d_pd, int32_t *d_pi,
+                          const float *d_qn, const float *d_cn, int64_t np, int is_l2, float *d_D, float *d_pd, int32_t *d_pi,
                           hipStream_t st);
 extern int g_coarse_select;
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,

@@ -994,24 +994,52 @@ void FlatIndex::tie_candidates(int64_t nf, const float *d_xf, const float *d_T, 
 
 int g_coarse_select = 1; // option ivf_coarse_select: 0 = the IVF coarse quantiser runs on the k-list kernels
 bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st) {
-	if (!g_coarse_select || metric != METRIC_L2 || nq < 20 || !coarse_select_supported(ntotal, np))
-		return false; // (fewer than 20 queries: FAISS's per-pair branch, other arithmetic)
+	if (!g_coarse_select || (metric != METRIC_L2 && metric != METRIC_IP) || nq < 20)
+		return false; // (fewer than 20 queries: FAISS's per-pair branch, other arithmetic for L2)
+	// inner product: one entry more than asked for, the merge flags boundary ties and resolve_ip_ties replays FAISS's heap
+	const bool ip = metric == METRIC_IP;
+	if (ip && !(ip_exact_ties && np + 1 <= flat_mfma_max_k(geom)))
+		return false;
+	const int64_t kk = ip ? np + 1 : np;
+	if (!coarse_select_supported(ntotal, kk))
+		return false;
 	use_device();
 	stream_wait(st, stream); // adds were enqueued on our own stream
+	if (have_last_search) // the scratch buffers are shared by all searches of this index (FlatIndex::search_flat)
+		stream_wait(st, last_search_stream);
+	last_search_stream = st;
+	have_last_search = true;
 	const int64_t qchunk = std::max<int64_t>(64, std::min<int64_t>(nq, ((int64_t)512 << 20) / (ntotal * 4) / 64 * 64));
 	ws_q.reserve((size_t)qchunk * ntotal * sizeof(float));
 	ws_qn.reserve((size_t)nq * sizeof(float));
-	ws_pd.reserve((size_t)nq * np * sizeof(float));
-	ws_pi.reserve((size_t)nq * np * sizeof(int32_t));
-	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
+	ws_pd.reserve((size_t)nq * kk * sizeof(float));
+	ws_pi.reserve((size_t)nq * kk * sizeof(int32_t));
+	TieFlags fl = {nullptr, nullptr, nullptr, nullptr};
+	if (ip) {
+		const size_t kflag = (size_t)(kk + std::max<int64_t>(16, kk / 2));
+		ws_flag.reserve(16 + (size_t)nq * 4 + (size_t)nq * kflag * 8);
+		fl.count = (int *)ws_flag.p;
+		fl.query = fl.count + 4;
+		fl.val = (float *)(fl.query + nq);
+		fl.row = (int *)(fl.val + (size_t)nq * kflag);
+		MVS_HIP(hipMemsetAsync(fl.count, 0, sizeof(int), st));
+	} else {
+		launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
+	}
 	begin_kernel_timing(st);
 	for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
 		const int64_t m = std::min(qchunk, nq - q0);
 		launch_coarse_select(d_x + q0 * d, m, d, vecs, geom.dp, geom.pair_interleaved ? 1 : 0, ntotal, (const float *)ws_qn.p + q0, norms,
-		                     np, (float *)ws_q.p, (float *)ws_pd.p + q0 * np, (int32_t *)ws_pi.p + q0 * np, st);
+		                     kk, ip ? 0 : 1, (float *)ws_q.p, (float *)ws_pd.p + q0 * kk, (int32_t *)ws_pi.p + q0 * kk, st);
 	}
 	end_kernel_timing(st);
-	launch_merge_partials(METRIC_L2, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, 1, nq, np, nullptr, label_offset, d_D, d_I, st);
+	launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, 1, nq, kk, nullptr, label_offset, d_D, d_I, st, np,
+	                      ip ? &fl : nullptr);
+	if (ip) {
+		SelectorDev nosel;
+		memset(&nosel, 0, sizeof nosel);
+		resolve_ip_ties(nq, d_x, np, fl, nosel, nullptr, d_D, d_I, st);
+	}
 	return true;
 }
 

@@ -458,7 +458,8 @@ def test_l2_coarse_filter_non_finite_queries_fall_back(mf):
 
 @pytest.mark.parametrize("nlist,nprobe,d,nq", [(256, 32, 128, 300), (1000, 7, 100, 77), (4096, 32, 64, 500), (512, 255, 32, 64),
                                                (2048, 1, 128, 20), (8192, 64, 16, 130)])
-def test_coarse_quantiser_by_distance_matrix(mf, nlist, nprobe, d, nq):
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_coarse_quantiser_by_distance_matrix(mf, metric, nlist, nprobe, d, nq):
     """IVF coarse quantisation over a few thousand centroids (csrc/coarse_select.hip): the whole [nq][nlist] distance matrix in
     the BLAS-branch arithmetic + one wavefront per query selecting the nprobe smallest (dis, id).  Same probes, same order as the
     k-list kernels (option ivf_coarse_select = 0) and as the oracle -- checked through the final result of the IVF search, with
@@ -473,19 +474,23 @@ def test_coarse_quantiser_by_distance_matrix(mf, nlist, nprobe, d, nq):
     xq = _clustered(nq, d, nlist + 1)
     xq[: nq // 4] = cent[rs.randint(0, nlist, nq // 4)]  # distance 0 to a (possibly duplicated) centroid
     xq[nq // 2, 0] = np.nan
-    g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
     g.ivf_set_centroids(cent)
     g.add(xb)
     D1, I1 = g.search(xq, 10, nprobe=nprobe)
     g.set_option("ivf_coarse_select", 0)
     D0, I0 = g.search(xq, 10, nprobe=nprobe)
     g.set_option("ivf_coarse_select", 1)
+    # (inner product: boundary ties between duplicate centroids follow FAISS's CMin heap through resolve_ip_ties on both paths)
     assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
-    o = orc.Index(d, f"IVF{nlist},Flat", L2)
+    o = orc.Index(d, f"IVF{nlist},Flat", metric)
     o.ivf_set_centroids(cent)
     o.add(xb)
     m = min(nq, 96)
     Do, Io = o.search(xq[:m], 10, nprobe=nprobe)
     assert np.array_equal(D1[:m].view(np.uint32), Do.view(np.uint32))
-    ok = np.ones_like(Io, dtype=bool)  # labels wherever a distance is unique within its list (duplicated rows do not occur)
+    ok = np.ones_like(Io, dtype=bool)
+    if metric == IP:  # (equal scores inside a result list: FAISS's order depends on the probe order; tests above)
+        ok[:, 1:] &= Do[:, 1:] != Do[:, :-1]
+        ok[:, :-1] &= Do[:, 1:] != Do[:, :-1]
     assert np.array_equal(I1[:m][ok], Io[ok])
