@@ -119,18 +119,12 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 #pragma unroll
 	for (int it = 0; it < PL / 4; ++it) {
 		const int c = 4 * (64 * it + lane);
-		const float pad = __uint_as_float(0x7fc00000u); // NaN: never a candidate, whatever the metric
-		float4 v = make_float4(pad, pad, pad, pad);
-		if (c + 3 < nlist) {
-			v = *(const float4 *)(row + c);
-		} else {
-			if (c < nlist)
-				v.x = row[c];
-			if (c + 1 < nlist)
-				v.y = row[c + 1];
-			if (c + 2 < nlist)
-				v.z = row[c + 2];
-		}
+		// (nlist is a multiple of 4: a group of four is inside the row or past its end.  The address is clamped so that the loads of
+		// a lane are issued back to back -- behind branches they were 16 serial round trips; past the end: NaN, never a candidate)
+		const bool in = c < nlist;
+		float4 v = *(const float4 *)(row + (in ? c : 0));
+		const float pad = __uint_as_float(0x7fc00000u);
+		v.x = in ? v.x : pad, v.y = in ? v.y : pad, v.z = in ? v.z : pad, v.w = in ? v.w : pad;
 		const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
 		for (int e = 0; e < 4; ++e) {
