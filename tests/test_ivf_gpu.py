@@ -494,3 +494,28 @@ def test_coarse_quantiser_by_distance_matrix(mf, metric, nlist, nprobe, d, nq):
         ok[:, 1:] &= Do[:, 1:] != Do[:, :-1]
         ok[:, :-1] &= Do[:, 1:] != Do[:, :-1]
     assert np.array_equal(I1[:m][ok], Io[ok])
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_coarse_selection_when_one_lane_owns_the_nearest_centroids(mf, metric):
+    """The selection's fast path bounds the nprobe-th distance by the nprobe-th smallest LANE minimum; when the nearest centroids
+    all sit in one lane's ids (4 (64 i + lane) + e) that bound admits most of the row and the kernel falls back to the full
+    bitwise search (csrc/coarse_select.hip).  Same result either way."""
+    rs = np.random.RandomState(4)
+    d, nlist, nprobe, nq = 32, 4096, 40, 60
+    sign = 1.0 if metric == L2 else -1.0
+    cent = (rs.rand(nlist, d) + 50.0 * sign).astype(np.float32)  # far (L2) / low score (inner product)
+    near = np.array([4 * 64 * i + e for i in range(16) for e in range(4)])  # the 64 ids lane 0 holds
+    cent[near] = (rs.rand(64, d) * 0.1).astype(np.float32) * (1.0 if metric == L2 else 30.0)
+    xb = np.concatenate([cent[near] + rs.rand(64, d).astype(np.float32) * 0.01 for _ in range(40)] +
+                        [cent[rs.randint(0, nlist, 3000)] + rs.rand(3000, d).astype(np.float32) * 0.01]).astype(np.float32)
+    xq = (rs.rand(nq, d) * 0.1).astype(np.float32)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    g.ivf_set_centroids(cent)
+    g.add(xb)
+    D1, I1 = g.search(xq, 10, nprobe=nprobe)
+    g.set_option("ivf_coarse_select", 0)
+    D0, I0 = g.search(xq, 10, nprobe=nprobe)
+    g.set_option("ivf_coarse_select", 1)
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
+    assert (I1 >= 0).all() and (I1 < 2560).mean() > 0.9  # the rows around the near centroids
