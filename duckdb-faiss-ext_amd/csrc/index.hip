@@ -1810,6 +1810,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_ksplit_waves = v == 4 ? 4 : 8;
 		return true;
 	}
+	if (!strcmp(key, "ivf_cl_refresh")) { // IVF coarse filter: tiles (32 rows) between two refreshes of a wave's bounds (0 = 1,1,1,1,4.. 16)
+		g_ivf_cl_refresh = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "ivf_coarse_select")) { // IVF coarse quantiser: distance matrix + selection (1) or the k-list kernels (0)
 		g_coarse_select = v != 0;
 		return true;

@@ -35,6 +35,7 @@ typedef __attribute__((address_space(1))) const float glb_f32i;
 constexpr int IC_BN = 32;    // rows per tile
 constexpr int IC_QCAP = 256; // candidate queue of a work item (entries of 8 bytes)
 
+int g_ivf_cl_refresh = 16; // option ivf_cl_refresh (see IvfCollectArgs::refresh)
 struct IvfCollectArgs {
 	const int4 *items;         // {row_begin (multiple of 64, padded row space), row_end, qoff, nq_item <= 128}
 	const int *nitems_dev;     // device-side item count; the grid is an upper bound
@@ -51,6 +52,7 @@ struct IvfCollectArgs {
 	int kk;
 	int seg_rows; // rows per block: grid.y walks a list in segments (one wavefront per segment: long lists do not set the pace)
 	int collect;  // 0: bound estimation only (publish to the slots, append nothing)
+	int refresh;  // tiles between two refreshes of the bounds after the first (option ivf_cl_refresh; 0: 1, 1, 1, 1, 4, 4 ... 16)
 	const unsigned *rowmask; // IDSelector active: bit r of word w = padded row 32 w + r is accepted (nullptr: no selector)
 };
 
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 
 	for (int u = 0; u < ntiles; ++u) {
 		// bounds of the 128 slots: B = the kk-th best of the query's 16 class bests (bitonic network), table entry = B - 2E
-		const int period = u < 4 ? 1 : (u < 32 ? 4 : 16);
+		const int period = a.refresh > 0 ? a.refresh : (u < 4 ? 1 : (u < 32 ? 4 : 16));
 		if ((u % period) == 0) {
 			unsigned long long w[2][8];
 #pragma unroll
@@ -518,6 +520,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.kk = kk;
 	a.seg_rows = seg_rows;
 	a.collect = collect;
+	a.refresh = g_ivf_cl_refresh;
 	a.rowmask = d_rowmask;
 	hipLaunchKernelGGL(ivf_bf16_collect_kernel, dim3(max_items, nseg), dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
