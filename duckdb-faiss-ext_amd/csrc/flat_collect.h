@@ -30,7 +30,8 @@ struct CollectArgs {
 	long long n, row_first, split_rows;
 	int nq, nqb, nsplit, xcd_map;
 	int opt; // A/B bits (option cl_ksplit_opt): 0 = k-split kernel with 8 waves: s_setprio skew between the two waves of a SIMD;
-	         // 1 = wide kernels: bound refresh cadence counted in staged blocks instead of rows
+	         // 1 = wide kernels: bound refresh cadence counted in staged blocks instead of rows; 2..3 = d <= 128 kernel: refresh cadence
+	         // (0: every 8 / 32 / 128 staged blocks, 1: 4 / 16 / 64, 2: 16 / 64 / 256, 3: 32 / 128 / 512)
 };
 
 // csrc/flat_collect_wide.hip

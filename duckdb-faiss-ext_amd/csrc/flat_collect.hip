@@ -447,7 +447,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	for (int u = 0; u < ntiles; ++u) {
 		// Shared bound: every `period` tiles the lane fetches the 16 class slots of the two column blocks it owns and WAITS for
 		// them (one L2 round trip; the accumulators are dead here, so the transient registers are free).
-		const int period = u < 4 ? 1 : (u < 32 ? 4 : (u < 256 ? 16 : 64)); // (in staged blocks of CL_SUB tiles)
+		// (cadence 1, 1, 1, 1, then every 8 / 32 / 128 staged blocks: twice as sparse as first tuned, +1 % at the headline and at C2;
+		// A/B: option cl_ksplit_opt bits 2..3: 1 = the old cadence, 2 / 3 = sparser still)
+		const int pb = (a.opt >> 2) & 3, psh = pb == 1 ? 0 : (pb == 0 ? 1 : pb);
+		const int period = u < 4 ? 1 : (u < 32 ? 4 << psh : (u < 256 ? 16 << psh : 64 << psh)); // (in staged blocks of CL_SUB tiles)
 		if ((u % period) == 0) {
 			// B = the kk-th best of the 16 class bests (kk distinct rows are at least that good): as keys, the kk-th smallest
 			// (bitonic network in registers).  The pass bound B - 2E goes to the wave's table in LDS.
@@ -760,6 +763,7 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.nclass = kk;
 	a.nq = (int)nq;
 	a.rowmask = d_rowmask;
+	a.opt = g_ksplit_opt;
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
 	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	const int dp1 = collect_store_dims(g.d);
@@ -790,6 +794,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.stream_cnt = d_stream_cnt;
 	a.stream_cap = stream_cap;
 	a.rowmask = d_rowmask;
+	a.opt = g_ksplit_opt;
 	const int dp1 = collect_store_dims(g.d);
 	const int qblock = dp1 > 128 ? collect_wide_qblock(dp1) : CL_QBLOCK;
 	const int nqb = (int)((nq + qblock - 1) / qblock);
