@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 	for (int u = 0; u < nblocks; ++u) {
 		// (the cadence of flat_collect.hip -- every 64, 256, 1024, 4096 rows -- in staged blocks of WSUB * 16 rows)
 		constexpr int PS = 64 / (WSUB * RT) > 0 ? 64 / (WSUB * RT) : 1;
+		const int pb = (a.opt >> 2) & 3, psh = pb == 1 ? 0 : (pb == 0 ? 1 : pb); // (as in flat_collect.hip: bits 2..3 of cl_ksplit_opt)
 		const int period = a.opt & 2 ? (u < 4 ? 1 : (u < 32 ? 4 : (u < 256 ? 16 : 64)))
-		                             : (u < 4 * PS ? PS : (u < 32 * PS ? 4 * PS : (u < 256 * PS ? 16 * PS : 64 * PS)));
+		                             : (u < 4 * PS ? PS : (u < 32 * PS ? (4 * PS) << psh : (u < 256 * PS ? (16 * PS) << psh : (64 * PS) << psh)));
 		if ((u % period) == 0) {
 			// B = the kk-th best of the 16 class bests (bitonic network in registers); lane (hq, c) owns the two column blocks of
 			// query tile t = hq (hq < QT); the pass bound B - 2E goes to the wave's table in LDS
