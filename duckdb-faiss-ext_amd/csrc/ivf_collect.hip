@@ -555,7 +555,24 @@ __global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long lon
 	const float *y = rows + lane * pitch;
 	const float *xq = x + q * d;
 	float acc = 0.f;
-	for (int kk = 0; kk < d; ++kk) {
+	int kk = 0;
+	if ((d & 3) == 0) { // 16-byte loads of the query and of the staged row; the chain keeps its k order
+		for (; kk < d; kk += 4) {
+			const float4 xv = *(const float4 *)(xq + kk);
+			const float4 yv = *(const float4 *)(y + kk);
+			const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				if (IS_L2) {
+					const float t = __fsub_rn(xs[e], ys[e]);
+					acc = fmaf(t, t, acc);
+				} else {
+					acc = fmaf(xs[e], ys[e], acc);
+				}
+			}
+		}
+	}
+	for (; kk < d; ++kk) {
 		if (IS_L2) {
 			const float t = __fsub_rn(xq[kk], y[kk]);
 			acc = fmaf(t, t, acc);
