@@ -145,7 +145,28 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		return;
 	const int4 it = items[blockIdx.x];
 	const int l = list_of_blk64[it.x >> 6]; // every list starts at a multiple of 64 rows
-	const float *c = cent + (size_t)l * d;
+	// the item's query rows and its centroid pass through LDS once (coalesced 16-byte loads when d % 4 == 0): both halves below
+	// walk them element by element -- from global memory that was one dependent, uncoalesced load per element
+	extern __shared__ __attribute__((aligned(16))) float pk_lds[]; // [128][d + 1] query rows, then [d] the centroid
+	const int xp = d + 1;
+	float *xs = pk_lds, *c = pk_lds + 128 * xp;
+	if ((d & 3) == 0) {
+		const int cpr = d >> 2;
+		for (int i = threadIdx.x; i < it.w * cpr; i += 256) {
+			const int slot = i / cpr, ch = i - slot * cpr;
+			const float4 v = *(const float4 *)(x + (size_t)qidx[it.z + slot] * d + 4 * ch);
+			float *o = xs + slot * xp + 4 * ch;
+			o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+		}
+	} else {
+		for (int i = threadIdx.x; i < it.w * d; i += 256) {
+			const int slot = i / d, kk = i - slot * d;
+			xs[slot * xp + kk] = x[(size_t)qidx[it.z + slot] * d + kk];
+		}
+	}
+	for (int i = threadIdx.x; i < d; i += 256)
+		c[i] = cent[(size_t)l * d + i];
+	__syncthreads();
 	bf16x8i *dst = xi + (size_t)blockIdx.x * (8 * 4 * 64);
 	for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) { // (column block, k-block, lane)
 		const int lane = i & 63, kb = (i >> 6) & 3, cb = i >> 8;
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 			const int kk = kb * 32 + 8 * (lane >> 4) + e;
 			float o = 0.f;
 			if (slot < it.w && kk < d) {
-				const float xv = x[(size_t)qidx[it.z + slot] * d + kk];
+				const float xv = xs[slot * xp + kk];
 				o = IS_L2 ? 2.0f * __fsub_rn(xv, c[kk]) : xv;
 			}
 			v[e] = (__bf16)o;
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 			const int q = qidx[it.z + slot];
 			float xn = 0.f, cn = 0.f, xc = 0.f; // ||x'||^2 (L2) or ||x||^2 (IP); ||c||^2; <x, c>
 			for (int kk = 0; kk < d; ++kk) {
-				const float xv = x[(size_t)q * d + kk];
+				const float xv = xs[slot * xp + kk];
 				const float r = IS_L2 ? __fsub_rn(xv, c[kk]) : xv;
 				xn = fmaf(r, r, xn);
 				cn = fmaf(c[kk], c[kk], cn);
@@ -206,12 +227,18 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
                              float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st) {
 	if (max_items <= 0)
 		return;
-	if (metric == METRIC_L2)
-		hipLaunchKernelGGL(ivf_collect_pack_kernel<true>, dim3(max_items), dim3(256), 0, st, d_x, d, (const int4 *)d_items,
-		                   d_nitems, d_qidx, d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
-	else
-		hipLaunchKernelGGL(ivf_collect_pack_kernel<false>, dim3(max_items), dim3(256), 0, st, d_x, d, (const int4 *)d_items,
-		                   d_nitems, d_qidx, d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+	const size_t lds = ((size_t)128 * (d + 1) + d) * sizeof(float); // 66.5 KB at d = 128: two workgroups per CU
+	if (metric == METRIC_L2) {
+		auto kern = ivf_collect_pack_kernel<true>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
+		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+	} else {
+		auto kern = ivf_collect_pack_kernel<false>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
+		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+	}
 	MVS_HIP(hipGetLastError());
 }
 
