@@ -4,7 +4,7 @@
 // knn_L2sqr / knn_inner_product), same results bit for bit -- but the N x nq contraction, 99 % of the work, runs on the
 // bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16x the f32 MFMA rate per instruction-cycle) instead of the f32 one:
 //
-//   1. every f32 value is split x = hi + lo + r, hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x| (rows once, at the first
+//   1. every f32 value is split x = hi + lo + r, hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x| (rows once, at the first
 //      search after an add; queries per call);  <x,y> ~ <xh,yh> + <xh,yl> + <xl,yh>: three bf16 MFMAs per 16 dimensions,
 //      f32 accumulation.  |approx - exact chain| <= E = c(d) ||x|| ||y||, c(d) derived in prefilter_cerr() below.
 //   2. the fused epilogue of flat_mfma.hip (shared code, flat_fused.h) keeps, per query, the k' = k + margin best
@@ -42,8 +42,8 @@ constexpr int PF_SLOT_PERIOD = 32; // tiles between two reads of the shared thre
 // ---- error model ---------------------------------------------------------------------------------------------------
 // With S = sum |x_i y_i| <= ||x|| ||y|| (Cauchy-Schwarz) and u = 2^-24:
 //   exact chain (oracle / f32 MFMA, d sequential fmas):      |chain - <x,y>| <= d u S
-//   split x = xh + xl + xr, xh = bf16(x), xl = bf16(x - xh):  |x - xh| <= 2^-9 |x|, |xr| <= 2^-18 |x| (x - xh is exact in f32);
-//        dropped terms xl yl + xr y + x yr - xr yr:           <= 3.01 * 2^-18 S
+//   split x = xh + xl + xr, xh = bf16(x), xl = bf16(x - xh):  |x - xh| <= 2^-8 |x|, |xr| <= 2^-16 |x| (x - xh is exact in f32);
+//        dropped terms xl yl + xr y + x yr - xr yr:           <= 3.01 * 2^-16 S   (bf16 = 8 significant bits: unit roundoff 2^-8)
 //   bf16 MFMA: the 16 products of an instruction are exact in f32 (8 x 8 significant bits); the instruction returns
 //        C + their sum in f32.  Its internal alignment / rounding is not documented, so it is modelled as 4 ulp-units (two
 //        bits worse than one correctly rounded addition) of the magnitudes involved, per instruction:
@@ -53,7 +53,7 @@ constexpr int PF_SLOT_PERIOD = 32; // tiles between two reads of the shared thre
 //   rescore_verify_kernel needs an upper bound, not a tight one: a query it cannot prove is re-run on the exact kernel.
 float prefilter_cerr(int d) {
 	const double u = std::ldexp(1.0, -24);
-	const double split = 3.01 * std::ldexp(1.0, -18);
+	const double split = 3.01 * std::ldexp(1.0, -16);
 	const double mfma = (3.0 * d / 16.0) * 4.0 * u * (1.0 + 1.0 / 256);
 	const double chain = (double)d * u;
 	return (float)(1.25 * (split + mfma + chain));

@@ -215,11 +215,12 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
 // ---- error bound ---------------------------------------------------------------------------------------------------
 // u = 2^-24.  Primed quantities are centred (x' = fl(x - mu), y' = fl(y - mu)); S' = ||x'|| ||y'||_max >= sum |x'_i y'_i|
 // (Cauchy-Schwarz), S = ||x|| ||y||_max; every norm is inflated by 1e-4 for its own rounding.
-//   bf16 rounding of both operands: |x'_i y'_i - bf(x'_i) bf(y'_i)| <= (2 * 2^-9 + 2^-18) |x'_i y'_i|  -> (2^-8 + 2^-18) S'
+//   bf16 rounding of both operands: |x'_i y'_i - bf(x'_i) bf(y'_i)| <= (2 * 2^-8 + 2^-16) |x'_i y'_i|  -> (2^-7 + 2^-16) S'
+//   (bf16 keeps 8 significant bits: round-to-nearest errs by up to 2^-8 |v| per operand)
 //   bf16 MFMA accumulation, the chain starting at C = beta (undocumented internal rounding modelled as 4 ulp-units of the
 //   magnitudes per instruction, counted as d / 16 instructions, with a 1.25 safety factor as in flat_bf16.hip
-//   prefilter_cerr):                                                                      -> 1.25 (d/16) 4u ((1 + 2^-7) alpha S' + |beta|_max)
-//   => |s - (alpha <x', y'> + beta)| <= es = alpha (2^-8 + 2^-18) S' + that
+//   prefilter_cerr):                                                                      -> 1.25 (d/16) 4u ((1 + 2^-7 + 2^-16) alpha S' + |beta|_max)
+//   => |s - (alpha <x', y'> + beta)| <= es = alpha (2^-7 + 2^-16) S' + that
 //   centring: x', y' carry one rounding per component (<= u |.|), beta is a d-term f32 chain:
 //        L2: | ||x-y||^2 - (||x'||^2 + ||y'||^2 - 2<x',y'>) | <= 4u (xn' + yn'_max);  |beta + ||y'||^2| <= d u yn'_max
 //        IP: | <x,y> - (<x',y'> + <mu,y> + <x',mu>) | <= 4u S' + 2u ||mu|| ||y||_max;   |beta - <mu,y>| <= d u ||mu|| ||y||_max
@@ -250,8 +251,8 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
 	// s comes straight out of the MFMA chain: C starts at beta, the B operand carries alpha
 	const double al = IS_L2 ? 2.0 : 1.0;
 	const double bmax = IS_L2 ? (double)ync : MY; // >= |beta|
-	const double es = al * (0.00390625 + 3.814697265625e-06) * Sc +
-	                  1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * al * Sc + bmax);
+	const double es = al * (0.0078125 + 1.52587890625e-05) * Sc +
+	                  1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * al * Sc + bmax);
 	double E;
 	if (IS_L2)
 		E = es + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn) +

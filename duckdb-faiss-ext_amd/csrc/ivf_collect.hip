@@ -10,9 +10,10 @@
 //   work item   (list, <= 128 of the queries that probe it) = ONE wavefront; its queries enter as bf16(2 (x - c_list)) with
 //               gamma(slot) = -||x - c_list||^2, and the MFMA chain starts at C = beta(row) + gamma(slot):
 //               s = 2 <x', y'> - ||y'||^2 - ||x'||^2 = -||x - y||^2 (approximately), comparable across the lists of a query
-//   bound       |s - s_exact| <= E(slot) from ||x'||, the list's largest ||y'|| and d (ivf_collect_pack_kernel); the running
-//               bound B(q) = kk-th best of 16 row classes, shared by all items of the query through the class slots; every row
-//               with s >= B - 2E is a candidate (flat_collect.hip, "candidates")
+//   bound       |s - s_exact| <= E(slot) from ||x'||, the list's largest ||y'|| and d (ivf_collect_pack_kernel).  E differs
+//               between the lists a query probes, so the class slots (16 row classes per query, shared by all its items) hold
+//               LOWER bounds s - E(list) of distinct rows' exact values; B(q) = their kk-th best <= the exact kk-th value; a
+//               row of list l with s >= B - E(l) is a candidate (flat_collect.hip, "candidates", with per-list E)
 //   re-scoring  the candidates are grouped by query, recomputed with the scanner's arithmetic (t = x_k - y_k, acc = fmaf(t, t,
 //               acc), k ascending, on the ORIGINAL f32 rows) and the k best by (value, position in the list-sorted store)
 //               are kept -- the order of ivf_scan_kernel + merge_items_kernel.
@@ -123,7 +124,7 @@ void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int
 // ---- per item: query fragments, gamma, 2E ------------------------------------------------------------------------------
 // Error bound, in "s" units (s_exact = -D_oracle, the scanner's value), u = 2^-24, S' = ||x'|| ||y'||_max(list), norms inflated
 // by 1e-4 for their own rounding:
-//   bf16 rounding of both operands (the query operand carries the exact factor 2):        2 (2^-8 + 2^-18) S'
+//   bf16 rounding of both operands (the query operand carries the exact factor 2):        2 (2^-7 + 2^-16) S'
 //   MFMA accumulation from C = beta + gamma (4 ulp-units of the magnitudes per instruction, counted as d / 16 instructions,
 //   1.25 safety factor as in flat_collect.hip):                                            1.25 (d/16) 4u ((1 + 2^-7) 2 S' + xn' + yn'_max)
 //   C = fl(beta + gamma), beta and gamma d-term f32 chains:                               (d + 1) u (xn' + yn'_max)
@@ -131,7 +132,7 @@ void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int
 //   each residual:                                                                        (d + 8) u (||x'|| + ||y'||_max)^2
 //   E = the sum; e2 = 2 E (1 + 2^-10) + slack.  Non-finite -> NaN (the query is re-run on the scanner kernel).
 // Inner product (IS_L2 = false): the query enters as bf16(x) (not centred: <x, y> = <x, y'> + <x, c>), gamma = <x, c_list>, beta = 0;
-//   E = (2^-8 + 2^-18) S + 1.25 (d/16) 4u ((1 + 2^-7) S + |gamma|) + d u ||x|| ||c|| (gamma's chain) + u S (y' rounding)
+//   E = (2^-7 + 2^-16) S + 1.25 (d/16) 4u ((1 + 2^-7 + 2^-16) S + |gamma|) + d u ||x|| ||c|| (gamma's chain) + u S (y' rounding)
 //       + d u ||x|| (||c|| + ||y'||_max) (the scanner's chain over the original row),   S = ||x|| ||y'||_max(list)
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__restrict__ x, int d, const int4 *__restrict__ items,
@@ -203,11 +204,11 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 			const double nx = sqrt((double)xn * infl), ny = sqrt((double)yn * infl), nc = sqrt((double)cn * infl), S = nx * ny;
 			double E;
 			if (IS_L2)
-				E = 2.0 * (0.00390625 + 3.814697265625e-06) * S +
-				    1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * 2.0 * S + (double)xn + yn) +
+				E = 2.0 * (0.0078125 + 1.52587890625e-05) * S +
+				    1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * 2.0 * S + (double)xn + yn) +
 				    ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
 			else
-				E = (0.00390625 + 3.814697265625e-06) * S + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0078125) * S + nx * nc) +
+				E = (0.0078125 + 1.52587890625e-05) * S + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * S + nx * nc) +
 				    (double)d * u * nx * nc + u * S + ((double)d + 2.0) * u * nx * (nc + ny);
 			const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn + nx * nc) + 1e-30);
 			if (isfinite(xn) && isfinite(yn) && isfinite(r) && r < 1e30f)
@@ -245,17 +246,17 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
 // ---- the scan kernel: one wavefront per work item -----------------------------------------------------------------------
 // MFMA geometry, LDS layout of a tile, half-tile pipeline and rare path as flat_bf16_collect_kernel (csrc/flat_collect.hip);
 // what differs: the wave stages its own tiles (8 LDS-DMA instructions per 32-row tile), the chain starts at beta + gamma, the
-// bounds of the item's 128 slots live in an LDS table {B - 2E, gamma} that the wave refreshes itself.
+// bounds of the item's 128 slots live in an LDS table {B - E, gamma} that the wave refreshes itself.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollectArgs a) {
 	constexpr int KB = 4, PITCH = 256, TILE_BYTES = IC_BN * PITCH;
-	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 4 + 64) / 4];
+	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 8 + 64) / 4];
 	char *tbuf = (char *)smem;                                        // [2][TILE_BYTES]
 	float *nbuf = (float *)(tbuf + 2 * TILE_BYTES);                   // [2][64] beta of the tile's rows
 	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [IC_QCAP] candidate queue
-	float *ctab = (float *)(qbuf + IC_QCAP);                          // [4 t][16 c][2 i]{B - 2E, gamma}
-	int *qtab = (int *)(ctab + 128 * 2);                              // [128] query number of every slot
-	unsigned *qctl = (unsigned *)(qtab + 128);                        // [0] queue fill
+	float *ctab = (float *)(qbuf + IC_QCAP);                          // [4 t][16 c][2 i]{B_lower - E, gamma}
+	int *qtab = (int *)(ctab + 128 * 2);                              // [128]{query number, E (float bits)} of every slot
+	unsigned *qctl = (unsigned *)(qtab + 128 * 2);                    // [0] queue fill
 
 	if ((int)blockIdx.x >= *a.nitems_dev)
 		return;
@@ -277,8 +278,9 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	for (int i = 0; i < 2; ++i) {
 		const int slot = 32 * hq + 16 * i + c;
 		own_q[i] = slot < it.w ? a.qidx[it.z + slot] : -1;
-		own_e2[i] = a.ie2[(size_t)blockIdx.x * 128 + slot];
-		qtab[slot] = own_q[i];
+		own_e2[i] = 0.5f * a.ie2[(size_t)blockIdx.x * 128 + slot]; // E of THIS (query, list) pair (inflated, with slack)
+		qtab[2 * slot] = own_q[i];
+		qtab[2 * slot + 1] = __float_as_int(own_e2[i]);
 		ctab[((hq * 16 + c) * 2 + i) * 2 + 1] = a.igamma[(size_t)blockIdx.x * 128 + slot];
 	}
 
@@ -364,8 +366,10 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 			}
 			if (m == 0u)
 				continue;
-			int q;
-			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q) : "v"(qtab_lds + (unsigned)((32 * t + 16 * i + c) * 4)) : "memory");
+			int2 qe;
+			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qe) : "v"(qtab_lds + (unsigned)((32 * t + 16 * i + c) * 8)) : "memory");
+			const int q = qe.x;
+			const float eh = __int_as_float(qe.y);
 			while (m != 0u) {
 				const int j = __builtin_ctz(m);
 				m &= m - 1u;
@@ -374,7 +378,8 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 				const float v = (j & 2) ? hi : lo;
 				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
 				typedef __attribute__((address_space(1))) unsigned *GU;
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), ic_skey(v), __ATOMIC_RELAXED,
+				// the slots hold LOWER bounds s - E(list): E differs between the lists a query probes
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), ic_skey(v - eh), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
 				if (!a.collect)
 					continue;
@@ -401,7 +406,10 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	};
 
 	for (int u = 0; u < ntiles; ++u) {
-		// bounds of the 128 slots: B = the kk-th best of the query's 16 class bests (bitonic network), table entry = B - 2E
+		// bounds of the 128 slots: B = the kk-th best of the query's 16 class bests (bitonic network) -- each a LOWER bound
+		// s - E(its list) of a distinct row's exact value, so the exact kk-th best is >= B; a row of the result in THIS list has
+		// s >= exact - E >= B - E: table entry = B - E (E of this item's list).  With one E for all lists this is the B - 2E of
+		// csrc/flat_collect.hip.
 		const int period = a.refresh > 0 ? a.refresh : (u < 4 ? 1 : (u < 32 ? 4 : 16));
 		if ((u % period) == 0) {
 			unsigned long long w[2][8];
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		}
 
 		f32x4a acc[2][2]; // [row block][column block of the tile]
-		f32x4i cg[2];     // {B - 2E, gamma} x 2 column blocks of tile t in cg[t & 1]
+		f32x4i cg[2];     // {B - E, gamma} x 2 column blocks of tile t in cg[t & 1]
 		float mx0 = -INFINITY, mx1 = -INFINITY;
 		auto fold = [&](const f32x4a &p, int i) {
 			if (i == 0)

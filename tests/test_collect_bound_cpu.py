@@ -36,7 +36,7 @@ def flat_bound(metric_l2, x, mu, yn_max, ync_max, d):
     MY = np.sqrt(mun * infl) * np.sqrt(yn_max * infl)
     al = 2.0 if metric_l2 else 1.0
     bmax = ync_max if metric_l2 else MY
-    es = al * (2.0**-8 + 2.0**-18) * Sc + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 2.0**-7) * al * Sc + bmax)
+    es = al * (2.0**-7 + 2.0**-16) * Sc + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * al * Sc + bmax)
     if metric_l2:
         E = es + 4 * U * (xnc + ync_max) + d * U * ync_max + 2 * d * U * S + 4 * U * (xn + yn_max) + 2 * (d + 8) * U * (xn + yn_max)
     else:
@@ -74,6 +74,68 @@ def test_flat_bound_covers_the_emulated_coarse_value(metric_l2, kind):
             worst = max(worst, abs(s - s_exact) / E)
     assert worst < 0.9, worst  # below E with room: the Cauchy-Schwarz bf16 term dominates and is rarely tight
     assert worst > 1e-4  # ... and the rounding is exercised (not a vacuous check)
+
+
+@pytest.mark.parametrize("metric_l2", [True, False])
+def test_flat_bound_holds_at_bf16_rounding_ties(metric_l2):
+    """every component sits on a bf16 rounding midpoint (relative error 2^-8 per operand, the worst case) and the
+    row is collinear with the query (Cauchy-Schwarz tight).  With the unit roundoff taken as 2^-9 this came out at 1.98 E."""
+    d = 128
+    t = np.float32(1.0 + 2.0**-8)  # midway between the bf16 neighbours 1 and 1 + 2^-7: rounds to 1 (tie to even)
+    xb = np.concatenate([np.full((8, d), t), np.full((8, d), -t)]).astype(np.float32)  # mean row = 0
+    mu = xb.mean(0).astype(np.float32)
+    assert not mu.any()
+    yn_max = float((xb.astype(np.float64) ** 2).sum(1).max())
+    worst = 0.0
+    for sign in (1.0, -1.0):
+        x = np.full(d, sign * t, dtype=np.float32)
+        E = flat_bound(metric_l2, x, mu, yn_max, yn_max, d) / 2.0
+        bx = bf16(np.float32(2.0 if metric_l2 else 1.0) * x)
+        for r in (0, 8):
+            by = bf16(xb[r])
+            if metric_l2:
+                s = mfma_chain(bx, by, np.float32(-yn_max))
+                s_exact = float((x.astype(np.float64) ** 2).sum()) - float(((x.astype(np.float64) - xb[r]) ** 2).sum())
+            else:
+                s = mfma_chain(bx, by, np.float32(0.0))
+                s_exact = float((x.astype(np.float64) * xb[r]).sum())
+            worst = max(worst, abs(s - s_exact) / E)
+    assert 0.9 < worst <= 1.0, worst  # tight (the bound is attained up to its small terms) and not exceeded
+
+
+def ivf_bound(metric_l2, xn, yn, cn, d):
+    """E of ivf_collect_pack_kernel (csrc/ivf_collect.hip): xn = ||x - c||^2 (L2) or ||x||^2 (IP), yn = the list's largest
+    ||y - c||^2, cn = ||c||^2"""
+    infl = 1.0001
+    nx, ny, nc = np.sqrt(xn * infl), np.sqrt(yn * infl), np.sqrt(cn * infl)
+    S = nx * ny
+    if metric_l2:
+        return (2.0 * (2.0**-7 + 2.0**-16) * S + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * 2.0 * S + xn + yn)
+                + (d + 1.0) * U * (xn + yn) + (d + 8.0) * U * (nx + ny) ** 2)
+    return ((2.0**-7 + 2.0**-16) * S + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * S + nx * nc)
+            + d * U * nx * nc + U * S + (d + 2.0) * U * nx * (nc + ny))
+
+
+@pytest.mark.parametrize("metric_l2", [True, False])
+def test_ivf_bound_holds_at_bf16_rounding_ties(metric_l2):
+    """the same worst case on a residual list: c = 0, rows and query +-(1 + 2^-8) ones"""
+    d = 128
+    t = np.float32(1.0 + 2.0**-8)
+    n2 = float(d) * float(t) ** 2
+    E = ivf_bound(metric_l2, n2, n2, 0.0, d)
+    worst = 0.0
+    for sx in (1.0, -1.0):
+        x = np.full(d, sx * t, dtype=np.float32)
+        for sy in (1.0, -1.0):
+            y = np.full(d, sy * t, dtype=np.float32)
+            if metric_l2:  # chain from C = beta + gamma = -||y'||^2 - ||x'||^2: s ~ -||x - y||^2
+                s = mfma_chain(bf16(np.float32(2.0) * x), bf16(y), np.float32(np.float32(-n2) + np.float32(-n2)))
+                s_exact = -float(((x.astype(np.float64) - y) ** 2).sum())
+            else:
+                s = mfma_chain(bf16(x), bf16(y), np.float32(0.0))
+                s_exact = float((x.astype(np.float64) * y).sum())
+            worst = max(worst, abs(s - s_exact) / E)
+    assert 0.9 < worst <= 1.0, worst
 
 
 def test_bf16_emulation_is_round_to_nearest_even():
