@@ -212,7 +212,15 @@ void launch_ivf_select(int metric, const float *d_xq, int dp, const float *d_row
                        const IvfSelectPair *d_pairs, int npairs, const int *d_seg, int64_t nseg, int64_t total, int64_t k,
                        SelectorDev sel, const int64_t *d_idmap_sel, const int64_t *d_idmap_out, unsigned long long *keys_a,
                        unsigned long long *keys_b, void *d_temp, size_t temp_bytes, float *d_D, int64_t *d_I,
-                       hipStream_t st);
+                       hipStream_t st, bool raw_positions = false /* I = positions in d_rows instead of stored ids */);
+// csrc/ivf_ties.hip: FAISS's heap outcome under exact distance ties (arrival order = probe rank, then list position)
+void launch_ivf_mf_to_csr(int64_t *d_I, int64_t total, const int *d_perm_mf, hipStream_t st);
+void launch_ivf_finish(int metric, const float *d_pd, const int64_t *d_pi, int64_t nq, int kx, int k, const int64_t *d_rowids,
+                       const int64_t *d_idmap_out, float *d_D, int64_t *d_I, int *d_flag /* [1 + nq] */, hipStream_t st);
+void launch_ivf_tie_pass(int metric, const int *d_flag, int64_t nq, const float *d_x, int d, const float *d_pd, int kx, int k,
+                         const int64_t *d_coarse, int np, const int64_t *d_list_off, const float *d_codes, int dp,
+                         const int64_t *d_rowids, SelectorDev sel, const int64_t *d_idmap_sel, const int64_t *d_idmap_out,
+                         float *d_D, int64_t *d_I, hipStream_t st);
 // csrc/ivf_scan.hip: list-major scan without LDS staging (dp multiple of 16); same item / partial-list formats
 bool ivf_scan_supported(int dp, int64_t k);
 size_t ivf_scan_lds_bytes(int64_t k);

@@ -103,7 +103,7 @@ __global__ void ivf_emit_sorted_kernel(const float *pd1, const int *pi1, int kk,
 	const int j = (int)(i - q * k);
 	const int p = pi1[q * kk + j];
 	D[i] = pd1[q * kk + j];
-	I[i] = p >= 0 ? rowids[p] : -1;
+	I[i] = p >= 0 ? (rowids ? rowids[p] : (long long)p) : -1; // rowids == nullptr: the caller wants positions
 }
 // flagged queries -> list
 __global__ void ivf_compact_flags_kernel(const int *flags, int n, int *cnt, int *out) {
@@ -661,6 +661,33 @@ public:
 		// L2: it evaluates ||x||^2 + ||y||^2 - 2<x,y> (the Flat BLAS-branch arithmetic) instead of the scanner's
 		// sum (x-y)^2, i.e. the same neighbours up to rounding-level near-ties -> opt-in (option ivf_mfma = 1); the
 		// default keeps the scanner's arithmetic bit for bit.
+		// Exact distance ties (csrc/ivf_ties.hip): every path runs with ONE extra entry and emits (value, position in the
+		// list-sorted store) in its pure order; the finish kernel prints equal values by stored id and flags the queries tied
+		// at the k-th value, the tie pass replays FAISS's heap (arrival order = probe rank, then list position) for those.
+		if (exact_ties && !raw_pos && !(metric == METRIC_L2 && (mfma_mode == 1 || mfma_mode == 2)) && k < ((int64_t)1 << 14)) {
+			const int64_t kx = k + 1;
+			ws_tD.reserve((size_t)nq * kx * sizeof(float));
+			ws_tI.reserve((size_t)nq * kx * sizeof(int64_t));
+			ws_tflag.reserve((size_t)(nq + 16) * sizeof(int));
+			raw_pos = true;
+			reuse_coarse = true; // (the coarse assignment above)
+			try {
+				search_mapped(nq, d_x, kx, (float *)ws_tD.p, (int64_t *)ws_tI.p, params, d_idmap, stream);
+			} catch (...) {
+				raw_pos = reuse_coarse = false;
+				throw;
+			}
+			raw_pos = reuse_coarse = false;
+			const int64_t *idmap_out = (d_idmap && !raw_ids) ? d_idmap : nullptr;
+			launch_ivf_finish(metric, (const float *)ws_tD.p, (const int64_t *)ws_tI.p, nq, (int)kx, (int)k, (const int64_t *)rowids.p,
+			                  idmap_out, d_D, d_I, (int *)ws_tflag.p, stream);
+			SelectorDev tsel = selector.upload(params, stream);
+			launch_ivf_tie_pass(metric, (const int *)ws_tflag.p, nq, d_x, d, (const float *)ws_tD.p, (int)kx, (int)k,
+			                    (const int64_t *)ws_cI.p, (int)np, (const int64_t *)list_off_dev.p, (const float *)codes.p, dp,
+			                    (const int64_t *)rowids.p, tsel, d_idmap, idmap_out, d_D, d_I, stream);
+			stream_wait(st, stream);
+			return;
+		}
 		if (k > 256 || force_select) { // beyond the k-list kernels: all distances + segmented sort (csrc/ivf_select.hip)
 			select_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
 			return;
@@ -724,7 +751,7 @@ public:
 		                (unsigned *)ws_gslot.p, (float *)ws_xi.p, d_nitems, stream);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
-		                   k, (const int64_t *)rowids.p, raw_ids ? nullptr : d_idmap, d_D, d_I, stream);
+		                   k, raw_pos ? nullptr : (const int64_t *)rowids.p, (raw_ids || raw_pos) ? nullptr : d_idmap, d_D, d_I, stream);
 		snprintf(kinfo.name, sizeof kinfo.name, "ivf_scan_kernel");
 		kinfo.grid = max_items;
 		kinfo.block = 256;
@@ -793,7 +820,10 @@ public:
 		                       (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream, item_qn);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
-		                   k, (const int64_t *)rowids_mf.p, raw_ids ? nullptr : d_idmap, d_D, d_I, stream, G, shift);
+		                   k, raw_pos ? nullptr : (const int64_t *)rowids_mf.p, (raw_ids || raw_pos) ? nullptr : d_idmap, d_D, d_I, stream,
+		                   G, shift);
+		if (raw_pos) // positions in the padded MFMA store -> the list-sorted store
+			launch_ivf_mf_to_csr(d_I, nq * k, (const int *)perm_mf.p, stream);
 		snprintf(kinfo.name, sizeof kinfo.name, "ivf_mfma_scan (flat_mfma_resident_kernel items)");
 		kinfo.grid = max_items;
 		kinfo.block = 256;
@@ -914,13 +944,14 @@ public:
 		// (the selected lists are already in the scan kernels' order: value, then position -- inner product keeps it as
 		// merge_items_kernel does; the L2 merge of one split only translates the labels)
 		if (metric == METRIC_L2) {
-			launch_merge_partials(metric, pd1, pi1, 1, nq, kk, (const int64_t *)rowids.p, 0, d_D, d_I, stream, k, nullptr);
+			launch_merge_partials(metric, pd1, pi1, 1, nq, kk, raw_pos ? nullptr : (const int64_t *)rowids.p, 0, d_D, d_I, stream, k,
+			                      nullptr);
 		} else {
 			const long long tot = (long long)nq * k;
 			hipLaunchKernelGGL(ivf_emit_sorted_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, pd1, pi1, (int)kk,
-			                   (int)k, tot, (const long long *)rowids.p, d_D, (long long *)d_I);
+			                   (int)k, tot, raw_pos ? nullptr : (const long long *)rowids.p, d_D, (long long *)d_I);
 		}
-		if (d_idmap && !raw_ids) {
+		if (d_idmap && !raw_ids && !raw_pos) {
 			const long long tot = (long long)nq * k;
 			hipLaunchKernelGGL(ivf_map_labels_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
 			                   (long long *)d_I, tot, (const long long *)d_idmap);
@@ -943,9 +974,11 @@ public:
 			float *Df = (float *)((char *)ws_fb.p + xf_bytes);
 			int64_t *If = (int64_t *)((char *)Df + df_bytes);
 			launch_gather_query_rows(d_x, d, fail_q, nf, xf, stream);
-			DevBuf csub;
+			DevBuf csub, csave;
 			csub.reserve((size_t)nf * np * sizeof(int64_t));
+			csave.reserve((size_t)nf * np * sizeof(int64_t)); // the rows of ws_cI overwritten below (the tie pass reads them later)
 			launch_gather_query_rows((const float *)ws_cI.p, (int)(2 * np), fail_q, nf, (float *)csub.p, stream);
+			MVS_HIP(hipMemcpyAsync(csave.p, ws_cI.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
 			MVS_HIP(hipMemcpyAsync(ws_cI.p, csub.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
 			pf_suppressed = true;
 			reuse_coarse = true;
@@ -958,9 +991,11 @@ public:
 				timing_enabled = timing;
 				throw;
 			}
-			pf_suppressed = reuse_coarse = false;
+			pf_suppressed = false;
+			reuse_coarse = raw_pos; // (inside the exact-tie wrapper the batch's coarse assignment stays in force)
 			timing_enabled = timing;
-			MVS_HIP(hipStreamSynchronize(stream)); // csub is freed at scope exit
+			MVS_HIP(hipMemcpyAsync(ws_cI.p, csave.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+			MVS_HIP(hipStreamSynchronize(stream)); // csub / csave are freed at scope exit
 			launch_scatter_rows(fail_q, nf, k, Df, If, d_D, d_I, stream);
 			kinfo = keep;
 		}
@@ -1153,7 +1188,7 @@ public:
 			                    (float *)ws_pd.p, (int32_t *)ws_pi.p, (unsigned *)ws_gslot.p, stream);
 		end_kernel_timing(stream);
 		launch_merge_items(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, (const int *)ws_slots.p, (int)np, nq,
-		                   k, (const int64_t *)rowids.p, raw_ids ? nullptr : d_idmap, d_D, d_I, stream);
+		                   k, raw_pos ? nullptr : (const int64_t *)rowids.p, (raw_ids || raw_pos) ? nullptr : d_idmap, d_D, d_I, stream);
 		// the caller's stream continues after ours; pageable staging vectors die with this frame
 		MVS_HIP(hipStreamSynchronize(stream));
 		stream_wait(st, stream);
@@ -1228,8 +1263,8 @@ public:
 			begin_kernel_timing(stream);
 			launch_ivf_select(metric, (const float *)ws_q.p, dp, (const float *)codes.p, (const int64_t *)rowids.p,
 			                  (const IvfSelectPair *)ws_items.p, (int)pairs.size(), (const int *)ws_slots.p, nseg, total, k, sel,
-			                  d_idmap, raw_ids ? nullptr : d_idmap, (unsigned long long *)ws_pd.p,
-			                  (unsigned long long *)ws_pi.p, ws_xi.p, temp, d_D + q0 * k, d_I + q0 * k, stream);
+			                  d_idmap, (raw_ids || raw_pos) ? nullptr : d_idmap, (unsigned long long *)ws_pd.p,
+			                  (unsigned long long *)ws_pi.p, ws_xi.p, temp, d_D + q0 * k, d_I + q0 * k, stream, raw_pos);
 			end_kernel_timing(stream);
 			MVS_HIP(hipStreamSynchronize(stream)); // the pageable staging vectors are reused by the next chunk
 			bytes += (double)total * dp * 4.0;
@@ -1336,6 +1371,10 @@ public:
 			force_select = v != 0;
 			return true;
 		}
+		if (!strcmp(key, "ivf_exact_ties")) {
+			exact_ties = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_fast_scan")) { // 0 = the LDS-staged flat_direct item kernel
 			use_fast_scan = v != 0;
 			return true;
@@ -1343,6 +1382,8 @@ public:
 		return quantizer->set_option(key, v);
 	}
 	bool use_fast_scan = true;
+	bool exact_ties = true; // option ivf_exact_ties: 0 = the scan kernels' pure (value, position) order, no tie pass (diagnostics)
+	bool raw_pos = false;   // inside the exact-tie wrapper: the paths emit positions in the list-sorted store, no id map
 	bool force_select = false;
 	bool raw_ids = false;
 	int collect_mode = -1; // option ivf_collect: -1 auto, 0 never, 1 wherever the kernel exists (L2, d <= 128, k <= 16)
@@ -1377,7 +1418,7 @@ private:
 	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0;
-	DevBuf ws_cand, ws_ex, ws_fail, ws_fb;
+	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
 	int *h_fail = nullptr; // pinned
 	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel
 	bool reuse_coarse = false;

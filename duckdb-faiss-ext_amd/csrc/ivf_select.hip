@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void ivf_select_out_kernel(const unsigned long
 		if (key != EMPTY_KEY) {
 			const unsigned vk = (unsigned)(key >> 32);
 			v = key2f(IS_L2 ? vk : ~vk);
-			lab = rowids[(unsigned)key];
+			lab = rowids ? rowids[(unsigned)key] : (long long)(unsigned)key; // rowids == nullptr: positions
 			if (idmap)
 				lab = idmap[lab];
 		}
@@ -132,7 +132,7 @@ void launch_ivf_select(int metric, const float *d_xq, int dp, const float *d_row
                        const IvfSelectPair *d_pairs, int npairs, const int *d_seg, int64_t nseg, int64_t total, int64_t k,
                        SelectorDev sel, const int64_t *d_idmap_sel, const int64_t *d_idmap_out, unsigned long long *keys_a,
                        unsigned long long *keys_b, void *d_temp, size_t temp_bytes, float *d_D, int64_t *d_I,
-                       hipStream_t st) {
+                       hipStream_t st, bool raw_positions) {
 	const bool is_l2 = metric_order(metric) == METRIC_L2;
 	if (npairs > 0 && total > 0) {
 		const size_t lds = (size_t)dp * sizeof(float);
@@ -148,10 +148,10 @@ void launch_ivf_select(int metric, const float *d_xq, int dp, const float *d_row
 	}
 	if (is_l2)
 		hipLaunchKernelGGL(ivf_select_out_kernel<true>, dim3((unsigned)nseg), dim3(256), 0, st, keys_b, d_seg, (int)k,
-		                   (const long long *)d_rowids, (const long long *)d_idmap_out, d_D, (long long *)d_I);
+		                   raw_positions ? nullptr : (const long long *)d_rowids, (const long long *)d_idmap_out, d_D, (long long *)d_I);
 	else
 		hipLaunchKernelGGL(ivf_select_out_kernel<false>, dim3((unsigned)nseg), dim3(256), 0, st, keys_b, d_seg, (int)k,
-		                   (const long long *)d_rowids, (const long long *)d_idmap_out, d_D, (long long *)d_I);
+		                   raw_positions ? nullptr : (const long long *)d_rowids, (const long long *)d_idmap_out, d_D, (long long *)d_I);
 	MVS_HIP(hipGetLastError());
 }
 

@@ -133,15 +133,14 @@ def test_c3_ivf4096_10m_nprobe32(mf, torch):
     assert ix.last_kernel_info()["name"].startswith("ivf_bf16_collect")
     D, I = D.cpu().numpy(), I.cpu().numpy()
     _check_order_and_range(D, I, 0, n, True)
-    # ... and the scanner kernel on the same index gives the same distances on all 10k queries (labels: away from exact ties)
+    # ... and the scanner kernel on the same index gives the same distances and labels on all 10k queries
     ix.set_option("ivf_collect", 0)
     Ds, Is = ix.search_torch(xq, k, nprobe=nprobe)
     torch.cuda.synchronize()
     assert ix.last_kernel_info()["name"].startswith("ivf_scan_kernel")
     Ds, Is = Ds.cpu().numpy(), Is.cpu().numpy()
     assert np.array_equal(Ds.view(np.uint32), D.view(np.uint32))
-    distinct = np.array([len(np.unique(r)) == len(r) for r in D])
-    assert distinct.mean() > 0.95 and np.array_equal(Is[distinct], I[distinct])
+    assert np.array_equal(Is, I)  # labels on all 10k queries, exact ties included (csrc/ivf_ties.hip)
     ix.set_option("ivf_collect", -1)
     # oracle IVF sharing the trained centroids, 512 queries, bit-exact
     o = orc.Index(d, "IVF4096,Flat", L2)

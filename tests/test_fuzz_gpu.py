@@ -84,11 +84,9 @@ def test_ivf_fuzz(mf, seed):
     sel = _selector(rs, ids)
     D, I = g.search(xq, k, nprobe=nprobe, sel=sel)
     Do, Io = o.search(xq, k, nprobe=nprobe, sel=sel)
-    ok = np.array([len(np.unique(r[np.isfinite(r) & (np.abs(r) < 3e38)])) == (np.abs(r) < 3e38).sum() for r in Do])
     what = f"ivf seed={seed} d={d} nlist={nlist} n={n} nq={nq} k={k} nprobe={nprobe} metric={metric} sel={sel and sel[0]}"
-    assert ok.sum() >= 1, what
-    assert np.array_equal(I[ok], Io[ok]), what
-    assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32)), what
+    assert np.array_equal(I, Io), what  # every query: exact ties follow FAISS's heap (csrc/ivf_ties.hip)
+    assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), what
 
 
 @pytest.mark.parametrize("seed", range(10 * _SCALE))

@@ -1,7 +1,8 @@
 """IVFFlat on device vs the CPU oracle's restatement of IndexIVFFlat (no golden values exist in the reference for IVF
 results: parity unpinned by the reference).  Training assigns on the fused MFMA kernel and updates centroids in
 FAISS's summation order, so centroids are expected to be bit-identical to the oracle's; list scans use the per-pair
-arithmetic (IVFFlatScanner) and must match bit for bit away from exact distance ties."""
+arithmetic (IVFFlatScanner) and must match bit for bit, exact distance ties included (arrival order = probe rank, then list
+position; csrc/ivf_ties.hip)."""
 import numpy as np
 import pytest
 
@@ -23,7 +24,9 @@ def _clustered(n, d, seed, ncent=64, sigma=0.15):
 
 
 def _no_tie_rows(D):
-    """queries whose k results have pairwise distinct distances (tie order is probe-order dependent in FAISS)"""
+    """queries whose k results have pairwise distinct distances -- only the two opt-in L2 modes that evaluate the norms formula
+    instead of the scanner's arithmetic (ivf_mfma = 1 / 2) still need it; every default path reproduces FAISS's heap under
+    exact ties (csrc/ivf_ties.hip)"""
     return np.array([len(np.unique(r)) == len(r) for r in D])
 
 
@@ -70,7 +73,7 @@ def test_ivf_search_matches_oracle(mf, metric, nprobe, fast_scan):
     for k in (10, 40):  # 40: threshold classes wider than one 16-slot row
         Do, Io = o.search(xq, k, nprobe=nprobe)
         D, I = g.search(xq, k, nprobe=nprobe)
-        ok = _no_tie_rows(Do)
+        ok = np.ones(len(Do), dtype=bool)  # exact ties included (csrc/ivf_ties.hip)
         assert ok.sum() > 250
         assert np.array_equal(I[ok], Io[ok])
         assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
@@ -153,7 +156,7 @@ def test_ivf_with_hnsw_coarse_quantizer(mf, tmp_path, metric):
     for nprobe, efs in ((1, 0), (4, 16), (8, 64)):
         Do, Io = o.search(xq, 10, nprobe=nprobe, efSearch=efs)
         D, I = g.search(xq, 10, nprobe=nprobe, efSearch=efs)
-        ok = _no_tie_rows(Do)
+        ok = np.ones(len(Do), dtype=bool)  # exact ties included (csrc/ivf_ties.hip)
         assert ok.sum() > 150
         assert np.array_equal(I[ok], Io[ok]) and np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
     # write_index / read_index keep the graph of the quantizer
@@ -193,7 +196,7 @@ def test_ivf_inner_product_scans_on_the_mfma_kernel_bit_exact(mf, d, nlist):
         Do, Io = o.search(xq, k, nprobe=nprobe, sel=sel)
         D, I = g.search(xq, k, nprobe=nprobe, sel=sel)
         assert g.last_kernel_info()["name"].startswith("ivf_mfma_scan")
-        ok = _no_tie_rows(Do)
+        ok = np.ones(len(Do), dtype=bool)  # exact ties included (csrc/ivf_ties.hip)
         assert ok.sum() > 250
         assert np.array_equal(I[ok], Io[ok]), (nprobe, k, sel and sel[0])
         assert np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
@@ -201,7 +204,7 @@ def test_ivf_inner_product_scans_on_the_mfma_kernel_bit_exact(mf, d, nlist):
     D2, I2 = g.search(xq, 10, nprobe=4)
     assert g.last_kernel_info()["name"].startswith("ivf_scan_kernel")
     D1, I1 = o.search(xq, 10, nprobe=4)
-    ok = _no_tie_rows(D1)
+    ok = np.ones(len(D1), dtype=bool)  # exact ties included (csrc/ivf_ties.hip)
     assert np.array_equal(I2[ok], I1[ok])
 
 
@@ -243,7 +246,7 @@ def test_every_list_probed_large_nprobe_times_k(mf, metric):
     g.add(xb)
     D, I = g.search(xq, k, nprobe=nlist + 7)
     Do, Io = o.search(xq, k, nprobe=nlist + 7)
-    ok = _no_tie_rows(Do)
+    ok = np.ones(len(Do), dtype=bool)  # exact ties included (csrc/ivf_ties.hip)
     assert ok.sum() > 40
     assert np.array_equal(I[ok], Io[ok]) and np.array_equal(D[ok].view(np.uint32), Do[ok].view(np.uint32))
     Df, If = orc.flat_search(metric, xb, xq, k, force_path=orc.PATH_PAIR)
@@ -411,10 +414,7 @@ def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, npro
     D0, I0 = g.search(xq, k, nprobe=nprobe)
     assert g.last_kernel_info()["name"].startswith(("ivf_scan_kernel", "ivf_mfma_scan"))
     Do, Io = o.search(xq, k, nprobe=nprobe)
-    ok = _no_tie_rows(Do)
-    if metric == IP:  # ... and no tie ACROSS the k-th boundary either (FAISS keeps one of the two by probe order)
-        Dk1, _ = o.search(xq, k + 1, nprobe=nprobe)
-        ok &= Dk1[:, k - 1] != Dk1[:, k]
+    ok = np.ones(len(Do), dtype=bool)  # exact ties included (csrc/ivf_ties.hip)
     assert ok.sum() >= 1
     # (values of tied rows agree by definition, so whole distance rows agree; labels away from exact ties)
     assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)) and np.array_equal(D1.view(np.uint32), Do.view(np.uint32))
@@ -431,10 +431,7 @@ def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, npro
         Do2, Io2 = o.search(xq, k, nprobe=nprobe, sel=sel)
         assert np.isin(I2[I2 >= 0], keep).all()
         assert np.array_equal(D2.view(np.uint32), D3.view(np.uint32)) and np.array_equal(D2.view(np.uint32), Do2.view(np.uint32)), sel[0]
-        ok2 = _no_tie_rows(Do2)
-        if metric == IP:
-            Dk2, _ = o.search(xq, k + 1, nprobe=nprobe, sel=sel)
-            ok2 &= Dk2[:, k - 1] != Dk2[:, k]
+        ok2 = np.ones(len(Do2), dtype=bool)  # exact ties included (csrc/ivf_ties.hip)
         assert np.array_equal(I2[ok2], I3[ok2]) and np.array_equal(I2[ok2], Io2[ok2]), sel[0]
 
 
@@ -519,3 +516,77 @@ def test_coarse_selection_when_one_lane_owns_the_nearest_centroids(mf, metric):
     g.set_option("ivf_coarse_select", 1)
     assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32))
     assert (I1 >= 0).all() and (I1 < 2560).mean() > 0.9  # the rows around the near centroids
+
+
+def _tied_data(n, d, seed, metric):
+    """30 % duplicated rows on small-integer coordinates: most queries are tied at rank k, inside the result and across the
+    probed lists (inner product: integer scores collide all the time)"""
+    rs = np.random.RandomState(seed)
+    xb = rs.randint(-3, 4, size=(n, d)).astype(np.float32)
+    dup = rs.rand(n) < 0.3
+    xb[dup] = xb[rs.randint(0, n, size=int(dup.sum()))]
+    xq = rs.randint(-3, 4, size=(257, d)).astype(np.float32)
+    xq[:64] = xb[rs.randint(0, n, size=64)]  # queries ON rows: distance-0 ties among the copies
+    return xb, xq
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("desc", ["IVF16,Flat", "IDMap,IVF16,Flat"])
+@pytest.mark.parametrize("d", [32, 128, 200])
+def test_ivf_exact_ties_follow_the_heap(mf, metric, desc, d):
+    """duplicate-heavy IVF data, label-exact on EVERY query, every scan path (bf16 coarse filter, scanner
+    kernel, f32 MFMA items, k beyond the coarse filter, the all-distances path, selectors, < 20 queries)"""
+    n, nlist = 12000, 16
+    xb, xq = _tied_data(n, d, 77 + d, metric)
+    rs = np.random.RandomState(5)
+    ids = (rs.permutation(4 * n)[:n] + 3).astype(np.int64)  # stored ids NOT in arrival order: the heap compares (value, id)
+    o = orc.Index(d, desc, metric)
+    g = mf.index_factory(d, desc, metric)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    for a in (g, o):
+        for i0 in range(0, n, 5000):
+            a.add_with_ids(xb[i0 : i0 + 5000], ids[i0 : i0 + 5000])
+    keep = ids[rs.rand(n) < 0.5]
+    seen = set()
+    for opts, k, nprobe, sel, nq in (
+        ({}, 10, 4, None, 257),
+        ({}, 10, 16, None, 257),
+        ({}, 1, 3, None, 257),
+        ({"ivf_collect": 0}, 10, 4, None, 257),
+        ({"ivf_collect": 0, "ivf_mfma": 0}, 10, 5, None, 257),
+        ({}, 16, 4, None, 100),
+        ({}, 40, 8, None, 100),
+        ({}, 10, 4, ("batch", keep), 257),
+        ({"ivf_collect": 0}, 10, 4, ("batch", keep), 64),
+        ({}, 5, 6, None, 7),
+        ({"ivf_select": 1}, 10, 4, None, 64),
+        ({}, 300, 16, None, 33),
+    ):
+        for key, v in opts.items():
+            g.set_option(key, v)
+        D, I = g.search(xq[:nq], k, nprobe=nprobe, sel=sel)
+        seen.add(g.last_kernel_info()["name"].split(" ")[0])
+        for key in opts:
+            g.set_option(key, {"ivf_collect": -1, "ivf_mfma": -1, "ivf_select": 0}[key])
+        Do, Io = o.search(xq[:nq], k, nprobe=nprobe, sel=sel)
+        what = (opts, k, nprobe, sel and sel[0], nq)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), what
+        bad = np.flatnonzero((I != Io).any(axis=1))
+        assert bad.size == 0, (what, bad[:5], I[bad[:1]], Io[bad[:1]], D[bad[:1]])
+        if k == 10 and nprobe == 4 and sel is None and not opts:
+            Dk1, _ = o.search(xq[:nq], k + 1, nprobe=nprobe)
+            assert (Dk1[:, k - 1] == Dk1[:, k]).mean() > 0.2  # the boundary case is really exercised
+    assert len(seen) >= 3, seen
+
+
+def test_ivf_exact_ties_option_off_keeps_the_pure_order(mf):
+    """ivf_exact_ties = 0 (diagnostics): same values, the scan kernels' (value, position) order"""
+    xb, xq = _tied_data(6000, 32, 3, L2)
+    g = mf.index_factory(32, "IVF8,Flat", L2)
+    g.train(xb)
+    g.add(xb)
+    D1, I1 = g.search(xq, 10, nprobe=3)
+    g.set_option("ivf_exact_ties", 0)
+    D0, I0 = g.search(xq, 10, nprobe=3)
+    assert np.array_equal(D0, D1) and not np.array_equal(I0, I1)

@@ -166,3 +166,67 @@ def test_synth_generators_are_deterministic_and_windowed():
     c = orc.synth_clustered(200, 8, 7, n_centers=4, sigma=0.05)
     c2 = orc.synth_clustered(50, 8, 7, row0=150, n_centers=4, sigma=0.05)
     assert np.array_equal(c[150:], c2)
+
+
+def _heap_stream(is_max, k, vals, ids):
+    """FAISS's k-heap fed one (value, id) at a time with the strict insert rule, then heap_reorder (oracle/orc_core.c)"""
+    import ctypes as C
+
+    L = orc.lib()
+    hv = np.empty(k, dtype=np.float32)
+    hi = np.empty(k, dtype=np.int64)
+    pf, pi = hv.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p)
+    L.orc_heap_init.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_heap_replace_top.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int64]
+    L.orc_heap_reorder.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_heap_init(k, pf, pi, is_max)
+    for v, i in zip(vals, ids):
+        if (hv[0] > v) if is_max else (hv[0] < v):
+            L.orc_heap_replace_top(k, pf, pi, is_max, float(v), int(i))
+    L.orc_heap_reorder(k, pf, pi, is_max)
+    return hv, hi
+
+
+def _closed_form(is_max, k, vals, ids):
+    """what csrc/ivf_ties.hip computes: pure top-k by value, runs printed by id; at a boundary tie A_k = the first k arrivals
+    not worse than T, result = {better than T} + {tied rows of A_k minus the G extreme ids}"""
+    n = len(vals)
+    sgn = 1.0 if is_max else -1.0
+    key = sgn * vals  # smaller = better
+    order = np.lexsort((np.arange(n), key))  # pure order: (value, arrival position)
+    if n <= k:
+        sel = list(order)
+    else:
+        T = key[order[k - 1]]
+        if key[order[k]] != T:
+            sel = list(order[:k])
+        else:
+            A = [i for i in range(n) if key[i] <= T][:k]
+            better = [i for i in range(n) if key[i] < T]
+            G = len(better) - sum(1 for i in A if key[i] < T)
+            tied = sorted((i for i in A if key[i] == T), key=lambda i: ids[i])
+            tied = tied[: len(tied) - G] if is_max else tied[G:]
+            sel = better + tied
+    # print order: L2 (value asc, id asc); inner product (value desc, id desc)
+    sel.sort(key=lambda i: (key[i], ids[i] if is_max else -ids[i]))
+    hv = np.full(k, np.float32(3.4028234663852886e38 if is_max else -3.4028234663852886e38), dtype=np.float32)
+    hi = np.full(k, -1, dtype=np.int64)
+    hv[: len(sel)] = vals[sel]
+    hi[: len(sel)] = ids[sel]
+    return hv, hi
+
+
+@pytest.mark.parametrize("is_max", [1, 0])
+def test_ivf_tie_closed_form_equals_the_heap_in_any_arrival_order(is_max):
+    """IVF feeds the heap in probe order, not id order: the closed form the device implements (csrc/ivf_ties.hip) against
+    the oracle's heap replay on streams with few distinct values and ids unrelated to arrival order"""
+    rs = np.random.RandomState(11 + is_max)
+    for trial in range(400):
+        n = int(rs.choice([3, 8, 20, 60, 200]))
+        k = int(rs.choice([1, 2, 5, 10, 17]))
+        vals = rs.randint(0, int(rs.choice([2, 4, 12])), size=n).astype(np.float32)
+        ids = rs.permutation(5 * n)[:n].astype(np.int64)
+        hv, hi = _heap_stream(is_max, k, vals, ids)
+        cv, ci = _closed_form(is_max, k, vals, ids)
+        assert np.array_equal(hv, cv), (trial, n, k)
+        assert np.array_equal(hi, ci), (trial, n, k, vals, ids, hi, ci)
