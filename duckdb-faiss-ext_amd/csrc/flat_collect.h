@@ -43,6 +43,11 @@ size_t collect_wide_lds_bytes(int dp1);
 int collect_wide_block_rows(int dp1);
 void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,
                                int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out);
+// csrc/flat_collect_big.hip: 512 < d <= 1024, one wave per SIMD with all of k resident (512 registers per wave)
+extern int g_wide_big;
+int collect_big_qblock(int dp1);
+size_t collect_big_lds_bytes(int dp1);
+void launch_collect_big(int dp1, int metric, bool collect, const CollectArgs &a, int grid, hipStream_t st);
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
                               const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
                               unsigned *d_max_norm_bits, hipStream_t st);

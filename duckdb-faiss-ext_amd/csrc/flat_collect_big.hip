@@ -1,0 +1,404 @@
+// csrc/flat_collect_big.hip -- the bf16 coarse filter for 512 < d <= 1024 with ALL of k resident in ONE wave: one wavefront per
+// SIMD, 512 registers each.
+//
+// Same argument, bound, candidate stream and re-scoring as flat_collect.hip / flat_collect_wide.hip; only the geometry of the scan
+// differs.  flat_bf16_ksplit_kernel splits k over a wave pair because 32 queries x 24 k-blocks = 192 VGPRs of query fragments do
+// not fit next to the rest in 256 registers at two waves per SIMD; every A fragment read from LDS then feeds only 2-3 MFMAs, the
+// pair hands partial sums over through LDS behind a workgroup barrier per 16-row tile, and the matrix pipe is 36 % busy (VERDICT
+// r2 weak #4: the kernel is LDS-read-bound).  A gfx950 wave that runs alone on its SIMD owns 512 registers (256 VGPRs + 256
+// AGPRs, one unified file; the MFMA reads its A / B operands from either half), so here
+//   wave        NCB column blocks of 16 queries x KBT k-blocks of query fragments RESIDENT: 4 x 24 x 4 = 384 registers at the
+//               768-dim store (64 queries per wave), 3 x 32 x 4 = 384 at the 1024-dim store (48 queries); no k split, no
+//               hand-over, each ds_read_b128 of an A fragment feeds NCB MFMAs (64 matrix-pipe cycles at NCB = 4).
+//               hipcc's MFMA builtin only takes its A / B operands from VGPRs and treats AGPRs as spill space (the first
+//               version of this kernel spent 4 v_accvgpr_read per MFMA on half of its fragments), so the 60 fragments placed
+//               in AGPRs are consumed by hand-written v_mfma instructions with an AGPR srcB ("a" constraint); the other 36
+//               stay with the builtin.  The hand-written ones are invisible to the compiler's hazard recognizer: every
+//               accumulator is written once per NCB MFMAs (>= 48 cycles apart) and read by the vector ALU only behind a
+//               scheduling barrier one tile later (or behind explicit s_nops after the last tile).
+//   workgroup   4 waves = one per SIMD, one workgroup per CU: 256 (192) queries share every tile the CU stages
+//   tiles       16 rows x (64 KBT) bytes, a ring of three stages filled by LDS-DMA two tiles ahead; ONE barrier per tile whose
+//               s_waitcnt counts the newest tile's loads, so two tiles stay in flight across it
+//   epilogue    running maxima + bound test of tile u - 1 run on the vector ALU behind the first MFMAs of tile u (two
+//               accumulator sets, the tile loop unrolled by two): a lone wave has nobody else to fill its matrix pipe
+#include "flat_collect.h"
+
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+
+namespace mvs {
+
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+
+int g_wide_big = 1; // option cl_wide_big: 512 < d <= 1024 on flat_bf16_big_kernel (1) or on the k-split kernel (0)
+
+template <int KBT, int NCB, bool IS_L2, bool COLLECT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_bf16_big_kernel(const CollectArgs a) {
+	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
+	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB (768 dims) / 32 KB (1024)
+	constexpr int NST = 3;
+	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096;
+	constexpr int QW = 16 * NCB, QB = 4 * QW;
+	constexpr int RA = 4, RING = 8; // A fragments read RA k-blocks ahead into a ring of RING register quads
+	constexpr int FLUSH_EVERY = 8;
+	static_assert(STAGE_BYTES % 4096 == 0 && KBT % 4 == 0 && NCB >= 2 && NCB <= 4 && RA < RING, "geometry");
+
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	char *tbuf = (char *)smem;                                          // [NST][STAGE_BYTES]
+	float *nbuf = (float *)(tbuf + NST * STAGE_BYTES);                  // [NST][64] beta of the staged rows (16 used)
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + NST * 64); // [CL_QCAP] candidate queue
+	float *cqtab = (float *)(qbuf + CL_QCAP);                           // [4 waves][16 c][4]: pass bound of column block i, query c
+	unsigned *qctl = (unsigned *)(cqtab + 4 * 16 * 4);                  // [0] queue fill, [2..3] flush base
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int hq = lane >> 4, c = lane & 15;
+	int split, qb;
+	if (a.xcd_map) {
+		const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+		split = (idx / a.nqb) * 8 + xcd;
+		qb = idx % a.nqb;
+	} else {
+		split = blockIdx.x / a.nqb;
+		qb = blockIdx.x % a.nqb;
+	}
+	const long long r_begin = a.row_first + (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int nblocks = r_end > r_begin ? (int)((r_end - r_begin + RT - 1) / RT) : 0;
+	if (tid == 0)
+		qctl[0] = 0u;
+	const int qw = qb * QB + wave * QW;
+
+	// B fragments, resident for the whole scan: fragment f = cb * KBT + kb lives in an AGPR quad when f >= NV (the last NAG
+	// = 60 fragments: 240 of the 256 AGPRs), in VGPRs otherwise (36 fragments = 144 VGPRs)
+	constexpr int NAG = 60, NV = NCB * KBT - NAG;
+	static_assert(NV > 0 && NV * 4 <= 160, "VGPR-resident fragments");
+	bf16x8 bqv[NV], bqa[NAG];
+	{
+		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
+#pragma unroll
+		for (int cb = 0; cb < NCB; ++cb) {
+			const size_t qblk16 = (size_t)qb * (QB / 16) + wave * NCB + cb;
+#pragma unroll
+			for (int kb = 0; kb < KBT; ++kb) {
+				const int f = cb * KBT + kb;
+				const bf16x8 t = qsrc[(qblk16 * KBT + kb) * 64 + lane];
+				if (f < NV) {
+					bqv[f] = t;
+				} else {
+					bqa[f - NV] = t;
+					asm volatile("" : "+a"(bqa[f - NV])); // into its AGPR quad now; every later use asks for "a"
+				}
+			}
+		}
+	}
+
+	// LDS-DMA (as flat_collect_wide.hip): instruction inst = 4 i + wave fills LDS bytes [1024 inst, +1024) of the stage; lane l owns
+	// 16-byte slot S = 64 inst + l = (row r = S / C, position p = S % C) and fetches chunk (p & ~15) | ((p & 15) ^ (r & 15))
+	auto dma_block = [&](int u, int stg) {
+		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)u * RT) * PITCH; // uniform
+#pragma unroll
+		for (int i = 0; i < DMA_PER_WAVE; ++i) {
+			const int inst = 4 * i + wave;
+			const int S = 64 * inst + lane, r = S / C, p = S - r * C;
+			const unsigned off = (unsigned)(r * PITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + off), (lds_f32c *)(smem + (stg * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
+		}
+		if (wave == 0) {
+			const float *bb = a.yn + (r_begin + (long long)u * RT); // uniform
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (NST * STAGE_BYTES) / 4 + stg * 64), 4, 0, 0);
+		}
+	};
+	if (nblocks > 0) {
+		dma_block(0, 0);
+		dma_block(1, 1);
+	}
+	__syncthreads();
+
+	const unsigned rbase = (unsigned)(c * PITCH) + (unsigned)(((hq ^ c) & 15) * 16);
+	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
+	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 16 + c) * 16);
+
+	// candidates of one tile: rows whose coarse value reaches the pass bound of their query
+	auto rare = [&](const f32x4b (&sv)[NCB], f32x4n cqv, long long row0, int nvalid) {
+		int qo = qw;
+		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)
+#pragma unroll
+		for (int i = 0; i < NCB; ++i) {
+			const int q = qo + 16 * i + c;
+			const float c0 = cqv[i];
+			unsigned m = 0u;
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				if (4 * hq + r < nvalid && sv[i][r] >= c0) // NaN on either side: false
+					m |= 1u << r;
+			if (a.rowmask && m != 0u) { // IDSelector: rejected rows are neither candidates nor evidence for the bound
+				const unsigned long long rr = (unsigned long long)(row0 + 4 * hq);
+				m &= (unsigned)(((const unsigned *)a.rowmask)[rr >> 5] >> (rr & 31u));
+			}
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
+				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
+				const float v = (j & 2) ? hi : lo;
+				const unsigned row = (unsigned)(row0 + 4 * hq + j);
+				typedef __attribute__((address_space(1))) unsigned *GU;
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (COLLECT) {
+					unsigned pos;
+					const unsigned one = 1u;
+					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+					if (pos < (unsigned)CL_QCAP) {
+						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+					} else { // a burst beyond the queue: straight to the stream (by hand, wait included: flat_collect.hip)
+						unsigned long long gp;
+						const unsigned long long one64 = 1ull;
+						typedef __attribute__((address_space(1))) unsigned long long *GUL;
+						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+						             : "=&v"(gp)
+						             : "v"((GUL)a.stream_cnt), "v"(one64)
+						             : "memory");
+						if ((long long)gp < a.stream_cap)
+							*((GUL)a.stream + gp) = ent;
+					}
+				}
+			}
+		}
+		// the slot / stream updates are done before the next LDS-DMA is issued: the tile barrier's vmcnt counts loads only
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+	};
+
+	// bound refresh: lane (hq, c), hq < NCB, owns query c of column block hq; B = the kk-th best of its 16 class bests
+	auto refresh = [&]() {
+		if (hq < NCB) {
+			int qo = qw;
+			MVS_OPAQUE_VGPR(qo);
+			const int q = qo + 16 * hq + c;
+			const int qc = q < a.nq ? q : 0;
+			const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+			unsigned long long w[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const float e2v = __builtin_nontemporal_load(a.e2 + qc);
+#pragma unroll
+			for (int j = 0; j < 8; ++j)
+				asm volatile("" : "+v"(w[j]));
+			unsigned key[16];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				key[2 * j] = (unsigned)w[j];
+				key[2 * j + 1] = (unsigned)(w[j] >> 32);
+			}
+#pragma unroll
+			for (int kbit = 2; kbit <= 16; kbit <<= 1)
+#pragma unroll
+				for (int jb = kbit >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+					for (int x0 = 0; x0 < 16; ++x0) {
+						const int x1 = x0 ^ jb;
+						if (x1 > x0) {
+							const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
+							const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
+							const bool asc = (x0 & kbit) == 0;
+							key[x0] = asc ? lo : hi;
+							key[x1] = asc ? hi : lo;
+						}
+					}
+			unsigned kth = key[0];
+#pragma unroll
+			for (int j = 1; j < 16; ++j)
+				kth = (a.nclass - 1 == j) ? key[j] : kth;
+			const unsigned neutral = skey(-FLT_MAX);
+			const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
+			// (2E = NaN stays NaN; NaN: nothing passes)
+			cqtab[(wave * 16 + c) * 4 + hq] = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u);
+		}
+	};
+
+	f32x4b acc[2][NCB]; // two accumulator sets: tile u lives in acc[u & 1] while tile u - 1 (the other set) is tested
+	f32x4n pcq = {0.f, 0.f, 0.f, 0.f}; // the bounds tile u - 1 was scanned under
+	int stg = 0;
+	// one tile; PAR = u & 1 as a compile-time constant (the accumulator sets must be registers, not an indexed array)
+	auto tile = [&](auto parc, const int u) {
+		constexpr int par = decltype(parc)::value;
+		{
+			const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
+			if ((u % period) == 0)
+				refresh();
+			dma_block(u + 2, stg == 0 ? 2 : stg - 1); // the stage tile u - 1 left at the last barrier
+			const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + (stg * STAGE_BYTES) / 4)) + rbase;
+			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + stg * 64 + 4 * hq));
+			f32x4n Y, cqv;
+			asm volatile("ds_read_b128 %0, %1" : "=v"(Y) : "v"(nb_lds) : "memory");
+			asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds) : "memory");
+			// A fragment (k-block kb) of the tile's 16 rows: byte c * PITCH + 256 (kb >> 2) + (rb16 ^ (64 (kb & 3)))
+			bf16x8 A[RING];
+#pragma unroll
+			for (int kb = 0; kb < RA; ++kb)
+				asm volatile("ds_read_b128 %0, %1" : "=v"(A[kb % RING]) : "v"((tb ^ (unsigned)((kb & 3) * 64)) + (unsigned)((kb >> 2) * 256)) : "memory");
+			bool any_prev = false;
+#pragma unroll
+			for (int kb = 0; kb < KBT; ++kb) {
+				if (kb + RA < KBT) {
+					const int k2 = kb + RA;
+					asm volatile("ds_read_b128 %0, %1" : "=v"(A[k2 % RING]) : "v"((tb ^ (unsigned)((k2 & 3) * 64)) + (unsigned)((k2 >> 2) * 256)) : "memory");
+					// LDS returns in order: with RA reads younger than fragment kb outstanding, kb (and, the first time, beta and
+					// the bounds) has arrived
+					asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Y), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(RA));
+				} else {
+					asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A[kb % RING]), "+v"(A[(kb + 1) % RING]) : "n"(KBT - 1 - kb < RA ? KBT - 1 - kb : RA));
+				}
+#pragma unroll
+				for (int i = 0; i < NCB; ++i) {
+					const int f = i * KBT + kb;
+					if (f < NV) {
+						if (kb == 0) // the chain starts at beta(row): s comes out of the matrix pipe
+							acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], Y, 0, 0, 0);
+						else
+							acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], acc[par][i], 0, 0, 0);
+					} else { // srcB from an AGPR quad
+						if (kb == 0)
+							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+							             : "=&v"(acc[par][i])
+							             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]), "v"(Y));
+						else
+							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+							             : "+v"(acc[par][i])
+							             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]));
+					}
+				}
+				if (kb == 1 && u > 0) { // tile u - 1's running maxima against its bounds, behind this tile's first MFMAs
+#pragma unroll
+					for (int i = 0; i < NCB; ++i) {
+						const f32x4b &s = acc[par ^ 1][i];
+						const float mx = __builtin_fmaxf(__builtin_fmaxf(s[0], s[1]), __builtin_fmaxf(s[2], s[3]));
+						any_prev = any_prev || (mx >= pcq[i]);
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			if (u > 0 && __builtin_amdgcn_ballot_w64(any_prev) != 0ull) {
+				const long long prow0 = r_begin + (long long)(u - 1) * RT;
+				const int pnvalid = (int)((r_end - prow0) < RT ? (r_end - prow0) : RT);
+				rare(acc[par ^ 1], pcq, prow0, pnvalid);
+			}
+			pcq = cqv;
+			// block u + 1 has landed, this stage is free again; the newest block (the last DMA_PER_WAVE (+ 1: beta) loads of this
+			// wave -- nothing else is in flight, loads return in order) stays in flight across the barrier
+			if (wave == 0)
+				asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 1) : "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
+			stg = stg == 2 ? 0 : stg + 1;
+			if (COLLECT && (u % FLUSH_EVERY) == FLUSH_EVERY - 1 && u != nblocks - 1) {
+				const unsigned fill = qctl[0];
+				__syncthreads(); // everybody has read the same fill before anyone appends again
+				const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
+				if (n >= (unsigned)CL_QCAP / 2) {
+					if (tid == 0) {
+						*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+						qctl[0] = 0u;
+					}
+					__syncthreads();
+					const unsigned long long base = *(const unsigned long long *)(qctl + 2);
+					for (unsigned i = tid; i < n; i += 256)
+						if ((long long)(base + i) < a.stream_cap)
+							a.stream[base + i] = qbuf[i];
+					__syncthreads();
+				}
+			}
+		}
+	};
+	for (int u0 = 0; u0 < nblocks; u0 += 2) {
+		tile(std::integral_constant<int, 0>{}, u0);
+		if (u0 + 1 < nblocks)
+			tile(std::integral_constant<int, 1>{}, u0 + 1);
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the blocks fetched past the split's end)
+	// (the hand-written MFMAs have drained before the vector ALU reads their accumulators: >= 19 wait states on gfx950)
+	asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+	auto last_tile = [&](auto parc) { // the last tile's test (its accumulator set as a compile-time constant)
+		constexpr int lp = decltype(parc)::value;
+		bool any_t = false;
+#pragma unroll
+		for (int i = 0; i < NCB; ++i) {
+			const f32x4b &sv = acc[lp][i];
+			const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
+			any_t = any_t || (mx >= pcq[i]);
+		}
+		if (__builtin_amdgcn_ballot_w64(any_t) != 0ull) {
+			const long long prow0 = r_begin + (long long)(nblocks - 1) * RT;
+			const int pnvalid = (int)((r_end - prow0) < RT ? (r_end - prow0) : RT);
+			rare(acc[lp], pcq, prow0, pnvalid);
+		}
+	};
+	if (nblocks > 0) {
+		if ((nblocks - 1) & 1)
+			last_tile(std::integral_constant<int, 1>{});
+		else
+			last_tile(std::integral_constant<int, 0>{});
+	}
+	if (COLLECT) {
+		__syncthreads(); // every wave's appends are in
+		const unsigned fill = qctl[0];
+		const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
+		if (n > 0) {
+			if (tid == 0)
+				*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+			__syncthreads();
+			const unsigned long long base = *(const unsigned long long *)(qctl + 2);
+			for (unsigned i = tid; i < n; i += 256)
+				if ((long long)(base + i) < a.stream_cap)
+					a.stream[base + i] = qbuf[i];
+		}
+	}
+}
+
+int collect_big_ncb(int dp1) {
+	return dp1 == 768 ? 4 : 3;
+}
+int collect_big_qblock(int dp1) {
+	return 4 * 16 * collect_big_ncb(dp1);
+}
+size_t collect_big_lds_bytes(int dp1) {
+	return (size_t)3 * (16 * dp1 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
+}
+
+template <int KBT, int NCB>
+static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int grid, size_t lds, hipStream_t st) {
+#define MVS_BIG(L2, CO)                                                                                           \
+	{                                                                                                             \
+		auto kern = flat_bf16_big_kernel<KBT, NCB, L2, CO>;                                                       \
+		ensure_dynamic_lds((const void *)kern, lds);                                                              \
+		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                                    \
+	}
+	if (metric == METRIC_L2 && collect)
+		MVS_BIG(true, true)
+	else if (metric == METRIC_L2)
+		MVS_BIG(true, false)
+	else if (collect)
+		MVS_BIG(false, true)
+	else
+		MVS_BIG(false, false)
+#undef MVS_BIG
+	MVS_HIP(hipGetLastError());
+}
+
+void launch_collect_big(int dp1, int metric, bool collect, const CollectArgs &a, int grid, hipStream_t st) {
+	const size_t lds = collect_big_lds_bytes(dp1);
+	if (dp1 == 768)
+		launch_big_inst<24, 4>(metric, collect, a, grid, lds, st);
+	else if (dp1 == 1024)
+		launch_big_inst<32, 3>(metric, collect, a, grid, lds, st);
+	else
+		throw_faiss("mvs::launch_collect_big", __FILE__, "no instance for a %d-dim store", dp1);
+}
+
+} // namespace mvs

@@ -790,6 +790,8 @@ static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }
 int collect_wide_qblock(int dp1) {
+	if (g_wide_big && (dp1 == 768 || dp1 == 1024)) // flat_bf16_big_kernel: one wave per SIMD, all of k resident
+		return collect_big_qblock(dp1);
 	if (dp1 == 1024) // 8 waves, two column blocks per pair (2 x 16 k-blocks = 128 VGPRs of fragments)
 		return 128;
 	if (dp1 == 384)
@@ -804,9 +806,13 @@ static int wide_wsub(int dp1) {
 }
 // resident workgroups of the scan kernel on the device (256 CUs)
 int collect_wide_slots(int dp1) {
+	if (g_wide_big && (dp1 == 768 || dp1 == 1024))
+		return 256; // one workgroup per CU
 	return (dp1 == 1024 || (dp1 == 768 && g_ksplit_waves == 8)) ? 256 : 512;
 }
 size_t collect_wide_lds_bytes(int dp1) {
+	if (g_wide_big && (dp1 == 768 || dp1 == 1024))
+		return collect_big_lds_bytes(dp1);
 	if (dp1 == 1024) // flat_bf16_ksplit_kernel<8, 2, 2, 32>: two 32 KB stages, beta, queue, hand-over buffers, bounds, control
 		return (size_t)2 * (16 * 1024 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + (size_t)2 * 8 * 64 * 16 + 128 * 4 + 64;
 	if (dp1 == 512 && g_wide512_ksplit) // flat_bf16_ksplit_kernel<4, 2, 3, 16>
@@ -818,6 +824,8 @@ size_t collect_wide_lds_bytes(int dp1) {
 	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)4 * wide_qt(dp1) * 16 * 4 * 4 + 64;
 }
 int collect_wide_block_rows(int dp1) {
+	if (g_wide_big && (dp1 == 768 || dp1 == 1024))
+		return 16;
 	return 16 * wide_wsub(dp1);
 }
 
@@ -851,7 +859,9 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	a.opt = g_ksplit_opt;
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_wide_lds_bytes(dp1);
-	if (dp1 == 256) {
+	if (g_wide_big && (dp1 == 768 || dp1 == 1024)) {
+		launch_collect_big(dp1, metric, collect, a, grid, st);
+	} else if (dp1 == 256) {
 		if (collect)
 			launch_wide_inst<8, 2, 2, true>(metric, a, grid, lds, st);
 		else

@@ -1790,6 +1790,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		prefilter_mode = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "cl_wide_big")) { // 512 < d <= 1024 coarse filter: one wave per SIMD, all of k resident (1) or the k-split kernel (0)
+		g_wide_big = v != 0;
+		return true;
+	}
 	if (!strcmp(key, "cl_wide512_ksplit")) { // 384 < d <= 512 coarse filter on the k-split kernel (1) or on wide<16,1,2> (0)
 		g_wide512_ksplit = v != 0;
 		return true;

@@ -188,6 +188,34 @@ __global__ void pack_records_kernel(const float *D, const long long *G, long lon
 		out[i] = r;
 	}
 }
+// merged pure lists (value, global row) [nq][kk] -> D / I [nq][k]: inner product prints runs of equal scores in descending
+// row order (heap_reorder over a CMin heap), labels = id map or row + offset; flag: {count, queries...} of the queries whose
+// k-th and (k+1)-th scores are bit-equal (the cross-shard tie pass decides those)
+__global__ void sharded_finish_kernel(const float *__restrict__ mv, const long long *__restrict__ mg, int kk, int k, long long nq,
+                                      int is_l2, const long long *__restrict__ idmap, long long label_offset,
+                                      float *__restrict__ D, long long *__restrict__ I, int *__restrict__ flag) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq * k)
+		return;
+	const long long q = i / k;
+	const int j = (int)(i - q * k);
+	const float *v = mv + q * kk;
+	const long long *gq = mg + q * kk;
+	int src = j;
+	if (!is_l2 && gq[j] >= 0) {
+		int a = j, b = j;
+		while (a > 0 && gq[a - 1] >= 0 && v[a - 1] == v[j])
+			--a;
+		while (b + 1 < k && gq[b + 1] >= 0 && v[b + 1] == v[j])
+			++b;
+		src = a + (b - j);
+	}
+	const long long g = gq[src];
+	D[i] = v[src];
+	I[i] = g < 0 ? -1ll : (idmap ? idmap[g] : g + label_offset);
+	if (flag && j == k - 1 && kk > k && gq[k] >= 0 && v[k] == v[k - 1])
+		flag[1 + atomicAdd(flag, 1)] = (int)q;
+}
 __global__ void iota_kernel(long long *out, long long n, long long start) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n)
@@ -224,12 +252,12 @@ struct GrowI64 { // device int64 array that keeps its contents when it grows
 struct HostPinned {
 	void *p = nullptr;
 	size_t cap = 0;
-	void *get(size_t bytes) {
+	void *get(size_t bytes, bool portable = false) { // portable: every device of the node may DMA from / into it
 		if (bytes > cap) {
 			if (p)
 				(void)hipHostFree(p);
 			p = nullptr;
-			MVS_HIP(hipHostMalloc(&p, bytes + bytes / 4 + 256, hipHostMallocDefault));
+			MVS_HIP(hipHostMalloc(&p, bytes + bytes / 4 + 256, portable ? hipHostMallocPortable : hipHostMallocDefault));
 			cap = bytes + bytes / 4 + 256;
 		}
 		return p;
@@ -263,13 +291,17 @@ public:
 	// per-shard scratch
 	struct Scratch {
 		DevBuf x, D, I, rec, recv, T, rows;
+		DevBuf mv, mg, oD, oI, flag; // first device only: merged pure lists, finished results, tie flags {count, queries...}
 		HostPinned hx, hD, hI, hT, hrows;
 		void release() {
-			for (DevBuf *b : {&x, &D, &I, &rec, &recv, &T, &rows})
+			for (DevBuf *b : {&x, &D, &I, &rec, &recv, &T, &rows, &mv, &mg, &oD, &oI, &flag})
 				b->release();
 		}
 	};
 	std::vector<Scratch> sc;
+	HostPinned hq, hout;          // the batch's queries (one pinned copy for all devices) and its finished results
+	std::vector<hipEvent_t> ev;   // per shard: its records have arrived on the first device
+	hipEvent_t ev_x = nullptr;    // device-pointer entry: the caller's stream has produced the queries
 	int64_t last_flagged = 0; // diagnostics: queries the last search sent through the cross-shard tie pass
 
 	ShardedIndex(int d_, const std::string &desc, int metric_, const std::vector<int> &devices)
@@ -338,6 +370,11 @@ public:
 		for (void *c : comms)
 			if (c)
 				Rccl::get().comm_destroy(c);
+		for (hipEvent_t e : ev)
+			if (e)
+				(void)hipEventDestroy(e);
+		if (ev_x)
+			(void)hipEventDestroy(ev_x);
 		for (int g = 0; g < G; ++g) {
 			(void)hipSetDevice(devs[g]);
 			gnum_dev[g].release();
@@ -464,7 +501,7 @@ public:
 					s->add_with_ids(p.cnt, x + p.off * d, gn.data());
 				}
 			}
-			if (mode == ROWS_IVF && has_idmap) { // the whole id_map on every device
+			if (has_idmap && (mode == ROWS_IVF || g == 0)) { // the whole id_map on every device (Flat: the merging device only)
 				hipStream_t st = shards[g]->stream;
 				idmap_dev[g].ensure(base + n, base, st);
 				MVS_HIP(hipMemcpyAsync(idmap_dev[g].p + base, ids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
@@ -522,6 +559,12 @@ public:
 	}
 
 	// ------------------------------------------------------------------------------------------------ search
+	// Row shards: every device searches its rows (pure order, GLOBAL row numbers, k + 1 entries for inner product), packs
+	// 16-byte {value, global row} records, the records of all shards meet on the FIRST device -- peer copies over xGMI
+	// ("host" exchange: nothing passes through the host any more) or ONE ncclAllGather -- and are merged THERE
+	// (merge_records_kernel, one wave per query); a finish kernel prints FAISS's order with the user labels and flags
+	// exact inner-product ties at rank k.  The host sees nq x k results and one flag count.  (Round 2 merged G x nq x k
+	// candidates on 16 host threads and staged queries and results of the device-pointer entry through the host.)
 	void search(int64_t nq, const float *x, int64_t k, float *D, int64_t *I, const mvs_search_params *params) override {
 		if (k <= 0)
 			throw_faiss("virtual void faiss::Index::search(...) const", "faiss/Index.cpp", "Error: 'k > 0' failed");
@@ -537,17 +580,73 @@ public:
 			kinfo = shards[0]->kinfo;
 			return;
 		}
+		// the caller's pageable queries: ONE copy into pinned memory every device reads its H2D from
+		const size_t xbytes = (size_t)nq * d * sizeof(float);
+		float *hx = (float *)hq.get(xbytes, true);
+		memcpy(hx, x, xbytes);
+		search_rows(nq, hx, nullptr, -1, nullptr, k, params, D, I, nullptr, nullptr, x);
+	}
+
+	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                   hipStream_t st) override {
+		if (k <= 0)
+			throw_faiss("virtual void faiss::Index::search(...) const", "faiss/Index.cpp", "Error: 'k > 0' failed");
+		if (nq <= 0)
+			return;
+		if (mode == REPLICAS) { // (replicas split the batch: staged through the host as the host-pointer entry does)
+			std::vector<float> hxv((size_t)nq * d), hD((size_t)nq * k);
+			std::vector<int64_t> hI((size_t)nq * k);
+			MVS_HIP(hipMemcpyAsync(hxv.data(), d_x, hxv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+			MVS_HIP(hipStreamSynchronize(st));
+			search(nq, hxv.data(), k, hD.data(), hI.data(), params);
+			MVS_HIP(hipMemcpyAsync(d_D, hD.data(), hD.size() * sizeof(float), hipMemcpyHostToDevice, st));
+			MVS_HIP(hipMemcpyAsync(d_I, hI.data(), hI.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+			MVS_HIP(hipStreamSynchronize(st));
+			return;
+		}
+		// queries stay on the devices: the shard on the caller's device reads them in place, the others fetch them with a
+		// peer copy once the caller's stream has produced them
+		hipPointerAttribute_t at;
+		MVS_HIP(hipPointerGetAttributes(&at, d_x));
+		const int xdev = at.device;
+		MVS_HIP(hipSetDevice(xdev));
+		if (!ev_x)
+			MVS_HIP(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming));
+		MVS_HIP(hipEventRecord(ev_x, st));
+		search_rows(nq, nullptr, d_x, xdev, ev_x, k, params, nullptr, nullptr, d_D, d_I, nullptr);
+	}
+
+	// hx: pinned host queries (host-pointer entry) or d_x on device xdev, valid once x_ready has passed (device-pointer entry);
+	// results to D / I (host) or d_D / d_I (device memory of any device); x_pageable: the caller's queries for the (rare)
+	// cross-shard tie pass, fetched from d_x when null
+	void search_rows(int64_t nq, const float *hx, const float *d_x, int xdev, hipEvent_t x_ready, int64_t k,
+	                 const mvs_search_params *params, float *D, int64_t *I, float *d_D, int64_t *d_I, const float *x_pageable) {
 		const bool is_l2 = metric_order(metric) == METRIC_L2;
 		// inner product: one extra candidate per list detects an exact tie at the k-th score (FlatIndex::search_flat)
 		const bool tie_detect = metric == METRIC_IP && mode == ROWS_FLAT && ntotal > k && k + 1 <= 256;
 		const int64_t kk = tie_detect ? k + 1 : k;
-		const size_t cells = (size_t)nq * kk;
-		std::vector<const float *> hD(G);
-		std::vector<const int64_t *> hG(G);
+		const size_t cells = (size_t)nq * kk, ocells = (size_t)nq * k;
 		const bool use_rccl = exchange == 1 && ensure_comms();
-		on_all([&](int g) { shard_search(g, nq, x, kk, params, use_rccl); });
+		Scratch &w0 = sc[0];
+		MVS_HIP(hipSetDevice(devs[0]));
+		w0.recv.reserve(cells * sizeof(Rec) * G);
+		w0.mv.reserve(cells * sizeof(float));
+		w0.mg.reserve(cells * sizeof(int64_t));
+		w0.oD.reserve(ocells * sizeof(float));
+		w0.oI.reserve(ocells * sizeof(int64_t));
+		w0.flag.reserve((size_t)(nq + 16) * sizeof(int));
+		if (ev.empty()) {
+			ev.assign((size_t)G, nullptr);
+			for (int g = 0; g < G; ++g) {
+				MVS_HIP(hipSetDevice(devs[g]));
+				MVS_HIP(hipEventCreateWithFlags(&ev[g], hipEventDisableTiming));
+			}
+			MVS_HIP(hipSetDevice(devs[0]));
+		}
+		on_all([&](int g) { shard_search(g, nq, hx, d_x, xdev, x_ready, kk, params, use_rccl); });
+		hipStream_t s0 = streams[0];
 		if (use_rccl) {
-			// ONE all-gather of the packed {value, global row} records, then the first device hands the union to the host
+			// ONE all-gather of the packed {value, global row} records over xGMI; the first device merges its copy
 			Rccl &r = Rccl::get();
 			check_nccl(r.group_start(), "ncclGroupStart");
 			for (int g = 0; g < G; ++g) {
@@ -558,56 +657,94 @@ public:
 			}
 			check_nccl(r.group_end(), "ncclGroupEnd");
 			MVS_HIP(hipSetDevice(devs[0]));
-			Rec *hr = (Rec *)sc[0].hD.get(cells * sizeof(Rec) * G);
-			MVS_HIP(hipMemcpyAsync(hr, sc[0].recv.p, cells * sizeof(Rec) * G, hipMemcpyDeviceToHost, streams[0]));
-			for (int g = 0; g < G; ++g) {
-				MVS_HIP(hipSetDevice(devs[g]));
-				MVS_HIP(hipStreamSynchronize(streams[g]));
-			}
-			unpackD.resize(cells * G);
-			unpackG.resize(cells * G);
-			for (size_t i = 0; i < cells * G; ++i) {
-				unpackD[i] = hr[i].v;
-				unpackG[i] = hr[i].g;
-			}
-			for (int g = 0; g < G; ++g) {
-				hD[g] = unpackD.data() + cells * g;
-				hG[g] = unpackG.data() + cells * g;
-			}
 		} else {
-			for (int g = 0; g < G; ++g) {
-				hD[g] = (const float *)sc[g].hD.p;
-				hG[g] = (const int64_t *)sc[g].hI.p;
-			}
+			MVS_HIP(hipSetDevice(devs[0]));
+			for (int g = 1; g < G; ++g)
+				MVS_HIP(hipStreamWaitEvent(s0, ev[g], 0)); // shard g's records have landed in w0.recv
 		}
+		launch_merge_records(metric, (const int64_t *)w0.recv.p, G, nq, (int)kk, (int)kk, true, (float *)w0.mv.p, (int64_t *)w0.mg.p, s0);
+		// FAISS's print order, user labels, tie flags -- on the device
+		const int64_t *idmap0 = has_idmap ? idmap_dev[0].p : nullptr;
+		MVS_HIP(hipMemsetAsync(w0.flag.p, 0, sizeof(int), s0));
+		hipLaunchKernelGGL(sharded_finish_kernel, dim3((unsigned)((ocells + 255) / 256)), dim3(256), 0, s0, (const float *)w0.mv.p,
+		                   (const long long *)w0.mg.p, (int)kk, (int)k, (long long)nq, is_l2 ? 1 : 0, (const long long *)idmap0,
+		                   (long long)label_offset, (float *)w0.oD.p, (long long *)w0.oI.p, tie_detect ? (int *)w0.flag.p : nullptr);
+		MVS_HIP(hipGetLastError());
+		const size_t d_off = 64, i_off = d_off + ((ocells * sizeof(float) + 7) & ~(size_t)7);
+		char *ho = (char *)hout.get(i_off + ocells * sizeof(int64_t));
+		int *hflag = (int *)ho;
+		float *hD = (float *)(ho + d_off);
+		int64_t *hI = (int64_t *)(ho + i_off);
+		MVS_HIP(hipMemcpyAsync(hflag, w0.flag.p, sizeof(int), hipMemcpyDeviceToHost, s0));
+		if (D) {
+			MVS_HIP(hipMemcpyAsync(hD, w0.oD.p, ocells * sizeof(float), hipMemcpyDeviceToHost, s0));
+			MVS_HIP(hipMemcpyAsync(hI, w0.oI.p, ocells * sizeof(int64_t), hipMemcpyDeviceToHost, s0));
+		} else {
+			copy_between(d_D, w0.oD.p, devs[0], ocells * sizeof(float), s0);
+			copy_between(d_I, w0.oI.p, devs[0], ocells * sizeof(int64_t), s0);
+		}
+		for (int g = use_rccl ? 0 : G; g < G; ++g) { // (rccl: every rank's gather must finish before its buffers are reused)
+			MVS_HIP(hipSetDevice(devs[g]));
+			MVS_HIP(hipStreamSynchronize(streams[g]));
+		}
+		MVS_HIP(hipSetDevice(devs[0]));
+		MVS_HIP(hipStreamSynchronize(s0));
+		if (D) {
+			memcpy(D, hD, ocells * sizeof(float));
+			memcpy(I, hI, ocells * sizeof(int64_t));
+		}
+		const int nflag = tie_detect ? *hflag : 0;
+		last_flagged = nflag;
+		kinfo = shards[0]->kinfo;
+		if (nflag <= 0)
+			return;
+		// ---- exact inner-product ties at rank k across shards (rare): the host finishes those queries -------------------
+		std::vector<int> fq((size_t)nflag);
 		std::vector<float> mv(cells);
 		std::vector<int64_t> mg(cells);
-		merge_raw_lists_host(metric, nq, kk, G, hD.data(), hG.data(), mv.data(), mg.data());
-		// ---- output + tie detection ---------------------------------------------------------------------------
-		std::vector<int64_t> flagged;
-		for (int64_t q = 0; q < nq; ++q) {
-			const float *v = &mv[(size_t)q * kk];
-			const int64_t *gq = &mg[(size_t)q * kk];
-			for (int64_t j = 0; j < k; ++j) {
-				int64_t src = j;
-				if (!is_l2 && gq[j] >= 0) { // equal scores print in descending id order
-					int64_t a = j, b = j;
-					while (a > 0 && gq[a - 1] >= 0 && v[a - 1] == v[j])
-						--a;
-					while (b + 1 < k && gq[b + 1] >= 0 && v[b + 1] == v[j])
-						++b;
-					src = a + (b - j);
-				}
-				D[q * k + j] = v[src];
-				I[q * k + j] = to_label(gq[src]);
-			}
-			if (tie_detect && gq[k] >= 0 && v[k] == v[k - 1])
-				flagged.push_back(q);
+		MVS_HIP(hipMemcpy(fq.data(), (const int *)w0.flag.p + 1, (size_t)nflag * sizeof(int), hipMemcpyDeviceToHost));
+		MVS_HIP(hipMemcpy(mv.data(), w0.mv.p, cells * sizeof(float), hipMemcpyDeviceToHost));
+		MVS_HIP(hipMemcpy(mg.data(), w0.mg.p, cells * sizeof(int64_t), hipMemcpyDeviceToHost));
+		std::vector<int64_t> flagged(fq.begin(), fq.end());
+		std::sort(flagged.begin(), flagged.end());
+		std::vector<float> xv;
+		if (!x_pageable) {
+			xv.resize((size_t)nq * d);
+			MVS_HIP(hipSetDevice(xdev));
+			MVS_HIP(hipMemcpy(xv.data(), d_x, xv.size() * sizeof(float), hipMemcpyDeviceToHost));
+			MVS_HIP(hipSetDevice(devs[0]));
+			x_pageable = xv.data();
 		}
-		last_flagged = (int64_t)flagged.size();
-		if (!flagged.empty())
-			resolve_ties(flagged, x, k, kk, mv, mg, params, D, I);
+		std::vector<float> Dt;
+		std::vector<int64_t> It;
+		float *Dp = D;
+		int64_t *Ip = I;
+		if (!D) { // device-pointer entry: patch the finished block on the host and hand it back
+			Dt.resize(ocells);
+			It.resize(ocells);
+			MVS_HIP(hipMemcpy(Dt.data(), w0.oD.p, ocells * sizeof(float), hipMemcpyDeviceToHost));
+			MVS_HIP(hipMemcpy(It.data(), w0.oI.p, ocells * sizeof(int64_t), hipMemcpyDeviceToHost));
+			Dp = Dt.data();
+			Ip = It.data();
+		}
+		resolve_ties(flagged, x_pageable, k, kk, mv, mg, params, Dp, Ip);
+		if (!D) {
+			MVS_HIP(hipMemcpy(w0.oD.p, Dt.data(), ocells * sizeof(float), hipMemcpyHostToDevice));
+			MVS_HIP(hipMemcpy(w0.oI.p, It.data(), ocells * sizeof(int64_t), hipMemcpyHostToDevice));
+			copy_between(d_D, w0.oD.p, devs[0], ocells * sizeof(float), s0);
+			copy_between(d_I, w0.oI.p, devs[0], ocells * sizeof(int64_t), s0);
+			MVS_HIP(hipStreamSynchronize(s0));
+		}
 		kinfo = shards[0]->kinfo;
+	}
+	// dst (device memory of whichever device owns it) <- src on device src_dev, on stream st of src_dev
+	static void copy_between(void *dst, const void *src, int src_dev, size_t bytes, hipStream_t st) {
+		hipPointerAttribute_t at;
+		MVS_HIP(hipPointerGetAttributes(&at, dst));
+		if (at.device == src_dev)
+			MVS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+		else
+			MVS_HIP(hipMemcpyPeerAsync(dst, at.device, src, src_dev, bytes, st));
 	}
 	int64_t to_label(int64_t g) const {
 		if (g < 0)
@@ -615,43 +752,58 @@ public:
 		return has_idmap ? idmap_host[(size_t)g] : g + label_offset;
 	}
 
-	// raw search of shard g: queries H2D, pure-order top-kk with GLOBAL row numbers, then D2H (host exchange) or
-	// packed records left on the device (rccl exchange)
-	void shard_search(int g, int64_t nq, const float *x, int64_t kk, const mvs_search_params *params, bool for_rccl) {
+	// raw search of shard g: queries to the device (H2D from the shared pinned copy, a peer copy, or in place), pure-order
+	// top-kk with GLOBAL row numbers, packed into records; host exchange: the records go straight into the first device's
+	// receive buffer (slot g) and ev[g] marks their arrival
+	void shard_search(int g, int64_t nq, const float *hx, const float *d_x, int xdev, hipEvent_t x_ready, int64_t kk,
+	                  const mvs_search_params *params, bool for_rccl) {
 		IndexBase *s = shards[g];
 		s->use_device();
 		hipStream_t st = streams[g];
 		Scratch &w = sc[g];
 		const size_t xbytes = (size_t)nq * d * sizeof(float), cells = (size_t)nq * kk;
-		w.x.reserve(xbytes);
 		w.D.reserve(cells * sizeof(float));
 		w.I.reserve(cells * sizeof(int64_t));
-		void *hx = w.hx.get(xbytes);
-		memcpy(hx, x, xbytes);
-		MVS_HIP(hipMemcpyAsync(w.x.p, hx, xbytes, hipMemcpyHostToDevice, st));
+		const float *xq = nullptr;
+		if (hx) {
+			w.x.reserve(xbytes);
+			MVS_HIP(hipMemcpyAsync(w.x.p, hx, xbytes, hipMemcpyHostToDevice, st));
+			xq = (const float *)w.x.p;
+		} else {
+			MVS_HIP(hipStreamWaitEvent(st, x_ready, 0));
+			if (xdev == devs[g]) {
+				xq = d_x;
+			} else {
+				w.x.reserve(xbytes);
+				MVS_HIP(hipMemcpyPeerAsync(w.x.p, devs[g], d_x, xdev, xbytes, st));
+				xq = (const float *)w.x.p;
+			}
+		}
 		if (mode == ROWS_FLAT) {
 			auto *f = static_cast<FlatIndex *>(s);
 			const int64_t *selmap = has_idmap ? label_dev[g].p : gnum_dev[g].p; // the selector tests the label
-			f->search_flat(nq, (const float *)w.x.p, kk, (float *)w.D.p, (int64_t *)w.I.p, params, selmap, st);
+			f->search_flat(nq, xq, kk, (float *)w.D.p, (int64_t *)w.I.p, params, selmap, st);
 			if (f->ntotal > 0)
 				hipLaunchKernelGGL(map_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st,
 				                   (long long *)w.I.p, (long long)cells, (const long long *)gnum_dev[g].p);
 		} else {
-			s->search_mapped(nq, (const float *)w.x.p, kk, (float *)w.D.p, (int64_t *)w.I.p, params,
-			                 has_idmap ? idmap_dev[g].p : nullptr, st);
+			s->search_mapped(nq, xq, kk, (float *)w.D.p, (int64_t *)w.I.p, params, has_idmap ? idmap_dev[g].p : nullptr, st);
 		}
-		if (for_rccl) {
+		// rccl: packed into the send buffer; otherwise slot g of the first device's receive buffer, written in place when the
+		// shard lives there, else packed locally and pushed with one peer copy
+		const bool in_place = !for_rccl && devs[g] == devs[0];
+		Rec *out = in_place ? (Rec *)sc[0].recv.p + cells * g : nullptr;
+		if (!out) {
 			w.rec.reserve(cells * sizeof(Rec));
-			hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st,
-			                   (const float *)w.D.p, (const long long *)w.I.p, (long long)cells, (Rec *)w.rec.p);
-			MVS_HIP(hipGetLastError());
-			MVS_HIP(hipStreamSynchronize(st));
-		} else {
-			float *hD = (float *)w.hD.get(cells * sizeof(float));
-			int64_t *hI = (int64_t *)w.hI.get(cells * sizeof(int64_t));
-			MVS_HIP(hipMemcpyAsync(hD, w.D.p, cells * sizeof(float), hipMemcpyDeviceToHost, st));
-			MVS_HIP(hipMemcpyAsync(hI, w.I.p, cells * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-			MVS_HIP(hipStreamSynchronize(st));
+			out = (Rec *)w.rec.p;
+		}
+		hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, (const float *)w.D.p,
+		                   (const long long *)w.I.p, (long long)cells, out);
+		MVS_HIP(hipGetLastError());
+		if (!for_rccl) {
+			if (!in_place)
+				MVS_HIP(hipMemcpyPeerAsync((Rec *)sc[0].recv.p + cells * g, devs[0], w.rec.p, devs[g], cells * sizeof(Rec), st));
+			MVS_HIP(hipEventRecord(ev[g], st));
 		}
 	}
 
@@ -730,18 +882,6 @@ public:
 		}
 	}
 
-	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
-	                   hipStream_t st) override {
-		// the device-pointer API of a sharded index stages through the host (the shards live on other devices)
-		std::vector<float> hx((size_t)nq * d), hD((size_t)nq * k);
-		std::vector<int64_t> hI((size_t)nq * k);
-		MVS_HIP(hipMemcpyAsync(hx.data(), d_x, hx.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-		MVS_HIP(hipStreamSynchronize(st));
-		search(nq, hx.data(), k, hD.data(), hI.data(), params);
-		MVS_HIP(hipMemcpyAsync(d_D, hD.data(), hD.size() * sizeof(float), hipMemcpyHostToDevice, st));
-		MVS_HIP(hipMemcpyAsync(d_I, hI.data(), hI.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-		MVS_HIP(hipStreamSynchronize(st));
-	}
 	void search_mapped(int64_t, const float *, int64_t, float *, int64_t *, const mvs_search_params *, const int64_t *,
 	                   hipStream_t) override {
 		throw_faiss("mvs::ShardedIndex::search_mapped", __FILE__, "a sharded index cannot sit under an IDMap wrapper");
@@ -846,9 +986,6 @@ public:
 		kinfo = shards[0]->kinfo;
 	}
 
-private:
-	std::vector<float> unpackD;
-	std::vector<int64_t> unpackG;
 };
 
 // ---- entry points used by the C ABI ---------------------------------------------------------------------------
