@@ -686,6 +686,7 @@ int g_cl_abl = 0;         // option cl_abl: profiling ablation of the L2 scan (r
 int g_cl_nsplit = 0;      // option cl_nsplit: row splits of the main scan (0 = planned)
 int g_cl_seed_split = 0;    // option cl_seed_split: row splits of the pre-pass (0 = 32: 4.70 vs 4.96 ms per 2048-query call)
 int g_cl_seed_rows = 16384; // option cl_seed_rows: rows of the bound-estimation pre-pass
+int g_cl_seed_regs = 1;     // option cl_seed_regs: d <= 128 pre-pass with class maxima in registers (0: through the scan kernel's rare path)
 
 int flat_mfma_slot_stride(int64_t k);
 __global__ void init_gslot_kernel(unsigned *g, long long total, int stride, int k, int is_l2);
@@ -739,6 +740,176 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 		*nsplit_out = (int)nsplit;
 }
 
+
+// ---- bound estimation pre-pass (d <= 128): class maxima in REGISTERS ---------------------------------------------------------------
+// The COLLECT = false instance of the scan kernel warms the class slots through its rare path: with no bound yet EVERY value
+// passes, i.e. one global atomic per (query, row) pair -- 0.26 ms for 3 900 rows at C2, 0.4 ms for 16 384 at the headline, a
+// fixed cost every search, every DuckDB chunk and every row shard pays.  The accumulator layout makes
+// the atomics unnecessary: lane (hq, c) holds rows 16 rb + 4 hq + r of query c of a column block, and every tile starts at a
+// multiple of 32 rows, so register r of the lane ALWAYS belongs to row class 4 hq + r of that query.  The lane keeps a running
+// maximum per (column block, r) -- 32 registers -- and publishes 32 atomics at the very end: nq x 16 x (row splits) atomics per
+// search instead of nq x rows.  Same geometry, staging and fragment reads as the scan kernel; no bounds, no queue, no stream.
+template <bool IS_L2, bool SEL>
+__global__ __launch_bounds__(256, 2) void flat_bf16_seed_kernel(const CollectArgs a) {
+	constexpr int KB = 4, PITCH = 256;
+	constexpr int TILE_BYTES = CL_BN * PITCH, STAGE_BYTES = CL_SUB * TILE_BYTES;
+	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096;
+	extern __shared__ __attribute__((aligned(16))) float smem[];
+	float *nbuf = (float *)((char *)smem + 2 * STAGE_BYTES); // [2][64] beta of the staged rows
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int hq = lane >> 4, c = lane & 15;
+	const int split = blockIdx.x / a.nqb, qb = blockIdx.x % a.nqb;
+	const long long r_begin = a.row_first + (long long)split * a.split_rows;
+	long long r_end = r_begin + a.split_rows;
+	if (r_end > a.n)
+		r_end = a.n;
+	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin) / (CL_SUB * CL_BN)) : 0; // whole staged blocks only (the host rounds)
+	const int qw = qb * CL_QBLOCK + wave * 128;
+	bf16x8 bq[8][KB];
+	{
+		const bf16x8 *qsrc = (const bf16x8 *)a.qf;
+#pragma unroll
+		for (int cb = 0; cb < 8; ++cb) {
+			const size_t qblk16 = (size_t)qb * (CL_QBLOCK / 16) + wave * 8 + cb;
+#pragma unroll
+			for (int kb = 0; kb < KB; ++kb)
+				bq[cb][kb] = qsrc[(qblk16 * KB + kb) * 64 + lane];
+		}
+	}
+	unsigned dma_off;
+	{
+		const int rr = 4 * wave + (lane >> 4);
+		dma_off = (unsigned)(rr * PITCH + (((lane & 15) ^ rr) * 16));
+	}
+	auto dma_block = [&](int u) {
+#pragma unroll
+		for (int i = 0; i < DMA_PER_WAVE; ++i) {
+			const char *base = (const char *)a.yb + ((size_t)(r_begin + (long long)u * (CL_SUB * CL_BN)) + (size_t)i * 16) * PITCH; // uniform
+			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + dma_off),
+			                                 (lds_f32c *)(smem + ((u & 1) * STAGE_BYTES + (i * 4 + wave) * 1024) / 4), 16, 0, 0);
+		}
+		const float *nb = a.yn + (r_begin + (long long)u * (CL_SUB * CL_BN)); // uniform
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(nb + lane), (lds_f32c *)(smem + (2 * STAGE_BYTES) / 4 + (u & 1) * 64), 4, 0, 0);
+	};
+	if (ntiles > 0)
+		dma_block(0);
+	__syncthreads();
+	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)(((hq ^ c) & 15) * 16);
+	f32x4acc cm[8]; // running maximum of s: [column block][r] = class 4 hq + r of query qw + 16 cb + c
+#pragma unroll
+	for (int cb = 0; cb < 8; ++cb)
+		cm[cb] = f32x4acc {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+	for (int u = 0; u < ntiles; ++u) {
+#pragma unroll 1
+		for (int sub = 0; sub < CL_SUB; ++sub) {
+			bf16x8 A[KB][2];
+			f32x4n Y[2];
+			{
+				const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + (u & 1) * 64 + sub * CL_BN + 4 * hq));
+				asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(Y[0]), "=&v"(Y[1]) : "v"(nb_lds) : "memory");
+				const unsigned ab = (unsigned)(uintptr_t)((lds_f32c *)(smem + ((u & 1) * STAGE_BYTES + sub * TILE_BYTES) / 4)) + rbase;
+#pragma unroll
+				for (int kb = 0; kb < KB; ++kb) {
+					asm volatile("ds_read_b128 %0, %1" : "=v"(A[kb][0]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
+					asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(A[kb][1]) : "v"(ab ^ (unsigned)(kb * 64)) : "memory");
+				}
+			}
+			if (sub == 0)
+				dma_block(u + 1); // (past the range: padding rows or the rows behind it, fetched and never used)
+			unsigned rowbits = 0xFFFFFFFFu;
+			if (SEL) {
+				typedef __attribute__((address_space(4))) const unsigned cuint;
+				const long long row0 = r_begin + ((long long)u * CL_SUB + sub) * CL_BN;
+				rowbits = *((cuint *)a.rowmask + (row0 >> 5));
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)"
+			             : "+v"(Y[0]), "+v"(Y[1]), "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[2][0]), "+v"(A[2][1]),
+			               "+v"(A[3][0]), "+v"(A[3][1]));
+			f32x4acc acc[2][2];
+			auto fold = [&](int rb, int t) { // half (t, rb): rows 16 rb + 4 hq + r, column blocks 2 t, 2 t + 1
+#pragma unroll
+				for (int i = 0; i < 2; ++i)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						float v = acc[rb][i][r];
+						if (SEL) // rows the IDSelector rejects are no evidence for the bound
+							v = ((rowbits >> (16 * rb + 4 * hq + r)) & 1u) ? v : -INFINITY;
+						cm[2 * t + i][r] = __builtin_fmaxf(cm[2 * t + i][r], v); // (NaN: ignored)
+					}
+			};
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+#pragma unroll
+				for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+					for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+						for (int i = 0; i < 2; ++i) {
+							if (kb == 0)
+								acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb][rb], bq[2 * t + i][kb], Y[rb], 0, 0, 0);
+							else
+								acc[rb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb][rb], bq[2 * t + i][kb], acc[rb][i], 0, 0, 0);
+						}
+						if (kb == 1 && (t > 0 || rb > 0)) // the previous half, behind this half's MFMAs
+							fold(rb ^ 1, rb == 0 ? t - 1 : t);
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				}
+			}
+			fold(1, 3);
+		}
+		__syncthreads(); // also drains this block's LDS-DMA before the next block reads it
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (ntiles > 0) {
+#pragma unroll
+		for (int cb = 0; cb < 8; ++cb) {
+			const int q = qw + 16 * cb + c;
+			if (q < a.nq) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (cm[cb][r] > -INFINITY) {
+						typedef __attribute__((address_space(1))) unsigned *GU;
+						__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (4 * hq + r), skey(cm[cb][r]), __ATOMIC_RELAXED,
+						                       __HIP_MEMORY_SCOPE_AGENT);
+					}
+			}
+		}
+	}
+}
+static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t nq, hipStream_t st) {
+	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
+	const int64_t nblocks = rows / (CL_SUB * CL_BN); // whole staged blocks of 64 rows
+	if (nblocks <= 0)
+		return;
+	// one round of the 512 resident workgroups where the batch allows it, >= 8 staged blocks per workgroup
+	const int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(8, 512 / nqb), nblocks / 8));
+	a.row_first = 0;
+	a.split_rows = (nblocks + nsplit - 1) / nsplit * (CL_SUB * CL_BN);
+	a.n = nblocks * (CL_SUB * CL_BN);
+	a.nqb = nqb;
+	a.nsplit = (int)((nblocks * (CL_SUB * CL_BN) + a.split_rows - 1) / a.split_rows);
+	const int grid = nqb * a.nsplit;
+	const size_t lds = (size_t)2 * CL_SUB * CL_BN * 256 + 2 * 64 * 4 + 64;
+#define MVS_SEED(L2, SL)                                                                                           \
+	{                                                                                                              \
+		auto kern = flat_bf16_seed_kernel<L2, SL>;                                                                 \
+		ensure_dynamic_lds((const void *)kern, lds);                                                               \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                               \
+	}
+	if (metric == METRIC_L2 && a.rowmask)
+		MVS_SEED(true, true)
+	else if (metric == METRIC_L2)
+		MVS_SEED(true, false)
+	else if (a.rowmask)
+		MVS_SEED(false, true)
+	else
+		MVS_SEED(false, false)
+#undef MVS_SEED
+	MVS_HIP(hipGetLastError());
+}
+
 int collect_slot_stride(int kk) {
 	(void)kk;
 	return 16;
@@ -766,8 +937,15 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.rowmask = d_rowmask;
 	a.opt = g_ksplit_opt;
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
-	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	const int dp1 = collect_store_dims(g.d);
+	if (dp1 == 128 && g_cl_seed_regs) {
+		// d <= 128: class maxima in registers (flat_bf16_seed_kernel) -- cheap enough for 32 768 rows (an eighth of a small index)
+		const int64_t rows = std::min<int64_t>(g_cl_seed_rows > 16384 ? g_cl_seed_rows : 32768, n / 8) / 64 * 64;
+		if (rows >= 1024)
+			launch_collect_seed(metric, a, rows, nq, st);
+		return;
+	}
+	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	if (seed > 0 && seed < n) {
 		if (dp1 > 128)
 			launch_collect_wide_range(dp1, metric, false, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
@@ -826,6 +1004,34 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 		launch_collect_range<true>(g, metric, a, 0, n, nsplit, nq, st, grid_out, nsplit_out);
 	if (lds_out)
 		*lds_out = (int)(dp1 > 128 ? collect_wide_lds_bytes(dp1) : collect_lds_bytes(g));
+}
+
+// ---- stream overflow: the queries that hold more than their share --------------------------------------------------------------
+__global__ void collect_count_queries_kernel(const unsigned long long *__restrict__ stream, long long n, int *__restrict__ qcount) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		atomicAdd(&qcount[(unsigned)(stream[i] >> 32)], 1);
+}
+__global__ void collect_drop_heavy_kernel(const int *__restrict__ qcount, long long nq, int share, float *__restrict__ e2,
+                                          int *__restrict__ fail_cnt, int *__restrict__ fail_q, int *__restrict__ nheavy) {
+	const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nq || qcount[q] <= share || e2[q] != e2[q]) // (NaN: already out)
+		return;
+	e2[q] = __uint_as_float(0x7fc00000u); // NaN: nothing of this query passes any more
+	fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
+	atomicAdd(nheavy, 1);
+}
+// counts the (truncated) stream's entries per query, takes the queries above `share` out of the coarse filter; returns how many
+int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int64_t nq, int share, int *d_qcount /* [nq + 16], zeroed */,
+                              float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st) {
+	hipLaunchKernelGGL(collect_count_queries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_stream, (long long)n, d_qcount);
+	hipLaunchKernelGGL(collect_drop_heavy_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const int *)d_qcount,
+	                   (long long)nq, share, d_e2, d_fail_cnt, d_fail_q, d_qcount + nq);
+	MVS_HIP(hipGetLastError());
+	int nheavy = 0;
+	MVS_HIP(hipMemcpyAsync(&nheavy, d_qcount + nq, sizeof(int), hipMemcpyDeviceToHost, st));
+	MVS_HIP(hipStreamSynchronize(st));
+	return nheavy;
 }
 
 // ---- candidates -> exact values ----------------------------------------------------------------------------------------

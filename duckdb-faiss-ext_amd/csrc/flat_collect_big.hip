@@ -258,11 +258,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
 				for (int i = 0; i < NCB; ++i) {
 					const int f = i * KBT + kb;
-					if (f < NV) {
+					// A column block is accumulated EITHER by the builtin (all its fragments in VGPRs) OR by hand-written MFMAs
+					// (any of them in AGPRs): mixing the two on one accumulator made the compiler copy it between the files with
+					// v_accvgpr_read right in front of a hand-written MFMA -- a VALU write -> MFMA srcC hazard nobody pads.
+					const bool by_hand = (i + 1) * KBT > NV;
+					if (!by_hand) {
 						if (kb == 0) // the chain starts at beta(row): s comes out of the matrix pipe
 							acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], Y, 0, 0, 0);
 						else
 							acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], acc[par][i], 0, 0, 0);
+					} else if (f < NV) { // srcB in VGPRs
+						if (kb == 0)
+							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+							             : "=&v"(acc[par][i])
+							             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]), "v"(Y));
+						else
+							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+							             : "+v"(acc[par][i])
+							             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]));
 					} else { // srcB from an AGPR quad
 						if (kb == 0)
 							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"

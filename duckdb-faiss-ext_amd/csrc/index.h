@@ -177,12 +177,13 @@ public:
 	float *beta_h1 = nullptr;          // [h1_cap + 192] -||y - mu||^2 (L2) or <mu, y> (inner product)
 	float *mu_h1 = nullptr;            // [dp] the centre (mean of the rows present at the first build)
 	int64_t h1_cap = 0, h1_rows = 0;
-	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0;
+	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0, cl_heavy_total = 0;
+	int cl_stream_cap_per_query = 0; // option cl_stream_cap (0: 4096 entries per query, at least 2^20)
 	const unsigned long long *cl_sorted = nullptr;  // the re-scored candidate list of the last coarse-filter batch (in ws_stream)
 	const unsigned long long *tie_sorted = nullptr; // != nullptr: resolve_ip_ties reads A_k off that list instead of scanning again
 	bool tie_from_candidates = true; // option tie_from_candidates = 0: inner-product ties re-scan the database (A/B, tests)
 	bool cl_small_path = true; // batches of <= 256 queries on the one-wavefront-per-segment kernel (option cl_small_path)
-	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask, ws_items1;
+	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask, ws_items1, ws_qcount;
 	void ensure_bf16_rows(hipStream_t st);
 	void ensure_h1_rows(hipStream_t st);
 	// IVF coarse quantisation: the np nearest rows (L2, FAISS order) by distance matrix + selection (csrc/coarse_select.hip);
@@ -316,6 +317,8 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
 void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 int collect_slot_stride(int kk);
+int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int64_t nq, int share, int *d_qcount, float *d_e2,
+                              int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
                             unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, hipStream_t st);
@@ -341,7 +344,7 @@ void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_so
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,
                            int32_t *d_pi1, hipStream_t st);
-extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split;
+extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_regs;
 // csrc/ivf_collect.hip
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
                              float *d_beta, unsigned *d_list_max_bits, hipStream_t st);

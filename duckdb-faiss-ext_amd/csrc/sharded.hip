@@ -367,14 +367,19 @@ public:
 			}
 		}
 		workers.clear();
+		for (int g = 0; g < G && g < (int)ev.size(); ++g)
+			if (ev[g]) {
+				(void)hipSetDevice(devs[g]);
+				(void)hipEventDestroy(ev[g]);
+			}
+		ev.clear();
+		if (ev_x)
+			(void)hipEventDestroy(ev_x);
+		ev_x = nullptr;
 		for (void *c : comms)
 			if (c)
 				Rccl::get().comm_destroy(c);
-		for (hipEvent_t e : ev)
-			if (e)
-				(void)hipEventDestroy(e);
-		if (ev_x)
-			(void)hipEventDestroy(ev_x);
+		comms.clear();
 		for (int g = 0; g < G; ++g) {
 			(void)hipSetDevice(devs[g]);
 			gnum_dev[g].release();

@@ -165,3 +165,112 @@ def test_crafted_hnsw_image_is_rejected(mf, tmp_path):
     q.write_bytes(bytes(bad))
     with pytest.raises(mf.FaissException, match="entry point"):
         mf.read_index(str(q))
+
+
+# ---- two implementations, both directions: tests/faiss_format.py is a pure-Python restatement of the layout
+# that shares no code with csrc/index_io.hip; images it writes from ORACLE state must load and search like the oracle, files
+# the device library writes must parse into the state that was added.  (Not a check against a FAISS-written file: none exists.)
+import faiss_format as ff
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("idmap", [False, True])
+def test_python_written_flat_image_loads_and_searches_like_the_oracle(mf, tmp_path, metric, idmap):
+    d, n = 20, 3000
+    xb, xq = orc.synth_uniform(n, d, 5), orc.synth_uniform(50, d, 6)
+    ids = (np.random.RandomState(1).permutation(5 * n)[:n] + 9).astype(np.int64)
+    img = {"kind": "flat", "metric": metric, "x": xb}
+    if idmap:
+        img = {"kind": "idmap", "metric": metric, "ids": ids, "sub": img}
+    p = tmp_path / "py_flat.index"
+    p.write_bytes(ff.dumps(img))
+    g = mf.read_index(str(p))
+    assert g.ntotal == n and g.d == d and g.metric_type == metric and g.kind == (mf.KIND_IDMAP if idmap else mf.KIND_FLAT)
+    D, I = g.search(xq, 10)
+    Do, Io = orc.flat_search(metric, xb, xq, 10, id_map=ids if idmap else None)
+    assert np.array_equal(I, Io) and np.array_equal(_bits(D), _bits(Do))
+    # ... and what the device writes back is, byte for byte, the image the Python writer made
+    p2 = str(tmp_path / "dev_flat.index")
+    mf.write_index(g, p2)
+    assert open(p2, "rb").read() == p.read_bytes()
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_ivf_images_cross_both_ways(mf, tmp_path, metric, sparse):
+    d, nlist, n = 16, 32 if sparse else 8, 4000
+    xb = orc.synth_clustered(n, d, 21, n_centers=4 if sparse else 16, sigma=0.05 if sparse else 0.2)
+    xq = orc.synth_clustered(60, d, 22, n_centers=4 if sparse else 16, sigma=0.05 if sparse else 0.2)
+    ids = (np.random.RandomState(2).permutation(3 * n)[:n] + 1).astype(np.int64)
+    o = orc.Index(d, f"IVF{nlist},Flat", metric)
+    o.train(xb)
+    o.add_with_ids(xb, ids)
+    lists = [o.ivf_list(l) for l in range(nlist)]
+    if sparse:
+        assert sum(1 for i, _ in lists if len(i)) <= nlist // 2  # the "sprs" size table
+    img = {"kind": "ivfflat", "d": d, "metric": metric, "is_trained": True, "nprobe": 1, "lists": lists,
+           "quantizer": {"kind": "flat", "metric": metric if metric == IP else L2, "x": o.ivf_centroids()}}
+    p = tmp_path / "py_ivf.index"
+    p.write_bytes(ff.dumps(img))
+    g = mf.read_index(str(p))  # Python image -> device
+    assert g.ntotal == n and g.is_trained and g.nlist == nlist
+    for nprobe in (1, 5):
+        D, I = g.search(xq, 10, nprobe=nprobe)
+        Do, Io = o.search(xq, 10, nprobe=nprobe)
+        assert np.array_equal(I, Io) and np.array_equal(_bits(D), _bits(Do)), nprobe
+    g2 = mf.index_factory(d, f"IVF{nlist},Flat", metric)  # device-built -> file -> Python parser
+    g2.ivf_set_centroids(o.ivf_centroids())
+    g2.add_with_ids(xb, ids)
+    p2 = str(tmp_path / "dev_ivf.index")
+    mf.write_index(g2, p2)
+    back = ff.loads(open(p2, "rb").read())
+    assert back["kind"] == "ivfflat" and back["nlist"] == nlist and back["ntotal"] == n and back["metric"] == metric
+    assert back["list_type"] == ("sprs" if sparse else "full")
+    assert np.array_equal(_bits(back["quantizer"]["x"]), _bits(o.ivf_centroids()))
+    for (i0, c0), (i1, c1) in zip(lists, back["lists"]):
+        assert np.array_equal(i0, i1) and np.array_equal(_bits(c0), _bits(c1))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("idmap", [False, True])
+def test_hnsw_images_cross_both_ways(mf, tmp_path, metric, idmap):
+    d, M, n = 24, 8, 1500
+    xb, xq = orc.synth_uniform(n, d, 31) - 0.3, orc.synth_uniform(40, d, 32) - 0.3
+    ids = (np.random.RandomState(3).permutation(4 * n)[:n] + 5).astype(np.int64)
+    o = orc.Index(d, ("IDMap," if idmap else "") + f"HNSW{M}", metric)
+    o.add_with_ids(xb, ids) if idmap else o.add(xb)
+    go = o.hnsw_graph()
+    probas, cum = ff.hnsw_level_tables(M)
+    graph = dict(go, assign_probas=probas, cum_nneighbor_per_level=cum, efConstruction=40, efSearch=16)
+    img = {"kind": "hnswflat", "metric": metric, "graph": graph, "storage": {"kind": "flat", "metric": metric, "x": xb}}
+    if idmap:
+        img = {"kind": "idmap", "metric": metric, "ids": ids, "sub": dict(img, d=d)}
+    p = tmp_path / "py_hnsw.index"
+    p.write_bytes(ff.dumps(img))
+    g = mf.read_index(str(p))  # the oracle's graph through the Python writer into the device walk
+    assert g.ntotal == n
+    gg = g.hnsw_graph()
+    assert np.array_equal(gg["neighbors"], go["neighbors"]) and gg["entry_point"] == go["entry_point"] and gg["max_level"] == go["max_level"]
+    for efs in (16, 64):
+        D, I = g.search(xq, 10, efSearch=efs)
+        Do, Io = o.search(xq, 10, efSearch=efs)
+        assert np.array_equal(I, Io) and np.array_equal(_bits(D), _bits(Do)), efs
+    g2 = mf.index_factory(d, ("IDMap," if idmap else "") + f"HNSW{M}", metric)  # device-built (single-wave order) -> Python parser
+    g2.set_option("hnsw_build_waves", 1)
+    g2.add_with_ids(xb, ids) if idmap else g2.add(xb)
+    p2 = str(tmp_path / "dev_hnsw.index")
+    mf.write_index(g2, p2)
+    back = ff.loads(open(p2, "rb").read())
+    h = back["sub"] if idmap else back
+    if idmap:
+        assert back["kind"] == "idmap" and np.array_equal(back["ids"], ids)
+    assert h["kind"] == "hnswflat" and h["metric"] == metric and h["ntotal"] == n
+    bg = h["graph"]
+    assert np.array_equal(bg["neighbors"], go["neighbors"]) and np.array_equal(bg["levels"], go["levels"])
+    assert np.array_equal(bg["offsets"].astype(np.int64), go["offsets"]) and bg["entry_point"] == go["entry_point"]
+    assert np.allclose(bg["assign_probas"], probas, rtol=1e-12) and np.array_equal(bg["cum_nneighbor_per_level"], cum)
+    assert (bg["efConstruction"], bg["upper_beam"]) == (40, 1) and np.array_equal(_bits(h["storage"]["x"]), _bits(xb))

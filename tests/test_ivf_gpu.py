@@ -577,7 +577,7 @@ def test_ivf_exact_ties_follow_the_heap(mf, metric, desc, d):
         if k == 10 and nprobe == 4 and sel is None and not opts:
             Dk1, _ = o.search(xq[:nq], k + 1, nprobe=nprobe)
             assert (Dk1[:, k - 1] == Dk1[:, k]).mean() > 0.2  # the boundary case is really exercised
-    assert len(seen) >= 3, seen
+    assert len(seen) >= (3 if d <= 128 else 2), seen  # (d > 128: no coarse filter, no f32 MFMA items)
 
 
 def test_ivf_exact_ties_option_off_keeps_the_pure_order(mf):

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""How much the headline's rate depends on the DATA: the bf16 coarse filter admits every row within 2E of
+the running bound, and E scales with the norms of the centred vectors -- so candidates per query, fall-backs and QPS are
+properties of the data shape as much as of the kernel.  FlatL2 d=128 N=10M nq=10k k=10 (N, metric via env) on:
+  uniform        U[0,1)^d                                     (the headline)
+  clustered      Gaussian mixture, 1024 centres, sigma 0.1    (C3's rows)
+  normalised     clustered sigma 1.0, rows and queries L2-normalised (embedding-like)
+  offset         U[0,1)^d + 3                                 (large common mean: the centring must remove it)
+  integer        small integers 0..15                         (exact ties everywhere)
+  dup10          uniform with 10 % of the rows duplicated
+  sift_like      integer 0..255 coordinates with exponential magnitudes: norms spread over a decade (SIFT descriptors)
+  all_dup        64 distinct vectors repeated                 (the stream overflows: what the fall-back costs)
+For each: ms per 10k batch, QPS, candidates re-scored per query, stream overflows, queries re-run on the exact kernel, and
+whether labels AND distances equal the exact f32 kernel's on a 512-query sample (prefilter = 0)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
+import numpy as np, torch
+import mi355_faiss as mf
+
+n, d, nq, k = int(os.environ.get("N", 10_000_000)), 128, 10_000, 10
+metric = mf.METRIC_L2 if os.environ.get("METRIC", "L2") == "L2" else mf.METRIC_INNER_PRODUCT
+dev = "cuda:0"
+
+
+def rows(kind, m, seed, row0):
+    if kind == "uniform":
+        return mf.synth_uniform_torch(m, d, seed, row0=row0)
+    if kind == "clustered":
+        return mf.synth_clustered_torch(m, d, seed, row0=row0, n_centers=1024, sigma=0.1)
+    if kind == "normalised":
+        x = mf.synth_clustered_torch(m, d, seed, row0=row0, n_centers=1024, sigma=1.0)
+        return x / x.norm(dim=1, keepdim=True)
+    if kind == "offset":
+        return mf.synth_uniform_torch(m, d, seed, row0=row0) + 3.0
+    if kind == "integer":
+        return torch.floor(mf.synth_uniform_torch(m, d, seed, row0=row0) * 16.0)
+    if kind == "dup10":
+        x = mf.synth_uniform_torch(m, d, seed, row0=row0)
+        g = torch.Generator(device=dev); g.manual_seed(seed * 7919 + row0)
+        idx = torch.randperm(m, device=dev, generator=g)[: m // 10]
+        x[idx] = x[(idx + 12345) % m]
+        return x
+    if kind == "sift_like":
+        u = mf.synth_uniform_torch(m, d, seed, row0=row0)
+        s = mf.synth_uniform_torch(m, 1, seed + 99, row0=row0)
+        return torch.floor(torch.clamp(-torch.log(1.0 - u) * (20.0 + 60.0 * s), max=255.0))
+    if kind == "all_dup":
+        base = mf.synth_uniform_torch(64, d, seed)
+        return base[(torch.arange(m, device=dev) + row0) % 64].contiguous()
+    raise ValueError(kind)
+
+
+print(f"# coarse-filter data sensitivity: Flat{os.environ.get('METRIC', 'L2')} d={d} N={n} nq={nq} k={k}")
+print(f"{'data':<11} {'ms/batch':>9} {'QPS':>9} {'cand/query':>11} {'overflows':>9} {'exact re-runs':>13} {'kernel':<28} bit-exact vs f32 kernel (512 q)")
+for kind in os.environ.get("KINDS", "uniform clustered normalised offset integer dup10 sift_like all_dup").split():
+    ix = mf.index_factory(d, "Flat", metric)
+    for s0 in range(0, n, 1 << 20):
+        ix.add_torch(rows(kind, min(1 << 20, n - s0), 1234, s0)); torch.cuda.synchronize()
+    xq = rows(kind, nq, 4321, 0).contiguous()
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev); I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    ix.search_torch(xq, k, D=D, I=I); torch.cuda.synchronize()
+    c0, p0 = ix.collect_stats(), ix.prefilter_stats()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ix.search_torch(xq, k, D=D, I=I)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    c1, p1 = ix.collect_stats(), ix.prefilter_stats()
+    name = ix.last_kernel_info()["name"]
+    cand = (c1["candidates"] - c0["candidates"]) / max(c1["queries"] - c0["queries"], 1)
+    ovf = (c1["overflows"] - c0["overflows"]) / reps
+    fb = (p1["fallback_queries"] - p0["fallback_queries"]) / reps
+    ix.set_option("prefilter", 0)
+    De, Ie = ix.search_torch(xq[:512].contiguous(), k); torch.cuda.synchronize()
+    same = bool(torch.equal(Ie, I[:512]) and torch.equal(De.view(torch.int32), D[:512].view(torch.int32)))
+    print(f"{kind:<11} {ms:9.2f} {nq / ms * 1e3:9.0f} {cand:11.1f} {ovf:9.1f} {fb:13.1f} {name:<28} {same}", flush=True)
+    del ix
+    torch.cuda.empty_cache()
