@@ -17,10 +17,13 @@
 //               accumulator is written once per NCB MFMAs (>= 48 cycles apart) and read by the vector ALU only behind a
 //               scheduling barrier one tile later (or behind explicit s_nops after the last tile).
 //   workgroup   4 waves = one per SIMD, one workgroup per CU: 256 (192) queries share every tile the CU stages
-//   tiles       16 rows x (64 KBT) bytes, a ring of three stages filled by LDS-DMA two tiles ahead; ONE barrier per tile whose
-//               s_waitcnt counts the newest tile's loads, so two tiles stay in flight across it
+//   tiles       16 rows x (64 KBT) bytes, a ring of FOUR stages filled by LDS-DMA three tiles ahead.  A lone wave has nobody
+//               else to fill its matrix pipe, so nothing may sit between two tiles' MFMAs: the tile's ONE barrier stands in the
+//               MIDDLE of its MFMA loop (in front of k-block 8; its s_waitcnt lets the newest block's loads stay in flight),
+//               the LDS-DMA instructions of block u + 3 (~100 issue cycles each) are spread one per two k-blocks behind it,
+//               and the first fragments (and beta) of tile u + 1 are read from LDS under the last MFMAs of tile u
 //   epilogue    running maxima + bound test of tile u - 1 run on the vector ALU behind the first MFMAs of tile u (two
-//               accumulator sets, the tile loop unrolled by two): a lone wave has nobody else to fill its matrix pipe
+//               accumulator sets, the tile loop unrolled by two)
 #include "flat_collect.h"
 
 #include <algorithm>
@@ -37,12 +40,13 @@ template <int KBT, int NCB, bool IS_L2, bool COLLECT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_bf16_big_kernel(const CollectArgs a) {
 	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
 	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB (768 dims) / 32 KB (1024)
-	constexpr int NST = 3;
+	constexpr int NST = 4, KB_BAR = 8;
 	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096;
 	constexpr int QW = 16 * NCB, QB = 4 * QW;
 	constexpr int RA = 4, RING = 8; // A fragments read RA k-blocks ahead into a ring of RING register quads
 	constexpr int FLUSH_EVERY = 8;
-	static_assert(STAGE_BYTES % 4096 == 0 && KBT % 4 == 0 && NCB >= 2 && NCB <= 4 && RA < RING, "geometry");
+	static_assert(STAGE_BYTES % 4096 == 0 && KBT % RING == 0 && NCB >= 2 && NCB <= 4 && RA < RING, "geometry");
+	static_assert(KB_BAR + 2 * DMA_PER_WAVE < KBT + 1 && KB_BAR < KBT - RA, "the block's LDS-DMA instructions fit behind the barrier");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
 	char *tbuf = (char *)smem;                                          // [NST][STAGE_BYTES]
@@ -98,23 +102,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 	// LDS-DMA (as flat_collect_wide.hip): instruction inst = 4 i + wave fills LDS bytes [1024 inst, +1024) of the stage; lane l owns
 	// 16-byte slot S = 64 inst + l = (row r = S / C, position p = S % C) and fetches chunk (p & ~15) | ((p & 15) ^ (r & 15))
-	auto dma_block = [&](int u, int stg) {
+	auto dma_one = [&](int u, int stg, int i) {
 		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)u * RT) * PITCH; // uniform
-#pragma unroll
-		for (int i = 0; i < DMA_PER_WAVE; ++i) {
-			const int inst = 4 * i + wave;
-			const int S = 64 * inst + lane, r = S / C, p = S - r * C;
-			const unsigned off = (unsigned)(r * PITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
-			__builtin_amdgcn_global_load_lds((glb_f32c *)(base + off), (lds_f32c *)(smem + (stg * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
-		}
-		if (wave == 0) {
-			const float *bb = a.yn + (r_begin + (long long)u * RT); // uniform
-			__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (NST * STAGE_BYTES) / 4 + stg * 64), 4, 0, 0);
-		}
+		const int inst = 4 * i + wave;
+		const int S = 64 * inst + lane, r = S / C, p = S - r * C;
+		const unsigned off = (unsigned)(r * PITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + off), (lds_f32c *)(smem + (stg * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
+	};
+	auto dma_beta = [&](int u, int stg) { // wave 0 only
+		const float *bb = a.yn + (r_begin + (long long)u * RT); // uniform
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (NST * STAGE_BYTES) / 4 + stg * 64), 4, 0, 0);
 	};
 	if (nblocks > 0) {
-		dma_block(0, 0);
-		dma_block(1, 1);
+#pragma unroll
+		for (int b = 0; b < 3; ++b) {
+#pragma unroll
+			for (int i = 0; i < DMA_PER_WAVE; ++i)
+				dma_one(b, b, i);
+			if (wave == 0)
+				dma_beta(b, b);
+		}
 	}
 	__syncthreads();
 
@@ -224,108 +231,123 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 	f32x4b acc[2][NCB]; // two accumulator sets: tile u lives in acc[u & 1] while tile u - 1 (the other set) is tested
 	f32x4n pcq = {0.f, 0.f, 0.f, 0.f}; // the bounds tile u - 1 was scanned under
-	int stg = 0;
+	bf16x8 A[RING];                    // A fragments: k-block kb of the current tile in A[kb % RING], read RA k-blocks ahead -- across tiles
+	f32x4n Yv[2];                      // beta of the tile's rows, by tile parity
+	int stg = 0;                       // stage of tile u = u & 3
+	// A fragment (k-block kb) of a staged tile: byte c * PITCH + 256 (kb >> 2) + (rb16 ^ (64 (kb & 3)))
+	auto read_a = [&](bf16x8 &dst, int stage, int kb) {
+		const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + (stage * STAGE_BYTES) / 4)) + rbase;
+		asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((tb ^ (unsigned)((kb & 3) * 64)) + (unsigned)((kb >> 2) * 256)) : "memory");
+	};
+	auto read_y = [&](f32x4n &dst, int stage) {
+		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + stage * 64 + 4 * hq));
+		asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(nb_lds) : "memory");
+	};
+	if (nblocks > 0) { // tile 0's beta and first fragments
+		read_y(Yv[0], 0);
+#pragma unroll
+		for (int kb = 0; kb < RA; ++kb)
+			read_a(A[kb], 0, kb);
+	}
 	// one tile; PAR = u & 1 as a compile-time constant (the accumulator sets must be registers, not an indexed array)
 	auto tile = [&](auto parc, const int u) {
 		constexpr int par = decltype(parc)::value;
-		{
-			const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
-			if ((u % period) == 0)
-				refresh();
-			dma_block(u + 2, stg == 0 ? 2 : stg - 1); // the stage tile u - 1 left at the last barrier
-			const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + (stg * STAGE_BYTES) / 4)) + rbase;
-			const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + stg * 64 + 4 * hq));
-			f32x4n Y, cqv;
-			asm volatile("ds_read_b128 %0, %1" : "=v"(Y) : "v"(nb_lds) : "memory");
-			asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds) : "memory");
-			// A fragment (k-block kb) of the tile's 16 rows: byte c * PITCH + 256 (kb >> 2) + (rb16 ^ (64 (kb & 3)))
-			bf16x8 A[RING];
+		const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
+		if ((u % period) == 0)
+			refresh();
+		const int nstg = (stg + 1) & 3, dstg = (stg + 3) & 3; // tile u + 1's stage; block u + 3 goes where tile u - 1 was
+		f32x4n cqv;
+		bool any_prev = false;
 #pragma unroll
-			for (int kb = 0; kb < RA; ++kb)
-				asm volatile("ds_read_b128 %0, %1" : "=v"(A[kb % RING]) : "v"((tb ^ (unsigned)((kb & 3) * 64)) + (unsigned)((kb >> 2) * 256)) : "memory");
-			bool any_prev = false;
+		for (int kb = 0; kb < KBT; ++kb) {
+			if (kb == KB_BAR) {
+				// block u + 1 has landed for every wave (the newest block -- u + 2, this wave's last DMA_PER_WAVE (+ 1: beta) loads,
+				// nothing else is in flight, loads return in order -- stays in flight); everybody is done with tile u - 1's stage
+				if (wave == 0)
+					asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 1) : "memory");
+				else
+					asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
+			}
+			if (kb > KB_BAR && ((kb - KB_BAR) & 1) && (kb - KB_BAR) / 2 < DMA_PER_WAVE)
+				dma_one(u + 3, dstg, (kb - KB_BAR) / 2); // one LDS-DMA instruction per two k-blocks: its issue hides under their MFMAs
+			if (kb == KB_BAR + 2 && wave == 0)
+				dma_beta(u + 3, dstg);
+			if (kb == 2)
+				asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds) : "memory"); // this tile's bounds (tested one tile later)
+			if (kb == KBT - RA)
+				read_y(Yv[par ^ 1], nstg);
+			if (kb + RA < KBT)
+				read_a(A[(kb + RA) % RING], stg, kb + RA);
+			else
+				read_a(A[(kb + RA) % RING], nstg, kb + RA - KBT); // the next tile's first fragments (its block landed at the barrier)
+			// LDS returns in order: with RA reads younger than fragment kb outstanding, kb (and everything older) has arrived
+			asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(RA));
 #pragma unroll
-			for (int kb = 0; kb < KBT; ++kb) {
-				if (kb + RA < KBT) {
-					const int k2 = kb + RA;
-					asm volatile("ds_read_b128 %0, %1" : "=v"(A[k2 % RING]) : "v"((tb ^ (unsigned)((k2 & 3) * 64)) + (unsigned)((k2 >> 2) * 256)) : "memory");
-					// LDS returns in order: with RA reads younger than fragment kb outstanding, kb (and, the first time, beta and
-					// the bounds) has arrived
-					asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Y), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(RA));
-				} else {
-					asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A[kb % RING]), "+v"(A[(kb + 1) % RING]) : "n"(KBT - 1 - kb < RA ? KBT - 1 - kb : RA));
+			for (int i = 0; i < NCB; ++i) {
+				const int f = i * KBT + kb;
+				// A column block is accumulated EITHER by the builtin (all its fragments in VGPRs) OR by hand-written MFMAs
+				// (any of them in AGPRs): mixing the two on one accumulator made the compiler copy it between the files with
+				// v_accvgpr_read right in front of a hand-written MFMA -- a VALU write -> MFMA srcC hazard nobody pads.
+				const bool by_hand = (i + 1) * KBT > NV;
+				if (!by_hand) {
+					if (kb == 0) // the chain starts at beta(row): s comes out of the matrix pipe
+						acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], Yv[par], 0, 0, 0);
+					else
+						acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], acc[par][i], 0, 0, 0);
+				} else if (f < NV) { // srcB in VGPRs
+					if (kb == 0)
+						asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+						             : "=&v"(acc[par][i])
+						             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]), "v"(Yv[par]));
+					else
+						asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+						             : "+v"(acc[par][i])
+						             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]));
+				} else { // srcB from an AGPR quad
+					if (kb == 0)
+						asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
+						             : "=&v"(acc[par][i])
+						             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]), "v"(Yv[par]));
+					else
+						asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+						             : "+v"(acc[par][i])
+						             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]));
 				}
+			}
+			if (kb == 1 && u > 0) { // tile u - 1's running maxima against its bounds, behind this tile's first MFMAs
 #pragma unroll
 				for (int i = 0; i < NCB; ++i) {
-					const int f = i * KBT + kb;
-					// A column block is accumulated EITHER by the builtin (all its fragments in VGPRs) OR by hand-written MFMAs
-					// (any of them in AGPRs): mixing the two on one accumulator made the compiler copy it between the files with
-					// v_accvgpr_read right in front of a hand-written MFMA -- a VALU write -> MFMA srcC hazard nobody pads.
-					const bool by_hand = (i + 1) * KBT > NV;
-					if (!by_hand) {
-						if (kb == 0) // the chain starts at beta(row): s comes out of the matrix pipe
-							acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], Y, 0, 0, 0);
-						else
-							acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], acc[par][i], 0, 0, 0);
-					} else if (f < NV) { // srcB in VGPRs
-						if (kb == 0)
-							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
-							             : "=&v"(acc[par][i])
-							             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]), "v"(Y));
-						else
-							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
-							             : "+v"(acc[par][i])
-							             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]));
-					} else { // srcB from an AGPR quad
-						if (kb == 0)
-							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
-							             : "=&v"(acc[par][i])
-							             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]), "v"(Y));
-						else
-							asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
-							             : "+v"(acc[par][i])
-							             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]));
-					}
+					const f32x4b &sv = acc[par ^ 1][i];
+					const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
+					any_prev = any_prev || (mx >= pcq[i]);
 				}
-				if (kb == 1 && u > 0) { // tile u - 1's running maxima against its bounds, behind this tile's first MFMAs
-#pragma unroll
-					for (int i = 0; i < NCB; ++i) {
-						const f32x4b &s = acc[par ^ 1][i];
-						const float mx = __builtin_fmaxf(__builtin_fmaxf(s[0], s[1]), __builtin_fmaxf(s[2], s[3]));
-						any_prev = any_prev || (mx >= pcq[i]);
-					}
-				}
-				__builtin_amdgcn_sched_barrier(0);
 			}
-			if (u > 0 && __builtin_amdgcn_ballot_w64(any_prev) != 0ull) {
-				const long long prow0 = r_begin + (long long)(u - 1) * RT;
-				const int pnvalid = (int)((r_end - prow0) < RT ? (r_end - prow0) : RT);
-				rare(acc[par ^ 1], pcq, prow0, pnvalid);
-			}
-			pcq = cqv;
-			// block u + 1 has landed, this stage is free again; the newest block (the last DMA_PER_WAVE (+ 1: beta) loads of this
-			// wave -- nothing else is in flight, loads return in order) stays in flight across the barrier
-			if (wave == 0)
-				asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 1) : "memory");
-			else
-				asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
-			stg = stg == 2 ? 0 : stg + 1;
-			if (COLLECT && (u % FLUSH_EVERY) == FLUSH_EVERY - 1 && u != nblocks - 1) {
-				const unsigned fill = qctl[0];
-				__syncthreads(); // everybody has read the same fill before anyone appends again
-				const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
-				if (n >= (unsigned)CL_QCAP / 2) {
-					if (tid == 0) {
-						*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
-						qctl[0] = 0u;
-					}
-					__syncthreads();
-					const unsigned long long base = *(const unsigned long long *)(qctl + 2);
-					for (unsigned i = tid; i < n; i += 256)
-						if ((long long)(base + i) < a.stream_cap)
-							a.stream[base + i] = qbuf[i];
-					__syncthreads();
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (u > 0 && __builtin_amdgcn_ballot_w64(any_prev) != 0ull) {
+			const long long prow0 = r_begin + (long long)(u - 1) * RT;
+			const int pnvalid = (int)((r_end - prow0) < RT ? (r_end - prow0) : RT);
+			rare(acc[par ^ 1], pcq, prow0, pnvalid);
+		}
+		pcq = cqv;
+		stg = nstg;
+		if (COLLECT && (u % FLUSH_EVERY) == FLUSH_EVERY - 1 && u != nblocks - 1) {
+			// (the fragments read ahead for the next tile are in registers; the compiled LDS accesses below make hipcc drain the
+			// LDS-DMA in flight first -- once per FLUSH_EVERY tiles)
+			const unsigned fill = qctl[0];
+			__syncthreads(); // everybody has read the same fill before anyone appends again
+			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
+			if (n >= (unsigned)CL_QCAP / 2) {
+				if (tid == 0) {
+					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+					qctl[0] = 0u;
 				}
+				__syncthreads();
+				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
+				for (unsigned i = tid; i < n; i += 256)
+					if ((long long)(base + i) < a.stream_cap)
+						a.stream[base + i] = qbuf[i];
+				__syncthreads();
 			}
 		}
 	};
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		if (u0 + 1 < nblocks)
 			tile(std::integral_constant<int, 1>{}, u0 + 1);
 	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the blocks fetched past the split's end)
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // (the blocks fetched and the fragments read past the split's end)
 	// (the hand-written MFMAs have drained before the vector ALU reads their accumulators: >= 19 wait states on gfx950)
 	asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 	auto last_tile = [&](auto parc) { // the last tile's test (its accumulator set as a compile-time constant)
@@ -381,7 +403,7 @@ int collect_big_qblock(int dp1) {
 	return 4 * 16 * collect_big_ncb(dp1);
 }
 size_t collect_big_lds_bytes(int dp1) {
-	return (size_t)3 * (16 * dp1 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
+	return (size_t)4 * (16 * dp1 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
 }
 
 template <int KBT, int NCB>

@@ -169,6 +169,102 @@ __device__ __forceinline__ float eval_lanes(const QV<NI> &q, const float *vecs, 
 	return mydd;
 }
 
+// ---- bf16 FIRST LOOK (search only; option hnsw_bf16) ---------------------------------------------------------------------------
+// A second copy of the rows in bf16 (half the bytes).  Most neighbours of a hop are evaluated only to be thrown away: once the
+// candidate set is full a neighbour matters only if its distance is below the worst candidate (or below the worst result, under
+// a selector).  The walk therefore first computes every fresh neighbour's distance against the bf16 row and fetches the f32 row
+// only when the EXACT distance could still be below that threshold thr:
+//   L2   a = sum (q_i - y~_i)^2, y~ = bf16(y):  |a - D| <= 2^-7 ||y|| sqrt(D) + 2^-16 ||y||^2  (bf16 keeps 8 significant bits:
+//        |y~_i - y_i| <= 2^-8 |y_i|; Cauchy-Schwarz), so D < thr implies a < thr + c1 sqrt(thr) + c2: a neighbour with
+//        a >= thr' + c1 sqrt(thr') + c2, thr' = thr (1 + 1e-5), c1 = 2^-7 Ymax, c2 = 2^-16 Ymax^2 (Ymax = the largest row norm of
+//        the index, margins for the f32 arithmetic of both sums included) is skipped -- it could not have changed any set;
+//   IP   a = -<q, y~>:  |a - D| <= 2^-8 ||q|| ||y||: skipped when a >= thr + |thr| 1e-5 + (2^-8 + 2^-13) ||q|| Ymax.
+// Every neighbour that passes gets the usual exact evaluation, so the walk's decisions -- and its results, bit for bit -- are those
+// of the f32-only walk and of the oracle; "distance evaluations" keeps counting every fresh neighbour (what FAISS evaluates).
+template <int NI>
+struct QVH {
+	uint2 v[NI]; // 4 bf16 per lane and step
+};
+template <int NI>
+__device__ __forceinline__ void load_row_bf(QVH<NI> &y, const unsigned short *row, int dp4, int lane) {
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		const int idx = lane + 64 * i;
+		y.v[i] = idx < dp4 ? reinterpret_cast<const uint2 *>(row)[idx] : make_uint2(0u, 0u);
+	}
+}
+template <int NI, bool IS_L2>
+__device__ __forceinline__ float lane_partial_bf(const QV<NI> &q, const QVH<NI> &y) {
+	float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+	for (int i = 0; i < NI; i++) {
+		const float y0 = __uint_as_float(y.v[i].x << 16), y1 = __uint_as_float(y.v[i].x & 0xffff0000u);
+		const float y2 = __uint_as_float(y.v[i].y << 16), y3 = __uint_as_float(y.v[i].y & 0xffff0000u);
+		if (IS_L2) {
+			const float t0 = q.v[i].x - y0, t1 = q.v[i].y - y1, t2 = q.v[i].z - y2, t3 = q.v[i].w - y3;
+			a0 = fmaf(t0, t0, a0);
+			a1 = fmaf(t1, t1, a1);
+			a2 = fmaf(t2, t2, a2);
+			a3 = fmaf(t3, t3, a3);
+		} else {
+			a0 = fmaf(q.v[i].x, y0, a0);
+			a1 = fmaf(q.v[i].y, y1, a1);
+			a2 = fmaf(q.v[i].z, y2, a2);
+			a3 = fmaf(q.v[i].w, y3, a3);
+		}
+	}
+	return (a0 + a1) + (a2 + a3);
+}
+// approximate distances from q to the bf16 rows nid[l] of the lanes l in `mask` (structure of eval_lanes)
+template <int NI, bool IS_L2, int G>
+__device__ __forceinline__ float eval_lanes_bf(const QV<NI> &q, const unsigned short *vbf, int dp4, int nid, u64 mask, int lane) {
+	float mydd = 0.f;
+	while (mask) {
+		int ls[G], ids[G];
+		ls[0] = (int)__builtin_ctzll(mask);
+		mask &= mask - 1;
+#pragma unroll
+		for (int g = 1; g < G; g++) {
+			const bool more = mask != 0;
+			const int l = more ? (int)__builtin_ctzll(mask) : ls[0];
+			ls[g] = more ? l : -1;
+			mask = more ? (mask & (mask - 1)) : mask;
+			ids[g] = __builtin_amdgcn_readlane(nid, l);
+		}
+		ids[0] = __builtin_amdgcn_readlane(nid, ls[0]);
+		QVH<NI> y[G];
+#pragma unroll
+		for (int g = 0; g < G; g++)
+			load_row_bf(y[g], vbf + (size_t)ids[g] * dp4 * 4, dp4, lane);
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			const float t = wave_sum(lane_partial_bf<NI, IS_L2>(q, y[g]));
+			if (lane == ls[g])
+				mydd = IS_L2 ? t : -t;
+		}
+	}
+	return mydd;
+}
+// rows [r0, r1) of the f32 store -> bf16 copy; the largest squared row norm (float bits, atomicMax)
+__global__ void hnsw_rows_to_bf16_kernel(const float *__restrict__ vecs, long long r0, long long r1, int dp,
+                                         unsigned short *__restrict__ out, unsigned *__restrict__ max_bits) {
+	const long long r = r0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (r >= r1)
+		return;
+	float n2 = 0.f;
+	for (int c = lane; c < dp; c += 64) {
+		const float v = vecs[(size_t)r * dp + c];
+		const __bf16 h = (__bf16)v;
+		out[(size_t)r * dp + c] = *reinterpret_cast<const unsigned short *>(&h);
+		n2 = fmaf(v, v, n2);
+	}
+	for (int o = 32; o >= 1; o >>= 1)
+		n2 += __shfl_xor(n2, o);
+	if (lane == 0 && __float_as_uint(n2) > *max_bits)
+		atomicMax(max_bits, __float_as_uint(n2)); // (>= 0: the bit pattern orders like the value; NaN sorts above everything)
+}
+
 // keys[0..n) ascending; inserts nk, keeps at most cap entries (the largest falls off).  Returns the new count.
 __device__ __forceinline__ int sorted_insert(u64 *keys, int n, int cap, u64 nk, int lane) {
 	if (cap <= 256) {
@@ -416,10 +512,12 @@ struct SearchArgs {
 	int *counter;     // dynamic query queue (walk lengths vary a lot between queries)
 	float *D;
 	long long *I;
-	unsigned long long *stats; // [0] distance evaluations, [1] expanded vertices
+	unsigned long long *stats; // [0] distance evaluations, [1] expanded vertices, [9] f32 rows fetched (bf16 first look)
+	const unsigned short *vbf; // bf16 copy of the rows (BF instances)
+	const unsigned *ymax_bits; // largest squared row norm (float bits)
 };
 
-template <int NI, bool IS_L2, int G>
+template <int NI, bool IS_L2, int G, bool BF = false>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 	extern __shared__ u64 smem[];
 	u64 *ckeys = smem + a.hsize / 2; // MinimaxHeap candidates(ef); the visited hash sits in front (16-byte aligned)
@@ -437,6 +535,14 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 	unsigned long long p_desc = 0, p_pop = 0, p_nbr = 0, p_vis = 0, p_eval = 0, p_ins = 0, p_total = 0;
 	(void)p_desc, (void)p_pop, (void)p_nbr, (void)p_vis, (void)p_eval, (void)p_ins, (void)p_total;
 	const int ef = a.ef, k = a.k;
+	unsigned nf32 = 0;
+	float bf_c1 = 0.f, bf_c2 = 0.f, ymax = 0.f;
+	if (BF) {
+		const float y2 = __uint_as_float(*a.ymax_bits) * 1.0001f;
+		ymax = sqrtf(y2) * 1.0001f;
+		bf_c1 = 0.0078125f * ymax * 1.001f;
+		bf_c2 = 1.52587890625e-05f * y2 * 1.01f;
+	}
 	for (;;) {
 		int qn = 0;
 		if (lane == 0)
@@ -456,6 +562,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 		const unsigned long long tq0 = PROF_NOW();
 		QV<NI> q;
 		load_row(q, a.xq + (size_t)qi * g.dp4 * 4, g.dp4, lane);
+		float bf_eip = 0.f; // inner product: (2^-8 + 2^-13) ||q|| Ymax
+		if (BF && !IS_L2)
+			bf_eip = (0.00390625f + 0.0001220703125f) * sqrtf(rflf(wave_sum(lane_partial<NI, false>(q, q))) * 1.0001f) * ymax;
 		int nearest = a.entry_point;
 		float d_nearest = wave_dist1<NI, IS_L2>(q, g.vecs, g.dp4, nearest, lane);
 		ndis++;
@@ -520,13 +629,32 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 				const unsigned long long t4 = PROF_NOW();
 				PROF_ADD(p_vis, t3, t4);
 				ndis += (unsigned)__popcll(fmask);
-				const float mydd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, fmask, lane);
+				const float cmax = nc < ef ? FLT_MAX : key_dis(rfl64(ckeys[ef - 1]));
+				u64 need = fmask;
+				if (BF && fmask != 0ull) {
+					// a neighbour matters only below the worst candidate or (selectors) the worst result: nothing to skip until both
+					// sets are full
+					const float thr = fmaxf(cmax, rthr);
+					if (thr < FLT_MAX) {
+						const float ap = eval_lanes_bf<NI, IS_L2, G>(q, a.vbf, g.dp4, nid, fmask, lane);
+						float lim;
+						if (IS_L2) {
+							const float t = thr * 1.00001f;
+							lim = (t + bf_c1 * sqrtf(t) + bf_c2) * 1.00001f;
+						} else {
+							lim = thr + fabsf(thr) * 1e-5f + bf_eip;
+						}
+						need = fmask & ~__builtin_amdgcn_ballot_w64(fresh && ap >= lim); // (NaN: not skipped)
+					}
+					nf32 += (unsigned)__popcll(need);
+				}
+				const float exd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, need, lane);
+				const float mydd = (!BF || ((need >> lane) & 1ull)) ? exd : FLT_MAX; // skipped: beyond every threshold
 				const unsigned long long t5 = PROF_NOW();
 				PROF_ADD(p_eval, t4, t5);
 				bool pass = fresh;
 				if (fresh && a.sel.kind != MVS_SEL_NONE)
 					pass = sel_member_dev(a.sel, a.idmap ? a.idmap[nid] : nid);
-				const float cmax = nc < ef ? FLT_MAX : key_dis(rfl64(ckeys[ef - 1]));
 				// thresholds only ever tighten, so lanes rejected now stay rejected during the sequential pass
 				const bool maybe = fresh && (nc < ef || mydd < cmax || (pass && mydd < rthr));
 				u64 mm = __builtin_amdgcn_ballot_w64(maybe);
@@ -579,6 +707,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 		if (a.stats) {
 			atomicAdd(&a.stats[0], (unsigned long long)ndis);
 			atomicAdd(&a.stats[1], (unsigned long long)nexp);
+			if (BF)
+				atomicAdd(&a.stats[9], (unsigned long long)nf32);
 #ifdef MVS_HNSW_PROFILE
 			atomicAdd(&a.stats[2], p_desc);
 			atomicAdd(&a.stats[3], p_pop);
@@ -954,6 +1084,26 @@ struct SearchLaunch {
 	}
 };
 template <int NI, bool IS_L2, int G>
+struct SearchOccupancyBF {
+	static void run(int *out, size_t lds) {
+		int nb = 0;
+		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true>, lds);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)hnsw_search_kernel<NI, IS_L2, G, true>, 64, lds) !=
+		        hipSuccess ||
+		    nb <= 0)
+			nb = 8;
+		*out = nb;
+	}
+};
+template <int NI, bool IS_L2, int G>
+struct SearchLaunchBF {
+	static void run(const SearchArgs &a, int grid, size_t lds, hipStream_t st) {
+		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true>, lds);
+		hipLaunchKernelGGL((hnsw_search_kernel<NI, IS_L2, G, true>), dim3(grid), dim3(64), lds, st, a);
+		MVS_HIP(hipGetLastError());
+	}
+};
+template <int NI, bool IS_L2, int G>
 struct BuildLaunch {
 	static void run(const BuildArgs &a, int grid, size_t lds, hipStream_t st) {
 		ensure_dynamic_lds((const void *)hnsw_build_kernel<NI, IS_L2, G>, lds);
@@ -1037,6 +1187,8 @@ public:
 		neighbors.release();
 		locks.release();
 		nb0.release();
+		vbf.release();
+		ymax_dev.release();
 		if (h_stats)
 			(void)hipHostFree(h_stats);
 	}
@@ -1065,6 +1217,21 @@ public:
 		                   (long long)ntotal, L);
 		MVS_HIP(hipGetLastError());
 		nb0_rows = ntotal;
+	}
+
+	// bf16 copy of the rows for the first look of the search walk (option hnsw_bf16), extended after every add
+	void sync_bf16() {
+		if (vbf_rows >= ntotal)
+			return;
+		vbf.ensure((size_t)(vecs.cap / sizeof(float)) * sizeof(unsigned short), (size_t)vbf_rows * dp * sizeof(unsigned short), stream);
+		if (!ymax_dev.p) {
+			ymax_dev.ensure(64, 0, stream, 0);
+		}
+		const long long nr = ntotal - vbf_rows;
+		hipLaunchKernelGGL(hnsw_rows_to_bf16_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, stream, (const float *)vecs.p,
+		                   (long long)vbf_rows, (long long)ntotal, dp, (unsigned short *)vbf.p, (unsigned *)ymax_dev.p);
+		MVS_HIP(hipGetLastError());
+		vbf_rows = ntotal;
 	}
 
 	GraphDev graph_dev() const {
@@ -1273,9 +1440,14 @@ public:
 			int v = 0;
 			cus = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0 ? v : 256;
 		}
-		if (occ_lds != lds || occ_g != search_g) { // the occupancy query is not free: once per LDS size
+		const bool use_bf = bf16_look != 0 && d >= 64;
+		if (occ_lds != lds || occ_g != search_g || occ_bf != (int)use_bf) { // the occupancy query is not free: once per LDS size
 			int v = 8;
-			dispatch_ni<SearchOccupancy, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			if (use_bf)
+				dispatch_ni<SearchOccupancyBF, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			else
+				dispatch_ni<SearchOccupancy, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			occ_bf = (int)use_bf;
 			occ_g = search_g;
 			occ_waves = std::max(1, std::min(v, 32));
 			occ_lds = lds;
@@ -1322,8 +1494,18 @@ public:
 		a.D = d_D;
 		a.I = (long long *)d_I;
 		a.stats = (unsigned long long *)ws_stats.p;
+		a.vbf = nullptr;
+		a.ymax_bits = nullptr;
+		if (use_bf) {
+			sync_bf16();
+			a.vbf = (const unsigned short *)vbf.p;
+			a.ymax_bits = (const unsigned *)ymax_dev.p;
+		}
 		begin_kernel_timing(stream);
-		dispatch_ni<SearchLaunch, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
+		if (use_bf)
+			dispatch_ni<SearchLaunchBF, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
+		else
+			dispatch_ni<SearchLaunch, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
 		end_kernel_timing(stream);
 		snprintf(kinfo.name, sizeof kinfo.name, "hnsw_search_kernel");
 		kinfo.grid = grid;
@@ -1344,6 +1526,10 @@ public:
 			        (double)h_stats[7], (double)h_stats[8]);
 #endif
 			const unsigned long long nd = h_stats[0], ne = h_stats[1];
+			last_f32_rows = use_bf ? (double)h_stats[9] : (double)nd;
+			if (getenv("MVS_HNSW_STATS"))
+				fprintf(stderr, "[hnsw] %llu distance evaluations, %.0f f32 rows fetched (%.1f %%), bf16 first look %s\n", nd, last_f32_rows,
+				        nd ? 100.0 * last_f32_rows / (double)nd : 0.0, use_bf ? "on" : "off");
 			kinfo.bytes = (double)nd * ((double)d * 4.0 + 4.0); // n_visited * (4d + 4), counted by the kernel
 			kinfo.flops = (double)nd * d * (metric == METRIC_L2 ? 3.0 : 2.0);
 			kinfo.nsplit = (int)(ne / (unsigned long long)std::max<int64_t>(nq, 1)); // mean expanded vertices per query
@@ -1469,6 +1655,10 @@ public:
 			efSearch = (int)v;
 			return true;
 		}
+		if (!strcmp(key, "hnsw_bf16")) { // bf16 first look of the search walk (1) or every fresh neighbour's f32 row (0)
+			bf16_look = (int)v;
+			return true;
+		}
 		if (!strcmp(key, "hnsw_search_g")) {
 			search_g = (int)v;
 			return true;
@@ -1504,8 +1694,10 @@ private:
 	std::vector<int> cum_nn;
 	std::vector<int32_t> levels_h;
 	std::vector<int64_t> offsets_h;
-	KeepBuf vecs, offsets, neighbors, locks, nb0;
-	int64_t nb0_rows = 0;
+	KeepBuf vecs, offsets, neighbors, locks, nb0, vbf, ymax_dev;
+	int64_t nb0_rows = 0, vbf_rows = 0;
+	int bf16_look = 1, occ_bf = -1; // option hnsw_bf16: bf16 first look of the search walk (0: every fresh neighbour's f32 row is fetched)
+	double last_f32_rows = 0;
 	DevBuf ws_order, ws_counter, ws_stats, ws_q, ws_vis, sstamp, bvis, bstamp;
 	int cus = 0, occ_waves = 0, occ_g = -1;
 	int search_g = 0, search_waves_per_cu = 0; // options hnsw_search_g / hnsw_search_waves (0 = default)

@@ -179,6 +179,7 @@ public:
 	int64_t h1_cap = 0, h1_rows = 0;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_last_candidates = 0, cl_heavy_total = 0;
 	int cl_stream_cap_per_query = 0; // option cl_stream_cap (0: 4096 entries per query, at least 2^20)
+	int64_t cl_cap_hint = 0;         // entries per query the last overflow asked for (the next search starts there)
 	const unsigned long long *cl_sorted = nullptr;  // the re-scored candidate list of the last coarse-filter batch (in ws_stream)
 	const unsigned long long *tie_sorted = nullptr; // != nullptr: resolve_ip_ties reads A_k off that list instead of scanning again
 	bool tie_from_candidates = true; // option tie_from_candidates = 0: inner-product ties re-scan the database (A/B, tests)

@@ -398,9 +398,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	MVS_HIP(hipMemsetAsync(ws_e2.p, 0xff, (size_t)nq128 * sizeof(float), st)); // NaN: the slots behind the last query
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
 	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk) * sizeof(unsigned) + 64);
-	const int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024)
-	                                                        : std::max<int64_t>(nq * 4096, (int64_t)1 << 20);
-	const size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+	// candidate stream: 4096 entries per query to start with (option cl_stream_cap; at least 2^20), or what the last overflow
+	// showed this index's data to need (cl_cap_hint, up to 16384 per query: clustered rows with large norms admit thousands)
+	int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024)
+	                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
+	size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 	ws_stream.reserve(256 + 2 * half);
 	unsigned long long *cnt = (unsigned long long *)ws_stream.p;
 	unsigned long long *stream = (unsigned long long *)((char *)ws_stream.p + 256);
@@ -454,13 +456,29 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	++cl_overflows;
 	if (attempt > 0 || few)
 		return false;
-	ws_qcount.reserve((size_t)(nq + 16) * sizeof(int));
-	MVS_HIP(hipMemsetAsync(ws_qcount.p, 0, (size_t)(nq + 16) * sizeof(int), st));
-	const int nheavy = launch_collect_drop_heavy(stream, cap_entries, nq, (int)(cap_entries / nq), (int *)ws_qcount.p, (float *)ws_e2.p,
-	                                             fail_cnt, fail_q, st); // (syncs the stream)
-	if (nheavy <= 0 || nheavy >= nq)
-		return false;
-	cl_heavy_total += nheavy;
+	const int64_t grow_max = cl_stream_cap_per_query > 0 ? 4 * (int64_t)cl_stream_cap_per_query : 16384;
+	if (ncand + ncand / 8 <= nq * grow_max) {
+		// (a) the data simply admits more rows per query than the stream was sized for: a larger stream, one more scan (the
+		// class slots are warm: it admits no more than the first), and the next search of this index starts with that size
+		cap_entries = ncand + ncand / 8;
+		if (cl_stream_cap_per_query <= 0)
+			cl_cap_hint = std::max<int64_t>(cl_cap_hint, (cap_entries + nq - 1) / nq);
+		half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+		ws_stream.reserve(256 + 2 * half); // (a DevBuf keeps nothing when it grows: the counter is reset below anyway)
+		cnt = (unsigned long long *)ws_stream.p;
+		stream = (unsigned long long *)((char *)ws_stream.p + 256);
+		sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+	} else {
+		// (b) a few queries hold far more than their share: out of the coarse filter with them, one more scan for the others
+		ws_qcount.reserve((size_t)(nq + 16) * sizeof(int));
+		MVS_HIP(hipMemsetAsync(ws_qcount.p, 0, (size_t)(nq + 16) * sizeof(int), st));
+		const int64_t share = std::max<int64_t>(1, cap_entries / nq);
+		const int nheavy = launch_collect_drop_heavy(stream, cap_entries, nq, (int)std::min<int64_t>(4 * share, 1 << 30), (int *)ws_qcount.p,
+		                                             (float *)ws_e2.p, fail_cnt, fail_q, st); // (syncs the stream)
+		if (nheavy <= 0 || nheavy > nq / 2)
+			return false;
+		cl_heavy_total += nheavy;
+	}
 	MVS_HIP(hipMemsetAsync(cnt, 0, 16, st));
 	} // attempt
 	cl_queries_total += nq;

@@ -245,22 +245,35 @@ def test_inner_product_ties_are_resolved_from_the_candidate_list(mf, with_sel):
 
 @pytest.mark.parametrize("metric", [L2, IP])
 def test_stream_overflow_takes_out_only_the_heavy_queries(mf, metric):
-    """a few queries sit on a vector stored thousands of times (every copy is a candidate, rightly); the
-    stream overflows.  Only those queries leave the coarse filter (they are re-run on the exact kernel), the scan runs once more
-    for the others -- the batch stays on flat_bf16_collect_kernel and every answer is the exact kernel's and the oracle's."""
+    """a few queries sit on a vector stored tens of thousands of times (every copy is a candidate,
+    rightly); the stream overflows by far more than growing it would cure.  Only those queries leave the coarse filter (they are
+    re-run on the exact kernel), the scan runs once more for the others -- the batch stays on flat_bf16_collect_kernel and every
+    answer is the exact kernel's and the oracle's."""
     rs = np.random.RandomState(17)
     d, nb, nq = 128, 150_000, 600
     xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
-    hot = rs.rand(2, d).astype(np.float32) * (1.5 if metric == IP else 1.0)
-    xb[rs.permutation(nb)[:6000]] = hot[0]  # 6 000 copies of one vector, 3 000 of another
-    xb[rs.permutation(nb)[:3000]] = hot[1]
+    hot = rs.rand(d).astype(np.float32) * (1.5 if metric == IP else 1.0)
+    xb[rs.permutation(nb)[:60_000]] = hot  # 60 000 copies of one vector
     xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
-    xq[[5, 77, 300]] = hot[0]
-    xq[[9, 450]] = hot[1] * (1.0 if metric == L2 else 1.01)
+    xq[[5, 77, 300, 411, 599]] = hot
     cl, ex = _pair(mf, d, metric, xb)
-    cl.set_option("cl_stream_cap", 512)  # 512 entries per query on average: the hot queries alone hold thousands each
+    cl.set_option("cl_stream_cap", 128)  # 128 entries per query: the five hot queries alone hold 300 000
     D1, I1 = _check(cl, ex, xq, 10, metric, xb, oracle_rows=100)
     st, pf = cl.collect_stats(), cl.prefilter_stats()
     assert st["overflows"] == 1 and st["queries"] == nq, st  # one overflow, then the second scan served the batch
-    assert 3 <= pf["fallback_queries"] <= 12, pf  # the hot queries (and nobody else) went to the exact kernel
+    assert 5 <= pf["fallback_queries"] <= 40, pf  # the hot queries (and hardly anybody else) went to the exact kernel
+    cl.set_option("cl_stream_cap", 0)
+
+
+def test_stream_overflow_grows_the_stream_for_data_that_needs_it(mf):
+    """clustered rows with large norms admit thousands of rows per query (tools/collect_sensitivity.py): the stream is grown
+    once, the scan repeated, and the index remembers the size"""
+    xb = orc.synth_clustered(200_000, 128, 5, n_centers=64, sigma=0.1)
+    xq = orc.synth_clustered(700, 128, 6, n_centers=64, sigma=0.1)
+    cl, ex = _pair(mf, 128, L2, xb)
+    cl.set_option("cl_stream_cap", 64)
+    _check(cl, ex, xq, 10, L2, xb, oracle_rows=64)
+    st = cl.collect_stats()
+    assert st["overflows"] == 1 and st["queries"] == 700 and st["candidates"] > 700 * 64, st
+    assert cl.prefilter_stats()["fallback_queries"] == 0
     cl.set_option("cl_stream_cap", 0)

@@ -207,7 +207,10 @@ def test_ivf_images_cross_both_ways(mf, tmp_path, metric, sparse):
     xq = orc.synth_clustered(60, d, 22, n_centers=4 if sparse else 16, sigma=0.05 if sparse else 0.2)
     ids = (np.random.RandomState(2).permutation(3 * n)[:n] + 1).astype(np.int64)
     o = orc.Index(d, f"IVF{nlist},Flat", metric)
-    o.train(xb)
+    if sparse:  # k-means on wide data (it leaves no centroid without points), rows from four tight clusters only: most lists stay empty
+        o.train(orc.synth_clustered(n, d, 23, n_centers=64, sigma=0.3))
+    else:
+        o.train(xb)
     o.add_with_ids(xb, ids)
     lists = [o.ivf_list(l) for l in range(nlist)]
     if sparse:
