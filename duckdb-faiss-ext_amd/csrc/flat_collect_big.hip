@@ -243,11 +243,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		const unsigned nb_lds = (unsigned)(uintptr_t)((lds_f32c *)(nbuf + stage * 64 + 4 * hq));
 		asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(nb_lds) : "memory");
 	};
+	static_assert(RA == 4, "the end-of-tile wait names A[0..3]");
 	if (nblocks > 0) { // tile 0's beta and first fragments
 		read_y(Yv[0], 0);
 #pragma unroll
 		for (int kb = 0; kb < RA; ++kb)
 			read_a(A[kb], 0, kb);
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Yv[0]));
 	}
 	// one tile; PAR = u & 1 as a compile-time constant (the accumulator sets must be registers, not an indexed array)
 	auto tile = [&](auto parc, const int u) {
@@ -324,6 +326,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			}
 			__builtin_amdgcn_sched_barrier(0);
 		}
+		// The fragments (and beta) read ahead for the next tile must have LANDED before control leaves this straight-line block:
+		// hipcc counts an asm load's destination as written at the end of the statement and is free to copy or spill it on the
+		// way through the branches below (rare path, flush, bound refresh) -- a copy of a register whose ds_read is still in
+		// flight is garbage.  The last RA k-blocks' MFMAs are queued behind this wait, so it costs nothing.
+		asm volatile("s_waitcnt lgkmcnt(0)"
+		             : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Yv[par ^ 1]), "+v"(cqv));
 		if (u > 0 && __builtin_amdgcn_ballot_w64(any_prev) != 0ull) {
 			const long long prow0 = r_begin + (long long)(u - 1) * RT;
 			const int pnvalid = (int)((r_end - prow0) < RT ? (r_end - prow0) : RT);
