@@ -36,8 +36,11 @@ typedef float f32x4b __attribute__((ext_vector_type(4)));
 
 int g_wide_big = 1; // option cl_wide_big: 512 < d <= 1024 on flat_bf16_big_kernel (1) or on the k-split kernel (0)
 
-template <int KBT, int NCB, bool IS_L2, bool COLLECT>
+// MODE (option cl_big_mode, A/B): bit 0 = the next tile's first fragments and beta are read under the last MFMAs of this one;
+// bit 1 = the LDS-DMA instructions of block u + 3 are spread one per two k-blocks (else issued together behind the barrier)
+template <int KBT, int NCB, bool IS_L2, bool COLLECT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_bf16_big_kernel(const CollectArgs a) {
+	constexpr bool PF = (MODE & 1) != 0, SPREAD = (MODE & 2) != 0;
 	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
 	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB (768 dims) / 32 KB (1024)
 	constexpr int NST = 4, KB_BAR = 8;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(nb_lds) : "memory");
 	};
 	static_assert(RA == 4, "the end-of-tile wait names A[0..3]");
-	if (nblocks > 0) { // tile 0's beta and first fragments
+	if (PF && nblocks > 0) { // tile 0's beta and first fragments
 		read_y(Yv[0], 0);
 #pragma unroll
 		for (int kb = 0; kb < RA; ++kb)
@@ -260,6 +263,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		const int nstg = (stg + 1) & 3, dstg = (stg + 3) & 3; // tile u + 1's stage; block u + 3 goes where tile u - 1 was
 		f32x4n cqv;
 		bool any_prev = false;
+		if (!PF) { // this tile's beta and first fragments (its block landed at the previous tile's barrier)
+			read_y(Yv[par], stg);
+#pragma unroll
+			for (int kb = 0; kb < RA; ++kb)
+				read_a(A[kb], stg, kb);
+		}
 #pragma unroll
 		for (int kb = 0; kb < KBT; ++kb) {
 			if (kb == KB_BAR) {
@@ -270,20 +279,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 				else
 					asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
 			}
-			if (kb > KB_BAR && ((kb - KB_BAR) & 1) && (kb - KB_BAR) / 2 < DMA_PER_WAVE)
-				dma_one(u + 3, dstg, (kb - KB_BAR) / 2); // one LDS-DMA instruction per two k-blocks: its issue hides under their MFMAs
-			if (kb == KB_BAR + 2 && wave == 0)
-				dma_beta(u + 3, dstg);
+			if (SPREAD) {
+				if (kb > KB_BAR && ((kb - KB_BAR) & 1) && (kb - KB_BAR) / 2 < DMA_PER_WAVE)
+					dma_one(u + 3, dstg, (kb - KB_BAR) / 2); // one LDS-DMA instruction per two k-blocks: its issue hides under their MFMAs
+				if (kb == KB_BAR + 2 && wave == 0)
+					dma_beta(u + 3, dstg);
+			} else if (kb == KB_BAR) {
+#pragma unroll
+				for (int i = 0; i < DMA_PER_WAVE; ++i)
+					dma_one(u + 3, dstg, i);
+				if (wave == 0)
+					dma_beta(u + 3, dstg);
+			}
 			if (kb == 2)
 				asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds) : "memory"); // this tile's bounds (tested one tile later)
-			if (kb == KBT - RA)
+			if (PF && kb == KBT - RA)
 				read_y(Yv[par ^ 1], nstg);
 			if (kb + RA < KBT)
 				read_a(A[(kb + RA) % RING], stg, kb + RA);
-			else
+			else if (PF)
 				read_a(A[(kb + RA) % RING], nstg, kb + RA - KBT); // the next tile's first fragments (its block landed at the barrier)
 			// LDS returns in order: with RA reads younger than fragment kb outstanding, kb (and everything older) has arrived
-			asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(RA));
+			if (PF || kb + RA < KBT)
+				asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(RA));
+			else
+				asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(KBT - 1 - kb));
 #pragma unroll
 			for (int i = 0; i < NCB; ++i) {
 				const int f = i * KBT + kb;
@@ -330,8 +350,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		// hipcc counts an asm load's destination as written at the end of the statement and is free to copy or spill it on the
 		// way through the branches below (rare path, flush, bound refresh) -- a copy of a register whose ds_read is still in
 		// flight is garbage.  The last RA k-blocks' MFMAs are queued behind this wait, so it costs nothing.
-		asm volatile("s_waitcnt lgkmcnt(0)"
-		             : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Yv[par ^ 1]), "+v"(cqv));
+		if (PF)
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Yv[par ^ 1]), "+v"(cqv));
+		else
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cqv));
 		if (u > 0 && __builtin_amdgcn_ballot_w64(any_prev) != 0ull) {
 			const long long prow0 = r_begin + (long long)(u - 1) * RT;
 			const int pnvalid = (int)((r_end - prow0) < RT ? (r_end - prow0) : RT);
@@ -414,13 +436,25 @@ size_t collect_big_lds_bytes(int dp1) {
 	return (size_t)4 * (16 * dp1 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
 }
 
+int g_big_mode = 3; // option cl_big_mode (see MODE)
 template <int KBT, int NCB>
 static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int grid, size_t lds, hipStream_t st) {
-#define MVS_BIG(L2, CO)                                                                                           \
+#define MVS_BIG1(L2, CO, MD)                                                                                      \
 	{                                                                                                             \
-		auto kern = flat_bf16_big_kernel<KBT, NCB, L2, CO>;                                                       \
+		auto kern = flat_bf16_big_kernel<KBT, NCB, L2, CO, MD>;                                                   \
 		ensure_dynamic_lds((const void *)kern, lds);                                                              \
 		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                                    \
+	}
+#define MVS_BIG(L2, CO)                                                                                           \
+	{                                                                                                             \
+		if (g_big_mode == 0)                                                                                      \
+			MVS_BIG1(L2, CO, 0)                                                                                   \
+		else if (g_big_mode == 1)                                                                                 \
+			MVS_BIG1(L2, CO, 1)                                                                                   \
+		else if (g_big_mode == 2)                                                                                 \
+			MVS_BIG1(L2, CO, 2)                                                                                   \
+		else                                                                                                      \
+			MVS_BIG1(L2, CO, 3)                                                                                   \
 	}
 	if (metric == METRIC_L2 && collect)
 		MVS_BIG(true, true)
@@ -431,6 +465,7 @@ static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int 
 	else
 		MVS_BIG(false, false)
 #undef MVS_BIG
+#undef MVS_BIG1
 	MVS_HIP(hipGetLastError());
 }
 

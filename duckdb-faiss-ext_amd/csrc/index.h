@@ -306,7 +306,7 @@ size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
 int collect_store_dims(int d); // 128 / 256 / 384 / 512: row pitch of the bf16 store; 0: d is not served (csrc/flat_collect_wide.hip)
 int collect_wide_qblock(int dp1);
 extern int g_ksplit_waves, g_ksplit_ncb, g_ksplit_opt, g_wide384_ncb, g_wide512_ksplit;
-extern int g_wide_big; // csrc/flat_collect_big.hip
+extern int g_wide_big, g_big_mode; // csrc/flat_collect_big.hip
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
                               const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
                               unsigned *d_max_norm_bits, hipStream_t st);

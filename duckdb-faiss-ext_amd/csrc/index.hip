@@ -1826,6 +1826,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		prefilter_mode = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "cl_big_mode")) { // flat_bf16_big_kernel pipeline A/B: bit 0 cross-tile fragment prefetch, bit 1 spread LDS-DMA
+		g_big_mode = (int)(v & 3);
+		return true;
+	}
 	if (!strcmp(key, "cl_wide_big")) { // 512 < d <= 1024 coarse filter: one wave per SIMD, all of k resident (1) or the k-split kernel (0)
 		g_wide_big = v != 0;
 		return true;
