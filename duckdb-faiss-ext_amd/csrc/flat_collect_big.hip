@@ -364,6 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		if (COLLECT && (u % FLUSH_EVERY) == FLUSH_EVERY - 1 && u != nblocks - 1) {
 			// (the fragments read ahead for the next tile are in registers; the compiled LDS accesses below make hipcc drain the
 			// LDS-DMA in flight first -- once per FLUSH_EVERY tiles)
+			__syncthreads(); // the tile's own barrier stands in mid-tile: every wave's appends of this tile must be in before the look
 			const unsigned fill = qctl[0];
 			__syncthreads(); // everybody has read the same fill before anyone appends again
 			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;

@@ -252,7 +252,7 @@ def test_stream_overflow_takes_out_only_the_heavy_queries(mf, metric):
     rs = np.random.RandomState(17)
     d, nb, nq = 128, 150_000, 600
     xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
-    hot = rs.rand(d).astype(np.float32) * (1.5 if metric == IP else 1.0)
+    hot = rs.rand(d).astype(np.float32) - (0.5 if metric == IP else 0.0)  # (a vector like any other: only queries ON it are hot)
     xb[rs.permutation(nb)[:60_000]] = hot  # 60 000 copies of one vector
     xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
     xq[[5, 77, 300, 411, 599]] = hot
