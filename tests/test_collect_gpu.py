@@ -271,9 +271,9 @@ def test_stream_overflow_grows_the_stream_for_data_that_needs_it(mf):
     xb = orc.synth_clustered(200_000, 128, 5, n_centers=64, sigma=0.1)
     xq = orc.synth_clustered(700, 128, 6, n_centers=64, sigma=0.1)
     cl, ex = _pair(mf, 128, L2, xb)
-    cl.set_option("cl_stream_cap", 64)
+    cl.set_option("cl_stream_cap", 1024)  # (whole clusters of ~3 000 rows are within the bound of their queries)
     _check(cl, ex, xq, 10, L2, xb, oracle_rows=64)
     st = cl.collect_stats()
-    assert st["overflows"] == 1 and st["queries"] == 700 and st["candidates"] > 700 * 64, st
+    assert st["overflows"] == 1 and st["queries"] == 700 and st["candidates"] > 700 * 1024, st
     assert cl.prefilter_stats()["fallback_queries"] == 0
     cl.set_option("cl_stream_cap", 0)
