@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// A fragment (row block rb, k-block kb): row 16 rb + c, chunk 4 kb + hq -> byte 4096 rb + 256 c + (((4 kb + hq) ^ c) * 16)
 	// = 4096 rb + (rbase ^ (64 kb)) with rbase = 256 c | ((hq ^ c) * 16)  (4 kb and hq occupy disjoint bits of the chunk number)
 	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)(((hq ^ c) & 15) * 16);
+	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
 	// the lane's two bounds of tile t: cqtab[wave][t][c][0..1]
 	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 64 + c) * 8);
@@ -386,12 +387,13 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// Rare path of half a 32-query tile (row block rb; sv holds s of its 4 rows x 2 queries per lane): every passing row is
 	// published to its class slot (16 classes: row & 15) and appended.  Lane (hq, c): rows 16 rb + 4 hq + r, queries of column
 	// blocks 2 t + i.
-	// Candidate queue: every wave owns a quarter of it and keeps its fill in a scalar register -- an append is a ballot, a
-	// population count and ONE ds_write_b64, no LDS atomic and no round trip (round 2 took a slot with ds_add_rtn per candidate
-	// and sat out the LDS latency each time: the rare path cost 0.5 ms of a 2.8 ms launch at N = 1.25M, 1.3 of 18 ms at N = 10M).
-	constexpr unsigned WCAP = CL_QCAP / 4;
-	unsigned wfill = 0u; // entries in this wave's slice (wave-uniform)
-	const unsigned wq_lds = qbuf_lds + (unsigned)wave * WCAP * 8u;
+	// Vector-memory instructions this wave has issued behind its newest LDS-DMA (class-slot atomics of the rare path): the
+	// staged block's barrier has to wait for the DMA, not for them.  `__syncthreads()` waits for vmcnt(0), i.e. every block in
+	// which ANY of the workgroup's 512 queries found a candidate sat out an L2 atomic round trip (600 - 3 000 cycles under load,
+	// MI355X_MICROARCH.md) at its barrier -- most blocks while the bound converges: the "rare path" that cost 0.5 of 2.8 ms at
+	// N = 1.25M and 1.3 of 18 ms at N = 10M (cl_abl ablations) was mostly this wait.  vmcnt counts in issue order, so waiting
+	// until at most min(n, 7) operations are outstanding completes the DMA (and over-waits when n > 7).
+	unsigned natom = 0u; // a LOWER bound (an over-count would let the DMA slip past the barrier): one per column block with a candidate
 	auto rare = [&](const f32x4acc (&sv)[2], int rb, int t, bool any_t, f32x2n cqv, long long row0, int nvalid, unsigned rowbits) {
 		if (ABL & 1) {
 			MVS_KEEP_VGPR(any_t);
@@ -414,39 +416,37 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				if (SEL) // rows the IDSelector rejects: neither a candidate nor evidence for the bound
 					m &= (rowbits >> (16 * rb + 4 * hq)) & 15u;
 			}
-#pragma unroll
-			for (int r = 0; r < 4; ++r) { // row by row, the whole wave at once
-				const bool has = (m >> r) & 1u;
-				const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
-				if (bal == 0ull)
-					continue;
-				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + r);
-				if (has) {
-					typedef __attribute__((address_space(1))) unsigned *GU;
-					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(sv[i][r]), __ATOMIC_RELAXED,
-					                       __HIP_MEMORY_SCOPE_AGENT);
-				}
+			natom += __builtin_amdgcn_ballot_w64(m != 0u) != 0ull ? 1u : 0u; // (at least one slot atomic is issued below)
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
+				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
+				const float v = (j & 2) ? hi : lo;
+				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
+				typedef __attribute__((address_space(1))) unsigned *GU;
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
+				                       __HIP_MEMORY_SCOPE_AGENT);
 				if (COLLECT) {
-					const unsigned pos = wfill + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-					if (has) {
-						const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-						if (pos < WCAP) {
-							asm volatile("ds_write_b64 %0, %1" ::"v"(wq_lds + 8u * pos), "v"(ent) : "memory");
-						} else { // a burst beyond the wave's slice (cold start): straight to the stream.  By hand, wait included: a
-							// compiled atomic with a result makes hipcc wait for vmcnt(0) where the branches meet, i.e. EVERY
-							// candidate would sit out the class-slot atomic's L2 round trip and the next tile's LDS-DMA
-							unsigned long long gp;
-							const unsigned long long one64 = 1ull;
-							typedef __attribute__((address_space(1))) unsigned long long *GUL;
-							asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-							             : "=&v"(gp)
-							             : "v"((GUL)a.stream_cnt), "v"(one64)
-							             : "memory");
-							if ((long long)gp < a.stream_cap)
-								*((GUL)a.stream + gp) = ent;
-						}
+					unsigned pos;
+					const unsigned one = 1u;
+					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+					if (pos < (unsigned)CL_QCAP) {
+						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+					} else { // a burst beyond the queue (cold start): straight to the stream.  By hand, wait included: a
+						// compiled atomic with a result makes hipcc wait for vmcnt(0) where the branches meet, i.e. EVERY
+						// candidate would sit out the class-slot atomic's L2 round trip and the next tile's LDS-DMA
+						unsigned long long gp;
+						const unsigned long long one64 = 1ull;
+						typedef __attribute__((address_space(1))) unsigned long long *GUL;
+						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+						             : "=&v"(gp)
+						             : "v"((GUL)a.stream_cnt), "v"(one64)
+						             : "memory");
+						if ((long long)gp < a.stream_cap)
+							*((GUL)a.stream + gp) = ent;
 					}
-					wfill += (unsigned)__builtin_popcountll(bal);
 				}
 			}
 		}
@@ -535,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			for (int i = 0; i < DMA_PER_WAVE; ++i)
 				dma_issue(u + 1, i);
 			dma_norms(u + 1);
+			natom = 0u; // (everything older than these loads completes with them: vmcnt counts in issue order)
 		}
 		const long long row0 = r_begin + ((long long)u * CL_SUB + sub) * CL_BN;
 		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN); // (<= 0 behind the split's last row)
@@ -614,31 +615,50 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			rare(acc[1], 1, 3, any_of(cqv[1]), cqv[1], row0, nvalid, rowbits);
 		}
 		} // sub
-		if (ABL & 8) // profiling: no workgroup barrier (the waves drift apart; results wrong)
+		if (ABL & 8) { // profiling: no workgroup barrier (the waves drift apart; results wrong)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		else
-			__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
+		} else if (a.opt & 16) {
+			__syncthreads(); // (A/B, option cl_ksplit_opt bit 4: the plain barrier, vmcnt(0))
+		} else {
+			// the next block's LDS-DMA has landed (all but this wave's min(natom, 7) youngest vector-memory operations are done),
+			// every LDS access of this block is done, then the workgroup barrier
+			const unsigned na = natom < 7u ? natom : 7u;
+			if (na == 0u)
+				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			else if (na == 1u)
+				asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			else if (na == 2u)
+				asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			else if (na == 3u)
+				asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			else if (na == 4u)
+				asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			else if (na == 5u)
+				asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			else if (na == 6u)
+				asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		}
 		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
-			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue)
-			if (lane == 0)
-				qctl[4 + wave] = wfill < WCAP ? wfill : WCAP; // (what sits in the slice; the rest went straight to the stream)
-			__syncthreads();
-			const unsigned n0 = qctl[4], n1 = qctl[5], n2 = qctl[6], n3 = qctl[7];
-			const unsigned n = n0 + n1 + n2 + n3;
-			const bool go = n >= (unsigned)CL_QCAP / 2 || n0 >= WCAP || n1 >= WCAP || n2 >= WCAP || n3 >= WCAP || (u == ntiles - 1 && n > 0);
-			if (go) {
-				if (tid == 0)
+			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue; read and barrier by hand: a
+			// compiled LDS read / __syncthreads here would wait for vmcnt(0), i.e. for the slot atomics the barrier above let go)
+			unsigned fill;
+			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fill) : "v"(qcnt_lds) : "memory");
+			fill = (unsigned)__builtin_amdgcn_readfirstlane((int)fill);
+			asm volatile("s_barrier" ::: "memory"); // everybody has read the same fill before anyone appends again
+			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
+			if (n >= (unsigned)CL_QCAP / 2 || (u == ntiles - 1 && n > 0)) {
+				if (tid == 0) {
 					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
+					qctl[0] = 0u;
+				}
 				__syncthreads();
 				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
-				const unsigned off[4] = {0u, n0, n0 + n1, n0 + n1 + n2}, cnt[4] = {n0, n1, n2, n3};
-#pragma unroll
-				for (int w = 0; w < 4; ++w)
-					for (unsigned i = tid; i < cnt[w]; i += 256)
-						if ((long long)(base + off[w] + i) < a.stream_cap)
-							a.stream[base + off[w] + i] = qbuf[w * WCAP + i];
-				wfill = 0u;
-				__syncthreads(); // the slices are free again
+				for (unsigned i = tid; i < n; i += 256)
+					if ((long long)(base + i) < a.stream_cap)
+						a.stream[base + i] = qbuf[i];
+				__syncthreads();
 			}
 		}
 	}

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	__syncthreads();
 
 	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)(((hq ^ c) & 15) * 16);
+	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
 	const unsigned qtab_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int *)qtab);
 	const unsigned ct_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)ctab) + (unsigned)(c * 16);
@@ -343,8 +344,11 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 				*((GUL)a.stream + (b + i)) = ent;
 			}
 		}
+		if (lane == 0) {
+			const unsigned zero = 0u;
+			asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(qcnt_lds), "v"(zero) : "memory");
+		}
 	};
-	unsigned wfill = 0u; // entries in the queue: the wave is alone with it, so its fill lives in a scalar register (no LDS atomic)
 
 	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid, unsigned rowbits) {
 		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
@@ -360,45 +364,42 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 						m |= 1u << r;
 				m &= (rowbits >> (16 * rb + 4 * hq)) & 15u; // rows the IDSelector rejects: no candidate, no evidence for the bound
 			}
-			if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) // (wave-uniform: every lane walks the rows below, the fill stays scalar)
+			if (m == 0u)
 				continue;
 			int2 qe;
 			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qe) : "v"(qtab_lds + (unsigned)((32 * t + 16 * i + c) * 8)) : "memory");
 			const int q = qe.x;
 			const float eh = __int_as_float(qe.y);
-#pragma unroll
-			for (int j = 0; j < 4; ++j) { // row by row, the whole wave at once: a ballot, a population count, one ds_write_b64
-				const bool has = (m >> j) & 1u;
-				const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
-				if (bal == 0ull)
-					continue;
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
+				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
+				const float v = (j & 2) ? hi : lo;
 				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
-				if (has) {
-					typedef __attribute__((address_space(1))) unsigned *GU;
-					// the slots hold LOWER bounds s - E(list): E differs between the lists a query probes
-					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), ic_skey(sv[i][j] - eh), __ATOMIC_RELAXED,
-					                       __HIP_MEMORY_SCOPE_AGENT);
-				}
+				typedef __attribute__((address_space(1))) unsigned *GU;
+				// the slots hold LOWER bounds s - E(list): E differs between the lists a query probes
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), ic_skey(v - eh), __ATOMIC_RELAXED,
+				                       __HIP_MEMORY_SCOPE_AGENT);
 				if (!a.collect)
 					continue;
-				const unsigned pos = wfill + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-				if (has) {
-					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-					if (pos < (unsigned)IC_QCAP) {
-						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
-					} else { // a burst beyond the queue (cold start): straight to the stream
-						unsigned long long gp;
-						const unsigned long long one64 = 1ull;
-						typedef __attribute__((address_space(1))) unsigned long long *GUL;
-						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-						             : "=&v"(gp)
-						             : "v"((GUL)a.stream_cnt), "v"(one64)
-						             : "memory");
-						if ((long long)gp < a.stream_cap)
-							*((GUL)a.stream + gp) = ent;
-					}
+				unsigned pos;
+				const unsigned one = 1u;
+				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
+				const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+				if (pos < (unsigned)IC_QCAP) {
+					asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+				} else { // a burst beyond the queue (cold start): straight to the stream
+					unsigned long long gp;
+					const unsigned long long one64 = 1ull;
+					typedef __attribute__((address_space(1))) unsigned long long *GUL;
+					asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+					             : "=&v"(gp)
+					             : "v"((GUL)a.stream_cnt), "v"(one64)
+					             : "memory");
+					if ((long long)gp < a.stream_cap)
+						*((GUL)a.stream + gp) = ent;
 				}
-				wfill += (unsigned)__builtin_popcountll(bal);
 			}
 		}
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -522,10 +523,11 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		fold(acc[1][1], 1);
 		rare(acc[1], 1, 3, any_of(cg[1]), cg[1], row0, nvalid, rowbits);
 		__syncthreads(); // one wave: drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
-		if (wfill >= (unsigned)IC_QCAP / 2 || (u == ntiles - 1 && wfill > 0u)) {
-			flush(wfill < (unsigned)IC_QCAP ? wfill : (unsigned)IC_QCAP);
-			wfill = 0u;
-		}
+		unsigned fill;
+		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fill) : "v"(qcnt_lds) : "memory");
+		fill = (unsigned)__builtin_amdgcn_readfirstlane((int)fill);
+		if (fill >= (unsigned)IC_QCAP / 2 || (u == ntiles - 1 && fill > 0))
+			flush(fill < (unsigned)IC_QCAP ? fill : (unsigned)IC_QCAP);
 	}
 }
 
