@@ -387,13 +387,6 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// Rare path of half a 32-query tile (row block rb; sv holds s of its 4 rows x 2 queries per lane): every passing row is
 	// published to its class slot (16 classes: row & 15) and appended.  Lane (hq, c): rows 16 rb + 4 hq + r, queries of column
 	// blocks 2 t + i.
-	// Vector-memory instructions this wave has issued behind its newest LDS-DMA (class-slot atomics of the rare path): the
-	// staged block's barrier has to wait for the DMA, not for them.  `__syncthreads()` waits for vmcnt(0), i.e. every block in
-	// which ANY of the workgroup's 512 queries found a candidate sat out an L2 atomic round trip (600 - 3 000 cycles under load,
-	// MI355X_MICROARCH.md) at its barrier -- most blocks while the bound converges: the "rare path" that cost 0.5 of 2.8 ms at
-	// N = 1.25M and 1.3 of 18 ms at N = 10M (cl_abl ablations) was mostly this wait.  vmcnt counts in issue order, so waiting
-	// until at most min(n, 7) operations are outstanding completes the DMA (and over-waits when n > 7).
-	unsigned natom = 0u; // a LOWER bound (an over-count would let the DMA slip past the barrier): one per column block with a candidate
 	auto rare = [&](const f32x4acc (&sv)[2], int rb, int t, bool any_t, f32x2n cqv, long long row0, int nvalid, unsigned rowbits) {
 		if (ABL & 1) {
 			MVS_KEEP_VGPR(any_t);
@@ -416,7 +409,6 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				if (SEL) // rows the IDSelector rejects: neither a candidate nor evidence for the bound
 					m &= (rowbits >> (16 * rb + 4 * hq)) & 15u;
 			}
-			natom += __builtin_amdgcn_ballot_w64(m != 0u) != 0ull ? 1u : 0u; // (at least one slot atomic is issued below)
 			while (m != 0u) {
 				const int j = __builtin_ctz(m);
 				m &= m - 1u;
@@ -535,7 +527,6 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			for (int i = 0; i < DMA_PER_WAVE; ++i)
 				dma_issue(u + 1, i);
 			dma_norms(u + 1);
-			natom = 0u; // (everything older than these loads completes with them: vmcnt counts in issue order)
 		}
 		const long long row0 = r_begin + ((long long)u * CL_SUB + sub) * CL_BN;
 		const int nvalid = (int)((r_end - row0) < CL_BN ? (r_end - row0) : CL_BN); // (<= 0 behind the split's last row)
@@ -615,38 +606,14 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			rare(acc[1], 1, 3, any_of(cqv[1]), cqv[1], row0, nvalid, rowbits);
 		}
 		} // sub
-		if (ABL & 8) { // profiling: no workgroup barrier (the waves drift apart; results wrong)
+		if (ABL & 8) // profiling: no workgroup barrier (the waves drift apart; results wrong)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		} else if (a.opt & 16) {
-			__syncthreads(); // (A/B, option cl_ksplit_opt bit 4: the plain barrier, vmcnt(0))
-		} else {
-			// the next block's LDS-DMA has landed (all but this wave's min(natom, 7) youngest vector-memory operations are done),
-			// every LDS access of this block is done, then the workgroup barrier
-			const unsigned na = natom < 7u ? natom : 7u;
-			if (na == 0u)
-				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			else if (na == 1u)
-				asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			else if (na == 2u)
-				asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			else if (na == 3u)
-				asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			else if (na == 4u)
-				asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			else if (na == 5u)
-				asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			else if (na == 6u)
-				asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-			else
-				asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-		}
+		else
+			__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
 		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
-			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue; read and barrier by hand: a
-			// compiled LDS read / __syncthreads here would wait for vmcnt(0), i.e. for the slot atomics the barrier above let go)
-			unsigned fill;
-			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fill) : "v"(qcnt_lds) : "memory");
-			fill = (unsigned)__builtin_amdgcn_readfirstlane((int)fill);
-			asm volatile("s_barrier" ::: "memory"); // everybody has read the same fill before anyone appends again
+			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue)
+			const unsigned fill = qctl[0];
+			__syncthreads(); // everybody has read the same fill before anyone appends again
 			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
 			if (n >= (unsigned)CL_QCAP / 2 || (u == ntiles - 1 && n > 0)) {
 				if (tid == 0) {
