@@ -411,7 +411,7 @@ def main():
             # HBM bytes per launch come from the committed PMC passes of this same workload (PMC counters cannot be
             # collected from inside the process); null for any other workload
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
             if os.path.exists(tpath) and world == 1 and chunk == nq and not args.opt and args.efconstruction == 0:
                 for w in json.load(open(tpath)).get("workloads", []):
                     # a PMC figure is only valid for the launch it was measured on: same workload, same dominant kernel,
@@ -423,7 +423,7 @@ def main():
                         and w.get("kernel") == kinfo["name"]
                         and w.get("grid") == kinfo["grid"]
                     ):
-                        traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r2_traffic.json (" + w["source"] + ")"
+                        traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r3_traffic.json (" + w["source"] + ")"
             if kinfo["name"].startswith("flat_bf16_collect") or kinfo["name"].startswith("flat_bf16_wide"):
                 # bf16 coarse filter (csrc/flat_collect.hip; 128 < d <= 768: csrc/flat_collect_wide.hip): ONE bf16 MFMA product per element pair is the algorithm, so its
                 # algorithmic flops are 2 nq N d, priced against the dense bf16 peak; the candidates it admits are re-scored

@@ -636,7 +636,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 					// sets are full
 					const float thr = fmaxf(cmax, rthr);
 					if (thr < FLT_MAX) {
-						const float ap = eval_lanes_bf<NI, IS_L2, G>(q, a.vbf, g.dp4, nid, fmask, lane);
+						// (a bf16 row is half the registers of an f32 row: twice as many in flight)
+						const float ap = eval_lanes_bf<NI, IS_L2, (G * 2 > 32 ? 32 : G * 2)>(q, a.vbf, g.dp4, nid, fmask, lane);
 						float lim;
 						if (IS_L2) {
 							const float t = thr * 1.00001f;

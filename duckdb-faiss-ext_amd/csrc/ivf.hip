@@ -910,23 +910,27 @@ public:
 		for (int64_t l = 0; l < nlist; l++)
 			max_list = std::max(max_list, list_off[(size_t)l + 1] - list_off[(size_t)l]);
 		const int seg_rows = 512, nseg = (int)((max_list + seg_rows - 1) / seg_rows);
+		// (round 3, option ivf_cl_prepass = 1: the pre-pass walks the first rows of EVERY probed list with the work items of the
+		// main pass -- one grouping + packing per search instead of two, and 32 x 128 rows of evidence per query instead of 256)
+		int *d_nitems = nullptr, *d_cnt = nullptr;
 		for (int phase = 0; phase < 2; ++phase) {
 			const int64_t *keys = (const int64_t *)ws_cI.p;
-			if (phase == 0) {
+			if (phase == 0 && !cl_prepass_all) {
 				launch_ivf_mask_probes((const int64_t *)ws_cI.p, nq, (int)np, 0, 1, (int64_t *)ws_cimask.p, stream);
 				keys = (const int64_t *)ws_cimask.p;
 			}
-			int *d_nitems = nullptr, *d_cnt = nullptr;
-			launch_ivf_group(keys, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
-			                 (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
-			launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
-			                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
-			                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream);
+			if (phase == 0 || !cl_prepass_all) {
+				launch_ivf_group(keys, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
+				                 (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
+				launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
+				                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
+				                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream);
+			}
 			if (phase == 1)
 				begin_kernel_timing(stream);
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, phase == 0 ? 256 : seg_rows,
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
 			                        phase == 0 ? 1 : nseg, phase, rowmask, stream);
 			if (phase == 1)
 				end_kernel_timing(stream);
@@ -1392,6 +1396,11 @@ public:
 			force_select = v != 0;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_prepass")) { // coarse filter pre-pass: 0 = the nearest list of every query (own grouping), n > 0 = the first n rows of every probed list
+			cl_prepass_all = v > 0;
+			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
+			return true;
+		}
 		if (!strcmp(key, "ivf_exact_ties")) {
 			exact_ties = v != 0;
 			return true;
@@ -1403,6 +1412,8 @@ public:
 		return quantizer->set_option(key, v);
 	}
 	bool use_fast_scan = true;
+	bool cl_prepass_all = true; // option ivf_cl_prepass
+	int cl_prepass_rows = 128;
 	bool exact_ties = true; // option ivf_exact_ties: 0 = the scan kernels' pure (value, position) order, no tie pass (diagnostics)
 	bool raw_pos = false;   // inside the exact-tie wrapper: the paths emit positions in the list-sorted store, no id map
 	bool force_select = false;
