@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			MVS_KEEP_VGPR(any_t);
 			return;
 		}
-		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+		if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_t) == 0ull, 1)) // (hot path = fall-through: no taken branch per half tile)
 			return;
 		int qo = qw;
 		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)

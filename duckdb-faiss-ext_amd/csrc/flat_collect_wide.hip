@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * QT * 16 + c) * 16);
 
 	auto rare = [&](const f32x4w (&sv)[NCBP], int t, bool any_t, f32x4n cqv, long long row0, int nvalid) {
-		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+		if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_t) == 0ull, 1)) // (hot path = fall-through: no taken branch per half tile)
 			return;
 		int qo = qw;
 		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void flat_bf16_ksplit_ker
 	auto finish = [&](const f32x4w sv, const float cqv, const int qoff, const long long row0, const int nvalid) {
 		const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
 		const bool any_t = mx >= cqv; // NaN on either side: false
-		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+		if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_t) == 0ull, 1)) // (hot path = fall-through: no taken branch per half tile)
 			return;
 		int qo = qpair;
 		MVS_OPAQUE_VGPR(qo);

@@ -499,7 +499,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	cl_sorted = sorted;
 	snprintf(kinfo.name, sizeof kinfo.name, wide ? "flat_bf16_wide_kernel" : "flat_bf16_collect_kernel");
 	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
-	kinfo.bytes = (double)ntotal * d * 4.0 + (double)nq * d * 4.0 + (double)nq * kk * 12.0;
+	// one pass over the bf16 store (row pitch of the store + the row's f32 term) + the queries + the results
+	kinfo.bytes = (double)ntotal * (collect_store_dims(d) * 2.0 + 4.0) + (double)nq * d * 4.0 + (double)nq * kk * 12.0;
 	kinfo.grid = grid;
 	kinfo.block = few ? 64 : 256;
 	kinfo.lds_bytes = lds;

@@ -1412,7 +1412,7 @@ public:
 		return quantizer->set_option(key, v);
 	}
 	bool use_fast_scan = true;
-	bool cl_prepass_all = true; // option ivf_cl_prepass
+	bool cl_prepass_all = false; // option ivf_cl_prepass (n > 0 measured no faster than the nearest-list pre-pass: 2.83 / 2.88 / 2.93 vs 2.81 ms at C3)
 	int cl_prepass_rows = 128;
 	bool exact_ties = true; // option ivf_exact_ties: 0 = the scan kernels' pure (value, position) order, no tie pass (diagnostics)
 	bool raw_pos = false;   // inside the exact-tie wrapper: the paths emit positions in the list-sorted store, no id map

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	};
 
 	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid, unsigned rowbits) {
-		if (__builtin_amdgcn_ballot_w64(any_t) == 0ull)
+		if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_t) == 0ull, 1)) // (hot path = fall-through: no taken branch per half tile)
 			return;
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {

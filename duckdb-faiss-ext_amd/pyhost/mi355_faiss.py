@@ -206,9 +206,9 @@ class Index:
         self._owned = owned
         self._parent = parent  # keeps the owning index alive for borrowed handles
 
-    def __del__(self):
-        if getattr(self, "_h", None) and self._owned and _L is not None:  # (_L is None during interpreter shutdown)
-            _L.mvs_index_free(self._h)
+    def __del__(self, _free=_L.mvs_index_free):  # (bound at definition: module globals are None during interpreter shutdown)
+        if getattr(self, "_h", None) and getattr(self, "_owned", False):
+            _free(self._h)
         self._h = None
 
     d = property(lambda s: _L.mvs_index_d(s._h))
