@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--data", default="uniform", choices=["uniform", "clustered"])
     ap.add_argument("--centers", type=int, default=1024, help="clustered data: number of mixture centres")
     ap.add_argument("--sigma", type=float, default=0.1, help="clustered data: per-coordinate spread around a centre")
+    ap.add_argument("--query-groups", type=int, default=0, help="N > 1, Flat / IVF: G groups of N / G row shards, group g answers the "
+                    "g-th slice of the queries (0 = auto: 2 at N >= 8 for L2, else 1 = row shards only)")
     ap.add_argument("--no-configs", action="store_true", help="headline run: skip the embedded C2/C3/C4-shard/C5 lines")
     ap.add_argument("--no-host-pointer", action="store_true", help="headline run: skip the pageable-host-pointer timing")
     ap.add_argument("--parity-device", type=int, default=0, help="re-run this many queries on the exact device kernel "
@@ -159,8 +161,19 @@ def main():
 
     metric = mf.METRIC_L2 if args.metric == "L2" else mf.METRIC_INNER_PRODUCT
     n, d, nq, k = args.n, args.d, args.nq, args.k
+    # N ranks = G query groups x R row shards (rank = g * R + shard); G = 1: row shards only.  A shard's step has a part per (query,
+    # row) pair and a part per query (candidates while the bound converges, exact re-scoring, select): at 8 ranks 2 x 4 halves the
+    # second.  The inner-product tie protocol (below) and the HNSW replicas keep G = 1.
+    qgroups = args.query_groups
+    if qgroups <= 0:
+        qgroups = 2 if (world >= 8 and world % 2 == 0 and args.metric == "L2") else 1
+    if "HNSW" in args.index and "IVF" not in args.index:
+        qgroups = 1
+    if world % qgroups != 0 or (qgroups > 1 and args.metric != "L2" and "IVF" not in args.index):
+        raise SystemExit("--query-groups must divide --gpus (Flat inner product: 1)")
+    nshards = world // qgroups
     # row shard of this rank: [r0, r1)
-    r0, r1 = n * rank // world, n * (rank + 1) // world
+    r0, r1 = n * (rank % nshards) // nshards, n * (rank % nshards + 1) // nshards
     DB_SEED, Q_SEED = 1234, 4321
 
     if args.data == "uniform":
@@ -257,11 +270,12 @@ def main():
     # N > 1: two result / exchange buffer sets, so that the host merge of batch i runs while the GPUs search batch i+1
     pipelined = world > 1 and not is_hnsw and not args.no_pipeline and not ip_ties
     Dbuf, Ibuf = [D], [I]
-    xchs = [ShardExchange(nq, k, dev, ip_ties=ip_ties, metric=metric)]
+    xchs = [ShardExchange(nq, k, dev, ip_ties=ip_ties, metric=metric, qgroups=qgroups)]
     if pipelined:
         Dbuf.append(torch.empty_like(D))
         Ibuf.append(torch.empty_like(I))
-        xchs.append(ShardExchange(nq, k, dev, metric=metric))
+        xchs.append(ShardExchange(nq, k, dev, metric=metric, qgroups=qgroups))
+    gq0, gq1 = xchs[0].query_range()  # the queries this rank answers (all of them with one query group)
     state = {"it": 0, "pending": None}
     chunk = args.chunk if args.chunk > 0 else nq
     search_kw = {"nprobe": args.nprobe} if is_ivf else ({"efSearch": args.efsearch} if is_hnsw else {})
@@ -290,8 +304,8 @@ def main():
         slot = state["it"] % len(xchs)
         state["it"] += 1
         Ds, Is = Dbuf[slot], Ibuf[slot]
-        for q0 in range(0, nq, chunk):
-            q1 = min(nq, q0 + chunk)
+        for q0 in range(gq0, gq1, chunk):
+            q1 = min(gq1, q0 + chunk)
             ix.search_torch(xq[q0:q1], ks, D=Ds[q0:q1], I=Is[q0:q1], **search_kw)
         if ip_ties:
             fD, fI = xchs[slot].merge_ip_exact(Ds, Is, xq, lambda xf, T: ix.tie_candidates_torch(xf, T, k))
@@ -302,7 +316,7 @@ def main():
             # exchange step: per-shard (distance,label) blocks over xGMI + copy to pinned host memory, enqueued behind
             # the search; then the host k-way merge (rank 0) -- of the PREVIOUS batch when pipelined, so that it
             # overlaps this batch's search (every merge still happens inside the timed region: fence() drains)
-            xchs[slot].gather_async(Ds, Is)
+            xchs[slot].gather_async(Ds[gq0:gq1], Is[gq0:gq1])
             if pipelined:
                 drain()
                 state["pending"] = slot
@@ -374,8 +388,8 @@ def main():
             "config": {
                 "workload": "%s %s d=%d N=%d nq=%d k=%d" % (args.index, args.metric, d, n, nq, k),
                 "queries_per_call": chunk,
-                "row_shards": 1 if is_hnsw else world,
-                "replicas": world if is_hnsw else 1,
+                "row_shards": 1 if is_hnsw else nshards,
+                "replicas": world if is_hnsw else qgroups,  # (query groups: each holds the whole database as row_shards shards)
                 "exchange": (
                     "gather of disjoint result rows"
                     if is_hnsw

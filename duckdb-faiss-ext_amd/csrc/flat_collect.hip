@@ -292,7 +292,8 @@ void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, cons
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 // SEL: an IDSelector is active -- only the rows whose bit is set in a.rowmask (one bit per row, built per search by
 // collect_rowmask_kernel) are published and appended; the bound then is the kk-th best SELECTED row's, as it must be
-template <int KCH, bool IS_L2, bool COLLECT, int ABL = 0, bool SEL = false>
+// NC: row classes per query (row & (NC - 1)): 16, or 32 for 16 < kk <= 32 (the bound is the kk-th best of NC class bests)
+template <int KCH, bool IS_L2, bool COLLECT, int ABL = 0, bool SEL = false, int NC = 16>
 __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const CollectArgs a) {
 	constexpr int DP = KCH * 16;
 	constexpr int KB = DP / 32;               // k-blocks of 32 dimensions
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				const float v = (j & 2) ? hi : lo;
 				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
 				typedef __attribute__((address_space(1))) unsigned *GU;
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
 				if (COLLECT) {
 					unsigned pos;
@@ -462,27 +463,27 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			for (int i = 0; i < 2; ++i) { // one query at a time: 128 VGPRs of fragments are resident, the network needs ~40 more
 				const int q = qo + 32 * hq + 16 * i + c;
 				const int qc = q < a.nq ? q : 0;
-				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
-				unsigned long long w[8];
+				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC);
+				unsigned long long w[NC / 2];
 #pragma unroll
-				for (int j = 0; j < 8; ++j)
+				for (int j = 0; j < NC / 2; ++j)
 					w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const float e2v = __builtin_nontemporal_load(a.e2 + qc);
 #pragma unroll
-				for (int j = 0; j < 8; ++j) // every load is issued before the first is consumed: one round trip
+				for (int j = 0; j < NC / 2; ++j) // every load is issued before the first is consumed: one round trip
 					asm volatile("" : "+v"(w[j]));
-				unsigned key[16];
+				unsigned key[NC];
 #pragma unroll
-				for (int j = 0; j < 8; ++j) {
+				for (int j = 0; j < NC / 2; ++j) {
 					key[2 * j] = (unsigned)w[j];
 					key[2 * j + 1] = (unsigned)(w[j] >> 32);
 				}
 #pragma unroll
-				for (int kbit = 2; kbit <= 16; kbit <<= 1)
+				for (int kbit = 2; kbit <= NC; kbit <<= 1)
 #pragma unroll
 					for (int jb = kbit >> 1; jb > 0; jb >>= 1)
 #pragma unroll
-						for (int x0 = 0; x0 < 16; ++x0) {
+						for (int x0 = 0; x0 < NC; ++x0) {
 							const int x1 = x0 ^ jb;
 							if (x1 > x0) {
 								const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 						}
 				unsigned kth = key[0];
 #pragma unroll
-				for (int j = 1; j < 16; ++j)
+				for (int j = 1; j < NC; ++j)
 					kth = (a.nclass - 1 == j) ? key[j] : kth;
 				const unsigned neutral = skey(-FLT_MAX);
 				const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
@@ -714,6 +715,22 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 	}
 		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7) MVS_CL_ABL(11) MVS_CL_ABL(15)
 #undef MVS_CL_ABL
+	} else if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes
+#define MVS_CL_NC32(L2, SEL_)                                                                                           \
+	{                                                                                                                  \
+		auto kern = flat_bf16_collect_kernel<8, L2, COLLECT, 0, SEL_, 32>;                                             \
+		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
+	}
+		if (a.rowmask && metric == METRIC_L2)
+			MVS_CL_NC32(true, true)
+		else if (a.rowmask)
+			MVS_CL_NC32(false, true)
+		else if (metric == METRIC_L2)
+			MVS_CL_NC32(true, false)
+		else
+			MVS_CL_NC32(false, false)
+#undef MVS_CL_NC32
 	} else if (a.rowmask) {
 		if (metric == METRIC_L2) {
 			auto kern = flat_bf16_collect_kernel<8, true, COLLECT, 0, true>;
@@ -910,18 +927,21 @@ static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t
 	MVS_HIP(hipGetLastError());
 }
 
+// row classes per query: 16, or 32 for 16 < kk <= 32 (d <= 128 only: the wide instances keep 16)
 int collect_slot_stride(int kk) {
-	(void)kk;
-	return 16;
+	return kk > 16 ? 32 : 16;
+}
+int collect_max_k(int d) {
+	return collect_store_dims(d) == 128 ? 32 : (collect_store_dims(d) > 0 ? 16 : 0);
 }
 
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
                             unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, hipStream_t st) {
-	const int stride = 16; // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
+	const int stride = collect_slot_stride(kk); // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
-	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, 16,
+	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, stride,
 	                   0 /* larger s is better */);
 	MVS_HIP(hipMemsetAsync(d_stream_cnt, 0, 16, st));
 	CollectArgs a;
@@ -938,7 +958,7 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.opt = g_ksplit_opt;
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
 	const int dp1 = collect_store_dims(g.d);
-	if (dp1 == 128 && g_cl_seed_regs) {
+	if (dp1 == 128 && g_cl_seed_regs && stride == 16) { // (32 classes: 64 registers of maxima do not fit; the publish-only scan below)
 		// d <= 128: class maxima in registers (flat_bf16_seed_kernel) -- cheap enough for 32 768 rows (an eighth of a small index)
 		const int64_t rows = std::min<int64_t>(g_cl_seed_rows > 16384 ? g_cl_seed_rows : 32768, n / 8) / 64 * 64;
 		if (rows >= 1024)
@@ -966,7 +986,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.yn = d_norms;
 	a.e2 = d_e2;
 	a.gslot = d_gslot;
-	a.slot_stride = 16;
+	a.slot_stride = collect_slot_stride(kk);
 	a.nclass = kk;
 	a.nq = (int)nq;
 	a.stream = d_stream;
@@ -1070,7 +1090,17 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 	const unsigned row = (unsigned)ent;
 	const long long q = (long long)(ent >> 32);
 	const int sub = lane / CPR, ch = lane % CPR;
-#pragma unroll 8
+	const float *xq = x + q * d;
+	// d = DP (the headline's 128): the lane's WHOLE query in registers, every load issued before the rows are staged -- one memory
+	// round trip instead of one per four dimensions in front of the fma chain.  (global 16-byte loads need 4-byte alignment only)
+	const bool whole = d == DP;
+	float4 xr[CPR];
+	if (whole) {
+#pragma unroll
+		for (int c4 = 0; c4 < CPR; ++c4)
+			xr[c4] = *(const float4 *)(xq + c4 * 4);
+	}
+#pragma unroll 16
 	for (int r = 0; r < 64; r += RPI) {
 		const unsigned rr = (unsigned)__shfl((int)row, r + sub);
 		const float4 v = *(const float4 *)(vecs + (size_t)rr * DP + ch * 4);
@@ -1080,10 +1110,38 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 	if (i >= ncand)
 		return;
 	const float *y = rows + lane * PITCH;
-	const float *xq = x + q * d;
 	const bool odd = interleaved && ((row >> 4) & 1);
 	float ip = 0.f;
-	for (int g4 = 0; g4 < d; g4 += 4) {
+	if (whole) {
+#pragma unroll
+		for (int c4 = 0; c4 < CPR; ++c4) {
+			const float4 s = *(const float4 *)(y + c4 * 4);
+			float v0, v1, v2, v3;
+			if (!interleaved)
+				v0 = s.x, v1 = s.y, v2 = s.z, v3 = s.w;
+			else if (odd)
+				v0 = s.z, v1 = s.x, v2 = s.w, v3 = s.y;
+			else
+				v0 = s.x, v1 = s.z, v2 = s.y, v3 = s.w;
+			const float4 xv = xr[c4];
+			if (PAIR) {
+				float t = __fsub_rn(xv.x, v0);
+				ip = fmaf(t, t, ip);
+				t = __fsub_rn(xv.y, v1);
+				ip = fmaf(t, t, ip);
+				t = __fsub_rn(xv.z, v2);
+				ip = fmaf(t, t, ip);
+				t = __fsub_rn(xv.w, v3);
+				ip = fmaf(t, t, ip);
+			} else {
+				ip = fmaf(xv.x, v0, ip);
+				ip = fmaf(xv.y, v1, ip);
+				ip = fmaf(xv.z, v2, ip);
+				ip = fmaf(xv.w, v3, ip);
+			}
+		}
+	}
+	for (int g4 = whole ? d : 0; g4 < d; g4 += 4) {
 		const float4 s = *(const float4 *)(y + g4);
 		float v0, v1, v2, v3;
 		if (!interleaved)

@@ -183,6 +183,7 @@ public:
 	const unsigned long long *cl_sorted = nullptr;  // the re-scored candidate list of the last coarse-filter batch (in ws_stream)
 	const unsigned long long *tie_sorted = nullptr; // != nullptr: resolve_ip_ties reads A_k off that list instead of scanning again
 	bool tie_from_candidates = true; // option tie_from_candidates = 0: inner-product ties re-scan the database (A/B, tests)
+	bool cl_k32 = true;       // 16 < k <= 32 at d <= 128 on the coarse filter with 32 row classes (option cl_k32; 0: bf16x3 / f32 as before)
 	bool cl_small_path = true; // batches of <= 256 queries on the one-wavefront-per-segment kernel (option cl_small_path)
 	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask, ws_items1, ws_qcount;
 	void ensure_bf16_rows(hipStream_t st);
@@ -318,6 +319,7 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
 void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 int collect_slot_stride(int kk);
+int collect_max_k(int d); // largest k (+1 with tie detection) the coarse filter serves at this d: 32 (d <= 128), 16, or 0
 int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int64_t nq, int share, int *d_qcount, float *d_e2,
                               int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,

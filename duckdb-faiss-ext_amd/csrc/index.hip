@@ -410,7 +410,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, rowmask, st);
 	int grid = 0, nsplit = 0, lds = 0;
-	const bool few = !wide && nq <= 128 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
+	const bool few = !wide && nq <= 128 && kk <= 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
 	for (int attempt = 0;; ++attempt) {
 	begin_kernel_timing(st);
@@ -833,11 +833,12 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
 	if (wide && (kk > 16 || prefilter_mode == 1))
 		return false;
-	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16))
+	const int cl_kmax = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
+	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax))
 		return false;
 	// auto: the contraction must dominate.  The coarse filter wins from FAISS's first BLAS-branch batch on (N = 10M: 1.3 ms vs
 	// 3.5 ms at 64 queries, 1.7 vs 11.0 at 500); the bf16x3 kernel needs whole 256-query blocks to pay
-	const bool collect_ok = (prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16;
+	const bool collect_ok = (prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax;
 	// (N = 131 072: 0.35 vs 0.46 ms at 64 queries, 1.36 vs 3.88 at 10k; N = 65 536: 1.40 vs 2.25 at 10k but 1.07 vs 0.61 at 2048;
 	// below that the f32 kernel's ~0.3 ms wins everywhere)
 	const bool big_enough = ntotal >= 262144 || (collect_ok && ntotal >= 65536 && (double)nq * (double)ntotal >= 5e8) ||
@@ -857,7 +858,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	bool collected = false;
 	// Coarse filter (one bf16 product per pair, candidates by a proven bound): mode 2 forces it, auto prefers it where
 	// its kernel exists (d = 128 geometry, lists of <= 16); on a stream overflow the bf16x3 path below takes the batch
-	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= 16) {
+	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax) {
 		kp = (int)kk;
 		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st);
 		if (!collected)
@@ -1865,6 +1866,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "tie_from_candidates")) {
 		tie_from_candidates = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "cl_k32")) {
+		cl_k32 = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "cl_small_path")) { // 0: small batches on flat_bf16_collect_kernel as well (A/B)

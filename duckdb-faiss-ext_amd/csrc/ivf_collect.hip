@@ -578,20 +578,53 @@ __global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long lon
 	const unsigned long long ent = i < ncand ? sorted[i] : 0ull;
 	const long long q = (long long)(ent >> 32);
 	const int pos = i < ncand ? perm[(unsigned)ent] : 0;
-	for (int it = 0; it < cpr; ++it) { // 64 consecutive float4 of the 64 x cpr block per step
-		const int idx = it * 64 + lane, r = idx / cpr, ch = idx - r * cpr;
-		const int pp = __shfl(pos, r);
-		const float4 v = *(const float4 *)(rows_csr + (size_t)(pp < 0 ? 0 : pp) * dp + ch * 4);
-		*(float4 *)(rows + r * pitch + ch * 4) = v;
+	const float *xq = x + q * d;
+	// d = 128: the lane's whole query in registers, every load issued before the rows are staged (csrc/flat_collect.hip, collect_exact_kernel)
+	const bool whole = d == 128 && dp == 128;
+	float4 xr[32];
+	if (whole) {
+#pragma unroll
+		for (int c4 = 0; c4 < 32; ++c4)
+			xr[c4] = *(const float4 *)(xq + c4 * 4);
+#pragma unroll 16
+		for (int it = 0; it < 32; ++it) {
+			const int r = 2 * it + (lane >> 5), ch = lane & 31;
+			const int pp = __shfl(pos, r);
+			const float4 v = *(const float4 *)(rows_csr + (size_t)(pp < 0 ? 0 : pp) * 128 + ch * 4);
+			*(float4 *)(rows + r * 132 + ch * 4) = v;
+		}
+	} else {
+		for (int it = 0; it < cpr; ++it) { // 64 consecutive float4 of the 64 x cpr block per step
+			const int idx = it * 64 + lane, r = idx / cpr, ch = idx - r * cpr;
+			const int pp = __shfl(pos, r);
+			const float4 v = *(const float4 *)(rows_csr + (size_t)(pp < 0 ? 0 : pp) * dp + ch * 4);
+			*(float4 *)(rows + r * pitch + ch * 4) = v;
+		}
 	}
 	__syncthreads();
 	if (i >= ncand)
 		return;
 	const float *y = rows + lane * pitch;
-	const float *xq = x + q * d;
 	float acc = 0.f;
 	int kk = 0;
-	if ((d & 3) == 0) { // 16-byte loads of the query and of the staged row; the chain keeps its k order
+	if (whole) {
+#pragma unroll
+		for (int c4 = 0; c4 < 32; ++c4) {
+			const float4 xv = xr[c4];
+			const float4 yv = *(const float4 *)(y + c4 * 4);
+			const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				if (IS_L2) {
+					const float t = __fsub_rn(xs[e], ys[e]);
+					acc = fmaf(t, t, acc);
+				} else {
+					acc = fmaf(xs[e], ys[e], acc);
+				}
+			}
+		}
+		kk = d;
+	} else if ((d & 3) == 0) { // 16-byte loads of the query and of the staged row; the chain keeps its k order
 		for (; kk < d; kk += 4) {
 			const float4 xv = *(const float4 *)(xq + kk);
 			const float4 yv = *(const float4 *)(y + kk);

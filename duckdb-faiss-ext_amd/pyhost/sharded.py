@@ -62,41 +62,65 @@ class ShardExchange:
     """Pre-allocated buffers for the exchange step of one (nq, kk) search shape; kk = k, or k + 1 for inner product
     with exact boundary ties (`ip_ties=True`: shards must then search with k + 1 and option ip_exact_ties = 0)."""
 
-    def __init__(self, nq, k, device, group=None, ip_ties=False, metric=None):
+    def __init__(self, nq, k, device, group=None, ip_ties=False, metric=None, qgroups=1):
         # metric given + GPU tensors: the merge runs ON THE DEVICE right behind the all-gather (mvs_merge_records_device) and
         # only the merged [nq, k] block crosses PCIe; otherwise the gathered blocks go to pinned host memory and
         # mvs_merge_shards merges them on the CPU (gloo tests, or when the caller does not say which order applies)
+        # qgroups = G > 1: the ranks form G groups of R = world / G; group g holds the WHOLE database as R row shards and
+        # answers the g-th slice of the queries (rank = g * R + row shard).  A shard's step cost has a part per (query, row)
+        # pair and a part per query; 2 x 4 instead of 1 x 8 halves the second (bench.py --query-groups, DESIGN.md 6.1).
         self.metric = metric
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.G = max(1, int(qgroups))
+        if self.world % self.G != 0 or (ip_ties and self.G > 1):
+            raise ValueError("qgroups must divide the world size (and the inner-product tie protocol needs qgroups = 1)")
+        self.R = self.world // self.G
+        self.qg, self.rs = self.rank // self.R, self.rank % self.R
         self.nq, self.k = nq, k
+        self.nq_g = (nq + self.G - 1) // self.G  # queries per group (the last group may hold fewer)
         self.kk = k + 1 if ip_ties else k
         self.ip_ties = ip_ties
         self.device = device
         if self.world > 1:
-            self.grec = torch.empty((self.world, nq, self.kk, 2), dtype=torch.int64, device=device)
+            self.grec = torch.empty((self.world, self.nq_g, self.kk, 2), dtype=torch.int64, device=device)
             pin = torch.device(device).type == "cuda"
-            self.hrec = torch.empty((self.world, nq, self.kk, 2), dtype=torch.int64, pin_memory=pin)
+            self.hrec = torch.empty((self.world, self.nq_g, self.kk, 2), dtype=torch.int64, pin_memory=pin)
+
+    def query_range(self):
+        """queries [qa, qb) this rank answers (all of them unless qgroups > 1)"""
+        qa = min(self.nq, self.qg * self.nq_g)
+        return qa, min(self.nq, qa + self.nq_g)
+
+    def row_bounds(self, n):
+        """rows [r0, r1) of this rank's shard"""
+        return shard_bounds(n, self.rs, self.R)
 
     def gather_async(self, D, I, merge_rank=0):
         """first half: ONE all-gather of the packed records + (on merge_rank) the device-to-pinned-host copy, all enqueued
-        on the current stream; nothing here waits for the GPU, so the caller can go on enqueuing the next batch"""
+        on the current stream; nothing here waits for the GPU, so the caller can go on enqueuing the next batch.
+        D, I: this rank's results for ITS queries (query_range(); all nq of them when qgroups = 1)"""
         self._pending = None
         if self.world == 1:
             self._pending = (D, I, None)
             return
         rec = pack_records(D, I)
-        dist.all_gather_into_tensor(self.grec.view(self.world * self.nq, self.kk, 2), rec, group=self.group)
+        if rec.shape[0] < self.nq_g:  # the last query group: pad (the rows past nq are dropped after the merge)
+            pad = torch.zeros((self.nq_g - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+            pad[..., 1] = -1
+            rec = torch.cat([rec, pad], dim=0)
+        dist.all_gather_into_tensor(self.grec.view(self.world * self.nq_g, self.kk, 2), rec, group=self.group)
         if self.rank != merge_rank:
             return
         if self.grec.is_cuda and self.metric is not None and not self.ip_ties:
-            Dm, Im = mf.merge_records_torch(self.metric, self.grec, self.k)
             if not hasattr(self, "hD"):
-                self.hD = torch.empty((self.nq, self.k), dtype=torch.float32, pin_memory=True)
-                self.hI = torch.empty((self.nq, self.k), dtype=torch.int64, pin_memory=True)
-            self.hD.copy_(Dm, non_blocking=True)
-            self.hI.copy_(Im, non_blocking=True)
+                self.hD = torch.empty((self.G * self.nq_g, self.k), dtype=torch.float32, pin_memory=True)
+                self.hI = torch.empty((self.G * self.nq_g, self.k), dtype=torch.int64, pin_memory=True)
+            for g in range(self.G):  # one k-way merge per query group over its R row shards
+                Dm, Im = mf.merge_records_torch(self.metric, self.grec[g * self.R : (g + 1) * self.R], self.k)
+                self.hD[g * self.nq_g : (g + 1) * self.nq_g].copy_(Dm, non_blocking=True)
+                self.hI[g * self.nq_g : (g + 1) * self.nq_g].copy_(Im, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.grec.device))
             self._pending = ("device", None, ev)
@@ -120,9 +144,12 @@ class ShardExchange:
         if ev is not None:
             ev.synchronize()
         if isinstance(D, str):  # merged on the device by gather_async
-            return self.hD.numpy().copy(), self.hI.numpy().copy()
+            return self.hD.numpy()[: self.nq].copy(), self.hI.numpy()[: self.nq].copy()
         hD, hI = unpack_records(self.hrec.numpy())
-        return mf.merge_shards(metric, hD, hI)
+        if self.G == 1:
+            return mf.merge_shards(metric, hD, hI)
+        parts = [mf.merge_shards(metric, hD[g * self.R : (g + 1) * self.R], hI[g * self.R : (g + 1) * self.R]) for g in range(self.G)]
+        return (np.concatenate([p[0] for p in parts])[: self.nq], np.concatenate([p[1] for p in parts])[: self.nq])
 
     def merge(self, metric, D, I, merge_rank=0):
         """exchange + host merge; returns (D, I) numpy [nq, k] on merge_rank, (None, None) elsewhere"""

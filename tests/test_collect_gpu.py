@@ -62,6 +62,27 @@ def test_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 150_000, 600, 20), (128, 80_000, 300, 31), (96, 60_000, 150, 17), (128, 40_000, 40, 24)])
+def test_k_up_to_32_takes_the_coarse_filter_with_32_row_classes(mf, metric, d, nb, nq, k):
+    """16 < k <= 32 at d <= 128: 32 class slots per query (row & 31), the bound is the k-th best of them; same kernel, same
+    re-scoring, same answers as the exact f32 kernel and the oracle.  (Inner product searches k + 1 for the tie detection:
+    k <= 31.)  Small batches take the workgroup kernel here (the one-wavefront-per-segment kernel keeps 16 classes)."""
+    rs = np.random.RandomState(k * 1000 + d)
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[::53] = xb[11]  # duplicates: ties inside the result lists
+    cl, ex = _pair(mf, d, metric, xb)
+    _check(cl, ex, xq, k, metric, xb, oracle_rows=48)
+    st = cl.collect_stats()
+    assert st["queries"] == nq and st["overflows"] == 0, st
+    cl.set_option("cl_k32", 0)  # the round-2 route for these k: bf16x3 prefilter / exact kernel
+    D2, I2 = cl.search(xq, k)
+    assert cl.last_kernel_info()["name"] != KERNEL
+    D1, I1 = ex.search(xq, k)
+    assert np.array_equal(I2, I1) and np.array_equal(D2.view(np.uint32), D1.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
 def test_duplicates_and_ties_need_no_fall_back(mf, metric):
     """40 distinct vectors repeated 100k times: every row tied at the k-th value is a candidate -- 2 500 copies of each of
     the nearest vectors, more than the candidate stream holds: the batch overflows and the bf16x3 path (and behind it the

@@ -115,3 +115,45 @@ def test_two_rank_ivf_replicated_centroids_equals_unsharded():
     port = 31700 + (os.getpid() % 2000)
     mp.spawn(_ivf_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["same_D"] and ret["same_I"]
+
+
+def _qgroup_worker(rank, world, port, qgroups, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from sharded import ShardExchange
+
+    orc.set_num_threads(1)
+    n, d, nq, k = 12000, 24, 45, 10  # (45 queries: the last query group is shorter than the first)
+    xb = orc.synth_uniform(n, d, 1234)
+    xb[::89] = xb[7]  # duplicates -> ties across shards
+    xq = orc.synth_uniform(nq, d, 4321)
+    xch = ShardExchange(nq, k, "cpu", qgroups=qgroups)
+    r0, r1 = xch.row_bounds(n)
+    qa, qb = xch.query_range()
+    D, I = orc.flat_search(orc.METRIC_L2, xb[r0:r1], xq[qa:qb], k, force_path=orc.PATH_BLAS)
+    I = np.where(I >= 0, I + r0, -1)
+    Dm, Im = xch.merge(orc.METRIC_L2, torch.from_numpy(D), torch.from_numpy(I))
+    if rank == 0:
+        Dr, Ir = orc.flat_search(orc.METRIC_L2, xb, xq, k, force_path=orc.PATH_BLAS)
+        ret["shape"] = tuple(Dm.shape)
+        ret["same_D"] = bool(np.array_equal(Dm, Dr))
+        ret["same_I"] = bool(np.array_equal(Im, Ir))
+        ret["layout"] = (xch.G, xch.R)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,qgroups", [(4, 2), (2, 2)])
+def test_query_groups_times_row_shards_equal_unsharded(world, qgroups):
+    """bench.py --query-groups: G groups of R = world / G row shards, group g answers the g-th slice of the queries; one
+    all-gather, one k-way merge per group -> the unsharded result (4 ranks = 2 x 2; 2 ranks = 2 x 1: query slices only)"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33100 + (os.getpid() % 2000) + 7 * world
+    mp.spawn(_qgroup_worker, args=(world, port, qgroups, ret), nprocs=world, join=True)
+    assert ret["shape"] == (45, 10) and ret["layout"] == (qgroups, world // qgroups), dict(ret)
+    assert ret["same_D"] and ret["same_I"], dict(ret)
