@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--centers", type=int, default=1024, help="clustered data: number of mixture centres")
     ap.add_argument("--sigma", type=float, default=0.1, help="clustered data: per-coordinate spread around a centre")
     ap.add_argument("--query-groups", type=int, default=0, help="N > 1, Flat / IVF: G groups of N / G row shards, group g answers the "
-                    "g-th slice of the queries (0 = auto: 2 at N >= 8 for L2, else 1 = row shards only)")
+                    "g-th slice of the queries (0 = auto: 2 at N >= 4 for L2, else 1 = row shards only)")
     ap.add_argument("--no-configs", action="store_true", help="headline run: skip the embedded C2/C3/C4-shard/C5 lines")
     ap.add_argument("--no-host-pointer", action="store_true", help="headline run: skip the pageable-host-pointer timing")
     ap.add_argument("--parity-device", type=int, default=0, help="re-run this many queries on the exact device kernel "
@@ -166,7 +166,9 @@ def main():
     # second.  The inner-product tie protocol (below) and the HNSW replicas keep G = 1.
     qgroups = args.query_groups
     if qgroups <= 0:
-        qgroups = 2 if (world >= 8 and world % 2 == 0 and args.metric == "L2") else 1
+        # (one GPU's step at the shapes a decomposition hands it, headline, ms: 8 GPUs 1x8 3.16 | 2x4 3.02 | 4x2 2.99 | 8x1 3.30;
+        # 4 GPUs 1x4 5.40 | 2x2 5.19; 2 GPUs 1x2 9.67 | 2x1 9.51 -- profiles/r3_shard_shapes.txt)
+        qgroups = 2 if (world >= 4 and world % 2 == 0 and args.metric == "L2") else 1
     if "HNSW" in args.index and "IVF" not in args.index:
         qgroups = 1
     if world % qgroups != 0 or (qgroups > 1 and args.metric != "L2" and "IVF" not in args.index):

@@ -93,7 +93,7 @@ __device__ __forceinline__ float cl_dpp(float v) {
 // one thread per (row, 8 dims); the dp / 8 threads of a row are neighbours in a wave
 // max_bits[0]: largest squared norm of the ORIGINAL rows (shared with flat_bf16.hip), max_bits[8]: of the centred rows
 template <bool IS_L2>
-__global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp,
+__global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp, int dpd,
                                        int interleaved, const float *__restrict__ mu, unsigned short *__restrict__ dst,
                                        float *__restrict__ beta, const float *__restrict__ norms,
                                        unsigned *__restrict__ max_bits) {
@@ -137,7 +137,7 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 	}
 	if (!live)
 		return;
-	*(bf16x8 *)(dst + (size_t)r * dp + c8 * 8) = hi;
+	*(bf16x8 *)(dst + (size_t)r * dpd + c8 * 8) = hi; // (dpd = 128 >= dp: the store is zero-filled when it is allocated)
 	if (c8 == 0) {
 		beta[r] = IS_L2 ? -n2 : my;
 		const unsigned b = __float_as_uint(norms[r]);
@@ -156,10 +156,10 @@ void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, 
 	const long long total = (long long)nrows * (g.dp / 8);
 	const dim3 grid((unsigned)((total + 255) / 256));
 	if (metric == METRIC_L2)
-		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<true>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp,
+		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<true>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp, 128,
 		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
 	else
-		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<false>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp,
+		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<false>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp, 128,
 		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
 	MVS_HIP(hipGetLastError());
 }
@@ -187,8 +187,9 @@ __global__ void collect_pack_queries_kernel(const float *__restrict__ x, long lo
 	qf[i] = hi;
 }
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq) {
+	(void)g; // (the d <= 128 store is 128 dims wide whatever FlatGeom::dp is: 16 < d <= 64 rows are zero-padded)
 	const int64_t nblk16 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 16);
-	return (size_t)nblk16 * (g.dp / 32) * 64 * 16;
+	return (size_t)nblk16 * 4 * 64 * 16;
 }
 // the same for a store of dp1 dims and workgroups of `qblock` queries (csrc/flat_collect_wide.hip)
 size_t collect_qfrag_bytes_ex(int dp1, int qblock, int64_t nq) {
@@ -206,9 +207,9 @@ void launch_collect_pack_queries_ex(int d, int dp1, int qblock, int metric, cons
 void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x, int64_t nq, const float *d_mu, void *d_qf,
                                  hipStream_t st) {
 	const int64_t nblk16 = (nq + CL_QBLOCK - 1) / CL_QBLOCK * (CL_QBLOCK / 16);
-	const long long total = (long long)nblk16 * (g.dp / 32) * 64;
+	const long long total = (long long)nblk16 * 4 * 64;
 	hipLaunchKernelGGL(collect_pack_queries_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_x,
-	                   (long long)nq, g.d, g.dp / 32, d_mu, metric == METRIC_L2 ? 2.0f : 1.0f, (bf16x8 *)d_qf, total);
+	                   (long long)nq, g.d, 4, d_mu, metric == METRIC_L2 ? 2.0f : 1.0f, (bf16x8 *)d_qf, total);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -633,7 +634,8 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 }
 
 static size_t collect_lds_bytes(const FlatGeom &g) {
-	return (size_t)2 * CL_SUB * CL_BN * g.dp * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)CL_QBLOCK * 4 + 64;
+	(void)g;
+	return (size_t)2 * CL_SUB * CL_BN * 128 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)CL_QBLOCK * 4 + 64;
 }
 
 bool collect_supported(const FlatGeom &g) {
@@ -928,8 +930,9 @@ static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t
 }
 
 // row classes per query: 16, or 32 for 16 < kk <= 32 (d <= 128 only: the wide instances keep 16)
+int g_cl_nc32_from = 17; // option cl_nc32_from
 int collect_slot_stride(int kk) {
-	return kk > 16 ? 32 : 16;
+	return (kk > 16 || kk >= g_cl_nc32_from) ? 32 : 16;
 }
 int collect_max_k(int d) {
 	return collect_store_dims(d) == 128 ? 32 : (collect_store_dims(d) > 0 ? 16 : 0);
@@ -1321,15 +1324,28 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
 		launch_collect_exact_wide(metric, per_pair, d_sorted, ncand, d_x, g.d, d_vecs, g.dp, g.pair_interleaved ? 1 : 0, d_norms, d_qn, st);
 	} else if (ncand > 0) {
 		const dim3 grid((unsigned)((ncand + 63) / 64));
-		if (metric == METRIC_L2 && per_pair)
-			hipLaunchKernelGGL((collect_exact_kernel<true, 128, true>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,
-			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
-		else if (metric == METRIC_L2)
-			hipLaunchKernelGGL((collect_exact_kernel<true, 128>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,
-			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
+		// (row pitch of the f32 store = FlatGeom::dp: 128 for 64 < d <= 128, 64 / 32 below)
+#define MVS_CL_EXACT(DPV)                                                                                              \
+	{                                                                                                                  \
+		if (metric == METRIC_L2 && per_pair)                                                                           \
+			hipLaunchKernelGGL((collect_exact_kernel<true, DPV, true>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d, \
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);                                     \
+		else if (metric == METRIC_L2)                                                                                  \
+			hipLaunchKernelGGL((collect_exact_kernel<true, DPV>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d, \
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);                                     \
+		else                                                                                                           \
+			hipLaunchKernelGGL((collect_exact_kernel<false, DPV>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d, \
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);                                     \
+	}
+		if (g.dp == 128)
+			MVS_CL_EXACT(128)
+		else if (g.dp == 64)
+			MVS_CL_EXACT(64)
+		else if (g.dp == 32)
+			MVS_CL_EXACT(32)
 		else
-			hipLaunchKernelGGL((collect_exact_kernel<false, 128>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d,
-			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);
+			throw_faiss("mvs::launch_collect_rescore", __FILE__, "no re-scoring instance for a row pitch of %d floats", g.dp);
+#undef MVS_CL_EXACT
 		MVS_HIP(hipGetLastError());
 	}
 	launch_collect_select(metric, d_sorted, d_seg, nq, kk, d_pd1, d_pi1, st);

@@ -776,7 +776,8 @@ void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // row pitch (dims) of the bf16 store for a logical dimension: 128 (flat_collect.hip), 256, 384, 512 or 768 (k-split); 0 = not served
 int collect_store_dims(int d) {
-	return d <= 64 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : 0))))));
+	// (d <= 16: the f32 kernel's contraction is 8-16 dims deep and wins against a 128-dim bf16 product)
+	return d <= 16 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : 0))))));
 }
 int g_ksplit_waves = 4; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
 int g_wide512_ksplit = 0; // option cl_wide512_ksplit: the 512-dim store on the k-split kernel (8 k-blocks per wave, 3 column blocks)

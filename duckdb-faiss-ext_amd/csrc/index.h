@@ -347,7 +347,7 @@ void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_so
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,
                            int32_t *d_pi1, hipStream_t st);
-extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_regs;
+extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_regs, g_cl_nc32_from;
 // csrc/ivf_collect.hip
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
                              float *d_beta, unsigned *d_list_max_bits, hipStream_t st);

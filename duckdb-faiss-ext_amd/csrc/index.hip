@@ -410,7 +410,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, rowmask, st);
 	int grid = 0, nsplit = 0, lds = 0;
-	const bool few = !wide && nq <= 128 && kk <= 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
+	const bool few = !wide && nq <= 128 && collect_slot_stride(kk) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
 	for (int attempt = 0;; ++attempt) {
 	begin_kernel_timing(st);
@@ -827,11 +827,13 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
                                  int64_t out_off, const TieFlags *flp, hipStream_t st) {
 	// 128 < d <= 1024: only the coarse filter exists (csrc/flat_collect_wide.hip; no bf16x3 behind it)
 	const bool wide = collect_store_dims(d) > 128;
-	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !wide) || kk > 40)
+	// (16 < d <= 32: the coarse filter only, as for the wide stores)
+	const bool cl_only = wide || !prefilter_supported(geom);
+	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !collect_supported(geom)) || kk > 40)
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
-	if (wide && (kk > 16 || prefilter_mode == 1))
+	if (cl_only && (kk > (wide ? 16 : 32) || prefilter_mode == 1))
 		return false;
 	const int cl_kmax = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
 	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax))
@@ -864,7 +866,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		if (!collected)
 			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 	}
-	if (!collected && (has_sel || nq < 20 || wide))
+	if (!collected && (has_sel || nq < 20 || cl_only))
 		return false; // (stream overflow under a selector / in the per-pair branch: the exact kernels take the batch)
 	if (!collected) {
 	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the
@@ -1886,6 +1888,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "cl_stream_cap")) { // coarse filter: candidate-stream entries per query (diagnostics: provoke the overflow paths)
 		cl_stream_cap_per_query = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_nc32_from")) { // 32 row classes from this kk on (default 17: only where 16 classes cannot serve)
+		g_cl_nc32_from = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "cl_seed_regs")) { // d <= 128 pre-pass: class maxima in registers (1) or the scan kernel's rare path (0)

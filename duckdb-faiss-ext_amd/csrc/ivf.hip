@@ -714,7 +714,7 @@ public:
 			return;
 		}
 		// default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
-		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= 16 && d <= 128 &&
+		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= (collect_k32 ? 32 : 16) && d <= 128 &&
 		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26)) { // (faster than the scanner kernel from one query on)
 			if (collect_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
 				return;
@@ -885,8 +885,9 @@ public:
 		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
 		ws_qfail.reserve((size_t)nq * sizeof(int));
 		ws_cimask.reserve((size_t)npairs * sizeof(int64_t));
-		ws_gslot.reserve((size_t)nq * 16 * sizeof(unsigned) + 64);
-		launch_init_slots((unsigned *)ws_gslot.p, nq, 16, METRIC_IP, stream); // "larger s is better": all 16 classes neutral
+		const int nclass = k > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
+		ws_gslot.reserve((size_t)nq * nclass * sizeof(unsigned) + 64);
+		launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
 		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, (size_t)nq * sizeof(int), stream));
 		const int64_t cap_entries = std::max<int64_t>(nq * 4096, (int64_t)1 << 20);
 		const size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
@@ -1396,6 +1397,10 @@ public:
 			force_select = v != 0;
 			return true;
 		}
+		if (!strcmp(key, "ivf_collect_k32")) {
+			collect_k32 = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_prepass")) { // coarse filter pre-pass: 0 = the nearest list of every query (own grouping), n > 0 = the first n rows of every probed list
 			cl_prepass_all = v > 0;
 			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
@@ -1418,7 +1423,8 @@ public:
 	bool raw_pos = false;   // inside the exact-tie wrapper: the paths emit positions in the list-sorted store, no id map
 	bool force_select = false;
 	bool raw_ids = false;
-	int collect_mode = -1; // option ivf_collect: -1 auto, 0 never, 1 wherever the kernel exists (L2, d <= 128, k <= 16)
+	int collect_mode = -1; // option ivf_collect: -1 auto, 0 never, 1 wherever the kernel exists (d <= 128, k <= 32)
+	bool collect_k32 = true; // option ivf_collect_k32: 16 < k <= 32 with 32 row classes (0: the scanner kernel as in round 2)
 	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always, 2 = L2 prefilter + exact re-scoring
 
 	// introspection for parity tests

@@ -247,7 +247,9 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
 // MFMA geometry, LDS layout of a tile, half-tile pipeline and rare path as flat_bf16_collect_kernel (csrc/flat_collect.hip);
 // what differs: the wave stages its own tiles (8 LDS-DMA instructions per 32-row tile), the chain starts at beta + gamma, the
 // bounds of the item's 128 slots live in an LDS table {B - E, gamma} that the wave refreshes itself.
+// NC: row classes per query (16, or 32 for 16 < kk <= 32 -- csrc/flat_collect.hip)
 typedef float f32x4a __attribute__((ext_vector_type(4)));
+template <int NC>
 __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollectArgs a) {
 	constexpr int KB = 4, PITCH = 256, TILE_BYTES = IC_BN * PITCH;
 	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 8 + 64) / 4];
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
 				typedef __attribute__((address_space(1))) unsigned *GU;
 				// the slots hold LOWER bounds s - E(list): E differs between the lists a query probes
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), ic_skey(v - eh), __ATOMIC_RELAXED,
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - eh), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
 				if (!a.collect)
 					continue;
@@ -412,34 +414,45 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		// csrc/flat_collect.hip.
 		const int period = a.refresh > 0 ? a.refresh : (u < 4 ? 1 : (u < 32 ? 4 : 16));
 		if ((u % period) == 0) {
-			unsigned long long w[2][8];
-#pragma unroll
-			for (int i = 0; i < 2; ++i) {
+			// (NC = 16: both queries' slots in one round trip; NC = 32: one query at a time -- 32 keys + the network's temporaries)
+			unsigned long long w[NC == 16 ? 2 : 1][NC / 2];
+			auto fetch = [&](int i, int wi) {
 				const int qc = own_q[i] >= 0 ? own_q[i] : 0;
-				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
+				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC);
 #pragma unroll
-				for (int j = 0; j < 8; ++j)
-					w[i][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				for (int j = 0; j < NC / 2; ++j)
+					w[wi][j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			};
+			if (NC == 16) {
+				fetch(0, 0);
+				fetch(1, NC == 16 ? 1 : 0);
+#pragma unroll
+				for (int i = 0; i < (NC == 16 ? 2 : 1); ++i)
+#pragma unroll
+					for (int j = 0; j < NC / 2; ++j)
+						asm volatile("" : "+v"(w[i][j]));
 			}
 #pragma unroll
-			for (int i = 0; i < 2; ++i)
-#pragma unroll
-				for (int j = 0; j < 8; ++j)
-					asm volatile("" : "+v"(w[i][j]));
-#pragma unroll
 			for (int i = 0; i < 2; ++i) {
-				unsigned key[16];
+				const int wi = NC == 16 ? i : 0;
+				if (NC != 16) {
+					fetch(i, 0);
 #pragma unroll
-				for (int j = 0; j < 8; ++j) {
-					key[2 * j] = (unsigned)w[i][j];
-					key[2 * j + 1] = (unsigned)(w[i][j] >> 32);
+					for (int j = 0; j < NC / 2; ++j)
+						asm volatile("" : "+v"(w[0][j]));
+				}
+				unsigned key[NC];
+#pragma unroll
+				for (int j = 0; j < NC / 2; ++j) {
+					key[2 * j] = (unsigned)w[wi][j];
+					key[2 * j + 1] = (unsigned)(w[wi][j] >> 32);
 				}
 #pragma unroll
-				for (int kbit = 2; kbit <= 16; kbit <<= 1)
+				for (int kbit = 2; kbit <= NC; kbit <<= 1)
 #pragma unroll
 					for (int jb = kbit >> 1; jb > 0; jb >>= 1)
 #pragma unroll
-						for (int x0 = 0; x0 < 16; ++x0) {
+						for (int x0 = 0; x0 < NC; ++x0) {
 							const int x1 = x0 ^ jb;
 							if (x1 > x0) {
 								const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 						}
 				unsigned kth = key[0];
 #pragma unroll
-				for (int j = 1; j < 16; ++j)
+				for (int j = 1; j < NC; ++j)
 					kth = (a.kk - 1 == j) ? key[j] : kth;
 				const unsigned neutral = ic_skey(-FLT_MAX);
 				const float B = ic_skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
@@ -557,7 +570,10 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.collect = collect;
 	a.refresh = g_ivf_cl_refresh;
 	a.rowmask = d_rowmask;
-	hipLaunchKernelGGL(ivf_bf16_collect_kernel, dim3(max_items, nseg), dim3(64), 0, st, a);
+	if (kk > 16) // 32 row classes: the caller sized and initialised 32 slots per query (ivf_collect_slot_stride)
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<32>, dim3(max_items, nseg), dim3(64), 0, st, a);
+	else
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<16>, dim3(max_items, nseg), dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
 

@@ -392,7 +392,9 @@ def test_ivf_select_path_equals_k_list_path_at_small_k(mf):
 @pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("idmap", [False, True])
 @pytest.mark.parametrize("d,nlist,n,nq,k,nprobe", [(128, 64, 60000, 500, 10, 8), (64, 16, 20000, 200, 5, 16), (96, 32, 30000, 64, 15, 4),  # (15: k + 1 = 16 entries with the tie detection of csrc/ivf_ties.hip)
-                                                   (128, 32, 50000, 300, 1, 1), (100, 48, 40000, 777, 10, 48)])
+                                                   (128, 32, 50000, 300, 1, 1), (100, 48, 40000, 777, 10, 48),
+                                                   # 16 < k + 1 <= 32: 32 row classes per query (ivf_bf16_collect_kernel<32>)
+                                                   (128, 32, 50000, 300, 20, 6), (64, 16, 30000, 150, 31, 8), (96, 64, 60000, 90, 16, 12)])
 def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, nprobe, idmap, metric):
     """default for L2 batches of >= 64 queries, k <= 16 (option ivf_collect): bf16 coarse filter on residual rows with a
     proven bound + exact re-scoring in IVFFlatScanner's arithmetic (csrc/ivf_collect.hip); must equal the plain scanner
