@@ -38,17 +38,21 @@ int g_wide_big = 1; // option cl_wide_big: 512 < d <= 1024 on flat_bf16_big_kern
 
 // MODE (option cl_big_mode, A/B): bit 0 = the next tile's first fragments and beta are read under the last MFMAs of this one;
 // bit 1 = the LDS-DMA instructions of block u + 3 are spread one per two k-blocks (else issued together behind the barrier)
-template <int KBT, int NCB, bool IS_L2, bool COLLECT, int MODE>
+// KSPL (the 1536-dim store: 2): a row is KSPL PARTS of KBT k-blocks; a staged block holds ONE part of 16 rows (the ring, the barrier
+// and the LDS-DMA pattern are those of a KBT-wide store with KSPL times the rows), the accumulators run through the parts of a row
+// block (the chain starts at beta in part 0) and are tested after the last; all KSPL * KBT k-blocks of query fragments are resident.
+template <int KBT, int NCB, bool IS_L2, bool COLLECT, int MODE, int KSPL = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_bf16_big_kernel(const CollectArgs a) {
 	constexpr bool PF = (MODE & 1) != 0, SPREAD = (MODE & 2) != 0;
-	constexpr int PITCH = 64 * KBT, C = 4 * KBT, RT = 16;
+	constexpr int KT = KBT * KSPL; // k-blocks of a whole row
+	constexpr int PITCH = 64 * KBT, GPITCH = PITCH * KSPL, C = 4 * KBT, RT = 16; // bytes of a staged row (one part) / of a stored row
 	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB (768 dims) / 32 KB (1024)
 	constexpr int NST = 4, KB_BAR = 8;
 	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096;
 	constexpr int QW = 16 * NCB, QB = 4 * QW;
 	constexpr int RA = 4, RING = 8; // A fragments read RA k-blocks ahead into a ring of RING register quads
 	constexpr int FLUSH_EVERY = 8;
-	static_assert(STAGE_BYTES % 4096 == 0 && KBT % RING == 0 && NCB >= 2 && NCB <= 4 && RA < RING, "geometry");
+	static_assert(STAGE_BYTES % 4096 == 0 && KBT % RING == 0 && NCB >= 2 && NCB <= 4 && RA < RING && (KSPL == 1 || KSPL == 2), "geometry");
 	static_assert(KB_BAR + 2 * DMA_PER_WAVE < KBT + 1 && KB_BAR < KBT - RA, "the block's LDS-DMA instructions fit behind the barrier");
 
 	extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 	// B fragments, resident for the whole scan: fragment f = cb * KBT + kb lives in an AGPR quad when f >= NV (the last NAG
 	// = 60 fragments: 240 of the 256 AGPRs), in VGPRs otherwise (36 fragments = 144 VGPRs)
-	constexpr int NAG = 60, NV = NCB * KBT - NAG;
+	constexpr int NAG = KSPL == 2 ? 64 : 60, NV = NCB * KT - NAG; // (two parts: all 256 AGPRs -- with 16 left over hipcc parked a VGPR fragment there and copied it back in front of its MFMAs)
 	static_assert(NV > 0 && NV * 4 <= 160, "VGPR-resident fragments");
 	bf16x8 bqv[NV], bqa[NAG];
 	{
@@ -90,9 +94,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		for (int cb = 0; cb < NCB; ++cb) {
 			const size_t qblk16 = (size_t)qb * (QB / 16) + wave * NCB + cb;
 #pragma unroll
-			for (int kb = 0; kb < KBT; ++kb) {
-				const int f = cb * KBT + kb;
-				const bf16x8 t = qsrc[(qblk16 * KBT + kb) * 64 + lane];
+			for (int kb = 0; kb < KT; ++kb) {
+				const int f = cb * KT + kb;
+				const bf16x8 t = qsrc[(qblk16 * KT + kb) * 64 + lane];
 				if (f < NV) {
 					bqv[f] = t;
 				} else {
@@ -105,15 +109,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 	// LDS-DMA (as flat_collect_wide.hip): instruction inst = 4 i + wave fills LDS bytes [1024 inst, +1024) of the stage; lane l owns
 	// 16-byte slot S = 64 inst + l = (row r = S / C, position p = S % C) and fetches chunk (p & ~15) | ((p & 15) ^ (r & 15))
+	// (u: staged block = row block u / KSPL, part u % KSPL)
 	auto dma_one = [&](int u, int stg, int i) {
-		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)u * RT) * PITCH; // uniform
+		const char *base = (const char *)a.yb + (size_t)(r_begin + (long long)(u / KSPL) * RT) * GPITCH + (size_t)(u % KSPL) * PITCH; // uniform
 		const int inst = 4 * i + wave;
 		const int S = 64 * inst + lane, r = S / C, p = S - r * C;
-		const unsigned off = (unsigned)(r * PITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
+		const unsigned off = (unsigned)(r * GPITCH + (((p & ~15) | ((p & 15) ^ (r & 15))) * 16));
 		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + off), (lds_f32c *)(smem + (stg * STAGE_BYTES + inst * 1024) / 4), 16, 0, 0);
 	};
 	auto dma_beta = [&](int u, int stg) { // wave 0 only
-		const float *bb = a.yn + (r_begin + (long long)u * RT); // uniform
+		const float *bb = a.yn + (r_begin + (long long)(u / KSPL) * RT); // uniform
 		__builtin_amdgcn_global_load_lds((glb_f32c *)(bb + lane), (lds_f32c *)(smem + (NST * STAGE_BYTES) / 4 + stg * 64), 4, 0, 0);
 	};
 	if (nblocks > 0) {
@@ -255,13 +260,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Yv[0]));
 	}
 	// one tile; PAR = u & 1 as a compile-time constant (the accumulator sets must be registers, not an indexed array)
-	auto tile = [&](auto parc, const int u) {
+	// (hc: the part of the row block, compile time; v = u * KSPL + part is the staged block)
+	auto tile = [&](auto parc, auto hc, const int u) {
 		constexpr int par = decltype(parc)::value;
+		constexpr int part = decltype(hc)::value;
+		constexpr bool first = part == 0, last = part == KSPL - 1;
+		const int v = u * KSPL + part;
 		const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
-		if ((u % period) == 0)
+		if (first && (u % period) == 0)
 			refresh();
 		const int nstg = (stg + 1) & 3, dstg = (stg + 3) & 3; // tile u + 1's stage; block u + 3 goes where tile u - 1 was
-		f32x4n cqv;
+		f32x4n cqv = pcq; // (read from the table in the first part; the later parts leave pcq alone)
 		bool any_prev = false;
 		if (!PF) { // this tile's beta and first fragments (its block landed at the previous tile's barrier)
 			read_y(Yv[par], stg);
@@ -281,20 +290,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			}
 			if (SPREAD) {
 				if (kb > KB_BAR && ((kb - KB_BAR) & 1) && (kb - KB_BAR) / 2 < DMA_PER_WAVE)
-					dma_one(u + 3, dstg, (kb - KB_BAR) / 2); // one LDS-DMA instruction per two k-blocks: its issue hides under their MFMAs
+					dma_one(v + 3, dstg, (kb - KB_BAR) / 2); // one LDS-DMA instruction per two k-blocks: its issue hides under their MFMAs
 				if (kb == KB_BAR + 2 && wave == 0)
-					dma_beta(u + 3, dstg);
+					dma_beta(v + 3, dstg);
 			} else if (kb == KB_BAR) {
 #pragma unroll
 				for (int i = 0; i < DMA_PER_WAVE; ++i)
-					dma_one(u + 3, dstg, i);
+					dma_one(v + 3, dstg, i);
 				if (wave == 0)
-					dma_beta(u + 3, dstg);
+					dma_beta(v + 3, dstg);
 			}
-			if (kb == 2)
+			if (first && kb == 2)
 				asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds) : "memory"); // this tile's bounds (tested one tile later)
-			if (PF && kb == KBT - RA)
-				read_y(Yv[par ^ 1], nstg);
+			if (PF && kb == KBT - RA) // (beta of the staged block behind this one: the next row block's when this is the last part)
+				read_y(Yv[par ^ 1], nstg); // (not the last part: block v + 1 carries this row block's beta again -- unused, reloaded at the last part)
 			if (kb + RA < KBT)
 				read_a(A[(kb + RA) % RING], stg, kb + RA);
 			else if (PF)
@@ -306,18 +315,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 				asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(KBT - 1 - kb));
 #pragma unroll
 			for (int i = 0; i < NCB; ++i) {
-				const int f = i * KBT + kb;
+				const int f = i * KT + part * KBT + kb;
+				const bool start = first && kb == 0; // the chain starts at beta(row) in the row block's first part
 				// A column block is accumulated EITHER by the builtin (all its fragments in VGPRs) OR by hand-written MFMAs
 				// (any of them in AGPRs): mixing the two on one accumulator made the compiler copy it between the files with
 				// v_accvgpr_read right in front of a hand-written MFMA -- a VALU write -> MFMA srcC hazard nobody pads.
-				const bool by_hand = (i + 1) * KBT > NV;
+				const bool by_hand = (i + 1) * KT > NV;
 				if (!by_hand) {
-					if (kb == 0) // the chain starts at beta(row): s comes out of the matrix pipe
+					if (start) // s comes out of the matrix pipe
 						acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], Yv[par], 0, 0, 0);
 					else
 						acc[par][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kb % RING], bqv[f < NV ? f : 0], acc[par][i], 0, 0, 0);
 				} else if (f < NV) { // srcB in VGPRs
-					if (kb == 0)
+					if (start)
 						asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
 						             : "=&v"(acc[par][i])
 						             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]), "v"(Yv[par]));
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 						             : "+v"(acc[par][i])
 						             : "v"(A[kb % RING]), "v"(bqv[f < NV ? f : 0]));
 				} else { // srcB from an AGPR quad
-					if (kb == 0)
+					if (start)
 						asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3"
 						             : "=&v"(acc[par][i])
 						             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]), "v"(Yv[par]));
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 						             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]));
 				}
 			}
-			if (kb == 1 && u > 0) { // tile u - 1's running maxima against its bounds, behind this tile's first MFMAs
+			if (first && kb == 1 && u > 0) { // tile u - 1's running maxima against its bounds, behind this tile's first MFMAs
 #pragma unroll
 				for (int i = 0; i < NCB; ++i) {
 					const f32x4b &sv = acc[par ^ 1][i];
@@ -354,14 +364,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(Yv[par ^ 1]), "+v"(cqv));
 		else
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cqv));
-		if (u > 0 && __builtin_amdgcn_ballot_w64(any_prev) != 0ull) {
+		if (first && u > 0 && __builtin_amdgcn_ballot_w64(any_prev) != 0ull) {
 			const long long prow0 = r_begin + (long long)(u - 1) * RT;
 			const int pnvalid = (int)((r_end - prow0) < RT ? (r_end - prow0) : RT);
 			rare(acc[par ^ 1], pcq, prow0, pnvalid);
 		}
 		pcq = cqv;
 		stg = nstg;
-		if (COLLECT && (u % FLUSH_EVERY) == FLUSH_EVERY - 1 && u != nblocks - 1) {
+		if (COLLECT && last && (u % FLUSH_EVERY) == FLUSH_EVERY - 1 && u != nblocks - 1) {
 			// (the fragments read ahead for the next tile are in registers; the compiled LDS accesses below make hipcc drain the
 			// LDS-DMA in flight first -- once per FLUSH_EVERY tiles)
 			__syncthreads(); // the tile's own barrier stands in mid-tile: every wave's appends of this tile must be in before the look
@@ -383,9 +393,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		}
 	};
 	for (int u0 = 0; u0 < nblocks; u0 += 2) {
-		tile(std::integral_constant<int, 0>{}, u0);
-		if (u0 + 1 < nblocks)
-			tile(std::integral_constant<int, 1>{}, u0 + 1);
+		tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, u0);
+		if (KSPL > 1)
+			tile(std::integral_constant<int, 0>{}, std::integral_constant<int, KSPL - 1>{}, u0);
+		if (u0 + 1 < nblocks) {
+			tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, u0 + 1);
+			if (KSPL > 1)
+				tile(std::integral_constant<int, 1>{}, std::integral_constant<int, KSPL - 1>{}, u0 + 1);
+		}
 	}
 	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // (the blocks fetched and the fragments read past the split's end)
 	// (the hand-written MFMAs have drained before the vector ALU reads their accumulators: >= 19 wait states on gfx950)
@@ -428,21 +443,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 int collect_big_ncb(int dp1) {
-	return dp1 == 768 ? 4 : 3;
+	return dp1 == 768 ? 4 : (dp1 == 1024 ? 3 : 2); // (1536: 2 x 48 k-blocks = the 96 fragments of 4 x 24)
 }
 int collect_big_qblock(int dp1) {
 	return 4 * 16 * collect_big_ncb(dp1);
 }
 size_t collect_big_lds_bytes(int dp1) {
-	return (size_t)4 * (16 * dp1 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
+	const int part = dp1 == 1536 ? 768 : dp1; // dims of a staged block (the 1536-dim store is staged in two parts per row block)
+	return (size_t)4 * (16 * part * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
 }
 
 int g_big_mode = 3; // option cl_big_mode (see MODE)
-template <int KBT, int NCB>
+template <int KBT, int NCB, int KSPL = 1>
 static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int grid, size_t lds, hipStream_t st) {
 #define MVS_BIG1(L2, CO, MD)                                                                                      \
 	{                                                                                                             \
-		auto kern = flat_bf16_big_kernel<KBT, NCB, L2, CO, MD>;                                                   \
+		auto kern = flat_bf16_big_kernel<KBT, NCB, L2, CO, MD, KSPL>;                                                 \
 		ensure_dynamic_lds((const void *)kern, lds);                                                              \
 		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                                    \
 	}
@@ -476,6 +492,8 @@ void launch_collect_big(int dp1, int metric, bool collect, const CollectArgs &a,
 		launch_big_inst<24, 4>(metric, collect, a, grid, lds, st);
 	else if (dp1 == 1024)
 		launch_big_inst<32, 3>(metric, collect, a, grid, lds, st);
+	else if (dp1 == 1536)
+		launch_big_inst<24, 2, 2>(metric, collect, a, grid, lds, st);
 	else
 		throw_faiss("mvs::launch_collect_big", __FILE__, "no instance for a %d-dim store", dp1);
 }

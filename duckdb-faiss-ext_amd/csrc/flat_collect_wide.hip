@@ -777,7 +777,7 @@ void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_
 // row pitch (dims) of the bf16 store for a logical dimension: 128 (flat_collect.hip), 256, 384, 512 or 768 (k-split); 0 = not served
 int collect_store_dims(int d) {
 	// (d <= 16: the f32 kernel's contraction is 8-16 dims deep and wins against a 128-dim bf16 product)
-	return d <= 16 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : 0))))));
+	return d <= 16 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : (d <= 1536 ? 1536 : 0)))))));
 }
 int g_ksplit_waves = 4; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
 int g_wide512_ksplit = 0; // option cl_wide512_ksplit: the 512-dim store on the k-split kernel (8 k-blocks per wave, 3 column blocks)
@@ -787,11 +787,15 @@ int g_ksplit_ncb = 3;   // column blocks per wave pair (option cl_ksplit_ncb: 2,
 static int ksplit_ncb() {
 	return g_ksplit_ncb == 3 ? 3 : 2;
 }
+// flat_bf16_big_kernel (csrc/flat_collect_big.hip): the 768 / 1024-dim stores by option, the 1536-dim store always (its only kernel)
+static bool wide_on_big(int dp1) {
+	return dp1 == 1536 || (g_wide_big && (dp1 == 768 || dp1 == 1024));
+}
 static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }
 int collect_wide_qblock(int dp1) {
-	if (g_wide_big && (dp1 == 768 || dp1 == 1024)) // flat_bf16_big_kernel: one wave per SIMD, all of k resident
+	if (wide_on_big(dp1)) // flat_bf16_big_kernel: one wave per SIMD, all of k resident
 		return collect_big_qblock(dp1);
 	if (dp1 == 1024) // 8 waves, two column blocks per pair (2 x 16 k-blocks = 128 VGPRs of fragments)
 		return 128;
@@ -807,12 +811,12 @@ static int wide_wsub(int dp1) {
 }
 // resident workgroups of the scan kernel on the device (256 CUs)
 int collect_wide_slots(int dp1) {
-	if (g_wide_big && (dp1 == 768 || dp1 == 1024))
+	if (wide_on_big(dp1))
 		return 256; // one workgroup per CU
 	return (dp1 == 1024 || (dp1 == 768 && g_ksplit_waves == 8)) ? 256 : 512;
 }
 size_t collect_wide_lds_bytes(int dp1) {
-	if (g_wide_big && (dp1 == 768 || dp1 == 1024))
+	if (wide_on_big(dp1))
 		return collect_big_lds_bytes(dp1);
 	if (dp1 == 1024) // flat_bf16_ksplit_kernel<8, 2, 2, 32>: two 32 KB stages, beta, queue, hand-over buffers, bounds, control
 		return (size_t)2 * (16 * 1024 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + (size_t)2 * 8 * 64 * 16 + 128 * 4 + 64;
@@ -825,7 +829,7 @@ size_t collect_wide_lds_bytes(int dp1) {
 	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)4 * wide_qt(dp1) * 16 * 4 * 4 + 64;
 }
 int collect_wide_block_rows(int dp1) {
-	if (g_wide_big && (dp1 == 768 || dp1 == 1024))
+	if (wide_on_big(dp1))
 		return 16;
 	return 16 * wide_wsub(dp1);
 }
@@ -860,7 +864,7 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	a.opt = g_ksplit_opt;
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_wide_lds_bytes(dp1);
-	if (g_wide_big && (dp1 == 768 || dp1 == 1024)) {
+	if (wide_on_big(dp1)) {
 		launch_collect_big(dp1, metric, collect, a, grid, st);
 	} else if (dp1 == 256) {
 		if (collect)

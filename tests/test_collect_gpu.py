@@ -43,7 +43,8 @@ def _check(cl, ex, xq, k, metric, xb=None, oracle_rows=0, overflow=False):
     assert np.array_equal(I1, I0), "labels differ from the exact f32 kernel"
     assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), "distances differ from the exact f32 kernel"
     if oracle_rows:
-        Do, Io = orc.flat_search(metric, xb, xq[:oracle_rows], k, force_path=orc.PATH_BLAS)
+        # (the whole batch decides FAISS's branch: BLAS from 20 queries on, per pair below)
+        Do, Io = orc.flat_search(metric, xb, xq[:oracle_rows], k, force_path=orc.PATH_BLAS if len(xq) >= 20 else orc.PATH_PAIR)
         assert np.array_equal(I1[:oracle_rows], Io) and np.array_equal(D1[:oracle_rows].view(np.uint32), Do.view(np.uint32))
     return D1, I1
 

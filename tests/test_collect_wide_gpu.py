@@ -49,7 +49,9 @@ def _check(cl, ex, xq, k, metric, xb=None, oracle_rows=0, path=orc.PATH_BLAS, ke
 @pytest.mark.parametrize("d,nb,nq,k", [(256, 60_000, 600, 10), (192, 40_001, 257, 1), (129, 30_000, 300, 5), (384, 50_000, 333, 10),
                                        (300, 35_000, 130, 15), (512, 40_000, 260, 10), (400, 20_000, 64, 3),
                                        (768, 40_000, 300, 10), (600, 25_000, 65, 15), (513, 20_000, 200, 1), (700, 30_000, 1000, 4),
-                                       (1024, 30_000, 300, 10), (900, 20_000, 129, 16), (769, 20_000, 40, 2)])
+                                       (1024, 30_000, 300, 10), (900, 20_000, 129, 16), (769, 20_000, 40, 2),
+                                       # 1024 < d <= 1536: two 768-dim parts per row on the one-wave-per-SIMD kernel
+                                       (1536, 30_000, 300, 10), (1100, 20_000, 140, 5), (1025, 16_000, 33, 16), (1536, 12_345, 1000, 1)])
 def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
     rs = np.random.RandomState(d + nb)
     xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
@@ -65,7 +67,7 @@ def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
     assert st["candidates"] < nq * nb * 0.2, st
 
 
-@pytest.mark.parametrize("d", [384, 768, 1024])
+@pytest.mark.parametrize("d", [384, 768, 1024, 1536])
 @pytest.mark.parametrize("metric", [L2, IP])
 def test_wide_normalised_embeddings_and_added_rows(mf, metric, d):
     """unit vectors (the C4 shape at a width the kernel serves), rows added after the first search (the store grows, the
@@ -141,7 +143,8 @@ def test_wide_is_not_used_where_it_has_no_instance(mf):
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
-@pytest.mark.parametrize("d,idmap,frac", [(256, False, 0.5), (384, True, 0.05), (768, False, 0.3), (640, True, 0.9), (512, False, 0.01), (1024, True, 0.2)])
+@pytest.mark.parametrize("d,idmap,frac", [(256, False, 0.5), (384, True, 0.05), (768, False, 0.3), (640, True, 0.9), (512, False, 0.01), (1024, True, 0.2),
+                                          (1536, True, 0.3)])
 def test_wide_selector_searches(mf, metric, d, idmap, frac):
     """IDSelectorBitmap / IDSelectorBatch in front of the wide kernels: one selector bit per row, rejected rows are neither
     candidates nor evidence for the bound; FAISS's per-pair arithmetic under a selector (tests/test_collect_gpu.py)"""
@@ -174,7 +177,7 @@ def test_wide_selector_searches(mf, metric, d, idmap, frac):
     assert np.isin(I1[I1 >= 0], keep).all()
 
 
-@pytest.mark.parametrize("d", [256, 768, 1000])
+@pytest.mark.parametrize("d", [256, 768, 1000, 1536])
 def test_wide_inner_product_boundary_ties(mf, d):
     """integer data: many rows share the k-th score; FAISS's heap outcome from the candidate list (tests/test_collect_gpu.py)"""
     rs = np.random.RandomState(d)
