@@ -132,10 +132,10 @@ def test_wide_small_batch_uses_the_per_pair_arithmetic(mf, metric, d):
 
 
 def test_wide_is_not_used_where_it_has_no_instance(mf):
-    """d > 1024 stays on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
+    """d > 1536 stays on the exact kernels (prefilter = 2 only forces the filter where it exists)"""
     rs = np.random.RandomState(2)
-    xb = rs.rand(20_000, 1536).astype(np.float32)
-    ix = mf.index_factory(1536, "Flat", L2)
+    xb = rs.rand(20_000, 1600).astype(np.float32)
+    ix = mf.index_factory(1600, "Flat", L2)
     ix.set_option("prefilter", 2)
     ix.add(xb)
     D, I = ix.search(xb[:40], 3)
