@@ -10,6 +10,7 @@ every call fails loudly when no gfx950 device is usable.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -206,8 +207,11 @@ class Index:
         self._owned = owned
         self._parent = parent  # keeps the owning index alive for borrowed handles
 
-    def __del__(self, _free=_L.mvs_index_free):  # (bound at definition: module globals are None during interpreter shutdown)
-        if getattr(self, "_h", None) and getattr(self, "_owned", False):
+    def __del__(self, _free=_L.mvs_index_free, _finalizing=sys.is_finalizing):
+        # (both bound at definition: module globals are None during interpreter shutdown.  Indexes still alive when the interpreter
+        # finalizes are NOT freed: the HIP runtime / RCCL may already be gone -- freeing a sharded index then aborted the process with
+        # "double free or corruption" after the test summary; the OS reclaims the device memory with the process)
+        if getattr(self, "_h", None) and getattr(self, "_owned", False) and not _finalizing():
             _free(self._h)
         self._h = None
 

@@ -192,15 +192,15 @@ def test_collect_fuzz(mf, seed):
 
 @pytest.mark.parametrize("metric", [L2, IP])
 @pytest.mark.parametrize("idmap", [False, True])
-@pytest.mark.parametrize("frac", [0.3, 0.02])
-def test_selector_searches_on_the_coarse_filter(mf, metric, idmap, frac):
+@pytest.mark.parametrize("frac,d,k", [(0.3, 128, 10), (0.02, 128, 10), (0.2, 128, 24), (0.4, 48, 10)])  # (k = 24: 32 row classes; d = 48: padded rows)
+def test_selector_searches_on_the_coarse_filter(mf, metric, idmap, frac, d, k):
     """filtered search (IDSelectorBitmap / IDSelectorBatch, the reference's signature feature): the selector becomes one bit per
     row, rejected rows are neither candidates nor evidence for the bound, candidates are re-scored with the per-pair
     arithmetic FAISS uses under a selector; must equal the exact kernels' SEL instances and the oracle bit for bit"""
     from helpers import bitmap_from_ids
 
     rs = np.random.RandomState(17 + int(frac * 100))
-    d, n, nq, k = 128, 150_000, 300, 10
+    n, nq = 150_000, 300
     xb = rs.rand(n, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
     xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
     xb[rs.randint(0, n, 2000)] = xb[rs.randint(0, n, 2000)]

@@ -121,19 +121,24 @@ def test_error_model_is_an_upper_bound_with_room(mf):
 
 
 def test_selector_searches_never_take_the_prefilter(mf):
-    """inner product + IDSelector rides the fused f32 kernel's SEL instances (FAISS's per-pair branch); at sizes where
-    the auto mode would pick the prefilter the selector must still be honoured"""
+    """inner product + IDSelector: the bf16x3 prefilter has no selector instances -- such a search rides the coarse filter
+    (since round 3 also at d = 64: rows zero-padded in the 128-dim bf16 store) or, with the coarse filter off, the fused f32
+    kernel's SEL instances (FAISS's per-pair branch); the selector is honoured on every route"""
     rs = np.random.RandomState(4)
     xb = rs.rand(300_000, 64).astype(np.float32) - 0.5
     xq = rs.rand(600, 64).astype(np.float32) - 0.5
     ix = mf.index_factory(64, "Flat", IP)
     ix.add(xb)
     keep = np.arange(300_000)[rs.rand(300_000) < 0.3]
-    D, I = ix.search(xq, 10, sel=("batch", keep))
-    assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
-    assert np.isin(I, keep).all()
     Do, Io = orc.flat_search(IP, xb, xq[:64], 10, sel=("batch", keep))
+    D, I = ix.search(xq, 10, sel=("batch", keep))
+    assert ix.last_kernel_info()["name"] == "flat_bf16_collect_kernel"
+    assert np.isin(I, keep).all()
     assert np.array_equal(I[:64], Io) and np.array_equal(D[:64], Do)
+    ix.set_option("prefilter", 1)  # the bf16x3 prefilter wherever ITS kernel serves the shape: never under a selector
+    D1, I1 = ix.search(xq, 10, sel=("batch", keep))
+    assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
+    assert np.array_equal(I1, I) and np.array_equal(D1, D)
     D2, I2 = ix.search(xq, 10)  # and without the selector the same index does take it
     assert ix.last_kernel_info()["name"] == "flat_bf16x3_kernel"
 
