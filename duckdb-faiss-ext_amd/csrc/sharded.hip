@@ -140,7 +140,9 @@ struct Rccl {
 		for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
 			names.push_back(n);
 		for (const std::string &n : names) {
-			h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+			// (RTLD_LOCAL: only dlsym on the handle is used.  With RTLD_GLOBAL a PyTorch imported LATER in the same process bound some of
+			// its symbols into this copy and the process aborted at exit with "double free or corruption")
+			h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
 			if (h)
 				break;
 		}
@@ -377,7 +379,7 @@ public:
 			(void)hipEventDestroy(ev_x);
 		ev_x = nullptr;
 		for (void *c : comms)
-			if (c)
+			if (c && !getenv("MVS_RCCL_KEEP_COMMS")) // (diagnostic: leave the communicators to the process's exit)
 				Rccl::get().comm_destroy(c);
 		comms.clear();
 		for (int g = 0; g < G; ++g) {
