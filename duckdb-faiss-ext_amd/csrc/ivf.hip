@@ -914,7 +914,7 @@ public:
 		// (round 3, option ivf_cl_prepass = 1: the pre-pass walks the first rows of EVERY probed list with the work items of the
 		// main pass -- one grouping + packing per search instead of two, and 32 x 128 rows of evidence per query instead of 256)
 		int *d_nitems = nullptr, *d_cnt = nullptr;
-		for (int phase = 0; phase < 2; ++phase) {
+		for (int phase = cl_prepass_none ? 1 : 0; phase < 2; ++phase) {
 			const int64_t *keys = (const int64_t *)ws_cI.p;
 			if (phase == 0 && !cl_prepass_all) {
 				launch_ivf_mask_probes((const int64_t *)ws_cI.p, nq, (int)np, 0, 1, (int64_t *)ws_cimask.p, stream);
@@ -1403,6 +1403,7 @@ public:
 		}
 		if (!strcmp(key, "ivf_cl_prepass")) { // coarse filter pre-pass: 0 = the nearest list of every query (own grouping), n > 0 = the first n rows of every probed list
 			cl_prepass_all = v > 0;
+			cl_prepass_none = v < 0; // (A/B: no pre-pass at all -- the main pass starts with cold bounds)
 			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
 			return true;
 		}
@@ -1419,6 +1420,7 @@ public:
 	bool use_fast_scan = true;
 	bool cl_prepass_all = false; // option ivf_cl_prepass (n > 0 measured no faster than the nearest-list pre-pass: 2.83 / 2.88 / 2.93 vs 2.81 ms at C3)
 	int cl_prepass_rows = 128;
+	bool cl_prepass_none = false;
 	bool exact_ties = true; // option ivf_exact_ties: 0 = the scan kernels' pure (value, position) order, no tie pass (diagnostics)
 	bool raw_pos = false;   // inside the exact-tie wrapper: the paths emit positions in the list-sorted store, no id map
 	bool force_select = false;
