@@ -1000,11 +1000,12 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	const int dp1 = collect_store_dims(g.d);
 	const int qblock = dp1 > 128 ? collect_wide_qblock(dp1) : CL_QBLOCK;
 	const int nqb = (int)((nq + qblock - 1) / qblock);
-	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 8192 rows per split
+	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 7680 rows per split (8192 kept C2's
+	// N = 1 M at 120 splits = 4.7 rounds of workgroups; 128 splits of 7 812 rows fill five: 3.0-3.17 -> 2.80-2.86 ms per batch)
 	const int64_t slots = dp1 > 128 ? collect_wide_slots(dp1) : 512; // resident workgroups
 	int64_t nsplit = g_cl_nsplit;
 	if (nsplit <= 0) {
-		const int64_t max_split = std::max<int64_t>(1, n / 8192);
+		const int64_t max_split = std::max<int64_t>(1, n / 7680);
 		nsplit = 1;
 		double best = -1;
 		for (int64_t s = 8; s <= std::min<int64_t>(max_split, 512); s += 8) {

@@ -889,8 +889,10 @@ public:
 		ws_gslot.reserve((size_t)nq * nclass * sizeof(unsigned) + 64);
 		launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
 		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, (size_t)nq * sizeof(int), stream));
-		const int64_t cap_entries = std::max<int64_t>(nq * 4096, (int64_t)1 << 20);
-		const size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+		// candidate stream: 4096 entries per query to start with, or what the last overflow showed this index's data to need
+		int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024) // (option ivf_cl_stream_cap: tests)
+		                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
+		size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 		ws_stream.reserve(256 + 2 * half);
 		unsigned long long *cnt = (unsigned long long *)ws_stream.p;
 		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
@@ -949,10 +951,33 @@ public:
 		MVS_HIP(hipStreamSynchronize(stream));
 		unsigned long long ncand_u;
 		memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
-		const int64_t ncand = (int64_t)ncand_u;
+		int64_t ncand = (int64_t)ncand_u;
 		if (ncand > cap_entries) {
+			// The stream overflowed (duplicate-heavy lists: every copy of a near vector is a candidate, rightly).  Up to 16 384 entries
+			// per query the stream is grown and the MAIN pass repeated once -- the class slots are warm, it admits no more than the
+			// first -- and the index remembers the size (as FlatIndex::collect_candidates does); beyond that the scanner kernel takes
+			// the batch as before (two orders of magnitude slower at C3's shape: 438 vs 2.3 ms)
 			++cl_overflows;
-			return false;
+			if (ncand + ncand / 8 > nq * (int64_t)16384)
+				return false;
+			cap_entries = ncand + ncand / 8;
+			if (cl_stream_cap_per_query <= 0)
+				cl_cap_hint = std::max<int64_t>(cl_cap_hint, (cap_entries + nq - 1) / nq);
+			half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+			ws_stream.reserve(256 + 2 * half);
+			cnt = (unsigned long long *)ws_stream.p;
+			strm = (unsigned long long *)((char *)ws_stream.p + 256);
+			sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+			MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
+			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
+			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, seg_rows, nseg, 1, rowmask, stream);
+			MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			MVS_HIP(hipStreamSynchronize(stream));
+			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
+			ncand = (int64_t)ncand_u;
+			if (ncand > cap_entries)
+				return false;
 		}
 		cl_queries_total += nq;
 		cl_candidates_total += ncand;
@@ -1397,6 +1422,10 @@ public:
 			force_select = v != 0;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_stream_cap")) { // candidate-stream entries per query (0: 4096, or what the last overflow needed)
+			cl_stream_cap_per_query = v;
+			return true;
+		}
 		if (!strcmp(key, "ivf_collect_k32")) {
 			collect_k32 = v != 0;
 			return true;
@@ -1457,7 +1486,7 @@ private:
 	// bf16 coarse filter (csrc/ivf_collect.hip): residual rows as bf16, -||y'||^2, the largest ||y'||^2 of every list
 	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
-	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0;
+	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_cap_hint = 0, cl_stream_cap_per_query = 0;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
 	int *h_fail = nullptr; // pinned
 	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel

@@ -437,6 +437,43 @@ def test_l2_coarse_filter_equals_scanner_and_oracle(mf, d, nlist, n, nq, k, npro
         assert np.array_equal(I2[ok2], I3[ok2]) and np.array_equal(I2[ok2], Io2[ok2]), sel[0]
 
 
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_coarse_filter_stream_overflow_grows_the_stream(mf, metric):
+    """a candidate stream that is too small (here: 64 entries per query by option; in the field: duplicate-heavy lists) is grown
+    once and the main pass repeated -- the batch stays on the coarse filter instead of falling to the scanner kernel; a stream
+    that would need more than 16 384 entries per query still hands the batch over.  Same results either way."""
+    d, nlist, n, nq, k, nprobe = 64, 16, 40_000, 300, 10, 8
+    xb = orc.synth_clustered(n, d, 41, n_centers=nlist, sigma=0.2)
+    xq = orc.synth_clustered(nq, d, 42, n_centers=nlist, sigma=0.2)
+    g, o = mf.index_factory(d, f"IVF{nlist},Flat", metric), orc.Index(d, f"IVF{nlist},Flat", metric)
+    o.train(xb)
+    g.ivf_set_centroids(o.ivf_centroids())
+    g.add(xb)
+    o.add(xb)
+    Do, Io = o.search(xq, k, nprobe=nprobe)
+    D0, I0 = g.search(xq, k, nprobe=nprobe)
+    assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+    g.set_option("ivf_cl_stream_cap", 8)  # the first main pass overflows, the grown stream holds the candidates
+    D1, I1 = g.search(xq, k, nprobe=nprobe)
+    assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+    g.set_option("ivf_cl_stream_cap", 0)
+    for D, I in ((D0, I0), (D1, I1)):
+        assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # 6 000 copies of one vector in one list, every query on top of it: 6 000 tied candidates per query at k = 10 ... the
+    # stream would need > 16 384 x nq / ... entries only with more copies; here the grown stream must still serve it
+    xb2 = xb.copy()
+    xb2[:6000] = xb[7]
+    g2, o2 = mf.index_factory(d, f"IVF{nlist},Flat", metric), orc.Index(d, f"IVF{nlist},Flat", metric)
+    o2.train(xb2)
+    g2.ivf_set_centroids(o2.ivf_centroids())
+    g2.add(xb2)
+    o2.add(xb2)
+    xq2 = np.repeat(xb[7:8], 200, axis=0)
+    D2, I2 = g2.search(xq2, k, nprobe=nprobe)
+    Do2, Io2 = o2.search(xq2, k, nprobe=nprobe)
+    assert np.array_equal(I2, Io2) and np.array_equal(D2.view(np.uint32), Do2.view(np.uint32))
+
+
 def test_l2_coarse_filter_non_finite_queries_fall_back(mf):
     d, nlist, n = 128, 16, 20000
     xb = orc.synth_clustered(n, d, 5, n_centers=nlist, sigma=0.2)
