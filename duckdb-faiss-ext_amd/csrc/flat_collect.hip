@@ -935,7 +935,11 @@ int collect_slot_stride(int kk) {
 	return (kk > 16 || kk >= g_cl_nc32_from) ? 32 : 16;
 }
 int collect_max_k(int d) {
-	return collect_store_dims(d) == 128 ? 32 : (collect_store_dims(d) > 0 ? 16 : 0);
+	const int dp1 = collect_store_dims(d);
+	if (dp1 == 0)
+		return 0;
+	// (the k-split kernel -- option cl_wide_big = 0 at the 768 / 1024-dim stores -- keeps 16 classes)
+	return ((dp1 == 768 || dp1 == 1024) && !g_wide_big) ? 16 : 32;
 }
 
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows

@@ -41,7 +41,8 @@ int g_wide_big = 1; // option cl_wide_big: 512 < d <= 1024 on flat_bf16_big_kern
 // KSPL (the 1536-dim store: 2): a row is KSPL PARTS of KBT k-blocks; a staged block holds ONE part of 16 rows (the ring, the barrier
 // and the LDS-DMA pattern are those of a KBT-wide store with KSPL times the rows), the accumulators run through the parts of a row
 // block (the chain starts at beta in part 0) and are tested after the last; all KSPL * KBT k-blocks of query fragments are resident.
-template <int KBT, int NCB, bool IS_L2, bool COLLECT, int MODE, int KSPL = 1>
+// NC: row classes per query (16; 32 for 16 < kk <= 32 -- csrc/flat_collect.hip)
+template <int KBT, int NCB, bool IS_L2, bool COLLECT, int MODE, int KSPL = 1, int NC = 16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flat_bf16_big_kernel(const CollectArgs a) {
 	constexpr bool PF = (MODE & 1) != 0, SPREAD = (MODE & 2) != 0;
 	constexpr int KT = KBT * KSPL; // k-blocks of a whole row
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 				const float v = (j & 2) ? hi : lo;
 				const unsigned row = (unsigned)(row0 + 4 * hq + j);
 				typedef __attribute__((address_space(1))) unsigned *GU;
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (COLLECT) {
 					unsigned pos;
 					const unsigned one = 1u;
@@ -196,27 +197,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			MVS_OPAQUE_VGPR(qo);
 			const int q = qo + 16 * hq + c;
 			const int qc = q < a.nq ? q : 0;
-			const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
-			unsigned long long w[8];
+			const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC);
+			unsigned long long w[NC / 2];
 #pragma unroll
-			for (int j = 0; j < 8; ++j)
+			for (int j = 0; j < NC / 2; ++j)
 				w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const float e2v = __builtin_nontemporal_load(a.e2 + qc);
 #pragma unroll
-			for (int j = 0; j < 8; ++j)
+			for (int j = 0; j < NC / 2; ++j)
 				asm volatile("" : "+v"(w[j]));
-			unsigned key[16];
+			unsigned key[NC];
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
+			for (int j = 0; j < NC / 2; ++j) {
 				key[2 * j] = (unsigned)w[j];
 				key[2 * j + 1] = (unsigned)(w[j] >> 32);
 			}
 #pragma unroll
-			for (int kbit = 2; kbit <= 16; kbit <<= 1)
+			for (int kbit = 2; kbit <= NC; kbit <<= 1)
 #pragma unroll
 				for (int jb = kbit >> 1; jb > 0; jb >>= 1)
 #pragma unroll
-					for (int x0 = 0; x0 < 16; ++x0) {
+					for (int x0 = 0; x0 < NC; ++x0) {
 						const int x1 = x0 ^ jb;
 						if (x1 > x0) {
 							const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 					}
 			unsigned kth = key[0];
 #pragma unroll
-			for (int j = 1; j < 16; ++j)
+			for (int j = 1; j < NC; ++j)
 				kth = (a.nclass - 1 == j) ? key[j] : kth;
 			const unsigned neutral = skey(-FLT_MAX);
 			const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
@@ -473,7 +474,22 @@ static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int 
 		else                                                                                                      \
 			MVS_BIG1(L2, CO, 3)                                                                                   \
 	}
-	if (metric == METRIC_L2 && collect)
+#define MVS_BIG32(L2, CO)                                                                                         \
+	{                                                                                                             \
+		auto kern = flat_bf16_big_kernel<KBT, NCB, L2, CO, 3, KSPL, 32>;                                          \
+		ensure_dynamic_lds((const void *)kern, lds);                                                              \
+		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);                                    \
+	}
+	if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes per query (the default pipeline mode only)
+		if (metric == METRIC_L2 && collect)
+			MVS_BIG32(true, true)
+		else if (metric == METRIC_L2)
+			MVS_BIG32(true, false)
+		else if (collect)
+			MVS_BIG32(false, true)
+		else
+			MVS_BIG32(false, false)
+	} else if (metric == METRIC_L2 && collect)
 		MVS_BIG(true, true)
 	else if (metric == METRIC_L2)
 		MVS_BIG(true, false)
@@ -481,6 +497,7 @@ static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int 
 		MVS_BIG(false, true)
 	else
 		MVS_BIG(false, false)
+#undef MVS_BIG32
 #undef MVS_BIG
 #undef MVS_BIG1
 	MVS_HIP(hipGetLastError());

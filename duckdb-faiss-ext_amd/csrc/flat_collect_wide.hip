@@ -21,7 +21,8 @@ namespace mvs {
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
-template <int KB, int QT, int NCBP, bool IS_L2, bool COLLECT>
+// NC: row classes per query (16; 32 for 16 < kk <= 32 -- csrc/flat_collect.hip)
+template <int KB, int QT, int NCBP, bool IS_L2, bool COLLECT, int NC = 16>
 __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArgs a) {
 	constexpr int PITCH = 64 * KB;            // bytes per row
 	constexpr int C = 4 * KB;                 // 16-byte chunks per row (a multiple of 16)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 				const float v = (j & 2) ? hi : lo;
 				const unsigned row = (unsigned)(row0 + 4 * hq + j);
 				typedef __attribute__((address_space(1))) unsigned *GU;
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * 16) + (row & 15u), skey(v), __ATOMIC_RELAXED,
+				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
 				if (COLLECT) {
 					unsigned pos;
@@ -172,27 +173,27 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 				for (int i = 0; i < NCBP; ++i) { // (one query at a time: the resident fragments leave few registers)
 					const int q = qo + 16 * NCBP * hq + 16 * i + c;
 					const int qc = q < a.nq ? q : 0;
-					const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * 16);
-					unsigned long long w[8];
+					const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC);
+					unsigned long long w[NC / 2];
 #pragma unroll
-					for (int j = 0; j < 8; ++j)
+					for (int j = 0; j < NC / 2; ++j)
 						w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					const float e2v = __builtin_nontemporal_load(a.e2 + qc);
 #pragma unroll
-					for (int j = 0; j < 8; ++j)
+					for (int j = 0; j < NC / 2; ++j)
 						asm volatile("" : "+v"(w[j]));
-					unsigned key[16];
+					unsigned key[NC];
 #pragma unroll
-					for (int j = 0; j < 8; ++j) {
+					for (int j = 0; j < NC / 2; ++j) {
 						key[2 * j] = (unsigned)w[j];
 						key[2 * j + 1] = (unsigned)(w[j] >> 32);
 					}
 #pragma unroll
-					for (int kbit = 2; kbit <= 16; kbit <<= 1)
+					for (int kbit = 2; kbit <= NC; kbit <<= 1)
 #pragma unroll
 						for (int jb = kbit >> 1; jb > 0; jb >>= 1)
 #pragma unroll
-							for (int x0 = 0; x0 < 16; ++x0) {
+							for (int x0 = 0; x0 < NC; ++x0) {
 								const int x1 = x0 ^ jb;
 								if (x1 > x0) {
 									const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 							}
 					unsigned kth = key[0];
 #pragma unroll
-					for (int j = 1; j < 16; ++j)
+					for (int j = 1; j < NC; ++j)
 						kth = (a.nclass - 1 == j) ? key[j] : kth;
 					const unsigned neutral = skey(-FLT_MAX);
 					const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
@@ -836,15 +837,22 @@ int collect_wide_block_rows(int dp1) {
 
 template <int KB, int QT, int NCBP, bool COLLECT>
 static void launch_wide_inst(int metric, const CollectArgs &a, int grid, size_t lds, hipStream_t st) {
-	if (metric == METRIC_L2) {
-		auto kern = flat_bf16_wide_kernel<KB, QT, NCBP, true, COLLECT>;
-		ensure_dynamic_lds((const void *)kern, lds);
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-	} else {
-		auto kern = flat_bf16_wide_kernel<KB, QT, NCBP, false, COLLECT>;
-		ensure_dynamic_lds((const void *)kern, lds);
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+#define MVS_WIDE1(L2, NCV)                                                                                        \
+	{                                                                                                             \
+		auto kern = flat_bf16_wide_kernel<KB, QT, NCBP, L2, COLLECT, NCV>;                                        \
+		ensure_dynamic_lds((const void *)kern, lds);                                                              \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                              \
 	}
+	if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes per query
+		if (metric == METRIC_L2)
+			MVS_WIDE1(true, 32)
+		else
+			MVS_WIDE1(false, 32)
+	} else if (metric == METRIC_L2)
+		MVS_WIDE1(true, 16)
+	else
+		MVS_WIDE1(false, 16)
+#undef MVS_WIDE1
 	MVS_HIP(hipGetLastError());
 }
 

@@ -833,7 +833,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
-	if (cl_only && (kk > (wide ? 16 : 32) || prefilter_mode == 1))
+	if (cl_only && (kk > collect_max_k(d) || prefilter_mode == 1))
 		return false;
 	const int cl_kmax = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
 	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax))

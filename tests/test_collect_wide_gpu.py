@@ -51,15 +51,16 @@ def _check(cl, ex, xq, k, metric, xb=None, oracle_rows=0, path=orc.PATH_BLAS, ke
                                        (768, 40_000, 300, 10), (600, 25_000, 65, 15), (513, 20_000, 200, 1), (700, 30_000, 1000, 4),
                                        (1024, 30_000, 300, 10), (900, 20_000, 129, 16), (769, 20_000, 40, 2),
                                        # 1024 < d <= 1536: two 768-dim parts per row on the one-wave-per-SIMD kernel
-                                       (1536, 30_000, 300, 10), (1100, 20_000, 140, 5), (1025, 16_000, 33, 16), (1536, 12_345, 1000, 1)])
+                                       (1536, 30_000, 300, 10), (1100, 20_000, 140, 5), (1025, 16_000, 33, 16), (1536, 12_345, 1000, 1),
+                                       # 16 < k <= 32 (31 for inner product: k + 1 with the tie detection): 32 row classes per query
+                                       (256, 50_000, 300, 20), (384, 30_000, 200, 31), (512, 30_000, 150, 24), (768, 40_000, 300, 20),
+                                       (1024, 25_000, 100, 31), (1536, 20_000, 120, 20)])
 def test_wide_collect_equals_exact_kernel_and_oracle(mf, metric, d, nb, nq, k):
     rs = np.random.RandomState(d + nb)
     xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
     xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
     cl, ex = _pair(mf, d, metric, xb)
-    if metric == IP and k == 16:
-        k = 15  # (inner product keeps one rank for its tie detection)
-    _check(cl, ex, xq, k, metric, xb, oracle_rows=48)
+    _check(cl, ex, xq, k, metric, xb, oracle_rows=48)  # (inner product at k = 16 searches 17: 32 row classes)
     st = cl.collect_stats()
     assert st["queries"] == nq and st["overflows"] == 0 and st["candidates"] >= nq * k, st
     assert cl.prefilter_stats()["fallback_queries"] == 0
