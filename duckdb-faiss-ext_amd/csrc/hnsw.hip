@@ -86,8 +86,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 	v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
 	v += dpp_mov<0x141>(v); // row_half_mirror: quad 0 <-> quad 1
 	v += dpp_mov<0x140>(v); // row_mirror: lanes 0-7 <-> 8-15
-	v += __shfl_xor(v, 16);
-	v += __shfl_xor(v, 32);
+	// xor 16 / xor 32 on the vector ALU (gfx950's v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips
+	// through the LDS: with both operands = v the swap returns {v with its odd rows replaced by the even ones, v with its even rows
+	// replaced by the odd ones}; their sum is v[lane] + v[lane ^ 16] in every lane (same two addends as before: same bits)
+	{
+		const unsigned u = __float_as_uint(v);
+		const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+		v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+	}
+	{
+		const unsigned u = __float_as_uint(v);
+		const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+		v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+	}
 	return v;
 }
 
