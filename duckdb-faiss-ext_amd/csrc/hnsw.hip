@@ -495,6 +495,53 @@ __device__ __forceinline__ bool visited_test_and_set(VisitedSet &v, int nid, boo
 	return fresh;
 }
 
+// ---- sorted lists in REGISTERS (search, ef <= 128 and k <= 64) ---------------------------------------------------------------------
+// The candidate and result lists of a walk are sorted arrays of (distance, id) keys.  In LDS every insertion is two dependent round
+// trips (read all, fence, write the shifted tail, fence) and every hop reads the arrays again for pop_min / count_below; the walk's
+// chain of dependent LDS latencies is what bounds it (replacing the two ds_bpermute of the wave reduction alone took C5 from 14.3 to
+// 12.6 ms).  Entry i of a list lives in lane i & 63 of register v[i >> 6]: position = popcount of a ballot, the shift by one lane is
+// one DPP move (wave_shr:1) per dword, a uniform element is two v_readlane -- no LDS, no fence.
+__device__ __forceinline__ unsigned wave_shr1(unsigned v, unsigned lane0) { // lane l <- lane l - 1; lane 0 <- lane0 (uniform)
+	return (unsigned)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64 lane_get64(u64 v, int l) { // l uniform
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+	return ((u64)hi << 32) | lo;
+}
+template <int NB>
+__device__ __forceinline__ u64 rl_at(const u64 (&v)[NB], int i) { // i uniform, 0 <= i < 64 NB
+	u64 r = lane_get64(v[0], i & 63);
+#pragma unroll
+	for (int b = 1; b < NB; ++b) {
+		const u64 t = lane_get64(v[b], i & 63);
+		r = (i >> 6) == b ? t : r;
+	}
+	return r;
+}
+// sorted_insert on a register list: n entries, capacity cap <= 64 NB; returns the new n
+template <int NB>
+__device__ __forceinline__ int rl_insert(u64 (&v)[NB], int n, int cap, u64 nk, int lane) {
+	int pos = 0;
+#pragma unroll
+	for (int b = 0; b < NB; ++b) {
+		const int i = b * 64 + lane;
+		pos += (int)__popcll(__builtin_amdgcn_ballot_w64(i < n && v[b] < nk));
+	}
+	if (pos >= cap)
+		return n;
+#pragma unroll
+	for (int b = NB - 1; b >= 0; --b) { // highest block first: block b's lane 0 takes block b - 1's lane 63 as it was
+		const int i = b * 64 + lane;
+		const u64 carry = b > 0 ? lane_get64(v[b - 1], 63) : 0ull;
+		const unsigned lo = wave_shr1((unsigned)v[b], (unsigned)carry);
+		const unsigned hi = wave_shr1((unsigned)(v[b] >> 32), (unsigned)(carry >> 32));
+		const u64 prev = ((u64)hi << 32) | lo;
+		v[b] = i > pos ? prev : (i == pos ? nk : v[b]);
+	}
+	return n < cap ? n + 1 : cap;
+}
+
 // ------------------------------------------------------------------------------------------------ search kernel
 
 // -DMVS_HNSW_PROFILE: per-phase shader-clock totals in stats[2..8] (tools/hbench.py prints them); off in the product
@@ -528,11 +575,13 @@ struct SearchArgs {
 	const unsigned *ymax_bits; // largest squared row norm (float bits)
 };
 
-template <int NI, bool IS_L2, int G, bool BF = false>
+// RL: the candidate (ef <= 128) and result (k <= 64) lists live in registers instead of LDS
+template <int NI, bool IS_L2, int G, bool BF = false, bool RL = false>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 	extern __shared__ u64 smem[];
 	u64 *ckeys = smem + a.hsize / 2; // MinimaxHeap candidates(ef); the visited hash sits in front (16-byte aligned)
 	u64 *rkeys = ckeys + a.ef;       // result heap (k)
+	u64 creg[2] = {~0ull, ~0ull}, rreg[1] = {~0ull}; // (RL)
 	const int lane = threadIdx.x;
 	const GraphDev &g = a.g;
 	uint8_t *vis = a.visited + (size_t)blockIdx.x * a.vstride;
@@ -583,14 +632,19 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			greedy_update_nearest<NI, IS_L2, G, false>(g, q, level, nearest, d_nearest, lane, ndis);
 		// ---- search_from_candidates, level 0
 		int nc = 0, nr = 0, nvalid = 0;
-		nc = sorted_insert(ckeys, nc, ef, mk_key(d_nearest, nearest), lane);
+		// (the two lists: LDS arrays, or registers when RL)
+		auto c_insert = [&](u64 key) { nc = RL ? rl_insert<2>(creg, nc, ef, key, lane) : sorted_insert(ckeys, nc, ef, key, lane); };
+		auto r_insert = [&](u64 key) { nr = RL ? rl_insert<1>(rreg, nr, k, key, lane) : sorted_insert(rkeys, nr, k, key, lane); };
+		auto c_at = [&](int i) -> u64 { return RL ? rl_at<2>(creg, i) : rfl64(ckeys[i]); };
+		auto r_at = [&](int i) -> u64 { return RL ? rl_at<1>(rreg, i) : rfl64(rkeys[i]); };
+		c_insert(mk_key(d_nearest, nearest));
 		nvalid = 1;
 		float rthr = FLT_MAX; // heap threshold: the k-heap starts full of (FLT_MAX, -1)
 		{
 			const bool pass = a.sel.kind == MVS_SEL_NONE || sel_member_dev(a.sel, a.idmap ? a.idmap[nearest] : nearest);
 			if (pass && d_nearest < rthr) {
-				nr = sorted_insert(rkeys, nr, k, mk_key(d_nearest, nearest), lane);
-				rthr = nr < k ? FLT_MAX : key_dis(rfl64(rkeys[k - 1]));
+				r_insert(mk_key(d_nearest, nearest));
+				rthr = nr < k ? FLT_MAX : key_dis(r_at(k - 1));
 			}
 		}
 		(void)visited_test_and_set(vs, nearest, lane == 0, lane);
@@ -599,25 +653,50 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			const unsigned long long t0 = PROF_NOW();
 			// pop_min: first live entry of the sorted array
 			int pos = -1;
-			for (int base = 0; base < nc && pos < 0; base += 64) {
-				const int i = base + lane;
-				const bool live = i < nc && (unsigned)ckeys[i] != 0u;
-				const u64 m = __builtin_amdgcn_ballot_w64(live);
-				if (m)
-					pos = base + (int)__builtin_ctzll(m);
+			if (RL) {
+#pragma unroll
+				for (int b = 0; b < 2; ++b) {
+					const int i = b * 64 + lane;
+					const u64 m = __builtin_amdgcn_ballot_w64(i < nc && (unsigned)creg[b] != 0u);
+					if (m && pos < 0)
+						pos = b * 64 + (int)__builtin_ctzll(m);
+				}
+			} else {
+				for (int base = 0; base < nc && pos < 0; base += 64) {
+					const int i = base + lane;
+					const bool live = i < nc && (unsigned)ckeys[i] != 0u;
+					const u64 m = __builtin_amdgcn_ballot_w64(live);
+					if (m)
+						pos = base + (int)__builtin_ctzll(m);
+				}
 			}
-			const u64 ck = rfl64(ckeys[pos]);
+			const u64 ck = c_at(pos);
 			const int v0 = key_id(ck);
-			if (lane == 0)
-				ckeys[pos] = ck & 0xffffffff00000000ull; // tombstone keeps its distance
-			wave_fence();
+			if (RL) {
+#pragma unroll
+				for (int b = 0; b < 2; ++b)
+					if (b * 64 + lane == pos)
+						creg[b] &= 0xffffffff00000000ull; // tombstone keeps its distance
+			} else {
+				if (lane == 0)
+					ckeys[pos] = ck & 0xffffffff00000000ull; // tombstone keeps its distance
+				wave_fence();
+			}
 			nvalid--;
 			// count_below(d0) >= efSearch -> stop (check_relative_distance)
 			int nbelow = 0;
-			for (int base = 0; base < nc; base += 64) {
-				const int i = base + lane;
-				const bool lt = i < nc && (unsigned)(ckeys[i] >> 32) < (unsigned)(ck >> 32);
-				nbelow += (int)__popcll(__builtin_amdgcn_ballot_w64(lt));
+			if (RL) {
+#pragma unroll
+				for (int b = 0; b < 2; ++b) {
+					const int i = b * 64 + lane;
+					nbelow += (int)__popcll(__builtin_amdgcn_ballot_w64(i < nc && (unsigned)(creg[b] >> 32) < (unsigned)(ck >> 32)));
+				}
+			} else {
+				for (int base = 0; base < nc; base += 64) {
+					const int i = base + lane;
+					const bool lt = i < nc && (unsigned)(ckeys[i] >> 32) < (unsigned)(ck >> 32);
+					nbelow += (int)__popcll(__builtin_amdgcn_ballot_w64(lt));
+				}
 			}
 			if (nbelow >= a.efSearch)
 				break;
@@ -640,7 +719,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 				const unsigned long long t4 = PROF_NOW();
 				PROF_ADD(p_vis, t3, t4);
 				ndis += (unsigned)__popcll(fmask);
-				const float cmax = nc < ef ? FLT_MAX : key_dis(rfl64(ckeys[ef - 1]));
+				const float cmax = nc < ef ? FLT_MAX : key_dis(c_at(ef - 1));
 				u64 need = fmask;
 				if (BF && fmask != 0ull) {
 					// a neighbour matters only below the worst candidate or (selectors) the worst result: nothing to skip until both
@@ -679,18 +758,18 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 					const int id = __builtin_amdgcn_readlane(nid, l);
 					const u64 key = mk_key(dd, id);
 					if (((passmask >> l) & 1ull) && dd < rthr) { // res.add_result
-						nr = sorted_insert(rkeys, nr, k, key, lane);
-						rthr = nr < k ? FLT_MAX : key_dis(rfl64(rkeys[k - 1]));
+						r_insert(key);
+						rthr = nr < k ? FLT_MAX : key_dis(r_at(k - 1));
 					}
 					// candidates.push(v1, d)
 					if (nc == ef) {
-						const u64 last = rfl64(ckeys[ef - 1]);
+						const u64 last = c_at(ef - 1);
 						if (dd >= key_dis(last))
 							continue;
 						if ((unsigned)last != 0u)
 							nvalid--;
 					}
-					nc = sorted_insert(ckeys, nc, ef, key, lane);
+					c_insert(key);
 					nvalid++;
 				}
 				PROF_ADD(p_ins, t5, PROF_NOW());
@@ -704,7 +783,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			float dv = IS_L2 ? FLT_MAX : -FLT_MAX;
 			long long lab = -1;
 			if (j < nr) {
-				const u64 rk = rkeys[j];
+				const u64 rk = RL ? rreg[0] : rkeys[j]; // (RL: k <= 64, entry j lives in lane j)
 				const float dd = key_dis(rk);
 				dv = IS_L2 ? dd : -dd;
 				const int id = key_id(rk);
@@ -1116,6 +1195,27 @@ struct SearchLaunchBF {
 		MVS_HIP(hipGetLastError());
 	}
 };
+// (bf16 first look + the two lists in registers: ef <= 128, k <= 64)
+template <int NI, bool IS_L2, int G>
+struct SearchOccupancyBFRL {
+	static void run(int *out, size_t lds) {
+		int nb = 0;
+		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true, true>, lds);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)hnsw_search_kernel<NI, IS_L2, G, true, true>, 64, lds) !=
+		        hipSuccess ||
+		    nb <= 0)
+			nb = 8;
+		*out = nb;
+	}
+};
+template <int NI, bool IS_L2, int G>
+struct SearchLaunchBFRL {
+	static void run(const SearchArgs &a, int grid, size_t lds, hipStream_t st) {
+		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true, true>, lds);
+		hipLaunchKernelGGL((hnsw_search_kernel<NI, IS_L2, G, true, true>), dim3(grid), dim3(64), lds, st, a);
+		MVS_HIP(hipGetLastError());
+	}
+};
 template <int NI, bool IS_L2, int G>
 struct BuildLaunch {
 	static void run(const BuildArgs &a, int grid, size_t lds, hipStream_t st) {
@@ -1454,13 +1554,17 @@ public:
 			cus = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0 ? v : 256;
 		}
 		const bool use_bf = bf16_look != 0 && d >= 64;
-		if (occ_lds != lds || occ_g != search_g || occ_bf != (int)use_bf) { // the occupancy query is not free: once per LDS size
+		// the candidate / result lists in registers (csrc: "sorted lists in REGISTERS"): option hnsw_reg_lists, with the bf16 instances
+		const bool use_rl = use_bf && reg_lists != 0 && ef <= 128 && k <= 64;
+		if (occ_lds != lds || occ_g != search_g || occ_bf != (int)use_bf + 2 * (int)use_rl) { // the occupancy query is not free: once per LDS size
 			int v = 8;
-			if (use_bf)
+			if (use_rl)
+				dispatch_ni<SearchOccupancyBFRL, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			else if (use_bf)
 				dispatch_ni<SearchOccupancyBF, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
 			else
 				dispatch_ni<SearchOccupancy, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
-			occ_bf = (int)use_bf;
+			occ_bf = (int)use_bf + 2 * (int)use_rl;
 			occ_g = search_g;
 			occ_waves = std::max(1, std::min(v, 32));
 			occ_lds = lds;
@@ -1515,7 +1619,9 @@ public:
 			a.ymax_bits = (const unsigned *)ymax_dev.p;
 		}
 		begin_kernel_timing(stream);
-		if (use_bf)
+		if (use_rl)
+			dispatch_ni<SearchLaunchBFRL, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
+		else if (use_bf)
 			dispatch_ni<SearchLaunchBF, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
 		else
 			dispatch_ni<SearchLaunch, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
@@ -1668,6 +1774,10 @@ public:
 			efSearch = (int)v;
 			return true;
 		}
+		if (!strcmp(key, "hnsw_reg_lists")) {
+			reg_lists = (int)v;
+			return true;
+		}
 		if (!strcmp(key, "hnsw_bf16")) { // bf16 first look of the search walk (1) or every fresh neighbour's f32 row (0)
 			bf16_look = (int)v;
 			return true;
@@ -1709,6 +1819,7 @@ private:
 	std::vector<int64_t> offsets_h;
 	KeepBuf vecs, offsets, neighbors, locks, nb0, vbf, ymax_dev;
 	int64_t nb0_rows = 0, vbf_rows = 0;
+	int reg_lists = 1; // option hnsw_reg_lists: candidate / result lists in registers when ef <= 128 and k <= 64 (0: LDS arrays)
 	int bf16_look = 1, occ_bf = -1; // option hnsw_bf16: bf16 first look of the search walk (0: every fresh neighbour's f32 row is fetched)
 	double last_f32_rows = 0;
 	DevBuf ws_order, ws_counter, ws_stats, ws_q, ws_vis, sstamp, bvis, bstamp;
