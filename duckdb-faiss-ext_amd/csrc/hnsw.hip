@@ -1547,15 +1547,19 @@ public:
 			if (visited_lds >= 1024) // explicit slot count (power of two)
 				hsize = visited_lds;
 		}
-		const size_t lds = (size_t)(ef + k) * 8 + (size_t)hsize * 4 + 64;
+		const bool use_bf = bf16_look != 0 && d >= 64;
+		// the candidate / result lists in registers (csrc: "sorted lists in REGISTERS"): option hnsw_reg_lists, with the bf16 instances
+		const bool use_rl = use_bf && reg_lists != 0 && ef <= 128 && k <= 64;
+		// (register lists: the LDS holds the visited hash only -- 16 KB at ef = 128: ten waves per CU instead of nine)
+		const size_t lds = use_rl ? std::max<size_t>((size_t)hsize * 4, 64) : (size_t)(ef + k) * 8 + (size_t)hsize * 4 + 64;
+		// rows in flight per wave (option hnsw_search_g): with the lists in registers the walk is no longer a chain of LDS round trips
+		// and 8 rows in flight at three waves per SIMD beat 16 at two (C5: 9.5-10.0 vs 11.4-11.9 ms)
+		const int search_g = this->search_g ? this->search_g : (use_rl ? 8 : 16);
 		// one workgroup = one wave; fill every resident slot the kernel instance allows (VGPRs / LDS)
 		if (cus <= 0) {
 			int v = 0;
 			cus = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0 ? v : 256;
 		}
-		const bool use_bf = bf16_look != 0 && d >= 64;
-		// the candidate / result lists in registers (csrc: "sorted lists in REGISTERS"): option hnsw_reg_lists, with the bf16 instances
-		const bool use_rl = use_bf && reg_lists != 0 && ef <= 128 && k <= 64;
 		if (occ_lds != lds || occ_g != search_g || occ_bf != (int)use_bf + 2 * (int)use_rl) { // the occupancy query is not free: once per LDS size
 			int v = 8;
 			if (use_rl)
