@@ -575,13 +575,20 @@ struct SearchArgs {
 	const unsigned *ymax_bits; // largest squared row norm (float bits)
 };
 
-// RL: the candidate (ef <= 128) and result (k <= 64) lists live in registers instead of LDS
-template <int NI, bool IS_L2, int G, bool BF = false, bool RL = false>
+// RL: the candidate and result lists live in registers instead of LDS -- 1: ef <= 128, k <= 64; 2: ef <= 256, k <= 256
+template <int NI, bool IS_L2, int G, bool BF = false, int RL = 0>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
+	constexpr int NBC = RL == 2 ? 4 : 2, NBR = RL == 2 ? 4 : 1; // 64-entry blocks of the two lists
 	extern __shared__ u64 smem[];
 	u64 *ckeys = smem + a.hsize / 2; // MinimaxHeap candidates(ef); the visited hash sits in front (16-byte aligned)
 	u64 *rkeys = ckeys + a.ef;       // result heap (k)
-	u64 creg[2] = {~0ull, ~0ull}, rreg[1] = {~0ull}; // (RL)
+	u64 creg[NBC], rreg[NBR]; // (RL)
+#pragma unroll
+	for (int b = 0; b < NBC; ++b)
+		creg[b] = ~0ull;
+#pragma unroll
+	for (int b = 0; b < NBR; ++b)
+		rreg[b] = ~0ull;
 	const int lane = threadIdx.x;
 	const GraphDev &g = a.g;
 	uint8_t *vis = a.visited + (size_t)blockIdx.x * a.vstride;
@@ -633,10 +640,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 		// ---- search_from_candidates, level 0
 		int nc = 0, nr = 0, nvalid = 0;
 		// (the two lists: LDS arrays, or registers when RL)
-		auto c_insert = [&](u64 key) { nc = RL ? rl_insert<2>(creg, nc, ef, key, lane) : sorted_insert(ckeys, nc, ef, key, lane); };
-		auto r_insert = [&](u64 key) { nr = RL ? rl_insert<1>(rreg, nr, k, key, lane) : sorted_insert(rkeys, nr, k, key, lane); };
-		auto c_at = [&](int i) -> u64 { return RL ? rl_at<2>(creg, i) : rfl64(ckeys[i]); };
-		auto r_at = [&](int i) -> u64 { return RL ? rl_at<1>(rreg, i) : rfl64(rkeys[i]); };
+		auto c_insert = [&](u64 key) { nc = RL ? rl_insert<NBC>(creg, nc, ef, key, lane) : sorted_insert(ckeys, nc, ef, key, lane); };
+		auto r_insert = [&](u64 key) { nr = RL ? rl_insert<NBR>(rreg, nr, k, key, lane) : sorted_insert(rkeys, nr, k, key, lane); };
+		auto c_at = [&](int i) -> u64 { return RL ? rl_at<NBC>(creg, i) : rfl64(ckeys[i]); };
+		auto r_at = [&](int i) -> u64 { return RL ? rl_at<NBR>(rreg, i) : rfl64(rkeys[i]); };
 		c_insert(mk_key(d_nearest, nearest));
 		nvalid = 1;
 		float rthr = FLT_MAX; // heap threshold: the k-heap starts full of (FLT_MAX, -1)
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			int pos = -1;
 			if (RL) {
 #pragma unroll
-				for (int b = 0; b < 2; ++b) {
+				for (int b = 0; b < NBC; ++b) {
 					const int i = b * 64 + lane;
 					const u64 m = __builtin_amdgcn_ballot_w64(i < nc && (unsigned)creg[b] != 0u);
 					if (m && pos < 0)
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			const int v0 = key_id(ck);
 			if (RL) {
 #pragma unroll
-				for (int b = 0; b < 2; ++b)
+				for (int b = 0; b < NBC; ++b)
 					if (b * 64 + lane == pos)
 						creg[b] &= 0xffffffff00000000ull; // tombstone keeps its distance
 			} else {
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			int nbelow = 0;
 			if (RL) {
 #pragma unroll
-				for (int b = 0; b < 2; ++b) {
+				for (int b = 0; b < NBC; ++b) {
 					const int i = b * 64 + lane;
 					nbelow += (int)__popcll(__builtin_amdgcn_ballot_w64(i < nc && (unsigned)(creg[b] >> 32) < (unsigned)(ck >> 32)));
 				}
@@ -783,7 +790,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
 			float dv = IS_L2 ? FLT_MAX : -FLT_MAX;
 			long long lab = -1;
 			if (j < nr) {
-				const u64 rk = RL ? rreg[0] : rkeys[j]; // (RL: k <= 64, entry j lives in lane j)
+				u64 rk;
+				if (RL) { // entry j lives in lane j & 63 of block j >> 6
+					rk = rreg[0];
+#pragma unroll
+					for (int b = 1; b < NBR; ++b)
+						rk = (j >> 6) == b ? rreg[b] : rk;
+				} else {
+					rk = rkeys[j];
+				}
 				const float dd = key_dis(rk);
 				dv = IS_L2 ? dd : -dd;
 				const int id = key_id(rk);
@@ -1195,27 +1210,31 @@ struct SearchLaunchBF {
 		MVS_HIP(hipGetLastError());
 	}
 };
-// (bf16 first look + the two lists in registers: ef <= 128, k <= 64)
-template <int NI, bool IS_L2, int G>
-struct SearchOccupancyBFRL {
-	static void run(int *out, size_t lds) {
-		int nb = 0;
-		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true, true>, lds);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)hnsw_search_kernel<NI, IS_L2, G, true, true>, 64, lds) !=
-		        hipSuccess ||
-		    nb <= 0)
-			nb = 8;
-		*out = nb;
-	}
-};
-template <int NI, bool IS_L2, int G>
-struct SearchLaunchBFRL {
-	static void run(const SearchArgs &a, int grid, size_t lds, hipStream_t st) {
-		ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true, true>, lds);
-		hipLaunchKernelGGL((hnsw_search_kernel<NI, IS_L2, G, true, true>), dim3(grid), dim3(64), lds, st, a);
-		MVS_HIP(hipGetLastError());
-	}
-};
+// (bf16 first look + the two lists in registers: level 1 = ef <= 128, k <= 64; level 2 = ef <= 256, k <= 256)
+#define MVS_HNSW_RL_STRUCTS(LV)                                                                                        \
+	template <int NI, bool IS_L2, int G>                                                                               \
+	struct SearchOccupancyBFRL##LV {                                                                                   \
+		static void run(int *out, size_t lds) {                                                                        \
+			int nb = 0;                                                                                                \
+			ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true, LV>, lds);                         \
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)hnsw_search_kernel<NI, IS_L2, G, true, LV>, 64, \
+			                                                 lds) != hipSuccess ||                                     \
+			    nb <= 0)                                                                                               \
+				nb = 8;                                                                                                \
+			*out = nb;                                                                                                 \
+		}                                                                                                              \
+	};                                                                                                                 \
+	template <int NI, bool IS_L2, int G>                                                                               \
+	struct SearchLaunchBFRL##LV {                                                                                      \
+		static void run(const SearchArgs &a, int grid, size_t lds, hipStream_t st) {                                   \
+			ensure_dynamic_lds((const void *)hnsw_search_kernel<NI, IS_L2, G, true, LV>, lds);                         \
+			hipLaunchKernelGGL((hnsw_search_kernel<NI, IS_L2, G, true, LV>), dim3(grid), dim3(64), lds, st, a);        \
+			MVS_HIP(hipGetLastError());                                                                                \
+		}                                                                                                              \
+	};
+MVS_HNSW_RL_STRUCTS(1)
+MVS_HNSW_RL_STRUCTS(2)
+#undef MVS_HNSW_RL_STRUCTS
 template <int NI, bool IS_L2, int G>
 struct BuildLaunch {
 	static void run(const BuildArgs &a, int grid, size_t lds, hipStream_t st) {
@@ -1549,7 +1568,7 @@ public:
 		}
 		const bool use_bf = bf16_look != 0 && d >= 64;
 		// the candidate / result lists in registers (csrc: "sorted lists in REGISTERS"): option hnsw_reg_lists, with the bf16 instances
-		const bool use_rl = use_bf && reg_lists != 0 && ef <= 128 && k <= 64;
+		const int use_rl = !(use_bf && reg_lists != 0) ? 0 : ((ef <= 128 && k <= 64) ? 1 : ((ef <= 256 && k <= 256) ? 2 : 0));
 		// (register lists: the LDS holds the visited hash only -- 16 KB at ef = 128: ten waves per CU instead of nine)
 		const size_t lds = use_rl ? std::max<size_t>((size_t)hsize * 4, 64) : (size_t)(ef + k) * 8 + (size_t)hsize * 4 + 64;
 		// rows in flight per wave (option hnsw_search_g): with the lists in registers the walk is no longer a chain of LDS round trips
@@ -1560,15 +1579,17 @@ public:
 			int v = 0;
 			cus = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0 ? v : 256;
 		}
-		if (occ_lds != lds || occ_g != search_g || occ_bf != (int)use_bf + 2 * (int)use_rl) { // the occupancy query is not free: once per LDS size
+		if (occ_lds != lds || occ_g != search_g || occ_bf != (int)use_bf + 2 * use_rl) { // the occupancy query is not free: once per LDS size
 			int v = 8;
-			if (use_rl)
-				dispatch_ni<SearchOccupancyBFRL, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			if (use_rl == 2)
+				dispatch_ni<SearchOccupancyBFRL2, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			else if (use_rl)
+				dispatch_ni<SearchOccupancyBFRL1, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
 			else if (use_bf)
 				dispatch_ni<SearchOccupancyBF, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
 			else
 				dispatch_ni<SearchOccupancy, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
-			occ_bf = (int)use_bf + 2 * (int)use_rl;
+			occ_bf = (int)use_bf + 2 * use_rl;
 			occ_g = search_g;
 			occ_waves = std::max(1, std::min(v, 32));
 			occ_lds = lds;
@@ -1623,8 +1644,10 @@ public:
 			a.ymax_bits = (const unsigned *)ymax_dev.p;
 		}
 		begin_kernel_timing(stream);
-		if (use_rl)
-			dispatch_ni<SearchLaunchBFRL, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
+		if (use_rl == 2)
+			dispatch_ni<SearchLaunchBFRL2, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
+		else if (use_rl)
+			dispatch_ni<SearchLaunchBFRL1, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
 		else if (use_bf)
 			dispatch_ni<SearchLaunchBF, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
 		else

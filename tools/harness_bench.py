@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--ks", default="11,20,50,100,200,500,1000,2000")
     ap.add_argument("--sel-frac", type=float, default=0.1, help="selectivity of the run_sel bitmap")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--opt", action="append", default=[], help="index option key=value (e.g. hnsw_reg_lists=0)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -31,6 +32,9 @@ def main():
 
     d, n = args.d, args.n
     ix = mf.index_factory(d, args.index, mf.METRIC_INNER_PRODUCT)
+    for o in args.opt:
+        key, v = o.split("=")
+        ix.set_option(key, int(v))
     fl = mf.index_factory(d, "IDMap,Flat", mf.METRIC_INNER_PRODUCT)
     tb = 0.0
     for s0 in range(0, n, 65536):
