@@ -1110,6 +1110,8 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 	}
 #pragma unroll 16
 	for (int r = 0; r < 64; r += RPI) {
+		// (v_readlane + select instead of this ds_bpermute, fully unrolled, measured 0.40 instead of 0.14 ms: the loads then wait on
+		// scalar moves; the permutes of 16 iterations pipeline)
 		const unsigned rr = (unsigned)__shfl((int)row, r + sub);
 		const float4 v = *(const float4 *)(vecs + (size_t)rr * DP + ch * 4);
 		*(float4 *)(rows + (r + sub) * PITCH + ch * 4) = v;
@@ -1199,6 +1201,11 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 	sorted[i] = ok ? (((unsigned long long)bkey<IS_L2>(ex) << 32) | row) : ~0ull;
 }
 
+__device__ __forceinline__ unsigned long long cl_lane64(unsigned long long v, int l) { // l uniform
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+	return ((unsigned long long)hi << 32) | lo;
+}
 // One wave per query: the kk best keys (value, row) of its segment, kept as a sorted list spread over the lanes (lane i =
 // entry i): insert position by ballot, shift by one lane.
 template <bool IS_L2>
@@ -1218,16 +1225,20 @@ __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long 
 		while (pend != 0ull) {
 			const int L = __builtin_ctzll(pend);
 			pend &= pend - 1ull;
-			const unsigned long long ck = __shfl(key, L);
+			// (v_readlane / DPP wave_shr:1 instead of ds_bpermute: no LDS round trip per inserted candidate -- csrc/hnsw.hip, "sorted
+			// lists in REGISTERS")
+			const unsigned long long ck = cl_lane64(key, L);
 			if (ck >= worst)
 				continue;
 			const int pos = __popcll(__builtin_amdgcn_ballot_w64(lane < kk && mine <= ck));
-			const unsigned long long up = __shfl_up(mine, 1);
+			const unsigned long long up =
+			    ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(mine >> 32), 0x138, 0xf, 0xf, false) << 32) |
+			    (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)mine, 0x138, 0xf, 0xf, false);
 			if (lane == pos)
 				mine = ck;
 			else if (lane > pos && lane < kk)
 				mine = up;
-			worst = __shfl(mine, kk - 1);
+			worst = cl_lane64(mine, kk - 1);
 		}
 	}
 	if (lane < kk) {
