@@ -15,73 +15,92 @@
 
 namespace mvs {
 
-// ---- D[q][c]: 64 queries x 128 centroids per workgroup, 4 x 8 chains per thread, operands through LDS in slabs of 16 dims ------
+// ---- D[q][c]: 128 queries x 128 centroids per workgroup, 8 x 8 chains per thread, operands through LDS in slabs of 16 dims --------
+// (round 3: 64 x 128 with 4 x 8 chains read 12 LDS floats per 32 fmas -- 0.225 ms at C3's 10 000 x 4 096 x 128; 8 x 8 chains read 16
+// per 64 with four ds_read_b128)
 // centroid rows: pitch sdp, FlatGeom::pair_interleaved (every 4 floats stored [k0,k2,k1,k3] or, bit 4 of the row set,
 // [k1,k3,k0,k2]); dimensions >= d are zero on both sides (fma(0, 0, acc) = acc)
 __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restrict__ x, long long nq, int d,
                                                          const float *__restrict__ cent, int sdp, int interleaved, int nlist,
                                                          const float *__restrict__ qn, const float *__restrict__ cn,
                                                          int is_l2, float *__restrict__ D) {
-	__shared__ float xs[16][64 + 4];
-	__shared__ float ys[16][128 + 4];
+	__shared__ __attribute__((aligned(16))) float xs[16][128 + 4];
+	__shared__ __attribute__((aligned(16))) float ys[16][128 + 4];
 	const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-	const long long q0 = (long long)blockIdx.y * 64;
+	const long long q0 = (long long)blockIdx.y * 128;
 	const int c0 = blockIdx.x * 128;
-	float acc[4][8];
+	float acc[8][8];
 #pragma unroll
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < 8; ++i)
 #pragma unroll
 		for (int j = 0; j < 8; ++j)
 			acc[i][j] = 0.f;
-	for (int k0 = 0; k0 < d; k0 += 16) {
-		{ // queries: thread -> (row tid >> 2, dims 4 (tid & 3) ..)
-			const long long q = q0 + (tid >> 2);
-			const int kk = k0 + 4 * (tid & 3);
+	// the NEXT slab's operands travel from global memory into registers while the current slab is multiplied (without this the two
+	// barriers of a slab exposed a global round trip per 16 dims: 0.224 ms at C3's shape whatever the tile)
+	float xr[8];
+	float4 yr[2];
+	const long long qrow = q0 + (tid >> 1);
+	const int crow = c0 + (tid >> 1);
+	const bool flip = interleaved && ((crow >> 4) & 1);
+	auto fetch = [&](int k0) {
+		const int kk = k0 + 8 * (tid & 1);
 #pragma unroll
-			for (int e = 0; e < 4; ++e)
-				xs[4 * (tid & 3) + e][tid >> 2] = (q < nq && kk + e < d) ? x[q * d + kk + e] : 0.f;
+		for (int e = 0; e < 8; ++e)
+			xr[e] = (qrow < nq && kk + e < d) ? x[qrow * d + kk + e] : 0.f;
+#pragma unroll
+		for (int g = 0; g < 2; ++g) {
+			yr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (crow < nlist && kk + 4 * g < sdp)
+				yr[g] = *(const float4 *)(cent + (size_t)crow * sdp + kk + 4 * g);
 		}
-		{ // centroids: thread -> (row tid >> 1, dims 8 (tid & 1) ..)
-			const int c = c0 + (tid >> 1);
-			const int kk = k0 + 8 * (tid & 1);
-			const bool flip = interleaved && ((c >> 4) & 1);
+	};
+	fetch(0);
+	for (int k0 = 0; k0 < d; k0 += 16) {
 #pragma unroll
-			for (int g = 0; g < 2; ++g) {
-				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (c < nlist && kk + 4 * g < sdp)
-					v = *(const float4 *)(cent + (size_t)c * sdp + kk + 4 * g);
-				float y0 = v.x, y1 = v.y, y2 = v.z, y3 = v.w;
-				if (interleaved) {
-					y0 = flip ? v.z : v.x, y1 = flip ? v.x : v.z, y2 = flip ? v.w : v.y, y3 = flip ? v.y : v.w;
-				}
-				const int kb = 8 * (tid & 1) + 4 * g;
-				ys[kb + 0][tid >> 1] = y0;
-				ys[kb + 1][tid >> 1] = y1;
-				ys[kb + 2][tid >> 1] = y2;
-				ys[kb + 3][tid >> 1] = y3;
+		for (int e = 0; e < 8; ++e)
+			xs[8 * (tid & 1) + e][tid >> 1] = xr[e];
+#pragma unroll
+		for (int g = 0; g < 2; ++g) {
+			const float4 v = yr[g];
+			float y0 = v.x, y1 = v.y, y2 = v.z, y3 = v.w;
+			if (interleaved) {
+				y0 = flip ? v.z : v.x, y1 = flip ? v.x : v.z, y2 = flip ? v.w : v.y, y3 = flip ? v.y : v.w;
 			}
+			const int kb = 8 * (tid & 1) + 4 * g;
+			ys[kb + 0][tid >> 1] = y0;
+			ys[kb + 1][tid >> 1] = y1;
+			ys[kb + 2][tid >> 1] = y2;
+			ys[kb + 3][tid >> 1] = y3;
 		}
 		__syncthreads();
+		if (k0 + 16 < d)
+			fetch(k0 + 16);
 #pragma unroll
 		for (int k = 0; k < 16; ++k) { // k ascending: every accumulator is ONE k-ordered chain
-			float xv[4], yv[8];
+			const float4 xa = *(const float4 *)&xs[k][8 * ty], xb = *(const float4 *)&xs[k][8 * ty + 4];
+			const float4 ya = *(const float4 *)&ys[k][8 * tx], yb = *(const float4 *)&ys[k][8 * tx + 4];
+			const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+			// two chains per v_pk_fma_f32 (each half is an ordinary fma: same bits as the scalar chain, half the issue slots -- the
+			// kernel is bound by the vector ALU's issue rate: 0.224 ms whatever the tile or the staging)
+			typedef float f32x2c __attribute__((ext_vector_type(2)));
+			const f32x2c yp[4] = {{ya.x, ya.y}, {ya.z, ya.w}, {yb.x, yb.y}, {yb.z, yb.w}};
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
-				xv[i] = xs[k][4 * ty + i];
+			for (int i = 0; i < 8; ++i) {
+				const f32x2c xx = {xv[i], xv[i]};
 #pragma unroll
-			for (int j = 0; j < 8; ++j)
-				yv[j] = ys[k][8 * tx + j];
-#pragma unroll
-			for (int i = 0; i < 4; ++i)
-#pragma unroll
-				for (int j = 0; j < 8; ++j)
-					acc[i][j] = fmaf(xv[i], yv[j], acc[i][j]);
+				for (int j = 0; j < 4; ++j) {
+					f32x2c a2 = {acc[i][2 * j], acc[i][2 * j + 1]};
+					a2 = __builtin_elementwise_fma(xx, yp[j], a2);
+					acc[i][2 * j] = a2.x;
+					acc[i][2 * j + 1] = a2.y;
+				}
+			}
 		}
 		__syncthreads();
 	}
 #pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const long long q = q0 + 4 * ty + i;
+	for (int i = 0; i < 8; ++i) {
+		const long long q = q0 + 8 * ty + i;
 		if (q >= nq)
 			continue;
 		const float xn = is_l2 ? qn[q] : 0.f;
@@ -272,7 +291,7 @@ void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_ce
                           hipStream_t st) {
 	if (nq <= 0)
 		return;
-	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 63) / 64));
+	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
 	hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist, d_qn,
 	                   d_cn, is_l2, d_D);
 	MVS_HIP(hipGetLastError());
