@@ -1,0 +1,2 @@
+#!/bin/bash
+( time python3 -c "import __graft_entry__ as g; g.smoke()" ) 2>&1 | grep -v amdgpu.ids | tail -5
