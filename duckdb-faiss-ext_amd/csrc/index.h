@@ -354,7 +354,8 @@ void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int
 size_t ivf_collect_xi_bytes(int max_items);
 void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
-                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st);
+                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse = nullptr, int np = 0,
+                             float *d_ie2_pre = nullptr);
 void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,

@@ -883,6 +883,8 @@ public:
 		ws_xi.reserve(ivf_collect_xi_bytes(max_items));
 		ws_ig.reserve((size_t)max_items * 128 * sizeof(float));
 		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
+		if (cl_prepass_shared)
+			ws_ie2p.reserve((size_t)max_items * 128 * sizeof(float));
 		ws_qfail.reserve((size_t)nq * sizeof(int));
 		ws_cimask.reserve((size_t)npairs * sizeof(int64_t));
 		const int nclass = k > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
@@ -916,23 +918,29 @@ public:
 		// (round 3, option ivf_cl_prepass = 1: the pre-pass walks the first rows of EVERY probed list with the work items of the
 		// main pass -- one grouping + packing per search instead of two, and 32 x 128 rows of evidence per query instead of 256)
 		int *d_nitems = nullptr, *d_cnt = nullptr;
+		// (option ivf_cl_prepass_shared: ONE grouping + packing serves both passes -- the pre-pass walks the first 256 rows of the main
+		// pass's items with every slot switched off whose list is not its query's nearest (E = NaN): the same evidence as the
+		// nearest-list pre-pass without its own grouping and packing)
+		const bool shared = cl_prepass_shared && !cl_prepass_all && !cl_prepass_none;
 		for (int phase = cl_prepass_none ? 1 : 0; phase < 2; ++phase) {
 			const int64_t *keys = (const int64_t *)ws_cI.p;
-			if (phase == 0 && !cl_prepass_all) {
+			if (phase == 0 && !cl_prepass_all && !shared) {
 				launch_ivf_mask_probes((const int64_t *)ws_cI.p, nq, (int)np, 0, 1, (int64_t *)ws_cimask.p, stream);
 				keys = (const int64_t *)ws_cimask.p;
 			}
-			if (phase == 0 || !cl_prepass_all) {
+			if (phase == 0 || !(cl_prepass_all || shared)) {
 				launch_ivf_group(keys, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
 				                 (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
 				launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
 				                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
-				                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream);
+				                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream, shared ? (const int64_t *)ws_cI.p : nullptr, (int)np,
+				                        shared ? (float *)ws_ie2p.p : nullptr);
 			}
 			if (phase == 1)
 				begin_kernel_timing(stream);
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
-			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
+			                        (const float *)(phase == 0 && shared ? ws_ie2p.p : ws_ie2.p), (const unsigned short *)codes_bfr.p,
+			                        (const float *)beta_mf.p,
 			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
 			                        phase == 0 ? 1 : nseg, phase, rowmask, stream);
 			if (phase == 1)
@@ -1422,6 +1430,10 @@ public:
 			force_select = v != 0;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_prepass_shared")) { // 1: the pre-pass runs on the main pass's items (one grouping + packing per search)
+			cl_prepass_shared = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_stream_cap")) { // candidate-stream entries per query (0: 4096, or what the last overflow needed)
 			cl_stream_cap_per_query = v;
 			return true;
@@ -1450,6 +1462,7 @@ public:
 	bool cl_prepass_all = false; // option ivf_cl_prepass (n > 0 measured no faster than the nearest-list pre-pass: 2.83 / 2.88 / 2.93 vs 2.81 ms at C3)
 	int cl_prepass_rows = 128;
 	bool cl_prepass_none = false;
+	bool cl_prepass_shared = false; // option ivf_cl_prepass_shared (measured slower: 2.34 / 2.38 vs 2.27 / 2.32 ms at C3)
 	bool exact_ties = true; // option ivf_exact_ties: 0 = the scan kernels' pure (value, position) order, no tie pass (diagnostics)
 	bool raw_pos = false;   // inside the exact-tie wrapper: the paths emit positions in the list-sorted store, no id map
 	bool force_select = false;
@@ -1484,7 +1497,7 @@ private:
 	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf, cent_dev, list_of_blk, perm_mf, ws_iqn, ws_qmaxn;
 	bool mf_residual = false;
 	// bf16 coarse filter (csrc/ivf_collect.hip): residual rows as bf16, -||y'||^2, the largest ||y'||^2 of every list
-	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
+	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_ie2p, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_cap_hint = 0, cl_stream_cap_per_query = 0;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;

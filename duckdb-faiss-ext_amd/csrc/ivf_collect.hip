@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
                                                              const int *__restrict__ list_of_blk64,
                                                              const unsigned *__restrict__ list_max_bits,
                                                              bf16x8i *__restrict__ xi, float *__restrict__ igamma,
-                                                             float *__restrict__ ie2, int *__restrict__ qfail) {
+                                                             float *__restrict__ ie2, int *__restrict__ qfail,
+                                                             const long long *__restrict__ coarse, int np, float *__restrict__ ie2_pre) {
 	if ((int)blockIdx.x >= *nitems_dev)
 		return;
 	const int4 it = items[blockIdx.x];
@@ -218,6 +219,12 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		}
 		igamma[(size_t)blockIdx.x * 128 + slot] = g;
 		ie2[(size_t)blockIdx.x * 128 + slot] = e2;
+		// the pre-pass over THESE items (option ivf_cl_prepass_shared): only the slots whose list is their query's nearest take
+		// part -- E = NaN switches a slot off (nothing of it passes, nothing is published)
+		if (ie2_pre) {
+			const bool nearest = slot < it.w && coarse[(size_t)qidx[it.z + slot] * np] == (long long)l;
+			ie2_pre[(size_t)blockIdx.x * 128 + slot] = nearest ? e2 : __uint_as_float(0x7fc00000u);
+		}
 	}
 }
 size_t ivf_collect_xi_bytes(int max_items) {
@@ -225,7 +232,8 @@ size_t ivf_collect_xi_bytes(int max_items) {
 }
 void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
-                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st) {
+                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse, int np,
+                             float *d_ie2_pre) {
 	if (max_items <= 0)
 		return;
 	const size_t lds = ((size_t)128 * (d + 1) + d) * sizeof(float); // 66.5 KB at d = 128: two workgroups per CU
@@ -233,12 +241,14 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
 		auto kern = ivf_collect_pack_kernel<true>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
-		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
+		                   d_ie2_pre);
 	} else {
 		auto kern = ivf_collect_pack_kernel<false>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
-		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail);
+		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
+		                   d_ie2_pre);
 	}
 	MVS_HIP(hipGetLastError());
 }
