@@ -538,6 +538,19 @@ def main():
                     "launches": n_launch,
                     "algorithmic_bytes_per_launch": kinfo["bytes"],
                 }
+                if is_hnsw:
+                    # what the walk actually pulls out of the row stores per launch: a bf16 row (2d bytes) for every neighbour
+                    # looked at first, an f32 row (4d) for those that could still matter -- against the ALGORITHMIC 4d + 4 per
+                    # evaluation above (what FAISS's walk reads, the unit of SURVEY 8d)
+                    try:
+                        ws = ix.hnsw_walk_stats()
+                        moved = ws["bf16_rows"] * 2.0 * d + ws["f32_rows"] * 4.0 * d
+                        out["roofline"]["row_bytes_moved_per_launch"] = moved
+                        out["roofline"]["row_bytes_moved_GBps"] = round(moved / (avg_ms * 1e-3) / 1e9, 1)
+                        out["roofline"]["f32_rows_fetched_frac"] = round(ws["f32_rows"] / max(ws["evaluations"], 1.0), 4)
+                    except Exception as e:  # noqa: BLE001
+                        out["roofline"]["row_bytes_moved_per_launch"] = None
+                        out["roofline_moved_error"] = str(e)[:200]
                 if is_ivf:
                     # SURVEY 8d's own figure: every stored vector and id read ONCE per batch (list-major lower bound),
                     # whatever the number of <= 20-query work items that actually stream a list

@@ -1286,6 +1286,7 @@ public:
 	int dp, dp4;
 	int64_t build_waves = 0; // 0 = auto (concurrent, FAISS OpenMP semantics); 1 = deterministic order
 	int entry_point = -1, max_level = -1;
+	double last_evals = 0, last_bf16_rows = 0, last_f32_rows_pub = 0; // counters of the last timed search (hnsw_walk_stats)
 
 	HNSWIndex(int d_, int M_, int metric_) : IndexBase(MVS_KIND_HNSW, d_, metric_), M(M_), rng(12345) {
 		if (metric != METRIC_L2 && metric != METRIC_IP)
@@ -1673,6 +1674,9 @@ public:
 #endif
 			const unsigned long long nd = h_stats[0], ne = h_stats[1];
 			last_f32_rows = use_bf ? (double)h_stats[9] : (double)nd;
+			last_evals = (double)nd;
+			last_f32_rows_pub = last_f32_rows;
+			last_bf16_rows = use_bf ? (double)nd : 0.0; // (upper bound: before both lists are full a neighbour skips the first look)
 			if (getenv("MVS_HNSW_STATS"))
 				fprintf(stderr, "[hnsw] %llu distance evaluations, %.0f f32 rows fetched (%.1f %%), bf16 first look %s\n", nd, last_f32_rows,
 				        nd ? 100.0 * last_f32_rows / (double)nd : 0.0, use_bf ? "on" : "off");
@@ -1904,6 +1908,18 @@ int64_t hnsw_graph_info(IndexBase *ix, int *max_level, int *entry_point) {
 	if (entry_point)
 		*entry_point = h->entry_point;
 	return h->graph_slots();
+}
+bool hnsw_walk_stats(IndexBase *ix, double *evaluations, double *f32_rows, double *bf16_rows) {
+	if (ix->kind != MVS_KIND_HNSW)
+		return false;
+	auto *h = static_cast<HNSWIndex *>(ix);
+	if (evaluations)
+		*evaluations = h->last_evals;
+	if (f32_rows)
+		*f32_rows = h->last_f32_rows_pub;
+	if (bf16_rows)
+		*bf16_rows = h->last_bf16_rows;
+	return true;
 }
 bool hnsw_get_graph(IndexBase *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors) {
 	if (ix->kind != MVS_KIND_HNSW)

@@ -276,6 +276,7 @@ IndexBase *make_hnsw_index(int d, const std::string &desc, int metric);
 bool hnsw_set_ef_construction(IndexBase *ix, int v);
 int hnsw_get_ef_construction(IndexBase *ix); // -1 if not HNSW
 int64_t hnsw_graph_info(IndexBase *ix, int *max_level, int *entry_point); // neighbour slots, -1 if not HNSW
+bool hnsw_walk_stats(IndexBase *ix, double *evaluations, double *f32_rows, double *bf16_rows); // counters of the last timed search
 bool hnsw_get_graph(IndexBase *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors);
 IndexBase *hnsw_from_host(const HostIndex &h, int device);
 // csrc/io.cpp-ish (index_io.hip)

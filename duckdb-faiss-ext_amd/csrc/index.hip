@@ -1579,6 +1579,12 @@ int64_t mvs_index_hnsw_graph_info(mvs_index *ix, int *max_level, int *entry_poin
 		return -1;
 	}
 }
+int mvs_index_hnsw_walk_stats(mvs_index *ix, double *evaluations, double *f32_rows, double *bf16_rows) {
+	MVS_API_BEGIN
+	if (!hnsw_walk_stats(unwrap_idmap(ix->impl), evaluations, f32_rows, bf16_rows))
+		throw_faiss("mvs_index_hnsw_walk_stats", __FILE__, "not an HNSW index");
+	MVS_API_END
+}
 int mvs_index_hnsw_get_graph(mvs_index *ix, int32_t *levels, int64_t *offsets, int32_t *neighbors) {
 	MVS_API_BEGIN
 	if (!hnsw_get_graph(unwrap_idmap(ix->impl), levels, offsets, neighbors))

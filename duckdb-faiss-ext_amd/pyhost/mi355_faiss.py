@@ -106,6 +106,7 @@ _L.mvs_index_hnsw_set_ef_construction.argtypes = [_p, C.c_int]
 _L.mvs_index_hnsw_get_ef_construction.argtypes = [_p]
 _L.mvs_index_hnsw_graph_info.argtypes = [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _L.mvs_index_hnsw_graph_info.restype = _i64
+_L.mvs_index_hnsw_walk_stats.argtypes = [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
 _L.mvs_index_hnsw_get_graph.argtypes = [_p, _p, _p, _p]
 _L.mvs_index_ivf_nlist.argtypes = [_p]
 _L.mvs_index_ivf_nlist.restype = _i64
@@ -143,7 +144,7 @@ DECLARED_SYMBOLS = [
     "mvs_last_error", "mvs_index_factory", "mvs_index_free", "mvs_index_d", "mvs_index_ntotal",
     "mvs_index_is_trained", "mvs_index_metric_type", "mvs_index_kind", "mvs_index_idmap_sub",
     "mvs_index_ivf_quantizer", "mvs_index_ivf_nlist", "mvs_index_ivf_get_centroids", "mvs_index_ivf_set_centroids",
-    "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_get_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_get_graph",
+    "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_get_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_walk_stats", "mvs_index_hnsw_get_graph",
     "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
@@ -249,6 +250,12 @@ class Index:
 
     def set_ef_construction(self, v):
         _check(_L.mvs_index_hnsw_set_ef_construction(self._h, int(v)))
+
+    def hnsw_walk_stats(self):
+        """counters of the last search run with kernel timing on: distance evaluations, f32 rows fetched, bf16 rows looked at"""
+        ev, f32, bf = C.c_double(), C.c_double(), C.c_double()
+        _check(_L.mvs_index_hnsw_walk_stats(self._h, C.byref(ev), C.byref(f32), C.byref(bf)))
+        return {"evaluations": ev.value, "f32_rows": f32.value, "bf16_rows": bf.value}
 
     def hnsw_graph(self):
         """-> dict(levels[n], offsets[n+1], neighbors[...], max_level, entry_point) (FAISS's HNSW arrays)"""

@@ -96,6 +96,9 @@ int mvs_index_hnsw_get_ef_construction(mvs_index *ix);
  * empty): lets parity tests compare the device-built graph with the oracle's.  graph_info returns the number of
  * neighbour slots (offsets[ntotal]) or -1 if the index is not an HNSW index. */
 int64_t mvs_index_hnsw_graph_info(mvs_index *ix, int *max_level, int *entry_point);
+/* measurement only (bench.py): counters of the last search run with kernel timing on -- distance evaluations (what FAISS's walk
+   evaluates: the algorithmic unit of SURVEY 8d), f32 rows actually fetched, bf16 rows looked at first (csrc/hnsw.hip, "bf16 first look") */
+int mvs_index_hnsw_walk_stats(mvs_index *ix, double *evaluations, double *f32_rows, double *bf16_rows);
 int mvs_index_hnsw_get_graph(mvs_index *ix, int32_t *levels /* ntotal */, int64_t *offsets /* ntotal+1 */,
                              int32_t *neighbors /* offsets[ntotal] */);
 
