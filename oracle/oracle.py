@@ -17,7 +17,7 @@ _LIB = os.path.join(_HERE, "liborc.so")
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
 SEL_NONE, SEL_BITMAP, SEL_BATCH = 0, 1, 2
-PATH_AUTO, PATH_PAIR, PATH_BLAS = 0, 1, 2
+PATH_AUTO, PATH_PAIR, PATH_BLAS, PATH_OPENBLAS = 0, 1, 2, 3
 
 
 class OracleError(RuntimeError):
@@ -297,3 +297,82 @@ def set_metric_arg(v):
 
 def set_num_threads(n):
     lib().orc_set_num_threads(n)
+
+
+# ---- FAISS's BLAS branch on the real OpenBLAS (PATH_OPENBLAS): the independent reference for label stability ----------
+def openblas_path():
+    """numpy's bundled OpenBLAS with the 64-bit-integer scipy prefix (0.3.29 = /root/reference/vcpkg_ports/openblas/vcpkg.json:3)"""
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs", "libscipy_openblas64_*.so")))
+    return os.path.abspath(cands[0]) if cands else None
+
+
+def openblas_load(path=None):
+    """-> OpenBLAS's config string (version, core, threading); raises OracleError when no such library exists"""
+    path = path or openblas_path()
+    if path is None:
+        raise OracleError("no libscipy_openblas64_*.so under numpy.libs")
+    L = lib()
+    L.orc_openblas_load.argtypes = [C.c_char_p]
+    L.orc_openblas_config.restype = C.c_char_p
+    _check(L.orc_openblas_load(path.encode()))
+    return L.orc_openblas_config().decode()
+
+
+def openblas_census(metric, xb, xq, k, D_dev, I_dev, ref=None):
+    """Compare a device result (labels I_dev, values D_dev; [nq, k]) with FAISS's BLAS branch summed by the REAL OpenBLAS sgemm
+    (search at k + 1, so that the gap behind the last slot is known) and classify every (query, rank) slot.
+
+    Rounding band: an f32 inner product of d terms, summed in ANY order, deviates from the real value by at most
+    gamma_d |x|.|y| <= d u ||x|| ||y|| (u = 2^-24); with the norms (same bound each) and the two roundings of (xn + yn) - 2 ip a
+    computed L2 distance is within E = (d + 2) u (||x|| + ||y||)^2 of the real one, an inner product within d u ||x|| ||y||.
+    Two correct implementations can therefore rank two rows differently only if their REAL values are within 2 E of each other.
+    -> dict(slots, slots_label_differs, queries_label_differs, differing_slots_inside_band (must equal slots_label_differs),
+            fragile_adjacent_pairs (OpenBLAS neighbours in rank closer than 2 E: the slots that CAN flip), max_value_rel_diff)"""
+    xb, xq = _f32(xb), _f32(xq)
+    nq, d = xq.shape
+    if ref is None:  # (bench.py hands over the k + 1 run it timed)
+        openblas_load()
+        ref = flat_search(metric, xb, xq, k + 1, force_path=PATH_OPENBLAS)
+    Dob, Iob = ref
+    I_dev = np.asarray(I_dev)[:nq]
+    D_dev = np.asarray(D_dev)[:nq]
+    u = 2.0**-24
+    xnorm = np.sqrt((xq.astype(np.float64) ** 2).sum(1))
+    ymax = float(np.sqrt(float(norms(xb).max())))  # (f32 chain norms: the band is not sensitive to their last bits)
+    if metric == METRIC_L2:
+        E = (d + 2) * u * (xnorm + ymax) ** 2
+    else:
+        E = d * u * xnorm * ymax
+    diff = I_dev != Iob[:, :k]
+    qs, rs = np.nonzero(diff)
+    inside = 0
+    for q, r in zip(qs, rs):
+        a, b = int(I_dev[q, r]), int(Iob[q, r])
+        if a < 0 or b < 0:
+            continue
+        x64 = xq[q].astype(np.float64)
+        if metric == METRIC_L2:
+            ta = float(((x64 - xb[a].astype(np.float64)) ** 2).sum())
+            tb = float(((x64 - xb[b].astype(np.float64)) ** 2).sum())
+        else:
+            ta = float((x64 * xb[a].astype(np.float64)).sum())
+            tb = float((x64 * xb[b].astype(np.float64)).sum())
+        inside += abs(ta - tb) <= 2.0 * E[q]
+    gaps = np.abs(Dob[:, 1:].astype(np.float64) - Dob[:, :-1].astype(np.float64))  # [nq, k]: slot r vs r + 1 (the last: k vs k + 1)
+    valid = Iob[:, 1:] >= 0
+    fragile = int(((gaps <= 2.0 * E[:, None]) & valid).sum())
+    denom = np.maximum(np.abs(Dob[:, :k]).astype(np.float64), 1e-30)
+    rel = np.abs(D_dev.astype(np.float64) - Dob[:, :k].astype(np.float64)) / denom
+    return {
+        "reference": "FAISS BLAS branch (4096 x 1024 blocks, norms formula, CMax/CMin heaps) on OpenBLAS sgemm",
+        "queries": int(nq),
+        "slots": int(nq * k),
+        "slots_label_differs": int(diff.sum()),
+        "queries_label_differs": int(diff.any(1).sum()),
+        "differing_slots_inside_band": int(inside),
+        "fragile_adjacent_pairs": fragile,
+        "band": "real values within 2E; E = (d+2) u (|x|+|y|max)^2 (L2) | d u |x| |y|max (IP), u = 2^-24",
+        "max_value_rel_diff": float(rel[~diff].max()) if (~diff).any() else None,
+    }

@@ -53,6 +53,7 @@ extern "C" {
 #define ORC_PATH_AUTO 0 /* FAISS dispatch: sel || nq < 20 -> pair, else blas */
 #define ORC_PATH_PAIR 1
 #define ORC_PATH_BLAS 2
+#define ORC_PATH_OPENBLAS 3 /* the BLAS branch on the real OpenBLAS sgemm (orc_openblas_load first); FAISS's 4096 x 1024 blocking */
 
 typedef struct orc_index orc_index;
 
@@ -109,6 +110,11 @@ void orc_merge_shards(int metric, int64_t nq, int64_t k, int nshard, const float
 /* counter-based synthetic generator shared with the device (splitmix64 -> 24-bit uniform [0,1)) */
 void orc_synth_uniform(float *out, int64_t n_rows, int d, uint64_t seed, int64_t row0);
 void orc_synth_clustered(float *out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers, float sigma);
+/* dlopen an OpenBLAS with the 64-bit-integer scipy symbol prefix (numpy.libs/libscipy_openblas64_*.so, version 0.3.29 = the
+ * reference's vcpkg pin) for ORC_PATH_OPENBLAS; 0 on success */
+int orc_openblas_load(const char *path);
+const char *orc_openblas_config(void);
+void orc_openblas_set_num_threads(int n);
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -498,6 +498,108 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 	free(yn);
 }
 
+/* BLAS path on the REAL OpenBLAS (ORC_PATH_OPENBLAS): the same branch of utils/distances.cpp
+ * (exhaustive_L2sqr_blas / exhaustive_inner_product_blas) with FAISS's own blocking -- 4096 queries
+ * (distance_compute_blas_query_bs) x 1024 rows (distance_compute_blas_database_bs) per sgemm -- and the library the
+ * reference links (/root/reference/CMakeLists.txt:78-90 find_package(BLAS), vcpkg_ports/openblas/vcpkg.json:3 = 0.3.29;
+ * numpy's wheel bundles that very version as libscipy_openblas64_).  sgemm's summation order is OpenBLAS's own, so this is
+ * the INDEPENDENT reference for label stability: near-ties at rounding level may rank differently than under the
+ * k-ordered chain of search_blas above (tests/ and bench.py count such slots and check each against the rounding band).
+ * FAISS calls the Fortran symbol sgemm_("Transpose", "Not transpose", nyi, nxi, d, 1, y, d, x, d, 0, ip_block, nyi);
+ * cblas_sgemm(ColMajor, Trans, NoTrans, ...) is the same routine behind OpenBLAS's C front end.
+ * Norms: FAISS's fvec_norms_L2sqr is a SIMD loop whose order depends on the build; the k-ordered chain is used here. */
+#include <dlfcn.h>
+typedef void (*cblas_sgemm64_fn)(int order, int ta, int tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a,
+                                 int64_t lda, const float *b, int64_t ldb, float beta, float *c, int64_t ldc);
+static cblas_sgemm64_fn g_sgemm = NULL;
+static void (*g_blas_set_threads)(int) = NULL;
+static char g_blas_config[256] = "";
+
+int orc_openblas_load(const char *path) {
+	if (g_sgemm)
+		return 0;
+	void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+	if (!h)
+		return fail("orc_openblas_load", "oracle/orc_core.c", "dlopen(%s): %s", path, dlerror());
+	g_sgemm = (cblas_sgemm64_fn)dlsym(h, "scipy_cblas_sgemm64_");
+	if (!g_sgemm)
+		return fail("orc_openblas_load", "oracle/orc_core.c", "%s has no scipy_cblas_sgemm64_", path);
+	g_blas_set_threads = (void (*)(int))dlsym(h, "scipy_openblas_set_num_threads64_");
+	const char *(*cfg)(void) = (const char *(*)(void))dlsym(h, "scipy_openblas_get_config64_");
+	if (cfg)
+		snprintf(g_blas_config, sizeof g_blas_config, "%s", cfg());
+	return 0;
+}
+const char *orc_openblas_config(void) {
+	return g_blas_config;
+}
+void orc_openblas_set_num_threads(int n) {
+	if (g_blas_set_threads && n > 0)
+		g_blas_set_threads(n);
+}
+
+#define OB_QBS 4096 /* distance_compute_blas_query_bs */
+static int search_openblas(int metric, int d, int64_t nb, const float *xb, int64_t nq, const float *xq, int64_t k, float *D,
+                           int64_t *I) {
+	if (!g_sgemm)
+		return fail("orc_flat_search", "oracle/orc_core.c", "ORC_PATH_OPENBLAS: call orc_openblas_load() first");
+	const int is_max = metric == ORC_METRIC_L2;
+	float *xn = NULL, *yn = NULL;
+	if (is_max) {
+		xn = (float *)malloc((size_t)(nq > 0 ? nq : 1) * sizeof(float));
+		yn = (float *)malloc((size_t)(nb > 0 ? nb : 1) * sizeof(float));
+		orc_norms(xq, nq, d, xn);
+		orc_norms(xb, nb, d, yn);
+	}
+	float *ip_block = (float *)malloc((size_t)OB_QBS * BLAS_DBS * sizeof(float));
+	for (int64_t i0 = 0; i0 < nq; i0 += OB_QBS) {
+		const int64_t i1 = i0 + OB_QBS < nq ? i0 + OB_QBS : nq;
+#pragma omp parallel for
+		for (int64_t i = i0; i < i1; i++) /* res.begin_multiple */
+			heap_init(k, D + i * k, I + i * k, is_max);
+		for (int64_t j0 = 0; j0 < nb; j0 += BLAS_DBS) {
+			const int64_t j1 = j0 + BLAS_DBS < nb ? j0 + BLAS_DBS : nb;
+			const int64_t nyi = j1 - j0, nxi = i1 - i0;
+			g_sgemm(102 /* CblasColMajor */, 112 /* CblasTrans */, 111 /* CblasNoTrans */, nyi, nxi, d, 1.0f, xb + j0 * d, d,
+			        xq + i0 * d, d, 0.0f, ip_block, nyi);
+#pragma omp parallel for
+			for (int64_t i = i0; i < i1; i++) { /* distance formula + HeapBlockResultHandler::add_results */
+				const float *ip_line = ip_block + (i - i0) * nyi;
+				float *hv = D + i * k;
+				int64_t *hi = I + i * k;
+				float thr = hv[0];
+				if (is_max) {
+					const float xni = xn[i];
+					for (int64_t j = 0; j < nyi; j++) {
+						float dis = (xni + yn[j0 + j]) - 2.0f * ip_line[j];
+						if (dis < 0)
+							dis = 0;
+						if (thr > dis) {
+							heap_replace_top(k, hv, hi, 1, dis, j0 + j);
+							thr = hv[0];
+						}
+					}
+				} else {
+					for (int64_t j = 0; j < nyi; j++) {
+						const float dis = ip_line[j];
+						if (thr < dis) {
+							heap_replace_top(k, hv, hi, 0, dis, j0 + j);
+							thr = hv[0];
+						}
+					}
+				}
+			}
+		}
+#pragma omp parallel for
+		for (int64_t i = i0; i < i1; i++) /* res.end_multiple */
+			heap_reorder(k, D + i * k, I + i * k, is_max);
+	}
+	free(ip_block);
+	free(xn);
+	free(yn);
+	return 0;
+}
+
 static void translate_ids(int64_t n, int64_t *I, const int64_t *id_map) {
 	if (!id_map)
 		return;
@@ -521,16 +623,19 @@ static int flat_search_impl(int metric, int d, int64_t nb, const float *xb, int6
 		path = ORC_PATH_PAIR;
 	if (path == ORC_PATH_AUTO)
 		path = (sel.kind || nq < 20) ? ORC_PATH_PAIR : ORC_PATH_BLAS;
-	if (path == ORC_PATH_BLAS && sel.kind) {
+	if ((path == ORC_PATH_BLAS || path == ORC_PATH_OPENBLAS) && sel.kind) {
 		sel_free(&sel);
 		return fail("orc_flat_search", "faiss/utils/distances.cpp", "selector requires the per-pair path");
 	}
+	int rc = 0;
 	if (path == ORC_PATH_PAIR)
 		search_pair(metric, d, nb, xb, nq, xq, k, D, I, sel.kind ? &sel : NULL, id_map);
+	else if (path == ORC_PATH_OPENBLAS)
+		rc = search_openblas(metric, d, nb, xb, nq, xq, k, D, I);
 	else
 		search_blas(metric, d, nb, xb, nq, xq, k, D, I);
 	sel_free(&sel);
-	return 0;
+	return rc;
 }
 
 int orc_flat_search(int metric, int d, int64_t nb, const float *xb, int64_t nq, const float *xq, int64_t k, float *D,

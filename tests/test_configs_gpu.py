@@ -46,6 +46,21 @@ def _check_order_and_range(D, I, lo, hi, is_l2):
     assert np.isfinite(D).all()
 
 
+def _check_vs_openblas(metric, xb_h, xq_h, k, D, I, ns):
+    """The INDEPENDENT label reference: FAISS's BLAS branch summed by the real OpenBLAS sgemm (0.3.29, the
+    reference's vcpkg pin; numpy bundles it) instead of the oracle's k-ordered chain.  sgemm sums in its own order, so labels may
+    differ at rounding-level near-ties: every differing (query, rank) slot must sit inside the rounding band, and values agree to
+    1e-5 relative (north_star asks 1e-4)."""
+    if orc.openblas_path() is None:
+        pytest.skip("no OpenBLAS with the scipy 64-bit prefix on this host")
+    cen = orc.openblas_census(metric, xb_h, xq_h[:ns], k, D[:ns], I[:ns])
+    print("openblas census:", cen)
+    assert cen["differing_slots_inside_band"] == cen["slots_label_differs"], cen
+    assert cen["slots_label_differs"] <= cen["fragile_adjacent_pairs"], cen  # only fragile slots can flip
+    assert cen["max_value_rel_diff"] is not None and cen["max_value_rel_diff"] <= 1e-5, cen
+    return cen
+
+
 def _build_flat_uniform(mf, torch, n, d, metric, desc="Flat"):
     ix = mf.index_factory(d, desc, metric)
     for s0 in range(0, n, SLAB):
@@ -88,6 +103,7 @@ def test_headline_flat_l2_10m(mf, torch):
     Do, Io = orc.flat_search(L2, xb_h, xq[:ns].cpu().numpy(), k, force_path=orc.PATH_BLAS)
     assert np.array_equal(I[:ns], Io), "labels differ from the oracle"
     assert np.array_equal(D[:ns].view(np.uint32), Do.view(np.uint32)), "distances differ from the oracle"
+    _check_vs_openblas(L2, xb_h, xq.cpu().numpy(), k, D, I, 1024)
     # the DuckDB granularity (<= 2048 queries per call, :903-925) returns the same rows
     D2, I2 = ix.search_torch(xq[2048:4096].contiguous(), k)
     torch.cuda.synchronize()
@@ -112,6 +128,7 @@ def test_c2_flat_l2_1m_full_batch(mf, torch):
     ns = 2048
     Do, Io = orc.flat_search(L2, xb_h, xq[:ns].cpu().numpy(), k, force_path=orc.PATH_BLAS)
     assert np.array_equal(I[:ns], Io) and np.array_equal(D[:ns].view(np.uint32), Do.view(np.uint32))
+    _check_vs_openblas(L2, xb_h, xq.cpu().numpy(), k, D, I, 4096)
 
 
 def test_c3_ivf4096_10m_nprobe32(mf, torch):
