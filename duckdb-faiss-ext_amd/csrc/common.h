@@ -195,6 +195,9 @@ void launch_tie_resolve(const TieFlags &f, int nf, int64_t k, int64_t kout, cons
 
 void launch_merge_records(int metric, const int64_t *d_rec, int nshard, int64_t nq, int kk, int kout, bool raw, float *d_D,
                           int64_t *d_I, hipStream_t st);
+// host twin (csrc/merge_host.hip) for nshard * kk beyond a workgroup's LDS; rec on the host
+void merge_records_host(int metric, const int64_t *rec, int nshard, int64_t nq, int kk, int kout, bool raw, float *D_out,
+                        int64_t *I_out);
 // IVF (csrc/ivf.hip)
 size_t direct_items_lds_bytes(int dp, int64_t k);
 void launch_direct_items(int dp, int metric, const float *d_xq, int64_t nq, const float *d_rows, int64_t nrows,
@@ -217,6 +220,7 @@ void launch_ivf_select(int metric, const float *d_xq, int dp, const float *d_row
 void launch_ivf_mf_to_csr(int64_t *d_I, int64_t total, const int *d_perm_mf, hipStream_t st);
 void launch_ivf_finish(int metric, const float *d_pd, const int64_t *d_pi, int64_t nq, int kx, int k, const int64_t *d_rowids,
                        const int64_t *d_idmap_out, float *d_D, int64_t *d_I, int *d_flag /* [1 + nq] */, hipStream_t st);
+bool ivf_tie_pass_fits(int d, int64_t k); // A_k of a flagged query fits the tie pass's LDS
 void launch_ivf_tie_pass(int metric, const int *d_flag, int64_t nq, const float *d_x, int d, const float *d_pd, int kx, int k,
                          const int64_t *d_coarse, int np, const int64_t *d_list_off, const float *d_codes, int dp,
                          const int64_t *d_rowids, SelectorDev sel, const int64_t *d_idmap_sel, const int64_t *d_idmap_out,

@@ -598,6 +598,7 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 		else
 			launch_pf_inst<4>(metric, p.global_lists, s, ps, st);
 	}
+#ifdef MVS_PROFILING
 	if (g.dp == 128 && metric == METRIC_L2 && !p.global_lists && g_pf_abl) {
 #define MVS_PF_ABL(N)                                                                                                  \
 	if (g_pf_abl == N) {                                                                                               \
@@ -610,6 +611,7 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 		MVS_HIP(hipGetLastError());
 		return;
 	}
+#endif
 	if (g.dp == 128)
 		launch_pf_inst<8>(metric, p.global_lists, a, p, st);
 	else

@@ -708,6 +708,7 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 	a.nsplit = (int)nsplit;
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_lds_bytes(g);
+#ifdef MVS_PROFILING
 	if (metric == METRIC_L2 && COLLECT && g_cl_abl) {
 #define MVS_CL_ABL(N)                                                                                                  \
 	if (g_cl_abl == N) {                                                                                               \
@@ -717,7 +718,9 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 	}
 		MVS_CL_ABL(1) MVS_CL_ABL(3) MVS_CL_ABL(7) MVS_CL_ABL(11) MVS_CL_ABL(15)
 #undef MVS_CL_ABL
-	} else if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes
+	} else
+#endif
+	if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes
 #define MVS_CL_NC32(L2, SEL_)                                                                                           \
 	{                                                                                                                  \
 		auto kern = flat_bf16_collect_kernel<8, L2, COLLECT, 0, SEL_, 32>;                                             \

@@ -456,6 +456,7 @@ int g_mfma_variant = 2; // 1 = register-staged generic kernel, 2 = LDS-DMA + A-r
 
 template <int KSTEPS>
 static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
+#ifdef MVS_PROFILING // wrong-result ablation instances exist only in the profiling library (make profiling -> libmi355faiss_prof.so)
 	if (KSTEPS == 64 && metric == METRIC_L2 && g_mfma_variant >= 100) { // profiling ablations
 		const int abl = g_mfma_variant - 100;
 #define MVS_ABL(N)                                                                                                     \
@@ -469,6 +470,7 @@ static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPl
 		MVS_HIP(hipGetLastError());
 		return;
 	}
+#endif
 	if (p.global_lists && a.sel.kind == MVS_SEL_NONE) {
 		if (metric == METRIC_L2) {
 			auto kern = flat_mfma_resident_kernel<KSTEPS, true, 0, 2, false, false, false, true>;

@@ -1884,10 +1884,16 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		cl_small_path = v != 0;
 		return true;
 	}
+#ifdef MVS_PROFILING // wrong-result ablation knobs: profiling library only
 	if (!strcmp(key, "cl_abl")) {
 		g_cl_abl = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "pf_abl")) { // profiling only: results are wrong
+		g_pf_abl = (int)v;
+		return true;
+	}
+#endif
 	if (!strcmp(key, "cl_nsplit")) { // coarse filter: row splits of the main scan (0 = planned)
 		g_cl_nsplit = (int)v;
 		return true;
@@ -1924,10 +1930,6 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_pf_seed = (int)v;
 		return true;
 	}
-	if (!strcmp(key, "pf_abl")) { // profiling only: results are wrong
-		g_pf_abl = (int)v;
-		return true;
-	}
 	if (!strcmp(key, "pf_margin")) {
 		pf_margin = (int)std::min<int64_t>(16, std::max<int64_t>(1, v));
 		return true;
@@ -1960,7 +1962,11 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_mfma_nsplit = (int)v;
 		return true;
 	}
-	if (!strcmp(key, "mfma_variant")) { // A/B switch between kernel generations (process-wide)
+	if (!strcmp(key, "mfma_variant")) { // A/B switch between kernel generations (process-wide); >= 100: ablations, profiling library only
+#ifndef MVS_PROFILING
+		if (v >= 100)
+			return false;
+#endif
 		g_mfma_variant = (int)v;
 		return true;
 	}

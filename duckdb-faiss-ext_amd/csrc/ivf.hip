@@ -685,7 +685,9 @@ public:
 		// Exact distance ties (csrc/ivf_ties.hip): every path runs with ONE extra entry and emits (value, position in the
 		// list-sorted store) in its pure order; the finish kernel prints equal values by stored id and flags the queries tied
 		// at the k-th value, the tie pass replays FAISS's heap (arrival order = probe rank, then list position) for those.
-		if (exact_ties && !raw_pos && !(metric == METRIC_L2 && (mfma_mode == 1 || mfma_mode == 2)) && k < ((int64_t)1 << 14)) {
+		// (k so large that A_k does not fit the tie pass's LDS -- ~12 700 at d = 128 -- keeps the pure order, as k >= 16 384 always did)
+		if (exact_ties && !raw_pos && !(metric == METRIC_L2 && (mfma_mode == 1 || mfma_mode == 2)) && k < ((int64_t)1 << 14) &&
+		    ivf_tie_pass_fits(d, k)) {
 			const int64_t kx = k + 1;
 			ws_tD.reserve((size_t)nq * kx * sizeof(float));
 			ws_tI.reserve((size_t)nq * kx * sizeof(int64_t));

@@ -252,15 +252,22 @@ void launch_ivf_finish(int metric, const float *d_pd, const int64_t *d_pi, int64
 	MVS_HIP(hipGetLastError());
 }
 
+// the tie pass keeps the query (d floats) and A_k (k values + k ids) of a flagged query in LDS
+static size_t ivf_tie_pass_lds(int d, int k) {
+	const int dpad = (d + 3) & ~3, kpad = (k + 1) & ~1;
+	return (size_t)(dpad + kpad) * 4 + (size_t)k * 8 + 64;
+}
+bool ivf_tie_pass_fits(int d, int64_t k) {
+	return k < ((int64_t)1 << 24) && ivf_tie_pass_lds(d, (int)k) <= 150 * 1024;
+}
 void launch_ivf_tie_pass(int metric, const int *d_flag, int64_t nq, const float *d_x, int d, const float *d_pd, int kx, int k,
                          const int64_t *d_coarse, int np, const int64_t *d_list_off, const float *d_codes, int dp,
                          const int64_t *d_rowids, SelectorDev sel, const int64_t *d_idmap_sel, const int64_t *d_idmap_out,
                          float *d_D, int64_t *d_I, hipStream_t st) {
 	if (nq <= 0 || kx <= k)
 		return;
-	const int dpad = (d + 3) & ~3, kpad = (k + 1) & ~1;
-	const size_t lds = (size_t)(dpad + kpad) * 4 + (size_t)k * 8 + 64;
-	if (lds > 150 * 1024)
+	const size_t lds = ivf_tie_pass_lds(d, k);
+	if (lds > 150 * 1024) // (callers gate on ivf_tie_pass_fits: such k keep the pure order)
 		throw_faiss(__func__, __FILE__, "IVF tie pass: k = %d too large", k);
 	// no host round trip: a fixed grid of persistent workgroups, each takes flagged queries f, f + grid, ... (usually none)
 	const unsigned grid = (unsigned)std::min<int64_t>(nq, 2048);

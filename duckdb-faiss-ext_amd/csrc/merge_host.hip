@@ -89,6 +89,40 @@ void merge_shards_host(int metric, int64_t n, int64_t k, int nshard, const float
 	});
 }
 
+// Host twin of merge_records_kernel (csrc/util_kernels.hip) for the shapes whose candidates do not fit a workgroup's LDS
+// (nshard * kk beyond ~6 000 entries: k in the thousands on 8 shards -- the Go harness asks for up to ~2 000 rows per query,
+// /root/reference/go/main_test.go:26-32).  rec: [nshard][nq][kk][2] int64 records {value bits (low 32), global label} on the HOST.
+void merge_records_host(int metric, const int64_t *rec, int nshard, int64_t nq, int kk, int kout, bool raw, float *D_out,
+                        int64_t *I_out) {
+	const bool is_l2 = metric_order(metric) == METRIC_L2;
+	const float neutral = is_l2 ? FLT_MAX : -FLT_MAX;
+	parallel_queries(nq, [&](int64_t q0, int64_t q1) {
+		std::vector<Cand> c((size_t)nshard * kk);
+		for (int64_t q = q0; q < q1; ++q) {
+			int64_t m = 0;
+			for (int s = 0; s < nshard; ++s) {
+				const int64_t *r = rec + (((size_t)s * nq + q) * kk) * 2;
+				for (int j = 0; j < kk; ++j)
+					if (r[2 * j + 1] >= 0) {
+						const int32_t bits = (int32_t)r[2 * j];
+						float v;
+						__builtin_memcpy(&v, &bits, 4);
+						c[(size_t)m++] = {v, r[2 * j + 1], r[2 * j + 1]};
+					}
+			}
+			const int64_t keep = std::min<int64_t>(m, kout);
+			std::partial_sort(c.begin(), c.begin() + keep, c.begin() + m,
+			                  [&](const Cand &a, const Cand &b) { return cand_before(is_l2, a, b); });
+			if (!is_l2 && !raw)
+				print_order_ip(c.data(), keep);
+			for (int64_t j = 0; j < kout; ++j) {
+				D_out[q * kout + j] = j < keep ? c[(size_t)j].v : neutral;
+				I_out[q * kout + j] = j < keep ? c[(size_t)j].label : -1;
+			}
+		}
+	});
+}
+
 // The same merge for a multi-PROCESS host (pyhost/sharded.py under torchrun): shard blocks [nshard][n][kk] as gathered,
 // output the first kk of the union in the PURE order (no print reversal), -1 / neutral padded.
 void merge_shards_raw_host(int metric, int64_t n, int64_t kk, int nshard, const float *D, const int64_t *I, float *D_out,

@@ -590,8 +590,21 @@ void launch_merge_records(int metric, const int64_t *d_rec, int nshard, int64_t 
 		return;
 	const int c = nshard * kk;
 	const size_t lds = (size_t)c * 8 + ((size_t)(c + kout + 1) / 2) * 8 + (size_t)kout * 8 + 16;
-	if (lds > 150 * 1024)
-		throw_faiss(__func__, __FILE__, "merge: nshard * k = %d too large", c);
+	if (lds > 150 * 1024) {
+		// k in the thousands on several shards: the candidates of one query no longer fit a workgroup's LDS.  A cold shape
+		// (a single GPU serves such k through flat_direct / the all-distances IVF path, not through k-lists either): the
+		// records go to the host, merge_records_host (csrc/merge_host.hip) keeps the same kout best in the same order.
+		std::vector<int64_t> h_rec((size_t)nshard * nq * kk * 2);
+		std::vector<float> h_D((size_t)nq * kout);
+		std::vector<int64_t> h_I((size_t)nq * kout);
+		MVS_HIP(hipMemcpyAsync(h_rec.data(), d_rec, h_rec.size() * 8, hipMemcpyDeviceToHost, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		merge_records_host(metric, h_rec.data(), nshard, nq, kk, kout, raw, h_D.data(), h_I.data());
+		MVS_HIP(hipMemcpyAsync(d_D, h_D.data(), h_D.size() * 4, hipMemcpyHostToDevice, st));
+		MVS_HIP(hipMemcpyAsync(d_I, h_I.data(), h_I.size() * 8, hipMemcpyHostToDevice, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		return;
+	}
 	if (metric_order(metric) == METRIC_L2) {
 		auto kern = merge_records_kernel<true>;
 		ensure_dynamic_lds((const void *)kern, lds);

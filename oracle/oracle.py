@@ -320,6 +320,10 @@ def openblas_load(path=None):
     return L.orc_openblas_config().decode()
 
 
+def openblas_set_num_threads(n):
+    lib().orc_openblas_set_num_threads(int(n))
+
+
 def openblas_census(metric, xb, xq, k, D_dev, I_dev, ref=None):
     """Compare a device result (labels I_dev, values D_dev; [nq, k]) with FAISS's BLAS branch summed by the REAL OpenBLAS sgemm
     (search at k + 1, so that the gap behind the last slot is known) and classify every (query, rank) slot.

@@ -375,6 +375,29 @@ def test_ivf_large_k_select_path(mf, metric, idmap):
         assert np.array_equal(I[uniq], Io[uniq]), (k, nprobe)
 
 
+def test_ivf_k_beyond_the_tie_pass_lds_keeps_working(mf):
+    """the exact-tie wrapper was admitted for every k < 16 384 although the tie pass keeps A_k in LDS (fits up to
+    ~12 700 at d = 128): k in between threw "IVF tie pass: k too large" AFTER the whole k + 1 search.  Such k now keep the pure
+    order, as k >= 16 384 always did."""
+    d, nlist, n = 128, 16, 20000
+    xb = _clustered(n, d, 51)
+    xq = _clustered(6, d, 52)
+    o = orc.Index(d, f"IVF{nlist},Flat", L2)
+    o.train(xb)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+    g.ivf_set_centroids(o.ivf_centroids())
+    o.add(xb)
+    g.add(xb)
+    for k in (12000, 13000, 16383, 16384):
+        Do, Io = o.search(xq, k, nprobe=nlist)
+        D, I = g.search(xq, k, nprobe=nlist)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), k
+        uniq = np.ones_like(I, dtype=bool)
+        uniq[:, 1:] &= Do[:, 1:] != Do[:, :-1]
+        uniq[:, :-1] &= Do[:, 1:] != Do[:, :-1]
+        assert np.array_equal(I[uniq], Io[uniq]), k
+
+
 def test_ivf_select_path_equals_k_list_path_at_small_k(mf):
     d, nlist, n = 64, 16, 20000
     xb = _clustered(n, d, 41)

@@ -3,7 +3,7 @@
 tag=$1; shift
 out=gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.txt
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-host-pointer "$@" > $out/bench.json 2> $out/err.txt
 f=$(find $out/pmc -name "*counter_collection.csv" | head -1)
 python3 - "$f" > $out/pmc_sq.txt <<'PY'
 import csv, sys, collections
