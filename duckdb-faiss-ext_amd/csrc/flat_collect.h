@@ -29,9 +29,12 @@ struct CollectArgs {
 	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
 	long long n, row_first, split_rows;
 	int nq, nqb, nsplit, xcd_map;
+	float *pbnd; // d <= 128 scan: [nqb][512] pass bounds B - 2E in the order of a workgroup's LDS table (flat_collect.hip), or null
 	int opt; // A/B bits (option cl_ksplit_opt): 0 = k-split kernel with 8 waves: s_setprio skew between the two waves of a SIMD;
 	         // 1 = wide kernels: bound refresh cadence counted in staged blocks instead of rows; 2..3 = d <= 128 kernel: refresh cadence
-	         // (0: every 8 / 32 / 128 staged blocks, 1: 4 / 16 / 64, 2: 16 / 64 / 256, 3: 32 / 128 / 512)
+	         // (0: every 8 / 32 / 128 staged blocks, 1: 4 / 16 / 64, 2: 16 / 64 / 256, 3: 32 / 128 / 512); with the pass-bound table
+	         // (pbnd != null): bits 2..3 = table fetch period in staged blocks (0: 4, 1: 2, 2: 8, 3: 16), bits 4..5: full
+	         // derivation every 64 (0) / 16 (1) / 128 (2) staged blocks per workgroup, 3 = by the scan's progress (16 / 64 / 256)
 };
 
 // csrc/flat_collect_wide.hip
@@ -52,7 +55,8 @@ void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int inte
                               const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
                               unsigned *d_max_norm_bits, hipStream_t st);
 void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d,
-                               const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st);
+                               const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st,
+                               const unsigned long long *d_cnt = nullptr);
 
 __device__ __forceinline__ unsigned skey(float s) { // "larger s is better" as a smaller-is-better key
 	return ~f2key(s);

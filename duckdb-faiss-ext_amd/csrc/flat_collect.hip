@@ -91,7 +91,8 @@ __device__ __forceinline__ float cl_dpp(float v) {
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 // one thread per (row, 8 dims); the dp / 8 threads of a row are neighbours in a wave
-// max_bits[0]: largest squared norm of the ORIGINAL rows (shared with flat_bf16.hip), max_bits[8]: of the centred rows
+// max_bits[0]: largest squared norm of the ORIGINAL rows (shared with flat_bf16.hip), max_bits[8]: of the centred rows,
+// max_bits[12]: of the centred rows' bf16 rounding residuals y' - bf16(y')
 template <bool IS_L2>
 __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp, int dpd,
                                        int interleaved, const float *__restrict__ mu, unsigned short *__restrict__ dst,
@@ -115,24 +116,27 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 		}
 	}
 	bf16x8 hi;
-	float n2 = 0.f, my = 0.f; // partial ||y'||^2 and <mu, y>
+	float n2 = 0.f, my = 0.f, r2 = 0.f; // partial ||y'||^2, <mu, y> and ||y' - bf16(y')||^2 (the row's actual rounding residual)
 #pragma unroll
 	for (int e = 0; e < 8; ++e) {
 		const float m = mu[c8 * 8 + e];
 		const float c = v[e] - m;
 		hi[e] = (__bf16)c;
+		const float dl = c - (float)hi[e]; // (exact: the two agree in their leading 8 bits)
 		n2 = fmaf(c, c, n2);
 		my = fmaf(m, v[e], my);
+		r2 = fmaf(dl, dl, r2);
 	}
 	if (g8 == 16) { // the row's threads are one DPP row of 16 lanes: sum by quad_perm x 2, row_half_mirror, row_mirror (no LDS)
-		n2 += cl_dpp<0xB1>(n2), my += cl_dpp<0xB1>(my);
-		n2 += cl_dpp<0x4E>(n2), my += cl_dpp<0x4E>(my);
-		n2 += cl_dpp<0x141>(n2), my += cl_dpp<0x141>(my);
-		n2 += cl_dpp<0x140>(n2), my += cl_dpp<0x140>(my);
+		n2 += cl_dpp<0xB1>(n2), my += cl_dpp<0xB1>(my), r2 += cl_dpp<0xB1>(r2);
+		n2 += cl_dpp<0x4E>(n2), my += cl_dpp<0x4E>(my), r2 += cl_dpp<0x4E>(r2);
+		n2 += cl_dpp<0x141>(n2), my += cl_dpp<0x141>(my), r2 += cl_dpp<0x141>(r2);
+		n2 += cl_dpp<0x140>(n2), my += cl_dpp<0x140>(my), r2 += cl_dpp<0x140>(r2);
 	} else {
 		for (int o = g8 >> 1; o >= 1; o >>= 1) { // an aligned group of g8 lanes
 			n2 += __shfl_xor(n2, o);
 			my += __shfl_xor(my, o);
+			r2 += __shfl_xor(r2, o);
 		}
 	}
 	if (!live)
@@ -146,6 +150,9 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 		const unsigned bc = __float_as_uint(n2); // (>= 0 or NaN: the bit pattern orders like the value, NaN above everything)
 		if (bc > max_bits[8])
 			atomicMax(max_bits + 8, bc);
+		const unsigned br = __float_as_uint(r2);
+		if (br > max_bits[12])
+			atomicMax(max_bits + 12, br);
 	}
 }
 void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, int64_t row0, int64_t nrows, const float *d_mu,
@@ -218,6 +225,13 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
 // (Cauchy-Schwarz), S = ||x|| ||y||_max; every norm is inflated by 1e-4 for its own rounding.
 //   bf16 rounding of both operands: |x'_i y'_i - bf(x'_i) bf(y'_i)| <= (2 * 2^-8 + 2^-16) |x'_i y'_i|  -> (2^-7 + 2^-16) S'
 //   (bf16 keeps 8 significant bits: round-to-nearest errs by up to 2^-8 |v| per operand)
+//   ROUND 4 (mode 1, default): the same term from the ACTUAL rounding residuals instead of the worst case per element.  With
+//   a = alpha x' (what the pack kernel rounds), Q = bf(a), Y = bf(y'):  <a, y'> - <Q, Y> = <a - Q, y'> + <Q, y' - Y>, hence
+//        | . | <= ||a - Q|| ||y'||_max + (||a|| + ||a - Q||) ||y' - Y||_max        (Cauchy-Schwarz, nothing modelled)
+//   ||a - Q|| is computed here per query (the differences are exact in f32), ||y' - Y||_max when the bf16 store is built
+//   (max_norm_bits[12]).  A rounding residual is uniform inside its half ulp, so the norms come out near 0.41 x 2^-8 of the
+//   operand norms instead of 2^-8: E shrinks ~2.4x and with it the band of rows the scan has to admit (uniform rows at the
+//   headline: 234 -> ~150 candidates per query; the band is exponentially sensitive on clustered rows).
 //   bf16 MFMA accumulation, the chain starting at C = beta (undocumented internal rounding modelled as 4 ulp-units of the
 //   magnitudes per instruction, counted as d / 16 instructions, with a 1.25 safety factor as in flat_bf16.hip
 //   prefilter_cerr):                                                                      -> 1.25 (d/16) 4u ((1 + 2^-7 + 2^-16) alpha S' + |beta|_max)
@@ -233,18 +247,23 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
 template <bool IS_L2>
 __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq, int d, const float *__restrict__ mu,
                                       const unsigned *__restrict__ max_norm_bits, float *__restrict__ e2,
-                                      int *__restrict__ fail_cnt, int *__restrict__ fail_q) {
+                                      int *__restrict__ fail_cnt, int *__restrict__ fail_q, int bound_mode) {
 	const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= nq)
 		return;
-	float xn = 0.f, xnc = 0.f, mun = 0.f;
+	float xn = 0.f, xnc = 0.f, mun = 0.f, dq2 = 0.f;
+	const float alf = IS_L2 ? 2.0f : 1.0f;
 	for (int t = 0; t < d; ++t) {
 		const float v = x[q * d + t], m = mu[t], c = v - m;
 		xn = fmaf(v, v, xn);
 		xnc = fmaf(c, c, xnc);
 		mun = fmaf(m, m, mun);
+		const float a = alf * c; // exactly the operand collect_pack_queries_kernel rounds
+		const float dl = a - (float)(__bf16)a;
+		dq2 = fmaf(dl, dl, dq2);
 	}
 	const float yn = __uint_as_float(max_norm_bits[0]), ync = __uint_as_float(max_norm_bits[8]);
+	const float dyc = __uint_as_float(max_norm_bits[12]);
 	const double u = 5.9604644775390625e-08, infl = 1.0001;
 	const double S = sqrt((double)xn * infl) * sqrt((double)yn * infl);
 	const double Sc = sqrt((double)xnc * infl) * sqrt((double)ync * infl);
@@ -252,8 +271,12 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
 	// s comes straight out of the MFMA chain: C starts at beta, the B operand carries alpha
 	const double al = IS_L2 ? 2.0 : 1.0;
 	const double bmax = IS_L2 ? (double)ync : MY; // >= |beta|
-	const double es = al * (0.0078125 + 1.52587890625e-05) * Sc +
-	                  1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * al * Sc + bmax);
+	const double rnd_worst = al * (0.0078125 + 1.52587890625e-05) * Sc;
+	const double ndq = sqrt((double)dq2 * infl), ndy = sqrt((double)dyc * infl);
+	const double rnd_actual = ndq * sqrt((double)ync * infl) + (al * sqrt((double)xnc * infl) + ndq) * ndy;
+	// (never above the worst case; a non-finite residual norm poisons E below like any other non-finite input)
+	const double rnd = bound_mode == 0 ? rnd_worst : (rnd_actual < rnd_worst || !(rnd_actual == rnd_actual) ? rnd_actual : rnd_worst);
+	const double es = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * al * Sc + bmax);
 	double E;
 	if (IS_L2)
 		E = es + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn) +
@@ -261,13 +284,14 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
 	else
 		E = es + 4.0 * u * Sc + 2.0 * u * MY + (double)d * u * MY + (double)d * u * S;
 	float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (Sc + MY + (double)xnc + ync) + 1e-30);
-	const bool ok = isfinite(xn) && isfinite(yn) && isfinite(ync) && isfinite(mun) && isfinite(r) && r < 1e30f;
+	const bool ok = isfinite(xn) && isfinite(yn) && isfinite(ync) && isfinite(mun) && isfinite(dq2) && isfinite(dyc) && isfinite(r) && r < 1e30f;
 	if (!ok) {
 		r = __uint_as_float(0x7fc00000u);
 		fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
 	}
 	e2[q] = r;
 }
+int g_cl_bound_mode = 1; // option cl_bound_mode: bf16 rounding term from the actual residual norms (1) or the worst case per element (0)
 void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st) {
 	if (nq <= 0)
@@ -275,10 +299,10 @@ void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, cons
 	const dim3 grid((unsigned)((nq + 255) / 256));
 	if (metric == METRIC_L2)
 		hipLaunchKernelGGL(collect_bounds_kernel<true>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, d_e2,
-		                   d_fail_cnt, d_fail_q);
+		                   d_fail_cnt, d_fail_q, g_cl_bound_mode);
 	else
 		hipLaunchKernelGGL(collect_bounds_kernel<false>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, d_e2,
-		                   d_fail_cnt, d_fail_q);
+		                   d_fail_cnt, d_fail_q, g_cl_bound_mode);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -370,11 +394,45 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + lane), (lds_f32c *)(smem + (2 * STAGE_BYTES) / 4 + (u & 1) * 64),
 		                                 4, 0, 0);
 	};
+	// Pass bounds through a TABLE IN GLOBAL MEMORY (round 4).  Round 3 had every wave re-derive its 128 bounds from the class slots
+	// (an L2 round trip per query pair + a 16-key network, ~4.4 us of workgroup time, 11 times per 9 766-row split = 9 % of a shard's
+	// scan) -- and the 25 workgroups that share a query block all derived the same numbers.  Now a.pbnd holds B - 2E of every query in
+	// the order of the workgroup's LDS table, a wave fetches its 128 entries with two LDS-DMA instructions (no registers, no wait:
+	// they land before the staged block's barrier; a bound is valid whenever it was computed, so old and new entries may mix), and
+	// the full derivation runs once per PB_R staged blocks per workgroup at a phase that depends on the row split: the workgroups
+	// of a query block take turns and between them refresh the table every block or two.
+	const bool use_tab = a.pbnd != nullptr;
+	const int tab_bits = (a.opt >> 2) & 3;
+	const int tab_shift = tab_bits == 0 ? 2 : (tab_bits == 1 ? 1 : tab_bits + 1); // fetch every 4 (default) / 2 / 8 / 16 staged blocks
+	// full derivation every 64 staged blocks per workgroup (same box, N = 1.25 M / 1 M / 10 M, ms per step: every 16: 3.17 / 2.69 / 18.08,
+	// 32: 3.05 / 2.62 / 17.59, 64: 3.02 / 2.58 / 17.30), option bits 4..5: 1 = 16, 2 = 128, 3 = by the scan's progress: 16 while the
+	// query block's workgroups have seen little (the bound still moves), 64, then 256
+	// (the publish-only pre-pass of the 32-class instances runs a few blocks per workgroup from cold slots: every 4 blocks there)
+	const int duty_bits = (a.opt >> 4) & 3;
+	const int duty_g0 = duty_bits == 3 ? (int)(blockIdx.x / 512u) * ntiles : 0; // staged blocks this workgroup's predecessors on the slot saw
+	auto duty_mask_at = [&](int u) {
+		if (!COLLECT)
+			return 3;
+		if (duty_bits == 3) {
+			const int g = duty_g0 + u;
+			return g < 64 ? 15 : (g < 256 ? 63 : 255);
+		}
+		return duty_bits == 0 ? 63 : (duty_bits == 1 ? 15 : 127);
+	};
+	const int duty_phase = split * 13 + 5;
+	auto dma_bounds = [&]() {
+		const float *base = a.pbnd + (size_t)qb * CL_QBLOCK + wave * 128; // uniform
+		float *dst = cqtab + wave * 128;
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + lane), (lds_f32c *)dst, 4, 0, 16 /* sc1: agent scope */);
+		__builtin_amdgcn_global_load_lds((glb_f32c *)(base + 64 + lane), (lds_f32c *)(dst + 64), 4, 0, 16);
+	};
 	if (ntiles > 0) {
 #pragma unroll
 		for (int i = 0; i < DMA_PER_WAVE; ++i)
 			dma_issue(0, i);
 		dma_norms(0);
+		if (use_tab)
+			dma_bounds();
 	}
 	__syncthreads();
 
@@ -454,7 +512,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		// A/B: option cl_ksplit_opt bits 2..3: 1 = the old cadence, 2 / 3 = sparser still)
 		const int pb = (a.opt >> 2) & 3, psh = pb == 1 ? 0 : (pb == 0 ? 1 : pb);
 		const int period = u < 4 ? 1 : (u < 32 ? 4 << psh : (u < 256 ? 16 << psh : 64 << psh)); // (in staged blocks of CL_SUB tiles)
-		if ((u % period) == 0) {
+		const bool full = use_tab ? ((u + duty_phase) & duty_mask_at(u)) == 0 : (u % period) == 0;
+		if (use_tab && !full && u > 0 && (u & ((1 << tab_shift) - 1)) == 0)
+			dma_bounds(); // (lands before this block's barrier; until then the tiles use the entries already there)
+		if (full) {
 			// B = the kk-th best of the 16 class bests (kk distinct rows are at least that good): as keys, the kk-th smallest
 			// (bitonic network in registers).  The pass bound B - 2E goes to the wave's table in LDS.
 			int qo = qw;
@@ -505,6 +566,12 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				v[1] = i == 1 ? bv : v[1];
 			}
 			*(f32x2n *)(cqtab + (wave * 64 + hq * 16 + c) * 2) = v;
+			if (use_tab) { // ... and for every other workgroup of this query block (agent scope: the XCDs' L2s are not coherent)
+				unsigned long long bits;
+				__builtin_memcpy(&bits, &v, 8);
+				__hip_atomic_store((unsigned long long *)(a.pbnd + (size_t)qb * CL_QBLOCK + (wave * 64 + hq * 16 + c) * 2), bits, __ATOMIC_RELAXED,
+				                   __HIP_MEMORY_SCOPE_AGENT);
+			}
 		}
 #pragma unroll 1
 		for (int sub = 0; sub < CL_SUB; ++sub) {
@@ -694,10 +761,68 @@ int g_cl_seed_regs = 1;     // option cl_seed_regs: d <= 128 pre-pass with class
 int flat_mfma_slot_stride(int64_t k);
 __global__ void init_gslot_kernel(unsigned *g, long long total, int stride, int k, int is_l2);
 
+// The pass-bound table of the d <= 128 scan from the class slots as they stand: entry j of query block qb = the bound of query
+// qb * 512 + 128 w + 32 hq + 16 i + c with j = 128 w + 2 (16 hq + c) + i -- the order of the workgroup's LDS table.  B = the kk-th
+// best of the NC class bests (as keys: the kk-th smallest), pass bound = B - 2E; NaN (nothing passes) behind the last query and
+// for the queries without a finite 2E.  Runs in front of every scan launch (slots warm from the pre-pass or a previous attempt).
+template <int NC>
+__global__ void collect_bound_table_kernel(const unsigned *__restrict__ gslot, const float *__restrict__ e2, int nclass, int nq,
+                                           long long total, float *__restrict__ pbnd) {
+	const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= total)
+		return;
+	const int o = (int)(j & 127), w = (int)((j >> 7) & 3);
+	const long long qb = j >> 9;
+	const int i = o & 1, c = (o >> 1) & 15, hq = o >> 5;
+	const long long q = qb * CL_QBLOCK + w * 128 + 32 * hq + 16 * i + c;
+	float bv = __uint_as_float(0x7fc00000u);
+	if (q < nq) {
+		unsigned key[NC];
+#pragma unroll
+		for (int t = 0; t < NC; ++t)
+			key[t] = gslot[(size_t)q * NC + t];
+		// the (nclass - 1)-th smallest with duplicates counted: the key whose rank interval covers it
+		unsigned kth = 0xffffffffu;
+#pragma unroll
+		for (int t = 0; t < NC; ++t) {
+			int less = 0, leq = 0;
+#pragma unroll
+			for (int s2 = 0; s2 < NC; ++s2) {
+				less += key[s2] < key[t];
+				leq += key[s2] <= key[t];
+			}
+			if (less <= nclass - 1 && nclass - 1 < leq)
+				kth = key[t];
+		}
+		const unsigned neutral = skey(-FLT_MAX);
+		const float B = skey2f(kth < neutral ? kth : neutral);
+		bv = B - e2[q];
+	}
+	pbnd[j] = bv;
+}
+static void launch_collect_bound_table(const CollectArgs &a, int nqb, hipStream_t st) {
+	if (!a.pbnd)
+		return;
+	const long long total = (long long)nqb * CL_QBLOCK;
+	const dim3 grid((unsigned)((total + 255) / 256));
+	if (a.slot_stride == 32)
+		hipLaunchKernelGGL(collect_bound_table_kernel<32>, grid, dim3(256), 0, st, (const unsigned *)a.gslot, a.e2, a.nclass, a.nq, total, a.pbnd);
+	else
+		hipLaunchKernelGGL(collect_bound_table_kernel<16>, grid, dim3(256), 0, st, (const unsigned *)a.gslot, a.e2, a.nclass, a.nq, total, a.pbnd);
+	MVS_HIP(hipGetLastError());
+}
+size_t collect_bound_table_bytes(int64_t nq) {
+	return (size_t)((nq + CL_QBLOCK - 1) / CL_QBLOCK) * CL_QBLOCK * sizeof(float) + 1024;
+}
+int g_cl_tab = 1; // option cl_tab: pass bounds through the global table (1) or every wave derives its own (0, round 3)
+
 template <bool COLLECT>
 static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, int64_t row_first, int64_t row_end,
                                  int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out) {
 	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
+	if (!g_cl_tab)
+		a.pbnd = nullptr;
+	launch_collect_bound_table(a, nqb, st);
 	const int64_t ntiles = (row_end - row_first + CL_SUB * CL_BN - 1) / (CL_SUB * CL_BN); // staged blocks
 	const int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(nsplit_want, ntiles));
 	a.xcd_map = (nsplit >= 8 && nsplit % 8 == 0) ? 1 : 0;
@@ -948,7 +1073,7 @@ int collect_max_k(int d) {
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, hipStream_t st) {
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st) {
 	const int stride = collect_slot_stride(kk); // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
 	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, stride,
@@ -966,6 +1091,7 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.nq = (int)nq;
 	a.rowmask = d_rowmask;
 	a.opt = g_ksplit_opt;
+	a.pbnd = d_pbnd;
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
 	const int dp1 = collect_store_dims(g.d);
 	if (dp1 == 128 && g_cl_seed_regs && stride == 16) { // (32 classes: 64 registers of maxima do not fit; the publish-only scan below)
@@ -987,8 +1113,8 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 // the main scan: every row, candidates into the stream
 void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
-                         unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, hipStream_t st,
-                         int *grid_out, int *nsplit_out, int *lds_out) {
+                         unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
+                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out) {
 	CollectArgs a;
 	memset(&a, 0, sizeof a);
 	a.qf = d_qf;
@@ -1004,6 +1130,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.stream_cap = stream_cap;
 	a.rowmask = d_rowmask;
 	a.opt = g_ksplit_opt;
+	a.pbnd = d_pbnd;
 	const int dp1 = collect_store_dims(g.d);
 	const int qblock = dp1 > 128 ? collect_wide_qblock(dp1) : CL_QBLOCK;
 	const int nqb = (int)((nq + qblock - 1) / qblock);
@@ -1086,16 +1213,23 @@ __global__ void collect_segments_kernel(const unsigned long long *__restrict__ s
 // thread streaming its own row thrashes the 32 KB L1: 6.2 ms for 10^7 candidates), row pitch DP + 4 floats so that the 16
 // lanes of a ds_read_b128 phase hit distinct banks; then lane <-> candidate runs the k-ordered chain.
 // PAIR (L2 with an IDSelector: FAISS's per-pair branch, exhaustive_L2sqr_seq): t = x_k - y_k, acc = fmaf(t, t, acc), k ascending
+// cnt != null: the number of candidates is min(*cnt, ncand) -- read on the device, the host never waited for it -- and the grid is
+// a fixed number of waves that walk the groups of 64 in strides (round 4: no host round trip between the scan and the re-scoring).
 template <bool IS_L2, int DP, bool PAIR = false>
 __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *__restrict__ sorted, long long ncand,
                                                           const float *__restrict__ x, int d,
                                                           const float *__restrict__ vecs, int interleaved,
-                                                          const float *__restrict__ norms, const float *__restrict__ qn) {
+                                                          const float *__restrict__ norms, const float *__restrict__ qn,
+                                                          const unsigned long long *__restrict__ cnt) {
 	constexpr int PITCH = DP + 4, CPR = DP / 4; // floats per LDS row, float4 chunks per row
 	constexpr int RPI = 64 / CPR;               // rows per load instruction (2 at DP = 128)
 	__shared__ __attribute__((aligned(16))) float rows[64 * PITCH];
 	const int lane = threadIdx.x;
-	const long long i0 = (long long)blockIdx.x * 64;
+	if (cnt) {
+		const unsigned long long have = *cnt;
+		ncand = have < (unsigned long long)ncand ? (long long)have : ncand;
+	}
+	for (long long i0 = (long long)blockIdx.x * 64; i0 < ncand; i0 += (long long)gridDim.x * 64) {
 	const long long i = i0 + lane;
 	const unsigned long long ent = i < ncand ? sorted[i] : 0ull;
 	const unsigned row = (unsigned)ent;
@@ -1120,8 +1254,7 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 		*(float4 *)(rows + (r + sub) * PITCH + ch * 4) = v;
 	}
 	__syncthreads();
-	if (i >= ncand)
-		return;
+	if (i < ncand) {
 	const float *y = rows + lane * PITCH;
 	const bool odd = interleaved && ((row >> 4) & 1);
 	float ip = 0.f;
@@ -1202,6 +1335,9 @@ __global__ __launch_bounds__(64) void collect_exact_kernel(unsigned long long *_
 		ok = ex > -FLT_MAX;
 	}
 	sorted[i] = ok ? (((unsigned long long)bkey<IS_L2>(ex) << 32) | row) : ~0ull;
+	}
+	__syncthreads(); // (the next group's rows overwrite the tile)
+	}
 }
 
 __device__ __forceinline__ unsigned long long cl_lane64(unsigned long long v, int l) { // l uniform
@@ -1249,6 +1385,69 @@ __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long 
 		pd1[q * kk + lane] = have ? bkey2f<IS_L2>((unsigned)(mine >> 32)) : (IS_L2 ? FLT_MAX : -FLT_MAX);
 		pi1[q * kk + lane] = have ? (int)(unsigned)mine : -1;
 	}
+}
+
+// ---- candidates grouped by query WITHOUT the host knowing how many there are (round 4) ------------------------------------------
+// Round 3 read the stream's fill back to the host (a stream synchronisation in the middle of every search: the GPU idles for the
+// round trip, then for the launch latency of each of the ten small kernels behind it) because rocPRIM's radix sort and the
+// re-scoring grid want the count as a host value.  A counting sort by query needs neither: histogram -> prefix sums -> scatter,
+// all reading min(*cnt, cap) on the device; the order INSIDE a query's segment is whatever the atomics give (the selection
+// ranks (value, row) keys, the tie pass reads a segment as a set: neither depends on it).
+__global__ void collect_hist_kernel(const unsigned long long *__restrict__ stream, const unsigned long long *__restrict__ cnt,
+                                    long long cap, int *__restrict__ qcount) {
+	const unsigned long long have = *cnt;
+	const long long n = have < (unsigned long long)cap ? (long long)have : cap;
+	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+		atomicAdd(&qcount[(unsigned)(stream[i] >> 32)], 1);
+}
+// one workgroup: seg_b / seg_e of every query from the counts; cursor = seg_b
+__global__ __launch_bounds__(1024) void collect_offsets_kernel(const int *__restrict__ qcount, int nq, int *__restrict__ seg_b,
+                                                              int *__restrict__ seg_e, int *__restrict__ cursor) {
+	__shared__ int part[1024];
+	const int tid = threadIdx.x;
+	const int per = (nq + 1023) / 1024;
+	const int q0 = tid * per, q1 = q0 + per < nq ? q0 + per : nq;
+	int sum = 0;
+	for (int q = q0; q < q1; ++q)
+		sum += qcount[q];
+	part[tid] = sum;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) { // inclusive scan
+		const int v = tid >= off ? part[tid - off] : 0;
+		__syncthreads();
+		part[tid] += v;
+		__syncthreads();
+	}
+	int run = part[tid] - sum;
+	for (int q = q0; q < q1; ++q) {
+		const int c = qcount[q];
+		seg_b[q] = run;
+		cursor[q] = run;
+		run += c;
+		seg_e[q] = run;
+	}
+}
+__global__ void collect_scatter_kernel(const unsigned long long *__restrict__ stream, const unsigned long long *__restrict__ cnt,
+                                       long long cap, int *__restrict__ cursor, unsigned long long *__restrict__ sorted) {
+	const unsigned long long have = *cnt;
+	const long long n = have < (unsigned long long)cap ? (long long)have : cap;
+	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+		const unsigned long long ent = stream[i];
+		sorted[atomicAdd(&cursor[(unsigned)(ent >> 32)], 1)] = ent;
+	}
+}
+// d_work: [3 nq + 16] ints (counts | cursor; zeroed here), d_seg: [2 nq]
+void launch_collect_group_dev(const unsigned long long *d_stream, unsigned long long *d_sorted, const unsigned long long *d_cnt,
+                              int64_t cap, int64_t nq, int *d_seg, int *d_work, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	int *qcount = d_work, *cursor = d_work + nq;
+	MVS_HIP(hipMemsetAsync(qcount, 0, (size_t)nq * sizeof(int), st));
+	const unsigned grid = (unsigned)std::min<int64_t>((cap + 255) / 256, 2048);
+	hipLaunchKernelGGL(collect_hist_kernel, dim3(grid), dim3(256), 0, st, d_stream, d_cnt, (long long)cap, qcount);
+	hipLaunchKernelGGL(collect_offsets_kernel, dim3(1), dim3(1024), 0, st, (const int *)qcount, (int)nq, d_seg, d_seg + nq, cursor);
+	hipLaunchKernelGGL(collect_scatter_kernel, dim3(grid), dim3(256), 0, st, d_stream, d_cnt, (long long)cap, cursor, d_sorted);
+	MVS_HIP(hipGetLastError());
 }
 
 size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq) {
@@ -1332,29 +1531,35 @@ void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_se
 }
 
 // stream (ncand entries) -> per query the kk best exact candidates: pd1 / pi1 [nq][kk] (value, row), best first
+// d_cnt != null: device-count mode -- ncand is the stream's CAPACITY, the number of entries is min(*d_cnt, ncand) on the device,
+// d_temp holds [3 nq + 16] ints (launch_collect_group_dev) instead of the radix sort's temporary storage
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
-                            bool per_pair, hipStream_t st) {
+                            bool per_pair, hipStream_t st, const unsigned long long *d_cnt) {
 	if (nq <= 0)
 		return;
-	launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st);
+	if (d_cnt)
+		launch_collect_group_dev(d_stream, d_sorted, d_cnt, ncand, nq, d_seg, (int *)d_temp, st);
+	else
+		launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st);
 	if (ncand > 0 && collect_store_dims(g.d) > 128) {
-		launch_collect_exact_wide(metric, per_pair, d_sorted, ncand, d_x, g.d, d_vecs, g.dp, g.pair_interleaved ? 1 : 0, d_norms, d_qn, st);
+		launch_collect_exact_wide(metric, per_pair, d_sorted, ncand, d_x, g.d, d_vecs, g.dp, g.pair_interleaved ? 1 : 0, d_norms, d_qn, st, d_cnt);
 	} else if (ncand > 0) {
-		const dim3 grid((unsigned)((ncand + 63) / 64));
+		// (device-count mode: 8 192 waves walk the groups in strides -- two dispatch rounds of the 4 096 resident ones)
+		const dim3 grid((unsigned)(d_cnt ? std::min<int64_t>((ncand + 63) / 64, 8192) : (ncand + 63) / 64));
 		// (row pitch of the f32 store = FlatGeom::dp: 128 for 64 < d <= 128, 64 / 32 below)
 #define MVS_CL_EXACT(DPV)                                                                                              \
 	{                                                                                                                  \
 		if (metric == METRIC_L2 && per_pair)                                                                           \
 			hipLaunchKernelGGL((collect_exact_kernel<true, DPV, true>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d, \
-			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);                                     \
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn, d_cnt);                              \
 		else if (metric == METRIC_L2)                                                                                  \
 			hipLaunchKernelGGL((collect_exact_kernel<true, DPV>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d, \
-			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);                                     \
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn, d_cnt);                              \
 		else                                                                                                           \
 			hipLaunchKernelGGL((collect_exact_kernel<false, DPV>), grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, g.d, \
-			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn);                                     \
+			                   d_vecs, g.pair_interleaved ? 1 : 0, d_norms, d_qn, d_cnt);                              \
 	}
 		if (g.dp == 128)
 			MVS_CL_EXACT(128)

@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
 		return;
 	// FlatGeom::pair_interleaved: every 4 floats stored [k0,k2,k1,k3] (bit 4 of the row clear) or [k1,k3,k0,k2]
 	const int flip = interleaved ? (((r >> 4) & 1) ? 2 : 0) : 0;
-	float n2 = 0.f, my = 0.f;
+	float n2 = 0.f, my = 0.f, r2 = 0.f; // ||y'||^2, <mu, y>, ||y' - bf16(y')||^2 (flat_collect.hip, "ROUND 4")
 	for (int c8 = lane; c8 < dp1 / 8; c8 += 64) {
 		bf16x8 hi;
 #pragma unroll
@@ -640,14 +640,17 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
 			const float m = kk < d ? mu[kk] : 0.f;
 			const float cv = v - m;
 			hi[e] = (__bf16)cv;
+			const float dl = cv - (float)hi[e];
 			n2 = fmaf(cv, cv, n2);
 			my = fmaf(m, v, my);
+			r2 = fmaf(dl, dl, r2);
 		}
 		*(bf16x8 *)(dst + (size_t)r * dp1 + c8 * 8) = hi;
 	}
 	for (int o = 32; o >= 1; o >>= 1) {
 		n2 += __shfl_xor(n2, o);
 		my += __shfl_xor(my, o);
+		r2 += __shfl_xor(r2, o);
 	}
 	if (lane == 0) {
 		beta[r] = IS_L2 ? -n2 : my;
@@ -657,6 +660,9 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
 		const unsigned bc = __float_as_uint(n2);
 		if (bc > max_bits[8])
 			atomicMax(max_bits + 8, bc);
+		const unsigned br = __float_as_uint(r2);
+		if (br > max_bits[12])
+			atomicMax(max_bits + 12, br);
 	}
 }
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
@@ -681,10 +687,16 @@ template <bool IS_L2, bool PAIR>
 __global__ __launch_bounds__(64) void collect_exact_wide_kernel(unsigned long long *__restrict__ sorted, long long ncand,
                                                                const float *__restrict__ x, int d,
                                                                const float *__restrict__ vecs, int sdp, int interleaved,
-                                                               const float *__restrict__ norms, const float *__restrict__ qn) {
+                                                               const float *__restrict__ norms, const float *__restrict__ qn,
+                                                               const unsigned long long *__restrict__ cnt) {
 	__shared__ float tile[64][65];
 	const int lane = threadIdx.x;
-	const long long i = (long long)blockIdx.x * 64 + lane;
+	if (cnt) { // device-count mode (flat_collect.hip, "candidates grouped by query WITHOUT the host knowing how many there are")
+		const unsigned long long have = *cnt;
+		ncand = have < (unsigned long long)ncand ? (long long)have : ncand;
+	}
+	for (long long i0 = (long long)blockIdx.x * 64; i0 < ncand; i0 += (long long)gridDim.x * 64) {
+	const long long i = i0 + lane;
 	const unsigned long long ent = i < ncand ? sorted[i] : 0ull; // (idle lanes: row 0 of query 0, computed and dropped)
 	const unsigned row = (unsigned)ent;
 	const long long q = (long long)(ent >> 32);
@@ -737,8 +749,7 @@ __global__ __launch_bounds__(64) void collect_exact_wide_kernel(unsigned long lo
 		}
 		__syncthreads();
 	}
-	if (i >= ncand)
-		return;
+	if (i < ncand) {
 	float ex;
 	bool ok;
 	if (PAIR) {
@@ -753,16 +764,19 @@ __global__ __launch_bounds__(64) void collect_exact_wide_kernel(unsigned long lo
 		ok = ex > -FLT_MAX;
 	}
 	sorted[i] = ok ? (((unsigned long long)bkey<IS_L2>(ex) << 32) | row) : ~0ull;
+	}
+	}
 }
 void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d,
-                               const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st) {
+                               const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st,
+                               const unsigned long long *d_cnt) {
 	if (ncand <= 0)
 		return;
-	const dim3 grid((unsigned)((ncand + 63) / 64));
+	const dim3 grid((unsigned)(d_cnt ? std::min<int64_t>((ncand + 63) / 64, 8192) : (ncand + 63) / 64));
 #define MVS_EXW(L2, PR)                                                                                                \
 	{                                                                                                                  \
 		auto kern = collect_exact_wide_kernel<L2, PR>;                                                                 \
-		hipLaunchKernelGGL(kern, grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, d, d_vecs, sdp, interleaved, d_norms, d_qn); \
+		hipLaunchKernelGGL(kern, grid, dim3(64), 0, st, d_sorted, (long long)ncand, d_x, d, d_vecs, sdp, interleaved, d_norms, d_qn, d_cnt); \
 	}
 	if (metric == METRIC_L2 && per_pair)
 		MVS_EXW(true, true)

@@ -158,7 +158,7 @@ public:
 	void search_extra_metric(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                         const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
 
-	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi;
+	DevBuf ws_q, ws_qn, ws_pd, ws_pi, ws_gthr, ws_add, ws_xi, ws_pbnd;
 	DevBuf ws_flag, ws_tie; // inner-product boundary ties: flagged queries + tie-pass scratch
 	// bf16x3 prefilter (csrc/flat_bf16.hip): rows as bf16 hi/lo, derived lazily from `vecs` before a search
 	unsigned short *vecs_bf = nullptr; // [bf_cap][2 dp]
@@ -191,12 +191,20 @@ public:
 	// IVF coarse quantisation: the np nearest rows (L2, FAISS order) by distance matrix + selection (csrc/coarse_select.hip);
 	// false: shape not served, the caller uses search_device
 	bool coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st);
+	// defer_count: nothing waits for the candidate count between the scan and the re-scoring (device-count mode); the count is
+	// copied to h_flag_count[10..11] asynchronously and the caller checks it against cl_deferred_cap after ITS stream
+	// synchronisation -- on an overflow it runs the search again with defer_count = false (the synchronous overflow handling)
 	bool collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1, int32_t **pi1, int *fail_cnt, int *fail_q,
-	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st);
+	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, bool defer_count = false);
+	int64_t cl_deferred_cap = 0;
+	bool cl_defer = true; // option cl_defer_count
 	void drop_bf16_rows();
 	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
 	                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
 	                      const TieFlags *flp, hipStream_t st);
+	bool search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
+	                           const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
+	                           const TieFlags *flp, hipStream_t st, bool defer, bool *overflow);
 	int *h_flag_count = nullptr; // pinned
 	// row shard of a ShardedIndex (csrc/sharded.hip): results are the shard's ROW numbers in the pure order, no tie pass
 	// (the sharded index resolves ties across shards); an id map passed to search_flat then only feeds the selector
@@ -325,18 +333,19 @@ int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int
                               int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, hipStream_t st);
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st);
+size_t collect_bound_table_bytes(int64_t nq);
 size_t collect_rowmask_bytes(int64_t n);
 void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, unsigned long long *d_mask, hipStream_t st);
 void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
-                         unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, hipStream_t st,
-                         int *grid_out, int *nsplit_out, int *lds_out);
+                         unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
+                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out);
 size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq);
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
-                            bool per_pair, hipStream_t st);
+                            bool per_pair, hipStream_t st, const unsigned long long *d_cnt = nullptr);
 void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_seg, int64_t nq, const int *d_flag_query,
                              const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st);
 bool coarse_select_supported(int64_t nlist, int64_t np);
@@ -348,15 +357,15 @@ void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_so
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,
                            int32_t *d_pi1, hipStream_t st);
-extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_regs, g_cl_nc32_from;
+extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_regs, g_cl_nc32_from, g_cl_tab, g_cl_bound_mode;
 // csrc/ivf_collect.hip
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
-                             float *d_beta, unsigned *d_list_max_bits, hipStream_t st);
+                             float *d_beta, unsigned *d_list_max_bits /* [2 nlist] */, int64_t nlist, hipStream_t st);
 size_t ivf_collect_xi_bytes(int max_items);
 void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
-                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse = nullptr, int np = 0,
-                             float *d_ie2_pre = nullptr);
+                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse, int np,
+                             float *d_ie2_pre, int64_t nlist);
 void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,

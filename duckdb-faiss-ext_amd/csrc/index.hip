@@ -370,7 +370,8 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 // re-scored exactly.  Leaves the kk best exact candidates per query in *pd1 / *pi1 ([nq][kk]) and the queries whose bound
 // is not finite in fail_q.  false: the candidate stream overflowed (the caller uses the bf16x3 path instead).
 bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1_out, int32_t **pi1_out, int *fail_cnt,
-                                   int *fail_q, const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
+                                   int *fail_q, const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st,
+                                   bool defer_count) {
 	ensure_h1_rows(st);
 	// IDSelector: one bit per row, built per search (the selector sees idmap[row] behind an IndexIDMap, the row number else)
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
@@ -407,8 +408,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	unsigned long long *cnt = (unsigned long long *)ws_stream.p;
 	unsigned long long *stream = (unsigned long long *)((char *)ws_stream.p + 256);
 	unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+	ws_pbnd.reserve(collect_bound_table_bytes(nq));
+	float *pbnd = wide ? nullptr : (float *)ws_pbnd.p; // (the d <= 128 scan only)
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
-	                       (unsigned *)ws_gthr.p, cnt, rowmask, st);
+	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st);
 	int grid = 0, nsplit = 0, lds = 0;
 	const bool few = !wide && nq <= 128 && collect_slot_stride(kk) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
@@ -435,12 +438,16 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		lds = 20544;
 	} else {
 		launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
-		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, st, &grid, &nsplit, &lds);
+		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, pbnd, st, &grid, &nsplit, &lds);
 	}
 	end_kernel_timing(st);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	if (defer_count) { // the caller looks at the count after its own synchronisation
+		cl_deferred_cap = cap_entries;
+		break;
+	}
 	MVS_HIP(hipStreamSynchronize(st));
 	unsigned long long ncand_u;
 	memcpy(&ncand_u, h_flag_count + 10, sizeof ncand_u);
@@ -481,9 +488,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	}
 	MVS_HIP(hipMemsetAsync(cnt, 0, 16, st));
 	} // attempt
-	cl_queries_total += nq;
-	cl_candidates_total += ncand;
-	const size_t temp = ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0;
+	if (!defer_count) {
+		cl_queries_total += nq;
+		cl_candidates_total += ncand;
+	}
+	const size_t temp = defer_count ? ((size_t)3 * nq + 16) * sizeof(int) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 	ws_sorttmp.reserve(std::max<size_t>(temp, 16));
 	ws_seg.reserve((size_t)2 * nq * sizeof(int));
 	const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
@@ -492,8 +501,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
 	// (with a selector or fewer than 20 queries FAISS takes its per-pair branch: L2 = sum (x_k - y_k)^2; inner product is the
 	// same chain either way)
-	launch_collect_rescore(metric, stream, sorted, ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
-	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel || nq < 20, st);
+	launch_collect_rescore(metric, stream, sorted, defer_count ? cap_entries : ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
+	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel || nq < 20, st, defer_count ? cnt : nullptr);
 	*pd1_out = pd1;
 	*pi1_out = pi1;
 	cl_sorted = sorted;
@@ -825,6 +834,19 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
                                  const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map,
                                  int64_t out_off, const TieFlags *flp, hipStream_t st) {
+	// First pass: nothing between the scan and the re-scoring waits for the host (the candidate count stays on the device).  If the
+	// count, read after the search's own synchronisation, shows that the stream overflowed, the search runs again the round-3 way:
+	// count read back behind the scan, stream grown or the heavy queries taken out, scan repeated.
+	bool overflow = false;
+	const bool ok = search_prefilter_pass(nq, d_x, k_user, kk, d_D, d_I, params, d_idmap, out_map, out_off, flp, st, cl_defer, &overflow);
+	if (!overflow)
+		return ok;
+	return search_prefilter_pass(nq, d_x, k_user, kk, d_D, d_I, params, d_idmap, out_map, out_off, flp, st, false, &overflow);
+}
+bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
+                                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map,
+                                      int64_t out_off, const TieFlags *flp, hipStream_t st, bool defer, bool *overflow) {
+	*overflow = false;
 	// 128 < d <= 1024: only the coarse filter exists (csrc/flat_collect_wide.hip; no bf16x3 behind it)
 	const bool wide = collect_store_dims(d) > 128;
 	// (16 < d <= 32: the coarse filter only, as for the wide stores)
@@ -862,7 +884,7 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 	// its kernel exists (d = 128 geometry, lists of <= 16); on a stream overflow the bf16x3 path below takes the batch
 	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax) {
 		kp = (int)kk;
-		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st);
+		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer);
 		if (!collected)
 			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 	}
@@ -930,6 +952,17 @@ bool FlatIndex::search_prefilter(int64_t nq, const float *d_x, int64_t k_user, i
 		tie_sorted = nullptr;
 	} else {
 		MVS_HIP(hipStreamSynchronize(st));
+	}
+	if (collected && defer) { // the stream synchronised above: the candidate count of the scan is on the host now
+		unsigned long long ncand_u;
+		memcpy(&ncand_u, h_flag_count + 10, sizeof ncand_u);
+		cl_last_candidates = (int64_t)ncand_u;
+		if ((int64_t)ncand_u > cl_deferred_cap) {
+			*overflow = true; // (the results written so far come from a truncated stream: the synchronous pass overwrites them)
+			return false;
+		}
+		cl_queries_total += nq;
+		cl_candidates_total += (int64_t)ncand_u;
 	}
 	const int nf = h_flag_count[8];
 	pf_last_fallback = nf;
@@ -1894,6 +1927,18 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		return true;
 	}
 #endif
+	if (!strcmp(key, "cl_bound_mode")) { // bf16 rounding term of the coarse filter's bound: actual residual norms (1) | worst case (0)
+		g_cl_bound_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_defer_count")) { // 1 (default): no host round trip for the candidate count between scan and re-scoring
+		cl_defer = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "cl_tab")) { // d <= 128 scan: pass bounds through the global table (1, default) or derived per wave (0: round 3)
+		g_cl_tab = v != 0;
+		return true;
+	}
 	if (!strcmp(key, "cl_nsplit")) { // coarse filter: row splits of the main scan (0 = planned)
 		g_cl_nsplit = (int)v;
 		return true;

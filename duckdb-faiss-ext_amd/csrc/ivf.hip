@@ -613,12 +613,12 @@ public:
 				if (have_bfr) { // the coarse filter's view of the residuals: bf16 rows, beta (L2: -||y'||^2, IP: 0), per-list max
 					codes_bfr.reserve(((size_t)nrows_mf + 192) * 128 * sizeof(unsigned short));
 					beta_mf.reserve(((size_t)nrows_mf + 192) * sizeof(float));
-					list_max.reserve((size_t)nlist * sizeof(unsigned));
+					list_max.reserve((size_t)2 * nlist * sizeof(unsigned)); // [nlist] largest ||y'||^2 | [nlist] largest ||y' - bf16(y')||^2
 					MVS_HIP(hipMemsetAsync(codes_bfr.p, 0, ((size_t)nrows_mf + 192) * 128 * sizeof(unsigned short), stream));
 					MVS_HIP(hipMemsetAsync(beta_mf.p, 0, ((size_t)nrows_mf + 192) * sizeof(float), stream));
-					MVS_HIP(hipMemsetAsync(list_max.p, 0, (size_t)nlist * sizeof(unsigned), stream));
+					MVS_HIP(hipMemsetAsync(list_max.p, 0, (size_t)2 * nlist * sizeof(unsigned), stream));
 					launch_ivf_rows_to_bf16((const float *)tmp.p, nrows_mf, d, (const int *)list_of_blk.p,
-					                        (unsigned short *)codes_bfr.p, (float *)beta_mf.p, (unsigned *)list_max.p, stream);
+					                        (unsigned short *)codes_bfr.p, (float *)beta_mf.p, (unsigned *)list_max.p, nlist, stream);
 					if (!mf_residual) // inner product: s = <x, y'> + <x, c>, no row term
 						MVS_HIP(hipMemsetAsync(beta_mf.p, 0, ((size_t)nrows_mf + 192) * sizeof(float), stream));
 				}
@@ -936,7 +936,7 @@ public:
 				launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
 				                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
 				                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream, shared ? (const int64_t *)ws_cI.p : nullptr, (int)np,
-				                        shared ? (float *)ws_ie2p.p : nullptr);
+				                        shared ? (float *)ws_ie2p.p : nullptr, nlist);
 			}
 			if (phase == 1)
 				begin_kernel_timing(stream);

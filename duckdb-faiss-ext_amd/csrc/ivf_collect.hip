@@ -26,6 +26,7 @@
 #include <cstring>
 
 namespace mvs {
+extern int g_cl_bound_mode; // csrc/flat_collect.hip: bf16 rounding term of the bounds from the actual residual norms (1) | worst case (0)
 
 typedef __bf16 bf16x8i __attribute__((ext_vector_type(8)));
 typedef float f32x4i __attribute__((ext_vector_type(4)));
@@ -71,7 +72,7 @@ __device__ __forceinline__ float ic_dpp(float v) {
 // ---- storage: residual rows [n][d] f32 (padding rows are zero) -> bf16 [n][128] + beta + the largest ||y'||^2 of every list
 __global__ void ivf_rows_to_bf16_kernel(const float *__restrict__ src, long long nrows, int d,
                                         const int *__restrict__ list_of_blk64, unsigned short *__restrict__ dst,
-                                        float *__restrict__ beta, unsigned *__restrict__ list_max_bits) {
+                                        float *__restrict__ beta, unsigned *__restrict__ list_max_bits, int nlist) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // one (row, 8 dims); 16 neighbours share a row
 	const bool live = i < nrows * 16;
 	const long long r = live ? i >> 4 : 0;
@@ -91,15 +92,18 @@ __global__ void ivf_rows_to_bf16_kernel(const float *__restrict__ src, long long
 			if (c8 * 8 + e < d)
 				v8[e] = src[(size_t)r * d + c8 * 8 + e];
 	}
+	float r2 = 0.f; // ||y' - bf16(y')||^2: the row's actual rounding residual (csrc/flat_collect.hip, "ROUND 4")
 #pragma unroll
 	for (int e = 0; e < 8; ++e) {
 		hi[e] = (__bf16)v8[e];
+		const float dl = v8[e] - (float)hi[e];
 		n2 = fmaf(v8[e], v8[e], n2);
+		r2 = fmaf(dl, dl, r2);
 	}
-	n2 += ic_dpp<0xB1>(n2);
-	n2 += ic_dpp<0x4E>(n2);
-	n2 += ic_dpp<0x141>(n2);
-	n2 += ic_dpp<0x140>(n2);
+	n2 += ic_dpp<0xB1>(n2), r2 += ic_dpp<0xB1>(r2);
+	n2 += ic_dpp<0x4E>(n2), r2 += ic_dpp<0x4E>(r2);
+	n2 += ic_dpp<0x141>(n2), r2 += ic_dpp<0x141>(r2);
+	n2 += ic_dpp<0x140>(n2), r2 += ic_dpp<0x140>(r2);
 	if (!live)
 		return;
 	*(bf16x8i *)(dst + (size_t)r * 128 + c8 * 8) = hi;
@@ -109,15 +113,18 @@ __global__ void ivf_rows_to_bf16_kernel(const float *__restrict__ src, long long
 		const unsigned b = __float_as_uint(n2); // (>= 0 or NaN: the bit pattern orders like the value)
 		if (b > *m)
 			atomicMax(m, b);
+		const unsigned br = __float_as_uint(r2);
+		if (br > m[nlist])
+			atomicMax(m + nlist, br);
 	}
 }
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
-                             float *d_beta, unsigned *d_list_max_bits, hipStream_t st) {
+                             float *d_beta, unsigned *d_list_max_bits, int64_t nlist, hipStream_t st) {
 	if (nrows <= 0)
 		return;
 	const long long total = (long long)nrows * 16;
 	hipLaunchKernelGGL(ivf_rows_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_res,
-	                   (long long)nrows, d, d_list_of_blk64, d_bf, d_beta, d_list_max_bits);
+	                   (long long)nrows, d, d_list_of_blk64, d_bf, d_beta, d_list_max_bits, (int)nlist);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -142,7 +149,8 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
                                                              const unsigned *__restrict__ list_max_bits,
                                                              bf16x8i *__restrict__ xi, float *__restrict__ igamma,
                                                              float *__restrict__ ie2, int *__restrict__ qfail,
-                                                             const long long *__restrict__ coarse, int np, float *__restrict__ ie2_pre) {
+                                                             const long long *__restrict__ coarse, int np, float *__restrict__ ie2_pre,
+                                                             int nlist, int bound_mode) {
 	if ((int)blockIdx.x >= *nitems_dev)
 		return;
 	const int4 it = items[blockIdx.x];
@@ -191,28 +199,37 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		float g = 0.f, e2 = __uint_as_float(0x7fc00000u);
 		if (slot < it.w) {
 			const int q = qidx[it.z + slot];
-			float xn = 0.f, cn = 0.f, xc = 0.f; // ||x'||^2 (L2) or ||x||^2 (IP); ||c||^2; <x, c>
+			float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f; // ||x'||^2 (L2) or ||x||^2 (IP); ||c||^2; <x, c>; ||a - bf16(a)||^2 of the operand a
 			for (int kk = 0; kk < d; ++kk) {
 				const float xv = xs[slot * xp + kk];
 				const float r = IS_L2 ? __fsub_rn(xv, c[kk]) : xv;
 				xn = fmaf(r, r, xn);
 				cn = fmaf(c[kk], c[kk], cn);
 				xc = fmaf(xv, c[kk], xc);
+				const float a = IS_L2 ? 2.0f * r : r; // exactly what the loop above rounded to bf16
+				const float dl = a - (float)(__bf16)a;
+				dq2 = fmaf(dl, dl, dq2);
 			}
 			g = IS_L2 ? -xn : xc;
-			const float yn = __uint_as_float(list_max_bits[l]);
+			const float yn = __uint_as_float(list_max_bits[l]), dyn = __uint_as_float(list_max_bits[nlist + l]);
 			const double u = 5.9604644775390625e-08, infl = 1.0001;
 			const double nx = sqrt((double)xn * infl), ny = sqrt((double)yn * infl), nc = sqrt((double)cn * infl), S = nx * ny;
+			// bf16 rounding of both operands: the worst case per element, or (round 4, csrc/flat_collect.hip collect_bounds_kernel) from
+			// the ACTUAL residual norms: |<a, y'> - <bf(a), bf(y')>| <= ||a - bf(a)|| ||y'||_max + (||a|| + ||a - bf(a)||) ||y' - bf(y')||_max
+			const double al = IS_L2 ? 2.0 : 1.0;
+			const double ndq = sqrt((double)dq2 * infl), ndy = sqrt((double)dyn * infl);
+			const double rnd_worst = al * (0.0078125 + 1.52587890625e-05) * S, rnd_actual = ndq * ny + (al * nx + ndq) * ndy;
+			const double rnd = bound_mode == 0 ? rnd_worst : (rnd_actual < rnd_worst || !(rnd_actual == rnd_actual) ? rnd_actual : rnd_worst);
 			double E;
 			if (IS_L2)
-				E = 2.0 * (0.0078125 + 1.52587890625e-05) * S +
+				E = rnd +
 				    1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * 2.0 * S + (double)xn + yn) +
 				    ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
 			else
-				E = (0.0078125 + 1.52587890625e-05) * S + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * S + nx * nc) +
+				E = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * S + nx * nc) +
 				    (double)d * u * nx * nc + u * S + ((double)d + 2.0) * u * nx * (nc + ny);
 			const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn + nx * nc) + 1e-30);
-			if (isfinite(xn) && isfinite(yn) && isfinite(r) && r < 1e30f)
+			if (isfinite(xn) && isfinite(yn) && isfinite(dq2) && isfinite(dyn) && isfinite(r) && r < 1e30f)
 				e2 = r;
 			else
 				qfail[q] = 1;
@@ -233,7 +250,7 @@ size_t ivf_collect_xi_bytes(int max_items) {
 void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
                              float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse, int np,
-                             float *d_ie2_pre) {
+                             float *d_ie2_pre, int64_t nlist) {
 	if (max_items <= 0)
 		return;
 	const size_t lds = ((size_t)128 * (d + 1) + d) * sizeof(float); // 66.5 KB at d = 128: two workgroups per CU
@@ -242,13 +259,13 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
 		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
-		                   d_ie2_pre);
+		                   d_ie2_pre, (int)nlist, g_cl_bound_mode);
 	} else {
 		auto kern = ivf_collect_pack_kernel<false>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
 		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
-		                   d_ie2_pre);
+		                   d_ie2_pre, (int)nlist, g_cl_bound_mode);
 	}
 	MVS_HIP(hipGetLastError());
 }

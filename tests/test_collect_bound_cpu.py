@@ -24,8 +24,9 @@ def mfma_chain(a, b, c0, group=32):
     return float(acc)
 
 
-def flat_bound(metric_l2, x, mu, yn_max, ync_max, d):
-    """2E of collect_bounds_kernel (same terms, same order)"""
+def flat_bound(metric_l2, x, mu, yn_max, ync_max, d, dyc_max=None):
+    """2E of collect_bounds_kernel (same terms, same order).  dyc_max = the largest ||y' - bf16(y')||^2 of the store: the bf16
+    rounding term from the ACTUAL residual norms (round 4, cl_bound_mode = 1); None: the worst case 2^-8 per element (mode 0)"""
     xn = float((x.astype(np.float64) ** 2).sum())
     xc = (x - mu).astype(np.float32)
     xnc = float((xc.astype(np.float64) ** 2).sum())
@@ -36,7 +37,13 @@ def flat_bound(metric_l2, x, mu, yn_max, ync_max, d):
     MY = np.sqrt(mun * infl) * np.sqrt(yn_max * infl)
     al = 2.0 if metric_l2 else 1.0
     bmax = ync_max if metric_l2 else MY
-    es = al * (2.0**-7 + 2.0**-16) * Sc + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * al * Sc + bmax)
+    rnd = al * (2.0**-7 + 2.0**-16) * Sc
+    if dyc_max is not None:
+        a = np.float32(al) * xc
+        dq2 = float(((a - bf16(a)).astype(np.float64) ** 2).sum())
+        ndq, ndy = np.sqrt(dq2 * infl), np.sqrt(dyc_max * infl)
+        rnd = min(rnd, ndq * np.sqrt(ync_max * infl) + (al * np.sqrt(xnc * infl) + ndq) * ndy)
+    es = rnd + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * al * Sc + bmax)
     if metric_l2:
         E = es + 4 * U * (xnc + ync_max) + d * U * ync_max + 2 * d * U * S + 4 * U * (xn + yn_max) + 2 * (d + 8) * U * (xn + yn_max)
     else:
@@ -44,9 +51,10 @@ def flat_bound(metric_l2, x, mu, yn_max, ync_max, d):
     return 2.0 * E * (1.0 + 2.0**-10) + 8.0 * U * (Sc + MY + xnc + ync_max) + 1e-30
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("metric_l2", [True, False])
 @pytest.mark.parametrize("kind", ["uniform", "offset", "scaled", "tiny", "signed"])
-def test_flat_bound_covers_the_emulated_coarse_value(metric_l2, kind):
+def test_flat_bound_covers_the_emulated_coarse_value(metric_l2, kind, mode):
     seed = {"uniform": 1, "offset": 2, "scaled": 3, "tiny": 4, "signed": 5}[kind] * 2 + int(metric_l2)
     rs = np.random.RandomState(seed)
     d, n, nq = 128, 400, 10
@@ -57,10 +65,13 @@ def test_flat_bound_covers_the_emulated_coarse_value(metric_l2, kind):
     yc = (xb - mu).astype(np.float32)  # what the store holds before the bf16 rounding
     yn_max = float((xb.astype(np.float64) ** 2).sum(1).max())
     ync = (yc.astype(np.float64) ** 2).sum(1)
+    dyc_max = float((((yc - bf16(yc)).astype(np.float64)) ** 2).sum(1).max()) if mode == 1 else None
     worst = 0.0
+    ratio = []
     for q in range(nq):
         x = xq[q]
-        E = flat_bound(metric_l2, x, mu, yn_max, float(ync.max()), d) / 2.0
+        E = flat_bound(metric_l2, x, mu, yn_max, float(ync.max()), d, dyc_max) / 2.0
+        ratio.append(E / (flat_bound(metric_l2, x, mu, yn_max, float(ync.max()), d) / 2.0))
         xc = (x - mu).astype(np.float32)
         bx = bf16(np.float32(2.0 if metric_l2 else 1.0) * xc)  # alpha rides in the query operand (exact scaling)
         for r in range(0, n, 5):
@@ -74,6 +85,8 @@ def test_flat_bound_covers_the_emulated_coarse_value(metric_l2, kind):
             worst = max(worst, abs(s - s_exact) / E)
     assert worst < 0.9, worst  # below E with room: the Cauchy-Schwarz bf16 term dominates and is rarely tight
     assert worst > 1e-4  # ... and the rounding is exercised (not a vacuous check)
+    if mode == 1:  # the residual norms of random data sit near 0.4 x 2^-8 of the operand norms: E shrinks ~2x or more
+        assert max(ratio) <= 1.0 + 1e-12 and np.mean(ratio) < 0.6, ratio
 
 
 @pytest.mark.parametrize("metric_l2", [True, False])
@@ -87,9 +100,11 @@ def test_flat_bound_holds_at_bf16_rounding_ties(metric_l2):
     assert not mu.any()
     yn_max = float((xb.astype(np.float64) ** 2).sum(1).max())
     worst = 0.0
+    dyc_max = float((((xb - bf16(xb)).astype(np.float64)) ** 2).sum(1).max())  # every residual at its worst: 2^-8 |y_i|
     for sign in (1.0, -1.0):
         x = np.full(d, sign * t, dtype=np.float32)
-        E = flat_bound(metric_l2, x, mu, yn_max, yn_max, d) / 2.0
+        E = flat_bound(metric_l2, x, mu, yn_max, yn_max, d, dyc_max) / 2.0
+        assert E <= flat_bound(metric_l2, x, mu, yn_max, yn_max, d) / 2.0 * (1 + 1e-9)
         bx = bf16(np.float32(2.0 if metric_l2 else 1.0) * x)
         for r in (0, 8):
             by = bf16(xb[r])
@@ -103,17 +118,63 @@ def test_flat_bound_holds_at_bf16_rounding_ties(metric_l2):
     assert 0.9 < worst <= 1.0, worst  # tight (the bound is attained up to its small terms) and not exceeded
 
 
-def ivf_bound(metric_l2, xn, yn, cn, d):
+def ivf_bound(metric_l2, xn, yn, cn, d, dq2=None, dyn=None):
     """E of ivf_collect_pack_kernel (csrc/ivf_collect.hip): xn = ||x - c||^2 (L2) or ||x||^2 (IP), yn = the list's largest
-    ||y - c||^2, cn = ||c||^2"""
+    ||y - c||^2, cn = ||c||^2; dq2 = ||a - bf16(a)||^2 of the query operand a, dyn = the list's largest ||y' - bf16(y')||^2
+    (round 4: the rounding term from the actual residual norms; None = the worst case per element)"""
     infl = 1.0001
     nx, ny, nc = np.sqrt(xn * infl), np.sqrt(yn * infl), np.sqrt(cn * infl)
     S = nx * ny
+    al = 2.0 if metric_l2 else 1.0
+    rnd = al * (2.0**-7 + 2.0**-16) * S
+    if dq2 is not None:
+        ndq, ndy = np.sqrt(dq2 * infl), np.sqrt(dyn * infl)
+        rnd = min(rnd, ndq * ny + (al * nx + ndq) * ndy)
     if metric_l2:
-        return (2.0 * (2.0**-7 + 2.0**-16) * S + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * 2.0 * S + xn + yn)
+        return (rnd + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * 2.0 * S + xn + yn)
                 + (d + 1.0) * U * (xn + yn) + (d + 8.0) * U * (nx + ny) ** 2)
-    return ((2.0**-7 + 2.0**-16) * S + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * S + nx * nc)
+    return (rnd + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * S + nx * nc)
             + d * U * nx * nc + U * S + (d + 2.0) * U * nx * (nc + ny))
+
+
+@pytest.mark.parametrize("metric_l2", [True, False])
+def test_ivf_bound_from_residual_norms_covers_random_lists(metric_l2):
+    """a list of residual rows around c and queries near it: the emulated coarse value stays inside the residual-norm bound,
+    which is well below the worst-case one"""
+    rs = np.random.RandomState(11 + int(metric_l2))
+    d, n = 128, 300
+    c = (rs.rand(d) * 4).astype(np.float32)
+    rows = (c + rs.randn(n, d) * 0.3).astype(np.float32)
+    yres = (rows - c).astype(np.float32)  # what the store rounds to bf16
+    yn = float((yres.astype(np.float64) ** 2).sum(1).max())
+    dyn = float(((yres - bf16(yres)).astype(np.float64) ** 2).sum(1).max())
+    cn = float((c.astype(np.float64) ** 2).sum())
+    worst, ratios = 0.0, []
+    for q in range(8):
+        x = (c + rs.randn(d) * 0.3).astype(np.float32)
+        if metric_l2:
+            xr = (x - c).astype(np.float32)
+            a = np.float32(2.0) * xr
+            xn = float((xr.astype(np.float64) ** 2).sum())
+        else:
+            a = x
+            xn = float((x.astype(np.float64) ** 2).sum())
+        dq2 = float(((a - bf16(a)).astype(np.float64) ** 2).sum())
+        E = ivf_bound(metric_l2, xn, yn, cn, d, dq2, dyn)
+        ratios.append(E / ivf_bound(metric_l2, xn, yn, cn, d))
+        for r in range(0, n, 7):
+            by = bf16(yres[r])
+            if metric_l2:
+                b0 = np.float32(-float((yres[r].astype(np.float64) ** 2).sum()))
+                g0 = np.float32(-xn)
+                s = mfma_chain(bf16(a), by, np.float32(b0 + g0))
+                s_exact = -float(((x.astype(np.float64) - rows[r]) ** 2).sum())
+            else:
+                s = mfma_chain(bf16(a), by, np.float32((x.astype(np.float64) * c).sum()))
+                s_exact = float((x.astype(np.float64) * rows[r]).sum())
+            worst = max(worst, abs(s - s_exact) / E)
+    assert 1e-4 < worst < 0.9, worst
+    assert max(ratios) <= 1.0 + 1e-12 and np.mean(ratios) < 0.7, ratios
 
 
 @pytest.mark.parametrize("metric_l2", [True, False])

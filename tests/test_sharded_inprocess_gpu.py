@@ -71,11 +71,11 @@ def test_large_k_on_eight_shards_takes_the_host_merge(mf, metric):
     o.add(xb)
     sh = one.clone_to_gpu(0)
     sh.shard_to_gpus([0] * 8)
-    for k in (2048, 1500, 5000):
+    for k in (2048, 1500, 3000):
         ref = one.search(xq, k)
-        _same(sh.search(xq, k), ref, f"sharded k={k} vs unsharded")
         if k == 2048:
             _same(ref, o.search(xq, k), "unsharded vs oracle")
+        _same(sh.search(xq, k), ref, f"sharded k={k} vs unsharded")
     # the one-process-per-GPU host reaches the same merge through mvs_merge_records_device
     import torch
 

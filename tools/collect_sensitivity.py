@@ -55,6 +55,8 @@ print(f"# coarse-filter data sensitivity: Flat{os.environ.get('METRIC', 'L2')} d
 print(f"{'data':<11} {'ms/batch':>9} {'QPS':>9} {'cand/query':>11} {'overflows':>9} {'exact re-runs':>13} {'kernel':<28} bit-exact vs f32 kernel (512 q)")
 for kind in os.environ.get("KINDS", "uniform clustered normalised offset integer dup10 sift_like all_dup").split():
     ix = mf.index_factory(d, "Flat", metric)
+    for o in os.environ.get("OPTS", "").split():  # e.g. OPTS="cl_bound_mode=0"
+        ix.set_option(o.split("=")[0], int(o.split("=")[1]))
     for s0 in range(0, n, 1 << 20):
         ix.add_torch(rows(kind, min(1 << 20, n - s0), 1234, s0)); torch.cuda.synchronize()
     xq = rows(kind, nq, 4321, 0).contiguous()

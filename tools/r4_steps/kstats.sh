@@ -1,0 +1,15 @@
+#!/bin/bash
+# per-kernel times of one bench shape under rocprofv3 --kernel-trace --stats: ROWS=1250000 OPT="cl_defer_count=0" TAG=x
+O=$1
+extra=""; [ -n "${OPT:-}" ] && extra="--opt ${OPT//,/ --opt }"
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf $O/trace_${TAG}
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_${TAG} -- python3 bench.py --rows ${ROWS:-1250000} --no-cpu-baseline --no-configs --no-host-pointer --steps 10 --warmup 2 $extra ${ARGS:-} > $O/kstats_${TAG}.json 2> $O/kstats_${TAG}.err
+f=$(find $O/trace_${TAG} -name "*kernel_stats.csv" | head -1)
+python3 - "$f" <<'PY' | tee $O/kstats_${TAG}.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:22]:
+    print("%-70s calls %5s avg_us %10.1f total_ms %9.3f" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+rm -rf $O/trace_${TAG}
