@@ -193,6 +193,11 @@ void launch_gather_flagged(const float *d_x, int d, const TieFlags &f, int nf, i
 void launch_tie_resolve(const TieFlags &f, int nf, int64_t k, int64_t kout, const int64_t *d_first_ids /*[nf][kout]*/,
                         const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
 
+// inner product, k >= 100, exact tie at the k-th score: FAISS's ReservoirTopN outcome for the flagged queries (csrc/flat_reservoir.hip)
+int64_t reservoir_replay_max_k();
+void launch_reservoir_replay(const float *d_xf, int nf, int d, const float *d_vecs, int dp, int interleaved, int64_t n, int64_t k,
+                             SelectorDev sel, const int64_t *d_idmap, const float *d_T, float *d_scores, float *d_out_v,
+                             int32_t *d_out_r, hipStream_t st);
 void launch_merge_records(int metric, const int64_t *d_rec, int nshard, int64_t nq, int kk, int kout, bool raw, float *d_D,
                           int64_t *d_I, hipStream_t st);
 // host twin (csrc/merge_host.hip) for nshard * kk beyond a workgroup's LDS; rec on the host

@@ -1195,11 +1195,13 @@ int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int
 // ---- candidates -> exact values ----------------------------------------------------------------------------------------
 // segment of every query in the stream sorted by query
 __global__ void collect_segments_kernel(const unsigned long long *__restrict__ sorted, long long n, int *__restrict__ seg_b,
-                                        int *__restrict__ seg_e) {
+                                        int *__restrict__ seg_e, unsigned nq) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
 	const unsigned q = (unsigned)(sorted[i] >> 32);
+	if (q >= nq) // (the sentinel tail of launch_collect_group_est)
+		return;
 	if (i == 0 || (unsigned)(sorted[i - 1] >> 32) != q)
 		seg_b[q] = (int)i;
 	if (i == n - 1 || (unsigned)(sorted[i + 1] >> 32) != q)
@@ -1388,65 +1390,45 @@ __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long 
 }
 
 // ---- candidates grouped by query WITHOUT the host knowing how many there are (round 4) ------------------------------------------
-// Round 3 read the stream's fill back to the host (a stream synchronisation in the middle of every search: the GPU idles for the
-// round trip, then for the launch latency of each of the ten small kernels behind it) because rocPRIM's radix sort and the
-// re-scoring grid want the count as a host value.  A counting sort by query needs neither: histogram -> prefix sums -> scatter,
-// all reading min(*cnt, cap) on the device; the order INSIDE a query's segment is whatever the atomics give (the selection
-// ranks (value, row) keys, the tie pass reads a segment as a set: neither depends on it).
-__global__ void collect_hist_kernel(const unsigned long long *__restrict__ stream, const unsigned long long *__restrict__ cnt,
-                                    long long cap, int *__restrict__ qcount) {
+// Round 3 read the stream's fill back to the host behind the scan (a stream synchronisation in the middle of every search: the GPU
+// idles for the round trip, then for the launch latency of each of the ten small kernels behind it) because rocPRIM's radix sort
+// and the re-scoring grid want the count as a host value.  Now the host passes an ESTIMATE n_est (what the index's previous search
+// produced per query, + 30 %): the tail [min(*cnt, n_est), n_est) is filled with sentinel keys that sort behind every query, the
+// sort runs over n_est entries, the kernels behind it read min(*cnt, cap) on the device.  If the estimate was too small the
+// caller finds out from the count after ITS synchronisation and runs the search again the synchronous way.
+// (A counting sort by query -- histogram, prefix sums, scatter, all on the device count -- needs no estimate but took 120 us for
+// 1.4 M candidates against the radix sort's 65: one global atomic per entry on 10 000 counters, twice.)
+__global__ void collect_fill_tail_kernel(unsigned long long *__restrict__ stream, const unsigned long long *__restrict__ cnt,
+                                         long long n_est) {
 	const unsigned long long have = *cnt;
-	const long long n = have < (unsigned long long)cap ? (long long)have : cap;
-	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-		atomicAdd(&qcount[(unsigned)(stream[i] >> 32)], 1);
+	const long long b = have < (unsigned long long)n_est ? (long long)have : n_est;
+	for (long long i = b + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_est; i += (long long)gridDim.x * blockDim.x)
+		stream[i] = ~0ull;
 }
-// one workgroup: seg_b / seg_e of every query from the counts; cursor = seg_b
-__global__ __launch_bounds__(1024) void collect_offsets_kernel(const int *__restrict__ qcount, int nq, int *__restrict__ seg_b,
-                                                              int *__restrict__ seg_e, int *__restrict__ cursor) {
-	__shared__ int part[1024];
-	const int tid = threadIdx.x;
-	const int per = (nq + 1023) / 1024;
-	const int q0 = tid * per, q1 = q0 + per < nq ? q0 + per : nq;
-	int sum = 0;
-	for (int q = q0; q < q1; ++q)
-		sum += qcount[q];
-	part[tid] = sum;
-	__syncthreads();
-	for (int off = 1; off < 1024; off <<= 1) { // inclusive scan
-		const int v = tid >= off ? part[tid - off] : 0;
-		__syncthreads();
-		part[tid] += v;
-		__syncthreads();
-	}
-	int run = part[tid] - sum;
-	for (int q = q0; q < q1; ++q) {
-		const int c = qcount[q];
-		seg_b[q] = run;
-		cursor[q] = run;
-		run += c;
-		seg_e[q] = run;
-	}
+static int collect_qbits(int64_t nq) { // sort key: the query number and one bit more, so that the all-ones sentinel is no query
+	int qbits = 1;
+	while (((int64_t)1 << qbits) < nq)
+		++qbits;
+	return qbits + 1;
 }
-__global__ void collect_scatter_kernel(const unsigned long long *__restrict__ stream, const unsigned long long *__restrict__ cnt,
-                                       long long cap, int *__restrict__ cursor, unsigned long long *__restrict__ sorted) {
-	const unsigned long long have = *cnt;
-	const long long n = have < (unsigned long long)cap ? (long long)have : cap;
-	for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-		const unsigned long long ent = stream[i];
-		sorted[atomicAdd(&cursor[(unsigned)(ent >> 32)], 1)] = ent;
-	}
+size_t collect_sort_temp_bytes_est(int64_t n_est, int64_t nq) {
+	size_t bytes = 0;
+	MVS_HIP(rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n_est, 32,
+	                                 32 + collect_qbits(nq), (hipStream_t) nullptr));
+	return bytes;
 }
-// d_work: [3 nq + 16] ints (counts | cursor; zeroed here), d_seg: [2 nq]
-void launch_collect_group_dev(const unsigned long long *d_stream, unsigned long long *d_sorted, const unsigned long long *d_cnt,
-                              int64_t cap, int64_t nq, int *d_seg, int *d_work, hipStream_t st) {
+void launch_collect_group_est(unsigned long long *d_stream, unsigned long long *d_sorted, const unsigned long long *d_cnt,
+                              int64_t n_est, void *d_temp, size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st) {
 	if (nq <= 0)
 		return;
-	int *qcount = d_work, *cursor = d_work + nq;
-	MVS_HIP(hipMemsetAsync(qcount, 0, (size_t)nq * sizeof(int), st));
-	const unsigned grid = (unsigned)std::min<int64_t>((cap + 255) / 256, 2048);
-	hipLaunchKernelGGL(collect_hist_kernel, dim3(grid), dim3(256), 0, st, d_stream, d_cnt, (long long)cap, qcount);
-	hipLaunchKernelGGL(collect_offsets_kernel, dim3(1), dim3(1024), 0, st, (const int *)qcount, (int)nq, d_seg, d_seg + nq, cursor);
-	hipLaunchKernelGGL(collect_scatter_kernel, dim3(grid), dim3(256), 0, st, d_stream, d_cnt, (long long)cap, cursor, d_sorted);
+	MVS_HIP(hipMemsetAsync(d_seg, 0, (size_t)2 * nq * sizeof(int), st));
+	if (n_est <= 0)
+		return;
+	hipLaunchKernelGGL(collect_fill_tail_kernel, dim3((unsigned)std::min<int64_t>((n_est + 255) / 256, 1024)), dim3(256), 0, st, d_stream,
+	                   d_cnt, (long long)n_est);
+	MVS_HIP(rocprim::radix_sort_keys(d_temp, temp_bytes, d_stream, d_sorted, (size_t)n_est, 32, 32 + collect_qbits(nq), st));
+	hipLaunchKernelGGL(collect_segments_kernel, dim3((unsigned)((n_est + 255) / 256)), dim3(256), 0, st, d_sorted, (long long)n_est,
+	                   d_seg, d_seg + nq, (unsigned)nq);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -1472,7 +1454,7 @@ void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_so
 	if (ncand > 0) {
 		MVS_HIP(rocprim::radix_sort_keys(d_temp, temp_bytes, d_stream, d_sorted, (size_t)ncand, 32, 32 + qbits, st));
 		hipLaunchKernelGGL(collect_segments_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, d_sorted,
-		                   (long long)ncand, d_seg, d_seg + nq);
+		                   (long long)ncand, d_seg, d_seg + nq, (unsigned)nq);
 		MVS_HIP(hipGetLastError());
 	}
 }
@@ -1531,8 +1513,8 @@ void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_se
 }
 
 // stream (ncand entries) -> per query the kk best exact candidates: pd1 / pi1 [nq][kk] (value, row), best first
-// d_cnt != null: device-count mode -- ncand is the stream's CAPACITY, the number of entries is min(*d_cnt, ncand) on the device,
-// d_temp holds [3 nq + 16] ints (launch_collect_group_dev) instead of the radix sort's temporary storage
+// d_cnt != null: device-count mode -- ncand is the host's ESTIMATE of the number of entries (<= the stream's capacity; the sort
+// covers that many, sentinels behind the real ones), the real number is min(*d_cnt, ncand) on the device
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
@@ -1540,7 +1522,7 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
 	if (nq <= 0)
 		return;
 	if (d_cnt)
-		launch_collect_group_dev(d_stream, d_sorted, d_cnt, ncand, nq, d_seg, (int *)d_temp, st);
+		launch_collect_group_est(d_stream, d_sorted, d_cnt, ncand, d_temp, temp_bytes, nq, d_seg, st);
 	else
 		launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st);
 	if (ncand > 0 && collect_store_dims(g.d) > 128) {

@@ -198,6 +198,7 @@ public:
 	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, bool defer_count = false);
 	int64_t cl_deferred_cap = 0;
 	bool cl_defer = true; // option cl_defer_count
+	double cl_est_per_query = 0; // candidates per query of the last search (+ 30 %): the size the next search's sort is launched with
 	void drop_bf16_rows();
 	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
 	                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
@@ -342,6 +343,9 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
                          unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
                          hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out);
 size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq);
+size_t collect_sort_temp_bytes_est(int64_t n_est, int64_t nq);
+void launch_collect_group_est(unsigned long long *d_stream, unsigned long long *d_sorted, const unsigned long long *d_cnt,
+                              int64_t n_est, void *d_temp, size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
@@ -375,7 +379,7 @@ size_t ivf_rowmask_bytes(int64_t nrows_mf);
 void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
                         void *d_mask, hipStream_t st);
 void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
-                              int dp_csr, const int *d_perm, hipStream_t st);
+                              int dp_csr, const int *d_perm, hipStream_t st, const unsigned long long *d_cnt = nullptr);
 void launch_collect_flat_items(void *d_items, int *d_nitems, int *d_qidx, int64_t nq, int64_t n, hipStream_t st);
 void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st);
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);

@@ -444,10 +444,12 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-	if (defer_count) { // the caller looks at the count after its own synchronisation
-		cl_deferred_cap = cap_entries;
+	if (defer_count && cl_est_per_query > 0) { // the caller looks at the count after its own synchronisation
+		// (size of the sort: what the previous search of this index produced per query, + 30 %, in units of 64 K entries)
+		cl_deferred_cap = std::min<int64_t>(cap_entries, ((int64_t)(cl_est_per_query * (double)nq) + 65535) / 65536 * 65536);
 		break;
 	}
+	defer_count = false; // (the first search of an index has no estimate yet: the synchronous way, which leaves one)
 	MVS_HIP(hipStreamSynchronize(st));
 	unsigned long long ncand_u;
 	memcpy(&ncand_u, h_flag_count + 10, sizeof ncand_u);
@@ -491,8 +493,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	if (!defer_count) {
 		cl_queries_total += nq;
 		cl_candidates_total += ncand;
+		cl_est_per_query = 1.3 * (double)ncand / (double)std::max<int64_t>(nq, 1) + 64.0;
+		cl_deferred_cap = 0; // (tells the caller that this pass was synchronous)
 	}
-	const size_t temp = defer_count ? ((size_t)3 * nq + 16) * sizeof(int) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
+	const size_t temp = defer_count ? collect_sort_temp_bytes_est(cl_deferred_cap, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 	ws_sorttmp.reserve(std::max<size_t>(temp, 16));
 	ws_seg.reserve((size_t)2 * nq * sizeof(int));
 	const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
@@ -501,7 +505,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
 	// (with a selector or fewer than 20 queries FAISS takes its per-pair branch: L2 = sum (x_k - y_k)^2; inner product is the
 	// same chain either way)
-	launch_collect_rescore(metric, stream, sorted, defer_count ? cap_entries : ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
+	launch_collect_rescore(metric, stream, sorted, defer_count ? cl_deferred_cap : ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
 	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel || nq < 20, st, defer_count ? cnt : nullptr);
 	*pd1_out = pd1;
 	*pi1_out = pi1;
@@ -685,7 +689,9 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	// it merges across splits -- with ONE extra entry per list; the merge flags the queries whose k-th and (k+1)-th
 	// scores are bit-equal and resolve_ip_ties() replays the heap's outcome for those (usually none).
 	const int64_t k_user = k;
-	const bool tie_detect = metric == METRIC_IP && ip_exact_ties && !raw_rows && ntotal > k && k + 1 <= mfma_kmax;
+	// (k >= 100: FAISS's reservoir instead of its heap -- resolve_ip_ties replays that; any kernel may serve the k + 1 search)
+	const bool tie_detect = metric == METRIC_IP && ip_exact_ties && !raw_rows && ntotal > k &&
+	                        (k + 1 <= mfma_kmax || (k >= 100 && k + 1 <= std::min(flat_direct_max_k(), reservoir_replay_max_k())));
 	const int64_t *out_map = raw_rows ? nullptr : d_idmap; // label translation of the merge
 	const int64_t out_off = raw_rows ? 0 : label_offset;
 	if (tie_detect)
@@ -953,12 +959,13 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	} else {
 		MVS_HIP(hipStreamSynchronize(st));
 	}
-	if (collected && defer) { // the stream synchronised above: the candidate count of the scan is on the host now
+	if (collected && defer && cl_deferred_cap > 0) { // the stream synchronised above: the candidate count of the scan is on the host now
 		unsigned long long ncand_u;
 		memcpy(&ncand_u, h_flag_count + 10, sizeof ncand_u);
 		cl_last_candidates = (int64_t)ncand_u;
+		cl_est_per_query = 1.3 * (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 64.0;
 		if ((int64_t)ncand_u > cl_deferred_cap) {
-			*overflow = true; // (the results written so far come from a truncated stream: the synchronous pass overwrites them)
+			*overflow = true; // (more entries than the sort covered: the synchronous pass overwrites the results written so far)
 			return false;
 		}
 		cl_queries_total += nq;
@@ -1012,6 +1019,28 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 	if (nf <= 0)
 		return;
 	const int64_t kraw = kraw_in > 0 ? kraw_in : k + 1; // length of the raw candidate lists the merge recorded
+	if (k >= 100) {
+		// FAISS collects k >= 100 results in a ReservoirTopN, not a heap (utils/distances.cpp): which of the rows tied at the k-th
+		// score survive depends on the whole stream -- replayed for the flagged queries (csrc/flat_reservoir.hip)
+		const size_t xf_b = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255, t_b = ((size_t)nf * sizeof(float) + 255) & ~(size_t)255;
+		const size_t ov_b = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255, oi_b = ((size_t)nf * k * sizeof(int64_t) + 255) & ~(size_t)255;
+		const int64_t F = std::max<int64_t>(1, std::min<int64_t>(nf, ((int64_t)1 << 30) / std::max<int64_t>(ntotal * 4, 1)));
+		ws_tie.reserve(xf_b + t_b + 2 * ov_b + 2 * oi_b + (size_t)F * ntotal * sizeof(float) + 256);
+		char *b = (char *)ws_tie.p;
+		float *xf = (float *)b, *T = (float *)(b + xf_b), *ov = (float *)(b + xf_b + t_b), *Df = (float *)(b + xf_b + t_b + ov_b);
+		int32_t *oi = (int32_t *)(b + xf_b + t_b + 2 * ov_b);
+		int64_t *If = (int64_t *)(b + xf_b + t_b + 2 * ov_b + oi_b);
+		float *scores = (float *)(b + xf_b + t_b + 2 * ov_b + 2 * oi_b);
+		launch_gather_flagged(d_x, d, fl, nf, kraw, k, xf, T, st);
+		for (int64_t f0 = 0; f0 < nf; f0 += F) {
+			const int m = (int)std::min<int64_t>(F, nf - f0);
+			launch_reservoir_replay(xf + f0 * d, m, d, vecs, geom.dp, geom.pair_interleaved ? 1 : 0, ntotal, k, sel, d_idmap, T + f0, scores,
+			                        ov + f0 * k, oi + f0 * k, st);
+		}
+		launch_merge_partials(METRIC_IP, ov, oi, 1, nf, k, d_idmap, label_offset, Df, If, st); // print order, labels
+		launch_scatter_rows(fl.query, nf, k, Df, If, d_D, d_I, st);
+		return;
+	}
 	const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
 	const size_t t_bytes = ((size_t)nf * sizeof(float) + 255) & ~(size_t)255;
 	const size_t td_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;

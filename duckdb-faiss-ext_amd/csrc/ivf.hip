@@ -872,6 +872,20 @@ public:
 	// bf16 coarse filter (csrc/ivf_collect.hip).  false: the candidate stream overflowed (the caller uses the scanner kernel).
 	bool collect_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                    const int64_t *d_idmap, hipStream_t st, int64_t np) {
+		// First without a host round trip behind the scan (the candidate count stays on the device, the sort is sized from the
+		// previous search of this index: csrc/flat_collect.hip launch_collect_group_est); if the count, read at the end, exceeds
+		// that size the search runs again the synchronous way.
+		if (cl_defer && cl_est_per_query > 0) {
+			bool overflow = false;
+			const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, true, &overflow);
+			if (!overflow)
+				return ok;
+		}
+		bool overflow = false;
+		return collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, false, &overflow);
+	}
+	bool collect_search_pass(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                         const int64_t *d_idmap, hipStream_t st, int64_t np, bool defer, bool *overflow) {
 		build_lists_mf(false);
 		if (!have_bfr)
 			return false;
@@ -958,11 +972,15 @@ public:
 			MVS_HIP(hipHostMalloc((void **)&h_fail, 64, hipHostMallocDefault));
 		MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
-		MVS_HIP(hipStreamSynchronize(stream));
-		unsigned long long ncand_u;
-		memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
+		unsigned long long ncand_u = 0;
+		// (deferred: the sort covers n_est entries -- the previous search's candidates per query + 30 %, in units of 64 K)
+		const int64_t n_est = defer ? std::min<int64_t>(cap_entries, ((int64_t)(cl_est_per_query * (double)nq) + 65535) / 65536 * 65536) : 0;
+		if (!defer) {
+			MVS_HIP(hipStreamSynchronize(stream));
+			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
+		}
 		int64_t ncand = (int64_t)ncand_u;
-		if (ncand > cap_entries) {
+		if (!defer && ncand > cap_entries) {
 			// The stream overflowed (duplicate-heavy lists: every copy of a near vector is a candidate, rightly).  Up to 16 384 entries
 			// per query the stream is grown and the MAIN pass repeated once -- the class slots are warm, it admits no more than the
 			// first -- and the index remembers the size (as FlatIndex::collect_candidates does); beyond that the scanner kernel takes
@@ -989,17 +1007,25 @@ public:
 			if (ncand > cap_entries)
 				return false;
 		}
-		cl_queries_total += nq;
-		cl_candidates_total += ncand;
-		const size_t temp = ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0;
+		if (!defer) {
+			cl_queries_total += nq;
+			cl_candidates_total += ncand;
+			cl_est_per_query = 1.3 * (double)ncand / (double)std::max<int64_t>(nq, 1) + 64.0;
+		}
+		const size_t temp = defer ? collect_sort_temp_bytes_est(n_est, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 		ws_sorttmp.reserve(std::max<size_t>(temp, 16));
 		ws_seg.reserve((size_t)2 * nq * sizeof(int));
 		const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
 		ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
 		float *pd1 = (float *)ws_ex.p;
 		int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
-		launch_collect_group(strm, sorted, ncand, ws_sorttmp.p, temp, nq, (int *)ws_seg.p, stream);
-		launch_ivf_collect_exact(metric, sorted, ncand, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream);
+		if (defer) {
+			launch_collect_group_est(strm, sorted, cnt, n_est, ws_sorttmp.p, temp, nq, (int *)ws_seg.p, stream);
+			launch_ivf_collect_exact(metric, sorted, n_est, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream, cnt);
+		} else {
+			launch_collect_group(strm, sorted, ncand, ws_sorttmp.p, temp, nq, (int *)ws_seg.p, stream);
+			launch_ivf_collect_exact(metric, sorted, ncand, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream);
+		}
 		launch_collect_select(metric, sorted, (const int *)ws_seg.p, nq, kk, pd1, pi1, stream);
 		// the k best by (value, position in the list-sorted store), labels = stored ids (then the id map of an IDMap wrapper)
 		// (the selected lists are already in the scan kernels' order: value, then position -- inner product keeps it as
@@ -1023,6 +1049,17 @@ public:
 		kinfo.nsplit = (int)np;
 		kinfo.bytes = (double)nrows_mf * 256.0;               // every list's bf16 rows once (each list is probed by >= 1 item)
 		kinfo.flops = (double)nq * np * ((double)nsorted / nlist) * d * 2.0; // (average list length)
+		if (defer) { // the one host round trip of the search: candidate count (did the sort cover it?) and the fail list's length
+			MVS_HIP(hipStreamSynchronize(stream));
+			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
+			cl_est_per_query = 1.3 * (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 64.0;
+			if ((int64_t)ncand_u > n_est) {
+				*overflow = true;
+				return false;
+			}
+			cl_queries_total += nq;
+			cl_candidates_total += (int64_t)ncand_u;
+		}
 		const int nf = *h_fail;
 		pf_queries_total += nq;
 		pf_fallback_total += nf;
@@ -1440,6 +1477,10 @@ public:
 			cl_stream_cap_per_query = v;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_defer")) { // 1 (default): the candidate count stays on the device between scan and re-scoring
+			cl_defer = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_collect_k32")) {
 			collect_k32 = v != 0;
 			return true;
@@ -1502,6 +1543,8 @@ private:
 	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_ie2p, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_cap_hint = 0, cl_stream_cap_per_query = 0;
+	double cl_est_per_query = 0; // candidates per query of the last coarse-filter search + 30 %: sizes the next search's sort
+	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
 	int *h_fail = nullptr; // pinned
 	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel

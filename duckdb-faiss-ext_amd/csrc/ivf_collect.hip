@@ -613,11 +613,17 @@ template <bool IS_L2>
 __global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long long *__restrict__ sorted, long long ncand,
                                                               const float *__restrict__ x, int d,
                                                               const float *__restrict__ rows_csr, int dp,
-                                                              const int *__restrict__ perm) {
+                                                              const int *__restrict__ perm,
+                                                              const unsigned long long *__restrict__ cnt) {
 	__shared__ __attribute__((aligned(16))) float rows[64 * (128 + 4)];
 	const int pitch = dp + 4, cpr = dp / 4; // floats per LDS row (bank spread), float4 chunks per row
 	const int lane = threadIdx.x;
-	const long long i = (long long)blockIdx.x * 64 + lane;
+	if (cnt) { // device-count mode (csrc/flat_collect.hip): min(*cnt, ncand) candidates, a fixed grid walks them in strides
+		const unsigned long long have = *cnt;
+		ncand = have < (unsigned long long)ncand ? (long long)have : ncand;
+	}
+	for (long long i0 = (long long)blockIdx.x * 64; i0 < ncand; i0 += (long long)gridDim.x * 64) {
+	const long long i = i0 + lane;
 	const unsigned long long ent = i < ncand ? sorted[i] : 0ull;
 	const long long q = (long long)(ent >> 32);
 	const int pos = i < ncand ? perm[(unsigned)ent] : 0;
@@ -645,8 +651,7 @@ __global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long lon
 		}
 	}
 	__syncthreads();
-	if (i >= ncand)
-		return;
+	if (i < ncand) {
 	const float *y = rows + lane * pitch;
 	float acc = 0.f;
 	int kk = 0;
@@ -693,20 +698,24 @@ __global__ __launch_bounds__(64) void ivf_collect_exact_kernel(unsigned long lon
 	}
 	const bool ok = pos >= 0 && (IS_L2 ? acc < FLT_MAX : acc > -FLT_MAX);
 	sorted[i] = ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)pos) : ~0ull;
+	}
+	__syncthreads(); // (the next group's rows overwrite the tile)
+	}
 }
 // dp_csr: row pitch of the list-sorted f32 store (floats; a multiple of 4, <= 128)
 void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
-                              int dp_csr, const int *d_perm, hipStream_t st) {
+                              int dp_csr, const int *d_perm, hipStream_t st, const unsigned long long *d_cnt) {
 	if (ncand <= 0)
 		return;
 	if (dp_csr % 4 != 0 || dp_csr > 128)
 		throw_faiss("mvs::launch_ivf_collect_exact", __FILE__, "row pitch %d is not served", dp_csr);
+	const dim3 grid((unsigned)(d_cnt ? std::min<int64_t>((ncand + 63) / 64, 8192) : (ncand + 63) / 64));
 	if (metric == METRIC_L2)
-		hipLaunchKernelGGL(ivf_collect_exact_kernel<true>, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
-		                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm);
+		hipLaunchKernelGGL(ivf_collect_exact_kernel<true>, grid, dim3(64), 0, st, d_sorted,
+		                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm, d_cnt);
 	else
-		hipLaunchKernelGGL(ivf_collect_exact_kernel<false>, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, d_sorted,
-		                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm);
+		hipLaunchKernelGGL(ivf_collect_exact_kernel<false>, grid, dim3(64), 0, st, d_sorted,
+		                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm, d_cnt);
 	MVS_HIP(hipGetLastError());
 }
 

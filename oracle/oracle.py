@@ -299,6 +299,11 @@ def set_num_threads(n):
     lib().orc_set_num_threads(n)
 
 
+def set_reservoir(on):
+    """test hook: False = heaps at every k (FAISS: ReservoirTopN from k = 100 on)"""
+    lib().orc_set_reservoir(1 if on else 0)
+
+
 # ---- FAISS's BLAS branch on the real OpenBLAS (PATH_OPENBLAS): the independent reference for label stability ----------
 def openblas_path():
     """numpy's bundled OpenBLAS with the 64-bit-integer scipy prefix (0.3.29 = /root/reference/vcpkg_ports/openblas/vcpkg.json:3)"""

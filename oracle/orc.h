@@ -115,6 +115,8 @@ void orc_synth_clustered(float *out, int64_t n_rows, int d, uint64_t seed, int64
 int orc_openblas_load(const char *path);
 const char *orc_openblas_config(void);
 void orc_openblas_set_num_threads(int n);
+/* test hook: 0 = heaps at every k (FAISS switches to ReservoirTopN at k >= 100; for L2 the two must give the same result) */
+void orc_set_reservoir(int on);
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

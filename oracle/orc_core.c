@@ -173,6 +173,161 @@ static void heap_reorder(int64_t k, float *hv, int64_t *hi, int is_max) {
 	}
 }
 
+
+/* ------------------------------------------------- ReservoirTopN (k >= 100) */
+/* faiss/impl/ResultHandler.h ReservoirTopN + faiss/utils/partitioning.cpp partition_fuzzy_median3, restated: from
+ * k = distance_compute_min_k_reservoir = 100 on, knn_L2sqr / knn_inner_product (utils/distances.cpp, both the BLAS and the
+ * per-pair branch) collect results in a reservoir of capacity (2k + 15) & ~15 instead of a heap:
+ *   add(val, id):   if (C::cmp(threshold, val)) { if (i == capacity) shrink_fuzzy(); vals[i] = val; ids[i] = id; i++; }
+ *   shrink_fuzzy(): threshold = partition_fuzzy(vals, ids, capacity, n, (capacity + n) / 2, &i) -- keeps between n and
+ *                   (capacity + n) / 2 of the best entries IN ARRAY ORDER (equal values at the threshold: the first ones)
+ *   to_result():    the first n entries are pushed on a heap, the others pass the strict heap rule, heap_reorder prints.
+ * L2 (rows arrive in ascending id): the retained set is the k smallest (value, id) -- the heap's result, bit for bit
+ * (tests/test_oracle_semantics.py).  Inner product: which rows TIED at the k-th score survive depends on where the sampled
+ * thresholds fell, so the whole history is replayed here; the device does the same for the queries it flags. */
+#define ORC_MIN_K_RESERVOIR 100
+typedef struct {
+	int is_max;
+	int64_t n, cap, i;
+	float thr;
+	float *vals;
+	int64_t *ids;
+} reservoir_t;
+
+static inline int rcmp(int is_max, float a, float b) { /* C::cmp(a, b) */
+	return is_max ? a > b : a < b;
+}
+static float median3f(float a, float b, float c) {
+	if (a > b) {
+		float t = a;
+		a = b;
+		b = t;
+	}
+	if (c > b)
+		return b;
+	if (c > a)
+		return c;
+	return a;
+}
+static float sample_threshold_median3(int is_max, const float *vals, int64_t n, float thresh_inf, float thresh_sup) {
+	const uint64_t big_prime = 6700417;
+	float val3[3];
+	int vi = 0;
+	for (uint64_t i = 0; i < (uint64_t)n; i++) {
+		const float v = vals[(i * big_prime) % (uint64_t)n];
+		if (rcmp(is_max, v, thresh_inf) && rcmp(is_max, thresh_sup, v)) { /* thresh_inf < v < thresh_sup for CMax */
+			val3[vi++] = v;
+			if (vi == 3)
+				break;
+		}
+	}
+	if (vi == 3)
+		return median3f(val3[0], val3[1], val3[2]);
+	if (vi != 0)
+		return val3[0];
+	return thresh_inf;
+}
+/* partition_fuzzy_median3: returns the threshold, *q_out = entries kept (q_min <= q <= q_max) */
+static float partition_fuzzy(int is_max, float *vals, int64_t *ids, int64_t n, int64_t q_min, int64_t q_max, int64_t *q_out) {
+	if (q_min == 0) {
+		if (q_out)
+			*q_out = 0;
+		return neutral(!is_max);
+	}
+	if (q_max >= n) {
+		if (q_out)
+			*q_out = q_max;
+		return neutral(is_max);
+	}
+	float thresh_inf = neutral(!is_max); /* C::Crev::neutral() */
+	float thresh_sup = neutral(is_max);
+	float thresh = median3f(vals[0], vals[n / 2], vals[n - 1]);
+	int64_t n_eq = 0, n_lt = 0, q = 0;
+	for (int it = 0; it < 200; it++) {
+		n_lt = n_eq = 0;
+		for (int64_t j = 0; j < n; j++) { /* count_lt_and_eq */
+			if (rcmp(is_max, thresh, vals[j]))
+				n_lt++;
+			else if (vals[j] == thresh)
+				n_eq++;
+		}
+		if (n_lt <= q_min) {
+			if (n_lt + n_eq >= q_min) {
+				q = q_min;
+				break;
+			}
+			thresh_inf = thresh;
+		} else if (n_lt <= q_max) {
+			q = n_lt;
+			break;
+		} else {
+			thresh_sup = thresh;
+		}
+		const float new_thresh = sample_threshold_median3(is_max, vals, n, thresh_inf, thresh_sup);
+		if (new_thresh == thresh_inf) /* nothing between thresh_inf and thresh_sup */
+			break;
+		thresh = new_thresh;
+	}
+	int64_t n_eq_1 = q - n_lt;
+	if (n_eq_1 < 0) { /* more than q entries at the lower bound */
+		q = q_min;
+		thresh = nextafterf(thresh, is_max ? -INFINITY : INFINITY); /* C::Crev::nextafter */
+		n_eq_1 = q;
+	}
+	int64_t wp = 0; /* compress_array: order preserving; of the entries equal to thresh the first n_eq_1 stay */
+	for (int64_t j = 0; j < n; j++) {
+		if (rcmp(is_max, thresh, vals[j])) {
+			vals[wp] = vals[j];
+			ids[wp] = ids[j];
+			wp++;
+		} else if (n_eq_1 > 0 && vals[j] == thresh) {
+			vals[wp] = vals[j];
+			ids[wp] = ids[j];
+			wp++;
+			n_eq_1--;
+		}
+	}
+	if (q_out)
+		*q_out = wp;
+	return thresh;
+}
+static void reservoir_begin(reservoir_t *r, int is_max, int64_t k, float *vals, int64_t *ids) {
+	r->is_max = is_max;
+	r->n = k;
+	r->cap = (2 * k + 15) & ~(int64_t)15;
+	r->i = 0;
+	r->thr = neutral(is_max);
+	r->vals = vals;
+	r->ids = ids;
+}
+static inline void reservoir_add(reservoir_t *r, float val, int64_t id) { /* the caller has checked C::cmp(threshold, val) */
+	if (r->i == r->cap)
+		r->thr = partition_fuzzy(r->is_max, r->vals, r->ids, r->cap, r->n, (r->cap + r->n) / 2, &r->i);
+	r->vals[r->i] = val;
+	r->ids[r->i] = id;
+	r->i++;
+}
+static void reservoir_to_result(const reservoir_t *r, float *hv, int64_t *hi) {
+	const int64_t n = r->n, m = r->i < n ? r->i : n;
+	heap_init(n, hv, hi, r->is_max);
+	/* heap_push of the first min(i, n) entries == strict inserts into the neutral-filled heap (values equal to the neutral
+	 * element aside, which FAISS's own push would keep: they print as (neutral, id) there and as (neutral, -1) here) */
+	for (int64_t j = 0; j < m; j++)
+		if (accepts(r->is_max, hv[0], r->vals[j]))
+			heap_replace_top(n, hv, hi, r->is_max, r->vals[j], r->ids[j]);
+	for (int64_t j = n; j < r->i; j++) /* heap_addn */
+		if (accepts(r->is_max, hv[0], r->vals[j]))
+			heap_replace_top(n, hv, hi, r->is_max, r->vals[j], r->ids[j]);
+	heap_reorder(n, hv, hi, r->is_max);
+}
+static int g_reservoir = 1; /* orc_set_reservoir(0): heaps at every k (test hook: the two must agree for L2) */
+void orc_set_reservoir(int on) {
+	g_reservoir = on;
+}
+static inline int use_reservoir(int64_t k) {
+	return g_reservoir && k >= ORC_MIN_K_RESERVOIR;
+}
+
 /* ------------------------------------------------------- scalar primitives */
 
 static inline float ip_chain(const float *x, const float *y, int d) {
@@ -355,17 +510,38 @@ static void search_pair(int metric, int d, int64_t nb, const float *xb, int64_t 
 		const float *x = xq + i * d;
 		float *hv = D + i * k;
 		int64_t *hi = I + i * k;
-		heap_init(k, hv, hi, is_max);
+		/* knn_L2sqr / knn_inner_product / knn_extra_metrics: heap below k = 100, reservoir from there on */
+		const int resv = use_reservoir(k);
+		reservoir_t rs;
+		float *rv = NULL;
+		int64_t *ri = NULL;
+		if (resv) {
+			const int64_t cap = (2 * k + 15) & ~(int64_t)15;
+			rv = (float *)malloc((size_t)cap * sizeof(float));
+			ri = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+			reservoir_begin(&rs, is_max, k, rv, ri);
+		} else {
+			heap_init(k, hv, hi, is_max);
+		}
 		for (int64_t j = 0; j < nb; j++) {
 			if (sel && sel->kind && !sel_member(sel, id_map ? id_map[j] : j))
 				continue;
 			float dis = metric == ORC_METRIC_L2              ? l2_chain(x, xb + j * d, d)
 			            : metric == ORC_METRIC_INNER_PRODUCT ? ip_chain(x, xb + j * d, d)
 			                                                 : extra_distance(metric, marg, x, xb + j * d, d);
-			if (accepts(is_max, hv[0], dis))
+			if (resv) {
+				if (accepts(is_max, rs.thr, dis))
+					reservoir_add(&rs, dis, j);
+			} else if (accepts(is_max, hv[0], dis))
 				heap_replace_top(k, hv, hi, is_max, dis, j);
 		}
-		heap_reorder(k, hv, hi, is_max);
+		if (resv) {
+			reservoir_to_result(&rs, hv, hi);
+			free(rv);
+			free(ri);
+		} else {
+			heap_reorder(k, hv, hi, is_max);
+		}
 	}
 }
 
@@ -445,6 +621,12 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 	{
 		float *xt = (float *)aligned_alloc(64, (size_t)d * 16 * sizeof(float));
 		float *ipbuf = (float *)aligned_alloc(64, (size_t)BLAS_DBS * 16 * sizeof(float));
+		/* k >= 100: ReservoirBlockResultHandler instead of HeapBlockResultHandler (one reservoir per query of the group) */
+		const int resv = use_reservoir(k);
+		const int64_t rcap = (2 * k + 15) & ~(int64_t)15;
+		reservoir_t rs[16];
+		float *rv = resv ? (float *)malloc((size_t)16 * rcap * sizeof(float)) : NULL;
+		int64_t *ri = resv ? (int64_t *)malloc((size_t)16 * rcap * sizeof(int64_t)) : NULL;
 #pragma omp for schedule(dynamic, 1)
 		for (int64_t g = 0; g < ngroups; g++) {
 			const int64_t q0 = g * 16;
@@ -452,8 +634,12 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 			for (int kk = 0; kk < d; kk++)
 				for (int q = 0; q < 16; q++)
 					xt[(size_t)kk * 16 + q] = q < nqg ? xq[(q0 + q) * d + kk] : 0.f;
-			for (int q = 0; q < nqg; q++)
-				heap_init(k, D + (q0 + q) * k, I + (q0 + q) * k, is_max);
+			for (int q = 0; q < nqg; q++) {
+				if (resv)
+					reservoir_begin(&rs[q], is_max, k, rv + (size_t)q * rcap, ri + (size_t)q * rcap);
+				else
+					heap_init(k, D + (q0 + q) * k, I + (q0 + q) * k, is_max);
+			}
 			for (int64_t j0 = 0; j0 < nb; j0 += BLAS_DBS) {
 				const int64_t jb = nb - j0 < BLAS_DBS ? nb - j0 : BLAS_DBS;
 				int64_t j = 0;
@@ -465,7 +651,7 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 				for (int q = 0; q < nqg; q++) {
 					float *hv = D + (q0 + q) * k;
 					int64_t *hi = I + (q0 + q) * k;
-					float thr = hv[0];
+					float thr = resv ? rs[q].thr : hv[0];
 					if (is_max) {
 						const float xni = xn[q0 + q];
 						for (int64_t jj = 0; jj < jb; jj++) {
@@ -473,26 +659,42 @@ static void search_blas(int metric, int d, int64_t nb, const float *xb, int64_t 
 							if (dis < 0)
 								dis = 0;
 							if (thr > dis) {
-								heap_replace_top(k, hv, hi, 1, dis, j0 + jj);
-								thr = hv[0];
+								if (resv) {
+									reservoir_add(&rs[q], dis, j0 + jj);
+									thr = rs[q].thr;
+								} else {
+									heap_replace_top(k, hv, hi, 1, dis, j0 + jj);
+									thr = hv[0];
+								}
 							}
 						}
 					} else {
 						for (int64_t jj = 0; jj < jb; jj++) {
 							const float dis = ipbuf[jj * 16 + q];
 							if (thr < dis) {
-								heap_replace_top(k, hv, hi, 0, dis, j0 + jj);
-								thr = hv[0];
+								if (resv) {
+									reservoir_add(&rs[q], dis, j0 + jj);
+									thr = rs[q].thr;
+								} else {
+									heap_replace_top(k, hv, hi, 0, dis, j0 + jj);
+									thr = hv[0];
+								}
 							}
 						}
 					}
 				}
 			}
-			for (int q = 0; q < nqg; q++)
-				heap_reorder(k, D + (q0 + q) * k, I + (q0 + q) * k, is_max);
+			for (int q = 0; q < nqg; q++) {
+				if (resv)
+					reservoir_to_result(&rs[q], D + (q0 + q) * k, I + (q0 + q) * k);
+				else
+					heap_reorder(k, D + (q0 + q) * k, I + (q0 + q) * k, is_max);
+			}
 		}
 		free(xt);
 		free(ipbuf);
+		free(rv);
+		free(ri);
 	}
 	free(xn);
 	free(yn);
@@ -552,11 +754,21 @@ static int search_openblas(int metric, int d, int64_t nb, const float *xb, int64
 		orc_norms(xb, nb, d, yn);
 	}
 	float *ip_block = (float *)malloc((size_t)OB_QBS * BLAS_DBS * sizeof(float));
+	const int resv = use_reservoir(k);
+	const int64_t rcap = (2 * k + 15) & ~(int64_t)15;
+	const int64_t nres = nq < OB_QBS ? nq : OB_QBS;
+	reservoir_t *rs = resv ? (reservoir_t *)malloc((size_t)nres * sizeof(reservoir_t)) : NULL;
+	float *rv = resv ? (float *)malloc((size_t)nres * rcap * sizeof(float)) : NULL;
+	int64_t *ri = resv ? (int64_t *)malloc((size_t)nres * rcap * sizeof(int64_t)) : NULL;
 	for (int64_t i0 = 0; i0 < nq; i0 += OB_QBS) {
 		const int64_t i1 = i0 + OB_QBS < nq ? i0 + OB_QBS : nq;
 #pragma omp parallel for
-		for (int64_t i = i0; i < i1; i++) /* res.begin_multiple */
-			heap_init(k, D + i * k, I + i * k, is_max);
+		for (int64_t i = i0; i < i1; i++) { /* res.begin_multiple */
+			if (resv)
+				reservoir_begin(&rs[i - i0], is_max, k, rv + (size_t)(i - i0) * rcap, ri + (size_t)(i - i0) * rcap);
+			else
+				heap_init(k, D + i * k, I + i * k, is_max);
+		}
 		for (int64_t j0 = 0; j0 < nb; j0 += BLAS_DBS) {
 			const int64_t j1 = j0 + BLAS_DBS < nb ? j0 + BLAS_DBS : nb;
 			const int64_t nyi = j1 - j0, nxi = i1 - i0;
@@ -567,7 +779,8 @@ static int search_openblas(int metric, int d, int64_t nb, const float *xb, int64
 				const float *ip_line = ip_block + (i - i0) * nyi;
 				float *hv = D + i * k;
 				int64_t *hi = I + i * k;
-				float thr = hv[0];
+				reservoir_t *r = resv ? &rs[i - i0] : NULL;
+				float thr = resv ? r->thr : hv[0];
 				if (is_max) {
 					const float xni = xn[i];
 					for (int64_t j = 0; j < nyi; j++) {
@@ -575,25 +788,42 @@ static int search_openblas(int metric, int d, int64_t nb, const float *xb, int64
 						if (dis < 0)
 							dis = 0;
 						if (thr > dis) {
-							heap_replace_top(k, hv, hi, 1, dis, j0 + j);
-							thr = hv[0];
+							if (resv) {
+								reservoir_add(r, dis, j0 + j);
+								thr = r->thr;
+							} else {
+								heap_replace_top(k, hv, hi, 1, dis, j0 + j);
+								thr = hv[0];
+							}
 						}
 					}
 				} else {
 					for (int64_t j = 0; j < nyi; j++) {
 						const float dis = ip_line[j];
 						if (thr < dis) {
-							heap_replace_top(k, hv, hi, 0, dis, j0 + j);
-							thr = hv[0];
+							if (resv) {
+								reservoir_add(r, dis, j0 + j);
+								thr = r->thr;
+							} else {
+								heap_replace_top(k, hv, hi, 0, dis, j0 + j);
+								thr = hv[0];
+							}
 						}
 					}
 				}
 			}
 		}
 #pragma omp parallel for
-		for (int64_t i = i0; i < i1; i++) /* res.end_multiple */
-			heap_reorder(k, D + i * k, I + i * k, is_max);
+		for (int64_t i = i0; i < i1; i++) { /* res.end_multiple */
+			if (resv)
+				reservoir_to_result(&rs[i - i0], D + i * k, I + i * k);
+			else
+				heap_reorder(k, D + i * k, I + i * k, is_max);
+		}
 	}
+	free(rs);
+	free(rv);
+	free(ri);
 	free(ip_block);
 	free(xn);
 	free(yn);

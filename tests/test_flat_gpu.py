@@ -415,3 +415,57 @@ def test_inner_product_boundary_ties_follow_the_cmin_heap(mf, d, nb, k, nq, idma
         if nb >= 1000 and sel is None and nq >= 12:
             assert (Dn[:, k - 1] == Dn[:, k]).mean() > 0.3  # the case under test really occurs
         assert_same_results(D, I, Do, Io, False, what=f"IP ties d={d} nb={nb} k={k} nq={nq} idmap={idmap} sel={sel and sel[0]}")
+
+
+@pytest.mark.parametrize("idmap", [False, True])
+@pytest.mark.parametrize("nq", [7, 40])
+@pytest.mark.parametrize("d,nb,k", [(8, 6000, 100), (16, 20000, 250), (1, 5000, 128), (32, 9000, 1000)])
+def test_inner_product_k_from_100_follows_the_reservoir(mf, d, nb, k, nq, idmap):
+    """From k = 100 on FAISS collects results in a ReservoirTopN instead of a heap (utils/distances.cpp,
+    distance_compute_min_k_reservoir; impl/ResultHandler.h, utils/partitioning.cpp partition_fuzzy_median3): which of the rows TIED
+    at the k-th score survive depends on where the sampled thresholds fell while the stream went by.  Small-integer data puts
+    many rows on every boundary; the device replays the reservoir for the queries it flags (csrc/flat_reservoir.hip) and must
+    return the oracle's rows (oracle/orc_core.c reservoir_t) on every query -- fused kernel (k + 1 <= its k-lists) and
+    flat_direct (beyond), both FAISS branches, selectors, IDMap.  d = 1: scores = a handful of integers, thousands of ties."""
+    rs = np.random.RandomState(d * 77 + nb + k + nq)
+    if d > 1:
+        xb = rs.randint(-2, 3, size=(nb, d)).astype(np.float32)
+        xq = rs.randint(-2, 3, size=(nq, d)).astype(np.float32)
+    else:  # 1.5 k rows tied at the boundary, k / 2 better ones, k more tied, then worse ones: a shrink lands ON the boundary
+        v = np.concatenate([np.full(k + k // 2, 5), np.full(k // 2, 9), np.full(k, 5), rs.randint(0, 5, size=nb - 3 * k)])
+        xb = v.astype(np.float32).reshape(nb, 1)
+        xq = np.ones((nq, 1), dtype=np.float32)
+    ids = (rs.permutation(3 * nb)[:nb] + 5).astype(np.int64) if idmap else np.arange(nb, dtype=np.int64)
+    desc = "IDMap,Flat" if idmap else "Flat"
+    g, o = mf.index_factory(d, desc, IP), orc.Index(d, desc, IP)
+    for a in (g, o):
+        for i0 in range(0, nb, 2048):
+            a.add_with_ids(xb[i0 : i0 + 2048], ids[i0 : i0 + 2048]) if idmap else a.add(xb[i0 : i0 + 2048])
+    keep = ids[rs.rand(nb) < 0.7]
+    differs_from_heap = 0
+    for sel in (None, ("batch", keep)) if d > 1 else (None,):
+        D, I = g.search(xq, k, sel=sel)
+        Do, Io = o.search(xq, k, sel=sel)
+        assert_same_results(D, I, Do, Io, False, what=f"IP reservoir d={d} nb={nb} k={k} nq={nq} idmap={idmap} sel={sel and sel[0]}")
+        orc.set_reservoir(False)
+        try:
+            _, Ih = o.search(xq, k, sel=sel)
+        finally:
+            orc.set_reservoir(True)
+        differs_from_heap += int((Ih != Io).any(1).sum())
+    if d == 1:
+        assert differs_from_heap > 0  # the reservoir's outcome really is not the heap's on such data
+
+
+def test_l2_k_from_100_reservoir_equals_heap_on_the_device_too(mf):
+    """L2: the reservoir keeps the k smallest (distance, id) like the heap -- duplicate-heavy rows, k = 100 ... 1500"""
+    rs = np.random.RandomState(5)
+    d, nb = 16, 12000
+    xb = rs.randint(0, 4, size=(nb, d)).astype(np.float32)
+    xq = rs.randint(0, 4, size=(33, d)).astype(np.float32)
+    g, o = mf.index_factory(d, "Flat", L2), orc.Index(d, "Flat", L2)
+    g.add(xb)
+    o.add(xb)
+    for k in (100, 257, 1500):
+        assert_same_results(*g.search(xq, k), *o.search(xq, k), True, what=f"L2 k={k}")
+

@@ -230,3 +230,48 @@ def test_ivf_tie_closed_form_equals_the_heap_in_any_arrival_order(is_max):
         cv, ci = _closed_form(is_max, k, vals, ids)
         assert np.array_equal(hv, cv), (trial, n, k)
         assert np.array_equal(hi, ci), (trial, n, k, vals, ids, hi, ci)
+
+
+def test_reservoir_from_k_100_equals_the_heap_for_l2_and_differs_for_ip():
+    """FAISS's ReservoirTopN (k >= 100; oracle/orc_core.c reservoir_t) against the heap at the same k: for L2 (rows arrive in
+    ascending id) both keep the k smallest (distance, id); for inner product the rows tied at the k-th score differ in a fair
+    share of tie-heavy cases -- the values never do."""
+    rs = np.random.RandomState(5)
+    nd = {orc.METRIC_L2: 0, orc.METRIC_INNER_PRODUCT: 0}
+    try:
+        for trial in range(60):
+            nb, k = int(rs.randint(300, 3000)), int(rs.choice([100, 120, 200]))
+            vals = rs.randint(0, rs.randint(3, 40), size=nb).astype(np.float32)
+            xb = np.zeros((nb, 8), np.float32)
+            xb[:, 0] = vals
+            for metric in nd:
+                xq = np.zeros((1, 8), np.float32)
+                xq[0, 0] = 1.0 if metric == orc.METRIC_INNER_PRODUCT else 0.0
+                orc.set_reservoir(True)
+                Dr, Ir = orc.flat_search(metric, xb, xq, k)
+                orc.set_reservoir(False)
+                Dh, Ih = orc.flat_search(metric, xb, xq, k)
+                assert np.array_equal(Dr, Dh)
+                nd[metric] += not np.array_equal(Ir, Ih)
+                # either way: k distinct rows, each carrying its own value, in FAISS's print order
+                assert len(set(Ir[0].tolist())) == k
+                ref = vals[Ir[0]] if metric == orc.METRIC_INNER_PRODUCT else vals[Ir[0]] ** 2
+                assert np.array_equal(ref, Dr[0])
+    finally:
+        orc.set_reservoir(True)
+    assert nd[orc.METRIC_L2] == 0 and nd[orc.METRIC_INNER_PRODUCT] > 0, nd
+    # the crafted stream of DESIGN.md 3.5: 150 tied rows, 50 better ones, 100 more tied; k = 100
+    vals = np.array([5] * 150 + [9] * 50 + [5] * 100, np.float32)
+    xb = np.zeros((len(vals), 8), np.float32)
+    xb[:, 0] = vals
+    xq = np.zeros((1, 8), np.float32)
+    xq[0, 0] = 1.0
+    _, Ir = orc.flat_search(orc.METRIC_INNER_PRODUCT, xb, xq, 100)
+    assert sorted(Ir[0][50:].tolist()) == list(range(50))  # the shrink at the boundary kept the FIRST 50 tied rows ...
+    orc.set_reservoir(False)
+    try:
+        _, Ih = orc.flat_search(orc.METRIC_INNER_PRODUCT, xb, xq, 100)
+    finally:
+        orc.set_reservoir(True)
+    assert sorted(Ih[0][50:].tolist()) == list(range(50, 100))  # ... where the heap evicts them for the later, better rows
+

@@ -8,8 +8,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_${TAG} -- pytho
 f=$(find $O/trace_${TAG} -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY' | tee $O/kstats_${TAG}.txt
 import csv, sys
+import os
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:22]:
-    print("%-70s calls %5s avg_us %10.1f total_ms %9.3f" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+lo = int(os.environ.get("MINCALLS", "10"))
+tot = 0.0
+for r in rows:
+    if int(r["Calls"]) < lo:
+        continue
+    tot += float(r["TotalDurationNs"]) / 1e6
+    print("%-64s calls %5s avg_us %9.1f total_ms %9.3f per_step_us %8.1f" % (r["Name"][:64], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e3 / 12))
+print("sum of kernels with >= %d calls: %.3f ms = %.3f ms per step (10 timed + 2 warm-up steps)" % (lo, tot, tot / 12))
 PY
 rm -rf $O/trace_${TAG}
