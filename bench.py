@@ -516,7 +516,7 @@ def main():
             # HBM bytes per launch come from the committed PMC passes of this same workload (PMC counters cannot be
             # collected from inside the process); null for any other workload
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r4_traffic.json")
             if os.path.exists(tpath) and world == 1 and chunk == nq and not args.opt and args.efconstruction == 0:
                 for w in json.load(open(tpath)).get("workloads", []):
                     # a PMC figure is only valid for the launch it was measured on: same workload, same dominant kernel,
@@ -526,9 +526,9 @@ def main():
                         and w.get("workload") == out["config"]["workload"]
                         and w["data"] == out["data"]
                         and w.get("kernel") == kinfo["name"]
-                        and w.get("grid") == kinfo["grid"]
+                        and w.get("grid", kinfo["grid"]) == kinfo["grid"]
                     ):
-                        traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r3_traffic.json (" + w["source"] + ")"
+                        traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/r4_traffic.json (" + w["source"] + ")"
             if kinfo["name"].startswith("flat_bf16_collect") or kinfo["name"].startswith("flat_bf16_wide"):
                 # bf16 coarse filter (csrc/flat_collect.hip; 128 < d <= 768: csrc/flat_collect_wide.hip): ONE bf16 MFMA product per element pair is the algorithm, so its
                 # algorithmic flops are 2 nq N d, priced against the dense bf16 peak; the candidates it admits are re-scored
@@ -626,6 +626,8 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4),
                     "launches": n_launch,
                     "algorithmic_bytes_per_launch": kinfo["bytes"],
+                    "traffic_over_algorithmic": round(traffic / kinfo["bytes"], 3) if traffic else None,
+                    "grid": kinfo["grid"],
                 }
                 if is_hnsw:
                     # what the walk actually pulls out of the row stores per launch: a bf16 row (2d bytes) for every neighbour

@@ -4,7 +4,11 @@ O=$1
 extra=""; [ -n "${OPT:-}" ] && extra="--opt ${OPT//,/ --opt }"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf $O/trace_${TAG}
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_${TAG} -- python3 bench.py --rows ${ROWS:-1250000} --no-cpu-baseline --no-configs --no-host-pointer --steps 10 --warmup 2 $extra ${ARGS:-} > $O/kstats_${TAG}.json 2> $O/kstats_${TAG}.err
+if [ -n "${PYCMD:-}" ]; then  # any python command line instead of bench.py: PYCMD="tools/collect_sensitivity.py"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_${TAG} -- python3 $PYCMD > $O/kstats_${TAG}.json 2> $O/kstats_${TAG}.err
+else
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_${TAG} -- python3 bench.py --rows ${ROWS:-1250000} --no-cpu-baseline --no-configs --no-host-pointer --steps 10 --warmup 2 $extra ${ARGS:-} > $O/kstats_${TAG}.json 2> $O/kstats_${TAG}.err
+fi
 f=$(find $O/trace_${TAG} -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY' | tee $O/kstats_${TAG}.txt
 import csv, sys
