@@ -159,8 +159,8 @@ def secondary_layouts(args, world):
 
 
 EMBEDDED = [  # (name, workload of BASELINE.json configs[i], bench.py arguments)
-    ("C2", "IndexFlatL2 d=128 N=1M nq=10k k=10", ["--rows", "1000000", "--cpu-seconds", "4"]),
-    ("C3", "IVF4096,Flat d=128 N=10M nprobe=32 nq=10k k=10", ["--index", "IVF4096,Flat", "--data", "clustered", "--parity-device", "1024"]),
+    ("C2", "IndexFlatL2 d=128 N=1M nq=10k k=10", ["--rows", "1000000", "--cpu-seconds", "4", "--steps", "10", "--warmup", "2"]),
+    ("C3", "IVF4096,Flat d=128 N=10M nprobe=32 nq=10k k=10", ["--index", "IVF4096,Flat", "--data", "clustered", "--parity-device", "1024", "--steps", "10", "--warmup", "2"]),
     ("C4_shard", "IndexFlatIP d=768, one GPU's N/8 = 12.5M rows of N=100M, nq=10k k=10",
      ["--rows", "12500000", "--d", "768", "--metric", "IP", "--normalize", "--data", "clustered", "--sigma", "1.0", "--cpu-seconds", "8", "--parity-device", "256"]),
     ("C5", "IDMap,HNSW32 d=768 N=1M nq=10k k=10 efSearch=128",
@@ -176,6 +176,7 @@ def embedded_configs():
     res = {}
     for name, workload, extra in EMBEDDED:
         t0 = time.perf_counter()
+        # (3 steps unless the config says otherwise: the short ones take 10 -- their first searches size buffers and estimates)
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-configs", "--no-host-pointer"] + extra
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)

@@ -525,27 +525,35 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			for (int i = 0; i < 2; ++i) { // one query at a time: 128 VGPRs of fragments are resident, the network needs ~40 more
 				const int q = qo + 32 * hq + 16 * i + c;
 				const int qc = q < a.nq ? q : 0;
-				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC);
-				unsigned long long w[NC / 2];
-#pragma unroll
-				for (int j = 0; j < NC / 2; ++j)
-					w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const float e2v = __builtin_nontemporal_load(a.e2 + qc);
+				// NC = 128 (32 < kk <= 128): four SUBSETS of 32 classes (class = row & 127, subset = class >> 5); the ceil(kk / 4)-th best
+				// of a subset's class bests has that many distinct rows at least as good, the WORST of the four subsets' values has
+				// >= kk -- the same 32-key network four times instead of a 128-key one
+				constexpr int SUBN = NC > 32 ? 32 : NC, NSUB = NC / SUBN;
+				const int rank = NSUB == 1 ? a.nclass - 1 : (a.nclass + NSUB - 1) / NSUB - 1;
+				unsigned kth = 0u;
+#pragma unroll 1
+				for (int sb = 0; sb < NSUB; ++sb) {
+				const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC + sb * SUBN);
+				unsigned long long w[SUBN / 2];
 #pragma unroll
-				for (int j = 0; j < NC / 2; ++j) // every load is issued before the first is consumed: one round trip
+				for (int j = 0; j < SUBN / 2; ++j)
+					w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+				for (int j = 0; j < SUBN / 2; ++j) // every load is issued before the first is consumed: one round trip
 					asm volatile("" : "+v"(w[j]));
-				unsigned key[NC];
+				unsigned key[SUBN];
 #pragma unroll
-				for (int j = 0; j < NC / 2; ++j) {
+				for (int j = 0; j < SUBN / 2; ++j) {
 					key[2 * j] = (unsigned)w[j];
 					key[2 * j + 1] = (unsigned)(w[j] >> 32);
 				}
 #pragma unroll
-				for (int kbit = 2; kbit <= NC; kbit <<= 1)
+				for (int kbit = 2; kbit <= SUBN; kbit <<= 1)
 #pragma unroll
 					for (int jb = kbit >> 1; jb > 0; jb >>= 1)
 #pragma unroll
-						for (int x0 = 0; x0 < NC; ++x0) {
+						for (int x0 = 0; x0 < SUBN; ++x0) {
 							const int x1 = x0 ^ jb;
 							if (x1 > x0) {
 								const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
@@ -555,10 +563,12 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 								key[x1] = asc ? hi : lo;
 							}
 						}
-				unsigned kth = key[0];
+				unsigned ks = key[0];
 #pragma unroll
-				for (int j = 1; j < NC; ++j)
-					kth = (a.nclass - 1 == j) ? key[j] : kth;
+				for (int j = 1; j < SUBN; ++j)
+					ks = (rank == j) ? key[j] : ks;
+				kth = ks > kth ? ks : kth; // (keys: smaller = better; the worst subset decides)
+				}
 				const unsigned neutral = skey(-FLT_MAX);
 				const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
 				const float bv = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
@@ -695,6 +705,12 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 					if ((long long)(base + i) < a.stream_cap)
 						a.stream[base + i] = qbuf[i];
 				__syncthreads();
+				// The stream holds twice what it can take: this scan's result is lost anyway (the host grows the stream, drops the
+				// heavy queries or hands the batch to the exact kernels) -- stop feeding it.  On all-duplicates data (64 distinct
+				// vectors, N = 2 M: 31 250 copies of every query's nearest row) a scan that ran to its end pushed 3e8 candidates
+				// through the slot atomics and the overflow branch: 47 s per launch (profiles/r4_alldup_kstats.txt).
+				if ((long long)base > 2 * a.stream_cap)
+					break;
 			}
 		}
 	}
@@ -777,22 +793,28 @@ __global__ void collect_bound_table_kernel(const unsigned *__restrict__ gslot, c
 	const long long q = qb * CL_QBLOCK + w * 128 + 32 * hq + 16 * i + c;
 	float bv = __uint_as_float(0x7fc00000u);
 	if (q < nq) {
-		unsigned key[NC];
+		constexpr int SUBN = NC > 32 ? 32 : NC, NSUB = NC / SUBN; // (flat_bf16_collect_kernel: subsets of 32 classes at NC = 128)
+		const int rank = NSUB == 1 ? nclass - 1 : (nclass + NSUB - 1) / NSUB - 1;
+		unsigned kth = 0u;
+		for (int sb = 0; sb < NSUB; ++sb) {
+			unsigned key[SUBN];
 #pragma unroll
-		for (int t = 0; t < NC; ++t)
-			key[t] = gslot[(size_t)q * NC + t];
-		// the (nclass - 1)-th smallest with duplicates counted: the key whose rank interval covers it
-		unsigned kth = 0xffffffffu;
+			for (int t = 0; t < SUBN; ++t)
+				key[t] = gslot[(size_t)q * NC + sb * SUBN + t];
+			// the rank-th smallest with duplicates counted: the key whose rank interval covers it
+			unsigned ks = 0xffffffffu;
 #pragma unroll
-		for (int t = 0; t < NC; ++t) {
-			int less = 0, leq = 0;
+			for (int t = 0; t < SUBN; ++t) {
+				int less = 0, leq = 0;
 #pragma unroll
-			for (int s2 = 0; s2 < NC; ++s2) {
-				less += key[s2] < key[t];
-				leq += key[s2] <= key[t];
+				for (int s2 = 0; s2 < SUBN; ++s2) {
+					less += key[s2] < key[t];
+					leq += key[s2] <= key[t];
+				}
+				if (less <= rank && rank < leq)
+					ks = key[t];
 			}
-			if (less <= nclass - 1 && nclass - 1 < leq)
-				kth = key[t];
+			kth = ks > kth ? ks : kth;
 		}
 		const unsigned neutral = skey(-FLT_MAX);
 		const float B = skey2f(kth < neutral ? kth : neutral);
@@ -805,7 +827,9 @@ static void launch_collect_bound_table(const CollectArgs &a, int nqb, hipStream_
 		return;
 	const long long total = (long long)nqb * CL_QBLOCK;
 	const dim3 grid((unsigned)((total + 255) / 256));
-	if (a.slot_stride == 32)
+	if (a.slot_stride == 128)
+		hipLaunchKernelGGL(collect_bound_table_kernel<128>, grid, dim3(256), 0, st, (const unsigned *)a.gslot, a.e2, a.nclass, a.nq, total, a.pbnd);
+	else if (a.slot_stride == 32)
 		hipLaunchKernelGGL(collect_bound_table_kernel<32>, grid, dim3(256), 0, st, (const unsigned *)a.gslot, a.e2, a.nclass, a.nq, total, a.pbnd);
 	else
 		hipLaunchKernelGGL(collect_bound_table_kernel<16>, grid, dim3(256), 0, st, (const unsigned *)a.gslot, a.e2, a.nclass, a.nq, total, a.pbnd);
@@ -845,12 +869,18 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 #undef MVS_CL_ABL
 	} else
 #endif
-	if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes
+	if (a.slot_stride == 32 || a.slot_stride == 128) { // 16 < kk <= 32: 32 row classes; 32 < kk <= 128: 4 subsets of 32
 #define MVS_CL_NC32(L2, SEL_)                                                                                           \
 	{                                                                                                                  \
-		auto kern = flat_bf16_collect_kernel<8, L2, COLLECT, 0, SEL_, 32>;                                             \
-		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
+		if (a.slot_stride == 128) {                                                                                    \
+			auto kern = flat_bf16_collect_kernel<8, L2, COLLECT, 0, SEL_, 128>;                                        \
+			ensure_dynamic_lds((const void *)kern, lds);                                                               \
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                               \
+		} else {                                                                                                       \
+			auto kern = flat_bf16_collect_kernel<8, L2, COLLECT, 0, SEL_, 32>;                                         \
+			ensure_dynamic_lds((const void *)kern, lds);                                                               \
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                               \
+		}                                                                                                              \
 	}
 		if (a.rowmask && metric == METRIC_L2)
 			MVS_CL_NC32(true, true)
@@ -1060,13 +1090,16 @@ static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t
 // row classes per query: 16, or 32 for 16 < kk <= 32 (d <= 128 only: the wide instances keep 16)
 int g_cl_nc32_from = 17; // option cl_nc32_from
 int collect_slot_stride(int kk) {
-	return (kk > 16 || kk >= g_cl_nc32_from) ? 32 : 16;
+	return kk > 32 ? 128 : ((kk > 16 || kk >= g_cl_nc32_from) ? 32 : 16);
 }
 int collect_max_k(int d) {
 	const int dp1 = collect_store_dims(d);
 	if (dp1 == 0)
 		return 0;
-	// (the k-split kernel -- option cl_wide_big = 0 at the 768 / 1024-dim stores -- keeps 16 classes)
+	// (the k-split kernel -- option cl_wide_big = 0 at the 768 / 1024-dim stores -- keeps 16 classes; the d <= 128 scan serves
+	// kk <= 128 with four subsets of 32 classes, round 4)
+	if (dp1 == 128)
+		return 128;
 	return ((dp1 == 768 || dp1 == 1024) && !g_wide_big) ? 16 : 32;
 }
 
@@ -1347,8 +1380,8 @@ __device__ __forceinline__ unsigned long long cl_lane64(unsigned long long v, in
 	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
 	return ((unsigned long long)hi << 32) | lo;
 }
-// One wave per query: the kk best keys (value, row) of its segment, kept as a sorted list spread over the lanes (lane i =
-// entry i): insert position by ballot, shift by one lane.
+// One wave per query: the kk <= 128 best keys (value, row) of its segment, kept as a sorted list spread over the lanes (entry i in
+// lane i & 63 of register i >> 6): insert position by ballot, shift by one lane (the second register takes the first one's lane 63).
 template <bool IS_L2>
 __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long long *__restrict__ keys,
                                                            const int *__restrict__ seg_b, const int *__restrict__ seg_e,
@@ -1357,8 +1390,12 @@ __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long 
 	const int lane = threadIdx.x;
 	const int b = seg_b[q], e = seg_e[q];
 	const unsigned long long EMPTY = ~0ull;
-	unsigned long long mine = EMPTY; // entry `lane` of the sorted list
+	unsigned long long mine = EMPTY, mine2 = EMPTY; // entries `lane` and `64 + lane` of the sorted list
 	unsigned long long worst = EMPTY;
+	auto shr1 = [](unsigned long long v) { // lane i <- lane i - 1 (lane 0: 0)
+		return ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false) << 32) |
+		       (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
+	};
 	for (int base = b; base < e; base += 64) {
 		const int i = base + lane;
 		const unsigned long long key = i < e ? keys[i] : EMPTY;
@@ -1371,21 +1408,34 @@ __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long 
 			const unsigned long long ck = cl_lane64(key, L);
 			if (ck >= worst)
 				continue;
-			const int pos = __popcll(__builtin_amdgcn_ballot_w64(lane < kk && mine <= ck));
-			const unsigned long long up =
-			    ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(mine >> 32), 0x138, 0xf, 0xf, false) << 32) |
-			    (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)mine, 0x138, 0xf, 0xf, false);
+			const int pos = __popcll(__builtin_amdgcn_ballot_w64(lane < kk && mine <= ck)) +
+			                (kk > 64 ? __popcll(__builtin_amdgcn_ballot_w64(64 + lane < kk && mine2 <= ck)) : 0);
+			if (kk > 64) {
+				const unsigned long long carry = cl_lane64(mine, 63);
+				const unsigned long long sh2 = shr1(mine2);
+				const unsigned long long up2 = lane == 0 ? carry : sh2;
+				if (64 + lane == pos)
+					mine2 = ck;
+				else if (64 + lane > pos && 64 + lane < kk)
+					mine2 = up2;
+			}
+			const unsigned long long up = shr1(mine);
 			if (lane == pos)
 				mine = ck;
 			else if (lane > pos && lane < kk)
 				mine = up;
-			worst = cl_lane64(mine, kk - 1);
+			worst = kk > 64 ? cl_lane64(mine2, kk - 65) : cl_lane64(mine, kk - 1);
 		}
 	}
 	if (lane < kk) {
 		const bool have = mine != EMPTY;
 		pd1[q * kk + lane] = have ? bkey2f<IS_L2>((unsigned)(mine >> 32)) : (IS_L2 ? FLT_MAX : -FLT_MAX);
 		pi1[q * kk + lane] = have ? (int)(unsigned)mine : -1;
+	}
+	if (64 + lane < kk) {
+		const bool have = mine2 != EMPTY;
+		pd1[q * kk + 64 + lane] = have ? bkey2f<IS_L2>((unsigned)(mine2 >> 32)) : (IS_L2 ? FLT_MAX : -FLT_MAX);
+		pi1[q * kk + 64 + lane] = have ? (int)(unsigned)mine2 : -1;
 	}
 }
 

@@ -853,11 +853,15 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
                                       const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map,
                                       int64_t out_off, const TieFlags *flp, hipStream_t st, bool defer, bool *overflow) {
 	*overflow = false;
+	if (flp) // (a second pass must not see the tie flags the first one recorded from a truncated candidate set)
+		MVS_HIP(hipMemsetAsync(flp->count, 0, sizeof(int), st));
 	// 128 < d <= 1024: only the coarse filter exists (csrc/flat_collect_wide.hip; no bf16x3 behind it)
 	const bool wide = collect_store_dims(d) > 128;
 	// (16 < d <= 32: the coarse filter only, as for the wide stores)
 	const bool cl_only = wide || !prefilter_supported(geom);
-	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !collect_supported(geom)) || kk > 40)
+	// (lists beyond 40: only the coarse filter of the d <= 128 store, up to 128 -- four subsets of 32 row classes, round 4)
+	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !collect_supported(geom)) ||
+	    kk > std::max(40, cl_k32 ? collect_max_k(d) : 16))
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
@@ -894,8 +898,8 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		if (!collected)
 			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 	}
-	if (!collected && (has_sel || nq < 20 || cl_only))
-		return false; // (stream overflow under a selector / in the per-pair branch: the exact kernels take the batch)
+	if (!collected && (has_sel || nq < 20 || cl_only || kk > 40))
+		return false; // (stream overflow under a selector / in the per-pair branch / beyond the bf16x3 lists: the exact kernels take the batch)
 	if (!collected) {
 	// candidates per query (<= 64: one lane each in the proof).  The margin sets how often a query cannot be proven: at the
 	// headline (N = 10M, d = 128) 5 spare ranks leave ~3 of 10 000 queries to the exact kernel, 8 spare ranks ~none
