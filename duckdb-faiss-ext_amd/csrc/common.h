@@ -226,6 +226,10 @@ void launch_ivf_mf_to_csr(int64_t *d_I, int64_t total, const int *d_perm_mf, hip
 void launch_ivf_finish(int metric, const float *d_pd, const int64_t *d_pi, int64_t nq, int kx, int k, const int64_t *d_rowids,
                        const int64_t *d_idmap_out, float *d_D, int64_t *d_I, int *d_flag /* [1 + nq] */, hipStream_t st);
 bool ivf_tie_pass_fits(int d, int64_t k); // A_k of a flagged query fits the tie pass's LDS
+void launch_ivf_tie_emit(int metric, const int *d_flag, int nf, const float *d_x, int d, const float *d_T, int k,
+                         const int64_t *d_coarse, int np, const int64_t *d_list_off, const float *d_codes, int dp,
+                         const int64_t *d_rowids, SelectorDev sel, const int64_t *d_idmap_sel, float *d_emit_v, int64_t *d_emit_id,
+                         int *d_emit_p, hipStream_t st);
 void launch_ivf_tie_pass(int metric, const int *d_flag, int64_t nq, const float *d_x, int d, const float *d_pd, int kx, int k,
                          const int64_t *d_coarse, int np, const int64_t *d_list_off, const float *d_codes, int dp,
                          const int64_t *d_rowids, SelectorDev sel, const int64_t *d_idmap_sel, const int64_t *d_idmap_out,

@@ -354,8 +354,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	if (r_end > a.n)
 		r_end = a.n;
 	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + CL_SUB * CL_BN - 1) / (CL_SUB * CL_BN)) : 0; // staged blocks
-	if (tid == 0)
+	if (tid == 0) {
 		qctl[0] = 0u;
+		qctl[7] = 0u; // candidates counted after the stream filled up
+	}
 
 	// the wave's 128 queries = 8 column blocks of 16; block cb = 2 t + i belongs to "tile" t; lane (hq, c) sees query
 	// qw + 16 cb + c in every block and OWNS (bound refresh) the two blocks of t = hq
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			const int g = duty_g0 + u;
 			return g < 64 ? 15 : (g < 256 ? 63 : 255);
 		}
-		return duty_bits == 0 ? 63 : (duty_bits == 1 ? 15 : 127);
+		return duty_bits == 0 ? (NC > 32 ? 255 : 63) : (duty_bits == 1 ? 15 : 127); // (128 classes: four networks per derivation)
 	};
 	const int duty_phase = split * 13 + 5;
 	auto dma_bounds = [&]() {
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// the lane's two bounds of tile t: cqtab[wave][t][c][0..1]
 	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 64 + c) * 8);
 
+	int ovf = 0; // (uniform) set at a flush that found the stream full: the rare path then only counts
 	// Rare path of half a 32-query tile (row block rb; sv holds s of its 4 rows x 2 queries per lane): every passing row is
 	// published to its class slot (16 classes: row & 15) and appended.  Lane (hq, c): rows 16 rb + 4 hq + r, queries of column
 	// blocks 2 t + i.
@@ -479,7 +482,13 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				typedef __attribute__((address_space(1))) unsigned *GU;
 				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
-				if (COLLECT) {
+				if (COLLECT && ovf) {
+					// the stream is full: whatever is appended now is dropped, but the host wants the TRUE number of candidates (it sizes
+					// the next attempt from it) -- count, do not queue.  (All-duplicates data, 31 250 copies of every query's nearest row:
+					// 3e8 candidates through the queue's overflow branch took 47 s per launch.)
+					const unsigned one = 1u;
+					asm volatile("ds_add_u32 %0, %1" ::"v"(qcnt_lds + 28u), "v"(one) : "memory");
+				} else if (COLLECT) {
 					unsigned pos;
 					const unsigned one = 1u;
 					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
@@ -705,14 +714,14 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 					if ((long long)(base + i) < a.stream_cap)
 						a.stream[base + i] = qbuf[i];
 				__syncthreads();
-				// The stream holds twice what it can take: this scan's result is lost anyway (the host grows the stream, drops the
-				// heavy queries or hands the batch to the exact kernels) -- stop feeding it.  On all-duplicates data (64 distinct
-				// vectors, N = 2 M: 31 250 copies of every query's nearest row) a scan that ran to its end pushed 3e8 candidates
-				// through the slot atomics and the overflow branch: 47 s per launch (profiles/r4_alldup_kstats.txt).
-				if ((long long)base > 2 * a.stream_cap)
-					break;
+				ovf |= __builtin_amdgcn_readfirstlane((long long)(base + n) >= a.stream_cap ? 1 : 0); // (a scalar: no register of the hot loop)
 			}
 		}
+	}
+	if (COLLECT && ovf) {
+		__syncthreads();
+		if (tid == 0 && qctl[7] != 0u)
+			atomicAdd(a.stream_cnt, (unsigned long long)qctl[7]);
 	}
 }
 
@@ -1089,8 +1098,12 @@ static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t
 
 // row classes per query: 16, or 32 for 16 < kk <= 32 (d <= 128 only: the wide instances keep 16)
 int g_cl_nc32_from = 17; // option cl_nc32_from
-int collect_slot_stride(int kk) {
-	return kk > 32 ? 128 : ((kk > 16 || kk >= g_cl_nc32_from) ? 32 : 16);
+// (headline shape: kk = 32 on 32 classes admits 1 269 candidates per query -- the bound is the WORST class best --, on 4 x 32 classes 512;
+// but the 128-class instance's derivation is four networks and its scan ran 23.7 vs 23.2 ms there, 23.4 vs 20.3 at kk = 25: from 33 on)
+int collect_slot_stride(int kk, int dp1) {
+	if (dp1 == 128 && kk > 28) // (with the derivation every 256 blocks: kk = 33 on 4 x 32 classes 21.0 ms, kk = 32 on 32 classes 23.3)
+		return 128;
+	return (kk > 16 || kk >= g_cl_nc32_from) ? 32 : 16;
 }
 int collect_max_k(int d) {
 	const int dp1 = collect_store_dims(d);
@@ -1107,7 +1120,7 @@ int collect_max_k(int d) {
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
                             unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st) {
-	const int stride = collect_slot_stride(kk); // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
+	const int stride = collect_slot_stride(kk, collect_store_dims(g.d)); // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
 	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, stride,
 	                   0 /* larger s is better */);
@@ -1134,7 +1147,10 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 			launch_collect_seed(metric, a, rows, nq, st);
 		return;
 	}
-	const int64_t seed = std::min<int64_t>(n, std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
+	// (lists beyond 16: the bound is the kk-th best of the class bests, so the sample must grow with kk or the main scan starts with
+	// a bound that admits whole percents of the rows -- kk = 65 on 2 048 seed rows of a 150 000-row index: > 4 096 candidates per query)
+	const int64_t kscale = std::max(1, kk / 16);
+	const int64_t seed = std::min<int64_t>(n, kscale * std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	if (seed > 0 && seed < n) {
 		if (dp1 > 128)
 			launch_collect_wide_range(dp1, metric, false, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
@@ -1155,7 +1171,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.yn = d_norms;
 	a.e2 = d_e2;
 	a.gslot = d_gslot;
-	a.slot_stride = collect_slot_stride(kk);
+	a.slot_stride = collect_slot_stride(kk, collect_store_dims(g.d));
 	a.nclass = kk;
 	a.nq = (int)nq;
 	a.stream = d_stream;

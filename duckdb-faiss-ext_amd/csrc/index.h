@@ -100,6 +100,11 @@ public:
 	// search on behalf of an IndexIDMap wrapper: selector tests d_idmap[internal], labels = d_idmap[internal]
 	virtual void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
 	                           const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) = 0;
+	// IVF row shard of a ShardedIndex: for the flagged queries of the LAST search (d_flag = {count, queries...}; the coarse assignment
+	// of that search is still in place) this shard's first k rows not worse than T[f] in arrival order -- value, stored id, probe
+	// rank, -1 padded (csrc/ivf_ties.hip EMIT mode)
+	virtual void tie_emit(const int *d_flag, int nf, const float *d_x, const float *d_T, int64_t k, const mvs_search_params *params,
+	                      const int64_t *d_idmap_sel, float *d_v, int64_t *d_id, int *d_p, hipStream_t st);
 	virtual void to_device(int new_device) = 0;
 	virtual IndexBase *clone(int on_device) = 0; // deep copy living on `on_device`
 	virtual void to_host(HostIndex &out) = 0;    // host image (write_index, cross-device clone)
@@ -199,6 +204,7 @@ public:
 	int64_t cl_deferred_cap = 0;
 	bool cl_defer = true; // option cl_defer_count
 	double cl_est_per_query = 0; // candidates per query of the last search (+ 30 %): the size the next search's sort is launched with
+	int cl_skip = 0, cl_skip_len = 0; // searches that bypass the coarse filter after it gave up on this index's data (doubling, <= 64)
 	void drop_bf16_rows();
 	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
 	                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
@@ -328,7 +334,7 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
                                  hipStream_t st);
 void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st);
-int collect_slot_stride(int kk);
+int collect_slot_stride(int kk, int dp1 = 128); // class slots per query: 16 | 32 | 128 (d <= 128 store only)
 int collect_max_k(int d); // largest k (+1 with tie detection) the coarse filter serves at this d: 32 (d <= 128), 16, or 0
 int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int64_t nq, int share, int *d_qcount, float *d_e2,
                               int *d_fail_cnt, int *d_fail_q, hipStream_t st);

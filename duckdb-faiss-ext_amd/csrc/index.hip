@@ -190,6 +190,10 @@ void IndexBase::search(int64_t nq, const float *x, int64_t k, float *D, int64_t 
 	pinned.release(slot, stream);
 }
 
+void IndexBase::tie_emit(const int *, int, const float *, const float *, int64_t, const mvs_search_params *, const int64_t *, float *,
+                         int64_t *, int *, hipStream_t) {
+	throw_faiss("mvs::IndexBase::tie_emit", __FILE__, "not an IVF row shard");
+}
 void IndexBase::begin_kernel_timing(hipStream_t st) {
 	if (!timing_enabled)
 		return;
@@ -398,7 +402,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_e2.reserve((size_t)nq128 * sizeof(float));
 	MVS_HIP(hipMemsetAsync(ws_e2.p, 0xff, (size_t)nq128 * sizeof(float), st)); // NaN: the slots behind the last query
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
-	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk) * sizeof(unsigned) + 64);
+	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk, collect_store_dims(d)) * sizeof(unsigned) + 64);
 	// candidate stream: 4096 entries per query to start with (option cl_stream_cap; at least 2^20), or what the last overflow
 	// showed this index's data to need (cl_cap_hint, up to 16384 per query: clustered rows with large norms admit thousands)
 	int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024)
@@ -413,7 +417,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st);
 	int grid = 0, nsplit = 0, lds = 0;
-	const bool few = !wide && nq <= 128 && collect_slot_stride(kk) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
+	const bool few = !wide && nq <= 128 && collect_slot_stride(kk, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
 	for (int attempt = 0;; ++attempt) {
 	begin_kernel_timing(st);
@@ -723,7 +727,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	// L2 + selector, or a small batch (FAISS's per-pair branch, nq < 20) on a large database: the bf16 coarse filter masks by
 	// the selector and re-scores its candidates with the per-pair arithmetic FAISS uses there (csrc/flat_collect.hip); same
 	// results as the packed scan / staged kernels
-	if (((has_sel && metric == METRIC_L2) || small_batch) && !force_direct && !force_staged &&
+	// (inner product + selector beyond the fused kernel's LDS lists -- k in the dozens and above -- likewise, instead of the per-pair scan)
+	if (((has_sel && (metric == METRIC_L2 || !ip_on_mfma)) || small_batch) && !force_direct && !force_staged &&
 	    search_prefilter(nq, d_x, k_user, k, d_D, d_I, params, d_idmap, out_map, out_off, flp, st)) {
 		// handled
 	} else if (direct) {
@@ -893,10 +898,22 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	// Coarse filter (one bf16 product per pair, candidates by a proven bound): mode 2 forces it, auto prefers it where
 	// its kernel exists (d = 128 geometry, lists of <= 16); on a stream overflow the bf16x3 path below takes the batch
 	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax) {
-		kp = (int)kk;
-		collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer);
-		if (!collected)
-			MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+		// Data on which the filter gave up (every query sits on thousands of copies of its nearest row: two scans that only count,
+		// then the exact kernels anyway) is not asked again at once: the next 4, 8, ... 64 large searches of this index go straight to
+		// the fall-back (all-duplicates, N = 2 M: 1.3 s per batch with the two futile scans, 0.07 s without)
+		if (cl_skip > 0 && nq >= 20 && !has_sel && !cl_only && kk <= 40) {
+			--cl_skip;
+		} else {
+			kp = (int)kk;
+			collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer);
+			if (!collected) {
+				MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+				cl_skip_len = std::min(64, std::max(4, 2 * cl_skip_len));
+				cl_skip = cl_skip_len;
+			} else if (!defer) {
+				cl_skip_len = 0;
+			}
+		}
 	}
 	if (!collected && (has_sel || nq < 20 || cl_only || kk > 40))
 		return false; // (stream overflow under a selector / in the per-pair branch / beyond the bf16x3 lists: the exact kernels take the batch)

@@ -641,6 +641,26 @@ public:
 	}
 
 	// ---------------------------------------------------------------------------------------------- search
+	// row shard of a ShardedIndex: A_k of the flagged queries of the last search (csrc/ivf_ties.hip EMIT mode)
+	int64_t last_np = 0;
+	void tie_emit(const int *d_flag, int nf, const float *d_x, const float *d_T, int64_t k, const mvs_search_params *params,
+	              const int64_t *d_idmap_sel, float *d_v, int64_t *d_id, int *d_p, hipStream_t st) override {
+		use_device();
+		if (nf <= 0)
+			return;
+		stream_wait(stream, st);
+		if (ntotal == 0 || last_np <= 0) {
+			MVS_HIP(hipMemsetAsync(d_id, 0xff, (size_t)nf * k * sizeof(int64_t), stream));
+			MVS_HIP(hipMemsetAsync(d_p, 0xff, (size_t)nf * k * sizeof(int), stream));
+			MVS_HIP(hipMemsetAsync(d_v, 0, (size_t)nf * k * sizeof(float), stream));
+		} else {
+			build_lists();
+			SelectorDev tsel = selector.upload(params, stream);
+			launch_ivf_tie_emit(metric, d_flag, nf, d_x, d, d_T, (int)k, (const int64_t *)ws_cI.p, (int)last_np, (const int64_t *)list_off_dev.p,
+			                    (const float *)codes.p, dp, (const int64_t *)rowids.p, tsel, d_idmap_sel, d_v, d_id, d_p, stream);
+		}
+		stream_wait(st, stream);
+	}
 	void search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                   const int64_t *d_idmap, hipStream_t st) override {
 		use_device();
@@ -653,6 +673,7 @@ public:
 		if (np <= 0)
 			throw_faiss("virtual void faiss::IndexIVF::search(...) const", "faiss/IndexIVF.cpp",
 			            "Error: 'nprobe > 0' failed");
+		last_np = np;
 		// our stream carries the adds / list build; the caller's stream carries the queries
 		stream_wait(stream, st);
 		if (ntotal == 0) { // trained but empty: every heap stays at its neutral value

@@ -94,7 +94,12 @@ __global__ __launch_bounds__(256) void ivf_tie_pass_kernel(const int *__restrict
                                                           const long long *__restrict__ rowids, SelectorDev sel,
                                                           const long long *__restrict__ idmap_sel,
                                                           const long long *__restrict__ idmap_out, float *__restrict__ D,
-                                                          long long *__restrict__ I) {
+                                                          long long *__restrict__ I, const float *__restrict__ T_ext,
+                                                          float *__restrict__ emit_v, long long *__restrict__ emit_id,
+                                                          int *__restrict__ emit_p) {
+	// EMIT mode (emit_v != null; row shards, csrc/sharded.hip): T comes from the CROSS-SHARD merge (T_ext[f]) and the kernel only
+	// reports this shard's A_k -- value, stored id (= global row) and probe rank of its first k rows not worse than T in arrival
+	// order -- for the host to merge by (probe rank, global row) and to apply the closed form on.
 	extern __shared__ __attribute__((aligned(16))) float tp_sm[];
 	const int dpad = (d + 3) & ~3, kpad = (k + 1) & ~1;
 	float *xs = tp_sm;                          // [dpad]
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(256) void ivf_tie_pass_kernel(const int *__restrict
 	long long *aid = (long long *)(av + kpad);  // [k]     stored ids of A_k
 	int *ctl = (int *)(aid + k);                // [0] |A| so far, [1..4] per-wave counts, [5] rows better than T in the pure list,
 	                                            // [6] in A_k, [7] tied rows in A_k
+	int *ap = ctl + 8;                          // [k]     probe rank of the entries of A_k (EMIT mode)
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 	const int nflag = *flag_cnt;
 	for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
@@ -111,10 +117,10 @@ __global__ __launch_bounds__(256) void ivf_tie_pass_kernel(const int *__restrict
 			xs[t] = x[q * d + t];
 		if (tid < 8)
 			ctl[tid] = 0;
-		const float T = pd[q * kx + k - 1];
+		const float T = T_ext ? T_ext[f] : pd[q * kx + k - 1];
 		__syncthreads();
 		// rows strictly better than T in the pure top-k (all of them are there: fewer than k exist)
-		for (int t = tid; t < k; t += 256)
+		for (int t = tid; t < k && !emit_v; t += 256)
 			if (IS_L2 ? pd[q * kx + t] < T : pd[q * kx + t] > T)
 				atomicAdd(&ctl[5], 1);
 		bool full = false;
@@ -172,6 +178,8 @@ __global__ __launch_bounds__(256) void ivf_tie_pass_kernel(const int *__restrict
 				if (ok && pos < k) {
 					av[pos] = val;
 					aid[pos] = id;
+					if (emit_v)
+						ap[pos] = p;
 				}
 				const int tot = ctl[0] + ctl[1] + ctl[2] + ctl[3] + ctl[4];
 				__syncthreads();
@@ -182,6 +190,14 @@ __global__ __launch_bounds__(256) void ivf_tie_pass_kernel(const int *__restrict
 		}
 		__syncthreads();
 		const int na = ctl[0] < k ? ctl[0] : k;
+		if (emit_v) {
+			for (int t = tid; t < k; t += 256) {
+				emit_v[(size_t)f * k + t] = t < na ? av[t] : 0.f;
+				emit_id[(size_t)f * k + t] = t < na ? aid[t] : -1ll;
+				emit_p[(size_t)f * k + t] = t < na ? ap[t] : -1;
+			}
+			continue;
+		}
 		for (int t = tid; t < na; t += 256) {
 			if (av[t] == T)
 				atomicAdd(&ctl[7], 1);
@@ -255,7 +271,7 @@ void launch_ivf_finish(int metric, const float *d_pd, const int64_t *d_pi, int64
 // the tie pass keeps the query (d floats) and A_k (k values + k ids) of a flagged query in LDS
 static size_t ivf_tie_pass_lds(int d, int k) {
 	const int dpad = (d + 3) & ~3, kpad = (k + 1) & ~1;
-	return (size_t)(dpad + kpad) * 4 + (size_t)k * 8 + 64;
+	return (size_t)(dpad + kpad) * 4 + (size_t)k * 8 + 64 + (size_t)k * 4;
 }
 bool ivf_tie_pass_fits(int d, int64_t k) {
 	return k < ((int64_t)1 << 24) && ivf_tie_pass_lds(d, (int)k) <= 150 * 1024;
@@ -277,14 +293,44 @@ void launch_ivf_tie_pass(int metric, const int *d_flag, int64_t nq, const float 
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_flag, d_flag + 1, d_x, d, d_pd, kx, k,
 		                   (const long long *)d_coarse, np, (const long long *)d_list_off, d_codes, dp,
 		                   (const long long *)d_rowids, sel, (const long long *)d_idmap_sel, (const long long *)d_idmap_out, d_D,
-		                   (long long *)d_I);
+		                   (long long *)d_I, nullptr, nullptr, nullptr, nullptr);
 	} else {
 		auto kern = ivf_tie_pass_kernel<false>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_flag, d_flag + 1, d_x, d, d_pd, kx, k,
 		                   (const long long *)d_coarse, np, (const long long *)d_list_off, d_codes, dp,
 		                   (const long long *)d_rowids, sel, (const long long *)d_idmap_sel, (const long long *)d_idmap_out, d_D,
-		                   (long long *)d_I);
+		                   (long long *)d_I, nullptr, nullptr, nullptr, nullptr);
+	}
+	MVS_HIP(hipGetLastError());
+}
+
+// EMIT mode for a row shard: d_flag = {count, queries...} of the flagged queries, d_T their boundary values from the cross-shard
+// merge; out: [nf][k] value / stored id / probe rank of this shard's first k rows not worse than T in arrival order (-1 padded)
+void launch_ivf_tie_emit(int metric, const int *d_flag, int nf, const float *d_x, int d, const float *d_T, int k,
+                         const int64_t *d_coarse, int np, const int64_t *d_list_off, const float *d_codes, int dp,
+                         const int64_t *d_rowids, SelectorDev sel, const int64_t *d_idmap_sel, float *d_emit_v, int64_t *d_emit_id,
+                         int *d_emit_p, hipStream_t st) {
+	if (nf <= 0)
+		return;
+	const size_t lds = ivf_tie_pass_lds(d, k);
+	if (lds > 150 * 1024)
+		throw_faiss(__func__, __FILE__, "IVF tie pass: k = %d too large", k);
+	const unsigned grid = (unsigned)std::min<int>(nf, 2048);
+	if (metric_order(metric) == METRIC_L2) {
+		auto kern = ivf_tie_pass_kernel<true>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_flag, d_flag + 1, d_x, d, (const float *)nullptr, k + 1, k,
+		                   (const long long *)d_coarse, np, (const long long *)d_list_off, d_codes, dp, (const long long *)d_rowids, sel,
+		                   (const long long *)d_idmap_sel, (const long long *)nullptr, (float *)nullptr, (long long *)nullptr, d_T,
+		                   d_emit_v, (long long *)d_emit_id, d_emit_p);
+	} else {
+		auto kern = ivf_tie_pass_kernel<false>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_flag, d_flag + 1, d_x, d, (const float *)nullptr, k + 1, k,
+		                   (const long long *)d_coarse, np, (const long long *)d_list_off, d_codes, dp, (const long long *)d_rowids, sel,
+		                   (const long long *)d_idmap_sel, (const long long *)nullptr, (float *)nullptr, (long long *)nullptr, d_T,
+		                   d_emit_v, (long long *)d_emit_id, d_emit_p);
 	}
 	MVS_HIP(hipGetLastError());
 }

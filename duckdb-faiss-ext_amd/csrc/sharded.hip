@@ -329,8 +329,11 @@ public:
 				shards.push_back(index_factory(d, mode == REPLICAS ? desc.c_str() : inner.c_str(), metric));
 				if (mode == ROWS_FLAT)
 					shards.back()->set_option("raw_rows", 1);
-				if (mode == ROWS_IVF)
+				if (mode == ROWS_IVF) {
 					shards.back()->set_option("ivf_raw_ids", 1);
+					// exact distance ties are resolved ACROSS the shards (resolve_ties_ivf): a shard hands over its pure (value, id) order
+					shards.back()->set_option("ivf_exact_ties", 0);
+				}
 			}
 		} catch (...) {
 			for (auto *s : shards)
@@ -630,7 +633,11 @@ public:
 	                 const mvs_search_params *params, float *D, int64_t *I, float *d_D, int64_t *d_I, const float *x_pageable) {
 		const bool is_l2 = metric_order(metric) == METRIC_L2;
 		// inner product: one extra candidate per list detects an exact tie at the k-th score (FlatIndex::search_flat)
-		const bool tie_detect = metric == METRIC_IP && mode == ROWS_FLAT && ntotal > k && k + 1 <= 256;
+		// (k >= 100: FAISS's reservoir, whose outcome depends on the global interleaving of the shards' rows -- pure order there)
+		// IVF row shards (round 4): FAISS's heap sees the probed lists' rows in ARRIVAL order (probe rank, position in the list); the
+		// shards hand over k + 1 entries in the pure order and the queries tied at the k-th value take resolve_ties_ivf
+		const bool ivf_ties = mode == ROWS_IVF && ivf_exact_ties && ntotal > k && k + 1 <= 1024;
+		const bool tie_detect = (metric == METRIC_IP && mode == ROWS_FLAT && ntotal > k && k + 1 <= 256 && k < 100) || ivf_ties;
 		const int64_t kk = tie_detect ? k + 1 : k;
 		const size_t cells = (size_t)nq * kk, ocells = (size_t)nq * k;
 		const bool use_rccl = exchange == 1 && ensure_comms();
@@ -734,7 +741,10 @@ public:
 			Dp = Dt.data();
 			Ip = It.data();
 		}
-		resolve_ties(flagged, x_pageable, k, kk, mv, mg, params, Dp, Ip);
+		if (ivf_ties)
+			resolve_ties_ivf(flagged, x_pageable, k, kk, mv, mg, params, Dp, Ip);
+		else
+			resolve_ties(flagged, x_pageable, k, kk, mv, mg, params, Dp, Ip);
 		if (!D) {
 			MVS_HIP(hipMemcpy(w0.oD.p, Dt.data(), ocells * sizeof(float), hipMemcpyHostToDevice));
 			MVS_HIP(hipMemcpy(w0.oI.p, It.data(), ocells * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -866,6 +876,126 @@ public:
 		}
 	}
 
+	// Cross-shard tie pass of a row-sharded IVF index.  FAISS's single heap would have been fed the probed lists in probe order,
+	// each list front to back; a list's rows are spread over the shards, every shard holding a subsequence in insertion order with
+	// GLOBAL row numbers as stored ids -- so the arrival key of a row is (probe rank of its list, global row).  Every shard reports,
+	// per flagged query, its first k rows not worse than T in that order (IndexBase::tie_emit: the shard's coarse assignment of this
+	// batch is still in place and is the same on every shard); the first k of the union are A_k, and the closed form of
+	// csrc/ivf_ties.hip decides: result = {rows better than T} + {tied rows of A_k minus the G extreme ids}, G = #(rows better
+	// than T outside A_k) -- the LARGEST ids go for L2 (CMax root), the smallest for inner product.
+	bool ivf_exact_ties = true; // option ivf_exact_ties on the sharded handle: 0 = pure (value, id) order across shards
+	void resolve_ties_ivf(const std::vector<int64_t> &flagged, const float *x, int64_t k, int64_t kk, const std::vector<float> &mv,
+	                      const std::vector<int64_t> &mg, const mvs_search_params *params, float *D, int64_t *I) {
+		const int64_t nf = (int64_t)flagged.size();
+		const bool is_l2 = metric_order(metric) == METRIC_L2;
+		std::vector<int> hflagq((size_t)nf + 1);
+		std::vector<float> T((size_t)nf);
+		hflagq[0] = (int)nf;
+		for (int64_t f = 0; f < nf; ++f) {
+			hflagq[(size_t)f + 1] = (int)flagged[(size_t)f];
+			T[(size_t)f] = mv[(size_t)flagged[(size_t)f] * kk + k - 1];
+		}
+		struct Emit {
+			std::vector<float> v;
+			std::vector<int64_t> id;
+			std::vector<int> p;
+		};
+		std::vector<Emit> em((size_t)G);
+		on_all([&](int g) {
+			IndexBase *sh = shards[g];
+			sh->use_device();
+			hipStream_t st = streams[g];
+			Scratch &w = sc[g];
+			const size_t cells = (size_t)nf * k;
+			const size_t t_b = ((size_t)nf * sizeof(float) + 255) & ~(size_t)255, id_b = (cells * sizeof(int64_t) + 255) & ~(size_t)255,
+			             v_b = (cells * sizeof(float) + 255) & ~(size_t)255;
+			w.T.reserve(t_b + ((size_t)nf + 1) * sizeof(int) + 256);
+			w.rows.reserve(id_b + v_b + cells * sizeof(int) + 256);
+			float *dT = (float *)w.T.p;
+			int *dflag = (int *)((char *)w.T.p + t_b);
+			int64_t *did = (int64_t *)w.rows.p;
+			float *dv = (float *)((char *)w.rows.p + id_b);
+			int *dp = (int *)((char *)w.rows.p + id_b + v_b);
+			MVS_HIP(hipMemcpyAsync(dT, T.data(), (size_t)nf * sizeof(float), hipMemcpyHostToDevice, st));
+			MVS_HIP(hipMemcpyAsync(dflag, hflagq.data(), ((size_t)nf + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+			// the batch's queries up to the last flagged one (the kernel indexes them by query number)
+			const int64_t nqx = flagged.back() + 1;
+			DevBuf xtmp;
+			xtmp.reserve((size_t)nqx * d * sizeof(float));
+			MVS_HIP(hipMemcpyAsync(xtmp.p, x, (size_t)nqx * d * sizeof(float), hipMemcpyHostToDevice, st));
+			const float *xq = (const float *)xtmp.p;
+			sh->tie_emit(dflag, (int)nf, xq, dT, k, params, has_idmap ? idmap_dev[g].p : nullptr, dv, did, dp, st);
+			em[g].v.resize(cells);
+			em[g].id.resize(cells);
+			em[g].p.resize(cells);
+			MVS_HIP(hipMemcpyAsync(em[g].v.data(), dv, cells * sizeof(float), hipMemcpyDeviceToHost, st));
+			MVS_HIP(hipMemcpyAsync(em[g].id.data(), did, cells * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+			MVS_HIP(hipMemcpyAsync(em[g].p.data(), dp, cells * sizeof(int), hipMemcpyDeviceToHost, st));
+			MVS_HIP(hipStreamSynchronize(st));
+		});
+		struct Ent {
+			int p;
+			int64_t id;
+			float v;
+		};
+		for (int64_t f = 0; f < nf; ++f) {
+			const int64_t q = flagged[(size_t)f];
+			const float Tq = T[(size_t)f];
+			std::vector<Ent> all;
+			for (int g = 0; g < G; ++g)
+				for (int64_t j = 0; j < k; ++j) {
+					const size_t c = (size_t)f * k + j;
+					if (em[g].id[c] >= 0)
+						all.push_back({em[g].p[c], em[g].id[c], em[g].v[c]});
+				}
+			std::sort(all.begin(), all.end(), [](const Ent &a, const Ent &b) { return a.p != b.p ? a.p < b.p : a.id < b.id; });
+			if ((int64_t)all.size() > k)
+				all.resize((size_t)k); // A_k
+			// rows strictly better than T: all of them are in the merged pure list (fewer than k exist)
+			std::vector<std::pair<float, int64_t>> res;
+			for (int64_t j = 0; j < k; ++j) {
+				const float v = mv[(size_t)q * kk + j];
+				const int64_t gid = mg[(size_t)q * kk + j];
+				if (gid >= 0 && (is_l2 ? v < Tq : v > Tq))
+					res.push_back({v, gid});
+			}
+			const int64_t nbetter = (int64_t)res.size();
+			int64_t in_ak = 0;
+			std::vector<int64_t> tied;
+			for (const Ent &e : all) {
+				if (is_l2 ? e.v < Tq : e.v > Tq)
+					++in_ak;
+				else if (e.v == Tq)
+					tied.push_back(e.id);
+			}
+			const int64_t Gev = nbetter - in_ak;
+			std::sort(tied.begin(), tied.end());
+			const int64_t nt = (int64_t)tied.size();
+			// L2: the Gev largest ids are evicted, ascending id; inner product: the Gev smallest, printed in descending id
+			if (is_l2) {
+				for (int64_t t = 0; t < nt - Gev; ++t)
+					res.push_back({Tq, tied[(size_t)t]});
+			} else {
+				for (int64_t t = nt - 1; t >= Gev; --t)
+					res.push_back({Tq, tied[(size_t)t]});
+				// (the better part came out of the pure order -- score desc, id asc: equal scores print in descending id)
+				int64_t a = 0;
+				while (a < nbetter) {
+					int64_t b = a + 1;
+					while (b < nbetter && res[(size_t)b].first == res[(size_t)a].first)
+						++b;
+					std::reverse(res.begin() + a, res.begin() + b);
+					a = b;
+				}
+			}
+			for (int64_t j = 0; j < k; ++j) {
+				const bool have = j < (int64_t)res.size();
+				D[q * k + j] = have ? res[(size_t)j].first : (is_l2 ? FLT_MAX : -FLT_MAX);
+				I[q * k + j] = have ? to_label(res[(size_t)j].second) : -1;
+			}
+		}
+	}
+
 	bool ensure_comms() {
 		if (!comms.empty())
 			return true;
@@ -977,6 +1107,10 @@ public:
 	bool set_option(const char *key, int64_t v) override {
 		if (!strcmp(key, "shard_exchange")) { // 0 = host gather, 1 = rccl all-gather
 			exchange = (int)v;
+			return true;
+		}
+		if (!strcmp(key, "ivf_exact_ties") && mode == ROWS_IVF) { // across shards (the shards themselves keep the pure order)
+			ivf_exact_ties = v != 0;
 			return true;
 		}
 		bool any = false;

@@ -306,11 +306,15 @@ def test_small_batch_large_k_on_the_fused_kernel(mf):
     xb, xq = _data(300000, 24, 64, seed=5, center=True)
     for metric, k in ((L2, 80), (IP, 64)):
         ix = mf.index_factory(64, "Flat", metric)
+        ix.set_option("prefilter", 0)  # (since round 4 the coarse filter serves k <= 128 at this size: keep the fused kernel under test)
         ix.add(xb)
         D, I = ix.search(xq, k)
         assert ix.last_kernel_info()["name"] == "flat_mfma_kernel"
         Do, Io = orc.flat_search(metric, xb, xq, k)
         assert_same_results(D, I, Do, Io, metric == L2, what=f"small batch large k m={metric}")
+        ix.set_option("prefilter", -1)  # ... and the default route (24 queries, k = 64 / 80: the coarse filter) agrees
+        D2, I2 = ix.search(xq, k)
+        assert_same_results(D2, I2, Do, Io, metric == L2, what=f"small batch large k m={metric}, default route")
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
