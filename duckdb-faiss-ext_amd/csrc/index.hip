@@ -1951,6 +1951,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_ivf_cl_refresh = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "ivf_cl_xcd")) { // IVF coarse filter: items of one list on one XCD (1) or dealt round-robin over the XCDs (0)
+		g_ivf_cl_xcd = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "ivf_coarse_select")) { // IVF coarse quantiser: distance matrix + selection (1) or the k-list kernels (0)
 		g_coarse_select = v != 0;
 		return true;

@@ -26,6 +26,7 @@
 #include <cstring>
 
 namespace mvs {
+int g_ivf_cl_xcd = 1; // option ivf_cl_xcd: items of one list on one XCD (1) or dealt round-robin (0, round 3)
 extern int g_cl_bound_mode; // csrc/flat_collect.hip: bf16 rounding term of the bounds from the actual residual norms (1) | worst case (0)
 
 typedef __bf16 bf16x8i __attribute__((ext_vector_type(8)));
@@ -56,6 +57,7 @@ struct IvfCollectArgs {
 	int collect;  // 0: bound estimation only (publish to the slots, append nothing)
 	int refresh;  // tiles between two refreshes of the bounds after the first (option ivf_cl_refresh; 0: 1, 1, 1, 1, 4, 4 ... 16)
 	const unsigned *rowmask; // IDSelector active: bit r of word w = padded row 32 w + r is accepted (nullptr: no selector)
+	int xcd_map; // 1: XCD j (= blockIdx.x & 7) takes the contiguous item range [j n/8, (j+1) n/8) (option ivf_cl_xcd)
 };
 
 __device__ __forceinline__ unsigned ic_skey(float s) { // "larger s is better" as a smaller-is-better key
@@ -287,9 +289,21 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	int *qtab = (int *)(ctab + 128 * 2);                              // [128]{query number, E (float bits)} of every slot
 	unsigned *qctl = (unsigned *)(qtab + 128 * 2);                    // [0] queue fill
 
-	if ((int)blockIdx.x >= *a.nitems_dev)
+	// Items of one list are neighbours in the item table and stream the SAME rows; the dispatcher deals consecutive workgroups
+	// round-robin to the eight XCDs, so with item = blockIdx.x every XCD's L2 fetched the list for itself (PMC, C3's main pass:
+	// 5.08 GB on the memory side for 2.59 GB of list rows).  XCD j now takes the contiguous item range [j n/8, (j+1) n/8):
+	// neighbours run on one XCD at the same time and the second one finds the rows in that L2.
+	const int nitems = *a.nitems_dev;
+	int item = (int)blockIdx.x;
+	if (a.xcd_map) {
+		const int per = (nitems + 7) >> 3, idx = (int)(blockIdx.x >> 3);
+		item = (int)(blockIdx.x & 7u) * per + idx;
+		if (idx >= per)
+			return;
+	}
+	if (item >= nitems)
 		return;
-	const int4 it = a.items[blockIdx.x];
+	const int4 it = a.items[item];
 	const int lane = threadIdx.x;
 	const int hq = lane >> 4, c = lane & 15;
 	const long long r_begin = (long long)it.x + (long long)blockIdx.y * a.seg_rows;
@@ -307,16 +321,16 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	for (int i = 0; i < 2; ++i) {
 		const int slot = 32 * hq + 16 * i + c;
 		own_q[i] = slot < it.w ? a.qidx[it.z + slot] : -1;
-		own_e2[i] = 0.5f * a.ie2[(size_t)blockIdx.x * 128 + slot]; // E of THIS (query, list) pair (inflated, with slack)
+		own_e2[i] = 0.5f * a.ie2[(size_t)item * 128 + slot]; // E of THIS (query, list) pair (inflated, with slack)
 		qtab[2 * slot] = own_q[i];
 		qtab[2 * slot + 1] = __float_as_int(own_e2[i]);
-		ctab[((hq * 16 + c) * 2 + i) * 2 + 1] = a.igamma[(size_t)blockIdx.x * 128 + slot];
+		ctab[((hq * 16 + c) * 2 + i) * 2 + 1] = a.igamma[(size_t)item * 128 + slot];
 	}
 
 	// B fragments, resident: [column block][k-block]
 	bf16x8i bq[8][KB];
 	{
-		const bf16x8i *qsrc = (const bf16x8i *)a.xi + (size_t)blockIdx.x * (8 * 4 * 64);
+		const bf16x8i *qsrc = (const bf16x8i *)a.xi + (size_t)item * (8 * 4 * 64);
 #pragma unroll
 		for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
@@ -597,10 +611,12 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.collect = collect;
 	a.refresh = g_ivf_cl_refresh;
 	a.rowmask = d_rowmask;
+	a.xcd_map = (g_ivf_cl_xcd && max_items >= 64) ? 1 : 0; // (the Flat small-batch path has one or two items: nothing to place)
+	const unsigned gx = (unsigned)max_items + (a.xcd_map ? 8u : 0u);
 	if (kk > 16) // 32 row classes: the caller sized and initialised 32 slots per query (ivf_collect_slot_stride)
-		hipLaunchKernelGGL(ivf_bf16_collect_kernel<32>, dim3(max_items, nseg), dim3(64), 0, st, a);
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<32>, dim3(gx, nseg), dim3(64), 0, st, a);
 	else
-		hipLaunchKernelGGL(ivf_bf16_collect_kernel<16>, dim3(max_items, nseg), dim3(64), 0, st, a);
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<16>, dim3(gx, nseg), dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
 
