@@ -114,12 +114,22 @@ def launch_ranks(gpus, argv, timeout=None):
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    import signal
+
+    # (its own process group: a launch that outlives its time limit is ended as a whole -- launcher and ranks -- by the group id we
+    # created, so that no rank stays behind holding a GPU)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_child_env(), start_new_session=True)
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_child_env(), timeout=timeout)
-    except subprocess.TimeoutExpired as e:
-        return 124, None, "timed out after %s s: %s" % (timeout, str(e.stderr or "")[-300:])
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    return p.returncode, (lines[-1] if lines else None), (p.stderr or "")[-2000:]
+        so, se = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        so, se = p.communicate()
+        return 124, None, "timed out after %s s: %s" % (timeout, (se or "")[-300:])
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    return p.returncode, (lines[-1] if lines else None), (se or "")[-2000:]
 
 
 def secondary_layouts(args, world):
@@ -141,7 +151,7 @@ def secondary_layouts(args, world):
     if world >= 4 and world % 2 == 0 and args.metric == "L2":
         t0 = time.perf_counter()
         try:
-            rc, line, err = launch_ranks(world, ["--gpus", str(world), "--query-groups", "2"] + common, timeout=600)
+            rc, line, err = launch_ranks(world, ["--gpus", str(world), "--query-groups", "2"] + common, timeout=200)
             res["query_groups_2"] = digest(json.loads(line)) if rc == 0 and line else {"error": "rc=%d %s" % (rc, err[-300:])}
         except Exception as ex:  # noqa: BLE001  (a secondary entry must never cost the run its line)
             res["query_groups_2"] = {"error": repr(ex)[:300]}
@@ -149,7 +159,7 @@ def secondary_layouts(args, world):
     t0 = time.perf_counter()
     try:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--inlib-shards", str(world)] + common
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_child_env())
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=200, env=_child_env())
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         res["in_library_sharded_index"] = digest(json.loads(line[-1])) if p.returncode == 0 and line else {"error": (p.stderr or p.stdout)[-300:]}
     except Exception as ex:  # noqa: BLE001
