@@ -124,6 +124,97 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 	}
 }
 
+// ---- the same matrix on the f32 matrix pipe (round 4) ---------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 accumulates D = A B + C over its two k-steps in k order with one rounding per product -- the k-ordered
+// fma chain of the vector-ALU kernel above, bit for bit (csrc/flat_mfma.hip rests on the same property) -- at 4x the vector ALU's
+// issue-bound rate.  A = QUERIES (M), B = CENTROIDS (N): lane l holds A[q = l & 31][k = l >> 5], B[k = l >> 5][c = l & 31] and
+// D[q = 8 g + 4 (l >> 5) + e][c = l & 31] in register 4 g + e, so lanes 0..31 of a register write 32 CONSECUTIVE centroids of one
+// query: 128-byte runs, no transpose.  Workgroup = 128 queries x 128 centroids, wave w = centroid block 32 w .. 32 w + 31 against
+// all four query blocks (64 accumulator registers); operands through LDS in slabs of 16 dims exactly as above.
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void coarse_dist_mfma_kernel(const float *__restrict__ x, long long nq, int d,
+                                                              const float *__restrict__ cent, int sdp, int interleaved, int nlist,
+                                                              const float *__restrict__ qn, const float *__restrict__ cn,
+                                                              int is_l2, float *__restrict__ D) {
+	__shared__ __attribute__((aligned(16))) float xs[16][128 + 4];
+	__shared__ __attribute__((aligned(16))) float ys[16][128 + 4];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
+	const long long q0 = (long long)blockIdx.y * 128;
+	const int c0 = blockIdx.x * 128;
+	f32x16c acc[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t)
+#pragma unroll
+		for (int r = 0; r < 16; ++r)
+			acc[t][r] = 0.f;
+	float xr[8];
+	float4 yr[2];
+	const long long qrow = q0 + (tid >> 1);
+	const int crow = c0 + (tid >> 1);
+	const bool flip = interleaved && ((crow >> 4) & 1);
+	auto fetch = [&](int k0) {
+		const int kk = k0 + 8 * (tid & 1);
+#pragma unroll
+		for (int e = 0; e < 8; ++e)
+			xr[e] = (qrow < nq && kk + e < d) ? x[qrow * d + kk + e] : 0.f;
+#pragma unroll
+		for (int g = 0; g < 2; ++g) {
+			yr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (crow < nlist && kk + 4 * g < sdp)
+				yr[g] = *(const float4 *)(cent + (size_t)crow * sdp + kk + 4 * g);
+		}
+	};
+	fetch(0);
+	for (int k0 = 0; k0 < d; k0 += 16) {
+#pragma unroll
+		for (int e = 0; e < 8; ++e)
+			xs[8 * (tid & 1) + e][tid >> 1] = xr[e];
+#pragma unroll
+		for (int g = 0; g < 2; ++g) {
+			const float4 v = yr[g];
+			float y0 = v.x, y1 = v.y, y2 = v.z, y3 = v.w;
+			if (interleaved) {
+				y0 = flip ? v.z : v.x, y1 = flip ? v.x : v.z, y2 = flip ? v.w : v.y, y3 = flip ? v.y : v.w;
+			}
+			const int kb = 8 * (tid & 1) + 4 * g;
+			ys[kb + 0][tid >> 1] = y0;
+			ys[kb + 1][tid >> 1] = y1;
+			ys[kb + 2][tid >> 1] = y2;
+			ys[kb + 3][tid >> 1] = y3;
+		}
+		__syncthreads();
+		if (k0 + 16 < d)
+			fetch(k0 + 16);
+#pragma unroll
+		for (int k = 0; k < 16; k += 2) { // k ascending: every accumulator element is ONE k-ordered chain
+			const float b = ys[k + h][32 * wave + ln];
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const float a = xs[k + h][32 * t + ln];
+				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+			}
+		}
+		__syncthreads();
+	}
+	const int c = c0 + 32 * wave + ln;
+	const float cnv = (is_l2 && c < nlist) ? cn[c] : 0.f;
+#pragma unroll
+	for (int t = 0; t < 4; ++t)
+#pragma unroll
+		for (int g = 0; g < 4; ++g)
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const long long q = q0 + 32 * t + 8 * g + 4 * h + e;
+				if (q >= nq || c >= nlist)
+					continue;
+				const float ip = acc[t][4 * g + e];
+				float dis = fmaf(-2.0f, ip, (is_l2 ? qn[q] : 0.f) + cnv);
+				dis = dis < 0.f ? 0.f : dis; // FAISS: if (dis < 0) dis = 0  (NaN stays NaN)
+				D[q * nlist + c] = is_l2 ? dis : ip;
+			}
+}
+int g_coarse_mfma = 1; // option ivf_coarse_mfma: the distance matrix on the f32 matrix pipe (1) or on the vector ALU (0)
+
 // ---- one wavefront per query: the np smallest (dis, id) of its row of D -> pd / pi [nq][np] (any order; missing: FLT_MAX, -1) --
 // PL = values per lane (nlist <= 64 PL, a multiple of 4).  A row is a candidate iff dis < FLT_MAX / score > -FLT_MAX (the heap's
 // strict compare against its neutral value; NaN never enters).  Inner product: the pure order (score descending, id ascending);
@@ -292,8 +383,12 @@ void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_ce
 	if (nq <= 0)
 		return;
 	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
-	hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist, d_qn,
-	                   d_cn, is_l2, d_D);
+	if (g_coarse_mfma)
+		hipLaunchKernelGGL(coarse_dist_mfma_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist,
+		                   d_qn, d_cn, is_l2, d_D);
+	else
+		hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist, d_qn,
+		                   d_cn, is_l2, d_D);
 	MVS_HIP(hipGetLastError());
 #define MVS_CSEL(PL)                                                                                                               \
 	{                                                                                                                              \

@@ -1951,6 +1951,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_ivf_cl_refresh = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "ivf_coarse_mfma")) { // IVF coarse distance matrix on the f32 matrix pipe (1) or the vector ALU (0); same bits
+		g_coarse_mfma = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "ivf_cl_xcd")) { // IVF coarse filter: items of one list on one XCD (1) or dealt round-robin over the XCDs (0)
 		g_ivf_cl_xcd = (int)v;
 		return true;

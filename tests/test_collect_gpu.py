@@ -348,3 +348,48 @@ def test_stream_overflow_grows_the_stream_for_data_that_needs_it(mf):
     assert st["overflows"] == 1 and st["queries"] == 700 and st["candidates"] > 700 * 1024, st
     assert cl.prefilter_stats()["fallback_queries"] == 0
     cl.set_option("cl_stream_cap", 0)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_round4_switches_do_not_change_a_single_bit(mf, metric):
+    """Round 4 changed HOW the scan gets its bounds and how the candidates reach the re-scoring, not what comes out: the error bound
+    from the actual rounding residuals (cl_bound_mode), the pass bounds through the global table (cl_tab), the candidate count kept on
+    the device (cl_defer_count) -- every combination returns the labels and distances of the exact f32 kernel, searched twice so that
+    the second search of an index (sort sized from the first one's candidate count) is covered, also after rows were added."""
+    rs = np.random.RandomState(41)
+    d, nb, nq, k = 128, 140_000, 700, 10
+    xb = rs.rand(nb + 30_000, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[::97] = xb[5]
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    ex = mf.index_factory(d, "Flat", metric)
+    ex.set_option("prefilter", 0)
+    ex.add(xb[:nb])
+    D0, I0 = ex.search(xq, k)
+    ex.add(xb[nb:])
+    D0b, I0b = ex.search(xq, k)
+    cands = {}
+    try:
+        for bound in (1, 0):
+            for tab in (1, 0):
+                for defer in (1, 0):
+                    cl = mf.index_factory(d, "Flat", metric)
+                    cl.set_option("prefilter", 2)
+                    cl.set_option("cl_bound_mode", bound)
+                    cl.set_option("cl_tab", tab)
+                    cl.set_option("cl_defer_count", defer)
+                    cl.add(xb[:nb])
+                    for rep in range(2):
+                        D, I = cl.search(xq, k)
+                        assert cl.last_kernel_info()["name"] == KERNEL
+                        assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (bound, tab, defer, rep)
+                    cl.add(xb[nb:])  # more rows than the previous search's estimate was made for
+                    D, I = cl.search(xq, k)
+                    assert np.array_equal(I, I0b) and np.array_equal(D.view(np.uint32), D0b.view(np.uint32)), (bound, tab, defer, "added")
+                    st = cl.collect_stats()
+                    cands[(bound, tab)] = st["candidates"] / st["queries"]
+    finally:
+        cl = mf.index_factory(d, "Flat", metric)
+        cl.set_option("cl_bound_mode", 1)  # (process-wide knobs back to their defaults)
+        cl.set_option("cl_tab", 1)
+    assert cands[(1, 1)] < 0.8 * cands[(0, 1)], cands  # the residual-norm bound admits clearly fewer rows
+

@@ -652,3 +652,36 @@ def test_ivf_exact_ties_option_off_keeps_the_pure_order(mf):
     g.set_option("ivf_exact_ties", 0)
     D0, I0 = g.search(xq, 10, nprobe=3)
     assert np.array_equal(D0, D1) and not np.array_equal(I0, I1)
+
+
+def test_ivf_round4_switches_do_not_change_a_single_bit(mf):
+    """residual-norm bound (cl_bound_mode), items of one list on one XCD (ivf_cl_xcd), candidate count kept on the device
+    (ivf_cl_defer): same labels and distances as the scanner kernel in every combination, first and second search"""
+    d, nlist, n = 128, 64, 120_000
+    xb = _clustered(n, d, 61)
+    xq = _clustered(900, d, 62)
+    ref = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+    ref.train(xb)
+    ref.add(xb)
+    ref.set_option("ivf_collect", 0)
+    D0, I0 = ref.search(xq, 10, nprobe=8)
+    cent = ref.ivf_centroids()
+    try:
+        for bound in (1, 0):
+            for xcd in (1, 0):
+                for defer in (1, 0):
+                    g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+                    g.ivf_set_centroids(cent)
+                    g.add(xb)
+                    g.set_option("cl_bound_mode", bound)
+                    g.set_option("ivf_cl_xcd", xcd)
+                    g.set_option("ivf_cl_defer", defer)
+                    for rep in range(2):
+                        D, I = g.search(xq, 10, nprobe=8)
+                        assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+                        assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (bound, xcd, defer, rep)
+    finally:
+        g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+        g.set_option("cl_bound_mode", 1)
+        g.set_option("ivf_cl_xcd", 1)
+
