@@ -53,6 +53,8 @@ def _check_vs_openblas(metric, xb_h, xq_h, k, D, I, ns):
     1e-5 relative (north_star asks 1e-4)."""
     if orc.openblas_path() is None:
         pytest.skip("no OpenBLAS with the scipy 64-bit prefix on this host")
+    orc.openblas_load()
+    orc.openblas_set_num_threads(16)  # (FAISS's 1024-row sgemm blocks: 64 threads are 3x slower than 16 on the box's host)
     cen = orc.openblas_census(metric, xb_h, xq_h[:ns], k, D[:ns], I[:ns])
     print("openblas census:", cen)
     assert cen["differing_slots_inside_band"] == cen["slots_label_differs"], cen
