@@ -203,7 +203,8 @@ def embedded_configs():
                 "ms_per_step": j["ms_per_step"],
                 "steps": j["steps"],
                 "roofline": {kk: r.get(kk) for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_step", "avg_launch_ms",
-                                                      "frac_list_major_8d", "candidates_rescored_per_query")},
+                                                      "frac_list_major_8d", "candidates_rescored_per_query", "traffic",
+                                                      "traffic_over_algorithmic", "row_bytes_moved_GBps")},
                 "parity": {kk: j[kk] for kk in ("labels_bit_exact_vs_oracle", "labels_and_distances_bit_exact_vs_oracle", "parity_device",
                                                 "recall_at_10", "recall_sample_queries", "labels_equal_vs_openblas", "openblas_census") if kk in j},
                 "seconds": round(time.perf_counter() - t0, 1),

@@ -1045,7 +1045,8 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 		// score survive depends on the whole stream -- replayed for the flagged queries (csrc/flat_reservoir.hip)
 		const size_t xf_b = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255, t_b = ((size_t)nf * sizeof(float) + 255) & ~(size_t)255;
 		const size_t ov_b = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255, oi_b = ((size_t)nf * k * sizeof(int64_t) + 255) & ~(size_t)255;
-		const int64_t F = std::max<int64_t>(1, std::min<int64_t>(nf, ((int64_t)1 << 30) / std::max<int64_t>(ntotal * 4, 1)));
+		const int64_t F = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nf, 32768), // (flagged queries ride in grid.y)
+		                                                     ((int64_t)1 << 30) / std::max<int64_t>(ntotal * 4, 1)));
 		ws_tie.reserve(xf_b + t_b + 2 * ov_b + 2 * oi_b + (size_t)F * ntotal * sizeof(float) + 256);
 		char *b = (char *)ws_tie.p;
 		float *xf = (float *)b, *T = (float *)(b + xf_b), *ov = (float *)(b + xf_b + t_b), *Df = (float *)(b + xf_b + t_b + ov_b);
