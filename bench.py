@@ -660,6 +660,11 @@ def main():
                     lm = float(n) * d * 4 + float(n) * 8
                     out["roofline"]["list_major_bytes_8d"] = lm
                     out["roofline"]["frac_list_major_8d"] = round(lm / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
+                    try:  # census of the IVF coarse filter (csrc/ivf_collect.hip): candidates re-scored exactly, per query
+                        cs = ix.collect_stats()
+                        out["roofline"]["candidates_rescored_per_query"] = round(cs["candidates"] / max(cs["queries"], 1), 1)
+                    except Exception:  # noqa: BLE001
+                        pass
         # ---- CPU baseline (oracle, BLAS-path arithmetic, all host cores) + recall, N=1 only ----------
         if world == 1 and is_hnsw:
             out["distance_evals_per_query"] = round(kinfo["bytes"] / (4.0 * d + 4.0) / nq, 1)

@@ -11,6 +11,7 @@
 #include "flat_fused.h"
 #include "index.h"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace mvs {
@@ -132,87 +133,164 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(const float *__restric
 // query: 128-byte runs, no transpose.  Workgroup = 128 queries x 128 centroids, wave w = centroid block 32 w .. 32 w + 31 against
 // all four query blocks (64 accumulator registers); operands through LDS in slabs of 16 dims exactly as above.
 typedef float f32x16c __attribute__((ext_vector_type(16)));
+// Round 4, second cut (C3: 170 -> see DESIGN 3.2): slabs of 32 dims in TWO LDS buffers -- one barrier per slab, and the next slab's
+// operands are in flight (registers) during the 64 MFMAs of the current one (with 16-dim slabs the 32 MFMAs of a slab were shorter
+// than a global round trip and the pipe sat idle 60 % of the time); float4 loads of the query rows when d % 4 == 0; the query norms
+// of the workgroup in LDS for the epilogue.
+constexpr int CM_K = 32, CM_P = 128 + 4;
+// The (tile, slab) loop is flattened over a workgroup's tiles (tile += gridDim.x): launched with one workgroup per 128 x 128 tile
+// (default) it is the plain kernel; launched PERSISTENT (option ivf_coarse_persistent = 1: two workgroups per CU, the next tile's
+// first slab fetched under the current tile's last MFMAs, the epilogue's stores draining under the next tile) it measured SLOWER at
+// C3 -- 226 vs 176 us, every part of it (staging alone 73 vs 51, + stores 144 vs 93, + MFMAs without stores 169 vs 146:
+// profiles/r4_coarse_kernel_ablation.txt).  What that file shows for the default launch: staging (51 us), MFMAs (95) and stores
+// (30) add up instead of overlapping -- the two workgroups of a CU start together and stay in step.
 __global__ __launch_bounds__(256) void coarse_dist_mfma_kernel(const float *__restrict__ x, long long nq, int d,
                                                               const float *__restrict__ cent, int sdp, int interleaved, int nlist,
                                                               const float *__restrict__ qn, const float *__restrict__ cn,
-                                                              int is_l2, float *__restrict__ D) {
-	__shared__ __attribute__((aligned(16))) float xs[16][128 + 4];
-	__shared__ __attribute__((aligned(16))) float ys[16][128 + 4];
+                                                              int is_l2, float *__restrict__ D, int abl) {
+	extern __shared__ __attribute__((aligned(16))) float cm_lds[]; // [2]{xs[CM_K][CM_P], ys[CM_K][CM_P]}, qs[2][128]
+	float *qs = cm_lds + 4 * CM_K * CM_P;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
-	const long long q0 = (long long)blockIdx.y * 128;
-	const int c0 = blockIdx.x * 128;
+	const int ntx = (nlist + 127) / 128;
+	const long long ntiles = (long long)ntx * ((nq + 127) / 128);
 	f32x16c acc[4];
 #pragma unroll
 	for (int t = 0; t < 4; ++t)
 #pragma unroll
 		for (int r = 0; r < 16; ++r)
 			acc[t][r] = 0.f;
-	float xr[8];
-	float4 yr[2];
-	const long long qrow = q0 + (tid >> 1);
-	const int crow = c0 + (tid >> 1);
-	const bool flip = interleaved && ((crow >> 4) & 1);
-	auto fetch = [&](int k0) {
-		const int kk = k0 + 8 * (tid & 1);
+	float4 xr[4], yr[4]; // this thread's 16 dims (half = tid & 1) of query row / centroid row tid >> 1 of the slab in flight
+	float qv = 0.f;      // ... and, with a tile's first slab, the norm of query row tid (tid < 128)
+	bool flip = false;
+	const bool x4 = (d & 3) == 0;
+	auto fetch = [&](long long tile, int k0) {
+		const long long q0 = (tile / ntx) * 128;
+		const int c0 = (int)(tile % ntx) * 128;
+		const long long qrow = q0 + (tid >> 1);
+		const int crow = c0 + (tid >> 1);
+		flip = interleaved && ((crow >> 4) & 1);
+		const int kk = k0 + 16 * (tid & 1);
 #pragma unroll
-		for (int e = 0; e < 8; ++e)
-			xr[e] = (qrow < nq && kk + e < d) ? x[qrow * d + kk + e] : 0.f;
-#pragma unroll
-		for (int g = 0; g < 2; ++g) {
+		for (int g = 0; g < 4; ++g) {
+			xr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (qrow < nq) {
+				const float *src = x + qrow * d + kk + 4 * g;
+				if (x4) {
+					if (kk + 4 * g < d)
+						xr[g] = *(const float4 *)src;
+				} else {
+					xr[g].x = kk + 4 * g + 0 < d ? src[0] : 0.f;
+					xr[g].y = kk + 4 * g + 1 < d ? src[1] : 0.f;
+					xr[g].z = kk + 4 * g + 2 < d ? src[2] : 0.f;
+					xr[g].w = kk + 4 * g + 3 < d ? src[3] : 0.f;
+				}
+			}
 			yr[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 			if (crow < nlist && kk + 4 * g < sdp)
 				yr[g] = *(const float4 *)(cent + (size_t)crow * sdp + kk + 4 * g);
 		}
+		if (k0 == 0 && tid < 128)
+			qv = (is_l2 && q0 + tid < nq) ? qn[q0 + tid] : 0.f;
 	};
-	fetch(0);
-	for (int k0 = 0; k0 < d; k0 += 16) {
+	auto stage = [&](int buf) {
+		float *xs = cm_lds + buf * 2 * CM_K * CM_P, *ys = xs + CM_K * CM_P;
+		const int col = tid >> 1;
 #pragma unroll
-		for (int e = 0; e < 8; ++e)
-			xs[8 * (tid & 1) + e][tid >> 1] = xr[e];
-#pragma unroll
-		for (int g = 0; g < 2; ++g) {
+		for (int g = 0; g < 4; ++g) {
+			const int kb = 16 * (tid & 1) + 4 * g;
+			xs[(kb + 0) * CM_P + col] = xr[g].x;
+			xs[(kb + 1) * CM_P + col] = xr[g].y;
+			xs[(kb + 2) * CM_P + col] = xr[g].z;
+			xs[(kb + 3) * CM_P + col] = xr[g].w;
 			const float4 v = yr[g];
 			float y0 = v.x, y1 = v.y, y2 = v.z, y3 = v.w;
 			if (interleaved) {
 				y0 = flip ? v.z : v.x, y1 = flip ? v.x : v.z, y2 = flip ? v.w : v.y, y3 = flip ? v.y : v.w;
 			}
-			const int kb = 8 * (tid & 1) + 4 * g;
-			ys[kb + 0][tid >> 1] = y0;
-			ys[kb + 1][tid >> 1] = y1;
-			ys[kb + 2][tid >> 1] = y2;
-			ys[kb + 3][tid >> 1] = y3;
+			ys[(kb + 0) * CM_P + col] = y0;
+			ys[(kb + 1) * CM_P + col] = y1;
+			ys[(kb + 2) * CM_P + col] = y2;
+			ys[(kb + 3) * CM_P + col] = y3;
 		}
-		__syncthreads();
-		if (k0 + 16 < d)
-			fetch(k0 + 16);
+	};
+	long long tile = blockIdx.x;
+	if (tile < ntiles)
+		fetch(tile, 0);
+	int buf = 0, tp = 0;
+	for (; tile < ntiles; tile += gridDim.x, tp ^= 1) {
+		const long long q0 = (tile / ntx) * 128;
+		const int c0 = (int)(tile % ntx) * 128;
+		for (int k0 = 0; k0 < d; k0 += CM_K, buf ^= 1) {
+			stage(buf);
+			if (k0 == 0 && tid < 128)
+				qs[tp * 128 + tid] = qv;
+			// (the buffer written here was last read two slabs ago -- every wave has passed the barrier of the slab between; the same
+			// holds for qs[tp], read in the epilogue two tiles ago)
+			__syncthreads();
+			if (k0 + CM_K < d)
+				fetch(tile, k0 + CM_K);
+			else if (tile + gridDim.x < ntiles)
+				fetch(tile + gridDim.x, 0);
+			const float *xs = cm_lds + buf * 2 * CM_K * CM_P, *ys = xs + CM_K * CM_P;
 #pragma unroll
-		for (int k = 0; k < 16; k += 2) { // k ascending: every accumulator element is ONE k-ordered chain
-			const float b = ys[k + h][32 * wave + ln];
+			for (int k = 0; k < CM_K; k += 2) { // k ascending: every accumulator element is ONE k-ordered chain
+#ifdef MVS_PROFILING
+				if (abl & 2)
+					break;
+#endif
+				const float b = ys[(k + h) * CM_P + 32 * wave + ln];
 #pragma unroll
-			for (int t = 0; t < 4; ++t) {
-				const float a = xs[k + h][32 * t + ln];
-				acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+				for (int t = 0; t < 4; ++t) {
+					const float a = xs[(k + h) * CM_P + 32 * t + ln];
+					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+				}
 			}
 		}
-		__syncthreads();
+#ifdef MVS_PROFILING
+		if ((abl & 1) && acc[0][0] != 12345.678f) // (profiling library: no matrix written -- results are wrong)
+			continue;
+#endif
+		const int c = c0 + 32 * wave + ln;
+		const float cnv = (is_l2 && c < nlist) ? cn[c] : 0.f;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g)
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					const int ql = 32 * t + 8 * g + 4 * h + e;
+					const long long q = q0 + ql;
+					if (q >= nq || c >= nlist)
+						continue;
+					const float ip = acc[t][4 * g + e];
+					float dis = fmaf(-2.0f, ip, qs[tp * 128 + ql] + cnv);
+					dis = dis < 0.f ? 0.f : dis; // FAISS: if (dis < 0) dis = 0  (NaN stays NaN)
+					D[q * nlist + c] = is_l2 ? dis : ip;
+				}
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+				acc[t][r] = 0.f;
+		}
 	}
-	const int c = c0 + 32 * wave + ln;
-	const float cnv = (is_l2 && c < nlist) ? cn[c] : 0.f;
-#pragma unroll
-	for (int t = 0; t < 4; ++t)
-#pragma unroll
-		for (int g = 0; g < 4; ++g)
-#pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				const long long q = q0 + 32 * t + 8 * g + 4 * h + e;
-				if (q >= nq || c >= nlist)
-					continue;
-				const float ip = acc[t][4 * g + e];
-				float dis = fmaf(-2.0f, ip, (is_l2 ? qn[q] : 0.f) + cnv);
-				dis = dis < 0.f ? 0.f : dis; // FAISS: if (dis < 0) dis = 0  (NaN stays NaN)
-				D[q * nlist + c] = is_l2 ? dis : ip;
-			}
 }
+static int device_cu_count() { // compute units of the current device (256 on MI355X)
+	static int cached[64];
+	int dev = 0;
+	MVS_HIP(hipGetDevice(&dev));
+	if (dev < 0 || dev >= 64)
+		return 256;
+	if (!cached[dev]) {
+		int n = 0;
+		MVS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+		cached[dev] = n > 0 ? n : 256;
+	}
+	return cached[dev];
+}
+static size_t coarse_mfma_lds_bytes() {
+	return ((size_t)4 * CM_K * CM_P + 256) * sizeof(float);
+}
+int g_coarse_persistent = 0; // option ivf_coarse_persistent (measured slower, see coarse_dist_mfma_kernel)
+int g_coarse_abl = 0; // (profiling library only, option coarse_abl: 1 = no matrix written, 2 = no MFMA loop -- results wrong)
 int g_coarse_mfma = 1; // option ivf_coarse_mfma: the distance matrix on the f32 matrix pipe (1) or on the vector ALU (0)
 
 // ---- one wavefront per query: the np smallest (dis, id) of its row of D -> pd / pi [nq][np] (any order; missing: FLT_MAX, -1) --
@@ -383,9 +461,12 @@ void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_ce
 	if (nq <= 0)
 		return;
 	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
-	if (g_coarse_mfma)
-		hipLaunchKernelGGL(coarse_dist_mfma_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist,
-		                   d_qn, d_cn, is_l2, d_D);
+	if (g_coarse_mfma) {
+		ensure_dynamic_lds((const void *)coarse_dist_mfma_kernel, coarse_mfma_lds_bytes());
+		const long long ntiles = (long long)grid.x * grid.y;
+		hipLaunchKernelGGL(coarse_dist_mfma_kernel, dim3((unsigned)std::min<long long>(ntiles, g_coarse_persistent ? 2 * device_cu_count() : ntiles)), dim3(256), coarse_mfma_lds_bytes(), st, d_x, (long long)nq, d, d_cent, sdp,
+		                   interleaved, (int)nlist, d_qn, d_cn, is_l2, d_D, g_coarse_abl);
+	}
 	else
 		hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist, d_qn,
 		                   d_cn, is_l2, d_D);

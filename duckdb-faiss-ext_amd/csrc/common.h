@@ -255,7 +255,8 @@ int ivf_group_max_items(int64_t npairs, int64_t nlist, int group);
 size_t ivf_group_ws_ints(int64_t nlist);
 void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, int group, int shift,
                       const int64_t *d_list_begin, const int64_t *d_list_end, int *ws_int, void *d_items, int *d_qidx,
-                      int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st);
+                      int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st, int key_stride = 1,
+                      bool counters_zeroed = false);
 void launch_ivf_pack_item_fragments(const float *d_x, int d, int kc, int nch, const void *d_items, const int *d_nitems,
                                     int max_items, const int *d_qidx, float *d_qf, hipStream_t st);
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,

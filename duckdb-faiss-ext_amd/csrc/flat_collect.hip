@@ -1484,10 +1484,11 @@ size_t collect_sort_temp_bytes_est(int64_t n_est, int64_t nq) {
 	return bytes;
 }
 void launch_collect_group_est(unsigned long long *d_stream, unsigned long long *d_sorted, const unsigned long long *d_cnt,
-                              int64_t n_est, void *d_temp, size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st) {
+                              int64_t n_est, void *d_temp, size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st, bool seg_zeroed) {
 	if (nq <= 0)
 		return;
-	MVS_HIP(hipMemsetAsync(d_seg, 0, (size_t)2 * nq * sizeof(int), st));
+	if (!seg_zeroed)
+		MVS_HIP(hipMemsetAsync(d_seg, 0, (size_t)2 * nq * sizeof(int), st));
 	if (n_est <= 0)
 		return;
 	hipLaunchKernelGGL(collect_fill_tail_kernel, dim3((unsigned)std::min<int64_t>((n_est + 255) / 256, 1024)), dim3(256), 0, st, d_stream,
@@ -1510,13 +1511,14 @@ size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq) {
 
 // stream (ncand entries of q << 32 | row) -> sorted by query + the segment of every query (d_seg: [2 nq] begin | end)
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
-                          size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st) {
+                          size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st, bool seg_zeroed) {
 	if (nq <= 0)
 		return;
 	int qbits = 1;
 	while (((int64_t)1 << qbits) < nq)
 		++qbits;
-	MVS_HIP(hipMemsetAsync(d_seg, 0, (size_t)2 * nq * sizeof(int), st));
+	if (!seg_zeroed)
+		MVS_HIP(hipMemsetAsync(d_seg, 0, (size_t)2 * nq * sizeof(int), st));
 	if (ncand > 0) {
 		MVS_HIP(rocprim::radix_sort_keys(d_temp, temp_bytes, d_stream, d_sorted, (size_t)ncand, 32, 32 + qbits, st));
 		hipLaunchKernelGGL(collect_segments_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, d_sorted,
@@ -1588,9 +1590,9 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
 	if (nq <= 0)
 		return;
 	if (d_cnt)
-		launch_collect_group_est(d_stream, d_sorted, d_cnt, ncand, d_temp, temp_bytes, nq, d_seg, st);
+		launch_collect_group_est(d_stream, d_sorted, d_cnt, ncand, d_temp, temp_bytes, nq, d_seg, st, false);
 	else
-		launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st);
+		launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st, false);
 	if (ncand > 0 && collect_store_dims(g.d) > 128) {
 		launch_collect_exact_wide(metric, per_pair, d_sorted, ncand, d_x, g.d, d_vecs, g.dp, g.pair_interleaved ? 1 : 0, d_norms, d_qn, st, d_cnt);
 	} else if (ncand > 0) {

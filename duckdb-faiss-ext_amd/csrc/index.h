@@ -111,6 +111,9 @@ public:
 	virtual void set_label_offset(int64_t off) {
 		label_offset = off;
 	}
+	virtual bool collect_stats(int64_t *, int64_t *, int64_t *) { // coarse-filter census of an IVF index (mvs_index_collect_stats)
+		return false;
+	}
 	virtual bool set_option(const char *, int64_t) {
 		return false;
 	}
@@ -351,7 +354,8 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq);
 size_t collect_sort_temp_bytes_est(int64_t n_est, int64_t nq);
 void launch_collect_group_est(unsigned long long *d_stream, unsigned long long *d_sorted, const unsigned long long *d_cnt,
-                              int64_t n_est, void *d_temp, size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
+                              int64_t n_est, void *d_temp, size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st,
+                              bool seg_zeroed = false);
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
@@ -362,9 +366,9 @@ bool coarse_select_supported(int64_t nlist, int64_t np);
 void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
                           const float *d_qn, const float *d_cn, int64_t np, int is_l2, float *d_D, float *d_pd, int32_t *d_pi,
                           hipStream_t st);
-extern int g_coarse_select, g_ivf_cl_refresh, g_ivf_cl_xcd, g_coarse_mfma;
+extern int g_coarse_select, g_ivf_cl_refresh, g_ivf_cl_xcd, g_coarse_mfma, g_ivf_cl_lds_pad, g_coarse_abl, g_coarse_persistent;
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
-                          size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st);
+                          size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st, bool seg_zeroed = false);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,
                            int32_t *d_pi1, hipStream_t st);
 extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_regs, g_cl_nc32_from, g_cl_tab, g_cl_bound_mode;

@@ -1773,8 +1773,11 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
 	IndexBase *p = sharded_inner_view(ix->impl);
 	while (p->kind == MVS_KIND_IDMAP)
 		p = static_cast<IDMapIndex *>(p)->sub;
-	if (p->kind != MVS_KIND_FLAT)
-		throw_faiss("mvs_index_collect_stats", __FILE__, "not a Flat index");
+	if (p->kind != MVS_KIND_FLAT) {
+		if (p->collect_stats(queries, candidates, overflows)) // IVF: its own coarse filter (csrc/ivf_collect.hip)
+			return 0;
+		throw_faiss("mvs_index_collect_stats", __FILE__, "not a Flat or IVF index");
+	}
 	auto *f = static_cast<FlatIndex *>(p);
 	if (queries)
 		*queries = f->cl_queries_total;
@@ -1956,6 +1959,14 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_coarse_mfma = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "ivf_coarse_persistent")) { // coarse distance matrix: persistent workgroups (1) or one per tile (0, default: faster)
+		g_coarse_persistent = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "ivf_cl_lds_pad")) {
+		g_ivf_cl_lds_pad = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "ivf_cl_xcd")) { // IVF coarse filter: items of one list on one XCD (1) or dealt round-robin over the XCDs (0)
 		g_ivf_cl_xcd = (int)v;
 		return true;
@@ -1979,6 +1990,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 #ifdef MVS_PROFILING // wrong-result ablation knobs: profiling library only
 	if (!strcmp(key, "cl_abl")) {
 		g_cl_abl = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "coarse_abl")) { // profiling only: results are wrong
+		g_coarse_abl = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "pf_abl")) { // profiling only: results are wrong

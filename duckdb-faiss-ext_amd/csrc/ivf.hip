@@ -916,27 +916,31 @@ public:
 		ws_items.reserve((size_t)max_items * 16);
 		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
 		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
-		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		// (round 4: the counters of BOTH groupings in one buffer, and one control block {stream count | fail count | per-query fail
+		// flags | per-query segments}: two memsets per search instead of seven)
+		const size_t group_ints = (ivf_group_ws_ints(nlist) + 63) & ~(size_t)63;
+		ws_group.reserve(2 * group_ints * sizeof(int));
+		MVS_HIP(hipMemsetAsync(ws_group.p, 0, 2 * group_ints * sizeof(int), stream));
 		ws_xi.reserve(ivf_collect_xi_bytes(max_items));
 		ws_ig.reserve((size_t)max_items * 128 * sizeof(float));
 		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
 		if (cl_prepass_shared)
 			ws_ie2p.reserve((size_t)max_items * 128 * sizeof(float));
-		ws_qfail.reserve((size_t)nq * sizeof(int));
-		ws_cimask.reserve((size_t)npairs * sizeof(int64_t));
+		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int);
+		ws_qfail.reserve(ctl_bytes);
+		int *const ctl_qfail = (int *)((char *)ws_qfail.p + 256), *const ctl_seg = ctl_qfail + nq;
 		const int nclass = k > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
 		ws_gslot.reserve((size_t)nq * nclass * sizeof(unsigned) + 64);
 		launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
-		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, (size_t)nq * sizeof(int), stream));
+		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, ctl_bytes, stream));
 		// candidate stream: 4096 entries per query to start with, or what the last overflow showed this index's data to need
 		int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024) // (option ivf_cl_stream_cap: tests)
 		                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
 		size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 		ws_stream.reserve(256 + 2 * half);
-		unsigned long long *cnt = (unsigned long long *)ws_stream.p;
+		unsigned long long *cnt = (unsigned long long *)ws_qfail.p; // (zeroed with the control block above)
 		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
 		unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
-		MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
 		memset(&kinfo, 0, sizeof kinfo);
 		// IDSelector: one bit per padded row, built per search (the selector sees the stored id, through the id map if any)
 		const unsigned *rowmask = nullptr;
@@ -951,7 +955,7 @@ public:
 		int64_t max_list = 0;
 		for (int64_t l = 0; l < nlist; l++)
 			max_list = std::max(max_list, list_off[(size_t)l + 1] - list_off[(size_t)l]);
-		const int seg_rows = 512, nseg = (int)((max_list + seg_rows - 1) / seg_rows);
+		const int seg_rows = cl_seg_rows, nseg = (int)((max_list + seg_rows - 1) / seg_rows);
 		// (round 3, option ivf_cl_prepass = 1: the pre-pass walks the first rows of EVERY probed list with the work items of the
 		// main pass -- one grouping + packing per search instead of two, and 32 x 128 rows of evidence per query instead of 256)
 		int *d_nitems = nullptr, *d_cnt = nullptr;
@@ -961,16 +965,15 @@ public:
 		const bool shared = cl_prepass_shared && !cl_prepass_all && !cl_prepass_none;
 		for (int phase = cl_prepass_none ? 1 : 0; phase < 2; ++phase) {
 			const int64_t *keys = (const int64_t *)ws_cI.p;
-			if (phase == 0 && !cl_prepass_all && !shared) {
-				launch_ivf_mask_probes((const int64_t *)ws_cI.p, nq, (int)np, 0, 1, (int64_t *)ws_cimask.p, stream);
-				keys = (const int64_t *)ws_cimask.p;
-			}
+			// the nearest-list pre-pass: column 0 of the labels as a batch with one probe per query (key stride = nprobe)
+			const bool nearest_only = phase == 0 && !cl_prepass_all && !shared;
 			if (phase == 0 || !(cl_prepass_all || shared)) {
-				launch_ivf_group(keys, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
-				                 (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p, &d_nitems, &d_cnt, stream);
+				launch_ivf_group(keys, nq, nearest_only ? 1 : (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
+				                 (int *)ws_group.p + (phase == 0 ? 0 : group_ints), ws_items.p, (int *)ws_qidx.p, nullptr, &d_nitems, &d_cnt,
+				                 stream, nearest_only ? (int)np : 1, true);
 				launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
 				                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
-				                        (float *)ws_ie2.p, (int *)ws_qfail.p, stream, shared ? (const int64_t *)ws_cI.p : nullptr, (int)np,
+				                        (float *)ws_ie2.p, ctl_qfail, stream, shared ? (const int64_t *)ws_cI.p : nullptr, (int)np,
 				                        shared ? (float *)ws_ie2p.p : nullptr, nlist);
 			}
 			if (phase == 1)
@@ -985,10 +988,9 @@ public:
 		}
 		// queries without a finite bound -> fail list
 		ws_fail.reserve(64 + (size_t)nq * sizeof(int));
-		int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
-		MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), stream));
+		int *fail_cnt = (int *)((char *)ws_qfail.p + 64), *fail_q = (int *)ws_fail.p + 16; // (the count: in the zeroed control block)
 		hipLaunchKernelGGL(ivf_compact_flags_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
-		                   (const int *)ws_qfail.p, (int)nq, fail_cnt, fail_q);
+		                   (const int *)ctl_qfail, (int)nq, fail_cnt, fail_q);
 		if (!h_fail)
 			MVS_HIP(hipHostMalloc((void **)&h_fail, 64, hipHostMallocDefault));
 		MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -1014,7 +1016,6 @@ public:
 				cl_cap_hint = std::max<int64_t>(cl_cap_hint, (cap_entries + nq - 1) / nq);
 			half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 			ws_stream.reserve(256 + 2 * half);
-			cnt = (unsigned long long *)ws_stream.p;
 			strm = (unsigned long long *)((char *)ws_stream.p + 256);
 			sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 			MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
@@ -1035,19 +1036,18 @@ public:
 		}
 		const size_t temp = defer ? collect_sort_temp_bytes_est(n_est, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 		ws_sorttmp.reserve(std::max<size_t>(temp, 16));
-		ws_seg.reserve((size_t)2 * nq * sizeof(int));
 		const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
 		ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
 		float *pd1 = (float *)ws_ex.p;
 		int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
 		if (defer) {
-			launch_collect_group_est(strm, sorted, cnt, n_est, ws_sorttmp.p, temp, nq, (int *)ws_seg.p, stream);
+			launch_collect_group_est(strm, sorted, cnt, n_est, ws_sorttmp.p, temp, nq, ctl_seg, stream, true);
 			launch_ivf_collect_exact(metric, sorted, n_est, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream, cnt);
 		} else {
-			launch_collect_group(strm, sorted, ncand, ws_sorttmp.p, temp, nq, (int *)ws_seg.p, stream);
+			launch_collect_group(strm, sorted, ncand, ws_sorttmp.p, temp, nq, ctl_seg, stream, true);
 			launch_ivf_collect_exact(metric, sorted, ncand, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream);
 		}
-		launch_collect_select(metric, sorted, (const int *)ws_seg.p, nq, kk, pd1, pi1, stream);
+		launch_collect_select(metric, sorted, (const int *)ctl_seg, nq, kk, pd1, pi1, stream);
 		// the k best by (value, position in the list-sorted store), labels = stored ids (then the id map of an IDMap wrapper)
 		// (the selected lists are already in the scan kernels' order: value, then position -- inner product keeps it as
 		// merge_items_kernel does; the L2 merge of one split only translates the labels)
@@ -1498,6 +1498,12 @@ public:
 			cl_stream_cap_per_query = v;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_seg_rows")) { // rows per (work item, segment) wavefront of the main pass: a multiple of 32
+			if (v < 32 || v > 65536 || v % 32)
+				return false;
+			cl_seg_rows = (int)v;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_defer")) { // 1 (default): the candidate count stays on the device between scan and re-scoring
 			cl_defer = v != 0;
 			return true;
@@ -1564,7 +1570,17 @@ private:
 	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_ie2p, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_cap_hint = 0, cl_stream_cap_per_query = 0;
+	bool collect_stats(int64_t *queries, int64_t *candidates, int64_t *overflows) override {
+		if (queries)
+			*queries = cl_queries_total;
+		if (candidates)
+			*candidates = cl_candidates_total;
+		if (overflows)
+			*overflows = cl_overflows;
+		return true;
+	}
 	double cl_est_per_query = 0; // candidates per query of the last coarse-filter search + 30 %: sizes the next search's sort
+	int cl_seg_rows = 512;       // option ivf_cl_seg_rows
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
 	int *h_fail = nullptr; // pinned

@@ -26,7 +26,8 @@
 #include <cstring>
 
 namespace mvs {
-int g_ivf_cl_xcd = 1; // option ivf_cl_xcd: items of one list on one XCD (1) or dealt round-robin (0, round 3)
+int g_ivf_cl_lds_pad = 0; // (experiment: unused dynamic LDS per workgroup = fewer wavefronts per CU)
+int g_ivf_cl_xcd = 1; // option ivf_cl_xcd: items of one list on one XCD (1), their segments next to each other too (2), or dealt round-robin (0, round 3)
 extern int g_cl_bound_mode; // csrc/flat_collect.hip: bf16 rounding term of the bounds from the actual residual norms (1) | worst case (0)
 
 typedef __bf16 bf16x8i __attribute__((ext_vector_type(8)));
@@ -36,7 +37,7 @@ typedef __attribute__((address_space(3))) float lds_f32i;
 typedef __attribute__((address_space(1))) const float glb_f32i;
 
 constexpr int IC_BN = 32;    // rows per tile
-constexpr int IC_QCAP = 256; // candidate queue of a work item (entries of 8 bytes)
+constexpr int IC_QCAP = 128; // candidate queue of a work item (entries of 8 bytes; 128: 20 032 bytes of LDS per wavefront = EIGHT per CU, 256 made it seven)
 
 int g_ivf_cl_refresh = 16; // option ivf_cl_refresh (see IvfCollectArgs::refresh)
 struct IvfCollectArgs {
@@ -57,7 +58,9 @@ struct IvfCollectArgs {
 	int collect;  // 0: bound estimation only (publish to the slots, append nothing)
 	int refresh;  // tiles between two refreshes of the bounds after the first (option ivf_cl_refresh; 0: 1, 1, 1, 1, 4, 4 ... 16)
 	const unsigned *rowmask; // IDSelector active: bit r of word w = padded row 32 w + r is accepted (nullptr: no selector)
-	int xcd_map; // 1: XCD j (= blockIdx.x & 7) takes the contiguous item range [j n/8, (j+1) n/8) (option ivf_cl_xcd)
+	int nseg;    // segments per item (xcd_map >= 2 decodes the segment from blockIdx.x)
+	int gx8;     // workgroups of one segment round (a multiple of 8)
+	int xcd_map; // 2: as 1, and the segments of an item are consecutive workgroups of its XCD; 1: XCD j (= blockIdx.x & 7) takes the contiguous item range [j n/8, (j+1) n/8) (option ivf_cl_xcd)
 };
 
 __device__ __forceinline__ unsigned ic_skey(float s) { // "larger s is better" as a smaller-is-better key
@@ -180,7 +183,8 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		c[i] = cent[(size_t)l * d + i];
 	__syncthreads();
 	bf16x8i *dst = xi + (size_t)blockIdx.x * (8 * 4 * 64);
-	for (int i = threadIdx.x; i < 8 * 4 * 64; i += 256) { // (column block, k-block, lane)
+	// (only the column blocks that hold a slot: the scan kernel does not fetch the others)
+	for (int i = threadIdx.x; i < ((it.w + 15) >> 4) * 4 * 64; i += 256) { // (column block, k-block, lane)
 		const int lane = i & 63, kb = (i >> 6) & 3, cb = i >> 8;
 		const int slot = cb * 16 + (lane & 15);
 		bf16x8i v;
@@ -293,9 +297,31 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	// round-robin to the eight XCDs, so with item = blockIdx.x every XCD's L2 fetched the list for itself (PMC, C3's main pass:
 	// 5.08 GB on the memory side for 2.59 GB of list rows).  XCD j now takes the contiguous item range [j n/8, (j+1) n/8):
 	// neighbours run on one XCD at the same time and the second one finds the rows in that L2.
+	// (xcd_map = 2, round 4: the SEGMENTS of an item are neighbours too -- a one-dimensional grid, segment fastest inside the XCD's
+	// item range -- so the five or so waves of an item fetch its 32 KB of query fragments while they are in that L2, and the next
+	// item of the same list walks the same segment a few waves later.  With the segment in blockIdx.y the waves of one item were
+	// max_items launches apart: every one of them fetched the fragments from memory.)
 	const int nitems = *a.nitems_dev;
-	int item = (int)blockIdx.x;
-	if (a.xcd_map) {
+	int item = (int)blockIdx.x, seg = (int)blockIdx.y;
+	if (a.xcd_map >= 2) {
+		// (3: segment 0 of EVERY item first -- every query sees the head of each of its lists before anything else, as with the
+		// two-dimensional grid: walked item by item the bounds tighten late and the candidate count grows several times)
+		const int per = (nitems + 7) >> 3;
+		unsigned b = blockIdx.x;
+		int nsg = a.nseg, s0 = 0;
+		bool head = false;
+		if (a.xcd_map == 3 && a.nseg > 1) {
+			head = b < (unsigned)a.gx8;
+			if (!head)
+				b -= (unsigned)a.gx8, nsg = a.nseg - 1, s0 = 1;
+		}
+		const int idx = (int)(b >> 3);
+		const int local = head ? idx : idx / nsg;
+		seg = head ? 0 : s0 + (idx - local * nsg);
+		item = (int)(b & 7u) * per + local;
+		if (local >= per)
+			return;
+	} else if (a.xcd_map) {
 		const int per = (nitems + 7) >> 3, idx = (int)(blockIdx.x >> 3);
 		item = (int)(blockIdx.x & 7u) * per + idx;
 		if (idx >= per)
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	const int4 it = a.items[item];
 	const int lane = threadIdx.x;
 	const int hq = lane >> 4, c = lane & 15;
-	const long long r_begin = (long long)it.x + (long long)blockIdx.y * a.seg_rows;
+	const long long r_begin = (long long)it.x + (long long)seg * a.seg_rows;
 	if (r_begin >= it.y)
 		return;
 	const long long r_end = r_begin + a.seg_rows < it.y ? r_begin + a.seg_rows : it.y;
@@ -334,8 +360,8 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 #pragma unroll
 		for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-			for (int kb = 0; kb < KB; ++kb)
-				bq[cb][kb] = qsrc[(cb * 4 + kb) * 64 + lane];
+			for (int kb = 0; kb < KB; ++kb) // (column blocks past the item's last slot: zeros, not fetched -- their slots' bounds are NaN)
+				bq[cb][kb] = cb * 16 < it.w ? qsrc[(cb * 4 + kb) * 64 + lane] : bf16x8i{0, 0, 0, 0, 0, 0, 0, 0};
 	}
 
 	// LDS-DMA staging by this one wave: instruction i of a tile fills LDS bytes [1024 i, +1024) = rows 4 i + (l >> 4), position
@@ -611,12 +637,20 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.collect = collect;
 	a.refresh = g_ivf_cl_refresh;
 	a.rowmask = d_rowmask;
-	a.xcd_map = (g_ivf_cl_xcd && max_items >= 64) ? 1 : 0; // (the Flat small-batch path has one or two items: nothing to place)
-	const unsigned gx = (unsigned)max_items + (a.xcd_map ? 8u : 0u);
+	a.xcd_map = (g_ivf_cl_xcd && max_items >= 64) ? g_ivf_cl_xcd : 0; // (the Flat small-batch path has one or two items: nothing to place)
+	a.nseg = nseg;
+	unsigned gx = (unsigned)max_items + (a.xcd_map ? 8u : 0u);
+	if (a.xcd_map >= 2) {
+		gx = (gx + 7u) & ~7u;
+		if ((uint64_t)gx * (uint64_t)nseg >= ((uint64_t)1 << 31))
+			a.xcd_map = 1;
+	}
+	a.gx8 = (int)gx;
+	const dim3 grid = a.xcd_map >= 2 ? dim3(gx * (unsigned)nseg) : dim3(gx, nseg);
 	if (kk > 16) // 32 row classes: the caller sized and initialised 32 slots per query (ivf_collect_slot_stride)
-		hipLaunchKernelGGL(ivf_bf16_collect_kernel<32>, dim3(gx, nseg), dim3(64), 0, st, a);
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<32>, grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
 	else
-		hipLaunchKernelGGL(ivf_bf16_collect_kernel<16>, dim3(gx, nseg), dim3(64), 0, st, a);
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<16>, grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
 	MVS_HIP(hipGetLastError());
 }
 
