@@ -1051,10 +1051,9 @@ public:
 		// the k best by (value, position in the list-sorted store), labels = stored ids (then the id map of an IDMap wrapper)
 		// (the selected lists are already in the scan kernels' order: value, then position -- inner product keeps it as
 		// merge_items_kernel does; the L2 merge of one split only translates the labels)
-		if (metric == METRIC_L2) {
-			launch_merge_partials(metric, pd1, pi1, 1, nq, kk, raw_pos ? nullptr : (const int64_t *)rowids.p, 0, d_D, d_I, stream, k,
-			                      nullptr);
-		} else {
+		if (metric == METRIC_L2 && !raw_pos) {
+			launch_merge_partials(metric, pd1, pi1, 1, nq, kk, (const int64_t *)rowids.p, 0, d_D, d_I, stream, k, nullptr);
+		} else { // (inside the exact-tie wrapper the finish kernel orders equal values by stored id itself: positions as they are)
 			const long long tot = (long long)nq * k;
 			hipLaunchKernelGGL(ivf_emit_sorted_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, pd1, pi1, (int)kk,
 			                   (int)k, tot, raw_pos ? nullptr : (const long long *)rowids.p, d_D, (long long *)d_I);

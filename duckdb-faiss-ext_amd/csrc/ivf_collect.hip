@@ -156,58 +156,66 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
                                                              float *__restrict__ ie2, int *__restrict__ qfail,
                                                              const long long *__restrict__ coarse, int np, float *__restrict__ ie2_pre,
                                                              int nlist, int bound_mode) {
-	if ((int)blockIdx.x >= *nitems_dev)
+	// (round 4: one workgroup per HALF item -- slots 64 h .. 64 h + 63 -- with half the LDS: four workgroups per CU instead of two,
+	// and an item of <= 64 queries costs one workgroup's worth of work; the kernel waits on memory more than it computes)
+	const int item = (int)(blockIdx.x >> 1), s0 = 64 * (int)(blockIdx.x & 1u);
+	if (item >= *nitems_dev)
 		return;
-	const int4 it = items[blockIdx.x];
+	const int4 it = items[item];
+	if (s0 >= it.w && s0 > 0)
+		return; // (the first half also writes the NaN bounds of the unused slots 64 .. 127)
+	const int nsl = it.w - s0 < 64 ? (it.w - s0 > 0 ? it.w - s0 : 0) : 64; // slots of this half that hold a query
 	const int l = list_of_blk64[it.x >> 6]; // every list starts at a multiple of 64 rows
 	// the item's query rows and its centroid pass through LDS once (coalesced 16-byte loads when d % 4 == 0): both halves below
 	// walk them element by element -- from global memory that was one dependent, uncoalesced load per element
-	extern __shared__ __attribute__((aligned(16))) float pk_lds[]; // [128][d + 1] query rows, then [d] the centroid
+	extern __shared__ __attribute__((aligned(16))) float pk_lds[]; // [64][d + 1] query rows, then [d] the centroid
 	const int xp = d + 1;
-	float *xs = pk_lds, *c = pk_lds + 128 * xp;
+	float *xs = pk_lds, *c = pk_lds + 64 * xp;
 	if ((d & 3) == 0) {
 		const int cpr = d >> 2;
-		for (int i = threadIdx.x; i < it.w * cpr; i += 256) {
-			const int slot = i / cpr, ch = i - slot * cpr;
-			const float4 v = *(const float4 *)(x + (size_t)qidx[it.z + slot] * d + 4 * ch);
-			float *o = xs + slot * xp + 4 * ch;
+		for (int i = threadIdx.x; i < nsl * cpr; i += 256) {
+			const int sl = i / cpr, ch = i - sl * cpr;
+			const float4 v = *(const float4 *)(x + (size_t)qidx[it.z + s0 + sl] * d + 4 * ch);
+			float *o = xs + sl * xp + 4 * ch;
 			o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
 		}
 	} else {
-		for (int i = threadIdx.x; i < it.w * d; i += 256) {
-			const int slot = i / d, kk = i - slot * d;
-			xs[slot * xp + kk] = x[(size_t)qidx[it.z + slot] * d + kk];
+		for (int i = threadIdx.x; i < nsl * d; i += 256) {
+			const int sl = i / d, kk = i - sl * d;
+			xs[sl * xp + kk] = x[(size_t)qidx[it.z + s0 + sl] * d + kk];
 		}
 	}
 	for (int i = threadIdx.x; i < d; i += 256)
 		c[i] = cent[(size_t)l * d + i];
 	__syncthreads();
-	bf16x8i *dst = xi + (size_t)blockIdx.x * (8 * 4 * 64);
+	bf16x8i *dst = xi + (size_t)item * (8 * 4 * 64) + (size_t)(s0 >> 4) * (4 * 64);
 	// (only the column blocks that hold a slot: the scan kernel does not fetch the others)
-	for (int i = threadIdx.x; i < ((it.w + 15) >> 4) * 4 * 64; i += 256) { // (column block, k-block, lane)
+	for (int i = threadIdx.x; i < ((nsl + 15) >> 4) * 4 * 64; i += 256) { // (column block of this half, k-block, lane)
 		const int lane = i & 63, kb = (i >> 6) & 3, cb = i >> 8;
-		const int slot = cb * 16 + (lane & 15);
+		const int sl = cb * 16 + (lane & 15);
 		bf16x8i v;
 #pragma unroll
 		for (int e = 0; e < 8; ++e) {
 			const int kk = kb * 32 + 8 * (lane >> 4) + e;
 			float o = 0.f;
-			if (slot < it.w && kk < d) {
-				const float xv = xs[slot * xp + kk];
+			if (sl < nsl && kk < d) {
+				const float xv = xs[sl * xp + kk];
 				o = IS_L2 ? 2.0f * __fsub_rn(xv, c[kk]) : xv;
 			}
 			v[e] = (__bf16)o;
 		}
 		dst[i] = v;
 	}
-	if (threadIdx.x < 128) {
-		const int slot = threadIdx.x;
+	// slot bounds: this half's 64 slots; the first half of an item with <= 64 queries also writes the NaN entries of slots 64 .. 127
+	const int nout = (s0 == 0 && it.w <= 64) ? 128 : 64;
+	if ((int)threadIdx.x < nout) {
+		const int sl = threadIdx.x, slot = s0 + sl;
 		float g = 0.f, e2 = __uint_as_float(0x7fc00000u);
 		if (slot < it.w) {
 			const int q = qidx[it.z + slot];
 			float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f; // ||x'||^2 (L2) or ||x||^2 (IP); ||c||^2; <x, c>; ||a - bf16(a)||^2 of the operand a
 			for (int kk = 0; kk < d; ++kk) {
-				const float xv = xs[slot * xp + kk];
+				const float xv = xs[sl * xp + kk];
 				const float r = IS_L2 ? __fsub_rn(xv, c[kk]) : xv;
 				xn = fmaf(r, r, xn);
 				cn = fmaf(c[kk], c[kk], cn);
@@ -240,13 +248,13 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 			else
 				qfail[q] = 1;
 		}
-		igamma[(size_t)blockIdx.x * 128 + slot] = g;
-		ie2[(size_t)blockIdx.x * 128 + slot] = e2;
+		igamma[(size_t)item * 128 + slot] = g;
+		ie2[(size_t)item * 128 + slot] = e2;
 		// the pre-pass over THESE items (option ivf_cl_prepass_shared): only the slots whose list is their query's nearest take
 		// part -- E = NaN switches a slot off (nothing of it passes, nothing is published)
 		if (ie2_pre) {
 			const bool nearest = slot < it.w && coarse[(size_t)qidx[it.z + slot] * np] == (long long)l;
-			ie2_pre[(size_t)blockIdx.x * 128 + slot] = nearest ? e2 : __uint_as_float(0x7fc00000u);
+			ie2_pre[(size_t)item * 128 + slot] = nearest ? e2 : __uint_as_float(0x7fc00000u);
 		}
 	}
 }
@@ -259,17 +267,17 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
                              float *d_ie2_pre, int64_t nlist) {
 	if (max_items <= 0)
 		return;
-	const size_t lds = ((size_t)128 * (d + 1) + d) * sizeof(float); // 66.5 KB at d = 128: two workgroups per CU
+	const size_t lds = ((size_t)64 * (d + 1) + d) * sizeof(float); // 33.5 KB at d = 128: four workgroups per CU
 	if (metric == METRIC_L2) {
 		auto kern = ivf_collect_pack_kernel<true>;
 		ensure_dynamic_lds((const void *)kern, lds);
-		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
+		hipLaunchKernelGGL(kern, dim3(2 * max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
 		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
 		                   d_ie2_pre, (int)nlist, g_cl_bound_mode);
 	} else {
 		auto kern = ivf_collect_pack_kernel<false>;
 		ensure_dynamic_lds((const void *)kern, lds);
-		hipLaunchKernelGGL(kern, dim3(max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
+		hipLaunchKernelGGL(kern, dim3(2 * max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
 		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
 		                   d_ie2_pre, (int)nlist, g_cl_bound_mode);
 	}
