@@ -298,8 +298,11 @@ int g_coarse_mfma = 1; // option ivf_coarse_mfma: the distance matrix on the f32
 // strict compare against its neutral value; NaN never enters).  Inner product: the pure order (score descending, id ascending);
 // the caller asks for one entry more than nprobe and lets the merge flag boundary ties (FlatIndex::resolve_ip_ties).
 template <int PL, bool IS_L2>
+// outD != nullptr (L2, round 4): the list comes out ORDERED (dis ascending, id ascending -- what merge_partials_kernel made of it in a
+// launch of its own) straight into the caller's [nq][np] distances / labels (id + label_offset); pd / pi are not written.
 __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restrict__ D, int nlist, int np,
-                                                          float *__restrict__ pd, int *__restrict__ pi) {
+                                                          float *__restrict__ pd, int *__restrict__ pi,
+                                                          float *__restrict__ outD, long long *__restrict__ outI, long long label_offset) {
 	const long long q = blockIdx.x;
 	const int lane = threadIdx.x;
 	const float *row = D + q * nlist;
@@ -377,6 +380,8 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 						V = t;
 				}
 				int base = 0;
+				if (outD)
+					__syncthreads(); // (cand is reused for the compacted list: every lane has read its entries)
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
 					const bool take = e[i] <= V;
@@ -384,10 +389,26 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 					if (take) {
 						const int p = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
 						const unsigned kv = (unsigned)(e[i] >> 32);
-						pd[q * np + p] = IS_L2 ? __uint_as_float(kv) : key2f(~kv);
-						pi[q * np + p] = (int)(unsigned)e[i];
+						if (outD) {
+							cand[p] = e[i];
+						} else {
+							pd[q * np + p] = IS_L2 ? __uint_as_float(kv) : key2f(~kv);
+							pi[q * np + p] = (int)(unsigned)e[i];
+						}
 					}
 					base += __builtin_popcountll(m);
+				}
+				if (outD) { // exactly np distinct entries (key << 32 | id): lane p's rank = the entries below its own
+					__syncthreads();
+					if (lane < np) {
+						const unsigned long long mine = cand[lane];
+						int r = 0;
+						for (int j = 0; j < np; ++j)
+							r += cand[j] < mine ? 1 : 0;
+						const unsigned kv = (unsigned)(mine >> 32);
+						outD[q * np + r] = IS_L2 ? __uint_as_float(kv) : key2f(~kv);
+						outI[q * np + r] = (long long)(unsigned)mine + label_offset;
+					}
 				}
 				return;
 			}
@@ -435,11 +456,33 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 		if (take) {
 			const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
 			if (pos < np) {
-				pd[q * np + pos] = IS_L2 ? __uint_as_float(key[j]) : key2f(~key[j]);
-				pi[q * np + pos] = (int)id;
+				if (outD) {
+					cand[pos] = ((unsigned long long)key[j] << 32) | id; // (np <= 256 entries: ordered below)
+				} else {
+					pd[q * np + pos] = IS_L2 ? __uint_as_float(key[j]) : key2f(~key[j]);
+					pi[q * np + pos] = (int)id;
+				}
 			}
 		}
 		base += __builtin_popcountll(m);
+	}
+	if (outD) {
+		const int have = base < np ? base : np;
+		__syncthreads();
+		for (int p = lane; p < have; p += 64) {
+			const unsigned long long mine = cand[p];
+			int r = 0;
+			for (int j2 = 0; j2 < have; ++j2)
+				r += cand[j2] < mine ? 1 : 0;
+			const unsigned kv = (unsigned)(mine >> 32);
+			outD[q * np + r] = IS_L2 ? __uint_as_float(kv) : key2f(~kv);
+			outI[q * np + r] = (long long)(unsigned)mine + label_offset;
+		}
+		for (int pos = have + lane; pos < np; pos += 64) {
+			outD[q * np + pos] = IS_L2 ? FLT_MAX : -FLT_MAX;
+			outI[q * np + pos] = -1;
+		}
+		return;
 	}
 	for (int pos = base + lane; pos < np; pos += 64) {
 		pd[q * np + pos] = IS_L2 ? FLT_MAX : -FLT_MAX;
@@ -457,7 +500,7 @@ size_t coarse_select_matrix_bytes(int64_t nq, int64_t nlist) {
 // D (scratch, [nq][nlist]) <- distances; pd / pi [nq][np] <- the np nearest centroids of every query, unordered
 void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
                           const float *d_qn, const float *d_cn, int64_t np, int is_l2, float *d_D, float *d_pd, int32_t *d_pi,
-                          hipStream_t st) {
+                          hipStream_t st, float *d_outD, int64_t *d_outI, int64_t label_offset) {
 	if (nq <= 0)
 		return;
 	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
@@ -474,9 +517,9 @@ void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_ce
 #define MVS_CSEL(PL)                                                                                                               \
 	{                                                                                                                              \
 		if (is_l2)                                                                                                                 \
-			hipLaunchKernelGGL((coarse_select_kernel<PL, true>), dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi); \
+			hipLaunchKernelGGL((coarse_select_kernel<PL, true>), dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi, d_outD, (long long *)d_outI, (long long)label_offset); \
 		else                                                                                                                       \
-			hipLaunchKernelGGL((coarse_select_kernel<PL, false>), dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi); \
+			hipLaunchKernelGGL((coarse_select_kernel<PL, false>), dim3((unsigned)nq), dim3(64), 0, st, d_D, (int)nlist, (int)np, d_pd, d_pi, d_outD, (long long *)d_outI, (long long)label_offset); \
 	}
 	if (nlist <= 1024)
 		MVS_CSEL(16)

@@ -1153,12 +1153,14 @@ bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D
 	begin_kernel_timing(st);
 	for (int64_t q0 = 0; q0 < nq; q0 += qchunk) {
 		const int64_t m = std::min(qchunk, nq - q0);
+		// (L2: the selection kernel writes the ordered lists itself; inner product keeps the merge -- it flags the boundary ties)
 		launch_coarse_select(d_x + q0 * d, m, d, vecs, geom.dp, geom.pair_interleaved ? 1 : 0, ntotal, (const float *)ws_qn.p + q0, norms,
-		                     kk, ip ? 0 : 1, (float *)ws_q.p, (float *)ws_pd.p + q0 * kk, (int32_t *)ws_pi.p + q0 * kk, st);
+		                     kk, ip ? 0 : 1, (float *)ws_q.p, (float *)ws_pd.p + q0 * kk, (int32_t *)ws_pi.p + q0 * kk, st,
+		                     ip ? nullptr : d_D + q0 * np, ip ? nullptr : d_I + q0 * np, label_offset);
 	}
 	end_kernel_timing(st);
-	launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, 1, nq, kk, nullptr, label_offset, d_D, d_I, st, np,
-	                      ip ? &fl : nullptr);
+	if (ip)
+		launch_merge_partials(metric, (const float *)ws_pd.p, (const int32_t *)ws_pi.p, 1, nq, kk, nullptr, label_offset, d_D, d_I, st, np, &fl);
 	if (ip) {
 		SelectorDev nosel;
 		memset(&nosel, 0, sizeof nosel);

@@ -207,14 +207,16 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		dst[i] = v;
 	}
 	// slot bounds: this half's 64 slots; the first half of an item with <= 64 queries also writes the NaN entries of slots 64 .. 127
-	const int nout = (s0 == 0 && it.w <= 64) ? 128 : 64;
-	if ((int)threadIdx.x < nout) {
-		const int sl = threadIdx.x, slot = s0 + sl;
-		float g = 0.f, e2 = __uint_as_float(0x7fc00000u);
-		if (slot < it.w) {
-			const int q = qidx[it.z + slot];
-			float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f; // ||x'||^2 (L2) or ||x||^2 (IP); ||c||^2; <x, c>; ||a - bf16(a)||^2 of the operand a
-			for (int kk = 0; kk < d; ++kk) {
+	// The four sums of a slot -- ||x'||^2 (L2) or ||x||^2 (IP); ||c||^2; <x, c>; ||a - bf16(a)||^2 of the operand a -- as four partial
+	// chains over the dimensions k = j (mod 4), one per wave (a single 128-step chain per slot was the kernel's critical path: 8 us
+	// per workgroup whatever the number of slots; any summation order is inside the d u sum|terms| the bound allows for these sums)
+	__shared__ float part[4][64][4];
+	{
+		const int sl = threadIdx.x & 63, j = threadIdx.x >> 6;
+		float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f;
+		if (sl < nsl) {
+#pragma unroll 4
+			for (int kk = j; kk < d; kk += 4) {
 				const float xv = xs[sl * xp + kk];
 				const float r = IS_L2 ? __fsub_rn(xv, c[kk]) : xv;
 				xn = fmaf(r, r, xn);
@@ -224,6 +226,20 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 				const float dl = a - (float)(__bf16)a;
 				dq2 = fmaf(dl, dl, dq2);
 			}
+		}
+		part[j][sl][0] = xn, part[j][sl][1] = cn, part[j][sl][2] = xc, part[j][sl][3] = dq2;
+	}
+	__syncthreads();
+	const int nout = (s0 == 0 && it.w <= 64) ? 128 : 64;
+	if ((int)threadIdx.x < nout) {
+		const int sl = threadIdx.x, slot = s0 + sl;
+		float g = 0.f, e2 = __uint_as_float(0x7fc00000u);
+		if (slot < it.w) {
+			const int q = qidx[it.z + slot];
+			const float xn = ((part[0][sl][0] + part[1][sl][0]) + part[2][sl][0]) + part[3][sl][0];
+			const float cn = ((part[0][sl][1] + part[1][sl][1]) + part[2][sl][1]) + part[3][sl][1];
+			const float xc = ((part[0][sl][2] + part[1][sl][2]) + part[2][sl][2]) + part[3][sl][2];
+			const float dq2 = ((part[0][sl][3] + part[1][sl][3]) + part[2][sl][3]) + part[3][sl][3];
 			g = IS_L2 ? -xn : xc;
 			const float yn = __uint_as_float(list_max_bits[l]), dyn = __uint_as_float(list_max_bits[nlist + l]);
 			const double u = 5.9604644775390625e-08, infl = 1.0001;
