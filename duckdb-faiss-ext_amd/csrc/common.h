@@ -183,6 +183,8 @@ struct TieFlags {
 	float *val;  // [nq][k]   merged candidates in the pure order (score desc, row id asc)
 	int *row;    // [nq][k]
 };
+void launch_emit_sorted(const float *d_pd, const int32_t *d_pi, int64_t nq, int64_t k, int64_t kout, const int64_t *d_idmap,
+                        int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
 void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, int nsplit, int64_t nq, int64_t k,
                            const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st,
                            int64_t kout = -1, const TieFlags *flags = nullptr);

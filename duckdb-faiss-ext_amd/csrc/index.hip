@@ -958,7 +958,10 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	kinfo.nsplit = p.nsplit;
 	}
 	// the exact candidates through the normal merge: FAISS order, labels, inner-product tie flags
-	launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp);
+	if (collected && metric == METRIC_L2 && !flp) // (the coarse filter's selection is in FAISS's L2 order already: labels only)
+		launch_emit_sorted(pd1, pi1, nq, kp, k_user, out_map, out_off, d_D, d_I, st);
+	else
+		launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -108,32 +108,41 @@ __global__ void pack_queries_kernel(const float *__restrict__ x, long long nq, i
 // ||x_q||^2 as ONE k-ordered fma chain per query (the value FAISS's fvec_norm_L2sqr reference loop produces): one thread per
 // query runs the chain; the rows reach it through LDS in coalesced 64-dim slabs (a thread walking its own row from global
 // memory costs 3.6 ms for 10 000 x 768)
-__global__ __launch_bounds__(256) void query_norms_kernel(const float *__restrict__ x, long long nq, int d, float *__restrict__ out) {
-	__shared__ float tile[64][65];
-	const long long q0 = (long long)blockIdx.x * 64;
-	const int t = threadIdx.x & 63, w4 = threadIdx.x >> 6; // wave w4 fetches rows 16 w4 .. 16 w4 + 15 of the slab
+// (round 4: 16 rows per one-wave workgroup instead of 64 rows per 256 threads of which one wave ran the chains -- 10 000 queries
+// are 625 workgroups, not 157 on a 256-CU device -- and the chain loop unrolled so that its LDS reads are batched: the search
+// kernels wait for this one at the head of every step)
+__global__ __launch_bounds__(64) void query_norms_kernel(const float *__restrict__ x, long long nq, int d, float *__restrict__ out) {
+	__shared__ float tile[16][65];
+	const long long q0 = (long long)blockIdx.x * 16;
+	const int t = threadIdx.x;
 	float acc = 0.f;
 	for (int c0 = 0; c0 < d; c0 += 64) {
 		const int w = d - c0 < 64 ? d - c0 : 64;
 #pragma unroll
-		for (int j = 0; j < 16; ++j) {
-			const int r = w4 * 16 + j;
+		for (int r = 0; r < 16; ++r) {
 			const long long q = q0 + r;
 			tile[r][t] = (q < nq && t < w) ? x[q * d + c0 + t] : 0.f;
 		}
 		__syncthreads();
-		if (w4 == 0)
-			for (int i = 0; i < w; ++i)
-				acc = fmaf(tile[t][i], tile[t][i], acc);
+		if (t < 16) {
+			if (w == 64) {
+#pragma unroll
+				for (int i = 0; i < 64; ++i)
+					acc = fmaf(tile[t][i], tile[t][i], acc);
+			} else {
+				for (int i = 0; i < w; ++i)
+					acc = fmaf(tile[t][i], tile[t][i], acc);
+			}
+		}
 		__syncthreads();
 	}
-	if (w4 == 0 && q0 + t < nq)
+	if (t < 16 && q0 + t < nq)
 		out[q0 + t] = acc;
 }
 void launch_query_norms(const float *d_x, int64_t n, int d, float *d_out, hipStream_t st) {
 	if (n <= 0)
 		return;
-	hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, d_x, (long long)n, d, d_out);
+	hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, st, d_x, (long long)n, d, d_out);
 	MVS_HIP(hipGetLastError());
 }
 void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float *d_qf, float *d_qnorm,
@@ -144,7 +153,7 @@ void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float 
 	hipLaunchKernelGGL(pack_queries_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, d_x,
 	                   (long long)nq, g.d, g.kc, g.nch, d_qf, total4);
 	if (d_qnorm)
-		hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, d_x, (long long)nq, g.d, d_qnorm);
+		launch_query_norms(d_x, nq, g.d, d_qnorm, st);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -358,6 +367,31 @@ void launch_tie_resolve(const TieFlags &f, int nf, int64_t k, int64_t kout, cons
 	hipLaunchKernelGGL(tie_resolve_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f, nf, (int)k, (int)kout,
 	                   (const long long *)d_first_ids, (const long long *)d_idmap, (long long)label_offset, d_D,
 	                   (long long *)d_I);
+	MVS_HIP(hipGetLastError());
+}
+
+// One list per query that is ALREADY in FAISS's L2 order -- (distance, row) ascending, missing entries (FLT_MAX, -1) at the end: what
+// collect_select_kernel leaves -- only needs its labels: D / I [nq][kout] <- the first kout of k entries.  (merge_partials_kernel
+// with one split re-derives the order in k wave-wide rounds: 30 us per 10 000 queries at k = 10, a hundredth of a shard's step)
+__global__ void emit_sorted_kernel(const float *__restrict__ pd, const int32_t *__restrict__ pi, int k, int kout, long long total,
+                                   const long long *__restrict__ idmap, long long label_offset, float *__restrict__ D,
+                                   long long *__restrict__ I) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total)
+		return;
+	const long long q = i / kout;
+	const int j = (int)(i - q * kout);
+	const int id = pi[q * k + j];
+	D[i] = id < 0 ? FLT_MAX : pd[q * k + j];
+	I[i] = id < 0 ? -1ll : (idmap ? idmap[id] : (long long)id + label_offset);
+}
+void launch_emit_sorted(const float *d_pd, const int32_t *d_pi, int64_t nq, int64_t k, int64_t kout, const int64_t *d_idmap,
+                        int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st) {
+	const long long total = (long long)nq * kout;
+	if (total <= 0)
+		return;
+	hipLaunchKernelGGL(emit_sorted_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_pd, d_pi, (int)k, (int)kout, total,
+	                   (const long long *)d_idmap, (long long)label_offset, d_D, (long long *)d_I);
 	MVS_HIP(hipGetLastError());
 }
 
