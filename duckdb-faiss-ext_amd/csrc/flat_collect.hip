@@ -1406,15 +1406,103 @@ __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long 
 	const int lane = threadIdx.x;
 	const int b = seg_b[q], e = seg_e[q];
 	const unsigned long long EMPTY = ~0ull;
-	unsigned long long mine = EMPTY, mine2 = EMPTY; // entries `lane` and `64 + lane` of the sorted list
-	unsigned long long worst = EMPTY;
+	// Fast path (round 4; <= 1 024 candidates, lists of < 64 -- the usual case: 90-150 candidates for k = 10): every key in registers,
+	// U = the kk-th smallest of the 64 LANE MINIMA by value (an upper bound of the kk-th smallest value: the minima are distinct
+	// entries), the keys with value <= U -- a few times kk -- compacted into LDS and ranked against each other there.  The serial
+	// insertion below costs ~25 instructions per candidate that beats the running worst, ~kk ln(n / kk) + kk of them per query.
+	// Longer segments (clustered data: a few queries hold thousands of candidates and set the kernel's duration): the first 1 024
+	// entries go through the fast path, its result seeds the sorted list and the running worst of the serial loop, which then
+	// inserts only what beats a bound that is already tight.
+	int start = b;
+	unsigned long long seed_mine = EMPTY, seed_worst = EMPTY;
+	if (kk < 64) {
+		constexpr int R = 16;
+		__shared__ unsigned long long surv[256];
+		__shared__ unsigned long long top[64];
+		const int ce = e - b <= 1024 ? e : b + 1024; // end of the chunk taken here
+		const int n = ce - b, nr = (n + 63) >> 6;
+		unsigned long long kreg[R];
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			const int i = b + 64 * r + lane;
+			kreg[r] = (r < nr && i < ce) ? keys[i] : EMPTY;
+		}
+		unsigned U = 0xffffffffu;
+		if (n > 64) {
+			unsigned long long lmin = kreg[0];
+#pragma unroll
+			for (int r = 1; r < R; ++r)
+				lmin = kreg[r] < lmin ? kreg[r] : lmin;
+			const unsigned hi = (unsigned)(lmin >> 32); // (EMPTY: 0xffffffff)
+			U = 0u;
+#pragma unroll 1
+			for (int bit = 31; bit >= 0; --bit) {
+				const unsigned t = U | (1u << bit);
+				if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(hi < t)) < kk)
+					U = t;
+			}
+		}
+		// (values <= U: a few times kk unless many candidates share the boundary value; past 256 of them: the serial path)
+		int total = 0;
+#pragma unroll
+		for (int r = 0; r < R; ++r)
+			total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(kreg[r] != EMPTY && (unsigned)(kreg[r] >> 32) <= U));
+		if (total <= 256) {
+			int S = 0;
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				const bool take = kreg[r] != EMPTY && (unsigned)(kreg[r] >> 32) <= U;
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+				if (take)
+					surv[S + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = kreg[r];
+				S += __builtin_popcountll(m);
+			}
+			if (lane < 64)
+				top[lane] = EMPTY;
+			__syncthreads();
+			for (int p = lane; p < S; p += 64) {
+				const unsigned long long me = surv[p];
+				int rank = 0;
+				for (int j = 0; j < S; ++j) { // (equal keys cannot occur -- a row is scanned once per query --; ranked by position if they did)
+					const unsigned long long o = surv[j];
+					rank += (o < me || (o == me && j < p)) ? 1 : 0;
+				}
+				if (rank < kk)
+					top[rank] = me;
+			}
+			__syncthreads();
+			if (ce == e) { // the whole segment: done
+				if (lane < kk) {
+					const unsigned long long me = top[lane];
+					const bool have = me != EMPTY;
+					pd1[q * kk + lane] = have ? bkey2f<IS_L2>((unsigned)(me >> 32)) : (IS_L2 ? FLT_MAX : -FLT_MAX);
+					pi1[q * kk + lane] = have ? (int)(unsigned)me : -1;
+				}
+				return;
+			}
+			seed_mine = lane < kk ? top[lane] : EMPTY;
+			seed_worst = top[kk - 1];
+			start = ce;
+		}
+	}
+	unsigned long long mine = seed_mine, mine2 = EMPTY; // entries `lane` and `64 + lane` of the sorted list
+	unsigned long long worst = seed_worst;
 	auto shr1 = [](unsigned long long v) { // lane i <- lane i - 1 (lane 0: 0)
 		return ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false) << 32) |
 		       (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
 	};
-	for (int base = b; base < e; base += 64) {
-		const int i = base + lane;
-		const unsigned long long key = i < e ? keys[i] : EMPTY;
+	// (eight loads in flight per round trip: a segment of thousands of entries walked 64 at a time was one dependent global load
+	// per iteration -- the few heavy queries of a clustered batch set the kernel's duration)
+	for (int base8 = start; base8 < e; base8 += 512) {
+	unsigned long long k8[8];
+#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		const int i = base8 + 64 * r + lane;
+		k8[r] = i < e ? keys[i] : EMPTY;
+	}
+#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		const unsigned long long key = k8[r];
 		unsigned long long pend = __builtin_amdgcn_ballot_w64(key < worst);
 		while (pend != 0ull) {
 			const int L = __builtin_ctzll(pend);
@@ -1442,6 +1530,7 @@ __global__ __launch_bounds__(64) void collect_select_kernel(const unsigned long 
 				mine = up;
 			worst = kk > 64 ? cl_lane64(mine2, kk - 65) : cl_lane64(mine, kk - 1);
 		}
+	}
 	}
 	if (lane < kk) {
 		const bool have = mine != EMPTY;

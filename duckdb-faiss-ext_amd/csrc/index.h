@@ -206,7 +206,7 @@ public:
 	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, bool defer_count = false);
 	int64_t cl_deferred_cap = 0;
 	bool cl_defer = true; // option cl_defer_count
-	double cl_est_per_query = 0; // candidates per query of the last search (+ 30 %): the size the next search's sort is launched with
+	double cl_est_per_query = 0; // candidates per query of the last search: sizes the next search's sort (collect_sort_estimate)
 	int cl_skip = 0, cl_skip_len = 0; // searches that bypass the coarse filter after it gave up on this index's data (doubling, <= 64)
 	void drop_bf16_rows();
 	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
@@ -351,6 +351,13 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
                          unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
                          hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out);
+// Entries the deferred sort of a search is launched with, from the candidates per query c of the index's previous search: the
+// margin shrinks with the batch (the mean of nq heavy-tailed per-query counts), 17 % + 16 per query at 10 000 queries, 40 % at 64
+// (round 4, first cut: 30 % + 64 per query whatever the batch -- at C3's 149 per query the sort ran over 75 % more entries than it had)
+static inline int64_t collect_sort_estimate(double c, int64_t nq) {
+	const double per = c * (1.15 + 2.0 / sqrt((double)std::max<int64_t>(nq, 1))) + 16.0;
+	return ((int64_t)(per * (double)nq) + 65535) / 65536 * 65536;
+}
 size_t collect_sort_temp_bytes(int64_t ncand, int64_t nq);
 size_t collect_sort_temp_bytes_est(int64_t n_est, int64_t nq);
 void launch_collect_group_est(unsigned long long *d_stream, unsigned long long *d_sorted, const unsigned long long *d_cnt,
@@ -376,6 +383,9 @@ extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_reg
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
                              float *d_beta, unsigned *d_list_max_bits /* [2 nlist] */, int64_t nlist, hipStream_t st);
 size_t ivf_collect_xi_bytes(int max_items);
+void launch_ivf_collect_pack_nearest(int metric, const float *d_x, int d, int64_t nq, const int *d_slots, const void *d_items,
+                                     const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
+                                     float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st);
 void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
                              float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse, int np,

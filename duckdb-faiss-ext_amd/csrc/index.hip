@@ -450,7 +450,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 	if (defer_count && cl_est_per_query > 0) { // the caller looks at the count after its own synchronisation
 		// (size of the sort: what the previous search of this index produced per query, + 30 %, in units of 64 K entries)
-		cl_deferred_cap = std::min<int64_t>(cap_entries, ((int64_t)(cl_est_per_query * (double)nq) + 65535) / 65536 * 65536);
+		cl_deferred_cap = std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq));
 		break;
 	}
 	defer_count = false; // (the first search of an index has no estimate yet: the synchronous way, which leaves one)
@@ -497,7 +497,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	if (!defer_count) {
 		cl_queries_total += nq;
 		cl_candidates_total += ncand;
-		cl_est_per_query = 1.3 * (double)ncand / (double)std::max<int64_t>(nq, 1) + 64.0;
+		cl_est_per_query = (double)ncand / (double)std::max<int64_t>(nq, 1) + 1e-6;
 		cl_deferred_cap = 0; // (tells the caller that this pass was synchronous)
 	}
 	const size_t temp = defer_count ? collect_sort_temp_bytes_est(cl_deferred_cap, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
@@ -987,7 +987,7 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		unsigned long long ncand_u;
 		memcpy(&ncand_u, h_flag_count + 10, sizeof ncand_u);
 		cl_last_candidates = (int64_t)ncand_u;
-		cl_est_per_query = 1.3 * (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 64.0;
+		cl_est_per_query = (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 1e-6;
 		if ((int64_t)ncand_u > cl_deferred_cap) {
 			*overflow = true; // (more entries than the sort covered: the synchronous pass overwrites the results written so far)
 			return false;
@@ -2008,6 +2008,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 #endif
 	if (!strcmp(key, "cl_bound_mode")) { // bf16 rounding term of the coarse filter's bound: actual residual norms (1) | worst case (0)
 		g_cl_bound_mode = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_est")) { // tests: pretend the previous search had v candidates per query (a sort sized too small is re-run)
+		cl_est_per_query = (double)v + 1e-6;
 		return true;
 	}
 	if (!strcmp(key, "cl_defer_count")) { // 1 (default): no host round trip for the candidate count between scan and re-scoring

@@ -969,8 +969,14 @@ public:
 			const bool nearest_only = phase == 0 && !cl_prepass_all && !shared;
 			if (phase == 0 || !(cl_prepass_all || shared)) {
 				launch_ivf_group(keys, nq, nearest_only ? 1 : (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
-				                 (int *)ws_group.p + (phase == 0 ? 0 : group_ints), ws_items.p, (int *)ws_qidx.p, nullptr, &d_nitems, &d_cnt,
-				                 stream, nearest_only ? (int)np : 1, true);
+				                 (int *)ws_group.p + (phase == 0 ? 0 : group_ints), ws_items.p, (int *)ws_qidx.p,
+				                 nearest_only && cl_pack_nearest ? (int *)ws_slots.p : nullptr, &d_nitems, &d_cnt, stream,
+				                 nearest_only ? (int)np : 1, true);
+				if (nearest_only && cl_pack_nearest) // one pair per query: packed query by query (csrc/ivf_collect.hip)
+					launch_ivf_collect_pack_nearest(metric, d_x, d, nq, (const int *)ws_slots.p, ws_items.p, (const float *)cent_dev.p,
+					                                (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
+					                                (float *)ws_ie2.p, ctl_qfail, nlist, stream);
+				else
 				launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
 				                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
 				                        (float *)ws_ie2.p, ctl_qfail, stream, shared ? (const int64_t *)ws_cI.p : nullptr, (int)np,
@@ -997,7 +1003,7 @@ public:
 		MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
 		unsigned long long ncand_u = 0;
 		// (deferred: the sort covers n_est entries -- the previous search's candidates per query + 30 %, in units of 64 K)
-		const int64_t n_est = defer ? std::min<int64_t>(cap_entries, ((int64_t)(cl_est_per_query * (double)nq) + 65535) / 65536 * 65536) : 0;
+		const int64_t n_est = defer ? std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq)) : 0;
 		if (!defer) {
 			MVS_HIP(hipStreamSynchronize(stream));
 			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
@@ -1032,7 +1038,7 @@ public:
 		if (!defer) {
 			cl_queries_total += nq;
 			cl_candidates_total += ncand;
-			cl_est_per_query = 1.3 * (double)ncand / (double)std::max<int64_t>(nq, 1) + 64.0;
+			cl_est_per_query = (double)ncand / (double)std::max<int64_t>(nq, 1) + 1e-6;
 		}
 		const size_t temp = defer ? collect_sort_temp_bytes_est(n_est, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 		ws_sorttmp.reserve(std::max<size_t>(temp, 16));
@@ -1072,7 +1078,7 @@ public:
 		if (defer) { // the one host round trip of the search: candidate count (did the sort cover it?) and the fail list's length
 			MVS_HIP(hipStreamSynchronize(stream));
 			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
-			cl_est_per_query = 1.3 * (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 64.0;
+			cl_est_per_query = (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 1e-6;
 			if ((int64_t)ncand_u > n_est) {
 				*overflow = true;
 				return false;
@@ -1497,10 +1503,18 @@ public:
 			cl_stream_cap_per_query = v;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_pack_nearest")) { // 1 (default): the nearest-list pre-pass packs its one pair per query query by query
+			cl_pack_nearest = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_seg_rows")) { // rows per (work item, segment) wavefront of the main pass: a multiple of 32
 			if (v < 32 || v > 65536 || v % 32)
 				return false;
 			cl_seg_rows = (int)v;
+			return true;
+		}
+		if (!strcmp(key, "ivf_cl_est")) { // tests: pretend the previous search had v candidates per query (a sort sized too small is re-run)
+			cl_est_per_query = (double)v + 1e-6;
 			return true;
 		}
 		if (!strcmp(key, "ivf_cl_defer")) { // 1 (default): the candidate count stays on the device between scan and re-scoring
@@ -1578,8 +1592,9 @@ private:
 			*overflows = cl_overflows;
 		return true;
 	}
-	double cl_est_per_query = 0; // candidates per query of the last coarse-filter search + 30 %: sizes the next search's sort
+	double cl_est_per_query = 0; // candidates per query of the last coarse-filter search: sizes the next search's sort (collect_sort_estimate)
 	int cl_seg_rows = 512;       // option ivf_cl_seg_rows
+	bool cl_pack_nearest = true; // option ivf_cl_pack_nearest
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
 	int *h_fail = nullptr; // pinned

@@ -146,6 +146,29 @@ void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int
 // Inner product (IS_L2 = false): the query enters as bf16(x) (not centred: <x, y> = <x, y'> + <x, c>), gamma = <x, c_list>, beta = 0;
 //   E = (2^-7 + 2^-16) S + 1.25 (d/16) 4u ((1 + 2^-7 + 2^-16) S + |gamma|) + d u ||x|| ||c|| (gamma's chain) + u S (y' rounding)
 //       + d u ||x|| (||c|| + ||y'||_max) (the scanner's chain over the original row),   S = ||x|| ||y'||_max(list)
+// 2 E of one (query, list) pair from the four sums of ivf_collect_pack_kernel (NaN: not finite -> the query is re-run on the scanner)
+template <bool IS_L2>
+__device__ __forceinline__ float ivf_slot_e2(float xn, float cn, float dq2, float yn, float dyn, int d, int bound_mode) {
+	const double u = 5.9604644775390625e-08, infl = 1.0001;
+	const double nx = sqrt((double)xn * infl), ny = sqrt((double)yn * infl), nc = sqrt((double)cn * infl), S = nx * ny;
+	// bf16 rounding of both operands: the worst case per element, or (round 4, csrc/flat_collect.hip collect_bounds_kernel) from
+	// the ACTUAL residual norms: |<a, y'> - <bf(a), bf(y')>| <= ||a - bf(a)|| ||y'||_max + (||a|| + ||a - bf(a)||) ||y' - bf(y')||_max
+	const double al = IS_L2 ? 2.0 : 1.0;
+	const double ndq = sqrt((double)dq2 * infl), ndy = sqrt((double)dyn * infl);
+	const double rnd_worst = al * (0.0078125 + 1.52587890625e-05) * S, rnd_actual = ndq * ny + (al * nx + ndq) * ndy;
+	const double rnd = bound_mode == 0 ? rnd_worst : (rnd_actual < rnd_worst || !(rnd_actual == rnd_actual) ? rnd_actual : rnd_worst);
+	double E;
+	if (IS_L2)
+		E = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * 2.0 * S + (double)xn + yn) +
+		    ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
+	else
+		E = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * S + nx * nc) + (double)d * u * nx * nc + u * S +
+		    ((double)d + 2.0) * u * nx * (nc + ny);
+	const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn + nx * nc) + 1e-30);
+	if (isfinite(xn) && isfinite(yn) && isfinite(dq2) && isfinite(dyn) && isfinite(r) && r < 1e30f)
+		return r;
+	return __uint_as_float(0x7fc00000u);
+}
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__restrict__ x, int d, const int4 *__restrict__ items,
                                                              const int *__restrict__ nitems_dev, const int *__restrict__ qidx,
@@ -242,26 +265,8 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 			const float dq2 = ((part[0][sl][3] + part[1][sl][3]) + part[2][sl][3]) + part[3][sl][3];
 			g = IS_L2 ? -xn : xc;
 			const float yn = __uint_as_float(list_max_bits[l]), dyn = __uint_as_float(list_max_bits[nlist + l]);
-			const double u = 5.9604644775390625e-08, infl = 1.0001;
-			const double nx = sqrt((double)xn * infl), ny = sqrt((double)yn * infl), nc = sqrt((double)cn * infl), S = nx * ny;
-			// bf16 rounding of both operands: the worst case per element, or (round 4, csrc/flat_collect.hip collect_bounds_kernel) from
-			// the ACTUAL residual norms: |<a, y'> - <bf(a), bf(y')>| <= ||a - bf(a)|| ||y'||_max + (||a|| + ||a - bf(a)||) ||y' - bf(y')||_max
-			const double al = IS_L2 ? 2.0 : 1.0;
-			const double ndq = sqrt((double)dq2 * infl), ndy = sqrt((double)dyn * infl);
-			const double rnd_worst = al * (0.0078125 + 1.52587890625e-05) * S, rnd_actual = ndq * ny + (al * nx + ndq) * ndy;
-			const double rnd = bound_mode == 0 ? rnd_worst : (rnd_actual < rnd_worst || !(rnd_actual == rnd_actual) ? rnd_actual : rnd_worst);
-			double E;
-			if (IS_L2)
-				E = rnd +
-				    1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * 2.0 * S + (double)xn + yn) +
-				    ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
-			else
-				E = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * S + nx * nc) +
-				    (double)d * u * nx * nc + u * S + ((double)d + 2.0) * u * nx * (nc + ny);
-			const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn + nx * nc) + 1e-30);
-			if (isfinite(xn) && isfinite(yn) && isfinite(dq2) && isfinite(dyn) && isfinite(r) && r < 1e30f)
-				e2 = r;
-			else
+			e2 = ivf_slot_e2<IS_L2>(xn, cn, dq2, yn, dyn, d, bound_mode);
+			if (!(e2 == e2))
 				qfail[q] = 1;
 		}
 		igamma[(size_t)item * 128 + slot] = g;
@@ -273,6 +278,78 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 			ie2_pre[(size_t)item * 128 + slot] = nearest ? e2 : __uint_as_float(0x7fc00000u);
 		}
 	}
+}
+// The nearest-list pre-pass has ONE pair per query, spread over ~ nlist items of a few slots each: the item-wise kernel above
+// then spends a workgroup, and four dependent global round trips, on two or three queries (70 us at C3, as long as the main
+// pass's packing of 32 times the pairs).  Here one wave per QUERY: slot code (ivf_group_scatter_*: item << 7 | slot) -> item ->
+// list -> centroid; lanes 0..15 hold the sixteen 8-element pieces of the slot's fragment column, the four sums are reduced over
+// them.  Slots of an item that no query owns are not written: the scan gives them a NaN bound whatever is stored (own_q < 0).
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void ivf_collect_pack_nearest_kernel(const float *__restrict__ x, int d, long long nq,
+                                                                     const int *__restrict__ slots, const int4 *__restrict__ items,
+                                                                     const float *__restrict__ cent, const int *__restrict__ list_of_blk64,
+                                                                     const unsigned *__restrict__ list_max_bits, bf16x8i *__restrict__ xi,
+                                                                     float *__restrict__ igamma, float *__restrict__ ie2,
+                                                                     int *__restrict__ qfail, int nlist, int bound_mode) {
+	const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (q >= nq)
+		return;
+	const int code = slots[q];
+	if (code < 0)
+		return;
+	const int item = code >> 7, slot = code & 127;
+	const int4 it = items[item];
+	const int l = list_of_blk64[it.x >> 6];
+	float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f;
+	if (lane < 16) {
+		const int kb = lane >> 2, hq = lane & 3;
+		bf16x8i v;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			const int kk = kb * 32 + 8 * hq + e;
+			const bool in = kk < d;
+			const float xv = in ? x[q * d + kk] : 0.f, cv = in ? cent[(size_t)l * d + kk] : 0.f;
+			const float r = IS_L2 ? __fsub_rn(xv, cv) : xv;
+			const float a = IS_L2 ? 2.0f * r : r;
+			v[e] = (__bf16)a;
+			xn = fmaf(r, r, xn);
+			cn = fmaf(cv, cv, cn);
+			xc = fmaf(xv, cv, xc);
+			const float dl = a - (float)(__bf16)a;
+			dq2 = fmaf(dl, dl, dq2);
+		}
+		xi[(size_t)item * (8 * 4 * 64) + (size_t)(((slot >> 4) * 4 + kb) * 64 + hq * 16 + (slot & 15))] = v;
+	}
+#pragma unroll
+	for (int o = 8; o >= 1; o >>= 1) { // (lanes 16 .. 63 carry zeros)
+		xn += __shfl_xor(xn, o);
+		cn += __shfl_xor(cn, o);
+		xc += __shfl_xor(xc, o);
+		dq2 += __shfl_xor(dq2, o);
+	}
+	if (lane == 0) {
+		const float yn = __uint_as_float(list_max_bits[l]), dyn = __uint_as_float(list_max_bits[nlist + l]);
+		const float e2 = ivf_slot_e2<IS_L2>(xn, cn, dq2, yn, dyn, d, bound_mode);
+		if (!(e2 == e2))
+			qfail[q] = 1;
+		igamma[(size_t)item * 128 + slot] = IS_L2 ? -xn : xc;
+		ie2[(size_t)item * 128 + slot] = e2;
+	}
+}
+void launch_ivf_collect_pack_nearest(int metric, const float *d_x, int d, int64_t nq, const int *d_slots, const void *d_items,
+                                     const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
+                                     float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	const dim3 grid((unsigned)((nq + 3) / 4));
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(ivf_collect_pack_nearest_kernel<true>, grid, dim3(256), 0, st, d_x, d, (long long)nq, d_slots, (const int4 *)d_items,
+		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
+	else
+		hipLaunchKernelGGL(ivf_collect_pack_nearest_kernel<false>, grid, dim3(256), 0, st, d_x, d, (long long)nq, d_slots, (const int4 *)d_items,
+		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
+	MVS_HIP(hipGetLastError());
 }
 size_t ivf_collect_xi_bytes(int max_items) {
 	return (size_t)max_items * 8 * 4 * 64 * 16;

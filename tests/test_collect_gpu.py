@@ -393,3 +393,30 @@ def test_round4_switches_do_not_change_a_single_bit(mf, metric):
         cl.set_option("cl_tab", 1)
     assert cands[(1, 1)] < 0.8 * cands[(0, 1)], cands  # the residual-norm bound admits clearly fewer rows
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_sort_sized_too_small_is_run_again(mf, metric):
+    """cl_est: 'the previous search of this index had v candidates per query'.  1 -> the deferred sort covers far too few entries,
+    the search notices at its one synchronisation and runs again the synchronous way; 100 000 -> far too many (capped by the
+    stream); both return the exact kernel's bits.  Also a batch whose heaviest queries hold more than 1 024 candidates (duplicated
+    rows): collect_select_kernel's chunked path."""
+    rs = np.random.RandomState(77)
+    d, nb, nq, k = 128, 90_000, 300, 10
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[1000:3500] = xb[7]  # 2 500 copies of one row: every query near it holds all of them
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq[:40] = xb[7] + 1e-3 * rs.rand(40, d).astype(np.float32)
+    ex = mf.index_factory(d, "Flat", metric)
+    ex.set_option("prefilter", 0)
+    ex.add(xb)
+    D0, I0 = ex.search(xq, k)
+    cl = mf.index_factory(d, "Flat", metric)
+    cl.set_option("prefilter", 2)
+    cl.add(xb)
+    for est in (0, 1, 100000, 0):
+        if est:
+            cl.set_option("cl_est", est)
+        D, I = cl.search(xq, k)
+        assert cl.last_kernel_info()["name"] == KERNEL
+        assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), est

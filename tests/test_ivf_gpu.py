@@ -668,8 +668,10 @@ def test_ivf_round4_switches_do_not_change_a_single_bit(mf):
     cent = ref.ivf_centroids()
     try:
         for bound in (1, 0):
-            for xcd in (1, 0):
+            for xcd in (1, 0, 2, 3):  # (2 / 3: the segments of an item as neighbouring workgroups -- measured slower, kept as options)
                 for defer in (1, 0):
+                    if xcd >= 2 and (bound == 0 or defer == 0):
+                        continue
                     g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
                     g.ivf_set_centroids(cent)
                     g.add(xb)
@@ -685,3 +687,31 @@ def test_ivf_round4_switches_do_not_change_a_single_bit(mf):
         g.set_option("cl_bound_mode", 1)
         g.set_option("ivf_cl_xcd", 1)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_ivf_sort_sized_too_small_is_run_again(mf, metric):
+    """The candidate count stays on the device and the sort is sized from the previous search (csrc/index.h collect_sort_estimate);
+    an estimate that turns out too small (ivf_cl_est: 'the previous search had 1 candidate per query') must be noticed at the end of
+    the search and the search run again the synchronous way -- same bits as the scanner kernel; the pre-pass packed query by query
+    (ivf_cl_pack_nearest) and item by item give the same results too."""
+    d, nlist, n = 64, 32, 60_000
+    xb = _clustered(n, d, 71)
+    xq = _clustered(400, d, 72)
+    ref = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    ref.train(xb)
+    ref.add(xb)
+    ref.set_option("ivf_collect", 0)
+    D0, I0 = ref.search(xq, 10, nprobe=6)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    g.ivf_set_centroids(ref.ivf_centroids())
+    g.add(xb)
+    for pack in (1, 0):
+        g.set_option("ivf_cl_pack_nearest", pack)
+        for est in (1, 0, 100000):
+            D, I = g.search(xq, 10, nprobe=6)  # (leaves a true estimate)
+            if est:
+                g.set_option("ivf_cl_est", est)
+            D, I = g.search(xq, 10, nprobe=6)
+            assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+            assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (pack, est)
