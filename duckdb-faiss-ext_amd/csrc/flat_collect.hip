@@ -249,8 +249,10 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
                                       const unsigned *__restrict__ max_norm_bits, float *__restrict__ e2,
                                       int *__restrict__ fail_cnt, int *__restrict__ fail_q, int bound_mode) {
 	const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= nq)
+	if (q >= nq) {
+		e2[q] = __uint_as_float(0x7fc00000u); // (the slots behind the last query, up to the next multiple of 256: nothing passes)
 		return;
+	}
 	float xn = 0.f, xnc = 0.f, mun = 0.f, dq2 = 0.f;
 	const float alf = IS_L2 ? 2.0f : 1.0f;
 	for (int t = 0; t < d; ++t) {
@@ -1119,12 +1121,14 @@ int collect_max_k(int d) {
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st) {
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st,
+                            bool cnt_zeroed) {
 	const int stride = collect_slot_stride(kk, collect_store_dims(g.d)); // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
 	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, stride,
 	                   0 /* larger s is better */);
-	MVS_HIP(hipMemsetAsync(d_stream_cnt, 0, 16, st));
+	if (!cnt_zeroed)
+		MVS_HIP(hipMemsetAsync(d_stream_cnt, 0, 16, st));
 	CollectArgs a;
 	memset(&a, 0, sizeof a);
 	a.qf = d_qf;
@@ -1675,13 +1679,13 @@ void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_se
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
-                            bool per_pair, hipStream_t st, const unsigned long long *d_cnt) {
+                            bool per_pair, hipStream_t st, const unsigned long long *d_cnt, bool seg_zeroed) {
 	if (nq <= 0)
 		return;
 	if (d_cnt)
-		launch_collect_group_est(d_stream, d_sorted, d_cnt, ncand, d_temp, temp_bytes, nq, d_seg, st, false);
+		launch_collect_group_est(d_stream, d_sorted, d_cnt, ncand, d_temp, temp_bytes, nq, d_seg, st, seg_zeroed);
 	else
-		launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st, false);
+		launch_collect_group(d_stream, d_sorted, ncand, d_temp, temp_bytes, nq, d_seg, st, seg_zeroed);
 	if (ncand > 0 && collect_store_dims(g.d) > 128) {
 		launch_collect_exact_wide(metric, per_pair, d_sorted, ncand, d_x, g.d, d_vecs, g.dp, g.pair_interleaved ? 1 : 0, d_norms, d_qn, st, d_cnt);
 	} else if (ncand > 0) {

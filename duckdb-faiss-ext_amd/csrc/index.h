@@ -343,7 +343,7 @@ int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int
                               int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st);
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st, bool cnt_zeroed = false);
 size_t collect_bound_table_bytes(int64_t nq);
 size_t collect_rowmask_bytes(int64_t n);
 void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, unsigned long long *d_mask, hipStream_t st);
@@ -366,7 +366,7 @@ void launch_collect_group_est(unsigned long long *d_stream, unsigned long long *
 void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
-                            bool per_pair, hipStream_t st, const unsigned long long *d_cnt = nullptr);
+                            bool per_pair, hipStream_t st, const unsigned long long *d_cnt = nullptr, bool seg_zeroed = false);
 void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_seg, int64_t nq, const int *d_flag_query,
                              const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st);
 bool coarse_select_supported(int64_t nlist, int64_t np);

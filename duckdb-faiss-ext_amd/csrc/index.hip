@@ -400,7 +400,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
 	const int64_t nq128 = (nq + 255) / 256 * 256;
 	ws_e2.reserve((size_t)nq128 * sizeof(float));
-	MVS_HIP(hipMemsetAsync(ws_e2.p, 0xff, (size_t)nq128 * sizeof(float), st)); // NaN: the slots behind the last query
+	// (the bounds kernel writes NaN into the slots behind the last query itself)
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
 	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk, collect_store_dims(d)) * sizeof(unsigned) + 64);
 	// candidate stream: 4096 entries per query to start with (option cl_stream_cap; at least 2^20), or what the last overflow
@@ -409,13 +409,17 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
 	size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 	ws_stream.reserve(256 + 2 * half);
-	unsigned long long *cnt = (unsigned long long *)ws_stream.p;
+	// one zeroed control block {stream count | per-query segments} (round 4: one memset instead of three per search)
+	ws_seg.reserve(256 + (size_t)2 * nq * sizeof(int));
+	MVS_HIP(hipMemsetAsync(ws_seg.p, 0, 256 + (size_t)2 * nq * sizeof(int), st));
+	unsigned long long *cnt = (unsigned long long *)ws_seg.p;
+	int *const seg = (int *)((char *)ws_seg.p + 256);
 	unsigned long long *stream = (unsigned long long *)((char *)ws_stream.p + 256);
 	unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 	ws_pbnd.reserve(collect_bound_table_bytes(nq));
 	float *pbnd = wide ? nullptr : (float *)ws_pbnd.p; // (the d <= 128 scan only)
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
-	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st);
+	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st, true);
 	int grid = 0, nsplit = 0, lds = 0;
 	const bool few = !wide && nq <= 128 && collect_slot_stride(kk, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
@@ -477,8 +481,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		if (cl_stream_cap_per_query <= 0)
 			cl_cap_hint = std::max<int64_t>(cl_cap_hint, (cap_entries + nq - 1) / nq);
 		half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
-		ws_stream.reserve(256 + 2 * half); // (a DevBuf keeps nothing when it grows: the counter is reset below anyway)
-		cnt = (unsigned long long *)ws_stream.p;
+		ws_stream.reserve(256 + 2 * half); // (a DevBuf keeps nothing when it grows: the counter -- in ws_seg -- is reset below anyway)
 		stream = (unsigned long long *)((char *)ws_stream.p + 256);
 		sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 	} else {
@@ -502,7 +505,6 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	}
 	const size_t temp = defer_count ? collect_sort_temp_bytes_est(cl_deferred_cap, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 	ws_sorttmp.reserve(std::max<size_t>(temp, 16));
-	ws_seg.reserve((size_t)2 * nq * sizeof(int));
 	const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
 	ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
 	float *pd1 = (float *)ws_ex.p;
@@ -510,7 +512,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	// (with a selector or fewer than 20 queries FAISS takes its per-pair branch: L2 = sum (x_k - y_k)^2; inner product is the
 	// same chain either way)
 	launch_collect_rescore(metric, stream, sorted, defer_count ? cl_deferred_cap : ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
-	                       (const float *)ws_qn.p, (int *)ws_seg.p, pd1, pi1, has_sel || nq < 20, st, defer_count ? cnt : nullptr);
+	                       (const float *)ws_qn.p, seg, pd1, pi1, has_sel || nq < 20, st, defer_count ? cnt : nullptr, true);
 	*pd1_out = pd1;
 	*pi1_out = pi1;
 	cl_sorted = sorted;
@@ -1077,7 +1079,7 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 	launch_gather_flagged(d_x, d, fl, nf, kraw, k, xf, T, st);
 	(void)tD;
 	if (tie_sorted)
-		launch_collect_tie_rows(tie_sorted, (const int *)ws_seg.p, nq, fl.query, T, nf, (int)k, tI, st);
+		launch_collect_tie_rows(tie_sorted, (const int *)((const char *)ws_seg.p + 256), nq, fl.query, T, nf, (int)k, tI, st);
 	else
 		tie_candidates(nf, xf, T, k, tI, sel, d_idmap, st);
 	launch_tie_resolve(fl, nf, kraw, k, tI, d_idmap, label_offset, d_D, d_I, st);
