@@ -373,7 +373,7 @@ bool coarse_select_supported(int64_t nlist, int64_t np);
 void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
                           const float *d_qn, const float *d_cn, int64_t np, int is_l2, float *d_D, float *d_pd, int32_t *d_pi,
                           hipStream_t st, float *d_outD = nullptr, int64_t *d_outI = nullptr, int64_t label_offset = 0);
-extern int g_coarse_select, g_ivf_cl_refresh, g_ivf_cl_xcd, g_coarse_mfma, g_ivf_cl_lds_pad, g_coarse_abl, g_coarse_persistent;
+extern int g_coarse_select, g_ivf_cl_refresh, g_ivf_cl_xcd, g_coarse_mfma, g_ivf_cl_lds_pad, g_coarse_abl, g_coarse_persistent, g_ivf_cl_abl;
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st, bool seg_zeroed = false);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,

@@ -1999,6 +1999,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		g_cl_abl = (int)v;
 		return true;
 	}
+	if (!strcmp(key, "ivf_cl_abl")) { // profiling only: results are wrong
+		g_ivf_cl_abl = (int)v;
+		return true;
+	}
 	if (!strcmp(key, "coarse_abl")) { // profiling only: results are wrong
 		g_coarse_abl = (int)v;
 		return true;

@@ -26,6 +26,7 @@
 #include <cstring>
 
 namespace mvs {
+int g_ivf_cl_abl = 0;     // (profiling library only: 1 = the scan without its rare path -- results wrong)
 int g_ivf_cl_lds_pad = 0; // (experiment: unused dynamic LDS per workgroup = fewer wavefronts per CU)
 int g_ivf_cl_xcd = 1; // option ivf_cl_xcd: items of one list on one XCD (1), their segments next to each other too (2), or dealt round-robin (0, round 3)
 extern int g_cl_bound_mode; // csrc/flat_collect.hip: bf16 rounding term of the bounds from the actual residual norms (1) | worst case (0)
@@ -58,6 +59,7 @@ struct IvfCollectArgs {
 	int collect;  // 0: bound estimation only (publish to the slots, append nothing)
 	int refresh;  // tiles between two refreshes of the bounds after the first (option ivf_cl_refresh; 0: 1, 1, 1, 1, 4, 4 ... 16)
 	const unsigned *rowmask; // IDSelector active: bit r of word w = padded row 32 w + r is accepted (nullptr: no selector)
+	int abl;     // profiling library only (option ivf_cl_abl)
 	int nseg;    // segments per item (xcd_map >= 2 decodes the segment from blockIdx.x)
 	int gx8;     // workgroups of one segment round (a multiple of 8)
 	int xcd_map; // 2: as 1, and the segments of an item are consecutive workgroups of its XCD; 1: XCD j (= blockIdx.x & 7) takes the contiguous item range [j n/8, (j+1) n/8) (option ivf_cl_xcd)
@@ -521,6 +523,12 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	};
 
 	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid, unsigned rowbits) {
+#ifdef MVS_PROFILING
+		if (a.abl & 1) { // (profiling library only, option ivf_cl_abl: no rare path -- results are wrong)
+			asm volatile("" ::"v"(any_t));
+			return;
+		}
+#endif
 		if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_t) == 0ull, 1)) // (hot path = fall-through: no taken branch per half tile)
 			return;
 #pragma unroll
@@ -740,6 +748,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.rowmask = d_rowmask;
 	a.xcd_map = (g_ivf_cl_xcd && max_items >= 64) ? g_ivf_cl_xcd : 0; // (the Flat small-batch path has one or two items: nothing to place)
 	a.nseg = nseg;
+	a.abl = g_ivf_cl_abl;
 	unsigned gx = (unsigned)max_items + (a.xcd_map ? 8u : 0u);
 	if (a.xcd_map >= 2) {
 		gx = (gx + 7u) & ~7u;
