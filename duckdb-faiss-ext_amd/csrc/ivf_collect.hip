@@ -489,11 +489,11 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	__syncthreads();
 
 	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)(((hq ^ c) & 15) * 16);
-	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
 	const unsigned qtab_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int *)qtab);
 	const unsigned ct_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)ctab) + (unsigned)(c * 16);
 
+	int qfill = 0; // entries in the wave's queue (all lanes hold the same value; see the rare path below)
 	// flush the candidate queue to the global stream (the whole wave; by hand: no compiled atomic with a result in the loop)
 	auto flush = [&](unsigned n) {
 		unsigned long long base = 0ull;
@@ -516,12 +516,14 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 				*((GUL)a.stream + (b + i)) = ent;
 			}
 		}
-		if (lane == 0) {
-			const unsigned zero = 0u;
-			asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(qcnt_lds), "v"(zero) : "memory");
-		}
+		qfill = 0;
 	};
 
+	// Rare path.  At C3 it is not rare: 149 candidates per query over 32 x 2 441 rows are 1.9e-3 per (row, query) pair, a call covers
+	// 16 rows x 32 slots, so six calls in ten have a hit -- with the path switched off the scan drops from 0.93 to 0.64 ms
+	// (profiles/r4_ivf_scan_rare_path.txt).  Hence (round 4): the queue position comes from a wave-uniform fill count and the ballot of
+	// the lanes appending in this step (no LDS atomic with a result, no wait for it); both column blocks' {query, E} entries are
+	// fetched up front and waited for once; every loop in here is wave-uniform.
 	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid, unsigned rowbits) {
 #ifdef MVS_PROFILING
 		if (a.abl & 1) { // (profiling library only, option ivf_cl_abl: no rare path -- results are wrong)
@@ -531,56 +533,60 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 #endif
 		if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_t) == 0ull, 1)) // (hot path = fall-through: no taken branch per half tile)
 			return;
+		int2 qe0, qe1;
+		asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:128" : "=&v"(qe0), "=&v"(qe1) : "v"(qtab_lds + (unsigned)((32 * t + c) * 8)) : "memory");
+		unsigned m0 = 0u, m1 = 0u;
+		if (any_t) {
 #pragma unroll
-		for (int i = 0; i < 2; ++i) {
-			const float c0 = cg[2 * i];
-			unsigned m = 0u;
-			if (any_t) {
-#pragma unroll
-				for (int r = 0; r < 4; ++r)
-					if (16 * rb + 4 * hq + r < nvalid && sv[i][r] >= c0)
-						m |= 1u << r;
-				m &= (rowbits >> (16 * rb + 4 * hq)) & 15u; // rows the IDSelector rejects: no candidate, no evidence for the bound
+			for (int r = 0; r < 4; ++r) {
+				const bool in = 16 * rb + 4 * hq + r < nvalid;
+				m0 |= (in && sv[0][r] >= cg[0]) ? 1u << r : 0u;
+				m1 |= (in && sv[1][r] >= cg[2]) ? 1u << r : 0u;
 			}
-			if (m == 0u)
-				continue;
-			int2 qe;
-			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qe) : "v"(qtab_lds + (unsigned)((32 * t + 16 * i + c) * 8)) : "memory");
-			const int q = qe.x;
-			const float eh = __int_as_float(qe.y);
-			while (m != 0u) {
-				const int j = __builtin_ctz(m);
-				m &= m - 1u;
-				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
-				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
-				const float v = (j & 2) ? hi : lo;
-				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
+			const unsigned rbits = (rowbits >> (16 * rb + 4 * hq)) & 15u; // rows the IDSelector rejects: no candidate, no evidence for the bound
+			m0 &= rbits;
+			m1 &= rbits;
+		}
+		unsigned m = m0 | (m1 << 4); // bit 4 i + r: row r of column block i
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qe0), "+v"(qe1)::"memory");
+		while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) { // (wave-uniform: every lane takes part in every step)
+			const bool has = m != 0u;
+			const int j8 = has ? __builtin_ctz(m) : 0;
+			m &= m - 1u;
+			const int i = j8 >> 2, j = j8 & 3;
+			const float s0 = i ? sv[1][0] : sv[0][0], s1 = i ? sv[1][1] : sv[0][1], s2 = i ? sv[1][2] : sv[0][2], s3 = i ? sv[1][3] : sv[0][3];
+			const float lo = (j & 1) ? s1 : s0;
+			const float hi = (j & 1) ? s3 : s2;
+			const float v = (j & 2) ? hi : lo;
+			const int q = i ? qe1.x : qe0.x;
+			const float eh = __int_as_float(i ? qe1.y : qe0.y);
+			const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
+			const unsigned long long act = __builtin_amdgcn_ballot_w64(has && a.collect);
+			const unsigned pos = (unsigned)qfill + __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+			qfill = __builtin_amdgcn_readfirstlane(qfill + (int)__builtin_popcountll(act));
+			if (has) {
 				typedef __attribute__((address_space(1))) unsigned *GU;
 				// the slots hold LOWER bounds s - E(list): E differs between the lists a query probes
 				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - eh), __ATOMIC_RELAXED,
 				                       __HIP_MEMORY_SCOPE_AGENT);
-				if (!a.collect)
-					continue;
-				unsigned pos;
-				const unsigned one = 1u;
-				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
-				const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-				if (pos < (unsigned)IC_QCAP) {
-					asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
-				} else { // a burst beyond the queue (cold start): straight to the stream
-					unsigned long long gp;
-					const unsigned long long one64 = 1ull;
-					typedef __attribute__((address_space(1))) unsigned long long *GUL;
-					asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-					             : "=&v"(gp)
-					             : "v"((GUL)a.stream_cnt), "v"(one64)
-					             : "memory");
-					if ((long long)gp < a.stream_cap)
-						*((GUL)a.stream + gp) = ent;
+				if (a.collect) {
+					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
+					if (pos < (unsigned)IC_QCAP) {
+						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+					} else { // a burst beyond the queue (cold start): straight to the stream
+						unsigned long long gp;
+						const unsigned long long one64 = 1ull;
+						typedef __attribute__((address_space(1))) unsigned long long *GUL;
+						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+						             : "=&v"(gp)
+						             : "v"((GUL)a.stream_cnt), "v"(one64)
+						             : "memory");
+						if ((long long)gp < a.stream_cap)
+							*((GUL)a.stream + gp) = ent;
+					}
 				}
 			}
 		}
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	};
 
 	for (int u = 0; u < ntiles; ++u) {
@@ -712,9 +718,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		fold(acc[1][1], 1);
 		rare(acc[1], 1, 3, any_of(cg[1]), cg[1], row0, nvalid, rowbits);
 		__syncthreads(); // one wave: drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
-		unsigned fill;
-		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fill) : "v"(qcnt_lds) : "memory");
-		fill = (unsigned)__builtin_amdgcn_readfirstlane((int)fill);
+		const unsigned fill = (unsigned)qfill;
 		if (fill >= (unsigned)IC_QCAP / 2 || (u == ntiles - 1 && fill > 0))
 			flush(fill < (unsigned)IC_QCAP ? fill : (unsigned)IC_QCAP);
 	}
