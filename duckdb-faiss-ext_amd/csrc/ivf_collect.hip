@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) float lds_f32i;
 typedef __attribute__((address_space(1))) const float glb_f32i;
 
 constexpr int IC_BN = 32;    // rows per tile
-constexpr int IC_QCAP = 128; // candidate queue of a work item (entries of 8 bytes; 128: 20 032 bytes of LDS per wavefront = EIGHT per CU, 256 made it seven)
+constexpr int IC_QCAP = 160; // hit queue of a work item: 8 bytes {value, row} + 1 byte {slot} per entry (20 384 bytes of LDS per wavefront = EIGHT per CU)
 
 int g_ivf_cl_refresh = 16; // option ivf_cl_refresh (see IvfCollectArgs::refresh)
 struct IvfCollectArgs {
@@ -388,13 +388,13 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
 template <int NC>
 __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollectArgs a) {
 	constexpr int KB = 4, PITCH = 256, TILE_BYTES = IC_BN * PITCH;
-	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 8 + 64) / 4];
+	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 8 + IC_QCAP) / 4];
 	char *tbuf = (char *)smem;                                        // [2][TILE_BYTES]
 	float *nbuf = (float *)(tbuf + 2 * TILE_BYTES);                   // [2][64] beta of the tile's rows
-	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [IC_QCAP] candidate queue
+	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [IC_QCAP] hit queue {value bits | row << 32}
 	float *ctab = (float *)(qbuf + IC_QCAP);                          // [4 t][16 c][2 i]{B_lower - E, gamma}
 	int *qtab = (int *)(ctab + 128 * 2);                              // [128]{query number, E (float bits)} of every slot
-	unsigned *qctl = (unsigned *)(qtab + 128 * 2);                    // [0] queue fill
+	unsigned char *qslot = (unsigned char *)(qtab + 128 * 2);         // [IC_QCAP] slot of every queued hit
 
 	// Items of one list are neighbours in the item table and stream the SAME rows; the dispatcher deals consecutive workgroups
 	// round-robin to the eight XCDs, so with item = blockIdx.x every XCD's L2 fetched the list for itself (PMC, C3's main pass:
@@ -440,8 +440,6 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		return;
 	const long long r_end = r_begin + a.seg_rows < it.y ? r_begin + a.seg_rows : it.y;
 	const int ntiles = (int)((r_end - r_begin + IC_BN - 1) / IC_BN);
-	if (lane == 0)
-		qctl[0] = 0u;
 
 	// the lane OWNS (bound refresh) slots 32 hq + 16 i + c, i = 0, 1, i.e. column blocks 2 hq + i = the two blocks of tile t = hq
 	int own_q[2];
@@ -493,11 +491,47 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	const unsigned qtab_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int *)qtab);
 	const unsigned ct_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)ctab) + (unsigned)(c * 16);
 
-	int qfill = 0; // entries in the wave's queue (all lanes hold the same value; see the rare path below)
-	// flush the candidate queue to the global stream (the whole wave; by hand: no compiled atomic with a result in the loop)
-	auto flush = [&](unsigned n) {
+	const unsigned qslot_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)qslot);
+	// Rare path.  At C3 it is not rare: 149 candidates per query over 32 x 2 441 rows are 1.9e-3 per (row, query) pair, a call covers
+	// 16 rows x 32 slots, so six calls in ten have a hit, and a hit used to be worked off then and there by the ONE lane that had it
+	// (slot -> query and E from LDS, address arithmetic, class-slot atomic, queue position by an LDS atomic with result) while 63
+	// lanes waited: ~150 instructions per call, a third of the kernel (profiles/r4_ivf_scan_rare_path.txt: 0.93 ms with, 0.64 without).
+	// Now the loop only RECORDS a hit -- {value, row} and the slot into an LDS queue, position = wave-uniform fill + ballot rank --
+	// and drain() works the queue off with one hit per LANE: before every refresh of the wave's bounds (its own evidence is
+	// published first), when the queue is nearly full, and at the end.
+	int qfill = 0; // entries recorded (all lanes hold the same value); entries past IC_QCAP took the immediate path below
+	int qpub = 0;  // ... of which the first qpub have been published to the class slots already
+	// publish(): the recorded hits not yet published -> class slots (fire-and-forget atomics: nothing to wait for)
+	auto publish = [&]() {
+		const unsigned n = (unsigned)qfill < (unsigned)IC_QCAP ? (unsigned)qfill : (unsigned)IC_QCAP;
+		for (unsigned e = (unsigned)qpub + lane; e < n; e += 64) {
+			unsigned long long ent;
+			unsigned sl;
+			asm volatile("ds_read_b64 %0, %2\n\tds_read_u8 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(ent), "=&v"(sl)
+			             : "v"(qbuf_lds + 8u * e), "v"(qslot_lds + e)
+			             : "memory");
+			int2 qe;
+			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qe) : "v"(qtab_lds + sl * 8u) : "memory");
+			const float v = __uint_as_float((unsigned)ent);
+			const unsigned row = (unsigned)(ent >> 32);
+			typedef __attribute__((address_space(1))) unsigned *GU;
+			// the slots hold LOWER bounds s - E(list): E differs between the lists a query probes
+			__hip_atomic_fetch_min((GU)(a.gslot + (size_t)qe.x * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - __int_as_float(qe.y)),
+			                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		qpub = (int)n;
+	};
+	// drain(): publish what is left, then the whole queue -> the global stream behind ONE reservation (the only wait in here)
+	auto drain = [&]() {
+		publish();
+		const unsigned n = (unsigned)qpub;
+		qfill = 0;
+		qpub = 0;
+		if (n == 0u || !a.collect)
+			return;
 		unsigned long long base = 0ull;
-		if (lane == 0) {
+		if (lane == 0) { // (by hand: no compiled atomic with a result in the loop)
 			const unsigned long long n64 = n;
 			typedef __attribute__((address_space(1))) unsigned long long *GUL;
 			asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
@@ -507,23 +541,22 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		}
 		const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
 		const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
-		const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
-		for (unsigned i = lane; i < n; i += 64) {
+		base = ((unsigned long long)bhi << 32) | blo;
+		for (unsigned e = lane; e < n; e += 64) {
 			unsigned long long ent;
-			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ent) : "v"(qbuf_lds + 8u * i) : "memory");
-			if ((long long)(b + i) < a.stream_cap) {
+			unsigned sl;
+			asm volatile("ds_read_b64 %0, %2\n\tds_read_u8 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(ent), "=&v"(sl)
+			             : "v"(qbuf_lds + 8u * e), "v"(qslot_lds + e)
+			             : "memory");
+			int qq;
+			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qq) : "v"(qtab_lds + sl * 8u) : "memory");
+			if ((long long)(base + e) < a.stream_cap) {
 				typedef __attribute__((address_space(1))) unsigned long long *GUL;
-				*((GUL)a.stream + (b + i)) = ent;
+				*((GUL)a.stream + (base + e)) = ((unsigned long long)(unsigned)qq << 32) | (unsigned)(ent >> 32);
 			}
 		}
-		qfill = 0;
 	};
-
-	// Rare path.  At C3 it is not rare: 149 candidates per query over 32 x 2 441 rows are 1.9e-3 per (row, query) pair, a call covers
-	// 16 rows x 32 slots, so six calls in ten have a hit -- with the path switched off the scan drops from 0.93 to 0.64 ms
-	// (profiles/r4_ivf_scan_rare_path.txt).  Hence (round 4): the queue position comes from a wave-uniform fill count and the ballot of
-	// the lanes appending in this step (no LDS atomic with a result, no wait for it); both column blocks' {query, E} entries are
-	// fetched up front and waited for once; every loop in here is wave-uniform.
 	auto rare = [&](const f32x4a (&sv)[2], int rb, int t, bool any_t, f32x4i cg, long long row0, int nvalid, unsigned rowbits) {
 #ifdef MVS_PROFILING
 		if (a.abl & 1) { // (profiling library only, option ivf_cl_abl: no rare path -- results are wrong)
@@ -533,8 +566,6 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 #endif
 		if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_t) == 0ull, 1)) // (hot path = fall-through: no taken branch per half tile)
 			return;
-		int2 qe0, qe1;
-		asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:128" : "=&v"(qe0), "=&v"(qe1) : "v"(qtab_lds + (unsigned)((32 * t + c) * 8)) : "memory");
 		unsigned m0 = 0u, m1 = 0u;
 		if (any_t) {
 #pragma unroll
@@ -548,7 +579,6 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 			m1 &= rbits;
 		}
 		unsigned m = m0 | (m1 << 4); // bit 4 i + r: row r of column block i
-		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qe0), "+v"(qe1)::"memory");
 		while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) { // (wave-uniform: every lane takes part in every step)
 			const bool has = m != 0u;
 			const int j8 = has ? __builtin_ctz(m) : 0;
@@ -558,22 +588,22 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 			const float lo = (j & 1) ? s1 : s0;
 			const float hi = (j & 1) ? s3 : s2;
 			const float v = (j & 2) ? hi : lo;
-			const int q = i ? qe1.x : qe0.x;
-			const float eh = __int_as_float(i ? qe1.y : qe0.y);
 			const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
-			const unsigned long long act = __builtin_amdgcn_ballot_w64(has && a.collect);
+			const unsigned sl = (unsigned)(32 * t + 16 * i + c);
+			const unsigned long long act = __builtin_amdgcn_ballot_w64(has);
 			const unsigned pos = (unsigned)qfill + __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
 			qfill = __builtin_amdgcn_readfirstlane(qfill + (int)__builtin_popcountll(act));
 			if (has) {
-				typedef __attribute__((address_space(1))) unsigned *GU;
-				// the slots hold LOWER bounds s - E(list): E differs between the lists a query probes
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - eh), __ATOMIC_RELAXED,
-				                       __HIP_MEMORY_SCOPE_AGENT);
-				if (a.collect) {
-					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-					if (pos < (unsigned)IC_QCAP) {
-						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
-					} else { // a burst beyond the queue (cold start): straight to the stream
+				if (__builtin_expect(pos < (unsigned)IC_QCAP, 1)) {
+					const unsigned long long ent = ((unsigned long long)row << 32) | __float_as_uint(v);
+					asm volatile("ds_write_b64 %0, %1\n\tds_write_b8 %2, %3" ::"v"(qbuf_lds + 8u * pos), "v"(ent), "v"(qslot_lds + pos), "v"(sl) : "memory");
+				} else { // a burst beyond the queue (cold start): worked off at once, straight to the stream
+					int2 qe;
+					asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qe) : "v"(qtab_lds + sl * 8u) : "memory");
+					typedef __attribute__((address_space(1))) unsigned *GU;
+					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)qe.x * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - __int_as_float(qe.y)),
+					                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (a.collect) {
 						unsigned long long gp;
 						const unsigned long long one64 = 1ull;
 						typedef __attribute__((address_space(1))) unsigned long long *GUL;
@@ -582,7 +612,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 						             : "v"((GUL)a.stream_cnt), "v"(one64)
 						             : "memory");
 						if ((long long)gp < a.stream_cap)
-							*((GUL)a.stream + gp) = ent;
+							*((GUL)a.stream + gp) = ((unsigned long long)(unsigned)qe.x << 32) | row;
 					}
 				}
 			}
@@ -595,7 +625,10 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		// s >= exact - E >= B - E: table entry = B - E (E of this item's list).  With one E for all lists this is the B - 2E of
 		// csrc/flat_collect.hip.
 		const int period = a.refresh > 0 ? a.refresh : (u < 4 ? 1 : (u < 32 ? 4 : 16));
+		if (qfill > IC_QCAP / 2)
+			drain(); // (a queue more than half full is emptied)
 		if ((u % period) == 0) {
+			publish(); // (this wave's own evidence is in the class slots before it reads them)
 			// (NC = 16: both queries' slots in one round trip; NC = 32: one query at a time -- 32 keys + the network's temporaries)
 			unsigned long long w[NC == 16 ? 2 : 1][NC / 2];
 			auto fetch = [&](int i, int wi) {
@@ -718,9 +751,8 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		fold(acc[1][1], 1);
 		rare(acc[1], 1, 3, any_of(cg[1]), cg[1], row0, nvalid, rowbits);
 		__syncthreads(); // one wave: drains this tile's LDS-DMA (vmcnt(0)) before the next tile reads it
-		const unsigned fill = (unsigned)qfill;
-		if (fill >= (unsigned)IC_QCAP / 2 || (u == ntiles - 1 && fill > 0))
-			flush(fill < (unsigned)IC_QCAP ? fill : (unsigned)IC_QCAP);
+		if (u == ntiles - 1)
+			drain();
 	}
 }
 
