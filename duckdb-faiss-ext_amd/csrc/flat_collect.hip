@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	float *nbuf = (float *)(tbuf + 2 * STAGE_BYTES);            // [2][64] beta of the staged rows
 	unsigned long long *qbuf = (unsigned long long *)(nbuf + 2 * 64); // [CL_QCAP] candidate queue
 	float *cqtab = (float *)(qbuf + CL_QCAP);                   // [4 waves][4 t][16 c][2]: pass bound of every query
-	unsigned *qctl = (unsigned *)(cqtab + CL_QBLOCK);           // [0] queue fill, [2..3] flush base
+	unsigned *qctl = (unsigned *)(cqtab + CL_QBLOCK);           // [7] candidates counted after the stream filled up
+	float *qval = (float *)(qctl + 16);                         // [CL_QCAP] value of every queued hit (wave w: entries 512 w ..)
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -356,10 +357,8 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	if (r_end > a.n)
 		r_end = a.n;
 	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin + CL_SUB * CL_BN - 1) / (CL_SUB * CL_BN)) : 0; // staged blocks
-	if (tid == 0) {
-		qctl[0] = 0u;
+	if (tid == 0)
 		qctl[7] = 0u; // candidates counted after the stream filled up
-	}
 
 	// the wave's 128 queries = 8 column blocks of 16; block cb = 2 t + i belongs to "tile" t; lane (hq, c) sees query
 	// qw + 16 cb + c in every block and OWNS (bound refresh) the two blocks of t = hq
@@ -443,8 +442,10 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// A fragment (row block rb, k-block kb): row 16 rb + c, chunk 4 kb + hq -> byte 4096 rb + 256 c + (((4 kb + hq) ^ c) * 16)
 	// = 4096 rb + (rbase ^ (64 kb)) with rbase = 256 c | ((hq ^ c) * 16)  (4 kb and hq occupy disjoint bits of the chunk number)
 	const unsigned rbase = (unsigned)(c * PITCH) | (unsigned)(((hq ^ c) & 15) * 16);
+	constexpr int WQCAP = CL_QCAP / 4; // every wave has its own quarter of the queue
 	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
-	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf) + (unsigned)(wave * WQCAP * 8);
+	const unsigned qval_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)qval) + (unsigned)(wave * WQCAP * 4);
 	// the lane's two bounds of tile t: cqtab[wave][t][c][0..1]
 	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 64 + c) * 8);
 
@@ -452,6 +453,57 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// Rare path of half a 32-query tile (row block rb; sv holds s of its 4 rows x 2 queries per lane): every passing row is
 	// published to its class slot (16 classes: row & 15) and appended.  Lane (hq, c): rows 16 rb + 4 hq + r, queries of column
 	// blocks 2 t + i.
+	// (round 4: the loop only RECORDS a passing row -- {query, row} and its value into the wave's own part of the LDS queue, at
+	// position wave-uniform fill + ballot rank: no LDS atomic with a result, no address arithmetic, no class-slot atomic by the one lane
+	// that had the hit while 63 wait -- and publish() / wdrain() work the queue off with one hit per LANE at the next look at the queue.
+	// The path is entered in 7 % of the half tiles at N = 1.25 M (1.4 % at 10 M) and was 14 % (4.4 %) of the scan: profiles/
+	// r4_ablation_bare_mfma_loop.txt; the IVF scan, where it was a third, does the same: csrc/ivf_collect.hip.)
+	int wfill = 0, wpub = 0; // entries recorded by this wave / of those, already published to the class slots (wave-uniform)
+	auto publish = [&]() {
+		const unsigned n = (unsigned)wfill < (unsigned)WQCAP ? (unsigned)wfill : (unsigned)WQCAP;
+		for (unsigned e = (unsigned)wpub + lane; e < n; e += 64) {
+			unsigned long long ent;
+			float v;
+			asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(ent), "=&v"(v)
+			             : "v"(qbuf_lds + 8u * e), "v"(qval_lds + 4u * e)
+			             : "memory");
+			const unsigned row = (unsigned)ent;
+			typedef __attribute__((address_space(1))) unsigned *GU;
+			__hip_atomic_fetch_min((GU)(a.gslot + (size_t)(unsigned)(ent >> 32) * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED,
+			                       __HIP_MEMORY_SCOPE_AGENT);
+		}
+		wpub = (int)n;
+	};
+	auto wdrain = [&]() { // publish what is left; the wave's whole queue -> the global stream behind one reservation
+		publish();
+		const unsigned n = (unsigned)wpub;
+		wfill = 0;
+		wpub = 0;
+		if (!COLLECT || n == 0u)
+			return;
+		unsigned long long base = 0ull;
+		if (lane == 0) { // (by hand: a compiled atomic with a result makes hipcc wait where the branches meet)
+			const unsigned long long n64 = n;
+			typedef __attribute__((address_space(1))) unsigned long long *GUL;
+			asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+			             : "=&v"(base)
+			             : "v"((GUL)a.stream_cnt), "v"(n64)
+			             : "memory");
+		}
+		const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+		const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+		base = ((unsigned long long)bhi << 32) | blo;
+		for (unsigned e = lane; e < n; e += 64) {
+			unsigned long long ent;
+			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ent) : "v"(qbuf_lds + 8u * e) : "memory");
+			if ((long long)(base + e) < a.stream_cap) {
+				typedef __attribute__((address_space(1))) unsigned long long *GUL;
+				*((GUL)a.stream + (base + e)) = ent;
+			}
+		}
+		ovf |= (long long)(base + n) >= a.stream_cap ? 1 : 0; // (wave-uniform)
+	};
 	auto rare = [&](const f32x4acc (&sv)[2], int rb, int t, bool any_t, f32x2n cqv, long long row0, int nvalid, unsigned rowbits) {
 		if (ABL & 1) {
 			MVS_KEEP_VGPR(any_t);
@@ -461,45 +513,52 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			return;
 		int qo = qw;
 		MVS_OPAQUE_VGPR(qo); // (keeps the per-query addresses of this path out of the hot loop's registers)
+		unsigned m0 = 0u, m1 = 0u;
+		if (any_t) {
 #pragma unroll
-		for (int i = 0; i < 2; ++i) {
-			const int q = qo + 32 * t + 16 * i + c;
-			const float c0 = cqv[i];
-			unsigned m = 0u;
-			if (any_t) {
-#pragma unroll
-				for (int r = 0; r < 4; ++r)
-					if (16 * rb + 4 * hq + r < nvalid && sv[i][r] >= c0)
-						m |= 1u << r;
-				if (SEL) // rows the IDSelector rejects: neither a candidate nor evidence for the bound
-					m &= (rowbits >> (16 * rb + 4 * hq)) & 15u;
+			for (int r = 0; r < 4; ++r) {
+				const bool in = 16 * rb + 4 * hq + r < nvalid;
+				m0 |= (in && sv[0][r] >= cqv[0]) ? 1u << r : 0u;
+				m1 |= (in && sv[1][r] >= cqv[1]) ? 1u << r : 0u;
 			}
-			while (m != 0u) {
-				const int j = __builtin_ctz(m);
-				m &= m - 1u;
-				const float lo = (j & 1) ? sv[i][1] : sv[i][0];
-				const float hi = (j & 1) ? sv[i][3] : sv[i][2];
-				const float v = (j & 2) ? hi : lo;
-				const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
-				typedef __attribute__((address_space(1))) unsigned *GU;
-				__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED,
-				                       __HIP_MEMORY_SCOPE_AGENT);
-				if (COLLECT && ovf) {
-					// the stream is full: whatever is appended now is dropped, but the host wants the TRUE number of candidates (it sizes
-					// the next attempt from it) -- count, do not queue.  (All-duplicates data, 31 250 copies of every query's nearest row:
-					// 3e8 candidates through the queue's overflow branch took 47 s per launch.)
-					const unsigned one = 1u;
-					asm volatile("ds_add_u32 %0, %1" ::"v"(qcnt_lds + 28u), "v"(one) : "memory");
-				} else if (COLLECT) {
-					unsigned pos;
-					const unsigned one = 1u;
-					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
-					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
-					if (pos < (unsigned)CL_QCAP) {
-						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
-					} else { // a burst beyond the queue (cold start): straight to the stream.  By hand, wait included: a
-						// compiled atomic with a result makes hipcc wait for vmcnt(0) where the branches meet, i.e. EVERY
-						// candidate would sit out the class-slot atomic's L2 round trip and the next tile's LDS-DMA
+			if (SEL) { // rows the IDSelector rejects: neither a candidate nor evidence for the bound
+				const unsigned rbits = (rowbits >> (16 * rb + 4 * hq)) & 15u;
+				m0 &= rbits;
+				m1 &= rbits;
+			}
+		}
+		unsigned m = m0 | (m1 << 4); // bit 4 i + r: row r of column block i
+		while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) { // (wave-uniform: every lane takes part in every step)
+			const bool has = m != 0u;
+			const int j8 = has ? __builtin_ctz(m) : 0;
+			m &= m - 1u;
+			const int i = j8 >> 2, j = j8 & 3;
+			const float s0 = i ? sv[1][0] : sv[0][0], s1 = i ? sv[1][1] : sv[0][1], s2 = i ? sv[1][2] : sv[0][2], s3 = i ? sv[1][3] : sv[0][3];
+			const float lo = (j & 1) ? s1 : s0;
+			const float hi = (j & 1) ? s3 : s2;
+			const float v = (j & 2) ? hi : lo;
+			const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
+			const unsigned q = (unsigned)(qo + 32 * t + 16 * i + c);
+			const bool counting = COLLECT && ovf; // the stream is full: publish at once, count, do not queue (see wdrain / the host's re-run)
+			const unsigned long long act = __builtin_amdgcn_ballot_w64(has && !counting);
+			const unsigned pos = (unsigned)wfill + __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+			wfill = __builtin_amdgcn_readfirstlane(wfill + (int)__builtin_popcountll(act));
+			if (has) {
+				const unsigned long long ent = ((unsigned long long)q << 32) | row;
+				if (__builtin_expect(!counting && pos < (unsigned)WQCAP, 1)) {
+					asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(qbuf_lds + 8u * pos), "v"(ent), "v"(qval_lds + 4u * pos), "v"(v) : "memory");
+				} else {
+					typedef __attribute__((address_space(1))) unsigned *GU;
+					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED,
+					                       __HIP_MEMORY_SCOPE_AGENT);
+					if (counting) {
+						// the stream is full: whatever is appended now is dropped, but the host wants the TRUE number of candidates (it sizes
+						// the next attempt from it) -- count, do not queue.  (All-duplicates data, 31 250 copies of every query's nearest row:
+						// 3e8 candidates through the queue's overflow branch took 47 s per launch.)
+						const unsigned one = 1u;
+						asm volatile("ds_add_u32 %0, %1" ::"v"(qcnt_lds + 28u), "v"(one) : "memory");
+					} else if (COLLECT) { // a burst beyond the wave's queue (cold start): straight to the stream.  By hand, wait included: a
+						// compiled atomic with a result makes hipcc wait for vmcnt(0) where the branches meet
 						unsigned long long gp;
 						const unsigned long long one64 = 1ull;
 						typedef __attribute__((address_space(1))) unsigned long long *GUL;
@@ -513,7 +572,6 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 				}
 			}
 		}
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	};
 
 	for (int u = 0; u < ntiles; ++u) {
@@ -527,6 +585,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		if (use_tab && !full && u > 0 && (u & ((1 << tab_shift) - 1)) == 0)
 			dma_bounds(); // (lands before this block's barrier; until then the tiles use the entries already there)
 		if (full) {
+			publish(); // (this wave's own evidence is in the class slots before it reads them)
 			// B = the kk-th best of the 16 class bests (kk distinct rows are at least that good): as keys, the kk-th smallest
 			// (bitonic network in registers).  The pass bound B - 2E goes to the wave's table in LDS.
 			int qo = qw;
@@ -700,27 +759,17 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		else
 			__syncthreads(); // also drains this block's LDS-DMA (vmcnt(0)) before the next block reads it
-		if (COLLECT && ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1)) {
+		if ((u % CL_FLUSH_EVERY) == CL_FLUSH_EVERY - 1 || u == ntiles - 1) {
 			// (no LDS-DMA is in flight between the barrier above and the next tile's first issue)
-			const unsigned fill = qctl[0];
-			__syncthreads(); // everybody has read the same fill before anyone appends again
-			const unsigned n = fill < (unsigned)CL_QCAP ? fill : (unsigned)CL_QCAP;
-			if (n >= (unsigned)CL_QCAP / 2 || (u == ntiles - 1 && n > 0)) {
-				if (tid == 0) {
-					*(unsigned long long *)(qctl + 2) = atomicAdd(a.stream_cnt, (unsigned long long)n);
-					qctl[0] = 0u;
-				}
-				__syncthreads();
-				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
-				for (unsigned i = tid; i < n; i += 256)
-					if ((long long)(base + i) < a.stream_cap)
-						a.stream[base + i] = qbuf[i];
-				__syncthreads();
-				ovf |= __builtin_amdgcn_readfirstlane((long long)(base + n) >= a.stream_cap ? 1 : 0); // (a scalar: no register of the hot loop)
-			}
+			// every wave looks after its own queue: what it recorded since the last look goes to the class slots; the queue goes to
+			// the stream when it is half full, and at the end
+			if (wfill >= WQCAP / 2 || u == ntiles - 1)
+				wdrain();
+			else
+				publish();
 		}
 	}
-	if (COLLECT && ovf) {
+	if (COLLECT) { // (candidates that were only counted after the stream filled up: see the rare path)
 		__syncthreads();
 		if (tid == 0 && qctl[7] != 0u)
 			atomicAdd(a.stream_cnt, (unsigned long long)qctl[7]);
@@ -729,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 
 static size_t collect_lds_bytes(const FlatGeom &g) {
 	(void)g;
-	return (size_t)2 * CL_SUB * CL_BN * 128 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)CL_QBLOCK * 4 + 64;
+	return (size_t)2 * CL_SUB * CL_BN * 128 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)CL_QBLOCK * 4 + 64 + (size_t)CL_QCAP * 4;
 }
 
 bool collect_supported(const FlatGeom &g) {
