@@ -737,7 +737,7 @@ public:
 			return;
 		}
 		// default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
-		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && k <= (collect_k32 ? 32 : 16) && d <= 128 &&
+		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && (raw_pos && k > 1 ? k - 1 : k) <= (collect_k32 ? 32 : 16) && d <= 128 &&
 		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26)) { // (faster than the scanner kernel from one query on)
 			if (collect_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
 				return;
@@ -910,7 +910,12 @@ public:
 		build_lists_mf(false);
 		if (!have_bfr)
 			return false;
-		const int G = 128, shift = 7, kk = (int)k;
+		// Inside the exact-tie wrapper k is the user's k + 1 (the extra entry only tells whether the k-th value is tied).  The FILTER
+		// works with the user's k: a row tied with the k-th value passes any bound derived from k rows (the bound is on values), so the
+		// (k + 1)-th entry of the selection is a tied row if there is one -- and k = 32 stays on the 32-class instance, k = 16 on the
+		// 16-class one, instead of falling to the next instance or (k = 32) to the scanner kernel; the bound is the
+		// k-th, not the (k + 1)-th, best class.
+		const int G = 128, shift = 7, kk = (int)k, kf = raw_pos && k > 1 ? (int)k - 1 : (int)k;
 		const int64_t npairs = nq * np;
 		const int max_items = ivf_group_max_items(npairs, nlist, G);
 		ws_items.reserve((size_t)max_items * 16);
@@ -929,7 +934,7 @@ public:
 		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int);
 		ws_qfail.reserve(ctl_bytes);
 		int *const ctl_qfail = (int *)((char *)ws_qfail.p + 256), *const ctl_seg = ctl_qfail + nq;
-		const int nclass = k > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
+		const int nclass = kf > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
 		ws_gslot.reserve((size_t)nq * nclass * sizeof(unsigned) + 64);
 		launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
 		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, ctl_bytes, stream));
@@ -987,7 +992,7 @@ public:
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)(phase == 0 && shared ? ws_ie2p.p : ws_ie2.p), (const unsigned short *)codes_bfr.p,
 			                        (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
 			                        phase == 0 ? 1 : nseg, phase, rowmask, stream);
 			if (phase == 1)
 				end_kernel_timing(stream);
@@ -1027,7 +1032,7 @@ public:
 			MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kk, seg_rows, nseg, 1, rowmask, stream);
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, seg_rows, nseg, 1, rowmask, stream);
 			MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 			MVS_HIP(hipStreamSynchronize(stream));
 			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);

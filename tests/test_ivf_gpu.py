@@ -715,3 +715,30 @@ def test_ivf_sort_sized_too_small_is_run_again(mf, metric):
             D, I = g.search(xq, 10, nprobe=6)
             assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
             assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (pack, est)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("k", [1, 16, 31, 32])
+def test_ivf_k_on_the_coarse_filters_class_limits_with_exact_ties(mf, metric, k):
+    """The exact-tie wrapper searches k + 1 entries; the coarse filter works with the user's k (a row tied with the k-th value passes
+    any bound derived from k rows), so k = 32 stays on ivf_bf16_collect_kernel<32> and k = 16 on <16> (k = 32 used to fall
+    to the scanner kernel).  Integer data with duplicated rows: ties at the k-th value in most queries; equal to the scanner kernel,
+    which replays FAISS's heap too."""
+    rs = np.random.RandomState(90 + k)
+    d, nlist, n, nq = 32, 16, 40_000, 300
+    xb = rs.randint(0, 3, size=(n, d)).astype(np.float32)
+    m = n // 3
+    xb[0 : 3 * m : 3] = xb[1 : 3 * m : 3]
+    xq = rs.randint(0, 3, size=(nq, d)).astype(np.float32)
+    ref = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    ref.train(xb[:8000])
+    ref.add(xb)
+    ref.set_option("ivf_collect", 0)
+    D0, I0 = ref.search(xq, k, nprobe=5)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    g.ivf_set_centroids(ref.ivf_centroids())
+    g.add(xb)
+    D, I = g.search(xq, k, nprobe=5)
+    assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect"), g.last_kernel_info()["name"]
+    assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
