@@ -203,7 +203,7 @@ public:
 	// copied to h_flag_count[10..11] asynchronously and the caller checks it against cl_deferred_cap after ITS stream
 	// synchronisation -- on an overflow it runs the search again with defer_count = false (the synchronous overflow handling)
 	bool collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1, int32_t **pi1, int *fail_cnt, int *fail_q,
-	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, bool defer_count = false);
+	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, bool defer_count = false, int kf = 0);
 	int64_t cl_deferred_cap = 0;
 	bool cl_defer = true; // option cl_defer_count
 	double cl_est_per_query = 0; // candidates per query of the last search: sizes the next search's sort (collect_sort_estimate)

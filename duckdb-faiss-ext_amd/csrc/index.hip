@@ -373,9 +373,12 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 // Coarse filter front half (csrc/flat_collect.hip): bound estimation pre-pass, the scan, candidates grouped by query and
 // re-scored exactly.  Leaves the kk best exact candidates per query in *pd1 / *pi1 ([nq][kk]) and the queries whose bound
 // is not finite in fail_q.  false: the candidate stream overflowed (the caller uses the bf16x3 path instead).
+// kk: entries selected per query; kf <= kk: the k the FILTER works with (class slots, bound rank) -- see search_prefilter_pass
 bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float **pd1_out, int32_t **pi1_out, int *fail_cnt,
                                    int *fail_q, const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st,
-                                   bool defer_count) {
+                                   bool defer_count, int kf) {
+	if (kf <= 0 || kf > kk)
+		kf = kk;
 	ensure_h1_rows(st);
 	// IDSelector: one bit per row, built per search (the selector sees idmap[row] behind an IndexIDMap, the row number else)
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
@@ -402,7 +405,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_e2.reserve((size_t)nq128 * sizeof(float));
 	// (the bounds kernel writes NaN into the slots behind the last query itself)
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
-	ws_gthr.reserve((size_t)nq * collect_slot_stride(kk, collect_store_dims(d)) * sizeof(unsigned) + 64);
+	ws_gthr.reserve((size_t)nq * collect_slot_stride(kf, collect_store_dims(d)) * sizeof(unsigned) + 64);
 	// candidate stream: 4096 entries per query to start with (option cl_stream_cap; at least 2^20), or what the last overflow
 	// showed this index's data to need (cl_cap_hint, up to 16384 per query: clustered rows with large norms admit thousands)
 	int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024)
@@ -418,10 +421,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 	ws_pbnd.reserve(collect_bound_table_bytes(nq));
 	float *pbnd = wide ? nullptr : (float *)ws_pbnd.p; // (the d <= 128 scan only)
-	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
+	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st, true);
 	int grid = 0, nsplit = 0, lds = 0;
-	const bool few = !wide && nq <= 128 && collect_slot_stride(kk, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
+	const bool few = !wide && nq <= 128 && collect_slot_stride(kf, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
 	for (int attempt = 0;; ++attempt) {
 	begin_kernel_timing(st);
@@ -440,12 +443,12 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		MVS_HIP(hipMemsetAsync(gam, 0, g_bytes, st));
 		launch_collect_flat_items(b, nitems_dev, qidx, nq, ntotal, st);
 		launch_ivf_collect_scan(b, nitems_dev, nit, qidx, ws_pfq.p, gam, (const float *)ws_e2.p, vecs_h1, beta_h1,
-		                        (unsigned *)ws_gthr.p, stream, cnt, cap_entries, kk, seg_rows, nseg, 1, (const unsigned *)rowmask, st);
+		                        (unsigned *)ws_gthr.p, stream, cnt, cap_entries, kf, seg_rows, nseg, 1, (const unsigned *)rowmask, st);
 		grid = nit * nseg;
 		nsplit = nseg;
 		lds = 20544;
 	} else {
-		launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kk, (const float *)ws_e2.p,
+		launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, (const float *)ws_e2.p,
 		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, pbnd, st, &grid, &nsplit, &lds);
 	}
 	end_kernel_timing(st);
@@ -866,20 +869,25 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	const bool wide = collect_store_dims(d) > 128;
 	// (16 < d <= 32: the coarse filter only, as for the wide stores)
 	const bool cl_only = wide || !prefilter_supported(geom);
+	// The coarse FILTER works with the user's k even when the search carries one entry more for the inner-product tie detection
+	// (kk = k_user + 1): a row tied with the k-th score passes any bound derived from k rows -- the bound is on values -- so the
+	// (k + 1)-th entry of the SELECTION is a tied row if there is one.  The bound is then the k-th, not the (k + 1)-th, best class,
+	// and k = 32 / k = 16 stay on the 32- / 16-class instances (wide stores: k = 32 stays on the filter at all) -- ADVICE r3, low.
+	const int64_t kf = kk > k_user ? k_user : kk;
+	const int cl_kmax0 = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
+	const int cl_kmax = (int)std::min<int64_t>(cl_kmax0, 128 - (kk - kf)); // (collect_select_kernel: kk <= 128 entries)
 	// (lists beyond 40: only the coarse filter of the d <= 128 store, up to 128 -- four subsets of 32 row classes, round 4)
-	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !collect_supported(geom)) ||
-	    kk > std::max(40, cl_k32 ? collect_max_k(d) : 16))
+	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !collect_supported(geom)) || (kk > 40 && kf > cl_kmax))
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
-	if (cl_only && (kk > collect_max_k(d) || prefilter_mode == 1))
+	if (cl_only && (kf > std::min<int64_t>(collect_max_k(d), 128 - (kk - kf)) || prefilter_mode == 1))
 		return false;
-	const int cl_kmax = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
-	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax))
+	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kf <= cl_kmax))
 		return false;
 	// auto: the contraction must dominate.  The coarse filter wins from FAISS's first BLAS-branch batch on (N = 10M: 1.3 ms vs
 	// 3.5 ms at 64 queries, 1.7 vs 11.0 at 500); the bf16x3 kernel needs whole 256-query blocks to pay
-	const bool collect_ok = (prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax;
+	const bool collect_ok = (prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kf <= cl_kmax;
 	// (N = 131 072: 0.35 vs 0.46 ms at 64 queries, 1.36 vs 3.88 at 10k; N = 65 536: 1.40 vs 2.25 at 10k but 1.07 vs 0.61 at 2048;
 	// below that the f32 kernel's ~0.3 ms wins everywhere)
 	const bool big_enough = ntotal >= 262144 || (collect_ok && ntotal >= 65536 && (double)nq * (double)ntotal >= 5e8) ||
@@ -899,7 +907,7 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	bool collected = false;
 	// Coarse filter (one bf16 product per pair, candidates by a proven bound): mode 2 forces it, auto prefers it where
 	// its kernel exists (d = 128 geometry, lists of <= 16); on a stream overflow the bf16x3 path below takes the batch
-	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kk <= cl_kmax) {
+	if ((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kf <= cl_kmax) {
 		// Data on which the filter gave up (every query sits on thousands of copies of its nearest row: two scans that only count,
 		// then the exact kernels anyway) is not asked again at once: the next 4, 8, ... 64 large searches of this index go straight to
 		// the fall-back (all-duplicates, N = 2 M: 1.3 s per batch with the two futile scans, 0.07 s without)
@@ -907,7 +915,7 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 			--cl_skip;
 		} else {
 			kp = (int)kk;
-			collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer);
+			collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer, (int)kf);
 			if (!collected) {
 				MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 				cl_skip_len = std::min(64, std::max(4, 2 * cl_skip_len));

@@ -420,3 +420,27 @@ def test_sort_sized_too_small_is_run_again(mf, metric):
         D, I = cl.search(xq, k)
         assert cl.last_kernel_info()["name"] == KERNEL
         assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), est
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,k", [(128, 16), (128, 32), (128, 127), (768, 32), (256, 16)])
+def test_inner_product_filter_works_with_the_users_k(mf, d, k):
+    """Inner product carries k + 1 entries for the tie detection; the FILTER works with k (a row tied with the k-th score passes any
+    bound derived from k rows), so k = 32 stays on the coarse filter of the wide stores and on the 32-class instance at d <= 128.
+    Small-integer data with duplicated rows: ties at the k-th score in most queries; equal to the exact kernels (FAISS's heap)."""
+    rs = np.random.RandomState(100 + d + k)
+    nb, nq = 70_000, 200
+    xb = rs.randint(-2, 3, size=(nb, d)).astype(np.float32)
+    m = nb // 3
+    xb[0 : 3 * m : 3] = xb[1 : 3 * m : 3]
+    xq = rs.randint(-2, 3, size=(nq, d)).astype(np.float32)
+    ex = mf.index_factory(d, "Flat", IP)
+    ex.set_option("prefilter", 0)
+    ex.add(xb)
+    D0, I0 = ex.search(xq, k)
+    cl = mf.index_factory(d, "Flat", IP)
+    cl.set_option("prefilter", 2)
+    cl.add(xb)
+    D, I = cl.search(xq, k)
+    assert "bf16" in cl.last_kernel_info()["name"] and "x3" not in cl.last_kernel_info()["name"], cl.last_kernel_info()["name"]
+    assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
