@@ -742,3 +742,26 @@ def test_ivf_k_on_the_coarse_filters_class_limits_with_exact_ties(mf, metric, k)
     D, I = g.search(xq, k, nprobe=5)
     assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect"), g.last_kernel_info()["name"]
     assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_grouping_by_lds_histograms_at_an_odd_list_count(mf, metric):
+    """>= 16 384 (query, list) pairs take the per-workgroup LDS histograms of csrc/ivf_scan.hip (ivf_group_*_lds_kernel); a list count
+    that is no power of two, queries that crowd a few lists (clustered), chunks that end inside the last workgroup: same bits as the
+    scanner kernel, and the same again when the batch is small enough for the plain atomics."""
+    d, nlist, n = 48, 100, 50_000
+    xb = _clustered(n, d, 81, ncent=20)
+    xq = _clustered(2100, d, 82, ncent=20)
+    ref = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    ref.train(xb)
+    ref.add(xb)
+    ref.set_option("ivf_collect", 0)
+    g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
+    g.ivf_set_centroids(ref.ivf_centroids())
+    g.add(xb)
+    for nq, nprobe in ((2100, 9), (1500, 9), (2100, 100)):
+        D0, I0 = ref.search(xq[:nq], 10, nprobe=nprobe)
+        D, I = g.search(xq[:nq], 10, nprobe=nprobe)
+        assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+        assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (nq, nprobe)
