@@ -383,6 +383,9 @@ extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_reg
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
                              float *d_beta, unsigned *d_list_max_bits /* [2 nlist] */, int64_t nlist, hipStream_t st);
 size_t ivf_collect_xi_bytes(int max_items);
+void launch_ivf_collect_pack_pairs(int metric, const float *d_x, int d, int64_t nq, int np, const int *d_slots, const void *d_items,
+                                   const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
+                                   float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st);
 void launch_ivf_collect_pack_nearest(int metric, const float *d_x, int d, int64_t nq, const int *d_slots, const void *d_items,
                                      const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
                                      float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st);

@@ -972,15 +972,15 @@ public:
 			const int64_t *keys = (const int64_t *)ws_cI.p;
 			// the nearest-list pre-pass: column 0 of the labels as a batch with one probe per query (key stride = nprobe)
 			const bool nearest_only = phase == 0 && !cl_prepass_all && !shared;
+			const bool by_pairs = nearest_only ? cl_pack_nearest : (cl_pack_pairs && !shared && !(phase == 0 && cl_prepass_all));
 			if (phase == 0 || !(cl_prepass_all || shared)) {
 				launch_ivf_group(keys, nq, nearest_only ? 1 : (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
 				                 (int *)ws_group.p + (phase == 0 ? 0 : group_ints), ws_items.p, (int *)ws_qidx.p,
-				                 nearest_only && cl_pack_nearest ? (int *)ws_slots.p : nullptr, &d_nitems, &d_cnt, stream,
-				                 nearest_only ? (int)np : 1, true);
-				if (nearest_only && cl_pack_nearest) // one pair per query: packed query by query (csrc/ivf_collect.hip)
-					launch_ivf_collect_pack_nearest(metric, d_x, d, nq, (const int *)ws_slots.p, ws_items.p, (const float *)cent_dev.p,
-					                                (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
-					                                (float *)ws_ie2.p, ctl_qfail, nlist, stream);
+				                 by_pairs ? (int *)ws_slots.p : nullptr, &d_nitems, &d_cnt, stream, nearest_only ? (int)np : 1, true);
+				if (by_pairs) // packed pair by pair, sixteen lanes each (csrc/ivf_collect.hip)
+					launch_ivf_collect_pack_pairs(metric, d_x, d, nq, nearest_only ? 1 : (int)np, (const int *)ws_slots.p, ws_items.p,
+					                              (const float *)cent_dev.p, (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p,
+					                              (float *)ws_ig.p, (float *)ws_ie2.p, ctl_qfail, nlist, stream);
 				else
 				launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
 				                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
@@ -1508,6 +1508,10 @@ public:
 			cl_stream_cap_per_query = v;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_pack_pairs")) { // 1: the main pass packs its (query, list) pairs pair by pair; 0 (default, faster): item by item
+			cl_pack_pairs = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_pack_nearest")) { // 1 (default): the nearest-list pre-pass packs its one pair per query query by query
 			cl_pack_nearest = v != 0;
 			return true;
@@ -1600,6 +1604,7 @@ private:
 	double cl_est_per_query = 0; // candidates per query of the last coarse-filter search: sizes the next search's sort (collect_sort_estimate)
 	int cl_seg_rows = 512;       // option ivf_cl_seg_rows
 	bool cl_pack_nearest = true; // option ivf_cl_pack_nearest
+	bool cl_pack_pairs = false;  // option ivf_cl_pack_pairs (the main pass pair by pair: measured slower, 1.64-1.68 vs 1.59-1.61 ms at C3)
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
 	int *h_fail = nullptr; // pinned

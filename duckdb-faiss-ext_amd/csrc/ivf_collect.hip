@@ -287,25 +287,24 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 // list -> centroid; lanes 0..15 hold the sixteen 8-element pieces of the slot's fragment column, the four sums are reduced over
 // them.  Slots of an item that no query owns are not written: the scan gives them a NaN bound whatever is stored (own_q < 0).
 template <bool IS_L2>
-__global__ __launch_bounds__(256) void ivf_collect_pack_nearest_kernel(const float *__restrict__ x, int d, long long nq,
-                                                                     const int *__restrict__ slots, const int4 *__restrict__ items,
-                                                                     const float *__restrict__ cent, const int *__restrict__ list_of_blk64,
-                                                                     const unsigned *__restrict__ list_max_bits, bf16x8i *__restrict__ xi,
-                                                                     float *__restrict__ igamma, float *__restrict__ ie2,
-                                                                     int *__restrict__ qfail, int nlist, int bound_mode) {
-	const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (q >= nq)
-		return;
-	const int code = slots[q];
-	if (code < 0)
-		return;
-	const int item = code >> 7, slot = code & 127;
-	const int4 it = items[item];
-	const int l = list_of_blk64[it.x >> 6];
+__global__ __launch_bounds__(256) void ivf_collect_pack_pairs_kernel(const float *__restrict__ x, int d, long long npairs, int np,
+                                                                   const int *__restrict__ slots, const int4 *__restrict__ items,
+                                                                   const float *__restrict__ cent, const int *__restrict__ list_of_blk64,
+                                                                   const unsigned *__restrict__ list_max_bits, bf16x8i *__restrict__ xi,
+                                                                   float *__restrict__ igamma, float *__restrict__ ie2,
+                                                                   int *__restrict__ qfail, int nlist, int bound_mode) {
+	// sixteen lanes per (query, list) pair -- the sixteen 8-element pieces of the slot's fragment column --, sixteen pairs per workgroup
+	const long long p = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+	const int l16 = threadIdx.x & 15;
+	const int code = p < npairs ? slots[p] : -1;
 	float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f;
-	if (lane < 16) {
-		const int kb = lane >> 2, hq = lane & 3;
+	int item = 0, slot = 0, l = 0;
+	const long long q = p / np;
+	if (code >= 0) {
+		item = code >> 7, slot = code & 127;
+		const int4 it = items[item];
+		l = list_of_blk64[it.x >> 6];
+		const int kb = l16 >> 2, hq = l16 & 3;
 		bf16x8i v;
 #pragma unroll
 		for (int e = 0; e < 8; ++e) {
@@ -324,13 +323,13 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_nearest_kernel(const flo
 		xi[(size_t)item * (8 * 4 * 64) + (size_t)(((slot >> 4) * 4 + kb) * 64 + hq * 16 + (slot & 15))] = v;
 	}
 #pragma unroll
-	for (int o = 8; o >= 1; o >>= 1) { // (lanes 16 .. 63 carry zeros)
+	for (int o = 8; o >= 1; o >>= 1) { // (within the pair's sixteen lanes)
 		xn += __shfl_xor(xn, o);
 		cn += __shfl_xor(cn, o);
 		xc += __shfl_xor(xc, o);
 		dq2 += __shfl_xor(dq2, o);
 	}
-	if (lane == 0) {
+	if (code >= 0 && l16 == 0) {
 		const float yn = __uint_as_float(list_max_bits[l]), dyn = __uint_as_float(list_max_bits[nlist + l]);
 		const float e2 = ivf_slot_e2<IS_L2>(xn, cn, dq2, yn, dyn, d, bound_mode);
 		if (!(e2 == e2))
@@ -339,19 +338,27 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_nearest_kernel(const flo
 		ie2[(size_t)item * 128 + slot] = e2;
 	}
 }
+// slots: [nq * np] slot codes of the pairs (pair p = query p / np), -1: no list
+void launch_ivf_collect_pack_pairs(int metric, const float *d_x, int d, int64_t nq, int np, const int *d_slots, const void *d_items,
+                                   const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
+                                   float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st) {
+	const long long npairs = (long long)nq * np;
+	if (npairs <= 0)
+		return;
+	const dim3 grid((unsigned)((npairs + 15) / 16));
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(ivf_collect_pack_pairs_kernel<true>, grid, dim3(256), 0, st, d_x, d, npairs, np, d_slots, (const int4 *)d_items,
+		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
+	else
+		hipLaunchKernelGGL(ivf_collect_pack_pairs_kernel<false>, grid, dim3(256), 0, st, d_x, d, npairs, np, d_slots, (const int4 *)d_items,
+		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
+	MVS_HIP(hipGetLastError());
+}
 void launch_ivf_collect_pack_nearest(int metric, const float *d_x, int d, int64_t nq, const int *d_slots, const void *d_items,
                                      const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
                                      float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st) {
-	if (nq <= 0)
-		return;
-	const dim3 grid((unsigned)((nq + 3) / 4));
-	if (metric == METRIC_L2)
-		hipLaunchKernelGGL(ivf_collect_pack_nearest_kernel<true>, grid, dim3(256), 0, st, d_x, d, (long long)nq, d_slots, (const int4 *)d_items,
-		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
-	else
-		hipLaunchKernelGGL(ivf_collect_pack_nearest_kernel<false>, grid, dim3(256), 0, st, d_x, d, (long long)nq, d_slots, (const int4 *)d_items,
-		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
-	MVS_HIP(hipGetLastError());
+	launch_ivf_collect_pack_pairs(metric, d_x, d, nq, 1, d_slots, d_items, d_cent, d_list_of_blk64, d_list_max_bits, d_xi, d_igamma, d_ie2,
+	                              d_qfail, nlist, st);
 }
 size_t ivf_collect_xi_bytes(int max_items) {
 	return (size_t)max_items * 8 * 4 * 64 * 16;

@@ -706,8 +706,9 @@ def test_ivf_sort_sized_too_small_is_run_again(mf, metric):
     g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
     g.ivf_set_centroids(ref.ivf_centroids())
     g.add(xb)
-    for pack in (1, 0):
-        g.set_option("ivf_cl_pack_nearest", pack)
+    for pack in (1, 0, 2):
+        g.set_option("ivf_cl_pack_nearest", 1 if pack else 0)
+        g.set_option("ivf_cl_pack_pairs", 1 if pack == 2 else 0)  # (2: the main pass pair by pair as well -- an option, measured slower)
         for est in (1, 0, 100000):
             D, I = g.search(xq, 10, nprobe=6)  # (leaves a true estimate)
             if est:
