@@ -404,7 +404,6 @@ void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *
 void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
                               int dp_csr, const int *d_perm, hipStream_t st, const unsigned long long *d_cnt = nullptr);
 void launch_collect_flat_items(void *d_items, int *d_nitems, int *d_qidx, int64_t nq, int64_t n, hipStream_t st);
-void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st);
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,
                               const float *d_xq, int64_t nq, FlatDB db, int64_t k, SelectorDev sel,

@@ -1589,7 +1589,7 @@ private:
 	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf, cent_dev, list_of_blk, perm_mf, ws_iqn, ws_qmaxn;
 	bool mf_residual = false;
 	// bf16 coarse filter (csrc/ivf_collect.hip): residual rows as bf16, -||y'||^2, the largest ||y'||^2 of every list
-	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_ie2p, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_cimask, ws_rowmask;
+	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_ie2p, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_cap_hint = 0, cl_stream_cap_per_query = 0;
 	bool collect_stats(int64_t *queries, int64_t *candidates, int64_t *overflows) override {

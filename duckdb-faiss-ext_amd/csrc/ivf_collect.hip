@@ -989,22 +989,4 @@ void launch_collect_flat_items(void *d_items, int *d_nitems, int *d_qidx, int64_
 	MVS_HIP(hipGetLastError());
 }
 
-// keep only one probe rank range of the coarse labels: out[q][p] = (lo <= p < hi) ? in[q][p] : -1
-__global__ void ivf_mask_probes_kernel(const long long *__restrict__ in, long long total, int np, int lo, int hi,
-                                       long long *__restrict__ out) {
-	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= total)
-		return;
-	const int p = (int)(i % np);
-	out[i] = (p >= lo && p < hi) ? in[i] : -1;
-}
-void launch_ivf_mask_probes(const int64_t *d_in, int64_t nq, int np, int lo, int hi, int64_t *d_out, hipStream_t st) {
-	const long long total = (long long)nq * np;
-	if (total <= 0)
-		return;
-	hipLaunchKernelGGL(ivf_mask_probes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const long long *)d_in,
-	                   total, np, lo, hi, (long long *)d_out);
-	MVS_HIP(hipGetLastError());
-}
-
 } // namespace mvs
