@@ -397,7 +397,13 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st);
+                             hipStream_t st, unsigned long long *d_bucket = nullptr, unsigned *d_bcount = nullptr, int bpitch = 0,
+                             unsigned long long *d_units = nullptr, unsigned *d_unit_cnt = nullptr);
+void launch_ivf_bucket_finish(int metric, unsigned long long *d_bucket, const unsigned *d_bcount, int bpitch, const unsigned long long *d_units,
+                              const unsigned *d_unit_cnt, unsigned *d_done, int64_t nq, const float *d_x, int d, const float *d_rows_csr,
+                              int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi, const int64_t *d_rowids,
+                              const int64_t *d_idmap, int k, float *d_D, int64_t *d_I, const int64_t *d_fin_rowids,
+                              const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats, hipStream_t st);
 size_t ivf_rowmask_bytes(int64_t nrows_mf);
 void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
                         void *d_mask, hipStream_t st);

@@ -715,14 +715,23 @@ public:
 			ws_tflag.reserve((size_t)(nq + 16) * sizeof(int));
 			raw_pos = true;
 			reuse_coarse = true; // (the coarse assignment above)
+			const int64_t *idmap_out = (d_idmap && !raw_ids) ? d_idmap : nullptr;
+			// (round 5: the bucket path of collect_search prints the final lists and runs the tie pass itself -- fin_done)
+			fin_D = d_D, fin_I = d_I, fin_idmap = idmap_out, fin_k = k, fin_done = false;
 			try {
 				search_mapped(nq, d_x, kx, (float *)ws_tD.p, (int64_t *)ws_tI.p, params, d_idmap, stream);
 			} catch (...) {
 				raw_pos = reuse_coarse = false;
+				fin_D = nullptr, fin_I = nullptr;
 				throw;
 			}
 			raw_pos = reuse_coarse = false;
-			const int64_t *idmap_out = (d_idmap && !raw_ids) ? d_idmap : nullptr;
+			fin_D = nullptr, fin_I = nullptr;
+			if (fin_done) {
+				fin_done = false;
+				stream_wait(st, stream);
+				return;
+			}
 			launch_ivf_finish(metric, (const float *)ws_tD.p, (const int64_t *)ws_tI.p, nq, (int)kx, (int)k, (const int64_t *)rowids.p,
 			                  idmap_out, d_D, d_I, (int *)ws_tflag.p, stream);
 			SelectorDev tsel = selector.upload(params, stream);
@@ -896,6 +905,18 @@ public:
 		// First without a host round trip behind the scan (the candidate count stays on the device, the sort is sized from the
 		// previous search of this index: csrc/flat_collect.hip launch_collect_group_est); if the count, read at the end, exceeds
 		// that size the search runs again the synchronous way.
+		if (cl_bucket && k <= 64) {
+			// round 5 (csrc/collect_bucket.h): candidates in per-query buckets, one kernel behind the scan -- nothing to estimate; a
+			// bucket that proved too small (the count is read at the search's one synchronisation) is grown and the pass repeated
+			cl_bpitch_try = 0;
+			for (int attempt = 0; attempt < 6; ++attempt) {
+				bool overflow = false;
+				const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, true, &overflow);
+				if (!overflow)
+					return ok;
+			}
+			return false;
+		}
 		if (cl_defer && cl_est_per_query > 0) {
 			bool overflow = false;
 			const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, true, &overflow);
@@ -931,9 +952,15 @@ public:
 		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
 		if (cl_prepass_shared)
 			ws_ie2p.reserve((size_t)max_items * 128 * sizeof(float));
-		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int);
+		const bool bucket = cl_bucket && k <= 64;
+		// control block, zeroed by ONE memset: header {stream count @0 | fail count @64 | unit count @128 | bucket stats @192} |
+		// per-query fail flags | segments begin / end (bucket mode: hits / finished units per query) | (bucket mode) tie flags {count, queries}
+		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int) + (bucket ? ((size_t)nq + 64) * sizeof(int) : 0);
 		ws_qfail.reserve(ctl_bytes);
 		int *const ctl_qfail = (int *)((char *)ws_qfail.p + 256), *const ctl_seg = ctl_qfail + nq;
+		int *const ctl_flag = ctl_seg + 2 * nq;
+		unsigned *const ctl_units = (unsigned *)((char *)ws_qfail.p + 128);
+		unsigned long long *const ctl_stats = (unsigned long long *)((char *)ws_qfail.p + 192);
 		const int nclass = kf > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
 		ws_gslot.reserve((size_t)nq * nclass * sizeof(unsigned) + 64);
 		launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
@@ -941,7 +968,14 @@ public:
 		// candidate stream: 4096 entries per query to start with, or what the last overflow showed this index's data to need
 		int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024) // (option ivf_cl_stream_cap: tests)
 		                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
+		// bucket mode: cl_bpitch entries of 8 bytes per query (a multiple of 64; grown when a query's count exceeded it) + the unit list
+		const int bpitch = cl_bpitch_try > 0 ? cl_bpitch_try
+		                   : (int)(cl_stream_cap_per_query > 0 ? std::max<int64_t>(64, (cl_stream_cap_per_query + 63) / 64 * 64) : cl_bpitch);
 		size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+		if (bucket) {
+			half = ((size_t)nq * bpitch * 8 + 255) & ~(size_t)255;
+			ws_stream.reserve(256 + half + ((size_t)nq * (bpitch / 64) + 64) * 8);
+		} else
 		ws_stream.reserve(256 + 2 * half);
 		unsigned long long *cnt = (unsigned long long *)ws_qfail.p; // (zeroed with the control block above)
 		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
@@ -993,7 +1027,8 @@ public:
 			                        (const float *)(phase == 0 && shared ? ws_ie2p.p : ws_ie2.p), (const unsigned short *)codes_bfr.p,
 			                        (const float *)beta_mf.p,
 			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
-			                        phase == 0 ? 1 : nseg, phase, rowmask, stream);
+			                        phase == 0 ? 1 : nseg, phase, rowmask, stream, bucket ? strm : nullptr, (unsigned *)ctl_seg, bpitch,
+			                        sorted /* bucket mode: the unit list */, ctl_units);
 			if (phase == 1)
 				end_kernel_timing(stream);
 		}
@@ -1004,9 +1039,54 @@ public:
 		                   (const int *)ctl_qfail, (int)nq, fail_cnt, fail_q);
 		if (!h_fail)
 			MVS_HIP(hipHostMalloc((void **)&h_fail, 64, hipHostMallocDefault));
+		fin_done = false;
+		if (bucket) {
+			// ONE kernel: exact values, selection, and (inside the exact-tie wrapper) FAISS's print order + boundary flags; the tie pass
+			// for the flagged queries is enqueued behind it, BEFORE the search's one synchronisation (rounds 3-4 launched the finish
+			// kernel and the tie pass after it: two launch latencies with the GPU idle)
+			const bool fin = raw_pos && fin_D != nullptr && kk == fin_k + 1;
+			launch_ivf_bucket_finish(metric, strm, (const unsigned *)ctl_seg, bpitch, sorted, ctl_units, (unsigned *)(ctl_seg + nq), nq, d_x, d,
+			                         (const float *)codes.p, dp, (const int *)perm_mf.p, kk, d_D, d_I, raw_pos ? nullptr : (const int64_t *)rowids.p,
+			                         (d_idmap && !raw_ids && !raw_pos) ? d_idmap : nullptr, fin ? (int)fin_k : 0, fin ? fin_D : nullptr,
+			                         fin ? fin_I : nullptr, (const int64_t *)rowids.p, fin ? fin_idmap : nullptr, fin ? ctl_flag : nullptr, ctl_stats,
+			                         stream);
+			if (fin) {
+				SelectorDev tsel = selector.upload(params, stream);
+				launch_ivf_tie_pass(metric, ctl_flag, nq, d_x, d, d_D, (int)kk, (int)fin_k, (const int64_t *)ws_cI.p, (int)np,
+				                    (const int64_t *)list_off_dev.p, (const float *)codes.p, dp, (const int64_t *)rowids.p, tsel, d_idmap,
+				                    fin_idmap, fin_D, fin_I, stream);
+			}
+			MVS_HIP(hipMemcpyAsync(h_fail + 4, ctl_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+			snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel");
+			kinfo.grid = max_items * nseg;
+			kinfo.block = 64;
+			kinfo.nsplit = (int)np;
+			kinfo.bytes = (double)nrows_mf * 256.0;               // every list's bf16 rows once (each list is probed by >= 1 item)
+			kinfo.flops = (double)nq * np * ((double)nsorted / nlist) * d * 2.0; // (average list length)
+			MVS_HIP(hipStreamSynchronize(stream)); // the one host round trip of the search
+			unsigned long long st2[2];
+			memcpy(st2, h_fail + 4, sizeof st2);
+			if ((int64_t)st2[1] > bpitch) { // some query's bucket was too small: its result is incomplete
+				++cl_overflows;
+				const int64_t want = ((int64_t)st2[1] + (int64_t)st2[1] / 4 + 63) / 64 * 64;
+				if (want > 16384)
+					return false; // (duplicate-heavy lists: the scanner kernel takes the batch, as before)
+				cl_bpitch_try = (int)want;
+				if (cl_stream_cap_per_query <= 0) // (option ivf_cl_stream_cap: tests -- the index does not remember the size)
+					cl_bpitch = (int)want;
+				*overflow = true;
+				return false;
+			}
+			cl_queries_total += nq;
+			cl_candidates_total += (int64_t)st2[0];
+			cl_est_per_query = (double)st2[0] / (double)std::max<int64_t>(nq, 1) + 1e-6;
+			fin_done = fin;
+		}
+		unsigned long long ncand_u = 0;
+		if (!bucket) {
 		MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
-		unsigned long long ncand_u = 0;
 		// (deferred: the sort covers n_est entries -- the previous search's candidates per query + 30 %, in units of 64 K)
 		const int64_t n_est = defer ? std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq)) : 0;
 		if (!defer) {
@@ -1091,10 +1171,12 @@ public:
 			cl_queries_total += nq;
 			cl_candidates_total += (int64_t)ncand_u;
 		}
+		} // (!bucket)
 		const int nf = *h_fail;
 		pf_queries_total += nq;
 		pf_fallback_total += nf;
 		if (nf > 0) { // re-run on the scanner kernel with the same coarse assignment
+			fin_done = false; // (their rows of the pure lists change below: the wrapper prints the batch again)
 			const mvs_kernel_info keep = kinfo;
 			const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
 			const size_t df_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
@@ -1540,6 +1622,10 @@ public:
 			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_bucket")) {
+			cl_bucket = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_exact_ties")) {
 			exact_ties = v != 0;
 			return true;
@@ -1606,6 +1692,15 @@ private:
 	bool cl_pack_nearest = true; // option ivf_cl_pack_nearest
 	bool cl_pack_pairs = false;  // option ivf_cl_pack_pairs (the main pass pair by pair: measured slower, 1.64-1.68 vs 1.59-1.61 ms at C3)
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
+	bool cl_bucket = false;      // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
+	int cl_bpitch = 1024;        // bucket entries per query (grown on demand up to 16 384)
+	int cl_bpitch_try = 0;       // ... of the repeated pass of the search in progress
+	// the exact-tie wrapper's final outputs, handed to the bucket path (which sets fin_done when it printed them itself)
+	float *fin_D = nullptr;
+	int64_t *fin_I = nullptr;
+	const int64_t *fin_idmap = nullptr;
+	int64_t fin_k = 0;
+	bool fin_done = false;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
 	int *h_fail = nullptr; // pinned
 	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel

@@ -20,6 +20,7 @@
 // A list is walked in segments of 512 rows, one wavefront each (long lists do not set the pace).  A pre-pass over the first 256
 // rows of every query's nearest list (publish only) warms the bounds.
 #include "flat_fused.h"
+#include "collect_bucket.h"
 
 #include <algorithm>
 #include <cmath>
@@ -63,6 +64,14 @@ struct IvfCollectArgs {
 	int nseg;    // segments per item (xcd_map >= 2 decodes the segment from blockIdx.x)
 	int gx8;     // workgroups of one segment round (a multiple of 8)
 	int xcd_map; // 2: as 1, and the segments of an item are consecutive workgroups of its XCD; 1: XCD j (= blockIdx.x & 7) takes the contiguous item range [j n/8, (j+1) n/8) (option ivf_cl_xcd)
+	// round 5, bucket mode (bucket != nullptr): a candidate goes straight into ITS QUERY's bucket -- entry bcount[q]++ of
+	// bucket[q][bpitch], the padded row alone -- instead of the global stream: nothing has to be sorted by query afterwards
+	// (ivf_bucket_finish_kernel re-scores and selects bucket by bucket).  Entries past bpitch are only counted.
+	unsigned long long *bucket; // [nq][bpitch] entries of 8 bytes (the scan writes the low word; the finish kernel puts the exact key there)
+	unsigned *bcount;           // [nq] hits of the query so far
+	int bpitch;
+	unsigned long long *units;  // work list of the finish kernel: (query << 16 | group of 64 entries), appended by the lane that opens the group
+	unsigned *unit_cnt;
 };
 
 __device__ __forceinline__ unsigned ic_skey(float s) { // "larger s is better" as a smaller-is-better key
@@ -392,7 +401,8 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
 // bounds of the item's 128 slots live in an LDS table {B - E, gamma} that the wave refreshes itself.
 // NC: row classes per query (16, or 32 for 16 < kk <= 32 -- csrc/flat_collect.hip)
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-template <int NC>
+// BUCKET: candidates into per-query buckets + unit list (round 5) instead of the global stream
+template <int NC, bool BUCKET>
 __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollectArgs a) {
 	constexpr int KB = 4, PITCH = 256, TILE_BYTES = IC_BN * PITCH;
 	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 8 + IC_QCAP) / 4];
@@ -537,6 +547,37 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		qpub = 0;
 		if (n == 0u || !a.collect)
 			return;
+		if (BUCKET) { // one position per hit from its query's counter: every atomic of the drain is in flight before the first is waited for
+			constexpr int NB = (IC_QCAP + 63) / 64;
+			unsigned row[NB], pp[NB];
+			int qq[NB];
+#pragma unroll
+			for (int j = 0; j < NB; ++j) {
+				const unsigned e = lane + 64u * j;
+				pp[j] = 0xffffffffu;
+				if (e < n) {
+					unsigned long long ent;
+					unsigned sl;
+					asm volatile("ds_read_b64 %0, %2\n\tds_read_u8 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+					             : "=&v"(ent), "=&v"(sl)
+					             : "v"(qbuf_lds + 8u * e), "v"(qslot_lds + e)
+					             : "memory");
+					asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qq[j]) : "v"(qtab_lds + sl * 8u) : "memory");
+					row[j] = (unsigned)(ent >> 32);
+					pp[j] = __hip_atomic_fetch_add(a.bcount + qq[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < NB; ++j) {
+				if (pp[j] < (unsigned)a.bpitch) {
+					*(unsigned *)(a.bucket + (size_t)qq[j] * (size_t)a.bpitch + pp[j]) = row[j];
+					if ((pp[j] & 63u) == 0u)
+						a.units[__hip_atomic_fetch_add(a.unit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] =
+						    ((unsigned long long)(unsigned)qq[j] << 16) | (pp[j] >> 6);
+				}
+			}
+			return;
+		}
 		unsigned long long base = 0ull;
 		if (lane == 0) { // (by hand: no compiled atomic with a result in the loop)
 			const unsigned long long n64 = n;
@@ -610,7 +651,15 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 					typedef __attribute__((address_space(1))) unsigned *GU;
 					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)qe.x * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - __int_as_float(qe.y)),
 					                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (a.collect) {
+					if (a.collect && BUCKET) {
+						const unsigned p = __hip_atomic_fetch_add(a.bcount + qe.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (p < (unsigned)a.bpitch) {
+							*(unsigned *)(a.bucket + (size_t)qe.x * (size_t)a.bpitch + p) = row;
+							if ((p & 63u) == 0u)
+								a.units[__hip_atomic_fetch_add(a.unit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] =
+								    ((unsigned long long)(unsigned)qe.x << 16) | (p >> 6);
+						}
+					} else if (a.collect) {
 						unsigned long long gp;
 						const unsigned long long one64 = 1ull;
 						typedef __attribute__((address_space(1))) unsigned long long *GUL;
@@ -767,7 +816,8 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st) {
+                             hipStream_t st, unsigned long long *d_bucket, unsigned *d_bcount, int bpitch, unsigned long long *d_units,
+                             unsigned *d_unit_cnt) {
 	if (max_items <= 0 || nseg <= 0)
 		return;
 	IvfCollectArgs a;
@@ -789,6 +839,11 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.collect = collect;
 	a.refresh = g_ivf_cl_refresh;
 	a.rowmask = d_rowmask;
+	a.bucket = d_bucket;
+	a.bcount = d_bcount;
+	a.bpitch = bpitch;
+	a.units = d_units;
+	a.unit_cnt = d_unit_cnt;
 	a.xcd_map = (g_ivf_cl_xcd && max_items >= 64) ? g_ivf_cl_xcd : 0; // (the Flat small-batch path has one or two items: nothing to place)
 	a.nseg = nseg;
 	a.abl = g_ivf_cl_abl;
@@ -800,10 +855,14 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	}
 	a.gx8 = (int)gx;
 	const dim3 grid = a.xcd_map >= 2 ? dim3(gx * (unsigned)nseg) : dim3(gx, nseg);
-	if (kk > 16) // 32 row classes: the caller sized and initialised 32 slots per query (ivf_collect_slot_stride)
-		hipLaunchKernelGGL(ivf_bf16_collect_kernel<32>, grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
+	if (kk > 16 && d_bucket) // 32 row classes: the caller sized and initialised 32 slots per query (ivf_collect_slot_stride)
+		hipLaunchKernelGGL((ivf_bf16_collect_kernel<32, true>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
+	else if (kk > 16)
+		hipLaunchKernelGGL((ivf_bf16_collect_kernel<32, false>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
+	else if (d_bucket)
+		hipLaunchKernelGGL((ivf_bf16_collect_kernel<16, true>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
 	else
-		hipLaunchKernelGGL(ivf_bf16_collect_kernel<16>, grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
+		hipLaunchKernelGGL((ivf_bf16_collect_kernel<16, false>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -919,6 +978,248 @@ void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t 
 	else
 		hipLaunchKernelGGL(ivf_collect_exact_kernel<false>, grid, dim3(64), 0, st, d_sorted,
 		                   (long long)ncand, d_x, d, d_rows_csr, dp_csr, d_perm, d_cnt);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- round 5: buckets -> exact values -> the kk best -> the search's output: ONE kernel (csrc/collect_bucket.h) ---------------
+// A unit = 64 bucket entries of one query: rows staged through LDS and re-scored with the scanner's arithmetic exactly as
+// ivf_collect_exact_kernel does (lane <-> candidate; the QUERY is the same for the whole wave now: its loads are wave-uniform),
+// key = (order-preserving value key << 32) | position in the list-sorted store written over the entry.  The wave that completes
+// a query's last unit (a counter per query behind a release fence) selects the query's kk best and writes
+//   pd / pi [nq][kk]   the pure list (value, position | label), what collect_select_kernel + ivf_emit_sorted_kernel produced, and
+//   D / I [nq][k]      (inside the exact-tie wrapper) FAISS's print order + the boundary-tie flags: csrc/ivf_ties.hip
+//                      ivf_finish_kernel's rule applied to the list while it is still in registers.
+struct IvfBucketFinishArgs {
+	unsigned long long *bucket;
+	const unsigned *bcount;
+	int bpitch;
+	const unsigned long long *units;
+	const unsigned *unit_cnt;
+	unsigned *done; // [nq] units completed per query (zeroed)
+	long long nq;
+	const float *x;
+	int d;
+	const float *rows_csr;
+	int dp;
+	const int *perm;
+	int kk;
+	float *pd;
+	long long *pi;
+	const long long *rowids; // labels of the pure list (nullptr: positions), then through idmap if given
+	const long long *idmap;
+	int k; // fin (D != nullptr): k <= kk
+	float *D;
+	long long *I;
+	const long long *fin_rowids;
+	const long long *fin_idmap;
+	int *flag_cnt;
+	int *flag_q;
+	unsigned long long *stats; // [0] sum of the bucket counts, [1] the largest
+};
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void ivf_bucket_finish_kernel(const IvfBucketFinishArgs a) {
+	__shared__ __attribute__((aligned(16))) float rows[64 * (128 + 4)];
+	__shared__ unsigned long long surv[256];
+	__shared__ unsigned long long top[64];
+	__shared__ float fv[64];
+	__shared__ long long fid[64];
+	__shared__ int fp[64];
+	const int lane = threadIdx.x;
+	const int d = a.d, dp = a.dp, pitch = dp + 4, cpr = dp / 4, kk = a.kk;
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+	// queries without a single candidate have no unit: their (empty) lists are written here
+	for (long long q = (long long)blockIdx.x * 64 + lane; q < a.nq; q += (long long)gridDim.x * 64) {
+		if (a.bcount[q] != 0u)
+			continue;
+		for (int j = 0; j < kk; ++j) {
+			a.pd[q * kk + j] = neutral;
+			a.pi[q * kk + j] = -1;
+		}
+		if (a.D)
+			for (int j = 0; j < a.k; ++j) {
+				a.D[q * a.k + j] = neutral;
+				a.I[q * a.k + j] = -1;
+			}
+	}
+	const unsigned nunits = *a.unit_cnt;
+	const bool whole = d == 128 && dp == 128;
+	for (unsigned u = blockIdx.x; u < nunits; u += gridDim.x) {
+		const unsigned long long un = a.units[u];
+		const long long q = (long long)(un >> 16);
+		const int c0 = (int)(un & 0xffffu) * 64;
+		const unsigned have = a.bcount[q];
+		const int n = (int)(have < (unsigned)a.bpitch ? have : (unsigned)a.bpitch);
+		const int nrow = n - c0 < 64 ? n - c0 : 64;
+		unsigned long long *bq = a.bucket + (size_t)q * (size_t)a.bpitch;
+		const int pos = lane < nrow ? a.perm[(unsigned)bq[c0 + lane]] : -1;
+		const float *xq = a.x + q * d;
+		float4 xr[32];
+		if (whole) {
+#pragma unroll
+			for (int c4 = 0; c4 < 32; ++c4)
+				xr[c4] = *(const float4 *)(xq + c4 * 4);
+#pragma unroll 16
+			for (int it = 0; it < 16; ++it) {
+				const int r = 2 * it + (lane >> 5), ch = lane & 31;
+				const int pp = __shfl(pos, r);
+				const float4 v = *(const float4 *)(a.rows_csr + (size_t)(pp < 0 ? 0 : pp) * 128 + ch * 4);
+				*(float4 *)(rows + r * 132 + ch * 4) = v;
+			}
+			if (nrow > 32) {
+#pragma unroll 16
+				for (int it = 16; it < 32; ++it) {
+					const int r = 2 * it + (lane >> 5), ch = lane & 31;
+					const int pp = __shfl(pos, r);
+					const float4 v = *(const float4 *)(a.rows_csr + (size_t)(pp < 0 ? 0 : pp) * 128 + ch * 4);
+					*(float4 *)(rows + r * 132 + ch * 4) = v;
+				}
+			}
+		} else {
+			for (int it = 0; it < cpr; ++it) { // 64 consecutive float4 of the 64 x cpr block per step
+				const int idx = it * 64 + lane, r = idx / cpr, ch = idx - r * cpr;
+				const int pp = __shfl(pos, r);
+				const float4 v = *(const float4 *)(a.rows_csr + (size_t)(pp < 0 ? 0 : pp) * dp + ch * 4);
+				*(float4 *)(rows + r * pitch + ch * 4) = v;
+			}
+		}
+		__syncthreads();
+		if (lane < nrow) {
+			const float *y = rows + lane * pitch;
+			float acc = 0.f;
+			int kd = 0;
+			if (whole) {
+#pragma unroll
+				for (int c4 = 0; c4 < 32; ++c4) {
+					const float4 xv = xr[c4];
+					const float4 yv = *(const float4 *)(y + c4 * 4);
+					const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						if (IS_L2) {
+							const float t = __fsub_rn(xs[e], ys[e]);
+							acc = fmaf(t, t, acc);
+						} else {
+							acc = fmaf(xs[e], ys[e], acc);
+						}
+					}
+				}
+				kd = d;
+			} else if ((d & 3) == 0) {
+				for (; kd < d; kd += 4) {
+					const float4 xv = *(const float4 *)(xq + kd);
+					const float4 yv = *(const float4 *)(y + kd);
+					const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						if (IS_L2) {
+							const float t = __fsub_rn(xs[e], ys[e]);
+							acc = fmaf(t, t, acc);
+						} else {
+							acc = fmaf(xs[e], ys[e], acc);
+						}
+					}
+				}
+			}
+			for (; kd < d; ++kd) {
+				if (IS_L2) {
+					const float t = __fsub_rn(xq[kd], y[kd]);
+					acc = fmaf(t, t, acc);
+				} else {
+					acc = fmaf(xq[kd], y[kd], acc); // fvec_inner_product: the k-ordered chain
+				}
+			}
+			const bool ok = pos >= 0 && (IS_L2 ? acc < FLT_MAX : acc > -FLT_MAX);
+			// (agent-scope store: written THROUGH to the memory side, where the selecting wave -- possibly on another XCD, whose L2 is
+			// not coherent with this one inside a launch -- reads it with agent-scope loads.  A device-wide fence here instead writes
+			// back and invalidates whole L2s: 2.5 ms per launch when every unit did one)
+			__hip_atomic_store(bq + c0 + lane, ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)pos) : CB_EMPTY,
+			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the wave's key stores have completed (vmcnt) before the unit counts as done
+		int last = 0;
+		if (lane == 0) {
+			const unsigned t = __hip_atomic_fetch_add(a.done + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			last = t + 1u == (unsigned)((n + 63) >> 6);
+		}
+		last = __builtin_amdgcn_readfirstlane(last);
+		__syncthreads(); // (the staged rows are free)
+		if (!last)
+			continue;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		const unsigned long long mine = cb_select_wave(bq, n, kk, lane, surv, top);
+		const bool hv = mine != CB_EMPTY;
+		const float val = hv ? bkey2f<IS_L2>((unsigned)(mine >> 32)) : neutral;
+		const int ps = hv ? (int)(unsigned)mine : -1;
+		if (lane < kk) {
+			a.pd[q * kk + lane] = val;
+			long long lab = ps;
+			if (ps >= 0 && a.rowids) {
+				lab = a.rowids[ps];
+				if (a.idmap)
+					lab = a.idmap[lab];
+			}
+			a.pi[q * kk + lane] = lab;
+		}
+		if (a.D) { // csrc/ivf_ties.hip ivf_finish_kernel, entry j of the pure list in lane j
+			const int k = a.k;
+			fv[lane] = val;
+			fp[lane] = lane < kk ? ps : -1;
+			fid[lane] = (lane < kk && ps >= 0) ? a.fin_rowids[ps] : -1;
+			__syncthreads();
+			if (lane < k) {
+				const int j = lane;
+				if (fp[j] < 0) {
+					a.D[q * k + j] = neutral;
+					a.I[q * k + j] = -1;
+				} else {
+					const long long id = fid[j];
+					int lo = j, hi = j;
+					while (lo > 0 && fv[lo - 1] == val)
+						--lo;
+					while (hi + 1 < k && fp[hi + 1] >= 0 && fv[hi + 1] == val)
+						++hi;
+					int rank = 0;
+					for (int m = lo; m <= hi && hi > lo; ++m) {
+						const long long idm = fid[m];
+						rank += IS_L2 ? (idm < id || (idm == id && m < j)) : (idm > id || (idm == id && m < j));
+					}
+					const long long o = q * k + lo + rank;
+					a.D[o] = val;
+					a.I[o] = a.fin_idmap ? a.fin_idmap[id] : id;
+					if (j == k - 1 && kk > k && fp[k] >= 0 && fv[k] == val)
+						a.flag_q[atomicAdd(a.flag_cnt, 1)] = (int)q;
+				}
+			}
+			__syncthreads();
+		}
+		if (lane == 0) {
+			atomicAdd(a.stats, (unsigned long long)have);
+			atomicMax(a.stats + 1, (unsigned long long)have);
+		}
+	}
+}
+void launch_ivf_bucket_finish(int metric, unsigned long long *d_bucket, const unsigned *d_bcount, int bpitch, const unsigned long long *d_units,
+                              const unsigned *d_unit_cnt, unsigned *d_done, int64_t nq, const float *d_x, int d, const float *d_rows_csr,
+                              int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi, const int64_t *d_rowids,
+                              const int64_t *d_idmap, int k, float *d_D, int64_t *d_I, const int64_t *d_fin_rowids,
+                              const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	if (dp_csr % 4 != 0 || dp_csr > 128 || kk > 64 || kk < 1)
+		throw_faiss("mvs::launch_ivf_bucket_finish", __FILE__, "row pitch %d / k %d is not served", dp_csr, kk);
+	IvfBucketFinishArgs a;
+	memset(&a, 0, sizeof a);
+	a.bucket = d_bucket, a.bcount = d_bcount, a.bpitch = bpitch, a.units = d_units, a.unit_cnt = d_unit_cnt, a.done = d_done;
+	a.nq = nq, a.x = d_x, a.d = d, a.rows_csr = d_rows_csr, a.dp = dp_csr, a.perm = d_perm, a.kk = kk;
+	a.pd = d_pd, a.pi = (long long *)d_pi, a.rowids = (const long long *)d_rowids, a.idmap = (const long long *)d_idmap;
+	a.k = k, a.D = d_D, a.I = (long long *)d_I, a.fin_rowids = (const long long *)d_fin_rowids, a.fin_idmap = (const long long *)d_fin_idmap;
+	a.flag_cnt = d_flag, a.flag_q = d_flag ? d_flag + 1 : nullptr, a.stats = d_stats;
+	// a fixed grid walks the unit list in strides (its length is on the device): four waves per CU are resident (34 KB of LDS each)
+	const dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(nq, 1), 8192));
+	if (metric_order(metric) == METRIC_L2)
+		hipLaunchKernelGGL(ivf_bucket_finish_kernel<true>, grid, dim3(64), 0, st, a);
+	else
+		hipLaunchKernelGGL(ivf_bucket_finish_kernel<false>, grid, dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
 

@@ -11,7 +11,9 @@
 // golden vectors (test/sql/faiss.test, faiss3.test, faiss4.test, faiss7.test).
 //
 //   boundary_driver golden <training.csv> <queries.csv>
-//   boundary_driver ingest <n> <d> <threads>          (concurrent DataChunk ingest + self-query check)
+//   boundary_driver ingest <n> <d> <threads> [index]  (concurrent DataChunk ingest + self-query check; index = factory
+//                                                      string, default "IDMap,Flat"; IVF trains in AddFinalise on all rows)
+//   boundary_driver linkrate                          (host -> device copy rate of this box: pinned and pageable)
 #include "faiss/Index.h"
 #include "faiss/IndexHNSW.h"
 #include "faiss/IndexIDMap.h"
@@ -21,6 +23,7 @@
 #include "faiss/index_factory.h"
 #include "faiss/index_io.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -333,7 +336,7 @@ int run_golden(const char *train_csv, const char *query_csv) {
 }
 
 // concurrent ingest the way DuckDB drives faiss_add for a large table, then self-queries
-int run_ingest(size_t n, int d, int threads) {
+int run_ingest(size_t n, int d, int threads, const char *desc = "IDMap,Flat") {
 	std::vector<float> xb(n * (size_t)d);
 	uint64_t s = 88172645463325252ull;
 	for (auto &v : xb) {
@@ -345,15 +348,24 @@ int run_ingest(size_t n, int d, int threads) {
 	std::vector<faiss::idx_t> ids(n);
 	for (size_t i = 0; i < n; ++i)
 		ids[i] = (faiss::idx_t)(1000000 + 7 * i);
-	auto e = create(d, "IDMap,Flat", faiss::METRIC_L2);
+	const bool with_ids = !strncmp(desc, "IDMap", 5);
+	auto e = create(d, desc, faiss::METRIC_L2);
 	const auto t0 = std::chrono::steady_clock::now();
-	faiss_add(*e, n, xb.data(), ids.data(), threads);
+	faiss_add(*e, n, xb.data(), with_ids ? ids.data() : nullptr, threads);
 	// add() returns while the last H2D copies are still in flight: a 1-query search drains the index's stream
 	(void)faiss_search(*e, 1, xb.data(), 1);
 	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-	printf("ingestrate\t%.0f rows/s (%zu rows x %d dims in %zu add_with_ids calls of <= 2048 rows from %d threads: %.3f s, %.2f GB/s "
+	printf("ingestrate\t%.0f rows/s (%s: %zu rows x %d dims in %zu add calls of <= 2048 rows from %d threads: %.3f s, %.2f GB/s "
 	       "of row data)\n",
-	       (double)n / sec, n, d, (n + 2047) / 2048, threads, sec, (double)n * d * 4 / sec / 1e9);
+	       (double)n / sec, desc, n, d, (n + 2047) / 2048, threads, sec, (double)n * d * 4 / sec / 1e9);
+	printf("ingestjson\t{\"index\": \"%s\", \"rows\": %zu, \"d\": %d, \"threads\": %d, \"seconds\": %.4f, \"rows_per_s\": %.0f, "
+	       "\"GBps\": %.3f}\n",
+	       desc, n, d, threads, sec, (double)n / sec, (double)n * d * 4 / sec / 1e9);
+	if (!with_ids || strstr(desc, "HNSW") || strstr(desc, "IVF")) { // (approximate indexes: no self-query guarantee; the count is the check)
+		const bool okc = (size_t)e->index->ntotal == n;
+		printf("ingest\t%s ntotal=%lld, threads=%d\n", okc ? "OK" : "FAIL", (long long)e->index->ntotal, threads);
+		return okc ? 0 : 1;
+	}
 	if ((size_t)e->index->ntotal != n) {
 		printf("ingest\tFAIL ntotal %lld\n", (long long)e->index->ntotal);
 		return 1;
@@ -367,6 +379,40 @@ int run_ingest(size_t n, int d, int threads) {
 	printf("ingest\t%s %zu/%zu self-queries, ntotal=%lld, threads=%d\n", ok == nq ? "OK" : "FAIL", ok, nq,
 	       (long long)e->index->ntotal, threads);
 	return ok == nq ? 0 : 1;
+}
+
+// host -> device copy rate of this box (what the ingest rates are a fraction of): 256 MiB from pinned and from pageable memory
+extern "C" {
+int hipHostMalloc(void **, size_t, unsigned);
+int hipHostFree(void *);
+int hipMalloc(void **, size_t);
+int hipFree(void *);
+int hipMemcpy(void *, const void *, size_t, int);
+int hipDeviceSynchronize();
+}
+int run_linkrate() {
+	const size_t bytes = (size_t)256 << 20;
+	void *dev = nullptr, *pin = nullptr;
+	if (hipMalloc(&dev, bytes) != 0 || hipHostMalloc(&pin, bytes, 0) != 0) {
+		printf("linkrate\tFAIL allocation\n");
+		return 1;
+	}
+	std::vector<char> page(bytes, 1);
+	memset(pin, 1, bytes);
+	double best[2] = {0, 0};
+	for (int rep = 0; rep < 4; ++rep)
+		for (int kind = 0; kind < 2; ++kind) {
+			hipDeviceSynchronize();
+			const auto t0 = std::chrono::steady_clock::now();
+			hipMemcpy(dev, kind == 0 ? pin : (void *)page.data(), bytes, 1 /* hipMemcpyHostToDevice */);
+			hipDeviceSynchronize();
+			const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			best[kind] = std::max(best[kind], (double)bytes / sec / 1e9);
+		}
+	printf("linkjson\t{\"h2d_pinned_GBps\": %.2f, \"h2d_pageable_GBps\": %.2f, \"bytes\": %zu}\n", best[0], best[1], bytes);
+	hipFree(dev);
+	hipHostFree(pin);
+	return 0;
 }
 
 // README.md:61 index "IDMap,HNSW32": CreateFunction with the efConstruction parameter (:127-139), chunked faiss_add with
@@ -438,14 +484,16 @@ int main(int argc, char **argv) {
 		if (argc >= 4 && !strcmp(argv[1], "golden"))
 			return run_golden(argv[2], argv[3]);
 		if (argc >= 5 && !strcmp(argv[1], "ingest"))
-			return run_ingest((size_t)atoll(argv[2]), atoi(argv[3]), atoi(argv[4]));
+			return run_ingest((size_t)atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), argc >= 6 ? argv[5] : "IDMap,Flat");
+		if (argc >= 2 && !strcmp(argv[1], "linkrate"))
+			return run_linkrate();
 		if (argc >= 6 && !strcmp(argv[1], "hnsw"))
 			return run_hnsw((size_t)atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), argv[5]);
 	} catch (const std::exception &e) {
 		fprintf(stderr, "fatal: %s\n", e.what());
 		return 3;
 	}
-	fprintf(stderr, "usage: boundary_driver golden <training.csv> <queries.csv> | ingest <n> <d> <threads> | "
+	fprintf(stderr, "usage: boundary_driver golden <training.csv> <queries.csv> | ingest <n> <d> <threads> [index] | linkrate | "
 	                "hnsw <n> <d> <threads> <index file>\n");
 	return 2;
 }

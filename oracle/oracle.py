@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liborc.so")
+_LIB = os.environ.get("ORC_LIB_PATH") or os.path.join(_HERE, "liborc.so")  # (override: the ASan/UBSan build of `make sanitize`)
 
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
