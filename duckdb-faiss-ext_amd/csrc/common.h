@@ -149,15 +149,53 @@ void launch_rescore_verify(int metric, const float *d_ca, const int64_t *d_ci, i
 void launch_gather_query_rows(const float *d_x, int d, const int *d_fq, int nf, float *d_xf, hipStream_t st);
 void launch_scatter_rows(const int *d_fq, int nf, int64_t k, const float *d_Df, const int64_t *d_If, float *d_D,
                          int64_t *d_I, hipStream_t st);
-extern int g_pf_nsplit;
-extern int g_pf_abl;
-extern int g_pf_seed;
-extern int g_pf_classes32;
-extern int g_pf_sched;
-extern int g_mfma_variant;
-extern int g_mfma_nsplit;
-extern int g_mfma_warm;
-extern int g_mfma_global_lists;
+
+// ---- per-index tuning (round 5): every knob that used to be a process-wide `g_*` int --------------------------------------------
+// An index owns one Tuning (IndexBase::tune_); IndexBase::use_device() -- the first statement of every entry point -- makes it the
+// calling thread's current one, and the launch functions read tune().x.  Two indexes searched from two threads neither share
+// nor race on these values (SURVEY 8b "Threading"; reference src/faiss_extension.cpp:629 takes only a per-index lock).
+struct Tuning {
+	// csrc/coarse_select.hip
+	int coarse_persistent = 0; // option ivf_coarse_persistent (measured slower, see coarse_dist_mfma_kernel)
+	int coarse_abl = 0;        // (profiling library only, option coarse_abl: 1 = no matrix written, 2 = no MFMA loop -- results wrong)
+	int coarse_mfma = 1;       // option ivf_coarse_mfma: the distance matrix on the f32 matrix pipe (1) or on the vector ALU (0)
+	int coarse_select = 1;     // option ivf_coarse_select: 0 = the IVF coarse quantiser runs on the k-list kernels
+	// csrc/flat_bf16.hip
+	int pf_nsplit = 0;
+	int pf_sched = 0;     // option pf_sched (see the kernel)
+	int pf_classes32 = 0; // option pf_classes32 = 1: 32 classes + k-th smallest (measured slower: 67.4 vs 65.5 ms, same box)
+	int pf_seed = 0;      // rows of the seeding pre-pass (0 = off: measured no gain)
+	int pf_abl = 0;       // profiling: ablation instance of the d = 128 L2 kernel (results wrong)
+	// csrc/flat_collect.hip
+	int cl_bound_mode = 1;    // option cl_bound_mode: bf16 rounding term from the actual residual norms (1) or the worst case per element (0)
+	int cl_abl = 0;           // option cl_abl: profiling ablation of the L2 scan (results wrong)
+	int cl_nsplit = 0;        // option cl_nsplit: row splits of the main scan (0 = planned)
+	int cl_seed_split = 0;    // option cl_seed_split: row splits of the pre-pass (0 = 32)
+	int cl_seed_rows = 16384; // option cl_seed_rows: rows of the bound-estimation pre-pass
+	int cl_seed_regs = 1;     // option cl_seed_regs: d <= 128 pre-pass with class maxima in registers (0: through the scan kernel's rare path)
+	int cl_tab = 1;           // option cl_tab: pass bounds through the global table (1) or every wave derives its own (0, round 3)
+	int cl_nc32_from = 17;    // option cl_nc32_from
+	// csrc/flat_collect_wide.hip, flat_collect_big.hip
+	int wide_big = 1;       // option cl_wide_big: 512 < d <= 1024 on flat_bf16_big_kernel (1) or on the k-split kernel (0)
+	int big_mode = 3;       // option cl_big_mode (see MODE)
+	int ksplit_waves = 4;   // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
+	int wide512_ksplit = 0; // option cl_wide512_ksplit: the 512-dim store on the k-split kernel
+	int wide384_ncb = 3;    // option cl_wide384_ncb: column blocks per wave of the 384-dim instance (2 | 3)
+	int ksplit_opt = 0;     // option cl_ksplit_opt: bit 0 = s_setprio skew
+	int ksplit_ncb = 3;     // column blocks per wave pair (option cl_ksplit_ncb: 2, or 3 with 8 waves)
+	// csrc/flat_mfma.hip
+	int mfma_nsplit = 0;       // 0 = heuristic; > 0 forces the split count (tuning / tests)
+	int mfma_warm = 0;         // > 1: warm-up pre-pass over n / mfma_warm rows (experiment)
+	int mfma_global_lists = 1; // 1: k-lists in global memory for every k > 12
+	int mfma_variant = 2;      // 1 = register-staged generic kernel, 2 = LDS-DMA + A-ring resident kernel
+	// csrc/ivf_collect.hip
+	int ivf_cl_abl = 0;      // (profiling library only: 1 = the scan without its rare path -- results wrong)
+	int ivf_cl_lds_pad = 0;  // (experiment: unused dynamic LDS per workgroup = fewer wavefronts per CU)
+	int ivf_cl_xcd = 1;      // option ivf_cl_xcd: items of one list on one XCD (1), their segments next to each other too (2), or dealt round-robin (0)
+	int ivf_cl_refresh = 16; // option ivf_cl_refresh (see IvfCollectArgs::refresh)
+};
+const Tuning &tune();                      // the calling thread's current tuning (the defaults when no index call is in progress)
+void set_current_tuning(const Tuning *t);
 
 // direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic
 struct DirectPlan {
@@ -259,6 +297,9 @@ void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nli
                       const int64_t *d_list_begin, const int64_t *d_list_end, int *ws_int, void *d_items, int *d_qidx,
                       int *d_slots, int **d_nitems_out, int **d_cnt_out, hipStream_t st, int key_stride = 1,
                       bool counters_zeroed = false);
+void launch_ivf_group2(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, int group, int shift, const int64_t *d_list_begin,
+                       const int64_t *d_list_end, int *ws0, int *ws1, void *d_items0, int *d_qidx0, int *d_slots0, void *d_items1,
+                       int *d_qidx1, int *d_slots1, int **d_nitems0_out, int **d_nitems1_out, hipStream_t st);
 void launch_ivf_pack_item_fragments(const float *d_x, int d, int kc, int nch, const void *d_items, const int *d_nitems,
                                     int max_items, const int *d_qidx, float *d_qf, hipStream_t st);
 void launch_merge_items(int metric, const float *d_pd, const int32_t *d_pi, const int *d_slots, int nprobe, int64_t nq,

@@ -473,11 +473,6 @@ extern "C" void mvs_debug_counters(unsigned long long *out, int reset) {
 	}
 }
 #endif
-int g_pf_nsplit = 0;
-int g_pf_sched = 0; // option pf_sched (see the kernel)
-int g_pf_classes32 = 0; // option pf_classes32 = 1: 32 classes + k-th smallest (2.2x fewer insertions, but its blocking read + bisection cost more than they save: 67.4 vs 65.5 ms, same box)
-int g_pf_seed = 0; // rows of the seeding pre-pass (0 = off: measured no gain, the insertions are not what the first round waits for)
-int g_pf_abl = 0; // profiling: ablation instance of the d = 128 L2 kernel (results wrong)
 
 FlatSearchPlan plan_prefilter(const FlatGeom &g, int64_t nq, int64_t n, int64_t kp) {
 	FlatSearchPlan p;
@@ -490,8 +485,8 @@ FlatSearchPlan plan_prefilter(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	max_split = std::min<int64_t>(max_split, 512);
 	int64_t nsplit = 1;
 	p.xcd_map = false;
-	if (g_pf_nsplit > 0) {
-		nsplit = g_pf_nsplit;
+	if (tune().pf_nsplit > 0) {
+		nsplit = tune().pf_nsplit;
 	} else if (max_split >= 8) {
 		double best = -1;
 		for (int64_t s = 8; s <= max_split; s += 8) {
@@ -553,7 +548,7 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
                       int32_t *d_pi, unsigned *d_gthr, hipStream_t st) {
 	if (nq <= 0)
 		return;
-	const int nclass = (kp <= 16 && g_pf_classes32) ? 32 : (int)kp; // 32 classes + k'-th smallest for the common small-k case
+	const int nclass = (kp <= 16 && tune().pf_classes32) ? 32 : (int)kp; // 32 classes + k'-th smallest for the common small-k case
 	const int stride = flat_mfma_slot_stride(nclass);
 	const long long gtotal = (long long)nq * stride;
 	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gthr, gtotal, stride,
@@ -563,7 +558,7 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 	a.gslot = d_gthr;
 	a.slot_stride = stride;
 	a.nclass = nclass;
-	a.sched = g_pf_sched;
+	a.sched = tune().pf_sched;
 	a.qf = (const float *)d_qf;
 	a.qn = d_qnorm;
 	a.yb = (const float *)d_rows_bf;
@@ -583,9 +578,9 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 	// class slots, the k'-th best of a ~16k-row sample for every query, so that the 512 workgroups of the main launch's
 	// FIRST round do not all start with no bound at all (their cold-start insertions are what the other three waves of
 	// a workgroup wait for at the tile barrier).  Its partial lists are overwritten by the main launch.
-	if (g_pf_seed > 0 && n >= (int64_t)64 * g_pf_seed && !g_pf_abl) {
+	if (tune().pf_seed > 0 && n >= (int64_t)64 * tune().pf_seed && !tune().pf_abl) {
 		MfmaArgs s = a;
-		const int64_t rows = std::max<int64_t>(PF_BN, (int64_t)g_pf_seed / 8 / PF_BN * PF_BN);
+		const int64_t rows = std::max<int64_t>(PF_BN, (int64_t)tune().pf_seed / 8 / PF_BN * PF_BN);
 		s.n = rows * 8;
 		s.split_rows = rows;
 		s.nsplit = 8;
@@ -599,9 +594,9 @@ void launch_prefilter(const FlatGeom &g, const FlatSearchPlan &p, int metric, co
 			launch_pf_inst<4>(metric, p.global_lists, s, ps, st);
 	}
 #ifdef MVS_PROFILING
-	if (g.dp == 128 && metric == METRIC_L2 && !p.global_lists && g_pf_abl) {
+	if (g.dp == 128 && metric == METRIC_L2 && !p.global_lists && tune().pf_abl) {
 #define MVS_PF_ABL(N)                                                                                                  \
-	if (g_pf_abl == N) {                                                                                               \
+	if (tune().pf_abl == N) {                                                                                               \
 		auto kern = flat_bf16x3_kernel<8, true, false, N>;                                                             \
 		ensure_dynamic_lds((const void *)kern, (size_t)(p.lds_bytes));                                                 \
 		hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds_bytes, st, a);                                         \

@@ -41,13 +41,11 @@ struct CollectArgs {
 int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512, 768, 1024; 0 = the coarse filter does not serve d
 int collect_wide_qblock(int dp1);
 int collect_wide_slots(int dp1);
-extern int g_ksplit_waves, g_ksplit_ncb, g_ksplit_opt, g_wide384_ncb, g_wide512_ksplit; // 8: the k-split kernel runs one 512-thread workgroup per CU
 size_t collect_wide_lds_bytes(int dp1);
 int collect_wide_block_rows(int dp1);
 void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,
                                int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out);
 // csrc/flat_collect_big.hip: 512 < d <= 1024, one wave per SIMD with all of k resident (512 registers per wave)
-extern int g_wide_big;
 int collect_big_qblock(int dp1);
 size_t collect_big_lds_bytes(int dp1);
 void launch_collect_big(int dp1, int metric, bool collect, const CollectArgs &a, int grid, hipStream_t st);

@@ -293,7 +293,6 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
 	}
 	e2[q] = r;
 }
-int g_cl_bound_mode = 1; // option cl_bound_mode: bf16 rounding term from the actual residual norms (1) or the worst case per element (0)
 void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st) {
 	if (nq <= 0)
@@ -301,10 +300,128 @@ void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, cons
 	const dim3 grid((unsigned)((nq + 255) / 256));
 	if (metric == METRIC_L2)
 		hipLaunchKernelGGL(collect_bounds_kernel<true>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, d_e2,
-		                   d_fail_cnt, d_fail_q, g_cl_bound_mode);
+		                   d_fail_cnt, d_fail_q, tune().cl_bound_mode);
 	else
 		hipLaunchKernelGGL(collect_bounds_kernel<false>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, d_e2,
-		                   d_fail_cnt, d_fail_q, g_cl_bound_mode);
+		                   d_fail_cnt, d_fail_q, tune().cl_bound_mode);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- round 5: everything a search does PER QUERY in front of the scans, in one launch (d <= 128 store) -------------------------
+// Rounds 2-4: collect_pack_queries_kernel (6.7 us at 10 000 queries), query_norms_kernel (21: one wave per 16 queries),
+// collect_bounds_kernel (18.6: one THREAD per query walking its row with a 512-byte stride), init_gslot_kernel (4.9), a memset of
+// the control block (5) -- five launches and their gaps, ~ 70 us of a 2.7 ms shard step.  Here a workgroup takes 64 queries:
+// their rows pass through LDS once (coalesced), thread t < 64 runs query t's four chains -- ||x||^2 as the k-ordered fma chain the
+// exact re-scoring needs bit for bit (csrc/util_kernels.hip query_norms_kernel), and the three sums of collect_bounds_kernel --
+// while all threads write the bf16 fragments (collect_pack_queries_kernel's layout), the neutral class slots and the zeroed
+// control words of the workgroup's queries.
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void collect_query_prep_kernel(const float *__restrict__ x, long long nq, int d,
+                                                                const float *__restrict__ mu, const unsigned *__restrict__ max_norm_bits,
+                                                                bf16x8 *__restrict__ qf, long long nq_frag /* queries the fragment array covers */,
+                                                                float *__restrict__ qn, float *__restrict__ e2, long long nq_e2 /* entries of e2 */,
+                                                                int *__restrict__ fail_cnt, int *__restrict__ fail_q, int bound_mode,
+                                                                unsigned *__restrict__ gslot, int stride, int *__restrict__ ctl_hdr,
+                                                                int *__restrict__ ctl_seg /* [2 nq] */) {
+	__shared__ float xs[64][129];
+	__shared__ float ms[128];
+	const int tid = threadIdx.x;
+	const long long q0 = (long long)blockIdx.x * 64;
+	for (int i = tid; i < 128; i += 256)
+		ms[i] = i < d ? mu[i] : 0.f;
+	for (int i = tid; i < 64 * d; i += 256) {
+		const int r = i / d, t = i - r * d;
+		xs[r][t] = q0 + r < nq ? x[(q0 + r) * d + t] : 0.f;
+	}
+	__syncthreads();
+	if (tid < 64) {
+		const long long q = q0 + tid;
+		if (q < nq) {
+			float xn = 0.f, xnc = 0.f, mun = 0.f, dq2 = 0.f;
+			const float alf = IS_L2 ? 2.0f : 1.0f;
+			for (int t = 0; t < d; ++t) {
+				const float v = xs[tid][t], m = ms[t], c = v - m;
+				xn = fmaf(v, v, xn);
+				xnc = fmaf(c, c, xnc);
+				mun = fmaf(m, m, mun);
+				const float a = alf * c; // exactly the operand the fragment loop below rounds
+				const float dl = a - (float)(__bf16)a;
+				dq2 = fmaf(dl, dl, dq2);
+			}
+			qn[q] = xn;
+			const float yn = __uint_as_float(max_norm_bits[0]), ync = __uint_as_float(max_norm_bits[8]);
+			const float dyc = __uint_as_float(max_norm_bits[12]);
+			const double u = 5.9604644775390625e-08, infl = 1.0001;
+			const double S = sqrt((double)xn * infl) * sqrt((double)yn * infl);
+			const double Sc = sqrt((double)xnc * infl) * sqrt((double)ync * infl);
+			const double MY = sqrt((double)mun * infl) * sqrt((double)yn * infl); // >= |<mu, y>|
+			const double al = IS_L2 ? 2.0 : 1.0;
+			const double bmax = IS_L2 ? (double)ync : MY; // >= |beta|
+			const double rnd_worst = al * (0.0078125 + 1.52587890625e-05) * Sc;
+			const double ndq = sqrt((double)dq2 * infl), ndy = sqrt((double)dyc * infl);
+			const double rnd_actual = ndq * sqrt((double)ync * infl) + (al * sqrt((double)xnc * infl) + ndq) * ndy;
+			const double rnd = bound_mode == 0 ? rnd_worst : (rnd_actual < rnd_worst || !(rnd_actual == rnd_actual) ? rnd_actual : rnd_worst);
+			const double es = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * al * Sc + bmax);
+			double E; // (collect_bounds_kernel's formula, term by term)
+			if (IS_L2)
+				E = es + 4.0 * u * ((double)xnc + ync) + (double)d * u * ync + 2.0 * d * u * S + 4.0 * u * ((double)xn + yn) +
+				    2.0 * ((double)d + 8.0) * u * ((double)xn + yn);
+			else
+				E = es + 4.0 * u * Sc + 2.0 * u * MY + (double)d * u * MY + (double)d * u * S;
+			float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (Sc + MY + (double)xnc + ync) + 1e-30);
+			const bool ok = isfinite(xn) && isfinite(yn) && isfinite(ync) && isfinite(mun) && isfinite(dq2) && isfinite(dyc) && isfinite(r) && r < 1e30f;
+			if (!ok) {
+				r = __uint_as_float(0x7fc00000u);
+				fail_q[atomicAdd(fail_cnt, 1)] = (int)q;
+			}
+			e2[q] = r;
+		} else if (q < nq_e2) {
+			e2[q] = __uint_as_float(0x7fc00000u); // (the slots behind the last query: nothing passes)
+		}
+	}
+	// fragments of the workgroup's four 16-query blocks: entry (qblk16, kb, lane) = queries qblk16 * 16 + (lane & 15), dims kb * 32 + 8 (lane >> 4) + e
+	const float alpha = IS_L2 ? 2.0f : 1.0f;
+	for (int i = tid; i < 4 * 4 * 64; i += 256) {
+		const int lane = i & 63, kb = (i >> 6) & 3, qb = i >> 8;
+		const int r = qb * 16 + (lane & 15);
+		if (q0 + qb * 16 >= nq_frag)
+			continue;
+		bf16x8 hi;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			const int kk = kb * 32 + 8 * (lane >> 4) + e;
+			hi[e] = (__bf16)((q0 + r < nq && kk < d) ? alpha * (xs[r][kk] - ms[kk]) : 0.f); // (alpha = 1 or 2: exact)
+		}
+		qf[((q0 / 16 + qb) * 4 + kb) * 64 + lane] = hi;
+	}
+	// class slots neutral ("larger s is better" keys), control words zero
+	const unsigned neutral = ~f2key(-FLT_MAX);
+	for (int i = tid; i < 64 * stride; i += 256) {
+		const long long q = q0 + i / stride;
+		if (q < nq)
+			gslot[q * stride + (i % stride)] = neutral;
+	}
+	if (tid < 64 && q0 + tid < nq) {
+		ctl_seg[q0 + tid] = 0;
+		ctl_seg[nq + q0 + tid] = 0;
+	}
+	if (blockIdx.x == 0 && tid < 64)
+		ctl_hdr[tid] = 0;
+}
+// d <= 128 store only (collect_store_dims(d) == 128); e2 has (nq rounded up to 256) entries, qf covers nq rounded up to CL_QBLOCK
+void launch_collect_query_prep(int metric, const float *d_x, int64_t nq, int d, const float *d_mu, const unsigned *d_max_norm_bits,
+                               void *d_qf, float *d_qn, float *d_e2, int *d_fail_cnt, int *d_fail_q, unsigned *d_gslot, int stride,
+                               int *d_ctl_hdr, int *d_ctl_seg, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	const long long nq_frag = (nq + CL_QBLOCK - 1) / CL_QBLOCK * CL_QBLOCK, nq_e2 = (nq + 255) / 256 * 256;
+	const dim3 grid((unsigned)(nq_frag / 64));
+	if (metric == METRIC_L2)
+		hipLaunchKernelGGL(collect_query_prep_kernel<true>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, (bf16x8 *)d_qf,
+		                   nq_frag, d_qn, d_e2, nq_e2, d_fail_cnt, d_fail_q, tune().cl_bound_mode, d_gslot, stride, d_ctl_hdr, d_ctl_seg);
+	else
+		hipLaunchKernelGGL(collect_query_prep_kernel<false>, grid, dim3(256), 0, st, d_x, (long long)nq, d, d_mu, d_max_norm_bits, (bf16x8 *)d_qf,
+		                   nq_frag, d_qn, d_e2, nq_e2, d_fail_cnt, d_fail_q, tune().cl_bound_mode, d_gslot, stride, d_ctl_hdr, d_ctl_seg);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -828,11 +945,6 @@ void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, 
 	MVS_HIP(hipGetLastError());
 }
 
-int g_cl_abl = 0;         // option cl_abl: profiling ablation of the L2 scan (results wrong)
-int g_cl_nsplit = 0;      // option cl_nsplit: row splits of the main scan (0 = planned)
-int g_cl_seed_split = 0;    // option cl_seed_split: row splits of the pre-pass (0 = 32: 4.70 vs 4.96 ms per 2048-query call)
-int g_cl_seed_rows = 16384; // option cl_seed_rows: rows of the bound-estimation pre-pass
-int g_cl_seed_regs = 1;     // option cl_seed_regs: d <= 128 pre-pass with class maxima in registers (0: through the scan kernel's rare path)
 
 int flat_mfma_slot_stride(int64_t k);
 __global__ void init_gslot_kernel(unsigned *g, long long total, int stride, int k, int is_l2);
@@ -898,13 +1010,12 @@ static void launch_collect_bound_table(const CollectArgs &a, int nqb, hipStream_
 size_t collect_bound_table_bytes(int64_t nq) {
 	return (size_t)((nq + CL_QBLOCK - 1) / CL_QBLOCK) * CL_QBLOCK * sizeof(float) + 1024;
 }
-int g_cl_tab = 1; // option cl_tab: pass bounds through the global table (1) or every wave derives its own (0, round 3)
 
 template <bool COLLECT>
 static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, int64_t row_first, int64_t row_end,
                                  int64_t nsplit_want, int64_t nq, hipStream_t st, int *grid_out, int *nsplit_out) {
 	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
-	if (!g_cl_tab)
+	if (!tune().cl_tab)
 		a.pbnd = nullptr;
 	launch_collect_bound_table(a, nqb, st);
 	const int64_t ntiles = (row_end - row_first + CL_SUB * CL_BN - 1) / (CL_SUB * CL_BN); // staged blocks
@@ -918,9 +1029,9 @@ static void launch_collect_range(const FlatGeom &g, int metric, CollectArgs a, i
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_lds_bytes(g);
 #ifdef MVS_PROFILING
-	if (metric == METRIC_L2 && COLLECT && g_cl_abl) {
+	if (metric == METRIC_L2 && COLLECT && tune().cl_abl) {
 #define MVS_CL_ABL(N)                                                                                                  \
-	if (g_cl_abl == N) {                                                                                               \
+	if (tune().cl_abl == N) {                                                                                               \
 		auto kern = flat_bf16_collect_kernel<8, true, true, N>;                                                        \
 		ensure_dynamic_lds((const void *)kern, lds);                                                                   \
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                                   \
@@ -1148,13 +1259,12 @@ static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t
 }
 
 // row classes per query: 16, or 32 for 16 < kk <= 32 (d <= 128 only: the wide instances keep 16)
-int g_cl_nc32_from = 17; // option cl_nc32_from
 // (headline shape: kk = 32 on 32 classes admits 1 269 candidates per query -- the bound is the WORST class best --, on 4 x 32 classes 512;
 // but the 128-class instance's derivation is four networks and its scan ran 23.7 vs 23.2 ms there, 23.4 vs 20.3 at kk = 25: from 33 on)
 int collect_slot_stride(int kk, int dp1) {
 	if (dp1 == 128 && kk > 28) // (with the derivation every 256 blocks: kk = 33 on 4 x 32 classes 21.0 ms, kk = 32 on 32 classes 23.3)
 		return 128;
-	return (kk > 16 || kk >= g_cl_nc32_from) ? 32 : 16;
+	return (kk > 16 || kk >= tune().cl_nc32_from) ? 32 : 16;
 }
 int collect_max_k(int d) {
 	const int dp1 = collect_store_dims(d);
@@ -1164,18 +1274,19 @@ int collect_max_k(int d) {
 	// kk <= 128 with four subsets of 32 classes, round 4)
 	if (dp1 == 128)
 		return 128;
-	return ((dp1 == 768 || dp1 == 1024) && !g_wide_big) ? 16 : 32;
+	return ((dp1 == 768 || dp1 == 1024) && !tune().wide_big) ? 16 : 32;
 }
 
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
                             unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st,
-                            bool cnt_zeroed) {
+                            bool cnt_zeroed, bool slots_ready) {
 	const int stride = collect_slot_stride(kk, collect_store_dims(g.d)); // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
-	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, stride,
-	                   0 /* larger s is better */);
+	if (!slots_ready) // (launch_collect_query_prep set them neutral)
+		hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, stride, stride,
+		                   0 /* larger s is better */);
 	if (!cnt_zeroed)
 		MVS_HIP(hipMemsetAsync(d_stream_cnt, 0, 16, st));
 	CollectArgs a;
@@ -1189,13 +1300,13 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	a.nclass = kk;
 	a.nq = (int)nq;
 	a.rowmask = d_rowmask;
-	a.opt = g_ksplit_opt;
+	a.opt = tune().ksplit_opt;
 	a.pbnd = d_pbnd;
 	// (a fixed cost per search: scaled down with the database so that a row shard of a multi-GPU index does not pay 16k rows)
 	const int dp1 = collect_store_dims(g.d);
-	if (dp1 == 128 && g_cl_seed_regs && stride == 16) { // (32 classes: 64 registers of maxima do not fit; the publish-only scan below)
+	if (dp1 == 128 && tune().cl_seed_regs && stride == 16) { // (32 classes: 64 registers of maxima do not fit; the publish-only scan below)
 		// d <= 128: class maxima in registers (flat_bf16_seed_kernel) -- cheap enough for 32 768 rows (an eighth of a small index)
-		const int64_t rows = std::min<int64_t>(g_cl_seed_rows > 16384 ? g_cl_seed_rows : 32768, n / 8) / 64 * 64;
+		const int64_t rows = std::min<int64_t>(tune().cl_seed_rows > 16384 ? tune().cl_seed_rows : 32768, n / 8) / 64 * 64;
 		if (rows >= 1024)
 			launch_collect_seed(metric, a, rows, nq, st);
 		return;
@@ -1203,12 +1314,12 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	// (lists beyond 16: the bound is the kk-th best of the class bests, so the sample must grow with kk or the main scan starts with
 	// a bound that admits whole percents of the rows -- kk = 65 on 2 048 seed rows of a 150 000-row index: > 4 096 candidates per query)
 	const int64_t kscale = std::max(1, kk / 16);
-	const int64_t seed = std::min<int64_t>(n, kscale * std::min<int64_t>(g_cl_seed_rows, std::max<int64_t>(2048, n / 256)));
+	const int64_t seed = std::min<int64_t>(n, kscale * std::min<int64_t>(tune().cl_seed_rows, std::max<int64_t>(2048, n / 256)));
 	if (seed > 0 && seed < n) {
 		if (dp1 > 128)
-			launch_collect_wide_range(dp1, metric, false, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
+			launch_collect_wide_range(dp1, metric, false, a, 0, seed, tune().cl_seed_split > 0 ? tune().cl_seed_split : 32, nq, st, nullptr, nullptr);
 		else
-			launch_collect_range<false>(g, metric, a, 0, seed, g_cl_seed_split > 0 ? g_cl_seed_split : 32, nq, st, nullptr, nullptr);
+			launch_collect_range<false>(g, metric, a, 0, seed, tune().cl_seed_split > 0 ? tune().cl_seed_split : 32, nq, st, nullptr, nullptr);
 	}
 }
 
@@ -1231,7 +1342,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.stream_cnt = d_stream_cnt;
 	a.stream_cap = stream_cap;
 	a.rowmask = d_rowmask;
-	a.opt = g_ksplit_opt;
+	a.opt = tune().ksplit_opt;
 	a.pbnd = d_pbnd;
 	const int dp1 = collect_store_dims(g.d);
 	const int qblock = dp1 > 128 ? collect_wide_qblock(dp1) : CL_QBLOCK;
@@ -1239,7 +1350,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	// two workgroups per CU: 512 slots; whole rounds, splits a multiple of 8 (XCD mapping), >= 7680 rows per split (8192 kept C2's
 	// N = 1 M at 120 splits = 4.7 rounds of workgroups; 128 splits of 7 812 rows fill five: 3.0-3.17 -> 2.80-2.86 ms per batch)
 	const int64_t slots = dp1 > 128 ? collect_wide_slots(dp1) : 512; // resident workgroups
-	int64_t nsplit = g_cl_nsplit;
+	int64_t nsplit = tune().cl_nsplit;
 	if (nsplit <= 0) {
 		const int64_t max_split = std::max<int64_t>(1, n / 7680);
 		nsplit = 1;

@@ -34,7 +34,6 @@ namespace mvs {
 
 typedef float f32x4b __attribute__((ext_vector_type(4)));
 
-int g_wide_big = 1; // option cl_wide_big: 512 < d <= 1024 on flat_bf16_big_kernel (1) or on the k-split kernel (0)
 
 // MODE (option cl_big_mode, A/B): bit 0 = the next tile's first fragments and beta are read under the last MFMAs of this one;
 // bit 1 = the LDS-DMA instructions of block u + 3 are spread one per two k-blocks (else issued together behind the barrier)
@@ -454,7 +453,6 @@ size_t collect_big_lds_bytes(int dp1) {
 	return (size_t)4 * (16 * part * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
 }
 
-int g_big_mode = 3; // option cl_big_mode (see MODE)
 template <int KBT, int NCB, int KSPL = 1>
 static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int grid, size_t lds, hipStream_t st) {
 #define MVS_BIG1(L2, CO, MD)                                                                                      \
@@ -465,11 +463,11 @@ static void launch_big_inst(int metric, bool collect, const CollectArgs &a, int 
 	}
 #define MVS_BIG(L2, CO)                                                                                           \
 	{                                                                                                             \
-		if (g_big_mode == 0)                                                                                      \
+		if (tune().big_mode == 0)                                                                                      \
 			MVS_BIG1(L2, CO, 0)                                                                                   \
-		else if (g_big_mode == 1)                                                                                 \
+		else if (tune().big_mode == 1)                                                                                 \
 			MVS_BIG1(L2, CO, 1)                                                                                   \
-		else if (g_big_mode == 2)                                                                                 \
+		else if (tune().big_mode == 2)                                                                                 \
 			MVS_BIG1(L2, CO, 2)                                                                                   \
 		else                                                                                                      \
 			MVS_BIG1(L2, CO, 3)                                                                                   \

@@ -794,17 +794,12 @@ int collect_store_dims(int d) {
 	// (d <= 16: the f32 kernel's contraction is 8-16 dims deep and wins against a 128-dim bf16 product)
 	return d <= 16 ? 0 : (d <= 128 ? 128 : (d <= 256 ? 256 : (d <= 384 ? 384 : (d <= 512 ? 512 : (d <= 768 ? 768 : (d <= 1024 ? 1024 : (d <= 1536 ? 1536 : 0)))))));
 }
-int g_ksplit_waves = 4; // waves per workgroup of flat_bf16_ksplit_kernel (option cl_ksplit_waves: 4 or 8)
-int g_wide512_ksplit = 0; // option cl_wide512_ksplit: the 512-dim store on the k-split kernel (8 k-blocks per wave, 3 column blocks)
-int g_wide384_ncb = 3;  // option cl_wide384_ncb: column blocks per wave of the 384-dim instance (2 | 3)
-int g_ksplit_opt = 0;   // option cl_ksplit_opt: bit 0 = s_setprio skew
-int g_ksplit_ncb = 3;   // column blocks per wave pair (option cl_ksplit_ncb: 2, or 3 with 8 waves)
 static int ksplit_ncb() {
-	return g_ksplit_ncb == 3 ? 3 : 2;
+	return tune().ksplit_ncb == 3 ? 3 : 2;
 }
 // flat_bf16_big_kernel (csrc/flat_collect_big.hip): the 768 / 1024-dim stores by option, the 1536-dim store always (its only kernel)
 static bool wide_on_big(int dp1) {
-	return dp1 == 1536 || (g_wide_big && (dp1 == 768 || dp1 == 1024));
+	return dp1 == 1536 || (tune().wide_big && (dp1 == 768 || dp1 == 1024));
 }
 static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
@@ -815,10 +810,10 @@ int collect_wide_qblock(int dp1) {
 	if (dp1 == 1024) // 8 waves, two column blocks per pair (2 x 16 k-blocks = 128 VGPRs of fragments)
 		return 128;
 	if (dp1 == 384)
-		return g_wide384_ncb == 3 ? 192 : 128;
-	if (dp1 == 512 && g_wide512_ksplit)
+		return tune().wide384_ncb == 3 ? 192 : 128;
+	if (dp1 == 512 && tune().wide512_ksplit)
 		return 96;
-	return dp1 == 768 ? (g_ksplit_waves / 2) * 16 * ksplit_ncb() : 128 * wide_qt(dp1);
+	return dp1 == 768 ? (tune().ksplit_waves / 2) * 16 * ksplit_ncb() : 128 * wide_qt(dp1);
 }
 static int wide_wsub(int dp1) {
 	const int KB = dp1 / 32;
@@ -828,19 +823,19 @@ static int wide_wsub(int dp1) {
 int collect_wide_slots(int dp1) {
 	if (wide_on_big(dp1))
 		return 256; // one workgroup per CU
-	return (dp1 == 1024 || (dp1 == 768 && g_ksplit_waves == 8)) ? 256 : 512;
+	return (dp1 == 1024 || (dp1 == 768 && tune().ksplit_waves == 8)) ? 256 : 512;
 }
 size_t collect_wide_lds_bytes(int dp1) {
 	if (wide_on_big(dp1))
 		return collect_big_lds_bytes(dp1);
 	if (dp1 == 1024) // flat_bf16_ksplit_kernel<8, 2, 2, 32>: two 32 KB stages, beta, queue, hand-over buffers, bounds, control
 		return (size_t)2 * (16 * 1024 * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + (size_t)2 * 8 * 64 * 16 + 128 * 4 + 64;
-	if (dp1 == 512 && g_wide512_ksplit) // flat_bf16_ksplit_kernel<4, 2, 3, 16>
+	if (dp1 == 512 && tune().wide512_ksplit) // flat_bf16_ksplit_kernel<4, 2, 3, 16>
 		return (size_t)2 * (16 * 512 * 2 + 64 * 4) + (size_t)(CL_QCAP / 2) * 8 + (size_t)2 * 4 * 2 * 64 * 16 + 96 * 4 + 64;
 	if (dp1 == 768) // flat_bf16_ksplit_kernel: two 24 KB stages, beta, queue, hand-over buffers, bounds, control
-		return (size_t)(g_ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) +
-		       (size_t)(g_ksplit_waves == 4 && ksplit_ncb() == 3 ? CL_QCAP / 2 : CL_QCAP) * 8 +
-		       (size_t)2 * g_ksplit_waves * (ksplit_ncb() - 1) * 64 * 16 + (size_t)collect_wide_qblock(768) * 4 + 64;
+		return (size_t)(tune().ksplit_waves == 8 ? 3 : 2) * (16 * 768 * 2 + 64 * 4) +
+		       (size_t)(tune().ksplit_waves == 4 && ksplit_ncb() == 3 ? CL_QCAP / 2 : CL_QCAP) * 8 +
+		       (size_t)2 * tune().ksplit_waves * (ksplit_ncb() - 1) * 64 * 16 + (size_t)collect_wide_qblock(768) * 4 + 64;
 	return (size_t)2 * wide_wsub(dp1) * 16 * dp1 * 2 + 2 * 64 * 4 + (size_t)CL_QCAP * 8 + (size_t)4 * wide_qt(dp1) * 16 * 4 * 4 + 64;
 }
 int collect_wide_block_rows(int dp1) {
@@ -883,7 +878,7 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	a.split_rows = (nblocks + nsplit - 1) / nsplit * BR;
 	a.nqb = nqb;
 	a.nsplit = (int)nsplit;
-	a.opt = g_ksplit_opt;
+	a.opt = tune().ksplit_opt;
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_wide_lds_bytes(dp1);
 	if (wide_on_big(dp1)) {
@@ -894,7 +889,7 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 		else
 			launch_wide_inst<8, 2, 2, false>(metric, a, grid, lds, st);
 	} else if (dp1 == 384) {
-		if (g_wide384_ncb == 3) {
+		if (tune().wide384_ncb == 3) {
 			if (collect)
 				launch_wide_inst<12, 1, 3, true>(metric, a, grid, lds, st);
 			else
@@ -905,7 +900,7 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 			else
 				launch_wide_inst<12, 1, 2, false>(metric, a, grid, lds, st);
 		}
-	} else if (dp1 == 512 && g_wide512_ksplit) {
+	} else if (dp1 == 512 && tune().wide512_ksplit) {
 #define MVS_KSP5(L2, CO)                                                                                        \
 	{                                                                                                           \
 		auto kern = flat_bf16_ksplit_kernel<L2, CO, 4, 2, 3, 16>;                                               \
@@ -930,11 +925,11 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	} else if (dp1 == 768) {
 #define MVS_KSP(L2, CO)                                                                                         \
 	{                                                                                                           \
-		if (g_ksplit_waves == 8 && ksplit_ncb() == 3) {                                                         \
+		if (tune().ksplit_waves == 8 && ksplit_ncb() == 3) {                                                         \
 			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 3, 24>;                                               \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                              \
-		} else if (g_ksplit_waves == 8) {                                                                       \
+		} else if (tune().ksplit_waves == 8) {                                                                       \
 			auto kern = flat_bf16_ksplit_kernel<L2, CO, 8, 3, 2, 24>;                                               \
 			ensure_dynamic_lds((const void *)kern, lds);                                                        \
 			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);                              \

@@ -379,9 +379,6 @@ int64_t flat_mfma_max_k(const FlatGeom &) {
 	return 256;
 }
 
-int g_mfma_nsplit = 0; // 0 = heuristic; >0 forces the split count (tuning / tests)
-int g_mfma_warm = 0;   // > 1: warm-up pre-pass over n / g_mfma_warm rows (experiment)
-int g_mfma_global_lists = 1; // 1: k-lists in global memory for every k > 12 (10-16 % faster than one workgroup per CU
                              // with LDS lists, measured k = 16...80); 0 / -1: only when the LDS cannot hold them (k > 88)
 
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k) {
@@ -403,8 +400,8 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 		max_split = split_cap;
 	int64_t nsplit = 1;
 	p.xcd_map = false;
-	if (g_mfma_nsplit > 0) {
-		nsplit = g_mfma_nsplit;
+	if (tune().mfma_nsplit > 0) {
+		nsplit = tune().mfma_nsplit;
 	} else if (max_split >= 8) {
 		double best_eff = -1;
 		for (int64_t s = 8; s <= max_split; s += 8) {
@@ -435,7 +432,7 @@ FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t 
 	p.nsplit = (int)nsplit;
 	p.grid = p.nqb * p.nsplit;
 	// two workgroups per CU need <= ~80 KB each: with the 64 KB of tile buffers that is k <= 12 for LDS-resident lists
-	p.global_lists = g_mfma_global_lists < 0 ? k > flat_mfma_max_k_lds(g) : (g_mfma_global_lists > 0 && k > 12);
+	p.global_lists = tune().mfma_global_lists < 0 ? k > flat_mfma_max_k_lds(g) : (tune().mfma_global_lists > 0 && k > 12);
 	if (k > flat_mfma_max_k_lds(g))
 		p.global_lists = true;
 	p.lds_bytes = mfma_lds_bytes(g, k, p.global_lists);
@@ -452,13 +449,12 @@ int flat_mfma_slot_stride(int64_t k) {
 	return (int)((k + 15) / 16 * 16);
 }
 
-int g_mfma_variant = 2; // 1 = register-staged generic kernel, 2 = LDS-DMA + A-ring resident kernel
 
 template <int KSTEPS>
 static void launch_resident_v2(int metric, const MfmaArgs &a, const FlatSearchPlan &p, hipStream_t st) {
 #ifdef MVS_PROFILING // wrong-result ablation instances exist only in the profiling library (make profiling -> libmi355faiss_prof.so)
-	if (KSTEPS == 64 && metric == METRIC_L2 && g_mfma_variant >= 100) { // profiling ablations
-		const int abl = g_mfma_variant - 100;
+	if (KSTEPS == 64 && metric == METRIC_L2 && tune().mfma_variant >= 100) { // profiling ablations
+		const int abl = tune().mfma_variant - 100;
 #define MVS_ABL(N)                                                                                                     \
 	if (abl == N) {                                                                                                    \
 		auto kern = flat_mfma_resident_kernel<64, true, N>;                                                            \
@@ -606,8 +602,8 @@ void launch_flat_mfma(const FlatGeom &g, const FlatSearchPlan &p_in, int metric,
 	};
 	// Optional threshold warm-up (option mfma_warm = divisor): a pre-pass of the same kernel over the first
 	// n/divisor rows leaves the shared class slots holding valid bounds before all workgroups start cold.
-	if (g_mfma_warm > 1 && db.n / g_mfma_warm >= 4096) {
-		const int64_t n_pre = db.n / g_mfma_warm;
+	if (tune().mfma_warm > 1 && db.n / tune().mfma_warm >= 4096) {
+		const int64_t n_pre = db.n / tune().mfma_warm;
 		FlatSearchPlan pp = plan_flat_mfma(g, nq, n_pre, k);
 		if (pp.nsplit <= p.nsplit) {
 			MfmaArgs ap = a;

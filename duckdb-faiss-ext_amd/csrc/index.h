@@ -86,6 +86,8 @@ public:
 	IndexBase(int kind, int d, int metric);
 	virtual ~IndexBase();
 	void use_device() const;
+	Tuning tune_;                                  // this index's tuning knobs (csrc/common.h); current for the thread after use_device()
+	bool set_tuning(const char *key, int64_t v); // the option keys that are tuning knobs (csrc/index.hip)
 
 	// faiss::Index virtuals the glue calls (src/faiss_extension.cpp:396,510,512,583,607,609,631)
 	virtual void train(int64_t n, const float *x);
@@ -206,6 +208,7 @@ public:
 	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, bool defer_count = false, int kf = 0);
 	int64_t cl_deferred_cap = 0;
 	bool cl_defer = true; // option cl_defer_count
+	bool cl_prep1 = true;        // option cl_prep1: one fused per-query preparation kernel in front of the d <= 128 coarse filter
 	double cl_est_per_query = 0; // candidates per query of the last search: sizes the next search's sort (collect_sort_estimate)
 	int cl_skip = 0, cl_skip_len = 0; // searches that bypass the coarse filter after it gave up on this index's data (doubling, <= 64)
 	void drop_bf16_rows();
@@ -325,8 +328,6 @@ void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, 
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
 int collect_store_dims(int d); // 128 / 256 / 384 / 512: row pitch of the bf16 store; 0: d is not served (csrc/flat_collect_wide.hip)
 int collect_wide_qblock(int dp1);
-extern int g_ksplit_waves, g_ksplit_ncb, g_ksplit_opt, g_wide384_ncb, g_wide512_ksplit;
-extern int g_wide_big, g_big_mode; // csrc/flat_collect_big.hip
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
                               const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
                               unsigned *d_max_norm_bits, hipStream_t st);
@@ -343,7 +344,10 @@ int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int
                               int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st, bool cnt_zeroed = false);
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st, bool cnt_zeroed = false, bool slots_ready = false);
+void launch_collect_query_prep(int metric, const float *d_x, int64_t nq, int d, const float *d_mu, const unsigned *d_max_norm_bits,
+                               void *d_qf, float *d_qn, float *d_e2, int *d_fail_cnt, int *d_fail_q, unsigned *d_gslot, int stride,
+                               int *d_ctl_hdr, int *d_ctl_seg, hipStream_t st);
 size_t collect_bound_table_bytes(int64_t nq);
 size_t collect_rowmask_bytes(int64_t n);
 void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, unsigned long long *d_mask, hipStream_t st);
@@ -373,12 +377,10 @@ bool coarse_select_supported(int64_t nlist, int64_t np);
 void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_cent, int sdp, int interleaved, int64_t nlist,
                           const float *d_qn, const float *d_cn, int64_t np, int is_l2, float *d_D, float *d_pd, int32_t *d_pi,
                           hipStream_t st, float *d_outD = nullptr, int64_t *d_outI = nullptr, int64_t label_offset = 0);
-extern int g_coarse_select, g_ivf_cl_refresh, g_ivf_cl_xcd, g_coarse_mfma, g_ivf_cl_lds_pad, g_coarse_abl, g_coarse_persistent, g_ivf_cl_abl;
 void launch_collect_group(unsigned long long *d_stream, unsigned long long *d_sorted, int64_t ncand, void *d_temp,
                           size_t temp_bytes, int64_t nq, int *d_seg, hipStream_t st, bool seg_zeroed = false);
 void launch_collect_select(int metric, const unsigned long long *d_keys, const int *d_seg, int64_t nq, int kk, float *d_pd1,
                            int32_t *d_pi1, hipStream_t st);
-extern int g_cl_nsplit, g_cl_seed_rows, g_cl_abl, g_cl_seed_split, g_cl_seed_regs, g_cl_nc32_from, g_cl_tab, g_cl_bound_mode;
 // csrc/ivf_collect.hip
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
                              float *d_beta, unsigned *d_list_max_bits /* [2 nlist] */, int64_t nlist, hipStream_t st);
@@ -393,17 +395,22 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
                              const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
                              float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse, int np,
                              float *d_ie2_pre, int64_t nlist);
+void launch_ivf_collect_pack2(int metric, const float *d_x, int d, int64_t nq, const int *d_slots0, const void *d_items0, void *d_xi0,
+                              float *d_igamma0, float *d_ie20, const void *d_items1, const int *d_nitems1, int max_items1,
+                              const int *d_qidx1, void *d_xi1, float *d_igamma1, float *d_ie21, const float *d_cent,
+                              const int *d_list_of_blk64, const unsigned *d_list_max_bits, int *d_qfail, int64_t nlist, unsigned *d_gslot,
+                              int nclass, int *d_ctl_hdr, int *d_flag_cnt, hipStream_t st);
 void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_items, const int *d_qidx, const void *d_xi,
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st, unsigned long long *d_bucket = nullptr, unsigned *d_bcount = nullptr, int bpitch = 0,
-                             unsigned long long *d_units = nullptr, unsigned *d_unit_cnt = nullptr);
-void launch_ivf_bucket_finish(int metric, unsigned long long *d_bucket, const unsigned *d_bcount, int bpitch, const unsigned long long *d_units,
-                              const unsigned *d_unit_cnt, unsigned *d_done, int64_t nq, const float *d_x, int d, const float *d_rows_csr,
-                              int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi, const int64_t *d_rowids,
-                              const int64_t *d_idmap, int k, float *d_D, int64_t *d_I, const int64_t *d_fin_rowids,
-                              const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats, hipStream_t st);
+                             hipStream_t st);
+void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int64_t ncand, const unsigned long long *d_cnt,
+                              unsigned long long *d_bucket, unsigned *d_bcount, int bpitch, int64_t nq, const float *d_x, int d,
+                              const float *d_rows_csr, int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi,
+                              const int64_t *d_rowids, const int64_t *d_idmap, int k, float *d_D, int64_t *d_I,
+                              const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
+                              int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st);
 size_t ivf_rowmask_bytes(int64_t nrows_mf);
 void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
                         void *d_mask, hipStream_t st);

@@ -149,6 +149,7 @@ void stream_wait(hipStream_t waiter, hipStream_t signal) {
 
 void IndexBase::use_device() const {
 	MVS_HIP(hipSetDevice(device)); // DuckDB calls from arbitrary worker threads
+	set_current_tuning(&tune_);    // ... and this index's tuning is what the launches of this call read (csrc/common.h Tuning)
 }
 void IndexBase::train(int64_t, const float *) {
 	// faiss::Index::train: "does nothing by default"
@@ -392,6 +393,19 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	const int dp1 = collect_store_dims(d);
 	const bool wide = dp1 > 128; // csrc/flat_collect_wide.hip: no one-wavefront-per-segment path
 	ws_qn.reserve((size_t)nq * sizeof(float));
+	const int64_t nq128 = (nq + 255) / 256 * 256;
+	ws_e2.reserve((size_t)nq128 * sizeof(float));
+	ws_gthr.reserve((size_t)nq * collect_slot_stride(kf, collect_store_dims(d)) * sizeof(unsigned) + 64);
+	ws_seg.reserve(256 + (size_t)2 * nq * sizeof(int));
+	// Round 5 (d <= 128 store): fragments, ||x||^2, bounds, neutral class slots and the zeroed control block in ONE launch
+	// (csrc/flat_collect.hip collect_query_prep_kernel) instead of four kernels and a memset
+	const bool prep1 = !wide && cl_prep1;
+	if (prep1) {
+		ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
+		launch_collect_query_prep(metric, d_x, nq, d, mu_h1, d_max_norm_bits, ws_pfq.p, (float *)ws_qn.p, (float *)ws_e2.p, fail_cnt, fail_q,
+		                          (unsigned *)ws_gthr.p, collect_slot_stride(kf, collect_store_dims(d)), (int *)ws_seg.p,
+		                          (int *)((char *)ws_seg.p + 256), st);
+	} else {
 	if (wide) {
 		ws_pfq.reserve(collect_qfrag_bytes_ex(dp1, collect_wide_qblock(dp1), nq));
 		launch_collect_pack_queries_ex(d, dp1, collect_wide_qblock(dp1), metric, d_x, nq, mu_h1, ws_pfq.p, st);
@@ -401,11 +415,9 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	}
 	if (metric == METRIC_L2) // (inner product re-scores without them)
 		launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
-	const int64_t nq128 = (nq + 255) / 256 * 256;
-	ws_e2.reserve((size_t)nq128 * sizeof(float));
 	// (the bounds kernel writes NaN into the slots behind the last query itself)
 	launch_collect_bounds(metric, d_x, nq, d, mu_h1, d_max_norm_bits, (float *)ws_e2.p, fail_cnt, fail_q, st);
-	ws_gthr.reserve((size_t)nq * collect_slot_stride(kf, collect_store_dims(d)) * sizeof(unsigned) + 64);
+	}
 	// candidate stream: 4096 entries per query to start with (option cl_stream_cap; at least 2^20), or what the last overflow
 	// showed this index's data to need (cl_cap_hint, up to 16384 per query: clustered rows with large norms admit thousands)
 	int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024)
@@ -413,8 +425,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 	ws_stream.reserve(256 + 2 * half);
 	// one zeroed control block {stream count | per-query segments} (round 4: one memset instead of three per search)
-	ws_seg.reserve(256 + (size_t)2 * nq * sizeof(int));
-	MVS_HIP(hipMemsetAsync(ws_seg.p, 0, 256 + (size_t)2 * nq * sizeof(int), st));
+	if (!prep1)
+		MVS_HIP(hipMemsetAsync(ws_seg.p, 0, 256 + (size_t)2 * nq * sizeof(int), st));
 	unsigned long long *cnt = (unsigned long long *)ws_seg.p;
 	int *const seg = (int *)((char *)ws_seg.p + 256);
 	unsigned long long *stream = (unsigned long long *)((char *)ws_stream.p + 256);
@@ -422,7 +434,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_pbnd.reserve(collect_bound_table_bytes(nq));
 	float *pbnd = wide ? nullptr : (float *)ws_pbnd.p; // (the d <= 128 scan only)
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, (const float *)ws_e2.p,
-	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st, true);
+	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st, true, prep1);
 	int grid = 0, nsplit = 0, lds = 0;
 	const bool few = !wide && nq <= 128 && collect_slot_stride(kf, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
@@ -1129,9 +1141,8 @@ void FlatIndex::tie_candidates(int64_t nf, const float *d_xf, const float *d_T, 
 	                      (float *)ws_qn.p, d_rows_out, st);
 }
 
-int g_coarse_select = 1; // option ivf_coarse_select: 0 = the IVF coarse quantiser runs on the k-list kernels
 bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st) {
-	if (!g_coarse_select || (metric != METRIC_L2 && metric != METRIC_IP) || nq < 20)
+	if (!tune().coarse_select || (metric != METRIC_L2 && metric != METRIC_IP) || nq < 20)
 		return false; // (fewer than 20 queries: FAISS's per-pair branch, other arithmetic for L2)
 	// inner product: one entry more than asked for, the merge flags boundary ties and resolve_ip_ties replays FAISS's heap
 	const bool ip = metric == METRIC_IP;
@@ -1887,6 +1898,17 @@ int mvs_index_tie_candidates_device(mvs_index *ix, int64_t nf, const float *d_xf
 	f->offset_rows(d_rows_out, nf * k, st); // shard rows -> global rows (label offset)
 	MVS_API_END
 }
+int mvs_index_ivf_tie_emit_device(mvs_index *ix, int64_t nf, const int *d_flag, const float *d_x, const float *d_T, int64_t k,
+                                  float *d_v_out, int64_t *d_id_out, int *d_rank_out, const mvs_search_params *params,
+                                  void *stream) {
+	MVS_API_BEGIN
+	std::lock_guard<std::mutex> g(ix->mu);
+	if (ix->impl->kind != MVS_KIND_IVFFLAT || is_sharded(ix->impl))
+		throw_faiss("mvs_index_ivf_tie_emit_device", __FILE__, "a plain single-device IVF index is required");
+	if (nf > 0)
+		ix->impl->tie_emit(d_flag, (int)nf, d_x, d_T, k, params, nullptr, d_v_out, d_id_out, d_rank_out, (hipStream_t)stream);
+	MVS_API_END
+}
 int mvs_synth_uniform_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, void *stream) {
 	MVS_API_BEGIN
 	launch_synth_uniform(d_out, n_rows, d, seed, row0, (hipStream_t)stream);
@@ -1924,7 +1946,88 @@ int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value) {
 } // extern "C"
 
 namespace mvs {
+// Per-index tuning (round 5).  Every knob below used to be a process-wide int set through whichever index
+// happened to receive set_option -- DuckDB searches different indexes from different threads, so one index's A/B switch changed
+// the path (and raced with the launches) of another.  Now an index owns its Tuning; use_device(), the first statement of every
+// entry point, makes it the calling thread's current one; the launch functions read tune().x.
+static thread_local const Tuning *t_tune = nullptr;
+const Tuning &tune() {
+	static const Tuning defaults;
+	return t_tune ? *t_tune : defaults;
+}
+void set_current_tuning(const Tuning *t) {
+	t_tune = t;
+}
+bool IndexBase::set_tuning(const char *key, int64_t v) {
+	struct Key {
+		const char *name;
+		int Tuning::*field;
+		int mode; // 0: the value; 1: v != 0; 2: 2 or 3; 3: 4 or 8; 4: low two bits; 5: profiling library only; 6: the value, >= 100 profiling only
+	};
+	static const Key keys[] = {
+	    {"cl_big_mode", &Tuning::big_mode, 4},         // flat_bf16_big_kernel pipeline A/B: bit 0 cross-tile fragment prefetch, bit 1 spread LDS-DMA
+	    {"cl_wide_big", &Tuning::wide_big, 1},         // 512 < d <= 1024 coarse filter: one wave per SIMD, all of k resident (1) or the k-split kernel (0)
+	    {"cl_wide512_ksplit", &Tuning::wide512_ksplit, 1}, // 384 < d <= 512 coarse filter on the k-split kernel (1) or on wide<16,1,2> (0)
+	    {"cl_wide384_ncb", &Tuning::wide384_ncb, 2},   // 256 < d <= 384 coarse filter: column blocks per wave (2 | 3)
+	    {"cl_ksplit_opt", &Tuning::ksplit_opt, 0},
+	    {"cl_ksplit_ncb", &Tuning::ksplit_ncb, 2},     // column blocks per wave pair of the k-split coarse filter (2 | 3)
+	    {"cl_ksplit_waves", &Tuning::ksplit_waves, 3}, // 512 < d <= 768: waves per workgroup of the k-split coarse filter (4 or 8)
+	    {"ivf_cl_refresh", &Tuning::ivf_cl_refresh, 0}, // IVF coarse filter: tiles (32 rows) between two refreshes of a wave's bounds (0 = 1,1,1,1,4.. 16)
+	    {"ivf_coarse_mfma", &Tuning::coarse_mfma, 0},  // IVF coarse distance matrix on the f32 matrix pipe (1) or the vector ALU (0); same bits
+	    {"ivf_coarse_persistent", &Tuning::coarse_persistent, 0}, // coarse distance matrix: persistent workgroups (1) or one per tile (0, default: faster)
+	    {"ivf_cl_lds_pad", &Tuning::ivf_cl_lds_pad, 0},
+	    {"ivf_cl_xcd", &Tuning::ivf_cl_xcd, 0},        // IVF coarse filter: items of one list on one XCD (1) or dealt round-robin over the XCDs (0)
+	    {"ivf_coarse_select", &Tuning::coarse_select, 1}, // IVF coarse quantiser: distance matrix + selection (1) or the k-list kernels (0)
+	    {"cl_abl", &Tuning::cl_abl, 5},                // wrong-result ablation knobs: profiling library only
+	    {"ivf_cl_abl", &Tuning::ivf_cl_abl, 5},
+	    {"coarse_abl", &Tuning::coarse_abl, 5},
+	    {"pf_abl", &Tuning::pf_abl, 5},
+	    {"cl_bound_mode", &Tuning::cl_bound_mode, 0},  // bf16 rounding term of the coarse filter's bound: actual residual norms (1) | worst case (0)
+	    {"cl_tab", &Tuning::cl_tab, 1},                // d <= 128 scan: pass bounds through the global table (1, default) or derived per wave (0: round 3)
+	    {"cl_nsplit", &Tuning::cl_nsplit, 0},          // coarse filter: row splits of the main scan (0 = planned)
+	    {"cl_nc32_from", &Tuning::cl_nc32_from, 0},    // 32 row classes from this kk on (default 17: only where 16 classes cannot serve)
+	    {"cl_seed_regs", &Tuning::cl_seed_regs, 0},    // d <= 128 pre-pass: class maxima in registers (1) or the scan kernel's rare path (0)
+	    {"cl_seed_split", &Tuning::cl_seed_split, 0},
+	    {"cl_seed_rows", &Tuning::cl_seed_rows, 0},    // coarse filter: rows of the bound-estimation pre-pass
+	    {"pf_sched", &Tuning::pf_sched, 0},
+	    {"pf_classes32", &Tuning::pf_classes32, 0},
+	    {"pf_seed", &Tuning::pf_seed, 0},              // rows of the prefilter's seeding pre-pass (0 = off)
+	    {"pf_nsplit", &Tuning::pf_nsplit, 0},
+	    {"mfma_global_lists", &Tuning::mfma_global_lists, 0},
+	    {"mfma_warm", &Tuning::mfma_warm, 0},
+	    {"mfma_nsplit", &Tuning::mfma_nsplit, 0},
+	    {"mfma_variant", &Tuning::mfma_variant, 6},    // A/B switch between kernel generations; >= 100: ablations, profiling library only
+	};
+	for (const Key &e : keys) {
+		if (strcmp(key, e.name))
+			continue;
+		int val = (int)v;
+		switch (e.mode) {
+		case 1: val = v != 0; break;
+		case 2: val = v == 2 ? 2 : 3; break;
+		case 3: val = v == 4 ? 4 : 8; break;
+		case 4: val = (int)(v & 3); break;
+		case 5:
+#ifndef MVS_PROFILING
+			return false;
+#endif
+			break;
+		case 6:
+#ifndef MVS_PROFILING
+			if (v >= 100)
+				return false;
+#endif
+			break;
+		default: break;
+		}
+		tune_.*(e.field) = val;
+		return true;
+	}
+	return false;
+}
 bool FlatIndex::set_option(const char *key, int64_t v) {
+	if (set_tuning(key, v))
+		return true;
 	if (!strcmp(key, "metric_arg_bits")) { // faiss::Index::metric_arg as IEEE-754 bits (the option channel carries integers)
 		const uint32_t b = (uint32_t)v;
 		memcpy(&metric_arg, &b, 4);
@@ -1938,58 +2041,6 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		prefilter_mode = (int)v;
 		return true;
 	}
-	if (!strcmp(key, "cl_big_mode")) { // flat_bf16_big_kernel pipeline A/B: bit 0 cross-tile fragment prefetch, bit 1 spread LDS-DMA
-		g_big_mode = (int)(v & 3);
-		return true;
-	}
-	if (!strcmp(key, "cl_wide_big")) { // 512 < d <= 1024 coarse filter: one wave per SIMD, all of k resident (1) or the k-split kernel (0)
-		g_wide_big = v != 0;
-		return true;
-	}
-	if (!strcmp(key, "cl_wide512_ksplit")) { // 384 < d <= 512 coarse filter on the k-split kernel (1) or on wide<16,1,2> (0)
-		g_wide512_ksplit = v != 0;
-		return true;
-	}
-	if (!strcmp(key, "cl_wide384_ncb")) { // 256 < d <= 384 coarse filter: column blocks per wave (2 | 3)
-		g_wide384_ncb = v == 2 ? 2 : 3;
-		return true;
-	}
-	if (!strcmp(key, "cl_ksplit_opt")) {
-		g_ksplit_opt = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "cl_ksplit_ncb")) { // column blocks per wave pair of the k-split coarse filter (2 | 3)
-		g_ksplit_ncb = v == 2 ? 2 : 3;
-		return true;
-	}
-	if (!strcmp(key, "cl_ksplit_waves")) { // 512 < d <= 768: waves per workgroup of the k-split coarse filter (4 or 8)
-		g_ksplit_waves = v == 4 ? 4 : 8;
-		return true;
-	}
-	if (!strcmp(key, "ivf_cl_refresh")) { // IVF coarse filter: tiles (32 rows) between two refreshes of a wave's bounds (0 = 1,1,1,1,4.. 16)
-		g_ivf_cl_refresh = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "ivf_coarse_mfma")) { // IVF coarse distance matrix on the f32 matrix pipe (1) or the vector ALU (0); same bits
-		g_coarse_mfma = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "ivf_coarse_persistent")) { // coarse distance matrix: persistent workgroups (1) or one per tile (0, default: faster)
-		g_coarse_persistent = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "ivf_cl_lds_pad")) {
-		g_ivf_cl_lds_pad = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "ivf_cl_xcd")) { // IVF coarse filter: items of one list on one XCD (1) or dealt round-robin over the XCDs (0)
-		g_ivf_cl_xcd = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "ivf_coarse_select")) { // IVF coarse quantiser: distance matrix + selection (1) or the k-list kernels (0)
-		g_coarse_select = v != 0;
-		return true;
-	}
 	if (!strcmp(key, "tie_from_candidates")) {
 		tie_from_candidates = v != 0;
 		return true;
@@ -1998,30 +2049,12 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		cl_k32 = v != 0;
 		return true;
 	}
+	if (!strcmp(key, "cl_prep1")) { // 0: round 4's separate query-preparation kernels (A/B)
+		cl_prep1 = v != 0;
+		return true;
+	}
 	if (!strcmp(key, "cl_small_path")) { // 0: small batches on flat_bf16_collect_kernel as well (A/B)
 		cl_small_path = v != 0;
-		return true;
-	}
-#ifdef MVS_PROFILING // wrong-result ablation knobs: profiling library only
-	if (!strcmp(key, "cl_abl")) {
-		g_cl_abl = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "ivf_cl_abl")) { // profiling only: results are wrong
-		g_ivf_cl_abl = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "coarse_abl")) { // profiling only: results are wrong
-		g_coarse_abl = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "pf_abl")) { // profiling only: results are wrong
-		g_pf_abl = (int)v;
-		return true;
-	}
-#endif
-	if (!strcmp(key, "cl_bound_mode")) { // bf16 rounding term of the coarse filter's bound: actual residual norms (1) | worst case (0)
-		g_cl_bound_mode = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "cl_est")) { // tests: pretend the previous search had v candidates per query (a sort sized too small is re-run)
@@ -2032,52 +2065,12 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 		cl_defer = v != 0;
 		return true;
 	}
-	if (!strcmp(key, "cl_tab")) { // d <= 128 scan: pass bounds through the global table (1, default) or derived per wave (0: round 3)
-		g_cl_tab = v != 0;
-		return true;
-	}
-	if (!strcmp(key, "cl_nsplit")) { // coarse filter: row splits of the main scan (0 = planned)
-		g_cl_nsplit = (int)v;
-		return true;
-	}
 	if (!strcmp(key, "cl_stream_cap")) { // coarse filter: candidate-stream entries per query (diagnostics: provoke the overflow paths)
 		cl_stream_cap_per_query = (int)v;
 		return true;
 	}
-	if (!strcmp(key, "cl_nc32_from")) { // 32 row classes from this kk on (default 17: only where 16 classes cannot serve)
-		g_cl_nc32_from = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "cl_seed_regs")) { // d <= 128 pre-pass: class maxima in registers (1) or the scan kernel's rare path (0)
-		g_cl_seed_regs = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "cl_seed_split")) {
-		g_cl_seed_split = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "cl_seed_rows")) { // coarse filter: rows of the bound-estimation pre-pass
-		g_cl_seed_rows = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "pf_sched")) {
-		g_pf_sched = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "pf_classes32")) {
-		g_pf_classes32 = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "pf_seed")) { // rows of the prefilter's seeding pre-pass (0 = off)
-		g_pf_seed = (int)v;
-		return true;
-	}
 	if (!strcmp(key, "pf_margin")) {
 		pf_margin = (int)std::min<int64_t>(16, std::max<int64_t>(1, v));
-		return true;
-	}
-	if (!strcmp(key, "pf_nsplit")) {
-		g_pf_nsplit = (int)v;
 		return true;
 	}
 	if (!strcmp(key, "raw_rows")) {
@@ -2090,26 +2083,6 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "force_direct")) {
 		force_direct = v != 0;
-		return true;
-	}
-	if (!strcmp(key, "mfma_global_lists")) {
-		g_mfma_global_lists = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "mfma_warm")) {
-		g_mfma_warm = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "mfma_nsplit")) {
-		g_mfma_nsplit = (int)v;
-		return true;
-	}
-	if (!strcmp(key, "mfma_variant")) { // A/B switch between kernel generations (process-wide); >= 100: ablations, profiling library only
-#ifndef MVS_PROFILING
-		if (v >= 100)
-			return false;
-#endif
-		g_mfma_variant = (int)v;
 		return true;
 	}
 	return false;

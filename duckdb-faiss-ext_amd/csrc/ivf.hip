@@ -785,6 +785,7 @@ public:
 		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
 		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
 		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		group_clean_p = nullptr; // (the counters are left as this grouping made them)
 		int *d_nitems = nullptr, *d_cnt = nullptr;
 		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, 20, 5, (const int64_t *)list_off_dev.p,
 		                 (const int64_t *)list_off_dev.p + 1, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p,
@@ -854,6 +855,7 @@ public:
 		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
 		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
 		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		group_clean_p = nullptr;
 		int *d_nitems = nullptr, *d_cnt = nullptr;
 		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
 		                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
@@ -909,6 +911,7 @@ public:
 			// round 5 (csrc/collect_bucket.h): candidates in per-query buckets, one kernel behind the scan -- nothing to estimate; a
 			// bucket that proved too small (the count is read at the search's one synchronisation) is grown and the pass repeated
 			cl_bpitch_try = 0;
+			cl_cap_try = 0;
 			for (int attempt = 0; attempt < 6; ++attempt) {
 				bool overflow = false;
 				const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, true, &overflow);
@@ -945,37 +948,47 @@ public:
 		// (round 4: the counters of BOTH groupings in one buffer, and one control block {stream count | fail count | per-query fail
 		// flags | per-query segments}: two memsets per search instead of seven)
 		const size_t group_ints = (ivf_group_ws_ints(nlist) + 63) & ~(size_t)63;
+		const bool bucket = cl_bucket && k <= 64;
+		// Round 5, "prep2": both groupings in three launches (csrc/ivf_scan.hip launch_ivf_group2), both packings in one
+		// (launch_ivf_collect_pack2, which also sets the class slots neutral and clears the control block's header), and NO memset:
+		// the grouping counters are zeroed by the scatter kernel that last needed them, the per-query control words by the select
+		// kernel that last read them -- a buffer is cleared by the host only when it was (re)allocated.
+		const bool prep2 = bucket && cl_prep2 && !cl_prepass_all && !cl_prepass_none && !cl_prepass_shared && cl_pack_nearest && !cl_pack_pairs;
 		ws_group.reserve(2 * group_ints * sizeof(int));
-		MVS_HIP(hipMemsetAsync(ws_group.p, 0, 2 * group_ints * sizeof(int), stream));
+		if (!prep2 || ws_group.p != group_clean_p || ws_group.cap != group_clean_cap)
+			MVS_HIP(hipMemsetAsync(ws_group.p, 0, 2 * group_ints * sizeof(int), stream));
+		group_clean_p = nullptr;
 		ws_xi.reserve(ivf_collect_xi_bytes(max_items));
 		ws_ig.reserve((size_t)max_items * 128 * sizeof(float));
 		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
 		if (cl_prepass_shared)
 			ws_ie2p.reserve((size_t)max_items * 128 * sizeof(float));
-		const bool bucket = cl_bucket && k <= 64;
 		// control block, zeroed by ONE memset: header {stream count @0 | fail count @64 | unit count @128 | bucket stats @192} |
 		// per-query fail flags | segments begin / end (bucket mode: hits / finished units per query) | (bucket mode) tie flags {count, queries}
 		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int) + (bucket ? ((size_t)nq + 64) * sizeof(int) : 0);
 		ws_qfail.reserve(ctl_bytes);
 		int *const ctl_qfail = (int *)((char *)ws_qfail.p + 256), *const ctl_seg = ctl_qfail + nq;
 		int *const ctl_flag = ctl_seg + 2 * nq;
-		unsigned *const ctl_units = (unsigned *)((char *)ws_qfail.p + 128);
 		unsigned long long *const ctl_stats = (unsigned long long *)((char *)ws_qfail.p + 192);
 		const int nclass = kf > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
 		ws_gslot.reserve((size_t)nq * nclass * sizeof(unsigned) + 64);
-		launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
-		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, ctl_bytes, stream));
+		if (!prep2)
+			launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
+		if (!prep2 || ws_qfail.p != ctl_clean_p || ws_qfail.cap != ctl_clean_cap || ctl_clean_nq != nq)
+			MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, ctl_bytes, stream));
+		ctl_clean_p = nullptr;
 		// candidate stream: 4096 entries per query to start with, or what the last overflow showed this index's data to need
 		int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024) // (option ivf_cl_stream_cap: tests)
 		                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
+		if (bucket && cl_cap_try > 0)
+			cap_entries = cl_cap_try; // (the repeated pass of a search whose stream overflowed)
 		// bucket mode: cl_bpitch entries of 8 bytes per query (a multiple of 64; grown when a query's count exceeded it) + the unit list
 		const int bpitch = cl_bpitch_try > 0 ? cl_bpitch_try
 		                   : (int)(cl_stream_cap_per_query > 0 ? std::max<int64_t>(64, (cl_stream_cap_per_query + 63) / 64 * 64) : cl_bpitch);
 		size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
-		if (bucket) {
-			half = ((size_t)nq * bpitch * 8 + 255) & ~(size_t)255;
-			ws_stream.reserve(256 + half + ((size_t)nq * (bpitch / 64) + 64) * 8);
-		} else
+		if (bucket) // the stream, then the buckets: [nq][bpitch] keys of 8 bytes
+			ws_stream.reserve(256 + half + (size_t)nq * bpitch * 8);
+		else
 		ws_stream.reserve(256 + 2 * half);
 		unsigned long long *cnt = (unsigned long long *)ws_qfail.p; // (zeroed with the control block above)
 		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
@@ -1002,7 +1015,35 @@ public:
 		// pass's items with every slot switched off whose list is not its query's nearest (E = NaN): the same evidence as the
 		// nearest-list pre-pass without its own grouping and packing)
 		const bool shared = cl_prepass_shared && !cl_prepass_all && !cl_prepass_none;
-		for (int phase = cl_prepass_none ? 1 : 0; phase < 2; ++phase) {
+		if (prep2) {
+			const int max_items0 = ivf_group_max_items(nq, nlist, G);
+			ws_items0.reserve((size_t)max_items0 * 16);
+			ws_qidx0.reserve((size_t)nq * sizeof(int32_t));
+			int *d_nitems0 = nullptr;
+			ws_xi0.reserve(ivf_collect_xi_bytes(max_items0));
+			ws_ig0.reserve((size_t)max_items0 * 128 * sizeof(float));
+			ws_ie20.reserve((size_t)max_items0 * 128 * sizeof(float));
+			// (tried and dropped, profiles/r5_c3_ab.txt: the scan waves building their fragments / gamma / 2E themselves from the f32
+			// queries instead of reading packed ones -- no packing kernel, 0.5 GB less traffic, but every segment wave of an item
+			// repeats the item's conversion behind eight dependent load round trips: scan 0.77 -> 0.98 ms, step 1.58 -> 1.70)
+			launch_ivf_group2((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
+			                  (int *)ws_group.p, (int *)ws_group.p + group_ints, ws_items0.p, (int *)ws_qidx0.p, (int *)ws_slots.p, ws_items.p,
+			                  (int *)ws_qidx.p, nullptr, &d_nitems0, &d_nitems, stream);
+			group_clean_p = ws_group.p, group_clean_cap = ws_group.cap; // (zero again behind the scatter kernel)
+			launch_ivf_collect_pack2(metric, d_x, d, nq, (const int *)ws_slots.p, ws_items0.p, ws_xi0.p, (float *)ws_ig0.p, (float *)ws_ie20.p,
+			                         ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (float *)ws_ig.p, (float *)ws_ie2.p,
+			                         (const float *)cent_dev.p, (const int *)list_of_blk.p, (const unsigned *)list_max.p, ctl_qfail, nlist,
+			                         (unsigned *)ws_gslot.p, nclass, (int *)ws_qfail.p, ctl_flag, stream);
+			launch_ivf_collect_scan(ws_items0.p, d_nitems0, max_items0, (const int *)ws_qidx0.p, ws_xi0.p, (const float *)ws_ig0.p,
+			                        (const float *)ws_ie20.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, 256, 1, 0, rowmask, stream);
+			begin_kernel_timing(stream);
+			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
+			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, seg_rows, nseg, 1, rowmask, stream);
+			end_kernel_timing(stream);
+		}
+		for (int phase = prep2 ? 2 : (cl_prepass_none ? 1 : 0); phase < 2; ++phase) {
 			const int64_t *keys = (const int64_t *)ws_cI.p;
 			// the nearest-list pre-pass: column 0 of the labels as a batch with one probe per query (key stride = nprobe)
 			const bool nearest_only = phase == 0 && !cl_prepass_all && !shared;
@@ -1027,37 +1068,39 @@ public:
 			                        (const float *)(phase == 0 && shared ? ws_ie2p.p : ws_ie2.p), (const unsigned short *)codes_bfr.p,
 			                        (const float *)beta_mf.p,
 			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
-			                        phase == 0 ? 1 : nseg, phase, rowmask, stream, bucket ? strm : nullptr, (unsigned *)ctl_seg, bpitch,
-			                        sorted /* bucket mode: the unit list */, ctl_units);
+			                        phase == 0 ? 1 : nseg, phase, rowmask, stream);
 			if (phase == 1)
 				end_kernel_timing(stream);
 		}
-		// queries without a finite bound -> fail list
+		// queries without a finite bound -> fail list (bucket mode: compacted by the select kernel)
 		ws_fail.reserve(64 + (size_t)nq * sizeof(int));
 		int *fail_cnt = (int *)((char *)ws_qfail.p + 64), *fail_q = (int *)ws_fail.p + 16; // (the count: in the zeroed control block)
-		hipLaunchKernelGGL(ivf_compact_flags_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
-		                   (const int *)ctl_qfail, (int)nq, fail_cnt, fail_q);
+		if (!bucket)
+			hipLaunchKernelGGL(ivf_compact_flags_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
+			                   (const int *)ctl_qfail, (int)nq, fail_cnt, fail_q);
 		if (!h_fail)
-			MVS_HIP(hipHostMalloc((void **)&h_fail, 64, hipHostMallocDefault));
+			MVS_HIP(hipHostMalloc((void **)&h_fail, 512, hipHostMallocDefault)); // [0, 64): round 4's words; [256, 512): the control block's header
 		fin_done = false;
 		if (bucket) {
 			// ONE kernel: exact values, selection, and (inside the exact-tie wrapper) FAISS's print order + boundary flags; the tie pass
 			// for the flagged queries is enqueued behind it, BEFORE the search's one synchronisation (rounds 3-4 launched the finish
 			// kernel and the tie pass after it: two launch latencies with the GPU idle)
 			const bool fin = raw_pos && fin_D != nullptr && kk == fin_k + 1;
-			launch_ivf_bucket_finish(metric, strm, (const unsigned *)ctl_seg, bpitch, sorted, ctl_units, (unsigned *)(ctl_seg + nq), nq, d_x, d,
+			launch_ivf_bucket_finish(metric, strm, cap_entries, cnt, sorted /* the buckets */, (unsigned *)ctl_seg, bpitch, nq, d_x, d,
 			                         (const float *)codes.p, dp, (const int *)perm_mf.p, kk, d_D, d_I, raw_pos ? nullptr : (const int64_t *)rowids.p,
 			                         (d_idmap && !raw_ids && !raw_pos) ? d_idmap : nullptr, fin ? (int)fin_k : 0, fin ? fin_D : nullptr,
 			                         fin ? fin_I : nullptr, (const int64_t *)rowids.p, fin ? fin_idmap : nullptr, fin ? ctl_flag : nullptr, ctl_stats,
-			                         stream);
+			                         ctl_qfail, fail_cnt, fail_q, prep2, stream);
+			if (prep2)
+				ctl_clean_p = ws_qfail.p, ctl_clean_cap = ws_qfail.cap, ctl_clean_nq = nq;
 			if (fin) {
 				SelectorDev tsel = selector.upload(params, stream);
 				launch_ivf_tie_pass(metric, ctl_flag, nq, d_x, d, d_D, (int)kk, (int)fin_k, (const int64_t *)ws_cI.p, (int)np,
 				                    (const int64_t *)list_off_dev.p, (const float *)codes.p, dp, (const int64_t *)rowids.p, tsel, d_idmap,
 				                    fin_idmap, fin_D, fin_I, stream);
 			}
-			MVS_HIP(hipMemcpyAsync(h_fail + 4, ctl_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-			MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+			// (ONE copy of the control block's 256-byte header: stream count @0, fail count @64, bucket statistics @192)
+			MVS_HIP(hipMemcpyAsync(h_fail + 64, ws_qfail.p, 256, hipMemcpyDeviceToHost, stream));
 			snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel");
 			kinfo.grid = max_items * nseg;
 			kinfo.block = 64;
@@ -1065,8 +1108,20 @@ public:
 			kinfo.bytes = (double)nrows_mf * 256.0;               // every list's bf16 rows once (each list is probed by >= 1 item)
 			kinfo.flops = (double)nq * np * ((double)nsorted / nlist) * d * 2.0; // (average list length)
 			MVS_HIP(hipStreamSynchronize(stream)); // the one host round trip of the search
-			unsigned long long st2[2];
-			memcpy(st2, h_fail + 4, sizeof st2);
+			unsigned long long st2[2], nstream = 0;
+			memcpy(st2, (const char *)(h_fail + 64) + 192, sizeof st2);
+			memcpy(&nstream, h_fail + 64, sizeof nstream);
+			h_fail[0] = h_fail[64 + 16]; // (the fail count, where the code below reads it)
+			if ((int64_t)nstream > cap_entries) { // the STREAM overflowed (duplicate-heavy lists): grown once per size, as in round 3
+				++cl_overflows;
+				if ((int64_t)(nstream + nstream / 8) > nq * (int64_t)16384)
+					return false;
+				if (cl_stream_cap_per_query <= 0)
+					cl_cap_hint = std::max<int64_t>(cl_cap_hint, ((int64_t)(nstream + nstream / 8) + nq - 1) / nq);
+				cl_cap_try = (int64_t)(nstream + nstream / 8);
+				*overflow = true;
+				return false;
+			}
 			if ((int64_t)st2[1] > bpitch) { // some query's bucket was too small: its result is incomplete
 				++cl_overflows;
 				const int64_t want = ((int64_t)st2[1] + (int64_t)st2[1] / 4 + 63) / 64 * 64;
@@ -1079,8 +1134,8 @@ public:
 				return false;
 			}
 			cl_queries_total += nq;
-			cl_candidates_total += (int64_t)st2[0];
-			cl_est_per_query = (double)st2[0] / (double)std::max<int64_t>(nq, 1) + 1e-6;
+			cl_candidates_total += (int64_t)nstream;
+			cl_est_per_query = (double)nstream / (double)std::max<int64_t>(nq, 1) + 1e-6;
 			fin_done = fin;
 		}
 		unsigned long long ncand_u = 0;
@@ -1224,6 +1279,7 @@ public:
 		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
 		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
 		ws_group.reserve(ivf_group_ws_ints(nlist) * sizeof(int));
+		group_clean_p = nullptr;
 		int *d_nitems = nullptr, *d_cnt = nullptr;
 		launch_ivf_group((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p,
 		                 (const int64_t *)le_dev.p, (int *)ws_group.p, ws_items.p, (int *)ws_qidx.p, (int *)ws_slots.p,
@@ -1622,6 +1678,10 @@ public:
 			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_prep2")) {
+			cl_prep2 = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_bucket")) {
 			cl_bucket = v != 0;
 			return true;
@@ -1634,7 +1694,10 @@ public:
 			use_fast_scan = v != 0;
 			return true;
 		}
-		return quantizer->set_option(key, v);
+		// tuning knobs (csrc/common.h Tuning): this index's own copy AND the quantizer's -- their launches read whichever index
+		// entered last on the calling thread, and both must say the same
+		const bool mine = set_tuning(key, v);
+		return quantizer->set_option(key, v) || mine;
 	}
 	bool use_fast_scan = true;
 	bool cl_prepass_all = false; // option ivf_cl_prepass (n > 0 measured no faster than the nearest-list pre-pass: 2.83 / 2.88 / 2.93 vs 2.81 ms at C3)
@@ -1692,9 +1755,15 @@ private:
 	bool cl_pack_nearest = true; // option ivf_cl_pack_nearest
 	bool cl_pack_pairs = false;  // option ivf_cl_pack_pairs (the main pass pair by pair: measured slower, 1.64-1.68 vs 1.59-1.61 ms at C3)
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
-	bool cl_bucket = false;      // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
+	bool cl_bucket = true;       // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
 	int cl_bpitch = 1024;        // bucket entries per query (grown on demand up to 16 384)
+	bool cl_prep2 = true;        // option ivf_cl_prep2: fused grouping / packing / clearing in front of the scans (0 = round 4's launches)
+	void *group_clean_p = nullptr, *ctl_clean_p = nullptr; // the buffers known to be left zeroed by the previous search's kernels
+	size_t group_clean_cap = 0, ctl_clean_cap = 0;
+	int64_t ctl_clean_nq = 0;
+	DevBuf ws_items0, ws_qidx0, ws_xi0, ws_ig0, ws_ie20; // the nearest-list pre-pass's own work items (prep2)
 	int cl_bpitch_try = 0;       // ... of the repeated pass of the search in progress
+	int64_t cl_cap_try = 0;      // stream entries of the repeated pass of a search whose stream overflowed
 	// the exact-tie wrapper's final outputs, handed to the bucket path (which sets fin_done when it printed them itself)
 	float *fin_D = nullptr;
 	int64_t *fin_I = nullptr;

@@ -27,10 +27,6 @@
 #include <cstring>
 
 namespace mvs {
-int g_ivf_cl_abl = 0;     // (profiling library only: 1 = the scan without its rare path -- results wrong)
-int g_ivf_cl_lds_pad = 0; // (experiment: unused dynamic LDS per workgroup = fewer wavefronts per CU)
-int g_ivf_cl_xcd = 1; // option ivf_cl_xcd: items of one list on one XCD (1), their segments next to each other too (2), or dealt round-robin (0, round 3)
-extern int g_cl_bound_mode; // csrc/flat_collect.hip: bf16 rounding term of the bounds from the actual residual norms (1) | worst case (0)
 
 typedef __bf16 bf16x8i __attribute__((ext_vector_type(8)));
 typedef float f32x4i __attribute__((ext_vector_type(4)));
@@ -41,7 +37,6 @@ typedef __attribute__((address_space(1))) const float glb_f32i;
 constexpr int IC_BN = 32;    // rows per tile
 constexpr int IC_QCAP = 160; // hit queue of a work item: 8 bytes {value, row} + 1 byte {slot} per entry (20 384 bytes of LDS per wavefront = EIGHT per CU)
 
-int g_ivf_cl_refresh = 16; // option ivf_cl_refresh (see IvfCollectArgs::refresh)
 struct IvfCollectArgs {
 	const int4 *items;         // {row_begin (multiple of 64, padded row space), row_end, qoff, nq_item <= 128}
 	const int *nitems_dev;     // device-side item count; the grid is an upper bound
@@ -64,14 +59,6 @@ struct IvfCollectArgs {
 	int nseg;    // segments per item (xcd_map >= 2 decodes the segment from blockIdx.x)
 	int gx8;     // workgroups of one segment round (a multiple of 8)
 	int xcd_map; // 2: as 1, and the segments of an item are consecutive workgroups of its XCD; 1: XCD j (= blockIdx.x & 7) takes the contiguous item range [j n/8, (j+1) n/8) (option ivf_cl_xcd)
-	// round 5, bucket mode (bucket != nullptr): a candidate goes straight into ITS QUERY's bucket -- entry bcount[q]++ of
-	// bucket[q][bpitch], the padded row alone -- instead of the global stream: nothing has to be sorted by query afterwards
-	// (ivf_bucket_finish_kernel re-scores and selects bucket by bucket).  Entries past bpitch are only counted.
-	unsigned long long *bucket; // [nq][bpitch] entries of 8 bytes (the scan writes the low word; the finish kernel puts the exact key there)
-	unsigned *bcount;           // [nq] hits of the query so far
-	int bpitch;
-	unsigned long long *units;  // work list of the finish kernel: (query << 16 | group of 64 entries), appended by the lane that opens the group
-	unsigned *unit_cnt;
 };
 
 __device__ __forceinline__ unsigned ic_skey(float s) { // "larger s is better" as a smaller-is-better key
@@ -181,18 +168,18 @@ __device__ __forceinline__ float ivf_slot_e2(float xn, float cn, float dq2, floa
 	return __uint_as_float(0x7fc00000u);
 }
 template <bool IS_L2>
-__global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__restrict__ x, int d, const int4 *__restrict__ items,
-                                                             const int *__restrict__ nitems_dev, const int *__restrict__ qidx,
-                                                             const float *__restrict__ cent,
-                                                             const int *__restrict__ list_of_blk64,
-                                                             const unsigned *__restrict__ list_max_bits,
-                                                             bf16x8i *__restrict__ xi, float *__restrict__ igamma,
-                                                             float *__restrict__ ie2, int *__restrict__ qfail,
-                                                             const long long *__restrict__ coarse, int np, float *__restrict__ ie2_pre,
-                                                             int nlist, int bound_mode) {
+__device__ __forceinline__ void ivf_collect_pack_body(unsigned bid, const float *__restrict__ x, int d, const int4 *__restrict__ items,
+                                                      const int *__restrict__ nitems_dev, const int *__restrict__ qidx,
+                                                      const float *__restrict__ cent,
+                                                      const int *__restrict__ list_of_blk64,
+                                                      const unsigned *__restrict__ list_max_bits,
+                                                      bf16x8i *__restrict__ xi, float *__restrict__ igamma,
+                                                      float *__restrict__ ie2, int *__restrict__ qfail,
+                                                      const long long *__restrict__ coarse, int np, float *__restrict__ ie2_pre,
+                                                      int nlist, int bound_mode) {
 	// (round 4: one workgroup per HALF item -- slots 64 h .. 64 h + 63 -- with half the LDS: four workgroups per CU instead of two,
 	// and an item of <= 64 queries costs one workgroup's worth of work; the kernel waits on memory more than it computes)
-	const int item = (int)(blockIdx.x >> 1), s0 = 64 * (int)(blockIdx.x & 1u);
+	const int item = (int)(bid >> 1), s0 = 64 * (int)(bid & 1u);
 	if (item >= *nitems_dev)
 		return;
 	const int4 it = items[item];
@@ -290,20 +277,33 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__re
 		}
 	}
 }
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void ivf_collect_pack_kernel(const float *__restrict__ x, int d, const int4 *__restrict__ items,
+                                                             const int *__restrict__ nitems_dev, const int *__restrict__ qidx,
+                                                             const float *__restrict__ cent,
+                                                             const int *__restrict__ list_of_blk64,
+                                                             const unsigned *__restrict__ list_max_bits,
+                                                             bf16x8i *__restrict__ xi, float *__restrict__ igamma,
+                                                             float *__restrict__ ie2, int *__restrict__ qfail,
+                                                             const long long *__restrict__ coarse, int np, float *__restrict__ ie2_pre,
+                                                             int nlist, int bound_mode) {
+	ivf_collect_pack_body<IS_L2>(blockIdx.x, x, d, items, nitems_dev, qidx, cent, list_of_blk64, list_max_bits, xi, igamma, ie2, qfail, coarse,
+	                             np, ie2_pre, nlist, bound_mode);
+}
 // The nearest-list pre-pass has ONE pair per query, spread over ~ nlist items of a few slots each: the item-wise kernel above
 // then spends a workgroup, and four dependent global round trips, on two or three queries (70 us at C3, as long as the main
 // pass's packing of 32 times the pairs).  Here one wave per QUERY: slot code (ivf_group_scatter_*: item << 7 | slot) -> item ->
 // list -> centroid; lanes 0..15 hold the sixteen 8-element pieces of the slot's fragment column, the four sums are reduced over
 // them.  Slots of an item that no query owns are not written: the scan gives them a NaN bound whatever is stored (own_q < 0).
 template <bool IS_L2>
-__global__ __launch_bounds__(256) void ivf_collect_pack_pairs_kernel(const float *__restrict__ x, int d, long long npairs, int np,
-                                                                   const int *__restrict__ slots, const int4 *__restrict__ items,
-                                                                   const float *__restrict__ cent, const int *__restrict__ list_of_blk64,
-                                                                   const unsigned *__restrict__ list_max_bits, bf16x8i *__restrict__ xi,
-                                                                   float *__restrict__ igamma, float *__restrict__ ie2,
-                                                                   int *__restrict__ qfail, int nlist, int bound_mode) {
+__device__ __forceinline__ void ivf_collect_pack_pairs_body(unsigned bid, const float *__restrict__ x, int d, long long npairs, int np,
+                                                            const int *__restrict__ slots, const int4 *__restrict__ items,
+                                                            const float *__restrict__ cent, const int *__restrict__ list_of_blk64,
+                                                            const unsigned *__restrict__ list_max_bits, bf16x8i *__restrict__ xi,
+                                                            float *__restrict__ igamma, float *__restrict__ ie2,
+                                                            int *__restrict__ qfail, int nlist, int bound_mode) {
 	// sixteen lanes per (query, list) pair -- the sixteen 8-element pieces of the slot's fragment column --, sixteen pairs per workgroup
-	const long long p = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+	const long long p = (long long)bid * 16 + (threadIdx.x >> 4);
 	const int l16 = threadIdx.x & 15;
 	const int code = p < npairs ? slots[p] : -1;
 	float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f;
@@ -347,6 +347,92 @@ __global__ __launch_bounds__(256) void ivf_collect_pack_pairs_kernel(const float
 		ie2[(size_t)item * 128 + slot] = e2;
 	}
 }
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void ivf_collect_pack_pairs_kernel(const float *__restrict__ x, int d, long long npairs, int np,
+                                                                   const int *__restrict__ slots, const int4 *__restrict__ items,
+                                                                   const float *__restrict__ cent, const int *__restrict__ list_of_blk64,
+                                                                   const unsigned *__restrict__ list_max_bits, bf16x8i *__restrict__ xi,
+                                                                   float *__restrict__ igamma, float *__restrict__ ie2,
+                                                                   int *__restrict__ qfail, int nlist, int bound_mode) {
+	ivf_collect_pack_pairs_body<IS_L2>(blockIdx.x, x, d, npairs, np, slots, items, cent, list_of_blk64, list_max_bits, xi, igamma, ie2, qfail,
+	                                   nlist, bound_mode);
+}
+// Round 5: the packing of BOTH passes in one launch -- the first nb0 workgroups pack the nearest-list pre-pass pair by pair (set 0:
+// its own items / fragments / bounds), the others the main pass item by item (set 1).
+struct IvfPack2Args {
+	const float *x;
+	int d, nlist, bound_mode;
+	unsigned nb0;
+	long long nq;
+	const float *cent;
+	const int *list_of_blk64;
+	const unsigned *list_max_bits;
+	int *qfail;
+	// set 0 (pairs)
+	const int *slots0;
+	const int4 *items0;
+	bf16x8i *xi0;
+	float *igamma0, *ie20;
+	// set 1 (items)
+	const int4 *items1;
+	const int *nitems1;
+	const int *qidx1;
+	bf16x8i *xi1;
+	float *igamma1, *ie21;
+	unsigned *gslot; // [nq][nclass] class slots -> neutral
+	int nclass;
+	int *ctl_hdr;    // the control block's 64 header ints -> 0
+	int *flag_cnt;   // -> 0
+};
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void ivf_collect_pack2_kernel(const IvfPack2Args a) {
+	if (blockIdx.x < a.nb0) {
+		// (what launch_init_slots and the control block's memset did in launches of their own)
+		const long long q = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+		const int l16 = threadIdx.x & 15;
+		if (q < a.nq)
+			for (int c = l16; c < a.nclass; c += 16)
+				a.gslot[q * a.nclass + c] = ic_skey(-FLT_MAX);
+		if (blockIdx.x == 0 && threadIdx.x < 64) {
+			a.ctl_hdr[threadIdx.x] = 0;
+			if (threadIdx.x == 0)
+				*a.flag_cnt = 0;
+		}
+	}
+	if (blockIdx.x < a.nb0)
+		ivf_collect_pack_pairs_body<IS_L2>(blockIdx.x, a.x, a.d, a.nq, 1, a.slots0, a.items0, a.cent, a.list_of_blk64, a.list_max_bits, a.xi0,
+		                                   a.igamma0, a.ie20, a.qfail, a.nlist, a.bound_mode);
+	else
+		ivf_collect_pack_body<IS_L2>(blockIdx.x - a.nb0, a.x, a.d, a.items1, a.nitems1, a.qidx1, a.cent, a.list_of_blk64, a.list_max_bits,
+		                             a.xi1, a.igamma1, a.ie21, a.qfail, nullptr, 0, nullptr, a.nlist, a.bound_mode);
+}
+void launch_ivf_collect_pack2(int metric, const float *d_x, int d, int64_t nq, const int *d_slots0, const void *d_items0, void *d_xi0,
+                              float *d_igamma0, float *d_ie20, const void *d_items1, const int *d_nitems1, int max_items1,
+                              const int *d_qidx1, void *d_xi1, float *d_igamma1, float *d_ie21, const float *d_cent,
+                              const int *d_list_of_blk64, const unsigned *d_list_max_bits, int *d_qfail, int64_t nlist, unsigned *d_gslot,
+                              int nclass, int *d_ctl_hdr, int *d_flag_cnt, hipStream_t st) {
+	if (nq <= 0 || max_items1 <= 0)
+		return;
+	IvfPack2Args a;
+	memset(&a, 0, sizeof a);
+	a.gslot = d_gslot, a.nclass = nclass, a.ctl_hdr = d_ctl_hdr, a.flag_cnt = d_flag_cnt;
+	a.x = d_x, a.d = d, a.nlist = (int)nlist, a.bound_mode = tune().cl_bound_mode, a.nb0 = (unsigned)((nq + 15) / 16), a.nq = nq;
+	a.cent = d_cent, a.list_of_blk64 = d_list_of_blk64, a.list_max_bits = d_list_max_bits, a.qfail = d_qfail;
+	a.slots0 = d_slots0, a.items0 = (const int4 *)d_items0, a.xi0 = (bf16x8i *)d_xi0, a.igamma0 = d_igamma0, a.ie20 = d_ie20;
+	a.items1 = (const int4 *)d_items1, a.nitems1 = d_nitems1, a.qidx1 = d_qidx1, a.xi1 = (bf16x8i *)d_xi1, a.igamma1 = d_igamma1, a.ie21 = d_ie21;
+	const size_t lds = ((size_t)64 * (d + 1) + d) * sizeof(float);
+	const dim3 grid(a.nb0 + 2u * (unsigned)max_items1);
+	if (metric == METRIC_L2) {
+		auto kern = ivf_collect_pack2_kernel<true>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+	} else {
+		auto kern = ivf_collect_pack2_kernel<false>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+	}
+	MVS_HIP(hipGetLastError());
+}
 // slots: [nq * np] slot codes of the pairs (pair p = query p / np), -1: no list
 void launch_ivf_collect_pack_pairs(int metric, const float *d_x, int d, int64_t nq, int np, const int *d_slots, const void *d_items,
                                    const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
@@ -357,10 +443,10 @@ void launch_ivf_collect_pack_pairs(int metric, const float *d_x, int d, int64_t 
 	const dim3 grid((unsigned)((npairs + 15) / 16));
 	if (metric == METRIC_L2)
 		hipLaunchKernelGGL(ivf_collect_pack_pairs_kernel<true>, grid, dim3(256), 0, st, d_x, d, npairs, np, d_slots, (const int4 *)d_items,
-		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
+		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, tune().cl_bound_mode);
 	else
 		hipLaunchKernelGGL(ivf_collect_pack_pairs_kernel<false>, grid, dim3(256), 0, st, d_x, d, npairs, np, d_slots, (const int4 *)d_items,
-		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, g_cl_bound_mode);
+		                   d_cent, d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (int)nlist, tune().cl_bound_mode);
 	MVS_HIP(hipGetLastError());
 }
 void launch_ivf_collect_pack_nearest(int metric, const float *d_x, int d, int64_t nq, const int *d_slots, const void *d_items,
@@ -384,13 +470,13 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(2 * max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
 		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
-		                   d_ie2_pre, (int)nlist, g_cl_bound_mode);
+		                   d_ie2_pre, (int)nlist, tune().cl_bound_mode);
 	} else {
 		auto kern = ivf_collect_pack_kernel<false>;
 		ensure_dynamic_lds((const void *)kern, lds);
 		hipLaunchKernelGGL(kern, dim3(2 * max_items), dim3(256), lds, st, d_x, d, (const int4 *)d_items, d_nitems, d_qidx, d_cent,
 		                   d_list_of_blk64, d_list_max_bits, (bf16x8i *)d_xi, d_igamma, d_ie2, d_qfail, (const long long *)d_coarse, np,
-		                   d_ie2_pre, (int)nlist, g_cl_bound_mode);
+		                   d_ie2_pre, (int)nlist, tune().cl_bound_mode);
 	}
 	MVS_HIP(hipGetLastError());
 }
@@ -401,8 +487,7 @@ void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_
 // bounds of the item's 128 slots live in an LDS table {B - E, gamma} that the wave refreshes itself.
 // NC: row classes per query (16, or 32 for 16 < kk <= 32 -- csrc/flat_collect.hip)
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-// BUCKET: candidates into per-query buckets + unit list (round 5) instead of the global stream
-template <int NC, bool BUCKET>
+template <int NC>
 __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollectArgs a) {
 	constexpr int KB = 4, PITCH = 256, TILE_BYTES = IC_BN * PITCH;
 	__shared__ __attribute__((aligned(16))) float smem[(2 * TILE_BYTES + 2 * 64 * 4 + IC_QCAP * 8 + 128 * 8 + 128 * 8 + IC_QCAP) / 4];
@@ -461,19 +546,18 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	// the lane OWNS (bound refresh) slots 32 hq + 16 i + c, i = 0, 1, i.e. column blocks 2 hq + i = the two blocks of tile t = hq
 	int own_q[2];
 	float own_e2[2];
-#pragma unroll
-	for (int i = 0; i < 2; ++i) {
-		const int slot = 32 * hq + 16 * i + c;
-		own_q[i] = slot < it.w ? a.qidx[it.z + slot] : -1;
-		own_e2[i] = 0.5f * a.ie2[(size_t)item * 128 + slot]; // E of THIS (query, list) pair (inflated, with slack)
-		qtab[2 * slot] = own_q[i];
-		qtab[2 * slot + 1] = __float_as_int(own_e2[i]);
-		ctab[((hq * 16 + c) * 2 + i) * 2 + 1] = a.igamma[(size_t)item * 128 + slot];
-	}
-
 	// B fragments, resident: [column block][k-block]
 	bf16x8i bq[8][KB];
 	{
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const int slot = 32 * hq + 16 * i + c;
+			own_q[i] = slot < it.w ? a.qidx[it.z + slot] : -1;
+			own_e2[i] = 0.5f * a.ie2[(size_t)item * 128 + slot]; // E of THIS (query, list) pair (inflated, with slack)
+			qtab[2 * slot] = own_q[i];
+			qtab[2 * slot + 1] = __float_as_int(own_e2[i]);
+			ctab[((hq * 16 + c) * 2 + i) * 2 + 1] = a.igamma[(size_t)item * 128 + slot];
+		}
 		const bf16x8i *qsrc = (const bf16x8i *)a.xi + (size_t)item * (8 * 4 * 64);
 #pragma unroll
 		for (int cb = 0; cb < 8; ++cb)
@@ -547,37 +631,6 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		qpub = 0;
 		if (n == 0u || !a.collect)
 			return;
-		if (BUCKET) { // one position per hit from its query's counter: every atomic of the drain is in flight before the first is waited for
-			constexpr int NB = (IC_QCAP + 63) / 64;
-			unsigned row[NB], pp[NB];
-			int qq[NB];
-#pragma unroll
-			for (int j = 0; j < NB; ++j) {
-				const unsigned e = lane + 64u * j;
-				pp[j] = 0xffffffffu;
-				if (e < n) {
-					unsigned long long ent;
-					unsigned sl;
-					asm volatile("ds_read_b64 %0, %2\n\tds_read_u8 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-					             : "=&v"(ent), "=&v"(sl)
-					             : "v"(qbuf_lds + 8u * e), "v"(qslot_lds + e)
-					             : "memory");
-					asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qq[j]) : "v"(qtab_lds + sl * 8u) : "memory");
-					row[j] = (unsigned)(ent >> 32);
-					pp[j] = __hip_atomic_fetch_add(a.bcount + qq[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < NB; ++j) {
-				if (pp[j] < (unsigned)a.bpitch) {
-					*(unsigned *)(a.bucket + (size_t)qq[j] * (size_t)a.bpitch + pp[j]) = row[j];
-					if ((pp[j] & 63u) == 0u)
-						a.units[__hip_atomic_fetch_add(a.unit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] =
-						    ((unsigned long long)(unsigned)qq[j] << 16) | (pp[j] >> 6);
-				}
-			}
-			return;
-		}
 		unsigned long long base = 0ull;
 		if (lane == 0) { // (by hand: no compiled atomic with a result in the loop)
 			const unsigned long long n64 = n;
@@ -651,15 +704,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 					typedef __attribute__((address_space(1))) unsigned *GU;
 					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)qe.x * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - __int_as_float(qe.y)),
 					                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (a.collect && BUCKET) {
-						const unsigned p = __hip_atomic_fetch_add(a.bcount + qe.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						if (p < (unsigned)a.bpitch) {
-							*(unsigned *)(a.bucket + (size_t)qe.x * (size_t)a.bpitch + p) = row;
-							if ((p & 63u) == 0u)
-								a.units[__hip_atomic_fetch_add(a.unit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] =
-								    ((unsigned long long)(unsigned)qe.x << 16) | (p >> 6);
-						}
-					} else if (a.collect) {
+					if (a.collect) {
 						unsigned long long gp;
 						const unsigned long long one64 = 1ull;
 						typedef __attribute__((address_space(1))) unsigned long long *GUL;
@@ -816,8 +861,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st, unsigned long long *d_bucket, unsigned *d_bcount, int bpitch, unsigned long long *d_units,
-                             unsigned *d_unit_cnt) {
+                             hipStream_t st) {
 	if (max_items <= 0 || nseg <= 0)
 		return;
 	IvfCollectArgs a;
@@ -837,16 +881,11 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.kk = kk;
 	a.seg_rows = seg_rows;
 	a.collect = collect;
-	a.refresh = g_ivf_cl_refresh;
+	a.refresh = tune().ivf_cl_refresh;
 	a.rowmask = d_rowmask;
-	a.bucket = d_bucket;
-	a.bcount = d_bcount;
-	a.bpitch = bpitch;
-	a.units = d_units;
-	a.unit_cnt = d_unit_cnt;
-	a.xcd_map = (g_ivf_cl_xcd && max_items >= 64) ? g_ivf_cl_xcd : 0; // (the Flat small-batch path has one or two items: nothing to place)
+	a.xcd_map = (tune().ivf_cl_xcd && max_items >= 64) ? tune().ivf_cl_xcd : 0; // (the Flat small-batch path has one or two items: nothing to place)
 	a.nseg = nseg;
-	a.abl = g_ivf_cl_abl;
+	a.abl = tune().ivf_cl_abl;
 	unsigned gx = (unsigned)max_items + (a.xcd_map ? 8u : 0u);
 	if (a.xcd_map >= 2) {
 		gx = (gx + 7u) & ~7u;
@@ -855,14 +894,10 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	}
 	a.gx8 = (int)gx;
 	const dim3 grid = a.xcd_map >= 2 ? dim3(gx * (unsigned)nseg) : dim3(gx, nseg);
-	if (kk > 16 && d_bucket) // 32 row classes: the caller sized and initialised 32 slots per query (ivf_collect_slot_stride)
-		hipLaunchKernelGGL((ivf_bf16_collect_kernel<32, true>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
-	else if (kk > 16)
-		hipLaunchKernelGGL((ivf_bf16_collect_kernel<32, false>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
-	else if (d_bucket)
-		hipLaunchKernelGGL((ivf_bf16_collect_kernel<16, true>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
+	if (kk > 16) // 32 row classes: the caller sized and initialised 32 slots per query (ivf_collect_slot_stride)
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<32>, grid, dim3(64), (size_t)tune().ivf_cl_lds_pad, st, a);
 	else
-		hipLaunchKernelGGL((ivf_bf16_collect_kernel<16, false>), grid, dim3(64), (size_t)g_ivf_cl_lds_pad, st, a);
+		hipLaunchKernelGGL(ivf_bf16_collect_kernel<16>, grid, dim3(64), (size_t)tune().ivf_cl_lds_pad, st, a);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -981,130 +1016,161 @@ void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t 
 	MVS_HIP(hipGetLastError());
 }
 
-// ---- round 5: buckets -> exact values -> the kk best -> the search's output: ONE kernel (csrc/collect_bucket.h) ---------------
-// A unit = 64 bucket entries of one query: rows staged through LDS and re-scored with the scanner's arithmetic exactly as
-// ivf_collect_exact_kernel does (lane <-> candidate; the QUERY is the same for the whole wave now: its loads are wave-uniform),
-// key = (order-preserving value key << 32) | position in the list-sorted store written over the entry.  The wave that completes
-// a query's last unit (a counter per query behind a release fence) selects the query's kk best and writes
+// ---- round 5: stream -> exact values INTO PER-QUERY BUCKETS -> the kk best -> the search's output (csrc/collect_bucket.h) -----
+// Kernel A (ivf_exact_bucket_kernel) = ivf_collect_exact_kernel on the UNSORTED stream: the lane's entry (q << 32 | padded row)
+// is re-scored with the scanner's arithmetic as before, and the key (order-preserving value key << 32 | position in the
+// list-sorted store) goes to entry bcount[q]++ of bucket[q][bpitch].  The atomic that hands out the position is issued BEFORE the
+// rows are staged and its result is used after the 128-step chain: its round trip costs nothing.  (Taking the position in the
+// SCAN's drain instead -- measured: + 60 us on the scan, whose drain then waits for 64 round trips instead of one.)
+// Kernel B (ivf_bucket_select_kernel): one wavefront per query selects the kk best of its bucket and writes
 //   pd / pi [nq][kk]   the pure list (value, position | label), what collect_select_kernel + ivf_emit_sorted_kernel produced, and
 //   D / I [nq][k]      (inside the exact-tie wrapper) FAISS's print order + the boundary-tie flags: csrc/ivf_ties.hip
-//                      ivf_finish_kernel's rule applied to the list while it is still in registers.
-struct IvfBucketFinishArgs {
-	unsigned long long *bucket;
-	const unsigned *bcount;
-	int bpitch;
-	const unsigned long long *units;
-	const unsigned *unit_cnt;
-	unsigned *done; // [nq] units completed per query (zeroed)
-	long long nq;
-	const float *x;
-	int d;
-	const float *rows_csr;
-	int dp;
-	const int *perm;
-	int kk;
-	float *pd;
-	long long *pi;
-	const long long *rowids; // labels of the pure list (nullptr: positions), then through idmap if given
-	const long long *idmap;
-	int k; // fin (D != nullptr): k <= kk
-	float *D;
-	long long *I;
-	const long long *fin_rowids;
-	const long long *fin_idmap;
-	int *flag_cnt;
-	int *flag_q;
-	unsigned long long *stats; // [0] sum of the bucket counts, [1] the largest
+//                      ivf_finish_kernel's rule applied to the list while it is still in registers;
+// it also compacts the per-query fail flags (ivf_compact_flags_kernel's job) and sums the bucket statistics.
+struct EbMeta {
+	int q, pos;
+	unsigned slot;
 };
+// stream entry of lane `lane` of the group at `base`: query, bucket slot (the atomic's result is used behind the chains), position
+__device__ __forceinline__ EbMeta eb_load_meta(const unsigned long long *__restrict__ strm, long long base, int lane, long long ncand,
+                                               unsigned *__restrict__ bcount, const int *__restrict__ perm) {
+	EbMeta m;
+	const long long i = base + lane;
+	const bool in = i < ncand;
+	const unsigned long long ent = in ? strm[i] : 0ull;
+	m.q = (int)(ent >> 32); // (query numbers fit 31 bits: nq * nprobe < 2^26)
+	m.slot = 0xffffffffu;
+	if (in)
+		m.slot = __hip_atomic_fetch_add(bcount + m.q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	m.pos = in ? perm[(unsigned)ent] : 0;
+	return m;
+}
+// one half of a group: its 32 database rows and 32 query rows from registers into LDS, the 32 chains on lanes 0 .. 31, every
+// lane gets the value of lane (lane & 31).  (No barrier: one wavefront per workgroup, a wave's LDS operations execute in order.)
 template <bool IS_L2>
-__global__ __launch_bounds__(64) void ivf_bucket_finish_kernel(const IvfBucketFinishArgs a) {
-	__shared__ __attribute__((aligned(16))) float rows[64 * (128 + 4)];
-	__shared__ unsigned long long surv[256];
-	__shared__ unsigned long long top[64];
-	__shared__ float fv[64];
-	__shared__ long long fid[64];
-	__shared__ int fp[64];
-	const int lane = threadIdx.x;
-	const int d = a.d, dp = a.dp, pitch = dp + 4, cpr = dp / 4, kk = a.kk;
-	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
-	// queries without a single candidate have no unit: their (empty) lists are written here
-	for (long long q = (long long)blockIdx.x * 64 + lane; q < a.nq; q += (long long)gridDim.x * 64) {
-		if (a.bcount[q] != 0u)
-			continue;
-		for (int j = 0; j < kk; ++j) {
-			a.pd[q * kk + j] = neutral;
-			a.pi[q * kk + j] = -1;
-		}
-		if (a.D)
-			for (int j = 0; j < a.k; ++j) {
-				a.D[q * a.k + j] = neutral;
-				a.I[q * a.k + j] = -1;
-			}
-	}
-	const unsigned nunits = *a.unit_cnt;
-	const bool whole = d == 128 && dp == 128;
-	for (unsigned u = blockIdx.x; u < nunits; u += gridDim.x) {
-		const unsigned long long un = a.units[u];
-		const long long q = (long long)(un >> 16);
-		const int c0 = (int)(un & 0xffffu) * 64;
-		const unsigned have = a.bcount[q];
-		const int n = (int)(have < (unsigned)a.bpitch ? have : (unsigned)a.bpitch);
-		const int nrow = n - c0 < 64 ? n - c0 : 64;
-		unsigned long long *bq = a.bucket + (size_t)q * (size_t)a.bpitch;
-		const int pos = lane < nrow ? a.perm[(unsigned)bq[c0 + lane]] : -1;
-		const float *xq = a.x + q * d;
-		float4 xr[32];
-		if (whole) {
+__device__ __forceinline__ float eb_half(float *yrows, float *xrows, const f32x4i (&ry)[16], const f32x4i (&rx)[16], int lane, int sub,
+                                         int ch) {
+	// (f32x4i, the native vector type: whole-value copies of HIP's float4 STRUCT become memcpy calls that keep the buffers in
+	// scratch memory -- every load then waits for its own store)
 #pragma unroll
-			for (int c4 = 0; c4 < 32; ++c4)
-				xr[c4] = *(const float4 *)(xq + c4 * 4);
-#pragma unroll 16
-			for (int it = 0; it < 16; ++it) {
-				const int r = 2 * it + (lane >> 5), ch = lane & 31;
-				const int pp = __shfl(pos, r);
-				const float4 v = *(const float4 *)(a.rows_csr + (size_t)(pp < 0 ? 0 : pp) * 128 + ch * 4);
-				*(float4 *)(rows + r * 132 + ch * 4) = v;
-			}
-			if (nrow > 32) {
-#pragma unroll 16
-				for (int it = 16; it < 32; ++it) {
-					const int r = 2 * it + (lane >> 5), ch = lane & 31;
-					const int pp = __shfl(pos, r);
-					const float4 v = *(const float4 *)(a.rows_csr + (size_t)(pp < 0 ? 0 : pp) * 128 + ch * 4);
-					*(float4 *)(rows + r * 132 + ch * 4) = v;
+	for (int it = 0; it < 16; ++it) {
+		const int r = 2 * it + sub;
+		*(f32x4i *)(yrows + r * 132 + ch * 4) = ry[it];
+		*(f32x4i *)(xrows + r * 132 + ch * 4) = rx[it];
+	}
+	asm volatile("" ::: "memory");
+	float a2 = 0.f;
+	if (sub == 0) {
+		const float *y = yrows + lane * 132, *xx = xrows + lane * 132;
+#pragma unroll
+		for (int c4 = 0; c4 < 32; ++c4) {
+			const float4 xv = *(const float4 *)(xx + c4 * 4);
+			const float4 yv = *(const float4 *)(y + c4 * 4);
+			const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				if (IS_L2) {
+					const float t = __fsub_rn(xs[e], ys[e]);
+					a2 = fmaf(t, t, a2);
+				} else {
+					a2 = fmaf(xs[e], ys[e], a2);
 				}
 			}
-		} else {
-			for (int it = 0; it < cpr; ++it) { // 64 consecutive float4 of the 64 x cpr block per step
-				const int idx = it * 64 + lane, r = idx / cpr, ch = idx - r * cpr;
-				const int pp = __shfl(pos, r);
-				const float4 v = *(const float4 *)(a.rows_csr + (size_t)(pp < 0 ? 0 : pp) * dp + ch * 4);
-				*(float4 *)(rows + r * pitch + ch * 4) = v;
+		}
+	}
+	const float got = __shfl(a2, lane & 31);
+	asm volatile("" ::: "memory");
+	return got;
+}
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void ivf_exact_bucket_kernel(const unsigned long long *__restrict__ strm, long long ncand,
+                                                             const unsigned long long *__restrict__ cnt,
+                                                             const float *__restrict__ x, int d,
+                                                             const float *__restrict__ rows_csr, int dp,
+                                                             const int *__restrict__ perm, unsigned long long *__restrict__ bucket,
+                                                             unsigned *__restrict__ bcount, int bpitch) {
+	// d = dp = 128: the 64 entries of a group in two halves of 32; a half's 32 database rows AND its 32 query rows are staged
+	// through LDS with coalesced 512-byte loads (the stream is not sorted by query: a lane loading ITS query on its own touches 64
+	// cache lines per instruction), lanes 0 .. 31 run the chains of the half.  Both halves' 64 KB are requested at once into
+	// registers, the next group's stream entries, positions and bucket slots a whole group ahead.  (One wavefront per workgroup:
+	// LDS traffic of a wave is ordered, no barrier -- __syncthreads() would also wait for the loads in flight.)  Other shapes: rows
+	// staged, the query read per lane, as ivf_collect_exact_kernel.
+	__shared__ __attribute__((aligned(16))) float rows[64 * (128 + 4)];
+	__shared__ int mpos[64], mq[64];
+	const int pitch = dp + 4, cpr = dp / 4; // floats per LDS row (bank spread), float4 chunks per row
+	const int lane = threadIdx.x;
+	{
+		const unsigned long long have = *cnt;
+		ncand = have < (unsigned long long)ncand ? (long long)have : ncand;
+	}
+	const long long stride = (long long)gridDim.x * 64;
+	if (d == 128 && dp == 128) {
+		float *yrows = rows, *xrows = rows + 32 * 132;
+		const int sub = lane >> 5, ch = lane & 31;
+		long long i0 = (long long)blockIdx.x * 64;
+		if (i0 >= ncand)
+			return;
+		EbMeta cur = eb_load_meta(strm, i0, lane, ncand, bcount, perm);
+		while (i0 < ncand) {
+			const long long i1 = i0 + stride;
+			// BOTH halves' rows and queries are requested at once -- 64 KB in flight per wave, in registers (a wave alone on its SIMD
+			// owns 512) -- and the next group's stream entries, positions and bucket slots behind them: one gather round trip per group
+			f32x4i ry0[16], rx0[16], ry1[16], rx1[16];
+			// (positions and queries of the other lanes through LDS, not by __shfl: a loop around a cross-lane builtin is unrolled
+			// too late for the register buffers to be split into registers -- they landed in scratch memory, every load waited for)
+			mpos[lane] = cur.pos;
+			mq[lane] = cur.q;
+			asm volatile("" ::: "memory");
+#pragma unroll
+			for (int it = 0; it < 16; ++it) {
+				const int r = 2 * it + sub;
+				const int pp = mpos[r], qq = mq[r];
+				ry0[it] = *(const f32x4i *)(rows_csr + (size_t)(pp < 0 ? 0 : pp) * 128 + ch * 4);
+				rx0[it] = *(const f32x4i *)(x + (size_t)qq * 128 + ch * 4);
 			}
+#pragma unroll
+			for (int it = 0; it < 16; ++it) {
+				const int r = 32 + 2 * it + sub;
+				const int pp = mpos[r], qq = mq[r];
+				ry1[it] = *(const f32x4i *)(rows_csr + (size_t)(pp < 0 ? 0 : pp) * 128 + ch * 4);
+				rx1[it] = *(const f32x4i *)(x + (size_t)qq * 128 + ch * 4);
+			}
+			const EbMeta nxt = eb_load_meta(strm, i1, lane, ncand, bcount, perm); // (past the end: q = 0, pos = 0, no slot)
+			// (the half's 32 results sit in lanes 0 .. 31) lane 32 h + j takes the value lane j computed in half h
+			const float got0 = eb_half<IS_L2>(yrows, xrows, ry0, rx0, lane, sub, ch);
+			const float got1 = eb_half<IS_L2>(yrows, xrows, ry1, rx1, lane, sub, ch);
+			const float acc = sub == 0 ? got0 : got1;
+			if (i0 + lane < ncand) {
+				const bool ok = cur.pos >= 0 && (IS_L2 ? acc < FLT_MAX : acc > -FLT_MAX);
+				if (cur.slot < (unsigned)bpitch) // (entries past the bucket are only counted: the host grows the pitch and repeats the pass)
+					bucket[(size_t)cur.q * (size_t)bpitch + cur.slot] = ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)cur.pos) : CB_EMPTY;
+			}
+			cur = nxt;
+			i0 = i1;
+		}
+		return;
+	}
+	for (long long i0 = (long long)blockIdx.x * 64; i0 < ncand; i0 += stride) {
+		const long long i = i0 + lane;
+		const unsigned long long ent = i < ncand ? strm[i] : 0ull;
+		const long long q = (long long)(ent >> 32);
+		unsigned slot = 0xffffffffu;
+		if (i < ncand)
+			slot = __hip_atomic_fetch_add(bcount + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (used behind the chain)
+		const int pos = i < ncand ? perm[(unsigned)ent] : 0;
+		float acc = 0.f;
+		const float *xq = x + q * d;
+		for (int it = 0; it < cpr; ++it) { // 64 consecutive float4 of the 64 x cpr block per step
+			const int idx = it * 64 + lane, r = idx / cpr, ch = idx - r * cpr;
+			const int pp = __shfl(pos, r);
+			const float4 v = *(const float4 *)(rows_csr + (size_t)(pp < 0 ? 0 : pp) * dp + ch * 4);
+			*(float4 *)(rows + r * pitch + ch * 4) = v;
 		}
 		__syncthreads();
-		if (lane < nrow) {
+		if (i < ncand) {
 			const float *y = rows + lane * pitch;
-			float acc = 0.f;
 			int kd = 0;
-			if (whole) {
-#pragma unroll
-				for (int c4 = 0; c4 < 32; ++c4) {
-					const float4 xv = xr[c4];
-					const float4 yv = *(const float4 *)(y + c4 * 4);
-					const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-					for (int e = 0; e < 4; ++e) {
-						if (IS_L2) {
-							const float t = __fsub_rn(xs[e], ys[e]);
-							acc = fmaf(t, t, acc);
-						} else {
-							acc = fmaf(xs[e], ys[e], acc);
-						}
-					}
-				}
-				kd = d;
-			} else if ((d & 3) == 0) {
+			if ((d & 3) == 0) { // 16-byte loads of the query and of the staged row; the chain keeps its k order
 				for (; kd < d; kd += 4) {
 					const float4 xv = *(const float4 *)(xq + kd);
 					const float4 yv = *(const float4 *)(y + kd);
@@ -1129,97 +1195,138 @@ __global__ __launch_bounds__(64) void ivf_bucket_finish_kernel(const IvfBucketFi
 				}
 			}
 			const bool ok = pos >= 0 && (IS_L2 ? acc < FLT_MAX : acc > -FLT_MAX);
-			// (agent-scope store: written THROUGH to the memory side, where the selecting wave -- possibly on another XCD, whose L2 is
-			// not coherent with this one inside a launch -- reads it with agent-scope loads.  A device-wide fence here instead writes
-			// back and invalidates whole L2s: 2.5 ms per launch when every unit did one)
-			__hip_atomic_store(bq + c0 + lane, ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)pos) : CB_EMPTY,
-			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (slot < (unsigned)bpitch)
+				bucket[(size_t)q * (size_t)bpitch + slot] = ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)pos) : CB_EMPTY;
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the wave's key stores have completed (vmcnt) before the unit counts as done
-		int last = 0;
-		if (lane == 0) {
-			const unsigned t = __hip_atomic_fetch_add(a.done + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			last = t + 1u == (unsigned)((n + 63) >> 6);
-		}
-		last = __builtin_amdgcn_readfirstlane(last);
-		__syncthreads(); // (the staged rows are free)
-		if (!last)
-			continue;
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		const unsigned long long mine = cb_select_wave(bq, n, kk, lane, surv, top);
-		const bool hv = mine != CB_EMPTY;
-		const float val = hv ? bkey2f<IS_L2>((unsigned)(mine >> 32)) : neutral;
-		const int ps = hv ? (int)(unsigned)mine : -1;
-		if (lane < kk) {
-			a.pd[q * kk + lane] = val;
-			long long lab = ps;
-			if (ps >= 0 && a.rowids) {
-				lab = a.rowids[ps];
-				if (a.idmap)
-					lab = a.idmap[lab];
-			}
-			a.pi[q * kk + lane] = lab;
-		}
-		if (a.D) { // csrc/ivf_ties.hip ivf_finish_kernel, entry j of the pure list in lane j
-			const int k = a.k;
-			fv[lane] = val;
-			fp[lane] = lane < kk ? ps : -1;
-			fid[lane] = (lane < kk && ps >= 0) ? a.fin_rowids[ps] : -1;
-			__syncthreads();
-			if (lane < k) {
-				const int j = lane;
-				if (fp[j] < 0) {
-					a.D[q * k + j] = neutral;
-					a.I[q * k + j] = -1;
-				} else {
-					const long long id = fid[j];
-					int lo = j, hi = j;
-					while (lo > 0 && fv[lo - 1] == val)
-						--lo;
-					while (hi + 1 < k && fp[hi + 1] >= 0 && fv[hi + 1] == val)
-						++hi;
-					int rank = 0;
-					for (int m = lo; m <= hi && hi > lo; ++m) {
-						const long long idm = fid[m];
-						rank += IS_L2 ? (idm < id || (idm == id && m < j)) : (idm > id || (idm == id && m < j));
-					}
-					const long long o = q * k + lo + rank;
-					a.D[o] = val;
-					a.I[o] = a.fin_idmap ? a.fin_idmap[id] : id;
-					if (j == k - 1 && kk > k && fp[k] >= 0 && fv[k] == val)
-						a.flag_q[atomicAdd(a.flag_cnt, 1)] = (int)q;
-				}
-			}
-			__syncthreads();
-		}
-		if (lane == 0) {
-			atomicAdd(a.stats, (unsigned long long)have);
+		__syncthreads(); // (the next group's rows overwrite the tile)
+	}
+}
+struct IvfBucketSelectArgs {
+	const unsigned long long *bucket;
+	unsigned *bcount; // [nq]
+	int bpitch;
+	long long nq;
+	int kk;
+	float *pd;
+	long long *pi;
+	const long long *rowids; // labels of the pure list (nullptr: positions), then through idmap if given
+	const long long *idmap;
+	int k; // fin (D != nullptr): k < kk
+	float *D;
+	long long *I;
+	const long long *fin_rowids;
+	const long long *fin_idmap;
+	int *flag_cnt;
+	int *flag_q;
+	unsigned long long *stats; // [0] sum of the bucket counts, [1] the largest
+	int *qfail;                // per-query fail flags -> fail_q[fail_cnt++]
+	int *fail_cnt;
+	int *fail_q;
+	int reset; // leave bcount[q] and qfail[q] zero for the next search (prep2: no memset in front of a search)
+};
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSelectArgs a) {
+	__shared__ unsigned long long surv[256];
+	__shared__ unsigned long long top[64];
+	__shared__ float fv[64];
+	__shared__ long long fid[64];
+	__shared__ int fp[64];
+	const int lane = threadIdx.x, kk = a.kk;
+	const float neutral = IS_L2 ? FLT_MAX : -FLT_MAX;
+	const long long q = blockIdx.x;
+	const unsigned have = a.bcount[q];
+	const int n = (int)(have < (unsigned)a.bpitch ? have : (unsigned)a.bpitch);
+	if (lane == 0) {
+		// (one atomic per QUERY on one address -- sum and maximum of the counts -- serialised in L2: 250 us for 10 000 queries.  The
+		// sum is the stream's own count; the maximum matters only when a bucket was too small)
+		if (have > (unsigned)a.bpitch)
 			atomicMax(a.stats + 1, (unsigned long long)have);
+		if (a.qfail[q])
+			a.fail_q[atomicAdd(a.fail_cnt, 1)] = (int)q;
+		if (a.reset) {
+			a.bcount[q] = 0u;
+			a.qfail[q] = 0;
+		}
+	}
+	const unsigned long long mine = n > 0 ? cb_select_wave<false>(a.bucket + (size_t)q * (size_t)a.bpitch, n, kk, lane, surv, top) : CB_EMPTY;
+	const bool hv = mine != CB_EMPTY;
+	const float val = hv ? bkey2f<IS_L2>((unsigned)(mine >> 32)) : neutral;
+	const int ps = hv ? (int)(unsigned)mine : -1;
+	if (lane < kk) {
+		a.pd[q * kk + lane] = val;
+		long long lab = ps;
+		if (ps >= 0 && a.rowids) {
+			lab = a.rowids[ps];
+			if (a.idmap)
+				lab = a.idmap[lab];
+		}
+		a.pi[q * kk + lane] = lab;
+	}
+	if (a.D) { // csrc/ivf_ties.hip ivf_finish_kernel, entry j of the pure list in lane j
+		const int k = a.k;
+		fv[lane] = val;
+		fp[lane] = lane < kk ? ps : -1;
+		fid[lane] = (lane < kk && ps >= 0) ? a.fin_rowids[ps] : -1;
+		__syncthreads();
+		if (lane < k) {
+			const int j = lane;
+			if (fp[j] < 0) {
+				a.D[q * k + j] = neutral;
+				a.I[q * k + j] = -1;
+			} else {
+				const long long id = fid[j];
+				int lo = j, hi = j;
+				while (lo > 0 && fv[lo - 1] == val)
+					--lo;
+				while (hi + 1 < k && fp[hi + 1] >= 0 && fv[hi + 1] == val)
+					++hi;
+				int rank = 0;
+				for (int m = lo; m <= hi && hi > lo; ++m) {
+					const long long idm = fid[m];
+					rank += IS_L2 ? (idm < id || (idm == id && m < j)) : (idm > id || (idm == id && m < j));
+				}
+				const long long o = q * k + lo + rank;
+				a.D[o] = val;
+				a.I[o] = a.fin_idmap ? a.fin_idmap[id] : id;
+				if (j == k - 1 && kk > k && fp[k] >= 0 && fv[k] == val)
+					a.flag_q[atomicAdd(a.flag_cnt, 1)] = (int)q;
+			}
 		}
 	}
 }
-void launch_ivf_bucket_finish(int metric, unsigned long long *d_bucket, const unsigned *d_bcount, int bpitch, const unsigned long long *d_units,
-                              const unsigned *d_unit_cnt, unsigned *d_done, int64_t nq, const float *d_x, int d, const float *d_rows_csr,
-                              int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi, const int64_t *d_rowids,
-                              const int64_t *d_idmap, int k, float *d_D, int64_t *d_I, const int64_t *d_fin_rowids,
-                              const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats, hipStream_t st) {
+// d_strm: the scan's candidate stream (ncand = its capacity or the host's count; the real number is min(*d_cnt, ncand));
+// d_bucket [nq][bpitch] keys, d_bcount [nq] (zeroed); outputs as ivf_bucket_select_kernel describes
+void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int64_t ncand, const unsigned long long *d_cnt,
+                              unsigned long long *d_bucket, unsigned *d_bcount, int bpitch, int64_t nq, const float *d_x, int d,
+                              const float *d_rows_csr, int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi,
+                              const int64_t *d_rowids, const int64_t *d_idmap, int k, float *d_D, int64_t *d_I,
+                              const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
+                              int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st) {
 	if (nq <= 0)
 		return;
 	if (dp_csr % 4 != 0 || dp_csr > 128 || kk > 64 || kk < 1)
 		throw_faiss("mvs::launch_ivf_bucket_finish", __FILE__, "row pitch %d / k %d is not served", dp_csr, kk);
-	IvfBucketFinishArgs a;
+	const bool l2 = metric_order(metric) == METRIC_L2;
+	if (ncand > 0) { // a fixed grid walks the stream in strides (its length is on the device): two dispatch rounds of the 4 096 resident waves
+		const dim3 grid((unsigned)std::min<int64_t>((ncand + 63) / 64, 8192));
+		if (l2)
+			hipLaunchKernelGGL(ivf_exact_bucket_kernel<true>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr,
+			                   dp_csr, d_perm, d_bucket, d_bcount, bpitch);
+		else
+			hipLaunchKernelGGL(ivf_exact_bucket_kernel<false>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr,
+			                   dp_csr, d_perm, d_bucket, d_bcount, bpitch);
+	}
+	IvfBucketSelectArgs a;
 	memset(&a, 0, sizeof a);
-	a.bucket = d_bucket, a.bcount = d_bcount, a.bpitch = bpitch, a.units = d_units, a.unit_cnt = d_unit_cnt, a.done = d_done;
-	a.nq = nq, a.x = d_x, a.d = d, a.rows_csr = d_rows_csr, a.dp = dp_csr, a.perm = d_perm, a.kk = kk;
+	a.bucket = d_bucket, a.bcount = d_bcount, a.bpitch = bpitch, a.nq = nq, a.kk = kk;
 	a.pd = d_pd, a.pi = (long long *)d_pi, a.rowids = (const long long *)d_rowids, a.idmap = (const long long *)d_idmap;
 	a.k = k, a.D = d_D, a.I = (long long *)d_I, a.fin_rowids = (const long long *)d_fin_rowids, a.fin_idmap = (const long long *)d_fin_idmap;
 	a.flag_cnt = d_flag, a.flag_q = d_flag ? d_flag + 1 : nullptr, a.stats = d_stats;
-	// a fixed grid walks the unit list in strides (its length is on the device): four waves per CU are resident (34 KB of LDS each)
-	const dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(nq, 1), 8192));
-	if (metric_order(metric) == METRIC_L2)
-		hipLaunchKernelGGL(ivf_bucket_finish_kernel<true>, grid, dim3(64), 0, st, a);
+	a.qfail = d_qfail, a.fail_cnt = d_fail_cnt, a.fail_q = d_fail_q, a.reset = reset ? 1 : 0;
+	if (l2)
+		hipLaunchKernelGGL(ivf_bucket_select_kernel<true>, dim3((unsigned)nq), dim3(64), 0, st, a);
 	else
-		hipLaunchKernelGGL(ivf_bucket_finish_kernel<false>, grid, dim3(64), 0, st, a);
+		hipLaunchKernelGGL(ivf_bucket_select_kernel<false>, dim3((unsigned)nq), dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
 

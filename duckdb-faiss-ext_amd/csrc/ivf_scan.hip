@@ -579,6 +579,166 @@ __global__ void ivf_group_items_kernel(const int *cnt, const int *pair_off, cons
 		items[item_off[l] + g] = make_int4((int)list_begin[l], (int)list_end[l], pair_off[l] + g * G, min(G, n - g * G));
 }
 
+// ---- round 5: BOTH groupings of a coarse-filter search in three launches ------------------------------------------------------
+// The IVF coarse filter (csrc/ivf_collect.hip) groups the batch twice: all nq x nprobe pairs for the main pass (set 1) and
+// column 0 of the labels -- every query's nearest list -- for the publish-only pre-pass (set 0).  Rounds 3-4 ran the four
+// kernels above once per set (eight launches of 5-11 us each, two memsets in front).  Here: one count kernel with two LDS
+// histograms per workgroup, one scan kernel of two workgroups that also writes the work items, one scatter kernel for both
+// sets -- which then ZEROES the counters for the next search (nobody reads them after the scan kernel).
+struct Group2Set {
+	int *cnt, *pair_off, *item_off, *cursor, *nitems; // ws ints of the set (launch_ivf_group's layout)
+	int4 *items;
+	int *qidx;
+	int *slots; // slot codes per pair (may be null)
+};
+__global__ __launch_bounds__(1024) void ivf_group2_count_kernel(const long long *keys, int npairs, int nprobe, int nlist, int *cnt0,
+                                                               int *cnt1, int use_lds) {
+	extern __shared__ int gh[]; // [2][nlist]
+	const int base = blockIdx.x * GROUP_CHUNK;
+	if (!use_lds) {
+		for (int j = threadIdx.x; j < GROUP_CHUNK && base + j < npairs; j += 1024) {
+			const long long l = keys[base + j];
+			if (l >= 0) {
+				atomicAdd(&cnt1[l], 1);
+				if ((base + j) % nprobe == 0)
+					atomicAdd(&cnt0[l], 1);
+			}
+		}
+		return;
+	}
+	for (int i = threadIdx.x; i < 2 * nlist; i += 1024)
+		gh[i] = 0;
+	__syncthreads();
+	for (int j = threadIdx.x; j < GROUP_CHUNK && base + j < npairs; j += 1024) {
+		const long long l = keys[base + j];
+		if (l >= 0) {
+			atomicAdd(&gh[nlist + l], 1);
+			if ((base + j) % nprobe == 0)
+				atomicAdd(&gh[l], 1);
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < nlist; i += 1024) {
+		if (gh[i])
+			atomicAdd(&cnt0[i], gh[i]);
+		if (gh[nlist + i])
+			atomicAdd(&cnt1[i], gh[nlist + i]);
+	}
+}
+// workgroup s scans set s (pair offsets, item offsets, cursors, item count) and writes the set's work items
+__global__ __launch_bounds__(1024) void ivf_group2_scan_kernel(Group2Set s0, Group2Set s1, int nlist, int G, const long long *list_begin,
+                                                              const long long *list_end) {
+	const Group2Set s = blockIdx.x == 0 ? s0 : s1;
+	__shared__ int part_p[1024], part_i[1024];
+	const int t = threadIdx.x;
+	const int per = (nlist + 1023) / 1024;
+	const int l0 = t * per, l1 = min(nlist, l0 + per);
+	int sp = 0, si = 0;
+	for (int l = l0; l < l1; ++l) {
+		sp += s.cnt[l];
+		si += (s.cnt[l] + G - 1) / G;
+	}
+	part_p[t] = sp;
+	part_i[t] = si;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+		const int vp = t >= off ? part_p[t - off] : 0, vi = t >= off ? part_i[t - off] : 0;
+		__syncthreads();
+		part_p[t] += vp;
+		part_i[t] += vi;
+		__syncthreads();
+	}
+	int bp = part_p[t] - sp, bi = part_i[t] - si;
+	for (int l = l0; l < l1; ++l) {
+		const int n = s.cnt[l];
+		s.pair_off[l] = bp;
+		s.cursor[l] = bp;
+		s.item_off[l] = bi;
+		for (int g = 0; g * G < n; ++g)
+			s.items[bi + g] = make_int4((int)list_begin[l], (int)list_end[l], bp + g * G, min(G, n - g * G));
+		bp += n;
+		bi += (n + G - 1) / G;
+	}
+	if (t == 1023) {
+		s.pair_off[nlist] = part_p[1023];
+		s.item_off[nlist] = part_i[1023];
+		*s.nitems = part_i[1023];
+	}
+}
+__global__ __launch_bounds__(1024) void ivf_group2_scatter_kernel(const long long *keys, int npairs, int nprobe, int G, int shift,
+                                                                 Group2Set s0, Group2Set s1, int nlist, int use_lds) {
+	extern __shared__ int gh[]; // [2][nlist] pairs of this workgroup per (set, list), then their running rank; [2][nlist] first position of the run
+	int *gb = gh + 2 * nlist;
+	const int base = blockIdx.x * GROUP_CHUNK;
+	long long mine[GROUP_CHUNK / 1024];
+#pragma unroll
+	for (int u = 0; u < GROUP_CHUNK / 1024; ++u) {
+		const int j = threadIdx.x + 1024 * u;
+		mine[u] = base + j < npairs ? keys[base + j] : -1;
+	}
+	if (use_lds) {
+		for (int i = threadIdx.x; i < 2 * nlist; i += 1024)
+			gh[i] = 0;
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < GROUP_CHUNK / 1024; ++u) {
+			const int i = base + threadIdx.x + 1024 * u;
+			if (mine[u] >= 0) {
+				atomicAdd(&gh[nlist + mine[u]], 1);
+				if (i % nprobe == 0)
+					atomicAdd(&gh[mine[u]], 1);
+			}
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i < nlist; i += 1024) {
+			const int c0 = gh[i], c1 = gh[nlist + i];
+			if (c0)
+				gb[i] = atomicAdd(&s0.cursor[i], c0);
+			if (c1)
+				gb[nlist + i] = atomicAdd(&s1.cursor[i], c1);
+			gh[i] = 0;
+			gh[nlist + i] = 0;
+		}
+		__syncthreads();
+	}
+#pragma unroll
+	for (int u = 0; u < GROUP_CHUNK / 1024; ++u) {
+		const int i = base + threadIdx.x + 1024 * u;
+		if (i >= npairs)
+			continue;
+		const long long l = mine[u];
+		const bool first = i % nprobe == 0;
+		if (l < 0) {
+			if (s1.slots)
+				s1.slots[i] = -1;
+			if (first && s0.slots)
+				s0.slots[i / nprobe] = -1;
+			continue;
+		}
+		{
+			const int pos = use_lds ? gb[nlist + l] + atomicAdd(&gh[nlist + l], 1) : atomicAdd(&s1.cursor[l], 1);
+			s1.qidx[pos] = i / nprobe;
+			if (s1.slots) {
+				const int rel = pos - s1.pair_off[l];
+				s1.slots[i] = ((s1.item_off[l] + rel / G) << shift) | (rel % G);
+			}
+		}
+		if (first) {
+			const int pos = use_lds ? gb[l] + atomicAdd(&gh[l], 1) : atomicAdd(&s0.cursor[l], 1);
+			s0.qidx[pos] = i / nprobe;
+			if (s0.slots) {
+				const int rel = pos - s0.pair_off[l];
+				s0.slots[i / nprobe] = ((s0.item_off[l] + rel / G) << shift) | (rel % G);
+			}
+		}
+	}
+	// the counters are not read after the scan kernel: zero for the next search (launch_ivf_group2's contract)
+	for (int i = blockIdx.x * 1024 + threadIdx.x; i <= nlist; i += gridDim.x * 1024) {
+		s0.cnt[i] = 0;
+		s1.cnt[i] = 0;
+	}
+}
+
 size_t scan_lds_bytes(int64_t k) {
 	return (size_t)4 * SQG * k * 8 + (size_t)4 * SQG * 16 + SQG * 4 + 64;
 }
@@ -658,6 +818,39 @@ void launch_ivf_group(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nli
 	MVS_HIP(hipGetLastError());
 	*d_nitems_out = nitems;
 	*d_cnt_out = cnt;
+}
+
+// Both groupings of one coarse-filter search (see ivf_group2_count_kernel).  ws0 / ws1: ivf_group_ws_ints(nlist) ints each, whose
+// COUNTERS (the first nlist + 1 ints) are zero on entry and zero again on exit; set 0 = one probe per query (column 0 of the
+// [nq][nprobe] labels), set 1 = all pairs.
+void launch_ivf_group2(const int64_t *d_keys, int64_t nq, int nprobe, int64_t nlist, int group, int shift, const int64_t *d_list_begin,
+                       const int64_t *d_list_end, int *ws0, int *ws1, void *d_items0, int *d_qidx0, int *d_slots0, void *d_items1,
+                       int *d_qidx1, int *d_slots1, int **d_nitems0_out, int **d_nitems1_out, hipStream_t st) {
+	const int npairs = (int)(nq * nprobe);
+	auto mk = [&](int *ws, void *items, int *qidx, int *slots) {
+		Group2Set s;
+		s.cnt = ws, s.pair_off = s.cnt + (nlist + 1), s.item_off = s.pair_off + (nlist + 1), s.cursor = s.item_off + (nlist + 1);
+		s.nitems = s.cursor + (nlist + 1);
+		s.items = (int4 *)items, s.qidx = qidx, s.slots = slots;
+		return s;
+	};
+	const Group2Set s0 = mk(ws0, d_items0, d_qidx0, d_slots0), s1 = mk(ws1, d_items1, d_qidx1, d_slots1);
+	const int use_lds = nlist <= 8192 && npairs >= 4 * GROUP_CHUNK;
+	const unsigned chunks = (unsigned)((npairs + GROUP_CHUNK - 1) / GROUP_CHUNK);
+	const size_t lds_c = use_lds ? (size_t)2 * nlist * sizeof(int) : 0, lds_s = use_lds ? (size_t)4 * nlist * sizeof(int) : 0;
+	if (use_lds) {
+		ensure_dynamic_lds((const void *)ivf_group2_count_kernel, lds_c);
+		ensure_dynamic_lds((const void *)ivf_group2_scatter_kernel, lds_s);
+	}
+	hipLaunchKernelGGL(ivf_group2_count_kernel, dim3(chunks), dim3(1024), lds_c, st, (const long long *)d_keys, npairs, nprobe, (int)nlist,
+	                   s0.cnt, s1.cnt, use_lds);
+	hipLaunchKernelGGL(ivf_group2_scan_kernel, dim3(2), dim3(1024), 0, st, s0, s1, (int)nlist, group, (const long long *)d_list_begin,
+	                   (const long long *)d_list_end);
+	hipLaunchKernelGGL(ivf_group2_scatter_kernel, dim3(chunks), dim3(1024), lds_s, st, (const long long *)d_keys, npairs, nprobe, group,
+	                   shift, s0, s1, (int)nlist, use_lds);
+	MVS_HIP(hipGetLastError());
+	*d_nitems0_out = s0.nitems;
+	*d_nitems1_out = s1.nitems;
 }
 
 // the items' queries in MFMA B-fragment order (util_kernels.hip pack_queries_kernel), gathered through qidx:

@@ -132,6 +132,7 @@ _L.mvs_merge_shards_raw.argtypes = [C.c_int, _i64, _i64, C.c_int, _p, _p, _p, _p
 _L.mvs_merge_records_device.argtypes = [C.c_int, _i64, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p]
 _L.mvs_finish_ip_ties.argtypes = [_i64, _i64, _i64, _p, _p, _i64, _p, _p, _p, _p]
 _L.mvs_index_tie_candidates_device.argtypes = [_p, _i64, _p, _p, _i64, _p, C.POINTER(SearchParams), _p]
+_L.mvs_index_ivf_tie_emit_device.argtypes = [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(SearchParams), _p]
 _L.mvs_synth_uniform_device.argtypes = [_p, _i64, C.c_int, C.c_uint64, _i64, _p]
 _L.mvs_synth_clustered_device.argtypes = [_p, _i64, C.c_int, C.c_uint64, _i64, C.c_int, C.c_float, _p]
 _L.mvs_index_last_kernel_info.argtypes = [_p, C.POINTER(KernelInfo)]
@@ -149,7 +150,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
-    "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
+    "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_index_ivf_tie_emit_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
     "mvs_version",
 ]  # fmt: skip
@@ -355,6 +356,31 @@ class Index:
         _check(_L.mvs_index_search_device(self._h, nq, x.data_ptr(), k, D.data_ptr(), I.data_ptr(), C.byref(p), stream))
         del keep
         return D, I
+
+    def ivf_tie_emit_torch(self, flagged, xq, T, k, sel=None, stream=None):
+        """IVF row shard: for the flagged queries (int64 tensor of query numbers of the batch `xq` that has JUST been searched on this
+        index) this shard's first k rows not worse than T in arrival order: (value f32, stored id i64, probe rank i32), each [nf, k],
+        -1 padded -- include/mi355_faiss.h mvs_index_ivf_tie_emit_device"""
+        import torch
+
+        nf = int(flagged.shape[0])
+        dev = xq.device
+        v = torch.zeros((nf, k), dtype=torch.float32, device=dev)
+        ids = torch.full((nf, k), -1, dtype=torch.int64, device=dev)
+        rk = torch.full((nf, k), -1, dtype=torch.int32, device=dev)
+        if nf == 0:
+            return v, ids, rk
+        flag = torch.empty(nf + 1, dtype=torch.int32, device=dev)
+        flag[0] = nf
+        flag[1:] = flagged.to(torch.int32)
+        p, keep = make_params(0, 0, sel)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(_L.mvs_index_ivf_tie_emit_device(self._h, nf, C.c_void_p(flag.data_ptr()), C.c_void_p(xq.data_ptr()), C.c_void_p(T.data_ptr()),
+                                                int(k), C.c_void_p(v.data_ptr()), C.c_void_p(ids.data_ptr()), C.c_void_p(rk.data_ptr()),
+                                                C.byref(p), C.c_void_p(stream)))
+        del keep
+        return v, ids, rk
 
     def tie_candidates_torch(self, xf, T, k, sel=None, stream=None):
         """per flagged query the k smallest GLOBAL rows with score >= T (ascending, -1 padded) -- include/mi355_faiss.h"""

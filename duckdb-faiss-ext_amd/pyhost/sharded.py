@@ -212,3 +212,107 @@ class ShardExchange:
         if rawD is None:
             return None, None
         return mf.finish_ip_ties(k, rawD, rawI, flagged, first)
+
+    # ---- IVF with exact distance ties (round 5): collective, every rank calls it with the same arguments ------------------------
+    def merge_ivf_exact(self, metric, D, I, tie_emit, merge_rank=0):
+        """Row-sharded IVF, the heap's outcome under exact ties (include/mi355_faiss.h "IVF exact distance ties across PROCESSES";
+        csrc/sharded.hip resolve_ties_ivf is the in-library twin).  D, I: this rank's [nq, k+1] PURE-order lists (the shard searched
+        with k + 1 and option ivf_exact_ties = 0; labels = global rows); tie_emit(flagged i64 tensor, T f32 tensor) -> (v [nf, k] f32,
+        id [nf, k] i64, rank [nf, k] i32) torch: this rank's first k rows not worse than T in arrival order, -1 padded
+        (Index.ivf_tie_emit_torch).  Returns (D, I) numpy [nq, k] on merge_rank, (None, None) elsewhere."""
+        assert self.ip_ties and D.shape[1] == self.kk  # (ip_ties = "k + 1 entries per shard": the same buffers serve both protocols)
+        k, kk = self.k, self.kk
+        is_l2 = metric == mf.METRIC_L2
+        if self.world == 1:
+            rawD, rawI = mf.merge_shards_raw(metric, D.cpu().numpy()[None], I.cpu().numpy()[None])
+        else:
+            self.gather_async(D, I, merge_rank)
+            rawD = rawI = None
+            if self.rank == merge_rank:
+                if self.grec.is_cuda:
+                    rD, rI = mf.merge_records_torch(metric, self.grec, kk, raw=True)
+                    rawD, rawI = rD.cpu().numpy(), rI.cpu().numpy()
+                else:
+                    _, _, ev = self._pending
+                    if ev is not None:
+                        ev.synchronize()
+                    hD, hI = unpack_records(self.hrec.numpy())
+                    rawD, rawI = mf.merge_shards_raw(metric, hD, hI)
+            self._pending = None
+        flagged = np.zeros(0, dtype=np.int64)
+        if rawD is not None:
+            flagged = np.nonzero((rawI[:, k] >= 0) & (rawD[:, k] == rawD[:, k - 1]))[0].astype(np.int64)
+        nf_t = torch.tensor([flagged.size], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.broadcast(nf_t, src=merge_rank, group=self.group)
+        nf = int(nf_t.item())
+        em = None
+        if nf > 0:
+            fq = torch.empty(nf, dtype=torch.int64, device=self.device)
+            T = torch.empty(nf, dtype=torch.float32, device=self.device)
+            if rawD is not None:
+                fq.copy_(torch.from_numpy(flagged))
+                T.copy_(torch.from_numpy(np.ascontiguousarray(rawD[flagged, k - 1])))
+            if self.world > 1:
+                dist.broadcast(fq, src=merge_rank, group=self.group)
+                dist.broadcast(T, src=merge_rank, group=self.group)
+            v, ids, rk = tie_emit(fq, T)
+            # one record per entry: {value bits, id, probe rank} as three int64 -> ONE all-gather
+            rec = torch.stack([v.contiguous().view(torch.int32).to(torch.int64), ids.to(torch.int64), rk.to(torch.int64)], dim=-1).contiguous()
+            if self.world > 1:
+                allr = torch.empty((self.world, nf, k, 3), dtype=torch.int64, device=self.device)
+                dist.all_gather_into_tensor(allr.view(self.world * nf, k, 3), rec, group=self.group)
+                em = allr.cpu().numpy()
+            else:
+                em = rec.cpu().numpy()[None]
+        if rawD is None:
+            return None, None
+        # FAISS's print order of the pure lists: equal values by stored id -- ascending for L2, descending for inner product
+        outD = np.ascontiguousarray(rawD[:, :k]).copy()
+        outI = np.ascontiguousarray(rawI[:, :k]).copy()
+        neutral = np.float32(np.finfo(np.float32).max if is_l2 else -np.finfo(np.float32).max)
+        outD[outI < 0] = neutral
+        if not is_l2:
+            for q in range(outD.shape[0]):
+                a = 0
+                while a < k:
+                    b = a + 1
+                    while b < k and outI[q, b] >= 0 and outI[q, a] >= 0 and outD[q, b] == outD[q, a]:
+                        b += 1
+                    if b - a > 1:
+                        outI[q, a:b] = outI[q, a:b][::-1]
+                    a = b
+        for f in range(nf):
+            q = int(flagged[f])
+            Tq = rawD[q, k - 1]
+            e = em[:, f].reshape(-1, 3)
+            e = e[e[:, 1] >= 0]
+            ev = e[:, 0].astype(np.int32).view(np.float32)
+            order = np.lexsort((e[:, 1], e[:, 2]))[:k]  # A_k: the first k of the union by (probe rank, id)
+            av, aid = ev[order], e[order, 1]
+            better = (rawD[q, :k] < Tq) if is_l2 else (rawD[q, :k] > Tq)
+            better &= rawI[q, :k] >= 0
+            res = list(zip(rawD[q, :k][better].tolist(), rawI[q, :k][better].tolist()))
+            nbetter = len(res)
+            in_ak = int(np.count_nonzero((av < Tq) if is_l2 else (av > Tq)))
+            tied = np.sort(aid[av == Tq])
+            gev = nbetter - in_ak  # rows better than T that arrived after A_k was complete: each evicted a tied row
+            nt = len(tied)
+            if is_l2:  # the gev LARGEST ids were evicted; ascending id
+                keep = tied[: max(nt - gev, 0)].tolist()
+            else:  # the gev SMALLEST ids were evicted; printed in descending id
+                keep = tied[gev:][::-1].tolist()
+                a = 0
+                while a < nbetter:  # (the better part came out of the pure order: equal scores print in descending id)
+                    b = a + 1
+                    while b < nbetter and res[b][0] == res[a][0]:
+                        b += 1
+                    res[a:b] = res[a:b][::-1]
+                    a = b
+            res += [(float(Tq), int(t)) for t in keep]
+            for j in range(k):
+                if j < len(res):
+                    outD[q, j], outI[q, j] = np.float32(res[j][0]), res[j][1]
+                else:
+                    outD[q, j], outI[q, j] = neutral, -1
+        return outD, outI

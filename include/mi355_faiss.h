@@ -179,6 +179,20 @@ int mvs_index_tie_candidates_device(mvs_index *ix, int64_t nf, const float *d_xf
 int mvs_finish_ip_ties(int64_t n, int64_t k, int64_t kk, const float *raw_D, const int64_t *raw_I, int64_t nf,
                        const int64_t *flagged, const int64_t *first_rows, float *D_out, int64_t *I_out);
 
+/* ---- IVF exact distance ties across PROCESSES (round 5; DESIGN.md 3.5 "row-sharded IVF") ----------------------------------
+ * FAISS's IVFFlatScanner feeds a heap in ARRIVAL order -- probe rank of the list, then position in the list
+ * (IndexIVF::search_preassigned behind /root/reference/src/faiss_extension.cpp:631) -- so which rows tied at the k-th value
+ * survive depends on arrival order.  A row shard hands over its k + 1 best in the PURE order (option "ivf_exact_ties" = 0,
+ * search with k + 1, stored ids = global rows); for a query whose merged k-th and (k + 1)-th values are bit-equal every
+ * rank reports its first k rows NOT WORSE than T in arrival order -- value, stored id, probe rank of the list (-1 padded) --
+ * and the merge rank takes the first k of the union by (probe rank, id) = A_k and applies the closed form of csrc/ivf_ties.hip
+ * (pyhost/sharded.py merge_ivf_exact; the in-library ShardedIndex does the same in resolve_ties_ivf).
+ * d_flag = {nf, query numbers ...} on the device; d_x = the WHOLE batch of the search that has just run on this index (its coarse
+ * assignment is reused: the call must follow that search directly); d_T [nf]; outputs [nf][k]. */
+int mvs_index_ivf_tie_emit_device(mvs_index *ix, int64_t nf, const int *d_flag, const float *d_x, const float *d_T, int64_t k,
+                                  float *d_v_out, int64_t *d_id_out, int *d_rank_out, const mvs_search_params *params,
+                                  void *stream);
+
 /* ---- synthetic data (counter-based, identical on host oracle and device) and diagnostics -------- */
 int mvs_synth_uniform_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, void *stream);
 int mvs_synth_clustered_device(float *d_out, int64_t n_rows, int d, uint64_t seed, int64_t row0, int n_centers,

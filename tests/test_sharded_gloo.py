@@ -157,3 +157,93 @@ def test_query_groups_times_row_shards_equal_unsharded(world, qgroups):
     mp.spawn(_qgroup_worker, args=(world, port, qgroups, ret), nprocs=world, join=True)
     assert ret["shape"] == (45, 10) and ret["layout"] == (qgroups, world // qgroups), dict(ret)
     assert ret["same_D"] and ret["same_I"], dict(ret)
+
+
+def _ivf_tie_worker(rank, world, port, metric, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from sharded import ShardExchange, shard_bounds
+
+    orc.set_num_threads(2)
+    is_l2 = metric == orc.METRIC_L2
+    n, d, nq, k, nlist, nprobe = 9000, 16, 60, 10, 16, 4
+    rs = np.random.RandomState(5)
+    xb = rs.randint(-2, 3, size=(n, d)).astype(np.float32)  # integer coordinates: every distance is exact in f32, ties are real ties
+    dup = rs.randint(0, n, n * 3 // 10)
+    xb[dup] = xb[rs.randint(0, n, len(dup))]
+    xq = np.concatenate([rs.randint(-2, 3, size=(nq - 20, d)).astype(np.float32), xb[rs.randint(0, n, 20)]])
+    one = orc.Index(d, f"IVF{nlist},Flat", metric)
+    one.train(xb)
+    one.add(xb)
+    # the shard of this rank, stood in for by numpy (no GPU here): list l of the shard = the rows of the unsharded list l that
+    # fall into [r0, r1), in insertion order; probe order = the coarse quantiser's (an exact Flat search over the centroids)
+    r0, r1 = shard_bounds(n, rank, world)
+    lists = []
+    for l in range(nlist):
+        ids, codes = one.ivf_list(l)
+        m = (ids >= r0) & (ids < r1)
+        lists.append((ids[m], codes[m]))
+    _, probes = orc.flat_search(metric, one.ivf_centroids(), xq, nprobe)
+
+    def value(x, rows):
+        return ((x[None, :] - rows) ** 2).sum(axis=1).astype(np.float32) if is_l2 else (rows @ x).astype(np.float32)
+
+    def arrival(q):
+        """(value, id, probe rank) of every row of this shard the query visits, in arrival order"""
+        v, i, p = [], [], []
+        for pr, l in enumerate(probes[q]):
+            if l < 0:
+                continue
+            ids, codes = lists[int(l)]
+            v.append(value(xq[q], codes)), i.append(ids), p.append(np.full(len(ids), pr, dtype=np.int64))
+        return np.concatenate(v), np.concatenate(i), np.concatenate(p)
+
+    kk = k + 1
+    D = np.full((nq, kk), np.finfo(np.float32).max if is_l2 else -np.finfo(np.float32).max, dtype=np.float32)
+    I = np.full((nq, kk), -1, dtype=np.int64)
+    for q in range(nq):
+        v, i, _ = arrival(q)
+        o = np.lexsort((i, v if is_l2 else -v))[:kk]  # the shard's k + 1 best in the pure order
+        D[q, : len(o)], I[q, : len(o)] = v[o], i[o]
+
+    def tie_emit(fq, T):
+        nf = len(fq)
+        ev = np.zeros((nf, k), dtype=np.float32)
+        ei = np.full((nf, k), -1, dtype=np.int64)
+        ep = np.full((nf, k), -1, dtype=np.int32)
+        for f in range(nf):
+            v, i, p = arrival(int(fq[f]))
+            keep = np.nonzero(v <= T[f].item() if is_l2 else v >= T[f].item())[0][:k]
+            ev[f, : len(keep)], ei[f, : len(keep)], ep[f, : len(keep)] = v[keep], i[keep], p[keep]
+        return torch.from_numpy(ev), torch.from_numpy(ei), torch.from_numpy(ep)
+
+    xch = ShardExchange(nq, k, "cpu", ip_ties=True)  # (k + 1 entries per shard)
+    Dm, Im = xch.merge_ivf_exact(metric, torch.from_numpy(D), torch.from_numpy(I), tie_emit)
+    if rank == 0:
+        Dr, Ir = one.search(xq, k, nprobe=nprobe)
+        D11, _ = one.search(xq, k + 1, nprobe=nprobe)
+        ret["same_D"] = bool(np.array_equal(Dm, Dr))
+        ret["same_I"] = bool(np.array_equal(Im, Ir))
+        ret["tied_queries"] = int((D11[:, k - 1] == D11[:, k]).sum())
+        ret["bad"] = [int(q) for q in np.nonzero((Im != Ir).any(axis=1))[0][:5]]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("world", [2, 3])
+def test_ivf_row_shards_exact_ties_across_processes(metric, world):
+    """VERDICT r4 #5b: the one-process-per-GPU host merged IVF shards in the pure order; FAISS's scanner heap keeps the rows tied at
+    the k-th value by ARRIVAL order (probe rank, then list position).  ShardExchange.merge_ivf_exact runs the cross-process
+    protocol (include/mi355_faiss.h); integer coordinates with 30 % duplicated rows tie most queries at rank k -- every query must
+    equal the oracle's unsharded IVF search."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 34900 + (os.getpid() % 2000) + 11 * world + metric
+    mp.spawn(_ivf_tie_worker, args=(world, port, metric, ret), nprocs=world, join=True)
+    assert ret["tied_queries"] > 10, dict(ret)
+    assert ret["same_D"] and ret["same_I"], dict(ret)
