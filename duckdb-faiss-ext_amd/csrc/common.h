@@ -150,6 +150,14 @@ void launch_gather_query_rows(const float *d_x, int d, const int *d_fq, int nf, 
 void launch_scatter_rows(const int *d_fq, int nf, int64_t k, const float *d_Df, const int64_t *d_If, float *d_D,
                          int64_t *d_I, hipStream_t st);
 
+// Flat shadow (ARITH = 2): query norms, row norms (k-ordered chains of the ORIGINAL rows, by position in the list-sorted store) and
+// the rows' numbers in the Flat index -- the key's low word is the ROW NUMBER, so that equal values order by id as FAISS's L2 heap does
+struct IvfFlatArith {
+	const float *qn;
+	const float *yn;
+	const long long *rowids;
+};
+
 // ---- per-index tuning (round 5): every knob that used to be a process-wide `g_*` int --------------------------------------------
 // An index owns one Tuning (IndexBase::tune_); IndexBase::use_device() -- the first statement of every entry point -- makes it the
 // calling thread's current one, and the launch functions read tune().x.  Two indexes searched from two threads neither share

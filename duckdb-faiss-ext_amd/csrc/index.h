@@ -107,6 +107,11 @@ public:
 	// rank, -1 padded (csrc/ivf_ties.hip EMIT mode)
 	virtual void tie_emit(const int *d_flag, int nf, const float *d_x, const float *d_T, int64_t k, const mvs_search_params *params,
 	                      const int64_t *d_idmap_sel, float *d_v, int64_t *d_id, int *d_p, hipStream_t st);
+	// an IVF index as the internal clustering of a Flat L2 index (csrc/ivf.hip flat_shadow_search); false: not run
+	virtual bool flat_shadow_search(int64_t, const float *, int64_t, const float *, float *, int64_t *, const int64_t *, int64_t,
+	                                const unsigned *, int *, int *, int, hipStream_t) {
+		return false;
+	}
 	virtual void to_device(int new_device) = 0;
 	virtual IndexBase *clone(int on_device) = 0; // deep copy living on `on_device`
 	virtual void to_host(HostIndex &out) = 0;    // host image (write_index, cross-device clone)
@@ -201,6 +206,17 @@ public:
 	// IVF coarse quantisation: the np nearest rows (L2, FAISS order) by distance matrix + selection (csrc/coarse_select.hip);
 	// false: shape not served, the caller uses search_device
 	bool coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st);
+	// what the last coarse_topk left behind (csrc/ivf.hip flat_shadow_search): the [nq][ntotal] distance matrix -- whole only when
+	// the batch fitted one chunk --, and the rows' squared norms
+	const float *coarse_matrix() const {
+		return (const float *)ws_q.p;
+	}
+	bool coarse_matrix_covers(int64_t nq) const {
+		return ntotal > 0 && nq <= std::max<int64_t>(64, ((int64_t)512 << 20) / (ntotal * 4) / 64 * 64);
+	}
+	const float *row_norms() const {
+		return norms;
+	}
 	// defer_count: nothing waits for the candidate count between the scan and the re-scoring (device-count mode); the count is
 	// copied to h_flag_count[10..11] asynchronously and the caller checks it against cl_deferred_cap after ITS stream
 	// synchronisation -- on an overflow it runs the search again with defer_count = false (the synchronous overflow handling)
@@ -211,6 +227,36 @@ public:
 	bool cl_prep1 = true;        // option cl_prep1: one fused per-query preparation kernel in front of the d <= 128 coarse filter
 	double cl_est_per_query = 0; // candidates per query of the last search: sizes the next search's sort (collect_sort_estimate)
 	int cl_skip = 0, cl_skip_len = 0; // searches that bypass the coarse filter after it gave up on this index's data (doubling, <= 64)
+	// ---- shadow clustering (round 5): a Flat L2 index whose rows CLUSTER keeps an IVF index of the same rows and answers large
+	// batches through it -- nprobe nearest lists by the coarse filter with per-list centring, then a proof per query that no other
+	// list can matter; what cannot be proven is re-run on the Flat kernels.  Built lazily when the global-centring filter admits
+	// thousands of candidates per query (clustered rows with large norms: 9 764 at the C3 mixture, 45.6 ms per batch).
+	IndexBase *shadow = nullptr;
+	int64_t shadow_rows = -1;  // ntotal the shadow holds
+	int shadow_state = 0;      // 0 not wanted yet, 1 wanted / in use, -1 given up on this data (too many queries could not be proven)
+	int shadow_mode = -1;      // option flat_shadow: -1 auto, 0 never, 1 from the first large search on
+	int shadow_nprobe = 32;    // option flat_shadow_nprobe
+	int64_t shadow_queries = 0, shadow_unproven = 0;
+	bool shadow_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                   const int64_t *d_idmap, const int64_t *out_map, int64_t out_off, hipStream_t st);
+	void drop_shadow();
+	void set_timing(bool on) override {
+		timing_enabled = on;
+		if (shadow)
+			shadow->set_timing(on);
+	}
+	void resolve_timing(int *count, double *total_ms) override { // (the dominant kernel of a shadow search is timed by the shadow index)
+		resolve_kernel_timing(count, total_ms);
+		if (shadow) {
+			int c2 = 0;
+			double t2 = 0;
+			shadow->resolve_timing(&c2, &t2);
+			if (count)
+				*count += c2;
+			if (total_ms)
+				*total_ms += t2;
+		}
+	}
 	void drop_bf16_rows();
 	bool search_prefilter(int64_t nq, const float *d_x, int64_t k_user, int64_t kk, float *d_D, int64_t *d_I,
 	                      const mvs_search_params *params, const int64_t *d_idmap, const int64_t *out_map, int64_t out_off,
@@ -410,7 +456,12 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               const float *d_rows_csr, int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi,
                               const int64_t *d_rowids, const int64_t *d_idmap, int k, float *d_D, int64_t *d_I,
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
-                              int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st);
+                              int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa = nullptr,
+                              int64_t label_offset = 0);
+void launch_ivf_shadow_verify(const float *d_cmat, const float *d_cD, const int64_t *d_cI, int64_t nq, int nlist, int np, int d, int k,
+                              const float *d_qn, const float *d_cn, const unsigned *d_list_max, const int64_t *d_lb, const int64_t *d_le,
+                              const float *d_D, const int64_t *d_I, const unsigned *d_ymax_bits, int *d_fail_cnt, int *d_fail_q,
+                              hipStream_t st);
 size_t ivf_rowmask_bytes(int64_t nrows_mf);
 void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
                         void *d_mask, hipStream_t st);

@@ -265,6 +265,8 @@ FlatIndex::FlatIndex(int d_, int metric_) : IndexBase(MVS_KIND_FLAT, d_, metric_
 	is_trained = true;
 }
 FlatIndex::~FlatIndex() {
+	delete shadow;
+	shadow = nullptr;
 	(void)hipSetDevice(device);
 	if (stream)
 		(void)hipStreamSynchronize(stream);
@@ -910,6 +912,10 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		return false;
 	if (ntotal < 4096 || ntotal <= kk)
 		return false;
+	// Rows that cluster (round 5): through the shadow IVF index, when one is wanted (see FlatIndex::shadow_search)
+	if (metric == METRIC_L2 && !has_sel && !flp && kk == k_user && nq >= 256 && shadow_mode != 0 && (shadow_state == 1 || shadow_mode == 1) &&
+	    shadow_search(nq, d_x, k_user, d_D, d_I, params, d_idmap, out_map, out_off, st))
+		return true;
 	ws_fail.reserve(64 + (size_t)nq * sizeof(int));
 	int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
 	MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
@@ -1021,6 +1027,11 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	pf_last_fallback = nf;
 	pf_queries_total += nq;
 	pf_fallback_total += nf;
+	// the global-centring filter admits thousands of rows per query: this data clusters (or is badly conditioned) -- the next large
+	// search goes through a shadow IVF index of the rows (built then; FlatIndex::shadow_search)
+	if (collected && shadow_state == 0 && shadow_mode < 0 && metric == METRIC_L2 && !has_sel && nq >= 256 && ntotal >= 262144 && d % 32 == 0 &&
+	    d <= 128 && kk <= 32 && cl_last_candidates > 600 * nq)
+		shadow_state = 1;
 	memcpy(&pf_max_rel_err, h_flag_count + 9, sizeof(float));
 	if (nf > 0) {
 		// queries whose candidate set could not be proven complete: the exact kernel decides (results overwrite theirs)
@@ -1046,6 +1057,106 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		pf_suppressed = false;
 		timing_enabled = timing;
 		launch_scatter_rows(fail_q, nf, k_user, Df, If, d_D, d_I, st);
+		kinfo = keep;
+	}
+	return true;
+}
+
+// ---- shadow clustering of a Flat L2 index (round 5) ------------------------------------------------------------------
+// The coarse filter's error bound scales with ||x - mu|| ||y - mu|| for ONE centre mu.  Rows that form clusters far from each other
+// (embeddings; the C3 mixture: 1024 centres of norm^2 ~ 128, neighbours at distance^2 ~ 2.6) leave 2E larger than the spread of
+// distances inside the query's cluster: the whole cluster is admitted (9 764 candidates per query, 45.6 ms per 10k batch against
+// 17.3 on uniform rows).  The cure is the IVF index's per-list centring -- so the Flat index keeps one: k-means over its rows
+// (sqrt(N) lists), the rows list by list as bf16 residuals, and a large batch runs
+//   1. the IVF coarse filter over the nprobe nearest lists (C3's kernels), candidates re-scored with THIS index's arithmetic
+//      ((xn + yn) - 2 ip on the original rows, ties by row number) -- the result is exact IF no other list holds a better row;
+//   2. the proof, per query, that none does: every row of list j is at least ||x - c_j|| - r_j away (ivf_shadow_verify_kernel);
+//   3. the queries that cannot be proven (none on clustered rows; all on uniform rows) again on the Flat kernels.
+// More than a tenth of a batch unproven: the data does not cluster, the shadow is dropped for good.  false: the batch takes the normal path.
+void FlatIndex::drop_shadow() {
+	delete shadow;
+	shadow = nullptr;
+	shadow_rows = -1;
+}
+bool FlatIndex::shadow_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+                              const int64_t *d_idmap, const int64_t *out_map, int64_t out_off, hipStream_t st) {
+	if (d % 32 != 0 || d > 128 || k > 32 || ntotal < 65536 || ntotal >= ((int64_t)1 << 31) || ntotal <= k)
+		return false;
+	if (shadow && shadow_rows != ntotal)
+		drop_shadow(); // (rows were added: rebuilt below)
+	if (!shadow) {
+		MVS_HIP(hipStreamSynchronize(st));
+		int lg = 0;
+		while (((int64_t)1 << (2 * lg + 1)) < ntotal) // nlist = the power of two nearest to sqrt(N) (N = 10 M: 4 096)
+			++lg;
+		const int64_t nl = std::min<int64_t>(8192, std::max<int64_t>(256, (int64_t)1 << lg));
+		std::vector<float> rows((size_t)ntotal * d);
+		copy_rows_to_host(rows.data());
+		std::unique_ptr<IndexBase> iv(make_ivf_index(d, "IVF" + std::to_string(nl) + ",Flat", METRIC_L2));
+		if (!iv)
+			return false;
+		iv->train(ntotal, rows.data());
+		for (int64_t r0 = 0; r0 < ntotal; r0 += (int64_t)1 << 20)
+			iv->add(std::min<int64_t>((int64_t)1 << 20, ntotal - r0), rows.data() + (size_t)r0 * d);
+		shadow = iv.release();
+		shadow_rows = ntotal;
+		shadow->set_timing(timing_enabled);
+		use_device();
+	}
+	ensure_h1_rows(st); // (the proof needs the largest ||y||^2 of the rows: d_max_norm_bits[0], kept with the coarse filter's store)
+	ws_qn.reserve((size_t)nq * sizeof(float));
+	ws_fail.reserve(64 + (size_t)nq * sizeof(int));
+	int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
+	MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
+	if (!shadow->flat_shadow_search(nq, d_x, k, (const float *)ws_qn.p, d_D, d_I, out_map, out_off, d_max_norm_bits, fail_cnt, fail_q,
+	                                shadow_nprobe, st)) {
+		// (the candidate stream / a bucket beyond their limits -- rows stored thousands of times -- or a batch the coarse quantiser
+		// does not take: the shadow cannot serve this data; not asked again)
+		use_device();
+		shadow_state = -1;
+		drop_shadow();
+		return false;
+	}
+	use_device();
+	if (!h_flag_count)
+		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
+	MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+	MVS_HIP(hipStreamSynchronize(st));
+	const int nf = h_flag_count[8];
+	shadow_queries += nq;
+	shadow_unproven += nf;
+	kinfo = shadow->kinfo;
+	snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel (flat shadow)");
+	if ((int64_t)nf * 10 > nq) { // the lists of this data overlap: nothing is gained (uniform rows: every query) -- never again
+		shadow_state = -1;
+		drop_shadow();
+		return false;
+	}
+	pf_last_fallback = nf;
+	pf_queries_total += nq;
+	pf_fallback_total += nf;
+	if (nf > 0) { // the unproven queries: the Flat kernels decide (results overwrite theirs)
+		const mvs_kernel_info keep = kinfo;
+		const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
+		const size_t df_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
+		ws_fb.reserve(xf_bytes + df_bytes + (size_t)nf * k * sizeof(int64_t));
+		float *xf = (float *)ws_fb.p;
+		float *Df = (float *)((char *)ws_fb.p + xf_bytes);
+		int64_t *If = (int64_t *)((char *)Df + df_bytes);
+		launch_gather_query_rows(d_x, d, fail_q, nf, xf, st);
+		const int keep_state = shadow_state, keep_mode = shadow_mode;
+		shadow_state = 0, shadow_mode = 0; // (the re-run must not come back here)
+		const bool timing = timing_enabled;
+		timing_enabled = false;
+		try {
+			search_flat(nf, xf, k, Df, If, params, d_idmap, st);
+		} catch (...) {
+			shadow_state = keep_state, shadow_mode = keep_mode, timing_enabled = timing;
+			throw;
+		}
+		shadow_state = keep_state, shadow_mode = keep_mode, timing_enabled = timing;
+		launch_scatter_rows(fail_q, nf, k, Df, If, d_D, d_I, st);
 		kinfo = keep;
 	}
 	return true;
@@ -2047,6 +2158,16 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "cl_k32")) {
 		cl_k32 = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "flat_shadow")) { // -1 auto (built when the coarse filter admits thousands of rows per query), 0 never, 1 at once
+		shadow_mode = (int)v;
+		if (v != 0 && shadow_state < 0)
+			shadow_state = 0;
+		return true;
+	}
+	if (!strcmp(key, "flat_shadow_nprobe")) {
+		shadow_nprobe = (int)std::max<int64_t>(1, v);
 		return true;
 	}
 	if (!strcmp(key, "cl_prep1")) { // 0: round 4's separate query-preparation kernels (A/B)

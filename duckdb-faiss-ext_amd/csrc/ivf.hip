@@ -914,6 +914,8 @@ public:
 			cl_cap_try = 0;
 			for (int attempt = 0; attempt < 6; ++attempt) {
 				bool overflow = false;
+				if (shadow && attempt > 0) // (the caller's fail list holds the abandoned attempt's entries)
+					MVS_HIP(hipMemsetAsync(shadow->fail_cnt, 0, sizeof(int), stream));
 				const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, true, &overflow);
 				if (!overflow)
 					return ok;
@@ -1085,7 +1087,20 @@ public:
 			// ONE kernel: exact values, selection, and (inside the exact-tie wrapper) FAISS's print order + boundary flags; the tie pass
 			// for the flagged queries is enqueued behind it, BEFORE the search's one synchronisation (rounds 3-4 launched the finish
 			// kernel and the tie pass after it: two launch latencies with the GPU idle)
-			const bool fin = raw_pos && fin_D != nullptr && kk == fin_k + 1;
+			const bool fin = raw_pos && fin_D != nullptr && kk == fin_k + 1 && !shadow;
+			if (shadow) {
+				// Flat shadow: the candidates re-scored in the FLAT index's arithmetic, labels = Flat row numbers, the fail list is the
+				// caller's; then the proof that no unprobed list matters (csrc/ivf_collect.hip ivf_shadow_verify_kernel)
+				IvfFlatArith fa;
+				fa.qn = shadow->qn, fa.yn = (const float *)norms_csr.p, fa.rowids = (const long long *)rowids.p;
+				launch_ivf_bucket_finish(METRIC_L2, strm, cap_entries, cnt, sorted, (unsigned *)ctl_seg, bpitch, nq, d_x, d, (const float *)codes.p,
+				                         dp, (const int *)perm_mf.p, kk, d_D, d_I, nullptr, shadow->out_map, 0, nullptr, nullptr, nullptr, nullptr,
+				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off);
+				FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
+				launch_ivf_shadow_verify(qz->coarse_matrix(), (const float *)ws_cD.p, (const int64_t *)ws_cI.p, nq, (int)nlist, (int)np, d, kk,
+				                         shadow->qn, qz->row_norms(), (const unsigned *)list_max.p, (const int64_t *)lb_dev.p,
+				                         (const int64_t *)le_dev.p, d_D, d_I, shadow->ymax_bits, shadow->fail_cnt, shadow->fail_q, stream);
+			} else
 			launch_ivf_bucket_finish(metric, strm, cap_entries, cnt, sorted /* the buckets */, (unsigned *)ctl_seg, bpitch, nq, d_x, d,
 			                         (const float *)codes.p, dp, (const int *)perm_mf.p, kk, d_D, d_I, raw_pos ? nullptr : (const int64_t *)rowids.p,
 			                         (d_idmap && !raw_ids && !raw_pos) ? d_idmap : nullptr, fin ? (int)fin_k : 0, fin ? fin_D : nullptr,
@@ -1137,6 +1152,10 @@ public:
 			cl_candidates_total += (int64_t)nstream;
 			cl_est_per_query = (double)nstream / (double)std::max<int64_t>(nq, 1) + 1e-6;
 			fin_done = fin;
+			if (shadow) { // (the fail list is the caller's: it re-runs those queries on the Flat kernels)
+				stream_wait(st, stream);
+				return true;
+			}
 		}
 		unsigned long long ncand_u = 0;
 		if (!bucket) {
@@ -1712,6 +1731,59 @@ public:
 	bool collect_k32 = true; // option ivf_collect_k32: 16 < k <= 32 with 32 row classes (0: the scanner kernel as in round 2)
 	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always, 2 = L2 prefilter + exact re-scoring
 
+	// ---- Flat shadow (round 5; csrc/index.hip FlatIndex::shadow_search) ---------------------------------------------------------
+	// This index as the internal clustering of a Flat L2 index: nprobe nearest lists through the coarse filter, candidates re-scored
+	// in the Flat arithmetic, then a proof per query that the unprobed lists cannot matter (ivf_shadow_verify_kernel).  Queries that
+	// cannot be proven (and those whose bound was not finite) are appended to the caller's fail list.  false: the path did not run
+	// (stream / bucket beyond their limits, coarse quantiser not applicable) -- the caller takes its normal path for the batch.
+	struct ShadowCtx {
+		const float *qn;           // [nq] ||x||^2, k-ordered chains (the Flat index's re-scoring uses the same)
+		const int64_t *out_map;    // IDMap labels of the Flat rows, or nullptr
+		int64_t out_off;           // ... else label = row + out_off
+		const unsigned *ymax_bits; // the Flat index's largest ||y||^2
+		int *fail_cnt, *fail_q;
+	};
+	const ShadowCtx *shadow = nullptr;
+	DevBuf norms_csr; // ||y||^2 of every row by position in the list-sorted store (k-ordered chains: the Flat index's norms)
+	int64_t norms_csr_rows = -1;
+	bool flat_shadow_search(int64_t nq, const float *d_x, int64_t k, const float *d_qn, float *d_D, int64_t *d_I, const int64_t *d_out_map,
+	                        int64_t out_off, const unsigned *d_ymax_bits, int *d_fail_cnt, int *d_fail_q, int shadow_nprobe,
+	                        hipStream_t st) override {
+		use_device();
+		if (metric != METRIC_L2 || hnsw_M != 0 || d != dp || k > 32 || nq < 20 || ntotal <= k)
+			return false;
+		const int64_t np = std::min<int64_t>(shadow_nprobe, nlist);
+		if (nq * np >= ((int64_t)1 << 26))
+			return false;
+		stream_wait(stream, st);
+		build_lists_mf(false);
+		if (!have_bfr)
+			return false;
+		if (norms_csr_rows != nsorted) {
+			norms_csr.reserve((size_t)std::max<int64_t>(nsorted, 1) * sizeof(float));
+			launch_query_norms((const float *)codes.p, nsorted, d, (float *)norms_csr.p, stream);
+			norms_csr_rows = nsorted;
+		}
+		ws_cD.reserve((size_t)nq * np * sizeof(float));
+		ws_cI.reserve((size_t)nq * np * sizeof(int64_t));
+		FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
+		if (!qz->coarse_topk(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, stream) || !qz->coarse_matrix_covers(nq))
+			return false;
+		use_device();
+		ShadowCtx ctx;
+		ctx.qn = d_qn, ctx.out_map = d_out_map, ctx.out_off = out_off, ctx.ymax_bits = d_ymax_bits, ctx.fail_cnt = d_fail_cnt, ctx.fail_q = d_fail_q;
+		shadow = &ctx;
+		last_np = np;
+		bool ok = false;
+		try {
+			ok = collect_search(nq, d_x, k, d_D, d_I, nullptr, nullptr, st, np);
+		} catch (...) {
+			shadow = nullptr;
+			throw;
+		}
+		shadow = nullptr;
+		return ok;
+	}
 	// introspection for parity tests
 	void get_centroids(float *out) {
 		use_device();

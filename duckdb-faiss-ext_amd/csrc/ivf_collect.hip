@@ -1047,7 +1047,9 @@ __device__ __forceinline__ EbMeta eb_load_meta(const unsigned long long *__restr
 }
 // one half of a group: its 32 database rows and 32 query rows from registers into LDS, the 32 chains on lanes 0 .. 31, every
 // lane gets the value of lane (lane & 31).  (No barrier: one wavefront per workgroup, a wave's LDS operations execute in order.)
-template <bool IS_L2>
+// ARITH: 0 = the scanner's L2 (t = x_k - y_k, acc = fmaf(t, t, acc)), 1 = the inner-product chain, 2 = the chain for FAISS's BLAS-branch
+// L2 formula (Flat shadow, csrc/index.hip: the caller turns it into max(0, (xn + yn) - 2 ip))
+template <int ARITH>
 __device__ __forceinline__ float eb_half(float *yrows, float *xrows, const f32x4i (&ry)[16], const f32x4i (&rx)[16], int lane, int sub,
                                          int ch) {
 	// (f32x4i, the native vector type: whole-value copies of HIP's float4 STRUCT become memcpy calls that keep the buffers in
@@ -1069,7 +1071,7 @@ __device__ __forceinline__ float eb_half(float *yrows, float *xrows, const f32x4
 			const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
 			for (int e = 0; e < 4; ++e) {
-				if (IS_L2) {
+				if (ARITH == 0) {
 					const float t = __fsub_rn(xs[e], ys[e]);
 					a2 = fmaf(t, t, a2);
 				} else {
@@ -1082,13 +1084,26 @@ __device__ __forceinline__ float eb_half(float *yrows, float *xrows, const f32x4
 	asm volatile("" ::: "memory");
 	return got;
 }
-template <bool IS_L2>
+template <int ARITH>
+__device__ __forceinline__ unsigned long long eb_key(float acc, int pos, long long q, const IvfFlatArith &fa) {
+	constexpr bool L2KEY = ARITH != 1;
+	float v = acc;
+	unsigned low = (unsigned)pos;
+	if (ARITH == 2 && pos >= 0) {
+		v = fmaf(-2.0f, acc, fa.qn[q] + fa.yn[pos]);
+		v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
+		low = (unsigned)fa.rowids[pos];
+	}
+	const bool ok = pos >= 0 && (L2KEY ? v < FLT_MAX : v > -FLT_MAX);
+	return ok ? (((unsigned long long)bkey<L2KEY>(v) << 32) | low) : CB_EMPTY;
+}
+template <int ARITH>
 __global__ __launch_bounds__(64) void ivf_exact_bucket_kernel(const unsigned long long *__restrict__ strm, long long ncand,
                                                              const unsigned long long *__restrict__ cnt,
                                                              const float *__restrict__ x, int d,
                                                              const float *__restrict__ rows_csr, int dp,
                                                              const int *__restrict__ perm, unsigned long long *__restrict__ bucket,
-                                                             unsigned *__restrict__ bcount, int bpitch) {
+                                                             unsigned *__restrict__ bcount, int bpitch, const IvfFlatArith fa) {
 	// d = dp = 128: the 64 entries of a group in two halves of 32; a half's 32 database rows AND its 32 query rows are staged
 	// through LDS with coalesced 512-byte loads (the stream is not sorted by query: a lane loading ITS query on its own touches 64
 	// cache lines per instruction), lanes 0 .. 31 run the chains of the half.  Both halves' 64 KB are requested at once into
@@ -1137,13 +1152,12 @@ __global__ __launch_bounds__(64) void ivf_exact_bucket_kernel(const unsigned lon
 			}
 			const EbMeta nxt = eb_load_meta(strm, i1, lane, ncand, bcount, perm); // (past the end: q = 0, pos = 0, no slot)
 			// (the half's 32 results sit in lanes 0 .. 31) lane 32 h + j takes the value lane j computed in half h
-			const float got0 = eb_half<IS_L2>(yrows, xrows, ry0, rx0, lane, sub, ch);
-			const float got1 = eb_half<IS_L2>(yrows, xrows, ry1, rx1, lane, sub, ch);
+			const float got0 = eb_half<ARITH>(yrows, xrows, ry0, rx0, lane, sub, ch);
+			const float got1 = eb_half<ARITH>(yrows, xrows, ry1, rx1, lane, sub, ch);
 			const float acc = sub == 0 ? got0 : got1;
 			if (i0 + lane < ncand) {
-				const bool ok = cur.pos >= 0 && (IS_L2 ? acc < FLT_MAX : acc > -FLT_MAX);
 				if (cur.slot < (unsigned)bpitch) // (entries past the bucket are only counted: the host grows the pitch and repeats the pass)
-					bucket[(size_t)cur.q * (size_t)bpitch + cur.slot] = ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)cur.pos) : CB_EMPTY;
+					bucket[(size_t)cur.q * (size_t)bpitch + cur.slot] = eb_key<ARITH>(acc, cur.pos, cur.q, fa);
 			}
 			cur = nxt;
 			i0 = i1;
@@ -1177,7 +1191,7 @@ __global__ __launch_bounds__(64) void ivf_exact_bucket_kernel(const unsigned lon
 					const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
 					for (int e = 0; e < 4; ++e) {
-						if (IS_L2) {
+						if (ARITH == 0) {
 							const float t = __fsub_rn(xs[e], ys[e]);
 							acc = fmaf(t, t, acc);
 						} else {
@@ -1187,16 +1201,15 @@ __global__ __launch_bounds__(64) void ivf_exact_bucket_kernel(const unsigned lon
 				}
 			}
 			for (; kd < d; ++kd) {
-				if (IS_L2) {
+				if (ARITH == 0) {
 					const float t = __fsub_rn(xq[kd], y[kd]);
 					acc = fmaf(t, t, acc);
 				} else {
 					acc = fmaf(xq[kd], y[kd], acc); // fvec_inner_product: the k-ordered chain
 				}
 			}
-			const bool ok = pos >= 0 && (IS_L2 ? acc < FLT_MAX : acc > -FLT_MAX);
 			if (slot < (unsigned)bpitch)
-				bucket[(size_t)q * (size_t)bpitch + slot] = ok ? (((unsigned long long)bkey<IS_L2>(acc) << 32) | (unsigned)pos) : CB_EMPTY;
+				bucket[(size_t)q * (size_t)bpitch + slot] = eb_key<ARITH>(acc, pos, q, fa);
 		}
 		__syncthreads(); // (the next group's rows overwrite the tile)
 	}
@@ -1209,8 +1222,9 @@ struct IvfBucketSelectArgs {
 	int kk;
 	float *pd;
 	long long *pi;
-	const long long *rowids; // labels of the pure list (nullptr: positions), then through idmap if given
+	const long long *rowids; // labels of the pure list (nullptr: the keys' low words as they are), then through idmap if given
 	const long long *idmap;
+	long long label_offset;  // ... or + this (Flat shadow: label_offset of the Flat index)
 	int k; // fin (D != nullptr): k < kk
 	float *D;
 	long long *I;
@@ -1255,10 +1269,10 @@ __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSe
 	if (lane < kk) {
 		a.pd[q * kk + lane] = val;
 		long long lab = ps;
-		if (ps >= 0 && a.rowids) {
-			lab = a.rowids[ps];
-			if (a.idmap)
-				lab = a.idmap[lab];
+		if (ps >= 0) {
+			if (a.rowids)
+				lab = a.rowids[ps];
+			lab = a.idmap ? a.idmap[lab] : lab + a.label_offset;
 		}
 		a.pi[q * kk + lane] = lab;
 	}
@@ -1296,37 +1310,122 @@ __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSe
 }
 // d_strm: the scan's candidate stream (ncand = its capacity or the host's count; the real number is min(*d_cnt, ncand));
 // d_bucket [nq][bpitch] keys, d_bcount [nq] (zeroed); outputs as ivf_bucket_select_kernel describes
+// fa != nullptr: the Flat shadow's arithmetic (see IvfFlatArith) -- the lists come out in FAISS's Flat L2 order, labels = row + label_offset
 void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int64_t ncand, const unsigned long long *d_cnt,
                               unsigned long long *d_bucket, unsigned *d_bcount, int bpitch, int64_t nq, const float *d_x, int d,
                               const float *d_rows_csr, int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi,
                               const int64_t *d_rowids, const int64_t *d_idmap, int k, float *d_D, int64_t *d_I,
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
-                              int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st) {
+                              int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa,
+                              int64_t label_offset) {
 	if (nq <= 0)
 		return;
 	if (dp_csr % 4 != 0 || dp_csr > 128 || kk > 64 || kk < 1)
 		throw_faiss("mvs::launch_ivf_bucket_finish", __FILE__, "row pitch %d / k %d is not served", dp_csr, kk);
 	const bool l2 = metric_order(metric) == METRIC_L2;
+	IvfFlatArith nofa;
+	memset(&nofa, 0, sizeof nofa);
 	if (ncand > 0) { // a fixed grid walks the stream in strides (its length is on the device): two dispatch rounds of the 4 096 resident waves
 		const dim3 grid((unsigned)std::min<int64_t>((ncand + 63) / 64, 8192));
-		if (l2)
-			hipLaunchKernelGGL(ivf_exact_bucket_kernel<true>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr,
-			                   dp_csr, d_perm, d_bucket, d_bcount, bpitch);
+		if (fa)
+			hipLaunchKernelGGL(ivf_exact_bucket_kernel<2>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr, dp_csr,
+			                   d_perm, d_bucket, d_bcount, bpitch, *fa);
+		else if (l2)
+			hipLaunchKernelGGL(ivf_exact_bucket_kernel<0>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr, dp_csr,
+			                   d_perm, d_bucket, d_bcount, bpitch, nofa);
 		else
-			hipLaunchKernelGGL(ivf_exact_bucket_kernel<false>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr,
-			                   dp_csr, d_perm, d_bucket, d_bcount, bpitch);
+			hipLaunchKernelGGL(ivf_exact_bucket_kernel<1>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr, dp_csr,
+			                   d_perm, d_bucket, d_bcount, bpitch, nofa);
 	}
 	IvfBucketSelectArgs a;
 	memset(&a, 0, sizeof a);
 	a.bucket = d_bucket, a.bcount = d_bcount, a.bpitch = bpitch, a.nq = nq, a.kk = kk;
 	a.pd = d_pd, a.pi = (long long *)d_pi, a.rowids = (const long long *)d_rowids, a.idmap = (const long long *)d_idmap;
+	a.label_offset = label_offset;
 	a.k = k, a.D = d_D, a.I = (long long *)d_I, a.fin_rowids = (const long long *)d_fin_rowids, a.fin_idmap = (const long long *)d_fin_idmap;
 	a.flag_cnt = d_flag, a.flag_q = d_flag ? d_flag + 1 : nullptr, a.stats = d_stats;
 	a.qfail = d_qfail, a.fail_cnt = d_fail_cnt, a.fail_q = d_fail_q, a.reset = reset ? 1 : 0;
-	if (l2)
+	if (l2 || fa)
 		hipLaunchKernelGGL(ivf_bucket_select_kernel<true>, dim3((unsigned)nq), dim3(64), 0, st, a);
 	else
 		hipLaunchKernelGGL(ivf_bucket_select_kernel<false>, dim3((unsigned)nq), dim3(64), 0, st, a);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- Flat shadow (round 5): is the probed set PROVABLY enough? ------------------------------------------------------------------
+// A Flat L2 index whose rows are clustered keeps this IVF index as a shadow (csrc/index.hip FlatIndex::shadow_*): a search probes
+// the nprobe nearest lists exactly as C3 does, re-scores in the Flat arithmetic, and this kernel then checks, per query, that no
+// UNPROBED list can hold a row that belongs into the result.  Every row y of list j satisfies (triangle inequality)
+//        ||x - y|| >= ||x - c_j|| - ||y - c_j|| >= ||x - c_j|| - r_j,           r_j = the list's largest residual norm,
+// so list j is out as soon as  (sqrt(cd_j - e_c) - r_j (1 + 1e-4))^2 (1 - 1e-6) > D_k + e_f  with
+//   cd_j  the computed coarse distance ((xn + cn) - 2 ip, the matrix of csrc/coarse_select.hip), e_c = 2 (d + 2) u (||x|| + ||c_j||)^2
+//         what that formula can be off by (Higham: d + 2 roundings of magnitudes <= (||x|| + ||c||)^2; factor 2 for slack),
+//   D_k   the k-th COMPUTED distance found so far, e_f = 2 (d + 2) u (||x|| + ||y||_max)^2 what a row's computed Flat distance can be
+//         below its true one -- a row with computed distance <= D_k (ties included) has true distance <= D_k + e_f.
+// All in double.  A query with fewer than k results, a non-finite anything, or ONE list that cannot be excluded joins the fail list:
+// the caller re-runs it on the Flat kernels.  One wavefront per query.
+struct IvfShadowVerifyArgs {
+	const float *cmat;     // [nq][nlist] computed coarse distances
+	const float *cD;       // [nq][np] the probed lists' distances, ascending
+	const long long *cI;   // [nq][np] the probed lists
+	int nlist, np, d, k;
+	const float *qn;       // [nq] ||x||^2
+	const float *cn;       // [nlist] ||c||^2
+	const unsigned *list_max; // [nlist] largest ||y - c||^2 of every list (bit pattern)
+	const long long *lb, *le; // padded row range of every list (empty: lb == le)
+	const float *D;        // [nq][k] the results
+	const long long *I;
+	const unsigned *ymax_bits; // the Flat index's largest ||y||^2 (bit pattern)
+	int *fail_cnt;
+	int *fail_q;
+};
+__global__ __launch_bounds__(64) void ivf_shadow_verify_kernel(const IvfShadowVerifyArgs a) {
+	const long long q = blockIdx.x;
+	const int lane = threadIdx.x;
+	const double u = 5.9604644775390625e-08;
+	const float Dk = a.D[q * a.k + a.k - 1];
+	const bool have = a.I[q * a.k + a.k - 1] >= 0;
+	const double xn = (double)a.qn[q], nx = sqrt(xn > 0 ? xn : 0.0);
+	const double ny = sqrt((double)__uint_as_float(*a.ymax_bits));
+	const double ef = 2.0 * (a.d + 2.0) * u * (nx + ny) * (nx + ny);
+	const double thr = (double)Dk + ef;
+	const float cdl = a.cD[q * a.np + a.np - 1];
+	bool bad = !have || !(thr == thr) || !(xn == xn) || !(Dk < FLT_MAX);
+	for (int j = lane; j < a.nlist && !bad; j += 64) {
+		if (a.lb[j] == a.le[j])
+			continue; // an empty list holds nothing
+		const float cd = a.cmat[q * a.nlist + j];
+		bool probed = cd < cdl;
+		if (cd == cdl) {
+			for (int p = 0; p < a.np; ++p)
+				probed |= a.cI[q * a.np + p] == (long long)j;
+		}
+		if (probed)
+			continue;
+		const double cnj = (double)a.cn[j], nc = sqrt(cnj > 0 ? cnj : 0.0);
+		const double ec = 2.0 * (a.d + 2.0) * u * (nx + nc) * (nx + nc);
+		const double lo = (double)cd - ec;
+		const double A = lo > 0 ? sqrt(lo) : 0.0;
+		const double R = sqrt((double)__uint_as_float(a.list_max[j])) * 1.0001;
+		const double gap = A - R;
+		const bool out = gap > 0 && gap * gap * (1.0 - 1e-6) > thr; // (NaN anywhere: false)
+		bad |= !out;
+	}
+	if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0)
+		a.fail_q[atomicAdd(a.fail_cnt, 1)] = (int)q;
+}
+void launch_ivf_shadow_verify(const float *d_cmat, const float *d_cD, const int64_t *d_cI, int64_t nq, int nlist, int np, int d, int k,
+                              const float *d_qn, const float *d_cn, const unsigned *d_list_max, const int64_t *d_lb, const int64_t *d_le,
+                              const float *d_D, const int64_t *d_I, const unsigned *d_ymax_bits, int *d_fail_cnt, int *d_fail_q,
+                              hipStream_t st) {
+	if (nq <= 0)
+		return;
+	IvfShadowVerifyArgs a;
+	memset(&a, 0, sizeof a);
+	a.cmat = d_cmat, a.cD = d_cD, a.cI = (const long long *)d_cI, a.nlist = nlist, a.np = np, a.d = d, a.k = k, a.qn = d_qn, a.cn = d_cn;
+	a.list_max = d_list_max, a.lb = (const long long *)d_lb, a.le = (const long long *)d_le, a.D = d_D, a.I = (const long long *)d_I;
+	a.ymax_bits = d_ymax_bits, a.fail_cnt = d_fail_cnt, a.fail_q = d_fail_q;
+	hipLaunchKernelGGL(ivf_shadow_verify_kernel, dim3((unsigned)nq), dim3(64), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
 

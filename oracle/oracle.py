@@ -35,6 +35,12 @@ class _Params(C.Structure):
     ]
 
 
+def hnsw_set_pop_min_rule(rule):
+    """tie rule of the search walk's MinimaxHeap::pop_min: 0 = FAISS's heap-array order (default), 1 = smallest id among equal
+    minima (what the device walk does) -- oracle/orc_hnsw.c"""
+    lib().orc_hnsw_set_pop_min_rule(int(rule))
+
+
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("orc_core.c", "orc_hnsw.c", "orc.h", "orc_internal.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):

@@ -90,6 +90,9 @@ int orc_ivf_get_list(const orc_index *ix, int64_t list_no, int64_t *ids, float *
 
 /* HNSW (orc_hnsw.c): efConstruction setter (src/faiss_extension.cpp:136-139) and graph export for parity tests */
 int orc_hnsw_set_ef_construction_ix(orc_index *ix, int v);
+/* tie rule of MinimaxHeap::pop_min in the search walk: 0 = FAISS's array order (default), 1 = smallest id (the device walk's) */
+void orc_hnsw_set_pop_min_rule(int rule);
+int orc_hnsw_get_pop_min_rule(void);
 int64_t orc_hnsw_graph_size(orc_index *ix, int *max_level, int32_t *entry_point); /* total neighbor slots, -1 if not HNSW */
 int orc_hnsw_get_graph(orc_index *ix, int *levels, int64_t *offsets, int32_t *neighbors);
 int orc_hnsw_set_graph(orc_index *ix, int64_t n, const float *x, const int *levels, const int64_t *offsets,

@@ -524,6 +524,18 @@ static void mm_push(mmh_t *m, int32_t i, float v) {
 	mm_heap_push(++m->k, m->dis, m->ids, v, i);
 	++m->nvalid;
 }
+/* Which of several EQUAL minima pop_min takes.  0 (default) = FAISS: the heap ARRAY is scanned from the back and only a strictly
+ * smaller distance replaces the current pick, so the winner is whichever equal entry sits last in the array -- a function of the
+ * heap's memory layout (faiss/impl/HNSW.cpp MinimaxHeap::pop_min).  1 = the smallest id among the equal minima: the rule of the
+ * device walk (csrc/hnsw.hip keeps its candidates as (distance, id)-sorted arrays in registers).  The two differ only when two
+ * candidates are at bit-equal distance; bench.py's C5 line counts on how many queries that changes anything. */
+static int g_pop_min_rule = 0;
+void orc_hnsw_set_pop_min_rule(int rule) {
+	g_pop_min_rule = rule;
+}
+int orc_hnsw_get_pop_min_rule(void) {
+	return g_pop_min_rule;
+}
 static int32_t mm_pop_min(mmh_t *m, float *vmin_out) {
 	int i = m->k - 1;
 	while (i >= 0) {
@@ -537,7 +549,7 @@ static int32_t mm_pop_min(mmh_t *m, float *vmin_out) {
 	float vmin = m->dis[i];
 	i--;
 	while (i >= 0) {
-		if (m->ids[i] != -1 && m->dis[i] < vmin) {
+		if (m->ids[i] != -1 && (m->dis[i] < vmin || (g_pop_min_rule == 1 && m->dis[i] == vmin && m->ids[i] < m->ids[imin]))) {
 			vmin = m->dis[i];
 			imin = i;
 		}

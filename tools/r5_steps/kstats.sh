@@ -24,7 +24,7 @@ pat = os.environ.get("DOM", "collect_kernel hnsw_search_kernel flat_mfma_residen
 cands = [r for r in rows if any(p_ in r["Name"] for p_ in pat[:2])] or [r for r in rows if any(p_ in r["Name"] for p_ in pat)]
 dom = max(cands or rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
 idx = [i for i, nm in enumerate(names) if nm == dom]
-nsearch = S + W + 3
+nsearch = S + W
 lo = S
 tot = 0.0
 for r in rows:
@@ -39,8 +39,8 @@ print("sum of kernels with >= %d calls: %.3f ms" % (lo, tot))
 if len(idx) >= 12:
     # dominant launches per search (IVF: pre-pass + main = 2; Flat: 1)
     per = 2 if "ivf_bf16" in dom else 1
-    e = idx[-1 - 4 * per]           # last dominant launch of the last TIMED search (4 searches of the state-sensitivity leg follow)
-    b = idx[-1 - 5 * per]           # ... of the search before it
+    e = idx[-1]                     # last dominant launch of the last TIMED search (bench.py skips its extra searches under the profiler)
+    b = idx[-1 - per]               # ... of the search before it
     seg = tr[b + 1 : e + 1]
     # rotate: a search starts with its first kernel after the previous search's tail; print in launch order
     agg = collections.OrderedDict()
