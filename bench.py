@@ -221,6 +221,11 @@ def ingest_lines():
                 res[name] = {"error": (p.stderr or p.stdout)[-300:], "rc": p.returncode}
                 continue
             j["frac_of_h2d_pinned"] = round(j["GBps"] / pinned, 4) if pinned else None
+            if "HNSW" in j["index"]:
+                j["note"] = ("the driver's rows are UNIFORM random: the hardest case for a graph build (no structure, long walks) -- C5's clustered "
+                             "normalised rows build an order of magnitude faster: configs.C5.build_seconds for its 1 M rows")
+            if "IVF" in j["index"]:
+                j["note"] = "includes AddFinalise's k-means training on all rows (src/faiss_extension.cpp:583) and the list build"
             j["call_pattern"] = "add calls of <= 2048 rows (pageable buffers valid only during the call) from %d threads" % j["threads"]
             j["child_seconds"] = round(time.perf_counter() - t0, 1)
             res[name] = j
@@ -253,11 +258,13 @@ def embedded_configs():
                 "unit": j["unit"],
                 "ms_per_step": j["ms_per_step"],
                 "steps": j["steps"],
+                "build_seconds": j.get("config", {}).get("build_seconds"),
                 "roofline": {kk: r.get(kk) for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_step", "avg_launch_ms",
                                                       "frac_counter", "mfma_busy_frac", "list_major_bytes_8d", "candidates_rescored_per_query", "traffic",
                                                       "traffic_over_algorithmic", "row_bytes_moved_GBps")},
                 "parity": {kk: j[kk] for kk in ("labels_bit_exact_vs_oracle", "labels_and_distances_bit_exact_vs_oracle", "parity_device",
-                                                "recall_at_10", "recall_sample_queries", "labels_equal_vs_openblas", "openblas_census") if kk in j},
+                                                "recall_at_10", "recall_sample_queries", "labels_equal_vs_openblas", "openblas_census",
+                                                "hnsw_pop_min_tie_rule") if kk in j},
                 "seconds": round(time.perf_counter() - t0, 1),
             }
             for kk in ("cpu_baseline", "cpu_baseline_port", "cpu_baseline_openblas", "recall_efConstruction_200"):
@@ -874,6 +881,7 @@ def main():
                 xq_h = xq.cpu().numpy()
                 nq_cpu, done, t_cpu = 256, 0, 0.0
                 same = True
+                ref_parts = []
                 while t_cpu < args.cpu_seconds and done < nq:
                     m = min(nq_cpu, nq - done)
                     t1 = time.perf_counter()
@@ -881,8 +889,23 @@ def main():
                     t_cpu += time.perf_counter() - t1
                     same &= bool(np.array_equal(final["I"][done : done + m], Io))
                     same &= bool(np.array_equal(final["D"][done : done + m].view(np.uint32), Do.view(np.uint32)))
+                    ref_parts.append((Do, Io))
                     done += m
                     nq_cpu = min(4096, nq_cpu * 2)
+                # The walk's MinimaxHeap::pop_min takes, of several EQUAL minima, the one that sits last in FAISS's heap array; the
+                # device walk takes the smallest id.  The oracle has both rules: how many of the sampled queries
+                # change ANY label or distance between them on this data?  (a deviation documented by measurement)
+                try:
+                    orc.hnsw_set_pop_min_rule(1)
+                    differ, pos = 0, 0
+                    for Do, Io in ref_parts:
+                        m = len(Io)
+                        D1, I1 = o.search(xq_h[pos : pos + m], k, efSearch=args.efsearch)
+                        differ += int(((I1 != Io).any(axis=1) | (D1.view(np.uint32) != Do.view(np.uint32)).any(axis=1)).sum())
+                        pos += m
+                    out["hnsw_pop_min_tie_rule"] = {"queries": done, "results_differ_between_array_order_and_id_order": differ}
+                finally:
+                    orc.hnsw_set_pop_min_rule(0)
                 out["cpu_baseline"] = {
                     "value": round(done / t_cpu, 2),
                     "unit": "queries/s",

@@ -575,10 +575,14 @@ struct SearchArgs {
 	const unsigned *ymax_bits; // largest squared row norm (float bits)
 };
 
-// RL: the candidate and result lists live in registers instead of LDS -- 1: ef <= 128, k <= 64; 2: ef <= 256, k <= 256
+// RL: the candidate and result lists live in registers instead of LDS -- 1: ef <= 128, k <= 64; 2: ef <= 256, k <= 256;
+// round 5 (the harness asks for up to ~2 000 rows per query, go/main_test.go:26-32): 3: ef, k <= 512 -- HNSW128 d = 1536 N = 1 M, 43
+// queries, k = 500: 3.0 ms per batch against 5.2 on LDS lists (one query: 1.39 vs 1.75).  A level of 32 blocks (ef, k <= 2 048) was
+// measured SLOWER than the LDS lists (k = 1000: 9.7 vs 7.1 ms, one query 4.1 vs 1.9: every list operation walks all 32 blocks) and
+// is not built: profiles/r5_harness_shapes.txt
 template <int NI, bool IS_L2, int G, bool BF = false, int RL = 0>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(const SearchArgs a) {
-	constexpr int NBC = RL == 2 ? 4 : 2, NBR = RL == 2 ? 4 : 1; // 64-entry blocks of the two lists
+	constexpr int NBC = RL == 3 ? 8 : (RL == 2 ? 4 : 2), NBR = RL == 3 ? 8 : (RL == 2 ? 4 : 1); // 64-entry blocks of the two lists
 	extern __shared__ u64 smem[];
 	u64 *ckeys = smem + a.hsize / 2; // MinimaxHeap candidates(ef); the visited hash sits in front (16-byte aligned)
 	u64 *rkeys = ckeys + a.ef;       // result heap (k)
@@ -1234,6 +1238,7 @@ struct SearchLaunchBF {
 	};
 MVS_HNSW_RL_STRUCTS(1)
 MVS_HNSW_RL_STRUCTS(2)
+MVS_HNSW_RL_STRUCTS(3)
 #undef MVS_HNSW_RL_STRUCTS
 template <int NI, bool IS_L2, int G>
 struct BuildLaunch {
@@ -1569,7 +1574,8 @@ public:
 		}
 		const bool use_bf = bf16_look != 0 && d >= 64;
 		// the candidate / result lists in registers (csrc: "sorted lists in REGISTERS"): option hnsw_reg_lists, with the bf16 instances
-		const int use_rl = !(use_bf && reg_lists != 0) ? 0 : ((ef <= 128 && k <= 64) ? 1 : ((ef <= 256 && k <= 256) ? 2 : 0));
+		const int use_rl = !(use_bf && reg_lists != 0) ? 0
+		                   : ((ef <= 128 && k <= 64) ? 1 : ((ef <= 256 && k <= 256) ? 2 : ((ef <= 512 && k <= 512) ? 3 : 0)));
 		// (register lists: the LDS holds the visited hash only -- 16 KB at ef = 128: ten waves per CU instead of nine)
 		const size_t lds = use_rl ? std::max<size_t>((size_t)hsize * 4, 64) : (size_t)(ef + k) * 8 + (size_t)hsize * 4 + 64;
 		// rows in flight per wave (option hnsw_search_g): with the lists in registers the walk is no longer a chain of LDS round trips
@@ -1582,7 +1588,9 @@ public:
 		}
 		if (occ_lds != lds || occ_g != search_g || occ_bf != (int)use_bf + 2 * use_rl) { // the occupancy query is not free: once per LDS size
 			int v = 8;
-			if (use_rl == 2)
+			if (use_rl == 3)
+				dispatch_ni<SearchOccupancyBFRL3, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
+			else if (use_rl == 2)
 				dispatch_ni<SearchOccupancyBFRL2, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
 			else if (use_rl)
 				dispatch_ni<SearchOccupancyBFRL1, true>(dp4, metric == METRIC_L2, search_g, &v, lds);
@@ -1645,7 +1653,9 @@ public:
 			a.ymax_bits = (const unsigned *)ymax_dev.p;
 		}
 		begin_kernel_timing(stream);
-		if (use_rl == 2)
+		if (use_rl == 3)
+			dispatch_ni<SearchLaunchBFRL3, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
+		else if (use_rl == 2)
 			dispatch_ni<SearchLaunchBFRL2, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);
 		else if (use_rl)
 			dispatch_ni<SearchLaunchBFRL1, true>(dp4, metric == METRIC_L2, search_g, a, grid, lds, stream);

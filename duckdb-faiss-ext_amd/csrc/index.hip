@@ -470,7 +470,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 	if (defer_count && cl_est_per_query > 0) { // the caller looks at the count after its own synchronisation
-		// (size of the sort: what the previous search of this index produced per query, + 30 %, in units of 64 K entries)
+		// (size of the sort: collect_sort_estimate of what the previous search of this index produced per query, in units of 64 K entries)
 		cl_deferred_cap = std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq));
 		break;
 	}
@@ -995,6 +995,19 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 9, d_max_norm_bits + 4, sizeof(int), hipMemcpyDeviceToHost, st));
 	if (flp) {
+		if (collected && defer && cl_deferred_cap > 0) {
+			// (the sort covered cl_deferred_cap entries -- if the scan produced more, the tie pass below would work on a
+			// truncated candidate set, for k >= 100 with a full score pass per flagged query, only for the whole search to be repeated)
+			MVS_HIP(hipStreamSynchronize(st));
+			unsigned long long ncand_u;
+			memcpy(&ncand_u, h_flag_count + 10, sizeof ncand_u);
+			if ((int64_t)ncand_u > cl_deferred_cap) {
+				cl_last_candidates = (int64_t)ncand_u;
+				cl_est_per_query = (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 1e-6;
+				*overflow = true;
+				return false;
+			}
+		}
 		SelectorDev tsel;
 		memset(&tsel, 0, sizeof tsel);
 		if (has_sel)
@@ -1339,8 +1352,10 @@ void FlatIndex::to_device(int new_device) {
 	if (norms)
 		MVS_HIP(hipFree(norms));
 	drop_bf16_rows();
-	for (DevBuf *b : {&ws_flag, &ws_tie, &ws_pfq, &ws_cand, &ws_ex, &ws_fail, &ws_fb, &ws_e2, &ws_stream, &ws_sorttmp, &ws_seg})
+	for (DevBuf *b : {&ws_flag, &ws_tie, &ws_pfq, &ws_cand, &ws_ex, &ws_fail, &ws_fb, &ws_e2, &ws_stream, &ws_sorttmp, &ws_seg, &ws_pbnd,
+	                  &ws_rowmask, &ws_items1, &ws_qcount})
 		b->release();
+	drop_shadow(); // (the shadow clustering lives on the old device: rebuilt on demand)
 	ws_q.release();
 	ws_qn.release();
 	ws_pd.release();

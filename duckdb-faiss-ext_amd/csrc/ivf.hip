@@ -1379,9 +1379,12 @@ public:
 			int64_t *If = (int64_t *)((char *)Df + df_bytes);
 			launch_gather_query_rows(d_x, d, fail_q, nf, xf, stream);
 			// their probe lists, compacted to the front of the coarse-label buffer (np int64 = 2 np floats per query)
-			DevBuf csub;
+			DevBuf csub, csave;
 			csub.reserve((size_t)nf * np * sizeof(int64_t));
+			csave.reserve((size_t)nf * np * sizeof(int64_t)); // the rows of ws_cI overwritten below: a row shard's tie pass (tie_emit) reads the
+			                                                  // batch's whole coarse assignment after the search
 			launch_gather_query_rows((const float *)ws_cI.p, (int)(2 * np), fail_q, nf, (float *)csub.p, stream);
+			MVS_HIP(hipMemcpyAsync(csave.p, ws_cI.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
 			MVS_HIP(hipMemcpyAsync(ws_cI.p, csub.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
 			pf_suppressed = true;
 			reuse_coarse = true;
@@ -1396,7 +1399,8 @@ public:
 			}
 			pf_suppressed = reuse_coarse = false;
 			timing_enabled = timing;
-			MVS_HIP(hipStreamSynchronize(stream)); // csub is freed at scope exit
+			MVS_HIP(hipMemcpyAsync(ws_cI.p, csave.p, (size_t)nf * np * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+			MVS_HIP(hipStreamSynchronize(stream)); // csub / csave are freed at scope exit
 			launch_scatter_rows(fail_q, nf, k, Df, If, d_D, d_I, stream);
 			kinfo = keep;
 		}

@@ -173,3 +173,28 @@ def test_ivf_with_hnsw_coarse_quantizer():
     assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
     with pytest.raises(orc.OracleError, match="could not parse"):
         orc.Index(d, "IVF32_HNSW8,PQ4", L2)
+
+
+def test_pop_min_tie_rule_only_matters_under_exact_distance_ties():
+    """oracle/orc_hnsw.c: the walk's MinimaxHeap::pop_min in FAISS's heap-array order (default) or by smallest id (the device walk's
+    rule).  On float data without duplicate rows the two rules give the same results bit for bit; with every row stored twice
+    (candidates at bit-equal distance everywhere) both still return k valid neighbours at the same distances."""
+    d, n, nq, k = 16, 3000, 40, 5
+    xb, xq = orc.synth_uniform(n, d, 31), orc.synth_uniform(nq, d, 32)
+    ix = orc.Index(d, "HNSW16", orc.METRIC_L2)
+    ix.add(xb)
+    try:
+        D0, I0 = ix.search(xq, k, efSearch=32)
+        orc.hnsw_set_pop_min_rule(1)
+        D1, I1 = ix.search(xq, k, efSearch=32)
+        assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
+        orc.hnsw_set_pop_min_rule(0)
+        dup = orc.Index(d, "HNSW16", orc.METRIC_L2)
+        dup.add(np.concatenate([xb[:1500], xb[:1500]]))
+        Da, Ia = dup.search(xq, k, efSearch=32)
+        orc.hnsw_set_pop_min_rule(1)
+        Db, Ib = dup.search(xq, k, efSearch=32)
+        assert (Ia >= 0).all() and (Ib >= 0).all()
+        assert np.array_equal(Da.view(np.uint32), Db.view(np.uint32))  # (which twin of a pair is returned may differ, its distance cannot)
+    finally:
+        orc.hnsw_set_pop_min_rule(0)

@@ -242,3 +242,36 @@ def test_rccl_exchange_single_rank_and_save(mf, tmp_path, desc, metric):
     two.set_option("shard_exchange", 1)
     with pytest.raises(mf.FaissException, match="one device per shard"):
         two.search(xq, 10)
+
+
+def test_flat_ip_k_from_100_on_row_shards_keeps_the_pure_order_under_boundary_ties(mf):
+    """ADVICE r4 (csrc/sharded.hip, tie_detect needs k < 100): a SINGLE-GPU Flat inner-product index replays FAISS's ReservoirTopN
+    from k = 100 on (csrc/flat_reservoir.hip) -- which rows tied at the k-th score survive depends on the order the WHOLE stream
+    arrived in, which row shards do not have.  The sharded index therefore merges in the pure (score desc, id asc) order there.
+    This pins that behaviour: the returned SCORES are those of the unsharded index for every query, every returned label carries
+    its score, the labels are the unsharded index's wherever the k-th score is not tied, and under a tie the sharded answer is the
+    pure order (the smallest ids among the tied rows)."""
+    d, nb, k = 16, 20_000, 100
+    rs = np.random.RandomState(77)
+    xb = rs.randint(-2, 3, size=(nb, d)).astype(np.float32)  # small integers: exact scores, many ties
+    xq = rs.randint(-2, 3, size=(60, d)).astype(np.float32)
+    one, sh = mf.index_factory(d, "Flat", IP), mf.index_factory(d, "Flat", IP)
+    sh.shard_to_gpus([0, 0])
+    for a in (one, sh):
+        for i0 in range(0, nb, 2048):
+            a.add(xb[i0 : i0 + 2048])
+    D1, I1 = one.search(xq, k)
+    Ds, Is = sh.search(xq, k)
+    assert np.array_equal(Ds.view(np.uint32), D1.view(np.uint32))  # the multiset of the k best scores is a function of the data
+    sc = xq @ xb.T
+    assert np.array_equal(np.take_along_axis(sc, Is, axis=1), Ds)
+    tied_queries = 0
+    for q in range(len(xq)):
+        T = Ds[q, k - 1]
+        if (sc[q] == T).sum() == (Ds[q] == T).sum():  # every row at the boundary score is in the result: no choice to make
+            assert set(Is[q].tolist()) == set(I1[q].tolist())
+        else:
+            tied_queries += 1
+            want = np.sort(np.nonzero(sc[q] == T)[0])[: (Ds[q] == T).sum()]  # pure order: the smallest ids among the tied rows
+            assert set(Is[q][Ds[q] == T].tolist()) == set(want.tolist())
+    assert tied_queries > 10
