@@ -801,6 +801,10 @@ static int ksplit_ncb() {
 static bool wide_on_big(int dp1) {
 	return dp1 == 1536 || (tune().wide_big && (dp1 == 768 || dp1 == 1024));
 }
+// the label last_kernel_info() reports for a store pitch (bench.py's roofline line and the traffic table key on it)
+const char *collect_wide_kernel_name(int dp1) {
+	return wide_on_big(dp1) ? "flat_bf16_big_kernel" : "flat_bf16_wide_kernel";
+}
 static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }

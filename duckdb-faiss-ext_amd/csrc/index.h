@@ -372,6 +372,7 @@ void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, 
                             unsigned short *d_bf, float *d_beta, const float *d_norms, unsigned *d_max_norm_bits,
                             hipStream_t st);
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
+const char *collect_wide_kernel_name(int dp1); // "flat_bf16_big_kernel" / "flat_bf16_wide_kernel" for a store pitch > 128
 int collect_store_dims(int d); // 128 / 256 / 384 / 512: row pitch of the bf16 store; 0: d is not served (csrc/flat_collect_wide.hip)
 int collect_wide_qblock(int dp1);
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,

@@ -533,7 +533,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	*pd1_out = pd1;
 	*pi1_out = pi1;
 	cl_sorted = sorted;
-	snprintf(kinfo.name, sizeof kinfo.name, wide ? "flat_bf16_wide_kernel" : "flat_bf16_collect_kernel");
+	snprintf(kinfo.name, sizeof kinfo.name, "%s", wide ? collect_wide_kernel_name(collect_store_dims(d)) : "flat_bf16_collect_kernel");
 	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
 	// one pass over the bf16 store (row pitch of the store + the row's f32 term) + the queries + the results
 	kinfo.bytes = (double)ntotal * (collect_store_dims(d) * 2.0 + 4.0) + (double)nq * d * 4.0 + (double)nq * kk * 12.0;

@@ -263,7 +263,7 @@ def test_c4_flat_ip_768_one_gpu_shard_of_100m(mf, torch):
     D, I = ix.search_torch(xq, k)
     torch.cuda.synchronize()
     # the bf16 coarse filter with the k dimension split over wave pairs (csrc/flat_collect_wide.hip) serves this shape ...
-    assert ix.last_kernel_info()["name"] == "flat_bf16_wide_kernel", ix.last_kernel_info()
+    assert ix.last_kernel_info()["name"] == "flat_bf16_big_kernel", ix.last_kernel_info()
     D, I = D.cpu().numpy(), I.cpu().numpy()
     _check_order_and_range(D, I, r0, r1, False)
     # ... with the answers of the exact f32 kernel on all 10k queries, bit for bit
