@@ -562,6 +562,7 @@ def main():
 
     # (the census of the timed searches: the extra searches below must not dilute it)
     snap_collect, snap_prefilter = _snap(ix.collect_stats), _snap(ix.prefilter_stats)
+    snap_probe = _snap(ix.ivf_probe_stats) if is_ivf else None  # (of the timed batch, before the extra searches below)
     # state carried from one search to the next: one batch of DIFFERENT selectivity -- the midpoints of
     # neighbouring queries: nearer the centre of uniform data, between the clusters of clustered data -- then the benchmark's batch
     # again, each timed on its own, outside the timed region
@@ -818,6 +819,16 @@ def main():
                     try:  # census of the IVF coarse filter (csrc/ivf_collect.hip): candidates re-scored exactly, per query
                         cs = snap_collect
                         out["roofline"]["candidates_rescored_per_query"] = round(cs["candidates"] / max(cs["queries"], 1), 1)
+                    except Exception:  # noqa: BLE001
+                        pass
+                    try:  # probe pruning (csrc/ivf_collect.hip ivf_probe_prune_kernel): (query, list) pairs asked for / scanned
+                        ps = snap_probe
+                        out["roofline"]["probe_pairs"] = ps["pairs"]
+                        out["roofline"]["probe_pairs_scanned"] = ps["scanned"]
+                        out["roofline"]["scan_forced_drains"] = ps["forced_drains"]
+                        out["roofline"]["probe_pruning_note"] = ("probed lists that provably hold none of a query's k nearest rows (triangle "
+                                                                 "inequality on coarse distance and list radius) are not scanned; labels and "
+                                                                 "distances are those of scanning all nprobe lists (parity_device / the oracle)")
                     except Exception:  # noqa: BLE001
                         pass
         # ---- CPU baseline (oracle, BLAS-path arithmetic, all host cores) + recall, N=1 only ----------

@@ -656,36 +656,27 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 			const float v = (j & 2) ? hi : lo;
 			const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
 			const unsigned q = (unsigned)(qo + 32 * t + 16 * i + c);
+			// (round 5: a queue that cannot take this step's hits is drained then and there -- one reservation per queue; rounds 3-4 sent
+			// every hit beyond the queue to the stream on its own, one returning atomic + wait each: see csrc/ivf_collect.hip)
+			if (!(COLLECT && ovf) && __builtin_expect(wfill + (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(has)) > WQCAP, 0))
+				wdrain();
 			const bool counting = COLLECT && ovf; // the stream is full: publish at once, count, do not queue (see wdrain / the host's re-run)
 			const unsigned long long act = __builtin_amdgcn_ballot_w64(has && !counting);
 			const unsigned pos = (unsigned)wfill + __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
 			wfill = __builtin_amdgcn_readfirstlane(wfill + (int)__builtin_popcountll(act));
 			if (has) {
 				const unsigned long long ent = ((unsigned long long)q << 32) | row;
-				if (__builtin_expect(!counting && pos < (unsigned)WQCAP, 1)) {
+				if (__builtin_expect(!counting, 1)) {
 					asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(qbuf_lds + 8u * pos), "v"(ent), "v"(qval_lds + 4u * pos), "v"(v) : "memory");
 				} else {
+					// the stream is full: whatever is appended now is dropped, but the host wants the TRUE number of candidates (it sizes
+					// the next attempt from it) -- publish, count, do not queue.  (All-duplicates data, 31 250 copies of every query's
+					// nearest row: 3e8 candidates through the queue took 47 s per launch.)
 					typedef __attribute__((address_space(1))) unsigned *GU;
 					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)q * NC) + (row & (unsigned)(NC - 1)), skey(v), __ATOMIC_RELAXED,
 					                       __HIP_MEMORY_SCOPE_AGENT);
-					if (counting) {
-						// the stream is full: whatever is appended now is dropped, but the host wants the TRUE number of candidates (it sizes
-						// the next attempt from it) -- count, do not queue.  (All-duplicates data, 31 250 copies of every query's nearest row:
-						// 3e8 candidates through the queue's overflow branch took 47 s per launch.)
-						const unsigned one = 1u;
-						asm volatile("ds_add_u32 %0, %1" ::"v"(qcnt_lds + 28u), "v"(one) : "memory");
-					} else if (COLLECT) { // a burst beyond the wave's queue (cold start): straight to the stream.  By hand, wait included: a
-						// compiled atomic with a result makes hipcc wait for vmcnt(0) where the branches meet
-						unsigned long long gp;
-						const unsigned long long one64 = 1ull;
-						typedef __attribute__((address_space(1))) unsigned long long *GUL;
-						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-						             : "=&v"(gp)
-						             : "v"((GUL)a.stream_cnt), "v"(one64)
-						             : "memory");
-						if ((long long)gp < a.stream_cap)
-							*((GUL)a.stream + gp) = ent;
-					}
+					const unsigned one = 1u;
+					asm volatile("ds_add_u32 %0, %1" ::"v"(qcnt_lds + 28u), "v"(one) : "memory");
 				}
 			}
 		}

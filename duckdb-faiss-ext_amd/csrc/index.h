@@ -118,6 +118,9 @@ public:
 	virtual void set_label_offset(int64_t off) {
 		label_offset = off;
 	}
+	virtual bool probe_stats(int64_t *, int64_t *, int64_t *) { // IVF: (query, list) pairs of the last search / of those, scanned (mvs_index_ivf_probe_stats)
+		return false;
+	}
 	virtual bool collect_stats(int64_t *, int64_t *, int64_t *) { // coarse-filter census of an IVF index (mvs_index_collect_stats)
 		return false;
 	}
@@ -459,6 +462,9 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
                               int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa = nullptr,
                               int64_t label_offset = 0);
+// probed lists that provably hold none of a query's k nearest rows -> -1 in d_out (csrc/ivf_collect.hip ivf_probe_prune_kernel); np <= 256
+void launch_ivf_probe_prune(const float *d_x, int64_t nq, int d, const float *d_cD, const int64_t *d_cI, int np, int k, const float *d_cn,
+                            const unsigned *d_list_max, const int64_t *d_list_off, int64_t *d_out, int *d_kept, hipStream_t st);
 void launch_ivf_shadow_verify(const float *d_cmat, const float *d_cD, const int64_t *d_cI, int64_t nq, int nlist, int np, int d, int k,
                               const float *d_qn, const float *d_cn, const unsigned *d_list_max, const int64_t *d_lb, const int64_t *d_le,
                               const float *d_D, const int64_t *d_I, const unsigned *d_ymax_bits, int *d_fail_cnt, int *d_fail_q,

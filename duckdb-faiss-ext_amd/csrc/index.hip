@@ -1939,6 +1939,17 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
 		*overflows = f->cl_overflows;
 	MVS_API_END
 }
+int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains) {
+	MVS_API_BEGIN
+	IndexBase *p = sharded_inner_view(ix->impl);
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	if (p->kind == MVS_KIND_FLAT && static_cast<FlatIndex *>(p)->shadow) // a Flat index answering through its shadow clustering
+		p = static_cast<FlatIndex *>(p)->shadow;
+	if (!p->probe_stats(pairs, pairs_scanned, forced_drains))
+		throw_faiss("mvs_index_ivf_probe_stats", __FILE__, "not an IVF index");
+	MVS_API_END
+}
 int mvs_index_shard_info(const mvs_index *ix, int *devices, int max_devices, int64_t *rows_per_shard,
                          int64_t *last_tie_queries) {
 	return sharded_info(ix->impl, devices, max_devices, rows_per_shard, last_tie_queries);

@@ -1013,6 +1013,22 @@ public:
 		// (round 3, option ivf_cl_prepass = 1: the pre-pass walks the first rows of EVERY probed list with the work items of the
 		// main pass -- one grouping + packing per search instead of two, and 32 x 128 rows of evidence per query instead of 256)
 		int *d_nitems = nullptr, *d_cnt = nullptr;
+		// Round 5, probe pruning (csrc/ivf_collect.hip ivf_probe_prune_kernel): the grouping sees -1 for the probes that cannot matter
+		const int64_t *probe_keys = (const int64_t *)ws_cI.p;
+		const bool prune = cl_prune && metric == METRIC_L2 && hnsw_M == 0 && np <= 256 && np > 1 && !(params && params->sel_kind != MVS_SEL_NONE) &&
+		                   !cl_prepass_shared;
+		if (prune) {
+			ws_cIp.reserve((size_t)nq * np * sizeof(int64_t));
+			ws_kept.reserve((size_t)nq * sizeof(int));
+			launch_ivf_probe_prune(d_x, nq, d, (const float *)ws_cD.p, (const int64_t *)ws_cI.p, (int)np, kk,
+			                       static_cast<FlatIndex *>(quantizer)->row_norms(), (const unsigned *)list_max.p,
+			                       (const int64_t *)list_off_dev.p, (int64_t *)ws_cIp.p, (int *)ws_kept.p, stream);
+			probe_keys = (const int64_t *)ws_cIp.p;
+		}
+		cl_last_pairs = npairs, cl_last_nq = nq;
+		cl_pairs_pruned_pending = prune;
+		if (!prune)
+			cl_last_pairs_kept = npairs;
 		// (option ivf_cl_prepass_shared: ONE grouping + packing serves both passes -- the pre-pass walks the first 256 rows of the main
 		// pass's items with every slot switched off whose list is not its query's nearest (E = NaN): the same evidence as the
 		// nearest-list pre-pass without its own grouping and packing)
@@ -1028,7 +1044,7 @@ public:
 			// (tried and dropped, profiles/r5_c3_ab.txt: the scan waves building their fragments / gamma / 2E themselves from the f32
 			// queries instead of reading packed ones -- no packing kernel, 0.5 GB less traffic, but every segment wave of an item
 			// repeats the item's conversion behind eight dependent load round trips: scan 0.77 -> 0.98 ms, step 1.58 -> 1.70)
-			launch_ivf_group2((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
+			launch_ivf_group2(probe_keys, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
 			                  (int *)ws_group.p, (int *)ws_group.p + group_ints, ws_items0.p, (int *)ws_qidx0.p, (int *)ws_slots.p, ws_items.p,
 			                  (int *)ws_qidx.p, nullptr, &d_nitems0, &d_nitems, stream);
 			group_clean_p = ws_group.p, group_clean_cap = ws_group.cap; // (zero again behind the scatter kernel)
@@ -1046,7 +1062,7 @@ public:
 			end_kernel_timing(stream);
 		}
 		for (int phase = prep2 ? 2 : (cl_prepass_none ? 1 : 0); phase < 2; ++phase) {
-			const int64_t *keys = (const int64_t *)ws_cI.p;
+			const int64_t *keys = probe_keys;
 			// the nearest-list pre-pass: column 0 of the labels as a batch with one probe per query (key stride = nprobe)
 			const bool nearest_only = phase == 0 && !cl_prepass_all && !shared;
 			const bool by_pairs = nearest_only ? cl_pack_nearest : (cl_pack_pairs && !shared && !(phase == 0 && cl_prepass_all));
@@ -1097,7 +1113,7 @@ public:
 				                         dp, (const int *)perm_mf.p, kk, d_D, d_I, nullptr, shadow->out_map, 0, nullptr, nullptr, nullptr, nullptr,
 				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off);
 				FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
-				launch_ivf_shadow_verify(qz->coarse_matrix(), (const float *)ws_cD.p, (const int64_t *)ws_cI.p, nq, (int)nlist, (int)np, d, kk,
+				launch_ivf_shadow_verify(qz->coarse_matrix(), (const float *)ws_cD.p, probe_keys, nq, (int)nlist, (int)np, d, kk,
 				                         shadow->qn, qz->row_norms(), (const unsigned *)list_max.p, (const int64_t *)lb_dev.p,
 				                         (const int64_t *)le_dev.p, d_D, d_I, shadow->ymax_bits, shadow->fail_cnt, shadow->fail_q, stream);
 			} else
@@ -1127,6 +1143,7 @@ public:
 			memcpy(st2, (const char *)(h_fail + 64) + 192, sizeof st2);
 			memcpy(&nstream, h_fail + 64, sizeof nstream);
 			h_fail[0] = h_fail[64 + 16]; // (the fail count, where the code below reads it)
+			cl_last_bursts = (int64_t)(unsigned)h_fail[64 + 32]; // mid-tile drains of a scan wave's hit queue (header byte 128)
 			if ((int64_t)nstream > cap_entries) { // the STREAM overflowed (duplicate-heavy lists): grown once per size, as in round 3
 				++cl_overflows;
 				if ((int64_t)(nstream + nstream / 8) > nq * (int64_t)16384)
@@ -1701,6 +1718,10 @@ public:
 			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
 			return true;
 		}
+		if (!strcmp(key, "ivf_probe_prune")) {
+			cl_prune = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_prep2")) {
 			cl_prep2 = v != 0;
 			return true;
@@ -1826,6 +1847,28 @@ private:
 			*overflows = cl_overflows;
 		return true;
 	}
+	// (query, list) pairs of the last coarse-filter search and how many of them the scan kept (mvs_index_ivf_probe_stats; the per-query
+	// counts stay on the device until somebody asks)
+	bool probe_stats(int64_t *pairs, int64_t *scanned, int64_t *bursts) override {
+		use_device();
+		if (cl_pairs_pruned_pending && cl_last_nq > 0) {
+			MVS_HIP(hipStreamSynchronize(stream));
+			std::vector<int> h((size_t)cl_last_nq);
+			MVS_HIP(hipMemcpy(h.data(), ws_kept.p, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+			cl_last_pairs_kept = 0;
+			for (int v : h)
+				cl_last_pairs_kept += v;
+			cl_pairs_pruned_pending = false;
+		}
+		if (pairs)
+			*pairs = cl_last_pairs;
+		if (scanned)
+			*scanned = cl_last_pairs_kept;
+		if (bursts)
+			*bursts = cl_last_bursts;
+		return true;
+	}
+	int64_t cl_last_nq = 0, cl_last_bursts = 0;
 	double cl_est_per_query = 0; // candidates per query of the last coarse-filter search: sizes the next search's sort (collect_sort_estimate)
 	int cl_seg_rows = 512;       // option ivf_cl_seg_rows
 	bool cl_pack_nearest = true; // option ivf_cl_pack_nearest
@@ -1833,6 +1876,10 @@ private:
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
 	bool cl_bucket = true;       // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
 	int cl_bpitch = 1024;        // bucket entries per query (grown on demand up to 16 384)
+	bool cl_prune = true;        // option ivf_probe_prune: probed lists that provably hold none of a query's k nearest rows are not scanned (L2)
+	int64_t cl_last_pairs = 0, cl_last_pairs_kept = 0; // (query, list) pairs of the last coarse-filter search / of those, scanned
+	DevBuf ws_cIp, ws_kept;
+	bool cl_pairs_pruned_pending = false; // ws_kept of the last search has not been summed yet (collect statistics do it on demand)
 	bool cl_prep2 = true;        // option ivf_cl_prep2: fused grouping / packing / clearing in front of the scans (0 = round 4's launches)
 	void *group_clean_p = nullptr, *ctl_clean_p = nullptr; // the buffers known to be left zeroed by the previous search's kernels
 	size_t group_clean_cap = 0, ctl_clean_cap = 0;

@@ -692,30 +692,21 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 			const unsigned row = (unsigned)(row0 + 16 * rb + 4 * hq + j);
 			const unsigned sl = (unsigned)(32 * t + 16 * i + c);
 			const unsigned long long act = __builtin_amdgcn_ballot_w64(has);
+			const int nact = (int)__builtin_popcountll(act);
+			// (round 5: a queue that cannot take this step's hits is drained THEN AND THERE -- one reservation per <= 160 hits.  Rounds
+			// 3-4 sent every hit beyond the queue straight to the stream, one returning atomic + wait each: a list whose own queries all
+			// pass most of its rows -- a giant list covering several clusters, E of its pairs is large -- took 1.3 ms in that branch
+			// while the rest of the launch had long finished: profiles/r5_c3_ab.txt, 6)
+			if (__builtin_expect(qfill + nact > IC_QCAP, 0)) {
+				if (a.collect && lane == 0) // census: forced drains (control block header, byte 128; mvs_index_ivf_probe_stats)
+					__hip_atomic_fetch_add((unsigned *)(a.stream_cnt + 16), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				drain();
+			}
 			const unsigned pos = (unsigned)qfill + __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-			qfill = __builtin_amdgcn_readfirstlane(qfill + (int)__builtin_popcountll(act));
+			qfill = __builtin_amdgcn_readfirstlane(qfill + nact);
 			if (has) {
-				if (__builtin_expect(pos < (unsigned)IC_QCAP, 1)) {
-					const unsigned long long ent = ((unsigned long long)row << 32) | __float_as_uint(v);
-					asm volatile("ds_write_b64 %0, %1\n\tds_write_b8 %2, %3" ::"v"(qbuf_lds + 8u * pos), "v"(ent), "v"(qslot_lds + pos), "v"(sl) : "memory");
-				} else { // a burst beyond the queue (cold start): worked off at once, straight to the stream
-					int2 qe;
-					asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qe) : "v"(qtab_lds + sl * 8u) : "memory");
-					typedef __attribute__((address_space(1))) unsigned *GU;
-					__hip_atomic_fetch_min((GU)(a.gslot + (size_t)qe.x * NC) + (row & (unsigned)(NC - 1)), ic_skey(v - __int_as_float(qe.y)),
-					                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (a.collect) {
-						unsigned long long gp;
-						const unsigned long long one64 = 1ull;
-						typedef __attribute__((address_space(1))) unsigned long long *GUL;
-						asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-						             : "=&v"(gp)
-						             : "v"((GUL)a.stream_cnt), "v"(one64)
-						             : "memory");
-						if ((long long)gp < a.stream_cap)
-							*((GUL)a.stream + gp) = ((unsigned long long)(unsigned)qe.x << 32) | row;
-					}
-				}
+				const unsigned long long ent = ((unsigned long long)row << 32) | __float_as_uint(v);
+				asm volatile("ds_write_b64 %0, %1\n\tds_write_b8 %2, %3" ::"v"(qbuf_lds + 8u * pos), "v"(ent), "v"(qslot_lds + pos), "v"(sl) : "memory");
 			}
 		}
 	};
@@ -1395,8 +1386,10 @@ __global__ __launch_bounds__(64) void ivf_shadow_verify_kernel(const IvfShadowVe
 		if (a.lb[j] == a.le[j])
 			continue; // an empty list holds nothing
 		const float cd = a.cmat[q * a.nlist + j];
-		bool probed = cd < cdl;
-		if (cd == cdl) {
+		// (cI may be the PRUNED probe list of ivf_probe_prune_kernel: a pruned list counts as unprobed and is proven here, in this
+		// index's arithmetic)
+		bool probed = false;
+		if (cd <= cdl) {
 			for (int p = 0; p < a.np; ++p)
 				probed |= a.cI[q * a.np + p] == (long long)j;
 		}
@@ -1426,6 +1419,112 @@ void launch_ivf_shadow_verify(const float *d_cmat, const float *d_cD, const int6
 	a.list_max = d_list_max, a.lb = (const long long *)d_lb, a.le = (const long long *)d_le, a.D = d_D, a.I = (const long long *)d_I;
 	a.ymax_bits = d_ymax_bits, a.fail_cnt = d_fail_cnt, a.fail_q = d_fail_q;
 	hipLaunchKernelGGL(ivf_shadow_verify_kernel, dim3((unsigned)nq), dim3(64), 0, st, a);
+	MVS_HIP(hipGetLastError());
+}
+
+// ---- probe pruning (round 5): probed lists that PROVABLY hold none of a query's k nearest rows are not scanned -------------------
+// IndexIVF::search scans the nprobe nearest lists whatever they hold.  A list j whose every row is farther from x than k rows of the
+// query's nearest lists are contributes nothing to the result -- not even under ties, the inequality is strict -- so leaving it out
+// changes no label and no distance.  Witnesses: the first m probes (rank order) whose lists hold >= k rows together; every row y of
+// list p has  ||x - y|| <= ||x - c_p|| + r_p  (r_p = the list's largest residual norm, list_max).  With cd = the COMPUTED coarse
+// distance, e_c = 2 (d + 2) u (||x|| + ||c||)^2 what FAISS's (xn + yn) - 2 ip formula can be off by, eps = 2 (d + 2) u the relative
+// error of the scanner's sum of squares:  W = max_{p < m} (sqrt(cd_p + e_c) + r_p)^2 (1 + eps) bounds the k-th COMPUTED result from
+// above, (sqrt(cd_j - e_c) - r_j)^2 (1 - eps) bounds every computed distance of list j from below; j is pruned when the second
+// exceeds the first.  All in double; r inflated by 1e-4 (its f32 chain); anything non-finite: nothing is pruned.  L2 only, no
+// IDSelector (the witnesses must be selectable rows).  out[q][p] = the list or -1; the probe list itself (ties, tie pass) stays whole.
+struct IvfProbePruneArgs {
+	const float *x;        // [nq][d]
+	const float *cD;       // [nq][np] computed coarse distances, ascending
+	const long long *cI;   // [nq][np]
+	long long *out;        // [nq][np]
+	int *kept;             // [nq] probes kept (statistics), may be null
+	int nq, np, d, k;
+	const float *cn;       // [nlist] ||c||^2
+	const unsigned *list_max;
+	const long long *list_off; // [nlist + 1] rows of every list
+};
+__global__ __launch_bounds__(256) void ivf_probe_prune_kernel(const IvfProbePruneArgs a) {
+	__shared__ double sU[4][256];
+	__shared__ int sN[4][256];
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const long long q = (long long)blockIdx.x * 4 + w;
+	if (q >= a.nq)
+		return; // (no workgroup barrier below: a wave works on its own rows of the tables)
+	const double u = 5.9604644775390625e-08, eps = 2.0 * (a.d + 2.0) * u;
+	double xn = 0.0;
+	for (int i = lane; i < a.d; i += 64) {
+		const double v = (double)a.x[q * a.d + i];
+		xn += v * v;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		xn += __shfl_xor(xn, off);
+	const double nx = sqrt(xn) * (1.0 + 1e-9);
+	double lo2[4]; // (np <= 256: four entries per lane) lower bound of the list's computed distances; < 0: cannot be pruned
+	long long id[4];
+#pragma unroll
+	for (int e = 0; e < 4; ++e) {
+		const int p = lane + 64 * e;
+		lo2[e] = -1.0;
+		id[e] = -1;
+		if (p >= a.np)
+			continue;
+		const long long j = a.cI[q * a.np + p];
+		id[e] = j;
+		double U = INFINITY;
+		int n = 0;
+		if (j >= 0) {
+			const double cd = (double)a.cD[q * a.np + p];
+			const double cnj = (double)a.cn[j], nc = sqrt(cnj > 0 ? cnj : 0.0) * (1.0 + 1e-7);
+			const double ec = 2.0 * (a.d + 2.0) * u * (nx + nc) * (nx + nc);
+			const double R = sqrt((double)__uint_as_float(a.list_max[j])) * 1.0001;
+			const double hi = sqrt(cd + ec) + R;
+			U = hi * hi * (1.0 + eps);
+			const double l = cd - ec, A = l > 0 ? sqrt(l) : 0.0, gap = A - R;
+			if (gap > 0)
+				lo2[e] = gap * gap * (1.0 - eps);
+			n = (int)(a.list_off[j + 1] - a.list_off[j]);
+			if (!(U == U) || !(cd == cd))
+				U = INFINITY, lo2[e] = -1.0;
+		}
+		sU[w][p] = U;
+		sN[w][p] = n;
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (single wave: LDS keeps its accesses in order)
+	double W = 0.0;
+	int m = 0, cum = 0;
+	for (; m < a.np && cum < a.k; ++m) {
+		cum += sN[w][m];
+		W = sU[w][m] > W ? sU[w][m] : W;
+	}
+	const bool can = cum >= a.k && W < INFINITY;
+	int mine = 0;
+#pragma unroll
+	for (int e = 0; e < 4; ++e) {
+		const int p = lane + 64 * e;
+		if (p >= a.np)
+			continue;
+		const bool prune = can && p >= m && lo2[e] > W; // (strict; NaN: false)
+		a.out[q * a.np + p] = prune ? -1ll : id[e];
+		mine += (!prune && id[e] >= 0) ? 1 : 0;
+	}
+	if (a.kept) {
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+			mine += __shfl_xor(mine, off);
+		if (lane == 0)
+			a.kept[q] = mine;
+	}
+}
+void launch_ivf_probe_prune(const float *d_x, int64_t nq, int d, const float *d_cD, const int64_t *d_cI, int np, int k, const float *d_cn,
+                            const unsigned *d_list_max, const int64_t *d_list_off, int64_t *d_out, int *d_kept, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	IvfProbePruneArgs a;
+	memset(&a, 0, sizeof a);
+	a.x = d_x, a.cD = d_cD, a.cI = (const long long *)d_cI, a.out = (long long *)d_out, a.kept = d_kept, a.nq = (int)nq, a.np = np, a.d = d;
+	a.k = k, a.cn = d_cn, a.list_max = d_list_max, a.list_off = (const long long *)d_list_off;
+	hipLaunchKernelGGL(ivf_probe_prune_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, a);
 	MVS_HIP(hipGetLastError());
 }
 

@@ -120,6 +120,7 @@ _L.mvs_index_to_gpu.argtypes = [_p, C.c_int]
 _L.mvs_index_clone_to_gpu.argtypes = [C.POINTER(_p), _p, C.c_int]
 _L.mvs_index_prefilter_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_float), C.POINTER(C.c_float)]
 _L.mvs_index_collect_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
+_L.mvs_index_ivf_probe_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_index_shard_to_gpus.argtypes = [_p, C.POINTER(C.c_int), C.c_int]
 _L.mvs_index_shard_info.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_write_index.argtypes = [_p, C.c_char_p]
@@ -148,7 +149,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_get_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_walk_stats", "mvs_index_hnsw_get_graph",
     "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
-    "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
+    "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_ivf_probe_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
     "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_index_ivf_tie_emit_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
@@ -309,6 +310,12 @@ class Index:
         q, f, e, b = _i64(0), _i64(0), C.c_float(0), C.c_float(0)
         _check(_L.mvs_index_prefilter_stats(self._h, C.byref(q), C.byref(f), C.byref(e), C.byref(b)))
         return {"queries": q.value, "fallback_queries": f.value, "max_rel_err": e.value, "err_bound": b.value}
+
+    def ivf_probe_stats(self):
+        """(query, list) pairs of the last IVF coarse-filter search and how many of them were scanned (probe pruning)."""
+        a, b, c = _i64(0), _i64(0), _i64(0)
+        _check(_L.mvs_index_ivf_probe_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"pairs": a.value, "scanned": b.value, "forced_drains": c.value}
 
     def collect_stats(self):
         q, c, o = _i64(0), _i64(0), _i64(0)

@@ -221,6 +221,12 @@ int mvs_index_prefilter_stats(mvs_index *ix, int64_t *queries, int64_t *fallback
 /* bf16 coarse filter of the same search (csrc/flat_collect.hip; option prefilter = 2): queries it served, candidates it
  * re-scored exactly for them, batches whose candidate stream overflowed (served by the bf16x3 path instead) */
 int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates, int64_t *overflows);
+/* IVF, diagnostics: the (query, probed list) pairs of the index's last coarse-filter search (nq x nprobe) and how many of them were
+ * scanned.  IndexIVF::search (faiss/IndexIVF.cpp search_preassigned, reached from src/faiss_extension.cpp:631) scans every probed
+ * list; this path leaves out the lists that PROVABLY hold none of a query's k nearest rows (triangle inequality on the coarse
+ * distance and the list's radius, option ivf_probe_prune, L2 without an IDSelector) -- labels and distances are unchanged.
+ * forced_drains: how often a scan wavefront of the last search had to empty its LDS hit queue in the middle of a tile. */
+int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains);
 int mvs_device_count(void);
 const char *mvs_version(void);
 
