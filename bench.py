@@ -826,6 +826,7 @@ def main():
                         out["roofline"]["probe_pairs"] = ps["pairs"]
                         out["roofline"]["probe_pairs_scanned"] = ps["scanned"]
                         out["roofline"]["scan_forced_drains"] = ps["forced_drains"]
+                        out["roofline"]["candidates_admitted_per_query"] = round(ps["admitted"] / max(nq, 1), 1)
                         out["roofline"]["probe_pruning_note"] = ("probed lists that provably hold none of a query's k nearest rows (triangle "
                                                                  "inequality on coarse distance and list radius) are not scanned; labels and "
                                                                  "distances are those of scanning all nprobe lists (parity_device / the oracle)")

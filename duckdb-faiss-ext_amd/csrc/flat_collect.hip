@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 	// The path is entered in 7 % of the half tiles at N = 1.25 M (1.4 % at 10 M) and was 14 % (4.4 %) of the scan: profiles/
 	// r4_ablation_bare_mfma_loop.txt; the IVF scan, where it was a third, does the same: csrc/ivf_collect.hip.)
 	int wfill = 0, wpub = 0; // entries recorded by this wave / of those, already published to the class slots (wave-uniform)
-	auto publish = [&]() {
+	auto publish = [&]() __attribute__((always_inline)) {
 		const unsigned n = (unsigned)wfill < (unsigned)WQCAP ? (unsigned)wfill : (unsigned)WQCAP;
 		for (unsigned e = (unsigned)wpub + lane; e < n; e += 64) {
 			unsigned long long ent;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		}
 		wpub = (int)n;
 	};
-	auto wdrain = [&]() { // publish what is left; the wave's whole queue -> the global stream behind one reservation
+	auto wdrain = [&]() __attribute__((always_inline)) { // publish what is left; the wave's whole queue -> the global stream behind one reservation
 		publish();
 		const unsigned n = (unsigned)wpub;
 		wfill = 0;

@@ -118,7 +118,7 @@ public:
 	virtual void set_label_offset(int64_t off) {
 		label_offset = off;
 	}
-	virtual bool probe_stats(int64_t *, int64_t *, int64_t *) { // IVF: (query, list) pairs of the last search / of those, scanned (mvs_index_ivf_probe_stats)
+	virtual bool probe_stats(int64_t *, int64_t *, int64_t *, int64_t *) { // IVF: (query, list) pairs of the last search / of those, scanned (mvs_index_ivf_probe_stats)
 		return false;
 	}
 	virtual bool collect_stats(int64_t *, int64_t *, int64_t *) { // coarse-filter census of an IVF index (mvs_index_collect_stats)
@@ -454,7 +454,11 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st);
+                             hipStream_t st, float *d_stream_u = nullptr);
+// final-bound filter between the scan and the exact stage (csrc/ivf_collect.hip): entries whose s + E is below the bound the scan ended with are dropped
+void launch_ivf_refilter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
+                         const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned long long *d_out,
+                         unsigned long long *d_out_cnt, hipStream_t st);
 void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int64_t ncand, const unsigned long long *d_cnt,
                               unsigned long long *d_bucket, unsigned *d_bcount, int bpitch, int64_t nq, const float *d_x, int d,
                               const float *d_rows_csr, int dp_csr, const int *d_perm, int kk, float *d_pd, int64_t *d_pi,

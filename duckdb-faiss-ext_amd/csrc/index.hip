@@ -1939,14 +1939,14 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
 		*overflows = f->cl_overflows;
 	MVS_API_END
 }
-int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains) {
+int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains, int64_t *admitted) {
 	MVS_API_BEGIN
 	IndexBase *p = sharded_inner_view(ix->impl);
 	while (p->kind == MVS_KIND_IDMAP)
 		p = static_cast<IDMapIndex *>(p)->sub;
 	if (p->kind == MVS_KIND_FLAT && static_cast<FlatIndex *>(p)->shadow) // a Flat index answering through its shadow clustering
 		p = static_cast<FlatIndex *>(p)->shadow;
-	if (!p->probe_stats(pairs, pairs_scanned, forced_drains))
+	if (!p->probe_stats(pairs, pairs_scanned, forced_drains, admitted))
 		throw_faiss("mvs_index_ivf_probe_stats", __FILE__, "not an IVF index");
 	MVS_API_END
 }

@@ -995,6 +995,17 @@ public:
 		unsigned long long *cnt = (unsigned long long *)ws_qfail.p; // (zeroed with the control block above)
 		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
 		unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+		// final-bound filter (bucket mode): u per entry, Bf per query, the filtered stream; its count lives in the control block's header @8
+		const bool refilter = bucket && cl_refilter;
+		float *strm_u = nullptr, *bf_q = nullptr;
+		unsigned long long *strm2 = nullptr, *cnt2 = (unsigned long long *)ws_qfail.p + 1;
+		if (refilter) {
+			const size_t ub = ((size_t)cap_entries * 4 + 255) & ~(size_t)255, bb = ((size_t)nq * 4 + 255) & ~(size_t)255;
+			ws_stream2.reserve(ub + bb + (size_t)cap_entries * 8 + 256);
+			strm_u = (float *)ws_stream2.p;
+			bf_q = (float *)((char *)ws_stream2.p + ub);
+			strm2 = (unsigned long long *)((char *)ws_stream2.p + ub + bb);
+		}
 		memset(&kinfo, 0, sizeof kinfo);
 		// IDSelector: one bit per padded row, built per search (the selector sees the stored id, through the id map if any)
 		const unsigned *rowmask = nullptr;
@@ -1058,7 +1069,7 @@ public:
 			begin_kernel_timing(stream);
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, seg_rows, nseg, 1, rowmask, stream);
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, seg_rows, nseg, 1, rowmask, stream, strm_u);
 			end_kernel_timing(stream);
 		}
 		for (int phase = prep2 ? 2 : (cl_prepass_none ? 1 : 0); phase < 2; ++phase) {
@@ -1086,7 +1097,7 @@ public:
 			                        (const float *)(phase == 0 && shared ? ws_ie2p.p : ws_ie2.p), (const unsigned short *)codes_bfr.p,
 			                        (const float *)beta_mf.p,
 			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
-			                        phase == 0 ? 1 : nseg, phase, rowmask, stream);
+			                        phase == 0 ? 1 : nseg, phase, rowmask, stream, phase == 1 ? strm_u : nullptr);
 			if (phase == 1)
 				end_kernel_timing(stream);
 		}
@@ -1104,12 +1115,17 @@ public:
 			// for the flagged queries is enqueued behind it, BEFORE the search's one synchronisation (rounds 3-4 launched the finish
 			// kernel and the tie pass after it: two launch latencies with the GPU idle)
 			const bool fin = raw_pos && fin_D != nullptr && kk == fin_k + 1 && !shadow;
+			const unsigned long long *ex_strm = strm, *ex_cnt = cnt;
+			if (refilter) {
+				launch_ivf_refilter(strm, strm_u, cap_entries, cnt, (const unsigned *)ws_gslot.p, nclass, kf, nq, bf_q, strm2, cnt2, stream);
+				ex_strm = strm2, ex_cnt = cnt2;
+			}
 			if (shadow) {
 				// Flat shadow: the candidates re-scored in the FLAT index's arithmetic, labels = Flat row numbers, the fail list is the
 				// caller's; then the proof that no unprobed list matters (csrc/ivf_collect.hip ivf_shadow_verify_kernel)
 				IvfFlatArith fa;
 				fa.qn = shadow->qn, fa.yn = (const float *)norms_csr.p, fa.rowids = (const long long *)rowids.p;
-				launch_ivf_bucket_finish(METRIC_L2, strm, cap_entries, cnt, sorted, (unsigned *)ctl_seg, bpitch, nq, d_x, d, (const float *)codes.p,
+				launch_ivf_bucket_finish(METRIC_L2, ex_strm, cap_entries, ex_cnt, sorted, (unsigned *)ctl_seg, bpitch, nq, d_x, d, (const float *)codes.p,
 				                         dp, (const int *)perm_mf.p, kk, d_D, d_I, nullptr, shadow->out_map, 0, nullptr, nullptr, nullptr, nullptr,
 				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off);
 				FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
@@ -1117,7 +1133,7 @@ public:
 				                         shadow->qn, qz->row_norms(), (const unsigned *)list_max.p, (const int64_t *)lb_dev.p,
 				                         (const int64_t *)le_dev.p, d_D, d_I, shadow->ymax_bits, shadow->fail_cnt, shadow->fail_q, stream);
 			} else
-			launch_ivf_bucket_finish(metric, strm, cap_entries, cnt, sorted /* the buckets */, (unsigned *)ctl_seg, bpitch, nq, d_x, d,
+			launch_ivf_bucket_finish(metric, ex_strm, cap_entries, ex_cnt, sorted /* the buckets */, (unsigned *)ctl_seg, bpitch, nq, d_x, d,
 			                         (const float *)codes.p, dp, (const int *)perm_mf.p, kk, d_D, d_I, raw_pos ? nullptr : (const int64_t *)rowids.p,
 			                         (d_idmap && !raw_ids && !raw_pos) ? d_idmap : nullptr, fin ? (int)fin_k : 0, fin ? fin_D : nullptr,
 			                         fin ? fin_I : nullptr, (const int64_t *)rowids.p, fin ? fin_idmap : nullptr, fin ? ctl_flag : nullptr, ctl_stats,
@@ -1165,8 +1181,12 @@ public:
 				*overflow = true;
 				return false;
 			}
+			unsigned long long nkept = nstream;
+			if (refilter)
+				memcpy(&nkept, (const char *)(h_fail + 64) + 8, sizeof nkept);
+			cl_last_admitted = (int64_t)nstream;
 			cl_queries_total += nq;
-			cl_candidates_total += (int64_t)nstream;
+			cl_candidates_total += (int64_t)nkept; // (what the exact stage re-scored)
 			cl_est_per_query = (double)nstream / (double)std::max<int64_t>(nq, 1) + 1e-6;
 			fin_done = fin;
 			if (shadow) { // (the fail list is the caller's: it re-runs those queries on the Flat kernels)
@@ -1718,6 +1738,10 @@ public:
 			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_refilter")) {
+			cl_refilter = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_probe_prune")) {
 			cl_prune = v != 0;
 			return true;
@@ -1849,7 +1873,7 @@ private:
 	}
 	// (query, list) pairs of the last coarse-filter search and how many of them the scan kept (mvs_index_ivf_probe_stats; the per-query
 	// counts stay on the device until somebody asks)
-	bool probe_stats(int64_t *pairs, int64_t *scanned, int64_t *bursts) override {
+	bool probe_stats(int64_t *pairs, int64_t *scanned, int64_t *bursts, int64_t *admitted) override {
 		use_device();
 		if (cl_pairs_pruned_pending && cl_last_nq > 0) {
 			MVS_HIP(hipStreamSynchronize(stream));
@@ -1866,6 +1890,8 @@ private:
 			*scanned = cl_last_pairs_kept;
 		if (bursts)
 			*bursts = cl_last_bursts;
+		if (admitted)
+			*admitted = cl_last_admitted;
 		return true;
 	}
 	int64_t cl_last_nq = 0, cl_last_bursts = 0;
@@ -1876,6 +1902,9 @@ private:
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
 	bool cl_bucket = true;       // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
 	int cl_bpitch = 1024;        // bucket entries per query (grown on demand up to 16 384)
+	bool cl_refilter = true;     // option ivf_cl_refilter: candidates that do not pass the bound the scan ENDED with are dropped before the exact stage
+	DevBuf ws_stream2;           // {u per stream entry | Bf per query | the filtered stream}
+	int64_t cl_last_admitted = 0; // stream entries of the last search (before the final-bound filter)
 	bool cl_prune = true;        // option ivf_probe_prune: probed lists that provably hold none of a query's k nearest rows are not scanned (L2)
 	int64_t cl_last_pairs = 0, cl_last_pairs_kept = 0; // (query, list) pairs of the last coarse-filter search / of those, scanned
 	DevBuf ws_cIp, ws_kept;

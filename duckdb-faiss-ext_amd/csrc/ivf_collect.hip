@@ -49,6 +49,7 @@ struct IvfCollectArgs {
 	unsigned *gslot;           // [nq][16] class slots
 	unsigned long long *stream; // candidates (q << 32 | padded row)
 	unsigned long long *stream_cnt;
+	float *stream_u;           // (may be null) per entry: an UPPER bound s + E of the row's exact value -- the final-bound filter's input
 	long long stream_cap;
 	int kk;
 	int seg_rows; // rows per block: grid.y walks a list in segments (one wavefront per segment: long lists do not set the pace)
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 	int qfill = 0; // entries recorded (all lanes hold the same value); entries past IC_QCAP took the immediate path below
 	int qpub = 0;  // ... of which the first qpub have been published to the class slots already
 	// publish(): the recorded hits not yet published -> class slots (fire-and-forget atomics: nothing to wait for)
-	auto publish = [&]() {
+	auto publish = [&]() __attribute__((always_inline)) {
 		const unsigned n = (unsigned)qfill < (unsigned)IC_QCAP ? (unsigned)qfill : (unsigned)IC_QCAP;
 		for (unsigned e = (unsigned)qpub + lane; e < n; e += 64) {
 			unsigned long long ent;
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		qpub = (int)n;
 	};
 	// drain(): publish what is left, then the whole queue -> the global stream behind ONE reservation (the only wait in here)
-	auto drain = [&]() {
+	auto drain = [&]() __attribute__((always_inline)) { // (forced: past ~ 10 call sites the inliner leaves a CALL with the closure -- and the kernel's argument block -- in scratch memory)
 		publish();
 		const unsigned n = (unsigned)qpub;
 		qfill = 0;
@@ -650,11 +651,15 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 			             : "=&v"(ent), "=&v"(sl)
 			             : "v"(qbuf_lds + 8u * e), "v"(qslot_lds + e)
 			             : "memory");
-			int qq;
-			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qq) : "v"(qtab_lds + sl * 8u) : "memory");
+			int2 qe;
+			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(qe) : "v"(qtab_lds + sl * 8u) : "memory");
 			if ((long long)(base + e) < a.stream_cap) {
 				typedef __attribute__((address_space(1))) unsigned long long *GUL;
-				*((GUL)a.stream + (base + e)) = ((unsigned long long)(unsigned)qq << 32) | (unsigned)(ent >> 32);
+				*((GUL)a.stream + (base + e)) = ((unsigned long long)(unsigned)qe.x << 32) | (unsigned)(ent >> 32);
+				if (a.stream_u) { // s + E(this pair), rounded up: exact <= s + E (ivf_final_bound_kernel / ivf_refilter_kernel)
+					const float ub = __uint_as_float((unsigned)ent) + __int_as_float(qe.y);
+					a.stream_u[base + e] = fmaf(fabsf(ub), 1.1920929e-07f, ub);
+				}
 			}
 		}
 	};
@@ -852,7 +857,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st) {
+                             hipStream_t st, float *d_stream_u) {
 	if (max_items <= 0 || nseg <= 0)
 		return;
 	IvfCollectArgs a;
@@ -868,6 +873,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 	a.gslot = d_gslot;
 	a.stream = d_stream;
 	a.stream_cnt = d_stream_cnt;
+	a.stream_u = d_stream_u;
 	a.stream_cap = stream_cap;
 	a.kk = kk;
 	a.seg_rows = seg_rows;
@@ -1299,6 +1305,100 @@ __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSe
 		}
 	}
 }
+// ---- final-bound filter (round 5) ---------------------------------------------------------------------------------------------
+// The scan admits a row when its coarse value passes the bound of THAT MOMENT: s >= B_now - E.  Bounds only tighten, so most of the
+// ~ 134 candidates per query at C3 were admitted early and would not pass the bound the scan ENDS with.  The stream therefore carries
+// u = s + E per entry (an upper bound of the row's exact value, rounded up), and before the exact stage
+//   ivf_final_bound_kernel  Bf[q] = the kf-th best of the query's class slots at the end of the scan: kf distinct rows have exact
+//                           values >= Bf (every slot is a LOWER bound s' - E' of a row's exact value), so the kf-th best exact value
+//                           of the result is >= Bf;  -FLT_MAX while fewer than kf classes are set
+//   ivf_refilter_kernel     keeps an entry iff u >= Bf[q] (a row of the result has u >= exact >= Bf; ties included; NaN: kept) and
+//                           writes the survivors, compacted per workgroup (one reservation each), to a second stream
+// -- the same argument as the scan's own test with the last bound instead of the running one.  The exact stage reads 4-5 x fewer
+// rows (profiles/r5_c3_ab.txt, 7).
+__global__ __launch_bounds__(256) void ivf_final_bound_kernel(const unsigned *__restrict__ gslot, int nc, int kf, long long nq,
+                                                             float *__restrict__ bf) {
+	const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (q >= nq)
+		return;
+	unsigned key[32]; // (nc = 16 or 32)
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		key[j] = j < nc ? __hip_atomic_load(gslot + q * nc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+	// the kf-th smallest key (keys: smaller = better) by rank counting; equal keys are ordered by position
+	unsigned kth = 0xffffffffu;
+#pragma unroll
+	for (int j = 0; j < 32; ++j) {
+		int r = 0;
+#pragma unroll
+		for (int i = 0; i < 32; ++i)
+			r += (key[i] < key[j] || (key[i] == key[j] && i < j)) ? 1 : 0;
+		kth = (r == kf - 1) ? key[j] : kth;
+	}
+	const unsigned neutral = ic_skey(-FLT_MAX);
+	bf[q] = ic_skey2f(kth < neutral ? kth : neutral);
+}
+constexpr int RF_PER = 8; // entries per thread
+__global__ __launch_bounds__(256) void ivf_refilter_kernel(const unsigned long long *__restrict__ strm, const float *__restrict__ su,
+                                                          long long cap, const unsigned long long *__restrict__ cnt,
+                                                          const float *__restrict__ bf, unsigned long long *__restrict__ out,
+                                                          unsigned long long *__restrict__ out_cnt) {
+	__shared__ int wsum[4];
+	__shared__ unsigned long long gbase;
+	const unsigned long long have = *cnt;
+	const long long n = have < (unsigned long long)cap ? (long long)have : cap;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (long long b0 = (long long)blockIdx.x * (256 * RF_PER); b0 < n; b0 += (long long)gridDim.x * (256 * RF_PER)) {
+		unsigned long long ent[RF_PER];
+		bool keep[RF_PER];
+		int mine = 0;
+#pragma unroll
+		for (int e = 0; e < RF_PER; ++e) {
+			const long long i = b0 + e * 256 + threadIdx.x;
+			ent[e] = i < n ? strm[i] : 0ull;
+			const float u = i < n ? su[i] : 0.f;
+			const float b = bf[i < n ? (unsigned)(ent[e] >> 32) : 0u];
+			keep[e] = i < n && !(u < b);
+			mine += keep[e] ? 1 : 0;
+		}
+		// exclusive prefix over the workgroup: lanes by DPP-free shuffles, waves through LDS, ONE global reservation per workgroup
+		int inc = mine;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const int v = __shfl_up(inc, off);
+			inc += lane >= off ? v : 0;
+		}
+		if (lane == 63)
+			wsum[wave] = inc;
+		__syncthreads();
+		int wbase = 0, total = 0;
+#pragma unroll
+		for (int w = 0; w < 4; ++w) {
+			wbase += w < wave ? wsum[w] : 0;
+			total += wsum[w];
+		}
+		if (threadIdx.x == 0)
+			gbase = total ? atomicAdd(out_cnt, (unsigned long long)total) : 0ull;
+		__syncthreads();
+		unsigned long long pos = gbase + (unsigned long long)(wbase + inc - mine);
+#pragma unroll
+		for (int e = 0; e < RF_PER; ++e)
+			if (keep[e])
+				out[pos++] = ent[e];
+		__syncthreads(); // (wsum / gbase are rewritten by the next round)
+	}
+}
+void launch_ivf_refilter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
+                         const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned long long *d_out,
+                         unsigned long long *d_out_cnt, hipStream_t st) {
+	if (nq <= 0 || cap <= 0)
+		return;
+	hipLaunchKernelGGL(ivf_final_bound_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_gslot, nclass, kf, (long long)nq, d_bf);
+	const unsigned blocks = (unsigned)std::min<int64_t>((cap + 256 * RF_PER - 1) / (256 * RF_PER), 2048);
+	hipLaunchKernelGGL(ivf_refilter_kernel, dim3(blocks), dim3(256), 0, st, d_strm, d_su, (long long)cap, d_cnt, d_bf, d_out, d_out_cnt);
+	MVS_HIP(hipGetLastError());
+}
+
 // d_strm: the scan's candidate stream (ncand = its capacity or the host's count; the real number is min(*d_cnt, ncand));
 // d_bucket [nq][bpitch] keys, d_bcount [nq] (zeroed); outputs as ivf_bucket_select_kernel describes
 // fa != nullptr: the Flat shadow's arithmetic (see IvfFlatArith) -- the lists come out in FAISS's Flat L2 order, labels = row + label_offset

@@ -120,7 +120,7 @@ _L.mvs_index_to_gpu.argtypes = [_p, C.c_int]
 _L.mvs_index_clone_to_gpu.argtypes = [C.POINTER(_p), _p, C.c_int]
 _L.mvs_index_prefilter_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_float), C.POINTER(C.c_float)]
 _L.mvs_index_collect_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
-_L.mvs_index_ivf_probe_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
+_L.mvs_index_ivf_probe_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_index_shard_to_gpus.argtypes = [_p, C.POINTER(C.c_int), C.c_int]
 _L.mvs_index_shard_info.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_write_index.argtypes = [_p, C.c_char_p]
@@ -313,9 +313,9 @@ class Index:
 
     def ivf_probe_stats(self):
         """(query, list) pairs of the last IVF coarse-filter search and how many of them were scanned (probe pruning)."""
-        a, b, c = _i64(0), _i64(0), _i64(0)
-        _check(_L.mvs_index_ivf_probe_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"pairs": a.value, "scanned": b.value, "forced_drains": c.value}
+        a, b, c, e = _i64(0), _i64(0), _i64(0), _i64(0)
+        _check(_L.mvs_index_ivf_probe_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(e)))
+        return {"pairs": a.value, "scanned": b.value, "forced_drains": c.value, "admitted": e.value}
 
     def collect_stats(self):
         q, c, o = _i64(0), _i64(0), _i64(0)

@@ -225,8 +225,10 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
  * scanned.  IndexIVF::search (faiss/IndexIVF.cpp search_preassigned, reached from src/faiss_extension.cpp:631) scans every probed
  * list; this path leaves out the lists that PROVABLY hold none of a query's k nearest rows (triangle inequality on the coarse
  * distance and the list's radius, option ivf_probe_prune, L2 without an IDSelector) -- labels and distances are unchanged.
- * forced_drains: how often a scan wavefront of the last search had to empty its LDS hit queue in the middle of a tile. */
-int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains);
+ * forced_drains: how often a scan wavefront of the last search had to empty its LDS hit queue in the middle of a tile.
+ * admitted: candidates the scan of the last search admitted under its running bounds; mvs_index_collect_stats counts those that
+ * also passed the bound the scan ended with and were re-scored exactly (option ivf_cl_refilter). */
+int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains, int64_t *admitted);
 int mvs_device_count(void);
 const char *mvs_version(void);
 

@@ -126,3 +126,28 @@ def test_uniform_rows_and_inner_product_prune_nothing_harmful(mf, metric):
     if metric == IP:
         assert st["scanned"] == st["pairs"]
     assert _same(r1, o.search(xq, k, nprobe=nprobe)), st
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("k", [1, 10, 31])
+def test_final_bound_filter_drops_candidates_not_results(mf, metric, k):
+    """option ivf_cl_refilter (csrc/ivf_collect.hip ivf_refilter_kernel): candidates admitted under an early, loose bound are dropped when
+    they do not pass the bound the scan ENDED with -- fewer rows re-scored, the same answers, exact ties included"""
+    d, nlist, n, nq, nprobe = 64, 64, 80000, 500, 12
+    xb = orc.synth_clustered(n, d, 41, n_centers=nlist, sigma=0.2)
+    xq = orc.synth_clustered(nq, d, 42, n_centers=nlist, sigma=0.2)
+    xb[n // 2 :: 5] = xb[: len(xb[n // 2 :: 5])]  # copies: ties at and around rank k
+    xq[:60] = xb[7:67]
+    g, o = _pair(mf, d, f"IVF{nlist},Flat", metric, xb)
+    c0 = g.collect_stats()
+    r1 = g.search(xq, k, nprobe=nprobe)
+    assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+    c1, st = g.collect_stats(), g.ivf_probe_stats()
+    rescored = c1["candidates"] - c0["candidates"]
+    assert 0 < rescored <= st["admitted"], (rescored, st)
+    g.set_option("ivf_cl_refilter", 0)
+    r0 = g.search(xq, k, nprobe=nprobe)
+    c2 = g.collect_stats()
+    assert c2["candidates"] - c1["candidates"] == g.ivf_probe_stats()["admitted"]
+    assert c2["candidates"] - c1["candidates"] >= rescored
+    assert _same(r1, r0) and _same(r1, o.search(xq, k, nprobe=nprobe))
