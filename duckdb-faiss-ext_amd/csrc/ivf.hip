@@ -1065,7 +1065,7 @@ public:
 			                         (unsigned *)ws_gslot.p, nclass, (int *)ws_qfail.p, ctl_flag, stream);
 			launch_ivf_collect_scan(ws_items0.p, d_nitems0, max_items0, (const int *)ws_qidx0.p, ws_xi0.p, (const float *)ws_ig0.p,
 			                        (const float *)ws_ie20.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, 256, 1, 0, rowmask, stream);
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, cl_near_rows, 1, 0, rowmask, stream);
 			begin_kernel_timing(stream);
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
@@ -1096,7 +1096,7 @@ public:
 			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
 			                        (const float *)(phase == 0 && shared ? ws_ie2p.p : ws_ie2.p), (const unsigned short *)codes_bfr.p,
 			                        (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : 256) : seg_rows,
+			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : cl_near_rows) : seg_rows,
 			                        phase == 0 ? 1 : nseg, phase, rowmask, stream, phase == 1 ? strm_u : nullptr);
 			if (phase == 1)
 				end_kernel_timing(stream);
@@ -1738,6 +1738,10 @@ public:
 			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_near_rows")) { // rows of the nearest list the pre-pass looks at (a multiple of 32; A/B)
+			cl_near_rows = (int)std::max<int64_t>(32, std::min<int64_t>(4096, (v + 31) / 32 * 32));
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_refilter")) {
 			cl_refilter = v != 0;
 			return true;
@@ -1902,6 +1906,7 @@ private:
 	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
 	bool cl_bucket = true;       // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
 	int cl_bpitch = 1024;        // bucket entries per query (grown on demand up to 16 384)
+	int cl_near_rows = 256;      // option ivf_cl_near_rows: rows of every query's nearest list the publish-only pre-pass walks
 	bool cl_refilter = true;     // option ivf_cl_refilter: candidates that do not pass the bound the scan ENDED with are dropped before the exact stage
 	DevBuf ws_stream2;           // {u per stream entry | Bf per query | the filtered stream}
 	int64_t cl_last_admitted = 0; // stream entries of the last search (before the final-bound filter)

@@ -1316,29 +1316,32 @@ __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSe
 //                           writes the survivors, compacted per workgroup (one reservation each), to a second stream
 // -- the same argument as the scan's own test with the last bound instead of the running one.  The exact stage reads 4-5 x fewer
 // rows (profiles/r5_c3_ab.txt, 7).
-__global__ __launch_bounds__(256) void ivf_final_bound_kernel(const unsigned *__restrict__ gslot, int nc, int kf, long long nq,
-                                                             float *__restrict__ bf) {
-	const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+template <int NC>
+__global__ __launch_bounds__(64) void ivf_final_bound_kernel(const unsigned *__restrict__ gslot, int kf, long long nq, float *__restrict__ bf) {
+	const long long q = (long long)blockIdx.x * 64 + threadIdx.x;
 	if (q >= nq)
 		return;
-	unsigned key[32]; // (nc = 16 or 32)
+	unsigned key[NC];
+	const uint4 *src = (const uint4 *)(gslot + q * NC); // (the scan has finished: plain loads)
 #pragma unroll
-	for (int j = 0; j < 32; ++j)
-		key[j] = j < nc ? __hip_atomic_load(gslot + q * nc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+	for (int j = 0; j < NC / 4; ++j) {
+		const uint4 v = src[j];
+		key[4 * j] = v.x, key[4 * j + 1] = v.y, key[4 * j + 2] = v.z, key[4 * j + 3] = v.w;
+	}
 	// the kf-th smallest key (keys: smaller = better) by rank counting; equal keys are ordered by position
 	unsigned kth = 0xffffffffu;
 #pragma unroll
-	for (int j = 0; j < 32; ++j) {
+	for (int j = 0; j < NC; ++j) {
 		int r = 0;
 #pragma unroll
-		for (int i = 0; i < 32; ++i)
+		for (int i = 0; i < NC; ++i)
 			r += (key[i] < key[j] || (key[i] == key[j] && i < j)) ? 1 : 0;
 		kth = (r == kf - 1) ? key[j] : kth;
 	}
 	const unsigned neutral = ic_skey(-FLT_MAX);
 	bf[q] = ic_skey2f(kth < neutral ? kth : neutral);
 }
-constexpr int RF_PER = 8; // entries per thread
+constexpr int RF_PER = 2; // entries per thread (a latency-bound gather of Bf[q]: many small workgroups)
 __global__ __launch_bounds__(256) void ivf_refilter_kernel(const unsigned long long *__restrict__ strm, const float *__restrict__ su,
                                                           long long cap, const unsigned long long *__restrict__ cnt,
                                                           const float *__restrict__ bf, unsigned long long *__restrict__ out,
@@ -1393,8 +1396,11 @@ void launch_ivf_refilter(const unsigned long long *d_strm, const float *d_su, in
                          unsigned long long *d_out_cnt, hipStream_t st) {
 	if (nq <= 0 || cap <= 0)
 		return;
-	hipLaunchKernelGGL(ivf_final_bound_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_gslot, nclass, kf, (long long)nq, d_bf);
-	const unsigned blocks = (unsigned)std::min<int64_t>((cap + 256 * RF_PER - 1) / (256 * RF_PER), 2048);
+	if (nclass == 32)
+		hipLaunchKernelGGL(ivf_final_bound_kernel<32>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);
+	else
+		hipLaunchKernelGGL(ivf_final_bound_kernel<16>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);
+	const unsigned blocks = (unsigned)std::min<int64_t>((cap + 256 * RF_PER - 1) / (256 * RF_PER), 8192);
 	hipLaunchKernelGGL(ivf_refilter_kernel, dim3(blocks), dim3(256), 0, st, d_strm, d_su, (long long)cap, d_cnt, d_bf, d_out, d_out_cnt);
 	MVS_HIP(hipGetLastError());
 }
