@@ -465,7 +465,13 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               const int64_t *d_rowids, const int64_t *d_idmap, int k, float *d_D, int64_t *d_I,
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
                               int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa = nullptr,
-                              int64_t label_offset = 0);
+                              int64_t label_offset = 0, const unsigned *d_brow = nullptr, int rows_interleaved = 0,
+                              const unsigned long long *d_units = nullptr, const unsigned *d_unit_cnt = nullptr);
+size_t ivf_bucket_units_bytes(int64_t cap_entries);
+// final bound + the survivors into their queries' row buckets (csrc/ivf_collect.hip); launch_ivf_bucket_finish(..., d_brow) re-scores them
+void launch_ivf_bucket_scatter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
+                               const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned *d_brow, unsigned *d_bcount,
+                               int bpitch, unsigned long long *d_kept_cnt, unsigned long long *d_units, unsigned *d_unit_cnt, hipStream_t st);
 // probed lists that provably hold none of a query's k nearest rows -> -1 in d_out (csrc/ivf_collect.hip ivf_probe_prune_kernel); np <= 256
 void launch_ivf_probe_prune(const float *d_x, int64_t nq, int d, const float *d_cD, const int64_t *d_cI, int np, int k, const float *d_cn,
                             const unsigned *d_list_max, const int64_t *d_list_off, int64_t *d_out, int *d_kept, hipStream_t st);

@@ -999,12 +999,19 @@ public:
 		const bool refilter = bucket && cl_refilter;
 		float *strm_u = nullptr, *bf_q = nullptr;
 		unsigned long long *strm2 = nullptr, *cnt2 = (unsigned long long *)ws_qfail.p + 1;
+		// (second cut: the survivors go to per-query ROW buckets and one wavefront per query re-scores them -- d = 128 only)
+		const bool bexact = refilter && cl_bexact && d == 128 && dp == 128;
+		unsigned *brow = nullptr, *const bunit_cnt = (unsigned *)ws_qfail.p + 4; // (the unit count: control block header, byte 16)
+		unsigned long long *bunits = nullptr;
 		if (refilter) {
 			const size_t ub = ((size_t)cap_entries * 4 + 255) & ~(size_t)255, bb = ((size_t)nq * 4 + 255) & ~(size_t)255;
-			ws_stream2.reserve(ub + bb + (size_t)cap_entries * 8 + 256);
+			const size_t rb = bexact ? (((size_t)nq * bpitch * 4 + 255) & ~(size_t)255) : (size_t)cap_entries * 8;
+			ws_stream2.reserve(ub + bb + rb + (bexact ? ivf_bucket_units_bytes(cap_entries) : 0) + 256);
 			strm_u = (float *)ws_stream2.p;
 			bf_q = (float *)((char *)ws_stream2.p + ub);
 			strm2 = (unsigned long long *)((char *)ws_stream2.p + ub + bb);
+			brow = bexact ? (unsigned *)strm2 : nullptr;
+			bunits = bexact ? (unsigned long long *)((char *)ws_stream2.p + ub + bb + rb) : nullptr;
 		}
 		memset(&kinfo, 0, sizeof kinfo);
 		// IDSelector: one bit per padded row, built per search (the selector sees the stored id, through the id map if any)
@@ -1116,7 +1123,10 @@ public:
 			// kernel and the tie pass after it: two launch latencies with the GPU idle)
 			const bool fin = raw_pos && fin_D != nullptr && kk == fin_k + 1 && !shadow;
 			const unsigned long long *ex_strm = strm, *ex_cnt = cnt;
-			if (refilter) {
+			if (bexact) {
+				launch_ivf_bucket_scatter(strm, strm_u, cap_entries, cnt, (const unsigned *)ws_gslot.p, nclass, kf, nq, bf_q, brow,
+				                          (unsigned *)ctl_seg, bpitch, cnt2, bunits, bunit_cnt, stream);
+			} else if (refilter) {
 				launch_ivf_refilter(strm, strm_u, cap_entries, cnt, (const unsigned *)ws_gslot.p, nclass, kf, nq, bf_q, strm2, cnt2, stream);
 				ex_strm = strm2, ex_cnt = cnt2;
 			}
@@ -1127,7 +1137,7 @@ public:
 				fa.qn = shadow->qn, fa.yn = (const float *)norms_csr.p, fa.rowids = (const long long *)rowids.p;
 				launch_ivf_bucket_finish(METRIC_L2, ex_strm, cap_entries, ex_cnt, sorted, (unsigned *)ctl_seg, bpitch, nq, d_x, d, (const float *)codes.p,
 				                         dp, (const int *)perm_mf.p, kk, d_D, d_I, nullptr, shadow->out_map, 0, nullptr, nullptr, nullptr, nullptr,
-				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off);
+				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off, brow, 0, bunits, bunit_cnt);
 				FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
 				launch_ivf_shadow_verify(qz->coarse_matrix(), (const float *)ws_cD.p, probe_keys, nq, (int)nlist, (int)np, d, kk,
 				                         shadow->qn, qz->row_norms(), (const unsigned *)list_max.p, (const int64_t *)lb_dev.p,
@@ -1137,7 +1147,7 @@ public:
 			                         (const float *)codes.p, dp, (const int *)perm_mf.p, kk, d_D, d_I, raw_pos ? nullptr : (const int64_t *)rowids.p,
 			                         (d_idmap && !raw_ids && !raw_pos) ? d_idmap : nullptr, fin ? (int)fin_k : 0, fin ? fin_D : nullptr,
 			                         fin ? fin_I : nullptr, (const int64_t *)rowids.p, fin ? fin_idmap : nullptr, fin ? ctl_flag : nullptr, ctl_stats,
-			                         ctl_qfail, fail_cnt, fail_q, prep2, stream);
+			                         ctl_qfail, fail_cnt, fail_q, prep2, stream, nullptr, 0, brow, 0, bunits, bunit_cnt);
 			if (prep2)
 				ctl_clean_p = ws_qfail.p, ctl_clean_cap = ws_qfail.cap, ctl_clean_nq = nq;
 			if (fin) {
@@ -1742,6 +1752,10 @@ public:
 			cl_near_rows = (int)std::max<int64_t>(32, std::min<int64_t>(4096, (v + 31) / 32 * 32));
 			return true;
 		}
+		if (!strcmp(key, "ivf_cl_bexact")) {
+			cl_bexact = v != 0;
+			return true;
+		}
 		if (!strcmp(key, "ivf_cl_refilter")) {
 			cl_refilter = v != 0;
 			return true;
@@ -1907,6 +1921,7 @@ private:
 	bool cl_bucket = true;       // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
 	int cl_bpitch = 1024;        // bucket entries per query (grown on demand up to 16 384)
 	int cl_near_rows = 256;      // option ivf_cl_near_rows: rows of every query's nearest list the publish-only pre-pass walks
+	bool cl_bexact = true;       // option ivf_cl_bexact: the survivors of the final-bound filter in per-query row buckets, one wavefront per query re-scores them (d = 128)
 	bool cl_refilter = true;     // option ivf_cl_refilter: candidates that do not pass the bound the scan ENDED with are dropped before the exact stage
 	DevBuf ws_stream2;           // {u per stream entry | Bf per query | the filtered stream}
 	int64_t cl_last_admitted = 0; // stream entries of the last search (before the final-bound filter)

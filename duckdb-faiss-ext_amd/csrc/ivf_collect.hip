@@ -1089,7 +1089,7 @@ __device__ __forceinline__ unsigned long long eb_key(float acc, int pos, long lo
 	if (ARITH == 2 && pos >= 0) {
 		v = fmaf(-2.0f, acc, fa.qn[q] + fa.yn[pos]);
 		v = v < 0.f ? 0.f : v; // FAISS: if (dis < 0) dis = 0
-		low = (unsigned)fa.rowids[pos];
+		low = fa.rowids ? (unsigned)fa.rowids[pos] : (unsigned)pos;
 	}
 	const bool ok = pos >= 0 && (L2KEY ? v < FLT_MAX : v > -FLT_MAX);
 	return ok ? (((unsigned long long)bkey<L2KEY>(v) << 32) | low) : CB_EMPTY;
@@ -1405,6 +1405,197 @@ void launch_ivf_refilter(const unsigned long long *d_strm, const float *d_su, in
 	MVS_HIP(hipGetLastError());
 }
 
+// ---- bucketed exact stage (round 5, second cut): the survivors of the final-bound test go to their QUERY's bucket first, as (padded)
+// row numbers; then one wavefront per query re-scores its bucket -- the query row is fetched once (LDS, broadcast reads) instead of once
+// per candidate (half the gather traffic of ivf_exact_bucket_kernel, whose stream is not grouped by query), a query's ~ 36 rows are one
+// or two half groups of 32.  Keys go to the key bucket ivf_bucket_select_kernel reads; bcount[q] counts every survivor (also those
+// past the pitch: the select kernel reports the maximum, the host grows the pitch and repeats the pass).
+constexpr int BEX_CHUNK = 128, BEX_EXTRA = 4096; // candidates of a query per unit of the exact stage; extra wavefronts that walk the unit list
+// (a query's bucket counter takes ONE global atomic per workgroup round that has survivors of it: the round's 512 entries are counted
+// per query in an LDS hash table first.  One returning atomic per survivor -- the first version -- serialises on the counters of the
+// few queries that own thousands of survivors: 109 us at C3 against 16 for the plain compaction)
+constexpr int BSC_PER = 2, BSC_HASH = 1024; // entries per thread and round; LDS hash slots (a power of two > 256 * BSC_PER)
+__global__ __launch_bounds__(256) void ivf_bucket_scatter_kernel(const unsigned long long *__restrict__ strm, const float *__restrict__ su,
+                                                                long long cap, const unsigned long long *__restrict__ cnt,
+                                                                const float *__restrict__ bf, unsigned *__restrict__ brow,
+                                                                unsigned *__restrict__ bcount, int bpitch,
+                                                                unsigned long long *__restrict__ kept_cnt,
+                                                                unsigned long long *__restrict__ units, unsigned *__restrict__ unit_cnt) {
+	__shared__ unsigned hkey[BSC_HASH], hcnt[BSC_HASH], hbase[BSC_HASH];
+	__shared__ int wsum[4];
+	const unsigned long long have = *cnt;
+	const long long n = have < (unsigned long long)cap ? (long long)have : cap;
+	int mine = 0;
+	for (long long b0 = (long long)blockIdx.x * (256 * BSC_PER); b0 < n; b0 += (long long)gridDim.x * (256 * BSC_PER)) {
+		for (int h = threadIdx.x; h < BSC_HASH; h += 256)
+			hkey[h] = 0xffffffffu, hcnt[h] = 0u;
+		__syncthreads();
+		unsigned row[BSC_PER], q[BSC_PER], hs[BSC_PER], rk[BSC_PER];
+		bool keep[BSC_PER];
+#pragma unroll
+		for (int e = 0; e < BSC_PER; ++e) {
+			const long long i = b0 + e * 256 + threadIdx.x;
+			const unsigned long long ent = i < n ? strm[i] : 0ull;
+			row[e] = (unsigned)ent, q[e] = (unsigned)(ent >> 32);
+			keep[e] = i < n && !(su[i] < bf[q[e]]); // (NaN on either side: kept)
+			hs[e] = 0u, rk[e] = 0u;
+			if (keep[e]) {
+				unsigned h = (q[e] * 2654435761u) >> 22; // (10 bits)
+				for (;;) {
+					const unsigned old = atomicCAS(&hkey[h], 0xffffffffu, q[e]);
+					if (old == 0xffffffffu || old == q[e])
+						break;
+					h = (h + 1u) & (unsigned)(BSC_HASH - 1);
+				}
+				hs[e] = h;
+				rk[e] = atomicAdd(&hcnt[h], 1u);
+				++mine;
+			}
+		}
+		__syncthreads();
+		for (int h = threadIdx.x; h < BSC_HASH; h += 256)
+			if (hcnt[h])
+				hbase[h] = __hip_atomic_fetch_add(bcount + hkey[h], hcnt[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < BSC_PER; ++e) {
+			if (!keep[e])
+				continue;
+			const unsigned slot = hbase[hs[e]] + rk[e];
+			if (slot < (unsigned)bpitch) {
+				brow[(size_t)q[e] * (size_t)bpitch + slot] = row[e];
+				// a query's first BEX_CHUNK rows belong to its own wavefront; every further chunk becomes a unit of the extra waves
+				// (exactly one entry has slot = a given multiple of the chunk) -- a query sitting on thousands of candidates is not ONE
+				// wave's serial work (C3: 36 queries of a giant list, ~ 3 500 each, were 0.45 ms of tail)
+				if (slot >= (unsigned)BEX_CHUNK && (slot & (unsigned)(BEX_CHUNK - 1)) == 0u)
+					units[__hip_atomic_fetch_add(unit_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] =
+					    ((unsigned long long)q[e] << 32) | (slot / (unsigned)BEX_CHUNK);
+			}
+		}
+		__syncthreads(); // (the tables are cleared for the next round)
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		mine += __shfl_xor(mine, off);
+	if ((threadIdx.x & 63) == 0)
+		wsum[threadIdx.x >> 6] = mine;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+		if (t)
+			atomicAdd(kept_cnt, (unsigned long long)t);
+	}
+}
+// ARITH as ivf_exact_bucket_kernel; IL: the rows are a Flat index's pair-interleaved f32 store (csrc/common.h FlatGeom: inside every
+// four consecutive k the floats sit as [k0,k2,k1,k3] in rows with bit 4 clear, [k1,k3,k0,k2] in rows with bit 4 set).  d = dp = 128.
+template <int ARITH, bool IL>
+__global__ __launch_bounds__(64) void ivf_bucket_exact_kernel(const unsigned *__restrict__ brow, const unsigned *__restrict__ bcount,
+                                                             int bpitch, const float *__restrict__ x, const float *__restrict__ rows,
+                                                             const int *__restrict__ perm, unsigned long long *__restrict__ bucket,
+                                                             const IvfFlatArith fa, long long nq, const unsigned long long *__restrict__ units,
+                                                             const unsigned *__restrict__ unit_cnt) {
+	__shared__ __attribute__((aligned(16))) float yrows[32 * 132];
+	__shared__ __attribute__((aligned(16))) float xq[128];
+	__shared__ int mpos[32];
+	const int lane = threadIdx.x, sub = lane >> 5, ch = lane & 31;
+	// wavefront b < nq: the first BEX_CHUNK candidates of query b; the BEX_EXTRA wavefronts behind them walk the unit list
+	const bool extra = (long long)blockIdx.x >= nq;
+	const unsigned nunits = extra ? *unit_cnt : 1u;
+	for (unsigned un = extra ? (unsigned)((long long)blockIdx.x - nq) : 0u; un < nunits; un += (unsigned)BEX_EXTRA) {
+	long long q = blockIdx.x;
+	int begin = 0;
+	if (extra) {
+		const unsigned long long ue = units[un];
+		q = (long long)(ue >> 32);
+		begin = (int)(unsigned)ue * BEX_CHUNK;
+	}
+	const unsigned have = bcount[q];
+	int n = have < (unsigned)bpitch ? (int)have : bpitch;
+	n = n < begin + BEX_CHUNK ? n : begin + BEX_CHUNK;
+	if (n <= begin) {
+		if (!extra)
+			return;
+		continue;
+	}
+	asm volatile("" ::: "memory");
+	if (lane < 32)
+		*(f32x4i *)(xq + 4 * lane) = *(const f32x4i *)(x + (size_t)q * 128 + 4 * lane);
+	const unsigned *mine = brow + (size_t)q * (size_t)bpitch;
+	unsigned long long *keys = bucket + (size_t)q * (size_t)bpitch;
+	int pos = -1;
+	if (lane < 32 && begin + lane < n) {
+		const unsigned r = mine[begin + lane];
+		pos = perm ? perm[r] : (int)r;
+	}
+	for (int g0 = begin; g0 < n; g0 += 32) {
+		if (lane < 32)
+			mpos[lane] = pos;
+		asm volatile("" ::: "memory"); // (one wavefront: LDS keeps its accesses in order)
+		f32x4i ry[16];
+#pragma unroll
+		for (int it = 0; it < 16; ++it) {
+			const int pp = mpos[2 * it + sub];
+			ry[it] = pp >= 0 ? *(const f32x4i *)(rows + (size_t)pp * 128 + ch * 4) : f32x4i{0.f, 0.f, 0.f, 0.f};
+		}
+		const int cur = pos; // (this half group's position of lanes 0 .. 31)
+		pos = -1;
+		if (lane < 32 && g0 + 32 + lane < n) { // the next half group's rows, behind this one's loads
+			const unsigned r = mine[g0 + 32 + lane];
+			pos = perm ? perm[r] : (int)r;
+		}
+#pragma unroll
+		for (int it = 0; it < 16; ++it)
+			*(f32x4i *)(yrows + (2 * it + sub) * 132 + ch * 4) = ry[it];
+		asm volatile("" ::: "memory");
+		if (lane < 32 && cur >= 0) {
+			const float *y = yrows + lane * 132;
+			const bool flip = IL && ((cur >> 4) & 1);
+			float acc = 0.f;
+#pragma unroll
+			for (int c4 = 0; c4 < 32; ++c4) {
+				const float4 xv = *(const float4 *)(xq + c4 * 4);
+				const float4 yv = *(const float4 *)(y + c4 * 4);
+				const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+				float ys[4] = {yv.x, yv.y, yv.z, yv.w};
+				if (IL) {
+					ys[0] = flip ? yv.z : yv.x, ys[1] = flip ? yv.x : yv.z, ys[2] = flip ? yv.w : yv.y, ys[3] = flip ? yv.y : yv.w;
+				}
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					if (ARITH == 0) {
+						const float t = __fsub_rn(xs[e], ys[e]);
+						acc = fmaf(t, t, acc);
+					} else {
+						acc = fmaf(xs[e], ys[e], acc);
+					}
+				}
+			}
+			keys[g0 + lane] = eb_key<ARITH>(acc, cur, q, fa);
+		}
+		asm volatile("" ::: "memory"); // (the next half group's rows overwrite the tile)
+	}
+	if (!extra)
+		return;
+	} // unit
+}
+void launch_ivf_bucket_scatter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
+                               const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned *d_brow, unsigned *d_bcount,
+                               int bpitch, unsigned long long *d_kept_cnt, unsigned long long *d_units, unsigned *d_unit_cnt, hipStream_t st) {
+	if (nq <= 0 || cap <= 0)
+		return;
+	if (nclass == 32)
+		hipLaunchKernelGGL(ivf_final_bound_kernel<32>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);
+	else
+		hipLaunchKernelGGL(ivf_final_bound_kernel<16>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);
+	const unsigned blocks = (unsigned)std::min<int64_t>((cap + 256 * BSC_PER - 1) / (256 * BSC_PER), 4096);
+	hipLaunchKernelGGL(ivf_bucket_scatter_kernel, dim3(blocks), dim3(256), 0, st, d_strm, d_su, (long long)cap, d_cnt, d_bf, d_brow, d_bcount,
+	                   bpitch, d_kept_cnt, d_units, d_unit_cnt);
+	MVS_HIP(hipGetLastError());
+}
+size_t ivf_bucket_units_bytes(int64_t cap_entries) { // (every unit stands for BEX_CHUNK candidates of one query)
+	return ((size_t)(cap_entries / BEX_CHUNK) + 64) * sizeof(unsigned long long);
+}
+
 // d_strm: the scan's candidate stream (ncand = its capacity or the host's count; the real number is min(*d_cnt, ncand));
 // d_bucket [nq][bpitch] keys, d_bcount [nq] (zeroed); outputs as ivf_bucket_select_kernel describes
 // fa != nullptr: the Flat shadow's arithmetic (see IvfFlatArith) -- the lists come out in FAISS's Flat L2 order, labels = row + label_offset
@@ -1414,7 +1605,8 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               const int64_t *d_rowids, const int64_t *d_idmap, int k, float *d_D, int64_t *d_I,
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
                               int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa,
-                              int64_t label_offset) {
+                              int64_t label_offset, const unsigned *d_brow, int rows_interleaved, const unsigned long long *d_units,
+                              const unsigned *d_unit_cnt) {
 	if (nq <= 0)
 		return;
 	if (dp_csr % 4 != 0 || dp_csr > 128 || kk > 64 || kk < 1)
@@ -1422,7 +1614,29 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
 	const bool l2 = metric_order(metric) == METRIC_L2;
 	IvfFlatArith nofa;
 	memset(&nofa, 0, sizeof nofa);
-	if (ncand > 0) { // a fixed grid walks the stream in strides (its length is on the device): two dispatch rounds of the 4 096 resident waves
+	if (d_brow) { // the candidates sit in their queries' buckets already (launch_ivf_bucket_scatter): one wavefront per query
+		if (d != 128 || dp_csr != 128)
+			throw_faiss("mvs::launch_ivf_bucket_finish", __FILE__, "the bucketed exact stage serves d = 128 (got d = %d, pitch %d)", d, dp_csr);
+		const dim3 grid((unsigned)nq + (unsigned)BEX_EXTRA);
+#define MVS_BEX(AR, ILV) hipLaunchKernelGGL((ivf_bucket_exact_kernel<AR, ILV>), grid, dim3(64), 0, st, d_brow, d_bcount, bpitch, d_x, d_rows_csr, d_perm, d_bucket, fa ? *fa : nofa, (long long)nq, d_units, d_unit_cnt)
+		if (fa && fa->qn) {
+			if (rows_interleaved)
+				MVS_BEX(2, true);
+			else
+				MVS_BEX(2, false);
+		} else if (l2) {
+			if (rows_interleaved)
+				MVS_BEX(0, true);
+			else
+				MVS_BEX(0, false);
+		} else {
+			if (rows_interleaved)
+				MVS_BEX(1, true);
+			else
+				MVS_BEX(1, false);
+		}
+#undef MVS_BEX
+	} else if (ncand > 0) { // a fixed grid walks the stream in strides (its length is on the device): two dispatch rounds of the 4 096 resident waves
 		const dim3 grid((unsigned)std::min<int64_t>((ncand + 63) / 64, 8192));
 		if (fa)
 			hipLaunchKernelGGL(ivf_exact_bucket_kernel<2>, grid, dim3(64), 0, st, d_strm, (long long)ncand, d_cnt, d_x, d, d_rows_csr, dp_csr,
