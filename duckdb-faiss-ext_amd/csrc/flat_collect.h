@@ -24,6 +24,7 @@ struct CollectArgs {
 	unsigned *gslot;           // [nq][slot_stride] class slots: keys of the best s per row class (smaller key = better)
 	unsigned long long *stream; // candidates (q << 32 | row)
 	unsigned long long *stream_cnt; // [0] entries appended
+	float *stream_s;           // (may be null; d <= 128 scan) the coarse value s of every entry: the final-bound filter's input
 	const unsigned long long *rowmask; // SEL instances: bit r of word b = row 64 b + r passes the IDSelector
 	long long stream_cap;
 	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them

@@ -613,10 +613,16 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_collect_kernel(const Collect
 		base = ((unsigned long long)bhi << 32) | blo;
 		for (unsigned e = lane; e < n; e += 64) {
 			unsigned long long ent;
-			asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ent) : "v"(qbuf_lds + 8u * e) : "memory");
+			float v;
+			asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(ent), "=&v"(v)
+			             : "v"(qbuf_lds + 8u * e), "v"(qval_lds + 4u * e)
+			             : "memory");
 			if ((long long)(base + e) < a.stream_cap) {
 				typedef __attribute__((address_space(1))) unsigned long long *GUL;
 				*((GUL)a.stream + (base + e)) = ent;
+				if (a.stream_s) // (round 5: the final-bound filter -- launch_collect_final_thr, csrc/ivf_collect.hip launch_ivf_bucket_scatter)
+					a.stream_s[base + e] = v;
 			}
 		}
 		ovf |= (long long)(base + n) >= a.stream_cap ? 1 : 0; // (wave-uniform)
@@ -1268,6 +1274,54 @@ int collect_max_k(int d) {
 	return ((dp1 == 768 || dp1 == 1024) && !tune().wide_big) ? 16 : 32;
 }
 
+// thr[q] = B - 2E with the class slots as the scan LEFT them (linear in q): the scan admitted a row when s >= B_then - 2E; bounds only
+// tighten, so an entry with s < thr[q] is not in the result (round 5, the final-bound filter: csrc/ivf_collect.hip)
+template <int NC>
+__global__ void collect_final_thr_kernel(const unsigned *__restrict__ gslot, const float *__restrict__ e2, int nclass, long long nq,
+                                         float *__restrict__ thr) {
+	const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nq)
+		return;
+	constexpr int SUBN = NC > 32 ? 32 : NC, NSUB = NC / SUBN;
+	const int rank = NSUB == 1 ? nclass - 1 : (nclass + NSUB - 1) / NSUB - 1;
+	unsigned kth = 0u;
+	for (int sb = 0; sb < NSUB; ++sb) {
+		unsigned key[SUBN];
+#pragma unroll
+		for (int t = 0; t < SUBN; ++t)
+			key[t] = gslot[(size_t)q * NC + sb * SUBN + t];
+		unsigned ks = 0xffffffffu;
+#pragma unroll
+		for (int t = 0; t < SUBN; ++t) {
+			int less = 0, leq = 0;
+#pragma unroll
+			for (int s2 = 0; s2 < SUBN; ++s2) {
+				less += key[s2] < key[t];
+				leq += key[s2] <= key[t];
+			}
+			if (less <= rank && rank < leq)
+				ks = key[t];
+		}
+		kth = ks > kth ? ks : kth;
+	}
+	const unsigned neutral = skey(-FLT_MAX);
+	const float B = skey2f(kth < neutral ? kth : neutral);
+	thr[q] = B - e2[q]; // (the scan's own arithmetic; NaN: nothing of the query is in the stream)
+}
+void launch_collect_final_thr(const unsigned *d_gslot, int d, int kk, const float *d_e2, int64_t nq, float *d_thr, hipStream_t st) {
+	if (nq <= 0)
+		return;
+	const int stride = collect_slot_stride(kk, collect_store_dims(d));
+	const dim3 grid((unsigned)((nq + 63) / 64));
+	if (stride == 128)
+		hipLaunchKernelGGL(collect_final_thr_kernel<128>, grid, dim3(64), 0, st, d_gslot, d_e2, kk, (long long)nq, d_thr);
+	else if (stride == 32)
+		hipLaunchKernelGGL(collect_final_thr_kernel<32>, grid, dim3(64), 0, st, d_gslot, d_e2, kk, (long long)nq, d_thr);
+	else
+		hipLaunchKernelGGL(collect_final_thr_kernel<16>, grid, dim3(64), 0, st, d_gslot, d_e2, kk, (long long)nq, d_thr);
+	MVS_HIP(hipGetLastError());
+}
+
 // slots -> neutral, stream counter -> 0, then the bound-estimation pre-pass over the first rows
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
@@ -1318,7 +1372,7 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
                          unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
-                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out) {
+                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out, float *d_stream_s) {
 	CollectArgs a;
 	memset(&a, 0, sizeof a);
 	a.qf = d_qf;
@@ -1330,6 +1384,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 	a.nclass = kk;
 	a.nq = (int)nq;
 	a.stream = d_stream;
+	a.stream_s = d_stream_s;
 	a.stream_cnt = d_stream_cnt;
 	a.stream_cap = stream_cap;
 	a.rowmask = d_rowmask;

@@ -227,6 +227,19 @@ public:
 	                        const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st, bool defer_count = false, int kf = 0);
 	int64_t cl_deferred_cap = 0;
 	bool cl_defer = true; // option cl_defer_count
+	// Round 5, bucketed finish of the d = 128 L2 coarse filter: final-bound filter -> the survivors into per-query row buckets -> one
+	// wavefront per query re-scores them -> one wavefront per query selects and prints (csrc/ivf_collect.hip, shared with the IVF path):
+	// no radix sort, no segments, ~ 4 x fewer rows re-scored.  Set by search_prefilter_pass, consumed by collect_candidates.
+	bool cl_fbucket = true;      // option cl_fbucket
+	bool cl_fbucket_off = false; // a query's bucket overflowed on this index's data: the sorted pipeline from then on
+	int cl_fpitch = 256;         // bucket entries per query
+	float *cl_out_D = nullptr;
+	int64_t *cl_out_I = nullptr;
+	const int64_t *cl_out_map = nullptr;
+	int64_t cl_out_off = 0;
+	bool cl_emitted = false;     // collect_candidates wrote the final lists itself (the caller skips its emission)
+	unsigned long long *h_cl_hdr = nullptr; // pinned copy of the control block's header (bucket statistics)
+	DevBuf ws_fbk, ws_fbr;
 	bool cl_prep1 = true;        // option cl_prep1: one fused per-query preparation kernel in front of the d <= 128 coarse filter
 	double cl_est_per_query = 0; // candidates per query of the last search: sizes the next search's sort (collect_sort_estimate)
 	int cl_skip = 0, cl_skip_len = 0; // searches that bypass the coarse filter after it gave up on this index's data (doubling, <= 64)
@@ -404,7 +417,9 @@ void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, 
 void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
                          unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
-                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out);
+                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out, float *d_stream_s = nullptr);
+// thr[q] = B - 2E from the class slots as the scan left them (csrc/flat_collect.hip): the final-bound filter of the bucketed finish
+void launch_collect_final_thr(const unsigned *d_gslot, int d, int kk, const float *d_e2, int64_t nq, float *d_thr, hipStream_t st);
 // Entries the deferred sort of a search is launched with, from the candidates per query c of the index's previous search: the
 // margin shrinks with the batch (the mean of nq heavy-tailed per-query counts), 17 % + 16 per query at 10 000 queries, 40 % at 64
 // (round 4, first cut: 30 % + 64 per query whatever the batch -- at C3's 149 per query the sort ran over 75 % more entries than it had)

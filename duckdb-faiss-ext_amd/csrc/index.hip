@@ -440,6 +440,27 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	int grid = 0, nsplit = 0, lds = 0;
 	const bool few = !wide && nq <= 128 && collect_slot_stride(kf, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
+	// the bucketed finish (see cl_fbucket in csrc/index.h): the common L2 shape only
+	const bool fb = cl_fbucket && !cl_fbucket_off && cl_out_D && metric == METRIC_L2 && !wide && !few && d == 128 && geom.dp == 128 && kk <= 64 &&
+	                nq * (int64_t)cl_fpitch < ((int64_t)1 << 31);
+	cl_emitted = false;
+	float *stream_s = nullptr, *fb_thr = nullptr;
+	unsigned *fb_rows = nullptr;
+	unsigned long long *fb_keys = nullptr, *fb_units = nullptr;
+	auto fb_layout = [&]() { // (after every change of cap_entries / of the pitch: a DevBuf keeps nothing when it grows, so the scan's
+		// per-entry values and the buckets live in two buffers -- a larger pitch must not lose the values)
+		const size_t sb = ((size_t)cap_entries * 4 + 255) & ~(size_t)255, tb = ((size_t)nq * 4 + 255) & ~(size_t)255;
+		const size_t rb = ((size_t)nq * cl_fpitch * 4 + 255) & ~(size_t)255, kb = (size_t)nq * cl_fpitch * 8;
+		ws_fbk.reserve(sb + tb + 256);
+		ws_fbr.reserve(rb + kb + ivf_bucket_units_bytes(cap_entries) + 256);
+		stream_s = (float *)ws_fbk.p;
+		fb_thr = (float *)((char *)ws_fbk.p + sb);
+		fb_rows = (unsigned *)ws_fbr.p;
+		fb_keys = (unsigned long long *)((char *)ws_fbr.p + rb);
+		fb_units = (unsigned long long *)((char *)ws_fbr.p + rb + kb);
+	};
+	if (fb)
+		fb_layout();
 	for (int attempt = 0;; ++attempt) {
 	begin_kernel_timing(st);
 	if (few) {
@@ -463,7 +484,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		lds = 20544;
 	} else {
 		launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, (const float *)ws_e2.p,
-		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, pbnd, st, &grid, &nsplit, &lds);
+		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, pbnd, st, &grid, &nsplit, &lds, stream_s);
 	}
 	end_kernel_timing(st);
 	if (!h_flag_count)
@@ -471,7 +492,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 	if (defer_count && cl_est_per_query > 0) { // the caller looks at the count after its own synchronisation
 		// (size of the sort: collect_sort_estimate of what the previous search of this index produced per query, in units of 64 K entries)
-		cl_deferred_cap = std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq));
+		cl_deferred_cap = fb ? cap_entries : std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq)); // (no sort to size)
 		break;
 	}
 	defer_count = false; // (the first search of an index has no estimate yet: the synchronous way, which leaves one)
@@ -501,6 +522,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		ws_stream.reserve(256 + 2 * half); // (a DevBuf keeps nothing when it grows: the counter -- in ws_seg -- is reset below anyway)
 		stream = (unsigned long long *)((char *)ws_stream.p + 256);
 		sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+		if (fb)
+			fb_layout();
 	} else {
 		// (b) a few queries hold far more than their share: out of the coarse filter with them, one more scan for the others
 		ws_qcount.reserve((size_t)(nq + 16) * sizeof(int));
@@ -520,6 +543,55 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		cl_est_per_query = (double)ncand / (double)std::max<int64_t>(nq, 1) + 1e-6;
 		cl_deferred_cap = 0; // (tells the caller that this pass was synchronous)
 	}
+	bool fb_done = false;
+	if (fb) {
+		// final bound -> survivors into the queries' row buckets -> exact values (FAISS's BLAS-branch formula, or the per-pair sum with a
+		// selector / fewer than 20 queries) -> selection, FAISS's order, labels: straight into the caller's arrays
+		unsigned *bcount = (unsigned *)seg; // (zero: the preparation kernel / the memset above; the select kernel leaves it zero)
+		launch_collect_final_thr((const unsigned *)ws_gthr.p, d, kf, (const float *)ws_e2.p, nq, fb_thr, st);
+		if (!h_cl_hdr)
+			MVS_HIP(hipHostMalloc((void **)&h_cl_hdr, 256, hipHostMallocDefault));
+		for (;;) {
+			launch_ivf_bucket_scatter(stream, stream_s, cap_entries, cnt, nullptr, 0, 0, nq, fb_thr, fb_rows, bcount, cl_fpitch, cnt + 1, fb_units,
+			                          (unsigned *)cnt + 4, st);
+			IvfFlatArith fa;
+			memset(&fa, 0, sizeof fa);
+			if (!(has_sel || nq < 20))
+				fa.qn = (const float *)ws_qn.p, fa.yn = norms;
+			launch_ivf_bucket_finish(METRIC_L2, nullptr, cap_entries, nullptr, fb_keys, bcount, cl_fpitch, nq, d_x, d, vecs, geom.dp, nullptr, kk,
+			                         cl_out_D, cl_out_I, nullptr, cl_out_map, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+			                         (unsigned long long *)((char *)ws_seg.p + 192), nullptr, nullptr, nullptr, true, st, &fa, cl_out_off, fb_rows,
+			                         geom.pair_interleaved ? 1 : 0, fb_units, (const unsigned *)cnt + 4);
+			MVS_HIP(hipMemcpyAsync(h_cl_hdr, ws_seg.p, 256, hipMemcpyDeviceToHost, st));
+			if (defer_count) { // (the caller looks at the header behind its own synchronisation)
+				fb_done = true;
+				break;
+			}
+			MVS_HIP(hipStreamSynchronize(st));
+			unsigned long long bmax = 0;
+			memcpy(&bmax, (const char *)h_cl_hdr + 200, sizeof bmax);
+			if ((int64_t)bmax <= cl_fpitch) {
+				fb_done = true;
+				break;
+			}
+			// some query has more survivors than its bucket holds: a larger pitch (the index remembers it) and the finish once more -- the
+			// scan's stream and values are still there; beyond 16 384 per query the sorted pipeline takes this index for good
+			const int64_t want = ((int64_t)bmax + (int64_t)bmax / 4 + 63) / 64 * 64;
+			if (want > 16384 || nq * want >= ((int64_t)1 << 31)) {
+				cl_fbucket_off = true;
+				break;
+			}
+			cl_fpitch = (int)want;
+			fb_layout();
+			MVS_HIP(hipMemsetAsync((char *)ws_seg.p + 8, 0, 248 + (size_t)nq * sizeof(int), st)); // kept / unit counts, statistics, the bucket counters
+		}
+	}
+	if (fb_done) {
+		cl_emitted = true;
+		*pd1_out = nullptr;
+		*pi1_out = nullptr;
+		cl_sorted = nullptr;
+	} else {
 	const size_t temp = defer_count ? collect_sort_temp_bytes_est(cl_deferred_cap, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 	ws_sorttmp.reserve(std::max<size_t>(temp, 16));
 	const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
@@ -533,6 +605,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	*pd1_out = pd1;
 	*pi1_out = pi1;
 	cl_sorted = sorted;
+	}
 	snprintf(kinfo.name, sizeof kinfo.name, "%s", wide ? collect_wide_kernel_name(collect_store_dims(d)) : "flat_bf16_collect_kernel");
 	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
 	// one pass over the bf16 store (row pitch of the store + the row's f32 term) + the queries + the results
@@ -933,7 +1006,10 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 			--cl_skip;
 		} else {
 			kp = (int)kk;
+			const bool direct = metric == METRIC_L2 && !flp && kk == k_user; // (collect_candidates may write the final lists itself)
+			cl_out_D = direct ? d_D : nullptr, cl_out_I = direct ? d_I : nullptr, cl_out_map = out_map, cl_out_off = out_off;
 			collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer, (int)kf);
+			cl_out_D = nullptr, cl_out_I = nullptr;
 			if (!collected) {
 				MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 				cl_skip_len = std::min(64, std::max(4, 2 * cl_skip_len));
@@ -986,7 +1062,10 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	kinfo.nsplit = p.nsplit;
 	}
 	// the exact candidates through the normal merge: FAISS order, labels, inner-product tie flags
-	if (collected && metric == METRIC_L2 && !flp) // (the coarse filter's selection is in FAISS's L2 order already: labels only)
+	const bool emitted = collected && cl_emitted; // (the bucketed finish printed the lists already)
+	if (emitted)
+		;
+	else if (collected && metric == METRIC_L2 && !flp) // (the coarse filter's selection is in FAISS's L2 order already: labels only)
 		launch_emit_sorted(pd1, pi1, nq, kp, k_user, out_map, out_off, d_D, d_I, st);
 	else
 		launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp);
@@ -1023,6 +1102,19 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		tie_sorted = nullptr;
 	} else {
 		MVS_HIP(hipStreamSynchronize(st));
+	}
+	if (emitted) { // (synchronised above) a bucket too small for some query: its list is incomplete -- the sorted pipeline takes over for good
+		unsigned long long bmax = 0;
+		memcpy(&bmax, (const char *)h_cl_hdr + 200, sizeof bmax);
+		if ((int64_t)bmax > cl_fpitch) { // (the synchronous pass grows the pitch itself from there on)
+			const int64_t want = ((int64_t)bmax + (int64_t)bmax / 4 + 63) / 64 * 64;
+			if (want > 16384 || nq * want >= ((int64_t)1 << 31))
+				cl_fbucket_off = true;
+			else
+				cl_fpitch = (int)want;
+			*overflow = true;
+			return false;
+		}
 	}
 	if (collected && defer && cl_deferred_cap > 0) { // the stream synchronised above: the candidate count of the scan is on the host now
 		unsigned long long ncand_u;
@@ -2194,6 +2286,16 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "flat_shadow_nprobe")) {
 		shadow_nprobe = (int)std::max<int64_t>(1, v);
+		return true;
+	}
+	if (!strcmp(key, "cl_fbucket")) { // 0: the sorted pipeline behind the d = 128 L2 coarse filter (round 4); 1: the bucketed finish
+		cl_fbucket = v != 0;
+		cl_fbucket_off = false;
+		return true;
+	}
+	if (!strcmp(key, "cl_fpitch")) { // bucket entries per query of the bucketed finish (tests: provokes the overflow)
+		cl_fpitch = (int)std::max<int64_t>(64, std::min<int64_t>(16384, (v + 63) / 64 * 64));
+		cl_fbucket_off = false;
 		return true;
 	}
 	if (!strcmp(key, "cl_prep1")) { // 0: round 4's separate query-preparation kernels (A/B)

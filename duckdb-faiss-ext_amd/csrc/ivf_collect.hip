@@ -1252,11 +1252,12 @@ __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSe
 		// sum is the stream's own count; the maximum matters only when a bucket was too small)
 		if (have > (unsigned)a.bpitch)
 			atomicMax(a.stats + 1, (unsigned long long)have);
-		if (a.qfail[q])
+		if (a.qfail && a.qfail[q]) // (null: the caller keeps its own fail list -- the Flat index's bucketed finish)
 			a.fail_q[atomicAdd(a.fail_cnt, 1)] = (int)q;
 		if (a.reset) {
 			a.bcount[q] = 0u;
-			a.qfail[q] = 0;
+			if (a.qfail)
+				a.qfail[q] = 0;
 		}
 	}
 	const unsigned long long mine = n > 0 ? cb_select_wave<false>(a.bucket + (size_t)q * (size_t)a.bpitch, n, kk, lane, surv, top) : CB_EMPTY;
@@ -1583,7 +1584,9 @@ void launch_ivf_bucket_scatter(const unsigned long long *d_strm, const float *d_
                                int bpitch, unsigned long long *d_kept_cnt, unsigned long long *d_units, unsigned *d_unit_cnt, hipStream_t st) {
 	if (nq <= 0 || cap <= 0)
 		return;
-	if (nclass == 32)
+	if (!d_gslot)
+		; // (d_bf holds the thresholds already: the Flat index, launch_collect_final_thr)
+	else if (nclass == 32)
 		hipLaunchKernelGGL(ivf_final_bound_kernel<32>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);
 	else
 		hipLaunchKernelGGL(ivf_final_bound_kernel<16>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);

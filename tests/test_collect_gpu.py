@@ -444,3 +444,43 @@ def test_inner_product_filter_works_with_the_users_k(mf, d, k):
     D, I = cl.search(xq, k)
     assert "bf16" in cl.last_kernel_info()["name"] and "x3" not in cl.last_kernel_info()["name"], cl.last_kernel_info()["name"]
     assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["plain", "idmap", "selector", "few_queries", "duplicates", "k64"])
+def test_bucketed_finish_of_the_l2_filter_equals_the_sorted_pipeline(mf, case):
+    """round 5, option cl_fbucket (d = 128, L2): final-bound filter -> per-query row buckets -> one wavefront per query re-scores and
+    one selects (csrc/ivf_collect.hip, shared with the IVF path) instead of radix sort -> segments -> re-scoring -> selection ->
+    emission.  Same labels, same distance bits as the sorted pipeline, the exact f32 kernel and the oracle; a bucket too small for
+    the data (option cl_fpitch) is grown and the finish repeated; beyond 16 384 entries per query the sorted pipeline takes the index back."""
+    rs = np.random.RandomState(17)
+    d, nb, nq, k = 128, 120_000, (13 if case == "few_queries" else 500), (64 if case == "k64" else 10)
+    xb = rs.rand(nb, d).astype(np.float32)
+    if case == "duplicates":
+        xb[nb // 2 :: 3] = xb[: len(xb[nb // 2 :: 3])]
+    xq = rs.rand(nq, d).astype(np.float32)
+    xq[: nq // 5] = xb[11 : 11 + nq // 5]
+    ids = np.arange(nb, dtype=np.int64) * 7 + 3 if case == "idmap" else None
+    cl, ex = _pair(mf, d, L2, xb, "IDMap,Flat" if case == "idmap" else "Flat", ids)
+    sel = None
+    if case == "selector":
+        keep = np.arange(nb, dtype=np.int64)[::3]
+        sel = ("batch", keep)
+    D1, I1 = cl.search(xq, k, sel=sel)
+    assert cl.last_kernel_info()["name"] == KERNEL
+    cl.set_option("cl_fbucket", 0)
+    D0, I0 = cl.search(xq, k, sel=sel)
+    assert cl.last_kernel_info()["name"] == KERNEL
+    De, Ie = ex.search(xq, k, sel=sel)
+    assert np.array_equal(I1, I0) and np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), "bucketed finish differs from the sorted pipeline"
+    assert np.array_equal(I1, Ie) and np.array_equal(D1.view(np.uint32), De.view(np.uint32)), "differs from the exact f32 kernel"
+    if case in ("plain", "duplicates", "few_queries"):
+        Do, Io = orc.flat_search(L2, xb, xq[:64], k, force_path=orc.PATH_BLAS if nq >= 20 else orc.PATH_PAIR)
+        assert np.array_equal(I1[:64], Io[: len(I1[:64])]) and np.array_equal(D1[:64].view(np.uint32), Do[: len(D1[:64])].view(np.uint32))
+    if case == "duplicates":  # a 64-entry bucket overflows on a query that sits on many copies: the pitch grows, the finish runs again, same bits
+        xb2 = np.tile(xb[:64], (2000, 1))
+        c2, e2 = _pair(mf, d, L2, xb2)
+        c2.set_option("cl_fbucket", 1)
+        c2.set_option("cl_fpitch", 64)
+        D2, I2 = c2.search(xb2[:300].copy(), k)
+        D3, I3 = e2.search(xb2[:300].copy(), k)
+        assert np.array_equal(I2, I3) and np.array_equal(D2.view(np.uint32), D3.view(np.uint32))
