@@ -697,7 +697,7 @@ def main():
                     ):
                         traffic, traffic_src = w["hbm_bytes_per_launch"], "profiles/%s (" % tname + w["source"] + ")"
                         pmc_entry = w
-            if kinfo["name"].startswith("flat_bf16_collect") or kinfo["name"].startswith("flat_bf16_wide"):
+            if kinfo["name"].startswith(("flat_bf16_collect", "flat_bf16_wide", "flat_bf16_big")):
                 # bf16 coarse filter (csrc/flat_collect.hip; 128 < d <= 768: csrc/flat_collect_wide.hip): ONE bf16 MFMA product per element pair is the algorithm, so its
                 # algorithmic flops are 2 nq N d, priced against the dense bf16 peak; the candidates it admits are re-scored
                 # exactly in f32 (their kernels are inside the timed step, not inside this launch)

@@ -33,6 +33,10 @@
 namespace mvs {
 
 typedef float f32x4b __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int big_stages(int stage_bytes) { // LDS ring of the staged blocks
+	(void)stage_bytes; // (five stages at 24 KB blocks -- a block requested FOUR tiles ahead -- measured no different from four: 145.7 vs 145.1 ms at C4)
+	return 4;
+}
 
 
 // MODE (option cl_big_mode, A/B): bit 0 = the next tile's first fragments and beta are read under the last MFMAs of this one;
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	constexpr int KT = KBT * KSPL; // k-blocks of a whole row
 	constexpr int PITCH = 64 * KBT, GPITCH = PITCH * KSPL, C = 4 * KBT, RT = 16; // bytes of a staged row (one part) / of a stored row
 	constexpr int STAGE_BYTES = RT * PITCH; // 24 KB (768 dims) / 32 KB (1024)
-	constexpr int NST = 4, KB_BAR = 8;
+	constexpr int NST = big_stages(STAGE_BYTES), KB_BAR = 8; // (the ring's length is a parameter since round 5: see big_stages)
 	constexpr int DMA_PER_WAVE = STAGE_BYTES / 4096;
 	constexpr int QW = 16 * NCB, QB = 4 * QW;
 	constexpr int RA = 4, RING = 8; // A fragments read RA k-blocks ahead into a ring of RING register quads
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	};
 	if (nblocks > 0) {
 #pragma unroll
-		for (int b = 0; b < 3; ++b) {
+		for (int b = 0; b < NST - 1; ++b) {
 #pragma unroll
 			for (int i = 0; i < DMA_PER_WAVE; ++i)
 				dma_one(b, b, i);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	f32x4n pcq = {0.f, 0.f, 0.f, 0.f}; // the bounds tile u - 1 was scanned under
 	bf16x8 A[RING];                    // A fragments: k-block kb of the current tile in A[kb % RING], read RA k-blocks ahead -- across tiles
 	f32x4n Yv[2];                      // beta of the tile's rows, by tile parity
-	int stg = 0;                       // stage of tile u = u & 3
+	int stg = 0;                       // stage of tile u = u % NST
 	// A fragment (k-block kb) of a staged tile: byte c * PITCH + 256 (kb >> 2) + (rb16 ^ (64 (kb & 3)))
 	auto read_a = [&](bf16x8 &dst, int stage, int kb) {
 		const unsigned tb = (unsigned)(uintptr_t)((lds_f32c *)(smem + (stage * STAGE_BYTES) / 4)) + rbase;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		const int period = u < 8 ? 1 : (u < 64 ? 8 : (u < 512 ? 32 : 128));
 		if (first && (u % period) == 0)
 			refresh();
-		const int nstg = (stg + 1) & 3, dstg = (stg + 3) & 3; // tile u + 1's stage; block u + 3 goes where tile u - 1 was
+		const int nstg = stg + 1 == NST ? 0 : stg + 1, dstg = stg == 0 ? NST - 1 : stg - 1; // tile u + 1's stage; block u + NST - 1 goes where tile u - 1 was
 		f32x4n cqv = pcq; // (read from the table in the first part; the later parts leave pcq alone)
 		bool any_prev = false;
 		if (!PF) { // this tile's beta and first fragments (its block landed at the previous tile's barrier)
@@ -283,34 +287,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			if (kb == KB_BAR) {
 				// block u + 1 has landed for every wave (the newest block -- u + 2, this wave's last DMA_PER_WAVE (+ 1: beta) loads,
 				// nothing else is in flight, loads return in order -- stays in flight); everybody is done with tile u - 1's stage
+				// (NST - 3 newer blocks stay in flight: u + 2 .. u + NST - 2)
 				if (wave == 0)
-					asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 1) : "memory");
+					asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 3) * (DMA_PER_WAVE + 1)) : "memory");
 				else
-					asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
+					asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 3) * DMA_PER_WAVE) : "memory");
 			}
-			if (SPREAD) {
-				if (kb > KB_BAR && ((kb - KB_BAR) & 1) && (kb - KB_BAR) / 2 < DMA_PER_WAVE)
-					dma_one(v + 3, dstg, (kb - KB_BAR) / 2); // one LDS-DMA instruction per two k-blocks: its issue hides under their MFMAs
-				if (kb == KB_BAR + 2 && wave == 0)
-					dma_beta(v + 3, dstg);
-			} else if (kb == KB_BAR) {
-#pragma unroll
-				for (int i = 0; i < DMA_PER_WAVE; ++i)
-					dma_one(v + 3, dstg, i);
-				if (wave == 0)
-					dma_beta(v + 3, dstg);
-			}
-			if (first && kb == 2)
-				asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds) : "memory"); // this tile's bounds (tested one tile later)
-			if (PF && kb == KBT - RA) // (beta of the staged block behind this one: the next row block's when this is the last part)
-				read_y(Yv[par ^ 1], nstg); // (not the last part: block v + 1 carries this row block's beta again -- unused, reloaded at the last part)
-			if (kb + RA < KBT)
-				read_a(A[(kb + RA) % RING], stg, kb + RA);
-			else if (PF)
-				read_a(A[(kb + RA) % RING], nstg, kb + RA - KBT); // the next tile's first fragments (its block landed at the barrier)
-			// LDS returns in order: with RA reads younger than fragment kb outstanding, kb (and everything older) has arrived
-			if (PF || kb + RA < KBT)
-				asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(RA));
+			// Round 5: a lone wave issues IN ORDER -- whatever stands between two groups of MFMAs waits for the matrix pipe to take the
+			// group's last MFMA and then runs with only that one's 16 cycles to hide under (rounds 3-4: fragment read, wait, LDS-DMA
+			// address + issue, bound read all sat behind the k-block's NCB MFMAs: the pipe was 52 % busy, profiles/r5_pmc_c4.txt).
+			// Now ONE such instruction group follows EACH MFMA of the k-block: it issues while that MFMA runs and the next MFMA could
+			// not have issued anyway.  Fragment kb must have arrived before the k-block's first MFMA: LDS returns in order and
+			// the reads of fragments kb + 1 .. kb + RA - 1 are younger (the read of kb + RA is issued behind this k-block's first MFMA).
+			if (PF || kb + RA - 1 < KBT)
+				asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(RA - 1));
 			else
 				asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[kb % RING]), "+v"(Yv[par]), "+v"(cqv), "+v"(A[(kb + 1) % RING]) : "n"(KBT - 1 - kb));
 #pragma unroll
@@ -345,16 +335,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 						             : "+v"(acc[par][i])
 						             : "v"(A[kb % RING]), "a"(bqa[f >= NV ? f - NV : 0]));
 				}
-			}
-			if (first && kb == 1 && u > 0) { // tile u - 1's running maxima against its bounds, behind this tile's first MFMAs
-#pragma unroll
-				for (int i = 0; i < NCB; ++i) {
-					const f32x4b &sv = acc[par ^ 1][i];
-					const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
-					any_prev = any_prev || (mx >= pcq[i]);
+				__builtin_amdgcn_sched_barrier(0);
+				// ... and behind MFMA i, ONE of the k-block's other duties:
+				if (i == 0) { // the fragment RA k-blocks ahead (its ring slot was consumed RING - RA k-blocks ago)
+					if (kb + RA < KBT)
+						read_a(A[(kb + RA) % RING], stg, kb + RA);
+					else if (PF)
+						read_a(A[(kb + RA) % RING], nstg, kb + RA - KBT); // the next tile's first fragments (its block landed at the barrier)
 				}
+				if (i == (NCB > 2 ? 1 : NCB - 1)) { // the staging of block u + 3, this tile's bounds, the next block's beta
+					if (SPREAD) {
+						if (kb > KB_BAR && ((kb - KB_BAR) & 1) && (kb - KB_BAR) / 2 < DMA_PER_WAVE)
+							dma_one(v + NST - 1, dstg, (kb - KB_BAR) / 2); // one LDS-DMA instruction per two k-blocks
+						if (kb == KB_BAR + 2 && wave == 0)
+							dma_beta(v + NST - 1, dstg);
+					} else if (kb == KB_BAR) {
+#pragma unroll
+						for (int i2 = 0; i2 < DMA_PER_WAVE; ++i2)
+							dma_one(v + NST - 1, dstg, i2);
+						if (wave == 0)
+							dma_beta(v + NST - 1, dstg);
+					}
+					if (first && kb == 2)
+						asm volatile("ds_read_b128 %0, %1" : "=v"(cqv) : "v"(cq_lds) : "memory"); // this tile's bounds (tested one tile later)
+					if (PF && kb == KBT - RA) // (beta of the staged block behind this one: the next row block's when this is the last part)
+						read_y(Yv[par ^ 1], nstg); // (not the last part: block v + 1 carries this row block's beta again -- unused, reloaded at the last part)
+				}
+				if (i == (NCB > 2 ? 2 : NCB - 1) && first && kb == 1 && u > 0) { // tile u - 1's running maxima against its bounds
+#pragma unroll
+					for (int i3 = 0; i3 < NCB; ++i3) {
+						const f32x4b &sv = acc[par ^ 1][i3];
+						const float mx = __builtin_fmaxf(__builtin_fmaxf(sv[0], sv[1]), __builtin_fmaxf(sv[2], sv[3]));
+						any_prev = any_prev || (mx >= pcq[i3]);
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
 			}
-			__builtin_amdgcn_sched_barrier(0);
 		}
 		// The fragments (and beta) read ahead for the next tile must have LANDED before control leaves this straight-line block:
 		// hipcc counts an asm load's destination as written at the end of the statement and is free to copy or spill it on the
@@ -450,7 +466,7 @@ int collect_big_qblock(int dp1) {
 }
 size_t collect_big_lds_bytes(int dp1) {
 	const int part = dp1 == 1536 ? 768 : dp1; // dims of a staged block (the 1536-dim store is staged in two parts per row block)
-	return (size_t)4 * (16 * part * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
+	return (size_t)big_stages(16 * part * 2) * (16 * part * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
 }
 
 template <int KBT, int NCB, int KSPL = 1>
