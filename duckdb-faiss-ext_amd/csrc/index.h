@@ -238,6 +238,7 @@ public:
 	const int64_t *cl_out_map = nullptr;
 	int64_t cl_out_off = 0;
 	bool cl_emitted = false;     // collect_candidates wrote the final lists itself (the caller skips its emission)
+	bool cl_report_cnt = false;  // the scan's entry count (and the bucket header) still has to reach the host: launch_collect_report does it
 	unsigned long long *h_cl_hdr = nullptr; // pinned copy of the control block's header (bucket statistics)
 	DevBuf ws_fbk, ws_fbr;
 	bool cl_prep1 = true;        // option cl_prep1: one fused per-query preparation kernel in front of the d <= 128 coarse filter
@@ -419,6 +420,8 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
                          unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
                          hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out, float *d_stream_s = nullptr);
 // thr[q] = B - 2E from the class slots as the scan left them (csrc/flat_collect.hip): the final-bound filter of the bucketed finish
+void launch_collect_report(const void *d_hdr, const int *d_fail_cnt, const unsigned *d_maxnorm, int *h_flags, void *h_hdr, bool with_cnt,
+                           hipStream_t st);
 void launch_collect_final_thr(const unsigned *d_gslot, int d, int kk, const float *d_e2, int64_t nq, float *d_thr, hipStream_t st);
 // Entries the deferred sort of a search is launched with, from the candidates per query c of the index's previous search: the
 // margin shrinks with the batch (the mean of nq heavy-tailed per-query counts), 17 % + 16 per query at 10 000 queries, 40 % at 64
@@ -481,12 +484,14 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
                               int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa = nullptr,
                               int64_t label_offset = 0, const unsigned *d_brow = nullptr, int rows_interleaved = 0,
-                              const unsigned long long *d_units = nullptr, const unsigned *d_unit_cnt = nullptr);
+                              const unsigned long long *d_units = nullptr, const unsigned *d_unit_cnt = nullptr,
+                              const int *d_kept_blk = nullptr, int nkept_blk = 0, unsigned long long *d_kept_out = nullptr);
 size_t ivf_bucket_units_bytes(int64_t cap_entries);
+unsigned ivf_bucket_scatter_blocks(int64_t cap_entries);
 // final bound + the survivors into their queries' row buckets (csrc/ivf_collect.hip); launch_ivf_bucket_finish(..., d_brow) re-scores them
 void launch_ivf_bucket_scatter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
                                const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned *d_brow, unsigned *d_bcount,
-                               int bpitch, unsigned long long *d_kept_cnt, unsigned long long *d_units, unsigned *d_unit_cnt, hipStream_t st);
+                               int bpitch, int *d_kept_blk, unsigned long long *d_units, unsigned *d_unit_cnt, hipStream_t st);
 // probed lists that provably hold none of a query's k nearest rows -> -1 in d_out (csrc/ivf_collect.hip ivf_probe_prune_kernel); np <= 256
 void launch_ivf_probe_prune(const float *d_x, int64_t nq, int d, const float *d_cD, const int64_t *d_cI, int np, int k, const float *d_cn,
                             const unsigned *d_list_max, const int64_t *d_list_off, int64_t *d_out, int *d_kept, hipStream_t st);

@@ -489,7 +489,9 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	end_kernel_timing(st);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
-	MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+	cl_report_cnt = defer_count && cl_est_per_query > 0; // (deferred: the caller's report kernel carries the count, no copy of its own)
+	if (!cl_report_cnt)
+		MVS_HIP(hipMemcpyAsync(h_flag_count + 10, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 	if (defer_count && cl_est_per_query > 0) { // the caller looks at the count after its own synchronisation
 		// (size of the sort: collect_sort_estimate of what the previous search of this index produced per query, in units of 64 K entries)
 		cl_deferred_cap = fb ? cap_entries : std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq)); // (no sort to size)
@@ -552,7 +554,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		if (!h_cl_hdr)
 			MVS_HIP(hipHostMalloc((void **)&h_cl_hdr, 256, hipHostMallocDefault));
 		for (;;) {
-			launch_ivf_bucket_scatter(stream, stream_s, cap_entries, cnt, nullptr, 0, 0, nq, fb_thr, fb_rows, bcount, cl_fpitch, cnt + 1, fb_units,
+			launch_ivf_bucket_scatter(stream, stream_s, cap_entries, cnt, nullptr, 0, 0, nq, fb_thr, fb_rows, bcount, cl_fpitch, nullptr, fb_units,
 			                          (unsigned *)cnt + 4, st);
 			IvfFlatArith fa;
 			memset(&fa, 0, sizeof fa);
@@ -562,11 +564,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 			                         cl_out_D, cl_out_I, nullptr, cl_out_map, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
 			                         (unsigned long long *)((char *)ws_seg.p + 192), nullptr, nullptr, nullptr, true, st, &fa, cl_out_off, fb_rows,
 			                         geom.pair_interleaved ? 1 : 0, fb_units, (const unsigned *)cnt + 4);
-			MVS_HIP(hipMemcpyAsync(h_cl_hdr, ws_seg.p, 256, hipMemcpyDeviceToHost, st));
-			if (defer_count) { // (the caller looks at the header behind its own synchronisation)
+			if (defer_count) { // (the caller looks at the header behind its own synchronisation: its report kernel copies it)
 				fb_done = true;
 				break;
 			}
+			MVS_HIP(hipMemcpyAsync(h_cl_hdr, ws_seg.p, 256, hipMemcpyDeviceToHost, st));
 			MVS_HIP(hipStreamSynchronize(st));
 			unsigned long long bmax = 0;
 			memcpy(&bmax, (const char *)h_cl_hdr + 200, sizeof bmax);
@@ -1071,8 +1073,9 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
-	MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
-	MVS_HIP(hipMemcpyAsync(h_flag_count + 9, d_max_norm_bits + 4, sizeof(int), hipMemcpyDeviceToHost, st));
+	// (one kernel writes fail count, rounding residual and -- deferred count mode -- the scan's entry count / the bucket header to pinned memory)
+	launch_collect_report(collected ? ws_seg.p : nullptr, fail_cnt, d_max_norm_bits + 4, h_flag_count,
+	                      (emitted && cl_report_cnt) ? h_cl_hdr : nullptr, collected && cl_report_cnt, st);
 	if (flp) {
 		if (collected && defer && cl_deferred_cap > 0) {
 			// (the sort covered cl_deferred_cap entries -- if the scan produced more, the tie pass below would work on a

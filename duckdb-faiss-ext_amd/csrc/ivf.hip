@@ -1003,15 +1003,18 @@ public:
 		const bool bexact = refilter && cl_bexact && d == 128 && dp == 128;
 		unsigned *brow = nullptr, *const bunit_cnt = (unsigned *)ws_qfail.p + 4; // (the unit count: control block header, byte 16)
 		unsigned long long *bunits = nullptr;
+		int *bkept = nullptr; // per-workgroup survivor counts of the scatter kernel (summed into cnt2 by the selection kernel)
 		if (refilter) {
 			const size_t ub = ((size_t)cap_entries * 4 + 255) & ~(size_t)255, bb = ((size_t)nq * 4 + 255) & ~(size_t)255;
 			const size_t rb = bexact ? (((size_t)nq * bpitch * 4 + 255) & ~(size_t)255) : (size_t)cap_entries * 8;
-			ws_stream2.reserve(ub + bb + rb + (bexact ? ivf_bucket_units_bytes(cap_entries) : 0) + 256);
+			const size_t unb = bexact ? ((ivf_bucket_units_bytes(cap_entries) + 255) & ~(size_t)255) : 0;
+			ws_stream2.reserve(ub + bb + rb + unb + (bexact ? (size_t)ivf_bucket_scatter_blocks(cap_entries) * 4 : 0) + 256);
 			strm_u = (float *)ws_stream2.p;
 			bf_q = (float *)((char *)ws_stream2.p + ub);
 			strm2 = (unsigned long long *)((char *)ws_stream2.p + ub + bb);
 			brow = bexact ? (unsigned *)strm2 : nullptr;
 			bunits = bexact ? (unsigned long long *)((char *)ws_stream2.p + ub + bb + rb) : nullptr;
+			bkept = bexact ? (int *)((char *)ws_stream2.p + ub + bb + rb + unb) : nullptr;
 		}
 		memset(&kinfo, 0, sizeof kinfo);
 		// IDSelector: one bit per padded row, built per search (the selector sees the stored id, through the id map if any)
@@ -1125,7 +1128,7 @@ public:
 			const unsigned long long *ex_strm = strm, *ex_cnt = cnt;
 			if (bexact) {
 				launch_ivf_bucket_scatter(strm, strm_u, cap_entries, cnt, (const unsigned *)ws_gslot.p, nclass, kf, nq, bf_q, brow,
-				                          (unsigned *)ctl_seg, bpitch, cnt2, bunits, bunit_cnt, stream);
+				                          (unsigned *)ctl_seg, bpitch, bkept, bunits, bunit_cnt, stream);
 			} else if (refilter) {
 				launch_ivf_refilter(strm, strm_u, cap_entries, cnt, (const unsigned *)ws_gslot.p, nclass, kf, nq, bf_q, strm2, cnt2, stream);
 				ex_strm = strm2, ex_cnt = cnt2;
@@ -1137,7 +1140,8 @@ public:
 				fa.qn = shadow->qn, fa.yn = (const float *)norms_csr.p, fa.rowids = (const long long *)rowids.p;
 				launch_ivf_bucket_finish(METRIC_L2, ex_strm, cap_entries, ex_cnt, sorted, (unsigned *)ctl_seg, bpitch, nq, d_x, d, (const float *)codes.p,
 				                         dp, (const int *)perm_mf.p, kk, d_D, d_I, nullptr, shadow->out_map, 0, nullptr, nullptr, nullptr, nullptr,
-				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off, brow, 0, bunits, bunit_cnt);
+				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off, brow, 0, bunits, bunit_cnt, bkept,
+				                         bkept ? (int)ivf_bucket_scatter_blocks(cap_entries) : 0, cnt2);
 				FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
 				launch_ivf_shadow_verify(qz->coarse_matrix(), (const float *)ws_cD.p, probe_keys, nq, (int)nlist, (int)np, d, kk,
 				                         shadow->qn, qz->row_norms(), (const unsigned *)list_max.p, (const int64_t *)lb_dev.p,
@@ -1147,7 +1151,8 @@ public:
 			                         (const float *)codes.p, dp, (const int *)perm_mf.p, kk, d_D, d_I, raw_pos ? nullptr : (const int64_t *)rowids.p,
 			                         (d_idmap && !raw_ids && !raw_pos) ? d_idmap : nullptr, fin ? (int)fin_k : 0, fin ? fin_D : nullptr,
 			                         fin ? fin_I : nullptr, (const int64_t *)rowids.p, fin ? fin_idmap : nullptr, fin ? ctl_flag : nullptr, ctl_stats,
-			                         ctl_qfail, fail_cnt, fail_q, prep2, stream, nullptr, 0, brow, 0, bunits, bunit_cnt);
+			                         ctl_qfail, fail_cnt, fail_q, prep2, stream, nullptr, 0, brow, 0, bunits, bunit_cnt, bkept,
+			                         bkept ? (int)ivf_bucket_scatter_blocks(cap_entries) : 0, cnt2);
 			if (prep2)
 				ctl_clean_p = ws_qfail.p, ctl_clean_cap = ws_qfail.cap, ctl_clean_nq = nq;
 			if (fin) {

@@ -1234,6 +1234,9 @@ struct IvfBucketSelectArgs {
 	int *fail_cnt;
 	int *fail_q;
 	int reset; // leave bcount[q] and qfail[q] zero for the next search (prep2: no memset in front of a search)
+	const int *kept_blk;          // (may be null) per-workgroup survivor counts of the scatter kernel, nkept_blk of them
+	int nkept_blk;
+	unsigned long long *kept_out; // ... their sum goes here (the query-0 wavefront adds them up)
 };
 template <bool IS_L2>
 __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSelectArgs a) {
@@ -1247,6 +1250,16 @@ __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSe
 	const long long q = blockIdx.x;
 	const unsigned have = a.bcount[q];
 	const int n = (int)(have < (unsigned)a.bpitch ? have : (unsigned)a.bpitch);
+	if (q == 0 && a.kept_blk) { // the scatter kernel's per-workgroup survivor counts -> one number for the host
+		int t = 0;
+		for (int i = lane; i < a.nkept_blk; i += 64)
+			t += a.kept_blk[i];
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+			t += __shfl_xor(t, off);
+		if (lane == 0)
+			*a.kept_out = (unsigned long long)t;
+	}
 	if (lane == 0) {
 		// (one atomic per QUERY on one address -- sum and maximum of the counts -- serialised in L2: 250 us for 10 000 queries.  The
 		// sum is the stream's own count; the maximum matters only when a bucket was too small)
@@ -1420,7 +1433,7 @@ __global__ __launch_bounds__(256) void ivf_bucket_scatter_kernel(const unsigned 
                                                                 long long cap, const unsigned long long *__restrict__ cnt,
                                                                 const float *__restrict__ bf, unsigned *__restrict__ brow,
                                                                 unsigned *__restrict__ bcount, int bpitch,
-                                                                unsigned long long *__restrict__ kept_cnt,
+                                                                int *__restrict__ kept_blk,
                                                                 unsigned long long *__restrict__ units, unsigned *__restrict__ unit_cnt) {
 	__shared__ unsigned hkey[BSC_HASH], hcnt[BSC_HASH], hbase[BSC_HASH];
 	__shared__ int wsum[4];
@@ -1481,11 +1494,10 @@ __global__ __launch_bounds__(256) void ivf_bucket_scatter_kernel(const unsigned 
 	if ((threadIdx.x & 63) == 0)
 		wsum[threadIdx.x >> 6] = mine;
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-		if (t)
-			atomicAdd(kept_cnt, (unsigned long long)t);
-	}
+	// (the survivors of this workgroup: a plain store -- one atomic per workgroup on ONE counter serialised 2 700 of them behind the
+	// kernel's last workgroups, 54 of its 69 us; the selection kernel's first wavefront adds the entries up)
+	if (threadIdx.x == 0 && kept_blk)
+		kept_blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 // ARITH as ivf_exact_bucket_kernel; IL: the rows are a Flat index's pair-interleaved f32 store (csrc/common.h FlatGeom: inside every
 // four consecutive k the floats sit as [k0,k2,k1,k3] in rows with bit 4 clear, [k1,k3,k0,k2] in rows with bit 4 set).  d = dp = 128.
@@ -1579,9 +1591,12 @@ __global__ __launch_bounds__(64) void ivf_bucket_exact_kernel(const unsigned *__
 		return;
 	} // unit
 }
+unsigned ivf_bucket_scatter_blocks(int64_t cap_entries) { // workgroups of the scatter kernel = entries of its per-workgroup survivor counts
+	return (unsigned)std::min<int64_t>((cap_entries + 256 * BSC_PER - 1) / (256 * BSC_PER), 4096);
+}
 void launch_ivf_bucket_scatter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
                                const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned *d_brow, unsigned *d_bcount,
-                               int bpitch, unsigned long long *d_kept_cnt, unsigned long long *d_units, unsigned *d_unit_cnt, hipStream_t st) {
+                               int bpitch, int *d_kept_blk, unsigned long long *d_units, unsigned *d_unit_cnt, hipStream_t st) {
 	if (nq <= 0 || cap <= 0)
 		return;
 	if (!d_gslot)
@@ -1590,9 +1605,9 @@ void launch_ivf_bucket_scatter(const unsigned long long *d_strm, const float *d_
 		hipLaunchKernelGGL(ivf_final_bound_kernel<32>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);
 	else
 		hipLaunchKernelGGL(ivf_final_bound_kernel<16>, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, st, d_gslot, kf, (long long)nq, d_bf);
-	const unsigned blocks = (unsigned)std::min<int64_t>((cap + 256 * BSC_PER - 1) / (256 * BSC_PER), 4096);
+	const unsigned blocks = ivf_bucket_scatter_blocks(cap);
 	hipLaunchKernelGGL(ivf_bucket_scatter_kernel, dim3(blocks), dim3(256), 0, st, d_strm, d_su, (long long)cap, d_cnt, d_bf, d_brow, d_bcount,
-	                   bpitch, d_kept_cnt, d_units, d_unit_cnt);
+	                   bpitch, d_kept_blk, d_units, d_unit_cnt);
 	MVS_HIP(hipGetLastError());
 }
 size_t ivf_bucket_units_bytes(int64_t cap_entries) { // (every unit stands for BEX_CHUNK candidates of one query)
@@ -1609,7 +1624,7 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
                               int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa,
                               int64_t label_offset, const unsigned *d_brow, int rows_interleaved, const unsigned long long *d_units,
-                              const unsigned *d_unit_cnt) {
+                              const unsigned *d_unit_cnt, const int *d_kept_blk, int nkept_blk, unsigned long long *d_kept_out) {
 	if (nq <= 0)
 		return;
 	if (dp_csr % 4 != 0 || dp_csr > 128 || kk > 64 || kk < 1)
@@ -1659,6 +1674,7 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
 	a.k = k, a.D = d_D, a.I = (long long *)d_I, a.fin_rowids = (const long long *)d_fin_rowids, a.fin_idmap = (const long long *)d_fin_idmap;
 	a.flag_cnt = d_flag, a.flag_q = d_flag ? d_flag + 1 : nullptr, a.stats = d_stats;
 	a.qfail = d_qfail, a.fail_cnt = d_fail_cnt, a.fail_q = d_fail_q, a.reset = reset ? 1 : 0;
+	a.kept_blk = d_kept_blk, a.nkept_blk = nkept_blk, a.kept_out = d_kept_out;
 	if (l2 || fa)
 		hipLaunchKernelGGL(ivf_bucket_select_kernel<true>, dim3((unsigned)nq), dim3(64), 0, st, a);
 	else
