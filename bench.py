@@ -563,6 +563,7 @@ def main():
     # (the census of the timed searches: the extra searches below must not dilute it)
     snap_collect, snap_prefilter = _snap(ix.collect_stats), _snap(ix.prefilter_stats)
     snap_probe = _snap(ix.ivf_probe_stats) if is_ivf else None  # (of the timed batch, before the extra searches below)
+    snap_admitted = _snap(ix.ivf_probe_stats) if not is_ivf and not is_hnsw else None  # (Flat: what the scan admitted in the last search)
     # state carried from one search to the next: one batch of DIFFERENT selectivity -- the midpoints of
     # neighbouring queries: nearer the centre of uniform data, between the clusters of clustered data -- then the benchmark's batch
     # again, each timed on its own, outside the timed region
@@ -723,6 +724,7 @@ def main():
                     "grid": kinfo["grid"],
                     "lds_bytes": kinfo["lds_bytes"],
                     "candidates_rescored_per_query": round(cs["candidates"] / max(cs["queries"], 1), 1),
+                    "candidates_admitted_per_query": (round(snap_admitted["admitted"] / max(nq, 1), 1) if snap_admitted else None),
                     "candidate_stream_overflows": cs["overflows"],
                     "queries_rerun_on_exact_kernel": st["fallback_queries"],
                 }

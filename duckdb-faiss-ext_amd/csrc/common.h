@@ -180,6 +180,7 @@ struct Tuning {
 	int cl_nsplit = 0;        // option cl_nsplit: row splits of the main scan (0 = planned)
 	int cl_seed_split = 0;    // option cl_seed_split: row splits of the pre-pass (0 = 32)
 	int cl_seed_rows = 16384; // option cl_seed_rows: rows of the bound-estimation pre-pass
+	int cl_seed_reg_rows = 32768; // option cl_seed_reg_rows: ... of the register pre-pass of the d <= 128 store (flat_bf16_seed_kernel)
 	int cl_seed_regs = 1;     // option cl_seed_regs: d <= 128 pre-pass with class maxima in registers (0: through the scan kernel's rare path)
 	int cl_tab = 1;           // option cl_tab: pass bounds through the global table (1) or every wave derives its own (0, round 3)
 	int cl_nc32_from = 17;    // option cl_nc32_from

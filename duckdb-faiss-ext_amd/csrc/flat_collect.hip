@@ -1377,7 +1377,7 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	const int dp1 = collect_store_dims(g.d);
 	if (dp1 == 128 && tune().cl_seed_regs && stride == 16) { // (32 classes: 64 registers of maxima do not fit; the publish-only scan below)
 		// d <= 128: class maxima in registers (flat_bf16_seed_kernel) -- cheap enough for 32 768 rows (an eighth of a small index)
-		const int64_t rows = std::min<int64_t>(tune().cl_seed_rows > 16384 ? tune().cl_seed_rows : 32768, n / 8) / 64 * 64;
+		const int64_t rows = std::min<int64_t>(tune().cl_seed_rows > 16384 ? tune().cl_seed_rows : std::max(1024, tune().cl_seed_reg_rows), n / 8) / 64 * 64;
 		if (rows >= 1024)
 			launch_collect_seed(metric, a, rows, nq, st);
 		return;

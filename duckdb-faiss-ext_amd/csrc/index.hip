@@ -447,17 +447,20 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	float *stream_s = nullptr, *fb_thr = nullptr;
 	unsigned *fb_rows = nullptr;
 	unsigned long long *fb_keys = nullptr, *fb_units = nullptr;
+	int *fb_kept = nullptr; // per-workgroup survivor counts of the scatter kernel (their sum -> the control block's header @8)
 	auto fb_layout = [&]() { // (after every change of cap_entries / of the pitch: a DevBuf keeps nothing when it grows, so the scan's
 		// per-entry values and the buckets live in two buffers -- a larger pitch must not lose the values)
 		const size_t sb = ((size_t)cap_entries * 4 + 255) & ~(size_t)255, tb = ((size_t)nq * 4 + 255) & ~(size_t)255;
 		const size_t rb = ((size_t)nq * cl_fpitch * 4 + 255) & ~(size_t)255, kb = (size_t)nq * cl_fpitch * 8;
 		ws_fbk.reserve(sb + tb + 256);
-		ws_fbr.reserve(rb + kb + ivf_bucket_units_bytes(cap_entries) + 256);
+		const size_t unb = (ivf_bucket_units_bytes(cap_entries) + 255) & ~(size_t)255;
+		ws_fbr.reserve(rb + kb + unb + (size_t)ivf_bucket_scatter_blocks(cap_entries) * 4 + 256);
 		stream_s = (float *)ws_fbk.p;
 		fb_thr = (float *)((char *)ws_fbk.p + sb);
 		fb_rows = (unsigned *)ws_fbr.p;
 		fb_keys = (unsigned long long *)((char *)ws_fbr.p + rb);
 		fb_units = (unsigned long long *)((char *)ws_fbr.p + rb + kb);
+		fb_kept = (int *)((char *)ws_fbr.p + rb + kb + unb);
 	};
 	if (fb)
 		fb_layout();
@@ -554,7 +557,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		if (!h_cl_hdr)
 			MVS_HIP(hipHostMalloc((void **)&h_cl_hdr, 256, hipHostMallocDefault));
 		for (;;) {
-			launch_ivf_bucket_scatter(stream, stream_s, cap_entries, cnt, nullptr, 0, 0, nq, fb_thr, fb_rows, bcount, cl_fpitch, nullptr, fb_units,
+			launch_ivf_bucket_scatter(stream, stream_s, cap_entries, cnt, nullptr, 0, 0, nq, fb_thr, fb_rows, bcount, cl_fpitch, fb_kept, fb_units,
 			                          (unsigned *)cnt + 4, st);
 			IvfFlatArith fa;
 			memset(&fa, 0, sizeof fa);
@@ -563,7 +566,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 			launch_ivf_bucket_finish(METRIC_L2, nullptr, cap_entries, nullptr, fb_keys, bcount, cl_fpitch, nq, d_x, d, vecs, geom.dp, nullptr, kk,
 			                         cl_out_D, cl_out_I, nullptr, cl_out_map, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
 			                         (unsigned long long *)((char *)ws_seg.p + 192), nullptr, nullptr, nullptr, true, st, &fa, cl_out_off, fb_rows,
-			                         geom.pair_interleaved ? 1 : 0, fb_units, (const unsigned *)cnt + 4);
+			                         geom.pair_interleaved ? 1 : 0, fb_units, (const unsigned *)cnt + 4, fb_kept,
+			                         (int)ivf_bucket_scatter_blocks(cap_entries), cnt + 1);
 			if (defer_count) { // (the caller looks at the header behind its own synchronisation: its report kernel copies it)
 				fb_done = true;
 				break;
@@ -1107,8 +1111,10 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		MVS_HIP(hipStreamSynchronize(st));
 	}
 	if (emitted) { // (synchronised above) a bucket too small for some query: its list is incomplete -- the sorted pipeline takes over for good
-		unsigned long long bmax = 0;
+		unsigned long long bmax = 0, kept = 0;
 		memcpy(&bmax, (const char *)h_cl_hdr + 200, sizeof bmax);
+		memcpy(&kept, (const char *)h_cl_hdr + 8, sizeof kept);
+		cl_last_rescored = (int64_t)kept; // (survivors of the final-bound filter: what the exact stage re-scored)
 		if ((int64_t)bmax > cl_fpitch) { // (the synchronous pass grows the pitch itself from there on)
 			const int64_t want = ((int64_t)bmax + (int64_t)bmax / 4 + 63) / 64 * 64;
 			if (want > 16384 || nq * want >= ((int64_t)1 << 31))
@@ -1131,6 +1137,8 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		cl_queries_total += nq;
 		cl_candidates_total += (int64_t)ncand_u;
 	}
+	if (emitted && cl_last_rescored >= 0) // (mvs_index_collect_stats then reports what the exact stage re-scored, as for an IVF index)
+		cl_rescored_total += cl_last_rescored, cl_rescored_queries += nq, cl_admitted_in_fb += cl_last_candidates;
 	const int nf = h_flag_count[8];
 	pf_last_fallback = nf;
 	pf_queries_total += nq;
@@ -2028,8 +2036,8 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
 	auto *f = static_cast<FlatIndex *>(p);
 	if (queries)
 		*queries = f->cl_queries_total;
-	if (candidates)
-		*candidates = f->cl_candidates_total;
+	if (candidates) // (the bucketed finish re-scores the survivors of the final-bound filter only: admitted - (admitted - re-scored) of those searches)
+		*candidates = f->cl_candidates_total - (f->cl_admitted_in_fb - f->cl_rescored_total);
 	if (overflows)
 		*overflows = f->cl_overflows;
 	MVS_API_END
@@ -2041,8 +2049,20 @@ int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scan
 		p = static_cast<IDMapIndex *>(p)->sub;
 	if (p->kind == MVS_KIND_FLAT && static_cast<FlatIndex *>(p)->shadow) // a Flat index answering through its shadow clustering
 		p = static_cast<FlatIndex *>(p)->shadow;
-	if (!p->probe_stats(pairs, pairs_scanned, forced_drains, admitted))
-		throw_faiss("mvs_index_ivf_probe_stats", __FILE__, "not an IVF index");
+	if (!p->probe_stats(pairs, pairs_scanned, forced_drains, admitted)) {
+		if (p->kind != MVS_KIND_FLAT)
+			throw_faiss("mvs_index_ivf_probe_stats", __FILE__, "not an IVF index");
+		// a Flat index: no probes; `admitted` = candidates its coarse filter admitted in the last search (mvs_index_collect_stats counts
+		// the re-scored ones)
+		if (pairs)
+			*pairs = 0;
+		if (pairs_scanned)
+			*pairs_scanned = 0;
+		if (forced_drains)
+			*forced_drains = 0;
+		if (admitted)
+			*admitted = static_cast<FlatIndex *>(p)->cl_last_candidates;
+	}
 	MVS_API_END
 }
 int mvs_index_shard_info(const mvs_index *ix, int *devices, int max_devices, int64_t *rows_per_shard,
@@ -2221,6 +2241,7 @@ bool IndexBase::set_tuning(const char *key, int64_t v) {
 	    {"cl_seed_regs", &Tuning::cl_seed_regs, 0},    // d <= 128 pre-pass: class maxima in registers (1) or the scan kernel's rare path (0)
 	    {"cl_seed_split", &Tuning::cl_seed_split, 0},
 	    {"cl_seed_rows", &Tuning::cl_seed_rows, 0},    // coarse filter: rows of the bound-estimation pre-pass
+	    {"cl_seed_reg_rows", &Tuning::cl_seed_reg_rows, 0},
 	    {"pf_sched", &Tuning::pf_sched, 0},
 	    {"pf_classes32", &Tuning::pf_classes32, 0},
 	    {"pf_seed", &Tuning::pf_seed, 0},              // rows of the prefilter's seeding pre-pass (0 = off)

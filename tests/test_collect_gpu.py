@@ -465,8 +465,12 @@ def test_bucketed_finish_of_the_l2_filter_equals_the_sorted_pipeline(mf, case):
     if case == "selector":
         keep = np.arange(nb, dtype=np.int64)[::3]
         sel = ("batch", keep)
+    c0 = cl.collect_stats()
     D1, I1 = cl.search(xq, k, sel=sel)
     assert cl.last_kernel_info()["name"] == KERNEL
+    c1, adm = cl.collect_stats(), cl.ivf_probe_stats()["admitted"]
+    # (collect_stats counts what the exact stage re-scored: the survivors of the final-bound filter, never more than the scan admitted)
+    assert c1["queries"] - c0["queries"] == nq and 0 < c1["candidates"] - c0["candidates"] <= adm, (c0, c1, adm)
     cl.set_option("cl_fbucket", 0)
     D0, I0 = cl.search(xq, k, sel=sel)
     assert cl.last_kernel_info()["name"] == KERNEL
