@@ -260,7 +260,8 @@ def embedded_configs():
                 "steps": j["steps"],
                 "build_seconds": j.get("config", {}).get("build_seconds"),
                 "roofline": {kk: r.get(kk) for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_step", "avg_launch_ms",
-                                                      "frac_counter", "mfma_busy_frac", "list_major_bytes_8d", "candidates_rescored_per_query", "traffic",
+                                                      "frac_counter", "mfma_busy_frac", "list_major_bytes_8d", "candidates_rescored_per_query",
+                                                      "candidates_admitted_per_query", "probe_pairs", "probe_pairs_scanned", "scan_forced_drains", "traffic",
                                                       "traffic_over_algorithmic", "row_bytes_moved_GBps")},
                 "parity": {kk: j[kk] for kk in ("labels_bit_exact_vs_oracle", "labels_and_distances_bit_exact_vs_oracle", "parity_device",
                                                 "recall_at_10", "recall_sample_queries", "labels_equal_vs_openblas", "openblas_census",
