@@ -343,13 +343,16 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 #pragma unroll
 			for (int j = 0; j < PL; ++j)
 				mine += key[j] <= U ? 1 : 0;
-			int pos = 0;
-#pragma unroll 1
-			for (int l = 0; l < 63; ++l) {
-				const int c = __builtin_amdgcn_readlane(mine, l);
-				pos += lane > l ? c : 0;
+			// (exclusive prefix over the lanes in six shuffle steps; round 4 walked the 63 lanes with v_readlane -- with the bit searches
+			// below this kernel is bound by its own instruction latency, not by the 16 KB it reads per query: 60 us at C3)
+			int inc = mine;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const int v = __shfl_up(inc, off);
+				inc += lane >= off ? v : 0;
 			}
-			const int total = __builtin_amdgcn_readlane(pos + mine, 63);
+			int pos = inc - mine;
+			const int total = __builtin_amdgcn_readlane(inc, 63);
 			if (total <= 512) {
 #pragma unroll
 				for (int j = 0; j < PL; ++j) {
@@ -370,9 +373,13 @@ __global__ __launch_bounds__(64) void coarse_select_kernel(const float *__restri
 						b = 16; // bits 31..17 are zero in every entry (ids < 2^17)
 					const unsigned long long t = V | (1ull << b);
 					int cnt = 0;
+					if (total <= 128) { // (the usual case: a few times np keys survived -- two registers per lane hold them all)
+						cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(e[0] < t)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(e[1] < t));
+					} else {
 #pragma unroll
-					for (int i = 0; i < 8; ++i)
-						cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(e[i] < t));
+						for (int i = 0; i < 8; ++i)
+							cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(e[i] < t));
+					}
 					if (cnt < np)
 						V = t;
 				}
