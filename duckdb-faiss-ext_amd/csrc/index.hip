@@ -1456,7 +1456,7 @@ void FlatIndex::to_device(int new_device) {
 		MVS_HIP(hipFree(norms));
 	drop_bf16_rows();
 	for (DevBuf *b : {&ws_flag, &ws_tie, &ws_pfq, &ws_cand, &ws_ex, &ws_fail, &ws_fb, &ws_e2, &ws_stream, &ws_sorttmp, &ws_seg, &ws_pbnd,
-	                  &ws_rowmask, &ws_items1, &ws_qcount})
+	                  &ws_rowmask, &ws_items1, &ws_qcount, &ws_fbk, &ws_fbr})
 		b->release();
 	drop_shadow(); // (the shadow clustering lives on the old device: rebuilt on demand)
 	ws_q.release();
