@@ -25,6 +25,7 @@ struct CollectArgs {
 	unsigned long long *stream; // candidates (q << 32 | row)
 	unsigned long long *stream_cnt; // [0] entries appended
 	float *stream_s;           // (may be null; d <= 128 scan) the coarse value s of every entry: the final-bound filter's input
+	float *seed_stage;         // (may be null; flat_bf16_seed_kernel) [nsplit][nq][16] class maxima of every row split instead of atomics
 	const unsigned long long *rowmask; // SEL instances: bit r of word b = row 64 b + r passes the IDSelector
 	long long stream_cap;
 	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them

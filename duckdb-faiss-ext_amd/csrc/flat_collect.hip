@@ -1207,6 +1207,18 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_seed_kernel(const CollectArg
 		__syncthreads(); // also drains this block's LDS-DMA before the next block reads it
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (a.seed_stage) {
+		// Round 5: the split's class maxima as ONE coalesced 16-byte store per lane and column block (16 queries x 64 bytes = 1 KB per
+		// instruction) into [split][query][16]; collect_seed_reduce_kernel takes the maximum over the splits.  The atomics below -- nq x 16
+		// x nsplit = 4 M at the headline's batch, all at the kernel's end -- were 38 of its 99 us (profiles/r5_c3_ab.txt, 12).
+#pragma unroll
+		for (int cb = 0; cb < 8; ++cb) {
+			const int q = qw + 16 * cb + c;
+			if (q < a.nq)
+				*(f32x4acc *)(a.seed_stage + ((size_t)split * (size_t)a.nq + (size_t)q) * 16 + 4 * hq) = cm[cb]; // (-inf: no row seen)
+		}
+		return;
+	}
 	if (ntiles > 0) {
 #pragma unroll
 		for (int cb = 0; cb < 8; ++cb) {
@@ -1222,6 +1234,26 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_seed_kernel(const CollectArg
 			}
 		}
 	}
+}
+// one thread per (query, four classes): the maximum over the row splits' staged class maxima -> the class slots (neutral where no split saw a row)
+__global__ void collect_seed_reduce_kernel(const float *__restrict__ stage, int nsplit, long long nq, unsigned *__restrict__ gslot) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // = 4 q + quad
+	if (i >= nq * 4)
+		return;
+	f32x4acc m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+	for (int s = 0; s < nsplit; ++s) {
+		const f32x4acc v = *(const f32x4acc *)(stage + ((size_t)s * (size_t)nq * 16) + (size_t)i * 4);
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			m[r] = __builtin_fmaxf(m[r], v[r]); // (NaN: ignored, as the atomics on keys did)
+	}
+#pragma unroll
+	for (int r = 0; r < 4; ++r)
+		if (m[r] > -INFINITY) {
+			const unsigned k = skey(m[r]);
+			unsigned *p = gslot + (size_t)i * 4 + r;
+			*p = k < *p ? k : *p; // (the slots are neutral, or hold what an earlier attempt left: keep the better)
+		}
 }
 static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t nq, hipStream_t st) {
 	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
@@ -1252,7 +1284,13 @@ static void launch_collect_seed(int metric, CollectArgs a, int64_t rows, int64_t
 	else
 		MVS_SEED(false, false)
 #undef MVS_SEED
+	if (a.seed_stage)
+		hipLaunchKernelGGL(collect_seed_reduce_kernel, dim3((unsigned)((nq * 4 + 255) / 256)), dim3(256), 0, st, (const float *)a.seed_stage, a.nsplit,
+		                   (long long)nq, a.gslot);
 	MVS_HIP(hipGetLastError());
+}
+size_t collect_seed_stage_bytes(int64_t nq) { // (launch_collect_seed: at most 64 row splits)
+	return (size_t)64 * (size_t)nq * 16 * sizeof(float);
 }
 
 // row classes per query: 16, or 32 for 16 < kk <= 32 (d <= 128 only: the wide instances keep 16)
@@ -1352,7 +1390,7 @@ void launch_collect_report(const void *d_hdr, const int *d_fail_cnt, const unsig
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
                             unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st,
-                            bool cnt_zeroed, bool slots_ready) {
+                            bool cnt_zeroed, bool slots_ready, float *d_seed_stage) {
 	const int stride = collect_slot_stride(kk, collect_store_dims(g.d)); // 16 row classes whatever kk <= 16 is: the bound is the kk-th best of them
 	const long long gtotal = (long long)nq * stride;
 	if (!slots_ready) // (launch_collect_query_prep set them neutral)
@@ -1378,8 +1416,10 @@ void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, con
 	if (dp1 == 128 && tune().cl_seed_regs && stride == 16) { // (32 classes: 64 registers of maxima do not fit; the publish-only scan below)
 		// d <= 128: class maxima in registers (flat_bf16_seed_kernel) -- cheap enough for 32 768 rows (an eighth of a small index)
 		const int64_t rows = std::min<int64_t>(tune().cl_seed_rows > 16384 ? tune().cl_seed_rows : std::max(1024, tune().cl_seed_reg_rows), n / 8) / 64 * 64;
-		if (rows >= 1024)
+		if (rows >= 1024) {
+			a.seed_stage = d_seed_stage;
 			launch_collect_seed(metric, a, rows, nq, st);
+		}
 		return;
 	}
 	// (lists beyond 16: the bound is the kk-th best of the class bests, so the sample must grow with kk or the main scan starts with

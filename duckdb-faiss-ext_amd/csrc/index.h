@@ -230,6 +230,7 @@ public:
 	// Round 5, bucketed finish of the d = 128 L2 coarse filter: final-bound filter -> the survivors into per-query row buckets -> one
 	// wavefront per query re-scores them -> one wavefront per query selects and prints (csrc/ivf_collect.hip, shared with the IVF path):
 	// no radix sort, no segments, ~ 4 x fewer rows re-scored.  Set by search_prefilter_pass, consumed by collect_candidates.
+	bool cl_seed_stage = true;   // option cl_seed_stage: the register pre-pass stages its class maxima per row split, one reduce kernel publishes them
 	bool cl_fbucket = true;      // option cl_fbucket
 	bool cl_fbucket_off = false; // a query's bucket overflowed on this index's data: the sorted pipeline from then on
 	int cl_fpitch = 256;         // bucket entries per query
@@ -241,7 +242,7 @@ public:
 	int64_t cl_last_rescored = -1, cl_rescored_total = 0, cl_rescored_queries = 0, cl_admitted_in_fb = 0; // bucketed finish: survivors of the final-bound filter
 	bool cl_report_cnt = false;  // the scan's entry count (and the bucket header) still has to reach the host: launch_collect_report does it
 	unsigned long long *h_cl_hdr = nullptr; // pinned copy of the control block's header (bucket statistics)
-	DevBuf ws_fbk, ws_fbr;
+	DevBuf ws_fbk, ws_fbr, ws_seed;
 	bool cl_prep1 = true;        // option cl_prep1: one fused per-query preparation kernel in front of the d <= 128 coarse filter
 	double cl_est_per_query = 0; // candidates per query of the last search: sizes the next search's sort (collect_sort_estimate)
 	int cl_skip = 0, cl_skip_len = 0; // searches that bypass the coarse filter after it gave up on this index's data (doubling, <= 64)
@@ -409,7 +410,9 @@ int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int
                               int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                             int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot,
-                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st, bool cnt_zeroed = false, bool slots_ready = false);
+                            unsigned long long *d_stream_cnt, const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st, bool cnt_zeroed = false, bool slots_ready = false,
+                            float *d_seed_stage = nullptr);
+size_t collect_seed_stage_bytes(int64_t nq); // [64][nq][16] floats: the register pre-pass's class maxima per row split (csrc/flat_collect.hip)
 void launch_collect_query_prep(int metric, const float *d_x, int64_t nq, int d, const float *d_mu, const unsigned *d_max_norm_bits,
                                void *d_qf, float *d_qn, float *d_e2, int *d_fail_cnt, int *d_fail_q, unsigned *d_gslot, int stride,
                                int *d_ctl_hdr, int *d_ctl_seg, hipStream_t st);

@@ -435,8 +435,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 	ws_pbnd.reserve(collect_bound_table_bytes(nq));
 	float *pbnd = wide ? nullptr : (float *)ws_pbnd.p; // (the d <= 128 scan only)
+	if (!wide && cl_seed_stage)
+		ws_seed.reserve(collect_seed_stage_bytes(nq));
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, (const float *)ws_e2.p,
-	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st, true, prep1);
+	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st, true, prep1, (!wide && cl_seed_stage) ? (float *)ws_seed.p : nullptr);
 	int grid = 0, nsplit = 0, lds = 0;
 	const bool few = !wide && nq <= 128 && collect_slot_stride(kf, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
@@ -1456,7 +1458,7 @@ void FlatIndex::to_device(int new_device) {
 		MVS_HIP(hipFree(norms));
 	drop_bf16_rows();
 	for (DevBuf *b : {&ws_flag, &ws_tie, &ws_pfq, &ws_cand, &ws_ex, &ws_fail, &ws_fb, &ws_e2, &ws_stream, &ws_sorttmp, &ws_seg, &ws_pbnd,
-	                  &ws_rowmask, &ws_items1, &ws_qcount, &ws_fbk, &ws_fbr})
+	                  &ws_rowmask, &ws_items1, &ws_qcount, &ws_fbk, &ws_fbr, &ws_seed})
 		b->release();
 	drop_shadow(); // (the shadow clustering lives on the old device: rebuilt on demand)
 	ws_q.release();
@@ -2310,6 +2312,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "flat_shadow_nprobe")) {
 		shadow_nprobe = (int)std::max<int64_t>(1, v);
+		return true;
+	}
+	if (!strcmp(key, "cl_seed_stage")) { // 0: the register pre-pass publishes its class maxima with atomics (rounds 3-4)
+		cl_seed_stage = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "cl_fbucket")) { // 0: the sorted pipeline behind the d = 128 L2 coarse filter (round 4); 1: the bucketed finish
