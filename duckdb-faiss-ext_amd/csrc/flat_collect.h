@@ -12,6 +12,7 @@ typedef __attribute__((address_space(1))) const float glb_f32c;
 
 constexpr int CL_QBLOCK = 512;  // queries per workgroup
 constexpr int CL_BN = 32;       // rows per tile (one pass of the MFMA loop)
+constexpr double CL_MFMA_UNITS = 8.0; // modelled bf16-MFMA accumulation error, ulp-units (2^-24) of the magnitudes per 16 dimensions (csrc/flat_collect.hip)
 constexpr int CL_SUB = 2;       // tiles per staged block (one barrier per CL_SUB tiles)
 constexpr int CL_QCAP = 2048;   // candidate queue of a workgroup (entries of 8 bytes)
 constexpr int CL_FLUSH_EVERY = 2; // staged blocks between two looks at the queue

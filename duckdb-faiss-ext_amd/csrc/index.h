@@ -424,6 +424,7 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
                          unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
                          hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out, float *d_stream_s = nullptr);
 // thr[q] = B - 2E from the class slots as the scan left them (csrc/flat_collect.hip): the final-bound filter of the bucketed finish
+void launch_mfma_bf16_probe(const unsigned short *d_A, const unsigned short *d_Bt, const float *d_C, float *d_D, int64_t ntiles, hipStream_t st);
 void launch_collect_report(const void *d_hdr, const int *d_fail_cnt, const unsigned *d_maxnorm, int *h_flags, void *h_hdr, bool with_cnt,
                            hipStream_t st);
 void launch_collect_final_thr(const unsigned *d_gslot, int d, int kk, const float *d_e2, int64_t nq, float *d_thr, hipStream_t st);

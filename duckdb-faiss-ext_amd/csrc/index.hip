@@ -2175,6 +2175,20 @@ int mvs_synth_clustered_device(float *d_out, int64_t n_rows, int d, uint64_t see
 	MVS_API_END
 }
 
+int mvs_debug_mfma_bf16_16x16x32(const uint16_t *A, const uint16_t *Bt, const float *C, float *D, int64_t ntiles) {
+	MVS_API_BEGIN
+	if (ntiles <= 0)
+		return 0;
+	DevBuf a, b, c, d;
+	a.reserve((size_t)ntiles * 512 * 2), b.reserve((size_t)ntiles * 512 * 2), c.reserve((size_t)ntiles * 256 * 4), d.reserve((size_t)ntiles * 256 * 4);
+	MVS_HIP(hipMemcpy(a.p, A, (size_t)ntiles * 512 * 2, hipMemcpyHostToDevice));
+	MVS_HIP(hipMemcpy(b.p, Bt, (size_t)ntiles * 512 * 2, hipMemcpyHostToDevice));
+	MVS_HIP(hipMemcpy(c.p, C, (size_t)ntiles * 256 * 4, hipMemcpyHostToDevice));
+	launch_mfma_bf16_probe((const unsigned short *)a.p, (const unsigned short *)b.p, (const float *)c.p, (float *)d.p, ntiles, nullptr);
+	MVS_HIP(hipDeviceSynchronize());
+	MVS_HIP(hipMemcpy(D, d.p, (size_t)ntiles * 256 * 4, hipMemcpyDeviceToHost));
+	MVS_API_END
+}
 int mvs_index_last_kernel_info(const mvs_index *ix, mvs_kernel_info *out) {
 	MVS_API_BEGIN
 	*out = ix->impl->kinfo;

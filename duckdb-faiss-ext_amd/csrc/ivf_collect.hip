@@ -21,6 +21,7 @@
 // rows of every query's nearest list (publish only) warms the bounds.
 #include "flat_fused.h"
 #include "collect_bucket.h"
+#include "flat_collect.h" // CL_MFMA_UNITS: the modelled bf16-MFMA term of the bound
 
 #include <algorithm>
 #include <cmath>
@@ -136,14 +137,14 @@ void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int
 // Error bound, in "s" units (s_exact = -D_oracle, the scanner's value), u = 2^-24, S' = ||x'|| ||y'||_max(list), norms inflated
 // by 1e-4 for their own rounding:
 //   bf16 rounding of both operands (the query operand carries the exact factor 2):        2 (2^-7 + 2^-16) S'
-//   MFMA accumulation from C = beta + gamma (4 ulp-units of the magnitudes per instruction, counted as d / 16 instructions,
-//   1.25 safety factor as in flat_collect.hip):                                            1.25 (d/16) 4u ((1 + 2^-7) 2 S' + xn' + yn'_max)
+//   MFMA accumulation from C = beta + gamma (CL_MFMA_UNITS = 8 ulp-units of the magnitudes per 16 dimensions -- measured: csrc/flat_collect.hip --,
+//   1.25 safety factor as in flat_collect.hip):                                            1.25 (d/16) 8u ((1 + 2^-7) 2 S' + xn' + yn'_max)
 //   C = fl(beta + gamma), beta and gamma d-term f32 chains:                               (d + 1) u (xn' + yn'_max)
 //   the scanner's value: D = sum fl((x_k - y_k)^2) accumulated in f32, on x' - y' = x - y up to one rounding per component of
 //   each residual:                                                                        (d + 8) u (||x'|| + ||y'||_max)^2
 //   E = the sum; e2 = 2 E (1 + 2^-10) + slack.  Non-finite -> NaN (the query is re-run on the scanner kernel).
 // Inner product (IS_L2 = false): the query enters as bf16(x) (not centred: <x, y> = <x, y'> + <x, c>), gamma = <x, c_list>, beta = 0;
-//   E = (2^-7 + 2^-16) S + 1.25 (d/16) 4u ((1 + 2^-7 + 2^-16) S + |gamma|) + d u ||x|| ||c|| (gamma's chain) + u S (y' rounding)
+//   E = (2^-7 + 2^-16) S + 1.25 (d/16) 8u ((1 + 2^-7 + 2^-16) S + |gamma|) + d u ||x|| ||c|| (gamma's chain) + u S (y' rounding)
 //       + d u ||x|| (||c|| + ||y'||_max) (the scanner's chain over the original row),   S = ||x|| ||y'||_max(list)
 // 2 E of one (query, list) pair from the four sums of ivf_collect_pack_kernel (NaN: not finite -> the query is re-run on the scanner)
 template <bool IS_L2>
@@ -158,10 +159,10 @@ __device__ __forceinline__ float ivf_slot_e2(float xn, float cn, float dq2, floa
 	const double rnd = bound_mode == 0 ? rnd_worst : (rnd_actual < rnd_worst || !(rnd_actual == rnd_actual) ? rnd_actual : rnd_worst);
 	double E;
 	if (IS_L2)
-		E = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * 2.0 * S + (double)xn + yn) +
+		E = rnd + 1.25 * ((double)d / 16.0) * CL_MFMA_UNITS * u * ((1.0 + 0.0079) * 2.0 * S + (double)xn + yn) +
 		    ((double)d + 1.0) * u * ((double)xn + yn) + ((double)d + 8.0) * u * (nx + ny) * (nx + ny);
 	else
-		E = rnd + 1.25 * ((double)d / 16.0) * 4.0 * u * ((1.0 + 0.0079) * S + nx * nc) + (double)d * u * nx * nc + u * S +
+		E = rnd + 1.25 * ((double)d / 16.0) * CL_MFMA_UNITS * u * ((1.0 + 0.0079) * S + nx * nc) + (double)d * u * nx * nc + u * S +
 		    ((double)d + 2.0) * u * nx * (nc + ny);
 	const float r = (float)(2.0 * E * (1.0 + 0.0009765625) + 8.0 * u * (S + (double)xn + yn + nx * nc) + 1e-30);
 	if (isfinite(xn) && isfinite(yn) && isfinite(dq2) && isfinite(dyn) && isfinite(r) && r < 1e30f)

@@ -733,4 +733,34 @@ void launch_synth_clustered(float *d_out, int64_t n_rows, int d, uint64_t seed, 
 	MVS_HIP(hipGetLastError());
 }
 
+
+// ---- diagnostics: ONE v_mfma_f32_16x16x32_bf16 per wavefront on caller-supplied tiles (round 5) ------------------------------------
+// The coarse filters' error bound has one MODELLED term: what the bf16 MFMA's internal accumulation of 32 products + C can deviate
+// from the exact sum (csrc/flat_collect.hip: 4 ulp-units of the magnitudes per instruction x 1.25).  tests/test_mfma_model_gpu.py
+// feeds this kernel adversarial tiles and compares with the exact sum: the instruction itself, nothing around it.
+// A: [ntiles][16 rows][32 k] bf16 bits, Bt: [ntiles][16 columns][32 k] bf16 bits, C / D: [ntiles][16 rows][16 columns] f32.
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void mfma_bf16_probe_kernel(const unsigned short *__restrict__ A, const unsigned short *__restrict__ Bt,
+                                                            const float *__restrict__ C, float *__restrict__ D) {
+	const size_t t = blockIdx.x;
+	const int l = threadIdx.x, rc = l & 15, g = l >> 4;
+	const probe_bf16x8 a = *(const probe_bf16x8 *)(A + t * 512 + rc * 32 + 8 * g);  // row rc, k = 8 g .. 8 g + 7
+	const probe_bf16x8 b = *(const probe_bf16x8 *)(Bt + t * 512 + rc * 32 + 8 * g); // column rc, the same k
+	probe_f32x4 c;
+#pragma unroll
+	for (int r = 0; r < 4; ++r)
+		c[r] = C[t * 256 + (4 * g + r) * 16 + rc]; // rows 4 g + r, column rc
+	const probe_f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 4; ++r)
+		D[t * 256 + (4 * g + r) * 16 + rc] = d[r];
+}
+void launch_mfma_bf16_probe(const unsigned short *d_A, const unsigned short *d_Bt, const float *d_C, float *d_D, int64_t ntiles, hipStream_t st) {
+	if (ntiles <= 0)
+		return;
+	hipLaunchKernelGGL(mfma_bf16_probe_kernel, dim3((unsigned)ntiles), dim3(64), 0, st, d_A, d_Bt, d_C, d_D);
+	MVS_HIP(hipGetLastError());
+}
+
 } // namespace mvs

@@ -135,6 +135,7 @@ _L.mvs_finish_ip_ties.argtypes = [_i64, _i64, _i64, _p, _p, _i64, _p, _p, _p, _p
 _L.mvs_index_tie_candidates_device.argtypes = [_p, _i64, _p, _p, _i64, _p, C.POINTER(SearchParams), _p]
 _L.mvs_index_ivf_tie_emit_device.argtypes = [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(SearchParams), _p]
 _L.mvs_synth_uniform_device.argtypes = [_p, _i64, C.c_int, C.c_uint64, _i64, _p]
+_L.mvs_debug_mfma_bf16_16x16x32.argtypes = [_p, _p, _p, _p, _i64]
 _L.mvs_synth_clustered_device.argtypes = [_p, _i64, C.c_int, C.c_uint64, _i64, C.c_int, C.c_float, _p]
 _L.mvs_index_last_kernel_info.argtypes = [_p, C.POINTER(KernelInfo)]
 _L.mvs_index_set_kernel_timing.argtypes = [_p, C.c_int]
@@ -151,7 +152,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
     "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_ivf_probe_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
-    "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_index_ivf_tie_emit_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_index_last_kernel_info",
+    "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_index_ivf_tie_emit_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_debug_mfma_bf16_16x16x32", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
     "mvs_version",
 ]  # fmt: skip
@@ -495,6 +496,21 @@ def synth_uniform_torch(n, d, seed, row0=0, device="cuda:0", out=None):
     st = torch.cuda.current_stream(out.device).cuda_stream
     _check(_L.mvs_synth_uniform_device(out.data_ptr(), n, d, seed, row0, st))
     return out
+
+
+def mfma_bf16_16x16x32(A_bits, Bt_bits, C):
+    """D = A B + C by ONE v_mfma_f32_16x16x32_bf16 per tile (diagnostics): A_bits [n][16][32], Bt_bits [n][16][32] uint16 bf16
+    patterns (Bt = the columns of B as rows), C [n][16][16] float32"""
+    import numpy as np
+
+    A_bits = np.ascontiguousarray(A_bits, dtype=np.uint16)
+    Bt_bits = np.ascontiguousarray(Bt_bits, dtype=np.uint16)
+    Cc = np.ascontiguousarray(C, dtype=np.float32)
+    n = A_bits.shape[0]
+    assert A_bits.shape == (n, 16, 32) and Bt_bits.shape == (n, 16, 32) and Cc.shape == (n, 16, 16)
+    D = np.empty((n, 16, 16), dtype=np.float32)
+    _check(_L.mvs_debug_mfma_bf16_16x16x32(A_bits.ctypes.data, Bt_bits.ctypes.data, Cc.ctypes.data, D.ctypes.data, n))
+    return D
 
 
 def synth_clustered_torch(n, d, seed, row0=0, n_centers=1024, sigma=0.1, device="cuda:0", out=None):

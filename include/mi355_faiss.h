@@ -206,6 +206,10 @@ typedef struct mvs_kernel_info {
 	double last_ms;     /* HIP-event duration of that launch, if timed */
 	int32_t grid, block, lds_bytes, nsplit;
 } mvs_kernel_info;
+/* Diagnostics (no counterpart in the reference): ntiles independent v_mfma_f32_16x16x32_bf16 instructions, D = A B + C, on host
+ * buffers -- A [ntiles][16 rows][32 k] and Bt [ntiles][16 columns][32 k] as bf16 bit patterns, C / D [ntiles][16][16] f32.  The
+ * coarse filters' error bound models this instruction's internal accumulation; tests/test_mfma_model_gpu.py measures it. */
+int mvs_debug_mfma_bf16_16x16x32(const uint16_t *A, const uint16_t *Bt, const float *C, float *D, int64_t ntiles);
 int mvs_index_last_kernel_info(const mvs_index *ix, mvs_kernel_info *out);
 /* when enabled, the dominant kernel of every search is bracketed by HIP events on its stream */
 int mvs_index_set_kernel_timing(mvs_index *ix, int enabled);

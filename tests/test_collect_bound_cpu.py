@@ -43,7 +43,7 @@ def flat_bound(metric_l2, x, mu, yn_max, ync_max, d, dyc_max=None):
         dq2 = float(((a - bf16(a)).astype(np.float64) ** 2).sum())
         ndq, ndy = np.sqrt(dq2 * infl), np.sqrt(dyc_max * infl)
         rnd = min(rnd, ndq * np.sqrt(ync_max * infl) + (al * np.sqrt(xnc * infl) + ndq) * ndy)
-    es = rnd + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * al * Sc + bmax)
+    es = rnd + 1.25 * (d / 16.0) * 8.0 * U * ((1.0 + 0.0079) * al * Sc + bmax)
     if metric_l2:
         E = es + 4 * U * (xnc + ync_max) + d * U * ync_max + 2 * d * U * S + 4 * U * (xn + yn_max) + 2 * (d + 8) * U * (xn + yn_max)
     else:
@@ -131,9 +131,9 @@ def ivf_bound(metric_l2, xn, yn, cn, d, dq2=None, dyn=None):
         ndq, ndy = np.sqrt(dq2 * infl), np.sqrt(dyn * infl)
         rnd = min(rnd, ndq * ny + (al * nx + ndq) * ndy)
     if metric_l2:
-        return (rnd + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * 2.0 * S + xn + yn)
+        return (rnd + 1.25 * (d / 16.0) * 8.0 * U * ((1.0 + 0.0079) * 2.0 * S + xn + yn)
                 + (d + 1.0) * U * (xn + yn) + (d + 8.0) * U * (nx + ny) ** 2)
-    return (rnd + 1.25 * (d / 16.0) * 4.0 * U * ((1.0 + 0.0079) * S + nx * nc)
+    return (rnd + 1.25 * (d / 16.0) * 8.0 * U * ((1.0 + 0.0079) * S + nx * nc)
             + d * U * nx * nc + U * S + (d + 2.0) * U * nx * (nc + ny))
 
 
