@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	unsigned long long *qbuf = (unsigned long long *)(nbuf + NST * 64); // [CL_QCAP] candidate queue
 	float *cqtab = (float *)(qbuf + CL_QCAP);                           // [4 waves][16 c][4]: pass bound of column block i, query c
 	unsigned *qctl = (unsigned *)(cqtab + 4 * 16 * 4);                  // [0] queue fill, [2..3] flush base
+	float *qval = (float *)(qctl + 16);                                 // [CL_QCAP] coarse value of every queued candidate (round 5: the final-bound filter's input)
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	const unsigned rbase = (unsigned)(c * PITCH) + (unsigned)(((hq ^ c) & 15) * 16);
 	const unsigned qcnt_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned *)qctl);
 	const unsigned qbuf_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned long long *)qbuf);
+	const unsigned qval_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)qval);
 	const unsigned cq_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float *)cqtab) + (unsigned)((wave * 16 + c) * 16);
 
 	// candidates of one tile: rows whose coarse value reaches the pass bound of their query
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 					asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(qcnt_lds), "v"(one) : "memory");
 					const unsigned long long ent = ((unsigned long long)(unsigned)q << 32) | row;
 					if (pos < (unsigned)CL_QCAP) {
-						asm volatile("ds_write_b64 %0, %1" ::"v"(qbuf_lds + 8u * pos), "v"(ent) : "memory");
+						asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(qbuf_lds + 8u * pos), "v"(ent), "v"(qval_lds + 4u * pos), "v"(v) : "memory");
 					} else { // a burst beyond the queue: straight to the stream (by hand, wait included: flat_collect.hip)
 						unsigned long long gp;
 						const unsigned long long one64 = 1ull;
@@ -183,8 +185,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 						             : "=&v"(gp)
 						             : "v"((GUL)a.stream_cnt), "v"(one64)
 						             : "memory");
-						if ((long long)gp < a.stream_cap)
+						if ((long long)gp < a.stream_cap) {
 							*((GUL)a.stream + gp) = ent;
+							if (a.stream_s)
+								a.stream_s[gp] = v;
+						}
 					}
 				}
 			}
@@ -402,8 +407,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 				__syncthreads();
 				const unsigned long long base = *(const unsigned long long *)(qctl + 2);
 				for (unsigned i = tid; i < n; i += 256)
-					if ((long long)(base + i) < a.stream_cap)
+					if ((long long)(base + i) < a.stream_cap) {
 						a.stream[base + i] = qbuf[i];
+						if (a.stream_s)
+							a.stream_s[base + i] = qval[i];
+					}
 				__syncthreads();
 			}
 		}
@@ -452,8 +460,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			__syncthreads();
 			const unsigned long long base = *(const unsigned long long *)(qctl + 2);
 			for (unsigned i = tid; i < n; i += 256)
-				if ((long long)(base + i) < a.stream_cap)
+				if ((long long)(base + i) < a.stream_cap) {
 					a.stream[base + i] = qbuf[i];
+					if (a.stream_s)
+						a.stream_s[base + i] = qval[i];
+				}
 		}
 	}
 }
@@ -466,7 +477,7 @@ int collect_big_qblock(int dp1) {
 }
 size_t collect_big_lds_bytes(int dp1) {
 	const int part = dp1 == 1536 ? 768 : dp1; // dims of a staged block (the 1536-dim store is staged in two parts per row block)
-	return (size_t)big_stages(16 * part * 2) * (16 * part * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64;
+	return (size_t)big_stages(16 * part * 2) * (16 * part * 2 + 64 * 4) + (size_t)CL_QCAP * 8 + 4 * 16 * 4 * 4 + 64 + (size_t)CL_QCAP * 4;
 }
 
 template <int KBT, int NCB, int KSPL = 1>

@@ -231,6 +231,7 @@ public:
 	// wavefront per query re-scores them -> one wavefront per query selects and prints (csrc/ivf_collect.hip, shared with the IVF path):
 	// no radix sort, no segments, ~ 4 x fewer rows re-scored.  Set by search_prefilter_pass, consumed by collect_candidates.
 	bool cl_seed_stage = true;   // option cl_seed_stage: the register pre-pass stages its class maxima per row split, one reduce kernel publishes them
+	bool cl_wide_refilter = true; // option cl_wide_refilter: the final-bound filter in front of the sorted pipeline of the 512 < d <= 1536 stores (flat_bf16_big_kernel)
 	bool cl_fbucket = true;      // option cl_fbucket
 	bool cl_fbucket_off = false; // a query's bucket overflowed on this index's data: the sorted pipeline from then on
 	int cl_fpitch = 256;         // bucket entries per query
@@ -427,6 +428,8 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 void launch_mfma_bf16_probe(const unsigned short *d_A, const unsigned short *d_Bt, const float *d_C, float *d_D, int64_t ntiles, hipStream_t st);
 void launch_collect_report(const void *d_hdr, const int *d_fail_cnt, const unsigned *d_maxnorm, int *h_flags, void *h_hdr, bool with_cnt,
                            hipStream_t st);
+void launch_stream_refilter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt, const float *d_thr,
+                            unsigned long long *d_out, unsigned long long *d_out_cnt, hipStream_t st);
 void launch_collect_final_thr(const unsigned *d_gslot, int d, int kk, const float *d_e2, int64_t nq, float *d_thr, hipStream_t st);
 // Entries the deferred sort of a search is launched with, from the candidates per query c of the index's previous search: the
 // margin shrinks with the batch (the mean of nq heavy-tailed per-query counts), 17 % + 16 per query at 10 000 queries, 40 % at 64

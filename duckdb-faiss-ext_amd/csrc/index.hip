@@ -466,6 +466,17 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	};
 	if (fb)
 		fb_layout();
+	// (round 5) the 512 < d <= 1536 stores: the big kernel keeps every candidate's coarse value too; the final-bound filter then compacts
+	// the stream in front of the sort (a candidate costs 3-6 KB of f32 row there)
+	const bool wrf = !fb && wide && cl_wide_refilter && !strcmp(collect_wide_kernel_name(dp1), "flat_bf16_big_kernel");
+	auto wrf_layout = [&]() {
+		const size_t sb = ((size_t)cap_entries * 4 + 255) & ~(size_t)255;
+		ws_fbk.reserve(sb + (((size_t)nq * 4 + 255) & ~(size_t)255) + 256);
+		stream_s = (float *)ws_fbk.p;
+		fb_thr = (float *)((char *)ws_fbk.p + sb);
+	};
+	if (wrf)
+		wrf_layout();
 	for (int attempt = 0;; ++attempt) {
 	begin_kernel_timing(st);
 	if (few) {
@@ -531,6 +542,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
 		if (fb)
 			fb_layout();
+		if (wrf)
+			wrf_layout();
 	} else {
 		// (b) a few queries hold far more than their share: out of the coarse filter with them, one more scan for the others
 		ws_qcount.reserve((size_t)(nq + 16) * sizeof(int));
@@ -600,7 +613,9 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		*pi1_out = nullptr;
 		cl_sorted = nullptr;
 	} else {
-	const size_t temp = defer_count ? collect_sort_temp_bytes_est(cl_deferred_cap, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
+	// (the filtered stream is sorted in device-count mode whatever the count mode of the scan was)
+	const size_t temp = (defer_count || wrf) ? collect_sort_temp_bytes_est(defer_count ? cl_deferred_cap : std::max<int64_t>(ncand, 1), nq)
+	                                         : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
 	ws_sorttmp.reserve(std::max<size_t>(temp, 16));
 	const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
 	ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
@@ -608,11 +623,20 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
 	// (with a selector or fewer than 20 queries FAISS takes its per-pair branch: L2 = sum (x_k - y_k)^2; inner product is the
 	// same chain either way)
+	if (wrf) {
+		// stream -> (filter) -> `sorted` -> (sort by query) -> stream: the survivors' count lives in the control block's header @8
+		launch_collect_final_thr((const unsigned *)ws_gthr.p, d, kf, (const float *)ws_e2.p, nq, fb_thr, st);
+		launch_stream_refilter(stream, stream_s, cap_entries, cnt, fb_thr, sorted, cnt + 1, st);
+		launch_collect_rescore(metric, sorted, stream, defer_count ? cl_deferred_cap : std::max<int64_t>(ncand, 1), ws_sorttmp.p, temp, nq, kk, d_x, geom,
+		                       vecs, norms, (const float *)ws_qn.p, seg, pd1, pi1, has_sel || nq < 20, st, cnt + 1, true);
+		cl_sorted = stream;
+	} else {
 	launch_collect_rescore(metric, stream, sorted, defer_count ? cl_deferred_cap : ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
 	                       (const float *)ws_qn.p, seg, pd1, pi1, has_sel || nq < 20, st, defer_count ? cnt : nullptr, true);
+	cl_sorted = sorted;
+	}
 	*pd1_out = pd1;
 	*pi1_out = pi1;
-	cl_sorted = sorted;
 	}
 	snprintf(kinfo.name, sizeof kinfo.name, "%s", wide ? collect_wide_kernel_name(collect_store_dims(d)) : "flat_bf16_collect_kernel");
 	kinfo.flops = 2.0 * (double)nq * (double)ntotal * d;
@@ -2330,6 +2354,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "cl_seed_stage")) { // 0: the register pre-pass publishes its class maxima with atomics (rounds 3-4)
 		cl_seed_stage = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "cl_wide_refilter")) {
+		cl_wide_refilter = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "cl_fbucket")) { // 0: the sorted pipeline behind the d = 128 L2 coarse filter (round 4); 1: the bucketed finish

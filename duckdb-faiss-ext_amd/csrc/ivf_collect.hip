@@ -1406,6 +1406,15 @@ __global__ __launch_bounds__(256) void ivf_refilter_kernel(const unsigned long l
 		__syncthreads(); // (wsum / gbase are rewritten by the next round)
 	}
 }
+// the compaction alone, thresholds given (the Flat index's wide stores: csrc/index.hip collect_candidates)
+void launch_stream_refilter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt, const float *d_thr,
+                            unsigned long long *d_out, unsigned long long *d_out_cnt, hipStream_t st) {
+	if (cap <= 0)
+		return;
+	const unsigned blocks = (unsigned)std::min<int64_t>((cap + 256 * RF_PER - 1) / (256 * RF_PER), 8192);
+	hipLaunchKernelGGL(ivf_refilter_kernel, dim3(blocks), dim3(256), 0, st, d_strm, d_su, (long long)cap, d_cnt, d_thr, d_out, d_out_cnt);
+	MVS_HIP(hipGetLastError());
+}
 void launch_ivf_refilter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
                          const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned long long *d_out,
                          unsigned long long *d_out_cnt, hipStream_t st) {
