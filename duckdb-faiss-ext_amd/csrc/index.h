@@ -241,6 +241,7 @@ public:
 	int64_t cl_out_off = 0;
 	bool cl_emitted = false;     // collect_candidates wrote the final lists itself (the caller skips its emission)
 	int64_t cl_last_rescored = -1, cl_rescored_total = 0, cl_rescored_queries = 0, cl_admitted_in_fb = 0; // bucketed finish: survivors of the final-bound filter
+	bool cl_wrf_used = false;    // the last collect_candidates compacted the stream with the final-bound filter (wide stores)
 	bool cl_report_cnt = false;  // the scan's entry count (and the bucket header) still has to reach the host: launch_collect_report does it
 	unsigned long long *h_cl_hdr = nullptr; // pinned copy of the control block's header (bucket statistics)
 	DevBuf ws_fbk, ws_fbr, ws_seed;

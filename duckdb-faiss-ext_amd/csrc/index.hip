@@ -446,6 +446,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	const bool fb = cl_fbucket && !cl_fbucket_off && cl_out_D && metric == METRIC_L2 && !wide && !few && d == 128 && geom.dp == 128 && kk <= 64 &&
 	                nq * (int64_t)cl_fpitch < ((int64_t)1 << 31);
 	cl_emitted = false;
+	cl_wrf_used = false;
 	float *stream_s = nullptr, *fb_thr = nullptr;
 	unsigned *fb_rows = nullptr;
 	unsigned long long *fb_keys = nullptr, *fb_units = nullptr;
@@ -630,6 +631,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		launch_collect_rescore(metric, sorted, stream, defer_count ? cl_deferred_cap : std::max<int64_t>(ncand, 1), ws_sorttmp.p, temp, nq, kk, d_x, geom,
 		                       vecs, norms, (const float *)ws_qn.p, seg, pd1, pi1, has_sel || nq < 20, st, cnt + 1, true);
 		cl_sorted = stream;
+		cl_wrf_used = true;
+		if (!h_cl_hdr)
+			MVS_HIP(hipHostMalloc((void **)&h_cl_hdr, 256, hipHostMallocDefault));
+		if (!cl_report_cnt) // (synchronous count mode: the caller's report kernel does not carry the header)
+			MVS_HIP(hipMemcpyAsync(h_cl_hdr, ws_seg.p, 256, hipMemcpyDeviceToHost, st));
 	} else {
 	launch_collect_rescore(metric, stream, sorted, defer_count ? cl_deferred_cap : ncand, ws_sorttmp.p, temp, nq, kk, d_x, geom, vecs, norms,
 	                       (const float *)ws_qn.p, seg, pd1, pi1, has_sel || nq < 20, st, defer_count ? cnt : nullptr, true);
@@ -1105,7 +1111,7 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	// (one kernel writes fail count, rounding residual and -- deferred count mode -- the scan's entry count / the bucket header to pinned memory)
 	launch_collect_report(collected ? ws_seg.p : nullptr, fail_cnt, d_max_norm_bits + 4, h_flag_count,
-	                      (emitted && cl_report_cnt) ? h_cl_hdr : nullptr, collected && cl_report_cnt, st);
+	                      ((emitted || (collected && cl_wrf_used)) && cl_report_cnt) ? h_cl_hdr : nullptr, collected && cl_report_cnt, st);
 	if (flp) {
 		if (collected && defer && cl_deferred_cap > 0) {
 			// (the sort covered cl_deferred_cap entries -- if the scan produced more, the tie pass below would work on a
@@ -1163,7 +1169,12 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 		cl_queries_total += nq;
 		cl_candidates_total += (int64_t)ncand_u;
 	}
-	if (emitted && cl_last_rescored >= 0) // (mvs_index_collect_stats then reports what the exact stage re-scored, as for an IVF index)
+	if (collected && cl_wrf_used && !emitted) { // (the wide stores' filter: survivors in the control block's header @8)
+		unsigned long long kept = 0;
+		memcpy(&kept, (const char *)h_cl_hdr + 8, sizeof kept);
+		cl_last_rescored = (int64_t)kept;
+	}
+	if ((emitted || (collected && cl_wrf_used)) && cl_last_rescored >= 0) // (mvs_index_collect_stats then reports what the exact stage re-scored, as for an IVF index)
 		cl_rescored_total += cl_last_rescored, cl_rescored_queries += nq, cl_admitted_in_fb += cl_last_candidates;
 	const int nf = h_flag_count[8];
 	pf_last_fallback = nf;
