@@ -273,6 +273,234 @@ __global__ __launch_bounds__(256) void coarse_dist_mfma_kernel(const float *__re
 		}
 	}
 }
+// Round 5: the same tile, restaged, and the matrix written UNDER the next tile's MFMAs.
+// (1) The ISA of the kernel above holds one reason its three parts ADD UP (staging 51 + MFMAs 95 + stores 30 = 176 us,
+// profiles/r4_coarse_kernel_ablation.txt): the eight loads of a slab sit behind branches with an s_waitcnt vmcnt(0) between them -- four
+// serial round trips per slab -- and each touches 32 cache lines for 16 bytes.  Here: EIGHT lanes per row (an instruction reads whole
+// 128-byte lines: rows r8 + 32 i, float4 chunk c16 of the slab), every load unconditional from a clamped address (zeroed by a select
+// when the slab is staged), issued back to back a whole slab ahead of its LDS write; the tile in LDS ROW-major ([256 rows][32 dims + 4]:
+// eight ds_write_b128 per thread instead of 32 transposing ds_write_b32; the operand reads (row ln, dim k + h) collide two ways on
+// 36-float rows, 40 ds_read2_b32 per slab against 64 MFMAs of 64 cycles: free), requested one group of eight MFMAs ahead.
+// (2) The other reason: every tile costs the same, so all workgroups of the chip reach their epilogue TOGETHER -- a 33 MB burst of
+// stores per round with the matrix pipe idle, then MFMAs with HBM idle (one workgroup per tile, (1) alone: 170 -> 153 us at C3).
+// Persistent workgroups (two per CU, tile += gridDim.x; the (tile, slab) loop flattened so that the next tile's first slabs are
+// fetched and staged under the current tile's last MFMAs) keep a finished tile's 64 distances per lane in registers and store them
+// eight at a time behind the MFMA groups of the NEXT tile's first slab.
+// Same instruction, same k order, same epilogue arithmetic: same bits.  d % 4 == 0 (16-byte query rows), else the kernel above.
+constexpr int C2_K = 32, C2_P = C2_K + 4;
+template <bool IL>
+__global__ __launch_bounds__(256, 2) void coarse_dist_mfma2_kernel(const float *__restrict__ x, long long nq, int d,
+                                                               const float *__restrict__ cent, int sdp, int nlist,
+                                                               const float *__restrict__ qn, const float *__restrict__ cn,
+                                                               int is_l2, float *__restrict__ D, int abl) {
+	extern __shared__ __attribute__((aligned(16))) float c2_lds[]; // [2][256][C2_P]: rows 0..127 queries, 128..255 centroids; qs[2][128]
+	float *qs = c2_lds + 2 * 256 * C2_P;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
+	const int ntx = (nlist + 127) / 128;
+	const int ntiles = ntx * (int)((nq + 127) / 128);
+	const int S = (d + C2_K - 1) / C2_K; // slabs per tile
+	const int r4 = tid >> 2, c8 = tid & 3; // staging: tile rows r4 + 64 i (i < 2 queries, i >= 2 centroids), dims 8 c8 .. 8 c8 + 7 of the slab
+	if ((int)blockIdx.x >= ntiles)
+		return;
+	const int total = ((ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1) * S; // slabs of this workgroup
+	float4 rg[8];
+	float qv = 0.f;
+	unsigned fl = 0u; // bit i: centroid row r4 + 64 i of the slab in flight is a flipped row of the pair-interleaved store
+	// (32-bit running positions: a 64-bit division per slab costs more instructions than the slab's address arithmetic)
+	int f_tile = blockIdx.x, f_sl = 0, f_c0 = (int)(blockIdx.x % (unsigned)ntx) * 128; // the slab the next fetch() requests
+	long long f_q0 = (long long)(blockIdx.x / (unsigned)ntx) * 128;
+	auto fetch = [&]() __attribute__((always_inline)) {
+		const int kk = f_sl * C2_K + 8 * c8;
+		// (dims past the row: a valid address, zeroed when the slab is staged)
+		const int kx0 = kk < d ? kk : 0, kx1 = kk + 4 < d ? kk + 4 : 0, kc0 = kk < sdp ? kk : 0, kc1 = kk + 4 < sdp ? kk + 4 : 0;
+		fl = 0u;
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const long long qrow = f_q0 + r4 + 64 * i;
+			const int crow = f_c0 + r4 + 64 * i;
+			const float *xr = x + (qrow < nq ? qrow : nq - 1) * d; // (rows past the end: results never stored)
+			const float *cr = cent + (size_t)(crow < nlist ? crow : nlist - 1) * sdp;
+			rg[2 * i] = *(const float4 *)(xr + kx0);
+			rg[2 * i + 1] = *(const float4 *)(xr + kx1);
+			rg[4 + 2 * i] = *(const float4 *)(cr + kc0);
+			rg[4 + 2 * i + 1] = *(const float4 *)(cr + kc1);
+			fl |= (IL && ((crow >> 4) & 1)) ? (1u << i) : 0u;
+		}
+		if (f_sl == 0 && tid < 128)
+			qv = (is_l2 && f_q0 + tid < nq) ? qn[f_q0 + tid] : 0.f;
+		if (++f_sl == S) {
+			f_sl = 0;
+			f_tile += gridDim.x;
+			f_q0 = (long long)((unsigned)f_tile / (unsigned)ntx) * 128;
+			f_c0 = (int)((unsigned)f_tile % (unsigned)ntx) * 128;
+		}
+	};
+	int s_sl = 0, s_par = 0; // the slab the next stage() writes: its position in the tile, its tile's parity
+	auto stage = [&](int buf) __attribute__((always_inline)) {
+		// LDS rows of 32 dims + 4: every block of 8 dims as [k0 k2 k4 k6 | k1 k3 k5 k7] -- lane (ln, h) of the MFMA loop reads the four
+		// k-steps of its half (dims 8 b + 2 j + h) with ONE ds_read_b128 (16 lanes of a group on 16 different 16-byte slots of the
+		// 256-byte bank row: conflict-free, where ds_read_b32 of one dim across 32 rows is four-way whatever 16-byte-aligned pitch)
+		float *base = c2_lds + buf * 256 * C2_P + r4 * C2_P + 8 * c8;
+		const int kk = s_sl * C2_K + 8 * c8;
+		const bool okx0 = kk < d, okx1 = kk + 4 < d, okc0 = kk < sdp, okc1 = kk + 4 < sdp;
+		const bool cut = (s_sl + 1) * C2_K > (d < sdp ? d : sdp); // (uniform: only a row's last slab can reach past its end)
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			float4 a = rg[2 * i], b = rg[2 * i + 1], u = rg[4 + 2 * i], v = rg[4 + 2 * i + 1]; // (values: see fetch())
+			if (cut) {
+				a.x = okx0 ? a.x : 0.f, a.y = okx0 ? a.y : 0.f, a.z = okx0 ? a.z : 0.f, a.w = okx0 ? a.w : 0.f;
+				b.x = okx1 ? b.x : 0.f, b.y = okx1 ? b.y : 0.f, b.z = okx1 ? b.z : 0.f, b.w = okx1 ? b.w : 0.f;
+				u.x = okc0 ? u.x : 0.f, u.y = okc0 ? u.y : 0.f, u.z = okc0 ? u.z : 0.f, u.w = okc0 ? u.w : 0.f;
+				v.x = okc1 ? v.x : 0.f, v.y = okc1 ? v.y : 0.f, v.z = okc1 ? v.z : 0.f, v.w = okc1 ? v.w : 0.f;
+			}
+			*(float4 *)(base + 64 * i * C2_P) = make_float4(a.x, a.z, b.x, b.z);
+			*(float4 *)(base + 64 * i * C2_P + 4) = make_float4(a.y, a.w, b.y, b.w);
+			float4 ev = make_float4(u.x, u.z, v.x, v.z), od = make_float4(u.y, u.w, v.y, v.w);
+			if (IL) { // (csrc/common.h FlatGeom: four dims as [k0,k2,k1,k3] in rows with bit 4 clear, [k1,k3,k0,k2] with it set)
+				const bool f = (fl >> i) & 1u;
+				const float4 lo = make_float4(u.x, u.y, v.x, v.y), hi = make_float4(u.z, u.w, v.z, v.w);
+				ev.x = f ? hi.x : lo.x, ev.y = f ? hi.y : lo.y, ev.z = f ? hi.z : lo.z, ev.w = f ? hi.w : lo.w;
+				od.x = f ? lo.x : hi.x, od.y = f ? lo.y : hi.y, od.z = f ? lo.z : hi.z, od.w = f ? lo.w : hi.w;
+			}
+			*(float4 *)(base + (128 + 64 * i) * C2_P) = ev;
+			*(float4 *)(base + (128 + 64 * i) * C2_P + 4) = od;
+		}
+		if (s_sl == 0 && tid < 128)
+			qs[s_par * 128 + tid] = qv; // (read at the end of its tile; the tile two back was finished a barrier ago)
+		if (++s_sl == S)
+			s_sl = 0, s_par ^= 1;
+	};
+	f32x16c acc[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t)
+#pragma unroll
+		for (int r = 0; r < 16; ++r)
+			acc[t][r] = 0.f;
+	// the finished tile waiting to be stored: out[16 t + 4 g + e] = its distance for query row 32 t + 8 g + 4 h + e, centroid column ln
+	float out[64];
+	float *outp = D;       // D + (q0 + 4 h) * nlist + c of that tile
+	int qlim = 0;          // rows r = 32 t + 8 g + e with r < qlim are inside the matrix (0: the column is not, or nothing is pending)
+	bool pending = false, whole = false; // whole: every row and column of that tile is inside the matrix
+	// (fetch() is UNCONDITIONAL, also past the workgroup's last slab -- its addresses are clamped into the matrices anyway: behind a
+	// branch the loaded registers are merged with their old values, and the copies that merge needs wait for the loads on the spot)
+	fetch();
+	stage(0);
+	fetch();
+	__syncthreads();
+	int buf = 0, c_sl = 0, c_par = 0, c_tile = blockIdx.x; // the slab under the MFMAs
+	for (int it = 0; it < total; ++it, buf ^= 1) {
+#ifdef MVS_PROFILING
+		if (!(abl & 8)) // (8: MFMAs on whatever the first slab left in LDS)
+#endif
+		{
+			if (it + 1 < total)
+				stage(buf ^ 1); // (last read one slab ago: every wave has passed the barrier since)
+			fetch();
+		}
+		const float *xs = c2_lds + buf * 256 * C2_P + ln * C2_P + 4 * h, *ys = xs + (128 + 32 * wave) * C2_P;
+		// the operands of a block of 8 dims (four k-steps x four query blocks + the centroid block: five ds_read_b128), requested one
+		// block AHEAD of the 16 MFMAs that consume them
+		float4 a[2][4], b[2];
+#pragma unroll
+		for (int t = 0; t < 4; ++t)
+			a[0][t] = *(const float4 *)(xs + 32 * t * C2_P);
+		b[0] = *(const float4 *)ys;
+		const bool flush = pending; // (uniform)
+#pragma unroll
+		for (int g = 0; g < C2_K / 8; ++g) { // k ascending: every accumulator element is ONE k-ordered chain
+			if (g + 1 < C2_K / 8) {
+#pragma unroll
+				for (int t = 0; t < 4; ++t)
+					a[(g + 1) & 1][t] = *(const float4 *)(xs + 32 * t * C2_P + 8 * g + 8);
+				b[(g + 1) & 1] = *(const float4 *)(ys + 8 * g + 8);
+			}
+			__builtin_amdgcn_sched_barrier(0); // (left alone the scheduler sinks the requests behind the MFMAs they are meant to hide under)
+#ifdef MVS_PROFILING
+			if (abl & 2)
+				continue;
+#endif
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const float bv = j == 0 ? b[g & 1].x : j == 1 ? b[g & 1].y : j == 2 ? b[g & 1].z : b[g & 1].w;
+#pragma unroll
+				for (int t = 0; t < 4; ++t) {
+					const float4 av = a[g & 1][t];
+					acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(j == 0 ? av.x : j == 1 ? av.y : j == 2 ? av.z : av.w, bv, acc[t], 0, 0, 0);
+				}
+			}
+			if (flush) { // sixteen of the previous tile's 64 stores behind this block
+				if (whole) { // (uniform: the tile lies inside the matrix -- no test per store)
+#pragma unroll
+					for (int j = 0; j < 16; ++j) {
+						const int r = 16 * g + j, row = 32 * (r >> 4) + 8 * ((r >> 2) & 3) + (r & 3);
+						outp[(long long)row * nlist] = out[r];
+					}
+				} else {
+#pragma unroll
+					for (int j = 0; j < 16; ++j) {
+						const int r = 16 * g + j, row = 32 * (r >> 4) + 8 * ((r >> 2) & 3) + (r & 3);
+						if (row < qlim)
+							outp[(long long)row * nlist] = out[r];
+					}
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		pending = false;
+#ifdef MVS_PROFILING
+		if (abl & 32) // (32: no epilogue at all)
+			c_sl = -1000000;
+#endif
+		if (++c_sl == S) { // the tile is complete: its distances into out[], the accumulators cleared
+			const long long q0 = (long long)((unsigned)c_tile / (unsigned)ntx) * 128;
+			const int c0 = (int)((unsigned)c_tile % (unsigned)ntx) * 128, c = c0 + 32 * wave + ln;
+			const float cnv = (is_l2 && c < nlist) ? cn[c] : 0.f;
+			const float *qt = qs + c_par * 128;
+			c_sl = 0, c_par ^= 1, c_tile += gridDim.x;
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g)
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						const float ip = acc[t][4 * g + e];
+						float dis = fmaf(-2.0f, ip, qt[32 * t + 8 * g + 4 * h + e] + cnv);
+						dis = dis < 0.f ? 0.f : dis; // FAISS: if (dis < 0) dis = 0  (NaN stays NaN)
+						out[16 * t + 4 * g + e] = is_l2 ? dis : ip;
+					}
+#pragma unroll
+				for (int r = 0; r < 16; ++r)
+					acc[t][r] = 0.f;
+			}
+			const long long left = nq - q0 - 4 * h;
+			qlim = c < nlist ? (int)(left < 128 ? left : 128) : 0;
+			whole = q0 + 128 <= nq && c0 + 128 <= nlist;
+			outp = D + (q0 + 4 * h) * nlist + (c < nlist ? c : 0);
+#ifdef MVS_PROFILING
+			if ((abl & 1) && out[0] != 12345.678f) // (profiling library: no matrix written -- results are wrong)
+				qlim = 0;
+			if (abl & 4) // ... or every workgroup writes one and the same tile: the store instructions without their HBM traffic
+				outp = D + 4 * h * nlist + 32 * wave + ln;
+#endif
+			pending = true;
+		}
+#ifdef MVS_PROFILING
+		if (!(abl & 16)) // (16: no barrier between the slabs)
+#endif
+			__syncthreads();
+	}
+	if (pending) { // the workgroup's last tile
+#pragma unroll
+		for (int r = 0; r < 64; ++r) {
+			const int row = 32 * (r >> 4) + 8 * ((r >> 2) & 3) + (r & 3);
+			if (row < qlim)
+				outp[(long long)row * nlist] = out[r];
+		}
+	}
+}
+static size_t coarse_mfma2_lds_bytes() {
+	return ((size_t)2 * 256 * C2_P + 256) * sizeof(float);
+}
 static int device_cu_count() { // compute units of the current device (256 on MI355X)
 	static int cached[64];
 	int dev = 0;
@@ -508,7 +736,20 @@ void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_ce
 	if (nq <= 0)
 		return;
 	const dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
-	if (tune().coarse_mfma) {
+	if (tune().coarse_mfma >= 2 && (d & 3) == 0 && (sdp & 3) == 0) {
+		// (option ivf_coarse_mfma = 3: one workgroup per tile -- the same kernel without its store/MFMA overlap, for A/B)
+		const long long ntiles = (long long)grid.x * grid.y;
+		const unsigned wgs = (unsigned)std::min<long long>(ntiles, tune().coarse_mfma == 3 ? ntiles : (tune().coarse_abl & 64 ? 1 : 2) * device_cu_count());
+		if (interleaved) {
+			ensure_dynamic_lds((const void *)coarse_dist_mfma2_kernel<true>, coarse_mfma2_lds_bytes());
+			hipLaunchKernelGGL(coarse_dist_mfma2_kernel<true>, dim3(wgs), dim3(256), coarse_mfma2_lds_bytes(), st, d_x, (long long)nq, d,
+			                   d_cent, sdp, (int)nlist, d_qn, d_cn, is_l2, d_D, tune().coarse_abl);
+		} else {
+			ensure_dynamic_lds((const void *)coarse_dist_mfma2_kernel<false>, coarse_mfma2_lds_bytes());
+			hipLaunchKernelGGL(coarse_dist_mfma2_kernel<false>, dim3(wgs), dim3(256), coarse_mfma2_lds_bytes(), st, d_x, (long long)nq, d,
+			                   d_cent, sdp, (int)nlist, d_qn, d_cn, is_l2, d_D, tune().coarse_abl);
+		}
+	} else if (tune().coarse_mfma) {
 		ensure_dynamic_lds((const void *)coarse_dist_mfma_kernel, coarse_mfma_lds_bytes());
 		const long long ntiles = (long long)grid.x * grid.y;
 		hipLaunchKernelGGL(coarse_dist_mfma_kernel, dim3((unsigned)std::min<long long>(ntiles, tune().coarse_persistent ? 2 * device_cu_count() : ntiles)), dim3(256), coarse_mfma_lds_bytes(), st, d_x, (long long)nq, d, d_cent, sdp,

@@ -166,7 +166,7 @@ struct Tuning {
 	// csrc/coarse_select.hip
 	int coarse_persistent = 0; // option ivf_coarse_persistent (measured slower, see coarse_dist_mfma_kernel)
 	int coarse_abl = 0;        // (profiling library only, option coarse_abl: 1 = no matrix written, 2 = no MFMA loop -- results wrong)
-	int coarse_mfma = 1;       // option ivf_coarse_mfma: the distance matrix on the f32 matrix pipe (1) or on the vector ALU (0)
+	int coarse_mfma = 2;       // option ivf_coarse_mfma: the distance matrix on the f32 matrix pipe (2: round 5's staging, 1: round 4's) or on the vector ALU (0)
 	int coarse_select = 1;     // option ivf_coarse_select: 0 = the IVF coarse quantiser runs on the k-list kernels
 	// csrc/flat_bf16.hip
 	int pf_nsplit = 0;
