@@ -288,11 +288,11 @@ __global__ __launch_bounds__(256) void coarse_dist_mfma_kernel(const float *__re
 // eight at a time behind the MFMA groups of the NEXT tile's first slab.
 // Same instruction, same k order, same epilogue arithmetic: same bits.  d % 4 == 0 (16-byte query rows), else the kernel above.
 constexpr int C2_K = 32, C2_P = C2_K + 4;
-template <bool IL>
+template <bool IL, bool L2>
 __global__ __launch_bounds__(256, 2) void coarse_dist_mfma2_kernel(const float *__restrict__ x, long long nq, int d,
-                                                               const float *__restrict__ cent, int sdp, int nlist,
-                                                               const float *__restrict__ qn, const float *__restrict__ cn,
-                                                               int is_l2, float *__restrict__ D, int abl) {
+                                                                  const float *__restrict__ cent, int sdp, int nlist,
+                                                                  const float *__restrict__ qn, const float *__restrict__ cn,
+                                                                  float *__restrict__ D, int abl) {
 	extern __shared__ __attribute__((aligned(16))) float c2_lds[]; // [2][256][C2_P]: rows 0..127 queries, 128..255 centroids; qs[2][128]
 	float *qs = c2_lds + 2 * 256 * C2_P;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ln = lane & 31;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_mfma2_kernel(const float *
 			fl |= (IL && ((crow >> 4) & 1)) ? (1u << i) : 0u;
 		}
 		if (f_sl == 0 && tid < 128)
-			qv = (is_l2 && f_q0 + tid < nq) ? qn[f_q0 + tid] : 0.f;
+			qv = (L2 && f_q0 + tid < nq) ? qn[f_q0 + tid] : 0.f;
 		if (++f_sl == S) {
 			f_sl = 0;
 			f_tile += gridDim.x;
@@ -454,20 +454,22 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_mfma2_kernel(const float *
 		if (++c_sl == S) { // the tile is complete: its distances into out[], the accumulators cleared
 			const long long q0 = (long long)((unsigned)c_tile / (unsigned)ntx) * 128;
 			const int c0 = (int)((unsigned)c_tile % (unsigned)ntx) * 128, c = c0 + 32 * wave + ln;
-			const float cnv = (is_l2 && c < nlist) ? cn[c] : 0.f;
-			const float *qt = qs + c_par * 128;
+			const float cnv = (L2 && c < nlist) ? cn[c] : 0.f;
+			const float *qt = qs + c_par * 128 + 4 * h;
 			c_sl = 0, c_par ^= 1, c_tile += gridDim.x;
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {
 #pragma unroll
-				for (int g = 0; g < 4; ++g)
+				for (int g = 0; g < 4; ++g) {
+					const float4 q4 = *(const float4 *)(qt + 32 * t + 8 * g); // the norms of rows 32 t + 8 g + 4 h + 0 .. 3
 #pragma unroll
 					for (int e = 0; e < 4; ++e) {
 						const float ip = acc[t][4 * g + e];
-						float dis = fmaf(-2.0f, ip, qt[32 * t + 8 * g + 4 * h + e] + cnv);
+						float dis = fmaf(-2.0f, ip, (e == 0 ? q4.x : e == 1 ? q4.y : e == 2 ? q4.z : q4.w) + cnv);
 						dis = dis < 0.f ? 0.f : dis; // FAISS: if (dis < 0) dis = 0  (NaN stays NaN)
-						out[16 * t + 4 * g + e] = is_l2 ? dis : ip;
+						out[16 * t + 4 * g + e] = L2 ? dis : ip;
 					}
+				}
 #pragma unroll
 				for (int r = 0; r < 16; ++r)
 					acc[t][r] = 0.f;
@@ -740,15 +742,21 @@ void launch_coarse_select(const float *d_x, int64_t nq, int d, const float *d_ce
 		// (option ivf_coarse_mfma = 3: one workgroup per tile -- the same kernel without its store/MFMA overlap, for A/B)
 		const long long ntiles = (long long)grid.x * grid.y;
 		const unsigned wgs = (unsigned)std::min<long long>(ntiles, tune().coarse_mfma == 3 ? ntiles : (tune().coarse_abl & 64 ? 1 : 2) * device_cu_count());
-		if (interleaved) {
-			ensure_dynamic_lds((const void *)coarse_dist_mfma2_kernel<true>, coarse_mfma2_lds_bytes());
-			hipLaunchKernelGGL(coarse_dist_mfma2_kernel<true>, dim3(wgs), dim3(256), coarse_mfma2_lds_bytes(), st, d_x, (long long)nq, d,
-			                   d_cent, sdp, (int)nlist, d_qn, d_cn, is_l2, d_D, tune().coarse_abl);
-		} else {
-			ensure_dynamic_lds((const void *)coarse_dist_mfma2_kernel<false>, coarse_mfma2_lds_bytes());
-			hipLaunchKernelGGL(coarse_dist_mfma2_kernel<false>, dim3(wgs), dim3(256), coarse_mfma2_lds_bytes(), st, d_x, (long long)nq, d,
-			                   d_cent, sdp, (int)nlist, d_qn, d_cn, is_l2, d_D, tune().coarse_abl);
-		}
+#define MVS_CM2(ILV, L2V)                                                                                                          \
+	{                                                                                                                              \
+		ensure_dynamic_lds((const void *)coarse_dist_mfma2_kernel<ILV, L2V>, coarse_mfma2_lds_bytes());                            \
+		hipLaunchKernelGGL((coarse_dist_mfma2_kernel<ILV, L2V>), dim3(wgs), dim3(256), coarse_mfma2_lds_bytes(), st, d_x, (long long)nq, d, \
+		                   d_cent, sdp, (int)nlist, d_qn, d_cn, d_D, tune().coarse_abl);                                           \
+	}
+		if (interleaved && is_l2)
+			MVS_CM2(true, true)
+		else if (interleaved)
+			MVS_CM2(true, false)
+		else if (is_l2)
+			MVS_CM2(false, true)
+		else
+			MVS_CM2(false, false)
+#undef MVS_CM2
 	} else if (tune().coarse_mfma) {
 		ensure_dynamic_lds((const void *)coarse_dist_mfma_kernel, coarse_mfma_lds_bytes());
 		const long long ntiles = (long long)grid.x * grid.y;
