@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void coarse_dist_mfma_kernel(const float *__re
 // eight ds_write_b128 per thread instead of 32 transposing ds_write_b32; the operand reads (row ln, dim k + h) collide two ways on
 // 36-float rows, 40 ds_read2_b32 per slab against 64 MFMAs of 64 cycles: free), requested one group of eight MFMAs ahead.
 // (2) The other reason: every tile costs the same, so all workgroups of the chip reach their epilogue TOGETHER -- a 33 MB burst of
-// stores per round with the matrix pipe idle, then MFMAs with HBM idle (one workgroup per tile, (1) alone: 170 -> 153 us at C3).
+// stores per round with the matrix pipe idle, then MFMAs with HBM idle (one workgroup per tile, (1) alone: 170 -> 136 us at C3;
+// with (2): 123 .. 131; what is left and what was tried on top: profiles/r5_coarse_kernel.txt).
 // Persistent workgroups (two per CU, tile += gridDim.x; the (tile, slab) loop flattened so that the next tile's first slabs are
 // fetched and staged under the current tile's last MFMAs) keep a finished tile's 64 distances per lane in registers and store them
 // eight at a time behind the MFMA groups of the NEXT tile's first slab.
