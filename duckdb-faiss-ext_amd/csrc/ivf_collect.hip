@@ -1574,7 +1574,9 @@ __global__ __launch_bounds__(64) void ivf_bucket_exact_kernel(const unsigned *__
 			const float *y = yrows + lane * 132;
 			const bool flip = IL && ((cur >> 4) & 1);
 			float acc = 0.f;
-#pragma unroll
+			// (eight chunks per trip: fully unrolled, the ARITH = 2 instance hoists all 64 float4 of x and y -- 256 VGPRs + 20 AGPRs,
+			// ONE wave per SIMD where LDS allows two or three)
+#pragma unroll 8
 			for (int c4 = 0; c4 < 32; ++c4) {
 				const float4 xv = *(const float4 *)(xq + c4 * 4);
 				const float4 yv = *(const float4 *)(y + c4 * 4);
