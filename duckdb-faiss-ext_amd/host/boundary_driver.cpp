@@ -68,14 +68,21 @@ std::unique_ptr<IndexEntry> create(int d, const std::string &desc, faiss::Metric
 }
 
 // AddFunction :475-547 for one DataChunk
+// MVS_INGEST_PROFILE=1: the duration of every add call under the lock (where does an ingest's time go: the steady calls or the few
+// that grow the device buffers)
+static std::vector<double> g_add_us;
+static const bool g_add_profile = getenv("MVS_INGEST_PROFILE") != nullptr;
 void add_chunk(IndexEntry &entry, size_t n, const float *x, const faiss::idx_t *ids) {
 	if (!entry.needs_training) {
 		entry.faiss_lock->lock();
 		try {
+			const auto t0 = std::chrono::steady_clock::now();
 			if (entry.custom_labels)
 				entry.index->add_with_ids((faiss::idx_t)n, x, ids);
 			else
 				entry.index->add((faiss::idx_t)n, x);
+			if (g_add_profile)
+				g_add_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
 		} catch (faiss::FaissException exception) {
 			entry.faiss_lock->unlock();
 			std::string msg = exception.msg;
@@ -142,14 +149,17 @@ void faiss_add(IndexEntry &entry, size_t n, const float *x, const faiss::idx_t *
 	for (int t = 0; t < nthreads; ++t)
 		workers.emplace_back([&] {
 			try {
+				std::vector<float> chunk;
+				std::vector<faiss::idx_t> idc;
 				for (;;) {
 					size_t c = next++;
 					if (c >= nchunks)
 						break;
 					size_t r0 = c * STANDARD_VECTOR_SIZE, nr = std::min(STANDARD_VECTOR_SIZE, n - r0);
-					// the chunk lives in a buffer that is only valid during the call (DuckDB vector buffers)
-					std::vector<float> chunk(x + r0 * d, x + (r0 + nr) * d);
-					std::vector<faiss::idx_t> idc;
+					// the chunk lives in a buffer that is only valid during the call -- the worker's DataChunk, whose vector buffers
+					// DuckDB REUSES from chunk to chunk (a fresh 1 MB allocation per chunk costs a page-fault storm that an
+					// operator pipeline does not have: 8 threads of them slowed every add call from 39 to 60 us)
+					chunk.assign(x + r0 * d, x + (r0 + nr) * d);
 					if (ids)
 						idc.assign(ids + r0, ids + r0 + nr);
 					add_chunk(entry, nr, chunk.data(), ids ? idc.data() : nullptr);
@@ -355,6 +365,19 @@ int run_ingest(size_t n, int d, int threads, const char *desc = "IDMap,Flat") {
 	// add() returns while the last H2D copies are still in flight: a 1-query search drains the index's stream
 	(void)faiss_search(*e, 1, xb.data(), 1);
 	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (g_add_profile && !g_add_us.empty()) {
+		std::vector<double> v = g_add_us;
+		std::sort(v.begin(), v.end());
+		double tot = 0, slow = 0;
+		size_t nslow = 0;
+		for (double u : v) {
+			tot += u;
+			if (u > 500.0)
+				slow += u, ++nslow;
+		}
+		printf("ingestprofile\t%zu add calls: %.1f ms under the lock of %.1f ms; median %.1f us, p90 %.1f us; %zu calls over 500 us = %.1f ms\n",
+		       v.size(), tot / 1e3, sec * 1e3, v[v.size() / 2], v[v.size() * 9 / 10], nslow, slow / 1e3);
+	}
 	printf("ingestrate\t%.0f rows/s (%s: %zu rows x %d dims in %zu add calls of <= 2048 rows from %d threads: %.3f s, %.2f GB/s "
 	       "of row data)\n",
 	       (double)n / sec, desc, n, d, (n + 2047) / 2048, threads, sec, (double)n * d * 4 / sec / 1e9);
