@@ -112,55 +112,37 @@ __global__ void pack_queries_kernel(const float *__restrict__ x, long long nq, i
 // are 625 workgroups, not 157 on a 256-CU device -- and the chain loop unrolled so that its LDS reads are batched: the search
 // kernels wait for this one at the head of every step)
 __global__ __launch_bounds__(64) void query_norms_kernel(const float *__restrict__ x, long long nq, int d, float *__restrict__ out) {
-	// one wavefront = 64 rows: chunks of 128 columns through LDS with coalesced loads, all of a chunk's requests in flight at once,
-	// then every lane runs the k-ordered chain of ITS row (round 5: 16 rows per wave, 16 of 64 lanes chaining, 14 us at 10 000 x 128)
-	__shared__ float tile[64][129];
-	const long long q0 = (long long)blockIdx.x * 64;
+	__shared__ float tile[16][65];
+	const long long q0 = (long long)blockIdx.x * 16;
 	const int t = threadIdx.x;
 	float acc = 0.f;
-	for (int c0 = 0; c0 < d; c0 += 128) {
-		const int w = d - c0 < 128 ? d - c0 : 128;
-		if ((d & 3) == 0) { // 16-byte rows: two rows per instruction
-			const int col = 4 * (t & 31);
-			float4 v[32];
+	for (int c0 = 0; c0 < d; c0 += 64) {
+		const int w = d - c0 < 64 ? d - c0 : 64;
 #pragma unroll
-			for (int r = 0; r < 32; ++r) {
-				const long long q = q0 + 2 * r + (t >> 5);
-				const bool in = q < nq && col < w;
-				v[r] = *(const float4 *)(x + (in ? q : 0) * d + c0 + (in ? col : 0)); // (clamped: the requests are issued back to back)
-				if (!in)
-					v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-			}
-#pragma unroll
-			for (int r = 0; r < 32; ++r) {
-				float *o = &tile[2 * r + (t >> 5)][col];
-				o[0] = v[r].x, o[1] = v[r].y, o[2] = v[r].z, o[3] = v[r].w;
-			}
-		} else {
-			for (int r = 0; r < 64; ++r) {
-				const long long q = q0 + r;
-				tile[r][t] = (q < nq && t < w) ? x[q * d + c0 + t] : 0.f;
-				tile[r][64 + t] = (q < nq && 64 + t < w) ? x[q * d + c0 + 64 + t] : 0.f;
-			}
+		for (int r = 0; r < 16; ++r) {
+			const long long q = q0 + r;
+			tile[r][t] = (q < nq && t < w) ? x[q * d + c0 + t] : 0.f;
 		}
 		__syncthreads();
-		if (w == 128) {
-#pragma unroll 16
-			for (int i = 0; i < 128; ++i)
-				acc = fmaf(tile[t][i], tile[t][i], acc);
-		} else {
-			for (int i = 0; i < w; ++i)
-				acc = fmaf(tile[t][i], tile[t][i], acc);
+		if (t < 16) {
+			if (w == 64) {
+#pragma unroll
+				for (int i = 0; i < 64; ++i)
+					acc = fmaf(tile[t][i], tile[t][i], acc);
+			} else {
+				for (int i = 0; i < w; ++i)
+					acc = fmaf(tile[t][i], tile[t][i], acc);
+			}
 		}
 		__syncthreads();
 	}
-	if (q0 + t < nq)
+	if (t < 16 && q0 + t < nq)
 		out[q0 + t] = acc;
 }
 void launch_query_norms(const float *d_x, int64_t n, int d, float *d_out, hipStream_t st) {
 	if (n <= 0)
 		return;
-	hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_x, (long long)n, d, d_out);
+	hipLaunchKernelGGL(query_norms_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, st, d_x, (long long)n, d, d_out);
 	MVS_HIP(hipGetLastError());
 }
 void launch_pack_queries(const FlatGeom &g, const float *d_x, int64_t nq, float *d_qf, float *d_qnorm,
