@@ -112,22 +112,31 @@ __global__ void pack_queries_kernel(const float *__restrict__ x, long long nq, i
 // are 625 workgroups, not 157 on a 256-CU device -- and the chain loop unrolled so that its LDS reads are batched: the search
 // kernels wait for this one at the head of every step)
 __global__ __launch_bounds__(64) void query_norms_kernel(const float *__restrict__ x, long long nq, int d, float *__restrict__ out) {
-	__shared__ float tile[16][65];
+	// 16 rows per wavefront, 128 columns per pass: the 32 loads of a pass are in flight together (round 5; 64 columns per pass before:
+	// two load -> chain round trips at d = 128), then lanes 0..15 run the k-ordered chains of their rows
+	__shared__ float tile[16][129];
 	const long long q0 = (long long)blockIdx.x * 16;
 	const int t = threadIdx.x;
 	float acc = 0.f;
-	for (int c0 = 0; c0 < d; c0 += 64) {
-		const int w = d - c0 < 64 ? d - c0 : 64;
+	for (int c0 = 0; c0 < d; c0 += 128) {
+		const int w = d - c0 < 128 ? d - c0 : 128;
+		float v[32];
 #pragma unroll
 		for (int r = 0; r < 16; ++r) {
-			const long long q = q0 + r;
-			tile[r][t] = (q < nq && t < w) ? x[q * d + c0 + t] : 0.f;
+			const long long q = q0 + r < nq ? q0 + r : nq - 1; // (clamped: no branch between the requests; rows past the end are not written)
+			v[2 * r] = x[q * d + c0 + (t < w ? t : 0)];
+			v[2 * r + 1] = x[q * d + c0 + (64 + t < w ? 64 + t : 0)];
+		}
+#pragma unroll
+		for (int r = 0; r < 16; ++r) {
+			tile[r][t] = t < w ? v[2 * r] : 0.f;
+			tile[r][64 + t] = 64 + t < w ? v[2 * r + 1] : 0.f;
 		}
 		__syncthreads();
 		if (t < 16) {
-			if (w == 64) {
-#pragma unroll
-				for (int i = 0; i < 64; ++i)
+			if (w == 128) {
+#pragma unroll 16
+				for (int i = 0; i < 128; ++i)
 					acc = fmaf(tile[t][i], tile[t][i], acc);
 			} else {
 				for (int i = 0; i < w; ++i)
