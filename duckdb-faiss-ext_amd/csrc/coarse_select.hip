@@ -276,17 +276,18 @@ __global__ __launch_bounds__(256) void coarse_dist_mfma_kernel(const float *__re
 // Round 5: the same tile, restaged, and the matrix written UNDER the next tile's MFMAs.
 // (1) The ISA of the kernel above holds one reason its three parts ADD UP (staging 51 + MFMAs 95 + stores 30 = 176 us,
 // profiles/r4_coarse_kernel_ablation.txt): the eight loads of a slab sit behind branches with an s_waitcnt vmcnt(0) between them -- four
-// serial round trips per slab -- and each touches 32 cache lines for 16 bytes.  Here: EIGHT lanes per row (an instruction reads whole
-// 128-byte lines: rows r8 + 32 i, float4 chunk c16 of the slab), every load unconditional from a clamped address (zeroed by a select
-// when the slab is staged), issued back to back a whole slab ahead of its LDS write; the tile in LDS ROW-major ([256 rows][32 dims + 4]:
-// eight ds_write_b128 per thread instead of 32 transposing ds_write_b32; the operand reads (row ln, dim k + h) collide two ways on
-// 36-float rows, 40 ds_read2_b32 per slab against 64 MFMAs of 64 cycles: free), requested one group of eight MFMAs ahead.
+// serial round trips per slab -- and each touches 32 cache lines for 16 bytes.  Here: FOUR lanes per row and slab (32 bytes each, two
+// float4: an instruction reads 64 bytes of 16 rows' lines, its neighbour the other 64), every load unconditional from a clamped
+// address (zeroed by a select when a CUT slab is staged), issued back to back a whole slab ahead of its LDS write; the tile in LDS
+// ROW-major ([256 rows][32 dims + 4]) with every block of 8 dims de-interleaved ([k0 k2 k4 k6 | k1 k3 k5 k7]): eight ds_write_b128 per
+// thread instead of 32 transposing ds_write_b32, and lane (ln, h) of the MFMA loop reads the four k-steps of its half with ONE
+// conflict-free ds_read_b128 (20 per slab against 64 MFMAs of 64 cycles), requested one block of 16 MFMAs ahead.
 // (2) The other reason: every tile costs the same, so all workgroups of the chip reach their epilogue TOGETHER -- a 33 MB burst of
 // stores per round with the matrix pipe idle, then MFMAs with HBM idle (one workgroup per tile, (1) alone: 170 -> 136 us at C3;
 // with (2): 123 .. 131; what is left and what was tried on top: profiles/r5_coarse_kernel.txt).
 // Persistent workgroups (two per CU, tile += gridDim.x; the (tile, slab) loop flattened so that the next tile's first slabs are
 // fetched and staged under the current tile's last MFMAs) keep a finished tile's 64 distances per lane in registers and store them
-// eight at a time behind the MFMA groups of the NEXT tile's first slab.
+// sixteen at a time behind the MFMA blocks of the NEXT tile's first slab.
 // Same instruction, same k order, same epilogue arithmetic: same bits.  d % 4 == 0 (16-byte query rows), else the kernel above.
 constexpr int C2_K = 32, C2_P = C2_K + 4;
 template <bool IL, bool L2>
