@@ -103,6 +103,7 @@ void launch_row_norms(const float *d_vecs, int64_t n, int dp, float *d_norms, hi
 void launch_pad_rows(const float *d_src, int64_t n, int d, float *d_dst, int dp, hipStream_t st);
 // [n][d] row-major -> storage rows [n][dp] (zero padded; pair-interleaved if g says so); row0 = index of the first row
 void launch_pack_rows(const FlatGeom &g, const float *d_src, int64_t n, float *d_dst, int64_t row0, hipStream_t st);
+void launch_unpack_rows(const FlatGeom &g, const float *d_rows, int64_t row0, int64_t stride, int64_t n, float *d_dst, hipStream_t st);
 void launch_query_norms(const float *d_x, int64_t n, int d, float *d_out, hipStream_t st);
 
 FlatSearchPlan plan_flat_mfma(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
@@ -205,6 +206,7 @@ struct Tuning {
 };
 const Tuning &tune();                      // the calling thread's current tuning (the defaults when no index call is in progress)
 void set_current_tuning(const Tuning *t);
+void forget_current_tuning(const Tuning *t); // (an index is going away: the calling thread must not keep reading its knobs)
 
 // direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic
 struct DirectPlan {
@@ -229,6 +231,16 @@ struct TieFlags {
 	int *query;  // [nq]
 	float *val;  // [nq][k]   merged candidates in the pure order (score desc, row id asc)
 	int *row;    // [nq][k]
+};
+// Flat inner product behind the bucketed finish (round 6): the select kernel prints FAISS's order (score descending, equal scores in
+// descending row order) for the first kout of its kk = kout + 1 entries and records the boundary ties as merge_partials_kernel does
+struct IpFlatEmit {
+	TieFlags flags; // (count == nullptr: no tie detection)
+	int kout;
+	float *D;
+	long long *I;
+	const long long *idmap;
+	long long label_offset;
 };
 void launch_emit_sorted(const float *d_pd, const int32_t *d_pi, int64_t nq, int64_t k, int64_t kout, const int64_t *d_idmap,
                         int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);

@@ -88,6 +88,10 @@ public:
 	void use_device() const;
 	Tuning tune_;                                  // this index's tuning knobs (csrc/common.h); current for the thread after use_device()
 	bool set_tuning(const char *key, int64_t v); // the option keys that are tuning knobs (csrc/index.hip)
+	// a copy / shard set / shadow of an index keeps its knobs (they reverted to the defaults silently); wrappers pass it on
+	virtual void adopt_tuning(const Tuning &t) {
+		tune_ = t;
+	}
 
 	// faiss::Index virtuals the glue calls (src/faiss_extension.cpp:396,510,512,583,607,609,631)
 	virtual void train(int64_t n, const float *x);
@@ -107,10 +111,17 @@ public:
 	// rank, -1 padded (csrc/ivf_ties.hip EMIT mode)
 	virtual void tie_emit(const int *d_flag, int nf, const float *d_x, const float *d_T, int64_t k, const mvs_search_params *params,
 	                      const int64_t *d_idmap_sel, float *d_v, int64_t *d_id, int *d_p, hipStream_t st);
-	// an IVF index as the internal clustering of a Flat L2 index (csrc/ivf.hip flat_shadow_search); false: not run
-	virtual bool flat_shadow_search(int64_t, const float *, int64_t, const float *, float *, int64_t *, const int64_t *, int64_t,
-	                                const unsigned *, int *, int *, int, hipStream_t) {
-		return false;
+	// an IVF index as the internal clustering of a Flat L2 index (csrc/ivf.hip flat_shadow_search).  0: run; 1: this call's shape is
+	// not served (the caller takes its normal path for the batch, the shadow stays); 2: this DATA is not served (stream / bucket limits)
+	virtual int flat_shadow_search(int64_t, const float *, int64_t, const float *, float *, int64_t *, const int64_t *, int64_t,
+	                               const unsigned *, int *, int *, int, hipStream_t) {
+		return 1;
+	}
+	virtual int64_t flat_shadow_max_queries(int) { // queries one flat_shadow_search call takes (distance matrix, pair count)
+		return 0;
+	}
+	virtual size_t device_bytes() const { // HBM held by the index's row stores (approximate; mvs_index_shadow_stats)
+		return 0;
 	}
 	virtual void to_device(int new_device) = 0;
 	virtual IndexBase *clone(int on_device) = 0; // deep copy living on `on_device`
@@ -239,6 +250,8 @@ public:
 	int64_t *cl_out_I = nullptr;
 	const int64_t *cl_out_map = nullptr;
 	int64_t cl_out_off = 0;
+	const TieFlags *cl_out_flags = nullptr; // (inner product: the boundary-tie flags of the search, or null)
+	int cl_out_kout = 0;                    // (inner product: entries printed per query; the selection carries kk >= kout)
 	bool cl_emitted = false;     // collect_candidates wrote the final lists itself (the caller skips its emission)
 	int64_t cl_last_rescored = -1, cl_rescored_total = 0, cl_rescored_queries = 0, cl_admitted_in_fb = 0; // bucketed finish: survivors of the final-bound filter
 	bool cl_wrf_used = false;    // the last collect_candidates compacted the stream with the final-bound filter (wide stores)
@@ -258,6 +271,11 @@ public:
 	int shadow_mode = -1;      // option flat_shadow: -1 auto, 0 never, 1 from the first large search on
 	int shadow_nprobe = 32;    // option flat_shadow_nprobe
 	int64_t shadow_queries = 0, shadow_unproven = 0;
+	int64_t shadow_trained_rows = 0; // ntotal when the clustering was trained (re-trained once the index has doubled)
+	uint64_t mut_gen = 0, shadow_gen = 0; // generation of the rows (bumped by reset()) / the one the shadow was built from
+	double shadow_build_seconds = 0;      // time spent building / extending the shadow (inside searches), mvs_index_shadow_stats
+	int64_t shadow_builds = 0, shadow_extends = 0;
+	bool shadow_sync(hipStream_t st);
 	bool shadow_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                   const int64_t *d_idmap, const int64_t *out_map, int64_t out_off, hipStream_t st);
 	void drop_shadow();
@@ -313,6 +331,10 @@ public:
 
 	explicit IDMapIndex(IndexBase *sub);
 	~IDMapIndex() override;
+	void adopt_tuning(const Tuning &t) override {
+		tune_ = t;
+		sub->adopt_tuning(t);
+	}
 	void train(int64_t n, const float *x) override;
 	void add(int64_t n, const float *x) override;
 	void add_with_ids(int64_t n, const float *x, const int64_t *ids) override;
@@ -494,7 +516,8 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa = nullptr,
                               int64_t label_offset = 0, const unsigned *d_brow = nullptr, int rows_interleaved = 0,
                               const unsigned long long *d_units = nullptr, const unsigned *d_unit_cnt = nullptr,
-                              const int *d_kept_blk = nullptr, int nkept_blk = 0, unsigned long long *d_kept_out = nullptr);
+                              const int *d_kept_blk = nullptr, int nkept_blk = 0, unsigned long long *d_kept_out = nullptr,
+                              const IpFlatEmit *ipf = nullptr);
 size_t ivf_bucket_units_bytes(int64_t cap_entries);
 unsigned ivf_bucket_scatter_blocks(int64_t cap_entries);
 // final bound + the survivors into their queries' row buckets (csrc/ivf_collect.hip); launch_ivf_bucket_finish(..., d_brow) re-scores them

@@ -14,6 +14,7 @@
 #include <mutex>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -147,6 +148,7 @@ IndexBase::IndexBase(int kind_, int d_, int metric_) : kind(kind_), d(d_), metri
 	MVS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 }
 IndexBase::~IndexBase() {
+	forget_current_tuning(&tune_); // (the destroying thread's next launch read freed memory; other threads enter through use_device())
 	if (stream) {
 		(void)hipSetDevice(device);
 		(void)hipStreamSynchronize(stream);
@@ -463,9 +465,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	int grid = 0, nsplit = 0, lds = 0;
 	const bool few = !wide && nq <= 128 && collect_slot_stride(kf, collect_store_dims(d)) == 16 && ntotal < ((int64_t)1 << 31) && cl_small_path; // (one work item; at 256 queries: 1.92 vs 1.55 ms)
 	int64_t ncand = 0;
-	// the bucketed finish (see cl_fbucket in csrc/index.h): the common L2 shape only
-	const bool fb = cl_fbucket && !cl_fbucket_off && cl_out_D && metric == METRIC_L2 && !wide && !few && d == 128 && geom.dp == 128 && kk <= 64 &&
-	                nq * (int64_t)cl_fpitch < ((int64_t)1 << 31);
+	// the bucketed finish (see cl_fbucket in csrc/index.h): the common d = 128 shape; round 6: inner product too -- faiss_create's default
+	// metric (src/faiss_extension.cpp:105) gets the headline's pipeline, the select kernel prints FAISS's CMin-heap order and the tie flags
+	const bool fb = cl_fbucket && !cl_fbucket_off && cl_out_D && (metric == METRIC_L2 || metric == METRIC_IP) && !wide && !few && d == 128 &&
+	                geom.dp == 128 && kk <= 64 && nq * (int64_t)cl_fpitch < ((int64_t)1 << 31);
 	cl_emitted = false;
 	cl_wrf_used = false;
 	float *stream_s = nullptr, *fb_thr = nullptr;
@@ -600,6 +603,19 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 			memset(&fa, 0, sizeof fa);
 			if (!(has_sel || nq < 20))
 				fa.qn = (const float *)ws_qn.p, fa.yn = norms;
+			if (metric == METRIC_IP) { // the k-ordered chain either way (fvec_inner_product = the BLAS-branch oracle arithmetic)
+				IpFlatEmit ipf;
+				memset(&ipf, 0, sizeof ipf);
+				if (cl_out_flags)
+					ipf.flags = *cl_out_flags;
+				ipf.kout = cl_out_kout, ipf.D = cl_out_D, ipf.I = (long long *)cl_out_I;
+				ipf.idmap = (const long long *)cl_out_map, ipf.label_offset = cl_out_off;
+				launch_ivf_bucket_finish(METRIC_IP, nullptr, cap_entries, nullptr, fb_keys, bcount, cl_fpitch, nq, d_x, d, vecs, geom.dp, nullptr, kk,
+				                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+				                         (unsigned long long *)((char *)ws_seg.p + 192), nullptr, nullptr, nullptr, true, st, nullptr, 0, fb_rows,
+				                         geom.pair_interleaved ? 1 : 0, fb_units, (const unsigned *)cnt + 4, fb_kept,
+				                         (int)ivf_bucket_scatter_blocks(cap_entries), cnt + 1, &ipf);
+			} else
 			launch_ivf_bucket_finish(METRIC_L2, nullptr, cap_entries, nullptr, fb_keys, bcount, cl_fpitch, nq, d_x, d, vecs, geom.dp, nullptr, kk,
 			                         cl_out_D, cl_out_I, nullptr, cl_out_map, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
 			                         (unsigned long long *)((char *)ws_seg.p + 192), nullptr, nullptr, nullptr, true, st, &fa, cl_out_off, fb_rows,
@@ -678,7 +694,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 
 void FlatIndex::reset() {
 	ntotal = 0;
+	++mut_gen; // (rows change in place from here on: a shadow clustering of the old rows must not answer -- ADVICE r5)
 	drop_bf16_rows();
+	drop_shadow();
+	if (shadow_state == 1)
+		shadow_state = 0;
 }
 
 void FlatIndex::copy_rows_to_host(float *out) {
@@ -1065,10 +1085,12 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 			--cl_skip;
 		} else {
 			kp = (int)kk;
-			const bool direct = metric == METRIC_L2 && !flp && kk == k_user; // (collect_candidates may write the final lists itself)
+			// (collect_candidates may write the final lists itself: L2 as they are, inner product with the tie flags of this search)
+			const bool direct = (metric == METRIC_L2 && !flp && kk == k_user) || (metric == METRIC_IP && kk <= k_user + 1 && (flp || kk == k_user));
 			cl_out_D = direct ? d_D : nullptr, cl_out_I = direct ? d_I : nullptr, cl_out_map = out_map, cl_out_off = out_off;
+			cl_out_flags = flp, cl_out_kout = (int)k_user;
 			collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer, (int)kf);
-			cl_out_D = nullptr, cl_out_I = nullptr;
+			cl_out_D = nullptr, cl_out_I = nullptr, cl_out_flags = nullptr;
 			if (!collected) {
 				MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 				cl_skip_len = std::min(64, std::max(4, 2 * cl_skip_len));
@@ -1251,88 +1273,150 @@ void FlatIndex::drop_shadow() {
 	delete shadow;
 	shadow = nullptr;
 	shadow_rows = -1;
+	shadow_trained_rows = 0;
+	shadow_gen = 0;
+}
+// Build (or extend) the shadow from the rows WHERE THEY ARE (round 6; round 5 copied every row to the host, re-laid it out there, trained
+// and re-added from host memory inside the first large search, and dropped the whole clustering on every add()):
+//   * training sample: min(N, 256 nlist) rows at an even stride, unpacked on the device, ONE copy to the host for the k-means driver
+//     (csrc/ivf.hip kmeans keeps FAISS's host-side control flow); the sample has exactly the size FAISS would subsample to;
+//   * rows: unpacked in 1 M-row blocks on the device and appended through the IVF index's device add -- no host round trip;
+//   * rows added to the Flat index later are APPENDED (assign + append is the IVF add): the next large search extends the shadow by
+//     rows [shadow_rows, ntotal); the clustering is re-trained only after the index has doubled since it was trained;
+//   * reset() (and anything else that changes rows in place) bumps mut_gen: a shadow of another generation is dropped.
+bool FlatIndex::shadow_sync(hipStream_t st) {
+	if (shadow && (shadow_gen != mut_gen || shadow_rows > ntotal || ntotal > 2 * std::max<int64_t>(shadow_trained_rows, 1)))
+		drop_shadow();
+	if (shadow && shadow_rows == ntotal)
+		return true;
+	const auto t0 = std::chrono::steady_clock::now();
+	MVS_HIP(hipStreamSynchronize(st));
+	MVS_HIP(hipStreamSynchronize(stream)); // (adds of the host API)
+	const int64_t blk = (int64_t)1 << 20;
+	DevBuf rows;
+	bool built = false;
+	if (!shadow) {
+		int lg = 0;
+		while (((int64_t)1 << (2 * lg + 1)) < ntotal) // nlist = the power of two nearest to sqrt(N) (N = 10 M: 4 096)
+			++lg;
+		const int64_t nl = std::min<int64_t>(8192, std::max<int64_t>(256, (int64_t)1 << lg));
+		std::unique_ptr<IndexBase> iv(make_ivf_index(d, "IVF" + std::to_string(nl) + ",Flat", METRIC_L2));
+		if (!iv)
+			return false;
+		iv->adopt_tuning(tune_); // (the Flat index's knobs reach its shadow and the shadow's quantizer)
+		const int64_t ns = std::min<int64_t>(ntotal, nl * 256), stride = std::max<int64_t>(1, ntotal / ns);
+		rows.reserve((size_t)std::max(ns, std::min(blk, ntotal)) * d * sizeof(float));
+		launch_unpack_rows(geom, vecs, 0, stride, ns, (float *)rows.p, st);
+		std::vector<float> sample((size_t)ns * d);
+		MVS_HIP(hipMemcpyAsync(sample.data(), rows.p, sample.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		iv->train(ns, sample.data());
+		shadow = iv.release();
+		shadow_rows = 0;
+		shadow_trained_rows = ntotal;
+		shadow_gen = mut_gen;
+		shadow->set_timing(timing_enabled);
+		use_device();
+		built = true;
+	} else {
+		rows.reserve((size_t)std::min(blk, ntotal - shadow_rows) * d * sizeof(float));
+	}
+	for (int64_t r0 = shadow_rows; r0 < ntotal; r0 += blk) {
+		const int64_t n = std::min(blk, ntotal - r0);
+		launch_unpack_rows(geom, vecs, r0, 1, n, (float *)rows.p, st);
+		shadow->add_device(n, (const float *)rows.p, st); // (labels = row numbers: the shadow's ids continue where it stopped)
+		use_device();
+	}
+	MVS_HIP(hipStreamSynchronize(st)); // (`rows` is freed at scope exit)
+	shadow_rows = ntotal;
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	shadow_build_seconds += sec;
+	if (built)
+		++shadow_builds;
+	else
+		++shadow_extends;
+	return true;
 }
 bool FlatIndex::shadow_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
                               const int64_t *d_idmap, const int64_t *out_map, int64_t out_off, hipStream_t st) {
 	if (d % 32 != 0 || d > 128 || k > 32 || ntotal < 65536 || ntotal >= ((int64_t)1 << 31) || ntotal <= k)
 		return false;
-	if (shadow && shadow_rows != ntotal)
-		drop_shadow(); // (rows were added: rebuilt below)
-	if (!shadow) {
-		MVS_HIP(hipStreamSynchronize(st));
-		int lg = 0;
-		while (((int64_t)1 << (2 * lg + 1)) < ntotal) // nlist = the power of two nearest to sqrt(N) (N = 10 M: 4 096)
-			++lg;
-		const int64_t nl = std::min<int64_t>(8192, std::max<int64_t>(256, (int64_t)1 << lg));
-		std::vector<float> rows((size_t)ntotal * d);
-		copy_rows_to_host(rows.data());
-		std::unique_ptr<IndexBase> iv(make_ivf_index(d, "IVF" + std::to_string(nl) + ",Flat", METRIC_L2));
-		if (!iv)
-			return false;
-		iv->train(ntotal, rows.data());
-		for (int64_t r0 = 0; r0 < ntotal; r0 += (int64_t)1 << 20)
-			iv->add(std::min<int64_t>((int64_t)1 << 20, ntotal - r0), rows.data() + (size_t)r0 * d);
-		shadow = iv.release();
-		shadow_rows = ntotal;
-		shadow->set_timing(timing_enabled);
-		use_device();
-	}
+	if (!shadow_sync(st))
+		return false;
 	ensure_h1_rows(st); // (the proof needs the largest ||y||^2 of the rows: d_max_norm_bits[0], kept with the coarse filter's store)
 	ws_qn.reserve((size_t)nq * sizeof(float));
 	ws_fail.reserve(64 + (size_t)nq * sizeof(int));
 	int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
-	MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
 	launch_query_norms(d_x, nq, d, (float *)ws_qn.p, st);
-	if (!shadow->flat_shadow_search(nq, d_x, k, (const float *)ws_qn.p, d_D, d_I, out_map, out_off, d_max_norm_bits, fail_cnt, fail_q,
-	                                shadow_nprobe, st)) {
-		// (the candidate stream / a bucket beyond their limits -- rows stored thousands of times -- or a batch the coarse quantiser
-		// does not take: the shadow cannot serve this data; not asked again)
-		use_device();
-		shadow_state = -1;
-		drop_shadow();
-		return false;
-	}
-	use_device();
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
-	MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
-	MVS_HIP(hipStreamSynchronize(st));
-	const int nf = h_flag_count[8];
-	shadow_queries += nq;
-	shadow_unproven += nf;
-	kinfo = shadow->kinfo;
-	snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel (flat shadow)");
-	if ((int64_t)nf * 10 > nq) { // the lists of this data overlap: nothing is gained (uniform rows: every query) -- never again
-		shadow_state = -1;
-		drop_shadow();
+	// (a batch the coarse quantiser's distance matrix or the pair count does not cover is served in pieces -- round 5 gave
+	// the shadow up for good on the first such batch)
+	const int64_t cover = shadow->flat_shadow_max_queries(shadow_nprobe);
+	if (cover < 256)
 		return false;
-	}
-	pf_last_fallback = nf;
-	pf_queries_total += nq;
-	pf_fallback_total += nf;
-	if (nf > 0) { // the unproven queries: the Flat kernels decide (results overwrite theirs)
-		const mvs_kernel_info keep = kinfo;
-		const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
-		const size_t df_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
-		ws_fb.reserve(xf_bytes + df_bytes + (size_t)nf * k * sizeof(int64_t));
-		float *xf = (float *)ws_fb.p;
-		float *Df = (float *)((char *)ws_fb.p + xf_bytes);
-		int64_t *If = (int64_t *)((char *)Df + df_bytes);
-		launch_gather_query_rows(d_x, d, fail_q, nf, xf, st);
-		const int keep_state = shadow_state, keep_mode = shadow_mode;
-		shadow_state = 0, shadow_mode = 0; // (the re-run must not come back here)
-		const bool timing = timing_enabled;
-		timing_enabled = false;
-		try {
-			search_flat(nf, xf, k, Df, If, params, d_idmap, st);
-		} catch (...) {
-			shadow_state = keep_state, shadow_mode = keep_mode, timing_enabled = timing;
-			throw;
+	mvs_kernel_info kacc;
+	memset(&kacc, 0, sizeof kacc);
+	int nf_total = 0;
+	for (int64_t q0 = 0; q0 < nq; q0 += cover) {
+		const int64_t m = std::min(cover, nq - q0);
+		MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+		const int rc = shadow->flat_shadow_search(m, d_x + q0 * d, k, (const float *)ws_qn.p + q0, d_D + q0 * k, d_I + q0 * k, out_map, out_off,
+		                                          d_max_norm_bits, fail_cnt, fail_q, shadow_nprobe, st);
+		use_device();
+		if (rc != 0) {
+			// 1: this CALL's shape is not served (too few queries in the piece, ...): the batch takes the normal path, the shadow stays;
+			// 2: the candidate stream / a bucket beyond their limits -- rows stored thousands of times: the shadow cannot serve this data
+			if (rc == 2) {
+				shadow_state = -1;
+				drop_shadow();
+			}
+			return false;
 		}
-		shadow_state = keep_state, shadow_mode = keep_mode, timing_enabled = timing;
-		launch_scatter_rows(fail_q, nf, k, Df, If, d_D, d_I, st);
-		kinfo = keep;
+		MVS_HIP(hipMemcpyAsync(h_flag_count + 8, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		const int nf = h_flag_count[8];
+		shadow_queries += m;
+		shadow_unproven += nf;
+		nf_total += nf;
+		if (q0 == 0)
+			kacc = shadow->kinfo;
+		else
+			kacc.flops += shadow->kinfo.flops, kacc.bytes += shadow->kinfo.bytes;
+		if ((int64_t)nf * 10 > m) { // the lists of this data overlap: nothing is gained (uniform rows: every query) -- never again
+			shadow_state = -1;
+			drop_shadow();
+			return false;
+		}
+		if (nf > 0) { // the unproven queries: the Flat kernels decide (results overwrite theirs)
+			const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
+			const size_t df_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
+			ws_fb.reserve(xf_bytes + df_bytes + (size_t)nf * k * sizeof(int64_t));
+			float *xf = (float *)ws_fb.p;
+			float *Df = (float *)((char *)ws_fb.p + xf_bytes);
+			int64_t *If = (int64_t *)((char *)Df + df_bytes);
+			launch_gather_query_rows(d_x + q0 * d, d, fail_q, nf, xf, st);
+			const int keep_state = shadow_state, keep_mode = shadow_mode;
+			shadow_state = 0, shadow_mode = 0; // (the re-run must not come back here)
+			const bool timing = timing_enabled;
+			timing_enabled = false;
+			try {
+				search_flat(nf, xf, k, Df, If, params, d_idmap, st);
+			} catch (...) {
+				shadow_state = keep_state, shadow_mode = keep_mode, timing_enabled = timing;
+				throw;
+			}
+			shadow_state = keep_state, shadow_mode = keep_mode, timing_enabled = timing;
+			launch_scatter_rows(fail_q, nf, k, Df, If, d_D + q0 * k, d_I + q0 * k, st);
+			if (q0 + cover < nq)
+				MVS_HIP(hipStreamSynchronize(st)); // (ws_fb / the fail list are reused by the next piece)
+		}
 	}
+	kinfo = kacc;
+	snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel (flat shadow)");
+	pf_last_fallback = nf_total;
+	pf_queries_total += nq;
+	pf_fallback_total += nf_total;
 	return true;
 }
 
@@ -2034,6 +2118,7 @@ int mvs_index_clone_to_gpu(mvs_index **out, const mvs_index *src, int device) {
 	} else {
 		impl = src->impl->clone(device);
 	}
+	impl->adopt_tuning(src->impl->tune_);
 	auto *h = new mvs_index;
 	h->impl = impl;
 	h->owned = true;
@@ -2054,6 +2139,7 @@ int mvs_index_shard_to_gpus(mvs_index *ix, const int *devices, int ndev) {
 	HostIndex img;
 	ix->impl->to_host(img);
 	IndexBase *sharded = shard_from_host(img, std::vector<int>(devices, devices + ndev));
+	sharded->adopt_tuning(ix->impl->tune_);
 	if (ix->owned)
 		delete ix->impl;
 	ix->impl = sharded;
@@ -2096,6 +2182,23 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
 		*candidates = f->cl_candidates_total - (f->cl_admitted_in_fb - f->cl_rescored_total);
 	if (overflows)
 		*overflows = f->cl_overflows;
+	MVS_API_END
+}
+int mvs_index_shadow_stats(mvs_index *ix, int64_t *stats /* [8] */, double *build_seconds) {
+	MVS_API_BEGIN
+	IndexBase *p = sharded_inner_view(ix->impl);
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	if (p->kind != MVS_KIND_FLAT)
+		throw_faiss("mvs_index_shadow_stats", __FILE__, "not a Flat index");
+	auto *f = static_cast<FlatIndex *>(p);
+	if (stats) {
+		stats[0] = f->shadow_state, stats[1] = f->shadow ? f->shadow_rows : -1, stats[2] = f->shadow_queries, stats[3] = f->shadow_unproven;
+		stats[4] = f->shadow_builds, stats[5] = f->shadow_extends, stats[6] = f->shadow ? (int64_t)f->shadow->device_bytes() : 0;
+		stats[7] = f->shadow ? ivf_nlist_of(f->shadow) : 0;
+	}
+	if (build_seconds)
+		*build_seconds = f->shadow_build_seconds;
 	MVS_API_END
 }
 int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains, int64_t *admitted) {
@@ -2279,6 +2382,10 @@ const Tuning &tune() {
 }
 void set_current_tuning(const Tuning *t) {
 	t_tune = t;
+}
+void forget_current_tuning(const Tuning *t) {
+	if (t_tune == t)
+		t_tune = nullptr;
 }
 bool IndexBase::set_tuning(const char *key, int64_t v) {
 	struct Key {

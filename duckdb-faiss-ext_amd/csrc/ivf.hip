@@ -1696,6 +1696,10 @@ public:
 	void set_timing(bool on) override {
 		timing_enabled = on;
 	}
+	void adopt_tuning(const Tuning &t) override {
+		tune_ = t;
+		quantizer->adopt_tuning(t);
+	}
 	bool set_option(const char *key, int64_t v) override {
 		if (!strcmp(key, "ivf_collect")) {
 			collect_mode = (int)v;
@@ -1818,19 +1822,28 @@ public:
 	const ShadowCtx *shadow = nullptr;
 	DevBuf norms_csr; // ||y||^2 of every row by position in the list-sorted store (k-ordered chains: the Flat index's norms)
 	int64_t norms_csr_rows = -1;
-	bool flat_shadow_search(int64_t nq, const float *d_x, int64_t k, const float *d_qn, float *d_D, int64_t *d_I, const int64_t *d_out_map,
-	                        int64_t out_off, const unsigned *d_ymax_bits, int *d_fail_cnt, int *d_fail_q, int shadow_nprobe,
-	                        hipStream_t st) override {
+	int64_t flat_shadow_max_queries(int shadow_nprobe) override {
+		const int64_t np = std::min<int64_t>(std::max(shadow_nprobe, 1), nlist);
+		const int64_t by_pairs = (((int64_t)1 << 26) - 1) / np;
+		const int64_t by_matrix = std::max<int64_t>(64, ((int64_t)512 << 20) / (std::max<int64_t>(nlist, 1) * 4) / 64 * 64); // FlatIndex::coarse_matrix_covers
+		return std::min(by_pairs, by_matrix) / 64 * 64;
+	}
+	size_t device_bytes() const override {
+		return (size_t)cap * dp * sizeof(float) + codes.cap + codes_bfr.cap + beta_mf.cap + rowids.cap + norms_csr.cap;
+	}
+	int flat_shadow_search(int64_t nq, const float *d_x, int64_t k, const float *d_qn, float *d_D, int64_t *d_I, const int64_t *d_out_map,
+	                       int64_t out_off, const unsigned *d_ymax_bits, int *d_fail_cnt, int *d_fail_q, int shadow_nprobe,
+	                       hipStream_t st) override {
 		use_device();
 		if (metric != METRIC_L2 || hnsw_M != 0 || d != dp || k > 32 || nq < 20 || ntotal <= k)
-			return false;
+			return 1;
 		const int64_t np = std::min<int64_t>(shadow_nprobe, nlist);
 		if (nq * np >= ((int64_t)1 << 26))
-			return false;
+			return 1;
 		stream_wait(stream, st);
 		build_lists_mf(false);
 		if (!have_bfr)
-			return false;
+			return 2;
 		if (norms_csr_rows != nsorted) {
 			norms_csr.reserve((size_t)std::max<int64_t>(nsorted, 1) * sizeof(float));
 			launch_query_norms((const float *)codes.p, nsorted, d, (float *)norms_csr.p, stream);
@@ -1840,7 +1853,7 @@ public:
 		ws_cI.reserve((size_t)nq * np * sizeof(int64_t));
 		FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
 		if (!qz->coarse_topk(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, stream) || !qz->coarse_matrix_covers(nq))
-			return false;
+			return 1;
 		use_device();
 		ShadowCtx ctx;
 		ctx.qn = d_qn, ctx.out_map = d_out_map, ctx.out_off = out_off, ctx.ymax_bits = d_ymax_bits, ctx.fail_cnt = d_fail_cnt, ctx.fail_q = d_fail_q;
@@ -1854,7 +1867,7 @@ public:
 			throw;
 		}
 		shadow = nullptr;
-		return ok;
+		return ok ? 0 : 2;
 	}
 	// introspection for parity tests
 	void get_centroids(float *out) {

@@ -1238,6 +1238,7 @@ struct IvfBucketSelectArgs {
 	const int *kept_blk;          // (may be null) per-workgroup survivor counts of the scatter kernel, nkept_blk of them
 	int nkept_blk;
 	unsigned long long *kept_out; // ... their sum goes here (the query-0 wavefront adds them up)
+	IpFlatEmit ipf;               // (D != nullptr) the Flat index's inner-product output: see index.h
 };
 template <bool IS_L2>
 __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSelectArgs a) {
@@ -1278,7 +1279,39 @@ __global__ __launch_bounds__(64) void ivf_bucket_select_kernel(const IvfBucketSe
 	const bool hv = mine != CB_EMPTY;
 	const float val = hv ? bkey2f<IS_L2>((unsigned)(mine >> 32)) : neutral;
 	const int ps = hv ? (int)(unsigned)mine : -1;
-	if (lane < kk) {
+	if (a.ipf.D) { // Flat inner product (csrc/util_kernels.hip merge_partials_kernel<false>'s print rule and tie flags; entry j in lane j)
+		const int kout = a.ipf.kout;
+		fv[lane] = val;
+		fp[lane] = lane < kk ? ps : -1;
+		__syncthreads();
+		if (lane < kout) {
+			int src = lane;
+			if (fp[lane] >= 0) { // a run of equal scores is printed with the larger row first
+				int lo = lane, hi = lane;
+				while (lo > 0 && fp[lo - 1] >= 0 && fv[lo - 1] == val)
+					--lo;
+				while (hi + 1 < kout && fp[hi + 1] >= 0 && fv[hi + 1] == val)
+					++hi;
+				src = lo + (hi - lane);
+			}
+			const int id = fp[src];
+			a.ipf.D[q * kout + lane] = fv[src];
+			a.ipf.I[q * kout + lane] = id < 0 ? -1ll : (a.ipf.idmap ? a.ipf.idmap[id] : (long long)id + a.ipf.label_offset);
+		}
+		if (a.ipf.flags.count && kout < kk && fp[kout] >= 0 && fv[kout] == fv[kout - 1]) {
+			int slot = 0;
+			if (lane == 0) {
+				slot = atomicAdd(a.ipf.flags.count, 1);
+				a.ipf.flags.query[slot] = (int)q;
+			}
+			slot = __shfl(slot, 0);
+			if (lane < kk) {
+				a.ipf.flags.val[(size_t)slot * kk + lane] = fv[lane];
+				a.ipf.flags.row[(size_t)slot * kk + lane] = fp[lane];
+			}
+		}
+	}
+	if (a.pd && lane < kk) {
 		a.pd[q * kk + lane] = val;
 		long long lab = ps;
 		if (ps >= 0) {
@@ -1636,7 +1669,8 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
                               const int64_t *d_fin_rowids, const int64_t *d_fin_idmap, int *d_flag, unsigned long long *d_stats,
                               int *d_qfail, int *d_fail_cnt, int *d_fail_q, bool reset, hipStream_t st, const IvfFlatArith *fa,
                               int64_t label_offset, const unsigned *d_brow, int rows_interleaved, const unsigned long long *d_units,
-                              const unsigned *d_unit_cnt, const int *d_kept_blk, int nkept_blk, unsigned long long *d_kept_out) {
+                              const unsigned *d_unit_cnt, const int *d_kept_blk, int nkept_blk, unsigned long long *d_kept_out,
+                              const IpFlatEmit *ipf) {
 	if (nq <= 0)
 		return;
 	if (dp_csr % 4 != 0 || dp_csr > 128 || kk > 64 || kk < 1)
@@ -1687,6 +1721,8 @@ void launch_ivf_bucket_finish(int metric, const unsigned long long *d_strm, int6
 	a.flag_cnt = d_flag, a.flag_q = d_flag ? d_flag + 1 : nullptr, a.stats = d_stats;
 	a.qfail = d_qfail, a.fail_cnt = d_fail_cnt, a.fail_q = d_fail_q, a.reset = reset ? 1 : 0;
 	a.kept_blk = d_kept_blk, a.nkept_blk = nkept_blk, a.kept_out = d_kept_out;
+	if (ipf)
+		a.ipf = *ipf;
 	if (l2 || fa)
 		hipLaunchKernelGGL(ivf_bucket_select_kernel<true>, dim3((unsigned)nq), dim3(64), 0, st, a);
 	else

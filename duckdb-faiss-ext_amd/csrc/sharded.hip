@@ -1104,6 +1104,11 @@ public:
 	void set_label_offset(int64_t off) override {
 		label_offset = off;
 	}
+	void adopt_tuning(const Tuning &t) override {
+		tune_ = t;
+		for (IndexBase *sh : shards)
+			sh->adopt_tuning(t);
+	}
 	bool set_option(const char *key, int64_t v) override {
 		if (!strcmp(key, "shard_exchange")) { // 0 = host gather, 1 = rccl all-gather
 			exchange = (int)v;

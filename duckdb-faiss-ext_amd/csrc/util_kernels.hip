@@ -82,6 +82,32 @@ void launch_pack_rows(const FlatGeom &g, const float *d_src, int64_t n, float *d
 	MVS_HIP(hipGetLastError());
 }
 
+// the inverse: storage rows row0 + i * stride (i < n) -> plain [n][d] rows (the shadow clustering of a Flat index is built and extended
+// from the rows where they are, csrc/index.hip FlatIndex::shadow_search)
+__global__ void unpack_rows_kernel(const float *__restrict__ src, int dp, int interleave, long long row0, long long stride, long long n, int d,
+                                   float *__restrict__ dst) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * d)
+		return;
+	const long long j = i / d, r = row0 + j * stride;
+	const int k = (int)(i - j * d);
+	int sk = k;
+	if (interleave) { // stored [k0,k2,k1,k3] (bit 4 of r clear) or [k1,k3,k0,k2]
+		const int e = k & 3;
+		const int pos = ((r >> 4) & 1) ? (e == 0 ? 2 : e == 1 ? 0 : e == 2 ? 3 : 1) : (e == 0 ? 0 : e == 1 ? 2 : e == 2 ? 1 : 3);
+		sk = (k & ~3) + pos;
+	}
+	dst[i] = src[r * dp + sk];
+}
+void launch_unpack_rows(const FlatGeom &g, const float *d_rows, int64_t row0, int64_t stride, int64_t n, float *d_dst, hipStream_t st) {
+	if (n <= 0)
+		return;
+	const long long total = (long long)n * g.d;
+	hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_rows, g.dp, g.pair_interleaved ? 1 : 0,
+	                   (long long)row0, (long long)stride, (long long)n, g.d, d_dst);
+	MVS_HIP(hipGetLastError());
+}
+
 // ---- query packing: [nq][d] -> MFMA B-fragment order + norms -----------------------------------------
 // qf[(((qblk32*nch + ch)*(KSTEPS/4) + s4)*64 + lane)*4 + e] = x[qblk32*32 + (lane&31)][ch*kc + 2*(4*s4+e) + (lane>>5)]
 __global__ void pack_queries_kernel(const float *__restrict__ x, long long nq, int d, int kc, int nch,

@@ -121,6 +121,7 @@ _L.mvs_index_clone_to_gpu.argtypes = [C.POINTER(_p), _p, C.c_int]
 _L.mvs_index_prefilter_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_float), C.POINTER(C.c_float)]
 _L.mvs_index_collect_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_index_ivf_probe_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
+_L.mvs_index_shadow_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(C.c_double)]
 _L.mvs_index_shard_to_gpus.argtypes = [_p, C.POINTER(C.c_int), C.c_int]
 _L.mvs_index_shard_info.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_write_index.argtypes = [_p, C.c_char_p]
@@ -150,7 +151,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_get_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_walk_stats", "mvs_index_hnsw_get_graph",
     "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
-    "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_ivf_probe_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
+    "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_ivf_probe_stats", "mvs_index_shadow_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
     "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_index_ivf_tie_emit_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_debug_mfma_bf16_16x16x32", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
@@ -317,6 +318,15 @@ class Index:
         a, b, c, e = _i64(0), _i64(0), _i64(0), _i64(0)
         _check(_L.mvs_index_ivf_probe_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(e)))
         return {"pairs": a.value, "scanned": b.value, "forced_drains": c.value, "admitted": e.value}
+
+    def shadow_stats(self):
+        """Flat L2: the shadow clustering's state, size and cost -- include/mi355_faiss.h mvs_index_shadow_stats"""
+        st, sec = (_i64 * 8)(), C.c_double(0)
+        _check(_L.mvs_index_shadow_stats(self._h, st, C.byref(sec)))
+        keys = ("state", "rows", "queries", "unproven", "builds", "extends", "device_bytes", "nlist")
+        out = {k: int(v) for k, v in zip(keys, st)}
+        out["build_seconds"] = sec.value
+        return out
 
     def collect_stats(self):
         q, c, o = _i64(0), _i64(0), _i64(0)

@@ -233,6 +233,12 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
  * admitted: candidates the scan of the last search admitted under its running bounds; mvs_index_collect_stats counts those that
  * also passed the bound the scan ended with and were re-scored exactly (option ivf_cl_refilter). */
 int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scanned, int64_t *forced_drains, int64_t *admitted);
+/* Flat L2 index, diagnostics of its shadow clustering (rows that cluster are answered through an internal IVF index of the same rows
+ * with a per-query exactness proof, csrc/index.hip FlatIndex::shadow_search -- results are those of faiss::IndexFlat::search,
+ * src/faiss_extension.cpp:631).  stats[8] = {state (0 not wanted, 1 in use, -1 given up on this data), rows the shadow holds (-1: none),
+ * queries answered through it, of those re-run on the Flat kernels (unproven), builds (k-means), extensions (rows appended after
+ * add()), device bytes the shadow holds, its nlist}; build_seconds = time spent building / extending it inside search calls. */
+int mvs_index_shadow_stats(mvs_index *ix, int64_t *stats, double *build_seconds);
 int mvs_device_count(void);
 const char *mvs_version(void);
 

@@ -81,3 +81,62 @@ def test_rows_that_do_not_cluster_give_the_shadow_up_and_stay_exact(mf, kind):
         assert "flat shadow" not in name, name
     else:
         assert "flat shadow" in name, name
+
+
+def test_shadow_is_extended_by_add_instead_of_rebuilt(mf):
+    """round 6: rows added after the shadow was built are APPENDED to it at the next large search (one
+    k-means per index, not per add/search cycle); the answers stay the Flat index's bit for bit; the stats say what happened."""
+    import torch
+
+    d, n0, step, nq, k = 128, 1_048_576, 65_536, 1024, 10
+    dev = torch.device("cuda", 0)
+    ix = mf.index_factory(d, "Flat", L2)
+    ix.set_option("flat_shadow", 1)  # from the first large search on
+    xb = mf.synth_clustered_torch(n0 + 3 * step, d, 1234, row0=0, n_centers=1024, sigma=0.1, device=dev)
+    xq = mf.synth_clustered_torch(nq, d, 4321, row0=0, n_centers=1024, sigma=0.1, device=dev)
+    ix.add_torch(xb[:n0])
+    ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    st = ix.shadow_stats()
+    assert st["state"] >= 0 and st["rows"] == n0 and st["builds"] == 1 and st["extends"] == 0 and st["device_bytes"] > n0 * d * 2, st
+    assert st["build_seconds"] > 0
+    for i in range(3):  # DuckDB: insert, then query
+        ix.add_torch(xb[n0 + i * step : n0 + (i + 1) * step])
+        D, I = ix.search_torch(xq, k)
+        torch.cuda.synchronize()
+        assert "flat shadow" in ix.last_kernel_info()["name"], ix.last_kernel_info()
+        st = ix.shadow_stats()
+        assert st["builds"] == 1 and st["extends"] == i + 1 and st["rows"] == n0 + (i + 1) * step, st
+    assert int(I.max()) >= n0, "rows added after the build must be found"
+    ix.set_option("prefilter", 0)
+    ix.set_option("flat_shadow", 0)
+    De, Ie = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"].startswith("flat_mfma")
+    assert torch.equal(Ie, I) and torch.equal(De.view(torch.int32), D.view(torch.int32))
+
+
+def test_a_batch_beyond_the_coarse_matrix_is_served_in_pieces_and_keeps_the_shadow(mf):
+    """one batch the coarse quantiser's distance matrix does not cover used to drop a just-built shadow for good."""
+    import torch
+
+    d, n, k = 64, 262_144, 10
+    dev = torch.device("cuda", 0)
+    ix = mf.index_factory(d, "Flat", L2)
+    ix.set_option("flat_shadow", 1)
+    ix.set_option("flat_shadow_nprobe", 64)
+    xb = mf.synth_clustered_torch(n, d, 77, row0=0, n_centers=512, sigma=0.1, device=dev)
+    ix.add_torch(xb)
+    nq = 262_144 + 5_000  # nlist 512: the 512 MB distance matrix covers 262 144 queries -> two pieces
+    xq = mf.synth_clustered_torch(nq, d, 78, row0=0, n_centers=512, sigma=0.1, device=dev)
+    D, I = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    assert "flat shadow" in ix.last_kernel_info()["name"], ix.last_kernel_info()
+    st = ix.shadow_stats()
+    assert st["state"] >= 0 and st["rows"] == n and st["queries"] == nq, st
+    ix.set_option("prefilter", 0)
+    ix.set_option("flat_shadow", 0)
+    for q0 in (0, 262_144 - 512, nq - 1024):
+        De, Ie = ix.search_torch(xq[q0 : q0 + 1024].contiguous(), k)
+        torch.cuda.synchronize()
+        assert torch.equal(Ie, I[q0 : q0 + 1024]) and torch.equal(De.view(torch.int32), D[q0 : q0 + 1024].view(torch.int32))
