@@ -169,6 +169,7 @@ struct Tuning {
 	int coarse_abl = 0;        // (profiling library only, option coarse_abl: 1 = no matrix written, 2 = no MFMA loop -- results wrong)
 	int coarse_mfma = 2;       // option ivf_coarse_mfma: the distance matrix on the f32 matrix pipe (2: round 5's staging, 1: round 4's) or on the vector ALU (0)
 	int coarse_select = 1;     // option ivf_coarse_select: 0 = the IVF coarse quantiser runs on the k-list kernels
+	int coarse_bf16 = 1;       // option ivf_coarse_bf16: L2 coarse quantiser as a bf16 filter + exact re-scoring, no distance matrix (csrc/coarse_bf16.hip; 0: round 5's matrix + selection)
 	// csrc/flat_bf16.hip
 	int pf_nsplit = 0;
 	int pf_sched = 0;     // option pf_sched (see the kernel)
@@ -207,6 +208,22 @@ struct Tuning {
 const Tuning &tune();                      // the calling thread's current tuning (the defaults when no index call is in progress)
 void set_current_tuning(const Tuning *t);
 void forget_current_tuning(const Tuning *t); // (an index is going away: the calling thread must not keep reading its knobs)
+
+// ---- roctx ranges (round 6; SURVEY 5 "tracing"): stage / search / exchange / merge show up as named ranges in a
+// rocprofv3 --marker-trace run.  The roctx library is bound at run time and only when asked for (env MVS_ROCTX=1) or when a
+// rocprofiler tool is attached to the process; otherwise a TraceRange is two predictable branches.
+void trace_push(const char *name);
+void trace_pop();
+struct TraceRange {
+	explicit TraceRange(const char *name) {
+		trace_push(name);
+	}
+	~TraceRange() {
+		trace_pop();
+	}
+	TraceRange(const TraceRange &) = delete;
+	TraceRange &operator=(const TraceRange &) = delete;
+};
 
 // direct (per-pair) path: nq < 20 or selector present -- FAISS exhaustive_*_seq arithmetic
 struct DirectPlan {

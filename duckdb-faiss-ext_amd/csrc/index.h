@@ -34,6 +34,7 @@ struct PinnedRing {
 	int next = 0;
 	int acquire(size_t bytes);
 	void release(int slot, hipStream_t st);
+	void drop_events();
 	~PinnedRing();
 };
 
@@ -211,6 +212,10 @@ public:
 	int64_t cl_cap_hint = 0;         // entries per query the last overflow asked for (the next search starts there)
 	const unsigned long long *cl_sorted = nullptr;  // the re-scored candidate list of the last coarse-filter batch (in ws_stream)
 	const unsigned long long *tie_sorted = nullptr; // != nullptr: resolve_ip_ties reads A_k off that list instead of scanning again
+	const unsigned long long *tie_bucket = nullptr; // ... or off the bucketed finish's per-query key buckets (round 6)
+	const unsigned long long *cl_fb_keys = nullptr; // (the key buckets of the last inner-product bucketed finish)
+	const unsigned *tie_bcount = nullptr;
+	int tie_bpitch = 0;
 	bool tie_from_candidates = true; // option tie_from_candidates = 0: inner-product ties re-scan the database (A/B, tests)
 	bool cl_k32 = true;       // 16 < k <= 32 at d <= 128 on the coarse filter with 32 row classes (option cl_k32; 0: bf16x3 / f32 as before)
 	bool cl_small_path = true; // batches of <= 256 queries on the one-wavefront-per-segment kernel (option cl_small_path)
@@ -219,7 +224,12 @@ public:
 	void ensure_h1_rows(hipStream_t st);
 	// IVF coarse quantisation: the np nearest rows (L2, FAISS order) by distance matrix + selection (csrc/coarse_select.hip);
 	// false: shape not served, the caller uses search_device
-	bool coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st);
+	// need_matrix: the caller reads coarse_matrix() afterwards (the Flat shadow's proof); otherwise L2 quantisers of 16 < d <= 128 take the
+	// bf16 filter + exact re-scoring of csrc/coarse_bf16.hip (round 6: no distance matrix at all, same output bit for bit)
+	bool coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st, bool need_matrix = true);
+	DevBuf ws_cb16;
+	int64_t cb16_queries = 0; // queries served by csrc/coarse_bf16.hip (diagnostics)
+	size_t cb16_stats_off = 0; // byte offset of the exhaustive-query counter in ws_cb16
 	// what the last coarse_topk left behind (csrc/ivf.hip flat_shadow_search): the [nq][ntotal] distance matrix -- whole only when
 	// the batch fitted one chunk --, and the rows' squared norms
 	const float *coarse_matrix() const {
@@ -321,6 +331,21 @@ public:
 	hipStream_t last_search_stream = nullptr;
 	bool have_last_search = false;
 	void grow(int64_t need, hipStream_t st);
+	// ---- ingest staging (round 6): DataChunk-sized adds are collected in a pinned slot and sent to the device once per slot ----
+	PinnedRing add_ring;
+	int pend_slot = -1, add_flip = 0;
+	size_t pend_bytes = 0;
+	int64_t pend_rows = 0, pend_row0 = 0; // rows of ntotal that are staged, not yet on the device / the first of them
+	bool lazy_adds = true;                // option lazy_adds = 0: every add() goes to the device at once (round 5)
+	int64_t add_flushes = 0;
+	bool flush_adds();                    // true: rows were sent (on `stream`)
+	struct Retired {
+		void *a, *b;
+		hipEvent_t done;
+	};
+	std::vector<Retired> retired; // row stores replaced by a growth: freed once the copy out of them has finished
+	void retire_buffers(hipStream_t st, void *a, void *b);
+	void reap_retired(bool wait);
 };
 
 class IDMapIndex : public IndexBase {
@@ -328,6 +353,11 @@ public:
 	IndexBase *sub; // owned
 	int64_t *ids = nullptr;
 	int64_t idcap = 0;
+	PinnedRing id_ring; // (round 6) the ids of DataChunk-sized adds are staged like their rows
+	int idp_slot = -1;
+	size_t idp_bytes = 0;
+	int64_t idp_row0 = 0;
+	void flush_ids();
 
 	explicit IDMapIndex(IndexBase *sub);
 	~IDMapIndex() override;
@@ -470,6 +500,8 @@ void launch_collect_rescore(int metric, unsigned long long *d_stream, unsigned l
                             size_t temp_bytes, int64_t nq, int kk, const float *d_x, const FlatGeom &g, const float *d_vecs,
                             const float *d_norms, const float *d_qn, int *d_seg, float *d_pd1, int32_t *d_pi1,
                             bool per_pair, hipStream_t st, const unsigned long long *d_cnt = nullptr, bool seg_zeroed = false);
+void launch_collect_tie_rows_bucket(const unsigned long long *d_bucket, const unsigned *d_bcount, int pitch, const int *d_flag_query,
+                                    const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st);
 void launch_collect_tie_rows(const unsigned long long *d_sorted, const int *d_seg, int64_t nq, const int *d_flag_query,
                              const float *d_T, int nf, int k, int64_t *d_first, hipStream_t st);
 bool coarse_select_supported(int64_t nlist, int64_t np);
@@ -505,6 +537,13 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
                              hipStream_t st, float *d_stream_u = nullptr);
 // final-bound filter between the scan and the exact stage (csrc/ivf_collect.hip): entries whose s + E is below the bound the scan ended with are dropped
+// csrc/coarse_bf16.hip: the coarse quantiser as a bf16 filter + exact re-scoring inside one workgroup per 32 queries
+bool coarse_bf16_supported(int d, int64_t nlist, int64_t np);
+size_t coarse_bf16_cand_bytes(int64_t nq);
+void launch_coarse_bf16(const float *d_x, int64_t nq, int d, const void *d_qf, const float *d_qn, const float *d_e2, const unsigned short *d_yb,
+                        const float *d_beta, const float *d_cent, int sdp, int interleaved, const float *d_cn, int64_t nlist, int64_t np,
+                        unsigned short *d_cand, int *d_ccount, float *d_outD, int64_t *d_outI, int64_t label_offset,
+                        unsigned long long *d_stats, hipStream_t st);
 void launch_ivf_refilter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
                          const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned long long *d_out,
                          unsigned long long *d_out_cnt, hipStream_t st);

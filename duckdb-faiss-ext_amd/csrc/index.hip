@@ -14,6 +14,7 @@
 #include <mutex>
 
 #include <algorithm>
+#include <dlfcn.h>
 #include <chrono>
 #include <cstdarg>
 #include <cstdlib>
@@ -62,11 +63,23 @@ PinnedRing::~PinnedRing() {
 			(void)hipEventDestroy(ev[i]);
 	}
 }
+void PinnedRing::drop_events() { // (the owner moves to another device: events are created again, there, by the next acquire)
+	for (int i = 0; i < NB; ++i)
+		if (ev[i]) {
+			(void)hipEventSynchronize(ev[i]);
+			(void)hipEventDestroy(ev[i]);
+			ev[i] = nullptr;
+		}
+}
 // The staging copy of add(): pageable rows -> a pinned slot that only the copy engine reads afterwards.  Non-temporal stores skip
 // the read-for-ownership of the destination lines (tools/micro/h2d_chunks.cpp on the GPU box, 1 MB chunks: 23.9 us against memcpy's
 // 35.5; with the hipMemcpyAsync behind it 30.0 against 26.4 GB/s).  dst is 16-byte aligned (slots are page aligned), src need not be.
 static void stage_copy(void *dst, const void *src, size_t bytes) {
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+	if ((uintptr_t)dst & 15) { // (chunks of rows whose size is no multiple of 16 bytes follow each other unaligned: plain copy)
+		memcpy(dst, src, bytes);
+		return;
+	}
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	const size_t n16 = bytes / 16;
 	const char *s = (const char *)src;
@@ -293,6 +306,7 @@ FlatIndex::~FlatIndex() {
 	(void)hipSetDevice(device);
 	if (stream)
 		(void)hipStreamSynchronize(stream);
+	reap_retired(true);
 	if (vecs)
 		(void)hipFree(vecs);
 	if (norms)
@@ -610,9 +624,12 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 					ipf.flags = *cl_out_flags;
 				ipf.kout = cl_out_kout, ipf.D = cl_out_D, ipf.I = (long long *)cl_out_I;
 				ipf.idmap = (const long long *)cl_out_map, ipf.label_offset = cl_out_off;
+				// (reset = false: the per-query counts stay for the tie pass -- FlatIndex::resolve_ip_ties reads A_k off the buckets; the
+				// next search's preparation zeroes them)
+				cl_fb_keys = fb_keys, tie_bcount = bcount, tie_bpitch = cl_fpitch;
 				launch_ivf_bucket_finish(METRIC_IP, nullptr, cap_entries, nullptr, fb_keys, bcount, cl_fpitch, nq, d_x, d, vecs, geom.dp, nullptr, kk,
 				                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-				                         (unsigned long long *)((char *)ws_seg.p + 192), nullptr, nullptr, nullptr, true, st, nullptr, 0, fb_rows,
+				                         (unsigned long long *)((char *)ws_seg.p + 192), nullptr, nullptr, nullptr, false, st, nullptr, 0, fb_rows,
 				                         geom.pair_interleaved ? 1 : 0, fb_units, (const unsigned *)cnt + 4, fb_kept,
 				                         (int)ivf_bucket_scatter_blocks(cap_entries), cnt + 1, &ipf);
 			} else
@@ -693,6 +710,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 }
 
 void FlatIndex::reset() {
+	if (pend_slot >= 0) { // (staged rows die with the index's contents: the slot goes back to the ring unused)
+		pend_rows = 0;
+		flush_adds();
+	}
 	ntotal = 0;
 	++mut_gen; // (rows change in place from here on: a shadow clustering of the old rows must not answer -- ADVICE r5)
 	drop_bf16_rows();
@@ -703,6 +724,7 @@ void FlatIndex::reset() {
 
 void FlatIndex::copy_rows_to_host(float *out) {
 	use_device();
+	flush_adds();
 	MVS_HIP(hipStreamSynchronize(stream));
 	if (ntotal <= 0)
 		return;
@@ -731,18 +753,69 @@ void FlatIndex::grow(int64_t need, hipStream_t st) {
 	// +64 floats: the LDS-DMA staging reads whole 64-float pieces and may run past the last row
 	MVS_HIP(hipMalloc((void **)&nv, ((size_t)nc * geom.dp + 64) * sizeof(float)));
 	MVS_HIP(hipMalloc((void **)&nn, ((size_t)nc + 64) * sizeof(float))); // + 64: the prefilter stages norms past the end
-	if (ntotal > 0) {
-		MVS_HIP(hipMemcpyAsync(nv, vecs, (size_t)ntotal * geom.dp * sizeof(float), hipMemcpyDeviceToDevice, st));
-		MVS_HIP(hipMemcpyAsync(nn, norms, (size_t)ntotal * sizeof(float), hipMemcpyDeviceToDevice, st));
+	// (rows staged but not flushed yet -- pend_rows -- are not on the device: only what is there is copied)
+	const int64_t have = ntotal - pend_rows;
+	if (have > 0) {
+		MVS_HIP(hipMemcpyAsync(nv, vecs, (size_t)have * geom.dp * sizeof(float), hipMemcpyDeviceToDevice, st));
+		MVS_HIP(hipMemcpyAsync(nn, norms, (size_t)have * sizeof(float), hipMemcpyDeviceToDevice, st));
 	}
-	MVS_HIP(hipStreamSynchronize(st));
-	if (vecs)
-		MVS_HIP(hipFree(vecs));
-	if (norms)
-		MVS_HIP(hipFree(norms));
+	// round 6: the old buffers are freed when the copy out of them has finished -- checked at the next growth, flush or reader, never
+	// waited for here (round 5: a stream synchronisation + two hipFree per growth, 4 ms each, 10 % of a 10 M-row ingest under faiss_lock)
+	retire_buffers(st, vecs, norms);
 	vecs = nv;
 	norms = nn;
 	cap = nc;
+}
+void FlatIndex::retire_buffers(hipStream_t st, void *a, void *b) {
+	reap_retired(false);
+	if (!a && !b)
+		return;
+	Retired r;
+	r.a = a, r.b = b;
+	MVS_HIP(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+	MVS_HIP(hipEventRecord(r.done, st));
+	retired.push_back(r);
+}
+void FlatIndex::reap_retired(bool wait) {
+	for (size_t i = 0; i < retired.size();) {
+		Retired &r = retired[i];
+		if (wait)
+			(void)hipEventSynchronize(r.done);
+		else if (hipEventQuery(r.done) != hipSuccess) {
+			++i;
+			continue;
+		}
+		(void)hipEventDestroy(r.done);
+		if (r.a)
+			(void)hipFree(r.a);
+		if (r.b)
+			(void)hipFree(r.b);
+		retired.erase(retired.begin() + (long)i);
+	}
+}
+// Ingest staging (round 6).  The glue adds <= 2048 rows per call under faiss_lock
+// (src/faiss_extension.cpp:475-547); round 5 paid a staging copy, an H2D copy, two kernel launches and an event record per call
+// (39-60 us per 1 MB: 13 GB/s of a 57 GB/s link).  Now a call only copies its rows behind the previous call's in the current pinned slot
+// (8 MB); the H2D copy, pack_rows and the norms run ONCE per slot -- when it is full, or when anything wants to read the rows.
+bool FlatIndex::flush_adds() {
+	if (pend_slot < 0)
+		return false;
+	TraceRange tr("mvs:stage_rows (H2D + pack_rows + norms of one pinned slot)");
+	const bool sent = pend_rows > 0;
+	if (pend_rows > 0) {
+		ws_add.reserve((size_t)2 * PinnedRing::SLOT_BYTES);
+		float *raw = (float *)((char *)ws_add.p + (size_t)add_flip * PinnedRing::SLOT_BYTES);
+		add_flip ^= 1;
+		MVS_HIP(hipMemcpyAsync(raw, add_ring.buf[pend_slot], pend_bytes, hipMemcpyHostToDevice, stream));
+		add_ring.release(pend_slot, stream);
+		launch_pack_rows(geom, raw, pend_rows, vecs + (size_t)pend_row0 * geom.dp, pend_row0, stream);
+		launch_query_norms(raw, pend_rows, d, norms + pend_row0, stream);
+		++add_flushes;
+	}
+	pend_slot = -1;
+	pend_bytes = 0;
+	pend_rows = 0;
+	return sent;
 }
 
 // faiss::IndexFlatCodes::add: append n*d floats  (src/faiss_extension.cpp:512,609)
@@ -753,19 +826,37 @@ void FlatIndex::add(int64_t n, const float *x) {
 	if (ntotal + n > (int64_t)0x7fffffff - 1024)
 		throw_faiss("mvs::FlatIndex::add", __FILE__, "a single-device shard holds at most 2^31 rows");
 	grow(ntotal + n, stream);
+	const size_t nbytes = (size_t)n * d * sizeof(float);
+	if (lazy_adds && nbytes <= PinnedRing::SLOT_BYTES / 2) {
+		// a DataChunk-sized add: behind the rows already staged in the current slot; the device side runs once per slot (flush_adds)
+		if (pend_slot >= 0 && pend_bytes + nbytes > PinnedRing::SLOT_BYTES)
+			flush_adds();
+		if (pend_slot < 0) {
+			pend_slot = add_ring.acquire(PinnedRing::SLOT_BYTES);
+			pend_bytes = 0, pend_rows = 0, pend_row0 = ntotal;
+		}
+		stage_copy((char *)add_ring.buf[pend_slot] + pend_bytes, x, nbytes);
+		pend_bytes += nbytes;
+		pend_rows += n;
+		ntotal += n;
+		if (pend_bytes + nbytes > PinnedRing::SLOT_BYTES) // (no room for another chunk of this size: the copy engine takes the slot
+			flush_adds();                                 // now, while the callers stage the next one)
+		return;
+	}
+	flush_adds();
 	// pinned staging in slots of <= SLOT_BYTES (the caller's buffer is free again when we return); each slot is
 	// copied H2D into a raw device buffer and re-laid out into the storage format by pack_rows
 	const int64_t rows_per_slot = std::max<int64_t>(1, (int64_t)PinnedRing::SLOT_BYTES / ((int64_t)d * 4));
-	ws_add.reserve((size_t)std::min(rows_per_slot, n) * d * sizeof(float) * 2);
-	int flip = 0;
-	for (int64_t r0 = 0; r0 < n; r0 += rows_per_slot, flip ^= 1) {
+	ws_add.reserve((size_t)2 * PinnedRing::SLOT_BYTES);
+	for (int64_t r0 = 0; r0 < n; r0 += rows_per_slot) {
 		const int64_t nr = std::min(rows_per_slot, n - r0);
 		const size_t bytes = (size_t)nr * d * sizeof(float);
-		const int slot = pinned.acquire(bytes);
-		stage_copy(pinned.buf[slot], x + r0 * d, bytes);
-		float *raw = (float *)ws_add.p + (size_t)flip * std::min(rows_per_slot, n) * d;
-		MVS_HIP(hipMemcpyAsync(raw, pinned.buf[slot], bytes, hipMemcpyHostToDevice, stream));
-		pinned.release(slot, stream);
+		const int slot = add_ring.acquire(bytes);
+		stage_copy(add_ring.buf[slot], x + r0 * d, bytes);
+		float *raw = (float *)((char *)ws_add.p + (size_t)add_flip * PinnedRing::SLOT_BYTES);
+		add_flip ^= 1;
+		MVS_HIP(hipMemcpyAsync(raw, add_ring.buf[slot], bytes, hipMemcpyHostToDevice, stream));
+		add_ring.release(slot, stream);
 		launch_pack_rows(geom, raw, nr, vecs + (size_t)(ntotal + r0) * geom.dp, ntotal + r0, stream);
 		launch_query_norms(raw, nr, d, norms + ntotal + r0, stream);
 	}
@@ -776,6 +867,7 @@ void FlatIndex::add_device(int64_t n, const float *d_x, hipStream_t st) {
 	use_device();
 	if (n <= 0)
 		return;
+	flush_adds();
 	stream_wait(st, stream); // earlier host-API adds live on our own stream
 	grow(ntotal + n, st);
 	launch_pack_rows(geom, d_x, n, vecs + (size_t)ntotal * geom.dp, ntotal, st);
@@ -838,6 +930,9 @@ void FlatIndex::search_extra_metric(int64_t nq, const float *d_x, int64_t k, flo
 void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                             const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
 	use_device();
+	TraceRange tr("mvs:flat_search");
+	if (flush_adds()) // (rows staged by add() reach the device before anything reads them)
+		stream_wait(st, stream);
 	if (k <= 0)
 		throw_faiss("virtual void faiss::IndexFlat::search(...) const", "faiss/IndexFlat.cpp", "Error: 'k > 0' failed");
 	if (nq <= 0)
@@ -1175,13 +1270,14 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 			tsel = selector.upload(params, st);
 		// (after the coarse filter the rows at or above the boundary score all are candidates: no second pass over the database)
 		tie_sorted = collected && tie_from_candidates ? cl_sorted : nullptr;
+		tie_bucket = (emitted && tie_from_candidates && k_user < 100) ? cl_fb_keys : nullptr; // (k >= 100: the reservoir replay reads scores, not A_k)
 		try {
 			resolve_ip_ties(nq, d_x, k_user, *flp, tsel, d_idmap, d_D, d_I, st, kp); // (syncs the stream)
 		} catch (...) {
-			tie_sorted = nullptr;
+			tie_sorted = nullptr, tie_bucket = nullptr;
 			throw;
 		}
-		tie_sorted = nullptr;
+		tie_sorted = nullptr, tie_bucket = nullptr;
 	} else {
 		MVS_HIP(hipStreamSynchronize(st));
 	}
@@ -1389,19 +1485,25 @@ bool FlatIndex::shadow_search(int64_t nq, const float *d_x, int64_t k, float *d_
 			return false;
 		}
 		if (nf > 0) { // the unproven queries: the Flat kernels decide (results overwrite theirs)
-			const size_t xf_bytes = ((size_t)nf * d * sizeof(float) + 255) & ~(size_t)255;
-			const size_t df_bytes = ((size_t)nf * k * sizeof(float) + 255) & ~(size_t)255;
-			ws_fb.reserve(xf_bytes + df_bytes + (size_t)nf * k * sizeof(int64_t));
+			// Their batch went down FAISS's BLAS branch (nq >= 20: (xn + yn) - 2 ip); fewer than 20 of them on their own would take the
+			// per-pair branch (sum (x - y)^2: other last bits -- round 5 returned those, found by round 6's extension test).  The re-run
+			// is padded to 20 queries with copies of the first; only the first nf results are used.
+			const int nr = nf < 20 ? 20 : nf;
+			for (int i = nf; i < nr; ++i)
+				MVS_HIP(hipMemcpyAsync(fail_q + i, fail_q, sizeof(int), hipMemcpyDeviceToDevice, st));
+			const size_t xf_bytes = ((size_t)nr * d * sizeof(float) + 255) & ~(size_t)255;
+			const size_t df_bytes = ((size_t)nr * k * sizeof(float) + 255) & ~(size_t)255;
+			ws_fb.reserve(xf_bytes + df_bytes + (size_t)nr * k * sizeof(int64_t));
 			float *xf = (float *)ws_fb.p;
 			float *Df = (float *)((char *)ws_fb.p + xf_bytes);
 			int64_t *If = (int64_t *)((char *)Df + df_bytes);
-			launch_gather_query_rows(d_x + q0 * d, d, fail_q, nf, xf, st);
+			launch_gather_query_rows(d_x + q0 * d, d, fail_q, nr, xf, st);
 			const int keep_state = shadow_state, keep_mode = shadow_mode;
 			shadow_state = 0, shadow_mode = 0; // (the re-run must not come back here)
 			const bool timing = timing_enabled;
 			timing_enabled = false;
 			try {
-				search_flat(nf, xf, k, Df, If, params, d_idmap, st);
+				search_flat(nr, xf, k, Df, If, params, d_idmap, st);
 			} catch (...) {
 				shadow_state = keep_state, shadow_mode = keep_mode, timing_enabled = timing;
 				throw;
@@ -1469,6 +1571,8 @@ void FlatIndex::resolve_ip_ties(int64_t nq, const float *d_x, int64_t k, const T
 	(void)tD;
 	if (tie_sorted)
 		launch_collect_tie_rows(tie_sorted, (const int *)((const char *)ws_seg.p + 256), nq, fl.query, T, nf, (int)k, tI, st);
+	else if (tie_bucket) // (round 6: the bucketed finish keeps every survivor's exact key in its query's bucket)
+		launch_collect_tie_rows_bucket(tie_bucket, tie_bcount, tie_bpitch, fl.query, T, nf, (int)k, tI, st);
 	else
 		tie_candidates(nf, xf, T, k, tI, sel, d_idmap, st);
 	launch_tie_resolve(fl, nf, kraw, k, tI, d_idmap, label_offset, d_D, d_I, st);
@@ -1489,6 +1593,7 @@ void FlatIndex::offset_rows(int64_t *d_rows, int64_t total, hipStream_t st) {
 void FlatIndex::tie_candidates(int64_t nf, const float *d_xf, const float *d_T, int64_t k, int64_t *d_rows_out,
                                SelectorDev sel, const int64_t *d_selmap, hipStream_t st) {
 	use_device();
+	flush_adds();
 	if (nf <= 0)
 		return;
 	if (ntotal == 0) {
@@ -1510,9 +1615,44 @@ void FlatIndex::tie_candidates(int64_t nf, const float *d_xf, const float *d_T, 
 	                      (float *)ws_qn.p, d_rows_out, st);
 }
 
-bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st) {
+bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D, int64_t *d_I, hipStream_t st, bool need_matrix) {
+	flush_adds();
 	if (!tune().coarse_select || (metric != METRIC_L2 && metric != METRIC_IP) || nq < 20)
 		return false; // (fewer than 20 queries: FAISS's per-pair branch, other arithmetic for L2)
+	if (!need_matrix && metric == METRIC_L2 && tune().coarse_bf16 && coarse_bf16_supported(d, ntotal, np) && (geom.dp & 3) == 0) {
+		// round 6 (csrc/coarse_bf16.hip): this index's own coarse-filter operands -- the centred bf16 store, the query fragments, ||x||^2
+		// and 2E(q) of collect_query_prep_kernel -- one filter workgroup per 32 queries, one exact wavefront per query
+		use_device();
+		stream_wait(st, stream); // adds were enqueued on our own stream
+		if (have_last_search)
+			stream_wait(st, last_search_stream);
+		last_search_stream = st;
+		have_last_search = true;
+		ensure_h1_rows(st);
+		ws_qn.reserve((size_t)nq * sizeof(float));
+		ws_e2.reserve((size_t)((nq + 255) / 256 * 256) * sizeof(float));
+		ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
+		ws_seg.reserve(256 + (size_t)2 * nq * sizeof(int));
+		ws_fail.reserve(64 + (size_t)nq * sizeof(int));
+		int *fail_cnt = (int *)ws_fail.p, *fail_q = fail_cnt + 16;
+		MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
+		// (no class slots here: stride 0; queries without a finite bound come back with e2 = NaN and are computed exhaustively)
+		launch_collect_query_prep(metric, d_x, nq, d, mu_h1, d_max_norm_bits, ws_pfq.p, (float *)ws_qn.p, (float *)ws_e2.p, fail_cnt, fail_q,
+		                          nullptr, 0, (int *)ws_seg.p, (int *)((char *)ws_seg.p + 256), st);
+		const size_t cb = (coarse_bf16_cand_bytes(nq) + 255) & ~(size_t)255, nb = ((size_t)nq * sizeof(int) + 255) & ~(size_t)255;
+		const bool fresh = ws_cb16.cap < cb + nb + 64;
+		ws_cb16.reserve(cb + nb + 64);
+		if (fresh)
+			MVS_HIP(hipMemsetAsync((char *)ws_cb16.p + cb + nb, 0, 64, st)); // (the exhaustive-query counter)
+		cb16_stats_off = cb + nb;
+		begin_kernel_timing(st);
+		launch_coarse_bf16(d_x, nq, d, ws_pfq.p, (const float *)ws_qn.p, (const float *)ws_e2.p, vecs_h1, beta_h1, vecs, geom.dp,
+		                   geom.pair_interleaved ? 1 : 0, norms, ntotal, np, (unsigned short *)ws_cb16.p, (int *)((char *)ws_cb16.p + cb), d_D, d_I,
+		                   label_offset, (unsigned long long *)((char *)ws_cb16.p + cb + nb), st);
+		end_kernel_timing(st);
+		cb16_queries += nq;
+		return true;
+	}
 	// inner product: one entry more than asked for, the merge flags boundary ties and resolve_ip_ties replays FAISS's heap
 	const bool ip = metric == METRIC_IP;
 	if (ip && !(ip_exact_ties && np + 1 <= flat_mfma_max_k(geom)))
@@ -1565,6 +1705,7 @@ bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D
 void FlatIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                               const mvs_search_params *params, hipStream_t st) {
 	use_device();
+	flush_adds();
 	stream_wait(st, stream); // adds were enqueued on our own stream
 	search_flat(nq, d_x, k, d_D, d_I, params, nullptr, st);
 }
@@ -1577,7 +1718,11 @@ void FlatIndex::to_device(int new_device) {
 	if (new_device < 0 || new_device >= ndev)
 		throw_faiss("faiss::gpu::index_cpu_to_gpu", "faiss/gpu/GpuCloner.cpp", "Invalid GPU device %d", new_device);
 	use_device();
+	flush_adds();
 	MVS_HIP(hipStreamSynchronize(stream));
+	reap_retired(true);
+	add_ring.drop_events();
+	pinned.drop_events();
 	float *nv = nullptr, *nn = nullptr;
 	MVS_HIP(hipSetDevice(new_device));
 	if (cap > 0) {
@@ -1630,6 +1775,7 @@ static void check_device(int dev) {
 IndexBase *FlatIndex::clone(int on_device) {
 	check_device(on_device);
 	use_device();
+	flush_adds();
 	MVS_HIP(hipStreamSynchronize(stream));
 	auto *c = new FlatIndex(d, metric);
 	try {
@@ -1678,6 +1824,7 @@ void IDMapIndex::grow_ids(int64_t need, hipStream_t st) {
 	const int64_t nc = std::max<int64_t>(need, 2 * idcap + 4096); // (as FlatIndex::grow)
 	int64_t *ni = nullptr;
 	MVS_HIP(hipMalloc((void **)&ni, (size_t)nc * sizeof(int64_t)));
+	flush_ids(); // (staged ids go to the old array first: the copy below carries them over)
 	if (ntotal > 0)
 		MVS_HIP(hipMemcpyAsync(ni, ids, (size_t)ntotal * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
 	MVS_HIP(hipStreamSynchronize(st));
@@ -1692,18 +1839,41 @@ void IDMapIndex::add_with_ids(int64_t n, const float *x, const int64_t *xids) {
 	if (n <= 0)
 		return;
 	sub->add(n, x);
+	use_device();
 	grow_ids(ntotal + n, stream);
 	const size_t bytes = (size_t)n * sizeof(int64_t);
-	const int slot = pinned.acquire(bytes);
-	memcpy(pinned.buf[slot], xids, bytes);
-	MVS_HIP(hipMemcpyAsync(ids + ntotal, pinned.buf[slot], bytes, hipMemcpyHostToDevice, stream));
-	pinned.release(slot, stream);
+	// round 6: the ids of DataChunk-sized adds are staged like their rows (FlatIndex::add) -- one H2D copy per full slot, not per call
+	if (bytes > PinnedRing::SLOT_BYTES / 2 || (idp_slot >= 0 && idp_bytes + bytes > PinnedRing::SLOT_BYTES))
+		flush_ids();
+	if (bytes > PinnedRing::SLOT_BYTES / 2) {
+		const int slot = id_ring.acquire(bytes);
+		memcpy(id_ring.buf[slot], xids, bytes);
+		MVS_HIP(hipMemcpyAsync(ids + ntotal, id_ring.buf[slot], bytes, hipMemcpyHostToDevice, stream));
+		id_ring.release(slot, stream);
+	} else {
+		if (idp_slot < 0) {
+			idp_slot = id_ring.acquire(PinnedRing::SLOT_BYTES);
+			idp_bytes = 0, idp_row0 = ntotal;
+		}
+		memcpy((char *)id_ring.buf[idp_slot] + idp_bytes, xids, bytes);
+		idp_bytes += bytes;
+	}
 	ntotal = sub->ntotal;
+}
+void IDMapIndex::flush_ids() {
+	if (idp_slot < 0)
+		return;
+	if (idp_bytes > 0)
+		MVS_HIP(hipMemcpyAsync(ids + idp_row0, id_ring.buf[idp_slot], idp_bytes, hipMemcpyHostToDevice, stream));
+	id_ring.release(idp_slot, stream);
+	idp_slot = -1;
+	idp_bytes = 0;
 }
 void IDMapIndex::add_with_ids_device(int64_t n, const float *d_x, const int64_t *d_ids, hipStream_t st) {
 	use_device();
 	if (n <= 0)
 		return;
+	flush_ids();
 	stream_wait(st, stream);
 	sub->add_device(n, d_x, st);
 	grow_ids(ntotal + n, st);
@@ -1715,6 +1885,7 @@ void IDMapIndex::add_with_ids_device(int64_t n, const float *d_x, const int64_t 
 void IDMapIndex::search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                                const mvs_search_params *params, hipStream_t st) {
 	use_device();
+	flush_ids();
 	stream_wait(st, stream); // id_map writes happened on our own stream; the sub-index searches on `st`
 	sub->search_mapped(nq, d_x, k, d_D, d_I, params, ids, st);
 	kinfo = sub->kinfo;
@@ -1727,6 +1898,10 @@ void IDMapIndex::to_device(int new_device) {
 		return;
 	sub->to_device(new_device);
 	use_device();
+	flush_ids();
+	MVS_HIP(hipStreamSynchronize(stream));
+	id_ring.drop_events();
+	pinned.drop_events();
 	MVS_HIP(hipStreamSynchronize(stream));
 	int64_t *ni = nullptr;
 	if (idcap > 0) {
@@ -1750,6 +1925,7 @@ void IDMapIndex::to_device(int new_device) {
 IndexBase *IDMapIndex::clone(int on_device) {
 	check_device(on_device);
 	use_device();
+	flush_ids();
 	MVS_HIP(hipStreamSynchronize(stream));
 	IndexBase *subc = sub->clone(on_device);
 	IDMapIndex *c = nullptr;
@@ -1776,6 +1952,7 @@ IndexBase *IDMapIndex::clone(int on_device) {
 void FlatIndex::search_mapped(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I,
                               const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
 	use_device();
+	flush_adds();
 	stream_wait(st, stream); // adds were enqueued on our own stream
 	search_flat(nq, d_x, k, d_D, d_I, params, d_idmap, st);
 }
@@ -1794,6 +1971,7 @@ void FlatIndex::to_host(HostIndex &out) {
 }
 void IDMapIndex::to_host(HostIndex &out) {
 	use_device();
+	flush_ids();
 	MVS_HIP(hipStreamSynchronize(stream));
 	out.kind = MVS_KIND_IDMAP;
 	out.d = d;
@@ -2184,6 +2362,43 @@ int mvs_index_collect_stats(mvs_index *ix, int64_t *queries, int64_t *candidates
 		*overflows = f->cl_overflows;
 	MVS_API_END
 }
+int mvs_trace_push(const char *name) {
+	trace_push(name ? name : "mvs");
+	return 0;
+}
+int mvs_trace_pop(void) {
+	trace_pop();
+	return 0;
+}
+int mvs_index_get_stat(mvs_index *ix, const char *name, int64_t *value) {
+	MVS_API_BEGIN
+	IndexBase *p = sharded_inner_view(ix->impl);
+	while (p->kind == MVS_KIND_IDMAP)
+		p = static_cast<IDMapIndex *>(p)->sub;
+	if (!name || !value)
+		throw_faiss("mvs_index_get_stat", __FILE__, "null argument");
+	if (!strcmp(name, "coarse_bf16_queries") || !strcmp(name, "coarse_bf16_exhaustive")) {
+		// IVF: queries whose coarse quantisation ran on csrc/coarse_bf16.hip / of those, computed against every centroid
+		IndexBase *qz = ivf_quantizer_of(p);
+		if (!qz || qz->kind != MVS_KIND_FLAT)
+			throw_faiss("mvs_index_get_stat", __FILE__, "%s: not an IVF index with a Flat quantizer", name);
+		auto *f = static_cast<FlatIndex *>(qz);
+		if (!strcmp(name, "coarse_bf16_queries")) {
+			*value = f->cb16_queries;
+		} else {
+			unsigned long long v = 0;
+			if (f->ws_cb16.p && f->cb16_stats_off) {
+				f->use_device();
+				MVS_HIP(hipDeviceSynchronize());
+				MVS_HIP(hipMemcpy(&v, (const char *)f->ws_cb16.p + f->cb16_stats_off, sizeof v, hipMemcpyDeviceToHost));
+			}
+			*value = (int64_t)v;
+		}
+	} else {
+		throw_faiss("mvs_index_get_stat", __FILE__, "unknown statistic %s", name);
+	}
+	MVS_API_END
+}
 int mvs_index_shadow_stats(mvs_index *ix, int64_t *stats /* [8] */, double *build_seconds) {
 	MVS_API_BEGIN
 	IndexBase *p = sharded_inner_view(ix->impl);
@@ -2371,6 +2586,46 @@ int mvs_index_set_option(mvs_index *ix, const char *key, int64_t value) {
 } // extern "C"
 
 namespace mvs {
+namespace {
+struct Roctx {
+	int (*push)(const char *) = nullptr;
+	int (*pop)() = nullptr;
+	Roctx() {
+		bool want = false;
+		if (const char *e = getenv("MVS_ROCTX"))
+			want = e[0] && e[0] != '0';
+		for (const char *v : {"ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY", "HSA_TOOLS_LIB", "LD_PRELOAD"})
+			if (const char *e = getenv(v))
+				want = want || strstr(e, "rocprof") != nullptr;
+		if (!want)
+			return;
+		for (const char *n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+			void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+			if (!h)
+				continue;
+			push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+			pop = (int (*)())dlsym(h, "roctxRangePop");
+			if (push && pop)
+				return;
+			push = nullptr, pop = nullptr;
+		}
+	}
+};
+const Roctx &roctx() {
+	static const Roctx r;
+	return r;
+}
+} // namespace
+void trace_push(const char *name) {
+	const Roctx &r = roctx();
+	if (r.push)
+		(void)r.push(name);
+}
+void trace_pop() {
+	const Roctx &r = roctx();
+	if (r.pop)
+		(void)r.pop();
+}
 // Per-index tuning (round 5).  Every knob below used to be a process-wide int set through whichever index
 // happened to receive set_option -- DuckDB searches different indexes from different threads, so one index's A/B switch changed
 // the path (and raced with the launches) of another.  Now an index owns its Tuning; use_device(), the first statement of every
@@ -2407,6 +2662,7 @@ bool IndexBase::set_tuning(const char *key, int64_t v) {
 	    {"ivf_cl_lds_pad", &Tuning::ivf_cl_lds_pad, 0},
 	    {"ivf_cl_xcd", &Tuning::ivf_cl_xcd, 0},        // IVF coarse filter: items of one list on one XCD (1) or dealt round-robin over the XCDs (0)
 	    {"ivf_coarse_select", &Tuning::coarse_select, 1}, // IVF coarse quantiser: distance matrix + selection (1) or the k-list kernels (0)
+	    {"ivf_coarse_bf16", &Tuning::coarse_bf16, 1},     // L2 coarse quantiser: bf16 filter + exact re-scoring (1, csrc/coarse_bf16.hip) or distance matrix + selection (0)
 	    {"cl_abl", &Tuning::cl_abl, 5},                // wrong-result ablation knobs: profiling library only
 	    {"ivf_cl_abl", &Tuning::ivf_cl_abl, 5},
 	    {"coarse_abl", &Tuning::coarse_abl, 5},
@@ -2458,6 +2714,11 @@ bool IndexBase::set_tuning(const char *key, int64_t v) {
 bool FlatIndex::set_option(const char *key, int64_t v) {
 	if (set_tuning(key, v))
 		return true;
+	if (!strcmp(key, "lazy_adds")) { // 0: every add() reaches the device at once (round 5's ingest, for A/B)
+		flush_adds();
+		lazy_adds = v != 0;
+		return true;
+	}
 	if (!strcmp(key, "metric_arg_bits")) { // faiss::Index::metric_arg as IEEE-754 bits (the option channel carries integers)
 		const uint32_t b = (uint32_t)v;
 		memcpy(&metric_arg, &b, 4);

@@ -673,6 +673,7 @@ public:
 		if (np <= 0)
 			throw_faiss("virtual void faiss::IndexIVF::search(...) const", "faiss/IndexIVF.cpp",
 			            "Error: 'nprobe > 0' failed");
+		TraceRange tr(raw_pos ? "mvs:ivf_search (inside the exact-tie wrapper)" : "mvs:ivf_search");
 		last_np = np;
 		// our stream carries the adds / list build; the caller's stream carries the queries
 		stream_wait(stream, st);
@@ -693,9 +694,10 @@ public:
 		memset(&qp, 0, sizeof qp);
 		qp.efSearch = params ? params->efSearch : 0; // quantizer_params of an HNSW coarse quantizer (:679-681)
 		if (!reuse_coarse) { // (a prefilter re-run keeps the coarse assignment of the batch its queries came from)
+			TraceRange trc("mvs:ivf_coarse_quantiser");
 			// a Flat L2 quantizer of a few thousand centroids: distance matrix + per-query selection (csrc/coarse_select.hip)
 			const bool done = hnsw_M == 0 && static_cast<FlatIndex *>(quantizer)->coarse_topk(nq, d_x, np, (float *)ws_cD.p,
-			                                                                                  (int64_t *)ws_cI.p, stream);
+			                                                                                  (int64_t *)ws_cI.p, stream, shadow != nullptr);
 			if (!done)
 				quantizer->search_device(nq, d_x, np, (float *)ws_cD.p, (int64_t *)ws_cI.p, hnsw_M > 0 ? &qp : nullptr, stream);
 		}

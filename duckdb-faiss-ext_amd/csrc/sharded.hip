@@ -657,8 +657,11 @@ public:
 			}
 			MVS_HIP(hipSetDevice(devs[0]));
 		}
+		trace_push("mvs:shard_search (every shard, its own stream)");
 		on_all([&](int g) { shard_search(g, nq, hx, d_x, xdev, x_ready, kk, params, use_rccl); });
+		trace_pop();
 		hipStream_t s0 = streams[0];
+		TraceRange tr_x(use_rccl ? "mvs:exchange (ncclAllGather of 16-byte records) + merge" : "mvs:exchange (peer copies) + merge");
 		if (use_rccl) {
 			// ONE all-gather of the packed {value, global row} records over xGMI; the first device merges its copy
 			Rccl &r = Rccl::get();

@@ -122,6 +122,9 @@ _L.mvs_index_prefilter_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C
 _L.mvs_index_collect_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_index_ivf_probe_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_index_shadow_stats.argtypes = [_p, C.POINTER(_i64), C.POINTER(C.c_double)]
+_L.mvs_index_get_stat.argtypes = [_p, C.c_char_p, C.POINTER(_i64)]
+_L.mvs_trace_push.argtypes = [C.c_char_p]
+_L.mvs_trace_pop.argtypes = []
 _L.mvs_index_shard_to_gpus.argtypes = [_p, C.POINTER(C.c_int), C.c_int]
 _L.mvs_index_shard_info.argtypes = [_p, C.POINTER(C.c_int), C.c_int, C.POINTER(_i64), C.POINTER(_i64)]
 _L.mvs_write_index.argtypes = [_p, C.c_char_p]
@@ -151,7 +154,7 @@ DECLARED_SYMBOLS = [
     "mvs_index_hnsw_set_ef_construction", "mvs_index_hnsw_get_ef_construction", "mvs_index_hnsw_graph_info", "mvs_index_hnsw_walk_stats", "mvs_index_hnsw_get_graph",
     "mvs_index_train", "mvs_index_add",
     "mvs_index_add_with_ids", "mvs_index_search", "mvs_index_to_gpu", "mvs_index_device", "mvs_index_clone_to_gpu",
-    "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_ivf_probe_stats", "mvs_index_shadow_stats", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
+    "mvs_index_prefilter_stats", "mvs_index_collect_stats", "mvs_index_ivf_probe_stats", "mvs_index_shadow_stats", "mvs_index_get_stat", "mvs_trace_push", "mvs_trace_pop", "mvs_index_shard_to_gpus", "mvs_index_shard_info", "mvs_write_index",
     "mvs_read_index", "mvs_index_add_device", "mvs_index_search_device", "mvs_index_set_label_offset",
     "mvs_merge_shards", "mvs_merge_shards_raw", "mvs_merge_records_device", "mvs_finish_ip_ties", "mvs_index_tie_candidates_device", "mvs_index_ivf_tie_emit_device", "mvs_synth_uniform_device", "mvs_synth_clustered_device", "mvs_debug_mfma_bf16_16x16x32", "mvs_index_last_kernel_info",
     "mvs_index_set_kernel_timing", "mvs_index_kernel_time_stats", "mvs_index_set_option", "mvs_device_count",
@@ -161,6 +164,21 @@ DECLARED_SYMBOLS = [
 
 def lib():
     return _L
+
+
+class trace_range:
+    """with trace_range("exchange"): ... -- a roctx range (include/mi355_faiss.h mvs_trace_push / mvs_trace_pop)"""
+
+    def __init__(self, name):
+        self.name = name.encode()
+
+    def __enter__(self):
+        _L.mvs_trace_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _L.mvs_trace_pop()
+        return False
 
 
 def _check(rc):
@@ -318,6 +336,12 @@ class Index:
         a, b, c, e = _i64(0), _i64(0), _i64(0), _i64(0)
         _check(_L.mvs_index_ivf_probe_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(e)))
         return {"pairs": a.value, "scanned": b.value, "forced_drains": c.value, "admitted": e.value}
+
+    def get_stat(self, name):
+        """a named diagnostic counter -- include/mi355_faiss.h mvs_index_get_stat"""
+        v = _i64(0)
+        _check(_L.mvs_index_get_stat(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def shadow_stats(self):
         """Flat L2: the shadow clustering's state, size and cost -- include/mi355_faiss.h mvs_index_shadow_stats"""

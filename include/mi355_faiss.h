@@ -239,6 +239,15 @@ int mvs_index_ivf_probe_stats(mvs_index *ix, int64_t *pairs, int64_t *pairs_scan
  * queries answered through it, of those re-run on the Flat kernels (unproven), builds (k-means), extensions (rows appended after
  * add()), device bytes the shadow holds, its nlist}; build_seconds = time spent building / extending it inside search calls. */
 int mvs_index_shadow_stats(mvs_index *ix, int64_t *stats, double *build_seconds);
+/* diagnostics by name (tests, bench): "coarse_bf16_queries" = queries of an IVF index whose coarse quantisation (IndexIVF::search ->
+ * quantizer->search, src/faiss_extension.cpp:631) ran as a bf16 filter + exact re-scoring (csrc/coarse_bf16.hip);
+ * "coarse_bf16_exhaustive" = of those, queries that were computed against every centroid (list overflow / no finite bound) */
+int mvs_index_get_stat(mvs_index *ix, const char *name, int64_t *value);
+/* named ranges for rocprofv3 --marker-trace (roctx; bound at run time, only under a profiler or with MVS_ROCTX=1): the library
+ * marks its own stages (row staging, Flat / IVF search, shard search, exchange, merge); a host that merges shard results itself
+ * (pyhost/sharded.py: the exchange of src/gpu/gpu.cpp:48's multi-GPU layout) brackets its stages with these */
+int mvs_trace_push(const char *name);
+int mvs_trace_pop(void);
 int mvs_device_count(void);
 const char *mvs_version(void);
 

@@ -41,6 +41,12 @@ def test_three_kernels_one_set_of_probe_lists(mf, metric, d, nlist, n, nq, nprob
     o.add(xb)
     k = 5
     ro = o.search(xq, k, nprobe=nprobe)
+    # round 6: L2 quantisers of 16 < d <= 128, nlist % 16 == 0, nprobe <= 64 take csrc/coarse_bf16.hip (no matrix at all) -- same lists
+    served = metric == L2 and 16 < d <= 128 and nlist % 16 == 0 and nprobe <= 64
+    before = g.get_stat("coarse_bf16_queries")
+    assert _same(g.search(xq, k, nprobe=nprobe), ro), ("bf16", d, nlist)
+    assert g.get_stat("coarse_bf16_queries") - before == (nq if served else 0)
+    g.set_option("ivf_coarse_bf16", 0)
     for mode in (2, 1, 0):
         g.set_option("ivf_coarse_mfma", mode)
         assert _same(g.search(xq, k, nprobe=nprobe), ro), (mode, d, nlist)
@@ -61,6 +67,44 @@ def test_integer_centroids_with_tied_coarse_distances(mf):
     g.add(xb)
     o.add(xb)
     ro = o.search(xq, 10, nprobe=nprobe)
+    assert _same(g.search(xq, 10, nprobe=nprobe), ro), "bf16"
+    assert g.get_stat("coarse_bf16_queries") == nq
+    g.set_option("ivf_coarse_bf16", 0)
     for mode in (2, 1, 0):
         g.set_option("ivf_coarse_mfma", mode)
         assert _same(g.search(xq, 10, nprobe=nprobe), ro), mode
+
+
+@pytest.mark.parametrize("case", ["overflow", "nonfinite", "np64", "nearly_all"])
+def test_bf16_coarse_quantiser_edge_cases(mf, case):
+    """csrc/coarse_bf16.hip: a candidate list that overflows (every centroid the same point), a query whose bound is not finite, the
+    largest served nprobe, nprobe close to nlist -- the exhaustive fallback inside the exact kernel must give the matrix path's lists."""
+    d, nlist, n, nq, nprobe, k = 64, 1024, 40000, 200, 16, 4
+    rs = np.random.RandomState(5)
+    cent = rs.randn(nlist, d).astype(np.float32)
+    if case == "overflow":
+        cent[:] = cent[0]  # 1024 identical centroids: all tied, all candidates (> 512 per query)
+        cent[::7] += 1e-3
+    if case == "np64":
+        nprobe = 64
+    if case == "nearly_all":
+        nlist, nprobe = 256, 60
+        cent = cent[:nlist]
+    xb = (cent[rs.randint(0, nlist, n)] + 0.3 * rs.randn(n, d)).astype(np.float32)
+    xq = (cent[rs.randint(0, nlist, nq)] + 0.3 * rs.randn(nq, d)).astype(np.float32)
+    if case == "nonfinite":
+        xq[3] *= 1e19  # ||x||^2 overflows: no finite bound, FAISS's own distances are inf / nan for this query
+    g, o = mf.index_factory(d, f"IVF{nlist},Flat", L2), orc.Index(d, f"IVF{nlist},Flat", L2)
+    o.ivf_set_centroids(cent)
+    g.ivf_set_centroids(o.ivf_centroids())
+    g.add(xb)
+    o.add(xb)
+    got = g.search(xq, k, nprobe=nprobe)
+    assert g.get_stat("coarse_bf16_queries") == nq
+    if case in ("overflow", "nonfinite"):
+        assert g.get_stat("coarse_bf16_exhaustive") >= 1
+    g.set_option("ivf_coarse_bf16", 0)
+    ref = g.search(xq, k, nprobe=nprobe)
+    assert _same(got, ref), case
+    if case != "nonfinite":
+        assert _same(got, o.search(xq, k, nprobe=nprobe)), case

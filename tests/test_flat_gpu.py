@@ -473,3 +473,56 @@ def test_l2_k_from_100_reservoir_equals_heap_on_the_device_too(mf):
     for k in (100, 257, 1500):
         assert_same_results(*g.search(xq, k), *o.search(xq, k), True, what=f"L2 k={k}")
 
+
+
+@pytest.mark.parametrize("desc,d", [("Flat", 128), ("IDMap,Flat", 13), ("IDMap,Flat", 128), ("Flat", 770)])
+def test_staged_adds_reach_every_reader(mf, tmp_path, desc, d):
+    """round 6: DataChunk-sized add() calls (src/faiss_extension.cpp:510,512: <= 2048 rows each) are collected in a pinned
+    slot and sent to the device once per 8 MB -- ntotal counts them at once, and search / write_index / clone / a growth of the row store
+    in between all see every row.  Same results as an index that got its rows in one call and as one with the staging switched off."""
+    rs = np.random.RandomState(d)
+    n, nq, k = 30_000, 40, 5
+    xb = rs.rand(n, d).astype(np.float32)
+    xq = rs.rand(nq, d).astype(np.float32)
+    ids = (np.arange(n, dtype=np.int64) * 7 + 3) if desc.startswith("IDMap") else None
+
+    def feed(ix, lo, hi, chunk):
+        for i0 in range(lo, hi, chunk):
+            i1 = min(hi, i0 + chunk)
+            if ids is None:
+                ix.add(xb[i0:i1])
+            else:
+                ix.add_with_ids(xb[i0:i1], ids[i0:i1])
+
+    whole = mf.index_factory(d, desc, L2)
+    feed(whole, 0, n, n)
+    eager = mf.index_factory(d, desc, L2)
+    eager.set_option("lazy_adds", 0)
+    lazy = mf.index_factory(d, desc, L2)
+    checkpoints = [1, 2048 + 77, 9_000, 20_001, n]
+    lo = 0
+    for hi in checkpoints:
+        feed(lazy, lo, hi, 777 if hi < 20_000 else 2048)  # (odd chunks: unaligned staging offsets at d = 13)
+        feed(eager, lo, hi, 2048)
+        lo = hi
+        assert lazy.ntotal == hi
+        kk = min(k, hi)
+        a, b = lazy.search(xq, kk), eager.search(xq, kk)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), hi
+    a, b = lazy.search(xq, k), whole.search(xq, k)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    # a write with rows still staged: the file holds them all
+    more = rs.rand(300, d).astype(np.float32)
+    if ids is None:
+        lazy.add(more)
+        whole.add(more)
+    else:
+        mid = np.arange(300, dtype=np.int64) + 10_000_000
+        lazy.add_with_ids(more, mid)
+        whole.add_with_ids(more, mid)
+    path = str(tmp_path / "staged.index")
+    mf.write_index(lazy, path)
+    back = mf.read_index(path)
+    assert back.ntotal == n + 300
+    a, b = back.search(xq, k), whole.search(xq, k)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))

@@ -10,6 +10,9 @@ properties of the data shape as much as of the kernel.  FlatL2 d=128 N=10M nq=10
   dup10          uniform with 10 % of the rows duplicated
   sift_like      integer 0..255 coordinates with exponential magnitudes: norms spread over a decade (SIFT descriptors)
   all_dup        64 distinct vectors repeated                 (the stream overflows: what the fall-back costs)
+  normalised_s03 / normalised_s01   as normalised with sigma 0.3 / 0.1 (tighter clusters on the sphere); outlier: normalised + one row x 100
+  interleaved    clustered rows, then 3 cycles of add(65 536 rows) + search (DuckDB: insert, then query): ms per search of the cycle
+(env D: dimensions, default 128; N; METRIC = L2 | IP; KINDS)
 For each: ms per 10k batch, QPS, candidates re-scored per query, stream overflows, queries re-run on the exact kernel, and
 whether labels AND distances equal the exact f32 kernel's on a 512-query sample (prefilter = 0)."""
 import os, sys, time
@@ -18,7 +21,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ex
 import numpy as np, torch
 import mi355_faiss as mf
 
-n, d, nq, k = int(os.environ.get("N", 10_000_000)), 128, 10_000, 10
+n, d, nq, k = int(os.environ.get("N", 10_000_000)), int(os.environ.get("D", 128)), 10_000, 10
 metric = mf.METRIC_L2 if os.environ.get("METRIC", "L2") == "L2" else mf.METRIC_INNER_PRODUCT
 dev = "cuda:0"
 
@@ -28,9 +31,15 @@ def rows(kind, m, seed, row0):
         return mf.synth_uniform_torch(m, d, seed, row0=row0)
     if kind == "clustered":
         return mf.synth_clustered_torch(m, d, seed, row0=row0, n_centers=1024, sigma=0.1)
-    if kind == "normalised":
-        x = mf.synth_clustered_torch(m, d, seed, row0=row0, n_centers=1024, sigma=1.0)
-        return x / x.norm(dim=1, keepdim=True)
+    if kind.startswith("normalised") or kind == "outlier":
+        # normalised (sigma 1.0) | normalised_s03 | normalised_s01: embedding-like rows of decreasing spread around 1024 directions
+        # outlier: normalised rows with ONE row of 100 x the norm (round 6, VERDICT r5 #6: the bound uses one global ||y'||max)
+        sg = {"normalised": 1.0, "normalised_s03": 0.3, "normalised_s01": 0.1, "outlier": 1.0}[kind]
+        x = mf.synth_clustered_torch(m, d, seed, row0=row0, n_centers=1024, sigma=sg)
+        x = x / x.norm(dim=1, keepdim=True)
+        if kind == "outlier" and seed == 1234 and row0 <= 12345 < row0 + m:
+            x[12345 - row0] *= 100.0
+        return x
     if kind == "offset":
         return mf.synth_uniform_torch(m, d, seed, row0=row0) + 3.0
     if kind == "integer":
@@ -52,14 +61,15 @@ def rows(kind, m, seed, row0):
 
 
 print(f"# coarse-filter data sensitivity: Flat{os.environ.get('METRIC', 'L2')} d={d} N={n} nq={nq} k={k}")
-print(f"{'data':<11} {'ms/batch':>9} {'QPS':>9} {'cand/query':>11} {'overflows':>9} {'exact re-runs':>13} {'kernel':<28} bit-exact vs f32 kernel (512 q)")
+print(f"{'data':<14} {'ms/batch':>9} {'QPS':>9} {'cand/query':>11} {'overflows':>9} {'exact re-runs':>13} {'kernel':<28} bit-exact vs f32 kernel (512 q)")
 for kind in os.environ.get("KINDS", "uniform clustered normalised offset integer dup10 sift_like all_dup").split():
     ix = mf.index_factory(d, "Flat", metric)
     for o in os.environ.get("OPTS", "").split():  # e.g. OPTS="cl_bound_mode=0"
         ix.set_option(o.split("=")[0], int(o.split("=")[1]))
     for s0 in range(0, n, 1 << 20):
-        ix.add_torch(rows(kind, min(1 << 20, n - s0), 1234, s0)); torch.cuda.synchronize()
-    xq = rows(kind, nq, 4321, 0).contiguous()
+        ix.add_torch(rows("clustered" if kind == "interleaved" else kind, min(1 << 20, n - s0), 1234, s0)); torch.cuda.synchronize()
+    base_kind = "clustered" if kind == "interleaved" else kind
+    xq = rows(base_kind, nq, 4321, 0).contiguous()
     D = torch.empty((nq, k), dtype=torch.float32, device=dev); I = torch.empty((nq, k), dtype=torch.int64, device=dev)
     # (warm-up: the first search sizes buffers; on rows that cluster the second one builds the shadow IVF index.  all_dup: ONE, as in
     # rounds 3-4 -- the filter gives up on that data and is retried every 4, 8, ... searches: more warm-ups would put a retry into the timed three)
@@ -67,11 +77,21 @@ for kind in os.environ.get("KINDS", "uniform clustered normalised offset integer
         ix.search_torch(xq, k, D=D, I=I); torch.cuda.synchronize()
     c0, p0 = ix.collect_stats(), ix.prefilter_stats()
     reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ix.search_torch(xq, k, D=D, I=I)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / reps * 1e3
+    if kind == "interleaved":
+        extra = [rows("clustered", 65536, 1234, n + 65536 * i) for i in range(reps)]
+        torch.cuda.synchronize()
+        ms = 0.0
+        for i in range(reps):
+            ix.add_torch(extra[i]); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ix.search_torch(xq, k, D=D, I=I); torch.cuda.synchronize()
+            ms += (time.perf_counter() - t0) * 1e3 / reps
+    else:
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ix.search_torch(xq, k, D=D, I=I)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
     c1, p1 = ix.collect_stats(), ix.prefilter_stats()
     name = ix.last_kernel_info()["name"]
     cand = (c1["candidates"] - c0["candidates"]) / max(c1["queries"] - c0["queries"], 1)
@@ -80,6 +100,6 @@ for kind in os.environ.get("KINDS", "uniform clustered normalised offset integer
     ix.set_option("prefilter", 0)
     De, Ie = ix.search_torch(xq[:512].contiguous(), k); torch.cuda.synchronize()
     same = bool(torch.equal(Ie, I[:512]) and torch.equal(De.view(torch.int32), D[:512].view(torch.int32)))
-    print(f"{kind:<11} {ms:9.2f} {nq / ms * 1e3:9.0f} {cand:11.1f} {ovf:9.1f} {fb:13.1f} {name:<28} {same}", flush=True)
+    print(f"{kind:<14} {ms:9.2f} {nq / ms * 1e3:9.0f} {cand:11.1f} {ovf:9.1f} {fb:13.1f} {name:<28} {same}", flush=True)
     del ix
     torch.cuda.empty_cache()
