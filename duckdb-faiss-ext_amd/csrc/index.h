@@ -230,6 +230,8 @@ public:
 	DevBuf ws_cb16;
 	int64_t cb16_queries = 0; // queries served by csrc/coarse_bf16.hip (diagnostics)
 	size_t cb16_stats_off = 0; // byte offset of the exhaustive-query counter in ws_cb16
+	int64_t cb16_last_nq = 0;  // queries / offset of the per-query candidate counts of the last call (diagnostics)
+	size_t cb16_ccount_off = 0;
 	// what the last coarse_topk left behind (csrc/ivf.hip flat_shadow_search): the [nq][ntotal] distance matrix -- whole only when
 	// the batch fitted one chunk --, and the rows' squared norms
 	const float *coarse_matrix() const {
@@ -540,9 +542,11 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
 // csrc/coarse_bf16.hip: the coarse quantiser as a bf16 filter + exact re-scoring inside one workgroup per 32 queries
 bool coarse_bf16_supported(int d, int64_t nlist, int64_t np);
 size_t coarse_bf16_cand_bytes(int64_t nq);
+size_t coarse_bf16_cls_bytes(int64_t nq, int64_t nlist, int64_t np);
+int coarse_bf16_slices(int64_t nq, int64_t nlist, int64_t np);
 void launch_coarse_bf16(const float *d_x, int64_t nq, int d, const void *d_qf, const float *d_qn, const float *d_e2, const unsigned short *d_yb,
                         const float *d_beta, const float *d_cent, int sdp, int interleaved, const float *d_cn, int64_t nlist, int64_t np,
-                        unsigned short *d_cand, int *d_ccount, float *d_outD, int64_t *d_outI, int64_t label_offset,
+                        unsigned short *d_cand, int *d_ccount, float *d_cls, float *d_outD, int64_t *d_outI, int64_t label_offset,
                         unsigned long long *d_stats, hipStream_t st);
 void launch_ivf_refilter(const unsigned long long *d_strm, const float *d_su, int64_t cap, const unsigned long long *d_cnt,
                          const unsigned *d_gslot, int nclass, int kf, int64_t nq, float *d_bf, unsigned long long *d_out,

@@ -660,8 +660,12 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 			cl_fpitch = (int)want;
 			fb_layout();
 			MVS_HIP(hipMemsetAsync((char *)ws_seg.p + 8, 0, 248 + (size_t)nq * sizeof(int), st)); // kept / unit counts, statistics, the bucket counters
+			if (cl_out_flags) // (inner product: the tie flags of the abandoned finish were taken from truncated buckets)
+				MVS_HIP(hipMemsetAsync(cl_out_flags->count, 0, sizeof(int), st));
 		}
 	}
+	if (fb && !fb_done && cl_out_flags) // (the sorted pipeline below flags the boundary ties itself)
+		MVS_HIP(hipMemsetAsync(cl_out_flags->count, 0, sizeof(int), st));
 	if (fb_done) {
 		cl_emitted = true;
 		*pd1_out = nullptr;
@@ -747,8 +751,10 @@ void FlatIndex::grow(int64_t need, hipStream_t st) {
 	if (need <= cap)
 		return;
 	// doubling for chunked ingest (every growth re-allocates and copies all rows: 19 growths by 1.5 were 35-49 ms of a 10 M row
-	// ingest's 400), exactly `need` for an add larger than that
-	const int64_t nc = std::max<int64_t>(need, 2 * cap + 4096);
+	// ingest's 400), exactly `need` for an add larger than that.  Round 6: by FOUR while the store is below 2 GB (a growth costs ~ 3 ms of
+	// hipMalloc under faiss_lock whatever its size: 14 of them were 39 of a 10 M-row ingest's 275 ms; 288 GB of HBM can afford the slack)
+	const int64_t row_bytes = (int64_t)geom.dp * 4;
+	const int64_t nc = std::max<int64_t>(need, (cap * row_bytes < ((int64_t)2 << 30) ? 4 : 2) * cap + 4096);
 	float *nv = nullptr, *nn = nullptr;
 	// +64 floats: the LDS-DMA staging reads whole 64-float pieces and may run past the last row
 	MVS_HIP(hipMalloc((void **)&nv, ((size_t)nc * geom.dp + 64) * sizeof(float)));
@@ -767,7 +773,7 @@ void FlatIndex::grow(int64_t need, hipStream_t st) {
 	cap = nc;
 }
 void FlatIndex::retire_buffers(hipStream_t st, void *a, void *b) {
-	reap_retired(false);
+	// (not reaped here: hipFree waits for the whole device -- during an ingest that is a stall under faiss_lock; readers reap)
 	if (!a && !b)
 		return;
 	Retired r;
@@ -931,6 +937,8 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
                             const mvs_search_params *params, const int64_t *d_idmap, hipStream_t st) {
 	use_device();
 	TraceRange tr("mvs:flat_search");
+	if (!retired.empty())
+		reap_retired(false);
 	if (flush_adds()) // (rows staged by add() reach the device before anything reads them)
 		stream_wait(st, stream);
 	if (k <= 0)
@@ -1629,6 +1637,17 @@ bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D
 		last_search_stream = st;
 		have_last_search = true;
 		ensure_h1_rows(st);
+		if (nq > 65536) { // (k-means assigns 10^6 training rows at once: in equal pieces of <= 64 K queries, the scratch stays that size)
+			const int64_t pieces = (nq + 65535) / 65536, per = ((nq + pieces - 1) / pieces + 63) / 64 * 64; // (>= 32 K each: never a < 20-query tail)
+			for (int64_t q0 = 0; q0 < nq;) {
+				int64_t m = std::min<int64_t>(per, nq - q0);
+				if (nq - q0 - m < 20)
+					m = nq - q0;
+				(void)coarse_topk(m, d_x + q0 * d, np, d_D + q0 * np, d_I + q0 * np, st, need_matrix);
+				q0 += m;
+			}
+			return true;
+		}
 		ws_qn.reserve((size_t)nq * sizeof(float));
 		ws_e2.reserve((size_t)((nq + 255) / 256 * 256) * sizeof(float));
 		ws_pfq.reserve(collect_qfrag_bytes(geom, nq));
@@ -1640,17 +1659,21 @@ bool FlatIndex::coarse_topk(int64_t nq, const float *d_x, int64_t np, float *d_D
 		launch_collect_query_prep(metric, d_x, nq, d, mu_h1, d_max_norm_bits, ws_pfq.p, (float *)ws_qn.p, (float *)ws_e2.p, fail_cnt, fail_q,
 		                          nullptr, 0, (int *)ws_seg.p, (int *)((char *)ws_seg.p + 256), st);
 		const size_t cb = (coarse_bf16_cand_bytes(nq) + 255) & ~(size_t)255, nb = ((size_t)nq * sizeof(int) + 255) & ~(size_t)255;
-		const bool fresh = ws_cb16.cap < cb + nb + 64;
-		ws_cb16.reserve(cb + nb + 64);
+		const size_t lb = (coarse_bf16_cls_bytes(nq, ntotal, np) + 255) & ~(size_t)255;
+		// (the exhaustive-query counter sits at the FRONT: the buffer's layout behind it changes with nq)
+		const bool fresh = ws_cb16.cap < 256 + cb + nb + lb;
+		ws_cb16.reserve(256 + cb + nb + lb);
 		if (fresh)
-			MVS_HIP(hipMemsetAsync((char *)ws_cb16.p + cb + nb, 0, 64, st)); // (the exhaustive-query counter)
-		cb16_stats_off = cb + nb;
+			MVS_HIP(hipMemsetAsync(ws_cb16.p, 0, 256, st));
+		cb16_stats_off = 0;
+		char *const cbase = (char *)ws_cb16.p + 256;
 		begin_kernel_timing(st);
 		launch_coarse_bf16(d_x, nq, d, ws_pfq.p, (const float *)ws_qn.p, (const float *)ws_e2.p, vecs_h1, beta_h1, vecs, geom.dp,
-		                   geom.pair_interleaved ? 1 : 0, norms, ntotal, np, (unsigned short *)ws_cb16.p, (int *)((char *)ws_cb16.p + cb), d_D, d_I,
-		                   label_offset, (unsigned long long *)((char *)ws_cb16.p + cb + nb), st);
+		                   geom.pair_interleaved ? 1 : 0, norms, ntotal, np, (unsigned short *)cbase, (int *)(cbase + cb), (float *)(cbase + cb + nb), d_D, d_I,
+		                   label_offset, (unsigned long long *)ws_cb16.p, st);
 		end_kernel_timing(st);
 		cb16_queries += nq;
+		cb16_last_nq = nq, cb16_ccount_off = 256 + cb;
 		return true;
 	}
 	// inner product: one entry more than asked for, the merge flags boundary ties and resolve_ip_ties replays FAISS's heap
@@ -1821,7 +1844,8 @@ void IDMapIndex::add_device(int64_t, const float *, hipStream_t) {
 void IDMapIndex::grow_ids(int64_t need, hipStream_t st) {
 	if (need <= idcap)
 		return;
-	const int64_t nc = std::max<int64_t>(need, 2 * idcap + 4096); // (as FlatIndex::grow)
+	// (as FlatIndex::grow; by eight while the array is below 64 MB: every growth ends in a hipFree that waits for the device)
+	const int64_t nc = std::max<int64_t>(need, (idcap < ((int64_t)8 << 20) ? 8 : 2) * idcap + 4096);
 	int64_t *ni = nullptr;
 	MVS_HIP(hipMalloc((void **)&ni, (size_t)nc * sizeof(int64_t)));
 	flush_ids(); // (staged ids go to the old array first: the copy below carries them over)
@@ -2377,7 +2401,7 @@ int mvs_index_get_stat(mvs_index *ix, const char *name, int64_t *value) {
 		p = static_cast<IDMapIndex *>(p)->sub;
 	if (!name || !value)
 		throw_faiss("mvs_index_get_stat", __FILE__, "null argument");
-	if (!strcmp(name, "coarse_bf16_queries") || !strcmp(name, "coarse_bf16_exhaustive")) {
+	if (!strcmp(name, "coarse_bf16_queries") || !strcmp(name, "coarse_bf16_exhaustive") || !strcmp(name, "coarse_bf16_candidates")) {
 		// IVF: queries whose coarse quantisation ran on csrc/coarse_bf16.hip / of those, computed against every centroid
 		IndexBase *qz = ivf_quantizer_of(p);
 		if (!qz || qz->kind != MVS_KIND_FLAT)
@@ -2385,9 +2409,20 @@ int mvs_index_get_stat(mvs_index *ix, const char *name, int64_t *value) {
 		auto *f = static_cast<FlatIndex *>(qz);
 		if (!strcmp(name, "coarse_bf16_queries")) {
 			*value = f->cb16_queries;
+		} else if (!strcmp(name, "coarse_bf16_candidates")) { // candidates re-scored exactly in the LAST call (its last piece), summed
+			int64_t sum = 0;
+			if (f->ws_cb16.p && f->cb16_last_nq > 0) {
+				f->use_device();
+				MVS_HIP(hipDeviceSynchronize());
+				std::vector<int> cc((size_t)f->cb16_last_nq);
+				MVS_HIP(hipMemcpy(cc.data(), (const char *)f->ws_cb16.p + f->cb16_ccount_off, cc.size() * sizeof(int), hipMemcpyDeviceToHost));
+				for (int v : cc)
+					sum += v > 0 ? v : 0;
+			}
+			*value = sum;
 		} else {
 			unsigned long long v = 0;
-			if (f->ws_cb16.p && f->cb16_stats_off) {
+			if (f->ws_cb16.p) {
 				f->use_device();
 				MVS_HIP(hipDeviceSynchronize());
 				MVS_HIP(hipMemcpy(&v, (const char *)f->ws_cb16.p + f->cb16_stats_off, sizeof v, hipMemcpyDeviceToHost));

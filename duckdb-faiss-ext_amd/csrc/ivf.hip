@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <random>
+#include <atomic>
 #include <thread>
 
 namespace mvs {
@@ -305,10 +306,33 @@ public:
 			            "Error: 'nx >= k' failed: Number of training points (%ld) should be at least as large as number "
 			            "of clusters (%ld)",
 			            (long)nx, (long)k);
-		for (int64_t i = 0; i < nx * d; i++)
-			if (!std::isfinite(x_in[i]))
+		{
+			// FAISS checks EVERY training value on the host (faiss/Clustering.cpp); 1.28 G values at C3's ingest: split over threads
+			const int64_t tot = nx * d;
+			const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(16, std::min<int64_t>(std::thread::hardware_concurrency(), tot >> 22)));
+			std::atomic<bool> bad(false);
+			auto scan = [&](int64_t b, int64_t e) {
+				bool ok = true;
+				for (int64_t i = b; i < e && ok; i += 4096) {
+					const int64_t m = std::min<int64_t>(e, i + 4096);
+					float acc = 0.f; // (x * 0 is 0 for every finite x, NaN otherwise: a branch-free pass the compiler vectorises)
+					for (int64_t j = i; j < m; ++j)
+						acc += x_in[j] * 0.0f;
+					ok = acc == 0.f;
+				}
+				if (!ok)
+					bad.store(true);
+			};
+			std::vector<std::thread> th;
+			for (int t = 1; t < nt; ++t)
+				th.emplace_back(scan, tot * t / nt, tot * (t + 1) / nt);
+			scan(0, tot / nt);
+			for (auto &t : th)
+				t.join();
+			if (bad.load())
 				throw_faiss("virtual void faiss::Clustering::train_encoded(...)", "faiss/Clustering.cpp",
 				            "input contains NaN's or Inf's");
+		}
 		std::vector<float> sub;
 		const float *x = x_in;
 		if (nx > k * max_pts) { // subsample_training_set
@@ -353,7 +377,10 @@ public:
 		const size_t wsb = kmeans_update_ws_bytes(nx, k);
 		dws.reserve(wsb);
 		for (int it = 0; it < niter; it++) {
-			qz->search_device(nx, (const float *)dx.p, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
+			// (round 6: the assignment is a Flat search with k = 1 over a few thousand rows -- csrc/coarse_bf16.hip serves it, same labels)
+			if (!qz->coarse_topk(nx, (const float *)dx.p, 1, (float *)dD.p, (int64_t *)dI.p, stream, false))
+				qz->search_device(nx, (const float *)dx.p, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
+			use_device();
 			// compute_centroids on device in FAISS's summation order (csrc/kmeans_update.hip); only the k x d
 			// centroids and the k counts come back for the (rare, RNG-driven) empty-cluster splits
 			launch_kmeans_update((const float *)dx.p, nx, d, (const int64_t *)dI.p, k, (float *)dcent.p, (float *)dhass.p,
@@ -441,7 +468,9 @@ public:
 		ids_h.reserve((size_t)(ntotal + n));
 		for (int64_t i0 = 0; i0 < n; i0 += bs) {
 			const int64_t nb = std::min(bs, n - i0);
-			quantizer->search_device(nb, d_x + i0 * d, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
+			if (!(hnsw_M == 0 && static_cast<FlatIndex *>(quantizer)->coarse_topk(nb, d_x + i0 * d, 1, (float *)dD.p, (int64_t *)dI.p, stream, false)))
+				quantizer->search_device(nb, d_x + i0 * d, 1, (float *)dD.p, (int64_t *)dI.p, nullptr, stream);
+			use_device();
 			MVS_HIP(hipMemcpyAsync(lab.data(), dI.p, (size_t)nb * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 			launch_pad_rows(d_x + i0 * d, nb, d, raw + (size_t)(ntotal + i0) * dp, dp, stream);
 			MVS_HIP(hipStreamSynchronize(stream));

@@ -110,7 +110,8 @@ class ShardExchange:
             pad = torch.zeros((self.nq_g - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
             pad[..., 1] = -1
             rec = torch.cat([rec, pad], dim=0)
-        dist.all_gather_into_tensor(self.grec.view(self.world * self.nq_g, self.kk, 2), rec, group=self.group)
+        with mf.trace_range("mvs:exchange (all_gather of 16-byte records)"):  # (roctx: shows up in rocprofv3 --marker-trace)
+            dist.all_gather_into_tensor(self.grec.view(self.world * self.nq_g, self.kk, 2), rec, group=self.group)
         if self.rank != merge_rank:
             return
         if self.grec.is_cuda and self.metric is not None and not self.ip_ties:
@@ -141,6 +142,10 @@ class ShardExchange:
         D, I, ev = pend
         if self.world == 1:
             return D.cpu().numpy(), I.cpu().numpy()
+        with mf.trace_range("mvs:merge (wait for the records + k-way merge)"):
+            return self._merge_host_body(metric, D, I, ev)
+
+    def _merge_host_body(self, metric, D, I, ev):
         if ev is not None:
             ev.synchronize()
         if isinstance(D, str):  # merged on the device by gather_async

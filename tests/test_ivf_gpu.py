@@ -766,3 +766,20 @@ def test_grouping_by_lds_histograms_at_an_odd_list_count(mf, metric):
         D, I = g.search(xq[:nq], 10, nprobe=nprobe)
         assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
         assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (nq, nprobe)
+
+
+@pytest.mark.parametrize("where", ["first", "middle", "last"])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_training_rejects_non_finite_values_wherever_they_sit(mf, where, bad):
+    """faiss/Clustering.cpp train_encoded checks EVERY training value ("input contains NaN's or Inf's"); the check runs on several host
+    threads since round 6 -- a bad value in any thread's part, also the array's very last float, must be found."""
+    d, n = 32, 300_000  # 9.6 M floats: more than one thread's share
+    x = np.random.RandomState(1).rand(n, d).astype(np.float32)
+    pos = {"first": (0, 0), "middle": (n // 2 + 17, 5), "last": (n - 1, d - 1)}[where]
+    x[pos] = bad
+    ix = mf.index_factory(d, "IVF64,Flat", L2)
+    with pytest.raises(mf.FaissException, match="input contains NaN's or Inf's"):
+        ix.train(x)
+    x[pos] = 0.5
+    ix.train(x)  # (and the clean array trains)
+    assert ix.is_trained

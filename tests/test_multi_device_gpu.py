@@ -94,3 +94,32 @@ def test_bench_self_launch_two_ranks_over_rccl(mf):
     col = j["config"]["collective"]
     assert col["backend"] == "nccl" and col["world_size"] == 2 and col["allreduce_of_ones"] == 2 and col["distinct_devices"] == 2, col
     assert j["merged_labels_bit_exact_vs_oracle"] is True and j["merged_distances_bit_exact_vs_oracle"] is True
+
+
+@pytest.mark.parametrize("exchange", [0, 1])
+def test_c4_shape_flat_ip_768_on_distinct_devices(mf, exchange):
+    """BASELINE.json configs[3] in small: IndexFlatIP d=768 k=10 row-sharded over every visible device (round 6) -- each
+    shard's search runs flat_bf16_big_kernel (the wide stores' coarse filter), the records travel by peer copy / one ncclAllGather, the
+    merge replays FAISS's inner-product tie rule across shards.  Normalised rows with duplicates: exact ties at the k-th score."""
+    have = _need(mf, 2)
+    G = min(have, 8)
+    d, nb, nq, k = 768, 80_000 * G, 256, 10
+    rs = np.random.RandomState(768 + exchange)
+    xb = rs.randn(nb, d).astype(np.float32)
+    xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+    xb[rs.randint(0, nb, 2000)] = xb[rs.randint(0, nb, 2000)]
+    xq = np.concatenate([rs.randn(nq - 40, d).astype(np.float32), xb[rs.randint(0, nb, 40)]])
+    xq /= np.linalg.norm(xq, axis=1, keepdims=True)
+    one, sh = mf.index_factory(d, "Flat", IP), mf.index_factory(d, "Flat", IP)
+    sh.shard_to_gpus(list(range(G)))
+    sh.set_option("shard_exchange", exchange)
+    for a in (one, sh):
+        a.set_option("prefilter", 2)
+        for i0 in range(0, nb, 1 << 16):
+            a.add(xb[i0 : i0 + (1 << 16)])
+    ref = one.search(xq, k)
+    assert one.last_kernel_info()["name"] == "flat_bf16_big_kernel"
+    _same(sh.search(xq, k), ref, "C4 shape on %d devices (exchange %d) vs one device" % (G, exchange))
+    assert sh.last_kernel_info()["name"] == "flat_bf16_big_kernel"
+    Do, Io = orc.flat_search(IP, xb, xq[:32], k, force_path=orc.PATH_BLAS)
+    assert np.array_equal(ref[1][:32], Io) and np.array_equal(ref[0][:32].view(np.uint32), Do.view(np.uint32))

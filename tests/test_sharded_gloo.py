@@ -247,3 +247,59 @@ def test_ivf_row_shards_exact_ties_across_processes(metric, world):
     mp.spawn(_ivf_tie_worker, args=(world, port, metric, ret), nprocs=world, join=True)
     assert ret["tied_queries"] > 10, dict(ret)
     assert ret["same_D"] and ret["same_I"], dict(ret)
+
+
+def _c4_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "duckdb-faiss-ext_amd", "pyhost"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from sharded import ShardExchange, shard_bounds
+
+    orc.set_num_threads(2)
+    IP = orc.METRIC_INNER_PRODUCT
+    n, d, nq, k = 8000, 768, 48, 10
+    rs = np.random.RandomState(4)
+    xb = rs.randn(n, d).astype(np.float32)
+    xb /= np.linalg.norm(xb, axis=1, keepdims=True)
+    xb[rs.randint(0, n, 600)] = xb[rs.randint(0, n, 600)]  # duplicated rows land in different shards: exact ties at the k-th score
+    xq = np.concatenate([rs.randn(nq - 16, d).astype(np.float32), xb[rs.randint(0, n, 16)]])
+    xq /= np.linalg.norm(xq, axis=1, keepdims=True)
+    r0, r1 = shard_bounds(n, rank, world)
+    # the shard's pure-order k + 1 list in the ORACLE's arithmetic (k-ordered chains: what the device's exact re-scoring produces)
+    Dp, Ip = orc.flat_search(IP, xb[r0:r1], xq, min(k + 1, r1 - r0), force_path=orc.PATH_BLAS)
+    kk = Dp.shape[1]
+    order = np.lexsort((Ip, -Dp), axis=1)  # (score desc, row asc) -- the kernels' pure order
+    Dp, Ip = np.take_along_axis(Dp, order, axis=1), np.take_along_axis(Ip, order, axis=1) + r0
+    assert kk == k + 1
+
+    def tie_candidates(xf, T):
+        out = np.full((len(T), k), -1, dtype=np.int64)
+        Df, If = orc.flat_search(IP, xb[r0:r1], xf.numpy(), min(256, r1 - r0), force_path=orc.PATH_BLAS)
+        for f in range(len(T)):
+            rows = np.sort(If[f][Df[f] >= T[f].item()])[:k] + r0
+            out[f, : len(rows)] = rows
+        return torch.from_numpy(out)
+
+    xch = ShardExchange(nq, k, "cpu", ip_ties=True)
+    Dm, Im = xch.merge_ip_exact(torch.from_numpy(Dp.copy()), torch.from_numpy(Ip.copy()), torch.from_numpy(xq), tie_candidates)
+    if rank == 0:
+        Dr, Ir = orc.flat_search(IP, xb, xq, k, force_path=orc.PATH_BLAS)
+        D11, _ = orc.flat_search(IP, xb, xq, k + 1, force_path=orc.PATH_BLAS)
+        ret["same_D"] = bool(np.array_equal(Dm.view(np.uint32), Dr.view(np.uint32)))
+        ret["same_I"] = bool(np.array_equal(Im, Ir))
+        ret["tied"] = int((D11[:, k - 1] == D11[:, k]).sum())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_shape_flat_ip_768_four_ranks():
+    """BASELINE.json configs[3] in small (IndexFlatIP d=768 k=10, row shards + all-gather merge): four gloo ranks, the
+    shards' lists in the oracle's arithmetic, boundary ties between shards resolved by the second exchange -- equals the unsharded search."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 36100 + (os.getpid() % 2000)
+    mp.spawn(_c4_worker, args=(4, port, ret), nprocs=4, join=True)
+    assert ret["same_D"] and ret["same_I"], dict(ret)

@@ -34,5 +34,8 @@ for mode in (1, 0, 1, 0):
     print(f"ivf_coarse_bf16={mode}: {ms:.3f} ms per {nq}-query search (N={n}, nlist={nlist}, nprobe={nprobe})", flush=True)
     res.setdefault(mode, (D.clone(), I.clone()))
 same = torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0].view(torch.int32), res[1][0].view(torch.int32))
-print("bit-equal:", same, " coarse_bf16_queries:", ix.get_stat("coarse_bf16_queries"), " exhaustive:", ix.get_stat("coarse_bf16_exhaustive"))
+ix.set_option("ivf_coarse_bf16", 1)
+ix.search_torch(xq, k, nprobe=nprobe)
+print("bit-equal:", same, " coarse_bf16_queries:", ix.get_stat("coarse_bf16_queries"), " exhaustive:", ix.get_stat("coarse_bf16_exhaustive"),
+      " candidates per query (last search):", ix.get_stat("coarse_bf16_candidates") / nq)
 sys.exit(0 if same else 1)

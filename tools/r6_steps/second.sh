@@ -9,7 +9,7 @@ timeout 300 python tools/coarse_bench.py > gpurun_out/r6_coarse_bench.log 2>&1; 
 cat gpurun_out/r6_coarse_bench.log
 timeout 900 python -m pytest -x -q -m gpu tests/test_ivf_gpu.py tests/test_ivf_probe_prune_gpu.py "tests/test_configs_gpu.py::test_c3_ivf4096_10m_nprobe32" > gpurun_out/r6_ivf_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r6_ivf_tests.log
 tail -5 gpurun_out/r6_ivf_tests.log
-ROWS=10000000 ARGS="--index IVF4096,Flat --data clustered" TAG=c3 bash tools/r5_steps/kstats.sh gpurun_out > /dev/null 2>&1
-ROWS=10000000 ARGS="--metric IP" TAG=hip STEPS=5 WARMUP=2 bash tools/r5_steps/kstats.sh gpurun_out > /dev/null 2>&1
+ROWS=10000000 ARGS="--index IVF4096,Flat --data clustered" TAG=c3 bash tools/kstats.sh gpurun_out > /dev/null 2>&1
+ROWS=10000000 ARGS="--metric IP" TAG=hip STEPS=5 WARMUP=2 bash tools/kstats.sh gpurun_out > /dev/null 2>&1
 tail -25 gpurun_out/kstats_c3.txt; tail -25 gpurun_out/kstats_hip.txt
 cat gpurun_out/r6_dbg_shadow.log | cut -c1-400

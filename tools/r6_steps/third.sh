@@ -11,7 +11,7 @@ timeout 900 python -m pytest -x -q -m gpu tests/test_coarse_matrix_gpu.py tests/
 tail -12 $O/r6_third_tests.log | cut -c1-300
 for t in 8 1; do MVS_INGEST_PROFILE=1 duckdb-faiss-ext_amd/host/boundary_driver ingest 10000000 128 $t IDMap,Flat 2>&1 | grep -E "ingestprofile|ingestrate|ingest\s" ; done | tee $O/r6_ingest.log
 duckdb-faiss-ext_amd/host/boundary_driver ingest 10000000 128 8 Flat 2>&1 | grep -E "ingestrate|ingest\s" | tee -a $O/r6_ingest.log
-ROWS=10000000 ARGS="--index IVF4096,Flat --data clustered" TAG=c3 bash tools/r5_steps/kstats.sh $O > /dev/null 2>&1
-ROWS=10000000 ARGS="--metric IP" TAG=hip STEPS=5 WARMUP=2 bash tools/r5_steps/kstats.sh $O > /dev/null 2>&1
+ROWS=10000000 ARGS="--index IVF4096,Flat --data clustered" TAG=c3 bash tools/kstats.sh $O > /dev/null 2>&1
+ROWS=10000000 ARGS="--metric IP" TAG=hip STEPS=5 WARMUP=2 bash tools/kstats.sh $O > /dev/null 2>&1
 tail -22 $O/kstats_c3.txt | cut -c1-160; tail -16 $O/kstats_hip.txt | cut -c1-160
 grep -o '"ms_per_step": [0-9.]*' $O/kstats_c3.json $O/kstats_hip.json
