@@ -761,7 +761,7 @@ def main():
             # HBM bytes per launch come from the committed PMC passes of this same workload (PMC counters cannot be
             # collected from inside the process); null for any other workload
             traffic, traffic_src = None, None
-            tname = next((t for t in ("r5_traffic.json", "r4_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r4_traffic.json")
+            tname = next((t for t in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r4_traffic.json")
             tpath = os.path.join(ROOT, "profiles", tname)
             pmc_entry = None
             if os.path.exists(tpath) and world == 1 and chunk == nq and not args.opt and args.efconstruction == 0:

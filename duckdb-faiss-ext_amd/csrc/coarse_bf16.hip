@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void coarse_bf16_filter_kernel(const Coarse
 	__shared__ __attribute__((aligned(16))) unsigned char tile_s[2][64 * CB16_ROWB];
 	__shared__ __attribute__((aligned(16))) float beta_s[2][64];
 	__shared__ float thr_s[CB16_QB];
-	__shared__ int cnt_s[CB16_QB];
+	__shared__ int cnt_s[CB16_QB], base_s[CB16_QB];
 	__shared__ unsigned short cand_s[PASS == 2 ? CB16_QB : 1][CB16_LCAP];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int col = lane & 15, rg = lane >> 4;
@@ -201,25 +201,32 @@ __global__ __launch_bounds__(256, 2) void coarse_bf16_filter_kernel(const Coarse
 	if (rg == 0) // (the counts of the wave's own 32 queries)
 		cnt_s[32 * wave + col] = hc[0], cnt_s[32 * wave + 16 + col] = hc[1];
 	__syncthreads();
-	// the slice's lists -> the queries' global lists: ONE returning atomic per (query, slice) that has candidates
-	for (int qi = 32 * wave; qi < 32 * wave + 32; ++qi) {
+	// the slice's lists -> the queries' global lists: ONE returning atomic per (query, slice) that has candidates -- lane l < 32 reserves
+	// for the wave's query l, all 32 atomics in flight at once (v3b walked the 32 queries one by one behind 32 round trips: 25 us)
+	{
+		const int qi = 32 * wave + (lane & 31);
 		const long long q = q0 + qi;
-		if (q >= a.nq)
-			continue;
 		const int n = cnt_s[qi];
 		const bool finite = thr_s[qi] == thr_s[qi];
-		if (!finite) {
-			if (slice == 0 && lane == 0)
-				a.ccount[q] = -(1 << 30); // (nothing passed anywhere: no other workgroup touches the counter)
-			continue;
-		}
-		if (n == 0)
-			continue;
 		int base = 0;
-		if (lane == 0) // (an overflowing slice pushes the count past CAP: the exact kernel then computes every centroid of the query)
-			base = atomicAdd(a.ccount + q, n > CB16_LCAP ? CB16_CAP + 1 : n);
-		base = __builtin_amdgcn_readfirstlane(base);
-		if (n <= CB16_LCAP && lane < n && base + lane < CB16_CAP)
+		if (lane < 32 && q < a.nq) {
+			if (!finite) {
+				if (slice == 0)
+					a.ccount[q] = -(1 << 30); // (nothing passed anywhere: no other workgroup touches the counter)
+			} else if (n > 0) { // (an overflowing slice pushes the count past CAP: the exact kernel then computes every centroid of the query)
+				base = atomicAdd(a.ccount + q, n > CB16_LCAP ? CB16_CAP + 1 : n);
+			}
+			base_s[qi] = base;
+		}
+	}
+	asm volatile("" ::: "memory"); // (base_s of the wave's own queries: written and read by this wave only)
+	for (int qi = 32 * wave; qi < 32 * wave + 32; ++qi) {
+		const long long q = q0 + qi;
+		const int n = cnt_s[qi];
+		if (q >= a.nq || n == 0 || n > CB16_LCAP || !(thr_s[qi] == thr_s[qi]))
+			continue;
+		const int base = base_s[qi];
+		if (lane < n && base + lane < CB16_CAP)
 			a.cand[(size_t)q * CB16_CAP + base + lane] = cand_s[qi][lane];
 	}
 }

@@ -153,6 +153,7 @@ void launch_scatter_rows(const int *d_fq, int nf, int64_t k, const float *d_Df, 
 
 // Flat shadow (ARITH = 2): query norms, row norms (k-ordered chains of the ORIGINAL rows, by position in the list-sorted store) and
 // the rows' numbers in the Flat index -- the key's low word is the ROW NUMBER, so that equal values order by id as FAISS's L2 heap does
+constexpr int CL_OUTL_CAP = 256; // outlier rows kept out of a Flat index's bf16 store and in every query's candidate set (csrc/flat_collect.hip)
 struct IvfFlatArith {
 	const float *qn;
 	const float *yn;

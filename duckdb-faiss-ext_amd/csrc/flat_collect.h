@@ -54,7 +54,7 @@ size_t collect_big_lds_bytes(int dp1);
 void launch_collect_big(int dp1, int metric, bool collect, const CollectArgs &a, int grid, hipStream_t st);
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
                               const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
-                              unsigned *d_max_norm_bits, hipStream_t st);
+                              unsigned *d_max_norm_bits, hipStream_t st, int *d_outl);
 void launch_collect_exact_wide(int metric, bool per_pair, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d,
                                const float *d_vecs, int sdp, int interleaved, const float *d_norms, const float *d_qn, hipStream_t st,
                                const unsigned long long *d_cnt = nullptr);

@@ -90,14 +90,93 @@ template <int CTRL>
 __device__ __forceinline__ float cl_dpp(float v) {
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
+// ---- outlier rows (round 6) --------------------------------------------------------------------------------
+// E(q) scales with the LARGEST ||y'|| of the store: one row of 100 x the usual norm made every query admit thousands of rows (the
+// stream overflowed, the batch fell to the bf16x3 / exact kernels: 17.5 -> 602 ms per batch at the headline, tools/collect_sensitivity.py
+// "outlier").  A row whose ||y'||^2 exceeds tau = 64 x the mean ||y'||^2 of the rows present when the store is first built (at most
+// CL_OUTL_CAP of them) is kept OUT of the store -- zero vector, beta = -inf: never a candidate, never evidence for a bound, not in the
+// maxima -- and IN every query's candidate set: collect_append_outliers_kernel puts (query, row) for every outlier row behind the scan's
+// entries in the candidate stream, so the exact stage scores it like any other candidate.  max_bits[2] = the largest ||y||^2 over the
+// rows that ARE in the store (the bound's S term), max_bits[3] = tau (float bits; +inf: no outlier handling -- small stores, the IVF
+// quantiser's centroids); outl[0] = count, outl[1 ..] = rows.
+__global__ void collect_outlier_threshold_kernel(const float *__restrict__ norms, long long nrows, const float *__restrict__ mu, int dp,
+                                                 unsigned *__restrict__ max_bits) {
+	__shared__ double part[256];
+	double acc = 0.0;
+	for (long long i = threadIdx.x; i < nrows; i += 256)
+		acc += (double)norms[i];
+	part[threadIdx.x] = acc;
+	__syncthreads();
+	for (int o = 128; o >= 1; o >>= 1) {
+		if (threadIdx.x < o)
+			part[threadIdx.x] += part[threadIdx.x + o];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		double mun = 0.0;
+		for (int k = 0; k < dp; ++k)
+			mun += (double)mu[k] * (double)mu[k];
+		// mean ||y - mu||^2 over the rows mu was averaged over = mean ||y||^2 - ||mu||^2
+		const double mean_c = part[0] / (double)(nrows > 0 ? nrows : 1) - mun;
+		const float tau = mean_c > 0.0 && mean_c < 1e30 ? (float)(64.0 * mean_c) : INFINITY; // (degenerate data: no outlier handling)
+		max_bits[3] = __float_as_uint(tau);
+	}
+}
+void launch_collect_outlier_threshold(const float *d_norms, int64_t nrows, const float *d_mu, int dp, unsigned *d_max_norm_bits, hipStream_t st) {
+	hipLaunchKernelGGL(collect_outlier_threshold_kernel, dim3(1), dim3(256), 0, st, d_norms, (long long)nrows, d_mu, dp, d_max_norm_bits);
+	MVS_HIP(hipGetLastError());
+}
+// (query, outlier row) for every query and every recorded outlier row behind the scan's entries; value +inf: they pass every
+// final-bound filter.  SEL: rows the IDSelector rejects are left out.
+__global__ __launch_bounds__(256) void collect_append_outliers_kernel(const int *__restrict__ outl, int nq, unsigned long long *__restrict__ stream,
+                                                                      float *__restrict__ stream_s, unsigned long long *__restrict__ cnt,
+                                                                      long long cap, const unsigned long long *__restrict__ rowmask) {
+	__shared__ unsigned long long base_s;
+	const int no = outl[0] < CL_OUTL_CAP ? outl[0] : CL_OUTL_CAP;
+	const long long total = (long long)nq * no;
+	for (long long b0 = (long long)blockIdx.x * 256; b0 < total; b0 += (long long)gridDim.x * 256) {
+		const long long i = b0 + threadIdx.x;
+		const int q = (int)(i / no), j = (int)(i - (long long)q * no);
+		const unsigned row = i < total ? (unsigned)outl[1 + j] : 0u;
+		const bool ok = i < total && (!rowmask || ((rowmask[row >> 6] >> (row & 63u)) & 1ull));
+		const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+		__shared__ int wsum[4];
+		if ((threadIdx.x & 63) == 0)
+			wsum[threadIdx.x >> 6] = __builtin_popcountll(m);
+		__syncthreads();
+		if (threadIdx.x == 0)
+			base_s = atomicAdd(cnt, (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+		__syncthreads();
+		int wb = 0;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); ++w)
+			wb += wsum[w];
+		const long long pos = (long long)base_s + wb + __builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+		if (ok && pos < cap) {
+			stream[pos] = ((unsigned long long)(unsigned)q << 32) | row;
+			if (stream_s)
+				stream_s[pos] = INFINITY;
+		}
+		__syncthreads();
+	}
+}
+void launch_collect_append_outliers(const int *d_outl, int n_outliers, int64_t nq, unsigned long long *d_stream, float *d_stream_s,
+                                    unsigned long long *d_cnt, int64_t cap, const unsigned long long *d_rowmask, hipStream_t st) {
+	if (n_outliers <= 0 || nq <= 0)
+		return;
+	const long long total = (long long)nq * std::min(n_outliers, CL_OUTL_CAP);
+	hipLaunchKernelGGL(collect_append_outliers_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 1024)), dim3(256), 0, st, d_outl, (int)nq,
+	                   d_stream, d_stream_s, d_cnt, (long long)cap, d_rowmask);
+	MVS_HIP(hipGetLastError());
+}
+
 // one thread per (row, 8 dims); the dp / 8 threads of a row are neighbours in a wave
 // max_bits[0]: largest squared norm of the ORIGINAL rows (shared with flat_bf16.hip), max_bits[8]: of the centred rows,
-// max_bits[12]: of the centred rows' bf16 rounding residuals y' - bf16(y')
+// max_bits[12]: of the centred rows' bf16 rounding residuals y' - bf16(y'); [2], [3], outl: see "outlier rows" above
 template <bool IS_L2>
 __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp, int dpd,
                                        int interleaved, const float *__restrict__ mu, unsigned short *__restrict__ dst,
                                        float *__restrict__ beta, const float *__restrict__ norms,
-                                       unsigned *__restrict__ max_bits) {
+                                       unsigned *__restrict__ max_bits, int *__restrict__ outl) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int g8 = dp / 8;
 	const bool live = i < nrows * g8;
@@ -141,12 +220,34 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 	}
 	if (!live)
 		return;
+	const unsigned b = __float_as_uint(norms[r]);
+	// (n2 is the whole row's sum in every one of its g8 threads; the first of them takes the slot, the others read it from its lane --
+	// the count may run past the capacity: rows beyond it stay in the store, and in the maxima)
+	const bool big = outl != nullptr && n2 > __uint_as_float(max_bits[3]);
+	int slot = CL_OUTL_CAP;
+	if (big && c8 == 0)
+		slot = atomicAdd(outl, 1);
+	slot = __shfl(slot, (int)(threadIdx.x & 63u) & ~(g8 - 1));
+	const bool out = big && slot < CL_OUTL_CAP;
+	if (out) {
+		if (c8 == 0)
+			outl[1 + slot] = (int)r;
+		const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+		*(bf16x8 *)(dst + (size_t)r * dpd + c8 * 8) = zero;
+		if (c8 == 0) {
+			beta[r] = -INFINITY;
+			if (b > max_bits[0])
+				atomicMax(max_bits, b);
+		}
+		return;
+	}
 	*(bf16x8 *)(dst + (size_t)r * dpd + c8 * 8) = hi; // (dpd = 128 >= dp: the store is zero-filled when it is allocated)
 	if (c8 == 0) {
 		beta[r] = IS_L2 ? -n2 : my;
-		const unsigned b = __float_as_uint(norms[r]);
 		if (b > max_bits[0])
 			atomicMax(max_bits, b);
+		if (b > max_bits[2])
+			atomicMax(max_bits + 2, b);
 		const unsigned bc = __float_as_uint(n2); // (>= 0 or NaN: the bit pattern orders like the value, NaN above everything)
 		if (bc > max_bits[8])
 			atomicMax(max_bits + 8, bc);
@@ -157,17 +258,17 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 }
 void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, int64_t row0, int64_t nrows, const float *d_mu,
                             unsigned short *d_bf, float *d_beta, const float *d_norms, unsigned *d_max_norm_bits,
-                            hipStream_t st) {
+                            hipStream_t st, int *d_outl) {
 	if (nrows <= 0)
 		return;
 	const long long total = (long long)nrows * (g.dp / 8);
 	const dim3 grid((unsigned)((total + 255) / 256));
 	if (metric == METRIC_L2)
 		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<true>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp, 128,
-		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
+		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits, d_outl);
 	else
 		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<false>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp, 128,
-		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
+		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits, d_outl);
 	MVS_HIP(hipGetLastError());
 }
 
@@ -267,7 +368,7 @@ __global__ void collect_bounds_kernel(const float *__restrict__ x, long long nq,
 		const float dl = a - (float)(__bf16)a;
 		dq2 = fmaf(dl, dl, dq2);
 	}
-	const float yn = __uint_as_float(max_norm_bits[0]), ync = __uint_as_float(max_norm_bits[8]);
+	const float yn = __uint_as_float(max_norm_bits[2]), ync = __uint_as_float(max_norm_bits[8]); // ([2]: over the rows IN the store)
 	const float dyc = __uint_as_float(max_norm_bits[12]);
 	const double u = 5.9604644775390625e-08, infl = 1.0001;
 	const double S = sqrt((double)xn * infl) * sqrt((double)yn * infl);
@@ -376,7 +477,7 @@ __global__ __launch_bounds__(256) void collect_query_prep_kernel(const float *__
 		if (q < nq) {
 			const float xn = part[0][tid], xnc = part[1][tid], mun = part[2][tid], dq2 = part[3][tid];
 			qn[q] = xn;
-			const float yn = __uint_as_float(max_norm_bits[0]), ync = __uint_as_float(max_norm_bits[8]);
+			const float yn = __uint_as_float(max_norm_bits[2]), ync = __uint_as_float(max_norm_bits[8]); // ([2]: over the rows IN the store)
 			const float dyc = __uint_as_float(max_norm_bits[12]);
 			const double u = 5.9604644775390625e-08, infl = 1.0001;
 			const double S = sqrt((double)xn * infl) * sqrt((double)yn * infl);

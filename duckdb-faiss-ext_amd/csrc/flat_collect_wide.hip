@@ -622,7 +622,8 @@ template <bool IS_L2>
 __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__restrict__ src, int sdp, int d, int dp1,
                                                                int interleaved, long long row0, long long nrows, const float *__restrict__ mu,
                                                                unsigned short *__restrict__ dst, float *__restrict__ beta,
-                                                               const float *__restrict__ norms, unsigned *__restrict__ max_bits) {
+                                                               const float *__restrict__ norms, unsigned *__restrict__ max_bits,
+                                                               int *__restrict__ outl) {
 	const long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	if (r >= row0 + nrows)
@@ -652,11 +653,36 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
 		my += __shfl_xor(my, o);
 		r2 += __shfl_xor(r2, o);
 	}
+	// outlier rows stay out of the store (csrc/flat_collect.hip "outlier rows"): zero vector, beta = -inf, not in the maxima
+	{
+		const float tau = __uint_as_float(max_bits[3]);
+		int slot = CL_OUTL_CAP;
+		if (n2 > tau && outl) {
+			if (lane == 0)
+				slot = atomicAdd(outl, 1);
+			slot = __shfl(slot, 0);
+		}
+		if (slot < CL_OUTL_CAP) {
+			const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+			for (int c8 = lane; c8 < dp1 / 8; c8 += 64)
+				*(bf16x8 *)(dst + (size_t)r * dp1 + c8 * 8) = zero;
+			if (lane == 0) {
+				outl[1 + slot] = (int)r;
+				beta[r] = -INFINITY;
+				const unsigned b = __float_as_uint(norms[r]);
+				if (b > max_bits[0])
+					atomicMax(max_bits, b);
+			}
+			return;
+		}
+	}
 	if (lane == 0) {
 		beta[r] = IS_L2 ? -n2 : my;
 		const unsigned b = __float_as_uint(norms[r]);
 		if (b > max_bits[0])
 			atomicMax(max_bits, b);
+		if (b > max_bits[2])
+			atomicMax(max_bits + 2, b);
 		const unsigned bc = __float_as_uint(n2);
 		if (bc > max_bits[8])
 			atomicMax(max_bits + 8, bc);
@@ -667,16 +693,16 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
 }
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
                               const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
-                              unsigned *d_max_norm_bits, hipStream_t st) {
+                              unsigned *d_max_norm_bits, hipStream_t st, int *d_outl) {
 	if (nrows <= 0)
 		return;
 	const dim3 grid((unsigned)((nrows + 3) / 4));
 	if (metric == METRIC_L2)
 		hipLaunchKernelGGL(rows_to_bf16_wide_kernel<true>, grid, dim3(256), 0, st, d_vecs, sdp, d, dp1, interleaved, (long long)row0,
-		                   (long long)nrows, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
+		                   (long long)nrows, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits, d_outl);
 	else
 		hipLaunchKernelGGL(rows_to_bf16_wide_kernel<false>, grid, dim3(256), 0, st, d_vecs, sdp, d, dp1, interleaved, (long long)row0,
-		                   (long long)nrows, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits);
+		                   (long long)nrows, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits, d_outl);
 	MVS_HIP(hipGetLastError());
 }
 

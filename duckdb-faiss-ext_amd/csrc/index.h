@@ -222,6 +222,10 @@ public:
 	DevBuf ws_e2, ws_stream, ws_sorttmp, ws_seg, ws_rowmask, ws_items1, ws_qcount;
 	void ensure_bf16_rows(hipStream_t st);
 	void ensure_h1_rows(hipStream_t st);
+	int *d_outl = nullptr; // [1 + CL_OUTL_CAP] outlier rows of the coarse-filter store: count, rows (csrc/flat_collect.hip "outlier rows")
+	int h1_outliers = 0;   // ... their number as the host last read it (after a conversion)
+	int64_t outl_total = 0; // (diagnostics: mvs_index_get_stat "flat_outlier_rows")
+	bool outlier_rows = true; // option outlier_rows
 	// IVF coarse quantisation: the np nearest rows (L2, FAISS order) by distance matrix + selection (csrc/coarse_select.hip);
 	// false: shape not served, the caller uses search_device
 	// need_matrix: the caller reads coarse_matrix() afterwards (the Flat shadow's proof); otherwise L2 quantisers of 16 < d <= 128 take the
@@ -445,14 +449,18 @@ bool collect_supported(const FlatGeom &g);
 void launch_collect_mean(const FlatGeom &g, const float *d_vecs, int64_t nrows, float *d_mu, hipStream_t st);
 void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, int64_t row0, int64_t nrows, const float *d_mu,
                             unsigned short *d_bf, float *d_beta, const float *d_norms, unsigned *d_max_norm_bits,
-                            hipStream_t st);
+                            hipStream_t st, int *d_outl = nullptr);
+// outlier rows of the coarse-filter store (csrc/flat_collect.hip "outlier rows")
+void launch_collect_outlier_threshold(const float *d_norms, int64_t nrows, const float *d_mu, int dp, unsigned *d_max_norm_bits, hipStream_t st);
+void launch_collect_append_outliers(const int *d_outl, int n_outliers, int64_t nq, unsigned long long *d_stream, float *d_stream_s,
+                                    unsigned long long *d_cnt, int64_t cap, const unsigned long long *d_rowmask, hipStream_t st);
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
 const char *collect_wide_kernel_name(int dp1); // "flat_bf16_big_kernel" / "flat_bf16_wide_kernel" for a store pitch > 128
 int collect_store_dims(int d); // 128 / 256 / 384 / 512: row pitch of the bf16 store; 0: d is not served (csrc/flat_collect_wide.hip)
 int collect_wide_qblock(int dp1);
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
                               const float *d_mu, unsigned short *d_bf, float *d_beta, const float *d_norms,
-                              unsigned *d_max_norm_bits, hipStream_t st);
+                              unsigned *d_max_norm_bits, hipStream_t st, int *d_outl);
 size_t collect_qfrag_bytes_ex(int dp1, int qblock, int64_t nq);
 void launch_collect_pack_queries_ex(int d, int dp1, int qblock, int metric, const float *d_x, int64_t nq, const float *d_mu,
                                     void *d_qf, hipStream_t st);
@@ -518,16 +526,6 @@ void launch_collect_select(int metric, const unsigned long long *d_keys, const i
 void launch_ivf_rows_to_bf16(const float *d_res, int64_t nrows, int d, const int *d_list_of_blk64, unsigned short *d_bf,
                              float *d_beta, unsigned *d_list_max_bits /* [2 nlist] */, int64_t nlist, hipStream_t st);
 size_t ivf_collect_xi_bytes(int max_items);
-void launch_ivf_collect_pack_pairs(int metric, const float *d_x, int d, int64_t nq, int np, const int *d_slots, const void *d_items,
-                                   const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
-                                   float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st);
-void launch_ivf_collect_pack_nearest(int metric, const float *d_x, int d, int64_t nq, const int *d_slots, const void *d_items,
-                                     const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
-                                     float *d_igamma, float *d_ie2, int *d_qfail, int64_t nlist, hipStream_t st);
-void launch_ivf_collect_pack(int metric, const float *d_x, int d, const void *d_items, const int *d_nitems, int max_items, const int *d_qidx,
-                             const float *d_cent, const int *d_list_of_blk64, const unsigned *d_list_max_bits, void *d_xi,
-                             float *d_igamma, float *d_ie2, int *d_qfail, hipStream_t st, const int64_t *d_coarse, int np,
-                             float *d_ie2_pre, int64_t nlist);
 void launch_ivf_collect_pack2(int metric, const float *d_x, int d, int64_t nq, const int *d_slots0, const void *d_items0, void *d_xi0,
                               float *d_igamma0, float *d_ie20, const void *d_items1, const int *d_nitems1, int max_items1,
                               const int *d_qidx1, void *d_xi1, float *d_igamma1, float *d_ie21, const float *d_cent,
@@ -577,8 +575,6 @@ void launch_ivf_shadow_verify(const float *d_cmat, const float *d_cD, const int6
 size_t ivf_rowmask_bytes(int64_t nrows_mf);
 void launch_ivf_rowmask(SelectorDev sel, const int64_t *d_rowids_mf, const int *d_perm, const int64_t *d_idmap, int64_t nrows_mf,
                         void *d_mask, hipStream_t st);
-void launch_ivf_collect_exact(int metric, unsigned long long *d_sorted, int64_t ncand, const float *d_x, int d, const float *d_rows_csr,
-                              int dp_csr, const int *d_perm, hipStream_t st, const unsigned long long *d_cnt = nullptr);
 void launch_collect_flat_items(void *d_items, int *d_nitems, int *d_qidx, int64_t nq, int64_t n, hipStream_t st);
 DirectPlan plan_flat_direct_extra(const FlatGeom &g, int64_t nq, int64_t n, int64_t k);
 void launch_flat_direct_extra(const FlatGeom &g, const DirectPlan &p, int metric, float metric_arg, int d,

@@ -333,6 +333,10 @@ void FlatIndex::drop_bf16_rows() {
 	vecs_h1 = nullptr;
 	beta_h1 = mu_h1 = nullptr;
 	h1_cap = h1_rows = 0;
+	if (d_outl)
+		(void)hipFree(d_outl);
+	d_outl = nullptr;
+	h1_outliers = 0;
 	if (d_max_norm_bits)
 		(void)hipFree(d_max_norm_bits);
 	d_max_norm_bits = nullptr;
@@ -378,7 +382,19 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 	}
 	if (!mu_h1) { // the centre is fixed at the first build (any vector is valid; rows added later only fit it less well)
 		MVS_HIP(hipMalloc((void **)&mu_h1, (size_t)std::max(geom.dp, 1024) * sizeof(float)));
-		launch_collect_mean(geom, vecs, std::min<int64_t>(ntotal, (int64_t)1 << 20), mu_h1, st);
+		const int64_t nm = std::min<int64_t>(ntotal, (int64_t)1 << 20);
+		launch_collect_mean(geom, vecs, nm, mu_h1, st);
+		// ... and so is the outlier threshold tau = 64 x the mean ||y - mu||^2 of those rows (csrc/flat_collect.hip "outlier rows").  Only
+		// stores large enough for the coarse filter to matter: an IVF quantiser's centroids, which csrc/coarse_bf16.hip searches through
+		// this store too, are never taken out of it.
+		const unsigned inf_bits = 0x7f800000u;
+		MVS_HIP(hipMemcpyAsync(d_max_norm_bits + 3, &inf_bits, sizeof inf_bits, hipMemcpyHostToDevice, st));
+		if (ntotal >= 262144 && outlier_rows) {
+			MVS_HIP(hipMalloc((void **)&d_outl, (size_t)(1 + CL_OUTL_CAP) * sizeof(int)));
+			MVS_HIP(hipMemsetAsync(d_outl, 0, (size_t)(1 + CL_OUTL_CAP) * sizeof(int), st));
+			launch_collect_outlier_threshold(norms, nm, mu_h1, geom.d, d_max_norm_bits, st);
+		}
+		MVS_HIP(hipStreamSynchronize(st)); // (inf_bits is a stack variable)
 	}
 	if (ntotal > h1_cap || !vecs_h1) {
 		unsigned short *nb = nullptr;
@@ -404,10 +420,17 @@ void FlatIndex::ensure_h1_rows(hipStream_t st) {
 	}
 	if (dp1 > 128) // csrc/flat_collect_wide.hip
 		launch_rows_to_bf16_wide(metric, vecs, geom.dp, geom.pair_interleaved ? 1 : 0, d, dp1, h1_rows, ntotal - h1_rows, mu_h1, vecs_h1,
-		                         beta_h1, norms, d_max_norm_bits, st);
+		                         beta_h1, norms, d_max_norm_bits, st, d_outl);
 	else
-		launch_rows_to_bf16_hi(geom, metric, vecs, h1_rows, ntotal - h1_rows, mu_h1, vecs_h1, beta_h1, norms, d_max_norm_bits, st);
+		launch_rows_to_bf16_hi(geom, metric, vecs, h1_rows, ntotal - h1_rows, mu_h1, vecs_h1, beta_h1, norms, d_max_norm_bits, st, d_outl);
 	h1_rows = ntotal;
+	if (d_outl) { // (one 4-byte read per conversion: the scans' launch code needs to know whether there is anything to append)
+		int cnt = 0;
+		MVS_HIP(hipMemcpyAsync(&cnt, d_outl, sizeof cnt, hipMemcpyDeviceToHost, st));
+		MVS_HIP(hipStreamSynchronize(st));
+		h1_outliers = std::min(cnt, CL_OUTL_CAP);
+		outl_total = cnt;
+	}
 }
 
 // Coarse filter front half (csrc/flat_collect.hip): bound estimation pre-pass, the scan, candidates grouped by query and
@@ -542,6 +565,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, pbnd, st, &grid, &nsplit, &lds, stream_s);
 	}
 	end_kernel_timing(st);
+	if (h1_outliers > 0) // the rows kept out of the store join every query's candidates (csrc/flat_collect.hip "outlier rows")
+		launch_collect_append_outliers(d_outl, h1_outliers, nq, stream, stream_s, cnt, cap_entries, rowmask, st);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	cl_report_cnt = defer_count && cl_est_per_query > 0; // (deferred: the caller's report kernel carries the count, no copy of its own)
@@ -2401,7 +2426,11 @@ int mvs_index_get_stat(mvs_index *ix, const char *name, int64_t *value) {
 		p = static_cast<IDMapIndex *>(p)->sub;
 	if (!name || !value)
 		throw_faiss("mvs_index_get_stat", __FILE__, "null argument");
-	if (!strcmp(name, "coarse_bf16_queries") || !strcmp(name, "coarse_bf16_exhaustive") || !strcmp(name, "coarse_bf16_candidates")) {
+	if (!strcmp(name, "flat_outlier_rows")) { // rows of a Flat index kept out of its coarse-filter store (found so far; csrc/flat_collect.hip)
+		if (p->kind != MVS_KIND_FLAT)
+			throw_faiss("mvs_index_get_stat", __FILE__, "%s: not a Flat index", name);
+		*value = static_cast<FlatIndex *>(p)->outl_total;
+	} else if (!strcmp(name, "coarse_bf16_queries") || !strcmp(name, "coarse_bf16_exhaustive") || !strcmp(name, "coarse_bf16_candidates")) {
 		// IVF: queries whose coarse quantisation ran on csrc/coarse_bf16.hip / of those, computed against every centroid
 		IndexBase *qz = ivf_quantizer_of(p);
 		if (!qz || qz->kind != MVS_KIND_FLAT)
@@ -2749,6 +2778,10 @@ bool IndexBase::set_tuning(const char *key, int64_t v) {
 bool FlatIndex::set_option(const char *key, int64_t v) {
 	if (set_tuning(key, v))
 		return true;
+	if (!strcmp(key, "outlier_rows")) { // 0: no row is kept out of the coarse-filter store (round 5; takes effect at the store's next first build)
+		outlier_rows = v != 0;
+		return true;
+	}
 	if (!strcmp(key, "lazy_adds")) { // 0: every add() reaches the device at once (round 5's ingest, for A/B)
 		flush_adds();
 		lazy_adds = v != 0;

@@ -108,23 +108,7 @@ __global__ void ivf_list_mean_kernel(const float *__restrict__ rows, const long 
 	}
 }
 // selected (value, position) lists [nq][kk], best first -> D / I [nq][k] with labels = stored ids
-__global__ void ivf_emit_sorted_kernel(const float *pd1, const int *pi1, int kk, int k, long long total, const long long *rowids,
-                                       float *D, long long *I) {
-	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= total)
-		return;
-	const long long q = i / k;
-	const int j = (int)(i - q * k);
-	const int p = pi1[q * kk + j];
-	D[i] = pd1[q * kk + j];
-	I[i] = p >= 0 ? (rowids ? rowids[p] : (long long)p) : -1; // rowids == nullptr: the caller wants positions
-}
 // flagged queries -> list
-__global__ void ivf_compact_flags_kernel(const int *flags, int n, int *cnt, int *out) {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && flags[i])
-		out[atomicAdd(cnt, 1)] = i;
-}
 __global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *out_bits) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	float v = i < n ? norms[i] : 0.f;
@@ -777,7 +761,7 @@ public:
 			return;
 		}
 		// default: bf16 coarse filter on residual rows + exact scanner-arithmetic re-scoring (csrc/ivf_collect.hip)
-		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && (raw_pos && k > 1 ? k - 1 : k) <= (collect_k32 ? 32 : 16) && d <= 128 &&
+		if ((metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 && mfma_mode < 0 && !pf_suppressed && (raw_pos && k > 1 ? k - 1 : k) <= 32 && d <= 128 &&
 		    dp % 4 == 0 && dp <= 128 && nq * np < ((int64_t)1 << 26)) { // (faster than the scanner kernel from one query on)
 			if (collect_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
 				return;
@@ -935,35 +919,22 @@ public:
 	// bf16 coarse filter (csrc/ivf_collect.hip).  false: the candidate stream overflowed (the caller uses the scanner kernel).
 	bool collect_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                    const int64_t *d_idmap, hipStream_t st, int64_t np) {
-		// First without a host round trip behind the scan (the candidate count stays on the device, the sort is sized from the
-		// previous search of this index: csrc/flat_collect.hip launch_collect_group_est); if the count, read at the end, exceeds
-		// that size the search runs again the synchronous way.
-		if (cl_bucket && k <= 64) {
-			// round 5 (csrc/collect_bucket.h): candidates in per-query buckets, one kernel behind the scan -- nothing to estimate; a
-			// bucket that proved too small (the count is read at the search's one synchronisation) is grown and the pass repeated
-			cl_bpitch_try = 0;
-			cl_cap_try = 0;
-			for (int attempt = 0; attempt < 6; ++attempt) {
-				bool overflow = false;
-				if (shadow && attempt > 0) // (the caller's fail list holds the abandoned attempt's entries)
-					MVS_HIP(hipMemsetAsync(shadow->fail_cnt, 0, sizeof(int), stream));
-				const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, true, &overflow);
-				if (!overflow)
-					return ok;
-			}
-			return false;
-		}
-		if (cl_defer && cl_est_per_query > 0) {
+		// Candidates go to per-query buckets and ONE finish chain behind the scan (csrc/collect_bucket.h): nothing to estimate; a bucket or
+		// stream that proved too small (the counts are read at the search's one synchronisation) is grown and the pass repeated
+		cl_bpitch_try = 0;
+		cl_cap_try = 0;
+		for (int attempt = 0; attempt < 6; ++attempt) {
 			bool overflow = false;
-			const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, true, &overflow);
+			if (shadow && attempt > 0) // (the caller's fail list holds the abandoned attempt's entries)
+				MVS_HIP(hipMemsetAsync(shadow->fail_cnt, 0, sizeof(int), stream));
+			const bool ok = collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, &overflow);
 			if (!overflow)
 				return ok;
 		}
-		bool overflow = false;
-		return collect_search_pass(nq, d_x, k, d_D, d_I, params, d_idmap, st, np, false, &overflow);
+		return false;
 	}
 	bool collect_search_pass(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
-	                         const int64_t *d_idmap, hipStream_t st, int64_t np, bool defer, bool *overflow) {
+	                         const int64_t *d_idmap, hipStream_t st, int64_t np, bool *overflow) {
 		build_lists_mf(false);
 		if (!have_bfr)
 			return false;
@@ -978,60 +949,49 @@ public:
 		ws_items.reserve((size_t)max_items * 16);
 		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
 		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
-		// (round 4: the counters of BOTH groupings in one buffer, and one control block {stream count | fail count | per-query fail
-		// flags | per-query segments}: two memsets per search instead of seven)
+		// Both groupings (the nearest-list pre-pass and the main pass) in three launches (csrc/ivf_scan.hip launch_ivf_group2), both
+		// packings in one (launch_ivf_collect_pack2, which also sets the class slots neutral and clears the control block's header), and
+		// NO memset: the grouping counters are zeroed by the scatter kernel that last needed them, the per-query control words by the
+		// select kernel that last read them -- a buffer is cleared by the host only when it was (re)allocated.
 		const size_t group_ints = (ivf_group_ws_ints(nlist) + 63) & ~(size_t)63;
-		const bool bucket = cl_bucket && k <= 64;
-		// Round 5, "prep2": both groupings in three launches (csrc/ivf_scan.hip launch_ivf_group2), both packings in one
-		// (launch_ivf_collect_pack2, which also sets the class slots neutral and clears the control block's header), and NO memset:
-		// the grouping counters are zeroed by the scatter kernel that last needed them, the per-query control words by the select
-		// kernel that last read them -- a buffer is cleared by the host only when it was (re)allocated.
-		const bool prep2 = bucket && cl_prep2 && !cl_prepass_all && !cl_prepass_none && !cl_prepass_shared && cl_pack_nearest && !cl_pack_pairs;
 		ws_group.reserve(2 * group_ints * sizeof(int));
-		if (!prep2 || ws_group.p != group_clean_p || ws_group.cap != group_clean_cap)
+		if (ws_group.p != group_clean_p || ws_group.cap != group_clean_cap)
 			MVS_HIP(hipMemsetAsync(ws_group.p, 0, 2 * group_ints * sizeof(int), stream));
 		group_clean_p = nullptr;
 		ws_xi.reserve(ivf_collect_xi_bytes(max_items));
 		ws_ig.reserve((size_t)max_items * 128 * sizeof(float));
 		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
-		if (cl_prepass_shared)
-			ws_ie2p.reserve((size_t)max_items * 128 * sizeof(float));
-		// control block, zeroed by ONE memset: header {stream count @0 | fail count @64 | unit count @128 | bucket stats @192} |
-		// per-query fail flags | segments begin / end (bucket mode: hits / finished units per query) | (bucket mode) tie flags {count, queries}
-		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int) + (bucket ? ((size_t)nq + 64) * sizeof(int) : 0);
+		// control block: header {stream count @0 | survivors @8 | unit count @16 | fail count @64 | forced drains @128 | bucket stats @192} |
+		// per-query fail flags | hits / finished units per query | tie flags {count, queries}
+		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int) + ((size_t)nq + 64) * sizeof(int);
 		ws_qfail.reserve(ctl_bytes);
 		int *const ctl_qfail = (int *)((char *)ws_qfail.p + 256), *const ctl_seg = ctl_qfail + nq;
 		int *const ctl_flag = ctl_seg + 2 * nq;
 		unsigned long long *const ctl_stats = (unsigned long long *)((char *)ws_qfail.p + 192);
 		const int nclass = kf > 16 ? 32 : 16; // row classes per query (ivf_bf16_collect_kernel<NC>)
 		ws_gslot.reserve((size_t)nq * nclass * sizeof(unsigned) + 64);
-		if (!prep2)
-			launch_init_slots((unsigned *)ws_gslot.p, nq, nclass, METRIC_IP, stream); // "larger s is better": every class neutral
-		if (!prep2 || ws_qfail.p != ctl_clean_p || ws_qfail.cap != ctl_clean_cap || ctl_clean_nq != nq)
+		if (ws_qfail.p != ctl_clean_p || ws_qfail.cap != ctl_clean_cap || ctl_clean_nq != nq)
 			MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, ctl_bytes, stream));
 		ctl_clean_p = nullptr;
 		// candidate stream: 4096 entries per query to start with, or what the last overflow showed this index's data to need
 		int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024) // (option ivf_cl_stream_cap: tests)
 		                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
-		if (bucket && cl_cap_try > 0)
+		if (cl_cap_try > 0)
 			cap_entries = cl_cap_try; // (the repeated pass of a search whose stream overflowed)
-		// bucket mode: cl_bpitch entries of 8 bytes per query (a multiple of 64; grown when a query's count exceeded it) + the unit list
+		// buckets: cl_bpitch entries of 8 bytes per query (a multiple of 64; grown when a query's count exceeded it) + the unit list
 		const int bpitch = cl_bpitch_try > 0 ? cl_bpitch_try
 		                   : (int)(cl_stream_cap_per_query > 0 ? std::max<int64_t>(64, (cl_stream_cap_per_query + 63) / 64 * 64) : cl_bpitch);
-		size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
-		if (bucket) // the stream, then the buckets: [nq][bpitch] keys of 8 bytes
-			ws_stream.reserve(256 + half + (size_t)nq * bpitch * 8);
-		else
-		ws_stream.reserve(256 + 2 * half);
+		const size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+		ws_stream.reserve(256 + half + (size_t)nq * bpitch * 8); // the stream, then the buckets: [nq][bpitch] keys of 8 bytes
 		unsigned long long *cnt = (unsigned long long *)ws_qfail.p; // (zeroed with the control block above)
 		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
-		unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
-		// final-bound filter (bucket mode): u per entry, Bf per query, the filtered stream; its count lives in the control block's header @8
-		const bool refilter = bucket && cl_refilter;
+		unsigned long long *bkeys = (unsigned long long *)((char *)ws_stream.p + 256 + half); // the buckets
+		// final-bound filter: u per entry, Bf per query, the filtered stream; its count lives in the control block's header @8
+		const bool refilter = cl_refilter;
 		float *strm_u = nullptr, *bf_q = nullptr;
 		unsigned long long *strm2 = nullptr, *cnt2 = (unsigned long long *)ws_qfail.p + 1;
 		// (second cut: the survivors go to per-query ROW buckets and one wavefront per query re-scores them -- d = 128 only)
-		const bool bexact = refilter && cl_bexact && d == 128 && dp == 128;
+		const bool bexact = refilter && d == 128 && dp == 128;
 		unsigned *brow = nullptr, *const bunit_cnt = (unsigned *)ws_qfail.p + 4; // (the unit count: control block header, byte 16)
 		unsigned long long *bunits = nullptr;
 		int *bkept = nullptr; // per-workgroup survivor counts of the scatter kernel (summed into cnt2 by the selection kernel)
@@ -1062,13 +1022,10 @@ public:
 		for (int64_t l = 0; l < nlist; l++)
 			max_list = std::max(max_list, list_off[(size_t)l + 1] - list_off[(size_t)l]);
 		const int seg_rows = cl_seg_rows, nseg = (int)((max_list + seg_rows - 1) / seg_rows);
-		// (round 3, option ivf_cl_prepass = 1: the pre-pass walks the first rows of EVERY probed list with the work items of the
-		// main pass -- one grouping + packing per search instead of two, and 32 x 128 rows of evidence per query instead of 256)
-		int *d_nitems = nullptr, *d_cnt = nullptr;
+		int *d_nitems = nullptr;
 		// Round 5, probe pruning (csrc/ivf_collect.hip ivf_probe_prune_kernel): the grouping sees -1 for the probes that cannot matter
 		const int64_t *probe_keys = (const int64_t *)ws_cI.p;
-		const bool prune = cl_prune && metric == METRIC_L2 && hnsw_M == 0 && np <= 256 && np > 1 && !(params && params->sel_kind != MVS_SEL_NONE) &&
-		                   !cl_prepass_shared;
+		const bool prune = cl_prune && metric == METRIC_L2 && hnsw_M == 0 && np <= 256 && np > 1 && !(params && params->sel_kind != MVS_SEL_NONE);
 		if (prune) {
 			ws_cIp.reserve((size_t)nq * np * sizeof(int64_t));
 			ws_kept.reserve((size_t)nq * sizeof(int));
@@ -1081,11 +1038,7 @@ public:
 		cl_pairs_pruned_pending = prune;
 		if (!prune)
 			cl_last_pairs_kept = npairs;
-		// (option ivf_cl_prepass_shared: ONE grouping + packing serves both passes -- the pre-pass walks the first 256 rows of the main
-		// pass's items with every slot switched off whose list is not its query's nearest (E = NaN): the same evidence as the
-		// nearest-list pre-pass without its own grouping and packing)
-		const bool shared = cl_prepass_shared && !cl_prepass_all && !cl_prepass_none;
-		if (prep2) {
+		{
 			const int max_items0 = ivf_group_max_items(nq, nlist, G);
 			ws_items0.reserve((size_t)max_items0 * 16);
 			ws_qidx0.reserve((size_t)nq * sizeof(int32_t));
@@ -1113,46 +1066,14 @@ public:
 			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, seg_rows, nseg, 1, rowmask, stream, strm_u);
 			end_kernel_timing(stream);
 		}
-		for (int phase = prep2 ? 2 : (cl_prepass_none ? 1 : 0); phase < 2; ++phase) {
-			const int64_t *keys = probe_keys;
-			// the nearest-list pre-pass: column 0 of the labels as a batch with one probe per query (key stride = nprobe)
-			const bool nearest_only = phase == 0 && !cl_prepass_all && !shared;
-			const bool by_pairs = nearest_only ? cl_pack_nearest : (cl_pack_pairs && !shared && !(phase == 0 && cl_prepass_all));
-			if (phase == 0 || !(cl_prepass_all || shared)) {
-				launch_ivf_group(keys, nq, nearest_only ? 1 : (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
-				                 (int *)ws_group.p + (phase == 0 ? 0 : group_ints), ws_items.p, (int *)ws_qidx.p,
-				                 by_pairs ? (int *)ws_slots.p : nullptr, &d_nitems, &d_cnt, stream, nearest_only ? (int)np : 1, true);
-				if (by_pairs) // packed pair by pair, sixteen lanes each (csrc/ivf_collect.hip)
-					launch_ivf_collect_pack_pairs(metric, d_x, d, nq, nearest_only ? 1 : (int)np, (const int *)ws_slots.p, ws_items.p,
-					                              (const float *)cent_dev.p, (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p,
-					                              (float *)ws_ig.p, (float *)ws_ie2.p, ctl_qfail, nlist, stream);
-				else
-				launch_ivf_collect_pack(metric, d_x, d, ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, (const float *)cent_dev.p,
-				                        (const int *)list_of_blk.p, (const unsigned *)list_max.p, ws_xi.p, (float *)ws_ig.p,
-				                        (float *)ws_ie2.p, ctl_qfail, stream, shared ? (const int64_t *)ws_cI.p : nullptr, (int)np,
-				                        shared ? (float *)ws_ie2p.p : nullptr, nlist);
-			}
-			if (phase == 1)
-				begin_kernel_timing(stream);
-			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
-			                        (const float *)(phase == 0 && shared ? ws_ie2p.p : ws_ie2.p), (const unsigned short *)codes_bfr.p,
-			                        (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, phase == 0 ? (cl_prepass_all ? cl_prepass_rows : cl_near_rows) : seg_rows,
-			                        phase == 0 ? 1 : nseg, phase, rowmask, stream, phase == 1 ? strm_u : nullptr);
-			if (phase == 1)
-				end_kernel_timing(stream);
-		}
-		// queries without a finite bound -> fail list (bucket mode: compacted by the select kernel)
+		// queries without a finite bound -> fail list (compacted by the select kernel)
 		ws_fail.reserve(64 + (size_t)nq * sizeof(int));
 		int *fail_cnt = (int *)((char *)ws_qfail.p + 64), *fail_q = (int *)ws_fail.p + 16; // (the count: in the zeroed control block)
-		if (!bucket)
-			hipLaunchKernelGGL(ivf_compact_flags_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
-			                   (const int *)ctl_qfail, (int)nq, fail_cnt, fail_q);
 		if (!h_fail)
 			MVS_HIP(hipHostMalloc((void **)&h_fail, 512, hipHostMallocDefault)); // [0, 64): round 4's words; [256, 512): the control block's header
 		fin_done = false;
-		if (bucket) {
-			// ONE kernel: exact values, selection, and (inside the exact-tie wrapper) FAISS's print order + boundary flags; the tie pass
+		{
+			// ONE finish chain: exact values, selection, and (inside the exact-tie wrapper) FAISS's print order + boundary flags; the tie pass
 			// for the flagged queries is enqueued behind it, BEFORE the search's one synchronisation (rounds 3-4 launched the finish
 			// kernel and the tie pass after it: two launch latencies with the GPU idle)
 			const bool fin = raw_pos && fin_D != nullptr && kk == fin_k + 1 && !shadow;
@@ -1169,23 +1090,22 @@ public:
 				// caller's; then the proof that no unprobed list matters (csrc/ivf_collect.hip ivf_shadow_verify_kernel)
 				IvfFlatArith fa;
 				fa.qn = shadow->qn, fa.yn = (const float *)norms_csr.p, fa.rowids = (const long long *)rowids.p;
-				launch_ivf_bucket_finish(METRIC_L2, ex_strm, cap_entries, ex_cnt, sorted, (unsigned *)ctl_seg, bpitch, nq, d_x, d, (const float *)codes.p,
+				launch_ivf_bucket_finish(METRIC_L2, ex_strm, cap_entries, ex_cnt, bkeys, (unsigned *)ctl_seg, bpitch, nq, d_x, d, (const float *)codes.p,
 				                         dp, (const int *)perm_mf.p, kk, d_D, d_I, nullptr, shadow->out_map, 0, nullptr, nullptr, nullptr, nullptr,
-				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, prep2, stream, &fa, shadow->out_off, brow, 0, bunits, bunit_cnt, bkept,
+				                         nullptr, ctl_stats, ctl_qfail, shadow->fail_cnt, shadow->fail_q, true, stream, &fa, shadow->out_off, brow, 0, bunits, bunit_cnt, bkept,
 				                         bkept ? (int)ivf_bucket_scatter_blocks(cap_entries) : 0, cnt2);
 				FlatIndex *qz = static_cast<FlatIndex *>(quantizer);
 				launch_ivf_shadow_verify(qz->coarse_matrix(), (const float *)ws_cD.p, probe_keys, nq, (int)nlist, (int)np, d, kk,
 				                         shadow->qn, qz->row_norms(), (const unsigned *)list_max.p, (const int64_t *)lb_dev.p,
 				                         (const int64_t *)le_dev.p, d_D, d_I, shadow->ymax_bits, shadow->fail_cnt, shadow->fail_q, stream);
 			} else
-			launch_ivf_bucket_finish(metric, ex_strm, cap_entries, ex_cnt, sorted /* the buckets */, (unsigned *)ctl_seg, bpitch, nq, d_x, d,
+			launch_ivf_bucket_finish(metric, ex_strm, cap_entries, ex_cnt, bkeys, (unsigned *)ctl_seg, bpitch, nq, d_x, d,
 			                         (const float *)codes.p, dp, (const int *)perm_mf.p, kk, d_D, d_I, raw_pos ? nullptr : (const int64_t *)rowids.p,
 			                         (d_idmap && !raw_ids && !raw_pos) ? d_idmap : nullptr, fin ? (int)fin_k : 0, fin ? fin_D : nullptr,
 			                         fin ? fin_I : nullptr, (const int64_t *)rowids.p, fin ? fin_idmap : nullptr, fin ? ctl_flag : nullptr, ctl_stats,
-			                         ctl_qfail, fail_cnt, fail_q, prep2, stream, nullptr, 0, brow, 0, bunits, bunit_cnt, bkept,
+			                         ctl_qfail, fail_cnt, fail_q, true, stream, nullptr, 0, brow, 0, bunits, bunit_cnt, bkept,
 			                         bkept ? (int)ivf_bucket_scatter_blocks(cap_entries) : 0, cnt2);
-			if (prep2)
-				ctl_clean_p = ws_qfail.p, ctl_clean_cap = ws_qfail.cap, ctl_clean_nq = nq;
+			ctl_clean_p = ws_qfail.p, ctl_clean_cap = ws_qfail.cap, ctl_clean_nq = nq;
 			if (fin) {
 				SelectorDev tsel = selector.upload(params, stream);
 				launch_ivf_tie_pass(metric, ctl_flag, nq, d_x, d, d_D, (int)kk, (int)fin_k, (const int64_t *)ws_cI.p, (int)np,
@@ -1233,102 +1153,12 @@ public:
 			cl_last_admitted = (int64_t)nstream;
 			cl_queries_total += nq;
 			cl_candidates_total += (int64_t)nkept; // (what the exact stage re-scored)
-			cl_est_per_query = (double)nstream / (double)std::max<int64_t>(nq, 1) + 1e-6;
 			fin_done = fin;
 			if (shadow) { // (the fail list is the caller's: it re-runs those queries on the Flat kernels)
 				stream_wait(st, stream);
 				return true;
 			}
 		}
-		unsigned long long ncand_u = 0;
-		if (!bucket) {
-		MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		MVS_HIP(hipMemcpyAsync(h_fail, fail_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
-		// (deferred: the sort covers n_est entries -- the previous search's candidates per query + 30 %, in units of 64 K)
-		const int64_t n_est = defer ? std::min<int64_t>(cap_entries, collect_sort_estimate(cl_est_per_query, nq)) : 0;
-		if (!defer) {
-			MVS_HIP(hipStreamSynchronize(stream));
-			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
-		}
-		int64_t ncand = (int64_t)ncand_u;
-		if (!defer && ncand > cap_entries) {
-			// The stream overflowed (duplicate-heavy lists: every copy of a near vector is a candidate, rightly).  Up to 16 384 entries
-			// per query the stream is grown and the MAIN pass repeated once -- the class slots are warm, it admits no more than the
-			// first -- and the index remembers the size (as FlatIndex::collect_candidates does); beyond that the scanner kernel takes
-			// the batch as before (two orders of magnitude slower at C3's shape: 438 vs 2.3 ms)
-			++cl_overflows;
-			if (ncand + ncand / 8 > nq * (int64_t)16384)
-				return false;
-			cap_entries = ncand + ncand / 8;
-			if (cl_stream_cap_per_query <= 0)
-				cl_cap_hint = std::max<int64_t>(cl_cap_hint, (cap_entries + nq - 1) / nq);
-			half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
-			ws_stream.reserve(256 + 2 * half);
-			strm = (unsigned long long *)((char *)ws_stream.p + 256);
-			sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
-			MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
-			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p,
-			                        (const float *)ws_ie2.p, (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p,
-			                        (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf, seg_rows, nseg, 1, rowmask, stream);
-			MVS_HIP(hipMemcpyAsync(h_fail + 2, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-			MVS_HIP(hipStreamSynchronize(stream));
-			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
-			ncand = (int64_t)ncand_u;
-			if (ncand > cap_entries)
-				return false;
-		}
-		if (!defer) {
-			cl_queries_total += nq;
-			cl_candidates_total += ncand;
-			cl_est_per_query = (double)ncand / (double)std::max<int64_t>(nq, 1) + 1e-6;
-		}
-		const size_t temp = defer ? collect_sort_temp_bytes_est(n_est, nq) : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
-		ws_sorttmp.reserve(std::max<size_t>(temp, 16));
-		const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
-		ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
-		float *pd1 = (float *)ws_ex.p;
-		int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
-		if (defer) {
-			launch_collect_group_est(strm, sorted, cnt, n_est, ws_sorttmp.p, temp, nq, ctl_seg, stream, true);
-			launch_ivf_collect_exact(metric, sorted, n_est, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream, cnt);
-		} else {
-			launch_collect_group(strm, sorted, ncand, ws_sorttmp.p, temp, nq, ctl_seg, stream, true);
-			launch_ivf_collect_exact(metric, sorted, ncand, d_x, d, (const float *)codes.p, dp, (const int *)perm_mf.p, stream);
-		}
-		launch_collect_select(metric, sorted, (const int *)ctl_seg, nq, kk, pd1, pi1, stream);
-		// the k best by (value, position in the list-sorted store), labels = stored ids (then the id map of an IDMap wrapper)
-		// (the selected lists are already in the scan kernels' order: value, then position -- inner product keeps it as
-		// merge_items_kernel does; the L2 merge of one split only translates the labels)
-		if (metric == METRIC_L2 && !raw_pos) {
-			launch_merge_partials(metric, pd1, pi1, 1, nq, kk, (const int64_t *)rowids.p, 0, d_D, d_I, stream, k, nullptr);
-		} else { // (inside the exact-tie wrapper the finish kernel orders equal values by stored id itself: positions as they are)
-			const long long tot = (long long)nq * k;
-			hipLaunchKernelGGL(ivf_emit_sorted_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, pd1, pi1, (int)kk,
-			                   (int)k, tot, raw_pos ? nullptr : (const long long *)rowids.p, d_D, (long long *)d_I);
-		}
-		if (d_idmap && !raw_ids && !raw_pos) {
-			const long long tot = (long long)nq * k;
-			hipLaunchKernelGGL(ivf_map_labels_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
-			                   (long long *)d_I, tot, (const long long *)d_idmap);
-		}
-		snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel");
-		kinfo.grid = max_items * nseg;
-		kinfo.block = 64;
-		kinfo.nsplit = (int)np;
-		kinfo.bytes = (double)nrows_mf * 256.0;               // every list's bf16 rows once (each list is probed by >= 1 item)
-		kinfo.flops = (double)nq * np * ((double)nsorted / nlist) * d * 2.0; // (average list length)
-		if (defer) { // the one host round trip of the search: candidate count (did the sort cover it?) and the fail list's length
-			MVS_HIP(hipStreamSynchronize(stream));
-			memcpy(&ncand_u, h_fail + 2, sizeof ncand_u);
-			cl_est_per_query = (double)ncand_u / (double)std::max<int64_t>(nq, 1) + 1e-6;
-			if ((int64_t)ncand_u > n_est) {
-				*overflow = true;
-				return false;
-			}
-			cl_queries_total += nq;
-			cl_candidates_total += (int64_t)ncand_u;
-		}
-		} // (!bucket)
 		const int nf = *h_fail;
 		pf_queries_total += nq;
 		pf_fallback_total += nf;
@@ -1748,20 +1578,8 @@ public:
 			force_select = v != 0;
 			return true;
 		}
-		if (!strcmp(key, "ivf_cl_prepass_shared")) { // 1: the pre-pass runs on the main pass's items (one grouping + packing per search)
-			cl_prepass_shared = v != 0;
-			return true;
-		}
 		if (!strcmp(key, "ivf_cl_stream_cap")) { // candidate-stream entries per query (0: 4096, or what the last overflow needed)
 			cl_stream_cap_per_query = v;
-			return true;
-		}
-		if (!strcmp(key, "ivf_cl_pack_pairs")) { // 1: the main pass packs its (query, list) pairs pair by pair; 0 (default, faster): item by item
-			cl_pack_pairs = v != 0;
-			return true;
-		}
-		if (!strcmp(key, "ivf_cl_pack_nearest")) { // 1 (default): the nearest-list pre-pass packs its one pair per query query by query
-			cl_pack_nearest = v != 0;
 			return true;
 		}
 		if (!strcmp(key, "ivf_cl_seg_rows")) { // rows per (work item, segment) wavefront of the main pass: a multiple of 32
@@ -1770,30 +1588,8 @@ public:
 			cl_seg_rows = (int)v;
 			return true;
 		}
-		if (!strcmp(key, "ivf_cl_est")) { // tests: pretend the previous search had v candidates per query (a sort sized too small is re-run)
-			cl_est_per_query = (double)v + 1e-6;
-			return true;
-		}
-		if (!strcmp(key, "ivf_cl_defer")) { // 1 (default): the candidate count stays on the device between scan and re-scoring
-			cl_defer = v != 0;
-			return true;
-		}
-		if (!strcmp(key, "ivf_collect_k32")) {
-			collect_k32 = v != 0;
-			return true;
-		}
-		if (!strcmp(key, "ivf_cl_prepass")) { // coarse filter pre-pass: 0 = the nearest list of every query (own grouping), n > 0 = the first n rows of every probed list
-			cl_prepass_all = v > 0;
-			cl_prepass_none = v < 0; // (A/B: no pre-pass at all -- the main pass starts with cold bounds)
-			cl_prepass_rows = v > 0 ? (int)((v + 31) / 32 * 32) : 128;
-			return true;
-		}
 		if (!strcmp(key, "ivf_cl_near_rows")) { // rows of the nearest list the pre-pass looks at (a multiple of 32; A/B)
 			cl_near_rows = (int)std::max<int64_t>(32, std::min<int64_t>(4096, (v + 31) / 32 * 32));
-			return true;
-		}
-		if (!strcmp(key, "ivf_cl_bexact")) {
-			cl_bexact = v != 0;
 			return true;
 		}
 		if (!strcmp(key, "ivf_cl_refilter")) {
@@ -1802,14 +1598,6 @@ public:
 		}
 		if (!strcmp(key, "ivf_probe_prune")) {
 			cl_prune = v != 0;
-			return true;
-		}
-		if (!strcmp(key, "ivf_cl_prep2")) {
-			cl_prep2 = v != 0;
-			return true;
-		}
-		if (!strcmp(key, "ivf_cl_bucket")) {
-			cl_bucket = v != 0;
 			return true;
 		}
 		if (!strcmp(key, "ivf_exact_ties")) {
@@ -1826,16 +1614,11 @@ public:
 		return quantizer->set_option(key, v) || mine;
 	}
 	bool use_fast_scan = true;
-	bool cl_prepass_all = false; // option ivf_cl_prepass (n > 0 measured no faster than the nearest-list pre-pass: 2.83 / 2.88 / 2.93 vs 2.81 ms at C3)
-	int cl_prepass_rows = 128;
-	bool cl_prepass_none = false;
-	bool cl_prepass_shared = false; // option ivf_cl_prepass_shared (measured slower: 2.34 / 2.38 vs 2.27 / 2.32 ms at C3)
 	bool exact_ties = true; // option ivf_exact_ties: 0 = the scan kernels' pure (value, position) order, no tie pass (diagnostics)
 	bool raw_pos = false;   // inside the exact-tie wrapper: the paths emit positions in the list-sorted store, no id map
 	bool force_select = false;
 	bool raw_ids = false;
 	int collect_mode = -1; // option ivf_collect: -1 auto, 0 never, 1 wherever the kernel exists (d <= 128, k <= 32)
-	bool collect_k32 = true; // option ivf_collect_k32: 16 < k <= 32 with 32 row classes (0: the scanner kernel as in round 2)
 	int mfma_mode = -1; // option ivf_mfma: -1 auto (inner product only), 0 never, 1 always, 2 = L2 prefilter + exact re-scoring
 
 	// ---- Flat shadow (round 5; csrc/index.hip FlatIndex::shadow_search) ---------------------------------------------------------
@@ -1926,7 +1709,7 @@ private:
 	DevBuf codes_mf, norms_mf, rowids_mf, lb_dev, le_dev, max_norm_mf, cent_dev, list_of_blk, perm_mf, ws_iqn, ws_qmaxn;
 	bool mf_residual = false;
 	// bf16 coarse filter (csrc/ivf_collect.hip): residual rows as bf16, -||y'||^2, the largest ||y'||^2 of every list
-	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_ie2p, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_rowmask;
+	DevBuf codes_bfr, beta_mf, list_max, ws_ig, ws_ie2, ws_qfail, ws_stream, ws_sorttmp, ws_seg, ws_rowmask;
 	bool have_bfr = false, mf_have_f32 = false;
 	int64_t cl_queries_total = 0, cl_candidates_total = 0, cl_overflows = 0, cl_cap_hint = 0, cl_stream_cap_per_query = 0;
 	bool collect_stats(int64_t *queries, int64_t *candidates, int64_t *overflows) override {
@@ -1962,15 +1745,9 @@ private:
 		return true;
 	}
 	int64_t cl_last_nq = 0, cl_last_bursts = 0;
-	double cl_est_per_query = 0; // candidates per query of the last coarse-filter search: sizes the next search's sort (collect_sort_estimate)
 	int cl_seg_rows = 512;       // option ivf_cl_seg_rows
-	bool cl_pack_nearest = true; // option ivf_cl_pack_nearest
-	bool cl_pack_pairs = false;  // option ivf_cl_pack_pairs (the main pass pair by pair: measured slower, 1.64-1.68 vs 1.59-1.61 ms at C3)
-	bool cl_defer = true;        // option ivf_cl_defer: no host round trip between the scan and the re-scoring
-	bool cl_bucket = true;       // option ivf_cl_bucket: candidates in per-query buckets + ONE finish kernel (csrc/collect_bucket.h); 0 = round 4's stream + radix sort
 	int cl_bpitch = 1024;        // bucket entries per query (grown on demand up to 16 384)
 	int cl_near_rows = 256;      // option ivf_cl_near_rows: rows of every query's nearest list the publish-only pre-pass walks
-	bool cl_bexact = true;       // option ivf_cl_bexact: the survivors of the final-bound filter in per-query row buckets, one wavefront per query re-scores them (d = 128)
 	bool cl_refilter = true;     // option ivf_cl_refilter: candidates that do not pass the bound the scan ENDED with are dropped before the exact stage
 	DevBuf ws_stream2;           // {u per stream entry | Bf per query | the filtered stream}
 	int64_t cl_last_admitted = 0; // stream entries of the last search (before the final-bound filter)
@@ -1978,7 +1755,6 @@ private:
 	int64_t cl_last_pairs = 0, cl_last_pairs_kept = 0; // (query, list) pairs of the last coarse-filter search / of those, scanned
 	DevBuf ws_cIp, ws_kept;
 	bool cl_pairs_pruned_pending = false; // ws_kept of the last search has not been summed yet (collect statistics do it on demand)
-	bool cl_prep2 = true;        // option ivf_cl_prep2: fused grouping / packing / clearing in front of the scans (0 = round 4's launches)
 	void *group_clean_p = nullptr, *ctl_clean_p = nullptr; // the buffers known to be left zeroed by the previous search's kernels
 	size_t group_clean_cap = 0, ctl_clean_cap = 0;
 	int64_t ctl_clean_nq = 0;

@@ -488,3 +488,47 @@ def test_bucketed_finish_of_the_l2_filter_equals_the_sorted_pipeline(mf, case):
         D2, I2 = c2.search(xb2[:300].copy(), k)
         D3, I3 = e2.search(xb2[:300].copy(), k)
         assert np.array_equal(I2, I3) and np.array_equal(D2.view(np.uint32), D3.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d", [128, 768])
+def test_outlier_rows_stay_out_of_the_store_and_in_every_candidate_set(mf, metric, d):
+    """round 6: the coarse filter's E scales with the LARGEST ||y - mu|| of the store -- one row of 100 x the usual norm
+    made every query admit thousands of rows (17.5 -> 602 ms per batch at the headline).  Rows beyond 64 x the mean squared centred norm
+    are kept out of the bf16 store and appended to every query's candidates: same answers as the exact kernel and the oracle -- also for
+    queries whose nearest row IS an outlier -- and the candidate count stays what it is without them."""
+    rs = np.random.RandomState(1000 + d + metric)
+    nb, nq, k = 270_000, 300, 10
+    xb = rs.randn(nb, d).astype(np.float32)
+    xq = rs.randn(nq, d).astype(np.float32)
+    plain, ex0 = _pair(mf, d, metric, xb)
+    plain.search(xq, k)
+    base = plain.collect_stats()["candidates"] / nq
+    out_rows = [12345, 200_001, 269_999]
+    xb2 = xb.copy()
+    xb2[out_rows] *= 100.0
+    xq2 = xq.copy()
+    xq2[:3] = xb2[out_rows] * 1.001  # queries that sit on the outliers: under L2 their nearest row is the outlier itself
+    cl, ex = _pair(mf, d, metric, xb2)
+    D, I = cl.search(xq2, k)
+    assert cl.last_kernel_info()["name"] == (KERNEL if d <= 128 else "flat_bf16_big_kernel")
+    D0, I0 = ex.search(xq2, k)
+    assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), "differs from the exact f32 kernel"
+    Do, Io = orc.flat_search(metric, xb2, xq2[:32], k, force_path=orc.PATH_BLAS)
+    assert np.array_equal(I[:32], Io) and np.array_equal(D[:32].view(np.uint32), Do.view(np.uint32)), "differs from the oracle"
+    assert cl.get_stat("flat_outlier_rows") == 3
+    if metric == L2:
+        assert [int(I[j][0]) for j in range(3)] == out_rows
+    else:  # inner product: the outliers' huge norms put them on top for every query with a positive score
+        assert set(out_rows) & set(I[:, 0].tolist())
+    per_query = cl.collect_stats()["candidates"] / nq
+    assert per_query < 2.0 * base + 3 + 5, (per_query, base)  # (3 appended rows per query; without the handling: thousands)
+    # switched off: still exact (the stream grows or the fall-back takes the batch), only slower
+    off = mf.index_factory(d, "Flat", metric)
+    off.set_option("prefilter", 2)
+    off.set_option("outlier_rows", 0)
+    for i0 in range(0, nb, 1 << 16):
+        off.add(xb2[i0 : i0 + (1 << 16)])
+    D0, I0 = off.search(xq2, k)
+    assert off.get_stat("flat_outlier_rows") == 0
+    assert np.array_equal(I0, I) and np.array_equal(D0.view(np.uint32), D.view(np.uint32))

@@ -654,9 +654,9 @@ def test_ivf_exact_ties_option_off_keeps_the_pure_order(mf):
     assert np.array_equal(D0, D1) and not np.array_equal(I0, I1)
 
 
-def test_ivf_round4_switches_do_not_change_a_single_bit(mf):
-    """residual-norm bound (cl_bound_mode), items of one list on one XCD (ivf_cl_xcd), candidate count kept on the device
-    (ivf_cl_defer): same labels and distances as the scanner kernel in every combination, first and second search"""
+def test_ivf_coarse_filter_switches_do_not_change_a_single_bit(mf):
+    """residual-norm bound (cl_bound_mode), items of one list on one XCD (ivf_cl_xcd), the final-bound filter (ivf_cl_refilter): same
+    labels and distances as the scanner kernel in every combination, first and second search"""
     d, nlist, n = 128, 64, 120_000
     xb = _clustered(n, d, 61)
     xq = _clustered(900, d, 62)
@@ -666,35 +666,28 @@ def test_ivf_round4_switches_do_not_change_a_single_bit(mf):
     ref.set_option("ivf_collect", 0)
     D0, I0 = ref.search(xq, 10, nprobe=8)
     cent = ref.ivf_centroids()
-    try:
-        for bound in (1, 0):
-            for xcd in (1, 0, 2, 3):  # (2 / 3: the segments of an item as neighbouring workgroups -- measured slower, kept as options)
-                for defer in (1, 0):
-                    if xcd >= 2 and (bound == 0 or defer == 0):
-                        continue
-                    g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
-                    g.ivf_set_centroids(cent)
-                    g.add(xb)
-                    g.set_option("cl_bound_mode", bound)
-                    g.set_option("ivf_cl_xcd", xcd)
-                    g.set_option("ivf_cl_defer", defer)
-                    for rep in range(2):
-                        D, I = g.search(xq, 10, nprobe=8)
-                        assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
-                        assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (bound, xcd, defer, rep)
-    finally:
-        g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
-        g.set_option("cl_bound_mode", 1)
-        g.set_option("ivf_cl_xcd", 1)
+    for bound in (1, 0):
+        for xcd in (1, 0, 2, 3):  # (2 / 3: the segments of an item as neighbouring workgroups -- measured slower, kept as options)
+            for refilter in (1, 0):
+                if xcd >= 2 and (bound == 0 or refilter == 0):
+                    continue
+                g = mf.index_factory(d, f"IVF{nlist},Flat", L2)
+                g.ivf_set_centroids(cent)
+                g.add(xb)
+                g.set_option("cl_bound_mode", bound)
+                g.set_option("ivf_cl_xcd", xcd)
+                g.set_option("ivf_cl_refilter", refilter)
+                for rep in range(2):
+                    D, I = g.search(xq, 10, nprobe=8)
+                    assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+                    assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (bound, xcd, refilter, rep)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("metric", [L2, IP])
-def test_ivf_sort_sized_too_small_is_run_again(mf, metric):
-    """The candidate count stays on the device and the sort is sized from the previous search (csrc/index.h collect_sort_estimate);
-    an estimate that turns out too small (ivf_cl_est: 'the previous search had 1 candidate per query') must be noticed at the end of
-    the search and the search run again the synchronous way -- same bits as the scanner kernel; the pre-pass packed query by query
-    (ivf_cl_pack_nearest) and item by item give the same results too."""
+def test_ivf_stream_and_buckets_sized_too_small_are_grown_and_run_again(mf, metric):
+    """The candidate count stays on the device; a stream or a per-query bucket that turns out too small (ivf_cl_stream_cap: 8 entries
+    per query) is noticed at the search's one synchronisation, grown, and the pass repeated -- same bits as the scanner kernel."""
     d, nlist, n = 64, 32, 60_000
     xb = _clustered(n, d, 71)
     xq = _clustered(400, d, 72)
@@ -706,16 +699,12 @@ def test_ivf_sort_sized_too_small_is_run_again(mf, metric):
     g = mf.index_factory(d, f"IVF{nlist},Flat", metric)
     g.ivf_set_centroids(ref.ivf_centroids())
     g.add(xb)
-    for pack in (1, 0, 2):
-        g.set_option("ivf_cl_pack_nearest", 1 if pack else 0)
-        g.set_option("ivf_cl_pack_pairs", 1 if pack == 2 else 0)  # (2: the main pass pair by pair as well -- an option, measured slower)
-        for est in (1, 0, 100000):
-            D, I = g.search(xq, 10, nprobe=6)  # (leaves a true estimate)
-            if est:
-                g.set_option("ivf_cl_est", est)
+    for cap in (0, 8, 64, 0):
+        g.set_option("ivf_cl_stream_cap", cap)
+        for rep in range(2):
             D, I = g.search(xq, 10, nprobe=6)
             assert g.last_kernel_info()["name"].startswith("ivf_bf16_collect")
-            assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (pack, est)
+            assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (cap, rep)
 
 
 @pytest.mark.gpu

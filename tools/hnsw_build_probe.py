@@ -12,7 +12,7 @@ d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 efc = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 x = mf.synth_uniform_torch(n, d, 99, row0=0)
 ix = mf.index_factory(d, "HNSW32", mf.METRIC_L2)
-ix.hnsw_set_ef_construction(efc)
+ix.set_ef_construction(efc)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i0 in range(0, n, 2048):  # the glue's DataChunks

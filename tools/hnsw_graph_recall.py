@@ -43,13 +43,13 @@ for efc in (40, 200):
     _, Io = o.search(xq_h, k, efSearch=efs)
     t0 = time.perf_counter()
     g = mf.index_factory(d, "HNSW32", mf.METRIC_L2)
-    g.hnsw_set_ef_construction(efc)
+    g.set_ef_construction(efc)
     g.add_torch(xb)
     torch.cuda.synchronize()
     t_g = time.perf_counter() - t0
     _, Ig = g.search_torch(xq, k, efSearch=efs)
     g1 = mf.index_factory(d, "HNSW32", mf.METRIC_L2)
-    g1.hnsw_set_ef_construction(efc)
+    g1.set_ef_construction(efc)
     g1.set_option("hnsw_build_waves", 1)  # FAISS's single-thread insertion order on the device: the oracle's graph bit for bit
     t0 = time.perf_counter()
     g1.add_torch(xb)
