@@ -279,6 +279,139 @@ __device__ __forceinline__ void ivf_collect_pack_body(unsigned bid, const float 
 		}
 	}
 }
+// The nearest-list pre-pass has ONE pair per query, spread over ~ nlist items of a few slots each: the item-wise kernel above
+// then spends a workgroup, and four dependent global round trips, on two or three queries (70 us at C3, as long as the main
+// pass's packing of 32 times the pairs).  Here one wave per QUERY: slot code (ivf_group_scatter_*: item << 7 | slot) -> item ->
+// list -> centroid; lanes 0..15 hold the sixteen 8-element pieces of the slot's fragment column, the four sums are reduced over
+// them.  Slots of an item that no query owns are not written: the scan gives them a NaN bound whatever is stored (own_q < 0).
+template <bool IS_L2>
+__device__ __forceinline__ void ivf_collect_pack_pairs_body(unsigned bid, const float *__restrict__ x, int d, long long npairs, int np,
+                                                            const int *__restrict__ slots, const int4 *__restrict__ items,
+                                                            const float *__restrict__ cent, const int *__restrict__ list_of_blk64,
+                                                            const unsigned *__restrict__ list_max_bits, bf16x8i *__restrict__ xi,
+                                                            float *__restrict__ igamma, float *__restrict__ ie2,
+                                                            int *__restrict__ qfail, int nlist, int bound_mode) {
+	// sixteen lanes per (query, list) pair -- the sixteen 8-element pieces of the slot's fragment column --, sixteen pairs per workgroup
+	const long long p = (long long)bid * 16 + (threadIdx.x >> 4);
+	const int l16 = threadIdx.x & 15;
+	const int code = p < npairs ? slots[p] : -1;
+	float xn = 0.f, cn = 0.f, xc = 0.f, dq2 = 0.f;
+	int item = 0, slot = 0, l = 0;
+	const long long q = p / np;
+	if (code >= 0) {
+		item = code >> 7, slot = code & 127;
+		const int4 it = items[item];
+		l = list_of_blk64[it.x >> 6];
+		const int kb = l16 >> 2, hq = l16 & 3;
+		bf16x8i v;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			const int kk = kb * 32 + 8 * hq + e;
+			const bool in = kk < d;
+			const float xv = in ? x[q * d + kk] : 0.f, cv = in ? cent[(size_t)l * d + kk] : 0.f;
+			const float r = IS_L2 ? __fsub_rn(xv, cv) : xv;
+			const float a = IS_L2 ? 2.0f * r : r;
+			v[e] = (__bf16)a;
+			xn = fmaf(r, r, xn);
+			cn = fmaf(cv, cv, cn);
+			xc = fmaf(xv, cv, xc);
+			const float dl = a - (float)(__bf16)a;
+			dq2 = fmaf(dl, dl, dq2);
+		}
+		xi[(size_t)item * (8 * 4 * 64) + (size_t)(((slot >> 4) * 4 + kb) * 64 + hq * 16 + (slot & 15))] = v;
+	}
+#pragma unroll
+	for (int o = 8; o >= 1; o >>= 1) { // (within the pair's sixteen lanes)
+		xn += __shfl_xor(xn, o);
+		cn += __shfl_xor(cn, o);
+		xc += __shfl_xor(xc, o);
+		dq2 += __shfl_xor(dq2, o);
+	}
+	if (code >= 0 && l16 == 0) {
+		const float yn = __uint_as_float(list_max_bits[l]), dyn = __uint_as_float(list_max_bits[nlist + l]);
+		const float e2 = ivf_slot_e2<IS_L2>(xn, cn, dq2, yn, dyn, d, bound_mode);
+		if (!(e2 == e2))
+			qfail[q] = 1;
+		igamma[(size_t)item * 128 + slot] = IS_L2 ? -xn : xc;
+		ie2[(size_t)item * 128 + slot] = e2;
+	}
+}
+// Round 5: the packing of BOTH passes in one launch -- the first nb0 workgroups pack the nearest-list pre-pass pair by pair (set 0:
+// its own items / fragments / bounds), the others the main pass item by item (set 1).
+struct IvfPack2Args {
+	const float *x;
+	int d, nlist, bound_mode;
+	unsigned nb0;
+	long long nq;
+	const float *cent;
+	const int *list_of_blk64;
+	const unsigned *list_max_bits;
+	int *qfail;
+	// set 0 (pairs)
+	const int *slots0;
+	const int4 *items0;
+	bf16x8i *xi0;
+	float *igamma0, *ie20;
+	// set 1 (items)
+	const int4 *items1;
+	const int *nitems1;
+	const int *qidx1;
+	bf16x8i *xi1;
+	float *igamma1, *ie21;
+	unsigned *gslot; // [nq][nclass] class slots -> neutral
+	int nclass;
+	int *ctl_hdr;    // the control block's 64 header ints -> 0
+	int *flag_cnt;   // -> 0
+};
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void ivf_collect_pack2_kernel(const IvfPack2Args a) {
+	if (blockIdx.x < a.nb0) {
+		// (what launch_init_slots and the control block's memset did in launches of their own)
+		const long long q = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+		const int l16 = threadIdx.x & 15;
+		if (q < a.nq)
+			for (int c = l16; c < a.nclass; c += 16)
+				a.gslot[q * a.nclass + c] = ic_skey(-FLT_MAX);
+		if (blockIdx.x == 0 && threadIdx.x < 64) {
+			a.ctl_hdr[threadIdx.x] = 0;
+			if (threadIdx.x == 0)
+				*a.flag_cnt = 0;
+		}
+	}
+	if (blockIdx.x < a.nb0)
+		ivf_collect_pack_pairs_body<IS_L2>(blockIdx.x, a.x, a.d, a.nq, 1, a.slots0, a.items0, a.cent, a.list_of_blk64, a.list_max_bits, a.xi0,
+		                                   a.igamma0, a.ie20, a.qfail, a.nlist, a.bound_mode);
+	else
+		ivf_collect_pack_body<IS_L2>(blockIdx.x - a.nb0, a.x, a.d, a.items1, a.nitems1, a.qidx1, a.cent, a.list_of_blk64, a.list_max_bits,
+		                             a.xi1, a.igamma1, a.ie21, a.qfail, nullptr, 0, nullptr, a.nlist, a.bound_mode);
+}
+void launch_ivf_collect_pack2(int metric, const float *d_x, int d, int64_t nq, const int *d_slots0, const void *d_items0, void *d_xi0,
+                              float *d_igamma0, float *d_ie20, const void *d_items1, const int *d_nitems1, int max_items1,
+                              const int *d_qidx1, void *d_xi1, float *d_igamma1, float *d_ie21, const float *d_cent,
+                              const int *d_list_of_blk64, const unsigned *d_list_max_bits, int *d_qfail, int64_t nlist, unsigned *d_gslot,
+                              int nclass, int *d_ctl_hdr, int *d_flag_cnt, hipStream_t st) {
+	if (nq <= 0 || max_items1 <= 0)
+		return;
+	IvfPack2Args a;
+	memset(&a, 0, sizeof a);
+	a.gslot = d_gslot, a.nclass = nclass, a.ctl_hdr = d_ctl_hdr, a.flag_cnt = d_flag_cnt;
+	a.x = d_x, a.d = d, a.nlist = (int)nlist, a.bound_mode = tune().cl_bound_mode, a.nb0 = (unsigned)((nq + 15) / 16), a.nq = nq;
+	a.cent = d_cent, a.list_of_blk64 = d_list_of_blk64, a.list_max_bits = d_list_max_bits, a.qfail = d_qfail;
+	a.slots0 = d_slots0, a.items0 = (const int4 *)d_items0, a.xi0 = (bf16x8i *)d_xi0, a.igamma0 = d_igamma0, a.ie20 = d_ie20;
+	a.items1 = (const int4 *)d_items1, a.nitems1 = d_nitems1, a.qidx1 = d_qidx1, a.xi1 = (bf16x8i *)d_xi1, a.igamma1 = d_igamma1, a.ie21 = d_ie21;
+	const size_t lds = ((size_t)64 * (d + 1) + d) * sizeof(float);
+	const dim3 grid(a.nb0 + 2u * (unsigned)max_items1);
+	if (metric == METRIC_L2) {
+		auto kern = ivf_collect_pack2_kernel<true>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+	} else {
+		auto kern = ivf_collect_pack2_kernel<false>;
+		ensure_dynamic_lds((const void *)kern, lds);
+		hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+	}
+	MVS_HIP(hipGetLastError());
+}
 size_t ivf_collect_xi_bytes(int max_items) {
 	return (size_t)max_items * 8 * 4 * 64 * 16;
 }
