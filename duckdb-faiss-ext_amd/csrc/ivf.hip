@@ -22,6 +22,7 @@
 #include <cstring>
 #include <random>
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 namespace mvs {
@@ -267,6 +268,16 @@ public:
 			is_trained = true;
 			return;
 		}
+		const auto t0 = std::chrono::steady_clock::now();
+		struct Report { // (MVS_INGEST_PROFILE=1: where an IVF ingest's time goes -- host/boundary_driver ingest)
+			std::chrono::steady_clock::time_point t0;
+			int64_t n;
+			~Report() {
+				if (getenv("MVS_INGEST_PROFILE"))
+					fprintf(stderr, "ivfprofile\ttrain(%lld rows): %.3f s\n", (long long)n,
+					        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+			}
+		} report {t0, n};
 		if (hnsw_M > 0) {
 			// Level1Quantizer::train_q1, quantizer_trains_alone == 2: k-means on an IndexFlatL2, centroids -> quantizer
 			FlatIndex assigner(d, METRIC_L2);
@@ -478,10 +489,14 @@ public:
 		use_device();
 		if (n <= 0)
 			return;
+		const auto t0 = std::chrono::steady_clock::now();
 		DevBuf dx;
 		dx.reserve((size_t)n * d * sizeof(float));
 		MVS_HIP(hipMemcpyAsync(dx.p, x, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice, stream));
 		add_core_device(n, (const float *)dx.p, ids);
+		if (getenv("MVS_INGEST_PROFILE"))
+			fprintf(stderr, "ivfprofile\tadd(%lld rows: H2D + assign + append): %.3f s\n", (long long)n,
+			        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 	}
 	void add(int64_t n, const float *x) override {
 		add_host(n, x, nullptr);
@@ -510,6 +525,14 @@ public:
 	void build_lists() {
 		if (!dirty)
 			return;
+		const auto t0_bl = std::chrono::steady_clock::now();
+		struct ReportBl {
+			std::chrono::steady_clock::time_point t0;
+			~ReportBl() {
+				if (getenv("MVS_INGEST_PROFILE"))
+					fprintf(stderr, "ivfprofile\tbuild_lists (CSR view): %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+			}
+		} report_bl {t0_bl};
 		list_off.assign((size_t)nlist + 1, 0);
 		for (int64_t i = 0; i < ntotal; i++) {
 			const int32_t l = assign_h[(size_t)i];
