@@ -299,6 +299,8 @@ FlatIndex::FlatIndex(int d_, int metric_) : IndexBase(MVS_KIND_FLAT, d_, metric_
 		            metric);
 	geom = flat_geom_for(d);
 	is_trained = true;
+	if (const char *e = getenv("MVS_LAZY_ADDS")) // (same-box A/B of the ingest staging through host/boundary_driver, which sets no options)
+		lazy_adds = atoi(e) != 0;
 }
 FlatIndex::~FlatIndex() {
 	delete shadow;
