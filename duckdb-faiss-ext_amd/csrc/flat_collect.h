@@ -44,6 +44,7 @@ struct CollectArgs {
 int collect_store_dims(int d); // row pitch (dims) of the bf16 store: 128, 256, 384, 512, 768, 1024; 0 = the coarse filter does not serve d
 int collect_wide_qblock(int dp1);
 int collect_wide_slots(int dp1);
+int collect_wide_max_classes(int dp1); // row classes per query the wide store's kernel can keep: 128 (wide / big kernels: 16 | 32 | 4 x 32) or 16 (k-split)
 size_t collect_wide_lds_bytes(int dp1);
 int collect_wide_block_rows(int dp1);
 void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a, int64_t row_first, int64_t row_end,

@@ -1427,6 +1427,8 @@ size_t collect_seed_stage_bytes(int64_t nq) { // (launch_collect_seed: at most 6
 int collect_slot_stride(int kk, int dp1) {
 	if (dp1 == 128 && kk > 28) // (with the derivation every 256 blocks: kk = 33 on 4 x 32 classes 21.0 ms, kk = 32 on 32 classes 23.3)
 		return 128;
+	if (dp1 > 128 && kk > 32 && collect_wide_max_classes(dp1) >= 128) // (round 6: the wide stores serve kk <= 128 the same way)
+		return 128;
 	return (kk > 16 || kk >= tune().cl_nc32_from) ? 32 : 16;
 }
 int collect_max_k(int d) {
@@ -1437,7 +1439,7 @@ int collect_max_k(int d) {
 	// kk <= 128 with four subsets of 32 classes, round 4)
 	if (dp1 == 128)
 		return 128;
-	return ((dp1 == 768 || dp1 == 1024) && !tune().wide_big) ? 16 : 32;
+	return collect_wide_max_classes(dp1); // (128, or the k-split kernel's 16)
 }
 
 // thr[q] = B - 2E with the class slots as the scan LEFT them (linear in q): the scan admitted a row when s >= B_then - 2E; bounds only

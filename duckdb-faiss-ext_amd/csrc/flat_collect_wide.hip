@@ -173,40 +173,49 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 				for (int i = 0; i < NCBP; ++i) { // (one query at a time: the resident fragments leave few registers)
 					const int q = qo + 16 * NCBP * hq + 16 * i + c;
 					const int qc = q < a.nq ? q : 0;
-					const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC);
-					unsigned long long w[NC / 2];
-#pragma unroll
-					for (int j = 0; j < NC / 2; ++j)
-						w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					const float e2v = __builtin_nontemporal_load(a.e2 + qc);
+					// NC = 128 (32 < kk <= 128, round 6): four SUBSETS of 32 classes (class = row & 127, subset = class >> 5); the worst of the
+					// subsets' ceil(kk / 4)-th best class values has >= kk distinct rows at least as good (csrc/flat_collect.hip)
+					constexpr int SUBN = NC > 32 ? 32 : NC, NSUB = NC / SUBN;
+					const int rank = NSUB == 1 ? a.nclass - 1 : (a.nclass + NSUB - 1) / NSUB - 1;
+					unsigned kth = 0u;
+#pragma unroll 1
+					for (int sb = 0; sb < NSUB; ++sb) {
+						const unsigned long long *src = (const unsigned long long *)(a.gslot + (size_t)qc * NC + sb * SUBN);
+						unsigned long long w[SUBN / 2];
 #pragma unroll
-					for (int j = 0; j < NC / 2; ++j)
-						asm volatile("" : "+v"(w[j]));
-					unsigned key[NC];
+						for (int j = 0; j < SUBN / 2; ++j)
+							w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-					for (int j = 0; j < NC / 2; ++j) {
-						key[2 * j] = (unsigned)w[j];
-						key[2 * j + 1] = (unsigned)(w[j] >> 32);
-					}
+						for (int j = 0; j < SUBN / 2; ++j)
+							asm volatile("" : "+v"(w[j]));
+						unsigned key[SUBN];
 #pragma unroll
-					for (int kbit = 2; kbit <= NC; kbit <<= 1)
+						for (int j = 0; j < SUBN / 2; ++j) {
+							key[2 * j] = (unsigned)w[j];
+							key[2 * j + 1] = (unsigned)(w[j] >> 32);
+						}
 #pragma unroll
-						for (int jb = kbit >> 1; jb > 0; jb >>= 1)
+						for (int kbit = 2; kbit <= SUBN; kbit <<= 1)
 #pragma unroll
-							for (int x0 = 0; x0 < NC; ++x0) {
-								const int x1 = x0 ^ jb;
-								if (x1 > x0) {
-									const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
-									const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
-									const bool asc = (x0 & kbit) == 0;
-									key[x0] = asc ? lo : hi;
-									key[x1] = asc ? hi : lo;
+							for (int jb = kbit >> 1; jb > 0; jb >>= 1)
+#pragma unroll
+								for (int x0 = 0; x0 < SUBN; ++x0) {
+									const int x1 = x0 ^ jb;
+									if (x1 > x0) {
+										const unsigned lo = key[x0] < key[x1] ? key[x0] : key[x1];
+										const unsigned hi = key[x0] < key[x1] ? key[x1] : key[x0];
+										const bool asc = (x0 & kbit) == 0;
+										key[x0] = asc ? lo : hi;
+										key[x1] = asc ? hi : lo;
+									}
 								}
-							}
-					unsigned kth = key[0];
+						unsigned ks = key[0];
 #pragma unroll
-					for (int j = 1; j < NC; ++j)
-						kth = (a.nclass - 1 == j) ? key[j] : kth;
+						for (int j = 1; j < SUBN; ++j)
+							ks = (rank == j) ? key[j] : ks;
+						kth = ks > kth ? ks : kth; // (keys: smaller = better; the worst subset decides)
+					}
 					const unsigned neutral = skey(-FLT_MAX);
 					const float B = skey2f(kth < neutral ? kth : neutral); // -FLT_MAX while fewer than kk classes are set
 					const float bv = q < a.nq ? B - e2v : __uint_as_float(0x7fc00000u); // (2E = NaN stays NaN; NaN: nothing passes)
@@ -831,6 +840,13 @@ static bool wide_on_big(int dp1) {
 const char *collect_wide_kernel_name(int dp1) {
 	return wide_on_big(dp1) ? "flat_bf16_big_kernel" : "flat_bf16_wide_kernel";
 }
+// row classes the kernel serving a wide store can keep per query: the k-split kernel (A/B options) has its 16 hard-wired; the wide and
+// big kernels are instantiated for 16, 32 and 4 x 32
+int collect_wide_max_classes(int dp1) {
+	if (wide_on_big(dp1))
+		return 128;
+	return (dp1 == 768 || dp1 == 1024 || (dp1 == 512 && tune().wide512_ksplit)) ? 16 : 128;
+}
 static int wide_qt(int dp1) {
 	return dp1 <= 256 ? 2 : 1;
 }
@@ -882,7 +898,12 @@ static void launch_wide_inst(int metric, const CollectArgs &a, int grid, size_t 
 		ensure_dynamic_lds((const void *)kern, lds);                                                              \
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                              \
 	}
-	if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes per query
+	if (a.slot_stride == 128) { // 32 < kk <= 128: four subsets of 32 row classes (round 6)
+		if (metric == METRIC_L2)
+			MVS_WIDE1(true, 128)
+		else
+			MVS_WIDE1(false, 128)
+	} else if (a.slot_stride == 32) { // 16 < kk <= 32: 32 row classes per query
 		if (metric == METRIC_L2)
 			MVS_WIDE1(true, 32)
 		else

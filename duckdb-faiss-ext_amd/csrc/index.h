@@ -468,8 +468,8 @@ void launch_collect_pack_queries(const FlatGeom &g, int metric, const float *d_x
                                  hipStream_t st);
 void launch_collect_bounds(int metric, const float *d_x, int64_t nq, int d, const float *d_mu,
                            const unsigned *d_max_norm_bits, float *d_e2, int *d_fail_cnt, int *d_fail_q, hipStream_t st);
-int collect_slot_stride(int kk, int dp1 = 128); // class slots per query: 16 | 32 | 128 (d <= 128 store only)
-int collect_max_k(int d); // largest k (+1 with tie detection) the coarse filter serves at this d: 32 (d <= 128), 16, or 0
+int collect_slot_stride(int kk, int dp1 = 128); // class slots per query: 16 | 32 | 128 (kk > 32; wide stores: where the kernel has the instance)
+int collect_max_k(int d); // largest k (+1 with tie detection) the coarse filter serves at this d: 128, 16 (k-split kernels), or 0
 int launch_collect_drop_heavy(const unsigned long long *d_stream, int64_t n, int64_t nq, int share, int *d_qcount, float *d_e2,
                               int *d_fail_cnt, int *d_fail_q, hipStream_t st);
 void launch_collect_prepare(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
