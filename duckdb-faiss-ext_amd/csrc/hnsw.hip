@@ -864,6 +864,8 @@ struct BuildArgs {
 	int *counter;
 	int *locks;
 	int use_locks;
+	int count_spins;
+	unsigned char *clean; // [vertex] bit l: the level-l list is FULL and is the kept sequence of its last shrink (add_link's short cut)
 	uint8_t *visited; // [grid][vstride]
 	long long vstride;
 	unsigned *vstamp; // [grid] rolling stamp, persists across launches
@@ -884,6 +886,8 @@ __device__ __forceinline__ void wave_lock(const BuildArgs &a, int v, int lane) {
 		}
 		if (rfl(got))
 			break;
+		if (a.count_spins && lane == 0) // (MVS_INGEST_PROFILE: how long the build waits for vertex locks)
+			atomicAdd(&a.stats[1], 1ull);
 		__builtin_amdgcn_s_sleep(8);
 	}
 	__atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -956,9 +960,16 @@ __device__ __forceinline__ int shrink_select(const GraphDev &g, const u64 *keys,
 }
 
 // HNSW.cpp add_link(src -> dest); srcq = row of src
+// Round 6, the short cut for a list that is FULL and still the kept sequence k_1 .. k_L of its last shrink (flag `clean`, kept under the
+// vertex's lock): shrinking {k_1 .. k_L, dest} needs no pairwise pass.  Sorted by distance to src, every k_i in front of dest meets the very
+// kept set it met last time (k_1 .. k_{i-1}) and is kept again; dest is kept iff none of those is closer to it than src is; a k_i behind
+// dest was good against k_1 .. k_{i-1} and stays good against any subset, so only dest can prune it (dist(k_i, dest) < dist(k_i, src)).
+// <= 2L + 1 INDEPENDENT evaluations instead of ~L^2 / 4 dependent ones, the same list bit for bit (tests/test_hnsw_gpu.py: the single-wave
+// build still reproduces the oracle's graph).  Hub vertices of high-dimensional rows sit on full lists for most of a build and every
+// insertion near them queues on their lock: the short cut is what shortens that queue (profiles/r6_hnsw_build.txt).
 template <int NI, bool IS_L2, int G>
 __device__ __forceinline__ void add_link(const GraphDev &g, const QV<NI> &srcq, int src, int dest, int level, u64 *tkeys,
-                                         int *out_id, float *out_d, int lane, unsigned &ndis) {
+                                         int *out_id, float *out_d, int lane, unsigned &ndis, unsigned char *clean) {
 	const int L = nb_at(g, level);
 	int32_t *list = g.neighbors + g.offsets[src] + cum_at(g, level);
 	if (rfl(ld_nb<true>(list + L - 1)) == -1) { // room left: first free slot
@@ -999,124 +1010,220 @@ __device__ __forceinline__ void add_link(const GraphDev &g, const QV<NI> &srcq, 
 		ndis++;
 		nt = sorted_insert(tkeys, nt, L + 1, mk_key(dd, dest), lane);
 	}
-	const int nout = shrink_select<NI, IS_L2, G>(g, tkeys, nt, L, out_id, out_d, lane, ndis);
+	const unsigned lbit = level < 8 ? 1u << level : 0u;
+	unsigned cflag = 0u;
+	if (clean && lbit) {
+		if (lane == 0)
+			cflag = __hip_atomic_load(clean + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		cflag = (unsigned)rfl((int)cflag);
+	}
+	int nout;
+	if (cflag & lbit) {
+		// ---- the short cut: tkeys = k_1 .. k_L and dest, closest first
+		int r = 0;
+		for (int j0 = 0; j0 < nt; j0 += 64) {
+			const int j = j0 + lane;
+			const u64 m = __builtin_amdgcn_ballot_w64(j < nt && key_id(tkeys[j]) == dest);
+			if (m)
+				r = j0 + (int)__builtin_ctzll(m);
+		}
+		const float d_dest = key_dis(rfl64(tkeys[r]));
+		QV<NI> qd;
+		load_row(qd, g.vecs + (size_t)dest * g.dp4 * 4, g.dp4, lane);
+		bool good = true;
+		for (int j0 = 0; j0 < r && good; j0 += 64) { // is a kept row in front of dest closer to dest than src is?
+			const int j = j0 + lane;
+			const int kid = j < r ? key_id(tkeys[j]) : -1;
+			u64 m = __builtin_amdgcn_ballot_w64(j < r);
+			while (m && good) {
+				u64 sub = 0;
+#pragma unroll
+				for (int t = 0; t < G; t++)
+					if (m) {
+						sub |= m & (~m + 1);
+						m &= m - 1;
+					}
+				ndis += (unsigned)__popcll(sub);
+				const float dd = eval_lanes<NI, IS_L2, G>(qd, g.vecs, g.dp4, kid, sub, lane);
+				if (__builtin_amdgcn_ballot_w64(((sub >> lane) & 1ull) && dd < d_dest))
+					good = false;
+			}
+		}
+		if (!good)
+			return; // dest is pruned: the list stays what it is (and clean)
+		for (int j = lane; j <= r; j += 64)
+			out_id[j] = key_id(tkeys[j]);
+		nout = r + 1;
+		for (int j0 = 0; j0 < nt; j0 += 64) { // the rows behind dest: pruned when closer to dest than to src
+			const int j = j0 + lane;
+			const bool in = j > r && j < nt;
+			const u64 kk = in ? tkeys[j] : 0ull;
+			const int kid = in ? key_id(kk) : -1;
+			const u64 m = __builtin_amdgcn_ballot_w64(in);
+			if (!m)
+				continue;
+			ndis += (unsigned)__popcll(m);
+			const float dd = eval_lanes<NI, IS_L2, G>(qd, g.vecs, g.dp4, kid, m, lane);
+			const bool keep = in && !(dd < key_dis(kk));
+			const u64 km = __builtin_amdgcn_ballot_w64(keep);
+			const int pos = nout + (int)__popcll(km & ((1ull << lane) - 1ull));
+			if (keep && pos < L)
+				out_id[pos] = kid;
+			nout += (int)__popcll(km);
+		}
+		nout = nout < L ? nout : L; // "if (output.size() >= max_size) return"
+		wave_fence();
+	} else {
+		nout = shrink_select<NI, IS_L2, G>(g, tkeys, nt, L, out_id, out_d, lane, ndis);
+	}
 	// "while (resultSet.size()) neighbors[i++] = resultSet.top().id" : farthest first, then -1
 	for (int c0 = 0; c0 < L; c0 += 64) {
 		const int j = c0 + lane;
 		if (j < L)
 			st_nb(list + j, j < nout ? out_id[nout - 1 - j] : -1);
 	}
+	if (clean && lbit && lane == 0) {
+		const unsigned nf = nout == L ? (cflag | lbit) : (cflag & ~lbit);
+		if (nf != cflag)
+			__hip_atomic_store(clean + src, (unsigned char)nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
-template <int NI, bool IS_L2, int G>
-__global__ __launch_bounds__(64) void hnsw_build_kernel(const BuildArgs a) {
+// One WORKGROUP of W wavefronts per inserted point (round 6).  Wave 0 does what HNSW::add_with_locks does up to the forward links: greedy
+// descent, search_neighbors_to_add, shrink, add_link(pt -> neighbour).  The BACK links -- add_link(neighbour -> pt) for each of the <= 2M
+// selected neighbours, each under that neighbour's lock, each a shrink of a full list: 2M + 1 candidates, ~2 000 distance evaluations of
+// dependent row round trips -- are ~95 % of an insertion's evaluations and touch different vertices: the W waves share them out (t = wave,
+// wave + W, ...).  Same lists as the sequential loop (a back link reads and writes its own vertex's list only), a W-th of the latency:
+// profiles/r6_hnsw_build.txt -- the build is bound by the LATENCY of one insertion (the glue adds 2048 rows at a time, level bucket by level
+// bucket: four launches per chunk, each as long as its slowest insertion), not by bandwidth or issue slots.
+template <int NI, bool IS_L2, int G, int W>
+__global__ __launch_bounds__(64 * W) void hnsw_build_kernel(const BuildArgs a) {
 	extern __shared__ u64 smem[];
 	const GraphDev &g = a.g;
 	const int L0 = 2 * g.M;
-	u64 *rkeys = smem;                      // [efC] construction result set, bit 0 = already expanded
-	u64 *tkeys = rkeys + a.efC;             // [2M+1] add_link scratch
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	u64 *rkeys = smem;                      // [efC] construction result set, bit 0 = already expanded (wave 0)
+	int *sel_id = (int *)(rkeys + a.efC);   // [2M] link targets of the current level
+	int *ctl = sel_id + L0;                 // [2] the point's position in `order` | link targets of this level
+	u64 *tkeys = (u64 *)(ctl + 2) + (size_t)wave * (2 * (L0 + 1)); // per wave: [2M+1] add_link scratch
 	int *out_id = (int *)(tkeys + L0 + 1);  // [2M+1]
 	float *out_d = (float *)(out_id + L0 + 1);
-	int *sel_id = (int *)(out_d + L0 + 1);  // [2M] link targets of the current level
-	const int lane = threadIdx.x;
 	uint8_t *vis = a.visited + (size_t)blockIdx.x * a.vstride;
-	unsigned stamp = a.vstamp[blockIdx.x];
+	unsigned stamp = wave == 0 ? a.vstamp[blockIdx.x] : 0u;
 	unsigned ndis = 0;
 	const int efC = a.efC;
 	for (;;) {
-		int i = 0;
-		if (lane == 0)
-			i = atomicAdd(a.counter, 1);
-		i = rfl(i) + a.i0;
+		if (wave == 0) {
+			int i = 0;
+			if (lane == 0)
+				i = atomicAdd(a.counter, 1);
+			if (lane == 0)
+				ctl[0] = i;
+		}
+		__syncthreads();
+		const int i = rfl(ctl[0]) + a.i0;
 		if (i >= a.i1)
 			break;
 		const int pt = a.order[i];
 		QV<NI> q;
-		load_row(q, g.vecs + (size_t)pt * g.dp4 * 4, g.dp4, lane);
-		wave_lock(a, pt, lane);
 		int nearest = a.entry_point;
-		float d_nearest = wave_dist1<NI, IS_L2>(q, g.vecs, g.dp4, nearest, lane);
-		ndis++;
-		int level = a.max_level;
-		for (; level > a.pt_level; level--)
-			greedy_update_nearest<NI, IS_L2, G, true>(g, q, level, nearest, d_nearest, lane, ndis);
-		for (; level >= 0; level--) {
-			// ---- search_neighbors_to_add: candidates = the not yet expanded entries of the result set
-			if (++stamp == 256) {
-				clear_table(vis, a.vstride / 16, lane);
-				stamp = 1;
-			}
-			int nr = sorted_insert(rkeys, 0, efC, mk_key(d_nearest, nearest), lane);
-			if (lane == 0)
-				vis[nearest] = (uint8_t)stamp;
+		float d_nearest = 0.f;
+		if (wave == 0) {
+			load_row(q, g.vecs + (size_t)pt * g.dp4 * 4, g.dp4, lane);
+			wave_lock(a, pt, lane);
+			d_nearest = wave_dist1<NI, IS_L2>(q, g.vecs, g.dp4, nearest, lane);
+			ndis++;
+			for (int level = a.max_level; level > a.pt_level; level--)
+				greedy_update_nearest<NI, IS_L2, G, true>(g, q, level, nearest, d_nearest, lane, ndis);
+		}
+		for (int level = a.max_level < a.pt_level ? a.max_level : a.pt_level; level >= 0; level--) {
 			const int L = nb_at(g, level);
-			for (;;) {
-				int pos = -1;
-				for (int base = 0; base < nr && pos < 0; base += 64) {
-					const int i2 = base + lane;
-					const bool open = i2 < nr && ((unsigned)rkeys[i2] & 1u) == 0u;
-					const u64 m = __builtin_amdgcn_ballot_w64(open);
-					if (m)
-						pos = base + (int)__builtin_ctzll(m);
+			if (wave == 0) {
+				// ---- search_neighbors_to_add: candidates = the not yet expanded entries of the result set
+				if (++stamp == 256) {
+					clear_table(vis, a.vstride / 16, lane);
+					stamp = 1;
 				}
-				if (pos < 0)
-					break;
-				const u64 ck = rfl64(rkeys[pos]);
+				int nr = sorted_insert(rkeys, 0, efC, mk_key(d_nearest, nearest), lane);
 				if (lane == 0)
-					rkeys[pos] = ck | 1ull;
-				wave_fence();
-				const int cur = key_id(ck);
-				const long long base0 = g.offsets[cur] + cum_at(g, level);
-				for (int c0 = 0; c0 < L; c0 += 64) {
-					const int j = c0 + lane;
-					const int nid = j < L ? ld_nb<true>(g.neighbors + base0 + j) : -1;
-					const u64 vmask = __builtin_amdgcn_ballot_w64(nid >= 0);
-					const u64 pm = valid_prefix(vmask);
-					bool fresh = false;
-					if ((pm >> lane) & 1ull) {
-						fresh = vis[nid] != (uint8_t)stamp;
-						if (fresh)
-							vis[nid] = (uint8_t)stamp;
+					vis[nearest] = (uint8_t)stamp;
+				for (;;) {
+					int pos = -1;
+					for (int base = 0; base < nr && pos < 0; base += 64) {
+						const int i2 = base + lane;
+						const bool open = i2 < nr && ((unsigned)rkeys[i2] & 1u) == 0u;
+						const u64 m = __builtin_amdgcn_ballot_w64(open);
+						if (m)
+							pos = base + (int)__builtin_ctzll(m);
 					}
-					const u64 fmask = __builtin_amdgcn_ballot_w64(fresh);
-					ndis += (unsigned)__popcll(fmask);
-					const float mydd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, fmask, lane);
-					const float wmax = nr < efC ? FLT_MAX : key_dis(rfl64(rkeys[efC - 1]));
-					u64 mm = __builtin_amdgcn_ballot_w64(fresh && (nr < efC || mydd < wmax));
-					while (mm) {
-						const int l = (int)__builtin_ctzll(mm);
-						mm &= mm - 1;
-						const float dd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydd), l));
-						// "if (results.size() < efConstruction || results.top().d > dis)"
-						if (nr < efC || key_dis(rfl64(rkeys[nr - 1])) > dd)
-							nr = sorted_insert(rkeys, nr, efC, mk_key(dd, __builtin_amdgcn_readlane(nid, l)), lane);
-					}
-					if (~vmask)
+					if (pos < 0)
 						break;
+					const u64 ck = rfl64(rkeys[pos]);
+					if (lane == 0)
+						rkeys[pos] = ck | 1ull;
+					wave_fence();
+					const int cur = key_id(ck);
+					const long long base0 = g.offsets[cur] + cum_at(g, level);
+					for (int c0 = 0; c0 < L; c0 += 64) {
+						const int j = c0 + lane;
+						const int nid = j < L ? ld_nb<true>(g.neighbors + base0 + j) : -1;
+						const u64 vmask = __builtin_amdgcn_ballot_w64(nid >= 0);
+						const u64 pm = valid_prefix(vmask);
+						bool fresh = false;
+						if ((pm >> lane) & 1ull) {
+							fresh = vis[nid] != (uint8_t)stamp;
+							if (fresh)
+								vis[nid] = (uint8_t)stamp;
+						}
+						const u64 fmask = __builtin_amdgcn_ballot_w64(fresh);
+						ndis += (unsigned)__popcll(fmask);
+						const float mydd = eval_lanes<NI, IS_L2, G>(q, g.vecs, g.dp4, nid, fmask, lane);
+						const float wmax = nr < efC ? FLT_MAX : key_dis(rfl64(rkeys[efC - 1]));
+						u64 mm = __builtin_amdgcn_ballot_w64(fresh && (nr < efC || mydd < wmax));
+						while (mm) {
+							const int l = (int)__builtin_ctzll(mm);
+							mm &= mm - 1;
+							const float dd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mydd), l));
+							// "if (results.size() < efConstruction || results.top().d > dis)"
+							if (nr < efC || key_dis(rfl64(rkeys[nr - 1])) > dd)
+								nr = sorted_insert(rkeys, nr, efC, mk_key(dd, __builtin_amdgcn_readlane(nid, l)), lane);
+						}
+						if (~vmask)
+							break;
+					}
 				}
+				// ---- shrink to the level's capacity, then link both ways (add_links_starting_from)
+				const int nsel = shrink_select<NI, IS_L2, G>(g, rkeys, nr, L, out_id, out_d, lane, ndis);
+				for (int j = lane; j < nsel; j += 64)
+					sel_id[j] = out_id[nsel - 1 - j]; // priority_queue pops the farthest first
+				if (lane == 0)
+					ctl[1] = nsel;
+				wave_fence();
+				for (int t = 0; t < nsel; t++)
+					add_link<NI, IS_L2, G>(g, q, pt, rfl(sel_id[t]), level, tkeys, out_id, out_d, lane, ndis, a.clean);
+				wave_unlock(a, pt, lane);
 			}
-			// ---- shrink to the level's capacity, then link both ways (add_links_starting_from)
-			const int nsel = shrink_select<NI, IS_L2, G>(g, rkeys, nr, L, out_id, out_d, lane, ndis);
-			for (int j = lane; j < nsel; j += 64)
-				sel_id[j] = out_id[nsel - 1 - j]; // priority_queue pops the farthest first
-			wave_fence();
-			for (int t = 0; t < nsel; t++)
-				add_link<NI, IS_L2, G>(g, q, pt, rfl(sel_id[t]), level, tkeys, out_id, out_d, lane, ndis);
-			wave_unlock(a, pt, lane);
-			for (int t = 0; t < nsel; t++) {
+			__syncthreads();
+			const int nsel = rfl(ctl[1]);
+			for (int t = wave; t < nsel; t += W) {
 				const int other = rfl(sel_id[t]);
 				wave_lock(a, other, lane);
 				QV<NI> qo;
 				load_row(qo, g.vecs + (size_t)other * g.dp4 * 4, g.dp4, lane);
-				add_link<NI, IS_L2, G>(g, qo, other, pt, level, tkeys, out_id, out_d, lane, ndis);
+				add_link<NI, IS_L2, G>(g, qo, other, pt, level, tkeys, out_id, out_d, lane, ndis, a.clean);
 				wave_unlock(a, other, lane);
 			}
-			wave_lock(a, pt, lane);
+			__syncthreads();
+			if (wave == 0)
+				wave_lock(a, pt, lane);
 		}
-		wave_unlock(a, pt, lane);
+		if (wave == 0)
+			wave_unlock(a, pt, lane);
 	}
 	if (lane == 0) {
-		a.vstamp[blockIdx.x] = stamp;
+		if (wave == 0)
+			a.vstamp[blockIdx.x] = stamp;
 		if (a.stats)
 			atomicAdd(&a.stats[0], (unsigned long long)ndis);
 	}
@@ -1242,10 +1349,22 @@ MVS_HNSW_RL_STRUCTS(3)
 #undef MVS_HNSW_RL_STRUCTS
 template <int NI, bool IS_L2, int G>
 struct BuildLaunch {
-	static void run(const BuildArgs &a, int grid, size_t lds, hipStream_t st) {
-		ensure_dynamic_lds((const void *)hnsw_build_kernel<NI, IS_L2, G>, lds);
-		hipLaunchKernelGGL((hnsw_build_kernel<NI, IS_L2, G>), dim3(grid), dim3(64), lds, st, a);
+	template <int W>
+	static void run_w(const BuildArgs &a, int grid, size_t lds, hipStream_t st) {
+		ensure_dynamic_lds((const void *)hnsw_build_kernel<NI, IS_L2, G, W>, lds);
+		hipLaunchKernelGGL((hnsw_build_kernel<NI, IS_L2, G, W>), dim3(grid), dim3(64 * W), lds, st, a);
 		MVS_HIP(hipGetLastError());
+	}
+	// wg: wavefronts per inserted point (1 | 2 | 4 | 8)
+	static void run(const BuildArgs &a, int grid, size_t lds, hipStream_t st, int wg) {
+		if (wg >= 8)
+			run_w<8>(a, grid, lds, st);
+		else if (wg >= 4)
+			run_w<4>(a, grid, lds, st);
+		else if (wg >= 2)
+			run_w<2>(a, grid, lds, st);
+		else
+			run_w<1>(a, grid, lds, st);
 	}
 };
 
@@ -1290,6 +1409,9 @@ public:
 	int efSearch = 16;       // HNSW::efSearch default (the glue always passes SearchParametersHNSW, :693)
 	int dp, dp4;
 	int64_t build_waves = 0; // 0 = auto (concurrent, FAISS OpenMP semantics); 1 = deterministic order
+	const bool profile_build = getenv("MVS_INGEST_PROFILE") != nullptr;
+	int build_shortcut = 1;  // option hnsw_build_shortcut: add_link's short cut for full lists that are their last shrink's output (0: always the full pass)
+	int build_wg = 4;        // option hnsw_build_wg: wavefronts that share one insertion's back links (1 | 2 | 4 | 8)
 	int entry_point = -1, max_level = -1;
 	double last_evals = 0, last_bf16_rows = 0, last_f32_rows_pub = 0; // counters of the last timed search (hnsw_walk_stats)
 
@@ -1324,6 +1446,7 @@ public:
 		offsets.release();
 		neighbors.release();
 		locks.release();
+		clean.release();
 		nb0.release();
 		vbf.release();
 		ymax_dev.release();
@@ -1397,14 +1520,17 @@ public:
 		a.counter = (int *)ws_counter.p;
 		a.locks = (int *)locks.p;
 		a.use_locks = waves > 1;
+		a.count_spins = profile_build ? 1 : 0;
+		a.clean = build_shortcut ? (unsigned char *)clean.p : nullptr;
 		a.visited = (uint8_t *)bvis.p;
 		a.vstride = bvis_stride;
 		a.vstamp = (unsigned *)bstamp.p;
 		a.stats = (unsigned long long *)ws_stats.p;
 		MVS_HIP(hipMemsetAsync(ws_counter.p, 0, sizeof(int), stream));
 		const int L0 = 2 * M;
-		const size_t lds = (size_t)(efConstruction + L0 + 1) * 8 + (size_t)(L0 + 1) * 8 + (size_t)L0 * 4 + 64;
-		dispatch_ni<BuildLaunch, false>(dp4, metric == METRIC_L2, 0, a, waves, lds, stream);
+		const int wg = build_wg >= 8 ? 8 : (build_wg >= 4 ? 4 : (build_wg >= 2 ? 2 : 1)); // wavefronts per inserted point (hnsw_build_kernel)
+		const size_t lds = (size_t)efConstruction * 8 + (size_t)L0 * 4 + 8 + (size_t)wg * (L0 + 1) * 16 + 64;
+		dispatch_ni<BuildLaunch, false>(dp4, metric == METRIC_L2, 0, a, waves, lds, stream, wg);
 	}
 
 	// d_x: [n][d] rows on device, ordered after everything enqueued on `stream`
@@ -1437,6 +1563,7 @@ public:
 		neighbors.ensure(nb_new, nb_old, stream);
 		MVS_HIP(hipMemsetAsync((char *)neighbors.p + nb_old, 0xFF, nb_new - nb_old, stream)); // -1 = empty slot
 		locks.ensure((size_t)nt * sizeof(int), (size_t)n0 * sizeof(int), stream, 0);
+		clean.ensure((size_t)nt, (size_t)n0, stream, 0);
 		// hnsw_add_vertices: bucket sort by level, per bucket (highest level first) shuffle with rng2(789)
 		std::vector<int> hist((size_t)bucket_max + 1, 0);
 		for (int64_t i = 0; i < n; i++)
@@ -1518,6 +1645,9 @@ public:
 		unsigned long long st[2] = {0, 0};
 		MVS_HIP(hipMemcpy(st, ws_stats.p, sizeof st, hipMemcpyDeviceToHost));
 		build_distances += st[0];
+		if (profile_build)
+			fprintf(stderr, "hnswprofile\tadd(%lld rows): %llu distance evaluations, %llu failed lock attempts (each followed by s_sleep 8)\n", (long long)n,
+			        st[0], st[1]);
 	}
 	void add(int64_t n, const float *x) override {
 		use_device();
@@ -1719,6 +1849,8 @@ public:
 		HNSWIndex *c = static_cast<HNSWIndex *>(index_from_host(h, on_device));
 		c->rng = rng; // a clone continues the level stream where the source stands (read_index restarts it, like FAISS)
 		c->build_waves = build_waves;
+		c->build_wg = build_wg;
+		c->build_shortcut = build_shortcut;
 		c->label_offset = label_offset;
 		return c;
 	}
@@ -1796,6 +1928,8 @@ public:
 		offsets.ensure((size_t)(n + 1) * sizeof(int64_t), 0, stream);
 		neighbors.ensure(std::max<size_t>(h.neighbors.size() * 4, 16), 0, stream);
 		locks.ensure(std::max<size_t>((size_t)n * 4, 16), 0, stream, 0);
+		clean.ensure(std::max<size_t>((size_t)n, 16), 0, stream, 0);
+		MVS_HIP(hipMemsetAsync(clean.p, 0, clean.cap, stream)); // (nothing is known about the lists of a loaded graph)
 		if (n > 0) {
 			std::vector<float> tmp((size_t)n * dp, 0.f);
 			for (int64_t i = 0; i < n; i++)
@@ -1809,6 +1943,19 @@ public:
 	bool set_option(const char *key, int64_t v) override {
 		if (!strcmp(key, "hnsw_build_waves")) {
 			build_waves = v;
+			return true;
+		}
+		if (!strcmp(key, "hnsw_build_shortcut")) {
+			use_device();
+			if (clean.p) { // (lists change unflagged while the short cut is off: nothing is known about them when it comes back)
+				MVS_HIP(hipMemsetAsync(clean.p, 0, clean.cap, stream));
+				MVS_HIP(hipStreamSynchronize(stream));
+			}
+			build_shortcut = (int)v;
+			return true;
+		}
+		if (!strcmp(key, "hnsw_build_wg")) {
+			build_wg = (int)v;
 			return true;
 		}
 		if (!strcmp(key, "hnsw_ef_search")) {
@@ -1858,7 +2005,7 @@ private:
 	std::vector<int> cum_nn;
 	std::vector<int32_t> levels_h;
 	std::vector<int64_t> offsets_h;
-	KeepBuf vecs, offsets, neighbors, locks, nb0, vbf, ymax_dev;
+	KeepBuf vecs, offsets, neighbors, locks, clean, nb0, vbf, ymax_dev;
 	int64_t nb0_rows = 0, vbf_rows = 0;
 	int reg_lists = 1; // option hnsw_reg_lists: candidate / result lists in registers when ef <= 128 and k <= 64 (0: LDS arrays)
 	int bf16_look = 1, occ_bf = -1; // option hnsw_bf16: bf16 first look of the search walk (0: every fresh neighbour's f32 row is fetched)
