@@ -969,7 +969,7 @@ __device__ __forceinline__ int shrink_select(const GraphDev &g, const u64 *keys,
 // insertion near them queues on their lock: the short cut is what shortens that queue (profiles/r6_hnsw_build.txt).
 template <int NI, bool IS_L2, int G>
 __device__ __forceinline__ void add_link(const GraphDev &g, const QV<NI> &srcq, int src, int dest, int level, u64 *tkeys,
-                                         int *out_id, float *out_d, int lane, unsigned &ndis, unsigned char *clean) {
+                                         int *out_id, float *out_d, int lane, unsigned &ndis, unsigned char *clean, unsigned long long *nshort) {
 	const int L = nb_at(g, level);
 	int32_t *list = g.neighbors + g.offsets[src] + cum_at(g, level);
 	if (rfl(ld_nb<true>(list + L - 1)) == -1) { // room left: first free slot
@@ -1020,6 +1020,8 @@ __device__ __forceinline__ void add_link(const GraphDev &g, const QV<NI> &srcq, 
 	int nout;
 	if (cflag & lbit) {
 		// ---- the short cut: tkeys = k_1 .. k_L and dest, closest first
+		if (nshort && lane == 0)
+			atomicAdd(nshort, 1ull);
 		int r = 0;
 		for (int j0 = 0; j0 < nt; j0 += 64) {
 			const int j = j0 + lane;
@@ -1201,7 +1203,7 @@ __global__ __launch_bounds__(64 * W) void hnsw_build_kernel(const BuildArgs a) {
 					ctl[1] = nsel;
 				wave_fence();
 				for (int t = 0; t < nsel; t++)
-					add_link<NI, IS_L2, G>(g, q, pt, rfl(sel_id[t]), level, tkeys, out_id, out_d, lane, ndis, a.clean);
+					add_link<NI, IS_L2, G>(g, q, pt, rfl(sel_id[t]), level, tkeys, out_id, out_d, lane, ndis, a.clean, a.stats ? a.stats + 2 : nullptr);
 				wave_unlock(a, pt, lane);
 			}
 			__syncthreads();
@@ -1211,7 +1213,7 @@ __global__ __launch_bounds__(64 * W) void hnsw_build_kernel(const BuildArgs a) {
 				wave_lock(a, other, lane);
 				QV<NI> qo;
 				load_row(qo, g.vecs + (size_t)other * g.dp4 * 4, g.dp4, lane);
-				add_link<NI, IS_L2, G>(g, qo, other, pt, level, tkeys, out_id, out_d, lane, ndis, a.clean);
+				add_link<NI, IS_L2, G>(g, qo, other, pt, level, tkeys, out_id, out_d, lane, ndis, a.clean, a.stats ? a.stats + 2 : nullptr);
 				wave_unlock(a, other, lane);
 			}
 			__syncthreads();
@@ -1591,7 +1593,7 @@ public:
 		MVS_HIP(hipMemcpyAsync(ws_order.p, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
 		ws_counter.reserve(64);
 		ws_stats.reserve(128);
-		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 16, stream));
+		MVS_HIP(hipMemsetAsync(ws_stats.p, 0, 32, stream));
 		// visited tables of the build waves
 		int max_waves = build_waves > 0 ? (int)std::min<int64_t>(build_waves, 4096) : 1024;
 		const size_t vcap = vecs.cap / ((size_t)dp * sizeof(float)); // rows the vector store can hold
@@ -1642,12 +1644,13 @@ public:
 			i1 = i0;
 		}
 		MVS_HIP(hipStreamSynchronize(stream)); // `order` (pageable) and the caller's rows are done
-		unsigned long long st[2] = {0, 0};
+		unsigned long long st[4] = {0, 0, 0, 0};
 		MVS_HIP(hipMemcpy(st, ws_stats.p, sizeof st, hipMemcpyDeviceToHost));
 		build_distances += st[0];
+		build_shortcuts += st[2];
 		if (profile_build)
-			fprintf(stderr, "hnswprofile\tadd(%lld rows): %llu distance evaluations, %llu failed lock attempts (each followed by s_sleep 8)\n", (long long)n,
-			        st[0], st[1]);
+			fprintf(stderr, "hnswprofile\tadd(%lld rows): %llu distance evaluations, %llu short cuts, %llu failed lock attempts (each followed by s_sleep 8)\n",
+			        (long long)n, st[0], st[2], st[1]);
 	}
 	void add(int64_t n, const float *x) override {
 		use_device();
@@ -1940,6 +1943,15 @@ public:
 		MVS_HIP(hipMemcpy(offsets.p, offsets_h.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
 		ntotal = n;
 	}
+	bool named_stat(const char *name, int64_t *v) override {
+		if (!strcmp(name, "hnsw_build_distances"))
+			*v = (int64_t)build_distances;
+		else if (!strcmp(name, "hnsw_build_shortcuts"))
+			*v = (int64_t)build_shortcuts;
+		else
+			return false;
+		return true;
+	}
 	bool set_option(const char *key, int64_t v) override {
 		if (!strcmp(key, "hnsw_build_waves")) {
 			build_waves = v;
@@ -1997,7 +2009,7 @@ public:
 		if (graph_slots() > 0)
 			MVS_HIP(hipMemcpy(neighbors_out, neighbors.p, (size_t)graph_slots() * 4, hipMemcpyDeviceToHost));
 	}
-	unsigned long long build_distances = 0;
+	unsigned long long build_distances = 0, build_shortcuts = 0; // (mvs_index_get_stat: evaluations of all builds | add_link calls that took the short cut)
 
 private:
 	std::mt19937 rng; // RandomGenerator(12345)

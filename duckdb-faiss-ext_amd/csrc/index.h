@@ -130,6 +130,9 @@ public:
 	virtual void set_label_offset(int64_t off) {
 		label_offset = off;
 	}
+	virtual bool named_stat(const char *, int64_t *) { // index-specific counters of mvs_index_get_stat (HNSW: hnsw_build_distances | hnsw_build_shortcuts)
+		return false;
+	}
 	virtual bool probe_stats(int64_t *, int64_t *, int64_t *, int64_t *) { // IVF: (query, list) pairs of the last search / of those, scanned (mvs_index_ivf_probe_stats)
 		return false;
 	}

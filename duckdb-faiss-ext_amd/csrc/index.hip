@@ -2460,7 +2460,7 @@ int mvs_index_get_stat(mvs_index *ix, const char *name, int64_t *value) {
 			}
 			*value = (int64_t)v;
 		}
-	} else {
+	} else if (!p->named_stat(name, value)) {
 		throw_faiss("mvs_index_get_stat", __FILE__, "unknown statistic %s", name);
 	}
 	MVS_API_END

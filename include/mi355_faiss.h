@@ -243,7 +243,9 @@ int mvs_index_shadow_stats(mvs_index *ix, int64_t *stats, double *build_seconds)
  * quantizer->search, src/faiss_extension.cpp:631) ran as a bf16 filter + exact re-scoring (csrc/coarse_bf16.hip);
  * "coarse_bf16_exhaustive" = of those, queries that were computed against every centroid (list overflow / no finite bound);
  * "coarse_bf16_candidates" = centroids re-scored exactly in the last such call, summed over its queries; "flat_outlier_rows" = rows of a
- * Flat index kept out of its bf16 coarse-filter store because of their norm (they join every query's candidates: csrc/flat_collect.hip) */
+ * Flat index kept out of its bf16 coarse-filter store because of their norm (they join every query's candidates: csrc/flat_collect.hip);
+ * "hnsw_build_distances" / "hnsw_build_shortcuts" = distance evaluations of an HNSW index's builds so far / add_link calls that took the
+ * full-list short cut instead of HNSW::shrink_neighbor_list's pairwise pass (csrc/hnsw.hip; IndexHNSW::add, src/faiss_extension.cpp:510) */
 int mvs_index_get_stat(mvs_index *ix, const char *name, int64_t *value);
 /* named ranges for rocprofv3 --marker-trace (roctx; bound at run time, only under a profiler or with MVS_ROCTX=1): the library
  * marks its own stages (row staging, Flat / IVF search, shard search, exchange, merge); a host that merges shard results itself

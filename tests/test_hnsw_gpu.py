@@ -58,6 +58,33 @@ def test_deterministic_build_reproduces_oracle_graph(mf, metric, d, M, n):
     _assert_same_graph(o, g)
 
 
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,M,n", [(16, 4, 4000), (64, 8, 3000)])
+def test_full_list_short_cut_is_the_full_shrink(mf, metric, d, M, n):
+    """round 6: add_link's short cut for a list that is full and still the output of its last shrink (csrc/hnsw.hip) -- small M on
+    uniform rows fills the lists early, so most back links take it; the graph is the oracle's (FAISS's pairwise pass) bit for bit,
+    with the short cut and without, for fewer distance evaluations"""
+    xb = orc.synth_uniform(n, d, 29)
+    o, g = _pair(mf, d, f"HNSW{M}", metric, xb, chunk=1000)
+    _assert_same_graph(o, g)
+    assert g.get_stat("hnsw_build_shortcuts") > 100, g.get_stat("hnsw_build_shortcuts")
+    g0 = mf.index_factory(d, f"HNSW{M}", metric)
+    g0.set_option("hnsw_build_waves", 1)
+    g0.set_option("hnsw_build_shortcut", 0)
+    for i in range(0, n, 1000):
+        g0.add(xb[i : i + 1000])
+    _assert_same_graph(o, g0)
+    assert g0.get_stat("hnsw_build_shortcuts") == 0
+    assert g.get_stat("hnsw_build_distances") < g0.get_stat("hnsw_build_distances")
+    # the option can be flipped between adds: the flags of lists that changed unflagged are dropped with it
+    g1 = mf.index_factory(d, f"HNSW{M}", metric)
+    g1.set_option("hnsw_build_waves", 1)
+    for j, i in enumerate(range(0, n, 1000)):
+        g1.set_option("hnsw_build_shortcut", j & 1)
+        g1.add(xb[i : i + 1000])
+    _assert_same_graph(o, g1)
+
+
 def test_harness_shape_hnsw128_d1536(mf):
     """the Go harness index (go/benches_c.go:59): IDMap,HNSW128,Flat, d=1536, default metric inner product -- level-0
     lists of 256 slots (4 lane chunks), 6 float4 per lane per row"""
