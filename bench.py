@@ -665,16 +665,34 @@ def main():
                 except Exception:  # noqa: BLE001
                     return 0, 0
 
+            def scan():  # (rows the coarse filter admitted in the last search -- before the final-bound filter --, dominant kernel's ms)
+                try:
+                    adm = ix.ivf_probe_stats()["admitted"] if not is_ivf else None
+                    return (round(adm / max(nq, 1), 1) if adm is not None else None), round(ix.last_kernel_info()["last_ms"], 3)
+                except Exception:  # noqa: BLE001
+                    return None, None
+
             xq_other = (0.5 * (xq + xq.roll(1, 0))).contiguous()
             if args.normalize:
                 xq_other = prep(xq_other)
+            # (a search that follows ~50 ms without device work takes ~15 % longer WHATEVER the batch -- clocks and power state of an idle
+            # device, profiles/r6_batch_state.txt; the host-side census above is such a gap, so one discarded search comes first and the
+            # gap's own cost is reported on its own line.  Round 5's "other batch + 12 %" was this, not the batch.)
+            one(xq)
+            time.sleep(0.05)
+            t_idle = one(xq)
+            one(xq)
             c0 = cands()
             t_other = one(xq_other)
+            s_other = scan()
             c1 = cands()
             t_after = one(xq)
+            s_after = scan()
             c2 = cands()
             t_after2 = one(xq)
             state_sens = {
+                "other_batch_admitted_per_query": s_other[0], "step_after_admitted_per_query": s_after[0],
+                "step_after_50ms_idle_ms": round(t_idle, 3),
                 "first_call_ms": round(first_call_ms, 3) if first_call_ms is not None else None,
                 "other_batch": "midpoints of neighbouring queries",
                 "other_batch_ms": round(t_other, 3),

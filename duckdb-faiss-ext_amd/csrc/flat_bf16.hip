@@ -98,8 +98,9 @@ __global__ void rows_to_bf16_kernel(const float *__restrict__ src, long long row
 	*(bf16x8 *)(row + c8 * 8) = hi;
 	*(bf16x8 *)(row + dp + c8 * 8) = lo;
 	if (c8 == 0) { // largest squared row norm (>= 0: the bit pattern orders like the value; NaN sorts above everything)
+		// (agent-scope load: a plain one is served from this CU's vector cache as first fetched and every row would send its atomic)
 		const unsigned b = __float_as_uint(norms[r]);
-		if (b > *max_norm_bits)
+		if (b > __hip_atomic_load(max_norm_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 			atomicMax(max_norm_bits, b);
 	}
 }
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(64) void rescore_verify_kernel(const float *__restr
 		}
 		for (int o = 32; o >= 1; o >>= 1)
 			rel = fmaxf(rel, __shfl_xor(rel, o));
-		if (j == 0 && rel > 0.f && __float_as_uint(rel) > *max_rel_err_bits)
+		if (j == 0 && rel > 0.f && __float_as_uint(rel) > __hip_atomic_load(max_rel_err_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 			atomicMax(max_rel_err_bits, __float_as_uint(rel));
 	}
 	// proof

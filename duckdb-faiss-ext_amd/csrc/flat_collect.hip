@@ -172,14 +172,31 @@ void launch_collect_append_outliers(const int *d_outl, int n_outliers, int64_t n
 // one thread per (row, 8 dims); the dp / 8 threads of a row are neighbours in a wave
 // max_bits[0]: largest squared norm of the ORIGINAL rows (shared with flat_bf16.hip), max_bits[8]: of the centred rows,
 // max_bits[12]: of the centred rows' bf16 rounding residuals y' - bf16(y'); [2], [3], outl: see "outlier rows" above
+// (round 6: the maxima are kept in registers over a grid-stride loop and reach max_bits with ONE atomic per wave and maximum at the end.
+// Rounds 4-5 compared every row against a plain load of max_bits[..] -- which a CU's vector cache keeps serving as it was when the line
+// was first fetched, atomics by other CUs notwithstanding -- so nearly every row sent its atomicMax to the same L2 line: 9.9 M atomics
+// for 10 M rows, 103 ms for a 7.7 GB pass, most of a first search's 142 ms: profiles/r6_first_call.txt)
+__device__ __forceinline__ unsigned cl_wave_max_u32(unsigned v) {
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) {
+		const unsigned w = (unsigned)__shfl_xor((int)v, o);
+		v = w > v ? w : v;
+	}
+	return v;
+}
 template <bool IS_L2>
 __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long row0, long long nrows, int dp, int dpd,
                                        int interleaved, const float *__restrict__ mu, unsigned short *__restrict__ dst,
                                        float *__restrict__ beta, const float *__restrict__ norms,
                                        unsigned *__restrict__ max_bits, int *__restrict__ outl) {
-	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const int g8 = dp / 8;
-	const bool live = i < nrows * g8;
+	const long long total = nrows * g8, stride = (long long)gridDim.x * blockDim.x;
+	const float tau = outl ? __uint_as_float(max_bits[3]) : INFINITY; // (written before this launch)
+	unsigned m0 = 0u, m2 = 0u, m8 = 0u, m12 = 0u; // this thread's share of max_bits[0], [2], [8], [12]
+	// (every lane of a wave runs the same number of rounds: the DPP / shuffle sums below need the row's 16 neighbours)
+	for (long long base = (long long)blockIdx.x * blockDim.x; base < total; base += stride) {
+	const long long i = base + threadIdx.x;
+	const bool live = i < total;
 	const long long r = row0 + (live ? i / g8 : 0);
 	const int c8 = (int)(i % g8);
 	float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -218,16 +235,16 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 			r2 += __shfl_xor(r2, o);
 		}
 	}
-	if (!live)
-		return;
-	const unsigned b = __float_as_uint(norms[r]);
 	// (n2 is the whole row's sum in every one of its g8 threads; the first of them takes the slot, the others read it from its lane --
 	// the count may run past the capacity: rows beyond it stay in the store, and in the maxima)
-	const bool big = outl != nullptr && n2 > __uint_as_float(max_bits[3]);
+	const bool big = live && n2 > tau;
 	int slot = CL_OUTL_CAP;
 	if (big && c8 == 0)
 		slot = atomicAdd(outl, 1);
 	slot = __shfl(slot, (int)(threadIdx.x & 63u) & ~(g8 - 1));
+	if (!live)
+		continue;
+	const unsigned b = __float_as_uint(norms[r]);
 	const bool out = big && slot < CL_OUTL_CAP;
 	if (out) {
 		if (c8 == 0)
@@ -236,24 +253,31 @@ __global__ void rows_to_bf16_hi_kernel(const float *__restrict__ src, long long 
 		*(bf16x8 *)(dst + (size_t)r * dpd + c8 * 8) = zero;
 		if (c8 == 0) {
 			beta[r] = -INFINITY;
-			if (b > max_bits[0])
-				atomicMax(max_bits, b);
+			m0 = b > m0 ? b : m0;
 		}
-		return;
+		continue;
 	}
 	*(bf16x8 *)(dst + (size_t)r * dpd + c8 * 8) = hi; // (dpd = 128 >= dp: the store is zero-filled when it is allocated)
 	if (c8 == 0) {
 		beta[r] = IS_L2 ? -n2 : my;
-		if (b > max_bits[0])
-			atomicMax(max_bits, b);
-		if (b > max_bits[2])
-			atomicMax(max_bits + 2, b);
+		m0 = b > m0 ? b : m0;
+		m2 = b > m2 ? b : m2;
 		const unsigned bc = __float_as_uint(n2); // (>= 0 or NaN: the bit pattern orders like the value, NaN above everything)
-		if (bc > max_bits[8])
-			atomicMax(max_bits + 8, bc);
+		m8 = bc > m8 ? bc : m8;
 		const unsigned br = __float_as_uint(r2);
-		if (br > max_bits[12])
-			atomicMax(max_bits + 12, br);
+		m12 = br > m12 ? br : m12;
+	}
+	}
+	m0 = cl_wave_max_u32(m0), m2 = cl_wave_max_u32(m2), m8 = cl_wave_max_u32(m8), m12 = cl_wave_max_u32(m12);
+	if ((threadIdx.x & 63u) == 0u) {
+		if (m0)
+			atomicMax(max_bits, m0);
+		if (m2)
+			atomicMax(max_bits + 2, m2);
+		if (m8)
+			atomicMax(max_bits + 8, m8);
+		if (m12)
+			atomicMax(max_bits + 12, m12);
 	}
 }
 void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, int64_t row0, int64_t nrows, const float *d_mu,
@@ -262,7 +286,7 @@ void launch_rows_to_bf16_hi(const FlatGeom &g, int metric, const float *d_vecs, 
 	if (nrows <= 0)
 		return;
 	const long long total = (long long)nrows * (g.dp / 8);
-	const dim3 grid((unsigned)((total + 255) / 256));
+	const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, 16384)); // (grid-stride: 16 resident workgroups per CU, four rounds)
 	if (metric == METRIC_L2)
 		hipLaunchKernelGGL(rows_to_bf16_hi_kernel<true>, grid, dim3(256), 0, st, d_vecs, (long long)row0, (long long)nrows, g.dp, 128,
 		                   g.pair_interleaved ? 1 : 0, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits, d_outl);

@@ -633,10 +633,13 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
                                                                unsigned short *__restrict__ dst, float *__restrict__ beta,
                                                                const float *__restrict__ norms, unsigned *__restrict__ max_bits,
                                                                int *__restrict__ outl) {
-	const long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
-	if (r >= row0 + nrows)
-		return;
+	// (round 6: grid-stride over the rows, the maxima in registers, one atomic per wave and maximum at the end -- a plain load of
+	// max_bits[..] is served from the CU's vector cache as it was first fetched, so rounds 4-5 sent four atomics PER ROW to one L2 line:
+	// csrc/flat_collect.hip rows_to_bf16_hi_kernel)
+	const float tau = outl ? __uint_as_float(max_bits[3]) : INFINITY; // (written before this launch)
+	unsigned m0 = 0u, m2 = 0u, m8 = 0u, m12 = 0u;
+	for (long long r = row0 + (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < row0 + nrows; r += (long long)gridDim.x * 4) {
 	// FlatGeom::pair_interleaved: every 4 floats stored [k0,k2,k1,k3] (bit 4 of the row clear) or [k1,k3,k0,k2]
 	const int flip = interleaved ? (((r >> 4) & 1) ? 2 : 0) : 0;
 	float n2 = 0.f, my = 0.f, r2 = 0.f; // ||y'||^2, <mu, y>, ||y' - bf16(y')||^2 (flat_collect.hip, "ROUND 4")
@@ -662,9 +665,9 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
 		my += __shfl_xor(my, o);
 		r2 += __shfl_xor(r2, o);
 	}
+	const unsigned b = __float_as_uint(norms[r]);
 	// outlier rows stay out of the store (csrc/flat_collect.hip "outlier rows"): zero vector, beta = -inf, not in the maxima
 	{
-		const float tau = __uint_as_float(max_bits[3]);
 		int slot = CL_OUTL_CAP;
 		if (n2 > tau && outl) {
 			if (lane == 0)
@@ -678,26 +681,29 @@ __global__ __launch_bounds__(256) void rows_to_bf16_wide_kernel(const float *__r
 			if (lane == 0) {
 				outl[1 + slot] = (int)r;
 				beta[r] = -INFINITY;
-				const unsigned b = __float_as_uint(norms[r]);
-				if (b > max_bits[0])
-					atomicMax(max_bits, b);
 			}
-			return;
+			m0 = b > m0 ? b : m0;
+			continue;
 		}
 	}
-	if (lane == 0) {
+	if (lane == 0)
 		beta[r] = IS_L2 ? -n2 : my;
-		const unsigned b = __float_as_uint(norms[r]);
-		if (b > max_bits[0])
-			atomicMax(max_bits, b);
-		if (b > max_bits[2])
-			atomicMax(max_bits + 2, b);
-		const unsigned bc = __float_as_uint(n2);
-		if (bc > max_bits[8])
-			atomicMax(max_bits + 8, bc);
-		const unsigned br = __float_as_uint(r2);
-		if (br > max_bits[12])
-			atomicMax(max_bits + 12, br);
+	m0 = b > m0 ? b : m0;
+	m2 = b > m2 ? b : m2;
+	const unsigned bc = __float_as_uint(n2);
+	m8 = bc > m8 ? bc : m8;
+	const unsigned br = __float_as_uint(r2);
+	m12 = br > m12 ? br : m12;
+	}
+	if (lane == 0) { // (the wave's values are uniform: every lane saw the same sums)
+		if (m0)
+			atomicMax(max_bits, m0);
+		if (m2)
+			atomicMax(max_bits + 2, m2);
+		if (m8)
+			atomicMax(max_bits + 8, m8);
+		if (m12)
+			atomicMax(max_bits + 12, m12);
 	}
 }
 void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int interleaved, int d, int dp1, int64_t row0, int64_t nrows,
@@ -705,7 +711,7 @@ void launch_rows_to_bf16_wide(int metric, const float *d_vecs, int sdp, int inte
                               unsigned *d_max_norm_bits, hipStream_t st, int *d_outl) {
 	if (nrows <= 0)
 		return;
-	const dim3 grid((unsigned)((nrows + 3) / 4));
+	const dim3 grid((unsigned)std::min<int64_t>((nrows + 3) / 4, 16384)); // (grid-stride)
 	if (metric == METRIC_L2)
 		hipLaunchKernelGGL(rows_to_bf16_wide_kernel<true>, grid, dim3(256), 0, st, d_vecs, sdp, d, dp1, interleaved, (long long)row0,
 		                   (long long)nrows, d_mu, d_bf, d_beta, d_norms, d_max_norm_bits, d_outl);

@@ -272,7 +272,7 @@ __global__ void hnsw_rows_to_bf16_kernel(const float *__restrict__ vecs, long lo
 	}
 	for (int o = 32; o >= 1; o >>= 1)
 		n2 += __shfl_xor(n2, o);
-	if (lane == 0 && __float_as_uint(n2) > *max_bits)
+	if (lane == 0 && __float_as_uint(n2) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) // (agent scope: a plain load stays as first cached)
 		atomicMax(max_bits, __float_as_uint(n2)); // (>= 0: the bit pattern orders like the value; NaN sorts above everything)
 }
 

@@ -115,7 +115,7 @@ __global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *o
 	float v = i < n ? norms[i] : 0.f;
 	for (int o = 32; o >= 1; o >>= 1)
 		v = fmaxf(v, __shfl_xor(v, o));
-	if ((threadIdx.x & 63) == 0 && __float_as_uint(v) > *out_bits)
+	if ((threadIdx.x & 63) == 0 && __float_as_uint(v) > __hip_atomic_load(out_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) // (agent scope: a plain load stays as first cached)
 		atomicMax(out_bits, __float_as_uint(v)); // squared norms are >= 0: the bit pattern orders like the value
 }
 

@@ -116,10 +116,12 @@ __global__ void ivf_rows_to_bf16_kernel(const float *__restrict__ src, long long
 		beta[r] = -n2;
 		unsigned *m = list_max_bits + list_of_blk64[r >> 6];
 		const unsigned b = __float_as_uint(n2); // (>= 0 or NaN: the bit pattern orders like the value)
-		if (b > *m)
+		// (agent-scope loads: a plain load is served from this CU's vector cache as the line was first fetched -- every row would then send
+		// its atomic: csrc/flat_collect.hip rows_to_bf16_hi_kernel, round 6)
+		if (b > __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 			atomicMax(m, b);
 		const unsigned br = __float_as_uint(r2);
-		if (br > m[nlist])
+		if (br > __hip_atomic_load(m + nlist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 			atomicMax(m + nlist, br);
 	}
 }
