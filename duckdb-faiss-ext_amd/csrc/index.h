@@ -264,6 +264,7 @@ public:
 	bool cl_wide_refilter = true; // option cl_wide_refilter: the final-bound filter in front of the sorted pipeline of the 512 < d <= 1536 stores (flat_bf16_big_kernel)
 	bool cl_fbucket = true;      // option cl_fbucket
 	bool cl_fbucket_off = false; // a query's bucket overflowed on this index's data: the sorted pipeline from then on
+	bool cl_bigk = true; // option cl_bigk: lists of 129 .. 2048 entries on the coarse filter (bounds from row ranges, frozen scan, segmented sort); 0: the exact kernels
 	int cl_fpitch = 256;         // bucket entries per query
 	float *cl_out_D = nullptr;
 	int64_t *cl_out_I = nullptr;
@@ -489,7 +490,15 @@ void launch_collect_rowmask(SelectorDev sel, const int64_t *d_idmap, int64_t n, 
 void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms,
                          int64_t n, int64_t nq, int kk, const float *d_e2, unsigned *d_gslot, unsigned long long *d_stream,
                          unsigned long long *d_stream_cnt, int64_t stream_cap, const unsigned long long *d_rowmask, float *d_pbnd,
-                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out, float *d_stream_s = nullptr);
+                         hipStream_t st, int *grid_out, int *nsplit_out, int *lds_out, float *d_stream_s = nullptr, bool frozen = false);
+// lists beyond 128 entries (d <= 128 store): pass A -- T - 2E per query from nranges row ranges' class slots, into the scan's bound table;
+// the scan then runs with frozen = true (csrc/flat_collect.hip "lists beyond 128 entries")
+void launch_collect_big_bounds(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms, int64_t n,
+                               int64_t nq, int kf, int nranges, int64_t range_rows, const float *d_e2, unsigned *d_gslot,
+                               const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st);
+size_t collect_select_big_temp_bytes(int64_t ncand, int64_t nq);
+void launch_collect_select_big(int metric, unsigned long long *d_keys, unsigned long long *d_out, int64_t ncand, const int *d_seg, int64_t nq,
+                               int kk, void *d_temp, size_t temp_bytes, float *d_pd1, int32_t *d_pi1, hipStream_t st);
 // thr[q] = B - 2E from the class slots as the scan left them (csrc/flat_collect.hip): the final-bound filter of the bucketed finish
 void launch_mfma_bf16_probe(const unsigned short *d_A, const unsigned short *d_Bt, const float *d_C, float *d_D, int64_t ntiles, hipStream_t st);
 void launch_collect_report(const void *d_hdr, const int *d_fail_cnt, const unsigned *d_maxnorm, int *h_flags, void *h_hdr, bool with_cnt,

@@ -444,6 +444,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
                                    bool defer_count, int kf) {
 	if (kf <= 0 || kf > kk)
 		kf = kk;
+	// lists beyond 128 entries (round 6, d <= 128 store): the bounds come from a pass of their own over nranges row ranges, the scan runs
+	// against them frozen, the selection is a segmented sort -- csrc/flat_collect.hip "lists beyond 128 entries"
+	const bool bigk = kf > 128;
+	if (bigk)
+		defer_count = false; // (the candidate count sizes the sort: read back behind the scan)
 	ensure_h1_rows(st);
 	// IDSelector: one bit per row, built per search (the selector sees idmap[row] behind an IndexIDMap, the row number else)
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
@@ -459,7 +464,16 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_qn.reserve((size_t)nq * sizeof(float));
 	const int64_t nq128 = (nq + 255) / 256 * 256;
 	ws_e2.reserve((size_t)nq128 * sizeof(float));
-	ws_gthr.reserve((size_t)nq * collect_slot_stride(kf, collect_store_dims(d)) * sizeof(unsigned) + 64);
+	// (big lists: pass A looks at a quarter of the rows -- any rows give a valid bound, fewer rows a lower one and ~ntotal / rows times k
+	// candidates -- unless the candidates of a large batch would not fit: then at all of them)
+	const int bk_ranges = bigk ? (kf + 63) / 64 : 0;
+	int64_t bk_rows = 0; // rows per range
+	if (bigk) {
+		const bool whole = (double)nq * kf * 16.0 > (double)((int64_t)1 << 28);
+		const int64_t want = whole ? ntotal : std::max<int64_t>(ntotal / 4, (int64_t)bk_ranges * 16384);
+		bk_rows = std::min<int64_t>(std::max<int64_t>(want / bk_ranges, 4096), ntotal / bk_ranges) / 64 * 64;
+	}
+	ws_gthr.reserve((size_t)nq * collect_slot_stride(kf, collect_store_dims(d)) * sizeof(unsigned) * (bigk ? bk_ranges : 1) + 64);
 	ws_seg.reserve(256 + (size_t)2 * nq * sizeof(int));
 	// Round 5 (d <= 128 store): fragments, ||x||^2, bounds, neutral class slots and the zeroed control block in ONE launch
 	// (csrc/flat_collect.hip collect_query_prep_kernel) instead of four kernels and a memset
@@ -486,6 +500,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	// showed this index's data to need (cl_cap_hint, up to 16384 per query: clustered rows with large norms admit thousands)
 	int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024)
 	                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
+	if (bigk && cl_stream_cap_per_query <= 0) // (~ k ntotal / (rows of pass A) candidates per query, times the slack of a class bound)
+		cap_entries = std::max<int64_t>(cap_entries, nq * std::min<int64_t>(ntotal, 4 * (int64_t)kf * ntotal / std::max<int64_t>(bk_rows * bk_ranges, 1)));
 	size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 	ws_stream.reserve(256 + 2 * half);
 	// one zeroed control block {stream count | per-query segments} (round 4: one memset instead of three per search)
@@ -499,6 +515,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	float *pbnd = wide ? nullptr : (float *)ws_pbnd.p; // (the d <= 128 scan only)
 	if (!wide && cl_seed_stage)
 		ws_seed.reserve(collect_seed_stage_bytes(nq));
+	if (bigk)
+		launch_collect_big_bounds(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, bk_ranges, bk_rows, (const float *)ws_e2.p,
+		                          (unsigned *)ws_gthr.p, rowmask, (float *)ws_pbnd.p, st);
+	else
 	launch_collect_prepare(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, (const float *)ws_e2.p,
 	                       (unsigned *)ws_gthr.p, cnt, rowmask, pbnd, st, true, prep1, (!wide && cl_seed_stage) ? (float *)ws_seed.p : nullptr);
 	int grid = 0, nsplit = 0, lds = 0;
@@ -564,7 +584,8 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		lds = 20544;
 	} else {
 		launch_collect_scan(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, (const float *)ws_e2.p,
-		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, pbnd, st, &grid, &nsplit, &lds, stream_s);
+		                    (unsigned *)ws_gthr.p, stream, cnt, cap_entries, rowmask, bigk ? (float *)ws_pbnd.p : pbnd, st, &grid, &nsplit, &lds, stream_s,
+		                    bigk);
 	}
 	end_kernel_timing(st);
 	if (h1_outliers > 0) // the rows kept out of the store join every query's candidates (csrc/flat_collect.hip "outlier rows")
@@ -595,7 +616,9 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	++cl_overflows;
 	if (attempt > 0 || few)
 		return false;
-	const int64_t grow_max = cl_stream_cap_per_query > 0 ? 4 * (int64_t)cl_stream_cap_per_query : 16384;
+	const int64_t grow_max = cl_stream_cap_per_query > 0 ? 4 * (int64_t)cl_stream_cap_per_query : std::max<int64_t>(16384, bigk ? 64 * (int64_t)kf : 0);
+	if (bigk && ncand + ncand / 8 > nq * grow_max)
+		return false; // (frozen bounds: no query can be taken out of this scan -- the exact kernels take the batch)
 	if (ncand + ncand / 8 <= nq * grow_max) {
 		// (a) the data simply admits more rows per query than the stream was sized for: a larger stream, one more scan (the
 		// class slots are warm: it admits no more than the first), and the next search of this index starts with that size
@@ -700,8 +723,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		cl_sorted = nullptr;
 	} else {
 	// (the filtered stream is sorted in device-count mode whatever the count mode of the scan was)
-	const size_t temp = (defer_count || wrf) ? collect_sort_temp_bytes_est(defer_count ? cl_deferred_cap : std::max<int64_t>(ncand, 1), nq)
-	                                         : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
+	size_t temp = (defer_count || wrf) ? collect_sort_temp_bytes_est(defer_count ? cl_deferred_cap : std::max<int64_t>(ncand, 1), nq)
+	                                   : (ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0);
+	if (kk > 128 && ncand > 0) // (the selection of a big list is a segmented sort of the exact keys)
+		temp = std::max(temp, collect_select_big_temp_bytes(ncand, nq));
 	ws_sorttmp.reserve(std::max<size_t>(temp, 16));
 	const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
 	ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
@@ -1032,6 +1057,9 @@ void FlatIndex::search_flat(int64_t nq, const float *d_x, int64_t k, float *d_D,
 	if (((has_sel && (metric == METRIC_L2 || !ip_on_mfma)) || small_batch) && !force_direct && !force_staged &&
 	    search_prefilter(nq, d_x, k_user, k, d_D, d_I, params, d_idmap, out_map, out_off, flp, st)) {
 		// handled
+	} else if (k > mfma_kmax && !has_sel && !small_batch && !force_direct && !force_staged &&
+	           search_prefilter(nq, d_x, k_user, k, d_D, d_I, params, d_idmap, out_map, out_off, flp, st)) {
+		// (round 6) lists beyond the fused kernel's: the coarse filter's big-list path took the batch (FlatIndex::collect_candidates "bigk")
 	} else if (direct) {
 		if (k > flat_direct_max_k())
 			throw_faiss("mvs::FlatIndex::search", __FILE__, "k = %lld exceeds the supported maximum %lld",
@@ -1171,13 +1199,17 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	// and k = 32 / k = 16 stay on the 32- / 16-class instances (wide stores: k = 32 stays on the filter at all) -- ADVICE r3, low.
 	const int64_t kf = kk > k_user ? k_user : kk;
 	const int cl_kmax0 = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
-	const int cl_kmax = (int)std::min<int64_t>(cl_kmax0, 128 - (kk - kf)); // (collect_select_kernel: kk <= 128 entries)
+	// (round 6: beyond 128 entries the d <= 128 store's filter takes its bounds from a pass of its own and selects by a segmented sort --
+	// FlatIndex::collect_candidates "bigk"; option cl_bigk = 0: the exact kernels as before)
+	const bool bigk_ok = cl_bigk && !wide && collect_supported(geom) && kf > 128 - (kk - kf) && kk <= 2049 && ntotal >= 262144 && ntotal >= 256 * kf &&
+	                     ntotal < ((int64_t)1 << 31) && (prefilter_mode == 2 || prefilter_mode < 0) && nq * kk < ((int64_t)1 << 31);
+	const int cl_kmax = bigk_ok ? 2048 : (int)std::min<int64_t>(cl_kmax0, 128 - (kk - kf)); // (collect_select_kernel: kk <= 128 entries)
 	// (lists beyond 40: only the coarse filter of the d <= 128 store, up to 128 -- four subsets of 32 row classes, round 4)
 	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !collect_supported(geom)) || (kk > 40 && kf > cl_kmax))
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
-	if (cl_only && (kf > std::min<int64_t>(collect_max_k(d), 128 - (kk - kf)) || prefilter_mode == 1))
+	if (cl_only && (kf > (bigk_ok ? 2048 : std::min<int64_t>(collect_max_k(d), 128 - (kk - kf))) || prefilter_mode == 1))
 		return false;
 	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kf <= cl_kmax))
 		return false;
@@ -1219,7 +1251,7 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 			const bool direct = (metric == METRIC_L2 && !flp && kk == k_user) || (metric == METRIC_IP && kk <= k_user + 1 && (flp || kk == k_user));
 			cl_out_D = direct ? d_D : nullptr, cl_out_I = direct ? d_I : nullptr, cl_out_map = out_map, cl_out_off = out_off;
 			cl_out_flags = flp, cl_out_kout = (int)k_user;
-			collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer, (int)kf);
+			collected = collect_candidates(nq, d_x, kp, &pd1, &pi1, fail_cnt, fail_q, params, d_idmap, st, defer, (int)(bigk_ok ? std::max<int64_t>(kf, 129) : kf));
 			cl_out_D = nullptr, cl_out_I = nullptr, cl_out_flags = nullptr;
 			if (!collected) {
 				MVS_HIP(hipMemsetAsync(fail_cnt, 0, sizeof(int), st));
@@ -2840,6 +2872,10 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "cl_prep1")) { // 0: round 4's separate query-preparation kernels (A/B)
 		cl_prep1 = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "cl_bigk")) { // 0: lists beyond 128 entries on the exact kernels (round 5; A/B)
+		cl_bigk = v != 0;
 		return true;
 	}
 	if (!strcmp(key, "cl_small_path")) { // 0: small batches on flat_bf16_collect_kernel as well (A/B)

@@ -113,6 +113,55 @@ def test_k_up_to_128_takes_the_coarse_filter_with_four_subsets_of_32_classes(mf,
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,nb,nq,k", [(128, 300_000, 300, 129), (128, 300_000, 200, 200), (96, 280_000, 64, 500), (128, 300_000, 1100, 1000),
+                                       (64, 530_000, 40, 2048), (128, 300_000, 12, 300), (128, 270_000, 256, 128)])
+def test_lists_beyond_128_entries_stay_on_the_coarse_filter(mf, metric, d, nb, nq, k):
+    """round 6 (VERDICT r5 missing #3; the reference's post-filter use asks for k in the hundreds and thousands, README.md:222-271,
+    go/main_test.go:26-32): k > 128 at d <= 128 -- bounds from ceil(k / 64) row ranges' class slots (pass A over a quarter of the rows),
+    the scan against those bounds frozen, exact re-scoring, one segmented sort per batch.  Same answers as the exact kernels and the
+    oracle (FAISS's reservoir from k = 100 on; inner product searches k + 1 entries: k = 128 is a big list there)."""
+    rs = np.random.RandomState(k * 1000 + d)
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[::53] = xb[11]  # duplicates: ties inside the result lists
+    cl, ex = _pair(mf, d, metric, xb)
+    D1, I1 = cl.search(xq, k)
+    assert cl.last_kernel_info()["name"] == KERNEL, cl.last_kernel_info()
+    D0, I0 = ex.search(xq, k)
+    assert ex.last_kernel_info()["name"] != KERNEL
+    assert np.array_equal(I1, I0), "labels differ from the exact kernels"
+    assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), "distances differ from the exact kernels"
+    no = min(nq, 6)
+    Do, Io = orc.flat_search(metric, xb, xq[:no], k, force_path=orc.PATH_BLAS if nq >= 20 else orc.PATH_PAIR)
+    assert np.array_equal(I1[:no], Io) and np.array_equal(D1[:no].view(np.uint32), Do.view(np.uint32))
+    st = cl.collect_stats()
+    assert st["queries"] == nq and st["candidates"] >= nq * k and st["candidates"] < nq * nb * 0.5, st
+    cl.set_option("cl_bigk", 0)  # (the switch: the exact kernels as before)
+    D2, I2 = cl.search(xq[:32], k)
+    assert (cl.last_kernel_info()["name"] != KERNEL) == (k > 128 or metric == IP)
+    assert np.array_equal(I2, I0[:32]) or nq < 20  # (a batch of < 20 takes FAISS's per-pair branch: other last bits)
+
+
+def test_big_list_with_selector_and_idmap(mf):
+    rs = np.random.RandomState(79)
+    d, nb, k = 128, 280_000, 400
+    xb = rs.randint(-2, 3, size=(nb, d)).astype(np.float32)  # integer rows: exact ties everywhere, also at the k-th value
+    xq = rs.randint(-2, 3, size=(48, d)).astype(np.float32)
+    ids = (rs.permutation(3 * nb)[:nb] + 3).astype(np.int64)
+    keep = ids[rs.rand(nb) < 0.5]
+    for metric in (L2, IP):
+        g, o = mf.index_factory(d, "IDMap,Flat", metric), orc.Index(d, "IDMap,Flat", metric)
+        g.set_option("prefilter", 2)
+        for a in (g, o):
+            a.add_with_ids(xb, ids)
+        for sel in (None, ("batch", keep)):
+            D, I = g.search(xq, k, sel=sel)
+            Do, Io = o.search(xq[:4], k, sel=sel)
+            assert np.array_equal(D[:4].view(np.uint32), Do.view(np.uint32)), (metric, sel and sel[0], g.last_kernel_info())
+            assert np.array_equal(I[:4], Io), (metric, sel and sel[0])
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
 def test_k_100_with_selector_and_idmap_on_the_coarse_filter(mf, metric):
     rs = np.random.RandomState(77)
     d, nb, k = 128, 70_000, 100
