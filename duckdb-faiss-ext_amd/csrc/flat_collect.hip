@@ -1515,14 +1515,16 @@ __global__ void collect_final_thr_kernel(const unsigned *__restrict__ gslot, con
 // against the frozen T - 2E (a.opt bit 8) and streams what passes; the candidates are re-scored exactly, sorted per query
 // (rocPRIM segmented radix sort) and the first k taken: launch_collect_select_big.
 __global__ void collect_bound_table_multi_kernel(const unsigned *__restrict__ gslot, long long range_stride, int nranges,
-                                                 const float *__restrict__ e2, int nclass, int nq, long long total, float *__restrict__ pbnd) {
+                                                 const float *__restrict__ e2, int nclass, int nq, long long total, float *__restrict__ pbnd,
+                                                 int linear) {
 	const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= total)
 		return;
 	const int o = (int)(j & 127), w = (int)((j >> 7) & 3);
 	const long long qb = j >> 9;
 	const int i = o & 1, c = (o >> 1) & 15, hq = o >> 5;
-	const long long q = qb * CL_QBLOCK + w * 128 + 32 * hq + 16 * i + c; // (the table's order: collect_bound_table_kernel)
+	// (the d <= 128 scan's table order: collect_bound_table_kernel; the wide stores' kernels read one bound per query: linear)
+	const long long q = linear ? j : qb * CL_QBLOCK + w * 128 + 32 * hq + 16 * i + c;
 	float bv = __uint_as_float(0x7fc00000u);
 	if (q < nq) {
 		const int rank = (nclass + 3) / 4 - 1; // four subsets of 32 classes per range
@@ -1561,6 +1563,7 @@ void launch_collect_big_bounds(const FlatGeom &g, int metric, const void *d_qf, 
 	hipLaunchKernelGGL(init_gslot_kernel, dim3((unsigned)((gtotal + 255) / 256)), dim3(256), 0, st, d_gslot, gtotal, 128, 128, 0 /* larger s is better */);
 	const int kfp = (kf + nranges - 1) / nranges;
 	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
+	const int dp1 = collect_store_dims(g.d);
 	for (int p = 0; p < nranges; ++p) {
 		CollectArgs a;
 		memset(&a, 0, sizeof a);
@@ -1571,13 +1574,18 @@ void launch_collect_big_bounds(const FlatGeom &g, int metric, const void *d_qf, 
 		a.nq = (int)nq;
 		a.rowmask = d_rowmask;
 		a.opt = tune().ksplit_opt;
-		a.pbnd = d_pbnd; // (derived from this range's slots in front of its launch and refreshed by its workgroups)
-		const int64_t r0 = (n * p / nranges) / 64 * 64, r1 = std::min<int64_t>(n, r0 + range_rows);
-		launch_collect_range<false>(g, metric, a, r0, r1, std::max<int64_t>(8, std::min<int64_t>(64, 1024 / nqb)), nq, st, nullptr, nullptr);
+		const int64_t r0 = (n * p / nranges) / 192 * 192, r1 = std::min<int64_t>(n, r0 + range_rows);
+		if (dp1 > 128) { // (the wide stores' kernels derive their bounds per wave: no table)
+			const int nqbw = (int)((nq + collect_wide_qblock(dp1) - 1) / collect_wide_qblock(dp1));
+			launch_collect_wide_range(dp1, metric, false, a, r0, r1, std::max<int64_t>(8, std::min<int64_t>(64, 1024 / nqbw)), nq, st, nullptr, nullptr);
+		} else {
+			a.pbnd = d_pbnd; // (derived from this range's slots in front of its launch and refreshed by its workgroups)
+			launch_collect_range<false>(g, metric, a, r0, r1, std::max<int64_t>(8, std::min<int64_t>(64, 1024 / nqb)), nq, st, nullptr, nullptr);
+		}
 	}
-	const long long total = (long long)nqb * CL_QBLOCK;
+	const long long total = dp1 > 128 ? (long long)nq : (long long)nqb * CL_QBLOCK;
 	hipLaunchKernelGGL(collect_bound_table_multi_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, (const unsigned *)d_gslot,
-	                   (long long)nq * 128, nranges, d_e2, kfp, (int)nq, total, d_pbnd);
+	                   (long long)nq * 128, nranges, d_e2, kfp, (int)nq, total, d_pbnd, dp1 > 128 ? 1 : 0);
 	MVS_HIP(hipGetLastError());
 }
 

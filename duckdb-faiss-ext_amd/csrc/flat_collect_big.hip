@@ -205,6 +205,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			MVS_OPAQUE_VGPR(qo);
 			const int q = qo + 16 * hq + c;
 			const int qc = q < a.nq ? q : 0;
+			if (a.pbnd != nullptr && (a.opt & 256)) { // lists beyond 128 entries: frozen bounds, one per query (csrc/flat_collect.hip)
+				cqtab[(wave * 16 + c) * 4 + hq] = q < a.nq ? a.pbnd[qc] : __uint_as_float(0x7fc00000u);
+				return;
+			}
 			const float e2v = __builtin_nontemporal_load(a.e2 + qc);
 			// NC = 128 (32 < kk <= 128, round 6): four SUBSETS of 32 classes (class = row & 127, subset = class >> 5); the worst of the
 			// subsets' ceil(kk / 4)-th best class values has >= kk distinct rows at least as good (csrc/flat_collect.hip)

@@ -173,6 +173,13 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_wide_kernel(const CollectArg
 				for (int i = 0; i < NCBP; ++i) { // (one query at a time: the resident fragments leave few registers)
 					const int q = qo + 16 * NCBP * hq + 16 * i + c;
 					const int qc = q < a.nq ? q : 0;
+					if (a.pbnd != nullptr && (a.opt & 256)) { // lists beyond 128 entries: frozen bounds, one per query (csrc/flat_collect.hip)
+						const float bvf = q < a.nq ? a.pbnd[qc] : __uint_as_float(0x7fc00000u);
+						v[0] = i == 0 ? bvf : v[0];
+						v[1] = i == 1 ? bvf : v[1];
+						v[2] = i == 2 ? bvf : v[2];
+						continue;
+					}
 					const float e2v = __builtin_nontemporal_load(a.e2 + qc);
 					// NC = 128 (32 < kk <= 128, round 6): four SUBSETS of 32 classes (class = row & 127, subset = class >> 5); the worst of the
 					// subsets' ceil(kk / 4)-th best class values has >= kk distinct rows at least as good (csrc/flat_collect.hip)
@@ -935,7 +942,7 @@ void launch_collect_wide_range(int dp1, int metric, bool collect, CollectArgs a,
 	a.split_rows = (nblocks + nsplit - 1) / nsplit * BR;
 	a.nqb = nqb;
 	a.nsplit = (int)nsplit;
-	a.opt = tune().ksplit_opt;
+	a.opt = tune().ksplit_opt | (a.opt & 256); // (bit 8: frozen bounds, the caller's)
 	const int grid = nqb * (int)nsplit;
 	const size_t lds = collect_wide_lds_bytes(dp1);
 	if (wide_on_big(dp1)) {

@@ -459,6 +459,7 @@ void launch_collect_outlier_threshold(const float *d_norms, int64_t nrows, const
 void launch_collect_append_outliers(const int *d_outl, int n_outliers, int64_t nq, unsigned long long *d_stream, float *d_stream_s,
                                     unsigned long long *d_cnt, int64_t cap, const unsigned long long *d_rowmask, hipStream_t st);
 size_t collect_qfrag_bytes(const FlatGeom &g, int64_t nq);
+int collect_wide_max_classes(int dp1); // 128: the wide store's kernel has the 4 x 32-class instance (csrc/flat_collect_wide.hip)
 const char *collect_wide_kernel_name(int dp1); // "flat_bf16_big_kernel" / "flat_bf16_wide_kernel" for a store pitch > 128
 int collect_store_dims(int d); // 128 / 256 / 384 / 512: row pitch of the bf16 store; 0: d is not served (csrc/flat_collect_wide.hip)
 int collect_wide_qblock(int dp1);

@@ -552,7 +552,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 		fb_layout();
 	// (round 5) the 512 < d <= 1536 stores: the big kernel keeps every candidate's coarse value too; the final-bound filter then compacts
 	// the stream in front of the sort (a candidate costs 3-6 KB of f32 row there)
-	const bool wrf = !fb && wide && cl_wide_refilter && !strcmp(collect_wide_kernel_name(dp1), "flat_bf16_big_kernel");
+	const bool wrf = !fb && !bigk && wide && cl_wide_refilter && !strcmp(collect_wide_kernel_name(dp1), "flat_bf16_big_kernel");
 	auto wrf_layout = [&]() {
 		const size_t sb = ((size_t)cap_entries * 4 + 255) & ~(size_t)255;
 		ws_fbk.reserve(sb + (((size_t)nq * 4 + 255) & ~(size_t)255) + 256);
@@ -1201,7 +1201,7 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	const int cl_kmax0 = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
 	// (round 6: beyond 128 entries the d <= 128 store's filter takes its bounds from a pass of its own and selects by a segmented sort --
 	// FlatIndex::collect_candidates "bigk"; option cl_bigk = 0: the exact kernels as before)
-	const bool bigk_ok = cl_bigk && !wide && collect_supported(geom) && kf > 128 - (kk - kf) && kk <= 2049 && ntotal >= 262144 && ntotal >= 256 * kf &&
+	const bool bigk_ok = cl_bigk && (!wide || collect_wide_max_classes(collect_store_dims(d)) >= 128) && collect_supported(geom) && kf > 128 - (kk - kf) && kk <= 2049 && ntotal >= 262144 && ntotal >= 256 * kf &&
 	                     ntotal < ((int64_t)1 << 31) && (prefilter_mode == 2 || prefilter_mode < 0) && nq * kk < ((int64_t)1 << 31);
 	const int cl_kmax = bigk_ok ? 2048 : (int)std::min<int64_t>(cl_kmax0, 128 - (kk - kf)); // (collect_select_kernel: kk <= 128 entries)
 	// (lists beyond 40: only the coarse filter of the d <= 128 store, up to 128 -- four subsets of 32 row classes, round 4)

@@ -95,6 +95,28 @@ def test_wide_k_up_to_128_on_four_subsets_of_32_classes(mf, metric, d, nb, nq, k
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,nb,nq,k", [(256, 270_000, 200, 129), (384, 270_000, 100, 300), (768, 265_000, 150, 1000), (1536, 263_000, 40, 200),
+                                       (512, 265_000, 12, 400)])
+def test_wide_lists_beyond_128_entries(mf, metric, d, nb, nq, k):
+    """round 6: k > 128 on the wide stores -- bounds from row ranges' class slots, the scan against them frozen, segmented-sort
+    selection (tests/test_collect_gpu.py::test_lists_beyond_128_entries_stay_on_the_coarse_filter); same answers as the exact kernels
+    and the oracle"""
+    rs = np.random.RandomState(k + d)
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xq = rs.rand(nq, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[::53] = xb[11]
+    cl, ex = _pair(mf, d, metric, xb)
+    D1, I1 = cl.search(xq, k)
+    assert cl.last_kernel_info()["name"] in KERNEL, cl.last_kernel_info()
+    D0, I0 = ex.search(xq, k)
+    assert ex.last_kernel_info()["name"] not in KERNEL
+    assert np.array_equal(I1, I0), "labels differ from the exact kernels"
+    assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), "distances differ from the exact kernels"
+    Do, Io = orc.flat_search(metric, xb, xq[:3], k, force_path=orc.PATH_BLAS if nq >= 20 else orc.PATH_PAIR)
+    assert np.array_equal(I1[:3], Io) and np.array_equal(D1[:3].view(np.uint32), Do.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
 def test_wide_k_100_with_selector_and_idmap(mf, metric):
     rs = np.random.RandomState(78)
     d, nb, k = 768, 40_000, 100
