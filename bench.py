@@ -179,6 +179,9 @@ EMBEDDED = [  # (name, workload of BASELINE.json configs[i], bench.py arguments)
      ["--rows", "1250000", "--cpu-seconds", "4", "--parity-device", "1024", "--steps", "10", "--warmup", "2"]),
     ("H_IP", "IndexFlatIP d=128 N=10M nq=10k k=10 (faiss_create's default metric)",
      ["--metric", "IP", "--no-cpu-baseline", "--parity-device", "1024", "--steps", "5", "--warmup", "1"]),
+    # (round 6, VERDICT r5 missing #3: the list lengths of the reference's post-filter use, README.md:222-271 / go/main_test.go:26-32)
+    ("H_k1000", "IndexFlatL2 d=128 N=10M nq=2048 k=1000 (post-filter list length)",
+     ["--nq", "2048", "--k", "1000", "--no-cpu-baseline", "--parity-device", "64", "--steps", "3", "--warmup", "1"]),
     ("C3", "IVF4096,Flat d=128 N=10M nprobe=32 nq=10k k=10", ["--index", "IVF4096,Flat", "--data", "clustered", "--parity-device", "1024", "--steps", "10", "--warmup", "2"]),
     ("C4_shard", "IndexFlatIP d=768, one GPU's N/8 = 12.5M rows of N=100M, nq=10k k=10",
      ["--rows", "12500000", "--d", "768", "--metric", "IP", "--normalize", "--data", "clustered", "--sigma", "1.0", "--cpu-seconds", "8", "--parity-device", "256"]),

@@ -31,6 +31,7 @@ struct CollectArgs {
 	long long stream_cap;
 	int slot_stride, nclass; // 16 class slots per query (row & 15); nclass = kk, the rank of the bound among them
 	long long n, row_first, split_rows;
+	long long split_len; // flat_bf16_seed_kernel: rows of a split actually scanned (0: split_rows) -- pass A of the big lists strides over the database
 	int nq, nqb, nsplit, xcd_map;
 	float *pbnd; // d <= 128 scan: [nqb][512] pass bounds B - 2E in the order of a workgroup's LDS table (flat_collect.hip), or null
 	int opt; // A/B bits (option cl_ksplit_opt): 0 = k-split kernel with 8 waves: s_setprio skew between the two waves of a SIMD;

@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(256, 2) void flat_bf16_seed_kernel(const CollectArg
 	const int hq = lane >> 4, c = lane & 15;
 	const int split = blockIdx.x / a.nqb, qb = blockIdx.x % a.nqb;
 	const long long r_begin = a.row_first + (long long)split * a.split_rows;
-	long long r_end = r_begin + a.split_rows;
+	long long r_end = r_begin + (a.split_len > 0 ? a.split_len : a.split_rows); // (split_len: the big lists' pass A looks at a part of every stride)
 	if (r_end > a.n)
 		r_end = a.n;
 	const int ntiles = r_end > r_begin ? (int)((r_end - r_begin) / (CL_SUB * CL_BN)) : 0; // whole staged blocks only (the host rounds)
@@ -1554,6 +1554,93 @@ __global__ void collect_bound_table_multi_kernel(const unsigned *__restrict__ gs
 		bv = B - e2[q];
 	}
 	pbnd[j] = bv;
+}
+// pass A of the d <= 128 store on the REGISTER pre-pass kernel (flat_bf16_seed_kernel: a split's 16 class maxima, no atomics, no bounds,
+// the matrix pipe's pace): the splits are the ranges -- P = ceil(k / 8) strides of the database, split_len rows of each scanned --
+// and B_p = the ceil(k / P)-th best of split p's 16 class maxima.  (The class-slot version below took 13 ms of a 26 ms k = 1000 batch:
+// every range starts with cold slots, so its first rows all pass -- and 128-class derivations every four blocks; it stays for the wide
+// stores, which have no register pre-pass.)
+__global__ void collect_bound_table_seed_kernel(const float *__restrict__ stage, int nsplit, int rank, const float *__restrict__ e2, int nq,
+                                                long long total, float *__restrict__ pbnd) {
+	const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= total)
+		return;
+	const int o = (int)(j & 127), w = (int)((j >> 7) & 3);
+	const long long qb = j >> 9;
+	const int i = o & 1, c = (o >> 1) & 15, hq = o >> 5;
+	const long long q = qb * CL_QBLOCK + w * 128 + 32 * hq + 16 * i + c; // (the table's order: collect_bound_table_kernel)
+	float bv = __uint_as_float(0x7fc00000u);
+	if (q < nq) {
+		float T = INFINITY;
+		for (int p = 0; p < nsplit; ++p) {
+			float v[16];
+			const f32x4acc *src = (const f32x4acc *)(stage + ((size_t)p * (size_t)nq + (size_t)q) * 16);
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const f32x4acc x = src[t];
+				v[4 * t] = x[0], v[4 * t + 1] = x[1], v[4 * t + 2] = x[2], v[4 * t + 3] = x[3];
+			}
+			// the (rank + 1)-th largest of the 16 maxima, duplicates counted (-inf: a class without a row; NaN compares false: treated as -inf)
+			float b = -INFINITY;
+#pragma unroll
+			for (int t = 0; t < 16; ++t) {
+				const float vt = v[t] == v[t] ? v[t] : -INFINITY;
+				int greater = 0, geq = 0;
+#pragma unroll
+				for (int s2 = 0; s2 < 16; ++s2) {
+					const float vs = v[s2] == v[s2] ? v[s2] : -INFINITY;
+					greater += vs > vt;
+					geq += vs >= vt;
+				}
+				if (greater <= rank && rank < geq)
+					b = vt;
+			}
+			T = b < T ? b : T;
+		}
+		// (-inf: some split has fewer than rank + 1 classes with a row -- no bound, everything passes; the scan kernel's own neutral value)
+		const float B = T > -FLT_MAX ? T : -FLT_MAX;
+		bv = B - e2[q];
+	}
+	pbnd[j] = bv;
+}
+void launch_collect_big_bounds_seed(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms, int64_t n,
+                                    int64_t nq, int kf, int nsplits, int64_t split_len, const float *d_e2, float *d_stage,
+                                    const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st) {
+	CollectArgs a;
+	memset(&a, 0, sizeof a);
+	a.qf = d_qf, a.yb = d_rows, a.yn = d_norms, a.e2 = d_e2;
+	a.nq = (int)nq;
+	a.rowmask = d_rowmask;
+	a.seed_stage = d_stage;
+	const int nqb = (int)((nq + CL_QBLOCK - 1) / CL_QBLOCK);
+	a.row_first = 0;
+	a.split_rows = (n / nsplits) / 64 * 64; // the stride
+	a.split_len = std::min<int64_t>(split_len, a.split_rows) / 64 * 64;
+	a.n = n / 64 * 64;
+	a.nqb = nqb;
+	a.nsplit = nsplits;
+	const int grid = nqb * nsplits;
+	const size_t lds = (size_t)2 * CL_SUB * CL_BN * 256 + 2 * 64 * 4 + 64;
+#define MVS_SEED(L2, SL)                                                                                           \
+	{                                                                                                              \
+		auto kern = flat_bf16_seed_kernel<L2, SL>;                                                                 \
+		ensure_dynamic_lds((const void *)kern, lds);                                                               \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);                                               \
+	}
+	if (metric == METRIC_L2 && a.rowmask)
+		MVS_SEED(true, true)
+	else if (metric == METRIC_L2)
+		MVS_SEED(true, false)
+	else if (a.rowmask)
+		MVS_SEED(false, true)
+	else
+		MVS_SEED(false, false)
+#undef MVS_SEED
+	const int kfp = (kf + nsplits - 1) / nsplits;
+	const long long total = (long long)nqb * CL_QBLOCK;
+	hipLaunchKernelGGL(collect_bound_table_seed_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, (const float *)d_stage, nsplits,
+	                   kfp - 1, d_e2, (int)nq, total, d_pbnd);
+	MVS_HIP(hipGetLastError());
 }
 // pass A: d_gslot [nranges][nq][128] -> d_pbnd (the scan's table order) = T - 2E per query.  Range p = rows [p n / P, p n / P + range_rows).
 void launch_collect_big_bounds(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms, int64_t n,

@@ -497,6 +497,10 @@ void launch_collect_scan(const FlatGeom &g, int metric, const void *d_qf, const 
 void launch_collect_big_bounds(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms, int64_t n,
                                int64_t nq, int kf, int nranges, int64_t range_rows, const float *d_e2, unsigned *d_gslot,
                                const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st);
+// (d <= 128 store: pass A on the register pre-pass kernel -- nsplits = ceil(k / 8) strides, 16 class maxima each, d_stage [nsplits][nq][16])
+void launch_collect_big_bounds_seed(const FlatGeom &g, int metric, const void *d_qf, const unsigned short *d_rows, const float *d_norms, int64_t n,
+                                    int64_t nq, int kf, int nsplits, int64_t split_len, const float *d_e2, float *d_stage,
+                                    const unsigned long long *d_rowmask, float *d_pbnd, hipStream_t st);
 size_t collect_select_big_temp_bytes(int64_t ncand, int64_t nq);
 void launch_collect_select_big(int metric, unsigned long long *d_keys, unsigned long long *d_out, int64_t ncand, const int *d_seg, int64_t nq,
                                int kk, void *d_temp, size_t temp_bytes, float *d_pd1, int32_t *d_pi1, hipStream_t st);

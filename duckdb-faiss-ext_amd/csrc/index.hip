@@ -466,14 +466,19 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	ws_e2.reserve((size_t)nq128 * sizeof(float));
 	// (big lists: pass A looks at a quarter of the rows -- any rows give a valid bound, fewer rows a lower one and ~ntotal / rows times k
 	// candidates -- unless the candidates of a large batch would not fit: then at all of them)
-	const int bk_ranges = bigk ? (kf + 63) / 64 : 0;
+	// (d <= 128: the ranges are row splits of the register pre-pass kernel, 16 class maxima each, ceil(k / ranges) <= 8 of them decide; the
+	// wide stores: 128 class slots per range through the scan kernel's bound-estimation instances, <= 64 decide)
+	const bool bk_seed = bigk && !wide;
+	const int bk_ranges = bigk ? (bk_seed ? (kf + 7) / 8 : (kf + 63) / 64) : 0;
 	int64_t bk_rows = 0; // rows per range
 	if (bigk) {
 		const bool whole = (double)nq * kf * 16.0 > (double)((int64_t)1 << 28);
-		const int64_t want = whole ? ntotal : std::max<int64_t>(ntotal / 4, (int64_t)bk_ranges * 16384);
-		bk_rows = std::min<int64_t>(std::max<int64_t>(want / bk_ranges, 4096), ntotal / bk_ranges) / 64 * 64;
+		const int64_t want = whole ? ntotal : std::max<int64_t>(ntotal / 4, (int64_t)bk_ranges * (bk_seed ? 2048 : 16384));
+		bk_rows = std::min<int64_t>(std::max<int64_t>(want / bk_ranges, bk_seed ? 1024 : 4096), ntotal / bk_ranges) / 64 * 64;
 	}
-	ws_gthr.reserve((size_t)nq * collect_slot_stride(kf, collect_store_dims(d)) * sizeof(unsigned) * (bigk ? bk_ranges : 1) + 64);
+	ws_gthr.reserve((size_t)nq * collect_slot_stride(kf, collect_store_dims(d)) * sizeof(unsigned) * (bigk && !bk_seed ? bk_ranges : 1) + 64);
+	if (bk_seed)
+		ws_seed.reserve((size_t)bk_ranges * (size_t)nq * 16 * sizeof(float));
 	ws_seg.reserve(256 + (size_t)2 * nq * sizeof(int));
 	// Round 5 (d <= 128 store): fragments, ||x||^2, bounds, neutral class slots and the zeroed control block in ONE launch
 	// (csrc/flat_collect.hip collect_query_prep_kernel) instead of four kernels and a memset
@@ -515,7 +520,10 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	float *pbnd = wide ? nullptr : (float *)ws_pbnd.p; // (the d <= 128 scan only)
 	if (!wide && cl_seed_stage)
 		ws_seed.reserve(collect_seed_stage_bytes(nq));
-	if (bigk)
+	if (bk_seed)
+		launch_collect_big_bounds_seed(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, bk_ranges, bk_rows, (const float *)ws_e2.p,
+		                               (float *)ws_seed.p, rowmask, (float *)ws_pbnd.p, st);
+	else if (bigk)
 		launch_collect_big_bounds(geom, metric, ws_pfq.p, vecs_h1, beta_h1, ntotal, nq, kf, bk_ranges, bk_rows, (const float *)ws_e2.p,
 		                          (unsigned *)ws_gthr.p, rowmask, (float *)ws_pbnd.p, st);
 	else
