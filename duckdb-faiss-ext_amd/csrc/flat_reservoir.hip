@@ -20,6 +20,8 @@ namespace mvs {
 
 namespace {
 
+constexpr int RS_CHUNK = 4096; // scores staged per round of the replay (16 KB of LDS behind the reservoir)
+
 __device__ __forceinline__ bool rs_member(const SelectorDev &s, long long id) {
 	if (s.kind == MVS_SEL_BITMAP) {
 		const unsigned long long u = (unsigned long long)id;
@@ -78,6 +80,58 @@ __global__ __launch_bounds__(256) void ip_scores_kernel(const float *__restrict_
 				acc = fmaf(x[g4 + 3], v3, acc);
 		}
 	}
+	scores[(size_t)f * n + row] = acc;
+}
+
+// (round 6) the same scores with COALESCED row reads: a workgroup's 256 rows pass through LDS in slabs of 32 dimensions (128 contiguous
+// bytes per row and slab: eight lanes x 16 bytes), thread t then walks ITS row's slab -- the k-ordered chain is per row, so the rows
+// cannot be split across lanes, but their bytes need not be fetched 512 bytes apart by neighbouring threads (17 ms per flagged batch at
+// N = 10 M, d = 128 with the thread-per-row loads above; this one runs at the store's streaming rate).  dp % 32 == 0.
+__global__ __launch_bounds__(256) void ip_scores_tiled_kernel(const float *__restrict__ xf, int d, const float *__restrict__ vecs, int dp,
+                                                             int interleaved, long long n, SelectorDev sel,
+                                                             const long long *__restrict__ idmap, float *__restrict__ scores) {
+	__shared__ float tile[256][33];
+	const int t = threadIdx.x, f = blockIdx.y;
+	const long long row0 = (long long)blockIdx.x * 256, row = row0 + t;
+	const float *x = xf + (size_t)f * d;
+	const bool odd = interleaved && ((row >> 4) & 1);
+	float acc = 0.f;
+	for (int s0 = 0; s0 < d; s0 += 32) {
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { // 2 048 chunks of 16 bytes: chunk c = row (c >> 3), floats 4 (c & 7) ..
+			const int c = i * 256 + t, r = c >> 3, j4 = (c & 7) * 4;
+			float4 v = {0.f, 0.f, 0.f, 0.f};
+			if (row0 + r < n)
+				v = *(const float4 *)(vecs + (size_t)(row0 + r) * dp + s0 + j4);
+			tile[r][j4] = v.x, tile[r][j4 + 1] = v.y, tile[r][j4 + 2] = v.z, tile[r][j4 + 3] = v.w;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int g4 = 0; g4 < 32; g4 += 4) {
+			const float a0 = tile[t][g4], a1 = tile[t][g4 + 1], a2 = tile[t][g4 + 2], a3 = tile[t][g4 + 3];
+			float v0, v1, v2, v3;
+			if (!interleaved)
+				v0 = a0, v1 = a1, v2 = a2, v3 = a3;
+			else if (odd) // stored [k1,k3,k0,k2] (FlatGeom::pair_interleaved)
+				v0 = a2, v1 = a0, v2 = a3, v3 = a1;
+			else // stored [k0,k2,k1,k3]
+				v0 = a0, v1 = a2, v2 = a1, v3 = a3;
+			const int k0 = s0 + g4;
+			if (k0 < d)
+				acc = fmaf(x[k0], v0, acc);
+			if (k0 + 1 < d)
+				acc = fmaf(x[k0 + 1], v1, acc);
+			if (k0 + 2 < d)
+				acc = fmaf(x[k0 + 2], v2, acc);
+			if (k0 + 3 < d)
+				acc = fmaf(x[k0 + 3], v3, acc);
+		}
+	}
+	if (row >= n)
+		return;
+	if (sel.kind != MVS_SEL_NONE && !rs_member(sel, idmap ? idmap[row] : row))
+		acc = __uint_as_float(0x7fc00000u);
 	scores[(size_t)f * n + row] = acc;
 }
 
@@ -190,10 +244,46 @@ __global__ __launch_bounds__(64) void reservoir_replay_kernel(const float *__res
 		__syncthreads();
 	};
 
-	for (long long base = 0; base < n; base += 64) {
-		const long long row = base + lane;
-		const float v = row < n ? sc[row] : __uint_as_float(0x7fc00000u);
-		unsigned long long mask = __builtin_amdgcn_ballot_w64(rs_cmp(thr, v)); // C::cmp(threshold, val); NaN: never
+	// (round 6: the scores pass through LDS in chunks of RS_CHUNK -- sixteen 16-byte loads per lane in flight instead of one 4-byte load per
+	// 64 rows, whose latency was the whole 70 ms of a 10 M-row replay -- and the next group's value is read while this one is decided)
+	float *chunk = (float *)(rows + cap);
+	unsigned long long gmask = 0ull; // (uniform) the chunk's groups still to visit
+	for (long long cbase = 0; cbase < n; cbase += RS_CHUNK) {
+		__syncthreads();
+		if (cbase + RS_CHUNK <= n && ((size_t)(sc + cbase) & 15) == 0) { // (uniform) a whole aligned chunk: sixteen loads in flight, then the stores
+			float4 x[RS_CHUNK / 256];
+#pragma unroll
+			for (int i = 0; i < RS_CHUNK / 256; ++i)
+				x[i] = *(const float4 *)(sc + cbase + (long long)(i * 64 + lane) * 4);
+			// which of the chunk's 64 groups hold a score above the threshold AS IT STANDS (it only rises: a superset of the groups that
+			// will matter) -- load i covers groups 4 i .. 4 i + 3, sixteen lanes each; the walk below visits those groups only
+			gmask = 0ull;
+#pragma unroll
+			for (int i = 0; i < RS_CHUNK / 256; ++i) {
+				*(float4 *)(chunk + (i * 64 + lane) * 4) = x[i];
+				const unsigned long long m =
+				    __builtin_amdgcn_ballot_w64(rs_cmp(thr, x[i].x) || rs_cmp(thr, x[i].y) || rs_cmp(thr, x[i].z) || rs_cmp(thr, x[i].w));
+				const unsigned long long q4 = (m & 0xffffull ? 1ull : 0ull) | (m & 0xffff0000ull ? 2ull : 0ull) | (m & 0xffff00000000ull ? 4ull : 0ull) |
+				                              (m & 0xffff000000000000ull ? 8ull : 0ull);
+				gmask |= q4 << (4 * i);
+			}
+		} else {
+			gmask = ~0ull;
+			for (int i = 0; i < RS_CHUNK / 64; ++i) {
+				const long long e = cbase + (long long)i * 64 + lane;
+				chunk[i * 64 + lane] = e < n ? sc[e] : __uint_as_float(0x7fc00000u);
+			}
+		}
+		__syncthreads();
+		const int ngroups = (int)(((n - cbase < RS_CHUNK ? n - cbase : RS_CHUNK) + 63) / 64);
+		if (ngroups < 64)
+			gmask &= (1ull << ngroups) - 1ull;
+	while (gmask != 0ull) {
+		const int g = __builtin_ctzll(gmask);
+		gmask &= gmask - 1ull;
+		const long long row = cbase + (long long)g * 64 + lane;
+		const float v = chunk[g * 64 + lane];
+		unsigned long long mask = __builtin_amdgcn_ballot_w64(rs_cmp(thr, v)); // C::cmp(threshold, val); NaN: never (also behind the last row)
 		while (mask != 0ull) {
 			const int cnt = __popcll(mask);
 			const int room = cap - fill;
@@ -225,6 +315,7 @@ __global__ __launch_bounds__(64) void reservoir_replay_kernel(const float *__res
 				mask = rest & __builtin_amdgcn_ballot_w64(rs_cmp(thr, v));
 			}
 		}
+	}
 	}
 
 	// to_result as the closed form over the stored entries (array order = row order)
@@ -273,7 +364,7 @@ __global__ __launch_bounds__(64) void reservoir_replay_kernel(const float *__res
 } // namespace
 
 int64_t reservoir_replay_max_k() { // vals + rows of the reservoir in one wave's LDS
-	return (150 * 1024 / 8 - 16) / 2;
+	return ((150 * 1024 - RS_CHUNK * 4) / 8 - 16) / 2;
 }
 
 // d_xf: [nf][d] the flagged queries, d_T: [nf] their k-th best scores; out: [nf][k] (score, row) of FAISS's result, any order
@@ -283,9 +374,13 @@ void launch_reservoir_replay(const float *d_xf, int nf, int d, const float *d_ve
 	if (nf <= 0)
 		return;
 	const int cap = (int)((2 * k + 15) & ~(int64_t)15);
+	if (dp % 32 == 0)
+		hipLaunchKernelGGL(ip_scores_tiled_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nf), dim3(256), 0, st, d_xf, d, d_vecs, dp,
+		                   interleaved, (long long)n, sel, (const long long *)d_idmap, d_scores);
+	else
 	hipLaunchKernelGGL(ip_scores_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nf), dim3(256), 0, st, d_xf, d, d_vecs, dp,
 	                   interleaved, (long long)n, sel, (const long long *)d_idmap, d_scores);
-	const size_t lds = (size_t)cap * 8;
+	const size_t lds = (size_t)cap * 8 + (size_t)RS_CHUNK * 4;
 	auto kern = reservoir_replay_kernel;
 	ensure_dynamic_lds((const void *)kern, lds);
 	hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(64), lds, st, (const float *)d_scores, (long long)n, (int)k, cap, d_T, d_out_v,
