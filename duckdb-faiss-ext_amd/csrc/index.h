@@ -552,7 +552,7 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st, float *d_stream_u = nullptr);
+                             hipStream_t st, float *d_stream_u = nullptr, const float *d_bfix = nullptr);
 // final-bound filter between the scan and the exact stage (csrc/ivf_collect.hip): entries whose s + E is below the bound the scan ended with are dropped
 // csrc/coarse_bf16.hip: the coarse quantiser as a bf16 filter + exact re-scoring inside one workgroup per 32 queries
 bool coarse_bf16_supported(int d, int64_t nlist, int64_t np);

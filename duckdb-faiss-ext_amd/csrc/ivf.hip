@@ -110,6 +110,42 @@ __global__ void ivf_list_mean_kernel(const float *__restrict__ rows, const long 
 }
 // selected (value, position) lists [nq][kk], best first -> D / I [nq][k] with labels = stored ids
 // flagged queries -> list
+// ---- lists beyond 32 entries through the bf16 filter (round 6; IVFFlatIndex::collect_search_big)
+// B(q) in the scan's value space (larger = better: -distance | score) from the kk-th best exact value of the query's nearest lists
+__global__ void ivf_big_bound_kernel(const float *__restrict__ D, int kk, long long nq, int is_l2, float *__restrict__ bfix) {
+	const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nq)
+		return;
+	const float v = D[q * kk + kk - 1];
+	// (fewer than kk rows in those lists: FLT_MAX | -FLT_MAX -- no bound, everything passes)
+	bfix[q] = is_l2 ? (v < FLT_MAX ? -v : -FLT_MAX) : (v > -FLT_MAX ? v : -FLT_MAX);
+}
+// stream entries (q << 32 | padded row) -> (q << 32 | position in the list-sorted store); padding rows never pass the scan
+__global__ void ivf_big_translate_kernel(unsigned long long *__restrict__ strm, long long n, const int *__restrict__ perm) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const unsigned long long e = strm[i];
+	const int pos = perm[(unsigned)e];
+	strm[i] = (e & 0xffffffff00000000ull) | (unsigned)(pos < 0 ? 0 : pos);
+}
+// (value, position) lists [nq][k], best first -> D / I: positions (inside the exact-tie wrapper) or stored ids through the id map
+__global__ void ivf_big_emit_kernel(const float *__restrict__ pd, const int *__restrict__ pi, long long total, int is_l2,
+                                    const long long *__restrict__ rowids, const long long *__restrict__ idmap, float *__restrict__ D,
+                                    long long *__restrict__ I) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total)
+		return;
+	const int pos = pi[i];
+	long long lab = -1;
+	if (pos >= 0) {
+		lab = rowids ? rowids[pos] : (long long)pos;
+		if (idmap)
+			lab = idmap[lab];
+	}
+	D[i] = pos >= 0 ? pd[i] : (is_l2 ? FLT_MAX : -FLT_MAX);
+	I[i] = lab;
+}
 __global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *out_bits) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	float v = i < n ? norms[i] : 0.f;
@@ -779,6 +815,11 @@ public:
 			stream_wait(st, stream);
 			return;
 		}
+		// (round 6) lists of 33 .. 2048 entries: the bf16 filter against a frozen bound (collect_search_big)
+		if (cl_big && !force_select && (raw_pos && k > 1 ? k - 1 : k) > 32 && k <= 2049 && (metric == METRIC_L2 || metric == METRIC_IP) && collect_mode != 0 &&
+		    mfma_mode < 0 && !pf_suppressed && !shadow && hnsw_M == 0 && d <= 128 && (dp == 32 || dp == 64 || dp == 128) && nq * np < ((int64_t)1 << 26) &&
+		    nq * k < ((int64_t)1 << 31) && nsorted >= 16 * k && collect_search_big(nq, d_x, k, d_D, d_I, params, d_idmap, st, np))
+			return;
 		if (k > 256 || force_select) { // beyond the k-list kernels: all distances + segmented sort (csrc/ivf_select.hip)
 			select_search(nq, d_x, k, d_D, d_I, params, d_idmap, st, np);
 			return;
@@ -1434,11 +1475,18 @@ public:
 	// k > 256 (the harness's post-filter runs ask for ~2 000 rows, go/main_test.go:17-45): every probed list's distances as
 	// sortable keys, one segmented sort per chunk of queries, first k decoded.  The batch is cut so that one chunk holds at
 	// most 2^26 candidates (1 GiB of keys, double-buffered).
+	// (np_stride > np: only the np nearest of the np_stride lists the coarse quantiser assigned -- collect_search_big's bound)
 	void select_search(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
-	                   const int64_t *d_idmap, hipStream_t st, int64_t np) {
-		std::vector<int64_t> cl((size_t)nq * np);
-		MVS_HIP(hipMemcpyAsync(cl.data(), ws_cI.p, cl.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	                   const int64_t *d_idmap, hipStream_t st, int64_t np, int64_t np_stride = 0) {
+		if (np_stride <= 0)
+			np_stride = np;
+		std::vector<int64_t> cl_all((size_t)nq * np_stride);
+		MVS_HIP(hipMemcpyAsync(cl_all.data(), ws_cI.p, cl_all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 		MVS_HIP(hipStreamSynchronize(stream));
+		std::vector<int64_t> cl((size_t)nq * np);
+		for (int64_t q = 0; q < nq; ++q)
+			for (int64_t p = 0; p < np; ++p)
+				cl[(size_t)(q * np + p)] = cl_all[(size_t)(q * np_stride + p)];
 		ws_q.reserve((size_t)nq * dp * sizeof(float));
 		launch_pad_rows(d_x, nq, d, (float *)ws_q.p, dp, stream);
 		SelectorDev sel = selector.upload(params, stream);
@@ -1503,6 +1551,174 @@ public:
 		kinfo.flops = cands * d * (metric == METRIC_L2 ? 3.0 : 2.0);
 		kinfo.block = 256;
 		kinfo.nsplit = (int)np;
+	}
+	// Lists beyond 32 entries on the bf16 filter (round 6).  The class slots of the scan reach k = 32; past that the scanner kernel
+	// (k <= 256) and the all-distances + sort path served: 6-41 ms at C3's shape against 1 ms at k = 32 (tools/ivf_k_bench.py).  As for the
+	// Flat index (csrc/flat_collect.hip "lists beyond 128 entries") the bound comes from elsewhere and the scan runs against it FROZEN:
+	//   A. B(q) = the k-th best EXACT value among the rows of the query's nearest lists (select_search over the first np_a probes: a few
+	//      thousand rows per query) -- k real rows are at least that good, so every row of the result has s >= B - E(list);
+	//   B. the grouped bf16 scan of all probed lists against B (ivf_bf16_collect_kernel, a.bfix), candidates into the stream;
+	//   C. positions in the list-sorted store, grouped by query, re-scored with the scanner's arithmetic (fvec_L2sqr / fvec_inner_product
+	//      = the Flat per-pair chains: collect_exact_kernel), the k best by (value, position) -- the order of the k-list kernels, of
+	//      select_search and of the exact-tie wrapper's contract.
+	// false: not served / the stream overflowed / a query without a finite bound -- the caller's older paths take the batch.
+	bool collect_search_big(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
+	                        const int64_t *d_idmap, hipStream_t st, int64_t np) {
+		build_lists_mf(false);
+		if (!have_bfr || nsorted <= 0)
+			return false;
+		const int kk = (int)k, kf = raw_pos && k > 1 ? (int)k - 1 : (int)k;
+		const int G = 128, shift = 7;
+		// A. the bound: the nearest lists that hold ~3 k rows on average
+		const double avg_len = (double)nsorted / (double)nlist;
+		const int64_t np_a = std::min<int64_t>(np, std::max<int64_t>(1, (int64_t)(3.0 * kf / std::max(avg_len, 1.0)) + 1));
+		ws_bD.reserve((size_t)nq * kf * sizeof(float));
+		ws_bI.reserve((size_t)nq * kf * sizeof(int64_t));
+		ws_bfix.reserve((size_t)nq * sizeof(float));
+		{
+			const bool rp = raw_pos, ri = raw_ids;
+			raw_pos = true; // (positions: no label translation in the bound pass)
+			try {
+				select_search(nq, d_x, kf, (float *)ws_bD.p, (int64_t *)ws_bI.p, params, d_idmap, stream, np_a, np);
+			} catch (...) {
+				raw_pos = rp, raw_ids = ri;
+				throw;
+			}
+			raw_pos = rp, raw_ids = ri;
+		}
+		hipLaunchKernelGGL(ivf_big_bound_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, (const float *)ws_bD.p, kf, (long long)nq,
+		                   metric == METRIC_L2 ? 1 : 0, (float *)ws_bfix.p);
+		// B. grouping, packing (collect_search_pass's launches; the nearest-list item set is built and not scanned), the frozen scan
+		const int64_t npairs = nq * np;
+		const int max_items = ivf_group_max_items(npairs, nlist, G);
+		ws_items.reserve((size_t)max_items * 16);
+		ws_qidx.reserve((size_t)npairs * sizeof(int32_t));
+		ws_slots.reserve((size_t)npairs * sizeof(int32_t));
+		const size_t group_ints = (ivf_group_ws_ints(nlist) + 63) & ~(size_t)63;
+		ws_group.reserve(2 * group_ints * sizeof(int));
+		if (ws_group.p != group_clean_p || ws_group.cap != group_clean_cap)
+			MVS_HIP(hipMemsetAsync(ws_group.p, 0, 2 * group_ints * sizeof(int), stream));
+		group_clean_p = nullptr;
+		ws_xi.reserve(ivf_collect_xi_bytes(max_items));
+		ws_ig.reserve((size_t)max_items * 128 * sizeof(float));
+		ws_ie2.reserve((size_t)max_items * 128 * sizeof(float));
+		const size_t ctl_bytes = 256 + (size_t)3 * nq * sizeof(int) + ((size_t)nq + 64) * sizeof(int);
+		ws_qfail.reserve(ctl_bytes);
+		MVS_HIP(hipMemsetAsync(ws_qfail.p, 0, ctl_bytes, stream));
+		ctl_clean_p = nullptr;
+		int *const ctl_qfail = (int *)((char *)ws_qfail.p + 256), *const ctl_seg = ctl_qfail + nq;
+		int *const ctl_flag = ctl_seg + 2 * nq;
+		ws_gslot.reserve((size_t)nq * 32 * sizeof(unsigned) + 64);
+		// (~ k (rows probed) / (rows of the bound's lists) candidates per query, with slack; grown once when it proves too small)
+		int64_t cap_entries = std::max<int64_t>(nq * std::max<int64_t>(4096, 4 * (int64_t)kf * np / std::max<int64_t>(np_a, 1) / 2), (int64_t)1 << 20);
+		const unsigned *rowmask = nullptr;
+		if (params && params->sel_kind != MVS_SEL_NONE) {
+			SelectorDev sel = selector.upload(params, stream);
+			ws_rowmask.reserve(ivf_rowmask_bytes(nrows_mf));
+			launch_ivf_rowmask(sel, (const int64_t *)rowids_mf.p, (const int *)perm_mf.p, d_idmap, nrows_mf, ws_rowmask.p, stream);
+			rowmask = (const unsigned *)ws_rowmask.p;
+		}
+		int64_t max_list = 0;
+		for (int64_t l = 0; l < nlist; l++)
+			max_list = std::max(max_list, list_off[(size_t)l + 1] - list_off[(size_t)l]);
+		const int seg_rows = cl_seg_rows, nseg = (int)((max_list + seg_rows - 1) / seg_rows);
+		const int max_items0 = ivf_group_max_items(nq, nlist, G);
+		ws_items0.reserve((size_t)max_items0 * 16);
+		ws_qidx0.reserve((size_t)nq * sizeof(int32_t));
+		ws_xi0.reserve(ivf_collect_xi_bytes(max_items0));
+		ws_ig0.reserve((size_t)max_items0 * 128 * sizeof(float));
+		ws_ie20.reserve((size_t)max_items0 * 128 * sizeof(float));
+		int *d_nitems = nullptr, *d_nitems0 = nullptr;
+		launch_ivf_group2((const int64_t *)ws_cI.p, nq, (int)np, nlist, G, shift, (const int64_t *)lb_dev.p, (const int64_t *)le_dev.p,
+		                  (int *)ws_group.p, (int *)ws_group.p + group_ints, ws_items0.p, (int *)ws_qidx0.p, (int *)ws_slots.p, ws_items.p,
+		                  (int *)ws_qidx.p, nullptr, &d_nitems0, &d_nitems, stream);
+		group_clean_p = ws_group.p, group_clean_cap = ws_group.cap;
+		launch_ivf_collect_pack2(metric, d_x, d, nq, (const int *)ws_slots.p, ws_items0.p, ws_xi0.p, (float *)ws_ig0.p, (float *)ws_ie20.p,
+		                         ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (float *)ws_ig.p, (float *)ws_ie2.p,
+		                         (const float *)cent_dev.p, (const int *)list_of_blk.p, (const unsigned *)list_max.p, ctl_qfail, nlist,
+		                         (unsigned *)ws_gslot.p, 32, (int *)ws_qfail.p, ctl_flag, stream);
+		unsigned long long *cnt = (unsigned long long *)ws_qfail.p;
+		if (!h_fail)
+			MVS_HIP(hipHostMalloc((void **)&h_fail, 512, hipHostMallocDefault));
+		memset(&kinfo, 0, sizeof kinfo);
+		unsigned long long nstream = 0;
+		size_t half = 0;
+		for (int attempt = 0;; ++attempt) {
+			half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
+			ws_stream.reserve(256 + 2 * half);
+			unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
+			begin_kernel_timing(stream);
+			launch_ivf_collect_scan(ws_items.p, d_nitems, max_items, (const int *)ws_qidx.p, ws_xi.p, (const float *)ws_ig.p, (const float *)ws_ie2.p,
+			                        (const unsigned short *)codes_bfr.p, (const float *)beta_mf.p, (unsigned *)ws_gslot.p, strm, cnt, cap_entries, kf,
+			                        seg_rows, nseg, 1, rowmask, stream, nullptr, (const float *)ws_bfix.p);
+			end_kernel_timing(stream);
+			MVS_HIP(hipMemcpyAsync(h_fail + 64, ws_qfail.p, 256, hipMemcpyDeviceToHost, stream));
+			std::vector<int> qf;
+			if (attempt == 0) { // (the packing kernel flags the queries whose bound is not finite; nobody compacts them here)
+				qf.resize((size_t)nq);
+				MVS_HIP(hipMemcpyAsync(qf.data(), ctl_qfail, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, stream));
+			}
+			MVS_HIP(hipStreamSynchronize(stream));
+			memcpy(&nstream, h_fail + 64, sizeof nstream);
+			bool any_fail = false;
+			for (int v : qf)
+				any_fail |= v != 0;
+			if (any_fail) { // a query without a finite bound: the older paths take the batch
+				ctl_clean_p = nullptr;
+				return false;
+			}
+			if ((int64_t)nstream <= cap_entries)
+				break;
+			++cl_overflows;
+			if (attempt > 0 || (int64_t)(nstream + nstream / 8) > nq * std::max<int64_t>(16384, 64 * (int64_t)kf)) {
+				ctl_clean_p = nullptr;
+				return false;
+			}
+			cap_entries = (int64_t)(nstream + nstream / 8);
+			MVS_HIP(hipMemsetAsync(cnt, 0, 16, stream));
+		}
+		ctl_clean_p = nullptr; // (the control block is not in the state collect_search_pass leaves it in)
+		unsigned long long *strm = (unsigned long long *)((char *)ws_stream.p + 256);
+		unsigned long long *sorted = (unsigned long long *)((char *)ws_stream.p + 256 + half);
+		const int64_t ncand = (int64_t)nstream;
+		cl_last_admitted = ncand;
+		cl_queries_total += nq;
+		cl_candidates_total += ncand;
+		cl_last_pairs = cl_last_pairs_kept = npairs, cl_last_nq = nq;
+		cl_pairs_pruned_pending = false;
+		// C. positions, grouping, the scanner's arithmetic, selection
+		if (ncand > 0)
+			hipLaunchKernelGGL(ivf_big_translate_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, stream, strm, (long long)ncand,
+			                   (const int *)perm_mf.p);
+		size_t temp = ncand > 0 ? collect_sort_temp_bytes(ncand, nq) : 0;
+		if (kk > 128 && ncand > 0)
+			temp = std::max(temp, collect_select_big_temp_bytes(ncand, nq));
+		ws_pd.reserve(std::max<size_t>(temp, 16));
+		ws_big_seg.reserve(256 + (size_t)2 * nq * sizeof(int));
+		MVS_HIP(hipMemsetAsync(ws_big_seg.p, 0, 256 + (size_t)2 * nq * sizeof(int), stream));
+		const size_t ex_bytes = ((size_t)nq * kk * sizeof(float) + 255) & ~(size_t)255;
+		ws_ex.reserve(ex_bytes + (size_t)nq * kk * sizeof(int32_t));
+		float *pd1 = (float *)ws_ex.p;
+		int32_t *pi1 = (int32_t *)((char *)ws_ex.p + ex_bytes);
+		FlatGeom g2 = flat_geom_for(d);
+		g2.pair_interleaved = false; // (the list-sorted store holds plain rows of dp floats)
+		g2.dp = dp;
+		launch_collect_rescore(metric, strm, sorted, ncand, ws_pd.p, temp, nq, kk, d_x, g2, (const float *)codes.p, nullptr, nullptr,
+		                       (int *)((char *)ws_big_seg.p + 256), pd1, pi1, true /* the scanner's per-pair arithmetic */, stream, nullptr, true);
+		const long long total = (long long)nq * kk;
+		hipLaunchKernelGGL(ivf_big_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float *)pd1, (const int *)pi1, total,
+		                   metric == METRIC_L2 ? 1 : 0, raw_pos ? nullptr : (const long long *)rowids.p,
+		                   (d_idmap && !raw_ids && !raw_pos) ? (const long long *)d_idmap : nullptr, d_D, (long long *)d_I);
+		MVS_HIP(hipGetLastError());
+		snprintf(kinfo.name, sizeof kinfo.name, "ivf_bf16_collect_kernel");
+		kinfo.grid = max_items * nseg;
+		kinfo.block = 64;
+		kinfo.nsplit = (int)np;
+		kinfo.bytes = (double)nrows_mf * 256.0;
+		kinfo.flops = (double)nq * np * ((double)nsorted / nlist) * d * 2.0;
+		pf_queries_total += nq;
+		stream_wait(st, stream);
+		return true;
 	}
 	void search_device(int64_t nq, const float *d_x, int64_t k, float *d_D, int64_t *d_I, const mvs_search_params *params,
 	                   hipStream_t st) override {
@@ -1585,6 +1801,10 @@ public:
 		quantizer->adopt_tuning(t);
 	}
 	bool set_option(const char *key, int64_t v) override {
+		if (!strcmp(key, "ivf_cl_big")) { // 0: lists beyond 32 entries on the scanner / select kernels (round 5; A/B)
+			cl_big = (int)v;
+			return true;
+		}
 		if (!strcmp(key, "ivf_collect")) {
 			collect_mode = (int)v;
 			return true;
@@ -1791,6 +2011,8 @@ private:
 	int64_t fin_k = 0;
 	bool fin_done = false;
 	DevBuf ws_cand, ws_ex, ws_fail, ws_fb, ws_tD, ws_tI, ws_tflag;
+	DevBuf ws_bD, ws_bI, ws_bfix, ws_big_seg; // collect_search_big: the bound pass's lists, B(q), the grouping's segments
+	int cl_big = 1;                           // option ivf_cl_big: lists beyond 32 entries on the bf16 filter (0: the scanner / select kernels, round 5)
 	int *h_fail = nullptr; // pinned
 	bool pf_suppressed = false; // while the queries the proof rejected are re-run on the scanner kernel
 	bool reuse_coarse = false;

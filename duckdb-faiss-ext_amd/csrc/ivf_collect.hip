@@ -57,6 +57,7 @@ struct IvfCollectArgs {
 	int collect;  // 0: bound estimation only (publish to the slots, append nothing)
 	int refresh;  // tiles between two refreshes of the bounds after the first (option ivf_cl_refresh; 0: 1, 1, 1, 1, 4, 4 ... 16)
 	const unsigned *rowmask; // IDSelector active: bit r of word w = padded row 32 w + r is accepted (nullptr: no selector)
+	const float *bfix;       // (round 6, lists beyond 32 entries) [nq] FROZEN B(q): a lower bound of the exact kk-th best value found elsewhere -- the class slots are not consulted
 	int abl;     // profiling library only (option ivf_cl_abl)
 	int nseg;    // segments per item (xcd_map >= 2 decodes the segment from blockIdx.x)
 	int gx8;     // workgroups of one segment round (a multiple of 8)
@@ -659,7 +660,15 @@ __global__ __launch_bounds__(64, 2) void ivf_bf16_collect_kernel(const IvfCollec
 		const int period = a.refresh > 0 ? a.refresh : (u < 4 ? 1 : (u < 32 ? 4 : 16));
 		if (qfill > IC_QCAP / 2)
 			drain(); // (a queue more than half full is emptied)
-		if ((u % period) == 0) {
+		if (a.bfix != nullptr) { // frozen bounds: set once, nothing derived, nothing published that anyone reads
+			if (u == 0) {
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+					const float B = own_q[i] >= 0 ? a.bfix[own_q[i]] : 0.f;
+					ctab[((hq * 16 + c) * 2 + i) * 2 + 0] = own_q[i] >= 0 ? B - own_e2[i] : __uint_as_float(0x7fc00000u);
+				}
+			}
+		} else if ((u % period) == 0) {
 			publish(); // (this wave's own evidence is in the class slots before it reads them)
 			// (NC = 16: both queries' slots in one round trip; NC = 32: one query at a time -- 32 keys + the network's temporaries)
 			unsigned long long w[NC == 16 ? 2 : 1][NC / 2];
@@ -792,11 +801,14 @@ void launch_ivf_collect_scan(const void *d_items, const int *d_nitems, int max_i
                              const float *d_igamma, const float *d_ie2, const unsigned short *d_rows_bf, const float *d_beta,
                              unsigned *d_gslot, unsigned long long *d_stream, unsigned long long *d_stream_cnt,
                              int64_t stream_cap, int kk, int seg_rows, int nseg, int collect, const unsigned *d_rowmask,
-                             hipStream_t st, float *d_stream_u) {
+                             hipStream_t st, float *d_stream_u, const float *d_bfix) {
 	if (max_items <= 0 || nseg <= 0)
 		return;
 	IvfCollectArgs a;
 	memset(&a, 0, sizeof a);
+	a.bfix = d_bfix;
+	if (d_bfix)
+		kk = 16; // (frozen bounds: the 16-class instance, its slots unused)
 	a.items = (const int4 *)d_items;
 	a.nitems_dev = d_nitems;
 	a.qidx = d_qidx;

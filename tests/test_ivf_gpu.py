@@ -363,7 +363,8 @@ def test_ivf_large_k_select_path(mf, metric, idmap):
                               (1500, 8, xq[:20], ("batch", keep)), (3000, 32, xq[:3], None)]:
         Do, Io = o.search(q, k, nprobe=nprobe, sel=sel)
         D, I = g.search(q, k, nprobe=nprobe, sel=sel)
-        assert g.last_kernel_info()["name"].startswith("ivf_select")
+        # (round 6: up to k = 2048 the bf16 filter against a frozen bound serves these -- collect_search_big; beyond, the select path)
+        assert g.last_kernel_info()["name"].startswith("ivf_select") == (k > 2048), (k, g.last_kernel_info()["name"])
         # same candidates, same per-pair arithmetic: the sorted distance lists agree bit for bit (incl. the -1 / neutral
         # padding when fewer than k rows were probed); labels wherever a distance is unique within its list
         assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), (k, nprobe)
@@ -373,6 +374,41 @@ def test_ivf_large_k_select_path(mf, metric, idmap):
         uniq[:, :-1] &= Do[:, 1:] != Do[:, :-1]
         assert uniq[Io >= 0].mean() > 0.9
         assert np.array_equal(I[uniq], Io[uniq]), (k, nprobe)
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d,nlist,n,nq,k,nprobe,idmap", [(128, 32, 40000, 200, 33, 8, False), (128, 32, 40000, 100, 100, 16, True),
+                                                          (64, 16, 30000, 40, 257, 4, True), (128, 32, 40000, 12, 1000, 32, False)])
+def test_ivf_lists_beyond_32_entries_on_the_coarse_filter(mf, metric, d, nlist, n, nq, k, nprobe, idmap):
+    """round 6: k > 32 on an IVF index -- B(q) = the k-th best exact value among the rows of the query's nearest lists, the grouped bf16
+    scan of every probed list against that bound FROZEN, the candidates re-scored in the scanner's arithmetic and sorted
+    (IVFFlatIndex::collect_search_big).  Same lists as the scanner / select kernels (option ivf_cl_big = 0) and as the oracle, exact
+    ties included (the wrapper around every path replays FAISS's heap for the tied boundaries)."""
+    xb = _clustered(n, d, 61 + k)
+    xq = _clustered(nq, d, 62 + k)
+    xb[::41] = xb[7]  # duplicates: exact ties inside the lists and at boundaries
+    desc = f"IDMap,IVF{nlist},Flat" if idmap else f"IVF{nlist},Flat"
+    o = orc.Index(d, desc, metric)
+    o.train(xb)
+    g = mf.index_factory(d, desc, metric)
+    g.ivf_set_centroids(o.ivf_centroids())
+    ids = (np.random.RandomState(3).permutation(3 * n)[:n] + 5).astype(np.int64)
+    for a in (o, g):
+        a.add_with_ids(xb, ids) if idmap else a.add(xb)
+    keep = (ids if idmap else np.arange(n))[np.random.RandomState(4).rand(n) < 0.4].astype(np.int64)
+    for sel in (None, ("batch", keep)):
+        D1, I1 = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"] == "ivf_bf16_collect_kernel", g.last_kernel_info()
+        g.set_option("ivf_cl_big", 0)
+        D0, I0 = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"] != "ivf_bf16_collect_kernel"
+        g.set_option("ivf_cl_big", 1)
+        assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), (sel and sel[0])
+        assert np.array_equal(I1, I0), (sel and sel[0])
+        no = min(nq, 8)
+        Do, Io = o.search(xq[:no], k, nprobe=nprobe, sel=sel)
+        assert np.array_equal(D1[:no].view(np.uint32), Do.view(np.uint32)), (sel and sel[0])
+        assert np.array_equal(I1[:no], Io), (sel and sel[0])
 
 
 def test_ivf_k_beyond_the_tie_pass_lds_keeps_working(mf):
