@@ -120,6 +120,117 @@ __global__ void ivf_big_bound_kernel(const float *__restrict__ D, int kk, long l
 	// (fewer than kk rows in those lists: FLT_MAX | -FLT_MAX -- no bound, everything passes)
 	bfix[q] = is_l2 ? (v < FLT_MAX ? -v : -FLT_MAX) : (v > -FLT_MAX ? v : -FLT_MAX);
 }
+// The bound without the host (one workgroup per query): exact values of the first <= R rows of the query's nearest lists, in probe
+// order (the scanner's chains on the list-sorted f32 rows), then the kk-th best of them by a 32-step search over the keys.  Rows in
+// insertion order are a sample of their list: kk of them at least B good -- a valid bound, a little lower than the whole lists' would be.
+__device__ __forceinline__ bool ivf_big_sel_member(const SelectorDev &s, long long id) {
+	if (s.kind == MVS_SEL_BITMAP) {
+		const unsigned long long u = (unsigned long long)id;
+		if ((u >> 3) >= (unsigned long long)s.nbytes)
+			return false;
+		return (s.bitmap[u >> 3] >> (u & 7)) & 1;
+	}
+	if (s.kind == MVS_SEL_BATCH) {
+		long long lo = 0, hi = s.nids;
+		while (lo < hi) {
+			const long long mid = (lo + hi) >> 1;
+			if (s.sorted_ids[mid] < id)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo < s.nids && s.sorted_ids[lo] == id;
+	}
+	return true;
+}
+__global__ __launch_bounds__(256) void ivf_big_bound_direct_kernel(const float *__restrict__ xq, int d, int dp, const float *__restrict__ rows,
+                                                                  const long long *__restrict__ probes, int np,
+                                                                  const long long *__restrict__ list_off, int R, int kk, int is_l2,
+                                                                  SelectorDev sel, const long long *__restrict__ rowids,
+                                                                  const long long *__restrict__ idmap, float *__restrict__ bfix) {
+	extern __shared__ unsigned big_keys[]; // [R] order-preserving keys (smaller = better) | 8 words of reduction scratch | [R] rows | the tile
+	unsigned *red = big_keys + R;
+	int *rowidx = (int *)(red + 8);
+	float(*tile)[33] = (float(*)[33])(rowidx + R); // [256][33]: a slab of 32 dimensions of 256 rows (coalesced reads, conflict-free walks)
+	const long long q = blockIdx.x;
+	const int t = threadIdx.x;
+	const float *x = xq + (size_t)q * d;
+	int have = 0; // (uniform) rows taken so far
+	for (int p = 0; p < np && have < R; ++p) {
+		const long long l = probes[q * np + p];
+		if (l < 0)
+			continue;
+		const long long b = list_off[l];
+		const int len = (int)(list_off[l + 1] - b), take = len < R - have ? len : R - have;
+		for (int i = t; i < take; i += 256)
+			rowidx[have + i] = (int)(b + i);
+		have += take;
+	}
+	__syncthreads();
+	for (int base = 0; base < have; base += 256) {
+		const int mine = base + t;
+		float acc = 0.f;
+		for (int s0 = 0; s0 < d; s0 += 32) {
+			__syncthreads();
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { // 2 048 chunks of 16 bytes: chunk c = row (c >> 3), floats 4 (c & 7) ..
+				const int c = i * 256 + t, r = c >> 3, j4 = (c & 7) * 4;
+				float4 v = {0.f, 0.f, 0.f, 0.f};
+				if (base + r < have && s0 + j4 < dp)
+					v = *(const float4 *)(rows + (size_t)rowidx[base + r] * dp + s0 + j4);
+				tile[r][j4] = v.x, tile[r][j4 + 1] = v.y, tile[r][j4 + 2] = v.z, tile[r][j4 + 3] = v.w;
+			}
+			__syncthreads();
+			const int kend = d - s0 < 32 ? d - s0 : 32;
+			for (int j = 0; j < kend; ++j) { // the scanner's chains: k ascending
+				if (is_l2) {
+					const float tt = x[s0 + j] - tile[t][j];
+					acc = fmaf(tt, tt, acc);
+				} else {
+					acc = fmaf(x[s0 + j], tile[t][j], acc);
+				}
+			}
+		}
+		if (mine < have) {
+			bool ok = true;
+			if (sel.kind != MVS_SEL_NONE) {
+				const long long lab = rowids[rowidx[mine]];
+				ok = ivf_big_sel_member(sel, idmap ? idmap[lab] : lab);
+			}
+			const unsigned fb = __float_as_uint(acc), fk = fb ^ ((fb >> 31) ? 0xFFFFFFFFu : 0x80000000u); // unsigned order = float order
+			big_keys[mine] = ok ? (is_l2 ? fk : ~fk) : 0xFFFFFFFFu; // (rejected rows: behind everything; NaN sorts last either way)
+		}
+	}
+	__syncthreads();
+	// the kk-th smallest key: the largest U with fewer than kk keys below it, bit by bit
+	unsigned U = 0u;
+	for (int bit = 31; bit >= 0; --bit) {
+		const unsigned tt = U | (1u << bit);
+		int c = 0;
+		for (int i = t; i < have; i += 256)
+			c += big_keys[i] < tt ? 1 : 0;
+		for (int o = 32; o >= 1; o >>= 1)
+			c += __shfl_xor(c, o);
+		if ((t & 63) == 0)
+			red[t >> 6] = (unsigned)c;
+		__syncthreads();
+		const int total = (int)(red[0] + red[1] + red[2] + red[3]);
+		__syncthreads();
+		if (total < kk)
+			U = tt;
+	}
+	if (t == 0) {
+		float B = -FLT_MAX; // (fewer than kk admissible rows in reach: no bound, everything passes)
+		if (have >= kk && U != 0xFFFFFFFFu) {
+			const unsigned fk = is_l2 ? U : ~U;
+			const float v = __uint_as_float((fk & 0x80000000u) ? (fk ^ 0x80000000u) : ~fk);
+			B = is_l2 ? -v : v;
+			if (!(B > -FLT_MAX))
+				B = -FLT_MAX;
+		}
+		bfix[q] = B;
+	}
+}
 // stream entries (q << 32 | padded row) -> (q << 32 | position in the list-sorted store); padding rows never pass the scan
 __global__ void ivf_big_translate_kernel(unsigned long long *__restrict__ strm, long long n, const int *__restrict__ perm) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1572,9 +1683,21 @@ public:
 		// A. the bound: the nearest lists that hold ~3 k rows on average
 		const double avg_len = (double)nsorted / (double)nlist;
 		const int64_t np_a = std::min<int64_t>(np, std::max<int64_t>(1, (int64_t)(3.0 * kf / std::max(avg_len, 1.0)) + 1));
+		ws_bfix.reserve((size_t)nq * sizeof(float));
+		if (cl_big >= 1 && cl_big != 2) {
+			// (default) on the device: the first R = 4 k (256 .. 8192) rows of the nearest lists, no host round trip
+			const int R = (int)std::min<int64_t>(8192, std::max<int64_t>(256, 4 * (int64_t)kf));
+			SelectorDev bsel = selector.upload(params, stream);
+			const size_t blds = (size_t)(2 * R + 8) * sizeof(unsigned) + (size_t)256 * 33 * sizeof(float);
+			ensure_dynamic_lds((const void *)ivf_big_bound_direct_kernel, blds);
+			hipLaunchKernelGGL(ivf_big_bound_direct_kernel, dim3((unsigned)nq), dim3(256), blds, stream, d_x, d, dp,
+			                   (const float *)codes.p, (const long long *)ws_cI.p, (int)np, (const long long *)list_off_dev.p, R, kf,
+			                   metric == METRIC_L2 ? 1 : 0, bsel, (const long long *)rowids.p, (const long long *)d_idmap, (float *)ws_bfix.p);
+			MVS_HIP(hipGetLastError());
+		} else {
+		// (option ivf_cl_big = 2: the bound from ALL rows of the nearest lists through the select path -- tighter, two host round trips)
 		ws_bD.reserve((size_t)nq * kf * sizeof(float));
 		ws_bI.reserve((size_t)nq * kf * sizeof(int64_t));
-		ws_bfix.reserve((size_t)nq * sizeof(float));
 		{
 			const bool rp = raw_pos, ri = raw_ids;
 			raw_pos = true; // (positions: no label translation in the bound pass)
@@ -1588,6 +1711,7 @@ public:
 		}
 		hipLaunchKernelGGL(ivf_big_bound_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, (const float *)ws_bD.p, kf, (long long)nq,
 		                   metric == METRIC_L2 ? 1 : 0, (float *)ws_bfix.p);
+		}
 		// B. grouping, packing (collect_search_pass's launches; the nearest-list item set is built and not scanned), the frozen scan
 		const int64_t npairs = nq * np;
 		const int max_items = ivf_group_max_items(npairs, nlist, G);
@@ -1610,7 +1734,7 @@ public:
 		int *const ctl_flag = ctl_seg + 2 * nq;
 		ws_gslot.reserve((size_t)nq * 32 * sizeof(unsigned) + 64);
 		// (~ k (rows probed) / (rows of the bound's lists) candidates per query, with slack; grown once when it proves too small)
-		int64_t cap_entries = std::max<int64_t>(nq * std::max<int64_t>(4096, 4 * (int64_t)kf * np / std::max<int64_t>(np_a, 1) / 2), (int64_t)1 << 20);
+		int64_t cap_entries = std::max<int64_t>(nq * std::max<int64_t>(4096, 16 * (int64_t)kf), (int64_t)1 << 20);
 		const unsigned *rowmask = nullptr;
 		if (params && params->sel_kind != MVS_SEL_NONE) {
 			SelectorDev sel = selector.upload(params, stream);

@@ -402,6 +402,10 @@ def test_ivf_lists_beyond_32_entries_on_the_coarse_filter(mf, metric, d, nlist, 
         g.set_option("ivf_cl_big", 0)
         D0, I0 = g.search(xq, k, nprobe=nprobe, sel=sel)
         assert g.last_kernel_info()["name"] != "ivf_bf16_collect_kernel"
+        g.set_option("ivf_cl_big", 2)  # (the bound from every row of the nearest lists, through the select path)
+        D2, I2 = g.search(xq, k, nprobe=nprobe, sel=sel)
+        assert g.last_kernel_info()["name"] == "ivf_bf16_collect_kernel"
+        assert np.array_equal(D2.view(np.uint32), D0.view(np.uint32)) and np.array_equal(I2, I0), (sel and sel[0])
         g.set_option("ivf_cl_big", 1)
         assert np.array_equal(D1.view(np.uint32), D0.view(np.uint32)), (sel and sel[0])
         assert np.array_equal(I1, I0), (sel and sel[0])
