@@ -183,6 +183,8 @@ EMBEDDED = [  # (name, workload of BASELINE.json configs[i], bench.py arguments)
     ("H_k1000", "IndexFlatL2 d=128 N=10M nq=2048 k=1000 (post-filter list length)",
      ["--nq", "2048", "--k", "1000", "--no-cpu-baseline", "--parity-device", "64", "--steps", "3", "--warmup", "1"]),
     ("C3", "IVF4096,Flat d=128 N=10M nprobe=32 nq=10k k=10", ["--index", "IVF4096,Flat", "--data", "clustered", "--parity-device", "1024", "--steps", "10", "--warmup", "2"]),
+    ("C3_k100", "IVF4096,Flat d=128 N=10M nprobe=32 nq=2048 k=100 (list length beyond the scan's class slots)",
+     ["--index", "IVF4096,Flat", "--data", "clustered", "--nq", "2048", "--k", "100", "--no-cpu-baseline", "--parity-device", "64", "--steps", "5", "--warmup", "2"]),
     ("C4_shard", "IndexFlatIP d=768, one GPU's N/8 = 12.5M rows of N=100M, nq=10k k=10",
      ["--rows", "12500000", "--d", "768", "--metric", "IP", "--normalize", "--data", "clustered", "--sigma", "1.0", "--cpu-seconds", "8", "--parity-device", "256"]),
     ("C5", "IDMap,HNSW32 d=768 N=1M nq=10k k=10 efSearch=128",

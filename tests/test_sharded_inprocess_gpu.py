@@ -56,6 +56,28 @@ def test_flat_row_shards_equal_unsharded_and_oracle(mf, metric, idmap, G):
 
 
 @pytest.mark.parametrize("metric", [L2, IP])
+def test_big_lists_on_row_shards_take_the_coarse_filter_in_every_shard(mf, metric):
+    """round 6: k = 300 on two row shards of 270 k rows each -- every shard serves its k-list through the coarse filter's big-list
+    path (bounds from row ranges, frozen scan, segmented sort: tests/test_collect_gpu.py), the merge is the usual one; same answer as
+    the unsharded index and, on a sample, the oracle"""
+    d, nb, k = 128, 540_000, 300
+    rs = np.random.RandomState(17)
+    xb = rs.rand(nb, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    xb[rs.randint(0, nb, 4000)] = xb[rs.randint(0, nb, 4000)]
+    xq = rs.rand(64, d).astype(np.float32) - (0.5 if metric == IP else 0.0)
+    one, sh = mf.index_factory(d, "Flat", metric), mf.index_factory(d, "Flat", metric)
+    sh.shard_to_gpus([0, 0])
+    for a in (one, sh):
+        for i0 in range(0, nb, 1 << 16):
+            a.add(xb[i0 : i0 + (1 << 16)])
+    ref = one.search(xq, k)
+    assert one.last_kernel_info()["name"] == "flat_bf16_collect_kernel"
+    _same(sh.search(xq, k), ref, f"sharded vs unsharded big list m={metric}")
+    Do, Io = orc.flat_search(metric, xb, xq[:3], k, force_path=orc.PATH_BLAS)
+    assert np.array_equal(ref[1][:3], Io) and np.array_equal(ref[0][:3].view(np.uint32), Do.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
 def test_large_k_on_eight_shards_takes_the_host_merge(mf, metric):
     """k = 2048 on 8 shards: 16 392 candidates per query do not fit merge_records_kernel's LDS (the round-3 device
     merge threw "nshard * k too large" where a single GPU serves k up to ~5 000): the records take merge_records_host
