@@ -1661,7 +1661,8 @@ void launch_collect_big_bounds(const FlatGeom &g, int metric, const void *d_qf, 
 		a.nq = (int)nq;
 		a.rowmask = d_rowmask;
 		a.opt = tune().ksplit_opt;
-		const int64_t r0 = (n * p / nranges) / 192 * 192, r1 = std::min<int64_t>(n, r0 + range_rows);
+		// (disjoint ranges: the proof counts a row once -- strides of whole 192-row units, a range no longer than its stride)
+		const int64_t stride = (n / nranges) / 192 * 192, r0 = (int64_t)p * stride, r1 = std::min<int64_t>(n, r0 + std::min<int64_t>(range_rows, stride));
 		if (dp1 > 128) { // (the wide stores' kernels derive their bounds per wave: no table)
 			const int nqbw = (int)((nq + collect_wide_qblock(dp1) - 1) / collect_wide_qblock(dp1));
 			launch_collect_wide_range(dp1, metric, false, a, r0, r1, std::max<int64_t>(8, std::min<int64_t>(64, 1024 / nqbw)), nq, st, nullptr, nullptr);

@@ -505,8 +505,11 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	// showed this index's data to need (cl_cap_hint, up to 16384 per query: clustered rows with large norms admit thousands)
 	int64_t cap_entries = cl_stream_cap_per_query > 0 ? std::max<int64_t>(nq * cl_stream_cap_per_query, 1024)
 	                                                  : std::max<int64_t>(nq * std::max<int64_t>(4096, cl_cap_hint), (int64_t)1 << 20);
+	if (bigk && (ntotal / std::max(bk_ranges, 1) < 192 || bk_rows < 64))
+		return false; // (ranges too short to mean anything: the exact kernels)
 	if (bigk && cl_stream_cap_per_query <= 0) // (~ k ntotal / (rows of pass A) candidates per query, times the slack of a class bound)
-		cap_entries = std::max<int64_t>(cap_entries, nq * std::min<int64_t>(ntotal, 4 * (int64_t)kf * ntotal / std::max<int64_t>(bk_rows * bk_ranges, 1)));
+		cap_entries = std::min<int64_t>(((int64_t)1 << 31) - 4096,
+		                                std::max<int64_t>(cap_entries, nq * std::min<int64_t>(ntotal, 4 * (int64_t)kf * ntotal / std::max<int64_t>(bk_rows * bk_ranges, 1))));
 	size_t half = ((size_t)cap_entries * 8 + 255) & ~(size_t)255;
 	ws_stream.reserve(256 + 2 * half);
 	// one zeroed control block {stream count | per-query segments} (round 4: one memset instead of three per search)
@@ -625,7 +628,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	if (attempt > 0 || few)
 		return false;
 	const int64_t grow_max = cl_stream_cap_per_query > 0 ? 4 * (int64_t)cl_stream_cap_per_query : std::max<int64_t>(16384, bigk ? 64 * (int64_t)kf : 0);
-	if (bigk && ncand + ncand / 8 > nq * grow_max)
+	if (bigk && (ncand + ncand / 8 > nq * grow_max || ncand + ncand / 8 >= ((int64_t)1 << 31)))
 		return false; // (frozen bounds: no query can be taken out of this scan -- the exact kernels take the batch)
 	if (ncand + ncand / 8 <= nq * grow_max) {
 		// (a) the data simply admits more rows per query than the stream was sized for: a larger stream, one more scan (the

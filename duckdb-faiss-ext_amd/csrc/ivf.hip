@@ -1734,6 +1734,8 @@ public:
 		int *const ctl_flag = ctl_seg + 2 * nq;
 		ws_gslot.reserve((size_t)nq * 32 * sizeof(unsigned) + 64);
 		// (~ k (rows probed) / (rows of the bound's lists) candidates per query, with slack; grown once when it proves too small)
+		if ((double)nq * (double)std::max<int64_t>(4096, 16 * (int64_t)kf) >= 1.5e9)
+			return false; // (the grouping and the sort index their entries with 32 bits)
 		int64_t cap_entries = std::max<int64_t>(nq * std::max<int64_t>(4096, 16 * (int64_t)kf), (int64_t)1 << 20);
 		const unsigned *rowmask = nullptr;
 		if (params && params->sel_kind != MVS_SEL_NONE) {
@@ -1794,7 +1796,7 @@ public:
 			if ((int64_t)nstream <= cap_entries)
 				break;
 			++cl_overflows;
-			if (attempt > 0 || (int64_t)(nstream + nstream / 8) > nq * std::max<int64_t>(16384, 64 * (int64_t)kf)) {
+			if (attempt > 0 || (int64_t)(nstream + nstream / 8) > nq * std::max<int64_t>(16384, 64 * (int64_t)kf) || (int64_t)(nstream + nstream / 8) >= ((int64_t)1 << 31)) {
 				ctl_clean_p = nullptr;
 				return false;
 			}
