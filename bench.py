@@ -580,7 +580,8 @@ def main():
                 final["D"], final["I"] = fD, fI
             return
         if ivf_ties:
-            fD, fI = xchs[slot].merge_ivf_exact(metric, Ds, Is, lambda fq, T: ix.ivf_tie_emit_torch(fq, xq, T, k))
+            fD, fI = xchs[slot].merge_ivf_exact(metric, Ds, Is, lambda fq, T: ix.ivf_tie_emit_torch(fq, xq, T, k),
+                                                        ids_ascending=bool(ix.get_stat("ivf_ids_ascending")))
             if rank == 0:
                 final["D"], final["I"] = fD, fI
             return

@@ -257,6 +257,12 @@ __global__ void ivf_big_emit_kernel(const float *__restrict__ pd, const int *__r
 	D[i] = pos >= 0 ? pd[i] : (is_l2 ? FLT_MAX : -FLT_MAX);
 	I[i] = lab;
 }
+// tie_emit's precondition: flag = {nf, query numbers ...}; a number outside [0, nq) sets *bad (pinned host memory)
+__global__ void ivf_flag_check_kernel(const int *__restrict__ flag, int nf, int nq, int *bad) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nf && (flag[1 + i] < 0 || flag[1 + i] >= nq))
+		*bad = 1;
+}
 __global__ void ivf_max_norm_kernel(const float *norms, long long n, unsigned *out_bits) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	float v = i < n ? norms[i] : 0.f;
@@ -601,6 +607,17 @@ public:
 		if (ntotal + n > (int64_t)0x7fffffff - 1024)
 			throw_faiss("mvs::IVFFlatIndex::add", __FILE__, "a single-device shard holds at most 2^31 rows");
 		grow(ntotal + n);
+		// (the cross-process tie merge rebuilds FAISS's arrival order inside a list as (probe rank, stored id) -- true only
+		// while ids grow with insertion order; mvs_index_get_stat "ivf_ids_ascending" says whether they still do)
+		if (ids_host)
+			for (int64_t i = 0; i < n && ids_ascending; ++i) {
+				ids_ascending = ids_host[i] > last_id_seen;
+				last_id_seen = ids_host[i];
+			}
+		else {
+			ids_ascending = ids_ascending && ntotal > last_id_seen;
+			last_id_seen = std::max<int64_t>(last_id_seen, ntotal + n - 1);
+		}
 		const int64_t bs = 65536; // IndexIVF::add_with_ids block size
 		DevBuf dD, dI;
 		dD.reserve((size_t)std::min(bs, n) * sizeof(float));
@@ -826,12 +843,38 @@ public:
 	// ---------------------------------------------------------------------------------------------- search
 	// row shard of a ShardedIndex: A_k of the flagged queries of the last search (csrc/ivf_ties.hip EMIT mode)
 	int64_t last_np = 0;
+	int64_t last_coarse_nq = 0;           // the batch whose coarse assignment ws_cI holds (tie_emit reuses it)
+	const float *last_coarse_x = nullptr;
+	bool ids_ascending = true;            // every id added so far was larger than all before it (plain add(): always)
+	int64_t last_id_seen = -1;
+	bool named_stat(const char *name, int64_t *v) override {
+		if (!strcmp(name, "ivf_ids_ascending")) {
+			*v = ids_ascending ? 1 : 0;
+			return true;
+		}
+		return false;
+	}
 	void tie_emit(const int *d_flag, int nf, const float *d_x, const float *d_T, int64_t k, const mvs_search_params *params,
 	              const int64_t *d_idmap_sel, float *d_v, int64_t *d_id, int *d_p, hipStream_t st) override {
 		use_device();
 		if (nf <= 0)
 			return;
+		// (the preconditions, checked -- the coarse assignment in ws_cI is that of the LAST search's batch)
+		if (d_x != last_coarse_x || nf > last_coarse_nq)
+			throw_faiss("mvs::IVFFlatIndex::tie_emit", __FILE__,
+			            "the batch (%p, %lld flagged queries) is not the one of the search that has just run on this index (%p, %lld queries)",
+			            (const void *)d_x, (long long)nf, (const void *)last_coarse_x, (long long)last_coarse_nq);
 		stream_wait(stream, st);
+		{
+			if (!h_fail)
+				MVS_HIP(hipHostMalloc((void **)&h_fail, 512, hipHostMallocDefault));
+			h_fail[120] = 0;
+			hipLaunchKernelGGL(ivf_flag_check_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, stream, d_flag, nf, (int)last_coarse_nq, h_fail + 120);
+			MVS_HIP(hipStreamSynchronize(stream));
+			if (h_fail[120] != 0)
+				throw_faiss("mvs::IVFFlatIndex::tie_emit", __FILE__, "a flagged query number lies outside the last search's batch of %lld queries",
+				            (long long)last_coarse_nq);
+		}
 		if (ntotal == 0 || last_np <= 0) {
 			MVS_HIP(hipMemsetAsync(d_id, 0xff, (size_t)nf * k * sizeof(int64_t), stream));
 			MVS_HIP(hipMemsetAsync(d_p, 0xff, (size_t)nf * k * sizeof(int), stream));
@@ -878,6 +921,7 @@ public:
 		qp.efSearch = params ? params->efSearch : 0; // quantizer_params of an HNSW coarse quantizer (:679-681)
 		if (!reuse_coarse) { // (a prefilter re-run keeps the coarse assignment of the batch its queries came from)
 			TraceRange trc("mvs:ivf_coarse_quantiser");
+			last_coarse_nq = nq, last_coarse_x = d_x;
 			// a Flat L2 quantizer of a few thousand centroids: distance matrix + per-query selection (csrc/coarse_select.hip)
 			const bool done = hnsw_M == 0 && static_cast<FlatIndex *>(quantizer)->coarse_topk(nq, d_x, np, (float *)ws_cD.p,
 			                                                                                  (int64_t *)ws_cI.p, stream, shadow != nullptr);

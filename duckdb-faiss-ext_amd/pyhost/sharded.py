@@ -219,13 +219,18 @@ class ShardExchange:
         return mf.finish_ip_ties(k, rawD, rawI, flagged, first)
 
     # ---- IVF with exact distance ties (round 5): collective, every rank calls it with the same arguments ------------------------
-    def merge_ivf_exact(self, metric, D, I, tie_emit, merge_rank=0):
+    def merge_ivf_exact(self, metric, D, I, tie_emit, merge_rank=0, ids_ascending=None):
         """Row-sharded IVF, the heap's outcome under exact ties (include/mi355_faiss.h "IVF exact distance ties across PROCESSES";
         csrc/sharded.hip resolve_ties_ivf is the in-library twin).  D, I: this rank's [nq, k+1] PURE-order lists (the shard searched
         with k + 1 and option ivf_exact_ties = 0; labels = global rows); tie_emit(flagged i64 tensor, T f32 tensor) -> (v [nf, k] f32,
         id [nf, k] i64, rank [nf, k] i32) torch: this rank's first k rows not worse than T in arrival order, -1 padded
         (Index.ivf_tie_emit_torch).  Returns (D, I) numpy [nq, k] on merge_rank, (None, None) elsewhere."""
         assert self.ip_ties and D.shape[1] == self.kk  # (ip_ties = "k + 1 entries per shard": the same buffers serve both protocols)
+        # (ADVICE r5: A_k below is ordered by (probe rank, stored id) -- FAISS's arrival order inside a list only while ids grew with
+        # insertion order; pass Index.get_stat("ivf_ids_ascending") of the shard and the merge refuses what it cannot reproduce)
+        if ids_ascending is not None and not ids_ascending:
+            raise ValueError("merge_ivf_exact: the shard's ids do not grow with insertion order (add_with_ids with arbitrary ids): "
+                             "the heap's tie outcome cannot be rebuilt from (probe rank, id); search with ivf_exact_ties = 0 and merge_shards instead")
         k, kk = self.k, self.kk
         is_l2 = metric == mf.METRIC_L2
         if self.world == 1:

@@ -188,7 +188,9 @@ int mvs_finish_ip_ties(int64_t n, int64_t k, int64_t kk, const float *raw_D, con
  * and the merge rank takes the first k of the union by (probe rank, id) = A_k and applies the closed form of csrc/ivf_ties.hip
  * (pyhost/sharded.py merge_ivf_exact; the in-library ShardedIndex does the same in resolve_ties_ivf).
  * d_flag = {nf, query numbers ...} on the device; d_x = the WHOLE batch of the search that has just run on this index (its coarse
- * assignment is reused: the call must follow that search directly); d_T [nf]; outputs [nf][k]. */
+ * assignment is reused: the call must follow that search directly -- checked: another d_x, more flagged queries than the batch held or
+ * a query number outside it is an error); d_T [nf]; outputs [nf][k].  mvs_index_get_stat "ivf_ids_ascending" = 1 while every id added
+ * so far exceeded all before it -- the cross-process merge's arrival order (probe rank, id) is FAISS's only then. */
 int mvs_index_ivf_tie_emit_device(mvs_index *ix, int64_t nf, const int *d_flag, const float *d_x, const float *d_T, int64_t k,
                                   float *d_v_out, int64_t *d_id_out, int *d_rank_out, const mvs_search_params *params,
                                   void *stream);

@@ -682,6 +682,38 @@ def test_ivf_exact_ties_follow_the_heap(mf, metric, desc, d):
     assert len(seen) >= (3 if d <= 128 else 2), seen  # (d > 128: no coarse filter, no f32 MFMA items)
 
 
+def test_tie_emit_checks_its_preconditions(mf):
+    """mvs_index_ivf_tie_emit_device reuses the coarse assignment of the search that has just run -- another batch, more
+    flagged queries than that batch held or a query number outside it is refused; "ivf_ids_ascending" tells the cross-process merge
+    whether (probe rank, id) still is FAISS's arrival order"""
+    import torch
+
+    d, n = 32, 20000
+    xb = _clustered(n, d, 71)
+    g = mf.index_factory(d, "IVF16,Flat", L2)
+    g.train(xb)
+    g.add(xb)
+    assert g.get_stat("ivf_ids_ascending") == 1
+    dev = torch.device("cuda", 0)
+    xq = torch.from_numpy(_clustered(50, d, 72)).to(dev)
+    other = xq.clone()
+    g.set_option("ivf_exact_ties", 0)
+    D, I = g.search_torch(xq, 6, nprobe=4)
+    T = D[:3, 4].contiguous()
+    v, ids, rk = g.ivf_tie_emit_torch(torch.tensor([0, 1, 2], device=dev), xq, T, 5)  # the batch that was searched: fine
+    assert ids.shape == (3, 5) and int((ids >= 0).sum()) > 0
+    with pytest.raises(Exception, match="not the one of the search"):
+        g.ivf_tie_emit_torch(torch.tensor([0, 1, 2], device=dev), other, T, 5)
+    with pytest.raises(Exception, match="outside the last search"):
+        g.ivf_tie_emit_torch(torch.tensor([0, 1, 50], device=dev), xq, T, 5)
+    w = mf.index_factory(d, "IVF16,Flat", L2)  # (behind an IDMap the IVF index stores row numbers: ascending whatever the user's ids are)
+    w.train(xb)
+    w.add_with_ids(xb[:100], np.arange(100, dtype=np.int64) + 5)
+    assert w.get_stat("ivf_ids_ascending") == 1
+    w.add_with_ids(xb[100:200], np.arange(100, dtype=np.int64)[::-1].copy() + 1000)
+    assert w.get_stat("ivf_ids_ascending") == 0
+
+
 def test_ivf_exact_ties_option_off_keeps_the_pure_order(mf):
     """ivf_exact_ties = 0 (diagnostics): same values, the scan kernels' (value, position) order"""
     xb, xq = _tied_data(6000, 32, 3, L2)
