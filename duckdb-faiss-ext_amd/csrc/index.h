@@ -130,6 +130,9 @@ public:
 	virtual void set_label_offset(int64_t off) {
 		label_offset = off;
 	}
+	virtual const float *last_batch_ptr() const { // IVF: the device pointer of the batch whose coarse assignment the index still holds (tie_emit)
+		return nullptr;
+	}
 	virtual bool named_stat(const char *, int64_t *) { // index-specific counters of mvs_index_get_stat (HNSW: hnsw_build_distances | hnsw_build_shortcuts)
 		return false;
 	}

@@ -2640,6 +2640,10 @@ int mvs_index_ivf_tie_emit_device(mvs_index *ix, int64_t nf, const int *d_flag, 
 	std::lock_guard<std::mutex> g(ix->mu);
 	if (ix->impl->kind != MVS_KIND_IVFFLAT || is_sharded(ix->impl))
 		throw_faiss("mvs_index_ivf_tie_emit_device", __FILE__, "a plain single-device IVF index is required");
+	// (the coarse assignment the call reuses belongs to ONE batch -- another pointer is another batch as far as anyone can tell)
+	if (nf > 0 && ix->impl->last_batch_ptr() != d_x)
+		throw_faiss("mvs_index_ivf_tie_emit_device", __FILE__, "the batch at %p is not the one of the search that has just run on this index (%p)",
+		            (const void *)d_x, (const void *)ix->impl->last_batch_ptr());
 	if (nf > 0)
 		ix->impl->tie_emit(d_flag, (int)nf, d_x, d_T, k, params, nullptr, d_v_out, d_id_out, d_rank_out, (hipStream_t)stream);
 	MVS_API_END

@@ -847,6 +847,9 @@ public:
 	const float *last_coarse_x = nullptr;
 	bool ids_ascending = true;            // every id added so far was larger than all before it (plain add(): always)
 	int64_t last_id_seen = -1;
+	const float *last_batch_ptr() const override {
+		return last_coarse_x;
+	}
 	bool named_stat(const char *name, int64_t *v) override {
 		if (!strcmp(name, "ivf_ids_ascending")) {
 			*v = ids_ascending ? 1 : 0;
@@ -860,10 +863,11 @@ public:
 		if (nf <= 0)
 			return;
 		// (the preconditions, checked -- the coarse assignment in ws_cI is that of the LAST search's batch)
-		if (d_x != last_coarse_x || nf > last_coarse_nq)
-			throw_faiss("mvs::IVFFlatIndex::tie_emit", __FILE__,
-			            "the batch (%p, %lld flagged queries) is not the one of the search that has just run on this index (%p, %lld queries)",
-			            (const void *)d_x, (long long)nf, (const void *)last_coarse_x, (long long)last_coarse_nq);
+		// (the C ABI entry also insists on the very pointer of that search -- mvs_index_ivf_tie_emit_device; the in-library sharded index
+		// hands over its own copy of the same batch)
+		if (nf > last_coarse_nq)
+			throw_faiss("mvs::IVFFlatIndex::tie_emit", __FILE__, "%lld flagged queries, but the search that has just run on this index had %lld",
+			            (long long)nf, (long long)last_coarse_nq);
 		stream_wait(stream, st);
 		{
 			if (!h_fail)

@@ -702,7 +702,7 @@ def test_tie_emit_checks_its_preconditions(mf):
     T = D[:3, 4].contiguous()
     v, ids, rk = g.ivf_tie_emit_torch(torch.tensor([0, 1, 2], device=dev), xq, T, 5)  # the batch that was searched: fine
     assert ids.shape == (3, 5) and int((ids >= 0).sum()) > 0
-    with pytest.raises(Exception, match="not the one of the search"):
+    with pytest.raises(Exception, match="is not the one of the search"):
         g.ivf_tie_emit_torch(torch.tensor([0, 1, 2], device=dev), other, T, 5)
     with pytest.raises(Exception, match="outside the last search"):
         g.ivf_tie_emit_torch(torch.tensor([0, 1, 50], device=dev), xq, T, 5)
