@@ -1212,15 +1212,15 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	const int cl_kmax0 = cl_k32 ? collect_max_k(d) : std::min(16, collect_max_k(d)); // 32 row classes at d <= 128 (option cl_k32), else 16
 	// (round 6: beyond 128 entries the d <= 128 store's filter takes its bounds from a pass of its own and selects by a segmented sort --
 	// FlatIndex::collect_candidates "bigk"; option cl_bigk = 0: the exact kernels as before)
-	const bool bigk_ok = cl_bigk && (!wide || collect_wide_max_classes(collect_store_dims(d)) >= 128) && collect_supported(geom) && kf > 128 - (kk - kf) && kk <= 2049 && ntotal >= 262144 && ntotal >= 256 * kf &&
+	const bool bigk_ok = cl_bigk && (!wide || collect_wide_max_classes(collect_store_dims(d)) >= 128) && collect_supported(geom) && kf > 128 - (kk - kf) && kk <= std::min<int64_t>(wide ? 2049 : 4097, flat_direct_max_k()) /* (what the fall-back can serve) */ && ntotal >= 65536 && ntotal >= 64 * kf &&
 	                     ntotal < ((int64_t)1 << 31) && (prefilter_mode == 2 || prefilter_mode < 0) && nq * kk < ((int64_t)1 << 31);
-	const int cl_kmax = bigk_ok ? 2048 : (int)std::min<int64_t>(cl_kmax0, 128 - (kk - kf)); // (collect_select_kernel: kk <= 128 entries)
+	const int cl_kmax = bigk_ok ? 4096 : (int)std::min<int64_t>(cl_kmax0, 128 - (kk - kf)); // (collect_select_kernel: kk <= 128 entries)
 	// (lists beyond 40: only the coarse filter of the d <= 128 store, up to 128 -- four subsets of 32 row classes, round 4)
 	if (prefilter_mode == 0 || pf_suppressed || (!prefilter_supported(geom) && !collect_supported(geom)) || (kk > 40 && kf > cl_kmax))
 		return false;
 	// an IDSelector: only the coarse filter handles it (SEL instances); otherwise the exact kernels' SEL instances do
 	const bool has_sel = params && params->sel_kind != MVS_SEL_NONE;
-	if (cl_only && (kf > (bigk_ok ? 2048 : std::min<int64_t>(collect_max_k(d), 128 - (kk - kf))) || prefilter_mode == 1))
+	if (cl_only && (kf > (bigk_ok ? 4096 : std::min<int64_t>(collect_max_k(d), 128 - (kk - kf))) || prefilter_mode == 1))
 		return false;
 	if (has_sel && !((prefilter_mode == 2 || prefilter_mode < 0) && collect_supported(geom) && kf <= cl_kmax))
 		return false;
