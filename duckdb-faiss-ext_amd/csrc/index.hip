@@ -10,8 +10,11 @@
 // hipMemcpyAsync + the norm kernel run on the stream.
 #include "index.h"
 
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include <algorithm>
 #include <dlfcn.h>
@@ -95,6 +98,87 @@ static void stage_copy(void *dst, const void *src, size_t bytes) {
 #else
 	memcpy(dst, src, bytes);
 #endif
+}
+// Round 6: a chunk of the glue's size (1 MB) is copied by THREE threads (MVS_STAGE_THREADS).  The call runs under the glue's faiss_lock and seven of eight
+// calls are nothing but this copy (profiles/r6_ingest.txt: 36 us per MB with the other workers filling their next chunks, the
+// ceiling of the call pattern); helper threads that take the other parts shorten exactly that.  A helper spins between the
+// calls of an ingest burst (they follow each other within ~50 us) and goes to sleep 300 us after the last one; callers of different
+// indexes do not queue for the helpers (try_lock: the loser copies alone).  MVS_STAGE_THREADS=1 keeps the copy on the calling thread.
+namespace {
+struct StageHelper {
+	std::atomic<uint64_t> seq {0}, done {0};
+	const void *src = nullptr;
+	void *dst = nullptr;
+	size_t bytes = 0;
+	std::atomic<bool> sleeping {false};
+	std::mutex mu;
+	std::condition_variable cv;
+	void run() {
+		uint64_t seen = 0;
+		for (;;) {
+			const auto t0 = std::chrono::steady_clock::now();
+			unsigned spins = 0;
+			while (seq.load(std::memory_order_acquire) == seen) {
+				__builtin_ia32_pause();
+				if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+					std::unique_lock<std::mutex> lk(mu);
+					sleeping.store(true, std::memory_order_release);
+					cv.wait(lk, [&] { return seq.load(std::memory_order_acquire) != seen; });
+					sleeping.store(false, std::memory_order_release);
+				}
+			}
+			seen = seq.load(std::memory_order_acquire);
+			stage_copy(dst, src, bytes);
+			done.store(seen, std::memory_order_release);
+		}
+	}
+	void wake() {
+		if (sleeping.load(std::memory_order_acquire)) {
+			{ std::lock_guard<std::mutex> lk(mu); }
+			cv.notify_one();
+		}
+	}
+};
+} // namespace
+// dst <- src with the helpers' hands where it pays (>= 256 KB, 16-byte aligned parts); MVS_STAGE_THREADS = copying threads in all (1 .. 4)
+static void stage_copy_mt(void *dst, const void *src, size_t bytes) {
+	static const int nthreads = []() {
+		const char *e = getenv("MVS_STAGE_THREADS");
+		const int v = e ? atoi(e) : 3;
+		return v < 1 ? 1 : (v > 4 ? 4 : v);
+	}();
+	static std::mutex owner; // (callers of different indexes do not queue for the helpers: the loser copies alone)
+	static StageHelper *helpers[3] = {nullptr, nullptr, nullptr};
+	if (nthreads <= 1 || bytes < ((size_t)256 << 10) || ((uintptr_t)dst & 15) || !owner.try_lock()) {
+		stage_copy(dst, src, bytes);
+		return;
+	}
+	const int nh = nthreads - 1;
+	const size_t part = (bytes / (size_t)nthreads) & ~(size_t)63;
+	uint64_t job[3];
+	for (int i = 0; i < nh; ++i) {
+		if (!helpers[i]) {
+			helpers[i] = new StageHelper; // (never destroyed: its thread may outlive static destruction)
+			StageHelper *hp = helpers[i];
+			std::thread([hp]() { hp->run(); }).detach();
+		}
+		StageHelper &h = *helpers[i];
+		const size_t off = part * (size_t)(i + 1), len = i + 1 == nh ? bytes - off : part;
+		h.src = (const char *)src + off, h.dst = (char *)dst + off, h.bytes = len;
+		job[i] = h.seq.fetch_add(1, std::memory_order_acq_rel) + 1;
+		h.wake();
+	}
+	stage_copy(dst, src, part);
+	for (int i = 0; i < nh; ++i) {
+		StageHelper &h = *helpers[i];
+		unsigned spins = 0;
+		while (h.done.load(std::memory_order_acquire) != job[i]) {
+			__builtin_ia32_pause();
+			if ((++spins & 4095u) == 0)
+				h.wake(); // (the helper was on its way to sleep when the job was posted)
+		}
+	}
+	owner.unlock();
 }
 int PinnedRing::acquire(size_t bytes) {
 	const int i = next;
@@ -904,7 +988,7 @@ void FlatIndex::add(int64_t n, const float *x) {
 			pend_slot = add_ring.acquire(PinnedRing::SLOT_BYTES);
 			pend_bytes = 0, pend_rows = 0, pend_row0 = ntotal;
 		}
-		stage_copy((char *)add_ring.buf[pend_slot] + pend_bytes, x, nbytes);
+		stage_copy_mt((char *)add_ring.buf[pend_slot] + pend_bytes, x, nbytes);
 		pend_bytes += nbytes;
 		pend_rows += n;
 		ntotal += n;
@@ -921,7 +1005,7 @@ void FlatIndex::add(int64_t n, const float *x) {
 		const int64_t nr = std::min(rows_per_slot, n - r0);
 		const size_t bytes = (size_t)nr * d * sizeof(float);
 		const int slot = add_ring.acquire(bytes);
-		stage_copy(add_ring.buf[slot], x + r0 * d, bytes);
+		stage_copy_mt(add_ring.buf[slot], x + r0 * d, bytes);
 		float *raw = (float *)((char *)ws_add.p + (size_t)add_flip * PinnedRing::SLOT_BYTES);
 		add_flip ^= 1;
 		MVS_HIP(hipMemcpyAsync(raw, add_ring.buf[slot], bytes, hipMemcpyHostToDevice, stream));
