@@ -102,8 +102,9 @@ def test_k_up_to_128_takes_the_coarse_filter_with_four_subsets_of_32_classes(mf,
     xb[::53] = xb[11]  # duplicates: ties inside the result lists
     cl, ex = _pair(mf, d, metric, xb)
     if metric == IP and k + 1 > 128:
+        # (round 6: k + 1 = 129 entries are a "big list" -- served by the filter's range bounds on stores of >= 65 536 rows)
         D, I = cl.search(xq, k)
-        assert cl.last_kernel_info()["name"] != KERNEL
+        assert (cl.last_kernel_info()["name"] == KERNEL) == (nb >= 65536 and nb >= 64 * k)
         De, Ie = ex.search(xq, k)
         assert np.array_equal(I, Ie) and np.array_equal(D.view(np.uint32), De.view(np.uint32))
         return
