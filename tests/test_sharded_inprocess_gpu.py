@@ -214,7 +214,7 @@ def test_ivf_row_shards_exact_ties_follow_the_heap_in_arrival_order(mf, metric, 
             a.add_with_ids(xb[i0 : i0 + 2048], ids[i0 : i0 + 2048]) if idmap else a.add(xb[i0 : i0 + 2048])
     keep = (ids if idmap else np.arange(nb))[rs.rand(nb) < 0.6]
     for sel in (None, ("batch", keep)):
-        for nprobe, kk in ((4, 10), (nlist, 10), (8, 25)):
+        for nprobe, kk in ((4, 10), (nlist, 10), (8, 25), (8, 60)):  # (60: beyond the scan's class slots -- collect_search_big in every shard)
             ref = o.search(xq, kk, nprobe=nprobe, sel=sel)
             _same(one.search(xq, kk, nprobe=nprobe, sel=sel), ref, f"unsharded vs oracle m={metric} nprobe={nprobe} k={kk}")
             _same(sh.search(xq, kk, nprobe=nprobe, sel=sel), ref, f"sharded vs oracle m={metric} idmap={idmap} G={G} nprobe={nprobe} k={kk} sel={sel and sel[0]}")
