@@ -267,6 +267,7 @@ public:
 	bool cl_wide_refilter = true; // option cl_wide_refilter: the final-bound filter in front of the sorted pipeline of the 512 < d <= 1536 stores (flat_bf16_big_kernel)
 	bool cl_fbucket = true;      // option cl_fbucket
 	bool cl_fbucket_off = false; // a query's bucket overflowed on this index's data: the sorted pipeline from then on
+	int cl_bigk_whole = -1, cl_bigk_per = 0; // options (A/B of the big lists' pass A: rows looked at, rows per split that decide)
 	bool cl_bigk = true; // option cl_bigk: lists of 129 .. 2048 entries on the coarse filter (bounds from row ranges, frozen scan, segmented sort); 0: the exact kernels
 	int cl_fpitch = 256;         // bucket entries per query
 	float *cl_out_D = nullptr;

@@ -553,10 +553,19 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	// (d <= 128: the ranges are row splits of the register pre-pass kernel, 16 class maxima each, ceil(k / ranges) <= 8 of them decide; the
 	// wide stores: 128 class slots per range through the scan kernel's bound-estimation instances, <= 64 decide)
 	const bool bk_seed = bigk && !wide;
-	const int bk_ranges = bigk ? (bk_seed ? (kf + 7) / 8 : (kf + 63) / 64) : 0;
+	const int bk_per = cl_bigk_per > 0 ? cl_bigk_per : 8; // (rows of a split that decide its bound: the bk_per-th best of its 16 class maxima)
+	int bk_ranges = bigk ? (bk_seed ? (kf + bk_per - 1) / bk_per : (kf + 63) / 64) : 0;
+	if (bk_seed) { // (a small batch has few query blocks: more, shorter splits -- up to four times as many -- fill the device; the bound loosens a little)
+		const int nqb = (int)((nq + 511) / 512);
+		if (nqb * bk_ranges < 256 && bk_ranges < 64) // (k = 200 at 32 queries: 3.5 -> 2.3 ms; k = 1000 has splits enough and only loses tightness)
+			bk_ranges = std::max(bk_ranges, std::min(256 / nqb, 4 * bk_ranges));
+	}
 	int64_t bk_rows = 0; // rows per range
 	if (bigk) {
-		const bool whole = (double)nq * kf * 16.0 > (double)((int64_t)1 << 28);
+		// (a large batch pays the matrix pipe for pass A and the rare path, the gather and the sort for every candidate: all rows = a
+		// tighter bound = a third of the candidates; a small batch pays bandwidth: a quarter of the rows.  option cl_bigk_whole: -1 auto)
+		// (measured, N = 10 M, profiles/r6_big_k.txt: k = 1000 at 2 048 / 10 000 queries 15.2 / 70 ms on a quarter, 11.2 / 48 on all rows; k = 200: 8.3 / 31 against 13 / 36)
+		const bool whole = cl_bigk_whole >= 0 ? cl_bigk_whole != 0 : ((nq >= 512 && kf >= 512) || (double)nq * kf * 16.0 > (double)((int64_t)1 << 28));
 		const int64_t want = whole ? ntotal : std::max<int64_t>(ntotal / 4, (int64_t)bk_ranges * (bk_seed ? 2048 : 16384));
 		bk_rows = std::min<int64_t>(std::max<int64_t>(want / bk_ranges, bk_seed ? 1024 : 4096), ntotal / bk_ranges) / 64 * 64;
 	}
@@ -2971,6 +2980,14 @@ bool FlatIndex::set_option(const char *key, int64_t v) {
 	}
 	if (!strcmp(key, "cl_prep1")) { // 0: round 4's separate query-preparation kernels (A/B)
 		cl_prep1 = v != 0;
+		return true;
+	}
+	if (!strcmp(key, "cl_bigk_whole")) { // big lists, pass A: -1 auto, 0 a quarter of the rows, 1 all of them (A/B)
+		cl_bigk_whole = (int)v;
+		return true;
+	}
+	if (!strcmp(key, "cl_bigk_per")) { // big lists, d <= 128: rows of a pass-A split that decide its bound (1 .. 12; default 8)
+		cl_bigk_per = (int)std::min<int64_t>(12, std::max<int64_t>(0, v));
 		return true;
 	}
 	if (!strcmp(key, "cl_bigk")) { // 0: lists beyond 128 entries on the exact kernels (round 5; A/B)
