@@ -264,7 +264,7 @@ void launch_emit_sorted(const float *d_pd, const int32_t *d_pi, int64_t nq, int6
                         int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st);
 void launch_merge_partials(int metric, const float *d_pd, const int32_t *d_pi, int nsplit, int64_t nq, int64_t k,
                            const int64_t *d_idmap, int64_t label_offset, float *d_D, int64_t *d_I, hipStream_t st,
-                           int64_t kout = -1, const TieFlags *flags = nullptr);
+                           int64_t kout = -1, const TieFlags *flags = nullptr, bool presorted = false); // presorted: ONE list per query, already in the pure order
 // flagged queries -> contiguous [nf][d] query rows and their boundary scores T
 void launch_gather_flagged(const float *d_x, int d, const TieFlags &f, int nf, int64_t k, int64_t kout, float *d_xf,
                            float *d_T, hipStream_t st);

@@ -1415,7 +1415,7 @@ bool FlatIndex::search_prefilter_pass(int64_t nq, const float *d_x, int64_t k_us
 	else if (collected && metric == METRIC_L2 && !flp) // (the coarse filter's selection is in FAISS's L2 order already: labels only)
 		launch_emit_sorted(pd1, pi1, nq, kp, k_user, out_map, out_off, d_D, d_I, st);
 	else
-		launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp);
+		launch_merge_partials(metric, pd1, pi1, 1, nq, kp, out_map, out_off, d_D, d_I, st, k_user, flp, collected /* the coarse filter's selection is sorted */);
 	if (!h_flag_count)
 		MVS_HIP(hipHostMalloc((void **)&h_flag_count, 64, hipHostMallocDefault));
 	// (one kernel writes fail count, rounding residual and -- deferred count mode -- the scan's entry count / the bucket header to pinned memory)
