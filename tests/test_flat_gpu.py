@@ -475,6 +475,40 @@ def test_l2_k_from_100_reservoir_equals_heap_on_the_device_too(mf):
 
 
 
+def test_concurrent_ingest_into_several_indexes_shares_the_copy_helpers(mf):
+    """round 6: the staging copy of a DataChunk-sized add runs on three threads (csrc/index.hip stage_copy_mt).  The two helpers belong
+    to the library, not to an index: threads feeding DIFFERENT indexes at once either get them or copy alone -- every row of every index
+    arrives where it belongs (each row finds itself at distance 0 under its own number)."""
+    import threading
+
+    d, n = 128, 60_000
+    rs = np.random.RandomState(3)
+    data = [rs.rand(n, d).astype(np.float32) + t for t in range(3)]  # (three clouds apart: a row copied into the wrong index would show)
+    idx = [mf.index_factory(d, "Flat", L2) for _ in range(3)]
+    errs = []
+
+    def feed(t):
+        try:
+            for i0 in range(0, n, 2048):
+                idx[t].add(data[t][i0 : i0 + 2048])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=feed, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(3):
+        assert idx[t].ntotal == n
+        probe = np.arange(0, n, 997)
+        D, I = idx[t].search(data[t][probe], 1)
+        assert np.array_equal(I[:, 0], probe), t
+        assert float(D.max()) <= 1e-3, (t, float(D.max()))
+
+
+
 @pytest.mark.parametrize("desc,d", [("Flat", 128), ("IDMap,Flat", 13), ("IDMap,Flat", 128), ("Flat", 770)])
 def test_staged_adds_reach_every_reader(mf, tmp_path, desc, d):
     """round 6: DataChunk-sized add() calls (src/faiss_extension.cpp:510,512: <= 2048 rows each) are collected in a pinned
