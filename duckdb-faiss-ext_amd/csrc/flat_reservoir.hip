@@ -154,20 +154,28 @@ __device__ __forceinline__ bool rs_cmp(float a, float b) {
 
 // One wavefront per flagged query.  LDS: vals[cap] f32 | rows[cap] i32.  Everything that FAISS decides sequentially is decided
 // here in the same order; the wave only parallelises counting, probing and compaction, whose results do not depend on order.
-__global__ __launch_bounds__(64) void reservoir_replay_kernel(const float *__restrict__ scores, long long n, int k, int cap,
-                                                             const float *__restrict__ Tq, float *__restrict__ out_v,
-                                                             int *__restrict__ out_r) {
+// (round 6: FOUR wavefronts per query.  All four stage the scores -- a quarter of a 16 384-score round each, sixteen 16-byte loads
+// per lane in flight -- and note which groups of 64 hold a score above the threshold as it stood; wavefront 0 alone then walks those
+// groups through the reservoir, in order.  One wavefront could not pull 40 MB of scores per query faster than 6 ms.)
+__device__ __forceinline__ void rs_wave_fence() { // a wave's LDS operations execute in order: only the compiler must not reorder them
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(256) void reservoir_replay_kernel(const float *__restrict__ scores, long long n, int k, int cap,
+                                                              const float *__restrict__ Tq, float *__restrict__ out_v,
+                                                              int *__restrict__ out_r) {
 	extern __shared__ __attribute__((aligned(16))) float rs_lds[];
 	float *vals = rs_lds;
 	int *rows = (int *)(rs_lds + cap);
-	const int f = blockIdx.x, lane = threadIdx.x;
+	const int f = blockIdx.x, lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const float *sc = scores + (size_t)f * n;
 	const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 	float thr = -FLT_MAX; // C::neutral()
 	int fill = 0;
 
 	auto shrink = [&]() { // threshold = partition_fuzzy<C>(vals, ids, capacity, n = k, (capacity + k) / 2, &i)
-		__syncthreads(); // (one wave: orders the appends of other lanes before the reads below)
+		rs_wave_fence(); // (wavefront 0 only: orders the appends of other lanes before the reads below)
 		const int nn = cap, q_min = k, q_max = (cap + k) / 2;
 		float thresh_inf = FLT_MAX;   // C::Crev::neutral()
 		float thresh_sup = -FLT_MAX;  // C::neutral()
@@ -241,48 +249,59 @@ __global__ __launch_bounds__(64) void reservoir_replay_kernel(const float *__res
 		}
 		fill = wp;
 		thr = thresh;
-		__syncthreads();
+		rs_wave_fence();
 	};
 
-	// (round 6: the scores pass through LDS in chunks of RS_CHUNK -- sixteen 16-byte loads per lane in flight instead of one 4-byte load per
-	// 64 rows, whose latency was the whole 70 ms of a 10 M-row replay -- and the next group's value is read while this one is decided)
-	float *chunk = (float *)(rows + cap);
-	unsigned long long gmask = 0ull; // (uniform) the chunk's groups still to visit
-	for (long long cbase = 0; cbase < n; cbase += RS_CHUNK) {
-		__syncthreads();
-		if (cbase + RS_CHUNK <= n && ((size_t)(sc + cbase) & 15) == 0) { // (uniform) a whole aligned chunk: sixteen loads in flight, then the stores
-			float4 x[RS_CHUNK / 256];
+	float *chunk = (float *)(rows + cap);                                  // [4][RS_CHUNK] this round's scores
+	unsigned long long *gm_lds = (unsigned long long *)(chunk + 4 * RS_CHUNK); // [4] groups of each quarter worth a visit
+	float *thr_lds = (float *)(gm_lds + 4);                                // [1] the threshold as wavefront 0 left it
+	if (threadIdx.x == 0)
+		thr_lds[0] = thr;
+	for (long long rbase = 0; rbase < n; rbase += 4 * RS_CHUNK) {
+		__syncthreads(); // (the previous round's walk is over; thr_lds is current)
+		{
+			const float thr_s = thr_lds[0]; // (it only rises: groups selected under an older value are a superset)
+			const long long cbase = rbase + (long long)wave * RS_CHUNK;
+			float *dstc = chunk + wave * RS_CHUNK;
+			unsigned long long gmask = 0ull;
+			if (cbase + RS_CHUNK <= n && ((size_t)(sc + cbase) & 15) == 0) { // (uniform) a whole aligned quarter
+				float4 x[RS_CHUNK / 256];
 #pragma unroll
-			for (int i = 0; i < RS_CHUNK / 256; ++i)
-				x[i] = *(const float4 *)(sc + cbase + (long long)(i * 64 + lane) * 4);
-			// which of the chunk's 64 groups hold a score above the threshold AS IT STANDS (it only rises: a superset of the groups that
-			// will matter) -- load i covers groups 4 i .. 4 i + 3, sixteen lanes each; the walk below visits those groups only
-			gmask = 0ull;
+				for (int i = 0; i < RS_CHUNK / 256; ++i)
+					x[i] = *(const float4 *)(sc + cbase + (long long)(i * 64 + lane) * 4);
 #pragma unroll
-			for (int i = 0; i < RS_CHUNK / 256; ++i) {
-				*(float4 *)(chunk + (i * 64 + lane) * 4) = x[i];
-				const unsigned long long m =
-				    __builtin_amdgcn_ballot_w64(rs_cmp(thr, x[i].x) || rs_cmp(thr, x[i].y) || rs_cmp(thr, x[i].z) || rs_cmp(thr, x[i].w));
-				const unsigned long long q4 = (m & 0xffffull ? 1ull : 0ull) | (m & 0xffff0000ull ? 2ull : 0ull) | (m & 0xffff00000000ull ? 4ull : 0ull) |
-				                              (m & 0xffff000000000000ull ? 8ull : 0ull);
-				gmask |= q4 << (4 * i);
+				for (int i = 0; i < RS_CHUNK / 256; ++i) { // load i covers groups 4 i .. 4 i + 3, sixteen lanes each
+					*(float4 *)(dstc + (i * 64 + lane) * 4) = x[i];
+					const unsigned long long m =
+					    __builtin_amdgcn_ballot_w64(rs_cmp(thr_s, x[i].x) || rs_cmp(thr_s, x[i].y) || rs_cmp(thr_s, x[i].z) || rs_cmp(thr_s, x[i].w));
+					const unsigned long long q4 = (m & 0xffffull ? 1ull : 0ull) | (m & 0xffff0000ull ? 2ull : 0ull) |
+					                              (m & 0xffff00000000ull ? 4ull : 0ull) | (m & 0xffff000000000000ull ? 8ull : 0ull);
+					gmask |= q4 << (4 * i);
+				}
+			} else if (cbase < n) {
+				for (int i = 0; i < RS_CHUNK / 64; ++i) {
+					const long long e = cbase + (long long)i * 64 + lane;
+					dstc[i * 64 + lane] = e < n ? sc[e] : __uint_as_float(0x7fc00000u);
+				}
+				const long long left = n - cbase;
+				const int ngroups = (int)((left < RS_CHUNK ? left : RS_CHUNK) + 63) / 64;
+				gmask = ngroups >= 64 ? ~0ull : ((1ull << ngroups) - 1ull);
 			}
-		} else {
-			gmask = ~0ull;
-			for (int i = 0; i < RS_CHUNK / 64; ++i) {
-				const long long e = cbase + (long long)i * 64 + lane;
-				chunk[i * 64 + lane] = e < n ? sc[e] : __uint_as_float(0x7fc00000u);
-			}
+			if (lane == 0)
+				gm_lds[wave] = gmask;
 		}
 		__syncthreads();
-		const int ngroups = (int)(((n - cbase < RS_CHUNK ? n - cbase : RS_CHUNK) + 63) / 64);
-		if (ngroups < 64)
-			gmask &= (1ull << ngroups) - 1ull;
+		if (wave != 0)
+			continue;
+	for (int w = 0; w < 4; ++w) {
+		unsigned long long gmask = gm_lds[w];
+		const long long cbase = rbase + (long long)w * RS_CHUNK;
+		const float *cw = chunk + w * RS_CHUNK;
 	while (gmask != 0ull) {
 		const int g = __builtin_ctzll(gmask);
 		gmask &= gmask - 1ull;
 		const long long row = cbase + (long long)g * 64 + lane;
-		const float v = chunk[g * 64 + lane];
+		const float v = cw[g * 64 + lane];
 		unsigned long long mask = __builtin_amdgcn_ballot_w64(rs_cmp(thr, v)); // C::cmp(threshold, val); NaN: never (also behind the last row)
 		while (mask != 0ull) {
 			const int cnt = __popcll(mask);
@@ -317,9 +336,14 @@ __global__ __launch_bounds__(64) void reservoir_replay_kernel(const float *__res
 		}
 	}
 	}
+		if (lane == 0)
+			thr_lds[0] = thr;
+	}
+	if (wave != 0)
+		return;
 
 	// to_result as the closed form over the stored entries (array order = row order)
-	__syncthreads();
+	rs_wave_fence();
 	const float T = Tq[f];
 	int n_ge = 0, G = 0;
 	for (int j0 = 0; j0 < fill; j0 += 64) {
@@ -364,7 +388,7 @@ __global__ __launch_bounds__(64) void reservoir_replay_kernel(const float *__res
 } // namespace
 
 int64_t reservoir_replay_max_k() { // vals + rows of the reservoir in one wave's LDS
-	return ((150 * 1024 - RS_CHUNK * 4) / 8 - 16) / 2;
+	return ((150 * 1024 - 4 * RS_CHUNK * 4 - 64) / 8 - 16) / 2;
 }
 
 // d_xf: [nf][d] the flagged queries, d_T: [nf] their k-th best scores; out: [nf][k] (score, row) of FAISS's result, any order
@@ -380,10 +404,10 @@ void launch_reservoir_replay(const float *d_xf, int nf, int d, const float *d_ve
 	else
 	hipLaunchKernelGGL(ip_scores_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nf), dim3(256), 0, st, d_xf, d, d_vecs, dp,
 	                   interleaved, (long long)n, sel, (const long long *)d_idmap, d_scores);
-	const size_t lds = (size_t)cap * 8 + (size_t)RS_CHUNK * 4;
+	const size_t lds = (size_t)cap * 8 + (size_t)4 * RS_CHUNK * 4 + 64;
 	auto kern = reservoir_replay_kernel;
 	ensure_dynamic_lds((const void *)kern, lds);
-	hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(64), lds, st, (const float *)d_scores, (long long)n, (int)k, cap, d_T, d_out_v,
+	hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(256), lds, st, (const float *)d_scores, (long long)n, (int)k, cap, d_T, d_out_v,
 	                   d_out_r);
 	MVS_HIP(hipGetLastError());
 }
