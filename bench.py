@@ -1123,6 +1123,8 @@ def main():
                     "cores_note": "%d OpenBLAS threads in sgemm (picked by a probe on this host: queries/s scaled to N per thread count = %s), %d OpenMP threads in the norms / heap loops" % (ob_threads, ob_sweep, cores),
                     "thread_sweep_qps": ob_sweep,
                     "kind": "openblas",
+                    # (say what this baseline is next to the number)
+                    "note": "a weak CPU baseline: the fastest of 1..%d OpenBLAS threads on a shared %d-thread host (its sgemm peaks near 2 TFLOP/s here) -- reported, not the target" % (max(ob_threads, 16), os.cpu_count() or 0),
                     "sample": "%d of %d queries vs the full N=%d database in %.1f s: FAISS's BLAS branch (4096 x 1024 sgemm blocks, "
                     "(xn+yn)-2ip, CMax/CMin heaps at k+1=%d) on %s" % (done_ob, nq, n, t_ob, k + 1, ob_cfg),
                 }
