@@ -51,9 +51,11 @@ __global__ __launch_bounds__(256) void collect_colsum_kernel(const float *__rest
 	const int g8 = dp / 8, rl = threadIdx.x / g8, c8 = threadIdx.x % g8, nrl = 256 / g8;
 	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	const long long r0 = (long long)blockIdx.x * 1024;
-	if (rl >= nrl) // dp / 8 does not divide 256: the leftover threads would count rows twice
-		return;
-	for (long long r = r0 + rl; r < r0 + 1024 && r < nrows; r += nrl) {
+	// (round 6: the block's row lanes meet in LDS and ONE lane per column sends the atomic -- 2 048 float atomics per block on 128
+	// addresses were 3.2 ms of a first search for a 0.5 GB read)
+	__shared__ float red[256 * 8];
+	const bool idle = rl >= nrl; // dp / 8 does not divide 256: the leftover threads would count rows twice
+	for (long long r = r0 + rl; !idle && r < r0 + 1024 && r < nrows; r += nrl) {
 		const float4 s0 = *(const float4 *)(src + (size_t)r * dp + c8 * 8);
 		const float4 s1 = *(const float4 *)(src + (size_t)r * dp + c8 * 8 + 4);
 		float v[8];
@@ -70,7 +72,17 @@ __global__ __launch_bounds__(256) void collect_colsum_kernel(const float *__rest
 	}
 #pragma unroll
 	for (int e = 0; e < 8; ++e)
-		atomicAdd(sum + c8 * 8 + e, acc[e]);
+		red[threadIdx.x * 8 + e] = idle ? 0.f : acc[e];
+	__syncthreads();
+	if (rl == 0) { // (thread c8: the column group's first row lane)
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			float t = 0.f;
+			for (int l = 0; l < nrl; ++l)
+				t += red[(l * g8 + c8) * 8 + e];
+			atomicAdd(sum + c8 * 8 + e, t);
+		}
+	}
 }
 __global__ void collect_mean_kernel(float *sum, int dp, int d, float inv_n) {
 	for (int i = threadIdx.x; i < dp; i += blockDim.x)
@@ -104,16 +116,26 @@ __global__ void collect_outlier_threshold_kernel(const float *__restrict__ norms
                                                  unsigned *__restrict__ max_bits) {
 	__shared__ double part[256];
 	double acc = 0.0;
-	for (long long i = threadIdx.x; i < nrows; i += 256)
+	// (a mean: every 16th row of a large sample says the same -- one workgroup walking a million norms was 1.7 ms of a first search)
+	const long long step = nrows >= 65536 ? 16 : 1;
+	long long cnt = 0;
+	for (long long i = (long long)threadIdx.x * step; i < nrows; i += 256 * step) {
 		acc += (double)norms[i];
+		++cnt;
+	}
+	__shared__ long long pcnt[256];
+	pcnt[threadIdx.x] = cnt;
 	part[threadIdx.x] = acc;
 	__syncthreads();
 	for (int o = 128; o >= 1; o >>= 1) {
-		if (threadIdx.x < o)
+		if (threadIdx.x < o) {
 			part[threadIdx.x] += part[threadIdx.x + o];
+			pcnt[threadIdx.x] += pcnt[threadIdx.x + o];
+		}
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) {
+		nrows = pcnt[0];
 		double mun = 0.0;
 		for (int k = 0; k < dp; ++k)
 			mun += (double)mu[k] * (double)mu[k];
