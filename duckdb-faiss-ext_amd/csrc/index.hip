@@ -630,7 +630,7 @@ bool FlatIndex::collect_candidates(int64_t nq, const float *d_x, int kk, float *
 	int64_t ncand = 0;
 	// the bucketed finish (see cl_fbucket in csrc/index.h): the common d = 128 shape; round 6: inner product too -- faiss_create's default
 	// metric (src/faiss_extension.cpp:105) gets the headline's pipeline, the select kernel prints FAISS's CMin-heap order and the tie flags
-	const bool fb = cl_fbucket && !cl_fbucket_off && cl_out_D && (metric == METRIC_L2 || metric == METRIC_IP) && !wide && !few && d == 128 &&
+	const bool fb = !bigk && cl_fbucket && !cl_fbucket_off && cl_out_D && (metric == METRIC_L2 || metric == METRIC_IP) && !wide && !few && d == 128 &&
 	                geom.dp == 128 && kk <= 64 && nq * (int64_t)cl_fpitch < ((int64_t)1 << 31);
 	cl_emitted = false;
 	cl_wrf_used = false;
