@@ -72,6 +72,33 @@ def _build_flat_uniform(mf, torch, n, d, metric, desc="Flat"):
     return ix
 
 
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_headline_store_with_lists_of_1000(mf, torch, metric):
+    """round 6 (the bench line's H_k1000): the headline store asked for 1000 rows per query -- the list length of the reference's
+    post-filter use (README.md:222-271, go/main_test.go:26-32) -- stays on the bf16 filter (range bounds, frozen scan, segmented sort);
+    the exact kernels give the same rows and bits on a sample, and so does the oracle (FAISS's reservoir from k = 100 on)"""
+    n, d, nq, k = 10_000_000, 128, 2048, 1000
+    ix = _build_flat_uniform(mf, torch, n, d, metric)
+    xq = mf.synth_uniform_torch(nq, d, Q_SEED)
+    D, I = ix.search_torch(xq, k)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"] == "flat_bf16_collect_kernel"
+    cs = ix.collect_stats()
+    assert cs["queries"] == nq and k * nq <= cs["candidates"] <= 40 * k * nq, cs
+    assert ix.prefilter_stats()["fallback_queries"] == 0
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    ns = 48
+    ix.set_option("cl_bigk", 0)
+    Dx, Ix = ix.search_torch(xq[:ns].contiguous(), k)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"] != "flat_bf16_collect_kernel"
+    assert np.array_equal(Ix.cpu().numpy(), I[:ns]) and np.array_equal(Dx.cpu().numpy().view(np.uint32), D[:ns].view(np.uint32))
+    xb_h = orc.synth_uniform(n, d, DB_SEED)
+    Do, Io = orc.flat_search(metric, xb_h, xq[:ns].cpu().numpy(), k, force_path=orc.PATH_BLAS)
+    assert np.array_equal(I[:ns], Io), "labels differ from the oracle"
+    assert np.array_equal(D[:ns].view(np.uint32), Do.view(np.uint32)), "distances differ from the oracle"
+
+
 def test_headline_flat_l2_10m(mf, torch):
     n, d, nq, k = 10_000_000, 128, 10_000, 10
     ix = _build_flat_uniform(mf, torch, n, d, L2)
