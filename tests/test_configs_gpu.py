@@ -196,6 +196,21 @@ def test_c3_ivf4096_10m_nprobe32(mf, torch):
     Do, Io = o.search(xq[:ns].cpu().numpy(), k, nprobe=nprobe)
     assert np.array_equal(I[:ns], Io), "IVF labels differ from the oracle"
     assert np.array_equal(D[:ns].view(np.uint32), Do.view(np.uint32)), "IVF distances differ from the oracle"
+    # round 6 (the bench line's C3_k100): lists beyond the scan's class slots stay on the bf16 filter (collect_search_big) -- the scanner
+    # kernel gives the same rows and bits, and so does the oracle
+    xq2 = xq[:2048].contiguous()
+    D100, I100 = ix.search_torch(xq2, 100, nprobe=nprobe)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"].startswith("ivf_bf16_collect")
+    D100, I100 = D100.cpu().numpy(), I100.cpu().numpy()
+    ix.set_option("ivf_cl_big", 0)
+    Dsc, Isc = ix.search_torch(xq2[:256].contiguous(), 100, nprobe=nprobe)
+    torch.cuda.synchronize()
+    assert ix.last_kernel_info()["name"].startswith("ivf_scan_kernel")
+    ix.set_option("ivf_cl_big", 1)
+    assert np.array_equal(Dsc.cpu().numpy().view(np.uint32), D100[:256].view(np.uint32)) and np.array_equal(Isc.cpu().numpy(), I100[:256])
+    Do100, Io100 = o.search(xq[:32].cpu().numpy(), 100, nprobe=nprobe)
+    assert np.array_equal(I100[:32], Io100) and np.array_equal(D100[:32].view(np.uint32), Do100.view(np.uint32))
     # recall@10 against exact search on the same rows
     flat = mf.index_factory(d, "Flat", L2)
     for s0 in range(0, n, SLAB):
